@@ -1,0 +1,164 @@
+/*
+ * polara_hip.h — C ABI of libpolarahip.so: hand-written HIP kernels (gfx950 / MI355X) for the
+ * factorization-and-scoring hot path of evfro/polara (PureSVD + CoFFee).
+ *
+ * The reference is pure Python and has NO FFI of its own; each entry point below replaces one
+ * NumPy/SciPy/numba call site on the hot path (cited as file:line relative to the reference
+ * tree).  INTEGRATION.md shows the ctypes binding a Polara maintainer would add.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no C++/torch types.
+ *  - All `*_dev` pointers are DEVICE pointers (HBM) owned by the caller (the host layer allocates
+ *    them through torch, cupy, hipMalloc — anything).  The library never allocates device memory
+ *    and keeps no global state; scratch space is passed explicitly (`work`, sized by the matching
+ *    pk_*_work_bytes function).
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).  Every call only ENQUEUES
+ *    work on that stream and returns; the caller synchronises.
+ *  - Return value: 0 = ok, negative = error class (PK_E_*).  pk_last_error() returns a
+ *    thread-local message for the last failing call on the calling thread.
+ *  - Matrices are row-major with an explicit leading dimension (in elements).
+ *  - Index dtypes: row pointers int64, column indices int32, results int64 (like the reference's
+ *    `top_recs`, models.py:400).
+ */
+#ifndef POLARA_HIP_H
+#define POLARA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PK_OK 0
+#define PK_E_INVALID (-1)  /* bad argument                                  */
+#define PK_E_LAUNCH (-2)   /* HIP launch / runtime error                    */
+#define PK_E_UNSUPPORTED (-3)
+
+#define PK_VAL_F32 0
+#define PK_VAL_F64 1
+
+const char *pk_last_error(void);
+int pk_version(void);
+/* number of visible HIP devices (>=1 required by every compute call); fills name of `device`. */
+int pk_device_info(int device, char *name, int name_len, int *cu_count, int64_t *hbm_bytes);
+
+/* ------------------------------------------------------------------------------------------
+ * K1 / K4.  CSR x dense  (fp64 accumulate):   out[r, 0:nc] = sum_p vals[p] * X[indices[p], 0:nc]
+ *
+ * Replaces: scipy `csr_matvec(s)` inside ARPACK's reverse-communication loop for
+ * `svds(A, k)` (models.py:841-844: operator XH_X = A^T(A x)), and `test_matrix.dot(v)`
+ * (models.py:860, fold-in E = A_test V).  A^T products use the same kernel on the CSC arrays.
+ *
+ * Work is described by a task list built once per matrix by the host layer (polara_amd/csr.py):
+ * task t covers nnz range [task_begin[t], task_end[t]) of row task_row[t]; rows longer than the
+ * split threshold are cut into several tasks whose partial sums go to `partial[task_slot[t]]`
+ * (task_slot >= 0) and are added in slot order by a fix-up pass (deterministic, no atomics).
+ * ------------------------------------------------------------------------------------------ */
+int pk_spmm_csr_f64(void *stream,
+                    int64_t n_tasks, const int32_t *task_row_dev, const int64_t *task_begin_dev,
+                    const int64_t *task_end_dev, const int32_t *task_slot_dev,
+                    int64_t n_long, const int32_t *long_row_dev, const int32_t *long_slot_begin_dev,
+                    const int32_t *long_slot_end_dev,
+                    const int32_t *indices_dev, const void *vals_dev, int val_kind,
+                    const double *X_dev, int64_t ldx, int32_t nc,
+                    double *out_dev, int64_t ldo, double *partial_dev /* [n_slots x nc] or NULL */);
+
+/* ------------------------------------------------------------------------------------------
+ * K2.  Dense tall-skinny fp64 pieces of the block eigensolver / HOOI.
+ * Replace: ARPACK's Fortran re-orthogonalisation + LAPACK QR/SVD inside `svds`
+ * (models.py:844; lib/tensor.py:71,75,79) and numpy `qr` (tensor.py:61,63).
+ * ------------------------------------------------------------------------------------------ */
+/* G[la x lb] = A^T B, A: n x la, B: n x lb.  work >= pk_gram_work_bytes(n, la, lb). */
+int64_t pk_gram_work_bytes(int64_t n, int32_t la, int32_t lb);
+int pk_gram_f64(void *stream, int64_t n, int32_t la, int32_t lb, const double *A_dev, int64_t lda,
+                const double *B_dev, int64_t ldb, double *G_dev, int64_t ldg, void *work_dev);
+/* out[n x lout] = X[n x lin] * C[lin x lout]   (out must not alias X) */
+int pk_tsmm_f64(void *stream, int64_t n, int32_t lin, int32_t lout, const double *X_dev, int64_t ldx,
+                const double *C_dev, int64_t ldc, double *out_dev, int64_t ldo);
+/* Symmetric positive semi-definite eigen-decomposition by one-sided Jacobi, single workgroup.
+ * S (n x n, destroyed) -> evals[n] descending, evecs (n x n, ROW i = i-th eigenvector).
+ * info_dev[0] = sweeps used, info_dev[1] = 1 if converged.  n <= 1024. */
+int pk_eigh_psd_f64(void *stream, int32_t n, double *S_dev, int64_t lds_, double *evecs_dev, int64_t ldv,
+                    double *evals_dev, int32_t max_sweeps, double tol, int32_t *info_dev);
+/* out = alpha*Z + beta*Y + gamma*X over n_elems (Chebyshev three-term recurrence); Y/X may be NULL */
+int pk_axpbypcz_f64(void *stream, int64_t n_elems, double alpha, const double *Z_dev, double beta,
+                    const double *Y_dev, double gamma, const double *X_dev, double *out_dev);
+/* partial[b, j] = sum over row block b of (Z[i,j] - theta[j]*X[i,j])^2 ; nblocks = pk_resid_blocks(n) */
+int32_t pk_resid_blocks(int64_t n);
+int pk_resid_colnorm2_f64(void *stream, int64_t n, int32_t l, const double *Z_dev, int64_t ldz,
+                          const double *X_dev, int64_t ldx, const double *theta_dev, double *partial_dev);
+/* small general C = op(A) op(B) (any shape, one thread per output; for l x l glue only) */
+int pk_dgemm_small_f64(void *stream, int transA, int transB, int32_t M, int32_t N, int32_t K,
+                       const double *A_dev, int64_t lda, const double *B_dev, int64_t ldb,
+                       double *C_dev, int64_t ldc);
+/* X[i, j] *= s[j] */
+int pk_scale_cols_f64(void *stream, int64_t n, int32_t l, double *X_dev, int64_t ldx, const double *s_dev);
+
+/* ------------------------------------------------------------------------------------------
+ * K3.  Fused scoring: scores = E V^T (fp32 MFMA) + seen-item masking + per-user top-k,
+ * then exact fp64 re-scoring of the surviving candidates.  No dense score matrix ever exists.
+ *
+ * Replaces, per user chunk: `(test_matrix.dot(v)).dot(v.T)` (models.py:860),
+ * `downvote_seen_items` (models.py:494-519) and `get_topk_elements`/`topsort`
+ * (models.py:488-491, 561-563), i.e. the body of `_slice_recommender` (models.py:359-371).
+ * ------------------------------------------------------------------------------------------ */
+/* number of float elements of the MFMA-fragment-packed image of an [n x K] factor matrix */
+int64_t pk_pack_elems(int64_t n, int32_t K);
+int32_t pk_pack_kq(int32_t K); /* K padded to a multiple of 8, divided by 8 */
+/* src f64 [n x K] (ld) -> packed f32 fragments (32 rows per tile, zero padded) */
+int pk_pack_frag_f32(void *stream, int64_t n, int32_t K, const double *src_dev, int64_t ld, float *dst_dev);
+/* candidate capacity (power of two in {16,32,64}) used for a given topk; 0 if topk unsupported */
+int32_t pk_candidate_capacity(int32_t topk);
+/* Streams all item tiles against 32-user groups; keeps the KC best (fp32 score, item) pairs of
+ * each user among items NOT in the user's seen list (seen_ptr == NULL: no filtering).
+ * cand_* are [n_users_pad x KC] with n_users_pad = 32*ceil(n_users/32); unused slots have idx -1.
+ * seen lists must be sorted ascending per user (CSR canonical form). */
+int pk_score_candidates_f32(void *stream, int64_t n_users, int64_t n_items, int32_t K,
+                            const float *Vp_dev, const float *Ep_dev,
+                            const int64_t *seen_ptr_dev, const int32_t *seen_idx_dev,
+                            int32_t KC, float *cand_score_dev, int32_t *cand_idx_dev);
+/* Exact fp64 re-scoring + final ordering (score desc, item asc).  Writes topk item ids (int64) and
+ * optionally their fp64 scores.  flags[u] != 0 marks users whose result is NOT guaranteed exact by
+ * the fp32 candidate pass (bit0: candidate margin below the fp32 error bound; bit1: fewer than
+ * topk unseen items) — the host re-runs those through pk_score_exact_rows_f64.
+ * v_row_norm_max = max_i ||V[i,:]||_2 (<= 1 for orthonormal factors) enters the fp32 error bound. */
+int pk_rescore_topk_f64(void *stream, int64_t n_users, int64_t n_items, int32_t K,
+                        const double *V_dev, int64_t ldv, const double *E_dev, int64_t lde,
+                        const int64_t *seen_ptr_dev, int32_t KC, const float *cand_score_dev,
+                        const int32_t *cand_idx_dev, int32_t topk, double v_row_norm_max,
+                        int64_t *out_idx_dev, double *out_score_dev /* or NULL */, int32_t *flags_dev);
+/* Brute-force exact path for a list of users: all n_items fp64 scores, two-class key
+ * (unseen above seen, then score; the reference's downvote semantics, models.py:510-519), top-k.
+ * Outputs are compact [n_rows x topk] (row r belongs to user rows_dev[r]).
+ * work: pk_exact_work_bytes(n_rows, n_items) bytes. */
+int64_t pk_exact_work_bytes(int32_t n_rows, int64_t n_items);
+int pk_score_exact_rows_f64(void *stream, int32_t n_rows, const int32_t *rows_dev, int64_t n_items,
+                            int32_t K, const double *V_dev, int64_t ldv, const double *E_dev, int64_t lde,
+                            const int64_t *seen_ptr_dev, const int32_t *seen_idx_dev, int32_t topk,
+                            int64_t *out_idx_dev, double *out_score_dev, void *work_dev);
+/* Dense fp64 score rows (kept for `slice_recommendations`/`_user_scores`, models.py:277-291):
+ * out[r, :] = E[r, :] V^T for r in [0, n_rows). */
+int pk_dense_scores_f64(void *stream, int32_t n_rows, int64_t n_items, int32_t K, const double *V_dev,
+                        int64_t ldv, const double *E_dev, int64_t lde, double *out_dev, int64_t ldo);
+
+/* ------------------------------------------------------------------------------------------
+ * K5.  Sparse tensor-times-matrix (CoFFee / HOOI).
+ * Replaces numba `dttm_seq` / `dttm_par` (lib/sparse.py:203-234) called from `ttm3d_seq`
+ * (lib/tensor.py:7-19):  res[i0, j, k] += val * u[i1, j] * v[i2, k].
+ * nnz are pre-sorted by the output mode by the host layer; tasks as in pk_spmm_csr_f64, with
+ * idx1/idx2 the two contracted-mode indices of every nnz and `vals` optional (NULL = ones,
+ * data.py:805).  res is [n0 x (ra*rb)] row-major.
+ * ------------------------------------------------------------------------------------------ */
+int pk_ttm_f64(void *stream,
+               int64_t n_tasks, const int32_t *task_row_dev, const int64_t *task_begin_dev,
+               const int64_t *task_end_dev, const int32_t *task_slot_dev,
+               int64_t n_long, const int32_t *long_row_dev, const int32_t *long_slot_begin_dev,
+               const int32_t *long_slot_end_dev,
+               const int32_t *idx1_dev, const int32_t *idx2_dev, const double *vals_dev,
+               const double *u_dev, int64_t ldu, int32_t ra, const double *v_dev, int64_t ldv_, int32_t rb,
+               double *res_dev, int64_t ldr, double *partial_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POLARA_HIP_H */

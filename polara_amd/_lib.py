@@ -1,0 +1,87 @@
+"""ctypes binding of libpolarahip.so (the C ABI declared in include/polara_hip.h).
+
+Fails loudly: there is NO CPU fallback behind this module.  If the shared library is missing the
+import error says how to build it; compute calls on a machine without a HIP device raise.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libpolarahip.so')
+
+PK_VAL_F32, PK_VAL_F64 = 0, 1
+
+_vp, _i32, _i64, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+
+# name -> (restype, argtypes); mirrors include/polara_hip.h one to one
+PROTOTYPES = {
+    'pk_last_error': (C.c_char_p, []),
+    'pk_version': (C.c_int, []),
+    'pk_device_info': (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(_i64)]),
+    'pk_spmm_csr_f64': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, C.c_int,
+                                  _vp, _i64, _i32, _vp, _i64, _vp]),
+    'pk_gram_work_bytes': (_i64, [_i64, _i32, _i32]),
+    'pk_gram_f64': (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
+    'pk_tsmm_f64': (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64]),
+    'pk_eigh_psd_f64': (C.c_int, [_vp, _i32, _vp, _i64, _vp, _i64, _vp, _i32, _f64, _vp]),
+    'pk_axpbypcz_f64': (C.c_int, [_vp, _i64, _f64, _vp, _f64, _vp, _f64, _vp, _vp]),
+    'pk_resid_blocks': (_i32, [_i64]),
+    'pk_resid_colnorm2_f64': (C.c_int, [_vp, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _vp]),
+    'pk_dgemm_small_f64': (C.c_int, [_vp, C.c_int, C.c_int, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64]),
+    'pk_scale_cols_f64': (C.c_int, [_vp, _i64, _i32, _vp, _i64, _vp]),
+    'pk_pack_elems': (_i64, [_i64, _i32]),
+    'pk_pack_kq': (_i32, [_i32]),
+    'pk_pack_frag_f32': (C.c_int, [_vp, _i64, _i32, _vp, _i64, _vp]),
+    'pk_candidate_capacity': (_i32, [_i32]),
+    'pk_score_candidates_f32': (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+    'pk_rescore_topk_f64': (C.c_int, [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _vp,
+                                      _i32, _f64, _vp, _vp, _vp]),
+    'pk_exact_work_bytes': (_i64, [_i32, _i64]),
+    'pk_score_exact_rows_f64': (C.c_int, [_vp, _i32, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _i32,
+                                          _vp, _vp, _vp]),
+    'pk_dense_scores_f64': (C.c_int, [_vp, _i32, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _i64]),
+    'pk_ttm_f64': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp,
+                             _vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _vp]),
+}
+
+
+class PolaraHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Loads the library once and sets prototypes.  Raises PolaraHipError when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PolaraHipError(
+            'libpolarahip.so is not built (%s). Run `python -m polara_amd.build_native` '
+            '(needs hipcc; cross-compiles for gfx950 without a GPU). There is no CPU fallback.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError here = header and library out of sync
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load().pk_last_error()
+        raise PolaraHipError('%s failed (rc=%d): %s' % (what, rc, msg.decode() if msg else ''))
+
+
+def device_info(device=0):
+    lib = load()
+    name = C.create_string_buffer(64)
+    cu = C.c_int(0)
+    mem = C.c_int64(0)
+    n = lib.pk_device_info(device, name, 64, C.byref(cu), C.byref(mem))
+    if n <= 0:
+        check(n, 'pk_device_info')
+    return dict(n_devices=n, arch=name.value.decode(), cu_count=cu.value, hbm_bytes=mem.value)

@@ -1,0 +1,65 @@
+"""Builds polara_amd/libpolarahip.so from polara_amd/csrc with hipcc for gfx950 (in-tree).
+
+hipcc cross-compiles without a GPU, so this runs in the build container and the resulting .so
+travels to the GPU box with the repo snapshot.  Object files are rebuilt only when their source
+(or a header) is newer.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+ROOT = os.path.dirname(HERE)
+LIB = os.path.join(HERE, 'libpolarahip.so')
+OBJDIR = os.path.join(HERE, 'csrc', '_obj')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
+         '-I', os.path.join(ROOT, 'include')]
+
+
+def sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(('.hip', '.cpp')))
+
+
+def _newest_header():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    hs.append(os.path.join(ROOT, 'include', 'polara_hip.h'))
+    return max(os.path.getmtime(h) for h in hs)
+
+
+def _compile(src, force=False, extra=()):
+    obj = os.path.join(OBJDIR, src + '.o')
+    spath = os.path.join(CSRC, src)
+    if (not force and os.path.exists(obj)
+            and os.path.getmtime(obj) > max(os.path.getmtime(spath), _newest_header())):
+        return obj, False
+    cmd = [HIPCC] + FLAGS + list(extra) + ['-x', 'hip', '-c', spath, '-o', obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('hipcc failed for %s:\n%s\n%s' % (src, r.stdout, r.stderr))
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    return obj, True
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJDIR, exist_ok=True)
+    srcs = sources()
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        results = list(ex.map(lambda s: _compile(s, force), srcs))
+    objs = [o for o, _ in results]
+    rebuilt = any(c for _, c in results)
+    if rebuilt or not os.path.exists(LIB):
+        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('link failed:\n%s\n%s' % (r.stdout, r.stderr))
+    if verbose:
+        print('libpolarahip.so: %s (%d bytes)' % ('rebuilt' if rebuilt else 'up to date', os.path.getsize(LIB)))
+    return LIB
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)

@@ -1,0 +1,41 @@
+// Error channel + device info of libpolarahip.so (host-only translation unit).
+#include "pk_common.h"
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void pk_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *pk_last_error(void) { return g_err; }
+extern "C" int pk_version(void) { return 100; }
+
+extern "C" int pk_device_info(int device, char *name, int name_len, int *cu_count, int64_t *hbm_bytes) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        pk_set_error("pk_device_info: no HIP device visible (%s)", hipGetErrorString(e));
+        return PK_E_LAUNCH;
+    }
+    if (device < 0 || device >= n) {
+        pk_set_error("pk_device_info: device %d out of range [0,%d)", device, n);
+        return PK_E_INVALID;
+    }
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) {
+        pk_set_error("pk_device_info: %s", hipGetErrorString(e));
+        return PK_E_LAUNCH;
+    }
+    if (name && name_len > 0) {
+        strncpy(name, prop.gcnArchName, name_len - 1);
+        name[name_len - 1] = 0;
+    }
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    return n;
+}

@@ -1,0 +1,323 @@
+// K2: dense tall-skinny fp64 pieces of the block eigensolver and of HOOI (gfx950).
+//   gram   : G = A^T B           (n x la, n x lb -> la x lb), split over rows, deterministic reduce
+//   tsmm   : out = X C           (n x lin times lin x lout)
+//   axpbypcz, resid_colnorm2, scale_cols, dgemm_small
+// All HBM-bound (n is 1e5..5e7, l <= 256): the tiles are shaped so every global access is a
+// coalesced run of >= 128 bytes and each element of the tall operand is read once per 64 output
+// columns.  These replace ARPACK's Fortran re-orthogonalisation + LAPACK calls inside
+// scipy.sparse.linalg.svds (reference call sites models.py:844, lib/tensor.py:71,75,79).
+#include "pk_common.h"
+
+// ------------------------------------------------------------------------------------------ gram
+static int gram_splits(int64_t n, int la, int lb) {
+    int64_t tiles = pk_ceil_div(la, 64) * pk_ceil_div(lb, 64);
+    int64_t s = pk_ceil_div(1024, tiles);
+    int64_t max_by_rows = pk_ceil_div(n, 256);
+    if (s > max_by_rows) s = max_by_rows;
+    if (s > 512) s = 512;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+extern "C" int64_t pk_gram_work_bytes(int64_t n, int32_t la, int32_t lb) {
+    return (int64_t)gram_splits(n, la, lb) * la * lb * (int64_t)sizeof(double);
+}
+
+// block (256 threads = 16x16) computes a 64x64 tile of A^T B over its row range
+__global__ __launch_bounds__(256) void gram_kernel(int64_t n, int la, int lb, const double *__restrict__ A,
+                                                   int64_t lda, const double *__restrict__ B, int64_t ldb,
+                                                   double *__restrict__ partial, int tiles_j,
+                                                   int64_t rows_per_split) {
+    __shared__ double sA[16][64];
+    __shared__ double sB[16][64];
+    const int tid = threadIdx.x;
+    const int ti = blockIdx.x / tiles_j, tj = blockIdx.x % tiles_j;
+    const int split = blockIdx.y;
+    const int64_t r_begin = (int64_t)split * rows_per_split;
+    int64_t r_end = r_begin + rows_per_split;
+    if (r_end > n) r_end = n;
+    const int ty = tid >> 4, tx = tid & 15;
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+
+    for (int64_t r0 = r_begin; r0 < r_end; r0 += 16) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int idx = tid + 256 * q;
+            int rr = idx >> 6, c = idx & 63;
+            int64_t row = r0 + rr;
+            int ca = ti * 64 + c, cb = tj * 64 + c;
+            sA[rr][c] = (row < r_end && ca < la) ? A[row * lda + ca] : 0.0;
+            sB[rr][c] = (row < r_end && cb < lb) ? B[row * ldb + cb] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            double a[4], b[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                a[k] = sA[rr][ty * 4 + k];
+                b[k] = sB[rr][tx * 4 + k];
+            }
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 4; ++y) acc[x][y] = fma(a[x], b[y], acc[x][y]);
+        }
+        __syncthreads();
+    }
+    double *dst = partial + (int64_t)split * la * lb;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        int i = ti * 64 + ty * 4 + x;
+        if (i >= la) continue;
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            int j = tj * 64 + tx * 4 + y;
+            if (j < lb) dst[(int64_t)i * lb + j] = acc[x][y];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gram_reduce_kernel(int la, int lb, int splits,
+                                                          const double *__restrict__ partial,
+                                                          double *__restrict__ G, int64_t ldg) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)la * lb) return;
+    double acc = 0.0;
+    for (int s = 0; s < splits; ++s) acc += partial[(int64_t)s * la * lb + e];
+    G[(e / lb) * ldg + (e % lb)] = acc;
+}
+
+extern "C" int pk_gram_f64(void *stream, int64_t n, int32_t la, int32_t lb, const double *A_dev, int64_t lda,
+                           const double *B_dev, int64_t ldb, double *G_dev, int64_t ldg, void *work_dev) {
+    PK_REQUIRE(n >= 1 && la >= 1 && lb >= 1 && la <= 4096 && lb <= 4096, "pk_gram_f64: bad sizes");
+    PK_REQUIRE(lda >= la && ldb >= lb && ldg >= lb, "pk_gram_f64: bad leading dimension");
+    PK_REQUIRE(work_dev != nullptr, "pk_gram_f64: work buffer required");
+    hipStream_t st = pk_stream(stream);
+    const int splits = gram_splits(n, la, lb);
+    const int tiles_i = (int)pk_ceil_div(la, 64), tiles_j = (int)pk_ceil_div(lb, 64);
+    int64_t rows_per_split = pk_ceil_div(n, splits);
+    rows_per_split = pk_ceil_div(rows_per_split, 16) * 16;
+    hipLaunchKernelGGL(gram_kernel, dim3(tiles_i * tiles_j, splits), dim3(256), 0, st, n, la, lb, A_dev, lda,
+                       B_dev, ldb, static_cast<double *>(work_dev), tiles_j, rows_per_split);
+    PK_CHECK_LAUNCH("gram_kernel");
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)pk_ceil_div((int64_t)la * lb, 256)), dim3(256), 0, st,
+                       la, lb, splits, static_cast<const double *>(work_dev), G_dev, ldg);
+    PK_CHECK_LAUNCH("gram_reduce_kernel");
+    return PK_OK;
+}
+
+// ------------------------------------------------------------------------------------------ tsmm
+// block computes 64 rows x 64 output columns; k advanced 16 at a time through LDS
+__global__ __launch_bounds__(256) void tsmm_kernel(int64_t n, int lin, int lout, const double *__restrict__ X,
+                                                   int64_t ldx, const double *__restrict__ C, int64_t ldc,
+                                                   double *__restrict__ out, int64_t ldo) {
+    __shared__ double sX[64][17];
+    __shared__ double sC[16][64];
+    const int tid = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * 64;
+    const int col0 = blockIdx.y * 64;
+    const int ty = tid >> 4, tx = tid & 15;
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+
+    for (int k0 = 0; k0 < lin; k0 += 16) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int idx = tid + 256 * q;
+            {
+                int r = idx >> 4, kk = idx & 15;
+                int64_t row = row0 + r;
+                sX[r][kk] = (row < n && k0 + kk < lin) ? X[row * ldx + k0 + kk] : 0.0;
+            }
+            {
+                int kk = idx >> 6, c = idx & 63;
+                sC[kk][c] = (k0 + kk < lin && col0 + c < lout) ? C[(int64_t)(k0 + kk) * ldc + col0 + c] : 0.0;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            double a[4], b[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                a[k] = sX[ty * 4 + k][kk];
+                b[k] = sC[kk][tx * 4 + k];
+            }
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 4; ++y) acc[x][y] = fma(a[x], b[y], acc[x][y]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        int64_t row = row0 + ty * 4 + x;
+        if (row >= n) continue;
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            int c = col0 + tx * 4 + y;
+            if (c < lout) out[row * ldo + c] = acc[x][y];
+        }
+    }
+}
+
+extern "C" int pk_tsmm_f64(void *stream, int64_t n, int32_t lin, int32_t lout, const double *X_dev, int64_t ldx,
+                           const double *C_dev, int64_t ldc, double *out_dev, int64_t ldo) {
+    PK_REQUIRE(n >= 1 && lin >= 1 && lout >= 1, "pk_tsmm_f64: bad sizes");
+    PK_REQUIRE(ldx >= lin && ldc >= lout && ldo >= lout, "pk_tsmm_f64: bad leading dimension");
+    PK_REQUIRE(X_dev != out_dev, "pk_tsmm_f64: out must not alias X");
+    hipLaunchKernelGGL(tsmm_kernel, dim3((unsigned)pk_ceil_div(n, 64), (unsigned)pk_ceil_div(lout, 64)), dim3(256),
+                       0, pk_stream(stream), n, lin, lout, X_dev, ldx, C_dev, ldc, out_dev, ldo);
+    PK_CHECK_LAUNCH("tsmm_kernel");
+    return PK_OK;
+}
+
+// ------------------------------------------------------------------------------------------ elementwise
+__global__ __launch_bounds__(256) void axpbypcz_kernel(int64_t n, double alpha, const double *__restrict__ Z,
+                                                       double beta, const double *__restrict__ Y, double gamma,
+                                                       const double *__restrict__ X, double *__restrict__ out) {
+    int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 2;
+    for (; i + 1 < n; i += stride) {
+        double2 z = *reinterpret_cast<const double2 *>(Z + i);
+        double2 r = make_double2(alpha * z.x, alpha * z.y);
+        if (Y) {
+            double2 y = *reinterpret_cast<const double2 *>(Y + i);
+            r.x = fma(beta, y.x, r.x);
+            r.y = fma(beta, y.y, r.y);
+        }
+        if (X) {
+            double2 x = *reinterpret_cast<const double2 *>(X + i);
+            r.x = fma(gamma, x.x, r.x);
+            r.y = fma(gamma, x.y, r.y);
+        }
+        *reinterpret_cast<double2 *>(out + i) = r;
+    }
+    if (i < n) {  // odd tail element
+        double r = alpha * Z[i];
+        if (Y) r = fma(beta, Y[i], r);
+        if (X) r = fma(gamma, X[i], r);
+        out[i] = r;
+    }
+}
+
+extern "C" int pk_axpbypcz_f64(void *stream, int64_t n_elems, double alpha, const double *Z_dev, double beta,
+                               const double *Y_dev, double gamma, const double *X_dev, double *out_dev) {
+    PK_REQUIRE(n_elems >= 0 && Z_dev && out_dev, "pk_axpbypcz_f64: bad arguments");
+    PK_REQUIRE(((uintptr_t)Z_dev % 16 == 0) && ((uintptr_t)out_dev % 16 == 0) && ((uintptr_t)Y_dev % 16 == 0) &&
+                   ((uintptr_t)X_dev % 16 == 0),
+               "pk_axpbypcz_f64: buffers must be 16-byte aligned");
+    if (n_elems == 0) return PK_OK;
+    int64_t blocks = pk_ceil_div(pk_ceil_div(n_elems, 2), 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(axpbypcz_kernel, dim3((unsigned)blocks), dim3(256), 0, pk_stream(stream), n_elems, alpha,
+                       Z_dev, beta, Y_dev, gamma, X_dev, out_dev);
+    PK_CHECK_LAUNCH("axpbypcz_kernel");
+    return PK_OK;
+}
+
+// partial[b, j] = sum_{i in block b} (Z[i,j] - theta[j] X[i,j])^2 ; host (or caller) sums over b
+#define PK_RESID_ROWS 1024
+extern "C" int32_t pk_resid_blocks(int64_t n) { return (int32_t)pk_ceil_div(n, PK_RESID_ROWS); }
+
+__global__ __launch_bounds__(256) void resid_colnorm2_kernel(int64_t n, int l, const double *__restrict__ Z,
+                                                             int64_t ldz, const double *__restrict__ X,
+                                                             int64_t ldx, const double *__restrict__ theta,
+                                                             double *__restrict__ partial) {
+    // 256 threads: column = tid % cw, row lane = tid / cw, with cw = min(l rounded to pow2, 256)
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * PK_RESID_ROWS;
+    int64_t r1 = r0 + PK_RESID_ROWS;
+    if (r1 > n) r1 = n;
+    int cw = 1;
+    while (cw < l && cw < 256) cw <<= 1;
+    const int rl = tid / cw, nrl = 256 / cw;
+    for (int j0 = 0; j0 < l; j0 += cw) {
+        const int j = j0 + (tid % cw);
+        double acc = 0.0;
+        if (j < l) {
+            const double th = theta[j];
+            for (int64_t i = r0 + rl; i < r1; i += nrl) {
+                double d = Z[i * ldz + j] - th * X[i * ldx + j];
+                acc = fma(d, d, acc);
+            }
+        }
+        red[tid] = acc;
+        __syncthreads();
+        for (int s = nrl / 2; s > 0; s >>= 1) {
+            if (rl < s) red[tid] += red[tid + s * cw];
+            __syncthreads();
+        }
+        if (rl == 0 && j < l) partial[(int64_t)blockIdx.x * l + j] = red[tid];
+        __syncthreads();
+    }
+}
+
+extern "C" int pk_resid_colnorm2_f64(void *stream, int64_t n, int32_t l, const double *Z_dev, int64_t ldz,
+                                     const double *X_dev, int64_t ldx, const double *theta_dev,
+                                     double *partial_dev) {
+    PK_REQUIRE(n >= 1 && l >= 1 && ldz >= l && ldx >= l, "pk_resid_colnorm2_f64: bad sizes");
+    hipLaunchKernelGGL(resid_colnorm2_kernel, dim3((unsigned)pk_resid_blocks(n)), dim3(256), 0, pk_stream(stream),
+                       n, l, Z_dev, ldz, X_dev, ldx, theta_dev, partial_dev);
+    PK_CHECK_LAUNCH("resid_colnorm2_kernel");
+    return PK_OK;
+}
+
+__global__ __launch_bounds__(256) void scale_cols_kernel(int64_t n, int l, double *__restrict__ X, int64_t ldx,
+                                                         const double *__restrict__ s) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = n * l, stride = (int64_t)gridDim.x * blockDim.x;
+    for (; e < total; e += stride) {
+        int64_t i = e / l;
+        int j = (int)(e % l);
+        X[i * ldx + j] *= s[j];
+    }
+}
+
+extern "C" int pk_scale_cols_f64(void *stream, int64_t n, int32_t l, double *X_dev, int64_t ldx,
+                                 const double *s_dev) {
+    PK_REQUIRE(n >= 1 && l >= 1 && ldx >= l, "pk_scale_cols_f64: bad sizes");
+    int64_t blocks = pk_ceil_div(n * l, 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(scale_cols_kernel, dim3((unsigned)blocks), dim3(256), 0, pk_stream(stream), n, l, X_dev, ldx,
+                       s_dev);
+    PK_CHECK_LAUNCH("scale_cols_kernel");
+    return PK_OK;
+}
+
+// C[M x N] = op(A) op(B), one thread per output element (l x l glue only; perf irrelevant)
+__global__ __launch_bounds__(256) void dgemm_small_kernel(int tA, int tB, int M, int N, int K,
+                                                          const double *__restrict__ A, int64_t lda,
+                                                          const double *__restrict__ B, int64_t ldb,
+                                                          double *__restrict__ C, int64_t ldc) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (int64_t)M * N) return;
+    const int i = (int)(e / N), j = (int)(e % N);
+    double acc = 0.0;
+    for (int k = 0; k < K; ++k) {
+        double a = tA ? A[(int64_t)k * lda + i] : A[(int64_t)i * lda + k];
+        double b = tB ? B[(int64_t)j * ldb + k] : B[(int64_t)k * ldb + j];
+        acc = fma(a, b, acc);
+    }
+    C[(int64_t)i * ldc + j] = acc;
+}
+
+extern "C" int pk_dgemm_small_f64(void *stream, int transA, int transB, int32_t M, int32_t N, int32_t K,
+                                  const double *A_dev, int64_t lda, const double *B_dev, int64_t ldb,
+                                  double *C_dev, int64_t ldc) {
+    PK_REQUIRE(M >= 1 && N >= 1 && K >= 1 && ldc >= N, "pk_dgemm_small_f64: bad sizes");
+    hipLaunchKernelGGL(dgemm_small_kernel, dim3((unsigned)pk_ceil_div((int64_t)M * N, 256)), dim3(256), 0,
+                       pk_stream(stream), transA, transB, M, N, K, A_dev, lda, B_dev, ldb, C_dev, ldc);
+    PK_CHECK_LAUNCH("dgemm_small_kernel");
+    return PK_OK;
+}

@@ -1,0 +1,249 @@
+// K3 (second half): exact fp64 re-scoring of the fp32 candidates, final ordering, and the exact
+// brute-force path for the (rare) users the candidate pass cannot certify.
+//
+// Why: the reference scores in fp64 (models.py:860) and returns index lists, and the north-star
+// contract is "top-k index sets identical".  fp32 MFMA scores can flip near-ties at the k-th
+// boundary, so the candidate kernel keeps KC > topk items per user and this pass (a) recomputes
+// those KC scores in fp64 from the fp64 factors, (b) orders them (score desc, item asc), and
+// (c) certifies the result: every non-candidate has fp32 score <= tau32 (the KC-th candidate), so
+// its fp64 score is <= tau32 + err; if the k-th exact score clears that bound the top-k set is
+// provably the exact one, else the user is flagged and re-done by score_exact_rows (all items,
+// fp64, two-class key = the reference's downvote_seen_items semantics, models.py:510-519).
+#include "pk_common.h"
+#include <math.h>
+
+#define PK_IDX_NONE 0x7fffffff
+
+__device__ __forceinline__ bool pk_before64(double ka, int va, double kb, int vb) {
+    return (ka > kb) || (ka == kb && va < vb);
+}
+
+// wave bitonic sort (descending) of one (key, val) per lane
+__device__ __forceinline__ void pk_bitonic64(double &key, int &val, int lane) {
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const double ok = __shfl_xor(key, j, 64);
+            const int ov = __shfl_xor(val, j, 64);
+            const bool lower = (lane & j) == 0;
+            const bool desc = (lane & k) == 0;
+            const bool want_first = (lower == desc);
+            const bool other_first = pk_before64(ok, ov, key, val);
+            if (want_first == other_first) {
+                key = ok;
+                val = ov;
+            }
+        }
+    }
+}
+
+// one wave per user
+__global__ __launch_bounds__(256) void rescore_topk_kernel(
+    int64_t n_users, int64_t n_items, int K, const double *__restrict__ V, int64_t ldv,
+    const double *__restrict__ E, int64_t lde, const int64_t *__restrict__ seen_ptr, int KC,
+    const float *__restrict__ cand_score, const int32_t *__restrict__ cand_idx, int topk, double vmax,
+    int64_t *__restrict__ out_idx, double *__restrict__ out_score, int32_t *__restrict__ flags) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t user = (int64_t)blockIdx.x * 4 + wave;
+    if (user >= n_users) return;
+
+    // E row: lane holds E[user][lane + 64 g]
+    double ek[4];
+    double e2 = 0.0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int k = lane + 64 * g;
+        ek[g] = (k < K) ? E[user * lde + k] : 0.0;
+        e2 = fma(ek[g], ek[g], e2);
+    }
+    const double enorm = sqrt(pk_wave_sum(e2));
+
+    double my_s = -INFINITY;
+    int my_i = PK_IDX_NONE;
+    int n_valid = 0;
+    for (int t = 0; t < KC; ++t) {
+        const int idx = cand_idx[user * KC + t];  // wave-uniform
+        if (idx < 0) continue;
+        ++n_valid;
+        const double *vr = V + (int64_t)idx * ldv;
+        double part = 0.0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int k = lane + 64 * g;
+            if (k < K) part = fma(ek[g], vr[k], part);
+        }
+        const double s = pk_wave_sum(part);
+        if (lane == t) {
+            my_s = s;
+            my_i = idx;
+        }
+    }
+    pk_bitonic64(my_s, my_i, lane);
+
+    // certification
+    int flag = 0;
+    const int64_t n_seen = seen_ptr ? (seen_ptr[user + 1] - seen_ptr[user]) : 0;
+    if (n_items - n_seen < topk) {
+        flag |= 2;  // seen items must re-enter the list: exact path
+    } else if (n_valid == KC) {
+        const double tau32 = (double)cand_score[user * KC + KC - 1];
+        const double s_k = __shfl(my_s, topk - 1, 64);
+        // |fl32(e.v) - e.v| <= (K + 3) u32 |e||v|  (input rounding + K-term fmaf chain), u32 = 2^-24
+        const double bound = (double)(K + 3) * 5.9604644775390625e-08 * enorm * vmax;
+        if (bound > 0.0 && !(s_k - tau32 > bound)) flag |= 1;
+    }
+    if (lane < topk) {
+        out_idx[user * topk + lane] = (my_i == PK_IDX_NONE) ? -1 : (int64_t)my_i;
+        if (out_score) out_score[user * topk + lane] = my_s;
+    }
+    if (lane == 0) flags[user] = flag;
+}
+
+extern "C" int pk_rescore_topk_f64(void *stream, int64_t n_users, int64_t n_items, int32_t K, const double *V_dev,
+                                   int64_t ldv, const double *E_dev, int64_t lde, const int64_t *seen_ptr_dev,
+                                   int32_t KC, const float *cand_score_dev, const int32_t *cand_idx_dev,
+                                   int32_t topk, double v_row_norm_max, int64_t *out_idx_dev,
+                                   double *out_score_dev, int32_t *flags_dev) {
+    PK_REQUIRE(n_users >= 1 && K >= 1 && K <= 256 && ldv >= K && lde >= K, "pk_rescore_topk_f64: bad sizes");
+    PK_REQUIRE(KC >= 1 && KC <= 64 && topk >= 1 && topk <= KC, "pk_rescore_topk_f64: need topk <= KC <= 64");
+    hipLaunchKernelGGL(rescore_topk_kernel, dim3((unsigned)pk_ceil_div(n_users, 4)), dim3(256), 0, pk_stream(stream),
+                       n_users, n_items, K, V_dev, ldv, E_dev, lde, seen_ptr_dev, KC, cand_score_dev, cand_idx_dev,
+                       topk, v_row_norm_max, out_idx_dev, out_score_dev, flags_dev);
+    PK_CHECK_LAUNCH("rescore_topk_kernel");
+    return PK_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// exact rows: one workgroup per listed user
+// ------------------------------------------------------------------------------------------
+extern "C" int64_t pk_exact_work_bytes(int32_t n_rows, int64_t n_items) {
+    // fp64 score + 1 class byte per item, rows padded to 16 bytes
+    const int64_t per_row = n_items * 8 + ((n_items + 15) / 16) * 16;
+    return (int64_t)n_rows * per_row;
+}
+
+struct Best {
+    int cls;  // 0 = unseen (ranks first), 1 = seen, 2 = taken / none
+    double s;
+    int idx;
+};
+__device__ __forceinline__ bool best_before(const Best &a, const Best &b) {
+    if (a.cls != b.cls) return a.cls < b.cls;
+    if (a.s != b.s) return a.s > b.s;
+    return a.idx < b.idx;
+}
+
+__global__ __launch_bounds__(256) void score_exact_rows_kernel(
+    const int32_t *__restrict__ rows, int64_t n_items, int K, const double *__restrict__ V, int64_t ldv,
+    const double *__restrict__ E, int64_t lde, const int64_t *__restrict__ seen_ptr,
+    const int32_t *__restrict__ seen_idx, int topk, int64_t *__restrict__ out_idx,
+    double *__restrict__ out_score, unsigned char *__restrict__ work, int64_t per_row) {
+    __shared__ double s_e[256];
+    __shared__ int s_cls[256];
+    __shared__ double s_s[256];
+    __shared__ int s_i[256];
+    const int tid = threadIdx.x;
+    const int64_t user = rows[blockIdx.x];
+    double *score = reinterpret_cast<double *>(work + (int64_t)blockIdx.x * per_row);
+    unsigned char *cls = work + (int64_t)blockIdx.x * per_row + n_items * 8;
+
+    if (tid < K) s_e[tid] = E[user * lde + tid];
+    __syncthreads();
+    for (int64_t i = tid; i < n_items; i += 256) {
+        const double *vr = V + i * ldv;
+        double s = 0.0;
+        for (int k = 0; k < K; ++k) s = fma(s_e[k], vr[k], s);
+        score[i] = s;
+        cls[i] = 0;
+    }
+    __syncthreads();
+    if (seen_ptr) {
+        const int64_t p0 = seen_ptr[user], p1 = seen_ptr[user + 1];
+        for (int64_t p = p0 + tid; p < p1; p += 256) {
+            const int j = seen_idx[p];
+            if (j >= 0 && j < n_items) cls[j] = 1;
+        }
+    }
+    __syncthreads();
+    for (int t = 0; t < topk; ++t) {
+        Best b;
+        b.cls = 2;
+        b.s = -INFINITY;
+        b.idx = PK_IDX_NONE;
+        for (int64_t i = tid; i < n_items; i += 256) {
+            Best c;
+            c.cls = cls[i];
+            c.s = score[i];
+            c.idx = (int)i;
+            if (c.cls < 2 && best_before(c, b)) b = c;
+        }
+        s_cls[tid] = b.cls;
+        s_s[tid] = b.s;
+        s_i[tid] = b.idx;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (tid < st) {
+                Best x{s_cls[tid], s_s[tid], s_i[tid]}, y{s_cls[tid + st], s_s[tid + st], s_i[tid + st]};
+                if (best_before(y, x)) {
+                    s_cls[tid] = y.cls;
+                    s_s[tid] = y.s;
+                    s_i[tid] = y.idx;
+                }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            const bool ok = s_cls[0] < 2;
+            out_idx[(int64_t)blockIdx.x * topk + t] = ok ? (int64_t)s_i[0] : -1;
+            if (out_score) out_score[(int64_t)blockIdx.x * topk + t] = ok ? s_s[0] : -INFINITY;
+            if (ok) cls[s_i[0]] = 2;
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int pk_score_exact_rows_f64(void *stream, int32_t n_rows, const int32_t *rows_dev, int64_t n_items,
+                                       int32_t K, const double *V_dev, int64_t ldv, const double *E_dev,
+                                       int64_t lde, const int64_t *seen_ptr_dev, const int32_t *seen_idx_dev,
+                                       int32_t topk, int64_t *out_idx_dev, double *out_score_dev, void *work_dev) {
+    PK_REQUIRE(n_rows >= 0 && n_items >= 1 && K >= 1 && K <= 256 && topk >= 1, "pk_score_exact_rows_f64: bad sizes");
+    PK_REQUIRE(ldv >= K && lde >= K && work_dev, "pk_score_exact_rows_f64: bad arguments");
+    if (n_rows == 0) return PK_OK;
+    const int64_t per_row = n_items * 8 + ((n_items + 15) / 16) * 16;
+    hipLaunchKernelGGL(score_exact_rows_kernel, dim3((unsigned)n_rows), dim3(256), 0, pk_stream(stream), rows_dev,
+                       n_items, K, V_dev, ldv, E_dev, lde, seen_ptr_dev, seen_idx_dev, topk, out_idx_dev,
+                       out_score_dev, static_cast<unsigned char *>(work_dev), per_row);
+    PK_CHECK_LAUNCH("score_exact_rows_kernel");
+    return PK_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// dense fp64 score rows (slice_recommendations / _user_scores support, models.py:277-291, 857-861)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dense_scores_kernel(int n_rows, int64_t n_items, int K,
+                                                           const double *__restrict__ V, int64_t ldv,
+                                                           const double *__restrict__ E, int64_t lde,
+                                                           double *__restrict__ out, int64_t ldo) {
+    __shared__ double s_e[256];
+    const int r = blockIdx.y;
+    if (threadIdx.x < K) s_e[threadIdx.x] = E[(int64_t)r * lde + threadIdx.x];
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_items) return;
+    const double *vr = V + i * ldv;
+    double s = 0.0;
+    for (int k = 0; k < K; ++k) s = fma(s_e[k], vr[k], s);
+    out[(int64_t)r * ldo + i] = s;
+}
+
+extern "C" int pk_dense_scores_f64(void *stream, int32_t n_rows, int64_t n_items, int32_t K, const double *V_dev,
+                                   int64_t ldv, const double *E_dev, int64_t lde, double *out_dev, int64_t ldo) {
+    PK_REQUIRE(n_rows >= 1 && n_rows <= 65535 && n_items >= 1 && K >= 1 && K <= 256 && ldo >= n_items,
+               "pk_dense_scores_f64: bad sizes");
+    hipLaunchKernelGGL(dense_scores_kernel, dim3((unsigned)pk_ceil_div(n_items, 256), (unsigned)n_rows), dim3(256), 0,
+                       pk_stream(stream), n_rows, n_items, K, V_dev, ldv, E_dev, lde, out_dev, ldo);
+    PK_CHECK_LAUNCH("dense_scores_kernel");
+    return PK_OK;
+}

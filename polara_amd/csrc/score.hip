@@ -1,0 +1,362 @@
+// K3: fused  scores = E V^T  (fp32 MFMA)  +  seen-item masking  +  per-user top-k candidates.
+//
+// Replaces the body of RecommenderModel._slice_recommender (models.py:359-371):
+//   scores = (test_matrix.dot(v)).dot(v.T)          models.py:860   -> MFMA tiles, never stored
+//   downvote_seen_items(scores, slice_data)         models.py:494-519 -> mask bits per 32-item tile
+//   get_topk_elements -> apply_along_axis(topsort)  models.py:488-491,563 -> threshold + wave bitonic
+//
+// Orientation (the "swapped operand" trick): the MFMA computes  C[item][user] = V_tile * E_group^T
+// with v_mfma_f32_32x32x2_f32, so in the C layout (col = lane&31, row = (r&3)+8(r>>2)+4(lane>>5))
+// a LANE owns ONE user (lane&31) and 16 of the tile's 32 items.  All per-user state — running
+// threshold tau, position in the user's sorted seen list, candidate count — is therefore
+// lane-local in registers; no cross-lane traffic on the hot path and no workgroup barrier at all:
+// each wave owns a group of 32 users and streams every item tile independently.
+//
+// Operands: both factor matrices are pre-packed (pack.hip) into MFMA fragment order
+//   P[tile][q][lane][4]  with element e of lane (i = lane&31, h = lane>>5) = M[32*tile + i][8q + 2e + h]
+// so a wave's fragment load is one fully coalesced 1 KiB global_load_dwordx4.  E fragments stay in
+// registers for the whole kernel; V fragments stream from L2/MALL (V is n_items x K x 4 B, a few
+// tens of MB, shared by every wave of the chip).
+//
+// Selection: tau = score of the KC-th best candidate seen so far for that user (lazy).  A score
+// above tau is appended to a lane-private LDS ring (16 entries); when a ring is full the wave
+// bitonic-sorts {both rings of the user, current top-KC list} and refreshes the list and tau.
+// After warm-up almost every tile takes the fast path: 8 v_max3 + 1 compare + 1 ballot.
+#include "pk_common.h"
+#include <math.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define RING 16          // lane-private candidate ring entries
+#define PK_IDX_NONE 0x7fffffff
+
+// ---- ordering used everywhere: larger score first, then smaller item id ---------------------
+__device__ __forceinline__ bool pk_before(float ka, int va, float kb, int vb) {
+    return (ka > kb) || (ka == kb && va < vb);
+}
+
+// Wave-wide bitonic sort (descending by pk_before) of 64*SLOTS (key,val) pairs, element index
+// i = lane + 64*slot.
+template <int SLOTS>
+__device__ __forceinline__ void pk_bitonic_desc(float (&key)[SLOTS], int (&val)[SLOTS], int lane) {
+    constexpr int T = 64 * SLOTS;
+#pragma unroll
+    for (int k = 2; k <= T; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 64) {
+                // partner lives in another slot of the same lane (only SLOTS == 2, j == 64)
+                const int sj = j >> 6;
+#pragma unroll
+                for (int s = 0; s < SLOTS; ++s) {
+                    if ((s & sj) == 0) {
+                        const int i = lane + 64 * s;
+                        const bool desc = (i & k) == 0;
+                        const bool swap = desc ? pk_before(key[s + sj], val[s + sj], key[s], val[s])
+                                               : pk_before(key[s], val[s], key[s + sj], val[s + sj]);
+                        if (swap) {
+                            float tk = key[s]; key[s] = key[s + sj]; key[s + sj] = tk;
+                            int tv = val[s]; val[s] = val[s + sj]; val[s + sj] = tv;
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < SLOTS; ++s) {
+                    const int i = lane + 64 * s;
+                    const float ok = __shfl_xor(key[s], j, 64);
+                    const int ov = __shfl_xor(val[s], j, 64);
+                    const bool lower = (i & j) == 0;
+                    const bool desc = (i & k) == 0;
+                    const bool want_first = (lower == desc);  // this position keeps the element that sorts first
+                    const bool other_first = pk_before(ok, ov, key[s], val[s]);
+                    if (want_first == other_first) {
+                        key[s] = ok;
+                        val[s] = ov;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int KQ, int KC>
+__global__ __launch_bounds__(256) void score_candidates_kernel(
+    const float4 *__restrict__ Vp, const float4 *__restrict__ Ep, int64_t n_users, int n_items, int n_tiles,
+    const int64_t *__restrict__ seen_ptr, const int32_t *__restrict__ seen_idx,
+    float *__restrict__ cand_score, int32_t *__restrict__ cand_idx) {
+    constexpr int SLOTS = (2 * RING + KC + 63) / 64;
+    __shared__ uint2 ring_all[4][RING][64];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t group = (int64_t)blockIdx.x * 4 + wave;
+    if (group * 32 >= n_users) return;  // whole wave leaves; the kernel has no workgroup barrier
+    uint2(*ring)[64] = ring_all[wave];
+
+    const int ul = lane & 31, hi = lane >> 5;
+    const int64_t user = group * 32 + ul;
+    float *my_score = cand_score + group * 32 * KC;  // this wave's [32][KC] top lists
+    int32_t *my_idx = cand_idx + group * 32 * KC;
+
+    for (int s = lane; s < 32 * KC; s += 64) {
+        my_score[s] = -INFINITY;
+        my_idx[s] = -1;
+    }
+
+    float4 e[KQ];
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) e[q] = Ep[(group * KQ + q) * 64 + lane];
+
+    int64_t sp = 0, se = 0;
+    int nxt = PK_IDX_NONE;
+    if (seen_ptr != nullptr && user < n_users) {
+        sp = seen_ptr[user];
+        se = seen_ptr[user + 1];
+        if (sp < se) nxt = seen_idx[sp];
+    }
+    float tau = -INFINITY;
+    int cnt = 0;
+
+    // merge the rings of user x (lanes x, x+32) and its top list; refresh list, tau, counters
+    auto flush_user = [&](int x) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        const int c_lo = __builtin_amdgcn_readlane(cnt, x);
+        const int c_hi = __builtin_amdgcn_readlane(cnt, x + 32);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        float key[SLOTS];
+        int val[SLOTS];
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            const int i = lane + 64 * s;
+            float k = -INFINITY;
+            int v = PK_IDX_NONE;
+            if (i < RING) {
+                if (i < c_lo) {
+                    uint2 r = ring[i][x];
+                    k = __uint_as_float(r.x);
+                    v = (int)r.y;
+                }
+            } else if (i < 2 * RING) {
+                if (i - RING < c_hi) {
+                    uint2 r = ring[i - RING][x + 32];
+                    k = __uint_as_float(r.x);
+                    v = (int)r.y;
+                }
+            } else if (i < 2 * RING + KC) {
+                const int t = i - 2 * RING;
+                const int iv = my_idx[x * KC + t];
+                if (iv >= 0) {
+                    k = my_score[x * KC + t];
+                    v = iv;
+                }
+            }
+            key[s] = k;
+            val[s] = v;
+        }
+        pk_bitonic_desc<SLOTS>(key, val, lane);
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            const int i = lane + 64 * s;
+            if (i < KC) {
+                my_score[x * KC + i] = key[s];
+                my_idx[x * KC + i] = (val[s] == PK_IDX_NONE) ? -1 : val[s];
+            }
+        }
+        // new threshold: key of sorted element KC-1 (-inf while the list is not full)
+        const float ntau = __int_as_float(
+            __builtin_amdgcn_readlane(__float_as_int(key[(KC - 1) / 64]), (KC - 1) & 63));
+        if (ul == x) {
+            tau = ntau;
+            cnt = 0;
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    for (int tile = 0; tile < n_tiles; ++tile) {
+        const int j0 = tile * 32;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        const float4 *vp = Vp + ((int64_t)tile * KQ) * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            const float4 a = vp[q * 64];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, e[q].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, e[q].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, e[q].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, e[q].w, acc, 0, 0, 0);
+        }
+
+        // ---- seen-item mask of this tile for my user (bit b <-> item j0 + b) ---------------
+        const int jend = j0 + 32;
+        unsigned mask = 0;
+        while (__any(nxt < jend)) {
+            if (nxt < jend) {
+                mask |= 1u << (nxt - j0);
+                ++sp;
+                nxt = (sp < se) ? seen_idx[sp] : PK_IDX_NONE;
+            }
+        }
+        if (jend > n_items) mask |= ~0u << (n_items - j0);  // padding items of the last tile
+        if (__any(mask != 0)) {
+            const unsigned m2 = mask >> (4 * hi);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (m2 & (1u << ((r & 3) + 8 * (r >> 2)))) acc[r] = -INFINITY;
+        }
+
+        // ---- fast path: nothing in this tile beats the threshold of any user ---------------
+        float m = fmaxf(acc[0], acc[1]);
+#pragma unroll
+        for (int r = 2; r < 16; ++r) m = fmaxf(m, acc[r]);
+        if (__any(m > tau)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                bool c = acc[r] > tau;
+                if (__any(c)) {
+                    if (__any(c && cnt == RING)) {
+                        const unsigned long long full = __ballot(cnt == RING);
+                        unsigned um = (unsigned)(full | (full >> 32));
+                        while (um) {
+                            const int x = __builtin_ctz(um);
+                            um &= um - 1;
+                            flush_user(x);
+                        }
+                        c = acc[r] > tau;
+                    }
+                    if (c) {
+                        ring[cnt][lane] = make_uint2(__float_as_uint(acc[r]),
+                                                     (unsigned)(j0 + (r & 3) + 8 * (r >> 2) + 4 * hi));
+                        ++cnt;
+                    }
+                }
+            }
+        }
+    }
+    // final merge of whatever is left in the rings
+    {
+        const unsigned long long some = __ballot(cnt > 0);
+        unsigned um = (unsigned)(some | (some >> 32));
+        while (um) {
+            const int x = __builtin_ctz(um);
+            um &= um - 1;
+            flush_user(x);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// packing: f64 [n x K] -> f32 MFMA fragments, 32 rows per tile, K padded with zeros to 8*KQ
+// ------------------------------------------------------------------------------------------
+static const int kKqSet[] = {2, 4, 7, 8, 13, 16, 25, 32};
+
+extern "C" int32_t pk_pack_kq(int32_t K) {
+    const int need = (K + 7) / 8;
+    for (int kq : kKqSet)
+        if (kq >= need) return kq;
+    return 0;
+}
+
+extern "C" int64_t pk_pack_elems(int64_t n, int32_t K) {
+    const int kq = pk_pack_kq(K);
+    return pk_ceil_div(n, 32) * kq * 64 * 4;
+}
+
+__global__ __launch_bounds__(256) void pack_frag_kernel(int64_t n, int K, int kq, const double *__restrict__ src,
+                                                        int64_t ld, float4 *__restrict__ dst, int64_t total) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one float4 per thread
+    if (t >= total) return;
+    const int lane = (int)(t & 63);
+    const int64_t tq = t >> 6;
+    const int q = (int)(tq % kq);
+    const int64_t tile = tq / kq;
+    const int64_t row = tile * 32 + (lane & 31);
+    const int h = lane >> 5;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int k = 8 * q + 2 * e + h;
+        v[e] = (row < n && k < K) ? (float)src[row * ld + k] : 0.0f;
+    }
+    dst[t] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+extern "C" int pk_pack_frag_f32(void *stream, int64_t n, int32_t K, const double *src_dev, int64_t ld,
+                                float *dst_dev) {
+    const int kq = pk_pack_kq(K);
+    PK_REQUIRE(n >= 1 && K >= 1 && kq > 0, "pk_pack_frag_f32: n=%lld K=%d unsupported (K <= 256)", (long long)n, K);
+    PK_REQUIRE(ld >= K && ((uintptr_t)dst_dev % 16) == 0, "pk_pack_frag_f32: bad ld / alignment");
+    const int64_t total = pk_ceil_div(n, 32) * kq * 64;
+    hipLaunchKernelGGL(pack_frag_kernel, dim3((unsigned)pk_ceil_div(total, 256)), dim3(256), 0, pk_stream(stream), n,
+                       K, kq, src_dev, ld, reinterpret_cast<float4 *>(dst_dev), total);
+    PK_CHECK_LAUNCH("pack_frag_kernel");
+    return PK_OK;
+}
+
+extern "C" int32_t pk_candidate_capacity(int32_t topk) {
+    if (topk < 1) return 0;
+    if (topk <= 10) return 16;
+    if (topk <= 24) return 32;
+    if (topk <= 52) return 64;
+    return 0;
+}
+
+template <int KQ>
+static int launch_candidates_kq(hipStream_t st, int KC, dim3 grid, const float4 *Vp, const float4 *Ep,
+                                int64_t n_users, int n_items, int n_tiles, const int64_t *seen_ptr,
+                                const int32_t *seen_idx, float *cs, int32_t *ci) {
+    switch (KC) {
+        case 16:
+            hipLaunchKernelGGL((score_candidates_kernel<KQ, 16>), grid, dim3(256), 0, st, Vp, Ep, n_users, n_items,
+                               n_tiles, seen_ptr, seen_idx, cs, ci);
+            return PK_OK;
+        case 32:
+            hipLaunchKernelGGL((score_candidates_kernel<KQ, 32>), grid, dim3(256), 0, st, Vp, Ep, n_users, n_items,
+                               n_tiles, seen_ptr, seen_idx, cs, ci);
+            return PK_OK;
+        case 64:
+            hipLaunchKernelGGL((score_candidates_kernel<KQ, 64>), grid, dim3(256), 0, st, Vp, Ep, n_users, n_items,
+                               n_tiles, seen_ptr, seen_idx, cs, ci);
+            return PK_OK;
+    }
+    pk_set_error("pk_score_candidates_f32: KC=%d unsupported (16, 32, 64)", KC);
+    return PK_E_UNSUPPORTED;
+}
+
+extern "C" int pk_score_candidates_f32(void *stream, int64_t n_users, int64_t n_items, int32_t K,
+                                       const float *Vp_dev, const float *Ep_dev, const int64_t *seen_ptr_dev,
+                                       const int32_t *seen_idx_dev, int32_t KC, float *cand_score_dev,
+                                       int32_t *cand_idx_dev) {
+    PK_REQUIRE(n_users >= 1 && n_items >= 1 && n_items < 0x7fffff00LL, "pk_score_candidates_f32: bad sizes");
+    const int kq = pk_pack_kq(K);
+    PK_REQUIRE(kq > 0, "pk_score_candidates_f32: K=%d unsupported (K <= 256)", K);
+    PK_REQUIRE(((uintptr_t)Vp_dev % 16) == 0 && ((uintptr_t)Ep_dev % 16) == 0, "pk_score_candidates_f32: alignment");
+    hipStream_t st = pk_stream(stream);
+    const int n_tiles = (int)pk_ceil_div(n_items, 32);
+    const int64_t groups = pk_ceil_div(n_users, 32);
+    dim3 grid((unsigned)pk_ceil_div(groups, 4));
+    const float4 *Vp = reinterpret_cast<const float4 *>(Vp_dev);
+    const float4 *Ep = reinterpret_cast<const float4 *>(Ep_dev);
+    int rc = PK_E_UNSUPPORTED;
+#define PK_KQ_CASE(Q)                                                                                         \
+    case Q:                                                                                                   \
+        rc = launch_candidates_kq<Q>(st, KC, grid, Vp, Ep, n_users, (int)n_items, n_tiles, seen_ptr_dev,       \
+                                     seen_idx_dev, cand_score_dev, cand_idx_dev);                             \
+        break;
+    switch (kq) {
+        PK_KQ_CASE(2)
+        PK_KQ_CASE(4)
+        PK_KQ_CASE(7)
+        PK_KQ_CASE(8)
+        PK_KQ_CASE(13)
+        PK_KQ_CASE(16)
+        PK_KQ_CASE(25)
+        PK_KQ_CASE(32)
+    }
+#undef PK_KQ_CASE
+    if (rc != PK_OK) return rc;
+    PK_CHECK_LAUNCH("score_candidates_kernel");
+    return PK_OK;
+}

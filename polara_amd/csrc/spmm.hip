@@ -1,0 +1,156 @@
+// K1/K4: CSR x dense (fp64 accumulate) for gfx950.
+//
+// out[r, :] = sum_p vals[p] * X[indices[p], :]      (scipy csr_matvecs restated for a block of
+// nc right-hand sides; reference call sites: models.py:844 via svds' A^T(A x) operator and
+// models.py:860 `test_matrix.dot(v)`).
+//
+// Mapping: one 64-lane wave per task (a contiguous nnz range of ONE row).  Lanes own columns of
+// the dense block (lane + 64*g), so every gather of a row of X is a fully coalesced 512-byte
+// read; the (index, value) pairs of the task are fetched 64 at a time with one coalesced load and
+// broadcast to the wave through v_readlane (SGPR), which makes the X row base address scalar.
+// HBM/L2-bound by construction: 1 FMA per 8 bytes gathered.  No atomics: long rows are split into
+// tasks that write partial sums, added in slot order by spmm_fixup_kernel (deterministic).
+#include "pk_common.h"
+
+template <typename VT>
+__device__ __forceinline__ double pk_bcast_val(VT a, int t);
+template <>
+__device__ __forceinline__ double pk_bcast_val<float>(float a, int t) {
+    return (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), t));
+}
+template <>
+__device__ __forceinline__ double pk_bcast_val<double>(double a, int t) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(a), t);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(a), t);
+    return __hiloint2double(hi, lo);
+}
+
+template <typename VT, int CPL>
+__global__ __launch_bounds__(256) void spmm_csr_kernel(
+    int64_t n_tasks, const int32_t *__restrict__ task_row, const int64_t *__restrict__ task_begin,
+    const int64_t *__restrict__ task_end, const int32_t *__restrict__ task_slot,
+    const int32_t *__restrict__ indices, const VT *__restrict__ vals, const double *__restrict__ X,
+    int64_t ldx, int nc, double *__restrict__ out, int64_t ldo, double *__restrict__ partial) {
+    const int lane = threadIdx.x & 63;
+    // wave id made provably uniform so the task descriptors live in SGPRs
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t task = (int64_t)blockIdx.x * 4 + wave;
+    if (task >= n_tasks) return;
+    const int64_t p0 = task_begin[task];
+    const int64_t p1 = task_end[task];
+
+    int col[CPL];
+    double acc[CPL];
+#pragma unroll
+    for (int g = 0; g < CPL; ++g) {
+        int c = lane + 64 * g;
+        col[g] = c < nc ? c : nc - 1;  // clamp: out-of-range lanes read a valid column, discard later
+        acc[g] = 0.0;
+    }
+
+    for (int64_t p = p0; p < p1; p += 64) {
+        const int cnt = (int)((p1 - p) < 64 ? (p1 - p) : 64);
+        int j = 0;
+        VT a = (VT)0;
+        if (lane < cnt) {
+            j = indices[p + lane];
+            a = vals[p + lane];
+        }
+        // 8 gathers in flight per wave; lanes >= cnt hold (j = 0, a = 0): the padded steps of the
+        // last chunk add 0 * X[0, :] and need no branch
+        for (int t0 = 0; t0 < cnt; t0 += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = t0 + u;
+                const int jt = __builtin_amdgcn_readlane(j, t);
+                const double at = pk_bcast_val<VT>(a, t);
+                const double *xr = X + (int64_t)jt * ldx;
+#pragma unroll
+                for (int g = 0; g < CPL; ++g) acc[g] = fma(at, xr[col[g]], acc[g]);
+            }
+        }
+    }
+
+    const int slot = task_slot[task];
+    double *dst = slot < 0 ? out + (int64_t)task_row[task] * ldo : partial + (int64_t)slot * nc;
+#pragma unroll
+    for (int g = 0; g < CPL; ++g) {
+        int c = lane + 64 * g;
+        if (c < nc) dst[c] = acc[g];
+    }
+}
+
+// out[row, :] = sum_{s in [slot_begin, slot_end)} partial[s, :]   (fixed order)
+__global__ __launch_bounds__(256) void spmm_fixup_kernel(
+    int64_t n_long, const int32_t *__restrict__ long_row, const int32_t *__restrict__ slot_begin,
+    const int32_t *__restrict__ slot_end, const double *__restrict__ partial, int nc,
+    double *__restrict__ out, int64_t ldo) {
+    const int64_t r = blockIdx.x;
+    if (r >= n_long) return;
+    const int s0 = slot_begin[r], s1 = slot_end[r];
+    for (int c = threadIdx.x; c < nc; c += blockDim.x) {
+        double acc = 0.0;
+        for (int s = s0; s < s1; ++s) acc += partial[(int64_t)s * nc + c];
+        out[(int64_t)long_row[r] * ldo + c] = acc;
+    }
+}
+
+template <typename VT>
+static int launch_spmm(hipStream_t st, int64_t n_tasks, const int32_t *task_row, const int64_t *task_begin,
+                       const int64_t *task_end, const int32_t *task_slot, const int32_t *indices,
+                       const void *vals, const double *X, int64_t ldx, int nc, double *out, int64_t ldo,
+                       double *partial) {
+    dim3 grid((unsigned)pk_ceil_div(n_tasks, 4)), block(256);
+    const VT *v = static_cast<const VT *>(vals);
+    const int cpl = (nc + 63) / 64;
+#define PK_SPMM_CASE(C)                                                                              \
+    case C:                                                                                          \
+        hipLaunchKernelGGL((spmm_csr_kernel<VT, C>), grid, block, 0, st, n_tasks, task_row, task_begin, \
+                           task_end, task_slot, indices, v, X, ldx, nc, out, ldo, partial);          \
+        break;
+    switch (cpl) {
+        PK_SPMM_CASE(1)
+        PK_SPMM_CASE(2)
+        PK_SPMM_CASE(3)
+        PK_SPMM_CASE(4)
+        default:
+            pk_set_error("pk_spmm_csr_f64: nc=%d unsupported (max 256)", nc);
+            return PK_E_UNSUPPORTED;
+    }
+#undef PK_SPMM_CASE
+    return PK_OK;
+}
+
+extern "C" int pk_spmm_csr_f64(void *stream, int64_t n_tasks, const int32_t *task_row_dev,
+                               const int64_t *task_begin_dev, const int64_t *task_end_dev,
+                               const int32_t *task_slot_dev, int64_t n_long, const int32_t *long_row_dev,
+                               const int32_t *long_slot_begin_dev, const int32_t *long_slot_end_dev,
+                               const int32_t *indices_dev, const void *vals_dev, int val_kind,
+                               const double *X_dev, int64_t ldx, int32_t nc, double *out_dev, int64_t ldo,
+                               double *partial_dev) {
+    PK_REQUIRE(n_tasks >= 0 && nc >= 1 && nc <= 256, "pk_spmm_csr_f64: bad sizes n_tasks=%lld nc=%d",
+               (long long)n_tasks, nc);
+    PK_REQUIRE(ldo >= nc, "pk_spmm_csr_f64: ldo < nc");
+    PK_REQUIRE(n_long == 0 || partial_dev != nullptr, "pk_spmm_csr_f64: partial buffer required");
+    if (n_tasks == 0) return PK_OK;
+    hipStream_t st = pk_stream(stream);
+    int rc;
+    if (val_kind == PK_VAL_F32)
+        rc = launch_spmm<float>(st, n_tasks, task_row_dev, task_begin_dev, task_end_dev, task_slot_dev,
+                                indices_dev, vals_dev, X_dev, ldx, nc, out_dev, ldo, partial_dev);
+    else if (val_kind == PK_VAL_F64)
+        rc = launch_spmm<double>(st, n_tasks, task_row_dev, task_begin_dev, task_end_dev, task_slot_dev,
+                                 indices_dev, vals_dev, X_dev, ldx, nc, out_dev, ldo, partial_dev);
+    else {
+        pk_set_error("pk_spmm_csr_f64: bad val_kind %d", val_kind);
+        return PK_E_INVALID;
+    }
+    if (rc != PK_OK) return rc;
+    PK_CHECK_LAUNCH("spmm_csr_kernel");
+    if (n_long > 0) {
+        hipLaunchKernelGGL(spmm_fixup_kernel, dim3((unsigned)n_long), dim3(256), 0, st, n_long, long_row_dev,
+                           long_slot_begin_dev, long_slot_end_dev, partial_dev, nc, out_dev, ldo);
+        PK_CHECK_LAUNCH("spmm_fixup_kernel");
+    }
+    return PK_OK;
+}

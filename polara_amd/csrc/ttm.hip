@@ -1,0 +1,116 @@
+// K5: sparse tensor-times-matrix for HOOI (CoFFee), fp64.
+//
+//   res[i0, j, k] += val * u[i1, j] * v[i2, k]          for every nnz (i0, i1, i2)
+//
+// restates numba `dttm_seq` (lib/sparse.py:203-216) as called from `ttm3d_seq`
+// (lib/tensor.py:7-19).  The host layer sorts the nnz by the output mode once per mode, so the
+// output row of a task is fixed and the r_a x r_b accumulator block of that row lives in
+// registers (lane owns entries lane + 64 g of the flattened [r_a x r_b] block, j = e / r_b,
+// k = e % r_b — the reference's C-order reshape, tensor.py:70,74,78).  Long rows (e.g. the five
+// feedback levels of mode 2, each holding ~nnz/5 entries) are split into tasks with partial
+// blocks that a fix-up pass adds in slot order: deterministic, no atomics.  Latency-bound by
+// nature (0.5 GFLOP on ML-1M): the factor rows u[i1,:], v[i2,:] are tiny and L1/L2 resident.
+#include "pk_common.h"
+
+template <int EPL>
+__global__ __launch_bounds__(256) void ttm_kernel(
+    int64_t n_tasks, const int32_t *__restrict__ task_row, const int64_t *__restrict__ task_begin,
+    const int64_t *__restrict__ task_end, const int32_t *__restrict__ task_slot,
+    const int32_t *__restrict__ idx1, const int32_t *__restrict__ idx2, const double *__restrict__ vals,
+    const double *__restrict__ u, int64_t ldu, int ra, const double *__restrict__ v, int64_t ldv, int rb,
+    double *__restrict__ res, int64_t ldr, double *__restrict__ partial) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t task = (int64_t)blockIdx.x * 4 + wave;
+    if (task >= n_tasks) return;
+    const int64_t p0 = task_begin[task], p1 = task_end[task];
+    const int nout = ra * rb;
+    int jj[EPL], kk[EPL];
+    double acc[EPL];
+#pragma unroll
+    for (int g = 0; g < EPL; ++g) {
+        int e = lane + 64 * g;
+        if (e >= nout) e = nout - 1;
+        jj[g] = e / rb;
+        kk[g] = e % rb;
+        acc[g] = 0.0;
+    }
+    for (int64_t p = p0; p < p1; p += 64) {
+        const int cnt = (int)((p1 - p) < 64 ? (p1 - p) : 64);
+        int a1 = 0, a2 = 0;
+        double av = 0.0;
+        if (lane < cnt) {
+            a1 = idx1[p + lane];
+            a2 = idx2[p + lane];
+            av = vals ? vals[p + lane] : 1.0;
+        }
+        for (int t0 = 0; t0 < cnt; t0 += 4)
+#pragma unroll
+        for (int t = t0; t < t0 + 4; ++t) {  // padded steps use (i1 = 0, i2 = 0, val = 0)
+            const int i1 = __builtin_amdgcn_readlane(a1, t);
+            const int i2 = __builtin_amdgcn_readlane(a2, t);
+            const double vv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(av), t),
+                                               __builtin_amdgcn_readlane(__double2loint(av), t));
+            const double *ur = u + (int64_t)i1 * ldu;
+            const double *vr = v + (int64_t)i2 * ldv;
+#pragma unroll
+            for (int g = 0; g < EPL; ++g) acc[g] = fma(vv * ur[jj[g]], vr[kk[g]], acc[g]);
+        }
+    }
+    const int slot = task_slot[task];
+    double *dst = slot < 0 ? res + (int64_t)task_row[task] * ldr : partial + (int64_t)slot * nout;
+#pragma unroll
+    for (int g = 0; g < EPL; ++g) {
+        const int e = lane + 64 * g;
+        if (e < nout) dst[e] = acc[g];
+    }
+}
+
+__global__ __launch_bounds__(256) void ttm_fixup_kernel(int64_t n_long, const int32_t *__restrict__ long_row,
+                                                        const int32_t *__restrict__ slot_begin,
+                                                        const int32_t *__restrict__ slot_end,
+                                                        const double *__restrict__ partial, int nout,
+                                                        double *__restrict__ res, int64_t ldr) {
+    const int64_t r = blockIdx.x;
+    if (r >= n_long) return;
+    const int s0 = slot_begin[r], s1 = slot_end[r];
+    for (int c = threadIdx.x; c < nout; c += blockDim.x) {
+        double acc = 0.0;
+        for (int s = s0; s < s1; ++s) acc += partial[(int64_t)s * nout + c];
+        res[(int64_t)long_row[r] * ldr + c] = acc;
+    }
+}
+
+extern "C" int pk_ttm_f64(void *stream, int64_t n_tasks, const int32_t *task_row_dev, const int64_t *task_begin_dev,
+                          const int64_t *task_end_dev, const int32_t *task_slot_dev, int64_t n_long,
+                          const int32_t *long_row_dev, const int32_t *long_slot_begin_dev,
+                          const int32_t *long_slot_end_dev, const int32_t *idx1_dev, const int32_t *idx2_dev,
+                          const double *vals_dev, const double *u_dev, int64_t ldu, int32_t ra, const double *v_dev,
+                          int64_t ldv_, int32_t rb, double *res_dev, int64_t ldr, double *partial_dev) {
+    PK_REQUIRE(n_tasks >= 0 && ra >= 1 && rb >= 1 && (int64_t)ra * rb <= 1024,
+               "pk_ttm_f64: need ra*rb <= 1024 (got %d x %d)", ra, rb);
+    PK_REQUIRE(ldu >= ra && ldv_ >= rb && ldr >= (int64_t)ra * rb, "pk_ttm_f64: bad leading dimension");
+    PK_REQUIRE(n_long == 0 || partial_dev != nullptr, "pk_ttm_f64: partial buffer required");
+    if (n_tasks == 0) return PK_OK;
+    hipStream_t st = pk_stream(stream);
+    dim3 grid((unsigned)pk_ceil_div(n_tasks, 4)), block(256);
+    const int nout = ra * rb;
+    const int epl = (nout + 63) / 64;
+#define PK_TTM_LAUNCH(E)                                                                                       \
+    hipLaunchKernelGGL((ttm_kernel<E>), grid, block, 0, st, n_tasks, task_row_dev, task_begin_dev, task_end_dev, \
+                       task_slot_dev, idx1_dev, idx2_dev, vals_dev, u_dev, ldu, ra, v_dev, ldv_, rb, res_dev,  \
+                       ldr, partial_dev)
+    if (epl <= 1) PK_TTM_LAUNCH(1);
+    else if (epl <= 2) PK_TTM_LAUNCH(2);
+    else if (epl <= 4) PK_TTM_LAUNCH(4);
+    else if (epl <= 8) PK_TTM_LAUNCH(8);
+    else PK_TTM_LAUNCH(16);
+#undef PK_TTM_LAUNCH
+    PK_CHECK_LAUNCH("ttm_kernel");
+    if (n_long > 0) {
+        hipLaunchKernelGGL(ttm_fixup_kernel, dim3((unsigned)n_long), dim3(256), 0, st, n_long, long_row_dev,
+                           long_slot_begin_dev, long_slot_end_dev, partial_dev, nout, res_dev, ldr);
+        PK_CHECK_LAUNCH("ttm_fixup_kernel");
+    }
+    return PK_OK;
+}

@@ -1,0 +1,167 @@
+"""ArrayData: the slice of the `RecommenderData` protocol that the factorization-and-scoring hot
+path touches, backed by plain NumPy triplets.
+
+It lets the device models run and be benchmarked where Polara itself (pandas state machine,
+polara/recommender/data.py) is not installed — e.g. the GPU box.  When Polara is present, the same
+model classes accept its `RecommenderData` unchanged, because they only use:
+  fields, subscribe/on_change_event/on_update_event, to_coo, test_to_coo, get_test_shape,
+  warm_start, test_sample, holdout_size, test.testset/test.holdout.
+Semantics restated from data.py:777-884 (threshold_data, to_coo, test_to_coo, get_test_shape).
+"""
+from collections import namedtuple
+from weakref import WeakKeyDictionary
+import numpy as np
+
+Fields = namedtuple('Fields', 'userid itemid feedback')
+TestData = namedtuple('TestData', 'testset holdout')
+Triplets = namedtuple('Triplets', 'userid itemid feedback')
+
+
+class _Notifier:
+    """Weak-reference observer used by RecommenderData (data.py:35-76): callbacks must be bound
+    methods; they are invoked as func(subscriber)."""
+
+    def __init__(self, events):
+        self._subs = {e: WeakKeyDictionary() for e in events}
+
+    def subscribe(self, event, callback):
+        self._subs[event].setdefault(callback.__self__, set()).add(callback.__func__)
+
+    def __call__(self, event):
+        for ref in list(self._subs[event].keyrefs()):
+            sub = ref()
+            if sub is not None:
+                for func in list(self._subs[event].get(sub, ())):
+                    func(sub)
+
+
+class ArrayData:
+    """training: (users, items, feedback) arrays with contiguous 0-based ids.
+    test: triplets of the test users' known interactions, sorted by user (ids are re-based by the
+    model exactly like models.py:244-255), or None when test users are training users
+    (warm_start=False: the testset is recovered from the training rows of the holdout users,
+    data.py:820-832).  holdout: triplets hidden from the model (consumed by evaluation only)."""
+
+    def __init__(self, training, n_users=None, n_items=None, test=None, holdout=None, warm_start=False,
+                 fields=('userid', 'itemid', 'rating'), holdout_size=None):
+        u, i, f = (np.asarray(a) for a in training)
+        self._train = Triplets(u.astype(np.int64), i.astype(np.int64), np.asarray(f, dtype=np.float64))
+        self.n_users = int(n_users if n_users is not None else u.max() + 1)
+        self.n_items = int(n_items if n_items is not None else i.max() + 1)
+        self.fields = Fields(*fields)
+        self.warm_start = bool(warm_start)
+        self.test_sample = None
+        self.holdout_size = holdout_size if holdout_size is not None else (0 if holdout is None else 1)
+        self.on_change_event = 'on_change'
+        self.on_update_event = 'on_update'
+        self._notify = _Notifier([self.on_change_event, self.on_update_event])
+        self._feedback_levels = None
+        self.set_test_data(test, holdout, notify=False)
+
+    # ---- observer protocol (data.py:160-164) ----------------------------------------------------
+    def subscribe(self, event, model_callback):
+        self._notify.subscribe(event, model_callback)
+
+    def update(self):
+        pass
+
+    @property
+    def training(self):
+        return self._train
+
+    @property
+    def test(self):
+        return self._test
+
+    def set_training_data(self, training):
+        u, i, f = (np.asarray(a) for a in training)
+        self._train = Triplets(u.astype(np.int64), i.astype(np.int64), np.asarray(f, dtype=np.float64))
+        self._feedback_levels = None
+        self._notify(self.on_change_event)
+
+    def set_test_data(self, testset=None, holdout=None, notify=True):
+        def norm(t):
+            if t is None:
+                return None
+            u, i, f = (np.asarray(a) for a in t)
+            order = np.argsort(u, kind='stable')  # data.py `_try_sort_test_data`
+            return Triplets(u[order].astype(np.int64), i[order].astype(np.int64),
+                            np.asarray(f, dtype=np.float64)[order])
+        self._test = TestData(norm(testset), norm(holdout))
+        if notify:
+            self._notify(self.on_update_event)
+
+    # ---- the hot-path protocol ----------------------------------------------------------------------
+    @staticmethod
+    def threshold_data(idx, val, threshold, filter_values=True):
+        """data.py:777-791."""
+        if threshold is None:
+            return idx, val
+        keep = val >= threshold
+        if filter_values:
+            val = val[keep]
+            idx = tuple(x[keep] for x in idx) if isinstance(idx, tuple) else idx[keep, :]
+        else:
+            val = val.copy()
+            val[~keep] = 0
+        return idx, val
+
+    def _levels(self):
+        if self._feedback_levels is None:
+            self._feedback_levels = np.unique(self._train.feedback)  # sorted, like reindex(sort=True)
+        return self._feedback_levels
+
+    def to_coo(self, tensor_mode=False, feedback_threshold=None):
+        """data.py:794-817."""
+        u, i, f = self._train
+        if tensor_mode:
+            new_f = np.searchsorted(self._levels(), f)
+            idx = np.stack([u, i, new_f], axis=1)
+            val = np.ones(len(f))
+            shp = (self.n_users, self.n_items, len(self._levels()))
+        else:
+            idx = np.stack([u, i], axis=1)
+            val = f
+            shp = (self.n_users, self.n_items)
+        idx, val = self.threshold_data(idx, val, feedback_threshold)
+        return idx.astype(np.intp), np.ascontiguousarray(val), tuple(int(s) for s in shp)
+
+    def _recover_testset(self):
+        """data.py:820-832: training rows of the holdout users, sorted by user."""
+        users = np.unique(self._test.holdout.userid)
+        u, i, f = self._train
+        if len(users) == self.n_users:
+            sel = slice(None)
+        else:
+            sel = np.isin(u, users)
+        u, i, f = u[sel], i[sel], f[sel]
+        order = np.argsort(u, kind='stable')
+        return Triplets(u[order], i[order], f[order])
+
+    def test_to_coo(self, tensor_mode=False, feedback_threshold=None):
+        """data.py:835-862."""
+        testset = self._test.testset
+        if testset is None:
+            if self.warm_start or self._test.holdout is None:
+                raise ValueError('Unable to read test data')
+            testset = self._recover_testset()
+        u, i, f = testset
+        if tensor_mode:
+            levels = self._levels()
+            pos = np.searchsorted(levels, f)
+            if (pos >= len(levels)).any() or (levels[np.minimum(pos, len(levels) - 1)] != f).any():
+                raise NotImplementedError('Not all values of feedback are present in training data')
+            coo, val = (u, i), pos.astype(np.intp)
+        else:
+            coo, val = (u, i), f
+        coo, val = self.threshold_data(coo, val, feedback_threshold, filter_values=False)
+        return coo + (val,)
+
+    def get_test_shape(self, tensor_mode=False):
+        """data.py:865-884."""
+        src = self._test.holdout if self._test.holdout is not None else self._test.testset
+        num_users = len(np.unique(src.userid))
+        shape = (num_users, self.n_items)
+        if tensor_mode:
+            shape = shape + (len(self._levels()),)
+        return shape

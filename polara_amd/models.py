@@ -1,0 +1,468 @@
+"""Device-backed models behind Polara's `RecommenderModel` plugin surface.
+
+`SVDModel` (PureSVD) and `CoffeeModel` (CoFFee / Tucker) keep the names, constructor, properties,
+`factors` dict layout, cache-invalidation rules and return types of the reference classes
+(polara/recommender/models.py:70-604, 800-861, 901-1054) so they drop into `RecommenderData`
+/ `evaluate()` / `evaluation_engine` unchanged, while `build()` and `get_recommendations()` run on
+the GPU through libpolarahip.so.  There is no CPU path here: constructing the device backend
+without the library or a GPU raises.
+"""
+from timeit import default_timer as timer
+
+import numpy as np
+
+from . import defaults
+from .csr import coo_to_csr, nnz_balanced_row_partition
+from .solver import svd_topk, NoComm
+from . import scoring
+from . import tucker
+
+
+def get_default(name):
+    return defaults.get_config([name])[name]
+
+
+def _format_elapsed(seconds_total):
+    """tools/timing.py:10-17."""
+    minutes, seconds = divmod(seconds_total, 60)
+    hours, minutes = divmod(minutes, 60)
+    if hours == 0:
+        if minutes == 0:
+            return f'{seconds:.3f}s'
+        return f'{minutes:>02.0f}m:{seconds:>02.0f}s'
+    return f'{hours:.0f}h:{minutes:>02.0f}m:{seconds:>02.0f}s'
+
+
+class RecommenderModel:
+    """Base class: configuration, caching and the recommend pipeline (models.py:70-604)."""
+    _config = ('topk', 'filter_seen', 'switch_positive', 'feedback_threshold', 'verify_integrity')
+
+    def __init_subclass__(cls, **kw):
+        # the reference wraps every `build` with cache invalidation through a metaclass
+        # (models.py:34-67); same effect here
+        super().__init_subclass__(**kw)
+        if 'build' in cls.__dict__:
+            raw = cls.__dict__['build']
+
+            def build(self, *args, **kwargs):
+                self._is_ready = False
+                self._recommendations = None
+                res = raw(self, *args, **kwargs)
+                self._is_ready = True
+                return res
+            build.__name__ = 'build'
+            build.__doc__ = raw.__doc__
+            cls.build = build
+
+    def __init__(self, recommender_data, feedback_threshold=None, ops=None, comm=None):
+        self.data = recommender_data
+        self._recommendations = None
+        self.method = 'ABC'
+        self._topk = get_default('topk')
+        self._filter_seen = get_default('filter_seen')
+        self._feedback_threshold = feedback_threshold or get_default('feedback_threshold')
+        self.switch_positive = get_default('switch_positive')
+        self.verify_integrity = get_default('verify_integrity')
+        self.max_test_workers = get_default('max_test_workers')  # accepted, unused: no host chunk loop
+        self._prediction_key = self.data.fields.userid
+        self._prediction_target = self.data.fields.itemid
+        self._is_ready = False
+        self.verbose = True
+        self.training_time = []
+        self.recommend_stats = {}
+        self._ops = ops
+        self.comm = comm or NoComm()
+        self._factor_image = None
+        self.data.subscribe(self.data.on_change_event, self._renew_model)
+        self.data.subscribe(self.data.on_update_event, self._refresh_model)
+
+    # ---- device backend (fails loudly; no CPU fallback) ---------------------------------------------
+    @property
+    def ops(self):
+        if self._ops is None:
+            from .ops import HipOps
+            self._ops = HipOps()
+        return self._ops
+
+    # ---- caching protocol (models.py:99-148) -----------------------------------------------------------
+    @property
+    def recommendations(self):
+        if self._recommendations is None:
+            if not self._is_ready:
+                if self.verbose:
+                    print('{} model is not ready. Rebuilding.'.format(self.method))
+                self.build()
+            self._recommendations = self.get_recommendations()
+        return self._recommendations
+
+    def _renew_model(self):
+        self._recommendations = None
+        self._is_ready = False
+        self._factor_image = None
+
+    def _refresh_model(self):
+        self._recommendations = None
+
+    @property
+    def topk(self):
+        return self._topk
+
+    @topk.setter
+    def topk(self, new_value):
+        if (self._recommendations is not None) and (new_value > self._recommendations.shape[1]):
+            self._recommendations = None
+        self._topk = new_value
+
+    @property
+    def feedback_threshold(self):
+        return self._feedback_threshold
+
+    @feedback_threshold.setter
+    def feedback_threshold(self, new_value):
+        if self._feedback_threshold != new_value:
+            self._feedback_threshold = new_value
+            self._renew_model()
+
+    @property
+    def filter_seen(self):
+        return self._filter_seen
+
+    @filter_seen.setter
+    def filter_seen(self, new_value):
+        if self._filter_seen != new_value:
+            self._filter_seen = new_value
+            self._refresh_model()
+
+    def get_base_configuration(self):
+        return {attr: getattr(self, attr) for attr in self._config}
+
+    def build(self):
+        raise NotImplementedError('This must be implemented in subclasses')
+
+    def _track(self, start):
+        """tools/timing.py:20-34 contract: one entry per build, same message."""
+        elapsed = timer() - start
+        if self.training_time is not None:
+            self.training_time.append(elapsed)
+        if self.verbose:
+            print('{} training time: {}'.format(self.method, _format_elapsed(elapsed)))
+
+    # ---- data access (models.py:160-257) -----------------------------------------------------------------
+    def _training_csr(self, dtype=np.float64, ignore_feedback=False):
+        threshold = self.feedback_threshold
+        idx, val, shp = self.data.to_coo(tensor_mode=False, feedback_threshold=threshold)
+        val = np.ones_like(val, dtype=dtype) if ignore_feedback else np.asarray(val, dtype=dtype)
+        indptr, indices, values = coo_to_csr(idx[:, 0], idx[:, 1], val, shp)
+        return indptr, indices, values, shp
+
+    def get_training_matrix(self, feedback_threshold=None, ignore_feedback=False, sparse_format='csr', dtype=None):
+        """models.py:160-177 (returns a SciPy matrix for API compatibility)."""
+        from scipy.sparse import csr_matrix
+        threshold = feedback_threshold or self.feedback_threshold
+        idx, val, shp = self.data.to_coo(tensor_mode=False, feedback_threshold=threshold)
+        dtype = dtype or val.dtype
+        val = np.ones_like(val, dtype=dtype) if ignore_feedback else val.astype(dtype)
+        indptr, indices, values = coo_to_csr(idx[:, 0], idx[:, 1], val, shp)
+        m = csr_matrix((values, indices, indptr), shape=shp)
+        return m if sparse_format == 'csr' else m.asformat(sparse_format)
+
+    def _tensor_mode(self):
+        try:
+            return self.factors.get(self.data.fields.feedback, None) is not None
+        except AttributeError:
+            return False
+
+    def _get_test_data(self, feedback_threshold=None):
+        """models.py:227-257."""
+        tensor_mode = self._tensor_mode()
+        test_shape = self.data.get_test_shape(tensor_mode=tensor_mode)
+        threshold = feedback_threshold or self.feedback_threshold
+        if self.data.warm_start:
+            if threshold:
+                print('Specifying threshold has no effect in warm start.')
+            threshold = None
+        else:
+            if self.data.test_sample and (threshold is not None):
+                print('Specifying both threshold value and test_sample may change test data.')
+        user_idx, item_idx, feedback = self.data.test_to_coo(tensor_mode=tensor_mode, feedback_threshold=threshold)
+        idx_diff = np.diff(user_idx)
+        assert (idx_diff >= 0).all()  # calculations assume testset is sorted by users!
+        if (idx_diff > 1).any() or (user_idx.min() != 0):
+            test_users = user_idx[np.r_[0, np.where(idx_diff)[0] + 1]]
+            user_idx = np.r_[0, np.cumsum(idx_diff > 0)].astype(user_idx.dtype)
+        else:
+            test_users = np.arange(test_shape[0])
+        return (user_idx, item_idx, feedback), test_shape, test_users
+
+    def verify_data_integrity(self):
+        """models.py:581-604 reduced to the checks that do not need pandas."""
+        itemid, feedback = self.data.fields.itemid, self.data.fields.feedback
+        n_items = self.data.get_test_shape(tensor_mode=False)[1]
+        f = getattr(self, 'factors', {})
+        if f.get(itemid, None) is not None:
+            assert f[itemid].shape[0] == n_items
+        if feedback is not None and f.get(feedback, None) is not None:
+            assert f[feedback].shape[0] == self.data.get_test_shape(tensor_mode=True)[2]
+
+    # ---- recommend pipeline (models.py:359-405) ----------------------------------------------------------
+    def _item_factors_device(self):
+        raise NotImplementedError
+
+    def _test_weights(self, test_data):
+        """Per-entry fold-in coefficients; None = the feedback values themselves."""
+        return None
+
+    def get_recommendations(self):
+        if self.verify_integrity:
+            self.verify_data_integrity()
+        test_data, test_shape, _ = self._get_test_data()
+        n_users, n_items = int(test_shape[0]), int(test_shape[1])
+        indptr, indices, values = scoring.test_csr_from_triplet(test_data, (n_users, n_items),
+                                                                self._test_weights(test_data))
+        ops, comm = self.ops, self.comm
+        lo, hi = 0, n_users
+        if comm.world > 1:  # user-sharded scoring; V is replicated, no collective in the data path
+            bounds = nnz_balanced_row_partition(indptr, comm.world)
+            lo, hi = int(bounds[comm.rank]), int(bounds[comm.rank + 1])
+        sub_ptr = indptr[lo:hi + 1] - indptr[lo]
+        sub = slice(int(indptr[lo]), int(indptr[hi]))
+        stats = {}
+        if hi > lo:
+            T = ops.csr(sub_ptr, indices[sub], values[sub], (hi - lo, n_items))
+            recs = scoring.recommend(ops, self._item_factors_device(), T, self.topk, self.filter_seen, stats=stats)
+            recs = ops.to_host(recs)
+        else:
+            recs = np.empty((0, self.topk), dtype=np.int64)
+        self.recommend_stats = stats
+        if comm.world > 1:
+            recs = comm.gather_rows(recs, n_users, self.topk)
+        return recs
+
+    def slice_recommendations(self, test_data, shape, start, stop, test_users=None):
+        """Dense fp64 scores of test users [start, stop) + the slice triplet (models.py:857-861,
+        1042-1054).  Kept for `_user_scores`/`show_recommendations`-style consumers; computed on
+        device by pk_dense_scores_f64.  `get_recommendations` does NOT go through here."""
+        stop = min(stop, shape[0])
+        users, items, fdbk = test_data
+        sel = (users >= start) & (users < stop)
+        slice_data = (users[sel] - start, items[sel], fdbk[sel])
+        w = self._test_weights(test_data)
+        indptr, indices, values = scoring.test_csr_from_triplet(
+            slice_data, (stop - start, shape[1]), None if w is None else w[sel])
+        T = self.ops.csr(indptr, indices, values, (stop - start, shape[1]))
+        scores = scoring.dense_scores(self.ops, self._item_factors_device(), T, 0, stop - start)
+        return self.ops.to_host(scores), slice_data
+
+    def evaluate(self, *args, **kwargs):
+        """Metrics are a consumer of `recommendations` (models.py:408-485, evaluation.py) and out of
+        this package's scope; with Polara installed, its implementation is used on our results."""
+        try:
+            from polara.recommender.models import RecommenderModel as _Ref
+        except ImportError as e:
+            raise NotImplementedError('evaluate() needs polara (metrics are outside the hot path)') from e
+        return _Ref.evaluate(self, *args, **kwargs)
+
+
+class SVDModel(RecommenderModel):
+    """PureSVD (models.py:800-861)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._rank = defaults.svd_rank
+        self.method = 'PureSVD'
+        self.factors = {}
+        self.svd_tol = defaults.svd_tol
+        self.svd_seed = defaults.svd_seed
+        self.svd_block = defaults.svd_oversample
+        self.build_stats = {}
+
+    @property
+    def rank(self):
+        return self._rank
+
+    @rank.setter
+    def rank(self, new_value):
+        if new_value != self._rank:
+            self._rank = new_value
+            self._check_reduced_rank(new_value)
+            self._recommendations = None
+            self._factor_image = None
+
+    def _check_reduced_rank(self, rank):
+        """models.py:819-832: smaller rank = column prefix of the cached factors, no rebuild."""
+        for entity, factor in self.factors.items():
+            if factor is None:
+                continue
+            if factor.shape[-1] < rank:
+                self._is_ready = False
+                self.factors = dict.fromkeys(self.factors.keys())
+                break
+            else:
+                self.factors = dict(**self.factors)
+                self.factors[entity] = factor[..., :rank]
+
+    def _local_training_shard(self):
+        indptr, indices, values, shp = self._training_csr(dtype=np.float64)
+        comm = self.comm
+        if comm.world > 1:
+            bounds = nnz_balanced_row_partition(indptr, comm.world)
+            lo, hi = int(bounds[comm.rank]), int(bounds[comm.rank + 1])
+            sub = slice(int(indptr[lo]), int(indptr[hi]))
+            return indptr[lo:hi + 1] - indptr[lo], indices[sub], values[sub], (hi - lo, shp[1]), (lo, hi, shp[0])
+        return indptr, indices, values, shp, (0, shp[0], shp[0])
+
+    def build(self, operator=None, return_factors='vh'):
+        """models.py:835-855.  `operator` (HybridSVD's LinearOperator) is outside the device path."""
+        if operator is not None:
+            raise NotImplementedError('build(operator=...) is not supported by the device path yet')
+        indptr, indices, values, shp, (lo, hi, n_users) = self._local_training_shard()
+        ops = self.ops
+        A = ops.csr(indptr, indices, values, shp)
+        want_u = return_factors in (True, 'u')
+        start = timer()
+        U, sigma, V, stats = svd_topk(ops, A, self.rank, block=self.svd_block, tol=self.svd_tol,
+                                      seed=self.svd_seed, comm=self.comm, want_u=want_u,
+                                      verbose=False)
+        ops.synchronize()
+        self._track(start)
+        self.build_stats = stats
+        user_factors = None
+        if want_u:
+            user_factors = ops.to_host(U)
+            if self.comm.world > 1:
+                user_factors = self.comm.gather_rows(user_factors, n_users, self.rank, dtype=np.float64)
+        item_factors = np.asfortranarray(ops.to_host(V)) if return_factors in (True, 'vh') else None
+        self.factors[self.data.fields.userid] = user_factors
+        self.factors[self.data.fields.itemid] = item_factors
+        self.factors['singular_values'] = ops.to_host(sigma)
+        self._factor_image = scoring.FactorImage(ops, V) if item_factors is not None else None
+
+    def _item_factors_device(self):
+        if self._factor_image is None:
+            v = self.factors[self.data.fields.itemid]
+            self._factor_image = scoring.FactorImage(self.ops, self.ops.to_device(np.ascontiguousarray(v)))
+        return self._factor_image
+
+
+def flatten_scores(tensor_scores, flattener=None):
+    """models.py:983-1006 (tiny host glue on r2-length vectors)."""
+    flattener = flattener or slice(None)
+    if isinstance(flattener, str):
+        return getattr(np, flattener)(tensor_scores[..., slice(None)], axis=-1)
+    if isinstance(flattener, int):
+        return tensor_scores[..., flattener]
+    if isinstance(flattener, (list, slice)):
+        return np.sum(tensor_scores[..., flattener], axis=-1)
+    if isinstance(flattener, tuple):
+        slicer, method = flattener
+        return getattr(np, method)(tensor_scores[..., slicer or slice(None)], axis=-1)
+    if callable(flattener):
+        return flattener(tensor_scores)
+    raise ValueError('Unrecognized value for flattener attribute')
+
+
+class CoffeeModel(RecommenderModel):
+    """CoFFee: Tucker/HOOI on the (user, item, feedback) tensor (models.py:901-1054)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._mlrank = defaults.mlrank
+        self.factors = {}
+        self.chunk = defaults.test_chunk_size
+        self.method = 'CoFFee'
+        self._flattener = defaults.flattener
+        self.growth_tol = defaults.growth_tol
+        self.num_iters = defaults.num_iters
+        self.show_output = defaults.show_output
+        self.seed = None
+        self.parallel_ttm = defaults.parallel_ttm  # accepted; the device TTM is always parallel
+        self.core_norm_trace = []
+
+    @property
+    def mlrank(self):
+        return self._mlrank
+
+    @mlrank.setter
+    def mlrank(self, new_value):
+        if new_value != self._mlrank:
+            self._mlrank = new_value
+            self._check_reduced_rank(new_value)
+            self._recommendations = None
+            self._factor_image = None
+
+    @property
+    def flattener(self):
+        return self._flattener
+
+    @flattener.setter
+    def flattener(self, new_value):
+        if new_value != self._flattener:
+            self._flattener = new_value
+            self._recommendations = None
+
+    @staticmethod
+    def round_core(core, mode, rank):
+        """models.py:968-980."""
+        new_dims = [mode] + [m for m in range(core.ndim) if m != mode]
+        mode_dim = core.shape[mode]
+        flat_core = core.transpose(new_dims).reshape((mode_dim, -1), order='F')
+        u, s, vt = np.linalg.svd(flat_core, full_matrices=False)
+        rfactor = u[:, :rank]
+        inv = np.empty(len(new_dims), dtype=np.intp)
+        inv[np.array(new_dims)] = np.arange(len(new_dims))
+        new_core = (np.ascontiguousarray(s[:rank, np.newaxis] * vt[:rank, :])
+                    .reshape(rank, *[core.shape[i] for i in new_dims[1:]], order='F')
+                    .transpose(inv))
+        return rfactor, new_core
+
+    def _check_reduced_rank(self, mlrank):
+        """models.py:949-965."""
+        for mode, entity in enumerate(self.data.fields):
+            factor = self.factors.get(entity, None)
+            if factor is None:
+                continue
+            rank = mlrank[mode]
+            if factor.shape[1] < rank:
+                self._is_ready = False
+                self.factors = {}
+                break
+            elif factor.shape[1] == rank:
+                continue
+            else:
+                self.factors = dict(**self.factors)
+                rfactor, new_core = self.round_core(self.factors['core'], mode, rank)
+                self.factors[entity] = factor.dot(rfactor)
+                self.factors['core'] = new_core
+
+    def build(self):
+        """models.py:1009-1024."""
+        idx, val, shp = self.data.to_coo(tensor_mode=True)
+        ops = self.ops
+        start = timer()
+        u0, u1, u2, core, trace = tucker.hooi(ops, idx, val, shp, self.mlrank, num_iters=self.num_iters,
+                                              growth_tol=self.growth_tol, seed=self.seed,
+                                              verbose=self.show_output)
+        ops.synchronize()
+        self._track(start)
+        self.core_norm_trace = trace
+        userid, itemid, feedback = self.data.fields
+        self.factors[userid] = ops.to_host(u0)
+        self.factors[itemid] = ops.to_host(u1)
+        self.factors[feedback] = ops.to_host(u2)
+        self.factors['core'] = ops.to_host(core)
+        self._factor_image = None
+
+    def _item_factors_device(self):
+        if self._factor_image is None:
+            v = self.factors[self.data.fields.itemid]
+            self._factor_image = scoring.FactorImage(self.ops, self.ops.to_device(np.ascontiguousarray(v)))
+        return self._factor_image
+
+    def _test_weights(self, test_data):
+        """models.py:1042-1054 folded algebraically: the per-nnz outer products,
+        the reduceat over users and the tensordot with the flattened feedback factor collapse to a
+        per-entry coefficient c_f = W[f, :] . flatten(W^T)."""
+        w = self.factors[self.data.fields.feedback]
+        wt_flat = flatten_scores(w.T, self.flattener)
+        coef = w.dot(wt_flat)
+        return coef[np.asarray(test_data[2], dtype=np.intp)]

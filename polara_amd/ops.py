@@ -1,0 +1,261 @@
+"""HipOps: the device operator set the solvers are written against.
+
+Every method enqueues hand-written HIP kernels from libpolarahip.so (through the C ABI in
+include/polara_hip.h) on torch's current HIP stream.  torch is plumbing only: it owns the device
+allocations (tensors), the stream and — in polara_amd.dist — the RCCL communicator.
+There is no CPU implementation in this package: constructing HipOps without the library or
+without a GPU raises.  (tests/ carries a NumPy double of this interface to exercise the
+distributed orchestration on CPU with gloo; it never ships.)
+"""
+import ctypes as C
+import numpy as np
+import torch
+
+from . import _lib
+from .csr import build_row_tasks, csr_transpose, SPLIT_NNZ
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class DeviceCSR:
+    """A CSR matrix resident in HBM together with its row-task plan (and, lazily, its transpose)."""
+
+    def __init__(self, ops, indptr, indices, values, shape, split=SPLIT_NNZ):
+        self.ops = ops
+        self.shape = (int(shape[0]), int(shape[1]))
+        indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+        indices = np.ascontiguousarray(indices, dtype=np.int32)
+        values = np.ascontiguousarray(values)
+        if values.dtype == np.float64:
+            v32 = values.astype(np.float32)
+            if np.array_equal(v32.astype(np.float64), values):
+                values = v32  # ratings are exactly representable: halve the value stream
+        elif values.dtype != np.float32:
+            values = values.astype(np.float64)
+        self.nnz = int(indptr[-1])
+        self._host = (indptr, indices, values)
+        self.val_kind = _lib.PK_VAL_F32 if values.dtype == np.float32 else _lib.PK_VAL_F64
+        dev = ops.device
+        self.indptr = torch.from_numpy(indptr).to(dev)
+        self.indices = torch.from_numpy(indices).to(dev)
+        self.values = torch.from_numpy(values).to(dev)
+        plan = build_row_tasks(indptr, split)
+        self.n_tasks = len(plan['task_row'])
+        self.n_long = len(plan['long_row'])
+        self.n_slots = plan['n_slots']
+        self.plan = {k: torch.from_numpy(v).to(dev) for k, v in plan.items() if isinstance(v, np.ndarray)}
+        self._partial = None
+        self._T = None
+
+    def partial(self, nc):
+        need = self.n_slots * nc
+        if need == 0:
+            return None
+        if self._partial is None or self._partial.numel() < need:
+            self._partial = torch.empty(need, dtype=torch.float64, device=self.ops.device)
+        return self._partial
+
+    @property
+    def T(self):
+        if self._T is None:
+            indptr, indices, values = self._host
+            tp, ti, tv = csr_transpose(indptr, indices, values, self.shape[1])
+            self._T = DeviceCSR(self.ops, tp, ti, tv, (self.shape[1], self.shape[0]))
+            self._T._T = self
+        return self._T
+
+    def drop_host(self):
+        self._host = None
+
+
+class HipOps:
+    name = 'hip'
+
+    def __init__(self, device=None):
+        self.lib = _lib.load()  # raises PolaraHipError if the .so is not built
+        if not torch.cuda.is_available():
+            raise _lib.PolaraHipError('no HIP device visible: polara_amd has no CPU fallback')
+        self.device = torch.device(device if device is not None else 'cuda:%d' % torch.cuda.current_device())
+        self._gram_work = None
+        self._info = torch.zeros(2, dtype=torch.int32, device=self.device)
+
+    # ---- plumbing ---------------------------------------------------------------------------
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def empty(self, *shape, dtype=torch.float64):
+        return torch.empty(*shape, dtype=dtype, device=self.device)
+
+    def zeros(self, *shape, dtype=torch.float64):
+        return torch.zeros(*shape, dtype=dtype, device=self.device)
+
+    def to_device(self, a, dtype=None):
+        t = torch.as_tensor(np.ascontiguousarray(a))
+        if dtype is not None:
+            t = t.to(dtype)
+        return t.to(self.device)
+
+    def to_host(self, t):
+        return t.detach().cpu().numpy()
+
+    def csr(self, indptr, indices, values, shape, split=SPLIT_NNZ):
+        return DeviceCSR(self, indptr, indices, values, shape, split)
+
+    def randn(self, n, m, seed):
+        g = torch.Generator(device='cpu')
+        g.manual_seed(int(seed))
+        return torch.randn(n, m, generator=g, dtype=torch.float64).to(self.device)
+
+    # ---- K1/K4 ------------------------------------------------------------------------------
+    def spmm(self, A, X, out=None):
+        """out[n_rows x nc] = A @ X (fp64).  A: DeviceCSR, X: [n_cols x nc] row-major."""
+        assert X.dtype == torch.float64 and X.stride(-1) == 1 and X.shape[0] == A.shape[1]
+        nc = X.shape[1]
+        if out is None:
+            out = self.empty(A.shape[0], nc)
+        p = A.plan
+        _lib.check(self.lib.pk_spmm_csr_f64(
+            self.stream(), A.n_tasks, _ptr(p['task_row']), _ptr(p['task_begin']), _ptr(p['task_end']),
+            _ptr(p['task_slot']), A.n_long, _ptr(p['long_row']), _ptr(p['long_slot_begin']),
+            _ptr(p['long_slot_end']), _ptr(A.indices), _ptr(A.values), A.val_kind,
+            _ptr(X), X.stride(0), nc, _ptr(out), out.stride(0), _ptr(A.partial(nc))), 'pk_spmm_csr_f64')
+        return out
+
+    # ---- K2 ---------------------------------------------------------------------------------
+    def gram(self, A, B=None):
+        """A^T B  (la x lb), fp64."""
+        B = A if B is None else B
+        n, la = A.shape
+        lb = B.shape[1]
+        need = self.lib.pk_gram_work_bytes(n, la, lb)
+        if self._gram_work is None or self._gram_work.numel() * 8 < need:
+            self._gram_work = self.empty((need + 7) // 8)
+        G = self.empty(la, lb)
+        _lib.check(self.lib.pk_gram_f64(self.stream(), n, la, lb, _ptr(A), A.stride(0), _ptr(B), B.stride(0),
+                                        _ptr(G), G.stride(0), _ptr(self._gram_work)), 'pk_gram_f64')
+        return G
+
+    def tsmm(self, X, Cm, out=None):
+        """X[n x lin] @ C[lin x lout]."""
+        n, lin = X.shape
+        lout = Cm.shape[1]
+        if out is None:
+            out = self.empty(n, lout)
+        _lib.check(self.lib.pk_tsmm_f64(self.stream(), n, lin, lout, _ptr(X), X.stride(0), _ptr(Cm), Cm.stride(0),
+                                        _ptr(out), out.stride(0)), 'pk_tsmm_f64')
+        return out
+
+    def eigh_psd(self, S, max_sweeps=0, tol=0.0):
+        """Symmetric PSD S (l x l) -> (evals desc [l], evecs [l x l] with COLUMN j = j-th eigenvector)."""
+        n = S.shape[0]
+        W = S.clone().contiguous()
+        R = self.empty(n, n)
+        lam = self.empty(n)
+        _lib.check(self.lib.pk_eigh_psd_f64(self.stream(), n, _ptr(W), n, _ptr(R), n, _ptr(lam), max_sweeps, tol,
+                                            _ptr(self._info)), 'pk_eigh_psd_f64')
+        return lam, R.t()  # rows of R are eigenvectors -> return as columns (a view; strides swapped)
+
+    def axpbypcz(self, alpha, Z, beta=0.0, Y=None, gamma=0.0, X=None, out=None):
+        assert Z.is_contiguous() and (Y is None or Y.is_contiguous()) and (X is None or X.is_contiguous())
+        if out is None:
+            out = torch.empty_like(Z)
+        _lib.check(self.lib.pk_axpbypcz_f64(self.stream(), Z.numel(), float(alpha), _ptr(Z), float(beta), _ptr(Y),
+                                            float(gamma), _ptr(X), _ptr(out)), 'pk_axpbypcz_f64')
+        return out
+
+    def resid_colnorm2(self, Z, X, theta):
+        """sum_i (Z[i,j] - theta[j] X[i,j])^2 per column -> [l] (device tensor)."""
+        n, l = Z.shape
+        nb = self.lib.pk_resid_blocks(n)
+        part = self.empty(nb, l)
+        _lib.check(self.lib.pk_resid_colnorm2_f64(self.stream(), n, l, _ptr(Z), Z.stride(0), _ptr(X), X.stride(0),
+                                                  _ptr(theta), _ptr(part)), 'pk_resid_colnorm2_f64')
+        return part.sum(dim=0)
+
+    def small_mm(self, A, B, transA=False, transB=False):
+        A = A.contiguous()
+        B = B.contiguous()
+        M = A.shape[1] if transA else A.shape[0]
+        K = A.shape[0] if transA else A.shape[1]
+        N = B.shape[0] if transB else B.shape[1]
+        out = self.empty(M, N)
+        _lib.check(self.lib.pk_dgemm_small_f64(self.stream(), int(transA), int(transB), M, N, K, _ptr(A),
+                                               A.stride(0), _ptr(B), B.stride(0), _ptr(out), out.stride(0)),
+                   'pk_dgemm_small_f64')
+        return out
+
+    def scale_cols(self, X, s):
+        _lib.check(self.lib.pk_scale_cols_f64(self.stream(), X.shape[0], X.shape[1], _ptr(X), X.stride(0),
+                                              _ptr(s.contiguous())), 'pk_scale_cols_f64')
+        return X
+
+    # ---- K3 ---------------------------------------------------------------------------------
+    def pack_frag(self, M):
+        """f64 [n x K] -> packed f32 MFMA fragments (see csrc/score.hip)."""
+        n, K = M.shape
+        out = torch.empty(self.lib.pk_pack_elems(n, K), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.pk_pack_frag_f32(self.stream(), n, K, _ptr(M), M.stride(0), _ptr(out)),
+                   'pk_pack_frag_f32')
+        return out
+
+    def candidate_capacity(self, topk):
+        return self.lib.pk_candidate_capacity(topk)
+
+    def score_candidates(self, Vp, Ep, n_users, n_items, K, seen_ptr, seen_idx, KC):
+        n_pad = -(-n_users // 32) * 32
+        cs = torch.empty(n_pad * KC, dtype=torch.float32, device=self.device)
+        ci = torch.empty(n_pad * KC, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.pk_score_candidates_f32(self.stream(), n_users, n_items, K, _ptr(Vp), _ptr(Ep),
+                                                    _ptr(seen_ptr), _ptr(seen_idx), KC, _ptr(cs), _ptr(ci)),
+                   'pk_score_candidates_f32')
+        return cs, ci
+
+    def rescore_topk(self, V, E, n_items, seen_ptr, KC, cs, ci, topk, vmax, want_scores=True):
+        n_users, K = E.shape
+        out_idx = torch.empty(n_users, topk, dtype=torch.int64, device=self.device)
+        out_s = self.empty(n_users, topk) if want_scores else None
+        flags = torch.empty(n_users, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.pk_rescore_topk_f64(self.stream(), n_users, n_items, K, _ptr(V), V.stride(0), _ptr(E),
+                                                E.stride(0), _ptr(seen_ptr), KC, _ptr(cs), _ptr(ci), topk,
+                                                float(vmax), _ptr(out_idx), _ptr(out_s), _ptr(flags)),
+                   'pk_rescore_topk_f64')
+        return out_idx, out_s, flags
+
+    def score_exact_rows(self, rows, V, E, n_items, seen_ptr, seen_idx, topk):
+        n_rows = rows.numel()
+        K = E.shape[1]
+        out_idx = torch.empty(n_rows, topk, dtype=torch.int64, device=self.device)
+        out_s = self.empty(n_rows, topk)
+        work = torch.empty(self.lib.pk_exact_work_bytes(n_rows, n_items), dtype=torch.uint8, device=self.device)
+        _lib.check(self.lib.pk_score_exact_rows_f64(self.stream(), n_rows, _ptr(rows), n_items, K, _ptr(V),
+                                                    V.stride(0), _ptr(E), E.stride(0), _ptr(seen_ptr),
+                                                    _ptr(seen_idx), topk, _ptr(out_idx), _ptr(out_s), _ptr(work)),
+                   'pk_score_exact_rows_f64')
+        return out_idx, out_s
+
+    def dense_scores(self, V, E):
+        n_rows, K = E.shape
+        n_items = V.shape[0]
+        out = self.empty(n_rows, n_items)
+        _lib.check(self.lib.pk_dense_scores_f64(self.stream(), n_rows, n_items, K, _ptr(V), V.stride(0), _ptr(E),
+                                                E.stride(0), _ptr(out), out.stride(0)), 'pk_dense_scores_f64')
+        return out
+
+    # ---- K5 ---------------------------------------------------------------------------------
+    def ttm(self, plan, idx1, idx2, vals, u, v, n0):
+        """res[n0 x (ra*rb)] of the sorted-by-mode0 tensor described by `plan` (see tucker.py)."""
+        ra, rb = u.shape[1], v.shape[1]
+        res = self.empty(n0, ra * rb)
+        partial = self.empty(plan['n_slots'] * ra * rb) if plan['n_slots'] else None
+        _lib.check(self.lib.pk_ttm_f64(
+            self.stream(), plan['n_tasks'], _ptr(plan['task_row']), _ptr(plan['task_begin']),
+            _ptr(plan['task_end']), _ptr(plan['task_slot']), plan['n_long'], _ptr(plan['long_row']),
+            _ptr(plan['long_slot_begin']), _ptr(plan['long_slot_end']), _ptr(idx1), _ptr(idx2), _ptr(vals),
+            _ptr(u), u.stride(0), ra, _ptr(v), v.stride(0), rb, _ptr(res), res.stride(0), _ptr(partial)),
+            'pk_ttm_f64')
+        return res
+
+    def synchronize(self):
+        torch.cuda.synchronize(self.device)

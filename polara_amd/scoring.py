@@ -1,0 +1,81 @@
+"""Recommendation pipeline on device: fold-in -> fused MFMA scoring/masking/top-k candidates ->
+exact fp64 re-scoring -> (rare) exact rows.  Replaces the chunk loop of
+`RecommenderModel.get_recommendations` (models.py:391-405) and `_slice_recommender`
+(models.py:359-371); no `[chunk x n_items]` score matrix is ever materialised, so there is no
+chunking by host memory (utils.py:16-53) either.
+
+Inputs follow the reference's protocol: the test triplet of `_get_test_data` (models.py:227-257)
+turned into ONE canonical CSR whose explicit zeros are kept — zero-feedback entries contribute
+nothing to the fold-in (the reference drops them from `test_matrix`, models.py:198-203) but still
+count as seen (they stay in `slice_data`, models.py:494-519).
+"""
+import numpy as np
+import torch
+
+from .csr import coo_to_csr
+
+EXACT_ROWS_BYTES = 2 << 30  # work-buffer budget per launch of the exact path
+
+
+class FactorImage:
+    """Item factors resident in HBM in both forms the scoring kernels read: fp64 row-major
+    (re-scoring, fold-in) and fp32 MFMA-fragment packed (candidate pass)."""
+
+    def __init__(self, ops, V):
+        self.ops = ops
+        self.V = V.contiguous()
+        self.n_items, self.K = self.V.shape
+        self.Vp = ops.pack_frag(self.V)
+        self.vmax = float(torch.linalg.vector_norm(self.V, dim=1).max().item())
+
+
+def test_csr_from_triplet(test_data, shape, weights=None):
+    """(user_idx, item_idx, feedback) sorted by user -> canonical CSR arrays keeping zeros.
+    `weights`, if given, replaces the feedback values (CoFFee's per-entry coefficient)."""
+    users, items, fdbk = test_data
+    vals = np.asarray(fdbk if weights is None else weights, dtype=np.float64)
+    return coo_to_csr(users, items, vals, shape, sum_duplicates=True)
+
+
+def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stats=None):
+    """factors: FactorImage; T: ops-level CSR of the test users [n_users x n_items].
+    Returns int64 device tensor [n_users x topk] (+ fp64 scores), rows in test-user order,
+    columns by descending score — the contract of models.py:400-405."""
+    n_users, n_items = T.shape
+    if n_items != factors.n_items:
+        raise ValueError('test matrix and item factors disagree on the number of items')
+    if topk > n_items:
+        raise ValueError('kth(=%d) out of bounds (%d)' % (n_items - topk, n_items))  # numpy argpartition's error
+    KC = ops.candidate_capacity(topk)
+    if KC == 0:
+        raise NotImplementedError('topk=%d: the fused kernel supports topk <= 52' % topk)
+    K = factors.K
+    E = ops.spmm(T, factors.V)                       # fold-in, fp64 (K4)
+    Ep = ops.pack_frag(E)
+    seen_ptr = T.indptr if filter_seen else None
+    seen_idx = T.indices if filter_seen else None
+    cs, ci = ops.score_candidates(factors.Vp, Ep, n_users, n_items, K, seen_ptr, seen_idx, KC)   # K3
+    out_idx, out_s, flags = ops.rescore_topk(factors.V, E, n_items, seen_ptr, KC, cs, ci, topk,
+                                             factors.vmax, want_scores=True)
+    rows = torch.nonzero(flags, as_tuple=False).flatten().to(torch.int32)
+    n_flag = int(rows.numel())
+    if stats is not None:
+        stats['flagged_users'] = n_flag
+        stats['candidate_capacity'] = KC
+    if n_flag:
+        per = max(1, int(EXACT_ROWS_BYTES // (n_items * 9 + 16)))
+        for s in range(0, n_flag, per):
+            sub = rows[s:s + per].contiguous()
+            ex_idx, ex_s = ops.score_exact_rows(sub, factors.V, E, n_items, seen_ptr, seen_idx, topk)
+            out_idx[sub.long()] = ex_idx
+            out_s[sub.long()] = ex_s
+    if return_scores:
+        return out_idx, out_s
+    return out_idx
+
+
+def dense_scores(ops, factors, T, start, stop):
+    """Dense fp64 scores of test users [start, stop) — kept for `slice_recommendations` /
+    `_user_scores` (models.py:277-291, 857-861); not used by get_recommendations."""
+    E = ops.spmm(T, factors.V)
+    return ops.dense_scores(factors.V, E[start:stop].contiguous())

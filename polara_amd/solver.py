@@ -1,0 +1,195 @@
+"""Top-k singular triplets of a (row-sharded) sparse matrix: Chebyshev-filtered subspace iteration
+with locking + projector deflation on the item-side Gramian B = A^T A.
+
+This is the MI355X replacement for the `scipy.sparse.linalg.svds(A, k=rank)` call of
+`SVDModel.build` (models.py:841-844).  The reference's ARPACK runs a single-vector implicitly
+restarted Lanczos on the same operator (n_users >= n_items branch: XH_X = A^T(A x)) with tol=0,
+i.e. to machine precision; one Lanczos step = 2 single-threaded CSR mat-vecs.  On a GPU the CSR
+stream costs the same for 1 or 64 right-hand sides, so the natural shape is a BLOCK method whose
+only heavy operation is the Gramian step  Z = A^T (A Q)  (two SpMM launches, K1) and whose dense
+side (Gram matrices, l x l Jacobi eigh, tall-skinny GEMMs, K2) is O(n l^2).
+
+Algorithm (all fp64; results match ARPACK's to ~1e-10 in the projector, far inside the 1e-4
+contract, because both are converged to their respective floors):
+  X0 = orth(randn(n_items, l)),  l = k + oversample
+  repeat:
+    Rayleigh-Ritz on the active block:  Y = A X, H = Y^T Y (all-reduce), H = C Theta C^T,
+        X <- X C, Y <- Y C, Z = A^T Y (all-reduce)  [= B X, also the first filter step]
+    residuals r_j = ||Z_j - theta_j X_j||; lock the leading converged columns
+    Chebyshev filter of degree m on the deflated operator P B P, P = I - V_lock V_lock^T,
+        damping [0, theta_min(active)]; m chosen so the amplification spread inside the active
+        block stays below `spread` (keeps the block numerically full-rank)
+    X <- orth(P X)
+Multi-GPU: A is row-sharded; X, Z, V_lock are replicated; the only collectives are the sum
+all-reduces of H (l x l) and Z (n_items x l_active) — SURVEY.md §8(e).  Every rank takes the same
+control decisions because they derive from all-reduced data and deterministic kernels.
+"""
+import math
+import numpy as np
+import torch
+
+
+class NoComm:
+    """Single-process stand-in for the communicator interface (rank, world, allreduce)."""
+    rank = 0
+    world = 1
+
+    def allreduce(self, t):
+        return t
+
+
+def default_block(k, n_items):
+    over = max(14, int(math.ceil(0.28 * k)))
+    l = k + over
+    l = -(-l // 8) * 8
+    return int(min(l, n_items))
+
+
+def _project_out(ops, X, V):
+    """X - V (V^T X)."""
+    G = ops.gram(V, X)
+    return ops.axpbypcz(1.0, X, -1.0, ops.tsmm(V, G))
+
+
+def orthonormalize(ops, X, V_lock=None, passes=2):
+    """Orthonormal basis of span(X) (and orthogonal to V_lock) by eigen-whitening, twice."""
+    for _ in range(passes):
+        if V_lock is not None and V_lock.shape[1] > 0:
+            X = _project_out(ops, X, V_lock)
+        G = ops.gram(X)
+        lam, Cm = ops.eigh_psd(G)
+        s = torch.rsqrt(torch.clamp_min(lam, float(1e-300)).clamp_min(lam[0] * 1e-30))
+        Cs = ops.scale_cols(Cm.contiguous(), s)
+        X = ops.tsmm(X, Cs)
+    return X
+
+
+def _cheb_degree(theta_top, b, spread, m_max):
+    """Largest degree whose amplification T_m(x_top) of the top active Ritz value (relative to the
+    edge b of the damped interval [0, b], where T_m = 1) stays below `spread`."""
+    if b <= 0.0:
+        return 2
+    x_top = 2.0 * theta_top / b - 1.0
+    if x_top <= 1.0 + 1e-12:
+        return m_max
+    m = int(math.log(2.0 * spread) / math.acosh(x_top))
+    return max(2, min(m_max, m))
+
+
+def svd_topk(ops, A, k, block=None, tol=1e-12, max_outer=200, m_max=24, spread=1e7, seed=0,
+             comm=None, want_u=False, verbose=False):
+    """Returns (U_local | None, sigma[k] desc, V [n_items x k], stats) as device tensors of `ops`.
+
+    A: ops-level CSR of the LOCAL row shard (n_local x n_items).  Convergence: every one of the k
+    leading Ritz pairs has ||B x - theta x|| <= tol * theta_1  (B = A^T A, theta = sigma^2).
+    """
+    comm = comm or NoComm()
+    n_items = A.shape[1]
+    if not (0 < k <= n_items):
+        raise ValueError('k must satisfy 0 < k <= n_items')
+    l = int(block or default_block(k, n_items))
+    l = max(k, min(l, n_items))
+    At = A.T
+
+    X = orthonormalize(ops, ops.randn(n_items, l, seed))
+    V_lock = None
+    lam_lock = []
+    n_lock = 0
+    stats = dict(outer=0, gramian_steps=0, spmm_cols=0, degrees=[], locked_at=[], block=l, converged=False)
+    theta_host = res_host = None
+
+    def gramian(Xb):
+        Y = ops.spmm(A, Xb)
+        Z = comm.allreduce(ops.spmm(At, Y))
+        stats['gramian_steps'] += 1
+        stats['spmm_cols'] += Xb.shape[1]
+        return Z
+
+    for it in range(max_outer):
+        stats['outer'] = it + 1
+        # ---- Rayleigh-Ritz on the active block ------------------------------------------------
+        Y = ops.spmm(A, X)
+        H = comm.allreduce(ops.gram(Y))
+        theta, Cm = ops.eigh_psd(H)
+        Cm = Cm.contiguous()
+        X = ops.tsmm(X, Cm)
+        Y = ops.tsmm(Y, Cm)
+        Z = comm.allreduce(ops.spmm(At, Y))
+        stats['gramian_steps'] += 1
+        stats['spmm_cols'] += X.shape[1]
+        res2 = ops.resid_colnorm2(Z, X, theta)
+        theta_host = ops.to_host(theta).astype(np.float64)
+        res_host = np.sqrt(np.maximum(ops.to_host(res2), 0.0))
+        lam1 = lam_lock[0] if lam_lock else float(theta_host[0])
+        need = k - n_lock
+        # lock the leading run of converged columns (never more than still needed + a few guards)
+        thr = tol * lam1
+        n_new = 0
+        while n_new < len(res_host) and res_host[n_new] <= thr:
+            n_new += 1
+        if verbose and comm.rank == 0:
+            worst = float(res_host[:max(need, 1)].max() / lam1) if need > 0 else 0.0
+            print('[svd] it %3d lock %3d+%-3d active %3d  worst rel.res(first %d) %.2e' %
+                  (it, n_lock, n_new, X.shape[1], need, worst))
+        if n_new >= need:
+            # done: assemble the k leading vectors
+            take = need
+            Vk = X[:, :take] if V_lock is None else torch.cat([V_lock, X[:, :take]], dim=1)
+            lam_k = np.r_[np.asarray(lam_lock, dtype=np.float64), theta_host[:take]]
+            stats['converged'] = True
+            break
+        if n_new > 0 and X.shape[1] - n_new >= max(8, need - n_new):
+            newV = X[:, :n_new].contiguous()
+            V_lock = newV if V_lock is None else torch.cat([V_lock, newV], dim=1).contiguous()
+            lam_lock.extend(float(t) for t in theta_host[:n_new])
+            n_lock += n_new
+            stats['locked_at'].append((it, n_lock))
+            X = X[:, n_new:].contiguous()
+            Z = Z[:, n_new:].contiguous()
+            theta_host = theta_host[n_new:]
+        # ---- Chebyshev filter on P B P, damping [0, b] --------------------------------------------
+        b = float(theta_host[-1])
+        a0 = float(theta_host[0])
+        m = _cheb_degree(a0, b, spread, m_max)
+        stats['degrees'].append(m)
+        e = 0.5 * b
+        c = 0.5 * b
+        if e <= 0.0 or a0 <= c:
+            # degenerate spectrum estimate (e.g. numerically rank-deficient block): plain power step
+            Yc = Z if V_lock is None else _project_out(ops, Z, V_lock)
+        else:
+            sigma = e / (a0 - c)
+            tau = 2.0 / sigma
+            Zp = Z if V_lock is None else _project_out(ops, Z, V_lock)
+            Xc = X
+            Yc = ops.axpbypcz(sigma / e, Zp, -c * sigma / e, Xc)
+            for _ in range(2, m + 1):
+                sigma_new = 1.0 / (tau - sigma)
+                Zc = gramian(Yc)
+                if V_lock is not None:
+                    Zc = _project_out(ops, Zc, V_lock)
+                Yn = ops.axpbypcz(2.0 * sigma_new / e, Zc, -2.0 * sigma_new * c / e, Yc,
+                                  -sigma * sigma_new, Xc)
+                Xc, Yc = Yc, Yn
+                sigma = sigma_new
+        X = orthonormalize(ops, Yc, V_lock)
+    else:
+        # not converged: return the best available (flagged in stats)
+        take = min(k - n_lock, X.shape[1])
+        Vk = X[:, :take] if V_lock is None else torch.cat([V_lock, X[:, :take]], dim=1)
+        lam_k = np.r_[np.asarray(lam_lock, dtype=np.float64), theta_host[:take]]
+
+    Vk = Vk[:, :k].contiguous()
+    lam_k = np.maximum(lam_k[:k], 0.0)
+    order = np.argsort(-lam_k, kind='stable')
+    if not np.array_equal(order, np.arange(len(order))):
+        Vk = Vk[:, torch.as_tensor(order, device=Vk.device)].contiguous()
+        lam_k = lam_k[order]
+    sigma_k = np.sqrt(lam_k)
+    stats['final_rel_residual'] = float(res_host.max() / max(lam_k[0], 1e-300)) if stats['converged'] else None
+    U = None
+    if want_u:
+        U = ops.spmm(A, Vk)
+        inv = ops.to_device(np.where(sigma_k > 0, 1.0 / np.maximum(sigma_k, 1e-300), 0.0))
+        U = ops.scale_cols(U, inv)
+    return U, ops.to_device(sigma_k), Vk, stats

@@ -1,0 +1,55 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'tests')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name + '.npz'))
+
+
+@pytest.fixture(scope='session')
+def hip_ops():
+    """The product backend.  Fails (does not skip) when the library or the GPU is missing:
+    a -m gpu run that silently fell back to anything else would prove nothing."""
+    from polara_amd.ops import HipOps
+    return HipOps()
+
+
+class GoldenData:
+    """Feeds a model the exact COO triplets the reference model saw when the fixture was made."""
+
+    def __new__(cls, g):
+        from polara_amd.data import ArrayData
+
+        class _GD(ArrayData):
+            def __init__(self, g):
+                self.g = g
+                idx = g['train_idx']
+                shp = tuple(int(x) for x in g['train_shape'])
+                super().__init__((idx[:, 0], idx[:, 1], g['train_val']), n_users=shp[0], n_items=shp[1])
+
+            def to_coo(self, tensor_mode=False, feedback_threshold=None):
+                g = self.g
+                return g['train_idx'].astype(np.intp), g['train_val'], tuple(int(x) for x in g['train_shape'])
+
+            def test_to_coo(self, tensor_mode=False, feedback_threshold=None):
+                g = self.g
+                return (g['test_user'], g['test_item'], g['test_fdbk'])
+
+            def get_test_shape(self, tensor_mode=False):
+                s = tuple(int(x) for x in self.g['test_shape'])
+                return s if tensor_mode else s[:2]
+        return _GD(g)

@@ -1,0 +1,46 @@
+"""Worker for the world_size-2 gloo test (launched by torch.distributed.run).  Uses the TEST-ONLY
+NumPy double of the device ops: what is under test is the sharding + all-reduce orchestration."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+import numpy as np
+
+from conftest import load_golden, GoldenData
+from numpy_ops import NumpyOps
+from polara_amd.dist import init_from_env
+from polara_amd.models import SVDModel
+
+
+def main():
+    comm = init_from_env(backend='gloo')
+    out = {}
+    for name in ('svd_warm', 'svd_known'):
+        g = load_golden(name)
+        m = SVDModel(GoldenData(g), ops=NumpyOps(), comm=comm)
+        m.verbose = False
+        m.rank, m.topk, m.filter_seen = int(g['rank']), int(g['topk']), bool(g['filter_seen'])
+        m.build(return_factors=True)
+        recs = m.get_recommendations()
+        notie = g['boundary_gap'] > 0
+        U = m.factors[m.data.fields.userid]
+        V = m.factors[m.data.fields.itemid]
+        ok = (np.array_equal(recs[notie], g['recs'][notie])
+              and np.allclose(m.factors['singular_values'], g['sigma'], rtol=1e-9)
+              and U.shape == (int(g['train_shape'][0]), int(g['rank']))
+              and np.allclose(U.T @ U, np.eye(U.shape[1]), atol=1e-8)
+              and np.allclose(V @ V.T, g['V'] @ g['V'].T, atol=1e-8))
+        out[name] = bool(ok)
+        out[name + '_allreduces'] = comm.n_allreduce
+    comm.barrier()
+    if comm.rank == 0:
+        print('DIST_RESULT', out)
+    assert all(v for k, v in out.items() if not k.endswith('_allreduces')), out
+    assert comm.world == 2 and comm.n_allreduce > 0
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,184 @@
+"""TEST-ONLY NumPy/SciPy double of polara_amd.ops.HipOps (same method names and semantics on CPU
+torch tensors).  It exists so the solver / scoring / distributed ORCHESTRATION code — which is
+backend-agnostic — can be exercised in the GPU-less container (incl. world_size-2 gloo runs).
+It is never imported by the package; on a GPU the product path is HipOps and nothing else.
+"""
+import numpy as np
+import scipy.sparse as sps
+import torch
+
+from polara_amd.csr import csr_transpose
+
+
+class NpCSR:
+    def __init__(self, indptr, indices, values, shape):
+        self.shape = (int(shape[0]), int(shape[1]))
+        self.m = sps.csr_matrix((np.asarray(values, dtype=np.float64), indices, indptr), shape=self.shape)
+        self.nnz = self.m.nnz
+        self.indptr = torch.from_numpy(np.asarray(indptr, dtype=np.int64))
+        self.indices = torch.from_numpy(np.asarray(indices, dtype=np.int32))
+        self._T = None
+
+    @property
+    def T(self):
+        if self._T is None:
+            t = self.m.T.tocsr()
+            t.sort_indices()
+            self._T = NpCSR(t.indptr, t.indices, t.data, t.shape)
+            self._T._T = self
+        return self._T
+
+
+class NumpyOps:
+    name = 'numpy-test-double'
+    device = torch.device('cpu')
+
+    def empty(self, *shape, dtype=torch.float64):
+        return torch.empty(*shape, dtype=dtype)
+
+    def zeros(self, *shape, dtype=torch.float64):
+        return torch.zeros(*shape, dtype=dtype)
+
+    def to_device(self, a, dtype=None):
+        t = torch.as_tensor(np.ascontiguousarray(a))
+        return t.to(dtype) if dtype is not None else t
+
+    def to_host(self, t):
+        return t.detach().numpy()
+
+    def csr(self, indptr, indices, values, shape, split=None):
+        return NpCSR(indptr, indices, values, shape)
+
+    def randn(self, n, m, seed):
+        g = torch.Generator(device='cpu')
+        g.manual_seed(int(seed))
+        return torch.randn(n, m, generator=g, dtype=torch.float64)
+
+    def spmm(self, A, X, out=None):
+        r = torch.from_numpy(np.ascontiguousarray(A.m @ X.numpy()))
+        if out is not None:
+            out.copy_(r)
+            return out
+        return r
+
+    def gram(self, A, B=None):
+        B = A if B is None else B
+        return A.t() @ B
+
+    def tsmm(self, X, Cm, out=None):
+        return (X @ Cm).contiguous()
+
+    def eigh_psd(self, S, max_sweeps=0, tol=0.0):
+        w, v = np.linalg.eigh(S.numpy())
+        w = np.maximum(w[::-1], 0.0).copy()
+        v = v[:, ::-1].copy()
+        return torch.from_numpy(w), torch.from_numpy(v)
+
+    def axpbypcz(self, alpha, Z, beta=0.0, Y=None, gamma=0.0, X=None, out=None):
+        r = alpha * Z
+        if Y is not None:
+            r = r + beta * Y
+        if X is not None:
+            r = r + gamma * X
+        return r
+
+    def resid_colnorm2(self, Z, X, theta):
+        return ((Z - X * theta[None, :]) ** 2).sum(dim=0)
+
+    def small_mm(self, A, B, transA=False, transB=False):
+        return ((A.t() if transA else A) @ (B.t() if transB else B)).contiguous()
+
+    def scale_cols(self, X, s):
+        X.mul_(s[None, :])
+        return X
+
+    def synchronize(self):
+        pass
+
+    # ---- K5 double ------------------------------------------------------------------------------
+    def ttm(self, plan, idx1, idx2, vals, u, v, n0):
+        # plan carries the row of every task; rebuild the per-nnz output row from task ranges
+        i1 = idx1.numpy().astype(np.int64)
+        i2 = idx2.numpy().astype(np.int64)
+        nnz = len(i1)
+        rows = np.empty(nnz, dtype=np.int64)
+        tr = plan['task_row'].numpy()
+        tb = plan['task_begin'].numpy()
+        te = plan['task_end'].numpy()
+        for r, b, e in zip(tr, tb, te):
+            rows[b:e] = r
+        vv = np.ones(nnz) if vals is None else vals.numpy()
+        contrib = (vv[:, None] * u.numpy()[i1, :])[:, :, None] * v.numpy()[i2, :][:, None, :]
+        res = np.zeros((n0, u.shape[1], v.shape[1]))
+        np.add.at(res, rows, contrib)
+        return torch.from_numpy(res.reshape(n0, -1))
+
+    # ---- K3 doubles -------------------------------------------------------------------------------
+    def candidate_capacity(self, topk):
+        if topk < 1:
+            return 0
+        return 16 if topk <= 10 else 32 if topk <= 24 else 64 if topk <= 52 else 0
+
+    def pack_frag(self, M):
+        return M.to(torch.float32)
+
+    def score_candidates(self, Vp, Ep, n_users, n_items, K, seen_ptr, seen_idx, KC):
+        s = (Ep.numpy() @ Vp.numpy().T).astype(np.float32)
+        if seen_ptr is not None:
+            sp = seen_ptr.numpy()
+            si = seen_idx.numpy()
+            for u in range(n_users):
+                s[u, si[sp[u]:sp[u + 1]]] = -np.inf
+        n_pad = -(-n_users // 32) * 32
+        cs = np.full((n_pad, KC), -np.inf, dtype=np.float32)
+        ci = np.full((n_pad, KC), -1, dtype=np.int32)
+        kk = min(KC, n_items)
+        for u in range(n_users):
+            order = np.lexsort((np.arange(n_items), -s[u]))[:kk]
+            ok = np.isfinite(s[u, order])
+            cs[u, :ok.sum()] = s[u, order][ok]
+            ci[u, :ok.sum()] = order[ok]
+        return torch.from_numpy(cs.ravel()), torch.from_numpy(ci.ravel())
+
+    def rescore_topk(self, V, E, n_items, seen_ptr, KC, cs, ci, topk, vmax, want_scores=True):
+        n_users, K = E.shape
+        Vn, En = V.numpy(), E.numpy()
+        cs = cs.numpy().reshape(-1, KC)
+        ci = ci.numpy().reshape(-1, KC)
+        out_idx = np.full((n_users, topk), -1, dtype=np.int64)
+        out_s = np.full((n_users, topk), -np.inf)
+        flags = np.zeros(n_users, dtype=np.int32)
+        for u in range(n_users):
+            valid = ci[u] >= 0
+            idx = ci[u][valid]
+            s = Vn[idx] @ En[u]
+            order = np.lexsort((idx, -s))
+            idx, s = idx[order], s[order]
+            n = min(topk, len(idx))
+            out_idx[u, :n] = idx[:n]
+            out_s[u, :n] = s[:n]
+            n_seen = int(seen_ptr[u + 1] - seen_ptr[u]) if seen_ptr is not None else 0
+            if n_items - n_seen < topk:
+                flags[u] |= 2
+            elif valid.all():
+                bound = (K + 3) * 2.0 ** -24 * np.linalg.norm(En[u]) * vmax
+                if bound > 0 and not (s[topk - 1] - float(cs[u, KC - 1]) > bound):
+                    flags[u] |= 1
+        return torch.from_numpy(out_idx), torch.from_numpy(out_s), torch.from_numpy(flags)
+
+    def score_exact_rows(self, rows, V, E, n_items, seen_ptr, seen_idx, topk):
+        Vn, En = V.numpy(), E.numpy()
+        out_idx = np.full((len(rows), topk), -1, dtype=np.int64)
+        out_s = np.full((len(rows), topk), -np.inf)
+        for r, u in enumerate(rows.numpy()):
+            s = Vn @ En[u]
+            cls = np.zeros(n_items, dtype=np.int64)
+            if seen_ptr is not None:
+                cls[seen_idx.numpy()[int(seen_ptr[u]):int(seen_ptr[u + 1])]] = 1
+            order = np.lexsort((np.arange(n_items), -s, cls))[:topk]
+            out_idx[r, :len(order)] = order
+            out_s[r, :len(order)] = s[order]
+        return torch.from_numpy(out_idx), torch.from_numpy(out_s)
+
+    def dense_scores(self, V, E):
+        return E @ V.t()

@@ -1,0 +1,159 @@
+"""Host-side logic on CPU: CSR/task-plan builders, the ArrayData protocol, and the backend-agnostic
+orchestration (solver, scoring pipeline, HOOI driver, model classes) driven through the TEST-ONLY
+NumPy double of the device operator set (tests/numpy_ops.py) against the reference's golden vectors.
+This proves the orchestration; the HIP kernels themselves are proven by the -m gpu tests."""
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+from conftest import load_golden, GoldenData
+from numpy_ops import NumpyOps
+from oracle import polara_oracle as orc
+from polara_amd import csr as pcsr
+from polara_amd.data import ArrayData
+from polara_amd.models import SVDModel, CoffeeModel
+from polara_amd.solver import svd_topk
+
+
+def test_coo_to_csr_matches_scipy_and_sums_duplicates():
+    rng = np.random.RandomState(0)
+    r = rng.randint(0, 50, 3000)
+    c = rng.randint(0, 40, 3000)
+    v = rng.rand(3000)
+    ip, ix, vl = pcsr.coo_to_csr(r, c, v, (50, 40))
+    A = sps.coo_matrix((v, (r, c)), shape=(50, 40)).tocsr()
+    assert np.array_equal(ip, A.indptr) and np.array_equal(ix, A.indices) and np.allclose(vl, A.data)
+    tp, ti, tv = pcsr.csr_transpose(ip, ix, vl, 40)
+    At = A.T.tocsr()
+    At.sort_indices()
+    assert np.array_equal(tp, At.indptr) and np.array_equal(ti, At.indices) and np.allclose(tv, At.data)
+    with pytest.raises(ValueError):
+        pcsr.coo_to_csr([0, 60], [0, 1], [1.0, 1.0], (50, 40))
+
+
+@pytest.mark.parametrize('split', [4, 16, 1000])
+def test_row_tasks_cover_every_nnz_once(split):
+    rng = np.random.RandomState(1)
+    counts = np.r_[0, rng.randint(0, 60, 30), 0, 500, 0]
+    indptr = np.r_[0, np.cumsum(counts)].astype(np.int64)
+    plan = pcsr.build_row_tasks(indptr, split=split)
+    cov = np.zeros(indptr[-1], int)
+    for row, b, e in zip(plan['task_row'], plan['task_begin'], plan['task_end']):
+        assert indptr[row] <= b <= e <= indptr[row + 1] and e - b <= max(split, 1)
+        cov[b:e] += 1
+    assert (cov == 1).all()
+    assert set(plan['task_row']) == set(range(len(counts)))  # empty rows get a task too
+    slots = plan['task_slot'][plan['task_slot'] >= 0]
+    assert np.array_equal(slots, np.arange(plan['n_slots']))
+    for row, s0, s1 in zip(plan['long_row'], plan['long_slot_begin'], plan['long_slot_end']):
+        assert (plan['task_row'][np.isin(plan['task_slot'], np.arange(s0, s1))] == row).all()
+
+
+def test_nnz_balanced_partition():
+    indptr = np.r_[0, np.cumsum(np.r_[np.full(10, 100), np.full(90, 1)])].astype(np.int64)
+    b = pcsr.nnz_balanced_row_partition(indptr, 4)
+    assert b[0] == 0 and b[-1] == 100 and (np.diff(b) >= 0).all()
+    shard_nnz = np.diff(indptr[b])
+    assert shard_nnz.max() <= 1.5 * indptr[-1] / 4
+
+
+def test_arraydata_protocol_threshold_and_recovery():
+    u = np.array([0, 0, 1, 1, 2, 2, 2])
+    i = np.array([0, 1, 1, 2, 0, 2, 3])
+    f = np.array([5., 2., 4., 1., 3., 5., 2.])
+    hold = (np.array([0, 2]), np.array([3, 1]), np.array([4., 4.]))
+    d = ArrayData((u, i, f), n_users=3, n_items=4, holdout=hold, warm_start=False)
+    idx, val, shp = d.to_coo(feedback_threshold=3)
+    assert shp == (3, 4) and len(val) == 4 and (val >= 3).all()       # data.py:777-791 filter_values=True
+    tu, ti, tf = d.test_to_coo(feedback_threshold=3)
+    assert np.array_equal(tu, [0, 0, 2, 2, 2]) and np.array_equal(tf, [5, 0, 3, 5, 0])  # zeroed, not dropped
+    assert d.get_test_shape() == (2, 4)
+    idx3, val3, shp3 = d.to_coo(tensor_mode=True)
+    assert shp3 == (3, 4, 5) and (val3 == 1).all() and idx3[:, 2].max() == 4
+    calls = []
+
+    class M:
+        def cb(self):
+            calls.append(1)
+    m = M()
+    d.subscribe(d.on_update_event, m.cb)
+    d.set_test_data(holdout=hold)
+    assert calls == [1]
+
+
+@pytest.mark.parametrize('name', ['svd_warm', 'svd_known', 'svd_fewunseen', 'svd_nofilter'])
+def test_svd_model_orchestration_matches_reference(name):
+    g = load_golden(name)
+    m = SVDModel(GoldenData(g), ops=NumpyOps())
+    m.verbose = False
+    m.rank, m.topk, m.filter_seen = int(g['rank']), int(g['topk']), bool(g['filter_seen'])
+    m.build()
+    assert len(m.training_time) == 1 and m._is_ready
+    assert np.allclose(m.factors['singular_values'], g['sigma'], rtol=1e-9)
+    V = m.factors[m.data.fields.itemid]
+    assert V.flags.f_contiguous and np.allclose(V @ V.T, g['V'] @ g['V'].T, atol=1e-8)
+    assert m.factors[m.data.fields.userid] is None
+    recs = m.recommendations
+    notie = g['boundary_gap'] > 0
+    assert recs.dtype == np.int64 and recs.shape == g['recs'].shape
+    assert np.array_equal(recs[notie], g['recs'][notie])
+    if name == 'svd_fewunseen':
+        assert m.recommend_stats['flagged_users'] > 0   # exercised the exact two-class path
+    if name == 'svd_warm':   # rank setter truncates, does not rebuild (models.py:812-832)
+        m.rank = 5
+        assert m._is_ready and m.factors['singular_values'].shape == (5,)
+        assert np.array_equal(m.recommendations, g['recs_rank5'])
+        m.rank = 9
+        assert not m._is_ready
+
+
+@pytest.mark.parametrize('name', ['coffee_small', 'coffee_warm'])
+def test_coffee_model_orchestration_matches_reference(name):
+    g = load_golden(name)
+    m = CoffeeModel(GoldenData(g), ops=NumpyOps())
+    m.verbose = False
+    m.mlrank, m.topk, m.seed = tuple(int(x) for x in g['mlrank']), int(g['topk']), int(g['seed'])
+    m.num_iters, m.growth_tol = int(g['num_iters']), float(g['growth_tol'])
+    m.build()
+    assert np.allclose(m.core_norm_trace, g['core_norm_trace'], rtol=1e-9)
+    f = m.data.fields
+    for key, ref in ((f.userid, g['u0']), (f.itemid, g['u1']), (f.feedback, g['u2'])):
+        a = m.factors[key]
+        assert np.allclose(a @ a.T, ref @ ref.T, atol=1e-8)
+    assert m.factors['core'].shape == tuple(g['mlrank'])
+    notie = g['boundary_gap'] > 0
+    assert np.array_equal(m.recommendations[notie], g['recs'][notie])
+
+
+def test_topk_cache_rules_and_errors():
+    g = load_golden('svd_nofilter')
+    m = SVDModel(GoldenData(g), ops=NumpyOps())
+    m.verbose = False
+    m.rank = int(g['rank'])
+    m.topk = 10
+    r10 = m.recommendations
+    m.topk = 5                      # smaller k keeps the cache (models.py:123-128)
+    assert m._recommendations is r10
+    m.topk = 12
+    assert m._recommendations is None
+    m.topk = 10 ** 6
+    with pytest.raises(ValueError):
+        m.get_recommendations()
+    with pytest.raises(NotImplementedError):
+        SVDModel.build(m, operator=object())
+
+
+def test_solver_converges_on_planted_and_degenerate_inputs():
+    from polara_amd.synth import planted_csr, csr_to_numpy
+    c = csr_to_numpy(planted_csr(900, 400, 30, 12, seed=5, min_items=8, max_items=150))
+    ops = NumpyOps()
+    A = ops.csr(c['indptr'], c['indices'], c['values'], c['shape'])
+    _, s, V, st = svd_topk(ops, A, 12)
+    ref = np.linalg.svd(A.m.toarray(), compute_uv=False)[:12]
+    assert st['converged'] and np.allclose(s.numpy(), ref, rtol=1e-10)
+    assert np.allclose(V.numpy().T @ V.numpy(), np.eye(12), atol=1e-10)
+    # rank-deficient matrix with k beyond the numerical rank and block == n_items
+    B = sps.csr_matrix(np.outer(np.arange(1, 9.), np.arange(1, 7.)))
+    A2 = ops.csr(B.indptr, B.indices, B.data, B.shape)
+    _, s2, _, st2 = svd_topk(ops, A2, 3)
+    assert np.isclose(s2.numpy()[0], np.linalg.svd(B.toarray(), compute_uv=False)[0]) and s2.numpy()[1] < 1e-5 * s2.numpy()[0]
