@@ -1,0 +1,216 @@
+"""bench.py — users scored/sec (+ SVD build time) of the PureSVD hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], the largest single-GPU config): synthetic planted 1M users x
+100K items, ~1e8 nnz CSR, PureSVD rank 50, top-10, every user scored.  A "step" is one full
+`get_recommendations` pass over all users: fold-in SpMM -> fused MFMA score/mask/top-k ->
+exact fp64 re-scoring -> exact rows for uncertified users.  The SVD build (the other half of the
+metric) runs once before the timed region and is reported as `build_s` with its own roofline.
+Users are sharded over ranks (strong scaling: the total work is fixed); the build's only
+collective is the all-reduce of the Gramian-step block, scoring has none.
+
+Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel of the timed region
+(score_candidates, MFMA-bound: 2*n_users*n_items*rank flop per launch); `roofline_build` the SpMM
+(HBM-bound; algorithmic bytes per launch = nnz*(4+val_bytes) + 8*(n_rows+1) + 8*nc*(n_cols+n_rows)).
+`cpu_baseline` is the oracle (= the reference's SciPy/NumPy path restated) timed on this box's host
+cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--workload', default='s1m', choices=['s1m', 'ml20m', 'ml1m'])
+    ap.add_argument('--scale', type=float, default=1.0, help='shrink users/items (debug only; invalidates the number)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-users', type=int, default=0, help='users in the CPU scoring sample (0 = auto)')
+    return ap.parse_args()
+
+
+def spmm_alg_bytes(meta):
+    n_rows, n_cols, nnz, nc, vbytes = meta
+    return nnz * (4 + vbytes) + 8 * (n_rows + 1) + 8 * nc * (n_cols + n_rows)
+
+
+def events_ms(pairs):
+    return [e0.elapsed_time(e1) for e0, e1, _ in pairs]
+
+
+def cpu_baseline(c, V_host, rank, topk, n_score_users, build_rows):
+    """The oracle on host cores: (a) reference scoring path on the first `n_score_users` users
+    (chunked exactly like utils.py:16-53), (b) scipy svds on the first `build_rows` users."""
+    import scipy.sparse as sps
+    from oracle import polara_oracle as orc     # checker / CPU baseline only
+    try:
+        from threadpoolctl import threadpool_info
+        blas_threads = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
+    except Exception:
+        blas_threads = os.cpu_count()
+    indptr, indices, values = c['indptr'], c['indices'], c['values']
+    n_items = c['shape'][1]
+    # (a) scoring
+    hi = int(indptr[n_score_users])
+    users = np.repeat(np.arange(n_score_users, dtype=np.int64), np.diff(indptr[:n_score_users + 1]))
+    td = (users, indices[:hi].astype(np.int64), values[:hi].astype(np.float64))
+    t0 = time.perf_counter()
+    recs = orc.svd_recommendations(V_host, td, (n_score_users, n_items), topk, True)
+    t_score = time.perf_counter() - t0
+    # (b) build on a row sample
+    hb = int(indptr[build_rows])
+    A = sps.csr_matrix((values[:hb].astype(np.float64), indices[:hb], indptr[:build_rows + 1]),
+                       shape=(build_rows, n_items))
+    np.random.seed(0)
+    t0 = time.perf_counter()
+    orc.svd_build(A, rank)
+    t_build = time.perf_counter() - t0
+    return dict(value=n_score_users / t_score, unit='users/s', cores=int(blas_threads), kind='port',
+                sample='reference scoring path (chunked GEMM + downvote + per-row argpartition, fp64) on the first '
+                       '%d users of the same matrix with the GPU-built V; svds build timed on the first %d users '
+                       '(%d nnz)' % (n_score_users, build_rows, hb),
+                score_sample_s=t_score, build_sample_s=t_build, build_sample_users=build_rows,
+                build_sample_nnz=hb, host_cpus=os.cpu_count()), recs
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    from polara_amd.dist import init_from_env
+    from polara_amd.solver import NoComm
+    if world > 1:
+        comm = init_from_env()
+    else:
+        torch.cuda.set_device(0)
+        comm = NoComm()
+    rank_id = comm.rank
+    from polara_amd.ops import HipOps
+    from polara_amd.synth import make_workload, csr_to_numpy
+    from polara_amd.csr import nnz_balanced_row_partition
+    from polara_amd.solver import svd_topk
+    from polara_amd import scoring
+
+    dev = 'cuda:%d' % torch.cuda.current_device()
+    ops = HipOps(dev)
+    t_gen = time.perf_counter()
+    csr, cfg = make_workload(args.workload, device=dev, scale=args.scale)
+    c = csr_to_numpy(csr)
+    del csr
+    torch.cuda.empty_cache()
+    t_gen = time.perf_counter() - t_gen
+    n_users, n_items = c['shape']
+    nnz = int(c['indptr'][-1])
+    rank, topk = cfg['rank'], cfg['topk']
+
+    # ---- shard users (nnz-balanced contiguous blocks) -------------------------------------------------
+    bounds = nnz_balanced_row_partition(c['indptr'], comm.world)
+    lo, hi = int(bounds[rank_id]), int(bounds[rank_id + 1])
+    sub = slice(int(c['indptr'][lo]), int(c['indptr'][hi]))
+    A = ops.csr(c['indptr'][lo:hi + 1] - c['indptr'][lo], c['indices'][sub], c['values'][sub], (hi - lo, n_items))
+    _ = A.T   # CSC image built once (host transpose + upload), outside any timing
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            comm.barrier()
+        torch.cuda.synchronize()
+
+    # ---- SVD build (once) -------------------------------------------------------------------------------
+    ops.timers = {}
+    barrier()
+    t0 = time.perf_counter()
+    _, sigma, V, bstats = svd_topk(ops, A, rank, comm=comm)
+    barrier()
+    build_s = time.perf_counter() - t0
+    spmm_ev = ops.timers.get('spmm', [])
+    spmm_ms = events_ms(spmm_ev)
+    spmm_bytes = [spmm_alg_bytes(m) for _, _, m in spmm_ev]
+    ops.timers = None
+    F = scoring.FactorImage(ops, V)
+
+    # ---- timed region: K full scoring passes ------------------------------------------------------------
+    for _ in range(args.warmup):
+        scoring.recommend(ops, F, A, topk, True)
+    ops.timers = {}
+    stats = {}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        recs = scoring.recommend(ops, F, A, topk, True, stats=stats)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    cand_ms = events_ms(ops.timers.get('score_candidates', []))
+    fold_ms = events_ms(ops.timers.get('spmm', []))
+    ops.timers = None
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = n_users / (elapsed / args.steps)
+
+    if rank_id != 0:
+        return
+    cand_avg_ms = float(np.mean(cand_ms))
+    flops = 2.0 * (hi - lo) * n_items * rank
+    achieved_tf = flops / (cand_avg_ms * 1e-3) / 1e12
+    out = {
+        'metric': 'users scored/sec + SVD build time', 'value': value, 'unit': 'users/s',
+        'n_gpus': comm.world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
+        'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32 MFMA candidates + f64 rescoring/build',
+        'data': 'synthetic (planted low-rank + Zipf popularity, seeded; generated on GPU)',
+        'config': {'workload': {'s1m': 'Synthetic 1M users x 100K items, ~0.1% density CSR, PureSVD rank=50, top-10, all users scored (BASELINE.json configs[1])',
+                                'ml20m': 'ML-20M-shaped synthetic 138493 x 26744, PureSVD rank=100, top-20 (BASELINE.json configs[2])',
+                                'ml1m': 'ML-1M-shaped synthetic 6040 x 3706, PureSVD rank=10, top-10 (BASELINE.json configs[0])'}[args.workload],
+                   'n_users': n_users, 'n_items': n_items, 'nnz': nnz, 'rank': rank, 'topk': topk,
+                   'parallelism': 'users sharded over %d GPU(s); Gramian all-reduce in build only' % comm.world,
+                   'scale': args.scale},
+        'build_s': build_s,
+        'build': {'gramian_steps': bstats['gramian_steps'], 'outer_iterations': bstats['outer'],
+                  'block': bstats['block'], 'converged': bstats['converged'], 'spmm_launches': len(spmm_ms),
+                  'sigma_max': float(sigma[0].item()), 'sigma_min': float(sigma[-1].item())},
+        'score': {'fold_in_ms': float(np.mean(fold_ms)) if fold_ms else None, 'candidates_ms': cand_avg_ms,
+                  'flagged_users_last_step': stats.get('flagged_users'), 'candidate_capacity': stats.get('candidate_capacity')},
+        'roofline': {'kernel': 'score_candidates_kernel', 'bound': 'mfma', 'achieved': achieved_tf,
+                     'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved_tf / PEAK_FP32_MFMA_TFLOPS,
+                     'traffic': None, 'launches': len(cand_ms), 'avg_ms': cand_avg_ms,
+                     'flop_per_launch': flops},
+        'roofline_build': {'kernel': 'spmm_csr_kernel', 'bound': 'hbm',
+                           'achieved': float(sum(spmm_bytes) / (sum(spmm_ms) * 1e-3) / 1e9) if spmm_ms else None,
+                           'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
+                           'frac': float(sum(spmm_bytes) / (sum(spmm_ms) * 1e-3) / 1e9 / PEAK_HBM_GBPS) if spmm_ms else None,
+                           'traffic': None, 'launches': len(spmm_ms), 'total_ms': float(sum(spmm_ms)),
+                           'bytes_total': float(sum(spmm_bytes))},
+        'gen_s': t_gen,
+    }
+    if not args.no_cpu_baseline and comm.world == 1:
+        n_score = args.cpu_users or min(n_users, max(256, int(2.0e8 / max(n_items, 1))))   # ~2 chunks of the 1 GB rule
+        build_rows = min(n_users, max(1000, int(5e6 / max(nnz / n_users, 1))))
+        base, cpu_recs = cpu_baseline(c, np.ascontiguousarray(ops.to_host(V)), rank, topk, n_score, build_rows)
+        same = float((ops.to_host(recs[:n_score]) == cpu_recs).all(axis=1).mean())
+        base['gpu_vs_cpu_identical_rows'] = same
+        base['speedup_scoring'] = value / base['value']
+        out['cpu_baseline'] = base
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .csr import build_row_tasks, csr_transpose, SPLIT_NNZ
+from .csr import build_row_tasks, SPLIT_NNZ
 
 
 def _ptr(t):
@@ -59,12 +59,44 @@ class DeviceCSR:
 
     @property
     def T(self):
+        """CSR of A^T (= CSC of A).  Format conversion runs on the device (a stable sort by column,
+        torch plumbing): a host argsort of 1e8 indices would take longer than the whole build."""
         if self._T is None:
-            indptr, indices, values = self._host
-            tp, ti, tv = csr_transpose(indptr, indices, values, self.shape[1])
-            self._T = DeviceCSR(self.ops, tp, ti, tv, (self.shape[1], self.shape[0]))
+            dev = self.ops.device
+            n_rows, n_cols = self.shape
+            counts = (self.indptr[1:] - self.indptr[:-1])
+            rows = torch.repeat_interleave(torch.arange(n_rows, dtype=torch.int32, device=dev), counts)
+            order = torch.argsort(self.indices, stable=True)   # rows stay ascending within a column
+            t_indices = rows[order]
+            t_values = self.values[order]
+            t_counts = torch.bincount(self.indices.long(), minlength=n_cols)
+            t_indptr = torch.zeros(n_cols + 1, dtype=torch.int64, device=dev)
+            t_indptr[1:] = torch.cumsum(t_counts, 0)
+            del rows, order, counts, t_counts
+            self._T = DeviceCSR.from_device(self.ops, t_indptr, t_indices, t_values, (n_cols, n_rows))
             self._T._T = self
         return self._T
+
+    @classmethod
+    def from_device(cls, ops, indptr, indices, values, shape, split=SPLIT_NNZ):
+        """Wraps CSR arrays that already live in HBM (only the row pointers visit the host, to
+        build the task plan)."""
+        self = cls.__new__(cls)
+        self.ops = ops
+        self.shape = (int(shape[0]), int(shape[1]))
+        self.indptr, self.indices, self.values = indptr, indices, values
+        self.val_kind = _lib.PK_VAL_F32 if values.dtype == torch.float32 else _lib.PK_VAL_F64
+        host_ptr = indptr.cpu().numpy()
+        self.nnz = int(host_ptr[-1])
+        self._host = None
+        plan = build_row_tasks(host_ptr, split)
+        self.n_tasks = len(plan['task_row'])
+        self.n_long = len(plan['long_row'])
+        self.n_slots = plan['n_slots']
+        self.plan = {k: torch.from_numpy(v).to(ops.device) for k, v in plan.items() if isinstance(v, np.ndarray)}
+        self._partial = None
+        self._T = None
+        return self
 
     def drop_host(self):
         self._host = None
@@ -80,6 +112,26 @@ class HipOps:
         self.device = torch.device(device if device is not None else 'cuda:%d' % torch.cuda.current_device())
         self._gram_work = None
         self._info = torch.zeros(2, dtype=torch.int32, device=self.device)
+        # optional per-kernel HIP-event timing (bench.py): {'name': [(ev_start, ev_end, meta), ...]}
+        self.timers = None
+
+    def _timed(self, name, meta):
+        """Context manager recording HIP events on the launch stream around one kernel call."""
+        ops = self
+
+        class _T:
+            def __enter__(self_t):
+                if ops.timers is not None:
+                    self_t.e0 = torch.cuda.Event(enable_timing=True)
+                    self_t.e1 = torch.cuda.Event(enable_timing=True)
+                    self_t.e0.record(torch.cuda.current_stream(ops.device))
+
+            def __exit__(self_t, *exc):
+                if ops.timers is not None:
+                    self_t.e1.record(torch.cuda.current_stream(ops.device))
+                    ops.timers.setdefault(name, []).append((self_t.e0, self_t.e1, meta))
+                return False
+        return _T()
 
     # ---- plumbing ---------------------------------------------------------------------------
     def stream(self):
@@ -116,17 +168,19 @@ class HipOps:
         if out is None:
             out = self.empty(A.shape[0], nc)
         p = A.plan
-        _lib.check(self.lib.pk_spmm_csr_f64(
-            self.stream(), A.n_tasks, _ptr(p['task_row']), _ptr(p['task_begin']), _ptr(p['task_end']),
-            _ptr(p['task_slot']), A.n_long, _ptr(p['long_row']), _ptr(p['long_slot_begin']),
-            _ptr(p['long_slot_end']), _ptr(A.indices), _ptr(A.values), A.val_kind,
-            _ptr(X), X.stride(0), nc, _ptr(out), out.stride(0), _ptr(A.partial(nc))), 'pk_spmm_csr_f64')
+        with self._timed('spmm', (A.shape[0], A.shape[1], A.nnz, nc, A.values.element_size())):
+            _lib.check(self.lib.pk_spmm_csr_f64(
+                self.stream(), A.n_tasks, _ptr(p['task_row']), _ptr(p['task_begin']), _ptr(p['task_end']),
+                _ptr(p['task_slot']), A.n_long, _ptr(p['long_row']), _ptr(p['long_slot_begin']),
+                _ptr(p['long_slot_end']), _ptr(A.indices), _ptr(A.values), A.val_kind,
+                _ptr(X), X.stride(0), nc, _ptr(out), out.stride(0), _ptr(A.partial(nc))), 'pk_spmm_csr_f64')
         return out
 
     # ---- K2 ---------------------------------------------------------------------------------
     def gram(self, A, B=None):
         """A^T B  (la x lb), fp64."""
         B = A if B is None else B
+        assert A.stride(1) == 1 and B.stride(1) == 1 and A.shape[0] == B.shape[0]
         n, la = A.shape
         lb = B.shape[1]
         need = self.lib.pk_gram_work_bytes(n, la, lb)
@@ -139,6 +193,7 @@ class HipOps:
 
     def tsmm(self, X, Cm, out=None):
         """X[n x lin] @ C[lin x lout]."""
+        assert X.stride(1) == 1 and Cm.stride(1) == 1 and Cm.shape[0] == X.shape[1]
         n, lin = X.shape
         lout = Cm.shape[1]
         if out is None:
@@ -167,6 +222,7 @@ class HipOps:
 
     def resid_colnorm2(self, Z, X, theta):
         """sum_i (Z[i,j] - theta[j] X[i,j])^2 per column -> [l] (device tensor)."""
+        assert Z.stride(1) == 1 and X.stride(1) == 1 and theta.is_contiguous()
         n, l = Z.shape
         nb = self.lib.pk_resid_blocks(n)
         part = self.empty(nb, l)
@@ -187,6 +243,7 @@ class HipOps:
         return out
 
     def scale_cols(self, X, s):
+        assert X.stride(1) == 1
         _lib.check(self.lib.pk_scale_cols_f64(self.stream(), X.shape[0], X.shape[1], _ptr(X), X.stride(0),
                                               _ptr(s.contiguous())), 'pk_scale_cols_f64')
         return X
@@ -194,6 +251,7 @@ class HipOps:
     # ---- K3 ---------------------------------------------------------------------------------
     def pack_frag(self, M):
         """f64 [n x K] -> packed f32 MFMA fragments (see csrc/score.hip)."""
+        assert M.stride(1) == 1 and M.dtype == torch.float64
         n, K = M.shape
         out = torch.empty(self.lib.pk_pack_elems(n, K), dtype=torch.float32, device=self.device)
         _lib.check(self.lib.pk_pack_frag_f32(self.stream(), n, K, _ptr(M), M.stride(0), _ptr(out)),
@@ -207,12 +265,14 @@ class HipOps:
         n_pad = -(-n_users // 32) * 32
         cs = torch.empty(n_pad * KC, dtype=torch.float32, device=self.device)
         ci = torch.empty(n_pad * KC, dtype=torch.int32, device=self.device)
-        _lib.check(self.lib.pk_score_candidates_f32(self.stream(), n_users, n_items, K, _ptr(Vp), _ptr(Ep),
-                                                    _ptr(seen_ptr), _ptr(seen_idx), KC, _ptr(cs), _ptr(ci)),
-                   'pk_score_candidates_f32')
+        with self._timed('score_candidates', (n_users, n_items, K)):
+            _lib.check(self.lib.pk_score_candidates_f32(self.stream(), n_users, n_items, K, _ptr(Vp), _ptr(Ep),
+                                                        _ptr(seen_ptr), _ptr(seen_idx), KC, _ptr(cs), _ptr(ci)),
+                       'pk_score_candidates_f32')
         return cs, ci
 
     def rescore_topk(self, V, E, n_items, seen_ptr, KC, cs, ci, topk, vmax, want_scores=True):
+        assert V.stride(1) == 1 and E.stride(1) == 1
         n_users, K = E.shape
         out_idx = torch.empty(n_users, topk, dtype=torch.int64, device=self.device)
         out_s = self.empty(n_users, topk) if want_scores else None

@@ -1,0 +1,239 @@
+"""-m gpu: every HIP kernel, called through the C ABI (polara_amd.ops.HipOps -> libpolarahip.so),
+against NumPy/SciPy on the same seeded inputs.  Integer/index results must be bit-exact; fp64
+kernels are held to 1e-12 relative (summation order differs from BLAS), the fp32 MFMA candidate
+pass to the certified error bound it reports itself."""
+import numpy as np
+import pytest
+import scipy.sparse as sps
+import torch
+
+from numpy_ops import NumpyOps
+from oracle import polara_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def rand_csr(rng, n_rows, n_cols, mean, long_rows=(), empty_rows=(), dtype=np.float32, levels=5):
+    counts = rng.poisson(mean, n_rows).clip(0, n_cols)
+    for r, c in long_rows:
+        counts[r] = min(c, n_cols)
+    for r in empty_rows:
+        counts[r] = 0
+    indptr = np.r_[0, np.cumsum(counts)].astype(np.int64)
+    indices = np.concatenate([np.sort(rng.choice(n_cols, c, replace=False)) for c in counts] or [[]]).astype(np.int32)
+    if dtype == np.float32:
+        values = rng.randint(1, levels + 1, indptr[-1]).astype(np.float32)
+    else:
+        values = rng.randn(indptr[-1])
+    return indptr, indices, values
+
+
+def test_library_reports_gfx950(hip_ops):
+    from polara_amd import _lib
+    info = _lib.device_info(0)
+    assert info['n_devices'] >= 1 and 'gfx950' in info['arch'], info
+
+
+@pytest.mark.parametrize('nc', [1, 10, 50, 64, 72, 130, 256])
+@pytest.mark.parametrize('vdtype', [np.float32, np.float64])
+def test_spmm_matches_scipy(hip_ops, nc, vdtype):
+    rng = np.random.RandomState(nc)
+    n_rows, n_cols = 3000, 1500
+    indptr, indices, values = rand_csr(rng, n_rows, n_cols, 25, long_rows=[(5, 1400), (17, 1100), (2999, 1300)],
+                                       empty_rows=[0, 7, 2998], dtype=vdtype)
+    A = hip_ops.csr(indptr, indices, values, (n_rows, n_cols), split=256)
+    assert A.n_long >= 3
+    X = rng.randn(n_cols, nc)
+    out = hip_ops.to_host(hip_ops.spmm(A, hip_ops.to_device(X)))
+    ref = sps.csr_matrix((values.astype(np.float64), indices, indptr), shape=(n_rows, n_cols)) @ X
+    err = np.abs(out - ref).max() / np.abs(ref).max()
+    assert err < 1e-13, err
+    assert (out[[0, 7, 2998]] == 0).all()
+    # transpose product through the CSC plan
+    Y = rng.randn(n_rows, min(nc, 64))
+    outT = hip_ops.to_host(hip_ops.spmm(A.T, hip_ops.to_device(Y)))
+    refT = sps.csr_matrix((values.astype(np.float64), indices, indptr), shape=(n_rows, n_cols)).T @ Y
+    assert np.abs(outT - refT).max() / np.abs(refT).max() < 1e-13
+    # strided X (leading dimension > nc) is honoured
+    Xw = hip_ops.to_device(rng.randn(n_cols, nc + 5))
+    out2 = hip_ops.to_host(hip_ops.spmm(A, Xw[:, :nc]))
+    ref2 = sps.csr_matrix((values.astype(np.float64), indices, indptr), shape=(n_rows, n_cols)) @ hip_ops.to_host(Xw)[:, :nc]
+    assert np.abs(out2 - ref2).max() / np.abs(ref2).max() < 1e-13
+
+
+def test_spmm_is_deterministic(hip_ops):
+    rng = np.random.RandomState(3)
+    indptr, indices, values = rand_csr(rng, 2000, 900, 40, long_rows=[(3, 880)])
+    A = hip_ops.csr(indptr, indices, values, (2000, 900), split=128)
+    X = hip_ops.to_device(rng.randn(900, 64))
+    a = hip_ops.to_host(hip_ops.spmm(A, X))
+    b = hip_ops.to_host(hip_ops.spmm(A, X))
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize('shape', [(5000, 64, 64), (777, 10, 72), (40000, 130, 130), (33, 5, 3), (100000, 24, 24)])
+def test_gram_and_tsmm(hip_ops, shape):
+    n, la, lb = shape
+    rng = np.random.RandomState(n)
+    A, B = rng.randn(n, la), rng.randn(n, lb)
+    G = hip_ops.to_host(hip_ops.gram(hip_ops.to_device(A), hip_ops.to_device(B)))
+    ref = A.T @ B
+    assert np.abs(G - ref).max() / np.abs(ref).max() < 1e-13
+    Gs = hip_ops.to_host(hip_ops.gram(hip_ops.to_device(A)))
+    assert np.abs(Gs - A.T @ A).max() / np.abs(A.T @ A).max() < 1e-13
+    Cm = rng.randn(la, lb)
+    out = hip_ops.to_host(hip_ops.tsmm(hip_ops.to_device(A), hip_ops.to_device(Cm)))
+    assert np.abs(out - A @ Cm).max() / np.abs(A @ Cm).max() < 1e-13
+
+
+@pytest.mark.parametrize('n', [1, 2, 5, 24, 63, 64, 72, 128, 200])
+def test_eigh_psd_jacobi(hip_ops, n):
+    rng = np.random.RandomState(n)
+    M = rng.randn(n + 3, n) * np.logspace(0, -6, n)[None, :]   # badly scaled Gram matrix
+    S = M.T @ M
+    lam, C = hip_ops.eigh_psd(hip_ops.to_device(S))
+    lam, C = hip_ops.to_host(lam), hip_ops.to_host(C)
+    ref = np.linalg.eigvalsh(S)[::-1]
+    assert (np.diff(lam) <= 1e-300 + 1e-14 * lam[0]).all()
+    assert np.abs(lam - ref).max() <= 1e-12 * ref[0]
+    assert np.abs(C.T @ C - np.eye(n)).max() < 1e-12
+    assert np.abs(S @ C - C * lam[None, :]).max() <= 1e-11 * ref[0]
+    info = hip_ops.to_host(hip_ops._info)
+    assert info[1] == 1, 'jacobi did not converge: %s' % info
+    # small eigenvalues keep RELATIVE accuracy (what the whitening step relies on)
+    keep = ref > 1e-10 * ref[0]
+    assert np.abs(lam[keep] / ref[keep] - 1).max() < 1e-6
+
+
+def test_elementwise_and_small_kernels(hip_ops):
+    rng = np.random.RandomState(0)
+    for n in (1, 7, 1000, 100001):
+        Z, Y, X = rng.randn(n), rng.randn(n), rng.randn(n)
+        dz, dy, dx = (hip_ops.to_device(a) for a in (Z, Y, X))
+        assert np.allclose(hip_ops.to_host(hip_ops.axpbypcz(0.3, dz, -1.2, dy, 2.5, dx)), 0.3 * Z - 1.2 * Y + 2.5 * X, rtol=1e-14, atol=1e-14)
+        assert np.allclose(hip_ops.to_host(hip_ops.axpbypcz(0.3, dz, -1.2, dy)), 0.3 * Z - 1.2 * Y, rtol=1e-14, atol=1e-14)
+        assert np.allclose(hip_ops.to_host(hip_ops.axpbypcz(2.0, dz)), 2.0 * Z)
+    for n, l in ((5000, 64), (1025, 7), (300, 200), (3, 300)):
+        Z, X, th = rng.randn(n, l), rng.randn(n, l), rng.rand(l)
+        r = hip_ops.to_host(hip_ops.resid_colnorm2(hip_ops.to_device(Z), hip_ops.to_device(X), hip_ops.to_device(th)))
+        ref = ((Z - X * th) ** 2).sum(0)
+        assert np.allclose(r, ref, rtol=1e-12)
+        Xs = hip_ops.to_device(X.copy())
+        hip_ops.scale_cols(Xs, hip_ops.to_device(th))
+        assert np.allclose(hip_ops.to_host(Xs), X * th)
+    A, B = rng.randn(5, 900), rng.randn(5, 900)
+    assert np.allclose(hip_ops.to_host(hip_ops.small_mm(hip_ops.to_device(A), hip_ops.to_device(B), transB=True)), A @ B.T)
+    assert np.allclose(hip_ops.to_host(hip_ops.small_mm(hip_ops.to_device(A), hip_ops.to_device(B), transA=True)), A.T @ B)
+
+
+def brute_topk(V, E, seen_ptr, seen_idx, topk, filter_seen=True):
+    s = E @ V.T
+    n_users, n_items = s.shape
+    out = np.empty((n_users, topk), dtype=np.int64)
+    for u in range(n_users):
+        cls = np.zeros(n_items, dtype=np.int64)
+        if filter_seen:
+            cls[seen_idx[seen_ptr[u]:seen_ptr[u + 1]]] = 1
+        out[u] = np.lexsort((np.arange(n_items), -s[u], cls))[:topk]
+    return out, s
+
+
+@pytest.mark.parametrize('cfg', [dict(n_users=300, n_items=1000, K=10, topk=10),
+                                 dict(n_users=97, n_items=4099, K=50, topk=10),
+                                 dict(n_users=260, n_items=2500, K=100, topk=20),
+                                 dict(n_users=64, n_items=777, K=200, topk=50),
+                                 dict(n_users=33, n_items=31, K=7, topk=5),
+                                 dict(n_users=70, n_items=640, K=24, topk=1)])
+def test_fused_scoring_pipeline_exact(hip_ops, cfg):
+    from polara_amd import scoring
+    n_users, n_items, K, topk = cfg['n_users'], cfg['n_items'], cfg['K'], cfg['topk']
+    rng = np.random.RandomState(K)
+    V = np.linalg.qr(rng.randn(n_items, K))[0] if n_items >= K else rng.randn(n_items, K)
+    heavy = [(1, min(n_items - 2, 900))] if n_items > 100 else []
+    indptr, indices, values = rand_csr(rng, n_users, n_items, min(30, n_items // 3), long_rows=heavy,
+                                       empty_rows=[0], dtype=np.float32)
+    values[::7] = 0.0   # explicit zero-feedback entries stay 'seen'
+    T = hip_ops.csr(indptr, indices, values, (n_users, n_items))
+    F = scoring.FactorImage(hip_ops, hip_ops.to_device(V))
+    E = sps.csr_matrix((values.astype(np.float64), indices, indptr), shape=(n_users, n_items)) @ V
+    for filter_seen in (True, False):
+        stats = {}
+        recs, sc = scoring.recommend(hip_ops, F, T, topk, filter_seen, return_scores=True, stats=stats)
+        recs, sc = hip_ops.to_host(recs), hip_ops.to_host(sc)
+        ref, s = brute_topk(V, E, indptr, indices, topk, filter_seen)
+        # rows with an all-zero profile are pure ties (implementation-defined in the reference too)
+        live = np.abs(E).sum(1) > 0
+        gap_ok = np.ones(n_users, bool)
+        for u in range(n_users):   # exclude rows whose k-th/(k+1)-th exact scores tie within rounding
+            ss = np.sort(s[u][np.setdiff1d(np.arange(n_items), indices[indptr[u]:indptr[u + 1]] if filter_seen else [])])[::-1]
+            if len(ss) > topk:
+                gap_ok[u] = (ss[topk - 1] - ss[topk]) > 1e-12 * max(1.0, abs(ss[0]))
+        chk = live & gap_ok
+        bad = np.flatnonzero(~orc.topk_sets_equal(recs[chk], ref[chk]))
+        assert bad.size == 0, (cfg, filter_seen, 'first bad rows', bad[:5], recs[chk][bad[:2]], ref[chk][bad[:2]], stats)
+        assert (recs[chk] == ref[chk]).mean() > 0.999   # ordered equality (up to exact ties)
+        picked = np.take_along_axis(s, np.where(recs >= 0, recs, 0), axis=1)
+        assert np.allclose(sc[chk], picked[chk], rtol=1e-12, atol=1e-13)
+        if filter_seen:   # no seen item may appear while unseen ones remain
+            for u in np.flatnonzero(chk):
+                seen = set(indices[indptr[u]:indptr[u + 1]])
+                if n_items - len(seen) >= topk:
+                    assert not (set(recs[u]) & seen), (u, cfg)
+
+
+def test_few_unseen_items_reenter_after_unseen(hip_ops):
+    from polara_amd import scoring
+    rng = np.random.RandomState(5)
+    n_users, n_items, K, topk = 40, 48, 6, 10
+    V = np.linalg.qr(rng.randn(n_items, K))[0]
+    indptr, indices, values = rand_csr(rng, n_users, n_items, 20, long_rows=[(0, 46), (1, 44), (2, 48), (3, 39)])
+    T = hip_ops.csr(indptr, indices, values, (n_users, n_items))
+    F = scoring.FactorImage(hip_ops, hip_ops.to_device(V))
+    stats = {}
+    recs = hip_ops.to_host(scoring.recommend(hip_ops, F, T, topk, True, stats=stats))
+    test_data = (np.repeat(np.arange(n_users), np.diff(indptr)), indices.astype(np.int64), values.astype(np.float64))
+    ref = orc.svd_recommendations(V, test_data, (n_users, n_items), topk, True)   # the reference's own rule
+    assert stats['flagged_users'] >= 3
+    assert np.array_equal(recs, ref)
+
+
+@pytest.mark.parametrize('ranks', [(6, 5, 3), (13, 10, 2), (30, 30, 4), (4, 3, 5)])
+def test_ttm_matches_dttm_seq(hip_ops, ranks):
+    from polara_amd import tucker
+    rng = np.random.RandomState(sum(ranks))
+    shape = (500, 300, 5)
+    nnz = 20000
+    idx = np.stack([rng.randint(0, s, nnz) for s in shape], 1).astype(np.intp)
+    idx[:3000, 0] = 7   # a long output row
+    val = np.ones(nnz)
+    r0, r1, r2 = ranks
+    u0, u1, u2 = rng.randn(shape[0], r0), rng.randn(shape[1], r1), rng.randn(shape[2], r2)
+    for (m0, mu, mv), (Uu, Uv), modes in (((0, 2, 1), (u2, u1), ((2, 0), (1, 0))),
+                                          ((1, 2, 0), (u2, u0), ((2, 0), (0, 0))),
+                                          ((2, 1, 0), (u1, u0), ((1, 0), (0, 0)))):
+        mp = tucker.ModePlan(hip_ops, idx, val, shape, m0, mu, mv)
+        res = hip_ops.to_host(tucker.ttm(hip_ops, mp, hip_ops.to_device(Uu), hip_ops.to_device(Uv)))
+        ref = orc.ttm3d_seq(idx, val, shape, Uu, Uv, modes).reshape(shape[m0], -1)
+        assert np.abs(res - ref).max() <= 1e-12 * np.abs(ref).max(), (ranks, m0)
+    valr = rng.rand(nnz)
+    mp = tucker.ModePlan(hip_ops, idx, valr, shape, 0, 2, 1)
+    res = hip_ops.to_host(tucker.ttm(hip_ops, mp, hip_ops.to_device(u2), hip_ops.to_device(u1)))
+    ref = orc.ttm3d_seq(idx, valr, shape, u2, u1, ((2, 0), (1, 0))).reshape(shape[0], -1)
+    assert np.abs(res - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+def test_dense_scores_rows(hip_ops):
+    rng = np.random.RandomState(9)
+    V, E = rng.randn(1234, 37), rng.randn(5, 37)
+    out = hip_ops.to_host(hip_ops.dense_scores(hip_ops.to_device(V), hip_ops.to_device(E)))
+    assert np.allclose(out, E @ V.T, rtol=1e-12, atol=1e-12)
+
+
+def test_errors_are_loud(hip_ops):
+    from polara_amd._lib import PolaraHipError
+    with pytest.raises(PolaraHipError):
+        hip_ops.eigh_psd(hip_ops.zeros(2000, 2000))
+    X = hip_ops.zeros(10, 300)
+    A = hip_ops.csr(np.array([0, 1], dtype=np.int64), np.array([0], dtype=np.int32), np.array([1.0]), (1, 10))
+    with pytest.raises(PolaraHipError):
+        hip_ops.spmm(A, X)   # nc > 256

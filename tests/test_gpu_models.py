@@ -1,0 +1,146 @@
+"""-m gpu: the model classes on the HIP backend against (a) the reference's golden vectors,
+(b) the oracle on ML-1M-shaped seeded inputs (sizes the oracle finishes in seconds), and
+(c) size-independent properties on larger inputs.
+
+Tolerances (BASELINE.json north_star): singular values and scores within 1e-4 relative — we hold
+1e-9; top-k index lists identical on every row whose reference result is well defined (rows with
+an exact k-th/(k+1)-th tie are implementation-defined in the reference)."""
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+from conftest import load_golden, GoldenData
+from oracle import polara_oracle as orc
+from polara_amd.data import ArrayData
+from polara_amd.models import SVDModel, CoffeeModel
+from polara_amd.synth import make_workload, planted_csr, csr_to_numpy, csr_to_coo_triplets
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('name', ['svd_warm', 'svd_known', 'svd_fewunseen', 'svd_nofilter'])
+def test_svd_model_vs_reference_golden(hip_ops, name):
+    g = load_golden(name)
+    m = SVDModel(GoldenData(g), ops=hip_ops)
+    m.verbose = False
+    m.rank, m.topk, m.filter_seen = int(g['rank']), int(g['topk']), bool(g['filter_seen'])
+    m.build()
+    assert m.build_stats['converged']
+    assert np.allclose(m.factors['singular_values'], g['sigma'], rtol=1e-9, atol=0)
+    V = m.factors[m.data.fields.itemid]
+    assert V.flags.f_contiguous and np.abs(V @ V.T - g['V'] @ g['V'].T).max() < 1e-8
+    recs = m.recommendations
+    notie = g['boundary_gap'] > 0
+    assert recs.dtype == np.int64 and recs.shape == g['recs'].shape
+    assert np.array_equal(recs[notie], g['recs'][notie]), (recs[notie] != g['recs'][notie]).any(axis=1).sum()
+    # dense score rows (slice_recommendations surface) within 1e-9
+    td = (g['test_user'], g['test_item'], g['test_fdbk'])
+    for u, s in zip(g['probe_users'], g['probe_scores']):
+        sc, _ = m.slice_recommendations(td, tuple(int(x) for x in g['test_shape']), int(u), int(u) + 1)
+        assert np.allclose(sc[0], s, rtol=1e-9, atol=1e-10)
+    if name == 'svd_warm':
+        m.rank = 5
+        assert m._is_ready and np.array_equal(m.recommendations, g['recs_rank5'])
+
+
+@pytest.mark.parametrize('name', ['coffee_small', 'coffee_warm'])
+def test_coffee_model_vs_reference_golden(hip_ops, name):
+    g = load_golden(name)
+    m = CoffeeModel(GoldenData(g), ops=hip_ops)
+    m.verbose = False
+    m.mlrank, m.topk, m.seed = tuple(int(x) for x in g['mlrank']), int(g['topk']), int(g['seed'])
+    m.num_iters, m.growth_tol = int(g['num_iters']), float(g['growth_tol'])
+    m.build()
+    assert len(m.core_norm_trace) == len(g['core_norm_trace'])
+    assert np.allclose(m.core_norm_trace, g['core_norm_trace'], rtol=1e-9)
+    f = m.data.fields
+    for key, ref in ((f.userid, g['u0']), (f.itemid, g['u1']), (f.feedback, g['u2'])):
+        a = m.factors[key]
+        assert np.abs(a @ a.T - ref @ ref.T).max() < 1e-8
+    assert np.isclose(np.linalg.norm(m.factors['core']), np.linalg.norm(g['core']), rtol=1e-9)
+    notie = g['boundary_gap'] > 0
+    assert np.array_equal(m.recommendations[notie], g['recs'][notie])
+
+
+def _oracle_side(c, rank, topk, test_rows):
+    A = sps.csr_matrix((c['values'].astype(np.float64), c['indices'], c['indptr']), shape=c['shape'])
+    np.random.seed(0)
+    _, sigma, V = orc.svd_build(A, rank)
+    sub = A[test_rows]
+    coo = sub.tocoo()
+    order = np.lexsort((coo.col, coo.row))
+    td = (coo.row[order].astype(np.int64), coo.col[order].astype(np.int64), coo.data[order])
+    recs, scores = orc.svd_recommendations(V, td, (len(test_rows), c['shape'][1]), topk, True, return_scores=True)
+    full, sd = orc.svd_slice_recommendations(V, td, (len(test_rows), c['shape'][1]), 0, len(test_rows))
+    orc.downvote_seen_items(full, sd)
+    return sigma, V, recs, scores, orc.boundary_gap(full, topk)
+
+
+def test_ml1m_shaped_build_and_recs_vs_oracle(hip_ops):
+    """BASELINE config 0 shape (6040 x 3706, ~1M nnz, rank 10, top-10): all users scored."""
+    csr, cfg = make_workload('ml1m')
+    c = csr_to_numpy(csr)
+    u, i, v = csr_to_coo_triplets(csr)
+    n_users = c['shape'][0]
+    hold = (np.arange(n_users), np.zeros(n_users, np.int64), np.ones(n_users))   # all users are test users
+    d = ArrayData((u, i, v), n_users=n_users, n_items=c['shape'][1], holdout=hold, warm_start=False)
+    m = SVDModel(d, ops=hip_ops)
+    m.verbose = False
+    m.rank, m.topk = cfg['rank'], cfg['topk']
+    m.build()
+    recs = m.recommendations
+    sigma, V, o_recs, o_scores, gap = _oracle_side(c, cfg['rank'], cfg['topk'], np.arange(n_users))
+    assert np.abs(m.factors['singular_values'] / sigma - 1).max() < 1e-9
+    Vd = m.factors[d.fields.itemid]
+    assert np.abs(Vd @ Vd.T - V @ V.T).max() < 1e-8
+    ok = gap > 1e-9
+    same = (recs[ok] == o_recs[ok]).all(axis=1)
+    assert same.all(), ('rows differing', int((~same).sum()), 'of', int(ok.sum()))
+    assert ok.mean() > 0.99
+
+
+def test_rank50_top20_sample_vs_oracle_and_properties(hip_ops):
+    """A 30k x 12k planted matrix (rank 50 / top-20): oracle parity on a 1500-user sample, plus
+    properties over all users: descending exact scores, no seen item, idempotence, linearity of the
+    fold-in in the profile weights."""
+    from polara_amd import scoring
+    c = csr_to_numpy(planted_csr(30000, 12000, 60, 50, levels=10, seed=21, min_items=15, max_items=2500))
+    rank, topk = 50, 20
+    A = hip_ops.csr(c['indptr'], c['indices'], c['values'], c['shape'])
+    from polara_amd.solver import svd_topk
+    _, sigma, V, st = svd_topk(hip_ops, A, rank)
+    assert st['converged']
+    F = scoring.FactorImage(hip_ops, V)
+    recs, sc = scoring.recommend(hip_ops, F, A, topk, True, return_scores=True)
+    recs, sc = hip_ops.to_host(recs), hip_ops.to_host(sc)
+    rows = np.linspace(0, c['shape'][0] - 1, 1500).astype(np.int64)
+    o_sigma, o_V, o_recs, o_scores, gap = _oracle_side(c, rank, topk, rows)
+    assert np.abs(hip_ops.to_host(sigma) / o_sigma - 1).max() < 1e-9
+    ok = gap > 1e-9
+    assert (recs[rows][ok] == o_recs[ok]).all(), int((recs[rows][ok] != o_recs[ok]).any(axis=1).sum())
+    assert np.allclose(sc[rows][ok], o_scores[ok], rtol=1e-7, atol=1e-9)
+    # properties on ALL users
+    assert (np.diff(sc, axis=1) <= 0).all()
+    seen = sps.csr_matrix((np.ones_like(c['values']), c['indices'], c['indptr']), shape=c['shape'])
+    hit = seen[np.repeat(np.arange(c['shape'][0]), topk), recs.ravel()]
+    assert hit.sum() == 0
+    recs2 = hip_ops.to_host(scoring.recommend(hip_ops, F, A, topk, True))
+    assert np.array_equal(recs, recs2)
+    A2 = hip_ops.csr(c['indptr'], c['indices'], 3.0 * c['values'], c['shape'])   # scores scale, order does not
+    recs3, sc3 = scoring.recommend(hip_ops, F, A2, topk, True, return_scores=True)
+    assert np.array_equal(recs, hip_ops.to_host(recs3))
+    assert np.allclose(hip_ops.to_host(sc3), 3.0 * sc, rtol=1e-12)
+
+
+def test_build_returns_user_factors(hip_ops):
+    g = load_golden('svd_warm')
+    m = SVDModel(GoldenData(g), ops=hip_ops)
+    m.verbose = False
+    m.rank = int(g['rank'])
+    m.build(return_factors=True)
+    U = m.factors[m.data.fields.userid]
+    V = m.factors[m.data.fields.itemid]
+    s = m.factors['singular_values']
+    A = orc.get_training_matrix(g['train_idx'], g['train_val'], tuple(g['train_shape']), dtype=np.float64)
+    assert np.abs(U.T @ U - np.eye(len(s))).max() < 1e-9
+    assert np.abs(A @ V - U * s).max() < 1e-8 * s[0]
