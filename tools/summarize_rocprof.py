@@ -1,0 +1,63 @@
+"""Condenses rocprofv3 CSV output into small text summaries that fit in the repo (profiles/).
+
+usage: python tools/summarize_rocprof.py <rocprof_output_dir> <summary_out.txt>
+Handles --kernel-trace --stats (per-kernel table) and --pmc (per-kernel counter sums / launch).
+"""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+
+def short(name, n=70):
+    name = name.split('(')[0]
+    return name if len(name) <= n else name[:n - 3] + '...'
+
+
+def main(src, dst):
+    lines = []
+    for path in sorted(glob.glob(os.path.join(src, '**', '*.csv'), recursive=True)):
+        base = os.path.basename(path)
+        with open(path, newline='') as f:
+            rows = list(csv.DictReader(f))
+        if not rows:
+            continue
+        cols = list(rows[0].keys())
+        lines.append('## %s  (%d rows)  columns: %s' % (base, len(rows), ', '.join(cols)))
+        if 'kernel_stats' in base or ('Calls' in cols and 'AverageNs' in cols):
+            lines.append('%-72s %8s %14s %12s %7s' % ('kernel', 'calls', 'total_ms', 'avg_us', 'pct'))
+            for r in rows[:40]:
+                lines.append('%-72s %8s %14.3f %12.2f %7s' % (short(r['Name']), r['Calls'],
+                             float(r['TotalDurationNs']) / 1e6, float(r['AverageNs']) / 1e3, r.get('Percentage', '')))
+        elif 'counter_collection' in base or 'Counter_Name' in cols:
+            agg = defaultdict(lambda: [0.0, set()])
+            for r in rows:
+                k = (short(r.get('Kernel_Name', '?')), r['Counter_Name'])
+                agg[k][0] += float(r['Counter_Value'])
+                agg[k][1].add(r.get('Dispatch_Id', len(agg[k][1])))
+            lines.append('%-72s %-22s %10s %18s %18s' % ('kernel', 'counter', 'launches', 'sum', 'per_launch'))
+            for (kn, cn), (tot, disp) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:60]:
+                n = max(len(disp), 1)
+                lines.append('%-72s %-22s %10d %18.1f %18.1f' % (kn, cn, n, tot, tot / n))
+        elif 'kernel_trace' in base:
+            agg = defaultdict(lambda: [0, 0.0, None])
+            for r in rows:
+                d = float(r['End_Timestamp']) - float(r['Start_Timestamp'])
+                a = agg[short(r['Kernel_Name'])]
+                a[0] += 1
+                a[1] += d
+                a[2] = (r.get('VGPR_Count'), r.get('Accum_VGPR_Count'), r.get('SGPR_Count'), r.get('LDS_Block_Size'),
+                        r.get('Workgroup_Size'), r.get('Grid_Size'))
+            lines.append('%-72s %8s %14s %12s  %s' % ('kernel', 'calls', 'total_ms', 'avg_us', '(vgpr, agpr, sgpr, lds, wg, grid) of last launch'))
+            for kn, (n, tot, res) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+                lines.append('%-72s %8d %14.3f %12.2f  %s' % (kn, n, tot / 1e6, tot / n / 1e3, res))
+        lines.append('')
+    os.makedirs(os.path.dirname(os.path.abspath(dst)), exist_ok=True)
+    with open(dst, 'w') as f:
+        f.write('\n'.join(lines) + '\n')
+    print('\n'.join(lines[:80]))
+
+
+if __name__ == '__main__':
+    main(sys.argv[1], sys.argv[2])
