@@ -112,11 +112,17 @@ int32_t pk_candidate_capacity(int32_t topk);
 /* Streams all item tiles against 32-user groups; keeps the KC best (fp32 score, item) pairs of
  * each user among items NOT in the user's seen list (seen_ptr == NULL: no filtering).
  * cand_* are [n_users_pad x KC] with n_users_pad = 32*ceil(n_users/32); unused slots have idx -1.
- * seen lists must be sorted ascending per user (CSR canonical form). */
+ * seen lists must be sorted ascending per user (CSR canonical form).
+ * The item range is swept in chunks of `tiles_per_chunk` 32-item tiles, one launch per chunk, so the
+ * packed item factors of a chunk stay resident in the 4 MiB per-XCD L2 while every workgroup streams
+ * them; the per-user selection state is parked in `state_dev` between launches. */
+int64_t pk_score_state_bytes(int64_t n_users);
 int pk_score_candidates_f32(void *stream, int64_t n_users, int64_t n_items, int32_t K,
                             const float *Vp_dev, const float *Ep_dev,
                             const int64_t *seen_ptr_dev, const int32_t *seen_idx_dev,
-                            int32_t KC, float *cand_score_dev, int32_t *cand_idx_dev);
+                            int32_t KC, float *cand_score_dev, int32_t *cand_idx_dev,
+                            void *state_dev /* pk_score_state_bytes(n_users) */,
+                            int32_t tiles_per_chunk /* 0 = auto */);
 /* Exact fp64 re-scoring + final ordering (score desc, item asc).  Writes topk item ids (int64) and
  * optionally their fp64 scores.  flags[u] != 0 marks users whose result is NOT guaranteed exact by
  * the fp32 candidate pass (bit0: candidate margin below the fp32 error bound; bit1: fewer than

@@ -16,7 +16,12 @@ LIB = os.path.join(HERE, 'libpolarahip.so')
 OBJDIR = os.path.join(HERE, 'csrc', '_obj')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
-         '-I', os.path.join(ROOT, 'include')]
+         '-Wno-pass-failed', '-I', os.path.join(ROOT, 'include'),
+         # MFMA accumulators in arch VGPRs (gfx950 has a unified register file): the scoring
+         # epilogue reads them with v_max3 directly instead of 16 v_accvgpr_read per tile
+         '-mllvm', '-amdgpu-mfma-vgpr-form=1']
+if os.environ.get('PK_FAST_BUILD'):   # kernel-tuning builds: only the rank-50 / top-10 scoring instances
+    FLAGS.append('-DPK_FAST_BUILD')
 
 
 def sources():
@@ -46,11 +51,18 @@ def _compile(src, force=False, extra=()):
 
 def build(force=False, verbose=True):
     os.makedirs(OBJDIR, exist_ok=True)
+    # objects are only reusable if they were built with the same flags (e.g. PK_FAST_BUILD toggled)
+    stamp = os.path.join(OBJDIR, 'flags.txt')
+    flags_now = ' '.join(FLAGS)
+    if not os.path.exists(stamp) or open(stamp).read() != flags_now:
+        force = True
     srcs = sources()
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         results = list(ex.map(lambda s: _compile(s, force), srcs))
     objs = [o for o, _ in results]
     rebuilt = any(c for _, c in results)
+    with open(stamp, 'w') as f:
+        f.write(flags_now)
     if rebuilt or not os.path.exists(LIB):
         cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -24,10 +24,14 @@
 // After warm-up almost every tile takes the fast path: 8 v_max3 + 1 compare + 1 ballot.
 #include "pk_common.h"
 #include <math.h>
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define RING 16          // lane-private candidate ring entries
+#ifndef PK_SCORE_DEFAULT_VAR
+#define PK_SCORE_DEFAULT_VAR 0
+#endif
 #define PK_IDX_NONE 0x7fffffff
 
 // ---- ordering used everywhere: larger score first, then smaller item id ---------------------
@@ -80,51 +84,97 @@ __device__ __forceinline__ void pk_bitonic_desc(float (&key)[SLOTS], int (&val)[
     }
 }
 
-template <int KQ, int KC>
+// Per-lane state carried between the item-chunk launches of one scoring pass (global memory).
+struct LaneState {
+    int64_t sp;   // position in the user's seen list
+    float tau;    // current threshold
+    int cnt;      // entries in the lane's ring
+};
+
+// NSTEP = number of K=2 MFMA steps actually issued (ceil(rank/2) rounded up to a supported value);
+// the packed operands hold KQ = ceil(NSTEP/4) float4 groups, the tail group is only partly used.
+template <int NSTEP, int KC, int VAR>
 __global__ __launch_bounds__(256) void score_candidates_kernel(
-    const float4 *__restrict__ Vp, const float4 *__restrict__ Ep, int64_t n_users, int n_items, int n_tiles,
+    const float4 *__restrict__ Vp, const float4 *__restrict__ Ep, int64_t n_users, int n_items,
+    int tile_begin, int tile_end, int first, int last,
     const int64_t *__restrict__ seen_ptr, const int32_t *__restrict__ seen_idx,
-    float *__restrict__ cand_score, int32_t *__restrict__ cand_idx) {
+    float *__restrict__ cand_score, int32_t *__restrict__ cand_idx,
+    LaneState *__restrict__ st_lane, uint2 *__restrict__ st_ring, int ablate) {
+    constexpr int KQ = (NSTEP + 3) / 4;
     constexpr int SLOTS = (2 * RING + KC + 63) / 64;
+    // The running top-KC lists of the wave's 32 users live in LDS when they fit (KC <= 32): a flush
+    // then never touches global memory (no vmcnt drain in the middle of the MFMA stream).  They are
+    // copied from / to cand_score, cand_idx at the launch boundaries.
+    constexpr bool TOP_LDS = (KC <= 32);
     __shared__ uint2 ring_all[4][RING][64];
+    __shared__ uint2 top_all[TOP_LDS ? 4 : 1][TOP_LDS ? 32 * KC : 1];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t group = (int64_t)blockIdx.x * 4 + wave;
     if (group * 32 >= n_users) return;  // whole wave leaves; the kernel has no workgroup barrier
     uint2(*ring)[64] = ring_all[wave];
+    uint2 *top = top_all[TOP_LDS ? wave : 0];
 
     const int ul = lane & 31, hi = lane >> 5;
     const int64_t user = group * 32 + ul;
     float *my_score = cand_score + group * 32 * KC;  // this wave's [32][KC] top lists
     int32_t *my_idx = cand_idx + group * 32 * KC;
 
-    for (int s = lane; s < 32 * KC; s += 64) {
-        my_score[s] = -INFINITY;
-        my_idx[s] = -1;
-    }
-
     float4 e[KQ];
 #pragma unroll
     for (int q = 0; q < KQ; ++q) e[q] = Ep[(group * KQ + q) * 64 + lane];
 
     int64_t sp = 0, se = 0;
-    int nxt = PK_IDX_NONE;
-    if (seen_ptr != nullptr && user < n_users) {
-        sp = seen_ptr[user];
-        se = seen_ptr[user + 1];
-        if (sp < se) nxt = seen_idx[sp];
-    }
+    int nxt = PK_IDX_NONE, nxt2 = PK_IDX_NONE, nxt3 = PK_IDX_NONE;  // next three seen items (prefetch window)
     float tau = -INFINITY;
     int cnt = 0;
+    const bool has_seen = (seen_ptr != nullptr && user < n_users);
+    if (has_seen) {
+        sp = seen_ptr[user];
+        se = seen_ptr[user + 1];
+    }
+    LaneState *my_state = st_lane + group * 64 + lane;
+    uint2 *my_ring_state = st_ring + group * (RING * 64);
+    if (first) {
+        for (int s = lane; s < 32 * KC; s += 64) {
+            if (TOP_LDS) {
+                top[s] = make_uint2(__float_as_uint(-INFINITY), 0xffffffffu);
+            } else {
+                my_score[s] = -INFINITY;
+                my_idx[s] = -1;
+            }
+        }
+    } else {
+        if (TOP_LDS)
+            for (int s = lane; s < 32 * KC; s += 64) top[s] = make_uint2(__float_as_uint(my_score[s]), (unsigned)my_idx[s]);
+        // resume: restore the lane state and the ring image written by the previous chunk launch
+        const LaneState ls = *my_state;
+        if (has_seen) sp = ls.sp;
+        tau = ls.tau;
+        cnt = ls.cnt;
+        const int cmax = __builtin_amdgcn_readfirstlane((int)__reduce_max_sync(~0ull, cnt));
+        for (int i = 0; i < cmax; ++i) ring[i][lane] = my_ring_state[i * 64 + lane];
+    }
+    if (has_seen) {
+        if (sp < se) nxt = seen_idx[sp];
+        if (sp + 1 < se) nxt2 = seen_idx[sp + 1];
+        if (sp + 2 < se) nxt3 = seen_idx[sp + 2];
+    }
 
     // merge the rings of user x (lanes x, x+32) and its top list; refresh list, tau, counters
     auto flush_user = [&](int x) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
+        if (TOP_LDS) {
+            // LDS only: program order within the wave + the LDS pipe's in-order execution suffice;
+            // the barrier keeps the compiler from moving LDS accesses across the hand-off
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        }
         const int c_lo = __builtin_amdgcn_readlane(cnt, x);
         const int c_hi = __builtin_amdgcn_readlane(cnt, x + 32);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (!TOP_LDS) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         float key[SLOTS];
         int val[SLOTS];
 #pragma unroll
@@ -146,10 +196,18 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
                 }
             } else if (i < 2 * RING + KC) {
                 const int t = i - 2 * RING;
-                const int iv = my_idx[x * KC + t];
-                if (iv >= 0) {
-                    k = my_score[x * KC + t];
-                    v = iv;
+                if (TOP_LDS) {
+                    const uint2 r = top[x * KC + t];
+                    if ((int)r.y >= 0) {
+                        k = __uint_as_float(r.x);
+                        v = (int)r.y;
+                    }
+                } else {
+                    const int iv = my_idx[x * KC + t];
+                    if (iv >= 0) {
+                        k = my_score[x * KC + t];
+                        v = iv;
+                    }
                 }
             }
             key[s] = k;
@@ -160,8 +218,13 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
         for (int s = 0; s < SLOTS; ++s) {
             const int i = lane + 64 * s;
             if (i < KC) {
-                my_score[x * KC + i] = key[s];
-                my_idx[x * KC + i] = (val[s] == PK_IDX_NONE) ? -1 : val[s];
+                const int iv = (val[s] == PK_IDX_NONE) ? -1 : val[s];
+                if (TOP_LDS) {
+                    top[x * KC + i] = make_uint2(__float_as_uint(key[s]), (unsigned)iv);
+                } else {
+                    my_score[x * KC + i] = key[s];
+                    my_idx[x * KC + i] = iv;
+                }
             }
         }
         // new threshold: key of sorted element KC-1 (-inf while the list is not full)
@@ -174,66 +237,118 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
         __builtin_amdgcn_wave_barrier();
     };
 
-    for (int tile = 0; tile < n_tiles; ++tile) {
-        const int j0 = tile * 32;
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    // ---- building blocks of the tile pipeline --------------------------------------------------------
+    auto load_frags = [&](int tile, float4(&dst)[KQ]) {
         const float4 *vp = Vp + ((int64_t)tile * KQ) * 64 + lane;
 #pragma unroll
-        for (int q = 0; q < KQ; ++q) {
-            const float4 a = vp[q * 64];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, e[q].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, e[q].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, e[q].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, e[q].w, acc, 0, 0, 0);
-        }
-
-        // ---- seen-item mask of this tile for my user (bit b <-> item j0 + b) ---------------
-        const int jend = j0 + 32;
+        for (int q = 0; q < KQ; ++q) dst[q] = vp[q * 64];
+    };
+    // seen-item mask of a tile for my user (bit b <-> item 32*tile + b); advances the list cursor
+    auto walk_mask = [&](int tile) -> unsigned {
+        const int j0 = tile * 32, jend = j0 + 32;
         unsigned mask = 0;
+        if (ablate & 1) return 0u;   // tuning only: skip the seen-list walk
+        // the list cursor runs three entries ahead of its use, so the dependent load of the next
+        // seen item is (almost) never waited for: its latency hides behind whole tiles of MFMAs
         while (__any(nxt < jend)) {
             if (nxt < jend) {
                 mask |= 1u << (nxt - j0);
                 ++sp;
-                nxt = (sp < se) ? seen_idx[sp] : PK_IDX_NONE;
+                nxt = nxt2;
+                nxt2 = nxt3;
+                nxt3 = (sp + 2 < se) ? seen_idx[sp + 2] : PK_IDX_NONE;
             }
         }
         if (jend > n_items) mask |= ~0u << (n_items - j0);  // padding items of the last tile
-        if (__any(mask != 0)) {
-            const unsigned m2 = mask >> (4 * hi);
+        return mask;
+    };
+    // rare path: append the scores above tau to the lane rings (flushing full rings first)
+    auto push_candidates = [&](const float(&acc)[16], int j0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (m2 & (1u << ((r & 3) + 8 * (r >> 2)))) acc[r] = -INFINITY;
-        }
-
-        // ---- fast path: nothing in this tile beats the threshold of any user ---------------
-        float m = fmaxf(acc[0], acc[1]);
-#pragma unroll
-        for (int r = 2; r < 16; ++r) m = fmaxf(m, acc[r]);
-        if (__any(m > tau)) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                bool c = acc[r] > tau;
-                if (__any(c)) {
-                    if (__any(c && cnt == RING)) {
-                        const unsigned long long full = __ballot(cnt == RING);
-                        unsigned um = (unsigned)(full | (full >> 32));
-                        while (um) {
-                            const int x = __builtin_ctz(um);
-                            um &= um - 1;
-                            flush_user(x);
-                        }
-                        c = acc[r] > tau;
+        for (int r = 0; r < 16; ++r) {
+            bool c = acc[r] > tau;
+            if (__any(c)) {
+                if ((ablate & 4) && cnt == RING) cnt = 0;   // tuning only: drop instead of flushing
+                if (__any(c && cnt == RING)) {
+                    const unsigned long long full = __ballot(cnt == RING);
+                    unsigned um = (unsigned)(full | (full >> 32));
+                    while (um) {
+                        const int x = __builtin_ctz(um);
+                        um &= um - 1;
+                        flush_user(x);
                     }
-                    if (c) {
-                        ring[cnt][lane] = make_uint2(__float_as_uint(acc[r]),
-                                                     (unsigned)(j0 + (r & 3) + 8 * (r >> 2) + 4 * hi));
-                        ++cnt;
-                    }
+                    c = acc[r] > tau;
+                }
+                if (c) {
+                    ring[cnt][lane] = make_uint2(__float_as_uint(acc[r]),
+                                                 (unsigned)(j0 + (r & 3) + 8 * (r >> 2) + 4 * hi));
+                    ++cnt;
                 }
             }
         }
+    };
+    if constexpr (VAR == 0) {
+        // One tile per iteration; the fragments of the NEXT tile are requested before this tile's
+        // MFMAs so their L2 latency hides behind them.  MFMA/epilogue overlap comes from the other
+        // waves of the SIMD (3 per SIMD at 140 VGPRs).  An in-wave software pipeline (MFMAs of tile
+        // t+1 interleaved 1:3 with the epilogue VALU of tile t via sched_group_barrier) was measured
+        // SLOWER on MI355X (109 ms vs 97 ms per 1M x 100K pass): it drops occupancy to 2 waves/SIMD.
+        float4 a_nxt[KQ];
+        load_frags(tile_begin, a_nxt);
+        for (int tile = tile_begin; tile < tile_end; ++tile) {
+            float4 a[KQ];
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) a[q] = a_nxt[q];
+            load_frags((tile + 1 < tile_end) ? tile + 1 : tile, a_nxt);
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) {
+                if (4 * q + 0 < NSTEP) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, e[q].x, acc, 0, 0, 0);
+                if (4 * q + 1 < NSTEP) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, e[q].y, acc, 0, 0, 0);
+                if (4 * q + 2 < NSTEP) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, e[q].z, acc, 0, 0, 0);
+                if (4 * q + 3 < NSTEP) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, e[q].w, acc, 0, 0, 0);
+            }
+            // The list cursor must advance every tile; the mask itself is only needed when some
+            // RAW score beats the threshold (f32 MFMA shares the SIMD's FP32 lanes with the VALU, so
+            // every VALU instruction here is paid in MFMA time: keep the common path to
+            // 8 v_max3 + 1 compare and mask lazily).
+            const unsigned mask = walk_mask(tile);
+            float m_all = fmaxf(acc[0], acc[1]);
+#pragma unroll
+            for (int r = 2; r < 16; ++r) m_all = fmaxf(m_all, acc[r]);
+            if (!(ablate & 2) && __any(m_all > tau)) {
+                const unsigned m2 = mask >> (4 * hi);
+                float sc[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    sc[r] = (m2 & (1u << ((r & 3) + 8 * (r >> 2)))) ? -INFINITY : acc[r];
+                float m = fmaxf(sc[0], sc[1]);
+#pragma unroll
+                for (int r = 2; r < 16; ++r) m = fmaxf(m, sc[r]);
+                if (__any(m > tau)) push_candidates(sc, tile * 32);
+            }
+        }
+    }
+
+    if (!last) {
+        // park the state for the next item chunk (rings stay unsorted: no flush cost per chunk)
+        LaneState ls;
+        ls.sp = sp;
+        ls.tau = tau;
+        ls.cnt = cnt;
+        *my_state = ls;
+        const int cmax = __builtin_amdgcn_readfirstlane((int)__reduce_max_sync(~0ull, cnt));
+        __builtin_amdgcn_wave_barrier();
+        for (int i = 0; i < cmax; ++i) my_ring_state[i * 64 + lane] = ring[i][lane];
+        if (TOP_LDS)
+            for (int s = lane; s < 32 * KC; s += 64) {
+                const uint2 r = top[s];
+                my_score[s] = __uint_as_float(r.x);
+                my_idx[s] = (int)r.y;
+            }
+        return;
     }
     // final merge of whatever is left in the rings
     {
@@ -245,18 +360,31 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
             flush_user(x);
         }
     }
+    if (TOP_LDS) {
+        __builtin_amdgcn_wave_barrier();
+        for (int s = lane; s < 32 * KC; s += 64) {
+            const uint2 r = top[s];
+            my_score[s] = __uint_as_float(r.x);
+            my_idx[s] = (int)r.y;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
 // packing: f64 [n x K] -> f32 MFMA fragments, 32 rows per tile, K padded with zeros to 8*KQ
 // ------------------------------------------------------------------------------------------
-static const int kKqSet[] = {2, 4, 7, 8, 13, 16, 25, 32};
+static const int kNstepSet[] = {5, 8, 13, 16, 25, 32, 50, 64, 100, 128};
+
+static int pk_nstep(int K) {
+    const int need = (K + 1) / 2;
+    for (int n : kNstepSet)
+        if (n >= need) return n;
+    return 0;
+}
 
 extern "C" int32_t pk_pack_kq(int32_t K) {
-    const int need = (K + 7) / 8;
-    for (int kq : kKqSet)
-        if (kq >= need) return kq;
-    return 0;
+    const int n = pk_nstep(K);
+    return n ? (n + 3) / 4 : 0;
 }
 
 extern "C" int64_t pk_pack_elems(int64_t n, int32_t K) {
@@ -303,59 +431,101 @@ extern "C" int32_t pk_candidate_capacity(int32_t topk) {
     return 0;
 }
 
-template <int KQ>
-static int launch_candidates_kq(hipStream_t st, int KC, dim3 grid, const float4 *Vp, const float4 *Ep,
-                                int64_t n_users, int n_items, int n_tiles, const int64_t *seen_ptr,
-                                const int32_t *seen_idx, float *cs, int32_t *ci) {
-    switch (KC) {
-        case 16:
-            hipLaunchKernelGGL((score_candidates_kernel<KQ, 16>), grid, dim3(256), 0, st, Vp, Ep, n_users, n_items,
-                               n_tiles, seen_ptr, seen_idx, cs, ci);
-            return PK_OK;
-        case 32:
-            hipLaunchKernelGGL((score_candidates_kernel<KQ, 32>), grid, dim3(256), 0, st, Vp, Ep, n_users, n_items,
-                               n_tiles, seen_ptr, seen_idx, cs, ci);
-            return PK_OK;
-        case 64:
-            hipLaunchKernelGGL((score_candidates_kernel<KQ, 64>), grid, dim3(256), 0, st, Vp, Ep, n_users, n_items,
-                               n_tiles, seen_ptr, seen_idx, cs, ci);
-            return PK_OK;
+// L2 per XCD is 4 MiB: each launch streams an item chunk whose packed image (KQ KiB per 32-item
+// tile) stays L2-resident while every resident workgroup sweeps it.
+#define PK_CHUNK_BYTES (2560 * 1024)
+
+template <int NSTEP>
+static int launch_candidates_n(hipStream_t st, int KC, int var, int ablate, dim3 grid, const float4 *Vp, const float4 *Ep,
+                               int64_t n_users, int n_items, int n_tiles, int tiles_per_chunk,
+                               const int64_t *seen_ptr, const int32_t *seen_idx, float *cs, int32_t *ci,
+                               LaneState *st_lane, uint2 *st_ring) {
+    for (int t0 = 0; t0 < n_tiles; t0 += tiles_per_chunk) {
+        const int t1 = (t0 + tiles_per_chunk < n_tiles) ? t0 + tiles_per_chunk : n_tiles;
+        const int first = (t0 == 0), last = (t1 == n_tiles);
+#define PK_LAUNCH(KCV, VARV)                                                                                    \
+    hipLaunchKernelGGL((score_candidates_kernel<NSTEP, KCV, VARV>), grid, dim3(256), 0, st, Vp, Ep, n_users,    \
+                       n_items, t0, t1, first, last, seen_ptr, seen_idx, cs, ci, st_lane, st_ring, ablate)
+#ifdef PK_FAST_BUILD
+        if (KC != 16) return PK_E_UNSUPPORTED;
+        PK_LAUNCH(16, 0);
+#else
+        switch (KC) {
+            case 16:
+                PK_LAUNCH(16, PK_SCORE_DEFAULT_VAR);
+                break;
+            case 32:
+                PK_LAUNCH(32, PK_SCORE_DEFAULT_VAR);
+                break;
+            case 64:
+                PK_LAUNCH(64, PK_SCORE_DEFAULT_VAR);
+                break;
+            default:
+                pk_set_error("pk_score_candidates_f32: KC=%d unsupported (16, 32, 64)", KC);
+                return PK_E_UNSUPPORTED;
+        }
+#endif
+#undef PK_LAUNCH
     }
-    pk_set_error("pk_score_candidates_f32: KC=%d unsupported (16, 32, 64)", KC);
-    return PK_E_UNSUPPORTED;
+    return PK_OK;
+}
+
+extern "C" int64_t pk_score_state_bytes(int64_t n_users) {
+    const int64_t groups = pk_ceil_div(n_users, 32);
+    return groups * 64 * (int64_t)sizeof(LaneState) + groups * RING * 64 * (int64_t)sizeof(uint2);
 }
 
 extern "C" int pk_score_candidates_f32(void *stream, int64_t n_users, int64_t n_items, int32_t K,
                                        const float *Vp_dev, const float *Ep_dev, const int64_t *seen_ptr_dev,
                                        const int32_t *seen_idx_dev, int32_t KC, float *cand_score_dev,
-                                       int32_t *cand_idx_dev) {
+                                       int32_t *cand_idx_dev, void *state_dev, int32_t tiles_per_chunk) {
     PK_REQUIRE(n_users >= 1 && n_items >= 1 && n_items < 0x7fffff00LL, "pk_score_candidates_f32: bad sizes");
     const int kq = pk_pack_kq(K);
+    const int nstep = pk_nstep(K);
     PK_REQUIRE(kq > 0, "pk_score_candidates_f32: K=%d unsupported (K <= 256)", K);
     PK_REQUIRE(((uintptr_t)Vp_dev % 16) == 0 && ((uintptr_t)Ep_dev % 16) == 0, "pk_score_candidates_f32: alignment");
+    PK_REQUIRE(state_dev != nullptr && ((uintptr_t)state_dev % 16) == 0, "pk_score_candidates_f32: state buffer");
     hipStream_t st = pk_stream(stream);
     const int n_tiles = (int)pk_ceil_div(n_items, 32);
     const int64_t groups = pk_ceil_div(n_users, 32);
+    if (tiles_per_chunk <= 0) {
+        tiles_per_chunk = PK_CHUNK_BYTES / (kq * 1024);
+        if (tiles_per_chunk < 8) tiles_per_chunk = 8;
+    }
+    LaneState *st_lane = static_cast<LaneState *>(state_dev);
+    uint2 *st_ring = reinterpret_cast<uint2 *>(st_lane + groups * 64);
     dim3 grid((unsigned)pk_ceil_div(groups, 4));
     const float4 *Vp = reinterpret_cast<const float4 *>(Vp_dev);
     const float4 *Ep = reinterpret_cast<const float4 *>(Ep_dev);
     int rc = PK_E_UNSUPPORTED;
-#define PK_KQ_CASE(Q)                                                                                         \
+#define PK_N_CASE(Q)                                                                                          \
     case Q:                                                                                                   \
-        rc = launch_candidates_kq<Q>(st, KC, grid, Vp, Ep, n_users, (int)n_items, n_tiles, seen_ptr_dev,       \
-                                     seen_idx_dev, cand_score_dev, cand_idx_dev);                             \
+        rc = launch_candidates_n<Q>(st, KC, var, ablate, grid, Vp, Ep, n_users, (int)n_items, n_tiles,            \
+                                    tiles_per_chunk, seen_ptr_dev, seen_idx_dev, cand_score_dev, cand_idx_dev, \
+                                    st_lane, st_ring);                                                         \
         break;
-    switch (kq) {
-        PK_KQ_CASE(2)
-        PK_KQ_CASE(4)
-        PK_KQ_CASE(7)
-        PK_KQ_CASE(8)
-        PK_KQ_CASE(13)
-        PK_KQ_CASE(16)
-        PK_KQ_CASE(25)
-        PK_KQ_CASE(32)
+    const char *var_env = getenv("PK_SCORE_VAR");
+    const int var = var_env ? atoi(var_env) : PK_SCORE_DEFAULT_VAR;
+    (void)var;
+    const char *abl_env = getenv("PK_SCORE_ABLATE");   // kernel-tuning knob, never set in production
+    const int ablate = abl_env ? atoi(abl_env) : 0;
+    switch (nstep) {
+#ifdef PK_FAST_BUILD
+        PK_N_CASE(25)
+#else
+        PK_N_CASE(5)
+        PK_N_CASE(8)
+        PK_N_CASE(13)
+        PK_N_CASE(16)
+        PK_N_CASE(25)
+        PK_N_CASE(32)
+        PK_N_CASE(50)
+        PK_N_CASE(64)
+        PK_N_CASE(100)
+        PK_N_CASE(128)
+#endif
     }
-#undef PK_KQ_CASE
+#undef PK_N_CASE
     if (rc != PK_OK) return rc;
     PK_CHECK_LAUNCH("score_candidates_kernel");
     return PK_OK;

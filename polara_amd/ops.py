@@ -111,6 +111,8 @@ class HipOps:
             raise _lib.PolaraHipError('no HIP device visible: polara_amd has no CPU fallback')
         self.device = torch.device(device if device is not None else 'cuda:%d' % torch.cuda.current_device())
         self._gram_work = None
+        self._score_state = None
+        self.score_tiles_per_chunk = 0   # 0 = auto (L2-sized item chunks); tests force tiny chunks
         self._info = torch.zeros(2, dtype=torch.int32, device=self.device)
         # optional per-kernel HIP-event timing (bench.py): {'name': [(ev_start, ev_end, meta), ...]}
         self.timers = None
@@ -261,13 +263,18 @@ class HipOps:
     def candidate_capacity(self, topk):
         return self.lib.pk_candidate_capacity(topk)
 
-    def score_candidates(self, Vp, Ep, n_users, n_items, K, seen_ptr, seen_idx, KC):
+    def score_candidates(self, Vp, Ep, n_users, n_items, K, seen_ptr, seen_idx, KC, tiles_per_chunk=0):
         n_pad = -(-n_users // 32) * 32
+        need = self.lib.pk_score_state_bytes(n_users)
+        if self._score_state is None or self._score_state.numel() < need:
+            self._score_state = torch.empty(need, dtype=torch.uint8, device=self.device)
         cs = torch.empty(n_pad * KC, dtype=torch.float32, device=self.device)
         ci = torch.empty(n_pad * KC, dtype=torch.int32, device=self.device)
         with self._timed('score_candidates', (n_users, n_items, K)):
             _lib.check(self.lib.pk_score_candidates_f32(self.stream(), n_users, n_items, K, _ptr(Vp), _ptr(Ep),
-                                                        _ptr(seen_ptr), _ptr(seen_idx), KC, _ptr(cs), _ptr(ci)),
+                                                        _ptr(seen_ptr), _ptr(seen_idx), KC, _ptr(cs), _ptr(ci),
+                                                        _ptr(self._score_state),
+                                                        tiles_per_chunk or self.score_tiles_per_chunk),
                        'pk_score_candidates_f32')
         return cs, ci
 

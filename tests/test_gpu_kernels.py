@@ -181,6 +181,28 @@ def test_fused_scoring_pipeline_exact(hip_ops, cfg):
                     assert not (set(recs[u]) & seen), (u, cfg)
 
 
+@pytest.mark.parametrize('tiles_per_chunk', [1, 3, 17])
+def test_chunked_item_sweep_equals_single_sweep(hip_ops, tiles_per_chunk):
+    """The per-user selection state parked between item-chunk launches must make the result
+    independent of the chunking."""
+    from polara_amd import scoring
+    rng = np.random.RandomState(11)
+    n_users, n_items, K, topk = 150, 3000, 50, 10
+    V = np.linalg.qr(rng.randn(n_items, K))[0]
+    indptr, indices, values = rand_csr(rng, n_users, n_items, 40, long_rows=[(2, 2500)], empty_rows=[5])
+    T = hip_ops.csr(indptr, indices, values, (n_users, n_items))
+    F = scoring.FactorImage(hip_ops, hip_ops.to_device(V))
+    hip_ops.score_tiles_per_chunk = 10 ** 6
+    try:
+        ref, ref_s = scoring.recommend(hip_ops, F, T, topk, True, return_scores=True)
+        hip_ops.score_tiles_per_chunk = tiles_per_chunk
+        got, got_s = scoring.recommend(hip_ops, F, T, topk, True, return_scores=True)
+    finally:
+        hip_ops.score_tiles_per_chunk = 0
+    assert np.array_equal(hip_ops.to_host(ref), hip_ops.to_host(got))
+    assert np.array_equal(hip_ops.to_host(ref_s), hip_ops.to_host(got_s))
+
+
 def test_few_unseen_items_reenter_after_unseen(hip_ops):
     from polara_amd import scoring
     rng = np.random.RandomState(5)

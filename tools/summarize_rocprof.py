@@ -37,7 +37,14 @@ def main(src, dst):
                 agg[k][0] += float(r['Counter_Value'])
                 agg[k][1].add(r.get('Dispatch_Id', len(agg[k][1])))
             lines.append('%-72s %-22s %10s %18s %18s' % ('kernel', 'counter', 'launches', 'sum', 'per_launch'))
-            for (kn, cn), (tot, disp) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:60]:
+            ours = ('score_', 'spmm_', 'rescore_', 'eigh_', 'gram_', 'tsmm_', 'ttm_', 'pack_', 'axpby', 'resid', 'exact')
+            mine = {k: v for k, v in agg.items() if any(o in k[0] for o in ours)}
+            for (kn, cn), (tot, disp) in sorted(mine.items()):
+                n = max(len(disp), 1)
+                lines.append('%-72s %-22s %10d %18.1f %18.1f' % (kn, cn, n, tot, tot / n))
+            lines.append('-- other kernels (top by sum) --')
+            rest = {k: v for k, v in agg.items() if k not in mine}
+            for (kn, cn), (tot, disp) in sorted(rest.items(), key=lambda kv: -kv[1][0])[:25]:
                 n = max(len(disp), 1)
                 lines.append('%-72s %-22s %10d %18.1f %18.1f' % (kn, cn, n, tot, tot / n))
         elif 'kernel_trace' in base:
