@@ -6,9 +6,9 @@
 // whole problem lives in one CU's L1/L2 and the only thing that matters is the number of barriers:
 // a round-robin tournament gives n/2 independent row pairs per step, one __syncthreads per step.
 //
-// Row formulation: W := S (symmetric PSD), R := I.  Plane rotations are applied to ROW pairs of W
-// until all rows are mutually orthogonal; the same rotations accumulate in R.  At convergence
-// W = diag(lambda) U^T and R = U^T, i.e. row i of R is the eigenvector of lambda_i = ||W_i||.
+// Row formulation: W := S (symmetric PSD).  Plane rotations are applied to ROW pairs of W until all
+// rows are mutually orthogonal.  At convergence W = diag(lambda) U^T: lambda_i = ||W_i|| and
+// W_i / lambda_i is the eigenvector — no accumulated rotation matrix is needed.
 // One-sided Jacobi is insensitive to row scaling, which is what the whitening step needs
 // (Gram matrices of Chebyshev-filtered blocks are badly scaled by construction).
 #include "pk_common.h"
@@ -33,20 +33,53 @@ __device__ __forceinline__ void rr_pair(int m, int step, int k, int &p, int &q) 
     }
 }
 
-__global__ __launch_bounds__(EIGH_THREADS) void eigh_psd_kernel(int n, double *__restrict__ W, int64_t ldw,
-                                                                double *__restrict__ R, int64_t ldr,
+// One-sided Jacobi needs no accumulated rotation matrix for a PSD input: at convergence the rows of
+// W = J S are mutually orthogonal TO RELATIVE ACCURACY (that is the stopping rule) and W = Lambda U^T,
+// so eigenvector i is simply W_i / ||W_i|| and lambda_i = ||W_i||.  Rows that vanish exactly (an
+// exactly singular S, e.g. the all-zero matrix) are completed by Gram-Schmidt on unit vectors.
+// IN_LDS: the n x n work matrix lives in the CU's LDS (n <= 136: 148 KiB of the 160 KiB), so a
+// rotation costs LDS latency instead of an L2 round trip; larger n (<= 1024) stay L2 resident.
+// Each wave works on PW independent row pairs at a time so the three wave reductions of a pair
+// overlap with those of the other pairs (the butterfly is latency-, not throughput-bound).
+#define EIGH_PW 4   // row pairs per wave: one per 16-lane DPP row
+
+// All-reduce (sum) of a double within each 16-lane DPP row using only VALU data-parallel
+// primitives: quad_perm xor-1, xor-2, row_half_mirror, row_mirror.  No LDS traffic — the
+// ds_bpermute-based __shfl_xor version made the single CU's LDS pipe the bottleneck of the sweep.
+template <int CTRL>
+__device__ __forceinline__ double eigh_dpp_add(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return v + __hiloint2double(hi2, lo2);
+}
+__device__ __forceinline__ double eigh_row16_sum(double v) {
+    v = eigh_dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+    v = eigh_dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+    v = eigh_dpp_add<0x141>(v);  // row_half_mirror
+    v = eigh_dpp_add<0x140>(v);  // row_mirror
+    return v;
+}
+#define EIGH_LDS_MAX 136
+template <bool IN_LDS>
+__global__ __launch_bounds__(EIGH_THREADS) void eigh_psd_kernel(int n, double *__restrict__ Wg, int64_t ldwg,
+                                                                double *__restrict__ Rg, int64_t ldrg,
                                                                 double *__restrict__ evals, int max_sweeps,
                                                                 double tol, int *__restrict__ info) {
+    extern __shared__ __attribute__((aligned(16))) double eigh_smem[];
+    constexpr int NMAX = IN_LDS ? EIGH_LDS_MAX : 1024;
     __shared__ int s_rot;
-    __shared__ double s_lam[1024];
-    __shared__ int s_rank[1024];
+    __shared__ int s_flag;
+    __shared__ double s_lam[NMAX];
+    __shared__ int s_rank[NMAX];
+    __shared__ double s_vec[NMAX];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-    for (int e = tid; e < n * n; e += EIGH_THREADS) {
-        int i = e / n, j = e % n;
-        R[(int64_t)i * ldr + j] = (i == j) ? 1.0 : 0.0;
+    double *W = IN_LDS ? eigh_smem : Wg;
+    const int64_t ldw = IN_LDS ? n : ldwg;
+    if (IN_LDS) {
+        for (int e = tid; e < n * n; e += EIGH_THREADS) W[e] = Wg[(int64_t)(e / n) * ldwg + (e % n)];
     }
     __syncthreads();
 
@@ -57,40 +90,44 @@ __global__ __launch_bounds__(EIGH_THREADS) void eigh_psd_kernel(int n, double *_
         if (tid == 0) s_rot = 0;
         __syncthreads();
         for (int step = 0; step < m - 1; ++step) {
-            for (int k = wave; k < m / 2; k += EIGH_WAVES) {
-                int p, q;
-                rr_pair(m, step, k, p, q);
-                if (q >= n) continue;  // bye
+            for (int k0 = wave * EIGH_PW; k0 < m / 2; k0 += EIGH_WAVES * EIGH_PW) {
+                // lanes [16 s, 16 s + 16) of the wave own pair k0 + s; lane t of the row owns columns t + 16 e
+                const int slot = lane >> 4, t = lane & 15;
+                const int k = k0 + slot;
+                bool act = k < m / 2;
+                int p = 0, q = 0;
+                if (act) {
+                    rr_pair(m, step, k, p, q);
+                    act = q < n;  // bye
+                }
                 double *wp = W + (int64_t)p * ldw, *wq = W + (int64_t)q * ldw;
                 double alpha = 0.0, beta = 0.0, gamma = 0.0;
-                for (int c = lane; c < n; c += 64) {
-                    double a = wp[c], b = wq[c];
-                    alpha = fma(a, a, alpha);
-                    beta = fma(b, b, beta);
-                    gamma = fma(a, b, gamma);
+                if (act) {
+                    for (int c = t; c < n; c += 16) {
+                        const double a = wp[c], b = wq[c];
+                        alpha = fma(a, a, alpha);
+                        beta = fma(b, b, beta);
+                        gamma = fma(a, b, gamma);
+                    }
                 }
-                alpha = pk_wave_sum(alpha);
-                beta = pk_wave_sum(beta);
-                gamma = pk_wave_sum(gamma);
+                alpha = eigh_row16_sum(alpha);
+                beta = eigh_row16_sum(beta);
+                gamma = eigh_row16_sum(gamma);
                 // rotate only if the pair is not yet orthogonal to relative accuracy tol
-                if (gamma * gamma > tol2 * alpha * beta && gamma != 0.0) {
+                const bool rot = act && gamma * gamma > tol2 * alpha * beta && gamma != 0.0;
+                if (rot) {
                     const double zeta = (beta - alpha) / (2.0 * gamma);
-                    const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                    const double cs = 1.0 / sqrt(1.0 + t * t);
-                    const double sn = cs * t;
-                    for (int c = lane; c < n; c += 64) {
-                        double a = wp[c], b = wq[c];
+                    const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                    const double cs = 1.0 / sqrt(1.0 + tt * tt);
+                    const double sn = cs * tt;
+                    for (int c = t; c < n; c += 16) {
+                        const double a = wp[c], b = wq[c];
                         wp[c] = cs * a - sn * b;
                         wq[c] = sn * a + cs * b;
                     }
-                    double *rp = R + (int64_t)p * ldr, *rq = R + (int64_t)q * ldr;
-                    for (int c = lane; c < n; c += 64) {
-                        double a = rp[c], b = rq[c];
-                        rp[c] = cs * a - sn * b;
-                        rq[c] = sn * a + cs * b;
-                    }
-                    if (lane == 0) atomicAdd(&s_rot, 1);
                 }
+                const unsigned long long rb = __ballot(rot && t == 0);
+                if (lane == 0 && rb) atomicAdd(&s_rot, __popcll(rb));
             }
             __syncthreads();  // workgroup-scope: rows written by one wave are read by another next step
         }
@@ -98,15 +135,69 @@ __global__ __launch_bounds__(EIGH_THREADS) void eigh_psd_kernel(int n, double *_
         __syncthreads();
     }
 
-    // eigenvalues = row norms of W; rank-sort descending (ties by index)
+    // eigenvalues = row norms of W.  The rotation test gamma^2 > tol^2 alpha beta enforces mutual
+    // orthogonality to RELATIVE accuracy for every pair of rows whose squared norms do not underflow
+    // in that product; rows below 1e-100 * max (exactly singular S) escaped it, are not orthogonal
+    // and are rebuilt below.  Everything above that — including rows at 1e-15 * max, which still carry
+    // the trailing directions of a Chebyshev-filtered block — is kept and just normalised.
     for (int i = wave; i < n; i += EIGH_WAVES) {
         const double *wi = W + (int64_t)i * ldw;
         double a = 0.0;
         for (int c = lane; c < n; c += 64) a = fma(wi[c], wi[c], a);
-        a = pk_wave_sum(a);
-        if (lane == 0) s_lam[i] = sqrt(a);
+        a = sqrt(pk_wave_sum(a));
+        if (lane == 0) s_lam[i] = a;
     }
     __syncthreads();
+    if (tid == 0) {
+        double mx = 0.0;
+        for (int i = 0; i < n; ++i) mx = fmax(mx, s_lam[i]);
+        s_vec[0] = mx * 1e-100;
+    }
+    __syncthreads();
+    const double noise = s_vec[0];
+    __syncthreads();
+    for (int i = wave; i < n; i += EIGH_WAVES) {
+        double *wi = W + (int64_t)i * ldw;
+        const double a = s_lam[i];
+        const bool ok = (a > noise) && (a > 1e-290);
+        const double inv = ok ? 1.0 / a : 0.0;
+        for (int c = lane; c < n; c += 64) wi[c] *= inv;
+        if (lane == 0) s_rank[i] = ok ? 1 : 0;   // s_rank doubles as the "row is valid" flag here
+    }
+    __syncthreads();
+    // rebuild the invalid rows: Gram-Schmidt of unit vectors against all valid rows
+    for (int i = 0; i < n; ++i) {
+        if (s_rank[i]) continue;                       // uniform: shared memory
+        for (int j = 0; j < n; ++j) {
+            for (int c = tid; c < n; c += EIGH_THREADS) {
+                double v = (c == j) ? 1.0 : 0.0;
+                for (int r = 0; r < n; ++r) {
+                    if (!s_rank[r]) continue;
+                    const double *wr = W + (int64_t)r * ldw;
+                    v -= wr[j] * wr[c];
+                }
+                s_vec[c] = v;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                double nn = 0.0;
+                for (int c = 0; c < n; ++c) nn += s_vec[c] * s_vec[c];
+                s_flag = (nn > 0.25);
+                if (s_flag) {
+                    const double inv = 1.0 / sqrt(nn);
+                    double *wi = W + (int64_t)i * ldw;
+                    for (int c = 0; c < n; ++c) wi[c] = s_vec[c] * inv;
+                    s_rank[i] = 1;
+                }
+            }
+            __syncthreads();
+            const int done = s_flag;
+            __syncthreads();
+            if (done) break;
+        }
+    }
+    __syncthreads();
+    // rank-sort descending (ties by index)
     for (int i = tid; i < n; i += EIGH_THREADS) {
         const double li = s_lam[i];
         int r = 0;
@@ -118,9 +209,9 @@ __global__ __launch_bounds__(EIGH_THREADS) void eigh_psd_kernel(int n, double *_
         evals[r] = li;
     }
     __syncthreads();
-    // permute rows of R into W (scratch), fixing the sign so the largest |component| is positive
+    // emit the rows in rank order, fixing the sign so the largest |component| is positive
     for (int i = wave; i < n; i += EIGH_WAVES) {
-        const double *ri = R + (int64_t)i * ldr;
+        const double *ri = W + (int64_t)i * ldw;
         double best = 0.0;
         int bestc = 0x7fffffff;
         for (int c = lane; c < n; c += 64) {
@@ -141,13 +232,8 @@ __global__ __launch_bounds__(EIGH_THREADS) void eigh_psd_kernel(int n, double *_
             }
         }
         const double sgn = (bestc != 0x7fffffff && ri[bestc] < 0.0) ? -1.0 : 1.0;
-        double *dst = W + (int64_t)s_rank[i] * ldw;
+        double *dst = Rg + (int64_t)s_rank[i] * ldrg;
         for (int c = lane; c < n; c += 64) dst[c] = sgn * ri[c];
-    }
-    __syncthreads();
-    for (int e = tid; e < n * n; e += EIGH_THREADS) {
-        int i = e / n, j = e % n;
-        R[(int64_t)i * ldr + j] = W[(int64_t)i * ldw + j];
     }
     if (tid == 0 && info) {
         info[0] = sweep;
@@ -163,8 +249,24 @@ extern "C" int pk_eigh_psd_f64(void *stream, int32_t n, double *S_dev, int64_t l
     PK_REQUIRE(S_dev && evecs_dev && evals_dev && S_dev != evecs_dev, "pk_eigh_psd_f64: bad pointers");
     if (max_sweeps <= 0) max_sweeps = 40;
     if (tol <= 0.0) tol = 2.0 * 2.220446049250313e-16 * sqrt((double)n);  // ~ LAPACK dgesvj's sqrt(m)*eps
-    hipLaunchKernelGGL(eigh_psd_kernel, dim3(1), dim3(EIGH_THREADS), 0, pk_stream(stream), n, S_dev, lds_,
-                       evecs_dev, ldv, evals_dev, max_sweeps, tol, info_dev);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&eigh_psd_kernel<true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            EIGH_LDS_MAX * EIGH_LDS_MAX * 8);
+        if (e1 != hipSuccess) {
+            pk_set_error("pk_eigh_psd_f64: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e1));
+            return PK_E_LAUNCH;
+        }
+        attr_set = true;
+    }
+    if (n <= EIGH_LDS_MAX) {
+        hipLaunchKernelGGL(eigh_psd_kernel<true>, dim3(1), dim3(EIGH_THREADS), (size_t)n * n * sizeof(double),
+                           pk_stream(stream), n, S_dev, lds_, evecs_dev, ldv, evals_dev, max_sweeps, tol, info_dev);
+    } else {
+        hipLaunchKernelGGL(eigh_psd_kernel<false>, dim3(1), dim3(EIGH_THREADS), 0, pk_stream(stream), n, S_dev,
+                           lds_, evecs_dev, ldv, evals_dev, max_sweeps, tol, info_dev);
+    }
     PK_CHECK_LAUNCH("eigh_psd_kernel");
     return PK_OK;
 }

@@ -158,9 +158,11 @@ class HipOps:
         return DeviceCSR(self, indptr, indices, values, shape, split)
 
     def randn(self, n, m, seed):
-        g = torch.Generator(device='cpu')
+        # device-side Philox stream: identical on every rank for the same seed (the solver relies
+        # on all ranks starting from the same block), and no 50 MB host round trip
+        g = torch.Generator(device=self.device)
         g.manual_seed(int(seed))
-        return torch.randn(n, m, generator=g, dtype=torch.float64).to(self.device)
+        return torch.randn(n, m, generator=g, dtype=torch.float64, device=self.device)
 
     # ---- K1/K4 ------------------------------------------------------------------------------
     def spmm(self, A, X, out=None):

@@ -39,7 +39,7 @@ class NoComm:
 
 
 def default_block(k, n_items):
-    over = max(14, int(math.ceil(0.28 * k)))
+    over = max(14, (28 * k + 99) // 100)      # integer ceil(0.28 k): 50 -> 64, 100 -> 128 exactly
     l = k + over
     l = -(-l // 8) * 8
     return int(min(l, n_items))
@@ -186,7 +186,8 @@ def svd_topk(ops, A, k, block=None, tol=1e-12, max_outer=200, m_max=24, spread=1
         Vk = Vk[:, torch.as_tensor(order, device=Vk.device)].contiguous()
         lam_k = lam_k[order]
     sigma_k = np.sqrt(lam_k)
-    stats['final_rel_residual'] = float(res_host.max() / max(lam_k[0], 1e-300)) if stats['converged'] else None
+    stats['final_rel_residual'] = (float(res_host[:max(1, k - n_lock)].max() / max(lam_k[0], 1e-300))
+                                   if stats['converged'] else None)
     U = None
     if want_u:
         U = ops.spmm(A, Vk)

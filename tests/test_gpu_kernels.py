@@ -105,6 +105,27 @@ def test_eigh_psd_jacobi(hip_ops, n):
     assert np.abs(lam[keep] / ref[keep] - 1).max() < 1e-6
 
 
+@pytest.mark.parametrize('n', [8, 70, 130])
+def test_eigh_exactly_singular_inputs(hip_ops, n):
+    """Rows that vanish exactly are completed to an orthonormal basis (no rotation matrix is kept)."""
+    Z = np.zeros((n, n))
+    lam, C = hip_ops.eigh_psd(hip_ops.to_device(Z))
+    C = hip_ops.to_host(C)
+    assert (hip_ops.to_host(lam) == 0).all() and np.abs(C.T @ C - np.eye(n)).max() < 1e-12
+    S = np.zeros((n, n))
+    S[:3, :3] = np.array([[4., 1, 0], [1, 3, 0], [0, 0, 0]])     # exact zero rows/cols + a zero eigenvalue
+    lam, C = hip_ops.eigh_psd(hip_ops.to_device(S))
+    lam, C = hip_ops.to_host(lam), hip_ops.to_host(C)
+    assert np.allclose(lam[:2], np.linalg.eigvalsh(S)[::-1][:2]) and (lam[2:] == 0).all()
+    assert np.abs(C.T @ C - np.eye(n)).max() < 1e-12 and np.abs(S @ C - C * lam).max() < 1e-12
+    v = np.arange(1, n + 1.0)
+    S1 = np.outer(v, v)                                           # rank one, dense
+    lam, C = hip_ops.eigh_psd(hip_ops.to_device(S1))
+    lam, C = hip_ops.to_host(lam), hip_ops.to_host(C)
+    assert np.isclose(lam[0], v @ v) and np.abs(lam[1:]).max() < 1e-9 * lam[0]
+    assert np.abs(C.T @ C - np.eye(n)).max() < 1e-10
+
+
 def test_elementwise_and_small_kernels(hip_ops):
     rng = np.random.RandomState(0)
     for n in (1, 7, 1000, 100001):
