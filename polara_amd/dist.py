@@ -32,7 +32,13 @@ class TorchComm:
 
     def allreduce(self, t):
         if self.world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            if t.is_cuda and dist.get_backend(self.group) == 'gloo':
+                # debugging aid: several ranks sharing one GPU cannot use RCCL; stage through the host
+                h = t.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
             self.bytes_reduced += t.numel() * t.element_size()
             self.n_allreduce += 1
         return t
