@@ -147,6 +147,29 @@ def svd_build(svd_matrix, rank, return_factors='vh'):
     return user_factors, sigma, item_factors
 
 
+def rescale_matrix(matrix, scaling, axis, binary=True):
+    """preprocessing/matrices.py:71-93 (scaling == 1 still multiplies by ones, like the reference)."""
+    from scipy.sparse import diags
+    from scipy.sparse.linalg import norm as spnorm
+    if binary:
+        norm = np.sqrt(matrix.getnnz(axis=axis))
+    else:
+        norm = spnorm(matrix, axis=axis, ord=2)
+    scaling_values = np.power(norm, scaling - 1, where=norm != 0)
+    scaling_matrix = diags(scaling_values)
+    if axis == 0:
+        return matrix.dot(scaling_matrix)
+    return scaling_matrix.dot(matrix)
+
+
+def scaled_training_matrix(idx, val, shp, col_scaling=0.4, row_scaling=1, dtype=np.float64):
+    """ScaledMatrixMixin.get_training_matrix, models.py:891-895."""
+    m = get_training_matrix(idx, val, shp, dtype=dtype)
+    m = rescale_matrix(m, row_scaling, 1)
+    m = rescale_matrix(m, col_scaling, 0)
+    return m
+
+
 def svd_slice_recommendations(v, test_data, shape, start, stop):
     """models.py:857-861."""
     test_matrix, slice_data = get_test_matrix(test_data, shape, (start, stop))

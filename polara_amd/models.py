@@ -344,6 +344,53 @@ class SVDModel(RecommenderModel):
         return self._factor_image
 
 
+class ScaledMatrixMixin:
+    """models.py:864-895: diagonal row/column rescaling of the training matrix before the build,
+    A' = D_r A D_c with D = (sqrt(nnz per row/col))^(scaling-1)  (preprocessing/matrices.py:71-93,
+    binary norm).  A two-vector epilogue on the CSR values; scoring is unchanged."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._col_scaling = 0.4
+        self._row_scaling = 1
+        self.method = f'{self.method}-s'
+
+    @property
+    def col_scaling(self):
+        return self._col_scaling
+
+    @property
+    def row_scaling(self):
+        return self._row_scaling
+
+    @col_scaling.setter
+    def col_scaling(self, new_value):
+        if new_value != self._col_scaling:
+            self._col_scaling = new_value
+            self._recommendations = None
+
+    @row_scaling.setter
+    def row_scaling(self, new_value):
+        if new_value != self._row_scaling:
+            self._row_scaling = new_value
+            self._recommendations = None
+
+    def _training_csr(self, dtype=np.float64, ignore_feedback=False):
+        indptr, indices, values, shp = super()._training_csr(dtype=dtype, ignore_feedback=ignore_feedback)
+        row_nnz = np.diff(indptr).astype(np.float64)
+        col_nnz = np.bincount(indices, minlength=shp[1]).astype(np.float64)
+        rs = np.ones_like(row_nnz)
+        cs = np.ones_like(col_nnz)
+        np.power(np.sqrt(row_nnz), self.row_scaling - 1, where=row_nnz != 0, out=rs)
+        np.power(np.sqrt(col_nnz), self.col_scaling - 1, where=col_nnz != 0, out=cs)
+        values = (rs[np.repeat(np.arange(shp[0]), np.diff(indptr))] * values) * cs[indices]
+        return indptr, indices, values, shp
+
+
+class ScaledSVD(ScaledMatrixMixin, SVDModel):
+    """models.py:898."""
+
+
 def flatten_scores(tensor_scores, flattener=None):
     """models.py:983-1006 (tiny host glue on r2-length vectors)."""
     flattener = flattener or slice(None)

@@ -27,7 +27,7 @@ import pandas as pd
 
 import polara  # the reference
 from polara import RecommenderData, SVDModel
-from polara.recommender.models import CoffeeModel, RecommenderModel
+from polara.recommender.models import CoffeeModel, RecommenderModel, ScaledSVD
 from polara.recommender import utils as ref_utils
 from polara.lib import tensor as ref_tensor
 from polara.lib import sparse as ref_sparse
@@ -56,14 +56,16 @@ def metrics_to_dict(scores):
 
 
 def svd_fixture(name, df, data_cfg, rank, topk, filter_seen=True, feedback_threshold=None, seed=0,
-                extra_ranks=()):
+                extra_ranks=(), scaled=None):
     data = RecommenderData(df, 'userid', 'itemid', 'rating', seed=seed)
     data.verbose = False
     for k, v in data_cfg.items():
         setattr(data, k, v)
     quiet(data.prepare)
-    model = SVDModel(data, feedback_threshold=feedback_threshold)
+    model = (ScaledSVD if scaled else SVDModel)(data, feedback_threshold=feedback_threshold)
     model.verbose = False
+    if scaled:
+        model.col_scaling, model.row_scaling = scaled
     model.rank = rank
     model.topk = topk
     model.filter_seen = filter_seen
@@ -79,7 +81,10 @@ def svd_fixture(name, df, data_cfg, rank, topk, filter_seen=True, feedback_thres
     (tu, ti, tf), tshape, test_users = model._get_test_data()
 
     # ---- pin the oracle: same calls, same seed -> bit-equal --------------------------------
-    A = orc.get_training_matrix(idx, val, shp, dtype=np.float64)
+    if scaled:
+        A = orc.scaled_training_matrix(idx, val, shp, col_scaling=scaled[0], row_scaling=scaled[1])
+    else:
+        A = orc.get_training_matrix(idx, val, shp, dtype=np.float64)
     np.random.seed(seed)
     _, o_sigma, o_V = orc.svd_build(A, rank)
     assert np.array_equal(o_sigma, sigma), name
@@ -106,6 +111,8 @@ def svd_fixture(name, df, data_cfg, rank, topk, filter_seen=True, feedback_thres
                sigma=sigma, V=np.ascontiguousarray(V), recs=recs, rec_scores=o_scores,
                probe_users=probe_users, probe_scores=probe_scores, boundary_gap=gap,
                seed=np.int64(seed))
+    if scaled:
+        out['col_scaling'], out['row_scaling'] = np.float64(scaled[0]), np.float64(scaled[1])
     if data.test.holdout is not None:
         h = data.test.holdout
         out['holdout_user'] = h[userid].values.astype(np.int64)
@@ -229,6 +236,8 @@ if __name__ == '__main__':
                 dict(test_ratio=0, warm_start=False, holdout_size=1), rank=6, topk=10, seed=13)
     svd_fixture('svd_nofilter', frame(400, 260, 25, 5, 5, seed=14, min_items=10, max_items=100),
                 {}, rank=10, topk=10, filter_seen=False, seed=14)
+    svd_fixture('svd_scaled', frame(450, 300, 28, 6, 5, seed=17, min_items=10, max_items=110),
+                {}, rank=9, topk=10, seed=17, scaled=(0.4, 0.8))
     coffee_fixture('coffee_small', frame(260, 180, 22, 5, 5, seed=15, min_items=8, max_items=80),
                    dict(test_ratio=0, warm_start=False, holdout_size=1), mlrank=(6, 5, 3), topk=10,
                    seed=15)

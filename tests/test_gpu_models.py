@@ -12,7 +12,7 @@ import scipy.sparse as sps
 from conftest import load_golden, GoldenData
 from oracle import polara_oracle as orc
 from polara_amd.data import ArrayData
-from polara_amd.models import SVDModel, CoffeeModel
+from polara_amd.models import SVDModel, CoffeeModel, ScaledSVD
 from polara_amd.synth import make_workload, planted_csr, csr_to_numpy, csr_to_coo_triplets
 
 pytestmark = pytest.mark.gpu
@@ -41,6 +41,21 @@ def test_svd_model_vs_reference_golden(hip_ops, name):
     if name == 'svd_warm':
         m.rank = 5
         assert m._is_ready and np.array_equal(m.recommendations, g['recs_rank5'])
+
+
+def test_scaled_svd_vs_reference_golden(hip_ops):
+    """ScaledSVD: non-representable fp64 CSR values exercise the f64 value stream."""
+    g = load_golden('svd_scaled')
+    m = ScaledSVD(GoldenData(g), ops=hip_ops)
+    m.verbose = False
+    m.col_scaling, m.row_scaling = float(g['col_scaling']), float(g['row_scaling'])
+    m.rank, m.topk = int(g['rank']), int(g['topk'])
+    m.build()
+    assert np.allclose(m.factors['singular_values'], g['sigma'], rtol=1e-9)
+    V = m.factors[m.data.fields.itemid]
+    assert np.abs(V @ V.T - g['V'] @ g['V'].T).max() < 1e-8
+    notie = g['boundary_gap'] > 0
+    assert np.array_equal(m.recommendations[notie], g['recs'][notie])
 
 
 @pytest.mark.parametrize('name', ['coffee_small', 'coffee_warm'])

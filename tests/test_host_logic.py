@@ -11,7 +11,7 @@ from numpy_ops import NumpyOps
 from oracle import polara_oracle as orc
 from polara_amd import csr as pcsr
 from polara_amd.data import ArrayData
-from polara_amd.models import SVDModel, CoffeeModel
+from polara_amd.models import SVDModel, CoffeeModel, ScaledSVD
 from polara_amd.solver import svd_topk
 
 
@@ -105,6 +105,24 @@ def test_svd_model_orchestration_matches_reference(name):
         assert np.array_equal(m.recommendations, g['recs_rank5'])
         m.rank = 9
         assert not m._is_ready
+
+
+def test_scaled_svd_matches_reference():
+    g = load_golden('svd_scaled')
+    m = ScaledSVD(GoldenData(g), ops=NumpyOps())
+    m.verbose = False
+    m.col_scaling, m.row_scaling = float(g['col_scaling']), float(g['row_scaling'])
+    m.rank, m.topk = int(g['rank']), int(g['topk'])
+    m.build()
+    assert m.method == 'PureSVD-s'
+    assert np.allclose(m.factors['singular_values'], g['sigma'], rtol=1e-9)
+    notie = g['boundary_gap'] > 0
+    assert np.array_equal(m.recommendations[notie], g['recs'][notie])
+    # the scaled matrix itself equals the oracle's (= the reference's rescale_matrix chain)
+    ip, ix, vals, shp = m._training_csr()
+    ref = orc.scaled_training_matrix(g['train_idx'], g['train_val'], tuple(g['train_shape']),
+                                     float(g['col_scaling']), float(g['row_scaling']))
+    assert np.array_equal(ix, ref.indices) and np.allclose(vals, ref.data, rtol=1e-15)
 
 
 @pytest.mark.parametrize('name', ['coffee_small', 'coffee_warm'])

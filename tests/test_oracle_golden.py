@@ -8,13 +8,17 @@ import pytest
 from conftest import load_golden
 from oracle import polara_oracle as orc
 
-SVD_FIXTURES = ['svd_warm', 'svd_known', 'svd_fewunseen', 'svd_nofilter']
+SVD_FIXTURES = ['svd_warm', 'svd_known', 'svd_fewunseen', 'svd_nofilter', 'svd_scaled']
 
 
 @pytest.mark.parametrize('name', SVD_FIXTURES)
 def test_svd_build_matches_reference(name):
     g = load_golden(name)
-    A = orc.get_training_matrix(g['train_idx'], g['train_val'], tuple(g['train_shape']), dtype=np.float64)
+    if name == 'svd_scaled':
+        A = orc.scaled_training_matrix(g['train_idx'], g['train_val'], tuple(g['train_shape']),
+                                       float(g['col_scaling']), float(g['row_scaling']))
+    else:
+        A = orc.get_training_matrix(g['train_idx'], g['train_val'], tuple(g['train_shape']), dtype=np.float64)
     np.random.seed(int(g['seed']))
     _, sigma, V = orc.svd_build(A, int(g['rank']))
     assert np.allclose(sigma, g['sigma'], rtol=1e-10, atol=0)
