@@ -111,17 +111,23 @@ int pk_pack_frag_f32(void *stream, int64_t n, int32_t K, const double *src_dev, 
 int32_t pk_candidate_capacity(int32_t topk);
 /* Streams all item tiles against 32-user groups; keeps the KC best (fp32 score, item) pairs of
  * each user among items NOT in the user's seen list (seen_ptr == NULL: no filtering).
- * cand_* are [n_users_pad x KC] with n_users_pad = 32*ceil(n_users/32); unused slots have idx -1.
+ * cand_* are [splits x n_users_pad x KC] with n_users_pad = 32*ceil(n_users/32); unused slots have
+ * idx -1.  `splits` > 1 cuts the catalogue into that many contiguous item ranges, each swept by its
+ * own wave with its own threshold (more, smaller work items when there are few users); the per-range
+ * lists are merged by pk_rescore_topk_f64.
  * seen lists must be sorted ascending per user (CSR canonical form).
  * The item range is swept in chunks of `tiles_per_chunk` 32-item tiles, one launch per chunk, so the
  * packed item factors of a chunk stay resident in the 4 MiB per-XCD L2 while every workgroup streams
  * them; the per-user selection state is parked in `state_dev` between launches. */
-int64_t pk_score_state_bytes(int64_t n_users);
+int64_t pk_score_state_bytes(int64_t n_users, int32_t splits);
+/* recommended number of item splits for this many users (1 when the users alone fill the chip) */
+int32_t pk_score_splits(int64_t n_users, int32_t KC);
 int pk_score_candidates_f32(void *stream, int64_t n_users, int64_t n_items, int32_t K,
                             const float *Vp_dev, const float *Ep_dev,
                             const int64_t *seen_ptr_dev, const int32_t *seen_idx_dev,
-                            int32_t KC, float *cand_score_dev, int32_t *cand_idx_dev,
-                            void *state_dev /* pk_score_state_bytes(n_users) */,
+                            int32_t KC, int32_t splits /* splits*KC <= 64 */,
+                            float *cand_score_dev, int32_t *cand_idx_dev /* [splits][n_users_pad][KC] */,
+                            void *state_dev /* pk_score_state_bytes(n_users, splits) */,
                             int32_t tiles_per_chunk /* 0 = auto */);
 /* Exact fp64 re-scoring + final ordering (score desc, item asc).  Writes topk item ids (int64) and
  * optionally their fp64 scores.  flags[u] != 0 marks users whose result is NOT guaranteed exact by
@@ -130,8 +136,9 @@ int pk_score_candidates_f32(void *stream, int64_t n_users, int64_t n_items, int3
  * v_row_norm_max = max_i ||V[i,:]||_2 (<= 1 for orthonormal factors) enters the fp32 error bound. */
 int pk_rescore_topk_f64(void *stream, int64_t n_users, int64_t n_items, int32_t K,
                         const double *V_dev, int64_t ldv, const double *E_dev, int64_t lde,
-                        const int64_t *seen_ptr_dev, int32_t KC, const float *cand_score_dev,
-                        const int32_t *cand_idx_dev, int32_t topk, double v_row_norm_max,
+                        const int64_t *seen_ptr_dev, int32_t KC, int32_t splits,
+                        const float *cand_score_dev, const int32_t *cand_idx_dev, int32_t topk,
+                        double v_row_norm_max,
                         int64_t *out_idx_dev, double *out_score_dev /* or NULL */, int32_t *flags_dev);
 /* Brute-force exact path for a list of users: all n_items fp64 scores, two-class key
  * (unseen above seen, then score; the reference's downvote semantics, models.py:510-519), top-k.

@@ -41,7 +41,7 @@ __device__ __forceinline__ void pk_bitonic64(double &key, int &val, int lane) {
 // one wave per user
 __global__ __launch_bounds__(256) void rescore_topk_kernel(
     int64_t n_users, int64_t n_items, int K, const double *__restrict__ V, int64_t ldv,
-    const double *__restrict__ E, int64_t lde, const int64_t *__restrict__ seen_ptr, int KC,
+    const double *__restrict__ E, int64_t lde, const int64_t *__restrict__ seen_ptr, int KC, int splits,
     const float *__restrict__ cand_score, const int32_t *__restrict__ cand_idx, int topk, double vmax,
     int64_t *__restrict__ out_idx, double *__restrict__ out_score, int32_t *__restrict__ flags) {
     const int lane = threadIdx.x & 63;
@@ -60,25 +60,36 @@ __global__ __launch_bounds__(256) void rescore_topk_kernel(
     }
     const double enorm = sqrt(pk_wave_sum(e2));
 
+    // candidates: the union of the `splits` per-item-range top-KC lists of this user (<= 64 entries);
+    // list h of user u lives at ((h * n_pad + u) * KC)
+    const int64_t n_pad = ((n_users + 31) / 32) * 32;
     double my_s = -INFINITY;
     int my_i = PK_IDX_NONE;
-    int n_valid = 0;
-    for (int t = 0; t < KC; ++t) {
-        const int idx = cand_idx[user * KC + t];  // wave-uniform
-        if (idx < 0) continue;
-        ++n_valid;
-        const double *vr = V + (int64_t)idx * ldv;
-        double part = 0.0;
+    int n_cand = 0;
+    double tau32 = -INFINITY;   // bound on the fp32 score of every NON-candidate item
+    for (int h = 0; h < splits; ++h) {
+        const int64_t base = ((int64_t)h * n_pad + user) * KC;
+        int n_valid = 0;
+        for (int t = 0; t < KC; ++t) {
+            const int idx = cand_idx[base + t];  // wave-uniform
+            if (idx < 0) continue;
+            ++n_valid;
+            const double *vr = V + (int64_t)idx * ldv;
+            double part = 0.0;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int k = lane + 64 * g;
-            if (k < K) part = fma(ek[g], vr[k], part);
+            for (int g = 0; g < 4; ++g) {
+                const int k = lane + 64 * g;
+                if (k < K) part = fma(ek[g], vr[k], part);
+            }
+            const double s = pk_wave_sum(part);
+            if (lane == n_cand) {
+                my_s = s;
+                my_i = idx;
+            }
+            ++n_cand;
         }
-        const double s = pk_wave_sum(part);
-        if (lane == t) {
-            my_s = s;
-            my_i = idx;
-        }
+        // a full list may have left items of its range out: they score at most its KC-th entry
+        if (n_valid == KC) tau32 = fmax(tau32, (double)cand_score[base + KC - 1]);
     }
     pk_bitonic64(my_s, my_i, lane);
 
@@ -87,8 +98,7 @@ __global__ __launch_bounds__(256) void rescore_topk_kernel(
     const int64_t n_seen = seen_ptr ? (seen_ptr[user + 1] - seen_ptr[user]) : 0;
     if (n_items - n_seen < topk) {
         flag |= 2;  // seen items must re-enter the list: exact path
-    } else if (n_valid == KC) {
-        const double tau32 = (double)cand_score[user * KC + KC - 1];
+    } else if (tau32 > -INFINITY) {
         const double s_k = __shfl(my_s, topk - 1, 64);
         // |fl32(e.v) - e.v| <= (K + 3) u32 |e||v|  (input rounding + K-term fmaf chain), u32 = 2^-24
         const double bound = (double)(K + 3) * 5.9604644775390625e-08 * enorm * vmax;
@@ -103,13 +113,16 @@ __global__ __launch_bounds__(256) void rescore_topk_kernel(
 
 extern "C" int pk_rescore_topk_f64(void *stream, int64_t n_users, int64_t n_items, int32_t K, const double *V_dev,
                                    int64_t ldv, const double *E_dev, int64_t lde, const int64_t *seen_ptr_dev,
-                                   int32_t KC, const float *cand_score_dev, const int32_t *cand_idx_dev,
+                                   int32_t KC, int32_t splits, const float *cand_score_dev,
+                                   const int32_t *cand_idx_dev,
                                    int32_t topk, double v_row_norm_max, int64_t *out_idx_dev,
                                    double *out_score_dev, int32_t *flags_dev) {
     PK_REQUIRE(n_users >= 1 && K >= 1 && K <= 256 && ldv >= K && lde >= K, "pk_rescore_topk_f64: bad sizes");
-    PK_REQUIRE(KC >= 1 && KC <= 64 && topk >= 1 && topk <= KC, "pk_rescore_topk_f64: need topk <= KC <= 64");
+    PK_REQUIRE(KC >= 1 && splits >= 1 && KC * splits <= 64 && topk >= 1 && topk <= KC,
+               "pk_rescore_topk_f64: need topk <= KC and KC*splits <= 64");
     hipLaunchKernelGGL(rescore_topk_kernel, dim3((unsigned)pk_ceil_div(n_users, 4)), dim3(256), 0, pk_stream(stream),
-                       n_users, n_items, K, V_dev, ldv, E_dev, lde, seen_ptr_dev, KC, cand_score_dev, cand_idx_dev,
+                       n_users, n_items, K, V_dev, ldv, E_dev, lde, seen_ptr_dev, KC, splits, cand_score_dev,
+                       cand_idx_dev,
                        topk, v_row_norm_max, out_idx_dev, out_score_dev, flags_dev);
     PK_CHECK_LAUNCH("rescore_topk_kernel");
     return PK_OK;

@@ -96,7 +96,7 @@ struct LaneState {
 template <int NSTEP, int KC, int VAR>
 __global__ __launch_bounds__(256) void score_candidates_kernel(
     const float4 *__restrict__ Vp, const float4 *__restrict__ Ep, int64_t n_users, int n_items,
-    int tile_begin, int tile_end, int first, int last,
+    int n_tiles, int split_tiles, int chunk, int tiles_per_chunk,
     const int64_t *__restrict__ seen_ptr, const int32_t *__restrict__ seen_idx,
     float *__restrict__ cand_score, int32_t *__restrict__ cand_idx,
     LaneState *__restrict__ st_lane, uint2 *__restrict__ st_ring, int ablate) {
@@ -116,10 +116,25 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
     uint2(*ring)[64] = ring_all[wave];
     uint2 *top = top_all[TOP_LDS ? wave : 0];
 
+    // Item split: blockIdx.y = h owns the contiguous tile range [h*split_tiles, (h+1)*split_tiles) of
+    // the catalogue for ALL chunks, with its own threshold, rings, top lists and parked state, so
+    // that small user counts still fill the chip (the S partial top-KC lists are merged by the
+    // re-scoring kernel).  Launch `chunk` sweeps tiles_per_chunk tiles of every split.
+    const int split = blockIdx.y;
+    const int64_t n_groups = (n_users + 31) / 32;
+    const int t_lo = split * split_tiles;
+    const int t_hi = (t_lo + split_tiles < n_tiles) ? t_lo + split_tiles : n_tiles;
+    const int tile_begin = t_lo + chunk * tiles_per_chunk;
+    const int tile_end = (tile_begin + tiles_per_chunk < t_hi) ? tile_begin + tiles_per_chunk : t_hi;
+    const bool first = (chunk == 0);
+    const bool last = (tile_end >= t_hi);
+    if (!first && tile_begin >= t_hi) return;  // this split finished in an earlier launch
+
     const int ul = lane & 31, hi = lane >> 5;
     const int64_t user = group * 32 + ul;
-    float *my_score = cand_score + group * 32 * KC;  // this wave's [32][KC] top lists
-    int32_t *my_idx = cand_idx + group * 32 * KC;
+    const int64_t slot = (int64_t)split * n_groups + group;
+    float *my_score = cand_score + slot * 32 * KC;  // this wave's [32][KC] top lists of this split
+    int32_t *my_idx = cand_idx + slot * 32 * KC;
 
     float4 e[KQ];
 #pragma unroll
@@ -134,9 +149,19 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
         sp = seen_ptr[user];
         se = seen_ptr[user + 1];
     }
-    LaneState *my_state = st_lane + group * 64 + lane;
-    uint2 *my_ring_state = st_ring + group * (RING * 64);
+    LaneState *my_state = st_lane + slot * 64 + lane;
+    uint2 *my_ring_state = st_ring + slot * (RING * 64);
     if (first) {
+        if (has_seen && t_lo > 0) {
+            // skip the part of the seen list that belongs to earlier splits: lower_bound(item >= 32*t_lo)
+            const int target = t_lo * 32;
+            int64_t lo = sp, hi_ = se;
+            while (lo < hi_) {
+                const int64_t mid = (lo + hi_) >> 1;
+                if (seen_idx[mid] < target) lo = mid + 1; else hi_ = mid;
+            }
+            sp = lo;
+        }
         for (int s = lane; s < 32 * KC; s += 64) {
             if (TOP_LDS) {
                 top[s] = make_uint2(__float_as_uint(-INFINITY), 0xffffffffu);
@@ -268,7 +293,6 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
         for (int r = 0; r < 16; ++r) {
             bool c = acc[r] > tau;
             if (__any(c)) {
-                if ((ablate & 4) && cnt == RING) cnt = 0;   // tuning only: drop instead of flushing
                 if (__any(c && cnt == RING)) {
                     const unsigned long long full = __ballot(cnt == RING);
                     unsigned um = (unsigned)(full | (full >> 32));
@@ -294,7 +318,7 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
         // t+1 interleaved 1:3 with the epilogue VALU of tile t via sched_group_barrier) was measured
         // SLOWER on MI355X (109 ms vs 97 ms per 1M x 100K pass): it drops occupancy to 2 waves/SIMD.
         float4 a_nxt[KQ];
-        load_frags(tile_begin, a_nxt);
+        load_frags((tile_begin < n_tiles) ? tile_begin : 0, a_nxt);
         for (int tile = tile_begin; tile < tile_end; ++tile) {
             float4 a[KQ];
 #pragma unroll
@@ -437,15 +461,15 @@ extern "C" int32_t pk_candidate_capacity(int32_t topk) {
 
 template <int NSTEP>
 static int launch_candidates_n(hipStream_t st, int KC, int var, int ablate, dim3 grid, const float4 *Vp, const float4 *Ep,
-                               int64_t n_users, int n_items, int n_tiles, int tiles_per_chunk,
+                               int64_t n_users, int n_items, int n_tiles, int split_tiles, int tiles_per_chunk,
                                const int64_t *seen_ptr, const int32_t *seen_idx, float *cs, int32_t *ci,
                                LaneState *st_lane, uint2 *st_ring) {
-    for (int t0 = 0; t0 < n_tiles; t0 += tiles_per_chunk) {
-        const int t1 = (t0 + tiles_per_chunk < n_tiles) ? t0 + tiles_per_chunk : n_tiles;
-        const int first = (t0 == 0), last = (t1 == n_tiles);
+    const int n_chunks = (split_tiles + tiles_per_chunk - 1) / tiles_per_chunk;
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
 #define PK_LAUNCH(KCV, VARV)                                                                                    \
     hipLaunchKernelGGL((score_candidates_kernel<NSTEP, KCV, VARV>), grid, dim3(256), 0, st, Vp, Ep, n_users,    \
-                       n_items, t0, t1, first, last, seen_ptr, seen_idx, cs, ci, st_lane, st_ring, ablate)
+                       n_items, n_tiles, split_tiles, chunk, tiles_per_chunk, seen_ptr, seen_idx, cs, ci, st_lane, st_ring,  \
+                       ablate)
 #ifdef PK_FAST_BUILD
         if (KC != 16) return PK_E_UNSUPPORTED;
         PK_LAUNCH(16, 0);
@@ -470,38 +494,55 @@ static int launch_candidates_n(hipStream_t st, int KC, int var, int ablate, dim3
     return PK_OK;
 }
 
-extern "C" int64_t pk_score_state_bytes(int64_t n_users) {
+extern "C" int64_t pk_score_state_bytes(int64_t n_users, int32_t splits) {
+    const int64_t slots = pk_ceil_div(n_users, 32) * (splits < 1 ? 1 : splits);
+    return slots * 64 * (int64_t)sizeof(LaneState) + slots * RING * 64 * (int64_t)sizeof(uint2);
+}
+
+// How many item splits to use.  Every split pays its own threshold warm-up (measured on the
+// ML-20M-shaped workload: 2 splits at 2.1 rounds of wave slots are NOT faster), so the catalogue is
+// only cut when the user groups alone cannot fill the chip's ~2048-3072 wave slots even once;
+// limited by the 64 candidates the re-scoring wave can merge.
+extern "C" int32_t pk_score_splits(int64_t n_users, int32_t KC) {
     const int64_t groups = pk_ceil_div(n_users, 32);
-    return groups * 64 * (int64_t)sizeof(LaneState) + groups * RING * 64 * (int64_t)sizeof(uint2);
+    const int64_t slots = 256 * 8;
+    int64_t s = (groups > 0) ? slots / groups : 1;
+    const int smax = 64 / (KC > 0 ? KC : 64);
+    if (s > smax) s = smax;
+    if (s < 1) s = 1;
+    return (int32_t)s;
 }
 
 extern "C" int pk_score_candidates_f32(void *stream, int64_t n_users, int64_t n_items, int32_t K,
                                        const float *Vp_dev, const float *Ep_dev, const int64_t *seen_ptr_dev,
-                                       const int32_t *seen_idx_dev, int32_t KC, float *cand_score_dev,
-                                       int32_t *cand_idx_dev, void *state_dev, int32_t tiles_per_chunk) {
+                                       const int32_t *seen_idx_dev, int32_t KC, int32_t splits,
+                                       float *cand_score_dev, int32_t *cand_idx_dev, void *state_dev,
+                                       int32_t tiles_per_chunk) {
     PK_REQUIRE(n_users >= 1 && n_items >= 1 && n_items < 0x7fffff00LL, "pk_score_candidates_f32: bad sizes");
     const int kq = pk_pack_kq(K);
     const int nstep = pk_nstep(K);
     PK_REQUIRE(kq > 0, "pk_score_candidates_f32: K=%d unsupported (K <= 256)", K);
     PK_REQUIRE(((uintptr_t)Vp_dev % 16) == 0 && ((uintptr_t)Ep_dev % 16) == 0, "pk_score_candidates_f32: alignment");
     PK_REQUIRE(state_dev != nullptr && ((uintptr_t)state_dev % 16) == 0, "pk_score_candidates_f32: state buffer");
+    PK_REQUIRE(splits >= 1 && splits * KC <= 64, "pk_score_candidates_f32: need 1 <= splits and splits*KC <= 64");
     hipStream_t st = pk_stream(stream);
     const int n_tiles = (int)pk_ceil_div(n_items, 32);
     const int64_t groups = pk_ceil_div(n_users, 32);
+    const int split_tiles = (int)pk_ceil_div(n_tiles, splits);
     if (tiles_per_chunk <= 0) {
-        tiles_per_chunk = PK_CHUNK_BYTES / (kq * 1024);
+        tiles_per_chunk = PK_CHUNK_BYTES / (kq * 1024) / splits;   // the S chunks of a launch share the L2
         if (tiles_per_chunk < 8) tiles_per_chunk = 8;
     }
     LaneState *st_lane = static_cast<LaneState *>(state_dev);
-    uint2 *st_ring = reinterpret_cast<uint2 *>(st_lane + groups * 64);
-    dim3 grid((unsigned)pk_ceil_div(groups, 4));
+    uint2 *st_ring = reinterpret_cast<uint2 *>(st_lane + groups * splits * 64);
+    dim3 grid((unsigned)pk_ceil_div(groups, 4), (unsigned)splits);
     const float4 *Vp = reinterpret_cast<const float4 *>(Vp_dev);
     const float4 *Ep = reinterpret_cast<const float4 *>(Ep_dev);
     int rc = PK_E_UNSUPPORTED;
 #define PK_N_CASE(Q)                                                                                          \
     case Q:                                                                                                   \
         rc = launch_candidates_n<Q>(st, KC, var, ablate, grid, Vp, Ep, n_users, (int)n_items, n_tiles,            \
-                                    tiles_per_chunk, seen_ptr_dev, seen_idx_dev, cand_score_dev, cand_idx_dev, \
+                                    split_tiles, tiles_per_chunk, seen_ptr_dev, seen_idx_dev, cand_score_dev, cand_idx_dev, \
                                     st_lane, st_ring);                                                         \
         break;
     const char *var_env = getenv("PK_SCORE_VAR");

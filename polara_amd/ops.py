@@ -113,6 +113,7 @@ class HipOps:
         self._gram_work = None
         self._score_state = None
         self.score_tiles_per_chunk = 0   # 0 = auto (L2-sized item chunks); tests force tiny chunks
+        self.score_splits_override = 0   # 0 = auto (pk_score_splits)
         self._info = torch.zeros(2, dtype=torch.int32, device=self.device)
         # optional per-kernel HIP-event timing (bench.py): {'name': [(ev_start, ev_end, meta), ...]}
         self.timers = None
@@ -265,29 +266,32 @@ class HipOps:
     def candidate_capacity(self, topk):
         return self.lib.pk_candidate_capacity(topk)
 
-    def score_candidates(self, Vp, Ep, n_users, n_items, K, seen_ptr, seen_idx, KC, tiles_per_chunk=0):
+    def score_splits(self, n_users, KC):
+        return self.score_splits_override or self.lib.pk_score_splits(n_users, KC)
+
+    def score_candidates(self, Vp, Ep, n_users, n_items, K, seen_ptr, seen_idx, KC, splits=1, tiles_per_chunk=0):
         n_pad = -(-n_users // 32) * 32
-        need = self.lib.pk_score_state_bytes(n_users)
+        need = self.lib.pk_score_state_bytes(n_users, splits)
         if self._score_state is None or self._score_state.numel() < need:
             self._score_state = torch.empty(need, dtype=torch.uint8, device=self.device)
-        cs = torch.empty(n_pad * KC, dtype=torch.float32, device=self.device)
-        ci = torch.empty(n_pad * KC, dtype=torch.int32, device=self.device)
+        cs = torch.empty(splits * n_pad * KC, dtype=torch.float32, device=self.device)
+        ci = torch.empty(splits * n_pad * KC, dtype=torch.int32, device=self.device)
         with self._timed('score_candidates', (n_users, n_items, K)):
             _lib.check(self.lib.pk_score_candidates_f32(self.stream(), n_users, n_items, K, _ptr(Vp), _ptr(Ep),
-                                                        _ptr(seen_ptr), _ptr(seen_idx), KC, _ptr(cs), _ptr(ci),
+                                                        _ptr(seen_ptr), _ptr(seen_idx), KC, splits, _ptr(cs), _ptr(ci),
                                                         _ptr(self._score_state),
                                                         tiles_per_chunk or self.score_tiles_per_chunk),
                        'pk_score_candidates_f32')
         return cs, ci
 
-    def rescore_topk(self, V, E, n_items, seen_ptr, KC, cs, ci, topk, vmax, want_scores=True):
+    def rescore_topk(self, V, E, n_items, seen_ptr, KC, cs, ci, topk, vmax, want_scores=True, splits=1):
         assert V.stride(1) == 1 and E.stride(1) == 1
         n_users, K = E.shape
         out_idx = torch.empty(n_users, topk, dtype=torch.int64, device=self.device)
         out_s = self.empty(n_users, topk) if want_scores else None
         flags = torch.empty(n_users, dtype=torch.int32, device=self.device)
         _lib.check(self.lib.pk_rescore_topk_f64(self.stream(), n_users, n_items, K, _ptr(V), V.stride(0), _ptr(E),
-                                                E.stride(0), _ptr(seen_ptr), KC, _ptr(cs), _ptr(ci), topk,
+                                                E.stride(0), _ptr(seen_ptr), KC, splits, _ptr(cs), _ptr(ci), topk,
                                                 float(vmax), _ptr(out_idx), _ptr(out_s), _ptr(flags)),
                    'pk_rescore_topk_f64')
         return out_idx, out_s, flags

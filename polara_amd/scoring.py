@@ -54,14 +54,16 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
     Ep = ops.pack_frag(E)
     seen_ptr = T.indptr if filter_seen else None
     seen_idx = T.indices if filter_seen else None
-    cs, ci = ops.score_candidates(factors.Vp, Ep, n_users, n_items, K, seen_ptr, seen_idx, KC)   # K3
+    splits = ops.score_splits(n_users, KC)           # item ranges per user group (1 when users fill the chip)
+    cs, ci = ops.score_candidates(factors.Vp, Ep, n_users, n_items, K, seen_ptr, seen_idx, KC, splits)   # K3
     out_idx, out_s, flags = ops.rescore_topk(factors.V, E, n_items, seen_ptr, KC, cs, ci, topk,
-                                             factors.vmax, want_scores=True)
+                                             factors.vmax, want_scores=True, splits=splits)
     rows = torch.nonzero(flags, as_tuple=False).flatten().to(torch.int32)
     n_flag = int(rows.numel())
     if stats is not None:
         stats['flagged_users'] = n_flag
         stats['candidate_capacity'] = KC
+        stats['item_splits'] = splits
     if n_flag:
         per = max(1, int(EXACT_ROWS_BYTES // (n_items * 9 + 16)))
         for s in range(0, n_flag, per):

@@ -119,10 +119,13 @@ class NumpyOps:
             return 0
         return 16 if topk <= 10 else 32 if topk <= 24 else 64 if topk <= 52 else 0
 
+    def score_splits(self, n_users, KC):
+        return 1
+
     def pack_frag(self, M):
         return M.to(torch.float32)
 
-    def score_candidates(self, Vp, Ep, n_users, n_items, K, seen_ptr, seen_idx, KC):
+    def score_candidates(self, Vp, Ep, n_users, n_items, K, seen_ptr, seen_idx, KC, splits=1):
         s = (Ep.numpy() @ Vp.numpy().T).astype(np.float32)
         if seen_ptr is not None:
             sp = seen_ptr.numpy()
@@ -140,7 +143,7 @@ class NumpyOps:
             ci[u, :ok.sum()] = order[ok]
         return torch.from_numpy(cs.ravel()), torch.from_numpy(ci.ravel())
 
-    def rescore_topk(self, V, E, n_items, seen_ptr, KC, cs, ci, topk, vmax, want_scores=True):
+    def rescore_topk(self, V, E, n_items, seen_ptr, KC, cs, ci, topk, vmax, want_scores=True, splits=1):
         n_users, K = E.shape
         Vn, En = V.numpy(), E.numpy()
         cs = cs.numpy().reshape(-1, KC)

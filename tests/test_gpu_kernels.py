@@ -224,6 +224,35 @@ def test_chunked_item_sweep_equals_single_sweep(hip_ops, tiles_per_chunk):
     assert np.array_equal(hip_ops.to_host(ref_s), hip_ops.to_host(got_s))
 
 
+@pytest.mark.parametrize('cfg', [dict(K=50, topk=10, splits=4), dict(K=50, topk=10, splits=3),
+                                 dict(K=100, topk=20, splits=2), dict(K=24, topk=5, splits=2)])
+def test_item_splits_equal_single_range(hip_ops, cfg):
+    """Cutting the catalogue into S item ranges (own threshold/state each, merged at re-scoring) must
+    not change the result; also with ranges shorter than one chunk and more splits than tiles."""
+    from polara_amd import scoring
+    rng = np.random.RandomState(cfg['K'] + cfg['splits'])
+    K, topk = cfg['K'], cfg['topk']
+    for n_users, n_items in ((130, 2900), (40, 70)):
+        V = np.linalg.qr(rng.randn(n_items, K))[0] if n_items >= K else rng.randn(n_items, K)
+        indptr, indices, values = rand_csr(rng, n_users, n_items, min(35, n_items // 3),
+                                           long_rows=[(2, int(0.8 * n_items))], empty_rows=[5])
+        T = hip_ops.csr(indptr, indices, values, (n_users, n_items))
+        F = scoring.FactorImage(hip_ops, hip_ops.to_device(V))
+        try:
+            hip_ops.score_splits_override = 1
+            ref, ref_s = scoring.recommend(hip_ops, F, T, topk, True, return_scores=True)
+            hip_ops.score_splits_override = cfg['splits']
+            hip_ops.score_tiles_per_chunk = 7
+            st = {}
+            got, got_s = scoring.recommend(hip_ops, F, T, topk, True, return_scores=True, stats=st)
+        finally:
+            hip_ops.score_splits_override = 0
+            hip_ops.score_tiles_per_chunk = 0
+        assert st['item_splits'] == cfg['splits']
+        assert np.array_equal(hip_ops.to_host(ref), hip_ops.to_host(got))
+        assert np.array_equal(hip_ops.to_host(ref_s), hip_ops.to_host(got_s))
+
+
 def test_few_unseen_items_reenter_after_unseen(hip_ops):
     from polara_amd import scoring
     rng = np.random.RandomState(5)
