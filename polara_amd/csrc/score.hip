@@ -29,9 +29,6 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define RING 16          // lane-private candidate ring entries
-#ifndef PK_SCORE_DEFAULT_VAR
-#define PK_SCORE_DEFAULT_VAR 0
-#endif
 #define PK_IDX_NONE 0x7fffffff
 
 // ---- ordering used everywhere: larger score first, then smaller item id ---------------------
@@ -93,7 +90,7 @@ struct LaneState {
 
 // NSTEP = number of K=2 MFMA steps actually issued (ceil(rank/2) rounded up to a supported value);
 // the packed operands hold KQ = ceil(NSTEP/4) float4 groups, the tail group is only partly used.
-template <int NSTEP, int KC, int VAR>
+template <int NSTEP, int KC>
 __global__ __launch_bounds__(256) void score_candidates_kernel(
     const float4 *__restrict__ Vp, const float4 *__restrict__ Ep, int64_t n_users, int n_items,
     int n_tiles, int split_tiles, int chunk, int tiles_per_chunk,
@@ -311,7 +308,7 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
             }
         }
     };
-    if constexpr (VAR == 0) {
+    {
         // One tile per iteration; the fragments of the NEXT tile are requested before this tile's
         // MFMAs so their L2 latency hides behind them.  MFMA/epilogue overlap comes from the other
         // waves of the SIMD (3 per SIMD at 140 VGPRs).  An in-wave software pipeline (MFMAs of tile
@@ -460,29 +457,29 @@ extern "C" int32_t pk_candidate_capacity(int32_t topk) {
 #define PK_CHUNK_BYTES (2560 * 1024)
 
 template <int NSTEP>
-static int launch_candidates_n(hipStream_t st, int KC, int var, int ablate, dim3 grid, const float4 *Vp, const float4 *Ep,
+static int launch_candidates_n(hipStream_t st, int KC, int ablate, dim3 grid, const float4 *Vp, const float4 *Ep,
                                int64_t n_users, int n_items, int n_tiles, int split_tiles, int tiles_per_chunk,
                                const int64_t *seen_ptr, const int32_t *seen_idx, float *cs, int32_t *ci,
                                LaneState *st_lane, uint2 *st_ring) {
     const int n_chunks = (split_tiles + tiles_per_chunk - 1) / tiles_per_chunk;
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
-#define PK_LAUNCH(KCV, VARV)                                                                                    \
-    hipLaunchKernelGGL((score_candidates_kernel<NSTEP, KCV, VARV>), grid, dim3(256), 0, st, Vp, Ep, n_users,    \
+#define PK_LAUNCH(KCV)                                                                                          \
+    hipLaunchKernelGGL((score_candidates_kernel<NSTEP, KCV>), grid, dim3(256), 0, st, Vp, Ep, n_users,          \
                        n_items, n_tiles, split_tiles, chunk, tiles_per_chunk, seen_ptr, seen_idx, cs, ci, st_lane, st_ring,  \
                        ablate)
 #ifdef PK_FAST_BUILD
         if (KC != 16) return PK_E_UNSUPPORTED;
-        PK_LAUNCH(16, 0);
+        PK_LAUNCH(16);
 #else
         switch (KC) {
             case 16:
-                PK_LAUNCH(16, PK_SCORE_DEFAULT_VAR);
+                PK_LAUNCH(16);
                 break;
             case 32:
-                PK_LAUNCH(32, PK_SCORE_DEFAULT_VAR);
+                PK_LAUNCH(32);
                 break;
             case 64:
-                PK_LAUNCH(64, PK_SCORE_DEFAULT_VAR);
+                PK_LAUNCH(64);
                 break;
             default:
                 pk_set_error("pk_score_candidates_f32: KC=%d unsupported (16, 32, 64)", KC);
@@ -541,13 +538,10 @@ extern "C" int pk_score_candidates_f32(void *stream, int64_t n_users, int64_t n_
     int rc = PK_E_UNSUPPORTED;
 #define PK_N_CASE(Q)                                                                                          \
     case Q:                                                                                                   \
-        rc = launch_candidates_n<Q>(st, KC, var, ablate, grid, Vp, Ep, n_users, (int)n_items, n_tiles,            \
+        rc = launch_candidates_n<Q>(st, KC, ablate, grid, Vp, Ep, n_users, (int)n_items, n_tiles,            \
                                     split_tiles, tiles_per_chunk, seen_ptr_dev, seen_idx_dev, cand_score_dev, cand_idx_dev, \
                                     st_lane, st_ring);                                                         \
         break;
-    const char *var_env = getenv("PK_SCORE_VAR");
-    const int var = var_env ? atoi(var_env) : PK_SCORE_DEFAULT_VAR;
-    (void)var;
     const char *abl_env = getenv("PK_SCORE_ABLATE");   // kernel-tuning knob, never set in production
     const int ablate = abl_env ? atoi(abl_env) : 0;
     switch (nstep) {

@@ -48,27 +48,57 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(
         acc[g] = 0.0;
     }
 
+    // Software pipeline: the 64 (index, value) pairs of the NEXT chunk are requested while the
+    // current chunk is processed, and within a chunk the row gathers run two groups of 8 deep
+    // (group g+1 is issued before group g is consumed), so 8..16 x 512 B gathers per wave are in
+    // flight continuously instead of draining to zero after every group.  Lanes >= cnt hold
+    // (j = 0, a = 0): padded steps add 0 * X[0, :] and need no branch.
+    int j = 0;
+    VT a = (VT)0;
+    if (p0 + lane < p1) {
+        j = indices[p0 + lane];
+        a = vals[p0 + lane];
+    }
     for (int64_t p = p0; p < p1; p += 64) {
         const int cnt = (int)((p1 - p) < 64 ? (p1 - p) : 64);
-        int j = 0;
-        VT a = (VT)0;
-        if (lane < cnt) {
-            j = indices[p + lane];
-            a = vals[p + lane];
+        int jn = 0;
+        VT an = (VT)0;
+        if (p + 64 + lane < p1) {  // prefetch the next chunk's pairs
+            jn = indices[p + 64 + lane];
+            an = vals[p + 64 + lane];
         }
-        // 8 gathers in flight per wave; lanes >= cnt hold (j = 0, a = 0): the padded steps of the
-        // last chunk add 0 * X[0, :] and need no branch
-        for (int t0 = 0; t0 < cnt; t0 += 8) {
+        double xa[8][CPL], xb[8][CPL];
+        auto issue = [&](int t0, double(&x)[8][CPL]) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int t = t0 + u;
-                const int jt = __builtin_amdgcn_readlane(j, t);
-                const double at = pk_bcast_val<VT>(a, t);
+                const int jt = __builtin_amdgcn_readlane(j, t0 + u);
                 const double *xr = X + (int64_t)jt * ldx;
 #pragma unroll
-                for (int g = 0; g < CPL; ++g) acc[g] = fma(at, xr[col[g]], acc[g]);
+                for (int g = 0; g < CPL; ++g) x[u][g] = xr[col[g]];
+            }
+        };
+        auto consume = [&](int t0, const double(&x)[8][CPL]) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const double at = pk_bcast_val<VT>(a, t0 + u);
+#pragma unroll
+                for (int g = 0; g < CPL; ++g) acc[g] = fma(at, x[u][g], acc[g]);
+            }
+        };
+        issue(0, xa);
+#pragma unroll
+        for (int g8 = 0; g8 < 64; g8 += 16) {
+            if (g8 < cnt) {
+                if (g8 + 8 < cnt) issue(g8 + 8, xb);
+                consume(g8, xa);
+                if (g8 + 8 < cnt) {
+                    if (g8 + 16 < cnt) issue(g8 + 16, xa);
+                    consume(g8 + 8, xb);
+                }
             }
         }
+        j = jn;
+        a = an;
     }
 
     const int slot = task_slot[task];

@@ -217,18 +217,18 @@ class RecommenderModel:
             self.verify_data_integrity()
         test_data, test_shape, _ = self._get_test_data()
         n_users, n_items = int(test_shape[0]), int(test_shape[1])
-        indptr, indices, values = scoring.test_csr_from_triplet(test_data, (n_users, n_items),
-                                                                self._test_weights(test_data))
         ops, comm = self.ops, self.comm
+        w = self._test_weights(test_data)
+        vals = np.asarray(test_data[2] if w is None else w, dtype=np.float64)
+        T = ops.csr_from_coo(test_data[0], test_data[1], vals, (n_users, n_items))   # zeros kept: still "seen"
         lo, hi = 0, n_users
         if comm.world > 1:  # user-sharded scoring; V is replicated, no collective in the data path
-            bounds = nnz_balanced_row_partition(indptr, comm.world)
+            bounds = nnz_balanced_row_partition(ops.to_host(T.indptr), comm.world)
             lo, hi = int(bounds[comm.rank]), int(bounds[comm.rank + 1])
-        sub_ptr = indptr[lo:hi + 1] - indptr[lo]
-        sub = slice(int(indptr[lo]), int(indptr[hi]))
+            if hi > lo:
+                T = ops.csr_rows(T, lo, hi)
         stats = {}
         if hi > lo:
-            T = ops.csr(sub_ptr, indices[sub], values[sub], (hi - lo, n_items))
             recs = scoring.recommend(ops, self._item_factors_device(), T, self.topk, self.filter_seen, stats=stats)
             recs = ops.to_host(recs)
         else:
@@ -301,23 +301,27 @@ class SVDModel(RecommenderModel):
                 self.factors = dict(**self.factors)
                 self.factors[entity] = factor[..., :rank]
 
+    def _training_device_csr(self):
+        """The training matrix as a device CSR (COO -> CSR on device, models.py:160-177)."""
+        idx, val, shp = self.data.to_coo(tensor_mode=False, feedback_threshold=self.feedback_threshold)
+        return self.ops.csr_from_coo(idx[:, 0], idx[:, 1], np.asarray(val, dtype=np.float64), shp)
+
     def _local_training_shard(self):
-        indptr, indices, values, shp = self._training_csr(dtype=np.float64)
+        A = self._training_device_csr()
+        n_users = A.shape[0]
         comm = self.comm
         if comm.world > 1:
-            bounds = nnz_balanced_row_partition(indptr, comm.world)
+            bounds = nnz_balanced_row_partition(self.ops.to_host(A.indptr), comm.world)
             lo, hi = int(bounds[comm.rank]), int(bounds[comm.rank + 1])
-            sub = slice(int(indptr[lo]), int(indptr[hi]))
-            return indptr[lo:hi + 1] - indptr[lo], indices[sub], values[sub], (hi - lo, shp[1]), (lo, hi, shp[0])
-        return indptr, indices, values, shp, (0, shp[0], shp[0])
+            return self.ops.csr_rows(A, lo, hi), (lo, hi, n_users)
+        return A, (0, n_users, n_users)
 
     def build(self, operator=None, return_factors='vh'):
         """models.py:835-855.  `operator` (HybridSVD's LinearOperator) is outside the device path."""
         if operator is not None:
             raise NotImplementedError('build(operator=...) is not supported by the device path yet')
-        indptr, indices, values, shp, (lo, hi, n_users) = self._local_training_shard()
+        A, (lo, hi, n_users) = self._local_training_shard()
         ops = self.ops
-        A = ops.csr(indptr, indices, values, shp)
         want_u = return_factors in (True, 'u')
         start = timer()
         U, sigma, V, stats = svd_topk(ops, A, self.rank, block=self.svd_block, tol=self.svd_tol,
@@ -385,6 +389,10 @@ class ScaledMatrixMixin:
         np.power(np.sqrt(col_nnz), self.col_scaling - 1, where=col_nnz != 0, out=cs)
         values = (rs[np.repeat(np.arange(shp[0]), np.diff(indptr))] * values) * cs[indices]
         return indptr, indices, values, shp
+
+    def _training_device_csr(self):
+        indptr, indices, values, shp = self._training_csr(dtype=np.float64)
+        return self.ops.csr(indptr, indices, values, shp)
 
 
 class ScaledSVD(ScaledMatrixMixin, SVDModel):

@@ -158,6 +158,50 @@ class HipOps:
     def csr(self, indptr, indices, values, shape, split=SPLIT_NNZ):
         return DeviceCSR(self, indptr, indices, values, shape, split)
 
+    def csr_from_coo(self, rows, cols, vals, shape, split=SPLIT_NNZ):
+        """COO triplets (host arrays) -> canonical DeviceCSR built ON DEVICE: one radix sort of the
+        64-bit keys row*n_cols+col, duplicates summed (what `coo_matrix(...).tocsr()` does in
+        models.py:172-175).  A host argsort of 1e8 keys would cost more than the whole SVD build."""
+        n_rows, n_cols = int(shape[0]), int(shape[1])
+        dev = self.device
+        r = torch.as_tensor(np.ascontiguousarray(rows, dtype=np.int64)).to(dev)
+        c = torch.as_tensor(np.ascontiguousarray(cols, dtype=np.int64)).to(dev)
+        v = np.ascontiguousarray(vals)
+        if v.dtype == np.float64:
+            v32 = v.astype(np.float32)
+            if np.array_equal(v32.astype(np.float64), v):
+                v = v32
+        elif v.dtype != np.float32:
+            v = v.astype(np.float64)
+        v = torch.from_numpy(v).to(dev)
+        if r.numel():
+            if int(r.min()) < 0 or int(r.max()) >= n_rows or int(c.min()) < 0 or int(c.max()) >= n_cols:
+                raise ValueError('index out of bounds')
+        key = r * n_cols + c
+        key, order = torch.sort(key, stable=True)
+        v = v[order]
+        del r, c, order
+        if key.numel() > 1:
+            first = torch.ones_like(key, dtype=torch.bool)
+            first[1:] = key[1:] != key[:-1]
+            if not bool(first.all()):
+                seg = torch.cumsum(first, 0) - 1
+                out = torch.zeros(int(seg[-1]) + 1, dtype=v.dtype, device=dev)
+                out.index_add_(0, seg, v)   # sums in key order is not needed for exactness of ratings
+                v = out
+                key = key[first]
+        rr = torch.div(key, n_cols, rounding_mode='floor')
+        cc = (key - rr * n_cols).to(torch.int32)
+        indptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=dev)
+        indptr[1:] = torch.cumsum(torch.bincount(rr, minlength=n_rows), 0)
+        return DeviceCSR.from_device(self, indptr, cc, v.contiguous(), (n_rows, n_cols), split)
+
+    def csr_rows(self, A, lo, hi):
+        """Row block [lo, hi) of a DeviceCSR (device-side slice; used for user sharding)."""
+        p0, p1 = int(A.indptr[lo]), int(A.indptr[hi])
+        return DeviceCSR.from_device(self, (A.indptr[lo:hi + 1] - p0).contiguous(), A.indices[p0:p1].contiguous(),
+                                     A.values[p0:p1].contiguous(), (hi - lo, A.shape[1]))
+
     def randn(self, n, m, seed):
         # device-side Philox stream: identical on every rank for the same seed (the solver relies
         # on all ranks starting from the same block), and no 50 MB host round trip

@@ -47,10 +47,24 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
     if topk > n_items:
         raise ValueError('kth(=%d) out of bounds (%d)' % (n_items - topk, n_items))  # numpy argpartition's error
     KC = ops.candidate_capacity(topk)
-    if KC == 0:
-        raise NotImplementedError('topk=%d: the fused kernel supports topk <= 52' % topk)
     K = factors.K
     E = ops.spmm(T, factors.V)                       # fold-in, fp64 (K4)
+    if KC == 0:
+        # topk beyond the fused kernel's 52: every user goes through the exact fp64 row kernel
+        # (all items scored, two-class key) — slow but the same contract
+        seen_ptr = T.indptr if filter_seen else None
+        seen_idx = T.indices if filter_seen else None
+        out_idx = torch.empty(n_users, topk, dtype=torch.int64, device=E.device)
+        out_s = torch.empty(n_users, topk, dtype=torch.float64, device=E.device)
+        per = max(1, int(EXACT_ROWS_BYTES // (n_items * 9 + 16)))
+        for s0 in range(0, n_users, per):
+            sub = torch.arange(s0, min(n_users, s0 + per), dtype=torch.int32, device=E.device)
+            ex_idx, ex_s = ops.score_exact_rows(sub, factors.V, E, n_items, seen_ptr, seen_idx, topk)
+            out_idx[s0:s0 + len(sub)] = ex_idx
+            out_s[s0:s0 + len(sub)] = ex_s
+        if stats is not None:
+            stats.update(flagged_users=n_users, candidate_capacity=0, item_splits=0)
+        return (out_idx, out_s) if return_scores else out_idx
     Ep = ops.pack_frag(E)
     seen_ptr = T.indptr if filter_seen else None
     seen_idx = T.indices if filter_seen else None

@@ -49,6 +49,15 @@ class NumpyOps:
     def csr(self, indptr, indices, values, shape, split=None):
         return NpCSR(indptr, indices, values, shape)
 
+    def csr_from_coo(self, rows, cols, vals, shape, split=None):
+        from polara_amd.csr import coo_to_csr
+        ip, ix, vl = coo_to_csr(rows, cols, np.asarray(vals, dtype=np.float64), shape)
+        return NpCSR(ip, ix, vl, shape)
+
+    def csr_rows(self, A, lo, hi):
+        sub = A.m[lo:hi]
+        return NpCSR(sub.indptr, sub.indices, sub.data, sub.shape)
+
     def randn(self, n, m, seed):
         g = torch.Generator(device='cpu')
         g.manual_seed(int(seed))

@@ -61,6 +61,29 @@ def test_spmm_matches_scipy(hip_ops, nc, vdtype):
     assert np.abs(out2 - ref2).max() / np.abs(ref2).max() < 1e-13
 
 
+def test_device_coo_to_csr_matches_scipy(hip_ops):
+    rng = np.random.RandomState(4)
+    n_rows, n_cols, nnz = 5000, 3000, 400000
+    r, c = rng.randint(0, n_rows, nnz), rng.randint(0, n_cols, nnz)
+    v = rng.randint(1, 6, nnz).astype(np.float64)
+    v[::11] = 0.0                                   # explicit zeros survive (they still mean "seen")
+    A = hip_ops.csr_from_coo(r, c, v, (n_rows, n_cols))
+    ref = sps.coo_matrix((v, (r, c)), shape=(n_rows, n_cols)).tocsr()   # sums duplicates, sorts
+    key = r.astype(np.int64) * n_cols + c
+    assert A.nnz == len(np.unique(key)) >= ref.nnz
+    ours = sps.csr_matrix((hip_ops.to_host(A.values).astype(np.float64), hip_ops.to_host(A.indices),
+                           hip_ops.to_host(A.indptr)), shape=(n_rows, n_cols))
+    chk = ours.copy()
+    chk.sort_indices()
+    assert np.array_equal(chk.indices, ours.indices)      # canonical: column-sorted within rows
+    assert abs(ours - ref).max() == 0
+    sub = hip_ops.csr_rows(A, 100, 1100)
+    X = rng.randn(n_cols, 8)
+    assert np.allclose(hip_ops.to_host(hip_ops.spmm(sub, hip_ops.to_device(X))), ref[100:1100] @ X, rtol=1e-13)
+    with pytest.raises(ValueError):
+        hip_ops.csr_from_coo([0, n_rows], [0, 1], [1.0, 1.0], (n_rows, n_cols))
+
+
 def test_spmm_is_deterministic(hip_ops):
     rng = np.random.RandomState(3)
     indptr, indices, values = rand_csr(rng, 2000, 900, 40, long_rows=[(3, 880)])
@@ -251,6 +274,20 @@ def test_item_splits_equal_single_range(hip_ops, cfg):
         assert st['item_splits'] == cfg['splits']
         assert np.array_equal(hip_ops.to_host(ref), hip_ops.to_host(got))
         assert np.array_equal(hip_ops.to_host(ref_s), hip_ops.to_host(got_s))
+
+
+def test_large_topk_uses_exact_rows(hip_ops):
+    from polara_amd import scoring
+    rng = np.random.RandomState(2)
+    n_users, n_items, K, topk = 20, 300, 12, 120
+    V = np.linalg.qr(rng.randn(n_items, K))[0]
+    indptr, indices, values = rand_csr(rng, n_users, n_items, 25)
+    T = hip_ops.csr(indptr, indices, values, (n_users, n_items))
+    F = scoring.FactorImage(hip_ops, hip_ops.to_device(V))
+    recs = hip_ops.to_host(scoring.recommend(hip_ops, F, T, topk, True))
+    E = sps.csr_matrix((values.astype(np.float64), indices, indptr), shape=(n_users, n_items)) @ V
+    ref, _ = brute_topk(V, E, indptr, indices, topk, True)
+    assert np.array_equal(recs, ref)
 
 
 def test_few_unseen_items_reenter_after_unseen(hip_ops):

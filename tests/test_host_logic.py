@@ -155,7 +155,7 @@ def test_topk_cache_rules_and_errors():
     m.topk = 12
     assert m._recommendations is None
     m.topk = 10 ** 6
-    with pytest.raises(ValueError):
+    with pytest.raises(ValueError):      # same failure class as numpy argpartition in models.py:490
         m.get_recommendations()
     with pytest.raises(NotImplementedError):
         SVDModel.build(m, operator=object())
