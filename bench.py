@@ -52,6 +52,30 @@ def spmm_alg_bytes(meta):
     return nnz * (4 + vbytes) + 8 * (n_rows + 1) + 8 * nc * (n_cols + n_rows)
 
 
+def pmc_traffic():
+    """HBM/fabric bytes per launch of the two dominant kernels, from the committed rocprofv3 --pmc
+    passes of this same command (profiles/r01_bench_pmc_{fetch,write}_size.txt; separate passes, as
+    the tool requires).  FETCH_SIZE is doubled for the 16 B/lane fragment loads of the scoring kernel
+    (gfx950 counts 128 B requests as 64 B, MI355X_MICROARCH.md §HBM); the 8 B/lane SpMM gathers are
+    reported uncorrected.  Returns {} when the summaries are not there."""
+    out = {}
+    try:
+        def per_launch(fn, kernel):
+            for line in open(os.path.join(ROOT, 'profiles', fn)):
+                if kernel in line and ('FETCH_SIZE' in line or 'WRITE_SIZE' in line):
+                    return float(line.split()[-1]) * 1024.0     # KB -> bytes
+            return None
+        f_s, w_s = per_launch('r01_bench_pmc_fetch_size.txt', 'score_candidates_kernel'), per_launch('r01_bench_pmc_write_size.txt', 'score_candidates_kernel')
+        f_m, w_m = per_launch('r01_bench_pmc_fetch_size.txt', 'spmm_csr_kernel'), per_launch('r01_bench_pmc_write_size.txt', 'spmm_csr_kernel')
+        if f_s is not None and w_s is not None:
+            out['score'] = 2.0 * f_s + w_s
+        if f_m is not None and w_m is not None:
+            out['spmm'] = f_m + w_m
+    except OSError:
+        pass
+    return out
+
+
 def events_ms(pairs):
     return [e0.elapsed_time(e1) for e0, e1, _ in pairs]
 
@@ -170,12 +194,14 @@ def main():
     if rank_id != 0:
         return
     cand_avg_ms = float(np.mean(cand_ms))
+    traffic = pmc_traffic() if (args.workload == 's1m' and args.scale == 1.0 and comm.world == 1) else {}
     flops = 2.0 * (hi - lo) * n_items * rank
     achieved_tf = flops / (cand_avg_ms * 1e-3) / 1e12
     out = {
         'metric': 'users scored/sec + SVD build time', 'value': value, 'unit': 'users/s',
         'n_gpus': comm.world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
-        'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32 MFMA candidates + f64 rescoring/build',
+        'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32',
+        'dtype_detail': 'f32 MFMA candidate scoring; f64 exact re-scoring, fold-in and SVD build',
         'data': 'synthetic (planted low-rank + Zipf popularity, seeded; generated on GPU)',
         'config': {'workload': {'s1m': 'Synthetic 1M users x 100K items, ~0.1% density CSR, PureSVD rank=50, top-10, all users scored (BASELINE.json configs[1])',
                                 'ml20m': 'ML-20M-shaped synthetic 138493 x 26744, PureSVD rank=100, top-20 (BASELINE.json configs[2])',
@@ -191,18 +217,23 @@ def main():
                   'flagged_users_last_step': stats.get('flagged_users'), 'candidate_capacity': stats.get('candidate_capacity')},
         'roofline': {'kernel': 'score_candidates_kernel', 'bound': 'mfma', 'achieved': achieved_tf,
                      'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved_tf / PEAK_FP32_MFMA_TFLOPS,
-                     'traffic': None, 'launches': len(cand_ms), 'avg_ms': cand_avg_ms,
-                     'flop_per_launch': flops},
+                     'traffic': (traffic['score'] * 9 if 'score' in traffic else None),
+                     'traffic_note': 'HBM/fabric bytes per scoring pass = 9 item-chunk launches x (2*FETCH_SIZE + WRITE_SIZE) '
+                                     'of a separate rocprofv3 --pmc run (profiles/r01_bench_pmc_*.txt); algorithmic minimum ~1 GB',
+                     'launches': len(cand_ms), 'avg_ms': cand_avg_ms, 'flop_per_launch': flops},
         'roofline_build': {'kernel': 'spmm_csr_kernel', 'bound': 'hbm',
                            'achieved': float(sum(spmm_bytes) / (sum(spmm_ms) * 1e-3) / 1e9) if spmm_ms else None,
                            'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
                            'frac': float(sum(spmm_bytes) / (sum(spmm_ms) * 1e-3) / 1e9 / PEAK_HBM_GBPS) if spmm_ms else None,
-                           'traffic': None, 'launches': len(spmm_ms), 'total_ms': float(sum(spmm_ms)),
+                           'traffic': traffic.get('spmm'),
+                           'traffic_note': 'FETCH_SIZE + WRITE_SIZE per launch (profiles/r01_bench_pmc_*.txt): ~11x the '
+                                           'algorithmic bytes - the 512 B row gathers of the dense block miss the 4 MiB L2',
+                           'launches': len(spmm_ms), 'total_ms': float(sum(spmm_ms)),
                            'bytes_total': float(sum(spmm_bytes))},
         'gen_s': t_gen,
     }
     if not args.no_cpu_baseline and comm.world == 1:
-        n_score = args.cpu_users or min(n_users, max(256, int(2.0e8 / max(n_items, 1))))   # ~2 chunks of the 1 GB rule
+        n_score = args.cpu_users or min(n_users, 20000)   # ~16 chunks of the reference's 1 GB rule on S-1M, ~10 s
         build_rows = min(n_users, max(1000, int(5e6 / max(nnz / n_users, 1))))
         base, cpu_recs = cpu_baseline(c, np.ascontiguousarray(ops.to_host(V)), rank, topk, n_score, build_rows)
         same = float((ops.to_host(recs[:n_score]) == cpu_recs).all(axis=1).mean())
