@@ -120,8 +120,11 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     from polara_amd.dist import init_from_env
     from polara_amd.solver import NoComm
+    debug_backend = os.environ.get('PK_BENCH_DEBUG_BACKEND')   # e.g. 'gloo': N ranks sharing ONE GPU (path check only)
     if world > 1:
-        comm = init_from_env()
+        if debug_backend:
+            os.environ['LOCAL_RANK'] = '0'
+        comm = init_from_env(backend=debug_backend)
     else:
         torch.cuda.set_device(0)
         comm = NoComm()
@@ -185,7 +188,7 @@ def main():
     fold_ms = events_ms(ops.timers.get('spmm', []))
     ops.timers = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if debug_backend == 'gloo' else dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps
@@ -228,6 +231,10 @@ def main():
                            'traffic': traffic.get('spmm'),
                            'traffic_note': 'FETCH_SIZE + WRITE_SIZE per launch (profiles/r01_bench_pmc_*.txt): ~11x the '
                                            'algorithmic bytes - the 512 B row gathers of the dense block miss the 4 MiB L2',
+                           'gather_GBps': (float(sum(m[2] * m[3] * 8.0 for _, _, m in spmm_ev) / (sum(spmm_ms) * 1e-3) / 1e9)
+                                           if spmm_ms else None),
+                           'gather_note': 'nnz*nc*8 bytes of dense-row gathers per launch / time: the traffic that actually '
+                                          'bounds this kernel (profiles/r01_spmm_probe.json)',
                            'launches': len(spmm_ms), 'total_ms': float(sum(spmm_ms)),
                            'bytes_total': float(sum(spmm_bytes))},
         'gen_s': t_gen,
