@@ -272,14 +272,16 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
         if (ablate & 1) return 0u;   // tuning only: skip the seen-list walk
         // the list cursor runs three entries ahead of its use, so the dependent load of the next
         // seen item is (almost) never waited for: its latency hides behind whole tiles of MFMAs
-        while (__any(nxt < jend)) {
-            if (nxt < jend) {
-                mask |= 1u << (nxt - j0);
-                ++sp;
-                nxt = nxt2;
-                nxt2 = nxt3;
-                nxt3 = (sp + 2 < se) ? seen_idx[sp + 2] : PK_IDX_NONE;
-            }
+        if (__any(nxt < jend)) {
+            do {
+                if (nxt < jend) {
+                    mask |= 1u << (nxt - j0);
+                    ++sp;
+                    nxt = nxt2;
+                    nxt2 = nxt3;
+                    nxt3 = (sp + 2 < se) ? seen_idx[sp + 2] : PK_IDX_NONE;
+                }
+            } while (__any(nxt < jend));
         }
         if (jend > n_items) mask |= ~0u << (n_items - j0);  // padding items of the last tile
         return mask;
@@ -314,6 +316,9 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
         // waves of the SIMD (3 per SIMD at 140 VGPRs).  An in-wave software pipeline (MFMAs of tile
         // t+1 interleaved 1:3 with the epilogue VALU of tile t via sched_group_barrier) was measured
         // SLOWER on MI355X (109 ms vs 97 ms per 1M x 100K pass): it drops occupancy to 2 waves/SIMD.
+        // Also measured and rejected: two alternating fragment buffers with the tile body unrolled
+        // twice (no a <- a_nxt moves): 112 ms; one shared copy of the flush code with a resumable
+        // scan instead of 16 inlined copies: 95 ms vs 90 ms.
         float4 a_nxt[KQ];
         load_frags((tile_begin < n_tiles) ? tile_begin : 0, a_nxt);
         for (int tile = tile_begin; tile < tile_end; ++tile) {
@@ -340,14 +345,20 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
 #pragma unroll
             for (int r = 2; r < 16; ++r) m_all = fmaxf(m_all, acc[r]);
             if (!(ablate & 2) && __any(m_all > tau)) {
-                const unsigned m2 = mask >> (4 * hi);
                 float sc[16];
+                float m = m_all;
+                if (__any(mask != 0)) {
+                    const unsigned m2 = mask >> (4 * hi);
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    sc[r] = (m2 & (1u << ((r & 3) + 8 * (r >> 2)))) ? -INFINITY : acc[r];
-                float m = fmaxf(sc[0], sc[1]);
+                    for (int r = 0; r < 16; ++r)
+                        sc[r] = (m2 & (1u << ((r & 3) + 8 * (r >> 2)))) ? -INFINITY : acc[r];
+                    m = fmaxf(sc[0], sc[1]);
 #pragma unroll
-                for (int r = 2; r < 16; ++r) m = fmaxf(m, sc[r]);
+                    for (int r = 2; r < 16; ++r) m = fmaxf(m, sc[r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sc[r] = acc[r];
+                }
                 if (__any(m > tau)) push_candidates(sc, tile * 32);
             }
         }

@@ -492,16 +492,32 @@ class CoffeeModel(RecommenderModel):
     def build(self):
         """models.py:1009-1024."""
         idx, val, shp = self.data.to_coo(tensor_mode=True)
-        ops = self.ops
+        ops, comm = self.ops, self.comm
+        user_range = None
+        if comm.world > 1:
+            # users are sharded in nnz-balanced contiguous blocks; items / feedback factors replicated
+            order = np.argsort(idx[:, 0], kind='stable')
+            idx, val = idx[order], val[order]
+            counts = np.bincount(idx[:, 0], minlength=shp[0])
+            bounds = nnz_balanced_row_partition(np.r_[0, np.cumsum(counts)], comm.world)
+            lo, hi = int(bounds[comm.rank]), int(bounds[comm.rank + 1])
+            sel = (idx[:, 0] >= lo) & (idx[:, 0] < hi)
+            idx = idx[sel].copy()
+            val = val[sel]
+            idx[:, 0] -= lo
+            user_range = (lo, hi)
         start = timer()
         u0, u1, u2, core, trace = tucker.hooi(ops, idx, val, shp, self.mlrank, num_iters=self.num_iters,
                                               growth_tol=self.growth_tol, seed=self.seed,
-                                              verbose=self.show_output)
+                                              verbose=self.show_output, comm=comm, user_range=user_range)
         ops.synchronize()
         self._track(start)
         self.core_norm_trace = trace
         userid, itemid, feedback = self.data.fields
-        self.factors[userid] = ops.to_host(u0)
+        u0_host = ops.to_host(u0)
+        if comm.world > 1:
+            u0_host = comm.gather_rows(u0_host, shp[0], u0_host.shape[1], dtype=np.float64)
+        self.factors[userid] = u0_host
         self.factors[itemid] = ops.to_host(u1)
         self.factors[feedback] = ops.to_host(u2)
         self.factors['core'] = ops.to_host(core)

@@ -12,6 +12,7 @@ import numpy as np
 import torch
 
 from .csr import build_row_tasks
+from .solver import NoComm
 
 
 class ModePlan:
@@ -49,12 +50,27 @@ def _polish(ops, U):
     return ops.tsmm(U, Cm.contiguous())
 
 
-def left_svd(ops, M, r, want_v=False):
+def left_svd(ops, M, r, want_v=False, comm=None, n_total=None):
     """Top-r left singular vectors / values of dense M (n x m), descending; optionally V^T (r x m).
-    Mirrors what `svds(M, k=r)` returns to hooi (after its [::-1] reordering)."""
+    Mirrors what `svds(M, k=r)` returns to hooi (after its [::-1] reordering).
+    With `comm` the ROWS of M are sharded over ranks (the user mode): the m x m Gram matrix is
+    all-reduced, the eigenproblem is solved redundantly and each rank keeps its rows of U."""
     n, m = M.shape
-    if r > min(n, m):
-        raise ValueError('rank %d exceeds min(shape)=%d' % (r, min(n, m)))
+    n_all = n if n_total is None else n_total
+    if r > min(n_all, m):
+        raise ValueError('rank %d exceeds min(shape)=%d' % (r, min(n_all, m)))
+    if comm is not None and comm.world > 1:
+        if n_all < m:
+            raise NotImplementedError('row-sharded unfolding with fewer rows than columns')
+        lam, Cm = ops.eigh_psd(comm.allreduce(ops.gram(M)))
+        W = Cm[:, :r].contiguous()
+        s = torch.sqrt(torch.clamp_min(lam[:r], 0.0))
+        U = ops.tsmm(M, W)
+        U = ops.scale_cols(U, torch.where(s > 0, 1.0 / s, torch.zeros_like(s)))
+        G = comm.allreduce(ops.gram(U))          # Newton-Schulz polish with the GLOBAL Gram
+        Cn = 1.5 * torch.eye(r, dtype=torch.float64, device=G.device) - 0.5 * G
+        U = ops.tsmm(U, Cn.contiguous())
+        return U, s, (W.t().contiguous() if want_v else None)
     if n >= m:
         lam, Cm = ops.eigh_psd(ops.gram(M))
         W = Cm[:, :r].contiguous()
@@ -76,13 +92,24 @@ def left_svd(ops, M, r, want_v=False):
     return U, s, Vt
 
 
-def hooi(ops, idx, val, shape, core_shape, num_iters=25, growth_tol=0.01, seed=None, verbose=False):
+def hooi(ops, idx, val, shape, core_shape, num_iters=25, growth_tol=0.01, seed=None, verbose=False,
+         comm=None, user_range=None):
     """Returns (u0, u1, u2, core, trace): device fp64 factors [n_mode x r_mode] with orthonormal
     columns ordered by descending singular value, core [r0 x r1 x r2], and the per-iteration core
-    norms (lib/tensor.py:82-88)."""
+    norms (lib/tensor.py:82-88).
+
+    Multi-GPU: pass `comm` and `user_range=(lo, hi)`; `idx` then holds only the nnz of
+    users [lo, hi) (user indices already re-based to 0), the mode-0 factor u0 is returned as this
+    rank's [hi-lo x r0] row block, the mode-1 / mode-2 TTMs (which reduce over users) are
+    all-reduced, and every rank holds identical u1, u2, core."""
+    comm = comm or NoComm()
     idx = np.asarray(idx)
     r0, r1, r2 = (int(r) for r in core_shape)
     n0, n1, n2 = (int(s) for s in shape)
+    n0_total = n0
+    if user_range is not None:
+        n0 = int(user_range[1] - user_range[0])   # local rows of the user mode
+        shape = (n0, n1, n2)
     # same random start as the reference (lib/tensor.py:57-63)
     random_state = np.random if seed is None else np.random.RandomState(seed)
     u1 = np.linalg.qr(random_state.rand(n1, r1), mode='reduced')[0]
@@ -99,9 +126,9 @@ def hooi(ops, idx, val, shape, core_shape, num_iters=25, growth_tol=0.01, seed=N
     trace = []
     ss = vv = u0 = None
     for i in range(num_iters):
-        u0, _, _ = left_svd(ops, ttm(ops, mp0, u2, u1), r0)
-        u1, _, _ = left_svd(ops, ttm(ops, mp1, u2, u0), r1)
-        u2, ss, vv = left_svd(ops, ttm(ops, mp2, u1, u0), r2, want_v=True)
+        u0, _, _ = left_svd(ops, ttm(ops, mp0, u2, u1), r0, comm=comm, n_total=n0_total)   # rows = local users
+        u1, _, _ = left_svd(ops, comm.allreduce(ttm(ops, mp1, u2, u0)), r1)
+        u2, ss, vv = left_svd(ops, comm.allreduce(ttm(ops, mp2, u1, u0)), r2, want_v=True)
         g_norm_new = float(torch.linalg.vector_norm(ss).item())
         g_growth = (g_norm_new - g_norm_old) / g_norm_new
         g_norm_old = g_norm_new

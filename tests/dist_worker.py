@@ -12,7 +12,7 @@ import numpy as np
 from conftest import load_golden, GoldenData
 from numpy_ops import NumpyOps
 from polara_amd.dist import init_from_env
-from polara_amd.models import SVDModel
+from polara_amd.models import SVDModel, CoffeeModel
 
 
 def main():
@@ -35,6 +35,20 @@ def main():
               and np.allclose(V @ V.T, g['V'] @ g['V'].T, atol=1e-8))
         out[name] = bool(ok)
         out[name + '_allreduces'] = comm.n_allreduce
+    for name in ('coffee_small', 'coffee_warm'):
+        # sharded HOOI: user-mode factor rows stay local, item/feedback-mode TTMs are all-reduced
+        g = load_golden(name)
+        m = CoffeeModel(GoldenData(g), ops=NumpyOps(), comm=comm)
+        m.verbose = False
+        m.mlrank, m.topk, m.seed = tuple(int(x) for x in g['mlrank']), int(g['topk']), int(g['seed'])
+        m.num_iters, m.growth_tol = int(g['num_iters']), float(g['growth_tol'])
+        m.build()
+        f = m.data.fields
+        proj_ok = all(np.abs(m.factors[k] @ m.factors[k].T - ref @ ref.T).max() < 1e-8
+                      for k, ref in ((f.userid, g['u0']), (f.itemid, g['u1']), (f.feedback, g['u2'])))
+        notie = g['boundary_gap'] > 0
+        out[name] = bool(proj_ok and np.allclose(m.core_norm_trace, g['core_norm_trace'], rtol=1e-9)
+                          and np.array_equal(m.get_recommendations()[notie], g['recs'][notie]))
     comm.barrier()
     if comm.rank == 0:
         print('DIST_RESULT', out)
