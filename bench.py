@@ -43,6 +43,8 @@ def parse():
     ap.add_argument('--workload', default='s1m', choices=['s1m', 'ml20m', 'ml1m'])
     ap.add_argument('--scale', type=float, default=1.0, help='shrink users/items (debug only; invalidates the number)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--item-order', default='popularity', choices=['popularity', 'natural'],
+                    help='internal item order of the device path (models.py does the same relabelling)')
     ap.add_argument('--cpu-users', type=int, default=0, help='users in the CPU scoring sample (0 = auto)')
     return ap.parse_args()
 
@@ -152,7 +154,14 @@ def main():
     lo, hi = int(bounds[rank_id]), int(bounds[rank_id + 1])
     sub = slice(int(c['indptr'][lo]), int(c['indptr'][hi]))
     A = ops.csr(c['indptr'][lo:hi + 1] - c['indptr'][lo], c['indices'][sub], c['values'][sub], (hi - lo, n_items))
-    _ = A.T   # CSC image built once (host transpose + upload), outside any timing
+    inv_order = None
+    if args.item_order == 'popularity':
+        # internal item order = descending popularity over the WHOLE matrix (identical on every rank);
+        # results are mapped back to the external ids below.  Part of data ingest, like the CSC image.
+        from polara_amd.csr import popularity_order
+        rank_of, inv_order = popularity_order(c['indices'], n_items)
+        A = ops.csr_relabel_cols(A, rank_of)
+    _ = A.T   # CSC image built once (device transpose), outside any timing
 
     def barrier():
         torch.cuda.synchronize()
@@ -211,7 +220,7 @@ def main():
                                 'ml1m': 'ML-1M-shaped synthetic 6040 x 3706, PureSVD rank=10, top-10 (BASELINE.json configs[0])'}[args.workload],
                    'n_users': n_users, 'n_items': n_items, 'nnz': nnz, 'rank': rank, 'topk': topk,
                    'parallelism': 'users sharded over %d GPU(s); Gramian all-reduce in build only' % comm.world,
-                   'scale': args.scale},
+                   'scale': args.scale, 'item_order': args.item_order},
         'build_s': build_s,
         'build': {'gramian_steps': bstats['gramian_steps'], 'outer_iterations': bstats['outer'],
                   'block': bstats['block'], 'converged': bstats['converged'], 'spmm_launches': len(spmm_ms),
@@ -242,8 +251,14 @@ def main():
     if not args.no_cpu_baseline and comm.world == 1:
         n_score = args.cpu_users or min(n_users, 20000)   # ~16 chunks of the reference's 1 GB rule on S-1M, ~10 s
         build_rows = min(n_users, max(1000, int(5e6 / max(nnz / n_users, 1))))
-        base, cpu_recs = cpu_baseline(c, np.ascontiguousarray(ops.to_host(V)), rank, topk, n_score, build_rows)
-        same = float((ops.to_host(recs[:n_score]) == cpu_recs).all(axis=1).mean())
+        V_ext = ops.to_host(V)
+        if inv_order is not None:
+            V_ext = V_ext[rank_of]                                   # external item j = internal row rank_of[j]
+        base, cpu_recs = cpu_baseline(c, np.ascontiguousarray(V_ext), rank, topk, n_score, build_rows)
+        gpu_recs = ops.to_host(recs[:n_score])
+        if inv_order is not None:
+            gpu_recs = inv_order[gpu_recs].astype(np.int64)          # internal -> external item ids
+        same = float((gpu_recs == cpu_recs).all(axis=1).mean())
         base['gpu_vs_cpu_identical_rows'] = same
         base['speedup_scoring'] = value / base['value']
         out['cpu_baseline'] = base

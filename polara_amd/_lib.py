@@ -60,6 +60,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch must own the process' HIP runtime: it ships its own libamdhip64, and if ours
+    # (/opt/rocm, via RUNPATH) were loaded first the two runtimes would not share the device context
+    # ("no ROCm-capable device is detected" on the first launch).  Importing torch first makes the
+    # dynamic loader resolve our DT_NEEDED libamdhip64.so.7 to the copy torch already mapped.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise PolaraHipError(
             'libpolarahip.so is not built (%s). Run `python -m polara_amd.build_native` '

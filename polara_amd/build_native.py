@@ -4,6 +4,7 @@ hipcc cross-compiles without a GPU, so this runs in the build container and the 
 travels to the GPU box with the repo snapshot.  Object files are rebuilt only when their source
 (or a header) is newer.
 """
+import hashlib
 import os
 import subprocess
 import sys
@@ -28,17 +29,28 @@ def sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(('.hip', '.cpp')))
 
 
-def _newest_header():
+def _digest(paths, extra=''):
+    h = hashlib.sha1(extra.encode())
+    for p in sorted(paths):
+        with open(p, 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _headers():
     hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
     hs.append(os.path.join(ROOT, 'include', 'polara_hip.h'))
-    return max(os.path.getmtime(h) for h in hs)
+    return hs
 
 
 def _compile(src, force=False, extra=()):
+    """Rebuilds an object only when the CONTENT of its source, the headers or the flags changed
+    (content hashes, not mtimes: the snapshot that travels to the GPU box does not keep mtimes)."""
     obj = os.path.join(OBJDIR, src + '.o')
     spath = os.path.join(CSRC, src)
-    if (not force and os.path.exists(obj)
-            and os.path.getmtime(obj) > max(os.path.getmtime(spath), _newest_header())):
+    want = _digest([spath] + _headers(), ' '.join(FLAGS) + ' '.join(extra))
+    stamp = obj + '.sha1'
+    if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == want:
         return obj, False
     cmd = [HIPCC] + FLAGS + list(extra) + ['-x', 'hip', '-c', spath, '-o', obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -46,23 +58,18 @@ def _compile(src, force=False, extra=()):
         raise RuntimeError('hipcc failed for %s:\n%s\n%s' % (src, r.stdout, r.stderr))
     if r.stderr.strip():
         sys.stderr.write(r.stderr)
+    with open(stamp, 'w') as f:
+        f.write(want)
     return obj, True
 
 
 def build(force=False, verbose=True):
     os.makedirs(OBJDIR, exist_ok=True)
-    # objects are only reusable if they were built with the same flags (e.g. PK_FAST_BUILD toggled)
-    stamp = os.path.join(OBJDIR, 'flags.txt')
-    flags_now = ' '.join(FLAGS)
-    if not os.path.exists(stamp) or open(stamp).read() != flags_now:
-        force = True
     srcs = sources()
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         results = list(ex.map(lambda s: _compile(s, force), srcs))
     objs = [o for o, _ in results]
     rebuilt = any(c for _, c in results)
-    with open(stamp, 'w') as f:
-        f.write(flags_now)
     if rebuilt or not os.path.exists(LIB):
         cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)

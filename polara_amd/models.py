@@ -12,7 +12,7 @@ from timeit import default_timer as timer
 import numpy as np
 
 from . import defaults
-from .csr import coo_to_csr, nnz_balanced_row_partition
+from .csr import coo_to_csr, nnz_balanced_row_partition, popularity_order
 from .solver import svd_topk, NoComm
 from . import scoring
 from . import tucker
@@ -73,6 +73,10 @@ class RecommenderModel:
         self._ops = ops
         self.comm = comm or NoComm()
         self._factor_image = None
+        # internal item order of the device path (csr.popularity_order): external id -> internal
+        # position and back; None = identity.  `factors` and every result stay in EXTERNAL ids.
+        self._item_rank = None
+        self._item_inv = None
         self.data.subscribe(self.data.on_change_event, self._renew_model)
         self.data.subscribe(self.data.on_update_event, self._refresh_model)
 
@@ -206,7 +210,14 @@ class RecommenderModel:
 
     # ---- recommend pipeline (models.py:359-405) ----------------------------------------------------------
     def _item_factors_device(self):
-        raise NotImplementedError
+        """FactorImage of the item factors in INTERNAL item order (rebuilt from `factors` when the
+        cached one was invalidated, e.g. by a rank truncation)."""
+        if self._factor_image is None:
+            v = np.ascontiguousarray(self.factors[self.data.fields.itemid])
+            if self._item_inv is not None:
+                v = np.ascontiguousarray(v[self._item_inv])
+            self._factor_image = scoring.FactorImage(self.ops, self.ops.to_device(v))
+        return self._factor_image
 
     def _test_weights(self, test_data):
         """Per-entry fold-in coefficients; None = the feedback values themselves."""
@@ -220,7 +231,8 @@ class RecommenderModel:
         ops, comm = self.ops, self.comm
         w = self._test_weights(test_data)
         vals = np.asarray(test_data[2] if w is None else w, dtype=np.float64)
-        T = ops.csr_from_coo(test_data[0], test_data[1], vals, (n_users, n_items))   # zeros kept: still "seen"
+        cols = test_data[1] if self._item_rank is None else self._item_rank[np.asarray(test_data[1], dtype=np.intp)]
+        T = ops.csr_from_coo(test_data[0], cols, vals, (n_users, n_items))   # zeros kept: still "seen"
         lo, hi = 0, n_users
         if comm.world > 1:  # user-sharded scoring; V is replicated, no collective in the data path
             bounds = nnz_balanced_row_partition(ops.to_host(T.indptr), comm.world)
@@ -231,6 +243,8 @@ class RecommenderModel:
         if hi > lo:
             recs = scoring.recommend(ops, self._item_factors_device(), T, self.topk, self.filter_seen, stats=stats)
             recs = ops.to_host(recs)
+            if self._item_inv is not None:   # internal positions -> external item ids
+                recs = np.where(recs >= 0, self._item_inv[np.maximum(recs, 0)], -1).astype(np.int64)
         else:
             recs = np.empty((0, self.topk), dtype=np.int64)
         self.recommend_stats = stats
@@ -247,11 +261,15 @@ class RecommenderModel:
         sel = (users >= start) & (users < stop)
         slice_data = (users[sel] - start, items[sel], fdbk[sel])
         w = self._test_weights(test_data)
+        mapped = slice_data if self._item_rank is None else (
+            slice_data[0], self._item_rank[np.asarray(slice_data[1], dtype=np.intp)], slice_data[2])
         indptr, indices, values = scoring.test_csr_from_triplet(
-            slice_data, (stop - start, shape[1]), None if w is None else w[sel])
+            mapped, (stop - start, shape[1]), None if w is None else w[sel])
         T = self.ops.csr(indptr, indices, values, (stop - start, shape[1]))
-        scores = scoring.dense_scores(self.ops, self._item_factors_device(), T, 0, stop - start)
-        return self.ops.to_host(scores), slice_data
+        scores = self.ops.to_host(scoring.dense_scores(self.ops, self._item_factors_device(), T, 0, stop - start))
+        if self._item_rank is not None:
+            scores = np.ascontiguousarray(scores[:, self._item_rank])   # back to external item order
+        return scores, slice_data
 
     def evaluate(self, *args, **kwargs):
         """Metrics are a consumer of `recommendations` (models.py:408-485, evaluation.py) and out of
@@ -304,7 +322,8 @@ class SVDModel(RecommenderModel):
     def _training_device_csr(self):
         """The training matrix as a device CSR (COO -> CSR on device, models.py:160-177)."""
         idx, val, shp = self.data.to_coo(tensor_mode=False, feedback_threshold=self.feedback_threshold)
-        return self.ops.csr_from_coo(idx[:, 0], idx[:, 1], np.asarray(val, dtype=np.float64), shp)
+        self._item_rank, self._item_inv = popularity_order(idx[:, 1], shp[1])
+        return self.ops.csr_from_coo(idx[:, 0], self._item_rank[idx[:, 1]], np.asarray(val, dtype=np.float64), shp)
 
     def _local_training_shard(self):
         A = self._training_device_csr()
@@ -335,17 +354,14 @@ class SVDModel(RecommenderModel):
             user_factors = ops.to_host(U)
             if self.comm.world > 1:
                 user_factors = self.comm.gather_rows(user_factors, n_users, self.rank, dtype=np.float64)
-        item_factors = np.asfortranarray(ops.to_host(V)) if return_factors in (True, 'vh') else None
+        item_factors = None
+        if return_factors in (True, 'vh'):
+            item_factors = np.asfortranarray(ops.to_host(V)[self._item_rank])   # external item order
         self.factors[self.data.fields.userid] = user_factors
         self.factors[self.data.fields.itemid] = item_factors
         self.factors['singular_values'] = ops.to_host(sigma)
         self._factor_image = scoring.FactorImage(ops, V) if item_factors is not None else None
 
-    def _item_factors_device(self):
-        if self._factor_image is None:
-            v = self.factors[self.data.fields.itemid]
-            self._factor_image = scoring.FactorImage(self.ops, self.ops.to_device(np.ascontiguousarray(v)))
-        return self._factor_image
 
 
 class ScaledMatrixMixin:
@@ -392,7 +408,8 @@ class ScaledMatrixMixin:
 
     def _training_device_csr(self):
         indptr, indices, values, shp = self._training_csr(dtype=np.float64)
-        return self.ops.csr(indptr, indices, values, shp)
+        self._item_rank, self._item_inv = popularity_order(indices, shp[1])
+        return self.ops.csr_relabel_cols(self.ops.csr(indptr, indices, values, shp), self._item_rank)
 
 
 class ScaledSVD(ScaledMatrixMixin, SVDModel):
@@ -493,6 +510,9 @@ class CoffeeModel(RecommenderModel):
         """models.py:1009-1024."""
         idx, val, shp = self.data.to_coo(tensor_mode=True)
         ops, comm = self.ops, self.comm
+        self._item_rank, self._item_inv = popularity_order(idx[:, 1], shp[1])
+        idx = idx.copy()
+        idx[:, 1] = self._item_rank[idx[:, 1]]
         user_range = None
         if comm.world > 1:
             # users are sharded in nnz-balanced contiguous blocks; items / feedback factors replicated
@@ -509,7 +529,8 @@ class CoffeeModel(RecommenderModel):
         start = timer()
         u0, u1, u2, core, trace = tucker.hooi(ops, idx, val, shp, self.mlrank, num_iters=self.num_iters,
                                               growth_tol=self.growth_tol, seed=self.seed,
-                                              verbose=self.show_output, comm=comm, user_range=user_range)
+                                              verbose=self.show_output, comm=comm, user_range=user_range,
+                                              item_inv=self._item_inv)
         ops.synchronize()
         self._track(start)
         self.core_norm_trace = trace
@@ -518,16 +539,11 @@ class CoffeeModel(RecommenderModel):
         if comm.world > 1:
             u0_host = comm.gather_rows(u0_host, shp[0], u0_host.shape[1], dtype=np.float64)
         self.factors[userid] = u0_host
-        self.factors[itemid] = ops.to_host(u1)
+        self.factors[itemid] = np.ascontiguousarray(ops.to_host(u1)[self._item_rank])   # external item order
         self.factors[feedback] = ops.to_host(u2)
         self.factors['core'] = ops.to_host(core)
         self._factor_image = None
 
-    def _item_factors_device(self):
-        if self._factor_image is None:
-            v = self.factors[self.data.fields.itemid]
-            self._factor_image = scoring.FactorImage(self.ops, self.ops.to_device(np.ascontiguousarray(v)))
-        return self._factor_image
 
     def _test_weights(self, test_data):
         """models.py:1042-1054 folded algebraically: the per-nnz outer products,

@@ -158,6 +158,17 @@ class HipOps:
     def csr(self, indptr, indices, values, shape, split=SPLIT_NNZ):
         return DeviceCSR(self, indptr, indices, values, shape, split)
 
+    def csr_relabel_cols(self, A, col_map):
+        """CSR with column j renamed to col_map[j] (rows re-sorted on device).  `col_map`: int array."""
+        dev = self.device
+        cm = torch.as_tensor(np.ascontiguousarray(col_map, dtype=np.int64)).to(dev)
+        counts = A.indptr[1:] - A.indptr[:-1]
+        rows = torch.repeat_interleave(torch.arange(A.shape[0], dtype=torch.int64, device=dev), counts)
+        key = rows * A.shape[1] + cm[A.indices.long()]
+        key, order = torch.sort(key)
+        cc = (key - rows * A.shape[1]).to(torch.int32)   # rows are unchanged by a within-row permutation
+        return DeviceCSR.from_device(self, A.indptr, cc, A.values[order].contiguous(), A.shape)
+
     def csr_from_coo(self, rows, cols, vals, shape, split=SPLIT_NNZ):
         """COO triplets (host arrays) -> canonical DeviceCSR built ON DEVICE: one radix sort of the
         64-bit keys row*n_cols+col, duplicates summed (what `coo_matrix(...).tocsr()` does in

@@ -93,7 +93,7 @@ def left_svd(ops, M, r, want_v=False, comm=None, n_total=None):
 
 
 def hooi(ops, idx, val, shape, core_shape, num_iters=25, growth_tol=0.01, seed=None, verbose=False,
-         comm=None, user_range=None):
+         comm=None, user_range=None, item_inv=None):
     """Returns (u0, u1, u2, core, trace): device fp64 factors [n_mode x r_mode] with orthonormal
     columns ordered by descending singular value, core [r0 x r1 x r2], and the per-iteration core
     norms (lib/tensor.py:82-88).
@@ -101,7 +101,8 @@ def hooi(ops, idx, val, shape, core_shape, num_iters=25, growth_tol=0.01, seed=N
     Multi-GPU: pass `comm` and `user_range=(lo, hi)`; `idx` then holds only the nnz of
     users [lo, hi) (user indices already re-based to 0), the mode-0 factor u0 is returned as this
     rank's [hi-lo x r0] row block, the mode-1 / mode-2 TTMs (which reduce over users) are
-    all-reduced, and every rank holds identical u1, u2, core."""
+    all-reduced, and every rank holds identical u1, u2, core.
+    `item_inv`: see the start-block comment below."""
     comm = comm or NoComm()
     idx = np.asarray(idx)
     r0, r1, r2 = (int(r) for r in core_shape)
@@ -114,6 +115,10 @@ def hooi(ops, idx, val, shape, core_shape, num_iters=25, growth_tol=0.01, seed=N
     random_state = np.random if seed is None else np.random.RandomState(seed)
     u1 = np.linalg.qr(random_state.rand(n1, r1), mode='reduced')[0]
     u2 = np.linalg.qr(random_state.rand(n2, r2), mode='reduced')[0]
+    if item_inv is not None:
+        # the caller relabelled the item mode (internal row i = external item item_inv[i]): permute the
+        # start block the same way, so the iteration is the reference's up to that relabelling
+        u1 = np.ascontiguousarray(u1[item_inv])
     u1 = ops.to_device(u1)
     u2 = ops.to_device(u2)
 

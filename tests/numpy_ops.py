@@ -54,6 +54,12 @@ class NumpyOps:
         ip, ix, vl = coo_to_csr(rows, cols, np.asarray(vals, dtype=np.float64), shape)
         return NpCSR(ip, ix, vl, shape)
 
+    def csr_relabel_cols(self, A, col_map):
+        m = A.m.tocoo()
+        from polara_amd.csr import coo_to_csr
+        ip, ix, vl = coo_to_csr(m.row, np.asarray(col_map)[m.col], m.data, A.shape, sum_duplicates=False)
+        return NpCSR(ip, ix, vl, A.shape)
+
     def csr_rows(self, A, lo, hi):
         sub = A.m[lo:hi]
         return NpCSR(sub.indptr, sub.indices, sub.data, sub.shape)
