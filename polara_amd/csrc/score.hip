@@ -318,7 +318,9 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
         // SLOWER on MI355X (109 ms vs 97 ms per 1M x 100K pass): it drops occupancy to 2 waves/SIMD.
         // Also measured and rejected: two alternating fragment buffers with the tile body unrolled
         // twice (no a <- a_nxt moves): 112 ms; one shared copy of the flush code with a resumable
-        // scan instead of 16 inlined copies: 95 ms vs 90 ms.
+        // scan instead of 16 inlined copies: 95 ms vs 90 ms; a single rolling fragment buffer (group q
+        // of the next tile loaded right after group q's MFMAs, no register moves): 99 vs 81 ms — the
+        // compiler drains vmcnt(0) at the loop head, which exposes the latency of the late loads.
         float4 a_nxt[KQ];
         load_frags((tile_begin < n_tiles) ? tile_begin : 0, a_nxt);
         for (int tile = tile_begin; tile < tile_end; ++tile) {
