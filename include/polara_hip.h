@@ -128,7 +128,24 @@ int pk_score_candidates_f32(void *stream, int64_t n_users, int64_t n_items, int3
                             int32_t KC, int32_t splits /* splits*KC <= 64 */,
                             float *cand_score_dev, int32_t *cand_idx_dev /* [splits][n_users_pad][KC] */,
                             void *state_dev /* pk_score_state_bytes(n_users, splits) */,
-                            int32_t tiles_per_chunk /* 0 = auto */);
+                            int32_t tiles_per_chunk /* 0 = auto */,
+                            const float *user_bound_dev /* [n_users] or NULL */,
+                            const float *tile_bound_dev /* [ceil(n_items/32)] or NULL */);
+/* Exact pruning bounds for pk_score_candidates_f32 (Cauchy-Schwarz: |E_u . V_i| <= ||E_u|| ||V_i||).
+ * The reference scores every item for every user (models.py:860); the sweep may instead stop, per
+ * group of 32 users, at the first tile from which  ||E_u|| * max_{i >= tile} ||V_i||  can no longer
+ * beat the user's current KC-th best score.  Both bounds are rounded UP, so the candidate lists — and
+ * the certification done by pk_rescore_topk_f64 — are exactly those of the full sweep.
+ *   pk_row_norm_bound_f32:  out[r] >= ||src[r,:]||_2                       (user_bound from E)
+ *   pk_tile_norm_bound_f32: out[t] >= max_{i >= 32 t} ||V[i,:]||_2         (tile_bound; work: float[n_items])
+ * The bound falls fastest when the internal item order is by descending popularity or norm. */
+/* After the pass, the state buffer holds, for split h and user group g (32 users), 64 records of 16
+ * bytes starting at byte ((h * n_groups + g) * 64) * 16; the first int64 of each record is the tile at
+ * which that group left the sweep (= end of its tile range when it was never pruned): the number of
+ * tiles actually scored, for the roofline accounting of bench.py. */
+int pk_row_norm_bound_f32(void *stream, int64_t n, int32_t K, const double *src_dev, int64_t ld, float *out_dev);
+int pk_tile_norm_bound_f32(void *stream, int64_t n_items, int32_t K, const double *V_dev, int64_t ld,
+                           float *work_dev, float *out_dev);
 /* Exact fp64 re-scoring + final ordering (score desc, item asc).  Writes topk item ids (int64) and
  * optionally their fp64 scores.  flags[u] != 0 marks users whose result is NOT guaranteed exact by
  * the fp32 candidate pass (bit0: candidate margin below the fp32 error bound; bit1: fewer than

@@ -18,16 +18,17 @@ __device__ __forceinline__ bool pk_before64(double ka, int va, double kb, int vb
     return (ka > kb) || (ka == kb && va < vb);
 }
 
-// wave bitonic sort (descending) of one (key, val) per lane
-__device__ __forceinline__ void pk_bitonic64(double &key, int &val, int lane) {
+// bitonic sort (descending by pk_before64) inside aligned segments of SEG lanes, one (key, val) per lane
+template <int SEG>
+__device__ __forceinline__ void pk_bitonic_seg(double &key, int &val, int t) {
 #pragma unroll
-    for (int k = 2; k <= 64; k <<= 1) {
+    for (int k = 2; k <= SEG; k <<= 1) {
 #pragma unroll
         for (int j = k >> 1; j > 0; j >>= 1) {
             const double ok = __shfl_xor(key, j, 64);
             const int ov = __shfl_xor(val, j, 64);
-            const bool lower = (lane & j) == 0;
-            const bool desc = (lane & k) == 0;
+            const bool lower = (t & j) == 0;
+            const bool desc = (t & k) == 0;   // t < SEG: the last stage (k == SEG) is descending everywhere
             const bool want_first = (lower == desc);
             const bool other_first = pk_before64(ok, ov, key, val);
             if (want_first == other_first) {
@@ -38,77 +39,80 @@ __device__ __forceinline__ void pk_bitonic64(double &key, int &val, int lane) {
     }
 }
 
-// one wave per user
+// A LANE owns one candidate: it walks its own item row (the candidates of a user are popular items,
+// their rows sit in L2) against the user's E row with a serial fp64 FMA chain — no cross-lane
+// reduction at all; a segment of SEG >= KC*splits lanes owns one user, 64/SEG users share a wave.
+// (The first version gave a whole wave to each user and paid a 6-step fp64 wave reduction per
+// candidate plus a 64-lane sort: 2.7 ms per 1M users, instruction-bound.)
+template <int SEG>
 __global__ __launch_bounds__(256) void rescore_topk_kernel(
     int64_t n_users, int64_t n_items, int K, const double *__restrict__ V, int64_t ldv,
     const double *__restrict__ E, int64_t lde, const int64_t *__restrict__ seen_ptr, int KC, int splits,
     const float *__restrict__ cand_score, const int32_t *__restrict__ cand_idx, int topk, double vmax,
     int64_t *__restrict__ out_idx, double *__restrict__ out_score, int32_t *__restrict__ flags) {
+    constexpr int UPW = 64 / SEG;
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t user = (int64_t)blockIdx.x * 4 + wave;
-    if (user >= n_users) return;
+    const int wave = threadIdx.x >> 6;
+    const int ul = lane / SEG, t = lane % SEG;
+    const int64_t user = ((int64_t)blockIdx.x * 4 + wave) * UPW + ul;
+    const bool live = user < n_users;
+    const int64_t urow = live ? user : 0;
 
-    // E row: lane holds E[user][lane + 64 g]
-    double ek[4];
-    double e2 = 0.0;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int k = lane + 64 * g;
-        ek[g] = (k < K) ? E[user * lde + k] : 0.0;
-        e2 = fma(ek[g], ek[g], e2);
-    }
-    const double enorm = sqrt(pk_wave_sum(e2));
-
-    // candidates: the union of the `splits` per-item-range top-KC lists of this user (<= 64 entries);
+    // candidates: the union of the `splits` per-item-range top-KC lists of this user (<= SEG entries);
     // list h of user u lives at ((h * n_pad + u) * KC)
     const int64_t n_pad = ((n_users + 31) / 32) * 32;
-    double my_s = -INFINITY;
-    int my_i = PK_IDX_NONE;
-    int n_cand = 0;
+    int idx = -1;
+    if (live && t < KC * splits) idx = cand_idx[((int64_t)(t / KC) * n_pad + user) * KC + (t % KC)];
     double tau32 = -INFINITY;   // bound on the fp32 score of every NON-candidate item
     for (int h = 0; h < splits; ++h) {
-        const int64_t base = ((int64_t)h * n_pad + user) * KC;
-        int n_valid = 0;
-        for (int t = 0; t < KC; ++t) {
-            const int idx = cand_idx[base + t];  // wave-uniform
-            if (idx < 0) continue;
-            ++n_valid;
-            const double *vr = V + (int64_t)idx * ldv;
-            double part = 0.0;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int k = lane + 64 * g;
-                if (k < K) part = fma(ek[g], vr[k], part);
-            }
-            const double s = pk_wave_sum(part);
-            if (lane == n_cand) {
-                my_s = s;
-                my_i = idx;
-            }
-            ++n_cand;
-        }
         // a full list may have left items of its range out: they score at most its KC-th entry
-        if (n_valid == KC) tau32 = fmax(tau32, (double)cand_score[base + KC - 1]);
+        const int64_t last = ((int64_t)h * n_pad + urow) * KC + KC - 1;
+        if (cand_idx[last] >= 0) tau32 = fmax(tau32, (double)cand_score[last]);
     }
-    pk_bitonic64(my_s, my_i, lane);
+
+    const double *vr = V + (int64_t)(idx >= 0 ? idx : 0) * ldv;
+    const double *er = E + urow * lde;
+    double s = 0.0, e2 = 0.0;
+    const bool vec2 = ((ldv | lde) & 1) == 0 && ((((uintptr_t)V) | ((uintptr_t)E)) & 15) == 0;
+    int k = 0;
+    if (vec2) {
+        const double2 *v2 = reinterpret_cast<const double2 *>(vr);
+        const double2 *e2p = reinterpret_cast<const double2 *>(er);
+#pragma unroll 4
+        for (; k + 1 < K; k += 2) {
+            const double2 a = v2[k >> 1], b = e2p[k >> 1];
+            s = fma(b.x, a.x, s);
+            s = fma(b.y, a.y, s);
+            e2 = fma(b.x, b.x, e2);
+            e2 = fma(b.y, b.y, e2);
+        }
+    }
+    for (; k < K; ++k) {
+        const double b = er[k];
+        s = fma(b, vr[k], s);
+        e2 = fma(b, b, e2);
+    }
+    const double enorm = sqrt(e2);
+    double my_s = (idx >= 0) ? s : -INFINITY;
+    int my_i = (idx >= 0) ? idx : PK_IDX_NONE;
+    pk_bitonic_seg<SEG>(my_s, my_i, t);
 
     // certification
     int flag = 0;
-    const int64_t n_seen = seen_ptr ? (seen_ptr[user + 1] - seen_ptr[user]) : 0;
+    const int64_t n_seen = seen_ptr ? (seen_ptr[urow + 1] - seen_ptr[urow]) : 0;
+    const double s_k = __shfl(my_s, ul * SEG + topk - 1, 64);
     if (n_items - n_seen < topk) {
         flag |= 2;  // seen items must re-enter the list: exact path
     } else if (tau32 > -INFINITY) {
-        const double s_k = __shfl(my_s, topk - 1, 64);
         // |fl32(e.v) - e.v| <= (K + 3) u32 |e||v|  (input rounding + K-term fmaf chain), u32 = 2^-24
         const double bound = (double)(K + 3) * 5.9604644775390625e-08 * enorm * vmax;
         if (bound > 0.0 && !(s_k - tau32 > bound)) flag |= 1;
     }
-    if (lane < topk) {
-        out_idx[user * topk + lane] = (my_i == PK_IDX_NONE) ? -1 : (int64_t)my_i;
-        if (out_score) out_score[user * topk + lane] = my_s;
+    if (live && t < topk) {
+        out_idx[user * topk + t] = (my_i == PK_IDX_NONE) ? -1 : (int64_t)my_i;
+        if (out_score) out_score[user * topk + t] = my_s;
     }
-    if (lane == 0) flags[user] = flag;
+    if (live && t == 0) flags[user] = flag;
 }
 
 extern "C" int pk_rescore_topk_f64(void *stream, int64_t n_users, int64_t n_items, int32_t K, const double *V_dev,
@@ -120,10 +124,16 @@ extern "C" int pk_rescore_topk_f64(void *stream, int64_t n_users, int64_t n_item
     PK_REQUIRE(n_users >= 1 && K >= 1 && K <= 256 && ldv >= K && lde >= K, "pk_rescore_topk_f64: bad sizes");
     PK_REQUIRE(KC >= 1 && splits >= 1 && KC * splits <= 64 && topk >= 1 && topk <= KC,
                "pk_rescore_topk_f64: need topk <= KC and KC*splits <= 64");
-    hipLaunchKernelGGL(rescore_topk_kernel, dim3((unsigned)pk_ceil_div(n_users, 4)), dim3(256), 0, pk_stream(stream),
-                       n_users, n_items, K, V_dev, ldv, E_dev, lde, seen_ptr_dev, KC, splits, cand_score_dev,
-                       cand_idx_dev,
-                       topk, v_row_norm_max, out_idx_dev, out_score_dev, flags_dev);
+    const int seg = (KC * splits <= 16) ? 16 : (KC * splits <= 32) ? 32 : 64;
+#define PK_RESCORE(SEGV)                                                                                        \
+    hipLaunchKernelGGL((rescore_topk_kernel<SEGV>), dim3((unsigned)pk_ceil_div(n_users, 4 * (64 / SEGV))),      \
+                       dim3(256), 0, pk_stream(stream), n_users, n_items, K, V_dev, ldv, E_dev, lde,            \
+                       seen_ptr_dev, KC, splits, cand_score_dev, cand_idx_dev, topk, v_row_norm_max,            \
+                       out_idx_dev, out_score_dev, flags_dev)
+    if (seg == 16) PK_RESCORE(16);
+    else if (seg == 32) PK_RESCORE(32);
+    else PK_RESCORE(64);
+#undef PK_RESCORE
     PK_CHECK_LAUNCH("rescore_topk_kernel");
     return PK_OK;
 }

@@ -22,6 +22,13 @@
 // above tau is appended to a lane-private LDS ring (16 entries); when a ring is full the wave
 // bitonic-sorts {both rings of the user, current top-KC list} and refreshes the list and tau.
 // After warm-up almost every tile takes the fast path: 8 v_max3 + 1 compare + 1 ballot.
+//
+// Pruning (exact): |E_u . V_i| <= ||E_u|| ||V_i||.  The caller passes per-user upper bounds of
+// ||E_u|| and, per 32-item tile, an upper bound of max ||V_i|| over ALL items from that tile to the end
+// of the catalogue (a suffix maximum, so it is non-increasing whatever the item order; it falls
+// fastest when the items are ordered by descending norm or popularity).  tau never decreases, so
+// once  ||E_u|| * bound[tile] <= tau_u  holds for the 32 users of a wave no later item can enter any
+// of their lists: the wave merges its rings, writes its lists and leaves the sweep for good.
 #include "pk_common.h"
 #include <math.h>
 #include <stdlib.h>
@@ -85,8 +92,9 @@ __device__ __forceinline__ void pk_bitonic_desc(float (&key)[SLOTS], int (&val)[
 struct LaneState {
     int64_t sp;   // position in the user's seen list
     float tau;    // current threshold
-    int cnt;      // entries in the lane's ring
+    int cnt;      // entries in the lane's ring; PK_LANE_DONE once the wave has left the sweep (pruned)
 };
+#define PK_LANE_DONE (-1)
 
 // NSTEP = number of K=2 MFMA steps actually issued (ceil(rank/2) rounded up to a supported value);
 // the packed operands hold KQ = ceil(NSTEP/4) float4 groups, the tail group is only partly used.
@@ -96,7 +104,8 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
     int n_tiles, int split_tiles, int chunk, int tiles_per_chunk,
     const int64_t *__restrict__ seen_ptr, const int32_t *__restrict__ seen_idx,
     float *__restrict__ cand_score, int32_t *__restrict__ cand_idx,
-    LaneState *__restrict__ st_lane, uint2 *__restrict__ st_ring, int ablate) {
+    LaneState *__restrict__ st_lane, uint2 *__restrict__ st_ring,
+    const float *__restrict__ user_bound, const float *__restrict__ tile_bound, int ablate) {
     constexpr int KQ = (NSTEP + 3) / 4;
     constexpr int SLOTS = (2 * RING + KC + 63) / 64;
     // The running top-KC lists of the wave's 32 users live in LDS when they fit (KC <= 32): a flush
@@ -141,6 +150,11 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
     int nxt = PK_IDX_NONE, nxt2 = PK_IDX_NONE, nxt3 = PK_IDX_NONE;  // next three seen items (prefetch window)
     float tau = -INFINITY;
     int cnt = 0;
+    const bool prune = (user_bound != nullptr && tile_bound != nullptr) && !(ablate & 4);
+    // padding lanes of the last group never keep the wave in the sweep
+    const float en = (prune && user < n_users) ? user_bound[user] : -1.0f;
+    bool pruned = false;
+    int exit_tile = tile_end;
     const bool has_seen = (seen_ptr != nullptr && user < n_users);
     if (has_seen) {
         sp = seen_ptr[user];
@@ -168,10 +182,11 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
             }
         }
     } else {
-        if (TOP_LDS)
-            for (int s = lane; s < 32 * KC; s += 64) top[s] = make_uint2(__float_as_uint(my_score[s]), (unsigned)my_idx[s]);
         // resume: restore the lane state and the ring image written by the previous chunk launch
         const LaneState ls = *my_state;
+        if (ls.cnt == PK_LANE_DONE) return;  // wave-uniform: this group was pruned in an earlier launch
+        if (TOP_LDS)
+            for (int s = lane; s < 32 * KC; s += 64) top[s] = make_uint2(__float_as_uint(my_score[s]), (unsigned)my_idx[s]);
         if (has_seen) sp = ls.sp;
         tau = ls.tau;
         cnt = ls.cnt;
@@ -323,7 +338,30 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
         // compiler drains vmcnt(0) at the loop head, which exposes the latency of the late loads.
         float4 a_nxt[KQ];
         load_frags((tile_begin < n_tiles) ? tile_begin : 0, a_nxt);
+        float tb = prune ? tile_bound[(tile_begin < n_tiles) ? tile_begin : 0] : 0.0f;
         for (int tile = tile_begin; tile < tile_end; ++tile) {
+            if (prune) {
+                // can any item from this tile on still enter a list of this wave?
+                const bool open = en * tb > tau;
+                const unsigned long long ob = __ballot(open);
+                if (ob == 0ull) {
+                    pruned = true;
+                    exit_tile = tile;
+                    break;
+                }
+                // tau is only refreshed by a flush; the last few users that keep the wave in the sweep
+                // get their pending ring entries merged so that their tau is exact (checked every 8 tiles)
+                if ((tile & 7) == 7 && __popcll(ob) <= 16) {
+                    const unsigned long long pend = __ballot(cnt > 0);
+                    unsigned um = (unsigned)(ob | (ob >> 32)) & (unsigned)(pend | (pend >> 32));
+                    while (um) {
+                        const int x = __builtin_ctz(um);
+                        um &= um - 1;
+                        flush_user(x);
+                    }
+                }
+                tb = tile_bound[(tile + 1 < n_tiles) ? tile + 1 : tile];
+            }
             float4 a[KQ];
 #pragma unroll
             for (int q = 0; q < KQ; ++q) a[q] = a_nxt[q];
@@ -366,7 +404,7 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
         }
     }
 
-    if (!last) {
+    if (!last && !pruned) {
         // park the state for the next item chunk (rings stay unsorted: no flush cost per chunk)
         LaneState ls;
         ls.sp = sp;
@@ -401,6 +439,15 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
             my_score[s] = __uint_as_float(r.x);
             my_idx[s] = (int)r.y;
         }
+    }
+    {
+        // finished (possibly early): later chunk launches must not touch this group again; sp records
+        // the tile at which the group left the sweep (pk_score_state layout: see polara_hip.h)
+        LaneState ls;
+        ls.sp = exit_tile;
+        ls.tau = tau;
+        ls.cnt = PK_LANE_DONE;
+        *my_state = ls;
     }
 }
 
@@ -457,6 +504,67 @@ extern "C" int pk_pack_frag_f32(void *stream, int64_t n, int32_t K, const double
     return PK_OK;
 }
 
+// ---- pruning bounds ------------------------------------------------------------------------------
+// out[r] >= ||src[r, :]||_2 as a float (relative head-room 1e-6 covers the double->float rounding and
+// the rounding of the fp32 product  user_bound * tile_bound  inside the sweep).
+__global__ __launch_bounds__(256) void row_norm_bound_kernel(int64_t n, int K, const double *__restrict__ src,
+                                                             int64_t ld, float *__restrict__ out) {
+    // 16 lanes per row: coalesced 128-byte pieces of the row, 4-step butterfly inside the 16-lane group
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int l = threadIdx.x & 15;
+    double s = 0.0;
+    if (r < n) {
+        const double *row = src + r * ld;
+        for (int k = l; k < K; k += 16) s = fma(row[k], row[k], s);
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (r < n && l == 0) out[r] = (float)(sqrt(s) * (1.0 + 1e-6));
+}
+
+// out[t] = max(norm[32 t ...]) over ALL rows from tile t to the end (suffix maximum); one wave.
+__global__ __launch_bounds__(64) void tile_suffix_max_kernel(int64_t n, int64_t n_tiles, const float *__restrict__ norm,
+                                                             float *__restrict__ out) {
+    const int lane = threadIdx.x;
+    const int64_t seg = (n_tiles + 63) / 64;
+    const int64_t t0 = lane * seg, t1 = (t0 + seg < n_tiles) ? t0 + seg : n_tiles;
+    float run = 0.0f;
+    for (int64_t t = t1 - 1; t >= t0; --t) {
+        const int64_t i1 = (32 * t + 32 < n) ? 32 * t + 32 : n;
+        for (int64_t i = 32 * t; i < i1; ++i) run = fmaxf(run, norm[i]);
+        out[t] = run;
+    }
+    // carry[lane] = max of the segment totals of all higher lanes
+    float carry = 0.0f;
+    for (int l = 63; l > 0; --l) {
+        const float v = __shfl(run, l);
+        if (lane < l) carry = fmaxf(carry, v);
+    }
+    for (int64_t t = t0; t < t1; ++t) out[t] = fmaxf(out[t], carry);
+}
+
+extern "C" int pk_row_norm_bound_f32(void *stream, int64_t n, int32_t K, const double *src_dev, int64_t ld,
+                                     float *out_dev) {
+    PK_REQUIRE(n >= 1 && K >= 1 && ld >= K, "pk_row_norm_bound_f32: bad sizes");
+    hipLaunchKernelGGL(row_norm_bound_kernel, dim3((unsigned)pk_ceil_div(n, 16)), dim3(256), 0, pk_stream(stream), n,
+                       K, src_dev, ld, out_dev);
+    PK_CHECK_LAUNCH("row_norm_bound_kernel");
+    return PK_OK;
+}
+
+extern "C" int pk_tile_norm_bound_f32(void *stream, int64_t n_items, int32_t K, const double *V_dev, int64_t ld,
+                                      float *work_dev, float *out_dev) {
+    PK_REQUIRE(n_items >= 1 && K >= 1 && ld >= K, "pk_tile_norm_bound_f32: bad sizes");
+    hipStream_t st = pk_stream(stream);
+    hipLaunchKernelGGL(row_norm_bound_kernel, dim3((unsigned)pk_ceil_div(n_items, 16)), dim3(256), 0, st, n_items, K,
+                       V_dev, ld, work_dev);
+    PK_CHECK_LAUNCH("row_norm_bound_kernel");
+    hipLaunchKernelGGL(tile_suffix_max_kernel, dim3(1), dim3(64), 0, st, n_items, pk_ceil_div(n_items, 32), work_dev,
+                       out_dev);
+    PK_CHECK_LAUNCH("tile_suffix_max_kernel");
+    return PK_OK;
+}
+
 extern "C" int32_t pk_candidate_capacity(int32_t topk) {
     if (topk < 1) return 0;
     if (topk <= 10) return 16;
@@ -473,13 +581,13 @@ template <int NSTEP>
 static int launch_candidates_n(hipStream_t st, int KC, int ablate, dim3 grid, const float4 *Vp, const float4 *Ep,
                                int64_t n_users, int n_items, int n_tiles, int split_tiles, int tiles_per_chunk,
                                const int64_t *seen_ptr, const int32_t *seen_idx, float *cs, int32_t *ci,
-                               LaneState *st_lane, uint2 *st_ring) {
+                               LaneState *st_lane, uint2 *st_ring, const float *user_bound, const float *tile_bound) {
     const int n_chunks = (split_tiles + tiles_per_chunk - 1) / tiles_per_chunk;
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
 #define PK_LAUNCH(KCV)                                                                                          \
     hipLaunchKernelGGL((score_candidates_kernel<NSTEP, KCV>), grid, dim3(256), 0, st, Vp, Ep, n_users,          \
                        n_items, n_tiles, split_tiles, chunk, tiles_per_chunk, seen_ptr, seen_idx, cs, ci, st_lane, st_ring,  \
-                       ablate)
+                       user_bound, tile_bound, ablate)
 #ifdef PK_FAST_BUILD
         if (KC != 16) return PK_E_UNSUPPORTED;
         PK_LAUNCH(16);
@@ -527,7 +635,8 @@ extern "C" int pk_score_candidates_f32(void *stream, int64_t n_users, int64_t n_
                                        const float *Vp_dev, const float *Ep_dev, const int64_t *seen_ptr_dev,
                                        const int32_t *seen_idx_dev, int32_t KC, int32_t splits,
                                        float *cand_score_dev, int32_t *cand_idx_dev, void *state_dev,
-                                       int32_t tiles_per_chunk) {
+                                       int32_t tiles_per_chunk, const float *user_bound_dev,
+                                       const float *tile_bound_dev) {
     PK_REQUIRE(n_users >= 1 && n_items >= 1 && n_items < 0x7fffff00LL, "pk_score_candidates_f32: bad sizes");
     const int kq = pk_pack_kq(K);
     const int nstep = pk_nstep(K);
@@ -535,6 +644,8 @@ extern "C" int pk_score_candidates_f32(void *stream, int64_t n_users, int64_t n_
     PK_REQUIRE(((uintptr_t)Vp_dev % 16) == 0 && ((uintptr_t)Ep_dev % 16) == 0, "pk_score_candidates_f32: alignment");
     PK_REQUIRE(state_dev != nullptr && ((uintptr_t)state_dev % 16) == 0, "pk_score_candidates_f32: state buffer");
     PK_REQUIRE(splits >= 1 && splits * KC <= 64, "pk_score_candidates_f32: need 1 <= splits and splits*KC <= 64");
+    PK_REQUIRE((user_bound_dev == nullptr) == (tile_bound_dev == nullptr),
+               "pk_score_candidates_f32: user_bound and tile_bound go together (both or neither)");
     hipStream_t st = pk_stream(stream);
     const int n_tiles = (int)pk_ceil_div(n_items, 32);
     const int64_t groups = pk_ceil_div(n_users, 32);
@@ -553,7 +664,7 @@ extern "C" int pk_score_candidates_f32(void *stream, int64_t n_users, int64_t n_
     case Q:                                                                                                   \
         rc = launch_candidates_n<Q>(st, KC, ablate, grid, Vp, Ep, n_users, (int)n_items, n_tiles,            \
                                     split_tiles, tiles_per_chunk, seen_ptr_dev, seen_idx_dev, cand_score_dev, cand_idx_dev, \
-                                    st_lane, st_ring);                                                         \
+                                    st_lane, st_ring, user_bound_dev, tile_bound_dev);                         \
         break;
     const char *abl_env = getenv("PK_SCORE_ABLATE");   // kernel-tuning knob, never set in production
     const int ablate = abl_env ? atoi(abl_env) : 0;

@@ -321,10 +321,33 @@ class HipOps:
     def candidate_capacity(self, topk):
         return self.lib.pk_candidate_capacity(topk)
 
-    def score_splits(self, n_users, KC):
-        return self.score_splits_override or self.lib.pk_score_splits(n_users, KC)
+    def score_splits(self, n_users, KC, prune=False):
+        # a pruned sweep is never split: later item ranges would start from an empty list (threshold
+        # -inf) and could not be pruned by the thresholds the head of the catalogue establishes
+        if self.score_splits_override:
+            return self.score_splits_override
+        return 1 if prune else self.lib.pk_score_splits(n_users, KC)
 
-    def score_candidates(self, Vp, Ep, n_users, n_items, K, seen_ptr, seen_idx, KC, splits=1, tiles_per_chunk=0):
+    def row_norm_bound(self, M):
+        """float32 upper bounds of the row 2-norms of fp64 M (pruning bound of the candidate sweep)."""
+        assert M.stride(1) == 1
+        out = torch.empty(M.shape[0], dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.pk_row_norm_bound_f32(self.stream(), M.shape[0], M.shape[1], _ptr(M), M.stride(0),
+                                                  _ptr(out)), 'pk_row_norm_bound_f32')
+        return out
+
+    def tile_norm_bound(self, V):
+        """float32 [ceil(n/32)]: upper bound of max ||V[i,:]|| over all rows i >= 32*tile (suffix maximum)."""
+        assert V.stride(1) == 1
+        n = V.shape[0]
+        work = torch.empty(n, dtype=torch.float32, device=self.device)
+        out = torch.empty(-(-n // 32), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.pk_tile_norm_bound_f32(self.stream(), n, V.shape[1], _ptr(V), V.stride(0), _ptr(work),
+                                                   _ptr(out)), 'pk_tile_norm_bound_f32')
+        return out
+
+    def score_candidates(self, Vp, Ep, n_users, n_items, K, seen_ptr, seen_idx, KC, splits=1, tiles_per_chunk=0,
+                         user_bound=None, tile_bound=None):
         n_pad = -(-n_users // 32) * 32
         need = self.lib.pk_score_state_bytes(n_users, splits)
         if self._score_state is None or self._score_state.numel() < need:
@@ -335,9 +358,16 @@ class HipOps:
             _lib.check(self.lib.pk_score_candidates_f32(self.stream(), n_users, n_items, K, _ptr(Vp), _ptr(Ep),
                                                         _ptr(seen_ptr), _ptr(seen_idx), KC, splits, _ptr(cs), _ptr(ci),
                                                         _ptr(self._score_state),
-                                                        tiles_per_chunk or self.score_tiles_per_chunk),
+                                                        tiles_per_chunk or self.score_tiles_per_chunk,
+                                                        _ptr(user_bound), _ptr(tile_bound)),
                        'pk_score_candidates_f32')
         return cs, ci
+
+    def score_exit_tiles(self, n_users, splits=1):
+        """int64 [splits x n_groups]: tile at which each group of 32 users left the last candidate sweep."""
+        groups = -(-n_users // 32)
+        rec = self._score_state[:splits * groups * 64 * 16].view(torch.int64).view(splits, groups, 64, 2)
+        return rec[:, :, 0, 0].clone()
 
     def rescore_topk(self, V, E, n_items, seen_ptr, KC, cs, ci, topk, vmax, want_scores=True, splits=1):
         assert V.stride(1) == 1 and E.stride(1) == 1

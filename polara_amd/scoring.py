@@ -27,6 +27,7 @@ class FactorImage:
         self.n_items, self.K = self.V.shape
         self.Vp = ops.pack_frag(self.V)
         self.vmax = float(torch.linalg.vector_norm(self.V, dim=1).max().item())
+        self.tile_bound = ops.tile_norm_bound(self.V)   # exact pruning bound of the candidate sweep
 
 
 def test_csr_from_triplet(test_data, shape, weights=None):
@@ -37,7 +38,7 @@ def test_csr_from_triplet(test_data, shape, weights=None):
     return coo_to_csr(users, items, vals, shape, sum_duplicates=True)
 
 
-def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stats=None):
+def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stats=None, prune=True):
     """factors: FactorImage; T: ops-level CSR of the test users [n_users x n_items].
     Returns int64 device tensor [n_users x topk] (+ fp64 scores), rows in test-user order,
     columns by descending score — the contract of models.py:400-405."""
@@ -68,8 +69,12 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
     Ep = ops.pack_frag(E)
     seen_ptr = T.indptr if filter_seen else None
     seen_idx = T.indices if filter_seen else None
-    splits = ops.score_splits(n_users, KC)           # item ranges per user group (1 when users fill the chip)
-    cs, ci = ops.score_candidates(factors.Vp, Ep, n_users, n_items, K, seen_ptr, seen_idx, KC, splits)   # K3
+    splits = ops.score_splits(n_users, KC, prune)    # item ranges per user group (1 when pruning / users fill the chip)
+    # exact Cauchy-Schwarz pruning: a group of 32 users leaves the sweep once no later item can beat
+    # any of its thresholds (`prune=False` forces the full sweep: same result, tuning / tests only)
+    ub = ops.row_norm_bound(E) if prune else None
+    cs, ci = ops.score_candidates(factors.Vp, Ep, n_users, n_items, K, seen_ptr, seen_idx, KC, splits,
+                                  user_bound=ub, tile_bound=factors.tile_bound if prune else None)   # K3
     out_idx, out_s, flags = ops.rescore_topk(factors.V, E, n_items, seen_ptr, KC, cs, ci, topk,
                                              factors.vmax, want_scores=True, splits=splits)
     rows = torch.nonzero(flags, as_tuple=False).flatten().to(torch.int32)
@@ -78,6 +83,13 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
         stats['flagged_users'] = n_flag
         stats['candidate_capacity'] = KC
         stats['item_splits'] = splits
+        # tiles actually scored by the candidate sweep (pruning), for the roofline accounting
+        n_tiles = -(-n_items // 32)
+        split_tiles = -(-n_tiles // splits)
+        ex = ops.score_exit_tiles(n_users, splits)
+        lo = torch.arange(splits, device=ex.device, dtype=torch.int64)[:, None] * split_tiles
+        stats['tiles_scored'] = int((ex - lo).clamp_min(0).sum().item())
+        stats['tiles_total'] = int(ex.shape[1]) * n_tiles
     if n_flag:
         per = max(1, int(EXACT_ROWS_BYTES // (n_items * 9 + 16)))
         for s in range(0, n_flag, per):

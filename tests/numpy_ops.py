@@ -134,13 +134,22 @@ class NumpyOps:
             return 0
         return 16 if topk <= 10 else 32 if topk <= 24 else 64 if topk <= 52 else 0
 
-    def score_splits(self, n_users, KC):
+    def score_splits(self, n_users, KC, prune=False):
         return 1
 
     def pack_frag(self, M):
         return M.to(torch.float32)
 
-    def score_candidates(self, Vp, Ep, n_users, n_items, K, seen_ptr, seen_idx, KC, splits=1):
+    def row_norm_bound(self, M):
+        return torch.from_numpy((np.linalg.norm(M.numpy(), axis=1) * (1 + 1e-6)).astype(np.float32))
+
+    def tile_norm_bound(self, V):
+        nb = (np.linalg.norm(V.numpy(), axis=1) * (1 + 1e-6)).astype(np.float32)
+        suf = np.maximum.accumulate(nb[::-1])[::-1]
+        return torch.from_numpy(np.ascontiguousarray(suf[::32]))
+
+    def score_candidates(self, Vp, Ep, n_users, n_items, K, seen_ptr, seen_idx, KC, splits=1,
+                         user_bound=None, tile_bound=None):
         s = (Ep.numpy() @ Vp.numpy().T).astype(np.float32)
         if seen_ptr is not None:
             sp = seen_ptr.numpy()
@@ -157,6 +166,9 @@ class NumpyOps:
             cs[u, :ok.sum()] = s[u, order][ok]
             ci[u, :ok.sum()] = order[ok]
         return torch.from_numpy(cs.ravel()), torch.from_numpy(ci.ravel())
+
+    def score_exit_tiles(self, n_users, splits=1):
+        return torch.zeros(splits, -(-n_users // 32), dtype=torch.int64)
 
     def rescore_topk(self, V, E, n_items, seen_ptr, KC, cs, ci, topk, vmax, want_scores=True, splits=1):
         n_users, K = E.shape

@@ -247,6 +247,58 @@ def test_chunked_item_sweep_equals_single_sweep(hip_ops, tiles_per_chunk):
     assert np.array_equal(hip_ops.to_host(ref_s), hip_ops.to_host(got_s))
 
 
+def test_pruning_bounds_are_upper_bounds(hip_ops):
+    rng = np.random.RandomState(3)
+    for n, K in ((1000, 50), (33, 7), (4097, 200)):
+        M = rng.randn(n, K) * np.exp(rng.randn(n, 1) * 3)
+        M[5] = 0.0
+        nrm = np.linalg.norm(M, axis=1)
+        ub = hip_ops.to_host(hip_ops.row_norm_bound(hip_ops.to_device(M))).astype(np.float64)
+        assert ub.dtype == np.float64 and np.all(ub >= nrm) and np.all(ub <= nrm * (1 + 3e-6))
+        tb = hip_ops.to_host(hip_ops.tile_norm_bound(hip_ops.to_device(M))).astype(np.float64)
+        suf = np.maximum.accumulate(nrm[::-1])[::-1][::32]
+        assert tb.shape == suf.shape and np.all(tb >= suf) and np.all(tb <= suf * (1 + 3e-6))
+        assert np.all(np.diff(tb) <= 0)
+
+
+@pytest.mark.parametrize('cfg', [dict(n_users=1000, n_items=20000, K=50, topk=10, chunk=0),
+                                 dict(n_users=333, n_items=9000, K=100, topk=20, chunk=13),
+                                 dict(n_users=200, n_items=6000, K=24, topk=50, chunk=5),
+                                 dict(n_users=130, n_items=5000, K=50, topk=10, chunk=3, splits=3)])
+def test_pruned_sweep_equals_full_sweep(hip_ops, cfg):
+    """Exact pruning: with item norms decaying along the catalogue most user groups must leave the
+    sweep early, and the result (ids AND scores, flagged users included) must not change."""
+    from polara_amd import scoring
+    n_users, n_items, K, topk = cfg['n_users'], cfg['n_items'], cfg['K'], cfg['topk']
+    rng = np.random.RandomState(n_items)
+    decay = (1.0 + np.arange(n_items)) ** -0.7
+    V = rng.randn(n_items, K) / np.sqrt(K) * decay[:, None]
+    V[rng.randint(n_items // 4, n_items // 2, 3)] *= 3.0   # a few heavy items further down (bound is a suffix max)
+    indptr, indices, values = rand_csr(rng, n_users, n_items, 40, long_rows=[(2, n_items // 2)], empty_rows=[7])
+    T = hip_ops.csr(indptr, indices, values, (n_users, n_items))
+    F = scoring.FactorImage(hip_ops, hip_ops.to_device(V))
+    try:
+        hip_ops.score_tiles_per_chunk = cfg['chunk']
+        hip_ops.score_splits_override = cfg.get('splits', 0)
+        st_full, st = {}, {}
+        ref, ref_s = scoring.recommend(hip_ops, F, T, topk, True, return_scores=True, stats=st_full, prune=False)
+        got, got_s = scoring.recommend(hip_ops, F, T, topk, True, return_scores=True, stats=st)
+    finally:
+        hip_ops.score_tiles_per_chunk = 0
+        hip_ops.score_splits_override = 0
+    assert st_full['tiles_scored'] == st_full['tiles_total']
+    if 'splits' not in cfg:
+        assert st['item_splits'] == 1 and st['tiles_scored'] < 0.6 * st['tiles_total'], st
+    else:
+        assert st['item_splits'] == cfg['splits'] and st['tiles_scored'] <= st['tiles_total'], st
+    assert np.array_equal(hip_ops.to_host(ref), hip_ops.to_host(got))
+    assert np.array_equal(hip_ops.to_host(ref_s), hip_ops.to_host(got_s))
+    E = sps.csr_matrix((values.astype(np.float64), indices, indptr), shape=(n_users, n_items)) @ V
+    want, _ = brute_topk(V, E, indptr, indices, topk, True)
+    live = np.abs(E).sum(1) > 0
+    assert (hip_ops.to_host(got)[live] == want[live]).mean() > 0.999
+
+
 @pytest.mark.parametrize('cfg', [dict(K=50, topk=10, splits=4), dict(K=50, topk=10, splits=3),
                                  dict(K=100, topk=20, splits=2), dict(K=24, topk=5, splits=2)])
 def test_item_splits_equal_single_range(hip_ops, cfg):
