@@ -195,7 +195,17 @@ def main():
         recs = scoring.recommend(ops, F, A, topk, True, prune=not args.no_prune)
     barrier()
     elapsed = time.perf_counter() - t0
+    prof = None
+    if os.environ.get('PK_SCORE_PROFILE'):   # tuning builds only (polara_amd/build_native.py)
+        import ctypes
+        buf = (ctypes.c_ulonglong * 8)()
+        ops.lib.pk_debug_profile(None, 1)
     scoring.recommend(ops, F, A, topk, True, stats=stats, prune=not args.no_prune)   # untimed: sweep statistics
+    if os.environ.get('PK_SCORE_PROFILE'):
+        torch.cuda.synchronize()
+        ops.lib.pk_debug_profile(buf, 0)
+        prof = dict(zip(('kernel', 'flush', 'walk', 'push_incl_flush', 'prologue', 'epilogue', 'n_flush', 'tiles'), list(buf)))
+        print('PK_SCORE_PROFILE', prof, file=sys.stderr)
     cand_ms = events_ms(ops.timers.get('score_candidates', []))
     fold_ms = events_ms(ops.timers.get('spmm', []))
     ops.timers = None

@@ -122,9 +122,16 @@ int32_t pk_candidate_capacity(int32_t topk);
 int64_t pk_score_state_bytes(int64_t n_users, int32_t splits);
 /* recommended number of item splits for this many users (1 when the users alone fill the chip) */
 int32_t pk_score_splits(int64_t n_users, int32_t KC);
+/* Seen-item lists (the rows of the test CSR: everything downvote_seen_items masks, models.py:494-519)
+ * folded into ONE 64-bit record per 32-item tile a user has seen items in: (tile << 32) | item mask.
+ * tiles_dev has the capacity of seen_idx_dev and is addressed by the same seen_ptr_dev; the records
+ * of user u are tiles_dev[seen_ptr[u] .. seen_ptr[u] + ntiles_dev[u]).  Rows must be sorted by item. */
+int pk_seen_tiles_build(void *stream, int64_t n_users, const int64_t *seen_ptr_dev, const int32_t *seen_idx_dev,
+                        uint64_t *tiles_dev, int32_t *ntiles_dev);
 int pk_score_candidates_f32(void *stream, int64_t n_users, int64_t n_items, int32_t K,
                             const float *Vp_dev, const float *Ep_dev,
-                            const int64_t *seen_ptr_dev, const int32_t *seen_idx_dev,
+                            const int64_t *seen_ptr_dev, const uint64_t *seen_tiles_dev,
+                            const int32_t *seen_ntiles_dev /* all three NULL: nothing is masked */,
                             int32_t KC, int32_t splits /* splits*KC <= 64 */,
                             float *cand_score_dev, int32_t *cand_idx_dev /* [splits][n_users_pad][KC] */,
                             void *state_dev /* pk_score_state_bytes(n_users, splits) */,

@@ -43,3 +43,40 @@ __device__ __forceinline__ float pk_wave_max(float v) {
     return v;
 }
 __device__ __forceinline__ int pk_lane() { return threadIdx.x & 63; }
+
+// ---- value of lane (lane ^ J) without touching the LDS pipe ---------------------------------------
+// __shfl_xor compiles to ds_bpermute_b32: ~100+ cycles of LDS latency per dependent step, which made
+// the 21-stage wave sorts of the scoring kernels latency-bound (6.3K cycles per flush).  DPP modifiers
+// cover J = 1, 2 (quad_perm), 4 (row_half_mirror then quad reversal), 8 (row_ror:8); gfx950's
+// v_permlane16_swap / v_permlane32_swap cover J = 16, 32.
+template <int J>
+__device__ __forceinline__ int pk_lane_xor(int v) {
+    static_assert(J == 1 || J == 2 || J == 4 || J == 8 || J == 16 || J == 32, "pk_lane_xor: J must be a power of two < 64");
+    if constexpr (J == 1) {
+        return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+    } else if constexpr (J == 2) {
+        return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+    } else if constexpr (J == 4) {
+        const int y = __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);   // row_half_mirror: i -> 7 - i
+        return __builtin_amdgcn_update_dpp(0, y, 0x1B, 0xf, 0xf, true);            // quad_perm [3,2,1,0]
+    } else if constexpr (J == 8) {
+        return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, true);  // row_ror:8
+    } else if constexpr (J == 16) {
+        // (a, b) <- swap(odd rows of a, even rows of b): a = (v0 v0 v2 v2), b = (v1 v1 v3 v3)
+        const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+        return ((threadIdx.x >> 4) & 1) ? (int)r[0] : (int)r[1];
+    } else {
+        const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+        return ((threadIdx.x >> 5) & 1) ? (int)r[0] : (int)r[1];
+    }
+}
+template <int J>
+__device__ __forceinline__ float pk_lane_xor(float v) {
+    return __int_as_float(pk_lane_xor<J>(__float_as_int(v)));
+}
+template <int J>
+__device__ __forceinline__ double pk_lane_xor(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = pk_lane_xor<J>((int)(unsigned)(b & 0xffffffffll)), hi = pk_lane_xor<J>((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}

@@ -19,24 +19,28 @@ __device__ __forceinline__ bool pk_before64(double ka, int va, double kb, int vb
 }
 
 // bitonic sort (descending by pk_before64) inside aligned segments of SEG lanes, one (key, val) per lane
+template <int SEG, int K, int J>
+__device__ __forceinline__ void pk_bitonic_seg_merge(double &key, int &val, int t) {
+    const double ok = pk_lane_xor<J>(key);
+    const int ov = pk_lane_xor<J>(val);
+    const bool lower = (t & J) == 0;
+    const bool desc = (t & K) == 0;   // t < SEG: the last level (K == SEG) is descending everywhere
+    const bool want_first = (lower == desc);
+    const bool other_first = pk_before64(ok, ov, key, val);
+    if (want_first == other_first) {
+        key = ok;
+        val = ov;
+    }
+    if constexpr (J > 1) pk_bitonic_seg_merge<SEG, K, (J >> 1)>(key, val, t);
+}
+template <int SEG, int K>
+__device__ __forceinline__ void pk_bitonic_seg_levels(double &key, int &val, int t) {
+    if constexpr (K > 2) pk_bitonic_seg_levels<SEG, (K >> 1)>(key, val, t);
+    pk_bitonic_seg_merge<SEG, K, (K >> 1)>(key, val, t);
+}
 template <int SEG>
 __device__ __forceinline__ void pk_bitonic_seg(double &key, int &val, int t) {
-#pragma unroll
-    for (int k = 2; k <= SEG; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            const double ok = __shfl_xor(key, j, 64);
-            const int ov = __shfl_xor(val, j, 64);
-            const bool lower = (t & j) == 0;
-            const bool desc = (t & k) == 0;   // t < SEG: the last stage (k == SEG) is descending everywhere
-            const bool want_first = (lower == desc);
-            const bool other_first = pk_before64(ok, ov, key, val);
-            if (want_first == other_first) {
-                key = ok;
-                val = ov;
-            }
-        }
-    }
+    pk_bitonic_seg_levels<SEG, SEG>(key, val, t);
 }
 
 // A LANE owns one candidate: it walks its own item row (the candidates of a user are popular items,

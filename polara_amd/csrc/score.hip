@@ -36,7 +36,33 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define RING 16          // lane-private candidate ring entries
+
+#ifdef PK_SCORE_PROFILE
+// tuning builds only: wave-cycles spent in [0] whole kernel, [1] flushes, [2] seen-list walk, [3] push path,
+// [4] prologue (state restore), [5] epilogue; [6] flush count, [7] tiles
+__device__ unsigned long long pk_prof[8];
+extern "C" int pk_debug_profile(unsigned long long *out, int reset) {
+    if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(pk_prof), sizeof(pk_prof));
+    if (reset) {
+        unsigned long long z[8] = {0};
+        hipMemcpyToSymbol(HIP_SYMBOL(pk_prof), z, sizeof(z));
+    }
+    return 0;
+}
+#define PROF_T() __builtin_readcyclecounter()
+#define PROF_DECL unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PROF_ADD(i, t0) do { prof_acc[i] += (unsigned long long)(__builtin_readcyclecounter() - (t0)); } while (0)
+#define PROF_INC(i, n) do { prof_acc[i] += (unsigned long long)(n); } while (0)
+#define PROF_FLUSH() do { if (lane == 0) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&pk_prof[i_], prof_acc[i_]); } while (0)
+#else
+#define PROF_T() 0ull
+#define PROF_DECL
+#define PROF_ADD(i, t0) do { (void)(t0); } while (0)
+#define PROF_INC(i, n) do { } while (0)
+#define PROF_FLUSH() do { } while (0)
+#endif
 #define PK_IDX_NONE 0x7fffffff
+#define PK_TILE_NONE 0xffffffff00000000ull   // end of a seen-tile stream
 
 // ---- ordering used everywhere: larger score first, then smaller item id ---------------------
 __device__ __forceinline__ bool pk_before(float ka, int va, float kb, int vb) {
@@ -45,52 +71,59 @@ __device__ __forceinline__ bool pk_before(float ka, int va, float kb, int vb) {
 
 // Wave-wide bitonic sort (descending by pk_before) of 64*SLOTS (key,val) pairs, element index
 // i = lane + 64*slot.
-template <int SLOTS>
-__device__ __forceinline__ void pk_bitonic_desc(float (&key)[SLOTS], int (&val)[SLOTS], int lane) {
-    constexpr int T = 64 * SLOTS;
+template <int SLOTS, int K, int J>
+__device__ __forceinline__ void pk_bitonic_stage(float (&key)[SLOTS], int (&val)[SLOTS], int lane) {
+    if constexpr (J >= 64) {
+        // partner lives in another slot of the same lane (only SLOTS == 2, J == 64)
+        constexpr int sj = J >> 6;
 #pragma unroll
-    for (int k = 2; k <= T; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            if (j >= 64) {
-                // partner lives in another slot of the same lane (only SLOTS == 2, j == 64)
-                const int sj = j >> 6;
-#pragma unroll
-                for (int s = 0; s < SLOTS; ++s) {
-                    if ((s & sj) == 0) {
-                        const int i = lane + 64 * s;
-                        const bool desc = (i & k) == 0;
-                        const bool swap = desc ? pk_before(key[s + sj], val[s + sj], key[s], val[s])
-                                               : pk_before(key[s], val[s], key[s + sj], val[s + sj]);
-                        if (swap) {
-                            float tk = key[s]; key[s] = key[s + sj]; key[s + sj] = tk;
-                            int tv = val[s]; val[s] = val[s + sj]; val[s + sj] = tv;
-                        }
-                    }
+        for (int s = 0; s < SLOTS; ++s) {
+            if ((s & sj) == 0) {
+                const int i = lane + 64 * s;
+                const bool desc = (i & K) == 0;
+                const bool swap = desc ? pk_before(key[s + sj], val[s + sj], key[s], val[s])
+                                       : pk_before(key[s], val[s], key[s + sj], val[s + sj]);
+                if (swap) {
+                    float tk = key[s]; key[s] = key[s + sj]; key[s + sj] = tk;
+                    int tv = val[s]; val[s] = val[s + sj]; val[s + sj] = tv;
                 }
-            } else {
+            }
+        }
+    } else {
 #pragma unroll
-                for (int s = 0; s < SLOTS; ++s) {
-                    const int i = lane + 64 * s;
-                    const float ok = __shfl_xor(key[s], j, 64);
-                    const int ov = __shfl_xor(val[s], j, 64);
-                    const bool lower = (i & j) == 0;
-                    const bool desc = (i & k) == 0;
-                    const bool want_first = (lower == desc);  // this position keeps the element that sorts first
-                    const bool other_first = pk_before(ok, ov, key[s], val[s]);
-                    if (want_first == other_first) {
-                        key[s] = ok;
-                        val[s] = ov;
-                    }
-                }
+        for (int s = 0; s < SLOTS; ++s) {
+            const int i = lane + 64 * s;
+            const float ok = pk_lane_xor<J>(key[s]);
+            const int ov = pk_lane_xor<J>(val[s]);
+            const bool lower = (i & J) == 0;
+            const bool desc = (i & K) == 0;
+            const bool want_first = (lower == desc);  // this position keeps the element that sorts first
+            const bool other_first = pk_before(ok, ov, key[s], val[s]);
+            if (want_first == other_first) {
+                key[s] = ok;
+                val[s] = ov;
             }
         }
     }
 }
+template <int SLOTS, int K, int J>
+__device__ __forceinline__ void pk_bitonic_merge(float (&key)[SLOTS], int (&val)[SLOTS], int lane) {
+    pk_bitonic_stage<SLOTS, K, J>(key, val, lane);
+    if constexpr (J > 1) pk_bitonic_merge<SLOTS, K, (J >> 1)>(key, val, lane);
+}
+template <int SLOTS, int K>
+__device__ __forceinline__ void pk_bitonic_levels(float (&key)[SLOTS], int (&val)[SLOTS], int lane) {
+    if constexpr (K > 2) pk_bitonic_levels<SLOTS, (K >> 1)>(key, val, lane);
+    pk_bitonic_merge<SLOTS, K, (K >> 1)>(key, val, lane);
+}
+template <int SLOTS>
+__device__ __forceinline__ void pk_bitonic_desc(float (&key)[SLOTS], int (&val)[SLOTS], int lane) {
+    pk_bitonic_levels<SLOTS, 64 * SLOTS>(key, val, lane);
+}
 
 // Per-lane state carried between the item-chunk launches of one scoring pass (global memory).
 struct LaneState {
-    int64_t sp;   // position in the user's seen list
+    int64_t sp;   // position in the user's seen-tile stream
     float tau;    // current threshold
     int cnt;      // entries in the lane's ring; PK_LANE_DONE once the wave has left the sweep (pruned)
 };
@@ -102,7 +135,8 @@ template <int NSTEP, int KC>
 __global__ __launch_bounds__(256) void score_candidates_kernel(
     const float4 *__restrict__ Vp, const float4 *__restrict__ Ep, int64_t n_users, int n_items,
     int n_tiles, int split_tiles, int chunk, int tiles_per_chunk,
-    const int64_t *__restrict__ seen_ptr, const int32_t *__restrict__ seen_idx,
+    const int64_t *__restrict__ seen_ptr, const unsigned long long *__restrict__ seen_tiles,
+    const int32_t *__restrict__ seen_ntiles,
     float *__restrict__ cand_score, int32_t *__restrict__ cand_idx,
     LaneState *__restrict__ st_lane, uint2 *__restrict__ st_ring,
     const float *__restrict__ user_bound, const float *__restrict__ tile_bound, int ablate) {
@@ -119,6 +153,8 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t group = (int64_t)blockIdx.x * 4 + wave;
     if (group * 32 >= n_users) return;  // whole wave leaves; the kernel has no workgroup barrier
+    PROF_DECL;
+    const unsigned long long prof_k0 = PROF_T();
     uint2(*ring)[64] = ring_all[wave];
     uint2 *top = top_all[TOP_LDS ? wave : 0];
 
@@ -147,7 +183,8 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
     for (int q = 0; q < KQ; ++q) e[q] = Ep[(group * KQ + q) * 64 + lane];
 
     int64_t sp = 0, se = 0;
-    int nxt = PK_IDX_NONE, nxt2 = PK_IDX_NONE, nxt3 = PK_IDX_NONE;  // next three seen items (prefetch window)
+    // next three (tile, mask) records of the user's seen-tile stream (prefetch window)
+    unsigned long long nxt = PK_TILE_NONE, nxt2 = PK_TILE_NONE, nxt3 = PK_TILE_NONE;
     float tau = -INFINITY;
     int cnt = 0;
     const bool prune = (user_bound != nullptr && tile_bound != nullptr) && !(ablate & 4);
@@ -158,18 +195,17 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
     const bool has_seen = (seen_ptr != nullptr && user < n_users);
     if (has_seen) {
         sp = seen_ptr[user];
-        se = seen_ptr[user + 1];
+        se = sp + seen_ntiles[user];
     }
     LaneState *my_state = st_lane + slot * 64 + lane;
     uint2 *my_ring_state = st_ring + slot * (RING * 64);
     if (first) {
         if (has_seen && t_lo > 0) {
-            // skip the part of the seen list that belongs to earlier splits: lower_bound(item >= 32*t_lo)
-            const int target = t_lo * 32;
+            // skip the part of the stream that belongs to earlier splits: lower_bound(tile >= t_lo)
             int64_t lo = sp, hi_ = se;
             while (lo < hi_) {
                 const int64_t mid = (lo + hi_) >> 1;
-                if (seen_idx[mid] < target) lo = mid + 1; else hi_ = mid;
+                if ((unsigned)(seen_tiles[mid] >> 32) < (unsigned)t_lo) lo = mid + 1; else hi_ = mid;
             }
             sp = lo;
         }
@@ -194,13 +230,15 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
         for (int i = 0; i < cmax; ++i) ring[i][lane] = my_ring_state[i * 64 + lane];
     }
     if (has_seen) {
-        if (sp < se) nxt = seen_idx[sp];
-        if (sp + 1 < se) nxt2 = seen_idx[sp + 1];
-        if (sp + 2 < se) nxt3 = seen_idx[sp + 2];
+        if (sp < se) nxt = seen_tiles[sp];
+        if (sp + 1 < se) nxt2 = seen_tiles[sp + 1];
+        if (sp + 2 < se) nxt3 = seen_tiles[sp + 2];
     }
 
     // merge the rings of user x (lanes x, x+32) and its top list; refresh list, tau, counters
     auto flush_user = [&](int x) {
+        const unsigned long long prof_f0 = PROF_T();
+        PROF_INC(6, 1);
         if (TOP_LDS) {
             // LDS only: program order within the wave + the LDS pipe's in-order execution suffice;
             // the barrier keeps the compiler from moving LDS accesses across the hand-off
@@ -272,6 +310,7 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
             cnt = 0;
         }
         __builtin_amdgcn_wave_barrier();
+        PROF_ADD(1, prof_f0);
     };
 
     // ---- building blocks of the tile pipeline --------------------------------------------------------
@@ -280,23 +319,25 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
 #pragma unroll
         for (int q = 0; q < KQ; ++q) dst[q] = vp[q * 64];
     };
-    // seen-item mask of a tile for my user (bit b <-> item 32*tile + b); advances the list cursor
+    // seen-item mask of a tile for my user (bit b <-> item 32*tile + b); advances the stream cursor.
+    // The stream holds ONE record per tile the user has seen items in (pk_seen_tiles_build), so this
+    // is at most one step per tile — no inner loop, and the record is requested three records ahead
+    // of its use.  (The first version walked the raw item list: in the popular head of the catalogue
+    // a user has several seen items per tile, every one a dependent load — the sweep was latency
+    // bound there once pruning had cut it down to the head.)
     auto walk_mask = [&](int tile) -> unsigned {
         const int j0 = tile * 32, jend = j0 + 32;
         unsigned mask = 0;
         if (ablate & 1) return 0u;   // tuning only: skip the seen-list walk
-        // the list cursor runs three entries ahead of its use, so the dependent load of the next
-        // seen item is (almost) never waited for: its latency hides behind whole tiles of MFMAs
-        if (__any(nxt < jend)) {
-            do {
-                if (nxt < jend) {
-                    mask |= 1u << (nxt - j0);
-                    ++sp;
-                    nxt = nxt2;
-                    nxt2 = nxt3;
-                    nxt3 = (sp + 2 < se) ? seen_idx[sp + 2] : PK_IDX_NONE;
-                }
-            } while (__any(nxt < jend));
+        const bool hit = (unsigned)(nxt >> 32) == (unsigned)tile;
+        if (__any(hit)) {
+            if (hit) {
+                mask = (unsigned)nxt;
+                ++sp;
+                nxt = nxt2;
+                nxt2 = nxt3;
+                nxt3 = (sp + 2 < se) ? seen_tiles[sp + 2] : PK_TILE_NONE;
+            }
         }
         if (jend > n_items) mask |= ~0u << (n_items - j0);  // padding items of the last tile
         return mask;
@@ -339,6 +380,7 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
         float4 a_nxt[KQ];
         load_frags((tile_begin < n_tiles) ? tile_begin : 0, a_nxt);
         float tb = prune ? tile_bound[(tile_begin < n_tiles) ? tile_begin : 0] : 0.0f;
+        PROF_ADD(4, prof_k0);
         for (int tile = tile_begin; tile < tile_end; ++tile) {
             if (prune) {
                 // can any item from this tile on still enter a list of this wave?
@@ -380,11 +422,14 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
             // RAW score beats the threshold (f32 MFMA shares the SIMD's FP32 lanes with the VALU, so
             // every VALU instruction here is paid in MFMA time: keep the common path to
             // 8 v_max3 + 1 compare and mask lazily).
+            const unsigned long long prof_w0 = PROF_T();
             const unsigned mask = walk_mask(tile);
+            PROF_ADD(2, prof_w0);
             float m_all = fmaxf(acc[0], acc[1]);
 #pragma unroll
             for (int r = 2; r < 16; ++r) m_all = fmaxf(m_all, acc[r]);
             if (!(ablate & 2) && __any(m_all > tau)) {
+                const unsigned long long prof_p0 = PROF_T();
                 float sc[16];
                 float m = m_all;
                 if (__any(mask != 0)) {
@@ -400,6 +445,7 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
                     for (int r = 0; r < 16; ++r) sc[r] = acc[r];
                 }
                 if (__any(m > tau)) push_candidates(sc, tile * 32);
+                PROF_ADD(3, prof_p0);
             }
         }
     }
@@ -420,6 +466,9 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
                 my_score[s] = __uint_as_float(r.x);
                 my_idx[s] = (int)r.y;
             }
+        PROF_INC(7, tile_end - tile_begin);
+        PROF_ADD(0, prof_k0);
+        PROF_FLUSH();
         return;
     }
     // final merge of whatever is left in the rings
@@ -440,6 +489,9 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
             my_idx[s] = (int)r.y;
         }
     }
+    PROF_INC(7, exit_tile - tile_begin);
+    PROF_ADD(0, prof_k0);
+    PROF_FLUSH();
     {
         // finished (possibly early): later chunk launches must not touch this group again; sp records
         // the tile at which the group left the sweep (pk_score_state layout: see polara_hip.h)
@@ -501,6 +553,72 @@ extern "C" int pk_pack_frag_f32(void *stream, int64_t n, int32_t K, const double
     hipLaunchKernelGGL(pack_frag_kernel, dim3((unsigned)pk_ceil_div(total, 256)), dim3(256), 0, pk_stream(stream), n,
                        K, kq, src_dev, ld, reinterpret_cast<float4 *>(dst_dev), total);
     PK_CHECK_LAUNCH("pack_frag_kernel");
+    return PK_OK;
+}
+
+// ---- seen-tile stream ----------------------------------------------------------------------------
+// One wave per user: the sorted seen-item list [seen_ptr[u], seen_ptr[u+1]) is folded into one
+// 64-bit record (tile << 32 | 32-bit item mask) per tile that holds seen items, written compactly
+// from position seen_ptr[u] of `tiles` (same indptr as the item list, at most as many records).
+__global__ __launch_bounds__(256) void seen_tiles_kernel(int64_t n_users, const int64_t *__restrict__ seen_ptr,
+                                                         const int32_t *__restrict__ seen_idx,
+                                                         unsigned long long *__restrict__ tiles,
+                                                         int32_t *__restrict__ ntiles) {
+    const int lane = threadIdx.x & 63;
+    const int64_t user = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (user >= n_users) return;
+    const int64_t p0 = seen_ptr[user], p1 = seen_ptr[user + 1];
+    int count = 0;
+    bool carry = false;             // the last tile of the previous chunk is emitted with the next chunk
+    unsigned c_tile = 0, c_mask = 0;
+    for (int64_t base = p0; base < p1; base += 64) {
+        const int64_t i = base + lane;
+        const bool valid = i < p1;
+        const int idx = valid ? seen_idx[i] : 0;
+        const unsigned tile = valid ? (unsigned)idx >> 5 : 0xffffffffu;
+        unsigned m = valid ? 1u << (idx & 31) : 0u;
+        // OR of the bits of my tile over the lanes to my right (sorted list: equal tiles are adjacent)
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned t2 = __shfl_down(tile, off, 64);
+            const unsigned m2 = __shfl_down(m, off, 64);
+            if (lane + off < 64 && t2 == tile) m |= m2;
+        }
+        const unsigned tprev = __shfl_up(tile, 1, 64);
+        const bool head = valid && (lane == 0 || tprev != tile);
+        const unsigned long long heads = __ballot(head);
+        const int n_valid = (int)((p1 - base < 64) ? (p1 - base) : 64);
+        const int last_head = 63 - __builtin_clzll(heads);          // heads != 0: lane 0 is valid
+        const unsigned f_tile = __shfl(tile, 0, 64);
+        if (carry) {
+            if (f_tile == c_tile) {
+                if (lane == 0) m |= c_mask;                          // same tile continues in this chunk
+            } else {
+                if (lane == 0) tiles[p0 + count] = ((unsigned long long)c_tile << 32) | c_mask;
+                ++count;
+            }
+        }
+        const int rank = __popcll(heads & ((1ull << lane) - 1ull));
+        if (head && lane != last_head) tiles[p0 + count + rank] = ((unsigned long long)tile << 32) | m;
+        count += __popcll(heads) - 1;
+        c_tile = __shfl(tile, last_head, 64);
+        c_mask = __shfl(m, last_head, 64);
+        carry = true;
+        (void)n_valid;
+    }
+    if (carry) {
+        if (lane == 0) tiles[p0 + count] = ((unsigned long long)c_tile << 32) | c_mask;
+        ++count;
+    }
+    if (lane == 0) ntiles[user] = count;
+}
+
+extern "C" int pk_seen_tiles_build(void *stream, int64_t n_users, const int64_t *seen_ptr_dev,
+                                   const int32_t *seen_idx_dev, uint64_t *tiles_dev, int32_t *ntiles_dev) {
+    PK_REQUIRE(n_users >= 1 && seen_ptr_dev && seen_idx_dev && tiles_dev && ntiles_dev, "pk_seen_tiles_build: bad arguments");
+    hipLaunchKernelGGL(seen_tiles_kernel, dim3((unsigned)pk_ceil_div(n_users, 4)), dim3(256), 0, pk_stream(stream),
+                       n_users, seen_ptr_dev, seen_idx_dev, reinterpret_cast<unsigned long long *>(tiles_dev), ntiles_dev);
+    PK_CHECK_LAUNCH("seen_tiles_kernel");
     return PK_OK;
 }
 
@@ -580,13 +698,14 @@ extern "C" int32_t pk_candidate_capacity(int32_t topk) {
 template <int NSTEP>
 static int launch_candidates_n(hipStream_t st, int KC, int ablate, dim3 grid, const float4 *Vp, const float4 *Ep,
                                int64_t n_users, int n_items, int n_tiles, int split_tiles, int tiles_per_chunk,
-                               const int64_t *seen_ptr, const int32_t *seen_idx, float *cs, int32_t *ci,
+                               const int64_t *seen_ptr, const unsigned long long *seen_tiles,
+                               const int32_t *seen_ntiles, float *cs, int32_t *ci,
                                LaneState *st_lane, uint2 *st_ring, const float *user_bound, const float *tile_bound) {
     const int n_chunks = (split_tiles + tiles_per_chunk - 1) / tiles_per_chunk;
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
 #define PK_LAUNCH(KCV)                                                                                          \
     hipLaunchKernelGGL((score_candidates_kernel<NSTEP, KCV>), grid, dim3(256), 0, st, Vp, Ep, n_users,          \
-                       n_items, n_tiles, split_tiles, chunk, tiles_per_chunk, seen_ptr, seen_idx, cs, ci, st_lane, st_ring,  \
+                       n_items, n_tiles, split_tiles, chunk, tiles_per_chunk, seen_ptr, seen_tiles, seen_ntiles, cs, ci, st_lane, st_ring,  \
                        user_bound, tile_bound, ablate)
 #ifdef PK_FAST_BUILD
         if (KC != 16) return PK_E_UNSUPPORTED;
@@ -633,7 +752,8 @@ extern "C" int32_t pk_score_splits(int64_t n_users, int32_t KC) {
 
 extern "C" int pk_score_candidates_f32(void *stream, int64_t n_users, int64_t n_items, int32_t K,
                                        const float *Vp_dev, const float *Ep_dev, const int64_t *seen_ptr_dev,
-                                       const int32_t *seen_idx_dev, int32_t KC, int32_t splits,
+                                       const uint64_t *seen_tiles_dev, const int32_t *seen_ntiles_dev,
+                                       int32_t KC, int32_t splits,
                                        float *cand_score_dev, int32_t *cand_idx_dev, void *state_dev,
                                        int32_t tiles_per_chunk, const float *user_bound_dev,
                                        const float *tile_bound_dev) {
@@ -644,6 +764,9 @@ extern "C" int pk_score_candidates_f32(void *stream, int64_t n_users, int64_t n_
     PK_REQUIRE(((uintptr_t)Vp_dev % 16) == 0 && ((uintptr_t)Ep_dev % 16) == 0, "pk_score_candidates_f32: alignment");
     PK_REQUIRE(state_dev != nullptr && ((uintptr_t)state_dev % 16) == 0, "pk_score_candidates_f32: state buffer");
     PK_REQUIRE(splits >= 1 && splits * KC <= 64, "pk_score_candidates_f32: need 1 <= splits and splits*KC <= 64");
+    PK_REQUIRE((seen_ptr_dev == nullptr) == (seen_tiles_dev == nullptr) &&
+                   (seen_ptr_dev == nullptr) == (seen_ntiles_dev == nullptr),
+               "pk_score_candidates_f32: seen_ptr, seen_tiles, seen_ntiles go together (all or none)");
     PK_REQUIRE((user_bound_dev == nullptr) == (tile_bound_dev == nullptr),
                "pk_score_candidates_f32: user_bound and tile_bound go together (both or neither)");
     hipStream_t st = pk_stream(stream);
@@ -663,7 +786,9 @@ extern "C" int pk_score_candidates_f32(void *stream, int64_t n_users, int64_t n_
 #define PK_N_CASE(Q)                                                                                          \
     case Q:                                                                                                   \
         rc = launch_candidates_n<Q>(st, KC, ablate, grid, Vp, Ep, n_users, (int)n_items, n_tiles,            \
-                                    split_tiles, tiles_per_chunk, seen_ptr_dev, seen_idx_dev, cand_score_dev, cand_idx_dev, \
+                                    split_tiles, tiles_per_chunk, seen_ptr_dev,                                   \
+                                    reinterpret_cast<const unsigned long long *>(seen_tiles_dev), seen_ntiles_dev, \
+                                    cand_score_dev, cand_idx_dev,                                              \
                                     st_lane, st_ring, user_bound_dev, tile_bound_dev);                         \
         break;
     const char *abl_env = getenv("PK_SCORE_ABLATE");   // kernel-tuning knob, never set in production

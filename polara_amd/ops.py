@@ -346,6 +346,16 @@ class HipOps:
                                                    _ptr(out)), 'pk_tile_norm_bound_f32')
         return out
 
+    def seen_tiles(self, seen_ptr, seen_idx, n_users):
+        """The seen-item lists folded into one (tile << 32 | item mask) record per touched 32-item tile:
+        uint64 stream addressed by the same indptr + the record count per user."""
+        tiles = torch.empty(max(int(seen_idx.numel()), 1), dtype=torch.int64, device=self.device)
+        ntiles = torch.empty(n_users, dtype=torch.int32, device=self.device)
+        with self._timed('seen_tiles', (n_users, int(seen_idx.numel()))):
+            _lib.check(self.lib.pk_seen_tiles_build(self.stream(), n_users, _ptr(seen_ptr), _ptr(seen_idx),
+                                                    _ptr(tiles), _ptr(ntiles)), 'pk_seen_tiles_build')
+        return tiles, ntiles
+
     def score_candidates(self, Vp, Ep, n_users, n_items, K, seen_ptr, seen_idx, KC, splits=1, tiles_per_chunk=0,
                          user_bound=None, tile_bound=None):
         n_pad = -(-n_users // 32) * 32
@@ -354,9 +364,13 @@ class HipOps:
             self._score_state = torch.empty(need, dtype=torch.uint8, device=self.device)
         cs = torch.empty(splits * n_pad * KC, dtype=torch.float32, device=self.device)
         ci = torch.empty(splits * n_pad * KC, dtype=torch.int32, device=self.device)
+        tiles = ntiles = None
+        if seen_ptr is not None:
+            tiles, ntiles = self.seen_tiles(seen_ptr, seen_idx, n_users)
         with self._timed('score_candidates', (n_users, n_items, K)):
             _lib.check(self.lib.pk_score_candidates_f32(self.stream(), n_users, n_items, K, _ptr(Vp), _ptr(Ep),
-                                                        _ptr(seen_ptr), _ptr(seen_idx), KC, splits, _ptr(cs), _ptr(ci),
+                                                        _ptr(seen_ptr), _ptr(tiles), _ptr(ntiles), KC, splits,
+                                                        _ptr(cs), _ptr(ci),
                                                         _ptr(self._score_state),
                                                         tiles_per_chunk or self.score_tiles_per_chunk,
                                                         _ptr(user_bound), _ptr(tile_bound)),

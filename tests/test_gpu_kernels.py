@@ -247,6 +247,27 @@ def test_chunked_item_sweep_equals_single_sweep(hip_ops, tiles_per_chunk):
     assert np.array_equal(hip_ops.to_host(ref_s), hip_ops.to_host(got_s))
 
 
+def test_seen_tile_stream(hip_ops):
+    """pk_seen_tiles_build: one (tile << 32 | mask) record per touched tile, in order, for short, empty,
+    multi-chunk (> 64 entries) and dense rows."""
+    rng = np.random.RandomState(5)
+    n_users, n_items = 300, 5000
+    indptr, indices, values = rand_csr(rng, n_users, n_items, 30, long_rows=[(2, 4000), (9, 64), (10, 65), (11, 129)],
+                                       empty_rows=[0, 7])
+    sp, si = hip_ops.to_device(indptr.astype(np.int64)), hip_ops.to_device(indices.astype(np.int32))
+    tiles, ntiles = hip_ops.seen_tiles(sp, si, n_users)
+    tiles, ntiles = hip_ops.to_host(tiles).view(np.uint64), hip_ops.to_host(ntiles)
+    for u in range(n_users):
+        row = indices[indptr[u]:indptr[u + 1]].astype(np.int64)
+        want = {}
+        for j in row:
+            want[j >> 5] = want.get(j >> 5, 0) | (1 << (j & 31))
+        got = tiles[indptr[u]:indptr[u] + ntiles[u]]
+        assert ntiles[u] == len(want), u
+        assert [int(g >> np.uint64(32)) for g in got] == sorted(want), u
+        assert [int(g & np.uint64(0xffffffff)) for g in got] == [want[t] for t in sorted(want)], u
+
+
 def test_pruning_bounds_are_upper_bounds(hip_ops):
     rng = np.random.RandomState(3)
     for n, K in ((1000, 50), (33, 7), (4097, 200)):
