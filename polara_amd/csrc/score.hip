@@ -35,7 +35,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define RING 16          // lane-private candidate ring entries
+#define RING 16          // lane-private candidate ring entries (8 for KC == 16, see PAIRED below)
 
 #ifdef PK_SCORE_PROFILE
 // tuning builds only: wave-cycles spent in [0] whole kernel, [1] flushes, [2] seen-list walk, [3] push path,
@@ -121,6 +121,28 @@ __device__ __forceinline__ void pk_bitonic_desc(float (&key)[SLOTS], int (&val)[
     pk_bitonic_levels<SLOTS, 64 * SLOTS>(key, val, lane);
 }
 
+// the same network inside each 32-lane half (t = lane & 31): both halves end up descending
+template <int K, int J>
+__device__ __forceinline__ void pk_bitonic_half_merge(float &key, int &val, int t) {
+    const float ok = pk_lane_xor<J>(key);
+    const int ov = pk_lane_xor<J>(val);
+    const bool want_first = (((t & J) == 0) == ((t & K) == 0));
+    const bool other_first = pk_before(ok, ov, key, val);
+    if (want_first == other_first) {
+        key = ok;
+        val = ov;
+    }
+    if constexpr (J > 1) pk_bitonic_half_merge<K, (J >> 1)>(key, val, t);
+}
+template <int K>
+__device__ __forceinline__ void pk_bitonic_half_levels(float &key, int &val, int t) {
+    if constexpr (K > 2) pk_bitonic_half_levels<(K >> 1)>(key, val, t);
+    pk_bitonic_half_merge<K, (K >> 1)>(key, val, t);
+}
+__device__ __forceinline__ void pk_bitonic_half_desc(float &key, int &val, int t) {
+    pk_bitonic_half_levels<32>(key, val, t);
+}
+
 // Per-lane state carried between the item-chunk launches of one scoring pass (global memory).
 struct LaneState {
     int64_t sp;   // position in the user's seen-tile stream
@@ -141,12 +163,16 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
     LaneState *__restrict__ st_lane, uint2 *__restrict__ st_ring,
     const float *__restrict__ user_bound, const float *__restrict__ tile_bound, int ablate) {
     constexpr int KQ = (NSTEP + 3) / 4;
-    constexpr int SLOTS = (2 * RING + KC + 63) / 64;
+    // KC == 16: rings of 8, so that a user's list + both rings are 32 entries and TWO users are merged
+    // per flush, one in each half of the wave (15 sort stages per two users instead of 21 per user).
+    constexpr bool PAIRED = (KC == 16);
+    constexpr int RG = PAIRED ? 8 : RING;
+    constexpr int SLOTS = (2 * RG + KC + 63) / 64;
     // The running top-KC lists of the wave's 32 users live in LDS when they fit (KC <= 32): a flush
     // then never touches global memory (no vmcnt drain in the middle of the MFMA stream).  They are
     // copied from / to cand_score, cand_idx at the launch boundaries.
     constexpr bool TOP_LDS = (KC <= 32);
-    __shared__ uint2 ring_all[4][RING][64];
+    __shared__ uint2 ring_all[4][RG][64];
     __shared__ uint2 top_all[TOP_LDS ? 4 : 1][TOP_LDS ? 32 * KC : 1];
 
     const int lane = threadIdx.x & 63;
@@ -257,20 +283,20 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
             const int i = lane + 64 * s;
             float k = -INFINITY;
             int v = PK_IDX_NONE;
-            if (i < RING) {
+            if (i < RG) {
                 if (i < c_lo) {
                     uint2 r = ring[i][x];
                     k = __uint_as_float(r.x);
                     v = (int)r.y;
                 }
-            } else if (i < 2 * RING) {
-                if (i - RING < c_hi) {
-                    uint2 r = ring[i - RING][x + 32];
+            } else if (i < 2 * RG) {
+                if (i - RG < c_hi) {
+                    uint2 r = ring[i - RG][x + 32];
                     k = __uint_as_float(r.x);
                     v = (int)r.y;
                 }
-            } else if (i < 2 * RING + KC) {
-                const int t = i - 2 * RING;
+            } else if (i < 2 * RG + KC) {
+                const int t = i - 2 * RG;
                 if (TOP_LDS) {
                     const uint2 r = top[x * KC + t];
                     if ((int)r.y >= 0) {
@@ -312,6 +338,75 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
         __builtin_amdgcn_wave_barrier();
         PROF_ADD(1, prof_f0);
     };
+    // KC == 16: users x (lanes 0..31) and y (lanes 32..63; y < 0: nobody) merged in one 32-wide sort each
+    auto flush_pair = [&](int x, int y) {
+        const unsigned long long prof_f0 = PROF_T();
+        PROF_INC(6, 1);
+        __builtin_amdgcn_wave_barrier();
+        const int t = lane & 31;
+        const int yy = (y >= 0) ? y : x;
+        const int cx_lo = __builtin_amdgcn_readlane(cnt, x), cx_hi = __builtin_amdgcn_readlane(cnt, x + 32);
+        const int cy_lo = __builtin_amdgcn_readlane(cnt, yy), cy_hi = __builtin_amdgcn_readlane(cnt, yy + 32);
+        const int u = hi ? yy : x;
+        const int c_lo = hi ? cy_lo : cx_lo, c_hi = hi ? cy_hi : cx_hi;
+        const bool act = !hi || y >= 0;
+        float k = -INFINITY;
+        int v = PK_IDX_NONE;
+        if (act) {
+            if (t < KC) {
+                const uint2 r = top[u * KC + t];
+                if ((int)r.y >= 0) {
+                    k = __uint_as_float(r.x);
+                    v = (int)r.y;
+                }
+            } else if (t < KC + RG) {
+                if (t - KC < c_lo) {
+                    const uint2 r = ring[t - KC][u];
+                    k = __uint_as_float(r.x);
+                    v = (int)r.y;
+                }
+            } else if (t - KC - RG < c_hi) {
+                const uint2 r = ring[t - KC - RG][u + 32];
+                k = __uint_as_float(r.x);
+                v = (int)r.y;
+            }
+        }
+        pk_bitonic_half_desc(k, v, t);
+        if (act && t < KC) top[u * KC + t] = make_uint2(__float_as_uint(k), (unsigned)((v == PK_IDX_NONE) ? -1 : v));
+        const float tx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(k), KC - 1));
+        const float ty = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(k), 32 + KC - 1));
+        if (ul == x) {
+            tau = tx;
+            cnt = 0;
+        }
+        if (y >= 0 && ul == y) {
+            tau = ty;
+            cnt = 0;
+        }
+        __builtin_amdgcn_wave_barrier();
+        PROF_ADD(1, prof_f0);
+    };
+    // merge every user of the bit set `um`
+    auto flush_set = [&](unsigned um) {
+        if constexpr (PAIRED) {
+            while (um) {
+                const int x = __builtin_ctz(um);
+                um &= um - 1;
+                int y = -1;
+                if (um) {
+                    y = __builtin_ctz(um);
+                    um &= um - 1;
+                }
+                flush_pair(x, y);
+            }
+        } else {
+            while (um) {
+                const int x = __builtin_ctz(um);
+                um &= um - 1;
+                flush_user(x);
+            }
+        }
+    };
 
     // ---- building blocks of the tile pipeline --------------------------------------------------------
     auto load_frags = [&](int tile, float4(&dst)[KQ]) {
@@ -348,14 +443,16 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
         for (int r = 0; r < 16; ++r) {
             bool c = acc[r] > tau;
             if (__any(c)) {
-                if (__any(c && cnt == RING)) {
-                    const unsigned long long full = __ballot(cnt == RING);
+                if (__any(c && cnt == RG)) {
+                    const unsigned long long full = __ballot(cnt == RG);
                     unsigned um = (unsigned)(full | (full >> 32));
-                    while (um) {
-                        const int x = __builtin_ctz(um);
-                        um &= um - 1;
-                        flush_user(x);
+                    if (PAIRED && (__builtin_popcount(um) & 1)) {
+                        // the free half of the last sort takes a user whose rings are at least half full
+                        const unsigned long long part = __ballot(2 * cnt >= RG);
+                        const unsigned cand = (unsigned)(part | (part >> 32)) & ~um;
+                        if (cand) um |= 1u << __builtin_ctz(cand);
                     }
+                    flush_set(um);
                     c = acc[r] > tau;
                 }
                 if (c) {
@@ -395,12 +492,7 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
                 // get their pending ring entries merged so that their tau is exact (checked every 8 tiles)
                 if ((tile & 7) == 7 && __popcll(ob) <= 16) {
                     const unsigned long long pend = __ballot(cnt > 0);
-                    unsigned um = (unsigned)(ob | (ob >> 32)) & (unsigned)(pend | (pend >> 32));
-                    while (um) {
-                        const int x = __builtin_ctz(um);
-                        um &= um - 1;
-                        flush_user(x);
-                    }
+                    flush_set((unsigned)(ob | (ob >> 32)) & (unsigned)(pend | (pend >> 32)));
                 }
                 tb = tile_bound[(tile + 1 < n_tiles) ? tile + 1 : tile];
             }
@@ -474,12 +566,7 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
     // final merge of whatever is left in the rings
     {
         const unsigned long long some = __ballot(cnt > 0);
-        unsigned um = (unsigned)(some | (some >> 32));
-        while (um) {
-            const int x = __builtin_ctz(um);
-            um &= um - 1;
-            flush_user(x);
-        }
+        flush_set((unsigned)(some | (some >> 32)));
     }
     if (TOP_LDS) {
         __builtin_amdgcn_wave_barrier();

@@ -11,6 +11,7 @@
 // HBM/L2-bound by construction: 1 FMA per 8 bytes gathered.  No atomics: long rows are split into
 // tasks that write partial sums, added in slot order by spmm_fixup_kernel (deterministic).
 #include "pk_common.h"
+#include <stdlib.h>
 
 template <typename VT>
 __device__ __forceinline__ double pk_bcast_val(VT a, int t);
@@ -110,6 +111,133 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(
     }
 }
 
+// ---- second mapping: GROUPS nnz per wave step --------------------------------------------------
+// The wave is cut into GROUPS groups of LG = 64/GROUPS lanes; group g takes nnz g, g+GROUPS, ... of the
+// task and every lane owns FOUR columns (2l, 2l+1, 2LG+2l, 2LG+2l+1), fetched with two 16-byte loads
+// that are contiguous across the group.  Per wave step 2 row loads and 4 FMAs serve GROUPS nnz (~3-4
+// instructions per nnz for nc <= 64 instead of ~15 in the column-per-lane kernel); the 64 pairs of a
+// chunk still arrive through one coalesced load and reach the groups via ds_bpermute.  The group
+// partial sums are added in a fixed order at the end (deterministic).  Needs even nc / ldx and a
+// 16-byte aligned X, else the column-per-lane kernel runs.
+// Measured (S-1M, 1e8 nnz, MI355X): 5x fewer instructions and half the VMEM instructions buy only
+// 3-5 % (A.X 3.47 -> 3.28 ms, build SpMM total 351 -> 341 ms); fetching the pairs with per-group
+// broadcast loads instead of ds_bpermute was 35 % SLOWER.  The gathers themselves bound this kernel:
+// nnz * nc * 8 bytes of 400-512 B row pieces through L2 -> L1 at ~16 TB/s (A.X, X on chip) or from HBM
+// at ~7.3 TB/s (A^T.Y) — neither instruction issue nor loads in flight.
+template <typename VT, int GROUPS>
+__global__ __launch_bounds__(256) void spmm_csr_groups_kernel(
+    int64_t n_tasks, const int32_t *__restrict__ task_row, const int64_t *__restrict__ task_begin,
+    const int64_t *__restrict__ task_end, const int32_t *__restrict__ task_slot,
+    const int32_t *__restrict__ indices, const VT *__restrict__ vals, const double *__restrict__ X,
+    int64_t ldx, int nc, double *__restrict__ out, int64_t ldo, double *__restrict__ partial) {
+    constexpr int LG = 64 / GROUPS;
+    constexpr int U = 4;   // wave steps per register set (two sets in flight)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t task = (int64_t)blockIdx.x * 4 + wave;
+    if (task >= n_tasks) return;
+    const int64_t p0 = task_begin[task];
+    const int n = (int)(task_end[task] - p0);
+    const int g = lane / LG, l = lane % LG;
+    const int c0 = 2 * l, c1 = 2 * LG + 2 * l;
+    const bool ok0 = c0 < nc, ok1 = c1 < nc;          // nc is even: a column pair is in or out as a whole
+    const double *x0 = X + (ok0 ? c0 : 0);
+    const double *x1 = X + (ok1 ? c1 : 0);
+    const int32_t *ip = indices + p0;
+    const VT *vp = vals + p0;
+
+    double2 acc0 = make_double2(0.0, 0.0), acc1 = make_double2(0.0, 0.0);
+    constexpr int SPC = 64 / GROUPS;      // wave steps per 64-pair chunk
+    constexpr int SETS = SPC / U;         // register sets per chunk (U steps each)
+    // the 64 (index, value) pairs of a chunk are fetched with one coalesced load (next chunk prefetched)
+    // and handed to the groups through ds_bpermute: no extra VMEM instruction per step
+    int jc = 0, jn = 0;
+    VT ac = (VT)0, an = (VT)0;
+    if (lane < n) {
+        jc = ip[lane];
+        ac = vp[lane];
+    }
+    if (64 + lane < n) {
+        jn = ip[64 + lane];
+        an = vp[64 + lane];
+    }
+    auto issue = [&](int jch, int st0, double2(&xa)[U], double2(&xb)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int jj = __shfl(jch, (st0 + u) * GROUPS + g, 64);
+            const int64_t off = (int64_t)jj * ldx;
+            xa[u] = *reinterpret_cast<const double2 *>(x0 + off);
+            xb[u] = *reinterpret_cast<const double2 *>(x1 + off);
+        }
+    };
+    auto consume = [&](VT ach, int st0, const double2(&xa)[U], const double2(&xb)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const double aa = (double)__shfl(ach, (st0 + u) * GROUPS + g, 64);
+            acc0.x = fma(aa, xa[u].x, acc0.x);
+            acc0.y = fma(aa, xa[u].y, acc0.y);
+            acc1.x = fma(aa, xb[u].x, acc1.x);
+            acc1.y = fma(aa, xb[u].y, acc1.y);
+        }
+    };
+    double2 xa0[U], xb0[U], xa1[U], xb1[U];
+    issue(jc, 0, xa0, xb0);
+    for (int p = 0; p < n; p += 64) {
+        const int cnt = (n - p) < 64 ? (n - p) : 64;   // pairs of this chunk; padded lanes hold (0, 0.0)
+        const bool more = p + 64 < n;
+        int jf = 0;
+        VT af = (VT)0;
+        if (p + 128 + lane < n) {   // pairs two chunks ahead
+            jf = ip[p + 128 + lane];
+            af = vp[p + 128 + lane];
+        }
+        // sets alternate between the two register files; a set is skipped when the chunk ends before it
+#pragma unroll
+        for (int k = 0; k < SETS; ++k) {
+            const bool have = k * U * GROUPS < cnt;
+            const bool have_next = (k + 1 < SETS) ? ((k + 1) * U * GROUPS < cnt) : more;
+            if ((k & 1) == 0) {
+                if (have_next) {
+                    if (k + 1 < SETS) issue(jc, (k + 1) * U, xa1, xb1);
+                    else issue(jn, 0, xa1, xb1);
+                }
+                if (have) consume(ac, k * U, xa0, xb0);
+            } else {
+                if (have_next) {
+                    if (k + 1 < SETS) issue(jc, (k + 1) * U, xa0, xb0);
+                    else issue(jn, 0, xa0, xb0);
+                }
+                if (have) consume(ac, k * U, xa1, xb1);
+            }
+        }
+        jc = jn; ac = an;
+        jn = jf; an = af;
+    }
+
+    // add the GROUPS partial sums in group order (fixed): after the exchange every lane holds the total
+    if constexpr (GROUPS == 4) {
+        // (g0 + g1) and (g2 + g3) first, then the two pairs: the same association in every lane
+        acc0.x += pk_lane_xor<16>(acc0.x); acc0.y += pk_lane_xor<16>(acc0.y);
+        acc1.x += pk_lane_xor<16>(acc1.x); acc1.y += pk_lane_xor<16>(acc1.y);
+    }
+    if constexpr (GROUPS >= 2) {
+        acc0.x += pk_lane_xor<32>(acc0.x); acc0.y += pk_lane_xor<32>(acc0.y);
+        acc1.x += pk_lane_xor<32>(acc1.x); acc1.y += pk_lane_xor<32>(acc1.y);
+    }
+    const int slot = task_slot[task];
+    double *dst = slot < 0 ? out + (int64_t)task_row[task] * ldo : partial + (int64_t)slot * nc;
+    if (g == 0) {
+        if (ok0) {
+            dst[c0] = acc0.x;
+            dst[c0 + 1] = acc0.y;
+        }
+        if (ok1) {
+            dst[c1] = acc1.x;
+            dst[c1 + 1] = acc1.y;
+        }
+    }
+}
+
 // out[row, :] = sum_{s in [slot_begin, slot_end)} partial[s, :]   (fixed order)
 __global__ __launch_bounds__(256) void spmm_fixup_kernel(
     int64_t n_long, const int32_t *__restrict__ long_row, const int32_t *__restrict__ slot_begin,
@@ -132,6 +260,17 @@ static int launch_spmm(hipStream_t st, int64_t n_tasks, const int32_t *task_row,
                        double *partial) {
     dim3 grid((unsigned)pk_ceil_div(n_tasks, 4)), block(256);
     const VT *v = static_cast<const VT *>(vals);
+    const bool paired = (nc % 2 == 0) && (ldx % 2 == 0) && (((uintptr_t)X) % 16 == 0) && !getenv("PK_SPMM_LANE_COLUMNS");
+    if (paired) {
+#define PK_SPMM_GROUPS(G)                                                                                  \
+    hipLaunchKernelGGL((spmm_csr_groups_kernel<VT, G>), grid, block, 0, st, n_tasks, task_row, task_begin,  \
+                       task_end, task_slot, indices, v, X, ldx, nc, out, ldo, partial)
+        if (nc <= 64) PK_SPMM_GROUPS(4);
+        else if (nc <= 128) PK_SPMM_GROUPS(2);
+        else PK_SPMM_GROUPS(1);
+#undef PK_SPMM_GROUPS
+        return PK_OK;
+    }
     const int cpl = (nc + 63) / 64;
 #define PK_SPMM_CASE(C)                                                                              \
     case C:                                                                                          \
