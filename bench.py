@@ -43,6 +43,8 @@ def parse():
     ap.add_argument('--workload', default='s1m', choices=['s1m', 'ml20m', 'ml1m'])
     ap.add_argument('--no-prune', action='store_true',
                     help='score every item tile for every user (disables the exact norm-bound pruning of the sweep)')
+    ap.add_argument('--batches', type=int, default=0,
+                    help='user batches per scoring pass, round-robin on two HIP streams (0 = auto: one batch per 4M users)')
     ap.add_argument('--scale', type=float, default=1.0, help='shrink users/items (debug only; invalidates the number)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--item-order', default='popularity', choices=['popularity', 'natural'],
@@ -189,24 +191,28 @@ def main():
     F = scoring.FactorImage(ops, V)
 
     # ---- timed region: K full scoring passes ------------------------------------------------------------
+    kw = dict(prune=not args.no_prune, batches=args.batches or None)
     for _ in range(args.warmup):
-        scoring.recommend(ops, F, A, topk, True, prune=not args.no_prune)
-    ops.timers = {}
-    stats = {}
+        scoring.recommend(ops, F, A, topk, True, **kw)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        recs = scoring.recommend(ops, F, A, topk, True, prune=not args.no_prune)
+        recs = scoring.recommend(ops, F, A, topk, True, **kw)
     barrier()
     elapsed = time.perf_counter() - t0
+    # ---- untimed instrumented passes: one batch, HIP events around every kernel (the durations the roofline
+    # is computed from are those of the kernels running ALONE, not overlapped with another batch's fold-in)
+    ops.timers = {}
+    stats = {}
     prof = None
     if os.environ.get('PK_SCORE_PROFILE'):   # tuning builds only (polara_amd/build_native.py)
         import ctypes
         buf = (ctypes.c_ulonglong * 8)()
         ops.lib.pk_debug_profile(None, 1)
-    scoring.recommend(ops, F, A, topk, True, stats=stats, prune=not args.no_prune)   # untimed: sweep statistics
+    for _ in range(3):
+        scoring.recommend(ops, F, A, topk, True, stats=stats, prune=not args.no_prune, batches=1)
+    torch.cuda.synchronize()
     if os.environ.get('PK_SCORE_PROFILE'):
-        torch.cuda.synchronize()
         ops.lib.pk_debug_profile(buf, 0)
         prof = dict(zip(('kernel', 'flush', 'walk', 'push_incl_flush', 'prologue', 'epilogue', 'n_flush', 'tiles'), list(buf)))
         print('PK_SCORE_PROFILE', prof, file=sys.stderr)
@@ -239,7 +245,8 @@ def main():
                                 'ml1m': 'ML-1M-shaped synthetic 6040 x 3706, PureSVD rank=10, top-10 (BASELINE.json configs[0])'}[args.workload],
                    'n_users': n_users, 'n_items': n_items, 'nnz': nnz, 'rank': rank, 'topk': topk,
                    'parallelism': 'users sharded over %d GPU(s); Gramian all-reduce in build only' % comm.world,
-                   'scale': args.scale, 'item_order': args.item_order, 'prune': not args.no_prune},
+                   'scale': args.scale, 'item_order': args.item_order, 'prune': not args.no_prune,
+                   'batches': args.batches or 'auto'},
         'build_s': build_s,
         'build': {'gramian_steps': bstats['gramian_steps'], 'outer_iterations': bstats['outer'],
                   'block': bstats['block'], 'converged': bstats['converged'], 'spmm_launches': len(spmm_ms),
@@ -252,7 +259,8 @@ def main():
                      'traffic_note': 'HBM/fabric bytes per scoring pass = 9 item-chunk launches x (2*FETCH_SIZE + WRITE_SIZE) '
                                      'of a separate rocprofv3 --pmc run (profiles/r01_bench_pmc_*.txt); algorithmic minimum ~1 GB',
                      'launches': len(cand_ms), 'avg_ms': cand_avg_ms, 'flop_per_launch': flops_exec,
-                     'swept_fraction': swept,
+                     'swept_fraction': swept, 'exit_tile_quantiles': stats.get('exit_tile_quantiles'),
+                     'n_tiles': -(-n_items // 32),
                      'note': 'achieved/frac count only the MFMA tiles actually scored: the sweep is pruned exactly '
                              '(Cauchy-Schwarz bound, identical results; --no-prune scores every tile)',
                      'dense_equivalent': {'flop_per_launch': flops, 'TFLOP/s': flops / (cand_avg_ms * 1e-3) / 1e12,

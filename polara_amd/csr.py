@@ -81,7 +81,11 @@ def build_row_tasks(indptr, split=SPLIT_NNZ):
     if long_rows.size:
         long_task_mask = is_long[task_row]
         task_slot[long_task_mask] = np.arange(int(long_chunks.sum()), dtype=np.int32)
-    return dict(task_row=task_row.astype(np.int32), task_begin=begin, task_end=end, task_slot=task_slot,
+    # host-side index of the plan by row (tasks and long rows are in row order): lets a caller run a
+    # contiguous row range of the matrix as its own launch (user batches on separate streams)
+    row_first_task = np.concatenate(([0], np.cumsum(n_chunks))).astype(np.int64)
+    return dict(row_first_task=row_first_task,
+                task_row=task_row.astype(np.int32), task_begin=begin, task_end=end, task_slot=task_slot,
                 long_row=long_rows.astype(np.int32), long_slot_begin=slot_begin.astype(np.int32),
                 long_slot_end=slot_end.astype(np.int32), n_slots=int(long_chunks.sum()) if long_rows.size else 0)
 

@@ -15,8 +15,9 @@ from . import _lib
 from .csr import build_row_tasks, SPLIT_NNZ
 
 
-def _ptr(t):
-    return C.c_void_p(t.data_ptr()) if t is not None else None
+def _ptr(t, offset=0):
+    """device pointer of tensor `t`, advanced by `offset` ELEMENTS"""
+    return C.c_void_p(t.data_ptr() + offset * t.element_size()) if t is not None else None
 
 
 class DeviceCSR:
@@ -42,12 +43,15 @@ class DeviceCSR:
         self.indices = torch.from_numpy(indices).to(dev)
         self.values = torch.from_numpy(values).to(dev)
         plan = build_row_tasks(indptr, split)
+        self.row_first_task = plan.pop('row_first_task')   # host only
+        self.long_row_host = plan['long_row']
         self.n_tasks = len(plan['task_row'])
         self.n_long = len(plan['long_row'])
         self.n_slots = plan['n_slots']
         self.plan = {k: torch.from_numpy(v).to(dev) for k, v in plan.items() if isinstance(v, np.ndarray)}
         self._partial = None
         self._T = None
+        self._seen_tiles = None
 
     def partial(self, nc):
         need = self.n_slots * nc
@@ -56,6 +60,13 @@ class DeviceCSR:
         if self._partial is None or self._partial.numel() < need:
             self._partial = torch.empty(need, dtype=torch.float64, device=self.ops.device)
         return self._partial
+
+    def seen_tiles(self):
+        """(tiles, ntiles): this matrix's rows as seen-tile streams for the candidate sweep — a format image of
+        the CSR like the transpose, built once per matrix (pk_seen_tiles_build)."""
+        if self._seen_tiles is None:
+            self._seen_tiles = self.ops.seen_tiles(self.indptr, self.indices, self.shape[0])
+        return self._seen_tiles
 
     @property
     def T(self):
@@ -90,12 +101,15 @@ class DeviceCSR:
         self.nnz = int(host_ptr[-1])
         self._host = None
         plan = build_row_tasks(host_ptr, split)
+        self.row_first_task = plan.pop('row_first_task')   # host only
+        self.long_row_host = plan['long_row']
         self.n_tasks = len(plan['task_row'])
         self.n_long = len(plan['long_row'])
         self.n_slots = plan['n_slots']
         self.plan = {k: torch.from_numpy(v).to(ops.device) for k, v in plan.items() if isinstance(v, np.ndarray)}
         self._partial = None
         self._T = None
+        self._seen_tiles = None
         return self
 
     def drop_host(self):
@@ -112,6 +126,8 @@ class HipOps:
         self.device = torch.device(device if device is not None else 'cuda:%d' % torch.cuda.current_device())
         self._gram_work = None
         self._score_state = None
+        self._score_states = None
+        self._aux_streams = []
         self.score_tiles_per_chunk = 0   # 0 = auto (L2-sized item chunks); tests force tiny chunks
         self.score_splits_override = 0   # 0 = auto (pk_score_splits)
         self._info = torch.zeros(2, dtype=torch.int32, device=self.device)
@@ -139,6 +155,12 @@ class HipOps:
     # ---- plumbing ---------------------------------------------------------------------------
     def stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def aux_streams(self, n):
+        """n side streams (created once) for pipelining independent user batches"""
+        while len(self._aux_streams) < n:
+            self._aux_streams.append(torch.cuda.Stream(device=self.device))
+        return self._aux_streams[:n]
 
     def empty(self, *shape, dtype=torch.float64):
         return torch.empty(*shape, dtype=dtype, device=self.device)
@@ -221,18 +243,27 @@ class HipOps:
         return torch.randn(n, m, generator=g, dtype=torch.float64, device=self.device)
 
     # ---- K1/K4 ------------------------------------------------------------------------------
-    def spmm(self, A, X, out=None):
-        """out[n_rows x nc] = A @ X (fp64).  A: DeviceCSR, X: [n_cols x nc] row-major."""
+    def spmm(self, A, X, out=None, rows=None):
+        """out[n_rows x nc] = A @ X (fp64).  A: DeviceCSR, X: [n_cols x nc] row-major.
+        rows=(lo, hi): only rows [lo, hi) are computed (written to the same rows of the FULL-height `out`):
+        the tasks of a row range are a contiguous slice of the plan, so a user batch is its own launch."""
         assert X.dtype == torch.float64 and X.stride(-1) == 1 and X.shape[0] == A.shape[1]
         nc = X.shape[1]
         if out is None:
             out = self.empty(A.shape[0], nc)
         p = A.plan
-        with self._timed('spmm', (A.shape[0], A.shape[1], A.nnz, nc, A.values.element_size())):
+        t0, n_tasks, l0, n_long, nnz = 0, A.n_tasks, 0, A.n_long, A.nnz
+        if rows is not None:
+            lo, hi = int(rows[0]), int(rows[1])
+            t0, n_tasks = int(A.row_first_task[lo]), int(A.row_first_task[hi] - A.row_first_task[lo])
+            l0, l1 = (int(v) for v in np.searchsorted(A.long_row_host, [lo, hi]))
+            n_long = l1 - l0
+            nnz = None   # not needed by anyone for a partial launch
+        with self._timed('spmm', (A.shape[0], A.shape[1], nnz, nc, A.values.element_size())):
             _lib.check(self.lib.pk_spmm_csr_f64(
-                self.stream(), A.n_tasks, _ptr(p['task_row']), _ptr(p['task_begin']), _ptr(p['task_end']),
-                _ptr(p['task_slot']), A.n_long, _ptr(p['long_row']), _ptr(p['long_slot_begin']),
-                _ptr(p['long_slot_end']), _ptr(A.indices), _ptr(A.values), A.val_kind,
+                self.stream(), n_tasks, _ptr(p['task_row'], t0), _ptr(p['task_begin'], t0), _ptr(p['task_end'], t0),
+                _ptr(p['task_slot'], t0), n_long, _ptr(p['long_row'], l0), _ptr(p['long_slot_begin'], l0),
+                _ptr(p['long_slot_end'], l0), _ptr(A.indices), _ptr(A.values), A.val_kind,
                 _ptr(X), X.stride(0), nc, _ptr(out), out.stride(0), _ptr(A.partial(nc))), 'pk_spmm_csr_f64')
         return out
 
@@ -357,16 +388,20 @@ class HipOps:
         return tiles, ntiles
 
     def score_candidates(self, Vp, Ep, n_users, n_items, K, seen_ptr, seen_idx, KC, splits=1, tiles_per_chunk=0,
-                         user_bound=None, tile_bound=None):
+                         user_bound=None, tile_bound=None, seen_tiles=None):
         n_pad = -(-n_users // 32) * 32
         need = self.lib.pk_score_state_bytes(n_users, splits)
-        if self._score_state is None or self._score_state.numel() < need:
-            self._score_state = torch.empty(need, dtype=torch.uint8, device=self.device)
+        if self._score_states is None:
+            self._score_states = {}
+        skey = torch.cuda.current_stream(self.device).cuda_stream   # one state buffer per launch stream
+        if skey not in self._score_states or self._score_states[skey].numel() < need:
+            self._score_states[skey] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        self._score_state = self._score_states[skey]
         cs = torch.empty(splits * n_pad * KC, dtype=torch.float32, device=self.device)
         ci = torch.empty(splits * n_pad * KC, dtype=torch.int32, device=self.device)
         tiles = ntiles = None
         if seen_ptr is not None:
-            tiles, ntiles = self.seen_tiles(seen_ptr, seen_idx, n_users)
+            tiles, ntiles = seen_tiles if seen_tiles is not None else self.seen_tiles(seen_ptr, seen_idx, n_users)
         with self._timed('score_candidates', (n_users, n_items, K)):
             _lib.check(self.lib.pk_score_candidates_f32(self.stream(), n_users, n_items, K, _ptr(Vp), _ptr(Ep),
                                                         _ptr(seen_ptr), _ptr(tiles), _ptr(ntiles), KC, splits,
@@ -383,12 +418,16 @@ class HipOps:
         rec = self._score_state[:splits * groups * 64 * 16].view(torch.int64).view(splits, groups, 64, 2)
         return rec[:, :, 0, 0].clone()
 
-    def rescore_topk(self, V, E, n_items, seen_ptr, KC, cs, ci, topk, vmax, want_scores=True, splits=1):
+    def rescore_topk(self, V, E, n_items, seen_ptr, KC, cs, ci, topk, vmax, want_scores=True, splits=1, out=None):
         assert V.stride(1) == 1 and E.stride(1) == 1
         n_users, K = E.shape
-        out_idx = torch.empty(n_users, topk, dtype=torch.int64, device=self.device)
-        out_s = self.empty(n_users, topk) if want_scores else None
-        flags = torch.empty(n_users, dtype=torch.int32, device=self.device)
+        if out is not None:
+            out_idx, out_s, flags = out      # caller-owned (contiguous row slices of the full outputs)
+            assert out_idx.is_contiguous() and flags.is_contiguous() and (out_s is None or out_s.is_contiguous())
+        else:
+            out_idx = torch.empty(n_users, topk, dtype=torch.int64, device=self.device)
+            out_s = self.empty(n_users, topk) if want_scores else None
+            flags = torch.empty(n_users, dtype=torch.int32, device=self.device)
         _lib.check(self.lib.pk_rescore_topk_f64(self.stream(), n_users, n_items, K, _ptr(V), V.stride(0), _ptr(E),
                                                 E.stride(0), _ptr(seen_ptr), KC, splits, _ptr(cs), _ptr(ci), topk,
                                                 float(vmax), _ptr(out_idx), _ptr(out_s), _ptr(flags)),

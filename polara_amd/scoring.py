@@ -38,7 +38,7 @@ def test_csr_from_triplet(test_data, shape, weights=None):
     return coo_to_csr(users, items, vals, shape, sum_duplicates=True)
 
 
-def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stats=None, prune=True):
+def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stats=None, prune=True, batches=None):
     """factors: FactorImage; T: ops-level CSR of the test users [n_users x n_items].
     Returns int64 device tensor [n_users x topk] (+ fp64 scores), rows in test-user order,
     columns by descending score — the contract of models.py:400-405."""
@@ -49,8 +49,8 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
         raise ValueError('kth(=%d) out of bounds (%d)' % (n_items - topk, n_items))  # numpy argpartition's error
     KC = ops.candidate_capacity(topk)
     K = factors.K
-    E = ops.spmm(T, factors.V)                       # fold-in, fp64 (K4)
     if KC == 0:
+        E = ops.spmm(T, factors.V)                   # fold-in, fp64 (K4)
         # topk beyond the fused kernel's 52: every user goes through the exact fp64 row kernel
         # (all items scored, two-class key) — slow but the same contract
         seen_ptr = T.indptr if filter_seen else None
@@ -66,17 +66,53 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
         if stats is not None:
             stats.update(flagged_users=n_users, candidate_capacity=0, item_splits=0)
         return (out_idx, out_s) if return_scores else out_idx
-    Ep = ops.pack_frag(E)
+    E = ops.empty(n_users, K)
     seen_ptr = T.indptr if filter_seen else None
     seen_idx = T.indices if filter_seen else None
+    seen_tiles = T.seen_tiles() if filter_seen else None
     splits = ops.score_splits(n_users, KC, prune)    # item ranges per user group (1 when pruning / users fill the chip)
-    # exact Cauchy-Schwarz pruning: a group of 32 users leaves the sweep once no later item can beat
-    # any of its thresholds (`prune=False` forces the full sweep: same result, tuning / tests only)
-    ub = ops.row_norm_bound(E) if prune else None
-    cs, ci = ops.score_candidates(factors.Vp, Ep, n_users, n_items, K, seen_ptr, seen_idx, KC, splits,
-                                  user_bound=ub, tile_bound=factors.tile_bound if prune else None)   # K3
-    out_idx, out_s, flags = ops.rescore_topk(factors.V, E, n_items, seen_ptr, KC, cs, ci, topk,
-                                             factors.vmax, want_scores=True, splits=splits)
+    out_idx = torch.empty(n_users, topk, dtype=torch.int64, device=E.device)
+    out_s = torch.empty(n_users, topk, dtype=torch.float64, device=E.device)
+    flags = torch.empty(n_users, dtype=torch.int32, device=E.device)
+
+    def run_batch(u0, u1):
+        """fold-in -> bounds/pack -> candidate sweep -> exact re-scoring of users [u0, u1) on the current stream"""
+        nb = u1 - u0
+        ops.spmm(T, factors.V, out=E, rows=(u0, u1))                       # fold-in, fp64 (K4)
+        Eb = E[u0:u1]
+        Ep = ops.pack_frag(Eb)
+        # exact Cauchy-Schwarz pruning: a group of 32 users leaves the sweep once no later item can beat
+        # any of its thresholds (`prune=False` forces the full sweep: same result, tuning / tests only)
+        ub = ops.row_norm_bound(Eb) if prune else None
+        sp = seen_ptr[u0:u1 + 1] if filter_seen else None
+        st = (seen_tiles[0], seen_tiles[1][u0:u1]) if seen_tiles is not None else None
+        cs, ci = ops.score_candidates(factors.Vp, Ep, nb, n_items, K, sp, seen_idx, KC, splits,
+                                      user_bound=ub, tile_bound=factors.tile_bound if prune else None,
+                                      seen_tiles=st)                                          # K3
+        ops.rescore_topk(factors.V, Eb, n_items, sp, KC, cs, ci, topk, factors.vmax, want_scores=True,
+                         splits=splits, out=(out_idx[u0:u1], out_s[u0:u1], flags[u0:u1]))
+
+    # User batches are independent: with B > 1 they run round-robin on two side streams.  Measured on
+    # MI355X (S-1M): the fold-in SpMM of one batch and the MFMA sweep of another hardly overlap (B = 2:
+    # -4 %, B = 4: -1 %, B = 8: +55 % per pass — each kernel fills the chip on its own), so batching is
+    # only used to bound the temporaries of very large user sets (4M users per batch).
+    B = int(batches) if batches else -(-n_users // (1 << 22))
+    B = max(1, min(B, n_users // 4096)) if n_users >= 4096 else 1
+    if stats is not None:
+        B = 1                                # sweep statistics are read from the (single) state buffer
+    if B == 1:
+        run_batch(0, n_users)
+    else:
+        per = -(-(-(-n_users // B)) // 128) * 128          # batch size, multiple of 128 users (one workgroup)
+        main = torch.cuda.current_stream(E.device)
+        side = ops.aux_streams(2)
+        for sdev in side:
+            sdev.wait_stream(main)
+        for b, u0 in enumerate(range(0, n_users, per)):
+            with torch.cuda.stream(side[b % 2]):
+                run_batch(u0, min(n_users, u0 + per))
+        for sdev in side:
+            main.wait_stream(sdev)
     rows = torch.nonzero(flags, as_tuple=False).flatten().to(torch.int32)
     n_flag = int(rows.numel())
     if stats is not None:
@@ -90,6 +126,9 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
         lo = torch.arange(splits, device=ex.device, dtype=torch.int64)[:, None] * split_tiles
         stats['tiles_scored'] = int((ex - lo).clamp_min(0).sum().item())
         stats['tiles_total'] = int(ex.shape[1]) * n_tiles
+        q = torch.quantile((ex - lo).clamp_min(0).flatten().double(),
+                           torch.tensor([0.5, 0.9, 0.99, 0.999, 1.0], dtype=torch.float64, device=ex.device))
+        stats['exit_tile_quantiles'] = dict(zip(('p50', 'p90', 'p99', 'p999', 'max'), [float(v) for v in q.tolist()]))
     if n_flag:
         per = max(1, int(EXACT_ROWS_BYTES // (n_items * 9 + 16)))
         for s in range(0, n_flag, per):

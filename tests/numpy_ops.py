@@ -19,6 +19,9 @@ class NpCSR:
         self.indices = torch.from_numpy(np.asarray(indices, dtype=np.int32))
         self._T = None
 
+    def seen_tiles(self):
+        return None
+
     @property
     def T(self):
         if self._T is None:
@@ -69,10 +72,13 @@ class NumpyOps:
         g.manual_seed(int(seed))
         return torch.randn(n, m, generator=g, dtype=torch.float64)
 
-    def spmm(self, A, X, out=None):
+    def spmm(self, A, X, out=None, rows=None):
         r = torch.from_numpy(np.ascontiguousarray(A.m @ X.numpy()))
         if out is not None:
-            out.copy_(r)
+            if rows is not None:
+                out[rows[0]:rows[1]].copy_(r[rows[0]:rows[1]])
+            else:
+                out.copy_(r)
             return out
         return r
 
@@ -149,7 +155,7 @@ class NumpyOps:
         return torch.from_numpy(np.ascontiguousarray(suf[::32]))
 
     def score_candidates(self, Vp, Ep, n_users, n_items, K, seen_ptr, seen_idx, KC, splits=1,
-                         user_bound=None, tile_bound=None):
+                         user_bound=None, tile_bound=None, seen_tiles=None):
         s = (Ep.numpy() @ Vp.numpy().T).astype(np.float32)
         if seen_ptr is not None:
             sp = seen_ptr.numpy()
@@ -170,7 +176,7 @@ class NumpyOps:
     def score_exit_tiles(self, n_users, splits=1):
         return torch.zeros(splits, -(-n_users // 32), dtype=torch.int64)
 
-    def rescore_topk(self, V, E, n_items, seen_ptr, KC, cs, ci, topk, vmax, want_scores=True, splits=1):
+    def rescore_topk(self, V, E, n_items, seen_ptr, KC, cs, ci, topk, vmax, want_scores=True, splits=1, out=None):
         n_users, K = E.shape
         Vn, En = V.numpy(), E.numpy()
         cs = cs.numpy().reshape(-1, KC)
@@ -194,7 +200,12 @@ class NumpyOps:
                 bound = (K + 3) * 2.0 ** -24 * np.linalg.norm(En[u]) * vmax
                 if bound > 0 and not (s[topk - 1] - float(cs[u, KC - 1]) > bound):
                     flags[u] |= 1
-        return torch.from_numpy(out_idx), torch.from_numpy(out_s), torch.from_numpy(flags)
+        res = torch.from_numpy(out_idx), torch.from_numpy(out_s), torch.from_numpy(flags)
+        if out is not None:
+            for dst, src in zip(out, res):
+                dst.copy_(src)
+            return out
+        return res
 
     def score_exact_rows(self, rows, V, E, n_items, seen_ptr, seen_idx, topk):
         Vn, En = V.numpy(), E.numpy()

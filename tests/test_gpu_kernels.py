@@ -268,6 +268,30 @@ def test_seen_tile_stream(hip_ops):
         assert [int(g & np.uint64(0xffffffff)) for g in got] == [want[t] for t in sorted(want)], u
 
 
+def test_spmm_row_range_and_user_batches(hip_ops):
+    """A row range of the plan is its own launch; the pipelined (batched, two-stream) scoring pass must
+    return exactly what the single-batch pass returns."""
+    from polara_amd import scoring
+    rng = np.random.RandomState(21)
+    n_users, n_items, K, topk = 13000, 1500, 50, 10
+    indptr, indices, values = rand_csr(rng, n_users, n_items, 25, long_rows=[(3, 1400), (9000, 1300)], empty_rows=[0, 4097],
+                                       dtype=np.float32)
+    T = hip_ops.csr(indptr, indices, values, (n_users, n_items))
+    V = rng.randn(n_items, K) * ((1.0 + np.arange(n_items)) ** -0.6)[:, None]
+    Vd = hip_ops.to_device(V)
+    full = hip_ops.to_host(hip_ops.spmm(T, Vd))
+    out = hip_ops.zeros(n_users, K)
+    for lo, hi in ((0, 3), (3, 4), (4, 8999), (8999, 9001), (9001, n_users)):
+        hip_ops.spmm(T, Vd, out=out, rows=(lo, hi))
+    assert np.array_equal(hip_ops.to_host(out), full)
+    F = scoring.FactorImage(hip_ops, Vd)
+    ref, ref_s = scoring.recommend(hip_ops, F, T, topk, True, return_scores=True, batches=1)
+    for B in (2, 3):
+        got, got_s = scoring.recommend(hip_ops, F, T, topk, True, return_scores=True, batches=B)
+        assert np.array_equal(hip_ops.to_host(ref), hip_ops.to_host(got))
+        assert np.array_equal(hip_ops.to_host(ref_s), hip_ops.to_host(got_s))
+
+
 def test_pruning_bounds_are_upper_bounds(hip_ops):
     rng = np.random.RandomState(3)
     for n, K in ((1000, 50), (33, 7), (4097, 200)):
