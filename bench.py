@@ -61,9 +61,10 @@ def spmm_alg_bytes(meta):
 def pmc_traffic():
     """HBM/fabric bytes per launch of the two dominant kernels, from the committed rocprofv3 --pmc
     passes of this same command (profiles/r01_bench_pmc_{fetch,write}_size.txt; separate passes, as
-    the tool requires).  FETCH_SIZE is doubled for the 16 B/lane fragment loads of the scoring kernel
-    (gfx950 counts 128 B requests as 64 B, MI355X_MICROARCH.md §HBM); the 8 B/lane SpMM gathers are
-    reported uncorrected.  Returns {} when the summaries are not there."""
+    the tool requires).  FETCH_SIZE is doubled: both kernels read with 16 B/lane loads, which gfx950
+    tallies at half their size (128 B requests counted as 64 B, MI355X_MICROARCH.md §HBM; calibrated
+    there for streaming reads, assumed for the 256 B gather pieces of the SpMM).  Returns {} when the
+    summaries are not there."""
     out = {}
     try:
         def per_launch(fn, kernel):
@@ -72,11 +73,11 @@ def pmc_traffic():
                     return float(line.split()[-1]) * 1024.0     # KB -> bytes
             return None
         f_s, w_s = per_launch('r01_bench_pmc_fetch_size.txt', 'score_candidates_kernel'), per_launch('r01_bench_pmc_write_size.txt', 'score_candidates_kernel')
-        f_m, w_m = per_launch('r01_bench_pmc_fetch_size.txt', 'spmm_csr_kernel'), per_launch('r01_bench_pmc_write_size.txt', 'spmm_csr_kernel')
+        f_m, w_m = per_launch('r01_bench_pmc_fetch_size.txt', 'spmm_csr_groups_kernel'), per_launch('r01_bench_pmc_write_size.txt', 'spmm_csr_groups_kernel')
         if f_s is not None and w_s is not None:
             out['score'] = 2.0 * f_s + w_s
         if f_m is not None and w_m is not None:
-            out['spmm'] = f_m + w_m
+            out['spmm'] = 2.0 * f_m + w_m
     except OSError:
         pass
     return out
