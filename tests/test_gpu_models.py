@@ -159,3 +159,60 @@ def test_build_returns_user_factors(hip_ops):
     A = orc.get_training_matrix(g['train_idx'], g['train_val'], tuple(g['train_shape']), dtype=np.float64)
     assert np.abs(U.T @ U - np.eye(len(s))).max() < 1e-9
     assert np.abs(A @ V - U * s).max() < 1e-8 * s[0]
+
+
+def test_s1m_full_size_properties(hip_ops):
+    """BASELINE.json configs[1] at FULL size (1M users x 100K items, 1e8 nnz, rank 50, top-10), as bench.py runs
+    it: size-independent properties of the whole result + the CPU oracle on a 1 000-user sample."""
+    import torch
+    from polara_amd import scoring
+    from polara_amd.solver import svd_topk
+    from polara_amd.csr import popularity_order
+    ops = hip_ops
+    csr, cfg = make_workload('s1m', device=str(ops.device))
+    c = csr_to_numpy(csr)
+    del csr
+    n_users, n_items = c['shape']
+    rank, topk = cfg['rank'], cfg['topk']
+    A = ops.csr(c['indptr'], c['indices'], c['values'], c['shape'])
+    rank_of, inv_order = popularity_order(c['indices'], n_items)
+    A = ops.csr_relabel_cols(A, rank_of)
+    _, sigma, V, st = svd_topk(ops, A, rank)
+    assert st['converged'] and st['final_rel_residual'] < 1e-12
+    sig = ops.to_host(sigma)
+    assert np.all(np.diff(sig) < 0) and sig[-1] > 0
+    VtV = ops.to_host(ops.gram(V))
+    assert np.abs(VtV - np.eye(rank)).max() < 1e-12                      # orthonormal item factors
+    F = scoring.FactorImage(ops, V)
+    stats = {}
+    recs, sc = scoring.recommend(ops, F, A, topk, True, return_scores=True, stats=stats)
+    assert recs.shape == (n_users, topk) and int(recs.min()) >= 0 and int(recs.max()) < n_items
+    assert stats['flagged_users'] == 0 and stats['tiles_scored'] < 0.2 * stats['tiles_total']
+    assert bool((sc[:, 1:] <= sc[:, :-1]).all())                         # descending scores
+    assert bool((torch.sort(recs, dim=1).values.diff(dim=1) > 0).all())  # no duplicates in a row
+    # no seen item is recommended: (user, item) keys of the CSR are ascending -> binary search
+    rows = torch.repeat_interleave(torch.arange(n_users, device=recs.device), A.indptr[1:] - A.indptr[:-1])
+    keys = rows * n_items + A.indices.long()
+    q = (torch.arange(n_users, device=recs.device)[:, None] * n_items + recs).flatten()
+    pos = torch.searchsorted(keys, q).clamp_max(keys.numel() - 1)
+    assert not bool((keys[pos] == q).any())
+    del rows, keys, q, pos
+    # idempotence, and the pruned sweep against the full sweep on a 64K-user slice
+    recs2 = scoring.recommend(ops, F, A, topk, True)
+    assert bool((recs2 == recs).all())
+    T = ops.csr_rows(A, 0, 65536)
+    r_full = scoring.recommend(ops, F, T, topk, True, prune=False)
+    assert bool((r_full == recs[:65536]).all())
+    # scores are E V^T at the recommended items (fp64), checked on a slice
+    E = ops.spmm(T, V)[:4096]
+    want = torch.gather(E @ V.T, 1, recs[:4096])
+    assert torch.allclose(want, sc[:4096], rtol=1e-12, atol=1e-12)
+    # CPU oracle (reference path restated) on the first 1000 users, external item ids
+    n_chk = 1000
+    p1 = int(c['indptr'][n_chk])
+    test_data = (np.repeat(np.arange(n_chk), np.diff(c['indptr'][:n_chk + 1])), c['indices'][:p1].astype(np.int64),
+                 c['values'][:p1].astype(np.float64))
+    V_ext = np.ascontiguousarray(ops.to_host(V)[rank_of])
+    ref = orc.svd_recommendations(V_ext, test_data, (n_chk, n_items), topk, filter_seen=True)
+    got = inv_order[ops.to_host(recs[:n_chk])]
+    assert np.array_equal(got, ref)
