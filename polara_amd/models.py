@@ -12,6 +12,7 @@ from timeit import default_timer as timer
 import numpy as np
 
 from . import defaults
+from .operator import HostOperator
 from .csr import coo_to_csr, nnz_balanced_row_partition, popularity_order
 from .solver import svd_topk, NoComm
 from . import scoring
@@ -336,11 +337,21 @@ class SVDModel(RecommenderModel):
         return A, (0, n_users, n_users)
 
     def build(self, operator=None, return_factors='vh'):
-        """models.py:835-855.  `operator` (HybridSVD's LinearOperator) is outside the device path."""
-        if operator is not None:
-            raise NotImplementedError('build(operator=...) is not supported by the device path yet')
-        A, (lo, hi, n_users) = self._local_training_shard()
+        """models.py:835-855.  `operator`: a SciPy LinearOperator used INSTEAD of the training matrix
+        (models.py:838-839; HybridSVD passes L_K^T A L_S) — its products run on the host, the block solver
+        around them on the device (polara_amd/operator.py); single process only."""
         ops = self.ops
+        if operator is not None:
+            if self.comm.world > 1:
+                raise NotImplementedError('build(operator=...) with a sharded communicator')
+            idx, _, shp = self.data.to_coo(tensor_mode=False, feedback_threshold=self.feedback_threshold)
+            if tuple(operator.shape)[1] != shp[1]:
+                raise ValueError('operator has %d columns, the data %d items' % (operator.shape[1], shp[1]))
+            self._item_rank, self._item_inv = popularity_order(idx[:, 1], shp[1])
+            A = HostOperator(ops, operator, col_perm=self._item_rank)
+            lo, hi, n_users = 0, A.shape[0], A.shape[0]
+        else:
+            A, (lo, hi, n_users) = self._local_training_shard()
         want_u = return_factors in (True, 'u')
         start = timer()
         U, sigma, V, stats = svd_topk(ops, A, self.rank, block=self.svd_block, tol=self.svd_tol,

@@ -12,6 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .operator import HostOperator
 from .csr import build_row_tasks, SPLIT_NNZ
 
 
@@ -247,6 +248,8 @@ class HipOps:
         """out[n_rows x nc] = A @ X (fp64).  A: DeviceCSR, X: [n_cols x nc] row-major.
         rows=(lo, hi): only rows [lo, hi) are computed (written to the same rows of the FULL-height `out`):
         the tasks of a row range are a contiguous slice of the plan, so a user batch is its own launch."""
+        if isinstance(A, HostOperator):   # build(operator=...): host LinearOperator, models.py:835-844
+            return A.apply(X, out)
         assert X.dtype == torch.float64 and X.stride(-1) == 1 and X.shape[0] == A.shape[1]
         nc = X.shape[1]
         if out is None:

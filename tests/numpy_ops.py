@@ -73,6 +73,9 @@ class NumpyOps:
         return torch.randn(n, m, generator=g, dtype=torch.float64)
 
     def spmm(self, A, X, out=None, rows=None):
+        from polara_amd.operator import HostOperator
+        if isinstance(A, HostOperator):
+            return A.apply(X, out)
         r = torch.from_numpy(np.ascontiguousarray(A.m @ X.numpy()))
         if out is not None:
             if rows is not None:

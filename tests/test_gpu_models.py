@@ -216,3 +216,29 @@ def test_s1m_full_size_properties(hip_ops):
     ref = orc.svd_recommendations(V_ext, test_data, (n_chk, n_items), topk, filter_seen=True)
     got = inv_order[ops.to_host(recs[:n_chk])]
     assert np.array_equal(got, ref)
+
+
+def test_build_with_linear_operator_on_device_solver(hip_ops):
+    """build(operator=...) (models.py:835-844): host LinearOperator products, device block solver."""
+    from scipy.sparse.linalg import aslinearoperator, svds
+    g = load_golden('svd_known')
+    m = SVDModel(GoldenData(g), ops=hip_ops)
+    m.verbose = False
+    m.rank, m.topk = int(g['rank']), int(g['topk'])
+    A = m.get_training_matrix(dtype=np.float64)
+    d = 1.0 / np.sqrt(1.0 + np.asarray(A.getnnz(axis=0)).ravel())
+    op = aslinearoperator(A @ sps.diags(d))
+    m.build(operator=op, return_factors=True)
+    u, s, vt = svds(op, k=m.rank)
+    order = np.argsort(-s)
+    assert np.allclose(m.factors['singular_values'], s[order], rtol=1e-9)
+    V, U = m.factors[m.data.fields.itemid], m.factors[m.data.fields.userid]
+    assert np.abs(V @ V.T - vt.T @ vt).max() < 1e-8 and np.abs(U @ U.T - u @ u.T).max() < 1e-8
+    td, shp = (g['test_user'], g['test_item'], g['test_fdbk']), tuple(int(x) for x in g['test_shape'])
+    Vref = np.ascontiguousarray(vt.T[:, order])
+    want = orc.svd_recommendations(Vref, td, shp, m.topk, True)
+    scores, slice_data = orc.svd_slice_recommendations(Vref, td, shp, 0, shp[0])
+    orc.downvote_seen_items(scores, slice_data)
+    top = -np.sort(-scores, axis=1)[:, :m.topk + 1]
+    clear = (np.diff(-top, axis=1) > 1e-9 * np.abs(top[:, :1])).all(axis=1)
+    assert clear.mean() > 0.5 and np.array_equal(m.recommendations[clear], want[clear])

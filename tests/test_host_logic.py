@@ -175,3 +175,39 @@ def test_solver_converges_on_planted_and_degenerate_inputs():
     A2 = ops.csr(B.indptr, B.indices, B.data, B.shape)
     _, s2, _, st2 = svd_topk(ops, A2, 3)
     assert np.isclose(s2.numpy()[0], np.linalg.svd(B.toarray(), compute_uv=False)[0]) and s2.numpy()[1] < 1e-5 * s2.numpy()[0]
+
+
+def test_build_with_linear_operator_matches_svds():
+    """build(operator=...) (models.py:835-844): a SciPy LinearOperator replaces the training matrix; checked
+    against scipy's own svds of the same operator, including the recommendations that follow from it."""
+    from scipy.sparse.linalg import aslinearoperator, svds
+    import scipy.sparse as sps
+    g = load_golden('svd_known')
+    data = GoldenData(g)
+    m = SVDModel(data, ops=NumpyOps())
+    m.verbose = False
+    m.rank, m.topk = int(g['rank']), int(g['topk'])
+    A = m.get_training_matrix(dtype=np.float64)
+    d = 1.0 / np.sqrt(1.0 + np.asarray(A.getnnz(axis=0)).ravel())          # an item-side scaling, as EIGENREC does
+    op = aslinearoperator(A @ sps.diags(d))
+    m.build(operator=op, return_factors=True)
+    assert m._is_ready and len(m.training_time) == 1
+    u, s, vt = svds(op, k=m.rank)
+    order = np.argsort(-s)
+    assert np.allclose(m.factors['singular_values'], s[order], rtol=1e-9)
+    V = m.factors[data.fields.itemid]
+    U = m.factors[data.fields.userid]
+    assert np.abs(V @ V.T - vt.T @ vt).max() < 1e-8
+    assert U.shape == (A.shape[0], m.rank) and np.abs(U @ U.T - u @ u.T).max() < 1e-8
+    td, shp = (g['test_user'], g['test_item'], g['test_fdbk']), tuple(int(x) for x in g['test_shape'])
+    Vref = np.ascontiguousarray(vt.T[:, order])
+    want = orc.svd_recommendations(Vref, td, shp, m.topk, True)
+    scores, slice_data = orc.svd_slice_recommendations(Vref, td, shp, 0, shp[0])
+    orc.downvote_seen_items(scores, slice_data)
+    # rows whose k-th/(k+1)-th scores (or any two inside the top-k) tie are implementation-defined
+    top = -np.sort(-scores, axis=1)[:, :m.topk + 1]
+    clear = (np.diff(-top, axis=1) > 1e-9 * np.abs(top[:, :1])).all(axis=1)
+    got = m.recommendations
+    assert clear.mean() > 0.5 and np.array_equal(got[clear], want[clear])
+    with pytest.raises(ValueError):
+        m.build(operator=aslinearoperator(A[:, :-1]))
