@@ -125,9 +125,13 @@ int32_t pk_score_splits(int64_t n_users, int32_t KC);
 /* Seen-item lists (the rows of the test CSR: everything downvote_seen_items masks, models.py:494-519)
  * folded into ONE 64-bit record per 32-item tile a user has seen items in: (tile << 32) | item mask.
  * tiles_dev has the capacity of seen_idx_dev and is addressed by the same seen_ptr_dev; the records
- * of user u are tiles_dev[seen_ptr[u] .. seen_ptr[u] + ntiles_dev[u]).  Rows must be sorted by item. */
+ * of user u are tiles_dev[seen_ptr[u] .. seen_ptr[u] + ntiles_dev[u]).  rows_sorted = 1: every row ascending
+ * by item (canonical CSR); 0: any order within a row (columns only renamed, e.g. to a serving index). */
 int pk_seen_tiles_build(void *stream, int64_t n_users, const int64_t *seen_ptr_dev, const int32_t *seen_idx_dev,
+                        int32_t rows_sorted /* 0: rows in arbitrary item order, sorted in LDS */,
+                        int64_t max_row_len /* only read when rows_sorted == 0: <= pk_seen_tiles_max_unsorted_row() */,
                         uint64_t *tiles_dev, int32_t *ntiles_dev);
+int32_t pk_seen_tiles_max_unsorted_row(void);
 int pk_score_candidates_f32(void *stream, int64_t n_users, int64_t n_items, int32_t K,
                             const float *Vp_dev, const float *Ep_dev,
                             const int64_t *seen_ptr_dev, const uint64_t *seen_tiles_dev,

@@ -121,26 +121,36 @@ __device__ __forceinline__ void pk_bitonic_desc(float (&key)[SLOTS], int (&val)[
     pk_bitonic_levels<SLOTS, 64 * SLOTS>(key, val, lane);
 }
 
-// the same network inside each 32-lane half (t = lane & 31): both halves end up descending
+// Key-only network inside each 32-lane half (both halves end up descending): the element is ONE 32-bit
+// word — the score mapped to an order-preserving unsigned with its low 5 bits replaced by the source slot —
+// so a stage is a lane exchange + v_max_u32 + v_min_u32 + one v_cndmask on a compile-time lane mask
+// (~5 instructions instead of ~12 for a (score, item) pair with a tie-break).  The price: scores that
+// agree in all but their low 5 mantissa bits (2^-18 relative) may be ordered either way; the exact
+// re-scoring pass widens its certification bound by 2^-17 |tau| to cover that (rescore.hip).
 template <int K, int J>
-__device__ __forceinline__ void pk_bitonic_half_merge(float &key, int &val, int t) {
-    const float ok = pk_lane_xor<J>(key);
-    const int ov = pk_lane_xor<J>(val);
-    const bool want_first = (((t & J) == 0) == ((t & K) == 0));
-    const bool other_first = pk_before(ok, ov, key, val);
-    if (want_first == other_first) {
-        key = ok;
-        val = ov;
+constexpr unsigned long long pk_half_stage_mask() {
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l) {
+        const int t = l & 31;
+        if (((t & J) == 0) == ((t & K) == 0)) m |= 1ull << l;   // this lane keeps the larger element
     }
-    if constexpr (J > 1) pk_bitonic_half_merge<K, (J >> 1)>(key, val, t);
+    return m;
+}
+template <int K, int J>
+__device__ __forceinline__ void pk_sort32_half_merge(unsigned &key) {
+    const unsigned other = (unsigned)pk_lane_xor<J>((int)key);
+    const unsigned hi = key > other ? key : other, lo = key > other ? other : key;
+    key = __builtin_amdgcn_inverse_ballot_w64(pk_half_stage_mask<K, J>()) ? hi : lo;
+    if constexpr (J > 1) pk_sort32_half_merge<K, (J >> 1)>(key);
 }
 template <int K>
-__device__ __forceinline__ void pk_bitonic_half_levels(float &key, int &val, int t) {
-    if constexpr (K > 2) pk_bitonic_half_levels<(K >> 1)>(key, val, t);
-    pk_bitonic_half_merge<K, (K >> 1)>(key, val, t);
+__device__ __forceinline__ void pk_sort32_half_levels(unsigned &key) {
+    if constexpr (K > 2) pk_sort32_half_levels<(K >> 1)>(key);
+    pk_sort32_half_merge<K, (K >> 1)>(key);
 }
-__device__ __forceinline__ void pk_bitonic_half_desc(float &key, int &val, int t) {
-    pk_bitonic_half_levels<32>(key, val, t);
+__device__ __forceinline__ unsigned pk_float_order(float x) {   // a > b  <=>  order(a) > order(b)
+    const unsigned u = __float_as_uint(x);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
 // Per-lane state carried between the item-chunk launches of one scoring pass (global memory).
@@ -371,7 +381,11 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
                 v = (int)r.y;
             }
         }
-        pk_bitonic_half_desc(k, v, t);
+        unsigned key = (pk_float_order(k) & ~31u) | (unsigned)t;   // low 5 bits: the slot the element came from
+        pk_sort32_half_levels<32>(key);
+        const int src = (lane & 32) | (int)(key & 31u);
+        k = __shfl(k, src, 64);
+        v = __shfl(v, src, 64);
         if (act && t < KC) top[u * KC + t] = make_uint2(__float_as_uint(k), (unsigned)((v == PK_IDX_NONE) ? -1 : v));
         const float tx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(k), KC - 1));
         const float ty = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(k), 32 + KC - 1));
@@ -644,24 +658,54 @@ extern "C" int pk_pack_frag_f32(void *stream, int64_t n, int32_t K, const double
 }
 
 // ---- seen-tile stream ----------------------------------------------------------------------------
-// One wave per user: the sorted seen-item list [seen_ptr[u], seen_ptr[u+1]) is folded into one
-// 64-bit record (tile << 32 | 32-bit item mask) per tile that holds seen items, written compactly
-// from position seen_ptr[u] of `tiles` (same indptr as the item list, at most as many records).
+// One wave per user: the seen-item list [seen_ptr[u], seen_ptr[u+1]) is folded into one 64-bit record
+// (tile << 32 | 32-bit item mask) per tile that holds seen items, written compactly from position
+// seen_ptr[u] of `tiles` (same indptr as the item list, at most as many records).
+// SORTED = false: the list is in arbitrary order (a CSR whose columns were only RENAMED, e.g. to the
+// factor-norm order of the serving index); the wave first sorts it in LDS (bitonic, <= PK_SEEN_CAP entries).
+#define PK_SEEN_CAP 4096
+template <bool SORTED>
 __global__ __launch_bounds__(256) void seen_tiles_kernel(int64_t n_users, const int64_t *__restrict__ seen_ptr,
                                                          const int32_t *__restrict__ seen_idx,
                                                          unsigned long long *__restrict__ tiles,
                                                          int32_t *__restrict__ ntiles) {
+    __shared__ int sort_buf[SORTED ? 1 : 4][SORTED ? 1 : PK_SEEN_CAP];
     const int lane = threadIdx.x & 63;
     const int64_t user = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (user >= n_users) return;
     const int64_t p0 = seen_ptr[user], p1 = seen_ptr[user + 1];
+    int *buf = sort_buf[SORTED ? 0 : (threadIdx.x >> 6)];
+    if constexpr (!SORTED) {
+        const int n = (int)(p1 - p0);
+        int N = 64;
+        while (N < n) N <<= 1;
+        for (int i = lane; i < N; i += 64) buf[i] = (i < n) ? seen_idx[p0 + i] : 0x7fffffff;
+        __builtin_amdgcn_wave_barrier();
+        // ascending bitonic network in LDS; one wave, so program order + the in-order LDS pipe are the only
+        // synchronisation needed (the barriers keep the compiler from moving accesses across stages)
+        for (int k = 2; k <= N; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = lane; t < (N >> 1); t += 64) {
+                    const int pos = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    const int x = buf[pos], y = buf[pos + j];
+                    const bool up = (pos & k) == 0;
+                    if ((x > y) == up) {
+                        buf[pos] = y;
+                        buf[pos + j] = x;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
     int count = 0;
     bool carry = false;             // the last tile of the previous chunk is emitted with the next chunk
     unsigned c_tile = 0, c_mask = 0;
     for (int64_t base = p0; base < p1; base += 64) {
         const int64_t i = base + lane;
         const bool valid = i < p1;
-        const int idx = valid ? seen_idx[i] : 0;
+        int idx = 0;
+        if (valid) idx = SORTED ? seen_idx[i] : buf[i - p0];
         const unsigned tile = valid ? (unsigned)idx >> 5 : 0xffffffffu;
         unsigned m = valid ? 1u << (idx & 31) : 0u;
         // OR of the bits of my tile over the lanes to my right (sorted list: equal tiles are adjacent)
@@ -674,7 +718,6 @@ __global__ __launch_bounds__(256) void seen_tiles_kernel(int64_t n_users, const 
         const unsigned tprev = __shfl_up(tile, 1, 64);
         const bool head = valid && (lane == 0 || tprev != tile);
         const unsigned long long heads = __ballot(head);
-        const int n_valid = (int)((p1 - base < 64) ? (p1 - base) : 64);
         const int last_head = 63 - __builtin_clzll(heads);          // heads != 0: lane 0 is valid
         const unsigned f_tile = __shfl(tile, 0, 64);
         if (carry) {
@@ -691,7 +734,6 @@ __global__ __launch_bounds__(256) void seen_tiles_kernel(int64_t n_users, const 
         c_tile = __shfl(tile, last_head, 64);
         c_mask = __shfl(m, last_head, 64);
         carry = true;
-        (void)n_valid;
     }
     if (carry) {
         if (lane == 0) tiles[p0 + count] = ((unsigned long long)c_tile << 32) | c_mask;
@@ -700,11 +742,24 @@ __global__ __launch_bounds__(256) void seen_tiles_kernel(int64_t n_users, const 
     if (lane == 0) ntiles[user] = count;
 }
 
+extern "C" int32_t pk_seen_tiles_max_unsorted_row(void) { return PK_SEEN_CAP; }
+
 extern "C" int pk_seen_tiles_build(void *stream, int64_t n_users, const int64_t *seen_ptr_dev,
-                                   const int32_t *seen_idx_dev, uint64_t *tiles_dev, int32_t *ntiles_dev) {
+                                   const int32_t *seen_idx_dev, int32_t rows_sorted, int64_t max_row_len,
+                                   uint64_t *tiles_dev, int32_t *ntiles_dev) {
     PK_REQUIRE(n_users >= 1 && seen_ptr_dev && seen_idx_dev && tiles_dev && ntiles_dev, "pk_seen_tiles_build: bad arguments");
-    hipLaunchKernelGGL(seen_tiles_kernel, dim3((unsigned)pk_ceil_div(n_users, 4)), dim3(256), 0, pk_stream(stream),
-                       n_users, seen_ptr_dev, seen_idx_dev, reinterpret_cast<unsigned long long *>(tiles_dev), ntiles_dev);
+    dim3 grid((unsigned)pk_ceil_div(n_users, 4)), block(256);
+    unsigned long long *tiles = reinterpret_cast<unsigned long long *>(tiles_dev);
+    if (rows_sorted) {
+        hipLaunchKernelGGL(seen_tiles_kernel<true>, grid, block, 0, pk_stream(stream), n_users, seen_ptr_dev,
+                           seen_idx_dev, tiles, ntiles_dev);
+    } else {
+        PK_REQUIRE(max_row_len >= 0 && max_row_len <= PK_SEEN_CAP,
+                   "pk_seen_tiles_build: unsorted rows longer than %d entries (got %lld): sort the rows first",
+                   PK_SEEN_CAP, (long long)max_row_len);
+        hipLaunchKernelGGL(seen_tiles_kernel<false>, grid, block, 0, pk_stream(stream), n_users, seen_ptr_dev,
+                           seen_idx_dev, tiles, ntiles_dev);
+    }
     PK_CHECK_LAUNCH("seen_tiles_kernel");
     return PK_OK;
 }

@@ -367,7 +367,16 @@ class SVDModel(RecommenderModel):
                 user_factors = self.comm.gather_rows(user_factors, n_users, self.rank, dtype=np.float64)
         item_factors = None
         if return_factors in (True, 'vh'):
-            item_factors = np.asfortranarray(ops.to_host(V)[self._item_rank])   # external item order
+            Vh = ops.to_host(V)
+            item_factors = np.asfortranarray(Vh[self._item_rank])   # external item order
+            # serving index: the internal item order becomes DESCENDING FACTOR NORM, the order in which the
+            # pruning bound of the candidate sweep (a suffix maximum of these norms) falls fastest; a pure
+            # relabelling, test matrices are built against it later (get_recommendations)
+            by_norm = np.argsort(-np.linalg.norm(Vh, axis=1), kind='stable')
+            self._item_inv = np.ascontiguousarray(self._item_inv[by_norm])
+            self._item_rank = np.empty_like(self._item_inv)
+            self._item_rank[self._item_inv] = np.arange(len(self._item_inv), dtype=self._item_inv.dtype)
+            V = ops.to_device(np.ascontiguousarray(Vh[by_norm]))
         self.factors[self.data.fields.userid] = user_factors
         self.factors[self.data.fields.itemid] = item_factors
         self.factors['singular_values'] = ops.to_host(sigma)

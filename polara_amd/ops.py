@@ -53,6 +53,7 @@ class DeviceCSR:
         self._partial = None
         self._T = None
         self._seen_tiles = None
+        self.sorted_cols = True     # canonical CSR; False after a bare column renaming (csr_relabel_cols(sort=False))
 
     def partial(self, nc):
         need = self.n_slots * nc
@@ -66,7 +67,8 @@ class DeviceCSR:
         """(tiles, ntiles): this matrix's rows as seen-tile streams for the candidate sweep — a format image of
         the CSR like the transpose, built once per matrix (pk_seen_tiles_build)."""
         if self._seen_tiles is None:
-            self._seen_tiles = self.ops.seen_tiles(self.indptr, self.indices, self.shape[0])
+            self._seen_tiles = self.ops.seen_tiles(self.indptr, self.indices, self.shape[0],
+                                                   rows_sorted=self.sorted_cols)
         return self._seen_tiles
 
     @property
@@ -111,10 +113,22 @@ class DeviceCSR:
         self._partial = None
         self._T = None
         self._seen_tiles = None
+        self.sorted_cols = True     # canonical CSR; False after a bare column renaming (csr_relabel_cols(sort=False))
         return self
 
     def drop_host(self):
         self._host = None
+
+    def with_columns(self, indices, values):
+        """Same sparsity pattern per row (row pointers, task plan) with new column ids / values."""
+        new = DeviceCSR.__new__(DeviceCSR)
+        new.__dict__.update(self.__dict__)
+        new.indices, new.values = indices, values
+        new._host = None
+        new._partial = None
+        new._T = None
+        new._seen_tiles = None
+        return new
 
 
 class HipOps:
@@ -181,16 +195,26 @@ class HipOps:
     def csr(self, indptr, indices, values, shape, split=SPLIT_NNZ):
         return DeviceCSR(self, indptr, indices, values, shape, split)
 
-    def csr_relabel_cols(self, A, col_map):
-        """CSR with column j renamed to col_map[j] (rows re-sorted on device).  `col_map`: int array."""
+    def csr_relabel_cols(self, A, col_map, sort=True):
+        """CSR with column j renamed to col_map[j].  `col_map`: int array or device tensor.  The row pointers —
+        and with them the row-task plan — are those of A.  sort=True re-sorts every row on device (canonical
+        CSR); sort=False only renames (one gather): enough for SpMM, the seen-tile builder and the exact-row
+        kernel, none of which needs ordered rows (the result carries sorted_cols = False)."""
         dev = self.device
-        cm = torch.as_tensor(np.ascontiguousarray(col_map, dtype=np.int64)).to(dev)
+        if torch.is_tensor(col_map):
+            cm = col_map.to(device=dev, dtype=torch.int64)
+        else:
+            cm = torch.as_tensor(np.ascontiguousarray(col_map, dtype=np.int64)).to(dev)
+        if not sort:
+            new = A.with_columns(cm[A.indices.long()].to(torch.int32), A.values)
+            new.sorted_cols = False
+            return new
         counts = A.indptr[1:] - A.indptr[:-1]
         rows = torch.repeat_interleave(torch.arange(A.shape[0], dtype=torch.int64, device=dev), counts)
         key = rows * A.shape[1] + cm[A.indices.long()]
         key, order = torch.sort(key)
         cc = (key - rows * A.shape[1]).to(torch.int32)   # rows are unchanged by a within-row permutation
-        return DeviceCSR.from_device(self, A.indptr, cc, A.values[order].contiguous(), A.shape)
+        return A.with_columns(cc, A.values[order].contiguous())
 
     def csr_from_coo(self, rows, cols, vals, shape, split=SPLIT_NNZ):
         """COO triplets (host arrays) -> canonical DeviceCSR built ON DEVICE: one radix sort of the
@@ -233,8 +257,10 @@ class HipOps:
     def csr_rows(self, A, lo, hi):
         """Row block [lo, hi) of a DeviceCSR (device-side slice; used for user sharding)."""
         p0, p1 = int(A.indptr[lo]), int(A.indptr[hi])
-        return DeviceCSR.from_device(self, (A.indptr[lo:hi + 1] - p0).contiguous(), A.indices[p0:p1].contiguous(),
-                                     A.values[p0:p1].contiguous(), (hi - lo, A.shape[1]))
+        new = DeviceCSR.from_device(self, (A.indptr[lo:hi + 1] - p0).contiguous(), A.indices[p0:p1].contiguous(),
+                                    A.values[p0:p1].contiguous(), (hi - lo, A.shape[1]))
+        new.sorted_cols = A.sorted_cols
+        return new
 
     def randn(self, n, m, seed):
         # device-side Philox stream: identical on every rank for the same seed (the solver relies
@@ -380,14 +406,26 @@ class HipOps:
                                                    _ptr(out)), 'pk_tile_norm_bound_f32')
         return out
 
-    def seen_tiles(self, seen_ptr, seen_idx, n_users):
+    def seen_tiles(self, seen_ptr, seen_idx, n_users, rows_sorted=True):
         """The seen-item lists folded into one (tile << 32 | item mask) record per touched 32-item tile:
-        uint64 stream addressed by the same indptr + the record count per user."""
+        uint64 stream addressed by the same indptr + the record count per user.  rows_sorted=False: rows
+        in arbitrary item order (sorted inside the kernel; very long rows fall back to a device sort)."""
         tiles = torch.empty(max(int(seen_idx.numel()), 1), dtype=torch.int64, device=self.device)
         ntiles = torch.empty(n_users, dtype=torch.int32, device=self.device)
+        max_row = 0
+        if not rows_sorted:
+            max_row = int((seen_ptr[1:n_users + 1] - seen_ptr[:n_users]).max().item()) if n_users else 0
+            if max_row > self.lib.pk_seen_tiles_max_unsorted_row():
+                counts = seen_ptr[1:n_users + 1] - seen_ptr[:n_users]
+                rows = torch.repeat_interleave(torch.arange(n_users, dtype=torch.int64, device=self.device), counts)
+                lo, hi = int(seen_ptr[0]), int(seen_ptr[n_users])
+                key = torch.sort(rows * (1 << 31) + seen_idx[lo:hi].long()).values
+                seen_idx = torch.cat([seen_idx[:lo], (key & ((1 << 31) - 1)).to(torch.int32)])
+                rows_sorted = True
         with self._timed('seen_tiles', (n_users, int(seen_idx.numel()))):
             _lib.check(self.lib.pk_seen_tiles_build(self.stream(), n_users, _ptr(seen_ptr), _ptr(seen_idx),
-                                                    _ptr(tiles), _ptr(ntiles)), 'pk_seen_tiles_build')
+                                                    1 if rows_sorted else 0, max_row, _ptr(tiles), _ptr(ntiles)),
+                       'pk_seen_tiles_build')
         return tiles, ntiles
 
     def score_candidates(self, Vp, Ep, n_users, n_items, K, seen_ptr, seen_idx, KC, splits=1, tiles_per_chunk=0,

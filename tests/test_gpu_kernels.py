@@ -266,6 +266,22 @@ def test_seen_tile_stream(hip_ops):
         assert ntiles[u] == len(want), u
         assert [int(g >> np.uint64(32)) for g in got] == sorted(want), u
         assert [int(g & np.uint64(0xffffffff)) for g in got] == [want[t] for t in sorted(want)], u
+    # rows in arbitrary order (columns only renamed): sorted inside the kernel; a row beyond the LDS capacity
+    # takes the device-sort fallback.  Same stream either way.
+    for long_len in (4000, 4700):
+        ip, ix, _ = rand_csr(rng, n_users, n_items, 30, long_rows=[(2, long_len), (9, 64), (10, 65), (11, 129)],
+                             empty_rows=[0, 7])
+        shuffled = ix.copy()
+        for u in range(n_users):
+            rng.shuffle(shuffled[ip[u]:ip[u + 1]])
+        sp = hip_ops.to_device(ip.astype(np.int64))
+        t_ref, n_ref = hip_ops.seen_tiles(sp, hip_ops.to_device(ix.astype(np.int32)), n_users)
+        t_got, n_got = hip_ops.seen_tiles(sp, hip_ops.to_device(shuffled.astype(np.int32)), n_users, rows_sorted=False)
+        n_ref, n_got = hip_ops.to_host(n_ref), hip_ops.to_host(n_got)
+        assert np.array_equal(n_ref, n_got)
+        t_ref, t_got = hip_ops.to_host(t_ref), hip_ops.to_host(t_got)
+        for u in range(n_users):
+            assert np.array_equal(t_ref[ip[u]:ip[u] + n_ref[u]], t_got[ip[u]:ip[u] + n_ref[u]]), (long_len, u)
 
 
 def test_spmm_row_range_and_user_batches(hip_ops):
