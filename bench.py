@@ -223,12 +223,25 @@ def main():
     kw = dict(prune=not args.no_prune, batches=args.batches or None)
     for _ in range(args.warmup):
         scoring.recommend(ops, F, A, topk, True, **kw)
+    import gc
+    gc.collect()
+    gc_was = gc.isenabled()
+    if not os.environ.get('PK_BENCH_KEEP_GC'):
+        gc.disable()                      # no collector pauses inside the timed region
     barrier()
     t0 = time.perf_counter()
+    step_marks = []
     for _ in range(args.steps):
         recs = scoring.recommend(ops, F, A, topk, True, **kw)
+        if os.environ.get('PK_BENCH_STEP_TIMES'):   # debugging aid: recommend() ends with a host sync anyway
+            step_marks.append(time.perf_counter())
     barrier()
     elapsed = time.perf_counter() - t0
+    if gc_was:
+        gc.enable()
+    if step_marks:
+        print('step ms:', ' '.join('%.2f' % (1e3 * (b_ - a_)) for a_, b_ in zip([t0] + step_marks[:-1], step_marks)),
+              file=sys.stderr)
     # ---- untimed instrumented passes: one batch, HIP events around every kernel (the durations the roofline
     # is computed from are those of the kernels running ALONE, not overlapped with another batch's fold-in)
     ops.timers = {}
