@@ -38,8 +38,8 @@ PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--workload', default='s1m', choices=['s1m', 'ml20m', 'ml1m'])
     ap.add_argument('--no-prune', action='store_true',
                     help='score every item tile for every user (disables the exact norm-bound pruning of the sweep)')
