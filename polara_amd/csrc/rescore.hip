@@ -11,6 +11,7 @@
 // fp64, two-class key = the reference's downvote_seen_items semantics, models.py:510-519).
 #include "pk_common.h"
 #include <math.h>
+#include <stdlib.h>
 
 #define PK_IDX_NONE 0x7fffffff
 
@@ -19,10 +20,12 @@ __device__ __forceinline__ bool pk_before64(double ka, int va, double kb, int vb
 }
 
 // bitonic sort (descending by pk_before64) inside aligned segments of SEG lanes, one (key, val) per lane
-template <int SEG, int K, int J>
+// LPC: lanes per element (the LPC adjacent lanes of a candidate hold identical copies and perform identical
+// exchanges, so the network runs on all lanes with partners LPC * J lanes away)
+template <int SEG, int K, int J, int LPC>
 __device__ __forceinline__ void pk_bitonic_seg_merge(double &key, int &val, int t) {
-    const double ok = pk_lane_xor<J>(key);
-    const int ov = pk_lane_xor<J>(val);
+    const double ok = pk_lane_xor<J * LPC>(key);
+    const int ov = pk_lane_xor<J * LPC>(val);
     const bool lower = (t & J) == 0;
     const bool desc = (t & K) == 0;   // t < SEG: the last level (K == SEG) is descending everywhere
     const bool want_first = (lower == desc);
@@ -31,33 +34,114 @@ __device__ __forceinline__ void pk_bitonic_seg_merge(double &key, int &val, int 
         key = ok;
         val = ov;
     }
-    if constexpr (J > 1) pk_bitonic_seg_merge<SEG, K, (J >> 1)>(key, val, t);
+    if constexpr (J > 1) pk_bitonic_seg_merge<SEG, K, (J >> 1), LPC>(key, val, t);
 }
-template <int SEG, int K>
+template <int SEG, int K, int LPC>
 __device__ __forceinline__ void pk_bitonic_seg_levels(double &key, int &val, int t) {
-    if constexpr (K > 2) pk_bitonic_seg_levels<SEG, (K >> 1)>(key, val, t);
-    pk_bitonic_seg_merge<SEG, K, (K >> 1)>(key, val, t);
+    if constexpr (K > 2) pk_bitonic_seg_levels<SEG, (K >> 1), LPC>(key, val, t);
+    pk_bitonic_seg_merge<SEG, K, (K >> 1), LPC>(key, val, t);
 }
-template <int SEG>
+template <int SEG, int LPC>
 __device__ __forceinline__ void pk_bitonic_seg(double &key, int &val, int t) {
-    pk_bitonic_seg_levels<SEG, SEG>(key, val, t);
+    pk_bitonic_seg_levels<SEG, SEG, LPC>(key, val, t);
 }
 
-// A LANE owns one candidate: it walks its own item row (the candidates of a user are popular items,
-// their rows sit in L2) against the user's E row with a serial fp64 FMA chain — no cross-lane
-// reduction at all; a segment of SEG >= KC*splits lanes owns one user, 64/SEG users share a wave.
-// (The first version gave a whole wave to each user and paid a 6-step fp64 wave reduction per
-// candidate plus a 64-lane sort: 2.7 ms per 1M users, instruction-bound.)
-template <int SEG>
+// ---- the ONE summation order of every exact fp64 score in this file ---------------------------------
+// The K products are dealt to four chains by element PAIR: pair p = (2p, 2p+1) goes to chain p & 3, each
+// chain is a serial fma chain in increasing p, and the total is (c0 + c2) + (c1 + c3).  A thread working
+// alone (LPC = 1, and the exact-row kernel) keeps four accumulators; with LPC = 2 lane q owns chains q and
+// q + 2; with LPC = 4 lane q owns chain {0, 2, 1, 3}[q], so that the lane^1 exchange forms (c0 + c2) and
+// (c1 + c3) and the lane^2 exchange the total.  Whatever the lane layout — and whether a user goes
+// through the re-scoring kernel or the exact-row kernel — a given (user, item) score has the same bits.
+template <int LPC>
+__device__ __forceinline__ double pk_dot_chains(const double *__restrict__ vr, const double *er, int K, int q,
+                                                bool vvec2, bool evec2, double *e_norm2 = nullptr) {
+    double n2 = 0.0;   // sum of squares of the e elements this lane touches (any order: only feeds a bound)
+    constexpr int NLOC = 4 / LPC;
+    double acc[NLOC];
+#pragma unroll
+    for (int j = 0; j < NLOC; ++j) acc[j] = 0.0;
+    const int np = (K + 1) >> 1, nfull = K >> 1;
+    const int start = (LPC == 4) ? (((q & 1) << 1) | (q >> 1)) : q;
+    int p = start;
+    // all NLOC pairs of an iteration are complete: no bounds tests, loads of the iteration issued together
+    if (vvec2 && evec2) {
+        const double2 *v2 = reinterpret_cast<const double2 *>(vr);
+        const double2 *e2 = reinterpret_cast<const double2 *>(er);
+#pragma unroll 2
+        for (; p + (NLOC - 1) * LPC < nfull; p += 4) {
+            double2 a[NLOC], e[NLOC];
+#pragma unroll
+            for (int j = 0; j < NLOC; ++j) {
+                a[j] = v2[p + j * LPC];
+                e[j] = e2[p + j * LPC];
+            }
+#pragma unroll
+            for (int j = 0; j < NLOC; ++j) {
+                acc[j] = fma(e[j].x, a[j].x, acc[j]);
+                acc[j] = fma(e[j].y, a[j].y, acc[j]);
+                n2 = fma(e[j].x, e[j].x, fma(e[j].y, e[j].y, n2));
+            }
+        }
+    } else {
+        for (; p + (NLOC - 1) * LPC < nfull; p += 4) {
+#pragma unroll
+            for (int j = 0; j < NLOC; ++j) {
+                const int pj = p + j * LPC;
+                const double e0 = er[2 * pj], e1 = er[2 * pj + 1];
+                acc[j] = fma(e0, vr[2 * pj], acc[j]);
+                acc[j] = fma(e1, vr[2 * pj + 1], acc[j]);
+                n2 = fma(e0, e0, fma(e1, e1, n2));
+            }
+        }
+    }
+    // tail of the row (at most one iteration), incl. the half-filled last pair of an odd K
+#pragma unroll
+    for (int j = 0; j < NLOC; ++j) {
+        const int pj = p + j * LPC;
+        if (pj < nfull) {
+            const double e0 = er[2 * pj], e1 = er[2 * pj + 1];
+            acc[j] = fma(e0, vr[2 * pj], acc[j]);
+            acc[j] = fma(e1, vr[2 * pj + 1], acc[j]);
+            n2 = fma(e0, e0, fma(e1, e1, n2));
+        } else if (pj < np) {
+            const double e0 = er[2 * pj];
+            acc[j] = fma(e0, vr[2 * pj], acc[j]);
+            n2 = fma(e0, e0, n2);
+        }
+    }
+    if (e_norm2) {
+        if constexpr (LPC >= 2) n2 += pk_lane_xor<1>(n2);
+        if constexpr (LPC >= 4) n2 += pk_lane_xor<2>(n2);
+        *e_norm2 = n2;
+    }
+    double s;
+    if constexpr (LPC == 1) s = (acc[0] + acc[2]) + (acc[1] + acc[3]);
+    else if constexpr (LPC == 2) s = acc[0] + acc[1];
+    else s = acc[0];
+    if constexpr (LPC >= 2) s += pk_lane_xor<1>(s);
+    if constexpr (LPC >= 4) s += pk_lane_xor<2>(s);
+    return s;
+}
+
+// LPC adjacent lanes own one candidate: they walk the candidate's item row in interleaved 16-byte pieces
+// (the candidates of a user are popular items, their rows sit in L2) against the user's E row with serial
+// fp64 FMA chains and add their LPC partial sums at the end (one or two lane exchanges); a segment of
+// SEG >= KC*splits candidates owns one user, 64/(SEG*LPC) users share a wave.  LPC trades divergent-row
+// loads (each instruction touches 64/LPC different rows: the texture path handles them one line at a
+// time) against the instructions of the segment sort, which serve fewer users per wave.
+// (The first version gave a whole wave to each user and paid a 6-step fp64 wave reduction per candidate
+// plus a 64-lane sort: 2.7 ms per 1M users; LPC = 1: 1.04 ms.)
+template <int SEG, int LPC>
 __global__ __launch_bounds__(256) void rescore_topk_kernel(
     int64_t n_users, int64_t n_items, int K, const double *__restrict__ V, int64_t ldv,
     const double *__restrict__ E, int64_t lde, const int64_t *__restrict__ seen_ptr, int KC, int splits,
     const float *__restrict__ cand_score, const int32_t *__restrict__ cand_idx, int topk, double vmax,
     int64_t *__restrict__ out_idx, double *__restrict__ out_score, int32_t *__restrict__ flags) {
-    constexpr int UPW = 64 / SEG;
+    constexpr int UPW = 64 / (SEG * LPC);
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int ul = lane / SEG, t = lane % SEG;
+    const int ul = lane / (SEG * LPC), t = (lane / LPC) % SEG, q = lane % LPC;
     const int64_t user = ((int64_t)blockIdx.x * 4 + wave) * UPW + ul;
     const bool live = user < n_users;
     const int64_t urow = live ? user : 0;
@@ -76,35 +160,19 @@ __global__ __launch_bounds__(256) void rescore_topk_kernel(
 
     const double *vr = V + (int64_t)(idx >= 0 ? idx : 0) * ldv;
     const double *er = E + urow * lde;
-    double s = 0.0, e2 = 0.0;
-    const bool vec2 = ((ldv | lde) & 1) == 0 && ((((uintptr_t)V) | ((uintptr_t)E)) & 15) == 0;
-    int k = 0;
-    if (vec2) {
-        const double2 *v2 = reinterpret_cast<const double2 *>(vr);
-        const double2 *e2p = reinterpret_cast<const double2 *>(er);
-#pragma unroll 4
-        for (; k + 1 < K; k += 2) {
-            const double2 a = v2[k >> 1], b = e2p[k >> 1];
-            s = fma(b.x, a.x, s);
-            s = fma(b.y, a.y, s);
-            e2 = fma(b.x, b.x, e2);
-            e2 = fma(b.y, b.y, e2);
-        }
-    }
-    for (; k < K; ++k) {
-        const double b = er[k];
-        s = fma(b, vr[k], s);
-        e2 = fma(b, b, e2);
-    }
+    const bool vvec2 = (ldv & 1) == 0 && (((uintptr_t)V) & 15) == 0;
+    const bool evec2 = (lde & 1) == 0 && (((uintptr_t)E) & 15) == 0;
+    double e2;
+    const double s = pk_dot_chains<LPC>(vr, er, K, q, vvec2, evec2, &e2);
     const double enorm = sqrt(e2);
     double my_s = (idx >= 0) ? s : -INFINITY;
     int my_i = (idx >= 0) ? idx : PK_IDX_NONE;
-    pk_bitonic_seg<SEG>(my_s, my_i, t);
+    pk_bitonic_seg<SEG, LPC>(my_s, my_i, t);
 
     // certification
     int flag = 0;
     const int64_t n_seen = seen_ptr ? (seen_ptr[urow + 1] - seen_ptr[urow]) : 0;
-    const double s_k = __shfl(my_s, ul * SEG + topk - 1, 64);
+    const double s_k = __shfl(my_s, (ul * SEG + topk - 1) * LPC, 64);
     if (n_items - n_seen < topk) {
         flag |= 2;  // seen items must re-enter the list: exact path
     } else if (tau32 > -INFINITY) {
@@ -115,11 +183,11 @@ __global__ __launch_bounds__(256) void rescore_topk_kernel(
         const double tau_cert = tau32 + fabs(tau32) * 7.62939453125e-06;
         if (bound > 0.0 && !(s_k - tau_cert > bound)) flag |= 1;
     }
-    if (live && t < topk) {
+    if (live && q == 0 && t < topk) {
         out_idx[user * topk + t] = (my_i == PK_IDX_NONE) ? -1 : (int64_t)my_i;
         if (out_score) out_score[user * topk + t] = my_s;
     }
-    if (live && t == 0) flags[user] = flag;
+    if (live && q == 0 && t == 0) flags[user] = flag;
 }
 
 extern "C" int pk_rescore_topk_f64(void *stream, int64_t n_users, int64_t n_items, int32_t K, const double *V_dev,
@@ -132,14 +200,23 @@ extern "C" int pk_rescore_topk_f64(void *stream, int64_t n_users, int64_t n_item
     PK_REQUIRE(KC >= 1 && splits >= 1 && KC * splits <= 64 && topk >= 1 && topk <= KC,
                "pk_rescore_topk_f64: need topk <= KC and KC*splits <= 64");
     const int seg = (KC * splits <= 16) ? 16 : (KC * splits <= 32) ? 32 : 64;
-#define PK_RESCORE(SEGV)                                                                                        \
-    hipLaunchKernelGGL((rescore_topk_kernel<SEGV>), dim3((unsigned)pk_ceil_div(n_users, 4 * (64 / SEGV))),      \
+    const char *lpc_env = getenv("PK_RESCORE_LPC");      // kernel-tuning knob
+    const int lpc_req = lpc_env ? atoi(lpc_env) : 0;
+#define PK_RESCORE(SEGV, LPCV)                                                                                    \
+    hipLaunchKernelGGL((rescore_topk_kernel<SEGV, LPCV>), dim3((unsigned)pk_ceil_div(n_users, 4 * (64 / (SEGV * LPCV)))), \
                        dim3(256), 0, pk_stream(stream), n_users, n_items, K, V_dev, ldv, E_dev, lde,            \
                        seen_ptr_dev, KC, splits, cand_score_dev, cand_idx_dev, topk, v_row_norm_max,            \
                        out_idx_dev, out_score_dev, flags_dev)
-    if (seg == 16) PK_RESCORE(16);
-    else if (seg == 32) PK_RESCORE(32);
-    else PK_RESCORE(64);
+    if (seg == 16) {
+        if (lpc_req == 1) PK_RESCORE(16, 1);
+        else if (lpc_req == 4) PK_RESCORE(16, 4);
+        else PK_RESCORE(16, 2);
+    } else if (seg == 32) {
+        if (lpc_req == 1) PK_RESCORE(32, 1);
+        else PK_RESCORE(32, 2);
+    } else {
+        PK_RESCORE(64, 1);
+    }
 #undef PK_RESCORE
     PK_CHECK_LAUNCH("rescore_topk_kernel");
     return PK_OK;
@@ -183,9 +260,7 @@ __global__ __launch_bounds__(256) void score_exact_rows_kernel(
     __syncthreads();
     for (int64_t i = tid; i < n_items; i += 256) {
         const double *vr = V + i * ldv;
-        double s = 0.0;
-        for (int k = 0; k < K; ++k) s = fma(s_e[k], vr[k], s);
-        score[i] = s;
+        score[i] = pk_dot_chains<1>(vr, s_e, K, 0, false, false);   // same bits as the re-scoring kernel
         cls[i] = 0;
     }
     __syncthreads();
@@ -263,9 +338,7 @@ __global__ __launch_bounds__(256) void dense_scores_kernel(int n_rows, int64_t n
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n_items) return;
     const double *vr = V + i * ldv;
-    double s = 0.0;
-    for (int k = 0; k < K; ++k) s = fma(s_e[k], vr[k], s);
-    out[(int64_t)r * ldo + i] = s;
+    out[(int64_t)r * ldo + i] = pk_dot_chains<1>(vr, s_e, K, 0, false, false);
 }
 
 extern "C" int pk_dense_scores_f64(void *stream, int32_t n_rows, int64_t n_items, int32_t K, const double *V_dev,
