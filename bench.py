@@ -307,13 +307,14 @@ def main():
                              '(Cauchy-Schwarz bound, identical results; --no-prune scores every tile)',
                      'dense_equivalent': {'flop_per_launch': flops, 'TFLOP/s': flops / (cand_avg_ms * 1e-3) / 1e12,
                                           'frac_of_peak': flops / (cand_avg_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS}},
-        'roofline_build': {'kernel': 'spmm_csr_kernel', 'bound': 'hbm',
+        'roofline_build': {'kernel': 'spmm_csr_groups_kernel', 'bound': 'hbm',
                            'achieved': float(sum(spmm_bytes) / (sum(spmm_ms) * 1e-3) / 1e9) if spmm_ms else None,
                            'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
                            'frac': float(sum(spmm_bytes) / (sum(spmm_ms) * 1e-3) / 1e9 / PEAK_HBM_GBPS) if spmm_ms else None,
                            'traffic': traffic.get('spmm'),
-                           'traffic_note': 'FETCH_SIZE + WRITE_SIZE per launch (profiles/r01_bench_pmc_*.txt): ~11x the '
-                                           'algorithmic bytes - the 512 B row gathers of the dense block miss the 4 MiB L2',
+                           'traffic_note': '2*FETCH_SIZE + WRITE_SIZE per launch (profiles/r01_bench_pmc_*.txt): ~20x the '
+                                           'algorithmic bytes - the 400-512 B row gathers of the dense block are not '
+                                           'read once but once per nnz, and half of them miss L2/MALL',
                            'gather_GBps': (float(sum(m[2] * m[3] * 8.0 for _, _, m in spmm_ev) / (sum(spmm_ms) * 1e-3) / 1e9)
                                            if spmm_ms else None),
                            'gather_note': 'nnz*nc*8 bytes of dense-row gathers per launch / time: the traffic that actually '
