@@ -80,6 +80,13 @@ int pk_tsmm_f64(void *stream, int64_t n, int32_t lin, int32_t lout, const double
  * info_dev[0] = sweeps used, info_dev[1] = 1 if converged.  n <= 1024. */
 int pk_eigh_psd_f64(void *stream, int32_t n, double *S_dev, int64_t lds_, double *evecs_dev, int64_t ldv,
                     double *evals_dev, int32_t max_sweeps, double tol, int32_t *info_dev);
+/* Cholesky of a small SPD Gram matrix and the inverse of its factor: G + shift_rel*trace(G)*I = R^T R, Rinv = R^-1 (upper
+ * triangular), so that X <- X Rinv is orthonormal (CholeskyQR; replaces LAPACK's QR inside svds / numpy.qr,
+ * models.py:844, tensor.py:61).  info_dev[0] = 0 or (column + 1) of the first non-positive pivot.
+ * work: pk_chol_work_bytes(n) bytes (0 for n <= 136). */
+int64_t pk_chol_work_bytes(int32_t n);
+int pk_chol_rinv_f64(void *stream, int32_t n, const double *G_dev, int64_t ldg, double shift_rel, double *Rinv_dev,
+                     int64_t ldr, void *work_dev, int32_t *info_dev);
 /* out = alpha*Z + beta*Y + gamma*X over n_elems (Chebyshev three-term recurrence); Y/X may be NULL */
 int pk_axpbypcz_f64(void *stream, int64_t n_elems, double alpha, const double *Z_dev, double beta,
                     const double *Y_dev, double gamma, const double *X_dev, double *out_dev);

@@ -332,6 +332,20 @@ class HipOps:
                                             _ptr(self._info)), 'pk_eigh_psd_f64')
         return lam, R.t()  # rows of R are eigenvectors -> return as columns (a view; strides swapped)
 
+    def chol_rinv(self, G, shift_rel=0.0, info=None):
+        """Rinv (l x l upper triangular) with G + shift_rel*trace(G)*I = R^T R; info: int32 device tensor[1]
+        (0 = ok, j+1 = non-positive pivot at column j) — not read here, so no host sync."""
+        n = G.shape[0]
+        assert G.stride(1) == 1
+        Rinv = self.empty(n, n)
+        if info is None:
+            info = torch.zeros(1, dtype=torch.int32, device=self.device)
+        need = self.lib.pk_chol_work_bytes(n)
+        work = self.empty((need + 7) // 8) if need else None
+        _lib.check(self.lib.pk_chol_rinv_f64(self.stream(), n, _ptr(G), G.stride(0), float(shift_rel), _ptr(Rinv), n,
+                                             _ptr(work), _ptr(info)), 'pk_chol_rinv_f64')
+        return Rinv, info
+
     def axpbypcz(self, alpha, Z, beta=0.0, Y=None, gamma=0.0, X=None, out=None):
         assert Z.is_contiguous() and (Y is None or Y.is_contiguous()) and (X is None or X.is_contiguous())
         if out is None:

@@ -51,8 +51,9 @@ def _project_out(ops, X, V):
     return ops.axpbypcz(1.0, X, -1.0, ops.tsmm(V, G))
 
 
-def orthonormalize(ops, X, V_lock=None, passes=2):
-    """Orthonormal basis of span(X) (and orthogonal to V_lock) by eigen-whitening, twice."""
+def _whiten(ops, X, V_lock=None, passes=2):
+    """Orthonormal basis of span(X) (and orthogonal to V_lock) by eigen-whitening, twice: tolerant of
+    rank-deficient blocks (tiny eigenvalues are clamped), one Jacobi eigh per pass."""
     for _ in range(passes):
         if V_lock is not None and V_lock.shape[1] > 0:
             X = _project_out(ops, X, V_lock)
@@ -62,6 +63,27 @@ def orthonormalize(ops, X, V_lock=None, passes=2):
         Cs = ops.scale_cols(Cm.contiguous(), s)
         X = ops.tsmm(X, Cs)
     return X
+
+
+def orthonormalize(ops, X, V_lock=None):
+    """Orthonormal basis of span(X), orthogonal to V_lock.  Shifted CholeskyQR3: X <- X R^-1 with
+    G + s I = R^T R three times (shift s = 11 (m l + l (l + 1)) u trace(G) on the first pass only), each
+    pass one Gram matrix, one l x l Cholesky kernel and one tall-skinny GEMM — the filtered blocks have a
+    condition number up to the filter spread (1e7), which the shifted first pass is made for.  A block that
+    is numerically rank-deficient (non-positive pivot) falls back to the eigen-whitening."""
+    m, l = X.shape
+    u = 1.1102230246251565e-16
+    info = torch.zeros(3, dtype=torch.int32, device=X.device)
+    Y = X
+    for p in range(3):
+        if V_lock is not None and V_lock.shape[1] > 0:
+            Y = _project_out(ops, Y, V_lock)
+        G = ops.gram(Y)
+        Rinv, _ = ops.chol_rinv(G, 11.0 * (m * l + l * (l + 1)) * u if p == 0 else 0.0, info=info[p:p + 1])
+        Y = ops.tsmm(Y, Rinv)
+    if int(info.abs().sum().item()) != 0:
+        return _whiten(ops, X, V_lock)
+    return Y
 
 
 def _cheb_degree(theta_top, b, spread, m_max):

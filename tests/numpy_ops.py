@@ -98,6 +98,19 @@ class NumpyOps:
         v = v[:, ::-1].copy()
         return torch.from_numpy(w), torch.from_numpy(v)
 
+    def chol_rinv(self, G, shift_rel=0.0, info=None):
+        g = G.numpy()
+        n = g.shape[0]
+        out_info = torch.zeros(1, dtype=torch.int32) if info is None else info
+        try:
+            L = np.linalg.cholesky(g + shift_rel * np.trace(g) * np.eye(n))
+            Rinv = np.linalg.inv(L.T)
+            out_info[0] = 0
+        except np.linalg.LinAlgError:
+            Rinv = np.zeros((n, n))
+            out_info[0] = 1
+        return torch.from_numpy(np.ascontiguousarray(np.triu(Rinv))), out_info
+
     def axpbypcz(self, alpha, Z, beta=0.0, Y=None, gamma=0.0, X=None, out=None):
         r = alpha * Z
         if Y is not None:

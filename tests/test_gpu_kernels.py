@@ -149,6 +149,33 @@ def test_eigh_exactly_singular_inputs(hip_ops, n):
     assert np.abs(C.T @ C - np.eye(n)).max() < 1e-10
 
 
+@pytest.mark.parametrize('n', [1, 5, 64, 128, 136, 200])
+def test_chol_rinv(hip_ops, n):
+    rng = np.random.RandomState(n)
+    X = rng.randn(4 * n + 3, n) * np.exp(rng.randn(n) * 2)          # graded columns: cond(G) ~ 1e7
+    G = X.T @ X
+    Rinv, info = hip_ops.chol_rinv(hip_ops.to_device(G))
+    Rinv = hip_ops.to_host(Rinv)
+    assert int(hip_ops.to_host(info)[0]) == 0
+    assert np.allclose(Rinv, np.triu(Rinv))
+    Q = X @ Rinv
+    assert np.abs(Q.T @ Q - np.eye(n)).max() < 1e-8
+    R = np.linalg.cholesky(G).T
+    assert np.allclose(Rinv, np.linalg.inv(R), rtol=1e-7, atol=1e-9 * np.abs(np.linalg.inv(R)).max())
+    # relative shift: G + s*trace(G)*I
+    Rs, _ = hip_ops.chol_rinv(hip_ops.to_device(G), 1e-3)
+    Rs = hip_ops.to_host(Rs)
+    Gs = G + 1e-3 * np.trace(G) * np.eye(n)
+    assert np.abs(Rs.T @ Gs @ Rs - np.eye(n)).max() < 1e-8
+    if n >= 5:   # exactly singular input: reported, not silently wrong
+        Xd = X.copy()
+        Xd[:, -1] = Xd[:, 0]
+        Gd = Xd.T @ Xd
+        Gd[-1, -1] = Gd[0, 0] * (1 - 1e-12)
+        _, info = hip_ops.chol_rinv(hip_ops.to_device(Gd))
+        assert int(hip_ops.to_host(info)[0]) != 0
+
+
 def test_elementwise_and_small_kernels(hip_ops):
     rng = np.random.RandomState(0)
     for n in (1, 7, 1000, 100001):
