@@ -163,6 +163,12 @@ struct LaneState {
 
 // NSTEP = number of K=2 MFMA steps actually issued (ceil(rank/2) rounded up to a supported value);
 // the packed operands hold KQ = ceil(NSTEP/4) float4 groups, the tail group is only partly used.
+__host__ __device__ constexpr bool pk_top_in_lds(int nstep, int kc) { return kc <= 32 || nstep > 64; }
+__host__ __device__ constexpr int pk_ring_rows(int kc) { return kc == 16 ? 8 : RING; }
+__host__ __device__ constexpr size_t pk_score_lds_bytes(int nstep, int kc) {
+    return (size_t)(4 * pk_ring_rows(kc) * 64 + (pk_top_in_lds(nstep, kc) ? 4 * 32 * kc : 1)) * sizeof(uint2);
+}
+
 template <int NSTEP, int KC>
 __global__ __launch_bounds__(256) void score_candidates_kernel(
     const float4 *__restrict__ Vp, const float4 *__restrict__ Ep, int64_t n_users, int n_items,
@@ -176,14 +182,15 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
     // KC == 16: rings of 8, so that a user's list + both rings are 32 entries and TWO users are merged
     // per flush, one in each half of the wave (15 sort stages per two users instead of 21 per user).
     constexpr bool PAIRED = (KC == 16);
-    constexpr int RG = PAIRED ? 8 : RING;
+    constexpr int RG = pk_ring_rows(KC);
     constexpr int SLOTS = (2 * RG + KC + 63) / 64;
     // The running top-KC lists of the wave's 32 users live in LDS when they fit (KC <= 32): a flush
     // then never touches global memory (no vmcnt drain in the middle of the MFMA stream).  They are
     // copied from / to cand_score, cand_idx at the launch boundaries.
-    constexpr bool TOP_LDS = (KC <= 32);
-    __shared__ uint2 ring_all[4][RG][64];
-    __shared__ uint2 top_all[TOP_LDS ? 4 : 1][TOP_LDS ? 32 * KC : 1];
+    // KC = 64 lists (16 KiB per wave) move to LDS too when the rank is high enough that the fragment
+    // registers already limit the SIMD to one wave (NSTEP > 64: 96 KiB per workgroup, one workgroup per CU).
+    constexpr bool TOP_LDS = pk_top_in_lds(NSTEP, KC);
+    extern __shared__ uint2 pk_score_lds[];      // [4][RG][64] rings, then [4][32*KC] top lists (TOP_LDS)
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -191,8 +198,8 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
     if (group * 32 >= n_users) return;  // whole wave leaves; the kernel has no workgroup barrier
     PROF_DECL;
     const unsigned long long prof_k0 = PROF_T();
-    uint2(*ring)[64] = ring_all[wave];
-    uint2 *top = top_all[TOP_LDS ? wave : 0];
+    uint2(*ring)[64] = reinterpret_cast<uint2(*)[64]>(pk_score_lds + wave * (RG * 64));
+    uint2 *top = pk_score_lds + 4 * RG * 64 + (TOP_LDS ? wave * (32 * KC) : 0);
 
     // Item split: blockIdx.y = h owns the contiguous tile range [h*split_tiles, (h+1)*split_tiles) of
     // the catalogue for ALL chunks, with its own threshold, rings, top lists and parked state, so
@@ -846,7 +853,20 @@ static int launch_candidates_n(hipStream_t st, int KC, int ablate, dim3 grid, co
     const int n_chunks = (split_tiles + tiles_per_chunk - 1) / tiles_per_chunk;
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
 #define PK_LAUNCH(KCV)                                                                                          \
-    hipLaunchKernelGGL((score_candidates_kernel<NSTEP, KCV>), grid, dim3(256), 0, st, Vp, Ep, n_users,          \
+    if (pk_score_lds_bytes(NSTEP, KCV) > 64 * 1024) {                                                           \
+        static bool attr_set = false;   /* one flag per (NSTEP, KC) instance of this macro expansion */        \
+        if (!attr_set) {                                                                                        \
+            hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&score_candidates_kernel<NSTEP, KCV>), \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize,                     \
+                                                (int)pk_score_lds_bytes(NSTEP, KCV));                           \
+            if (e1 != hipSuccess) {                                                                             \
+                pk_set_error("pk_score_candidates_f32: cannot raise the LDS limit: %s", hipGetErrorString(e1)); \
+                return PK_E_LAUNCH;                                                                             \
+            }                                                                                                   \
+            attr_set = true;                                                                                    \
+        }                                                                                                       \
+    }                                                                                                           \
+    hipLaunchKernelGGL((score_candidates_kernel<NSTEP, KCV>), grid, dim3(256), pk_score_lds_bytes(NSTEP, KCV), st, Vp, Ep, n_users, \
                        n_items, n_tiles, split_tiles, chunk, tiles_per_chunk, seen_ptr, seen_tiles, seen_ntiles, cs, ci, st_lane, st_ring,  \
                        user_bound, tile_bound, ablate)
 #ifdef PK_FAST_BUILD
