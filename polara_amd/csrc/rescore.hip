@@ -178,9 +178,9 @@ __global__ __launch_bounds__(256) void rescore_topk_kernel(
     } else if (tau32 > -INFINITY) {
         // |fl32(e.v) - e.v| <= (K + 3) u32 |e||v|  (input rounding + K-term fmaf chain), u32 = 2^-24
         const double bound = (double)(K + 3) * 5.9604644775390625e-08 * enorm * vmax;
-        // the candidate sweep orders scores that agree to 2^-18 relative arbitrarily (key-only flush sort,
+        // the candidate sweep orders scores that agree to 2^-16 relative arbitrarily (key-only flush sorts,
         // score.hip): a non-candidate may exceed the KC-th candidate by that much
-        const double tau_cert = tau32 + fabs(tau32) * 7.62939453125e-06;
+        const double tau_cert = tau32 + fabs(tau32) * 3.0517578125e-05;
         if (bound > 0.0 && !(s_k - tau_cert > bound)) flag |= 1;
     }
     if (live && q == 0 && t < topk) {

@@ -64,69 +64,63 @@ extern "C" int pk_debug_profile(unsigned long long *out, int reset) {
 #define PK_IDX_NONE 0x7fffffff
 #define PK_TILE_NONE 0xffffffff00000000ull   // end of a seen-tile stream
 
-// ---- ordering used everywhere: larger score first, then smaller item id ---------------------
-__device__ __forceinline__ bool pk_before(float ka, int va, float kb, int vb) {
-    return (ka > kb) || (ka == kb && va < vb);
+// Wave-wide key-only bitonic sort (descending) of 64*SLOTS 32-bit keys, element index i = lane + 64*slot.
+// A key is the order-preserving image of a score with its low bits replaced by the element's source index
+// (see pk_float_order / the flush code): a stage is a lane exchange + v_max_u32 + v_min_u32 + one v_cndmask
+// on a compile-time lane mask, or a plain min/max when the partner is the other slot of the same lane.
+template <int K, int J, int S>
+constexpr unsigned long long pk_wave_stage_mask() {
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l) {
+        const int i = l + 64 * S;
+        if (((i & J) == 0) == ((i & K) == 0)) m |= 1ull << l;   // this position keeps the larger element
+    }
+    return m;
 }
-
-// Wave-wide bitonic sort (descending by pk_before) of 64*SLOTS (key,val) pairs, element index
-// i = lane + 64*slot.
 template <int SLOTS, int K, int J>
-__device__ __forceinline__ void pk_bitonic_stage(float (&key)[SLOTS], int (&val)[SLOTS], int lane) {
+__device__ __forceinline__ void pk_sort32_stage(unsigned (&key)[SLOTS]) {
     if constexpr (J >= 64) {
-        // partner lives in another slot of the same lane (only SLOTS == 2, J == 64)
-        constexpr int sj = J >> 6;
-#pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
-            if ((s & sj) == 0) {
-                const int i = lane + 64 * s;
-                const bool desc = (i & K) == 0;
-                const bool swap = desc ? pk_before(key[s + sj], val[s + sj], key[s], val[s])
-                                       : pk_before(key[s], val[s], key[s + sj], val[s + sj]);
-                if (swap) {
-                    float tk = key[s]; key[s] = key[s + sj]; key[s + sj] = tk;
-                    int tv = val[s]; val[s] = val[s + sj]; val[s + sj] = tv;
-                }
-            }
-        }
+        // partner lives in the other slot of the same lane (SLOTS == 2, J == 64, K == 128: descending)
+        const unsigned hi = key[0] > key[1] ? key[0] : key[1], lo = key[0] > key[1] ? key[1] : key[0];
+        key[0] = hi;
+        key[1] = lo;
     } else {
+        unsigned other[SLOTS];
 #pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
-            const int i = lane + 64 * s;
-            const float ok = pk_lane_xor<J>(key[s]);
-            const int ov = pk_lane_xor<J>(val[s]);
-            const bool lower = (i & J) == 0;
-            const bool desc = (i & K) == 0;
-            const bool want_first = (lower == desc);  // this position keeps the element that sorts first
-            const bool other_first = pk_before(ok, ov, key[s], val[s]);
-            if (want_first == other_first) {
-                key[s] = ok;
-                val[s] = ov;
-            }
+        for (int s = 0; s < SLOTS; ++s) other[s] = (unsigned)pk_lane_xor<J>((int)key[s]);
+        {
+            const unsigned hi = key[0] > other[0] ? key[0] : other[0], lo = key[0] > other[0] ? other[0] : key[0];
+            key[0] = __builtin_amdgcn_inverse_ballot_w64(pk_wave_stage_mask<K, J, 0>()) ? hi : lo;
+        }
+        if constexpr (SLOTS == 2) {
+            const unsigned hi = key[1] > other[1] ? key[1] : other[1], lo = key[1] > other[1] ? other[1] : key[1];
+            key[1] = __builtin_amdgcn_inverse_ballot_w64(pk_wave_stage_mask<K, J, 1>()) ? hi : lo;
         }
     }
 }
 template <int SLOTS, int K, int J>
-__device__ __forceinline__ void pk_bitonic_merge(float (&key)[SLOTS], int (&val)[SLOTS], int lane) {
-    pk_bitonic_stage<SLOTS, K, J>(key, val, lane);
-    if constexpr (J > 1) pk_bitonic_merge<SLOTS, K, (J >> 1)>(key, val, lane);
+__device__ __forceinline__ void pk_sort32_merge(unsigned (&key)[SLOTS]) {
+    pk_sort32_stage<SLOTS, K, J>(key);
+    if constexpr (J > 1) pk_sort32_merge<SLOTS, K, (J >> 1)>(key);
 }
 template <int SLOTS, int K>
-__device__ __forceinline__ void pk_bitonic_levels(float (&key)[SLOTS], int (&val)[SLOTS], int lane) {
-    if constexpr (K > 2) pk_bitonic_levels<SLOTS, (K >> 1)>(key, val, lane);
-    pk_bitonic_merge<SLOTS, K, (K >> 1)>(key, val, lane);
+__device__ __forceinline__ void pk_sort32_levels(unsigned (&key)[SLOTS]) {
+    if constexpr (K > 2) pk_sort32_levels<SLOTS, (K >> 1)>(key);
+    pk_sort32_merge<SLOTS, K, (K >> 1)>(key);
 }
 template <int SLOTS>
-__device__ __forceinline__ void pk_bitonic_desc(float (&key)[SLOTS], int (&val)[SLOTS], int lane) {
-    pk_bitonic_levels<SLOTS, 64 * SLOTS>(key, val, lane);
+__device__ __forceinline__ void pk_sort32_wave_desc(unsigned (&key)[SLOTS]) {
+    static_assert(SLOTS == 1 || SLOTS == 2, "pk_sort32_wave_desc: 64 or 128 elements");
+    pk_sort32_levels<SLOTS, 64 * SLOTS>(key);
 }
 
 // Key-only network inside each 32-lane half (both halves end up descending): the element is ONE 32-bit
 // word — the score mapped to an order-preserving unsigned with its low 5 bits replaced by the source slot —
 // so a stage is a lane exchange + v_max_u32 + v_min_u32 + one v_cndmask on a compile-time lane mask
 // (~5 instructions instead of ~12 for a (score, item) pair with a tie-break).  The price: scores that
-// agree in all but their low 5 mantissa bits (2^-18 relative) may be ordered either way; the exact
-// re-scoring pass widens its certification bound by 2^-17 |tau| to cover that (rescore.hip).
+// agree in all but their low 5 mantissa bits (2^-18 relative; 6 or 7 bits, 2^-16, in the wave-wide sort
+// above) may be ordered either way; the exact re-scoring pass widens its certification bound by
+// 2^-15 |tau| to cover that (rescore.hip).
 template <int K, int J>
 constexpr unsigned long long pk_half_stage_mask() {
     unsigned long long m = 0;
@@ -331,7 +325,38 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
             key[s] = k;
             val[s] = v;
         }
-        pk_bitonic_desc<SLOTS>(key, val, lane);
+        // key-only sort: low SRC_BITS of the ordered score carry the element's source index (lane + 64*slot);
+        // afterwards every position fetches its (score, item) from that source
+        constexpr unsigned SRC_MASK = 64u * SLOTS - 1u;
+        unsigned k32[SLOTS];
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) k32[s] = (pk_float_order(key[s]) & ~SRC_MASK) | (unsigned)(lane + 64 * s);
+        pk_sort32_wave_desc<SLOTS>(k32);
+        {
+            float ok[SLOTS];
+            int ov[SLOTS];
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) {
+                const int src = (int)(k32[s] & SRC_MASK);
+                float fk = __shfl(key[0], src & 63, 64);
+                int fv = __shfl(val[0], src & 63, 64);
+                if constexpr (SLOTS == 2) {
+                    const float fk1 = __shfl(key[1], src & 63, 64);
+                    const int fv1 = __shfl(val[1], src & 63, 64);
+                    if (src >= 64) {
+                        fk = fk1;
+                        fv = fv1;
+                    }
+                }
+                ok[s] = fk;
+                ov[s] = fv;
+            }
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) {
+                key[s] = ok[s];
+                val[s] = ov[s];
+            }
+        }
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
             const int i = lane + 64 * s;
