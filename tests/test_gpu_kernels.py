@@ -416,6 +416,49 @@ def test_item_splits_equal_single_range(hip_ops, cfg):
         assert np.array_equal(hip_ops.to_host(ref_s), hip_ops.to_host(got_s))
 
 
+@pytest.mark.parametrize('cfg', [dict(K=50, topk=10), dict(K=100, topk=20), dict(K=200, topk=50)])
+def test_near_tie_scores_are_resolved_exactly(hip_ops, cfg):
+    """Adversarial catalogue for the fp32 candidate pass: families of items whose factors are equal up to
+    1 +- a few 1e-8 .. 1e-6 (indistinguishable or nearly so in fp32, and inside the 2^-16 window in which the
+    key-only flush sorts may order either way), placed around every user's top-k boundary.  The certified
+    pipeline (candidates -> exact fp64 re-scoring -> exact rows for uncertified users) must still return the
+    exact fp64 order (score desc, item asc)."""
+    from polara_amd import scoring
+    K, topk = cfg['K'], cfg['topk']
+    rng = np.random.RandomState(K)
+    n_users, n_base, fam = 96, 400, 70        # family > the largest candidate capacity (64): certification must fail
+    base = rng.randn(n_base, K) / np.sqrt(K) * ((1.0 + np.arange(n_base)) ** -0.5)[:, None]
+    rows = []
+    for i in range(n_base):
+        rows.append(base[i])
+        if i < 40:                            # the head of the catalogue, where the top-k boundaries fall
+            for f in range(fam):
+                rows.append(base[i] * (1.0 + rng.choice([-1, 1]) * 10.0 ** rng.uniform(-8.5, -6.0)))
+    V = np.array(rows)
+    V = V[rng.permutation(len(V))]            # no helpful order: neither norm- nor id-sorted
+    n_items = V.shape[0]
+    indptr, indices, values = rand_csr(rng, n_users, n_items, 25, empty_rows=[3])
+    T = hip_ops.csr(indptr, indices, values, (n_users, n_items))
+    F = scoring.FactorImage(hip_ops, hip_ops.to_device(V))
+    E = sps.csr_matrix((values.astype(np.float64), indices, indptr), shape=(n_users, n_items)) @ V
+    for prune in (True, False):
+        st = {}
+        recs, sc = scoring.recommend(hip_ops, F, T, topk, True, return_scores=True, stats=st, prune=prune)
+        recs, sc = hip_ops.to_host(recs), hip_ops.to_host(sc)
+        want, s = brute_topk(V, E, indptr, indices, topk, True)
+        live = np.abs(E).sum(1) > 0
+        # the device sums every score in one fixed order; NumPy's dot may differ in the last bits, which can
+        # flip exact-to-1e-16 pairs: compare ORDER wherever consecutive reference scores differ by > 1e-13 rel.
+        for u in np.flatnonzero(live):
+            ref_s = s[u, want[u]]
+            got_s = s[u, recs[u]]
+            assert np.allclose(got_s, ref_s, rtol=1e-12, atol=0), (u, prune)
+            clear = np.abs(np.diff(ref_s)) > 1e-13 * np.abs(ref_s[:-1])
+            firm = np.r_[clear, True] & np.r_[True, clear]
+            assert np.array_equal(recs[u][firm], want[u][firm]), (u, prune, st)
+        assert st['flagged_users'] > 0        # the near-ties really did defeat the fp32 certification
+
+
 def test_large_topk_uses_exact_rows(hip_ops):
     from polara_amd import scoring
     rng = np.random.RandomState(2)
