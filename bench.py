@@ -272,6 +272,7 @@ def main():
         return
     cand_avg_ms = float(np.mean(cand_ms))
     traffic = pmc_traffic() if (args.workload == 's1m' and args.scale == 1.0 and comm.world == 1) else {}
+    n_chunk_launches = int(ops.lib.pk_score_chunk_launches(n_items, rank, 1, 0, 0 if args.no_prune else 1))
     flops = 2.0 * (hi - lo) * n_items * rank                     # the reference's dense contraction (models.py:860)
     swept = stats['tiles_scored'] / max(stats['tiles_total'], 1)    # share of the (user group x item tile) grid scored
     flops_exec = flops * swept
@@ -297,10 +298,10 @@ def main():
                   'flagged_users_last_step': stats.get('flagged_users'), 'candidate_capacity': stats.get('candidate_capacity')},
         'roofline': {'kernel': 'score_candidates_kernel', 'bound': 'mfma', 'achieved': achieved_tf,
                      'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved_tf / PEAK_FP32_MFMA_TFLOPS,
-                     'traffic': (traffic['score'] * 9 if 'score' in traffic else None),
-                     'traffic_note': 'HBM/fabric bytes per scoring pass = 9 item-chunk launches x (2*FETCH_SIZE + WRITE_SIZE) '
+                     'traffic': (traffic['score'] * n_chunk_launches if 'score' in traffic else None),
+                     'traffic_note': 'HBM/fabric bytes per scoring pass = item-chunk launches x (2*FETCH_SIZE + WRITE_SIZE) '
                                      'of a separate rocprofv3 --pmc run (profiles/r01_bench_pmc_*.txt); algorithmic minimum ~1 GB',
-                     'launches': len(cand_ms), 'avg_ms': cand_avg_ms, 'flop_per_launch': flops_exec,
+                     'launches': len(cand_ms), 'kernel_launches_per_pass': n_chunk_launches, 'avg_ms': cand_avg_ms, 'flop_per_launch': flops_exec,
                      'swept_fraction': swept, 'exit_tile_quantiles': stats.get('exit_tile_quantiles'),
                      'n_tiles': -(-n_items // 32),
                      'note': 'achieved/frac count only the MFMA tiles actually scored: the sweep is pruned exactly '

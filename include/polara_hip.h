@@ -149,6 +149,9 @@ int pk_score_candidates_f32(void *stream, int64_t n_users, int64_t n_items, int3
                             int32_t tiles_per_chunk /* 0 = auto */,
                             const float *user_bound_dev /* [n_users] or NULL */,
                             const float *tile_bound_dev /* [ceil(n_items/32)] or NULL */);
+/* launches pk_score_candidates_f32 issues for these arguments (fixed item chunks; doubling chunks when the
+ * pruning bounds are passed) */
+int32_t pk_score_chunk_launches(int64_t n_items, int32_t K, int32_t splits, int32_t tiles_per_chunk, int32_t pruned);
 /* Exact pruning bounds for pk_score_candidates_f32 (Cauchy-Schwarz: |E_u . V_i| <= ||E_u|| ||V_i||).
  * The reference scores every item for every user (models.py:860); the sweep may instead stop, per
  * group of 32 users, at the first tile from which  ||E_u|| * max_{i >= tile} ||V_i||  can no longer

@@ -166,7 +166,7 @@ __host__ __device__ constexpr size_t pk_score_lds_bytes(int nstep, int kc) {
 template <int NSTEP, int KC>
 __global__ __launch_bounds__(256) void score_candidates_kernel(
     const float4 *__restrict__ Vp, const float4 *__restrict__ Ep, int64_t n_users, int n_items,
-    int n_tiles, int split_tiles, int chunk, int tiles_per_chunk,
+    int n_tiles, int split_tiles, int chunk_begin, int chunk_tiles,
     const int64_t *__restrict__ seen_ptr, const unsigned long long *__restrict__ seen_tiles,
     const int32_t *__restrict__ seen_ntiles,
     float *__restrict__ cand_score, int32_t *__restrict__ cand_idx,
@@ -198,14 +198,15 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
     // Item split: blockIdx.y = h owns the contiguous tile range [h*split_tiles, (h+1)*split_tiles) of
     // the catalogue for ALL chunks, with its own threshold, rings, top lists and parked state, so
     // that small user counts still fill the chip (the S partial top-KC lists are merged by the
-    // re-scoring kernel).  Launch `chunk` sweeps tiles_per_chunk tiles of every split.
+    // re-scoring kernel).  A launch sweeps tiles [chunk_begin, chunk_begin + chunk_tiles) of every split
+    // (relative to the split's first tile).
     const int split = blockIdx.y;
     const int64_t n_groups = (n_users + 31) / 32;
     const int t_lo = split * split_tiles;
     const int t_hi = (t_lo + split_tiles < n_tiles) ? t_lo + split_tiles : n_tiles;
-    const int tile_begin = t_lo + chunk * tiles_per_chunk;
-    const int tile_end = (tile_begin + tiles_per_chunk < t_hi) ? tile_begin + tiles_per_chunk : t_hi;
-    const bool first = (chunk == 0);
+    const int tile_begin = t_lo + chunk_begin;
+    const int tile_end = (tile_begin + chunk_tiles < t_hi) ? tile_begin + chunk_tiles : t_hi;
+    const bool first = (chunk_begin == 0);
     const bool last = (tile_end >= t_hi);
     if (!first && tile_begin >= t_hi) return;  // this split finished in an earlier launch
 
@@ -875,8 +876,12 @@ static int launch_candidates_n(hipStream_t st, int KC, int ablate, dim3 grid, co
                                const int64_t *seen_ptr, const unsigned long long *seen_tiles,
                                const int32_t *seen_ntiles, float *cs, int32_t *ci,
                                LaneState *st_lane, uint2 *st_ring, const float *user_bound, const float *tile_bound) {
-    const int n_chunks = (split_tiles + tiles_per_chunk - 1) / tiles_per_chunk;
-    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+    // Item chunks: tiles_per_chunk each while every group sweeps (the chunk's packed image stays in L2);
+    // with pruning, groups leave the sweep early, so the chunks DOUBLE from launch to launch — the catalogue
+    // is covered in O(log) launches and the few groups still sweeping late (low bandwidth demand) are not
+    // cut into hundreds of launches (rank 200: 100-tile chunks, 157 launches for 500K items otherwise).
+    int chunk_tiles = tiles_per_chunk;
+    for (int chunk_begin = 0; chunk_begin < split_tiles; chunk_begin += chunk_tiles, chunk_tiles = (user_bound ? 2 * chunk_tiles : chunk_tiles)) {
 #define PK_LAUNCH(KCV)                                                                                          \
     if (pk_score_lds_bytes(NSTEP, KCV) > 64 * 1024) {                                                           \
         static bool attr_set = false;   /* one flag per (NSTEP, KC) instance of this macro expansion */        \
@@ -892,7 +897,7 @@ static int launch_candidates_n(hipStream_t st, int KC, int ablate, dim3 grid, co
         }                                                                                                       \
     }                                                                                                           \
     hipLaunchKernelGGL((score_candidates_kernel<NSTEP, KCV>), grid, dim3(256), pk_score_lds_bytes(NSTEP, KCV), st, Vp, Ep, n_users, \
-                       n_items, n_tiles, split_tiles, chunk, tiles_per_chunk, seen_ptr, seen_tiles, seen_ntiles, cs, ci, st_lane, st_ring,  \
+                       n_items, n_tiles, split_tiles, chunk_begin, chunk_tiles, seen_ptr, seen_tiles, seen_ntiles, cs, ci, st_lane, st_ring,  \
                        user_bound, tile_bound, ablate)
 #ifdef PK_FAST_BUILD
         if (KC != 16) return PK_E_UNSUPPORTED;
@@ -935,6 +940,23 @@ extern "C" int32_t pk_score_splits(int64_t n_users, int32_t KC) {
     if (s > smax) s = smax;
     if (s < 1) s = 1;
     return (int32_t)s;
+}
+
+// number of kernel launches pk_score_candidates_f32 issues for these arguments (item chunks; bench.py's
+// per-pass traffic accounting multiplies the per-launch PMC averages by it)
+extern "C" int32_t pk_score_chunk_launches(int64_t n_items, int32_t K, int32_t splits, int32_t tiles_per_chunk,
+                                           int32_t pruned) {
+    const int kq = pk_pack_kq(K);
+    if (kq <= 0 || n_items < 1 || splits < 1) return 0;
+    const int n_tiles = (int)pk_ceil_div(n_items, 32);
+    const int split_tiles = (int)pk_ceil_div(n_tiles, splits);
+    if (tiles_per_chunk <= 0) {
+        tiles_per_chunk = PK_CHUNK_BYTES / (kq * 1024) / splits;
+        if (tiles_per_chunk < 8) tiles_per_chunk = 8;
+    }
+    int n = 0, ct = tiles_per_chunk;
+    for (int b = 0; b < split_tiles; b += ct, ct = (pruned ? 2 * ct : ct)) ++n;
+    return n;
 }
 
 extern "C" int pk_score_candidates_f32(void *stream, int64_t n_users, int64_t n_items, int32_t K,
