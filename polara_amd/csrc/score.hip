@@ -8,19 +8,20 @@
 // Orientation (the "swapped operand" trick): the MFMA computes  C[item][user] = V_tile * E_group^T
 // with v_mfma_f32_32x32x2_f32, so in the C layout (col = lane&31, row = (r&3)+8(r>>2)+4(lane>>5))
 // a LANE owns ONE user (lane&31) and 16 of the tile's 32 items.  All per-user state — running
-// threshold tau, position in the user's sorted seen list, candidate count — is therefore
+// threshold tau, position in the user's seen-tile stream, candidate count — is therefore
 // lane-local in registers; no cross-lane traffic on the hot path and no workgroup barrier at all:
 // each wave owns a group of 32 users and streams every item tile independently.
 //
-// Operands: both factor matrices are pre-packed (pack.hip) into MFMA fragment order
+// Operands: both factor matrices are pre-packed (pk_pack_frag_f32 below) into MFMA fragment order
 //   P[tile][q][lane][4]  with element e of lane (i = lane&31, h = lane>>5) = M[32*tile + i][8q + 2e + h]
 // so a wave's fragment load is one fully coalesced 1 KiB global_load_dwordx4.  E fragments stay in
 // registers for the whole kernel; V fragments stream from L2/MALL (V is n_items x K x 4 B, a few
 // tens of MB, shared by every wave of the chip).
 //
 // Selection: tau = score of the KC-th best candidate seen so far for that user (lazy).  A score
-// above tau is appended to a lane-private LDS ring (16 entries); when a ring is full the wave
-// bitonic-sorts {both rings of the user, current top-KC list} and refreshes the list and tau.
+// above tau is appended to a lane-private LDS ring (8 or 16 entries); when a ring is full the wave
+// sorts {both rings of the user, current top-KC list} with a key-only bitonic network (two users at a
+// time, one per half of the wave, for KC = 16) and refreshes the list and tau.
 // After warm-up almost every tile takes the fast path: 8 v_max3 + 1 compare + 1 ballot.
 //
 // Pruning (exact): |E_u . V_i| <= ||E_u|| ||V_i||.  The caller passes per-user upper bounds of
@@ -29,6 +30,9 @@
 // fastest when the items are ordered by descending norm or popularity).  tau never decreases, so
 // once  ||E_u|| * bound[tile] <= tau_u  holds for the 32 users of a wave no later item can enter any
 // of their lists: the wave merges its rings, writes its lists and leaves the sweep for good.
+// tau is the exact score of the KC-th list entry, but the lists are ordered by keys that drop the low
+// 5-7 bits of the score: a tau refreshed later can be smaller by up to 2^-16 relative than an earlier one,
+// and a dropped item can exceed it by as much — the re-scoring kernel's certification allows for 2^-15.
 #include "pk_common.h"
 #include <math.h>
 #include <stdlib.h>
