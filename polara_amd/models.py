@@ -199,6 +199,38 @@ class RecommenderModel:
             test_users = np.arange(test_shape[0])
         return (user_idx, item_idx, feedback), test_shape, test_users
 
+    @staticmethod
+    def _slice_test_data(test_data, start, stop):
+        """models.py:260-270: the triplet of users [start, stop), users re-based to 0."""
+        user_coo, item_coo, fdbk_coo = test_data
+        slicer = (user_coo >= start) & (user_coo < stop)
+        return user_coo[slicer] - start, item_coo[slicer], fdbk_coo[slicer]
+
+    def get_test_matrix(self, test_data=None, shape=None, user_slice=None, dtype=None, ignore_feedback=False):
+        """models.py:180-211 (host-side, API compatibility): the SciPy CSR of the test users (zero feedback
+        dropped from the matrix, kept in the returned triplet — it still counts as seen) + that triplet.
+        The device path builds its own test CSR (scoring.test_csr_from_triplet) and never chunks."""
+        from scipy.sparse import csr_matrix
+        if test_data is None:
+            test_data, shape, _ = self._get_test_data()
+        elif shape is None:
+            raise ValueError('Shape of test data must be provided')
+        num_users = shape[0]
+        coo_data = test_data
+        if user_slice:
+            start, stop = user_slice
+            stop = min(stop, shape[0])
+            num_users = stop - start
+            coo_data = self._slice_test_data(test_data, start, stop)
+        user_coo, item_coo, fdbk_coo = coo_data
+        valid = fdbk_coo != 0
+        if not valid.all():
+            user_coo, item_coo, fdbk_coo = user_coo[valid], item_coo[valid], fdbk_coo[valid]
+        dtype = dtype or fdbk_coo.dtype
+        if ignore_feedback:
+            fdbk_coo = np.ones_like(fdbk_coo, dtype=dtype)
+        return csr_matrix((fdbk_coo, (user_coo, item_coo)), shape=(num_users, shape[1]), dtype=dtype), coo_data
+
     def verify_data_integrity(self):
         """models.py:581-604 reduced to the checks that do not need pandas."""
         itemid, feedback = self.data.fields.itemid, self.data.fields.feedback

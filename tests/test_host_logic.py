@@ -177,6 +177,22 @@ def test_solver_converges_on_planted_and_degenerate_inputs():
     assert np.isclose(s2.numpy()[0], np.linalg.svd(B.toarray(), compute_uv=False)[0]) and s2.numpy()[1] < 1e-5 * s2.numpy()[0]
 
 
+def test_get_test_matrix_matches_oracle():
+    """models.py:180-211 surface: same matrix and slice triplet as the oracle's restatement."""
+    g = load_golden('svd_known')
+    m = SVDModel(GoldenData(g), ops=NumpyOps())
+    td, shp = (g['test_user'], g['test_item'], g['test_fdbk']), tuple(int(x) for x in g['test_shape'])
+    for sl in (None, (3, 40), (0, shp[0] + 5)):
+        got, got_td = m.get_test_matrix(td, shp, sl)
+        want, want_td = orc.get_test_matrix(td, shp, sl)
+        assert got.shape == want.shape and (got != want).nnz == 0
+        assert all(np.array_equal(a, b) for a, b in zip(got_td, want_td))
+    auto, _ = m.get_test_matrix()
+    assert auto.shape == shp
+    with pytest.raises(ValueError):
+        m.get_test_matrix(td)
+
+
 def test_build_with_linear_operator_matches_svds():
     """build(operator=...) (models.py:835-844): a SciPy LinearOperator replaces the training matrix; checked
     against scipy's own svds of the same operator, including the recommendations that follow from it."""
