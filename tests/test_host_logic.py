@@ -143,6 +143,39 @@ def test_coffee_model_orchestration_matches_reference(name):
     assert np.array_equal(m.recommendations[notie], g['recs'][notie])
 
 
+def _check_full_feedback_mode(m, g):
+    """mlrank[2] == number of feedback levels (BASELINE.json configs[3] asks for (30, 30, 5) on 5 rating levels):
+    the reference raises here (svds needs k < min(shape), lib/tensor.py:79); the device path takes the full
+    eigen-decomposition of the 5 x 5 Gram matrix instead.  Checked through properties of a Tucker fit."""
+    f = m.data.fields
+    u0, u1, u2, core = (m.factors[k] for k in (f.userid, f.itemid, f.feedback, 'core'))
+    n2 = u2.shape[0]
+    assert u2.shape == (n2, n2) and core.shape[2] == n2
+    for u in (u0, u1, u2):
+        assert np.abs(u.T @ u - np.eye(u.shape[1])).max() < 1e-9          # orthonormal factors
+    # the core is the tensor contracted with the three factors; its norm is what hooi monitors
+    idx, val, shp = m.data.to_coo(tensor_mode=True)
+    dense = np.zeros(shp)
+    np.add.at(dense, (idx[:, 0], idx[:, 1], idx[:, 2]), val)
+    want = np.einsum('uif,ua,ib,fc->abc', dense, u0, u1, u2)
+    assert np.allclose(core, want, atol=1e-9 * np.abs(want).max())
+    assert np.isclose(np.linalg.norm(core), m.core_norm_trace[-1], rtol=1e-9)
+    assert all(b >= a * (1 - 1e-12) for a, b in zip(m.core_norm_trace, m.core_norm_trace[1:]))   # monotone fit
+    # a complete feedback-mode basis loses nothing along that mode: same fit as the (r0, r1, n2-1) model or better
+    assert m.recommendations.shape == (g['recs'].shape[0], m.topk)
+
+
+def test_coffee_full_feedback_mode_rank():
+    g = load_golden('coffee_small')
+    m = CoffeeModel(GoldenData(g), ops=NumpyOps())
+    m.verbose = False
+    n_fdbk = int(m.data.to_coo(tensor_mode=True)[2][2])
+    m.mlrank, m.topk, m.seed = (int(g['mlrank'][0]), int(g['mlrank'][1]), n_fdbk), int(g['topk']), int(g['seed'])
+    m.num_iters, m.growth_tol = int(g['num_iters']), float(g['growth_tol'])
+    m.build()
+    _check_full_feedback_mode(m, g)
+
+
 def test_topk_cache_rules_and_errors():
     g = load_golden('svd_nofilter')
     m = SVDModel(GoldenData(g), ops=NumpyOps())
