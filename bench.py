@@ -57,8 +57,8 @@ def parse():
 
 
 def spmm_alg_bytes(meta):
-    n_rows, n_cols, nnz, nc, vbytes = meta
-    return nnz * (4 + vbytes) + 8 * (n_rows + 1) + 8 * nc * (n_cols + n_rows)
+    n_rows, n_cols, nnz, nc, vbytes, xbytes = meta     # xbytes: element size of the dense input block
+    return nnz * (4 + vbytes) + 8 * (n_rows + 1) + nc * (xbytes * n_cols + 8 * n_rows)
 
 
 def pmc_traffic():
@@ -316,7 +316,7 @@ def main():
                            'traffic_note': '2*FETCH_SIZE + WRITE_SIZE per launch (profiles/r01_bench_pmc_*.txt): ~20x the '
                                            'algorithmic bytes - the 400-512 B row gathers of the dense block are not '
                                            'read once but once per nnz, and half of them miss L2/MALL',
-                           'gather_GBps': (float(sum(m[2] * m[3] * 8.0 for _, _, m in spmm_ev) / (sum(spmm_ms) * 1e-3) / 1e9)
+                           'gather_GBps': (float(sum(m[2] * m[3] * float(m[5]) for _, _, m in spmm_ev) / (sum(spmm_ms) * 1e-3) / 1e9)
                                            if spmm_ms else None),
                            'gather_note': 'nnz*nc*8 bytes of dense-row gathers per launch / time: the traffic that actually '
                                           'bounds this kernel (profiles/r01_spmm_probe.json)',

@@ -62,6 +62,18 @@ int pk_spmm_csr_f64(void *stream,
                     const int32_t *indices_dev, const void *vals_dev, int val_kind,
                     const double *X_dev, int64_t ldx, int32_t nc,
                     double *out_dev, int64_t ldo, double *partial_dev /* [n_slots x nc] or NULL */);
+/* Same product with the dense block X given in fp32 (x_kind = PK_VAL_F32; needs nc % 4 == 0, ldx % 4 == 0,
+ * 16-byte aligned X) or fp64 (PK_VAL_F64 = pk_spmm_csr_f64).  Accumulation and output are fp64.  Used for the
+ * approximate fold-in of the scoring pass: E' = A_test fl32(V) moves half the gather bytes of models.py:860's
+ * left factor; the re-scoring kernel certifies the result against the rounding of V (pk_rescore_topk_f64). */
+int pk_spmm_csr_x(void *stream,
+                  int64_t n_tasks, const int32_t *task_row_dev, const int64_t *task_begin_dev,
+                  const int64_t *task_end_dev, const int32_t *task_slot_dev,
+                  int64_t n_long, const int32_t *long_row_dev, const int32_t *long_slot_begin_dev,
+                  const int32_t *long_slot_end_dev,
+                  const int32_t *indices_dev, const void *vals_dev, int val_kind,
+                  const void *X_dev, int x_kind, int64_t ldx, int32_t nc,
+                  double *out_dev, int64_t ldo, double *partial_dev);
 
 /* ------------------------------------------------------------------------------------------
  * K2.  Dense tall-skinny fp64 pieces of the block eigensolver / HOOI.
@@ -178,6 +190,33 @@ int pk_rescore_topk_f64(void *stream, int64_t n_users, int64_t n_items, int32_t 
                         const float *cand_score_dev, const int32_t *cand_idx_dev, int32_t topk,
                         double v_row_norm_max,
                         int64_t *out_idx_dev, double *out_score_dev /* or NULL */, int32_t *flags_dev);
+/* General form: the r-th row processed is user rows_dev[r] (NULL: user r, n_rows = n_users) — used to re-do a
+ * list of users; e_err_dev (or NULL): per-user bound w_u such that the given E rows satisfy
+ * ||E'_u - E_u|| <= 2^-24 w_u (the approximate fold-in against fl32(V): w_u = sum_j |a_uj| ||V_j||).  Scores are
+ * then within delta_u = 2^-24 w_u max||V_i|| of the exact ones, and flags bit2 (value 4) marks the users whose
+ * order is NOT certified at that accuracy (two consecutive scores of the top-k, or the k-th and the best
+ * excluded item, closer than 2 delta_u): the host recomputes their E rows exactly and calls again with
+ * e_exact = 1 (the same e_err_dev: the non-candidates are still only known through the approximate sweep). */
+int pk_rescore_topk_rows_f64(void *stream, int64_t n_rows, const int32_t *rows_dev,
+                             const int32_t *n_rows_dev /* or NULL; else the list length is min(*n_rows_dev, n_rows) */,
+                             int64_t n_users, int64_t n_items,
+                             int32_t K, const double *V_dev, int64_t ldv, const double *E_dev, int64_t lde,
+                             const double *e_err_dev, int64_t e_err_ld /* e_err of user u at e_err_dev[u * e_err_ld] */,
+                             int32_t e_exact /* 1: these E rows are exact, the candidates came
+                             from a sweep over approximate ones (second call) */,
+                             const int64_t *seen_ptr_dev, int32_t KC, int32_t splits,
+                             const float *cand_score_dev, const int32_t *cand_idx_dev, int32_t topk,
+                             double v_row_norm_max,
+                             int64_t *out_idx_dev, double *out_score_dev /* or NULL */, int32_t *flags_dev);
+/* The re-do of flagged users without a host round trip: pk_flag_compact lists the users with (flags & mask) != 0
+ * (list capacity n, *count_dev = list length), pk_fold_rows_f64 recomputes the listed rows of E = A_test V in fp64
+ * straight from the CSR (row = row_offset + list[r]), pk_rescore_topk_rows_f64 re-scores them (rows_dev = the list,
+ * n_rows_dev = count_dev).  All three take the list length from device memory. */
+int pk_flag_compact(void *stream, int64_t n, const int32_t *flags_dev, int32_t mask, int32_t *list_dev,
+                    int32_t *count_dev);
+int pk_fold_rows_f64(void *stream, int64_t cap, const int32_t *list_dev, const int32_t *count_dev, int64_t row_offset,
+                     const int64_t *indptr_dev, const int32_t *indices_dev, const void *vals_dev, int val_kind,
+                     const double *V_dev, int64_t ldv, int32_t K, double *E_dev, int64_t lde);
 /* Brute-force exact path for a list of users: all n_items fp64 scores, two-class key
  * (unseen above seen, then score; the reference's downvote semantics, models.py:510-519), top-k.
  * Outputs are compact [n_rows x topk] (row r belongs to user rows_dev[r]).

@@ -20,6 +20,8 @@ PROTOTYPES = {
     'pk_device_info': (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(_i64)]),
     'pk_spmm_csr_f64': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, C.c_int,
                                   _vp, _i64, _i32, _vp, _i64, _vp]),
+    'pk_spmm_csr_x': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, C.c_int,
+                                _vp, C.c_int, _i64, _i32, _vp, _i64, _vp]),
     'pk_gram_work_bytes': (_i64, [_i64, _i32, _i32]),
     'pk_gram_f64': (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     'pk_tsmm_f64': (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64]),
@@ -46,6 +48,10 @@ PROTOTYPES = {
     'pk_tile_norm_bound_f32': (C.c_int, [_vp, _i64, _i32, _vp, _i64, _vp, _vp]),
     'pk_rescore_topk_f64': (C.c_int, [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _vp, _vp,
                                       _i32, _f64, _vp, _vp, _vp]),
+    'pk_flag_compact': (C.c_int, [_vp, _i64, _vp, _i32, _vp, _vp]),
+    'pk_fold_rows_f64': (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, C.c_int, _vp, _i64, _i32, _vp, _i64]),
+    'pk_rescore_topk_rows_f64': (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _i32, _i32,
+                                           _vp, _vp, _i32, _f64, _vp, _vp, _vp]),
     'pk_exact_work_bytes': (_i64, [_i32, _i64]),
     'pk_score_exact_rows_f64': (C.c_int, [_vp, _i32, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _i32,
                                           _vp, _vp, _vp]),

@@ -134,17 +134,24 @@ __device__ __forceinline__ double pk_dot_chains(const double *__restrict__ vr, c
 // plus a 64-lane sort: 2.7 ms per 1M users; LPC = 1: 1.04 ms.)
 template <int SEG, int LPC>
 __global__ __launch_bounds__(256) void rescore_topk_kernel(
-    int64_t n_users, int64_t n_items, int K, const double *__restrict__ V, int64_t ldv,
-    const double *__restrict__ E, int64_t lde, const int64_t *__restrict__ seen_ptr, int KC, int splits,
+    int64_t n_rows, const int32_t *__restrict__ rows, const int32_t *__restrict__ n_rows_dev, int64_t n_users,
+    int64_t n_items, int K, const double *__restrict__ V, int64_t ldv,
+    const double *__restrict__ E, int64_t lde, const double *__restrict__ e_err, int64_t e_err_ld, int e_exact,
+    const int64_t *__restrict__ seen_ptr, int KC, int splits,
     const float *__restrict__ cand_score, const int32_t *__restrict__ cand_idx, int topk, double vmax,
     int64_t *__restrict__ out_idx, double *__restrict__ out_score, int32_t *__restrict__ flags) {
     constexpr int UPW = 64 / (SEG * LPC);
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int ul = lane / (SEG * LPC), t = (lane / LPC) % SEG, q = lane % LPC;
-    const int64_t user = ((int64_t)blockIdx.x * 4 + wave) * UPW + ul;
-    const bool live = user < n_users;
-    const int64_t urow = live ? user : 0;
+    // the r-th row to process is user rows[r] (a list of users to re-do) or user r (everybody)
+    const int64_t r = ((int64_t)blockIdx.x * 4 + wave) * UPW + ul;
+    // the list length may only be known on the device (pk_flag_compact): the grid then covers its capacity
+    const int64_t n_eff = n_rows_dev ? ((int64_t)*n_rows_dev < n_rows ? (int64_t)*n_rows_dev : n_rows) : n_rows;
+    if (((int64_t)blockIdx.x * 4 + wave) * UPW >= n_eff) return;   // whole wave beyond the list
+    const bool live = r < n_eff;
+    const int64_t user = live ? (rows ? (int64_t)rows[r] : r) : 0;
+    const int64_t urow = user;
 
     // candidates: the union of the `splits` per-item-range top-KC lists of this user (<= SEG entries);
     // list h of user u lives at ((h * n_pad + u) * KC)
@@ -173,6 +180,20 @@ __global__ __launch_bounds__(256) void rescore_topk_kernel(
     int flag = 0;
     const int64_t n_seen = seen_ptr ? (seen_ptr[urow + 1] - seen_ptr[urow]) : 0;
     const double s_k = __shfl(my_s, (ul * SEG + topk - 1) * LPC, 64);
+    // E given only approximately (fold-in against the fp32 image of V, scoring.py): ||E' - E|| <= 2^-24 e_err[u],
+    // so every score here is within delta of the exact one and the ORDER is the exact order wherever
+    // consecutive scores are more than 2 delta apart (the k-th against the (k+1)-th too)
+    // e_exact: the E rows given now ARE exact, but the candidates were selected by a sweep over the approximate
+    // ones — only the bound on the non-candidates keeps a delta, there is nothing approximate left to order
+    const double delta = e_err ? e_err[urow * e_err_ld] * 5.9604644775390625e-08 * (1.0 + 1e-6) * vmax : 0.0;
+    if (delta > 0.0 && !e_exact) {
+        const int nxt_lane = lane + LPC;
+        const double s_next = (t + 1 < SEG) ? __shfl(my_s, nxt_lane & 63, 64) : -INFINITY;
+        const bool close = (t < topk) && !(my_s - s_next > 2.0 * delta);
+        const unsigned long long cb = __ballot(close);
+        const unsigned long long seg_mask = (SEG * LPC == 64) ? ~0ull : (((1ull << (SEG * LPC)) - 1ull) << (ul * SEG * LPC));
+        if (cb & seg_mask) flag |= 4;
+    }
     if (n_items - n_seen < topk) {
         flag |= 2;  // seen items must re-enter the list: exact path
     } else if (tau32 > -INFINITY) {
@@ -181,7 +202,9 @@ __global__ __launch_bounds__(256) void rescore_topk_kernel(
         // the candidate sweep orders scores that agree to 2^-16 relative arbitrarily (key-only flush sorts,
         // score.hip): a non-candidate may exceed the KC-th candidate by that much
         const double tau_cert = tau32 + fabs(tau32) * 3.0517578125e-05;
-        if (bound > 0.0 && !(s_k - tau_cert > bound)) flag |= 1;
+        const double slack = e_exact ? delta : 2.0 * delta;
+        if (bound > 0.0 && !(s_k - tau_cert > bound + slack))
+            flag |= (!e_exact && delta > 0.0 && s_k - tau_cert > bound + delta) ? 4 : 1;
     }
     if (live && q == 0 && t < topk) {
         out_idx[user * topk + t] = (my_i == PK_IDX_NONE) ? -1 : (int64_t)my_i;
@@ -190,22 +213,27 @@ __global__ __launch_bounds__(256) void rescore_topk_kernel(
     if (live && q == 0 && t == 0) flags[user] = flag;
 }
 
-extern "C" int pk_rescore_topk_f64(void *stream, int64_t n_users, int64_t n_items, int32_t K, const double *V_dev,
-                                   int64_t ldv, const double *E_dev, int64_t lde, const int64_t *seen_ptr_dev,
-                                   int32_t KC, int32_t splits, const float *cand_score_dev,
-                                   const int32_t *cand_idx_dev,
-                                   int32_t topk, double v_row_norm_max, int64_t *out_idx_dev,
-                                   double *out_score_dev, int32_t *flags_dev) {
+extern "C" int pk_rescore_topk_rows_f64(void *stream, int64_t n_rows, const int32_t *rows_dev,
+                                        const int32_t *n_rows_dev, int64_t n_users,
+                                        int64_t n_items, int32_t K, const double *V_dev, int64_t ldv,
+                                        const double *E_dev, int64_t lde, const double *e_err_dev,
+                                        int64_t e_err_ld, int32_t e_exact,
+                                        const int64_t *seen_ptr_dev, int32_t KC, int32_t splits,
+                                        const float *cand_score_dev, const int32_t *cand_idx_dev, int32_t topk,
+                                        double v_row_norm_max, int64_t *out_idx_dev, double *out_score_dev,
+                                        int32_t *flags_dev) {
     PK_REQUIRE(n_users >= 1 && K >= 1 && K <= 256 && ldv >= K && lde >= K, "pk_rescore_topk_f64: bad sizes");
+    PK_REQUIRE(n_rows >= 0 && n_rows <= n_users, "pk_rescore_topk_f64: bad row count");
     PK_REQUIRE(KC >= 1 && splits >= 1 && KC * splits <= 64 && topk >= 1 && topk <= KC,
                "pk_rescore_topk_f64: need topk <= KC and KC*splits <= 64");
+    if (n_rows == 0) return PK_OK;
     const int seg = (KC * splits <= 16) ? 16 : (KC * splits <= 32) ? 32 : 64;
     const char *lpc_env = getenv("PK_RESCORE_LPC");      // kernel-tuning knob
     const int lpc_req = lpc_env ? atoi(lpc_env) : 0;
 #define PK_RESCORE(SEGV, LPCV)                                                                                    \
-    hipLaunchKernelGGL((rescore_topk_kernel<SEGV, LPCV>), dim3((unsigned)pk_ceil_div(n_users, 4 * (64 / (SEGV * LPCV)))), \
-                       dim3(256), 0, pk_stream(stream), n_users, n_items, K, V_dev, ldv, E_dev, lde,            \
-                       seen_ptr_dev, KC, splits, cand_score_dev, cand_idx_dev, topk, v_row_norm_max,            \
+    hipLaunchKernelGGL((rescore_topk_kernel<SEGV, LPCV>), dim3((unsigned)pk_ceil_div(n_rows, 4 * (64 / (SEGV * LPCV)))), \
+                       dim3(256), 0, pk_stream(stream), n_rows, rows_dev, n_rows_dev, n_users, n_items, K, V_dev, ldv, E_dev, lde, \
+                       e_err_dev, e_err_ld, e_exact, seen_ptr_dev, KC, splits, cand_score_dev, cand_idx_dev, topk, v_row_norm_max,   \
                        out_idx_dev, out_score_dev, flags_dev)
     if (seg == 16) {
         if (lpc_req == 1) PK_RESCORE(16, 1);
@@ -219,6 +247,144 @@ extern "C" int pk_rescore_topk_f64(void *stream, int64_t n_users, int64_t n_item
     }
 #undef PK_RESCORE
     PK_CHECK_LAUNCH("rescore_topk_kernel");
+    return PK_OK;
+}
+
+extern "C" int pk_rescore_topk_f64(void *stream, int64_t n_users, int64_t n_items, int32_t K, const double *V_dev,
+                                   int64_t ldv, const double *E_dev, int64_t lde, const int64_t *seen_ptr_dev,
+                                   int32_t KC, int32_t splits, const float *cand_score_dev,
+                                   const int32_t *cand_idx_dev,
+                                   int32_t topk, double v_row_norm_max, int64_t *out_idx_dev,
+                                   double *out_score_dev, int32_t *flags_dev) {
+    return pk_rescore_topk_rows_f64(stream, n_users, nullptr, nullptr, n_users, n_items, K, V_dev, ldv, E_dev, lde,
+                                    nullptr, 0, 0, seen_ptr_dev, KC, splits, cand_score_dev, cand_idx_dev, topk, v_row_norm_max,
+                                    out_idx_dev, out_score_dev, flags_dev);
+}
+
+// ---- re-doing flagged users without the host -------------------------------------------------------
+// list[0 .. count) = users u in [0, n) with (flags[u] & mask) != 0, in no particular order (count is zeroed by
+// the caller-side memset in pk_flag_compact).  cap = n: the list cannot overflow.
+__global__ __launch_bounds__(256) void flag_compact_kernel(int64_t n, const int32_t *__restrict__ flags, int mask,
+                                                           int32_t *__restrict__ list, int32_t *__restrict__ count) {
+    const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool hit = u < n && (flags[u] & mask) != 0;
+    // one atomic per wave: lanes take consecutive slots behind the wave's base
+    const unsigned long long b = __ballot(hit);
+    if (b == 0ull) return;
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == __builtin_ctzll(b)) base = atomicAdd(count, __popcll(b));
+    base = __shfl(base, __builtin_ctzll(b), 64);
+    if (hit) list[base + __popcll(b & ((1ull << lane) - 1ull))] = (int32_t)u;
+}
+
+extern "C" int pk_flag_compact(void *stream, int64_t n, const int32_t *flags_dev, int32_t mask, int32_t *list_dev,
+                               int32_t *count_dev) {
+    PK_REQUIRE(n >= 1 && flags_dev && list_dev && count_dev, "pk_flag_compact: bad arguments");
+    hipStream_t st = pk_stream(stream);
+    if (hipMemsetAsync(count_dev, 0, sizeof(int32_t), st) != hipSuccess) {
+        pk_set_error("pk_flag_compact: memset failed");
+        return PK_E_LAUNCH;
+    }
+    hipLaunchKernelGGL(flag_compact_kernel, dim3((unsigned)pk_ceil_div(n, 256)), dim3(256), 0, st, n, flags_dev, mask,
+                       list_dev, count_dev);
+    PK_CHECK_LAUNCH("flag_compact_kernel");
+    return PK_OK;
+}
+
+// E[row_offset + list[r], 0:K] = sum_p vals[p] * V[indices[p], 0:K] in fp64 for the listed rows of a CSR.
+// A fixed grid of workgroups strides over the list (its length is only known on the device); the four waves
+// of a workgroup take every fourth 64-pair chunk of the row, eight independent row gathers in flight each
+// (a flagged row can have thousands of entries), and their partial sums are added in wave order.
+#define PK_FOLD_BLOCKS 2048
+template <typename VT, int CPL>
+__global__ __launch_bounds__(256) void fold_rows_kernel(int64_t cap, const int32_t *__restrict__ list,
+                                                        const int32_t *__restrict__ count, int64_t row_offset,
+                                                        const int64_t *__restrict__ indptr,
+                                                        const int32_t *__restrict__ indices,
+                                                        const VT *__restrict__ vals, const double *__restrict__ V,
+                                                        int64_t ldv, int K, double *__restrict__ E, int64_t lde) {
+    __shared__ double part[4][64 * CPL];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t n = (*count < cap) ? *count : cap;
+    int col[CPL];
+#pragma unroll
+    for (int g = 0; g < CPL; ++g) {
+        const int c = lane + 64 * g;
+        col[g] = c < K ? c : K - 1;     // clamp: out-of-range lanes read a valid column, discarded at the end
+    }
+    for (int64_t r = blockIdx.x; r < n; r += gridDim.x) {
+        const int64_t row = row_offset + list[r];
+        const int64_t p0 = indptr[row], p1 = indptr[row + 1];
+        double acc[CPL];
+#pragma unroll
+        for (int g = 0; g < CPL; ++g) acc[g] = 0.0;
+        for (int64_t base = p0 + 64 * wave; base < p1; base += 256) {
+            int j = 0;
+            double a = 0.0;             // padded lanes hold (0, 0.0): they add 0 * V[0, :]
+            if (base + lane < p1) {
+                j = indices[base + lane];
+                a = (double)vals[base + lane];
+            }
+            const int cnt = (int)((p1 - base < 64) ? (p1 - base) : 64);
+            for (int t0 = 0; t0 < cnt; t0 += 8) {
+                double x[8][CPL];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int jt = __builtin_amdgcn_readlane(j, (t0 + u) & 63);
+                    const double *vr = V + (int64_t)jt * ldv;
+#pragma unroll
+                    for (int g = 0; g < CPL; ++g) x[u][g] = vr[col[g]];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int lo = __builtin_amdgcn_readlane(__double2loint(a), (t0 + u) & 63);
+                    const int hi = __builtin_amdgcn_readlane(__double2hiint(a), (t0 + u) & 63);
+                    const double at = __hiloint2double(hi, lo);
+#pragma unroll
+                    for (int g = 0; g < CPL; ++g) acc[g] = fma(at, x[u][g], acc[g]);
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < CPL; ++g) part[wave][lane + 64 * g] = acc[g];
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int g = 0; g < CPL; ++g) {
+                const int c = lane + 64 * g;
+                if (c < K) E[row * lde + c] = ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int pk_fold_rows_f64(void *stream, int64_t cap, const int32_t *list_dev, const int32_t *count_dev,
+                                int64_t row_offset, const int64_t *indptr_dev, const int32_t *indices_dev,
+                                const void *vals_dev, int val_kind, const double *V_dev, int64_t ldv, int32_t K,
+                                double *E_dev, int64_t lde) {
+    PK_REQUIRE(cap >= 1 && K >= 1 && K <= 256 && ldv >= K && lde >= K, "pk_fold_rows_f64: bad sizes");
+    PK_REQUIRE(list_dev && count_dev && indptr_dev && indices_dev && vals_dev, "pk_fold_rows_f64: bad pointers");
+    dim3 grid((unsigned)(cap < PK_FOLD_BLOCKS ? cap : PK_FOLD_BLOCKS)), block(256);
+    PK_REQUIRE(val_kind == PK_VAL_F32 || val_kind == PK_VAL_F64, "pk_fold_rows_f64: bad val_kind %d", val_kind);
+    const int cpl = (K + 63) / 64;
+#define PK_FOLD(VT, C)                                                                                           \
+    hipLaunchKernelGGL((fold_rows_kernel<VT, C>), grid, block, 0, pk_stream(stream), cap, list_dev, count_dev,   \
+                       row_offset, indptr_dev, indices_dev, static_cast<const VT *>(vals_dev), V_dev, ldv, K,    \
+                       E_dev, lde)
+#define PK_FOLD_C(VT)                                                                                            \
+    switch (cpl) {                                                                                               \
+        case 1: PK_FOLD(VT, 1); break;                                                                           \
+        case 2: PK_FOLD(VT, 2); break;                                                                           \
+        case 3: PK_FOLD(VT, 3); break;                                                                           \
+        default: PK_FOLD(VT, 4); break;                                                                          \
+    }
+    if (val_kind == PK_VAL_F32) { PK_FOLD_C(float) } else { PK_FOLD_C(double) }
+#undef PK_FOLD_C
+#undef PK_FOLD
+    PK_CHECK_LAUNCH("fold_rows_kernel");
     return PK_OK;
 }
 

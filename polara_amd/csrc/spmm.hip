@@ -124,12 +124,16 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(
 // broadcast loads instead of ds_bpermute was 35 % SLOWER.  The gathers themselves bound this kernel:
 // nnz * nc * 8 bytes of 400-512 B row pieces through L2 -> L1 at ~16 TB/s (A.X, X on chip) or from HBM
 // at ~7.3 TB/s (A^T.Y) — neither instruction issue nor loads in flight.
-template <typename VT, int GROUPS>
+// XT = float: the dense block is read in fp32 (the fp32 image of the item factors for the approximate fold-in
+// of the scoring pass, scoring.py); a lane's four columns are then consecutive (4l .. 4l+3) and arrive with
+// ONE 16-byte load.  Accumulation and output stay fp64.
+template <typename VT, int GROUPS, typename XT>
 __global__ __launch_bounds__(256) void spmm_csr_groups_kernel(
     int64_t n_tasks, const int32_t *__restrict__ task_row, const int64_t *__restrict__ task_begin,
     const int64_t *__restrict__ task_end, const int32_t *__restrict__ task_slot,
-    const int32_t *__restrict__ indices, const VT *__restrict__ vals, const double *__restrict__ X,
+    const int32_t *__restrict__ indices, const VT *__restrict__ vals, const XT *__restrict__ X,
     int64_t ldx, int nc, double *__restrict__ out, int64_t ldo, double *__restrict__ partial) {
+    constexpr bool XF = sizeof(XT) == 4;
     constexpr int LG = 64 / GROUPS;
     constexpr int U = 4;   // wave steps per register set (two sets in flight)
     const int lane = threadIdx.x & 63;
@@ -139,10 +143,12 @@ __global__ __launch_bounds__(256) void spmm_csr_groups_kernel(
     const int64_t p0 = task_begin[task];
     const int n = (int)(task_end[task] - p0);
     const int g = lane / LG, l = lane % LG;
-    const int c0 = 2 * l, c1 = 2 * LG + 2 * l;
-    const bool ok0 = c0 < nc, ok1 = c1 < nc;          // nc is even: a column pair is in or out as a whole
-    const double *x0 = X + (ok0 ? c0 : 0);
-    const double *x1 = X + (ok1 ? c1 : 0);
+    // columns (c0, c0+1) and (c1, c1+1) of this lane; nc is even (a multiple of 4 for fp32 X): a pair is in or
+    // out as a whole
+    const int c0 = XF ? 4 * l : 2 * l, c1 = XF ? 4 * l + 2 : 2 * LG + 2 * l;
+    const bool ok0 = c0 < nc, ok1 = c1 < nc;
+    const XT *x0 = X + (ok0 ? c0 : 0);
+    const XT *x1 = X + (ok1 ? c1 : 0);
     const int32_t *ip = indices + p0;
     const VT *vp = vals + p0;
 
@@ -166,8 +172,14 @@ __global__ __launch_bounds__(256) void spmm_csr_groups_kernel(
         for (int u = 0; u < U; ++u) {
             const int jj = __shfl(jch, (st0 + u) * GROUPS + g, 64);
             const int64_t off = (int64_t)jj * ldx;
-            xa[u] = *reinterpret_cast<const double2 *>(x0 + off);
-            xb[u] = *reinterpret_cast<const double2 *>(x1 + off);
+            if constexpr (XF) {
+                const float4 f = *reinterpret_cast<const float4 *>(x0 + off);
+                xa[u] = make_double2((double)f.x, (double)f.y);
+                xb[u] = make_double2((double)f.z, (double)f.w);
+            } else {
+                xa[u] = *reinterpret_cast<const double2 *>(x0 + off);
+                xb[u] = *reinterpret_cast<const double2 *>(x1 + off);
+            }
         }
     };
     auto consume = [&](VT ach, int st0, const double2(&xa)[U], const double2(&xb)[U]) {
@@ -256,14 +268,31 @@ __global__ __launch_bounds__(256) void spmm_fixup_kernel(
 template <typename VT>
 static int launch_spmm(hipStream_t st, int64_t n_tasks, const int32_t *task_row, const int64_t *task_begin,
                        const int64_t *task_end, const int32_t *task_slot, const int32_t *indices,
-                       const void *vals, const double *X, int64_t ldx, int nc, double *out, int64_t ldo,
+                       const void *vals, const void *Xv, int x_kind, int64_t ldx, int nc, double *out, int64_t ldo,
                        double *partial) {
     dim3 grid((unsigned)pk_ceil_div(n_tasks, 4)), block(256);
     const VT *v = static_cast<const VT *>(vals);
+    if (x_kind == PK_VAL_F32) {
+        // fp32 dense block: groups mapping only (one 16-byte load = 4 columns)
+        const float *X = static_cast<const float *>(Xv);
+        if (!((nc % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)X) % 16 == 0))) {
+            pk_set_error("pk_spmm_csr_x: an fp32 dense block needs nc %% 4 == 0, ldx %% 4 == 0 and 16-byte alignment");
+            return PK_E_UNSUPPORTED;
+        }
+#define PK_SPMM_GROUPS_F(G)                                                                                     \
+    hipLaunchKernelGGL((spmm_csr_groups_kernel<VT, G, float>), grid, block, 0, st, n_tasks, task_row, task_begin, \
+                       task_end, task_slot, indices, v, X, ldx, nc, out, ldo, partial)
+        if (nc <= 64) PK_SPMM_GROUPS_F(4);
+        else if (nc <= 128) PK_SPMM_GROUPS_F(2);
+        else PK_SPMM_GROUPS_F(1);
+#undef PK_SPMM_GROUPS_F
+        return PK_OK;
+    }
+    const double *X = static_cast<const double *>(Xv);
     const bool paired = (nc % 2 == 0) && (ldx % 2 == 0) && (((uintptr_t)X) % 16 == 0) && !getenv("PK_SPMM_LANE_COLUMNS");
     if (paired) {
 #define PK_SPMM_GROUPS(G)                                                                                  \
-    hipLaunchKernelGGL((spmm_csr_groups_kernel<VT, G>), grid, block, 0, st, n_tasks, task_row, task_begin,  \
+    hipLaunchKernelGGL((spmm_csr_groups_kernel<VT, G, double>), grid, block, 0, st, n_tasks, task_row, task_begin,  \
                        task_end, task_slot, indices, v, X, ldx, nc, out, ldo, partial)
         if (nc <= 64) PK_SPMM_GROUPS(4);
         else if (nc <= 128) PK_SPMM_GROUPS(2);
@@ -290,28 +319,29 @@ static int launch_spmm(hipStream_t st, int64_t n_tasks, const int32_t *task_row,
     return PK_OK;
 }
 
-extern "C" int pk_spmm_csr_f64(void *stream, int64_t n_tasks, const int32_t *task_row_dev,
-                               const int64_t *task_begin_dev, const int64_t *task_end_dev,
-                               const int32_t *task_slot_dev, int64_t n_long, const int32_t *long_row_dev,
-                               const int32_t *long_slot_begin_dev, const int32_t *long_slot_end_dev,
-                               const int32_t *indices_dev, const void *vals_dev, int val_kind,
-                               const double *X_dev, int64_t ldx, int32_t nc, double *out_dev, int64_t ldo,
-                               double *partial_dev) {
-    PK_REQUIRE(n_tasks >= 0 && nc >= 1 && nc <= 256, "pk_spmm_csr_f64: bad sizes n_tasks=%lld nc=%d",
+extern "C" int pk_spmm_csr_x(void *stream, int64_t n_tasks, const int32_t *task_row_dev,
+                             const int64_t *task_begin_dev, const int64_t *task_end_dev,
+                             const int32_t *task_slot_dev, int64_t n_long, const int32_t *long_row_dev,
+                             const int32_t *long_slot_begin_dev, const int32_t *long_slot_end_dev,
+                             const int32_t *indices_dev, const void *vals_dev, int val_kind,
+                             const void *X_dev, int x_kind, int64_t ldx, int32_t nc, double *out_dev, int64_t ldo,
+                             double *partial_dev) {
+    PK_REQUIRE(n_tasks >= 0 && nc >= 1 && nc <= 256, "pk_spmm_csr: bad sizes n_tasks=%lld nc=%d",
                (long long)n_tasks, nc);
-    PK_REQUIRE(ldo >= nc, "pk_spmm_csr_f64: ldo < nc");
-    PK_REQUIRE(n_long == 0 || partial_dev != nullptr, "pk_spmm_csr_f64: partial buffer required");
+    PK_REQUIRE(ldo >= nc && ldx >= nc, "pk_spmm_csr: ldo/ldx < nc");
+    PK_REQUIRE(x_kind == PK_VAL_F32 || x_kind == PK_VAL_F64, "pk_spmm_csr_x: bad x_kind %d", x_kind);
+    PK_REQUIRE(n_long == 0 || partial_dev != nullptr, "pk_spmm_csr: partial buffer required");
     if (n_tasks == 0) return PK_OK;
     hipStream_t st = pk_stream(stream);
     int rc;
     if (val_kind == PK_VAL_F32)
         rc = launch_spmm<float>(st, n_tasks, task_row_dev, task_begin_dev, task_end_dev, task_slot_dev,
-                                indices_dev, vals_dev, X_dev, ldx, nc, out_dev, ldo, partial_dev);
+                                indices_dev, vals_dev, X_dev, x_kind, ldx, nc, out_dev, ldo, partial_dev);
     else if (val_kind == PK_VAL_F64)
         rc = launch_spmm<double>(st, n_tasks, task_row_dev, task_begin_dev, task_end_dev, task_slot_dev,
-                                 indices_dev, vals_dev, X_dev, ldx, nc, out_dev, ldo, partial_dev);
+                                 indices_dev, vals_dev, X_dev, x_kind, ldx, nc, out_dev, ldo, partial_dev);
     else {
-        pk_set_error("pk_spmm_csr_f64: bad val_kind %d", val_kind);
+        pk_set_error("pk_spmm_csr: bad val_kind %d", val_kind);
         return PK_E_INVALID;
     }
     if (rc != PK_OK) return rc;
@@ -322,4 +352,16 @@ extern "C" int pk_spmm_csr_f64(void *stream, int64_t n_tasks, const int32_t *tas
         PK_CHECK_LAUNCH("spmm_fixup_kernel");
     }
     return PK_OK;
+}
+
+extern "C" int pk_spmm_csr_f64(void *stream, int64_t n_tasks, const int32_t *task_row_dev,
+                               const int64_t *task_begin_dev, const int64_t *task_end_dev,
+                               const int32_t *task_slot_dev, int64_t n_long, const int32_t *long_row_dev,
+                               const int32_t *long_slot_begin_dev, const int32_t *long_slot_end_dev,
+                               const int32_t *indices_dev, const void *vals_dev, int val_kind,
+                               const double *X_dev, int64_t ldx, int32_t nc, double *out_dev, int64_t ldo,
+                               double *partial_dev) {
+    return pk_spmm_csr_x(stream, n_tasks, task_row_dev, task_begin_dev, task_end_dev, task_slot_dev, n_long,
+                         long_row_dev, long_slot_begin_dev, long_slot_end_dev, indices_dev, vals_dev, val_kind, X_dev,
+                         PK_VAL_F64, ldx, nc, out_dev, ldo, partial_dev);
 }

@@ -119,10 +119,19 @@ class DeviceCSR:
     def drop_host(self):
         self._host = None
 
+    def nonneg(self):
+        """True when no stored value is negative (checked once): the approximate fold-in's error weight
+        sum_j a_uj ||V_j|| needs |a_uj| = a_uj."""
+        if getattr(self, '_nonneg', None) is None:
+            self._nonneg = bool((self.values >= 0).all().item()) if self.values.numel() else True
+        return self._nonneg
+
     def with_columns(self, indices, values):
         """Same sparsity pattern per row (row pointers, task plan) with new column ids / values."""
         new = DeviceCSR.__new__(DeviceCSR)
         new.__dict__.update(self.__dict__)
+        if values is not self.values:
+            new._nonneg = None
         new.indices, new.values = indices, values
         new._host = None
         new._partial = None
@@ -271,29 +280,32 @@ class HipOps:
 
     # ---- K1/K4 ------------------------------------------------------------------------------
     def spmm(self, A, X, out=None, rows=None):
-        """out[n_rows x nc] = A @ X (fp64).  A: DeviceCSR, X: [n_cols x nc] row-major.
+        """out[n_rows x nc] = A @ X (fp64 accumulate, fp64 out).  A: DeviceCSR, X: [n_cols x nc] row-major, fp64
+        or fp32 (the fp32 image of the item factors for the approximate fold-in).
         rows=(lo, hi): only rows [lo, hi) are computed (written to the same rows of the FULL-height `out`):
         the tasks of a row range are a contiguous slice of the plan, so a user batch is its own launch."""
         if isinstance(A, HostOperator):   # build(operator=...): host LinearOperator, models.py:835-844
             return A.apply(X, out)
-        assert X.dtype == torch.float64 and X.stride(-1) == 1 and X.shape[0] == A.shape[1]
+        assert X.dtype in (torch.float64, torch.float32) and X.stride(-1) == 1 and X.shape[0] == A.shape[1]
         nc = X.shape[1]
         if out is None:
             out = self.empty(A.shape[0], nc)
+        x_kind = _lib.PK_VAL_F64 if X.dtype == torch.float64 else _lib.PK_VAL_F32
         p = A.plan
         t0, n_tasks, l0, n_long, nnz = 0, A.n_tasks, 0, A.n_long, A.nnz
+        tr, tb, te, ts = p['task_row'], p['task_begin'], p['task_end'], p['task_slot']
+        lr, lb, le = p['long_row'], p['long_slot_begin'], p['long_slot_end']
         if rows is not None:
             lo, hi = int(rows[0]), int(rows[1])
             t0, n_tasks = int(A.row_first_task[lo]), int(A.row_first_task[hi] - A.row_first_task[lo])
             l0, l1 = (int(v) for v in np.searchsorted(A.long_row_host, [lo, hi]))
             n_long = l1 - l0
             nnz = None   # not needed by anyone for a partial launch
-        with self._timed('spmm', (A.shape[0], A.shape[1], nnz, nc, A.values.element_size())):
-            _lib.check(self.lib.pk_spmm_csr_f64(
-                self.stream(), n_tasks, _ptr(p['task_row'], t0), _ptr(p['task_begin'], t0), _ptr(p['task_end'], t0),
-                _ptr(p['task_slot'], t0), n_long, _ptr(p['long_row'], l0), _ptr(p['long_slot_begin'], l0),
-                _ptr(p['long_slot_end'], l0), _ptr(A.indices), _ptr(A.values), A.val_kind,
-                _ptr(X), X.stride(0), nc, _ptr(out), out.stride(0), _ptr(A.partial(nc))), 'pk_spmm_csr_f64')
+        with self._timed('spmm', (A.shape[0], A.shape[1], nnz, nc, A.values.element_size(), X.element_size())):
+            _lib.check(self.lib.pk_spmm_csr_x(
+                self.stream(), n_tasks, _ptr(tr, t0), _ptr(tb, t0), _ptr(te, t0), _ptr(ts, t0), n_long,
+                _ptr(lr, l0), _ptr(lb, l0), _ptr(le, l0), _ptr(A.indices), _ptr(A.values), A.val_kind,
+                _ptr(X), x_kind, X.stride(0), nc, _ptr(out), out.stride(0), _ptr(A.partial(nc))), 'pk_spmm_csr_x')
         return out
 
     # ---- K2 ---------------------------------------------------------------------------------
@@ -473,7 +485,11 @@ class HipOps:
         rec = self._score_state[:splits * groups * 64 * 16].view(torch.int64).view(splits, groups, 64, 2)
         return rec[:, :, 0, 0].clone()
 
-    def rescore_topk(self, V, E, n_items, seen_ptr, KC, cs, ci, topk, vmax, want_scores=True, splits=1, out=None):
+    def rescore_topk(self, V, E, n_items, seen_ptr, KC, cs, ci, topk, vmax, want_scores=True, splits=1, out=None,
+                     rows=None, n_rows_dev=None, e_err=None, e_exact=False):
+        """Exact fp64 re-scoring + certification.  rows (int32 tensor): only these users are re-done (outputs
+        are still indexed by user: pass the full-size `out`); e_err: per-user error weight of an approximate E
+        (flags bit 4 = not certified at that accuracy)."""
         assert V.stride(1) == 1 and E.stride(1) == 1
         n_users, K = E.shape
         if out is not None:
@@ -483,11 +499,33 @@ class HipOps:
             out_idx = torch.empty(n_users, topk, dtype=torch.int64, device=self.device)
             out_s = self.empty(n_users, topk) if want_scores else None
             flags = torch.empty(n_users, dtype=torch.int32, device=self.device)
-        _lib.check(self.lib.pk_rescore_topk_f64(self.stream(), n_users, n_items, K, _ptr(V), V.stride(0), _ptr(E),
-                                                E.stride(0), _ptr(seen_ptr), KC, splits, _ptr(cs), _ptr(ci), topk,
-                                                float(vmax), _ptr(out_idx), _ptr(out_s), _ptr(flags)),
-                   'pk_rescore_topk_f64')
+        n_rows = n_users if rows is None else int(rows.numel())
+        e_ld = 0 if e_err is None else (e_err.stride(0) if e_err.numel() > 1 else 1)
+        _lib.check(self.lib.pk_rescore_topk_rows_f64(self.stream(), n_rows, _ptr(rows), _ptr(n_rows_dev), n_users,
+                                                     n_items, K, _ptr(V),
+                                                     V.stride(0), _ptr(E), E.stride(0), _ptr(e_err), e_ld,
+                                                     1 if e_exact else 0,
+                                                     _ptr(seen_ptr),
+                                                     KC, splits, _ptr(cs), _ptr(ci), topk, float(vmax),
+                                                     _ptr(out_idx), _ptr(out_s), _ptr(flags)),
+                   'pk_rescore_topk_rows_f64')
         return out_idx, out_s, flags
+
+    def flag_compact(self, flags, mask=7):
+        """(list int32[n], count int32[1]) of the users whose flags intersect `mask` — stays on the device."""
+        n = flags.numel()
+        lst = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+        cnt = torch.empty(1, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.pk_flag_compact(self.stream(), n, _ptr(flags), int(mask), _ptr(lst), _ptr(cnt)),
+                   'pk_flag_compact')
+        return lst, cnt
+
+    def fold_rows(self, A, lst, cnt, V, E, row_offset=0):
+        """E[row_offset + lst[r], :K] = (A V)[that row] in fp64 for r < cnt (device-side list)."""
+        assert V.stride(1) == 1 and E.stride(1) == 1 and V.dtype == torch.float64
+        _lib.check(self.lib.pk_fold_rows_f64(self.stream(), lst.numel(), _ptr(lst), _ptr(cnt), int(row_offset),
+                                             _ptr(A.indptr), _ptr(A.indices), _ptr(A.values), A.val_kind, _ptr(V),
+                                             V.stride(0), V.shape[1], _ptr(E), E.stride(0)), 'pk_fold_rows_f64')
 
     def score_exact_rows(self, rows, V, E, n_items, seen_ptr, seen_idx, topk):
         n_rows = rows.numel()

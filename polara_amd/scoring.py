@@ -28,6 +28,13 @@ class FactorImage:
         self.Vp = ops.pack_frag(self.V)
         self.vmax = float(torch.linalg.vector_norm(self.V, dim=1).max().item())
         self.tile_bound = ops.tile_norm_bound(self.V)   # exact pruning bound of the candidate sweep
+        # fp32 image for the approximate fold-in: columns 0..K-1 = fl32(V), column K = an upper bound of the
+        # row norm (so the same product also yields w_u = sum_j a_uj ||V_j||, the weight of the fold-in's
+        # rounding error), zero padding to a multiple of 4 columns (one 16-byte load = 4 columns)
+        self.Kx = -(-(self.K + 1) // 4) * 4
+        self.V32x = torch.zeros(self.n_items, self.Kx, dtype=torch.float32, device=self.V.device)
+        self.V32x[:, :self.K] = self.V.to(torch.float32)
+        self.V32x[:, self.K] = ops.row_norm_bound(self.V)
 
 
 def test_csr_from_triplet(test_data, shape, weights=None):
@@ -38,10 +45,18 @@ def test_csr_from_triplet(test_data, shape, weights=None):
     return coo_to_csr(users, items, vals, shape, sum_duplicates=True)
 
 
-def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stats=None, prune=True, batches=None):
+def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stats=None, prune=True, batches=None,
+              approx_fold_in=None):
     """factors: FactorImage; T: ops-level CSR of the test users [n_users x n_items].
     Returns int64 device tensor [n_users x topk] (+ fp64 scores), rows in test-user order,
-    columns by descending score — the contract of models.py:400-405."""
+    columns by descending score — the contract of models.py:400-405.
+
+    approx_fold_in (default: on when only the ids are asked for and the feedback is non-negative): the fold-in
+    E = T V gathers the fp32 image of V (half the bytes of the product that is bound by them); the
+    re-scoring kernel then knows every score to within delta_u = 2^-24 w_u max||V_i|| and certifies the ORDER
+    only where consecutive scores are further apart than 2 delta_u; the (few) other users get their E row
+    recomputed from the fp64 factors and are re-scored exactly.  The returned ids are those of the exact
+    pipeline either way."""
     n_users, n_items = T.shape
     if n_items != factors.n_items:
         raise ValueError('test matrix and item factors disagree on the number of items')
@@ -66,7 +81,12 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
         if stats is not None:
             stats.update(flagged_users=n_users, candidate_capacity=0, item_splits=0)
         return (out_idx, out_s) if return_scores else out_idx
-    E = ops.empty(n_users, K)
+    if approx_fold_in is None:
+        approx_fold_in = not return_scores
+    approx_fold_in = bool(approx_fold_in) and not return_scores and T.nonneg()
+    Kx = factors.Kx if approx_fold_in else K
+    Ex = ops.empty(n_users, Kx)
+    E = Ex[:, :K]                       # row stride Kx: every kernel below takes a leading dimension
     seen_ptr = T.indptr if filter_seen else None
     seen_idx = T.indices if filter_seen else None
     seen_tiles = T.seen_tiles() if filter_seen else None
@@ -75,22 +95,42 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
     out_s = torch.empty(n_users, topk, dtype=torch.float64, device=E.device)
     flags = torch.empty(n_users, dtype=torch.int32, device=E.device)
 
+    refolded = []                        # device counters of the users re-done with an exact fold-in
+
     def run_batch(u0, u1):
         """fold-in -> bounds/pack -> candidate sweep -> exact re-scoring of users [u0, u1) on the current stream"""
         nb = u1 - u0
-        ops.spmm(T, factors.V, out=E, rows=(u0, u1))                       # fold-in, fp64 (K4)
+        if approx_fold_in:
+            ops.spmm(T, factors.V32x, out=Ex, rows=(u0, u1))               # fold-in against fl32(V) (K4)
+            w = Ex[u0:u1, K]                                               # w_u = sum_j a_uj ||V_j|| (strided view)
+        else:
+            ops.spmm(T, factors.V, out=Ex, rows=(u0, u1))                  # fold-in, fp64 (K4)
+            w = None
         Eb = E[u0:u1]
         Ep = ops.pack_frag(Eb)
         # exact Cauchy-Schwarz pruning: a group of 32 users leaves the sweep once no later item can beat
         # any of its thresholds (`prune=False` forces the full sweep: same result, tuning / tests only)
         ub = ops.row_norm_bound(Eb) if prune else None
+        if ub is not None and w is not None:
+            ub = ub + (w * 1.2e-7).to(torch.float32)                      # ||E|| <= ||E'|| + 2^-24 w
         sp = seen_ptr[u0:u1 + 1] if filter_seen else None
         st = (seen_tiles[0], seen_tiles[1][u0:u1]) if seen_tiles is not None else None
         cs, ci = ops.score_candidates(factors.Vp, Ep, nb, n_items, K, sp, seen_idx, KC, splits,
                                       user_bound=ub, tile_bound=factors.tile_bound if prune else None,
                                       seen_tiles=st)                                          # K3
+        outs = (out_idx[u0:u1], out_s[u0:u1], flags[u0:u1])
         ops.rescore_topk(factors.V, Eb, n_items, sp, KC, cs, ci, topk, factors.vmax, want_scores=True,
-                         splits=splits, out=(out_idx[u0:u1], out_s[u0:u1], flags[u0:u1]))
+                         splits=splits, out=outs, e_err=w)
+        if approx_fold_in:
+            # every flagged user — order not certified at the accuracy of the approximate fold-in (bit 4), or
+            # bound for the exact-row kernel anyway (bits 1, 2), which must not see an approximate E — gets its
+            # E row recomputed from the fp64 factors and is re-scored; the list of those users never leaves the
+            # device (no host round trip inside the pass)
+            lst, cnt = ops.flag_compact(outs[2], 7)
+            ops.fold_rows(T, lst, cnt, factors.V, Ex, row_offset=u0)
+            ops.rescore_topk(factors.V, Eb, n_items, sp, KC, cs, ci, topk, factors.vmax, want_scores=True,
+                             splits=splits, out=outs, rows=lst, n_rows_dev=cnt, e_err=w, e_exact=True)
+            refolded.append(cnt)
 
     # User batches are independent: with B > 1 they run round-robin on two side streams.  Measured on
     # MI355X (S-1M): the fold-in SpMM of one batch and the MFMA sweep of another hardly overlap (B = 2:
@@ -117,6 +157,8 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
     n_flag = int(rows.numel())
     if stats is not None:
         stats['flagged_users'] = n_flag
+        stats['refolded_users'] = int(sum(int(c.item()) for c in refolded))
+        stats['approx_fold_in'] = bool(approx_fold_in)
         stats['candidate_capacity'] = KC
         stats['item_splits'] = splits
         # tiles actually scored by the candidate sweep (pruning), for the roofline accounting

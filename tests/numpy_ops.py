@@ -22,6 +22,9 @@ class NpCSR:
     def seen_tiles(self):
         return None
 
+    def nonneg(self):
+        return bool((self.m.data >= 0).all())
+
     @property
     def T(self):
         if self._T is None:
@@ -76,12 +79,13 @@ class NumpyOps:
         from polara_amd.operator import HostOperator
         if isinstance(A, HostOperator):
             return A.apply(X, out)
-        r = torch.from_numpy(np.ascontiguousarray(A.m @ X.numpy()))
+        r = torch.from_numpy(np.ascontiguousarray(A.m @ X.numpy().astype(np.float64)))
         if out is not None:
+            nc = r.shape[1]
             if rows is not None:
-                out[rows[0]:rows[1]].copy_(r[rows[0]:rows[1]])
+                out[rows[0]:rows[1], :nc].copy_(r[rows[0]:rows[1]])
             else:
-                out.copy_(r)
+                out[:, :nc].copy_(r)
             return out
         return r
 
@@ -192,8 +196,17 @@ class NumpyOps:
     def score_exit_tiles(self, n_users, splits=1):
         return torch.zeros(splits, -(-n_users // 32), dtype=torch.int64)
 
-    def rescore_topk(self, V, E, n_items, seen_ptr, KC, cs, ci, topk, vmax, want_scores=True, splits=1, out=None):
+    def rescore_topk(self, V, E, n_items, seen_ptr, KC, cs, ci, topk, vmax, want_scores=True, splits=1, out=None,
+                     rows=None, n_rows_dev=None, e_err=None, e_exact=False):
         n_users, K = E.shape
+        if rows is not None:
+            # re-do of a user list: compute everybody, keep only the listed users' results
+            res = self.rescore_topk(V, E, n_items, seen_ptr, KC, cs, ci, topk, vmax, want_scores, splits, None, None,
+                                    None, e_err, e_exact)
+            sel = rows.long() if n_rows_dev is None else rows[:int(n_rows_dev[0])].long()
+            for dst, src in zip(out, res):
+                dst[sel] = src[sel]
+            return out
         Vn, En = V.numpy(), E.numpy()
         cs = cs.numpy().reshape(-1, KC)
         ci = ci.numpy().reshape(-1, KC)
@@ -212,16 +225,37 @@ class NumpyOps:
             n_seen = int(seen_ptr[u + 1] - seen_ptr[u]) if seen_ptr is not None else 0
             if n_items - n_seen < topk:
                 flags[u] |= 2
+            delta = float(e_err[u]) * 2.0 ** -24 * (1 + 1e-6) * vmax if e_err is not None else 0.0
+            if delta > 0 and not e_exact:
+                ss = np.r_[s, -np.inf]
+                m = min(topk, len(s))
+                if m and (ss[:m] - ss[1:m + 1] <= 2 * delta).any():
+                    flags[u] |= 4
+            if n_items - n_seen < topk:
+                pass
             elif valid.all():
                 bound = (K + 3) * 2.0 ** -24 * np.linalg.norm(En[u]) * vmax
-                if bound > 0 and not (s[topk - 1] - float(cs[u, KC - 1]) > bound):
-                    flags[u] |= 1
+                tau = float(cs[u, KC - 1]); tau += abs(tau) * 2.0 ** -15
+                slack = delta if e_exact else 2 * delta
+                if bound > 0 and not (s[topk - 1] - tau > bound + slack):
+                    flags[u] |= 4 if (not e_exact and delta > 0 and s[topk - 1] - tau > bound + delta) else 1
         res = torch.from_numpy(out_idx), torch.from_numpy(out_s), torch.from_numpy(flags)
         if out is not None:
             for dst, src in zip(out, res):
                 dst.copy_(src)
             return out
         return res
+
+    def flag_compact(self, flags, mask=7):
+        hit = torch.nonzero((flags & mask) != 0).flatten().to(torch.int32)
+        lst = torch.zeros(max(flags.numel(), 1), dtype=torch.int32)
+        lst[:hit.numel()] = hit
+        return lst, torch.tensor([hit.numel()], dtype=torch.int32)
+
+    def fold_rows(self, A, lst, cnt, V, E, row_offset=0):
+        sel = lst[:int(cnt[0])].long() + row_offset
+        if sel.numel():
+            E[sel, :V.shape[1]] = torch.from_numpy(np.ascontiguousarray((A.m[sel.numpy()] @ V.numpy())))
 
     def score_exact_rows(self, rows, V, E, n_items, seen_ptr, seen_idx, topk):
         Vn, En = V.numpy(), E.numpy()

@@ -457,6 +457,48 @@ def test_near_tie_scores_are_resolved_exactly(hip_ops, cfg):
             firm = np.r_[clear, True] & np.r_[True, clear]
             assert np.array_equal(recs[u][firm], want[u][firm]), (u, prune, st)
         assert st['flagged_users'] > 0        # the near-ties really did defeat the fp32 certification
+        # ids-only call: approximate fold-in (fp32 image of V) + certification of the order + exact re-do
+        st2 = {}
+        ids = hip_ops.to_host(scoring.recommend(hip_ops, F, T, topk, True, stats=st2, prune=prune))
+        assert st2['approx_fold_in'] and st2['refolded_users'] > 0
+        for u in np.flatnonzero(live):
+            ref_s = s[u, want[u]]
+            clear = np.abs(np.diff(ref_s)) > 1e-13 * np.abs(ref_s[:-1])
+            firm = np.r_[clear, True] & np.r_[True, clear]
+            assert np.array_equal(ids[u][firm], want[u][firm]), (u, prune, st2)
+
+
+@pytest.mark.parametrize('cfg', [dict(n_users=3000, n_items=9000, K=50, topk=10),
+                                 dict(n_users=700, n_items=5000, K=100, topk=20),
+                                 dict(n_users=300, n_items=4000, K=26, topk=50)])
+def test_approximate_fold_in_returns_the_exact_ids(hip_ops, cfg):
+    """recommend(ids only) folds in against the fp32 image of V and certifies the order; it must return exactly
+    what the fp64 pipeline returns (which the other tests pin to the reference), on decaying-norm factors with
+    explicit zero feedback, long and empty rows; negative feedback switches the approximation off."""
+    from polara_amd import scoring
+    n_users, n_items, K, topk = cfg['n_users'], cfg['n_items'], cfg['K'], cfg['topk']
+    rng = np.random.RandomState(n_items + K)
+    V = rng.randn(n_items, K) / np.sqrt(K) * ((1.0 + np.arange(n_items)) ** -0.6)[:, None]
+    V = V[rng.permutation(n_items)]
+    indptr, indices, values = rand_csr(rng, n_users, n_items, 40, long_rows=[(2, n_items // 3)], empty_rows=[7],
+                                       dtype=np.float32)
+    values[::9] = 0.0
+    T = hip_ops.csr(indptr, indices, values, (n_users, n_items))
+    F = scoring.FactorImage(hip_ops, hip_ops.to_device(V))
+    exact = hip_ops.to_host(scoring.recommend(hip_ops, F, T, topk, True, approx_fold_in=False))
+    st = {}
+    fast = hip_ops.to_host(scoring.recommend(hip_ops, F, T, topk, True, stats=st))
+    assert st['approx_fold_in']
+    assert np.array_equal(exact, fast), (np.flatnonzero((exact != fast).any(axis=1))[:5], st)
+    for B in (2,):
+        if n_users >= 2 * 4096:
+            assert np.array_equal(exact, hip_ops.to_host(scoring.recommend(hip_ops, F, T, topk, True, batches=B)))
+    neg = values.copy()
+    neg[1::5] *= -1.0
+    Tn = hip_ops.csr(indptr, indices, neg, (n_users, n_items))
+    st = {}
+    scoring.recommend(hip_ops, F, Tn, topk, True, stats=st)
+    assert not st['approx_fold_in']
 
 
 def test_large_topk_uses_exact_rows(hip_ops):
