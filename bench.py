@@ -281,7 +281,8 @@ def main():
         'metric': 'users scored/sec + SVD build time', 'value': value, 'unit': 'users/s',
         'n_gpus': comm.world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
         'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32',
-        'dtype_detail': 'f32 MFMA candidate scoring; f64 exact re-scoring, fold-in and SVD build',
+        'dtype_detail': 'f32 MFMA candidate scoring; fold-in gathers fl32(V) with f64 accumulation, its rounding is part of the '
+                        'certification (uncertified users are re-folded in f64); f64 exact re-scoring and SVD build',
         'data': 'synthetic (planted low-rank + Zipf popularity, seeded; generated on GPU)',
         'config': {'workload': {'s1m': 'Synthetic 1M users x 100K items, ~0.1% density CSR, PureSVD rank=50, top-10, all users scored (BASELINE.json configs[1])',
                                 'ml20m': 'ML-20M-shaped synthetic 138493 x 26744, PureSVD rank=100, top-20 (BASELINE.json configs[2])',

@@ -61,6 +61,24 @@ def test_spmm_matches_scipy(hip_ops, nc, vdtype):
     assert np.abs(out2 - ref2).max() / np.abs(ref2).max() < 1e-13
 
 
+@pytest.mark.parametrize('nc', [4, 52, 64, 104, 204])
+def test_spmm_fp32_dense_block(hip_ops, nc):
+    """pk_spmm_csr_x with an fp32 dense block (the approximate fold-in): fp64 accumulation of fl32(X)."""
+    import torch
+    rng = np.random.RandomState(nc)
+    n_rows, n_cols = 700, 900
+    indptr, indices, values = rand_csr(rng, n_rows, n_cols, 30, long_rows=[(3, 850)], empty_rows=[0, 11], dtype=np.float32)
+    A = hip_ops.csr(indptr, indices, values, (n_rows, n_cols))
+    X32 = rng.randn(n_cols, nc).astype(np.float32)
+    got = hip_ops.to_host(hip_ops.spmm(A, hip_ops.to_device(X32)))
+    ref = sps.csr_matrix((values.astype(np.float64), indices, indptr), shape=(n_rows, n_cols)) @ X32.astype(np.float64)
+    assert got.dtype == np.float64 and np.allclose(got, ref, rtol=1e-13, atol=1e-13)
+    # a wider, strided output (the fold-in writes K of Kx columns of a row)
+    out = torch.zeros(n_rows, nc + 4, dtype=torch.float64, device=hip_ops.device)
+    hip_ops.spmm(A, hip_ops.to_device(X32), out=out[:, :nc])
+    assert np.allclose(hip_ops.to_host(out)[:, :nc], ref, rtol=1e-13, atol=1e-13) and float(out[:, nc:].abs().sum()) == 0.0
+
+
 def test_device_coo_to_csr_matches_scipy(hip_ops):
     rng = np.random.RandomState(4)
     n_rows, n_cols, nnz = 5000, 3000, 400000
