@@ -83,7 +83,7 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
         return (out_idx, out_s) if return_scores else out_idx
     if approx_fold_in is None:
         approx_fold_in = not return_scores
-    approx_fold_in = bool(approx_fold_in) and not return_scores and T.nonneg()
+    approx_fold_in = bool(approx_fold_in) and not return_scores and factors.Kx <= 256 and T.nonneg()
     Kx = factors.Kx if approx_fold_in else K
     Ex = ops.empty(n_users, Kx)
     E = Ex[:, :K]                       # row stride Kx: every kernel below takes a leading dimension
