@@ -11,6 +11,7 @@
 // HBM/L2-bound by construction: 1 FMA per 8 bytes gathered.  No atomics: long rows are split into
 // tasks that write partial sums, added in slot order by spmm_fixup_kernel (deterministic).
 #include "pk_common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 template <typename VT>
@@ -135,7 +136,11 @@ __global__ __launch_bounds__(256) void spmm_csr_groups_kernel(
     int64_t ldx, int nc, double *__restrict__ out, int64_t ldo, double *__restrict__ partial) {
     constexpr bool XF = sizeof(XT) == 4;
     constexpr int LG = 64 / GROUPS;
-    constexpr int U = 4;   // wave steps per register set (two sets in flight)
+    // wave steps per register set (two sets in flight); an fp32 row piece is one float4 per lane and step
+    // (half the registers of the fp64 pair), so twice as many steps fit in flight: fold-in 2.20 -> 1.98 ms.
+    // (16 steps: slower, occupancy; 8 steps for the fp64 block: slower too, 3.30 -> 4.07 ms.)
+    constexpr int U = XF ? 8 : 4;
+    using XA = typename std::conditional<XF, float4, double2>::type;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t task = (int64_t)blockIdx.x * 4 + wave;
@@ -155,6 +160,7 @@ __global__ __launch_bounds__(256) void spmm_csr_groups_kernel(
     double2 acc0 = make_double2(0.0, 0.0), acc1 = make_double2(0.0, 0.0);
     constexpr int SPC = 64 / GROUPS;      // wave steps per 64-pair chunk
     constexpr int SETS = SPC / U;         // register sets per chunk (U steps each)
+    static_assert(SETS >= 2 && SETS % 2 == 0, "the two register files alternate: an even number of sets per chunk");
     // the 64 (index, value) pairs of a chunk are fetched with one coalesced load (next chunk prefetched)
     // and handed to the groups through ds_bpermute: no extra VMEM instruction per step
     int jc = 0, jn = 0;
@@ -167,32 +173,34 @@ __global__ __launch_bounds__(256) void spmm_csr_groups_kernel(
         jn = ip[64 + lane];
         an = vp[64 + lane];
     }
-    auto issue = [&](int jch, int st0, double2(&xa)[U], double2(&xb)[U]) {
+    auto issue = [&](int jch, int st0, XA(&xa)[U], auto &xb) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int jj = __shfl(jch, (st0 + u) * GROUPS + g, 64);
             const int64_t off = (int64_t)jj * ldx;
-            if constexpr (XF) {
-                const float4 f = *reinterpret_cast<const float4 *>(x0 + off);
-                xa[u] = make_double2((double)f.x, (double)f.y);
-                xb[u] = make_double2((double)f.z, (double)f.w);
-            } else {
-                xa[u] = *reinterpret_cast<const double2 *>(x0 + off);
-                xb[u] = *reinterpret_cast<const double2 *>(x1 + off);
-            }
+            xa[u] = *reinterpret_cast<const XA *>(x0 + off);
+            if constexpr (!XF) xb[u] = *reinterpret_cast<const double2 *>(x1 + off);
         }
     };
-    auto consume = [&](VT ach, int st0, const double2(&xa)[U], const double2(&xb)[U]) {
+    auto consume = [&](VT ach, int st0, const XA(&xa)[U], const auto &xb) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const double aa = (double)__shfl(ach, (st0 + u) * GROUPS + g, 64);
-            acc0.x = fma(aa, xa[u].x, acc0.x);
-            acc0.y = fma(aa, xa[u].y, acc0.y);
-            acc1.x = fma(aa, xb[u].x, acc1.x);
-            acc1.y = fma(aa, xb[u].y, acc1.y);
+            if constexpr (XF) {
+                acc0.x = fma(aa, (double)xa[u].x, acc0.x);
+                acc0.y = fma(aa, (double)xa[u].y, acc0.y);
+                acc1.x = fma(aa, (double)xa[u].z, acc1.x);
+                acc1.y = fma(aa, (double)xa[u].w, acc1.y);
+            } else {
+                acc0.x = fma(aa, xa[u].x, acc0.x);
+                acc0.y = fma(aa, xa[u].y, acc0.y);
+                acc1.x = fma(aa, xb[u].x, acc1.x);
+                acc1.y = fma(aa, xb[u].y, acc1.y);
+            }
         }
     };
-    double2 xa0[U], xb0[U], xa1[U], xb1[U];
+    XA xa0[U], xa1[U];
+    double2 xb0[XF ? 1 : U], xb1[XF ? 1 : U];
     issue(jc, 0, xa0, xb0);
     for (int p = 0; p < n; p += 64) {
         const int cnt = (n - p) < 64 ? (n - p) : 64;   // pairs of this chunk; padded lanes hold (0, 0.0)
