@@ -177,6 +177,10 @@ int32_t pk_score_chunk_launches(int64_t n_items, int32_t K, int32_t splits, int3
  * which that group left the sweep (= end of its tile range when it was never pruned): the number of
  * tiles actually scored, for the roofline accounting of bench.py. */
 int pk_row_norm_bound_f32(void *stream, int64_t n, int32_t K, const double *src_dev, int64_t ld, float *out_dev);
+/* pk_pack_frag_f32 and the row bound in one pass over the block (the user side of a scoring pass):
+ * bound[r] >= ||src[r,:]||_2 + extra_scale * extra[r * extra_ld]   (extra_dev may be NULL). */
+int pk_pack_frag_bound_f32(void *stream, int64_t n, int32_t K, const double *src_dev, int64_t ld, float *dst_dev,
+                           float *bound_dev, const double *extra_dev, int64_t extra_ld, double extra_scale);
 int pk_tile_norm_bound_f32(void *stream, int64_t n_items, int32_t K, const double *V_dev, int64_t ld,
                            float *work_dev, float *out_dev);
 /* Exact fp64 re-scoring + final ordering (score desc, item asc).  Writes topk item ids (int64) and

@@ -44,6 +44,7 @@ PROTOTYPES = {
     'pk_score_candidates_f32': (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp,
                                           _i32, _vp, _vp]),
     'pk_score_chunk_launches': (_i32, [_i64, _i32, _i32, _i32, _i32]),
+    'pk_pack_frag_bound_f32': (C.c_int, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _i64, _f64]),
     'pk_row_norm_bound_f32': (C.c_int, [_vp, _i64, _i32, _vp, _i64, _vp]),
     'pk_tile_norm_bound_f32': (C.c_int, [_vp, _i64, _i32, _vp, _i64, _vp, _vp]),
     'pk_rescore_topk_f64': (C.c_int, [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _vp, _vp,

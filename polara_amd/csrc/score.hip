@@ -682,6 +682,57 @@ __global__ __launch_bounds__(256) void pack_frag_kernel(int64_t n, int K, int kq
     dst[t] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
+// The same packing of a [n x K] fp64 block with the pruning bound of every row computed on the way (the user
+// side of a scoring pass: E is read once instead of twice).  One wave per 32-row tile: lane (i = lane & 31,
+// h = lane >> 5) produces its float4 of every q-group and accumulates the squares of what it read; the two
+// halves of a row meet through one lane exchange.  bound[r] = ||src[r,:]|| (1 + 1e-6) + extra_scale * extra[r]
+// (extra: the error weight of an approximate fold-in, or NULL).
+__global__ __launch_bounds__(256) void pack_frag_bound_kernel(int64_t n, int K, int kq, const double *__restrict__ src,
+                                                              int64_t ld, float4 *__restrict__ dst,
+                                                              float *__restrict__ bound,
+                                                              const double *__restrict__ extra, int64_t extra_ld,
+                                                              double extra_scale, int64_t n_tiles) {
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= n_tiles) return;
+    const int64_t row = tile * 32 + (lane & 31);
+    const int h = lane >> 5;
+    const bool live = row < n;
+    const double *r = src + (live ? row : 0) * ld;
+    double ss = 0.0;
+    for (int q = 0; q < kq; ++q) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = 8 * q + 2 * e + h;
+            const double x = (live && k < K) ? r[k] : 0.0;
+            ss = fma(x, x, ss);
+            v[e] = (float)x;
+        }
+        dst[(tile * kq + q) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    ss += pk_lane_xor<32>(ss);
+    if (live && h == 0) {
+        double b = sqrt(ss) * (1.0 + 1e-6);
+        if (extra) b += extra_scale * extra[row * extra_ld];
+        bound[row] = (float)(b * (1.0 + 1e-7));   // the conversion rounds to nearest: keep it an upper bound
+    }
+}
+
+extern "C" int pk_pack_frag_bound_f32(void *stream, int64_t n, int32_t K, const double *src_dev, int64_t ld,
+                                      float *dst_dev, float *bound_dev, const double *extra_dev, int64_t extra_ld,
+                                      double extra_scale) {
+    const int kq = pk_pack_kq(K);
+    PK_REQUIRE(n >= 1 && K >= 1 && kq > 0, "pk_pack_frag_bound_f32: n=%lld K=%d unsupported (K <= 256)", (long long)n, K);
+    PK_REQUIRE(ld >= K && ((uintptr_t)dst_dev % 16) == 0 && bound_dev, "pk_pack_frag_bound_f32: bad ld / alignment / pointers");
+    const int64_t n_tiles = pk_ceil_div(n, 32);
+    hipLaunchKernelGGL(pack_frag_bound_kernel, dim3((unsigned)pk_ceil_div(n_tiles, 4)), dim3(256), 0, pk_stream(stream), n,
+                       K, kq, src_dev, ld, reinterpret_cast<float4 *>(dst_dev), bound_dev, extra_dev, extra_ld,
+                       extra_scale, n_tiles);
+    PK_CHECK_LAUNCH("pack_frag_bound_kernel");
+    return PK_OK;
+}
+
 extern "C" int pk_pack_frag_f32(void *stream, int64_t n, int32_t K, const double *src_dev, int64_t ld,
                                 float *dst_dev) {
     const int kq = pk_pack_kq(K);

@@ -414,6 +414,17 @@ class HipOps:
             return self.score_splits_override
         return 1 if prune else self.lib.pk_score_splits(n_users, KC)
 
+    def pack_frag_bound(self, M, extra=None, extra_scale=0.0):
+        """(packed fp32 fragments of M, float32 row bounds ||M[r,:]|| (+ extra_scale * extra[r])) in one pass."""
+        assert M.stride(1) == 1 and M.dtype == torch.float64
+        n, K = M.shape
+        out = torch.empty(self.lib.pk_pack_elems(n, K), dtype=torch.float32, device=self.device)
+        bound = torch.empty(n, dtype=torch.float32, device=self.device)
+        e_ld = 0 if extra is None else (extra.stride(0) if extra.numel() > 1 else 1)
+        _lib.check(self.lib.pk_pack_frag_bound_f32(self.stream(), n, K, _ptr(M), M.stride(0), _ptr(out), _ptr(bound),
+                                                   _ptr(extra), e_ld, float(extra_scale)), 'pk_pack_frag_bound_f32')
+        return out, bound
+
     def row_norm_bound(self, M):
         """float32 upper bounds of the row 2-norms of fp64 M (pruning bound of the candidate sweep)."""
         assert M.stride(1) == 1

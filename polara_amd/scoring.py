@@ -107,12 +107,13 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
             ops.spmm(T, factors.V, out=Ex, rows=(u0, u1))                  # fold-in, fp64 (K4)
             w = None
         Eb = E[u0:u1]
-        Ep = ops.pack_frag(Eb)
-        # exact Cauchy-Schwarz pruning: a group of 32 users leaves the sweep once no later item can beat
-        # any of its thresholds (`prune=False` forces the full sweep: same result, tuning / tests only)
-        ub = ops.row_norm_bound(Eb) if prune else None
-        if ub is not None and w is not None:
-            ub = ub + (w * 1.2e-7).to(torch.float32)                      # ||E|| <= ||E'|| + 2^-24 w
+        # fragments of E for the MFMA sweep + the users' side of the exact Cauchy-Schwarz pruning bound (a group
+        # of 32 users leaves the sweep once no later item can beat any of its thresholds), one pass over E;
+        # with the approximate fold-in ||E|| <= ||E'|| + 2^-24 w.  `prune=False` forces the full sweep (same
+        # result, tuning / tests only)
+        Ep, ub = ops.pack_frag_bound(Eb, extra=w, extra_scale=1.2e-7)
+        if not prune:
+            ub = None
         sp = seen_ptr[u0:u1 + 1] if filter_seen else None
         st = (seen_tiles[0], seen_tiles[1][u0:u1]) if seen_tiles is not None else None
         cs, ci = ops.score_candidates(factors.Vp, Ep, nb, n_items, K, sp, seen_idx, KC, splits,

@@ -166,6 +166,12 @@ class NumpyOps:
     def pack_frag(self, M):
         return M.to(torch.float32)
 
+    def pack_frag_bound(self, M, extra=None, extra_scale=0.0):
+        ub = self.row_norm_bound(M)
+        if extra is not None:
+            ub = ub + (extra.double() * extra_scale).to(torch.float32) * (1 + 1e-6)
+        return self.pack_frag(M), ub
+
     def row_norm_bound(self, M):
         return torch.from_numpy((np.linalg.norm(M.numpy(), axis=1) * (1 + 1e-6)).astype(np.float32))
 

@@ -353,6 +353,26 @@ def test_spmm_row_range_and_user_batches(hip_ops):
         assert np.array_equal(hip_ops.to_host(ref_s), hip_ops.to_host(got_s))
 
 
+def test_pack_frag_bound_matches_separate_kernels(hip_ops):
+    import torch
+    rng = np.random.RandomState(8)
+    for n, K, ldpad in ((1000, 50, 2), (33, 7, 0), (4097, 200, 4), (64, 100, 0)):
+        M = torch.zeros(n, K + ldpad, dtype=torch.float64, device=hip_ops.device)
+        M[:, :K] = hip_ops.to_device(rng.randn(n, K) * np.exp(rng.randn(n, 1) * 2))
+        Mv = M[:, :K]
+        extra = hip_ops.to_device(np.abs(rng.randn(n)) * 100)
+        p_ref = hip_ops.pack_frag(Mv.contiguous())
+        p_got, b_got = hip_ops.pack_frag_bound(Mv, extra=extra, extra_scale=1.2e-7)
+        assert torch.equal(p_ref, p_got)
+        nrm = np.linalg.norm(hip_ops.to_host(Mv), axis=1)
+        want = nrm + 1.2e-7 * hip_ops.to_host(extra)
+        b = hip_ops.to_host(b_got).astype(np.float64)
+        assert np.all(b >= want) and np.all(b <= want * (1 + 3e-6) + 1e-300)
+        _, b0 = hip_ops.pack_frag_bound(Mv)
+        b0 = hip_ops.to_host(b0).astype(np.float64)
+        assert np.all(b0 >= nrm) and np.all(b0 <= nrm * (1 + 3e-6) + 1e-300)
+
+
 def test_pruning_bounds_are_upper_bounds(hip_ops):
     rng = np.random.RandomState(3)
     for n, K in ((1000, 50), (33, 7), (4097, 200)):
