@@ -525,6 +525,8 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
         // scan instead of 16 inlined copies: 95 ms vs 90 ms; a single rolling fragment buffer (group q
         // of the next tile loaded right after group q's MFMAs, no register moves): 99 vs 81 ms — the
         // compiler drains vmcnt(0) at the loop head, which exposes the latency of the late loads.
+        // Forcing five waves per SIMD (amdgpu_waves_per_eu: 96 VGPRs, 12 spilled) on the pruned sweep: 3.47 vs
+        // 3.29 ms; four (120 VGPRs, no spill) is what the register allocator picks unprompted.
         float4 a_nxt[KQ];
         load_frags((tile_begin < n_tiles) ? tile_begin : 0, a_nxt);
         float tb = prune ? tile_bound[(tile_begin < n_tiles) ? tile_begin : 0] : 0.0f;
