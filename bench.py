@@ -6,17 +6,22 @@
 
 Workload (BASELINE.json configs[1], the largest single-GPU config): synthetic planted 1M users x
 100K items, ~1e8 nnz CSR, PureSVD rank 50, top-10, every user scored.  A "step" is one full
-`get_recommendations` pass over all users: fold-in SpMM -> fused MFMA score/mask/top-k ->
-exact fp64 re-scoring -> exact rows for uncertified users.  The SVD build (the other half of the
-metric) runs once before the timed region and is reported as `build_s` with its own roofline.
+`get_recommendations` pass over all users (polara_amd.scoring.recommend, the path the model classes
+run): fold-in SpMM (against the fp32 image of V, certified) -> fused MFMA score/mask/top-k sweep with
+exact norm-bound pruning -> exact fp64 re-scoring + certification -> exact re-do of the uncertified
+users.  The SVD build (the other half of the metric) runs once before the timed region (after one
+untimed warm-up build) and is reported as `build_s` — including the re-indexing of the catalogue by
+factor norm that the scoring passes use — with its own roofline.
 Users are sharded over ranks (strong scaling: the total work is fixed); the build's only
 collective is the all-reduce of the Gramian-step block, scoring has none.
 
 Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel of the timed region
-(score_candidates, MFMA-bound: 2*n_users*n_items*rank flop per launch); `roofline_build` the SpMM
-(HBM-bound; algorithmic bytes per launch = nnz*(4+val_bytes) + 8*(n_rows+1) + 8*nc*(n_cols+n_rows)).
+(score_candidates, MFMA-bound): `achieved`/`frac` on the MFMA flops actually executed (the pruned share of
+the reference's 2*n_users*n_items*rank), the dense-equivalent rate next to it; per-kernel durations come
+from three extra untimed passes with HIP events.  `roofline_build` describes the SpMM (HBM-bound; algorithmic
+bytes per launch = nnz*(4+val_bytes) + 8*(n_rows+1) + nc*(x_bytes*n_cols + 8*n_rows)).
 `cpu_baseline` is the oracle (= the reference's SciPy/NumPy path restated) timed on this box's host
-cores on a bounded sample.
+cores on a bounded sample; the GPU lists of that sample are compared with it row by row.
 """
 import argparse
 import json
