@@ -12,6 +12,8 @@ _TABLE = dict(
     flattener=slice(0, None), parallel_ttm=False, test_vectorize_target='parallel',
     # recommendations (defaults.py:41-42)
     topk=10, filter_seen=True,
+    # evaluation (defaults.py:46): exponential relevance contribution in NDCG
+    ndcg_alternative=True,
     # computation (defaults.py:48-51): accepted for API compatibility; the fused device path
     # has no dense score chunks, hence no use for the host-memory cap
     test_chunk_size=1000, max_test_workers=None, memory_hard_limit=1,

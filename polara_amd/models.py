@@ -304,14 +304,33 @@ class RecommenderModel:
             scores = np.ascontiguousarray(scores[:, self._item_rank])   # back to external item order
         return scores, slice_data
 
-    def evaluate(self, *args, **kwargs):
-        """Metrics are a consumer of `recommendations` (models.py:408-485, evaluation.py) and out of
-        this package's scope; with Polara installed, its implementation is used on our results."""
-        try:
+    def evaluate(self, metric_type='all', topk=None, not_rated_penalty=None, switch_positive=None,
+                 ignore_feedback=False, simple_rates=False, on_feedback_level=None):
+        """models.py:408-485.  With a Polara `RecommenderData` (pandas holdout) the reference's own metric code
+        runs on our recommendations; with `ArrayData` — or without Polara — polara_amd.evaluation does, the
+        same formulas on arrays (see its header for the one deliberate difference)."""
+        holdout = self.data.test.holdout
+        if hasattr(holdout, 'columns'):              # a pandas frame: Polara's data model is in use
             from polara.recommender.models import RecommenderModel as _Ref
-        except ImportError as e:
-            raise NotImplementedError('evaluate() needs polara (metrics are outside the hot path)') from e
-        return _Ref.evaluate(self, *args, **kwargs)
+            return _Ref.evaluate(self, metric_type=metric_type, topk=topk, not_rated_penalty=not_rated_penalty,
+                                 switch_positive=switch_positive, ignore_feedback=ignore_feedback,
+                                 simple_rates=simple_rates, on_feedback_level=on_feedback_level)
+        from . import evaluation
+        if holdout is None:
+            raise ValueError('evaluate() needs a holdout')
+        if int(topk or 0) > self.topk:
+            self.topk = topk                         # also flushes the cached recommendations (models.py:423-424)
+        recs = self.recommendations[:, :topk]
+        users, items, fdbk = holdout
+        order = np.argsort(users, kind='stable')     # rows of `recommendations` follow the sorted test users
+        n_items = self.data.get_test_shape(tensor_mode=False)[1]
+        return evaluation.evaluate(recs, np.asarray(users)[order], np.asarray(items)[order],
+                                   None if fdbk is None else np.asarray(fdbk)[order], n_items,
+                                   metric_type=metric_type, not_rated_penalty=not_rated_penalty,
+                                   switch_positive=switch_positive or self.switch_positive,
+                                   ignore_feedback=ignore_feedback, simple_rates=simple_rates,
+                                   holdout_size=self.data.holdout_size,
+                                   ndcg_alternative=get_default('ndcg_alternative'))
 
 
 class SVDModel(RecommenderModel):
