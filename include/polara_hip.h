@@ -230,6 +230,11 @@ int pk_score_exact_rows_f64(void *stream, int32_t n_rows, const int32_t *rows_de
                             int32_t K, const double *V_dev, int64_t ldv, const double *E_dev, int64_t lde,
                             const int64_t *seen_ptr_dev, const int32_t *seen_idx_dev, int32_t topk,
                             int64_t *out_idx_dev, double *out_score_dev, void *work_dev);
+/* Evaluation support (models.py:408-485, evaluation.py:24-44 `build_rank_matrix` restricted to the holdout):
+ * rank_out[e] = 1-based position of hold_item[e] in row hold_row[e] of the device-resident [n_users x topk]
+ * recommendation array, 0 if absent.  Every hit/rank metric is a reduction of this holdout-sized vector. */
+int pk_eval_ranks(void *stream, int64_t n_holdout, const int64_t *recs_dev, int32_t topk,
+                  const int64_t *hold_row_dev, const int64_t *hold_item_dev, int32_t *rank_out_dev);
 /* Dense fp64 score rows (kept for `slice_recommendations`/`_user_scores`, models.py:277-291):
  * out[r, :] = E[r, :] V^T for r in [0, n_rows). */
 int pk_dense_scores_f64(void *stream, int32_t n_rows, int64_t n_items, int32_t K, const double *V_dev,

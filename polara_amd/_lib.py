@@ -56,6 +56,7 @@ PROTOTYPES = {
     'pk_exact_work_bytes': (_i64, [_i32, _i64]),
     'pk_score_exact_rows_f64': (C.c_int, [_vp, _i32, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _i32,
                                           _vp, _vp, _vp]),
+    'pk_eval_ranks': (C.c_int, [_vp, _i64, _vp, _i32, _vp, _vp, _vp]),
     'pk_dense_scores_f64': (C.c_int, [_vp, _i32, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _i64]),
     'pk_ttm_f64': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp,
                              _vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _vp]),

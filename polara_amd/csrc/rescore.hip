@@ -516,3 +516,36 @@ extern "C" int pk_dense_scores_f64(void *stream, int32_t n_rows, int64_t n_items
     PK_CHECK_LAUNCH("dense_scores_kernel");
     return PK_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// evaluation support (models.py:408-485 consume the [n_users x topk] array): the rank (1-based, 0 = absent) at
+// which every holdout item was recommended to its user, straight from the device-resident top-k buffer —
+// only this holdout-sized vector travels to the host, not the recommendation array (20 GB at 50M users x top-50).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void eval_ranks_kernel(int64_t n_holdout, const int64_t *__restrict__ recs,
+                                                         int topk, const int64_t *__restrict__ hold_row,
+                                                         const int64_t *__restrict__ hold_item,
+                                                         int32_t *__restrict__ rank_out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_holdout) return;
+    const int64_t *row = recs + hold_row[e] * topk;
+    const int64_t item = hold_item[e];
+    int rank = 0;
+    for (int t = 0; t < topk; ++t)
+        if (row[t] == item) {
+            rank = t + 1;
+            break;
+        }
+    rank_out[e] = rank;
+}
+
+extern "C" int pk_eval_ranks(void *stream, int64_t n_holdout, const int64_t *recs_dev, int32_t topk,
+                             const int64_t *hold_row_dev, const int64_t *hold_item_dev, int32_t *rank_out_dev) {
+    PK_REQUIRE(n_holdout >= 0 && topk >= 1 && recs_dev && hold_row_dev && hold_item_dev && rank_out_dev,
+               "pk_eval_ranks: bad arguments");
+    if (n_holdout == 0) return PK_OK;
+    hipLaunchKernelGGL(eval_ranks_kernel, dim3((unsigned)pk_ceil_div(n_holdout, 256)), dim3(256), 0, pk_stream(stream),
+                       n_holdout, recs_dev, topk, hold_row_dev, hold_item_dev, rank_out_dev);
+    PK_CHECK_LAUNCH("eval_ranks_kernel");
+    return PK_OK;
+}

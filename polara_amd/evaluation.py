@@ -36,7 +36,13 @@ class _Matched:
     """Per holdout entry: the user's row, whether it counts as positive, its relevance, and the rank (1-based)
     at which the item was recommended (0 = not recommended)."""
 
-    def __init__(self, recommendations, holdout_user, holdout_item, holdout_fdbk, is_positive):
+    def __init__(self, recommendations, holdout_user, holdout_item, holdout_fdbk, is_positive, ranks=None,
+                 n_valid_recs=None):
+        """ranks / n_valid_recs: precomputed on the device (pk_eval_ranks) when the recommendation array stays
+        there; `recommendations` may then be just its shape (n_users, topk)."""
+        if ranks is not None:
+            self._from_ranks(recommendations, holdout_user, holdout_item, holdout_fdbk, is_positive, ranks, n_valid_recs)
+            return
         recs = np.array(recommendations, copy=False, ndmin=2)
         users = np.asarray(holdout_user)
         if (np.diff(users) < 0).any():
@@ -55,6 +61,22 @@ class _Matched:
         match = recs[row] == self.item[:, None]                      # [n_holdout x topk]
         self.rank = np.where(match.any(axis=1), match.argmax(axis=1) + 1, 0)
         self.n_valid_recs = (recs >= 0).sum(axis=1)                  # models may pad with negative ids
+
+    def _from_ranks(self, shape, holdout_user, holdout_item, holdout_fdbk, is_positive, ranks, n_valid_recs):
+        users = np.asarray(holdout_user)
+        if (np.diff(users) < 0).any():
+            raise ValueError('holdout must be sorted by user')
+        self.n_users, self.topk = int(shape[0]), int(shape[1])
+        self.recs = None
+        self.row = np.r_[0, np.cumsum(np.diff(users) != 0)] if len(users) else np.zeros(0, np.int64)
+        if len(users) and self.row[-1] + 1 != self.n_users:
+            raise ValueError('recommendations have %d rows, the holdout %d users' % (self.n_users, self.row[-1] + 1))
+        self.item = np.asarray(holdout_item)
+        self.rel = np.ones(len(users)) if holdout_fdbk is None else np.asarray(holdout_fdbk, dtype=np.float64)
+        self.positive = np.ones(len(users), bool) if is_positive is None else np.asarray(is_positive, bool)
+        self.split = is_positive is not None
+        self.rank = np.asarray(ranks).astype(np.int64)
+        self.n_valid_recs = (np.full(self.n_users, self.topk) if n_valid_recs is None else np.asarray(n_valid_recs))
 
     def per_user(self, values, mask):
         return np.bincount(self.row[mask], weights=values[mask] if values is not None else None,
@@ -176,7 +198,7 @@ def get_experience_scores(recommendations, n_items):
 
 def evaluate(recommendations, holdout_user, holdout_item, holdout_fdbk, n_items, metric_type='all', topk=None,
              not_rated_penalty=None, switch_positive=None, ignore_feedback=False, simple_rates=False,
-             holdout_size=None, ndcg_alternative=True):
+             holdout_size=None, ndcg_alternative=True, device_ranks=None):
     """models.py:408-485 on arrays.  Returns the same namedtuples in the same order (relevance, ranking,
     experience, hits — whatever the order of `metric_type`); a single family returns the tuple itself."""
     if metric_type == 'all':
@@ -185,23 +207,33 @@ def evaluate(recommendations, holdout_user, holdout_item, holdout_fdbk, n_items,
         metric_type = ['relevance', 'ranking']
     if not isinstance(metric_type, (list, tuple)):
         metric_type = [metric_type]
-    recs = np.array(recommendations, copy=False, ndmin=2)[:, :topk]
+    if device_ranks is not None:
+        # device_ranks = (ranks [n_holdout], n_valid_recs [n_users], (n_users, topk), n_unique_items): everything
+        # the metrics need from a recommendation array that stayed on the device
+        ranks, n_valid, shape, n_unique = device_ranks
+        recs = None
+    else:
+        recs = np.array(recommendations, copy=False, ndmin=2)[:, :topk]
     if (switch_positive is None) or (holdout_fdbk is None):
         not_rated_penalty = 1 if not_rated_penalty is None else not_rated_penalty
         is_positive = None
     else:
         not_rated_penalty = not_rated_penalty or 0
         is_positive = np.asarray(holdout_fdbk) >= switch_positive
-    m = _Matched(recs, holdout_user, holdout_item, None if ignore_feedback else holdout_fdbk, is_positive)
+    if recs is None:
+        m = _Matched(shape, holdout_user, holdout_item, None if ignore_feedback else holdout_fdbk, is_positive,
+                     ranks=ranks, n_valid_recs=n_valid)
+    else:
+        m = _Matched(recs, holdout_user, holdout_item, None if ignore_feedback else holdout_fdbk, is_positive)
     single = (holdout_size == 1) or simple_rates
     scores = []
     if 'relevance' in metric_type:
         scores.append(get_hr_score(m) if single else get_relevance_scores(m, not_rated_penalty))
     if 'ranking' in metric_type:
         scores.append(get_rr_scores(m) if single else
-                      get_ranking_scores(m, recs.shape[1], switch_positive, ndcg_alternative))
+                      get_ranking_scores(m, m.topk, switch_positive, ndcg_alternative))
     if 'experience' in metric_type:
-        scores.append(get_experience_scores(recs, n_items))
+        scores.append(Experience(n_unique / n_items) if recs is None else get_experience_scores(recs, n_items))
     if 'hits' in metric_type:
         scores.append(get_hits(m, not_rated_penalty))
     if not scores:

@@ -58,6 +58,7 @@ class RecommenderModel:
     def __init__(self, recommender_data, feedback_threshold=None, ops=None, comm=None):
         self.data = recommender_data
         self._recommendations = None
+        self._recs_dev = None
         self.method = 'ABC'
         self._topk = get_default('topk')
         self._filter_seen = get_default('filter_seen')
@@ -273,9 +274,10 @@ class RecommenderModel:
             if hi > lo:
                 T = ops.csr_rows(T, lo, hi)
         stats = {}
+        recs_dev = None
         if hi > lo:
-            recs = scoring.recommend(ops, self._item_factors_device(), T, self.topk, self.filter_seen, stats=stats)
-            recs = ops.to_host(recs)
+            recs_dev = scoring.recommend(ops, self._item_factors_device(), T, self.topk, self.filter_seen, stats=stats)
+            recs = ops.to_host(recs_dev)
             if self._item_inv is not None:   # internal positions -> external item ids
                 recs = np.where(recs >= 0, self._item_inv[np.maximum(recs, 0)], -1).astype(np.int64)
         else:
@@ -283,6 +285,10 @@ class RecommenderModel:
         self.recommend_stats = stats
         if comm.world > 1:
             recs = comm.gather_rows(recs, n_users, self.topk)
+            recs_dev = None
+        # the device-resident list (internal item ids) stays available to evaluate(), keyed by the host array it
+        # belongs to: any cache invalidation replaces that array
+        self._recs_dev = (recs, recs_dev) if recs_dev is not None else None
         return recs
 
     def slice_recommendations(self, test_data, shape, start, stop, test_users=None):
@@ -320,12 +326,27 @@ class RecommenderModel:
             raise ValueError('evaluate() needs a holdout')
         if int(topk or 0) > self.topk:
             self.topk = topk                         # also flushes the cached recommendations (models.py:423-424)
-        recs = self.recommendations[:, :topk]
+        full = self.recommendations
+        recs = full[:, :topk]
         users, items, fdbk = holdout
         order = np.argsort(users, kind='stable')     # rows of `recommendations` follow the sorted test users
+        users, items = np.asarray(users)[order], np.asarray(items)[order]
         n_items = self.data.get_test_shape(tensor_mode=False)[1]
-        return evaluation.evaluate(recs, np.asarray(users)[order], np.asarray(items)[order],
+        device_ranks = None
+        cached = getattr(self, '_recs_dev', None)
+        if cached is not None and cached[0] is full and self._item_rank is not None:
+            # hit ranks straight from the device-resident list (pk_eval_ranks): only holdout-sized vectors and
+            # two counts per user leave the device
+            import torch
+            ops = self.ops
+            rd = cached[1][:, :topk].contiguous() if topk else cached[1]
+            row = np.r_[0, np.cumsum(np.diff(users) != 0)] if len(users) else np.zeros(0, np.int64)
+            ranks = ops.to_host(ops.eval_ranks(rd, ops.to_device(row.astype(np.int64)),
+                                               ops.to_device(self._item_rank[items.astype(np.intp)].astype(np.int64))))
+            device_ranks = (ranks, ops.to_host((rd >= 0).sum(dim=1)), tuple(rd.shape), int(torch.unique(rd).numel()))
+        return evaluation.evaluate(recs, users, items,
                                    None if fdbk is None else np.asarray(fdbk)[order], n_items,
+                                   device_ranks=device_ranks,
                                    metric_type=metric_type, not_rated_penalty=not_rated_penalty,
                                    switch_positive=switch_positive or self.switch_positive,
                                    ignore_feedback=ignore_feedback, simple_rates=simple_rates,

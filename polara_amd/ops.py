@@ -550,6 +550,17 @@ class HipOps:
                    'pk_score_exact_rows_f64')
         return out_idx, out_s
 
+    def eval_ranks(self, recs, hold_row, hold_item):
+        """int32 [n_holdout]: 1-based rank of every holdout item in its user's row of the device-resident
+        recommendation array (0 = not recommended)."""
+        assert recs.dtype == torch.int64 and recs.is_contiguous()
+        hr = hold_row.to(device=self.device, dtype=torch.int64).contiguous()
+        hi = hold_item.to(device=self.device, dtype=torch.int64).contiguous()
+        out = torch.empty(hr.numel(), dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.pk_eval_ranks(self.stream(), hr.numel(), _ptr(recs), recs.shape[1], _ptr(hr), _ptr(hi),
+                                          _ptr(out)), 'pk_eval_ranks')
+        return out
+
     def dense_scores(self, V, E):
         n_rows, K = E.shape
         n_items = V.shape[0]

@@ -277,5 +277,10 @@ class NumpyOps:
             out_s[r, :len(order)] = s[order]
         return torch.from_numpy(out_idx), torch.from_numpy(out_s)
 
+    def eval_ranks(self, recs, hold_row, hold_item):
+        r, hr, hi = recs.numpy(), hold_row.numpy(), hold_item.numpy()
+        match = r[hr] == hi[:, None]
+        return torch.from_numpy(np.where(match.any(1), match.argmax(1) + 1, 0).astype(np.int32))
+
     def dense_scores(self, V, E):
         return E @ V.t()

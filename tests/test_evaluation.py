@@ -92,3 +92,52 @@ def test_model_evaluate_without_polara():
     rel, rank = m.evaluate('main')
     assert np.isclose(rel.precision, g['metric_Relevance_precision'], rtol=1e-13)
     assert np.isclose(rank.map, g['metric_Ranking_map'], rtol=1e-13) and np.isclose(rank.arhr, g['metric_Ranking_arhr'], rtol=1e-13)
+
+
+def _model_on_arrays(g, ops):
+    from polara_amd.data import ArrayData
+    from polara_amd.models import SVDModel
+    idx = g['train_idx']
+    shp = tuple(int(x) for x in g['train_shape'])
+    hold = (g['holdout_user'], g['holdout_item'], g['holdout_fdbk'])
+    d = ArrayData((idx[:, 0], idx[:, 1], g['train_val']), n_users=shp[0], n_items=shp[1], holdout=hold,
+                  warm_start=False, holdout_size=3)
+    m = SVDModel(d, ops=ops)
+    m.verbose = False
+    m.rank, m.topk = int(g['rank']), int(g['topk'])
+    return m
+
+
+def _check_device_ranks_path(ops):
+    """evaluate() after a real build + get_recommendations: the ranks come from the device-resident list
+    (pk_eval_ranks); every metric equals the host computation on the returned array, and the reference's."""
+    g = load_golden('svd_known')
+    m = _model_on_arrays(g, ops)
+    m.build()
+    recs = m.recommendations
+    assert m._recs_dev is not None and m._recs_dev[0] is recs
+    dev = m.evaluate('all')
+    order = np.argsort(g['holdout_user'], kind='stable')
+    host = ev.evaluate(recs, g['holdout_user'][order], g['holdout_item'][order], g['holdout_fdbk'][order],
+                       int(g['train_shape'][1]), holdout_size=3)
+    for a, b in zip(dev, host):
+        assert type(a).__name__ == type(b).__name__
+        for x, y in zip(a, b):
+            assert (x is None and y is None) or np.isclose(x, y, rtol=1e-14, atol=0), (type(a).__name__, x, y)
+    notie = g['boundary_gap'] > 0
+    if notie.all():
+        assert np.isclose(dev[3].true_positive, g['metric_Hits_true_positive'])
+    at5_dev, at5_host = m.evaluate('relevance', topk=5), ev.evaluate(recs, g['holdout_user'][order], g['holdout_item'][order],
+                                                                   g['holdout_fdbk'][order], int(g['train_shape'][1]),
+                                                                   metric_type='relevance', topk=5, holdout_size=3)
+    assert np.isclose(at5_dev.precision, at5_host.precision, rtol=1e-14)
+
+
+def test_model_evaluate_device_ranks_cpu_double():
+    from numpy_ops import NumpyOps
+    _check_device_ranks_path(NumpyOps())
+
+
+@pytest.mark.gpu
+def test_model_evaluate_device_ranks(hip_ops):
+    _check_device_ranks_path(hip_ops)
