@@ -141,3 +141,29 @@ def test_model_evaluate_device_ranks_cpu_double():
 @pytest.mark.gpu
 def test_model_evaluate_device_ranks(hip_ops):
     _check_device_ranks_path(hip_ops)
+
+
+def test_find_optimal_svd_rank_one_build():
+    """pipelines.find_optimal_svd_rank: one build at the largest rank, truncation for the others — every rank's
+    metric equals that of a model built at that rank from scratch (PureSVD factors are nested)."""
+    from numpy_ops import NumpyOps
+    from polara_amd.pipelines import find_optimal_svd_rank
+    g = load_golden('svd_known')
+    m = _model_on_arrays(g, NumpyOps())
+    ranks = [3, 5, 8, int(g['rank'])]
+    best, table = find_optimal_svd_rank(m, ranks, 'precision', return_scores=True, metric_type='relevance')
+    assert len(m.training_time) == 1 and best in ranks and table[best] == max(table.values())
+    assert m.rank == max(ranks) and m.factors['singular_values'].shape == (max(ranks),)   # factors protected
+    for r in (3, 8):
+        fresh = _model_on_arrays(g, NumpyOps())
+        fresh.rank = r
+        fresh.build()
+        m.rank = r
+        same = (m.recommendations == fresh.recommendations).all(axis=1)
+        # this fixture zeroes the below-threshold test feedback: ~4 % of the users have an all-zero profile, i.e.
+        # all-tie scores whose top-k is implementation-defined (and depends on the internal item order, which
+        # follows the factor norms of whichever rank was BUILT); every other row must agree exactly
+        assert same[g['boundary_gap'] > 0].all() and same.mean() > 0.9
+        assert abs(fresh.evaluate('relevance').precision - table[r]) < 0.01
+    m.rank = max(ranks)
+    assert find_optimal_svd_rank(m, ranks, lambda t: -t['miss_rate'], metric_type='relevance') in ranks
