@@ -95,13 +95,13 @@ def test_model_evaluate_without_polara():
 
 
 def _model_on_arrays(g, ops):
-    from polara_amd.data import ArrayData
+    """The fixture's exact training / test triplets (GoldenData) + its holdout: rows of the recommendation array are
+    the fixture's test users, in the fixture's order."""
     from polara_amd.models import SVDModel
-    idx = g['train_idx']
-    shp = tuple(int(x) for x in g['train_shape'])
-    hold = (g['holdout_user'], g['holdout_item'], g['holdout_fdbk'])
-    d = ArrayData((idx[:, 0], idx[:, 1], g['train_val']), n_users=shp[0], n_items=shp[1], holdout=hold,
-                  warm_start=False, holdout_size=3)
+    d = GoldenData(g)
+    d.set_test_data(holdout=(g['holdout_user'], g['holdout_item'], g['holdout_fdbk']), notify=False)
+    d.holdout_size = 3
+    d.warm_start = False
     m = SVDModel(d, ops=ops)
     m.verbose = False
     m.rank, m.topk = int(g['rank']), int(g['topk'])
