@@ -366,7 +366,8 @@ extern "C" int pk_fold_rows_f64(void *stream, int64_t cap, const int32_t *list_d
                                 const void *vals_dev, int val_kind, const double *V_dev, int64_t ldv, int32_t K,
                                 double *E_dev, int64_t lde) {
     PK_REQUIRE(cap >= 1 && K >= 1 && K <= 256 && ldv >= K && lde >= K, "pk_fold_rows_f64: bad sizes");
-    PK_REQUIRE(list_dev && count_dev && indptr_dev && indices_dev && vals_dev, "pk_fold_rows_f64: bad pointers");
+    // indices_dev / vals_dev may be NULL for a matrix without entries (never dereferenced then)
+    PK_REQUIRE(list_dev && count_dev && indptr_dev, "pk_fold_rows_f64: bad pointers");
     dim3 grid((unsigned)(cap < PK_FOLD_BLOCKS ? cap : PK_FOLD_BLOCKS)), block(256);
     PK_REQUIRE(val_kind == PK_VAL_F32 || val_kind == PK_VAL_F64, "pk_fold_rows_f64: bad val_kind %d", val_kind);
     const int cpl = (K + 63) / 64;

@@ -837,7 +837,8 @@ extern "C" int32_t pk_seen_tiles_max_unsorted_row(void) { return PK_SEEN_CAP; }
 extern "C" int pk_seen_tiles_build(void *stream, int64_t n_users, const int64_t *seen_ptr_dev,
                                    const int32_t *seen_idx_dev, int32_t rows_sorted, int64_t max_row_len,
                                    uint64_t *tiles_dev, int32_t *ntiles_dev) {
-    PK_REQUIRE(n_users >= 1 && seen_ptr_dev && seen_idx_dev && tiles_dev && ntiles_dev, "pk_seen_tiles_build: bad arguments");
+    // seen_idx_dev / tiles_dev may be NULL when the matrix has no entry at all (never dereferenced then)
+    PK_REQUIRE(n_users >= 1 && seen_ptr_dev && ntiles_dev, "pk_seen_tiles_build: bad arguments");
     dim3 grid((unsigned)pk_ceil_div(n_users, 4)), block(256);
     unsigned long long *tiles = reinterpret_cast<unsigned long long *>(tiles_dev);
     if (rows_sorted) {
