@@ -65,12 +65,38 @@ def _whiten(ops, X, V_lock=None, passes=2):
     return X
 
 
-def orthonormalize(ops, X, V_lock=None):
+def _refill(ops, X, V_lock, seed):
+    """Orthonormal block of the same width from a numerically RANK-DEFICIENT X (e.g. more vectors asked for
+    than the matrix has rank: the filtered copies of null-space directions are pure rounding noise inside the
+    range): an orthonormal basis of the numerical range of X (eigen-whitening, directions below 1e-10 of the
+    largest dropped) completed by fresh random vectors orthogonal to it and to V_lock."""
+    n, l = X.shape
+    if V_lock is not None and V_lock.shape[1] > 0:
+        X = _project_out(ops, X, V_lock)
+    lam, Cm = ops.eigh_psd(ops.gram(X))
+    lam_h = ops.to_host(lam)
+    ng = int((lam_h > lam_h[0] * 1e-20).sum()) if lam_h[0] > 0 else 0
+    parts = []
+    if ng:
+        Cs = ops.scale_cols(Cm[:, :ng].contiguous(), torch.rsqrt(lam[:ng]))
+        parts.append(_whiten(ops, ops.tsmm(X, Cs), V_lock, passes=1))
+    if ng < l:
+        R = ops.randn(n, l - ng, seed)
+        for _ in range(2):
+            if parts:
+                R = _project_out(ops, R, parts[0])
+            R = _whiten(ops, R, V_lock, passes=1)
+        parts.append(R)
+    return parts[0] if len(parts) == 1 else torch.cat(parts, dim=1).contiguous()
+
+
+def orthonormalize(ops, X, V_lock=None, seed=12345):
     """Orthonormal basis of span(X), orthogonal to V_lock.  Shifted CholeskyQR3: X <- X R^-1 with
     G + s I = R^T R three times (shift s = 11 (m l + l (l + 1)) u trace(G) on the first pass only), each
     pass one Gram matrix, one l x l Cholesky kernel and one tall-skinny GEMM — the filtered blocks have a
-    condition number up to the filter spread (1e7), which the shifted first pass is made for.  A block that
-    is numerically rank-deficient (non-positive pivot) falls back to the eigen-whitening."""
+    condition number up to the filter spread (1e7), which the shifted first pass is made for.  The result is
+    verified (||Y^T Y - I||): a block that is numerically rank-deficient — a Cholesky pivot breaks down, or the
+    three passes end without an orthonormal block — is rebuilt by `_refill`."""
     m, l = X.shape
     u = 1.1102230246251565e-16
     info = torch.zeros(3, dtype=torch.int32, device=X.device)
@@ -81,8 +107,10 @@ def orthonormalize(ops, X, V_lock=None):
         G = ops.gram(Y)
         Rinv, _ = ops.chol_rinv(G, 11.0 * (m * l + l * (l + 1)) * u if p == 0 else 0.0, info=info[p:p + 1])
         Y = ops.tsmm(Y, Rinv)
-    if int(info.abs().sum().item()) != 0:
-        return _whiten(ops, X, V_lock)
+    G = ops.gram(Y)
+    err = (G - torch.eye(l, dtype=G.dtype, device=G.device)).abs().max()
+    if int(info.abs().sum().item()) != 0 or not (float(err.item()) < 1e-8):
+        return _refill(ops, X, V_lock, seed)
     return Y
 
 
@@ -194,7 +222,7 @@ def svd_topk(ops, A, k, block=None, tol=1e-12, max_outer=200, m_max=24, spread=1
                                   -sigma * sigma_new, Xc)
                 Xc, Yc = Yc, Yn
                 sigma = sigma_new
-        X = orthonormalize(ops, Yc, V_lock)
+        X = orthonormalize(ops, Yc, V_lock, seed=seed + 1 + it)
     else:
         # not converged: return the best available (flagged in stats)
         take = min(k - n_lock, X.shape[1])

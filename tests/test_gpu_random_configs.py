@@ -80,3 +80,51 @@ def test_random_config_against_brute_force(hip_ops, cfg):
         assert np.array_equal(ids[u][firm], want[u][firm]), (cfg, u, ids[u], want[u])
         assert np.array_equal(ids2[u][firm], want[u][firm]), (cfg, u)
         assert np.allclose(sc[u][firm], ref_s[firm], rtol=1e-11, atol=1e-13 * scale), (cfg, u)
+
+
+def _svd_configs():
+    rng = np.random.RandomState(77)
+    out = []
+    for i in range(14):
+        n_items = int(rng.choice([12, 40, 130, 500, 1500]))
+        n_users = int(rng.choice([n_items, 3 * n_items, 2000]))
+        k = int(rng.choice([1, 3, 10, 25, 50]))
+        out.append(dict(seed=i, n_users=max(n_users, n_items), n_items=n_items, k=min(k, n_items - 1 if i % 3 else n_items),
+                        density=float(rng.choice([0.02, 0.1, 0.5])), kind=str(rng.choice(['plain', 'lowrank', 'dupcols']))))
+    return out
+
+
+@pytest.mark.parametrize('cfg', _svd_configs(), ids=lambda c: 'm%d_n%d_k%d_%s_s%d' % (c['n_users'], c['n_items'], c['k'], c['kind'], c['seed']))
+def test_random_svd_build_against_dense_svd(hip_ops, cfg):
+    """svd_topk on small random matrices — incl. k = n_items, numerically rank-deficient and duplicated-column
+    inputs (clustered / repeated singular values) — against NumPy's dense SVD: singular values to 1e-10 relative,
+    and the computed V spans an invariant subspace (||A^T A V - V diag(s^2)|| small)."""
+    from polara_amd.solver import svd_topk
+    rng = np.random.RandomState(1000 + cfg['seed'])
+    m, n, k = cfg['n_users'], cfg['n_items'], cfg['k']
+    A = sps.random(m, n, density=cfg['density'], random_state=rng, format='csr', data_rvs=lambda s: rng.randint(1, 6, s).astype(np.float64))
+    if cfg['kind'] == 'lowrank':
+        r = max(1, min(n // 3, 20))
+        B = (rng.rand(m, r) < 0.3) * rng.randint(1, 4, (m, r))
+        C = (rng.rand(r, n) < 0.3) * 1.0
+        A = sps.csr_matrix((B @ C).astype(np.float64))
+    elif cfg['kind'] == 'dupcols' and n >= 4:
+        D = A.toarray()
+        D[:, n // 2:n // 2 + n // 4] = D[:, :n // 4]            # repeated columns: repeated singular values / null space
+        A = sps.csr_matrix(D)
+    A.sort_indices()
+    if A.nnz == 0:
+        pytest.skip('empty draw')
+    T = hip_ops.csr(A.indptr.astype(np.int64), A.indices.astype(np.int32), A.data, (m, n))
+    _, sigma, V, st = svd_topk(hip_ops, T, k)
+    sigma, V = hip_ops.to_host(sigma), hip_ops.to_host(V)
+    ref = np.linalg.svd(A.toarray(), compute_uv=False)[:k]
+    assert st['converged'], st
+    big = ref > 1e-6 * ref[0]
+    assert np.allclose(sigma[big], ref[big], rtol=1e-10, atol=0), (sigma[:5], ref[:5])
+    # singular values in the numerical null space come out of the Gramian as sqrt(rounding of sigma_1^2): O(1e-8 sigma_1),
+    # for this solver as for the reference's ARPACK-on-A^T A (svds)
+    assert np.all(np.abs(sigma[~big]) < 1e-6 * ref[0])
+    assert np.abs(V.T @ V - np.eye(k)).max() < 1e-9
+    G = A.T @ (A @ V)
+    assert np.abs(G - V * sigma ** 2).max() <= 1e-9 * ref[0] ** 2
