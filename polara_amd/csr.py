@@ -101,7 +101,7 @@ def nnz_balanced_row_partition(indptr, parts):
     return np.maximum.accumulate(bounds)
 
 
-def popularity_order(cols, n_items):
+def popularity_order(cols, n_items, counts=None):
     """Internal item order of the device path: items by DESCENDING interaction count (ties by id).
 
     Why: the fused scoring kernel sweeps the catalogue once per user group keeping a running top-k
@@ -109,9 +109,12 @@ def popularity_order(cols, n_items):
     the first few percent of the sweep, and the users' seen items — mostly popular ones — cluster in
     the first tiles, so the candidate-push and seen-mask paths go quiet for the rest of the sweep.
     Pure relabelling: factors and recommendations are mapped back to external ids by the model layer.
+    `counts`: the per-item interaction counts when the caller already has them (a user-sharded dataset sums
+    them over ranks first, so that every rank derives the same order); `cols` is ignored then.
     Returns (rank int32[n_items]: external id -> internal position, inv int32[n_items]: internal -> external).
     """
-    counts = np.bincount(np.asarray(cols, dtype=np.int64), minlength=n_items)
+    if counts is None:
+        counts = np.bincount(np.asarray(cols, dtype=np.int64), minlength=n_items)
     inv = np.argsort(-counts, kind='stable').astype(np.int32)
     rank = np.empty(n_items, dtype=np.int32)
     rank[inv] = np.arange(n_items, dtype=np.int32)

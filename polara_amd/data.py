@@ -165,3 +165,47 @@ class ArrayData:
         if tensor_mode:
             shape = shape + (len(self._levels()),)
         return shape
+
+
+class ShardedArrayData(ArrayData):
+    """One rank's row block of a user-sharded dataset (polara_amd/shards.py).
+
+    User ids are LOCAL (0 .. hi-lo); `user_range = (lo, hi)` places the block among `n_users_total` users.
+    A model built on it with the job's communicator factorizes the WHOLE matrix (item factors, singular values
+    and — for CoFFee — feedback factors and core are global and identical on every rank) while everything
+    per-user stays with the rank that owns the user: the user-factor rows, `get_recommendations()` and
+    `evaluate()` cover the local users only (nothing of size n_users x topk is gathered; sum the hit counts
+    over ranks for job-wide metrics).  score_all=True makes every local user a test user with its training
+    row as the known preferences (the reference's `test_ratio=0, warm_start=False` state with the holdout
+    users' rows recovered from training, data.py:820-832)."""
+
+    def __init__(self, block, n_users_total, feedback_levels=None, score_all=True, holdout=None,
+                 fields=('userid', 'itemid', 'rating')):
+        indptr = np.asarray(block.indptr, dtype=np.int64)
+        u = np.repeat(np.arange(block.n_rows, dtype=np.int64), np.diff(indptr))
+        i = np.asarray(block.indices, dtype=np.int64)
+        f = np.ones(len(i)) if block.values is None else np.asarray(block.values, dtype=np.float64)
+        self.user_range = (int(block.row_lo), int(block.row_hi))
+        self.n_users_total = int(n_users_total)
+        self.local_csr = block
+        self._fixed_levels = None if feedback_levels is None else np.asarray(feedback_levels, dtype=np.float64)
+        super().__init__((u, i, f), n_users=block.n_rows, n_items=block.n_cols,
+                         test=(u, i, f) if score_all else None, holdout=holdout, fields=fields)
+
+    @classmethod
+    def from_shards(cls, path, rank=0, world=1, **kwargs):
+        """The block of rank `rank` of `world` from a dataset directory written by shards.write_csr_shards /
+        ShardWriter."""
+        from .shards import load_rank_block
+        block, manifest = load_rank_block(path, rank, world)
+        kwargs.setdefault('feedback_levels', manifest.get('feedback_levels'))
+        return cls(block, manifest['n_rows'], **kwargs)
+
+    def set_training_data(self, training):
+        raise NotImplementedError('a shard is immutable: write a new dataset (polara_amd.shards) instead')
+
+    def _levels(self):
+        # the SAME level set on every rank (a block need not contain every level)
+        if self._fixed_levels is not None:
+            return self._fixed_levels
+        return super()._levels()

@@ -242,6 +242,26 @@ class RecommenderModel:
         if feedback is not None and f.get(feedback, None) is not None:
             assert f[feedback].shape[0] == self.data.get_test_shape(tensor_mode=True)[2]
 
+    # ---- user-sharded datasets (data.ShardedArrayData) --------------------------------------------------
+    def _presharded(self):
+        """True when the data object is one rank's row block of a larger dataset: the model then never
+        partitions or gathers anything per-user itself."""
+        rng = getattr(self.data, 'user_range', None)
+        if rng is None:
+            return False
+        if self.comm.world == 1 and tuple(rng) != (0, self.data.n_users_total):
+            raise ValueError('users %d..%d of %d: a row block of a sharded dataset needs the communicator of its job'
+                             % (rng[0], rng[1], self.data.n_users_total))
+        return True
+
+    def _item_counts(self, cols, n_items):
+        """Interactions per item over the WHOLE dataset (summed over ranks for a sharded one): every rank must
+        derive the same internal item order."""
+        counts = np.bincount(np.asarray(cols, dtype=np.int64), minlength=n_items).astype(np.int64)
+        if self._presharded() and self.comm.world > 1:
+            counts = self.ops.to_host(self.comm.allreduce(self.ops.to_device(counts)))
+        return counts
+
     # ---- recommend pipeline (models.py:359-405) ----------------------------------------------------------
     def _item_factors_device(self):
         """FactorImage of the item factors in INTERNAL item order (rebuilt from `factors` when the
@@ -268,7 +288,8 @@ class RecommenderModel:
         cols = test_data[1] if self._item_rank is None else self._item_rank[np.asarray(test_data[1], dtype=np.intp)]
         T = ops.csr_from_coo(test_data[0], cols, vals, (n_users, n_items))   # zeros kept: still "seen"
         lo, hi = 0, n_users
-        if comm.world > 1:  # user-sharded scoring; V is replicated, no collective in the data path
+        gather = comm.world > 1 and not self._presharded()   # a pre-sharded dataset: T already is this rank's users
+        if gather:  # user-sharded scoring; V is replicated, no collective in the data path
             bounds = nnz_balanced_row_partition(ops.to_host(T.indptr), comm.world)
             lo, hi = int(bounds[comm.rank]), int(bounds[comm.rank + 1])
             if hi > lo:
@@ -283,7 +304,7 @@ class RecommenderModel:
         else:
             recs = np.empty((0, self.topk), dtype=np.int64)
         self.recommend_stats = stats
-        if comm.world > 1:
+        if gather:
             recs = comm.gather_rows(recs, n_users, self.topk)
             recs_dev = None
         # the device-resident list (internal item ids) stays available to evaluate(), keyed by the host array it
@@ -394,14 +415,25 @@ class SVDModel(RecommenderModel):
 
     def _training_device_csr(self):
         """The training matrix as a device CSR (COO -> CSR on device, models.py:160-177)."""
+        blk = getattr(self.data, 'local_csr', None)
+        if blk is not None and self.feedback_threshold is None:
+            # a block of an on-disk CSR dataset (polara_amd/shards.py): the arrays go to the device as they lie
+            # in the file, the internal item order is a renaming on the device — no COO, no sort
+            shp = (blk.n_rows, blk.n_cols)
+            self._item_rank, self._item_inv = popularity_order(None, shp[1], counts=self._item_counts(blk.indices, shp[1]))
+            values = np.ones(blk.nnz, dtype=np.float32) if blk.values is None else blk.values
+            return self.ops.csr_relabel_cols(self.ops.csr(blk.indptr, blk.indices, values, shp), self._item_rank)
         idx, val, shp = self.data.to_coo(tensor_mode=False, feedback_threshold=self.feedback_threshold)
-        self._item_rank, self._item_inv = popularity_order(idx[:, 1], shp[1])
+        self._item_rank, self._item_inv = popularity_order(None, shp[1], counts=self._item_counts(idx[:, 1], shp[1]))
         return self.ops.csr_from_coo(idx[:, 0], self._item_rank[idx[:, 1]], np.asarray(val, dtype=np.float64), shp)
 
     def _local_training_shard(self):
         A = self._training_device_csr()
         n_users = A.shape[0]
         comm = self.comm
+        if self._presharded():
+            lo, hi = self.data.user_range
+            return A, (int(lo), int(hi), int(self.data.n_users_total))
         if comm.world > 1:
             bounds = nnz_balanced_row_partition(self.ops.to_host(A.indptr), comm.world)
             lo, hi = int(bounds[comm.rank]), int(bounds[comm.rank + 1])
@@ -435,7 +467,7 @@ class SVDModel(RecommenderModel):
         user_factors = None
         if want_u:
             user_factors = ops.to_host(U)
-            if self.comm.world > 1:
+            if self.comm.world > 1 and not self._presharded():   # pre-sharded: the rows of the local users
                 user_factors = self.comm.gather_rows(user_factors, n_users, self.rank, dtype=np.float64)
         item_factors = None
         if return_factors in (True, 'vh'):
@@ -490,7 +522,7 @@ class ScaledMatrixMixin:
     def _training_csr(self, dtype=np.float64, ignore_feedback=False):
         indptr, indices, values, shp = super()._training_csr(dtype=dtype, ignore_feedback=ignore_feedback)
         row_nnz = np.diff(indptr).astype(np.float64)
-        col_nnz = np.bincount(indices, minlength=shp[1]).astype(np.float64)
+        col_nnz = self._item_counts(indices, shp[1]).astype(np.float64)
         rs = np.ones_like(row_nnz)
         cs = np.ones_like(col_nnz)
         np.power(np.sqrt(row_nnz), self.row_scaling - 1, where=row_nnz != 0, out=rs)
@@ -500,7 +532,7 @@ class ScaledMatrixMixin:
 
     def _training_device_csr(self):
         indptr, indices, values, shp = self._training_csr(dtype=np.float64)
-        self._item_rank, self._item_inv = popularity_order(indices, shp[1])
+        self._item_rank, self._item_inv = popularity_order(None, shp[1], counts=self._item_counts(indices, shp[1]))
         return self.ops.csr_relabel_cols(self.ops.csr(indptr, indices, values, shp), self._item_rank)
 
 
@@ -602,11 +634,16 @@ class CoffeeModel(RecommenderModel):
         """models.py:1009-1024."""
         idx, val, shp = self.data.to_coo(tensor_mode=True)
         ops, comm = self.ops, self.comm
-        self._item_rank, self._item_inv = popularity_order(idx[:, 1], shp[1])
+        self._item_rank, self._item_inv = popularity_order(None, shp[1], counts=self._item_counts(idx[:, 1], shp[1]))
         idx = idx.copy()
         idx[:, 1] = self._item_rank[idx[:, 1]]
         user_range = None
-        if comm.world > 1:
+        presharded = self._presharded()
+        if presharded:
+            # the data object already is this rank's users (ids re-based to 0): only the shape is global
+            user_range = tuple(int(x) for x in self.data.user_range)
+            shp = (int(self.data.n_users_total),) + tuple(shp[1:])
+        elif comm.world > 1:
             # users are sharded in nnz-balanced contiguous blocks; items / feedback factors replicated
             order = np.argsort(idx[:, 0], kind='stable')
             idx, val = idx[order], val[order]
@@ -628,7 +665,7 @@ class CoffeeModel(RecommenderModel):
         self.core_norm_trace = trace
         userid, itemid, feedback = self.data.fields
         u0_host = ops.to_host(u0)
-        if comm.world > 1:
+        if comm.world > 1 and not presharded:
             u0_host = comm.gather_rows(u0_host, shp[0], u0_host.shape[1], dtype=np.float64)
         self.factors[userid] = u0_host
         self.factors[itemid] = np.ascontiguousarray(ops.to_host(u1)[self._item_rank])   # external item order

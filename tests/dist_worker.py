@@ -15,6 +15,54 @@ from polara_amd.dist import init_from_env
 from polara_amd.models import SVDModel, CoffeeModel
 
 
+def presharded(comm):
+    """On-disk CSR shards (polara_amd/shards.py): rank 0 writes a 3-shard dataset, every rank maps its own run of
+    shards and builds on it; global factors must equal those of the single-process model of the whole matrix,
+    per-user outputs must be that model's rows of the local users."""
+    import tempfile
+    import torch.distributed as dist
+    from polara_amd import shards
+    from polara_amd.data import ShardedArrayData
+    from polara_amd.models import ScaledSVD
+    from polara_amd.synth import planted_csr, csr_to_numpy
+    c = csr_to_numpy(planted_csr(260, 70, mean_items=14, rank=4, seed=21, min_items=1, max_items=40))
+    box = [tempfile.mkdtemp(prefix='pkcsr_') if comm.rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    path = os.path.join(box[0], 'ds')
+    if comm.rank == 0:
+        shards.write_csr_shards(path, c['indptr'], c['indices'], c['values'], c['shape'][1], 3, value_dtype=np.float64)
+    comm.barrier()
+    local = ShardedArrayData.from_shards(path, comm.rank, comm.world)
+    whole = ShardedArrayData.from_shards(path)              # the single-process model of the same dataset
+    lo, hi = local.user_range
+    out = {}
+    for cls, cfg in ((SVDModel, dict(rank=5)), (ScaledSVD, dict(rank=5)), (CoffeeModel, dict(mlrank=(4, 4, 3), seed=1))):
+        res = []
+        for data, cm in ((local, comm), (whole, None)):
+            m = cls(data, ops=NumpyOps(), comm=cm)
+            m.verbose = False
+            for k, v in cfg.items():
+                setattr(m, k, v)
+            m.topk = 6
+            if cls is CoffeeModel:
+                m.build()
+            else:
+                m.build(return_factors=True)
+            res.append((m, m.get_recommendations()))
+        (ml, rl), (mw, rw) = res
+        f = local.fields
+        Vl, Vw = ml.factors[f.itemid], mw.factors[f.itemid]
+        Ul, Uw = ml.factors[f.userid], mw.factors[f.userid]
+        ok = Ul.shape[0] == hi - lo and np.abs(Vl @ Vl.T - Vw @ Vw.T).max() < 1e-8
+        ok = ok and np.abs(Ul @ Vl.T[:Ul.shape[1]] - Uw[lo:hi] @ Vw.T[:Uw.shape[1]]).max() < 1e-8 if cls is not CoffeeModel else ok
+        # local lists = the whole model's rows of the local users (both cover the users with >= 1 interaction, in order)
+        present = np.flatnonzero(np.diff(c['indptr']) > 0)
+        sel = (present >= lo) & (present < hi)
+        ok = ok and rl.shape == (int(sel.sum()), 6) and np.array_equal(rl, rw[sel])
+        out['presharded_' + cls.__name__] = bool(ok)
+    return out
+
+
 def main():
     comm = init_from_env(backend='gloo')
     out = {}
@@ -49,6 +97,7 @@ def main():
         notie = g['boundary_gap'] > 0
         out[name] = bool(proj_ok and np.allclose(m.core_norm_trace, g['core_norm_trace'], rtol=1e-9)
                           and np.array_equal(m.get_recommendations()[notie], g['recs'][notie]))
+    out.update(presharded(comm))
     comm.barrier()
     if comm.rank == 0:
         print('DIST_RESULT', out)

@@ -275,3 +275,31 @@ def test_build_with_linear_operator_on_device_solver(hip_ops):
     top = -np.sort(-scores, axis=1)[:, :m.topk + 1]
     clear = (np.diff(-top, axis=1) > 1e-9 * np.abs(top[:, :1])).all(axis=1)
     assert clear.mean() > 0.5 and np.array_equal(m.recommendations[clear], want[clear])
+
+
+def test_presharded_dataset_on_device(hip_ops, tmp_path):
+    """On-disk CSR shards -> mapped arrays -> DeviceCSR (no COO): same factors and lists as the triplet route,
+    with and without stored values, and against the oracle."""
+    from polara_amd import shards
+    from polara_amd.data import ShardedArrayData
+    c = csr_to_numpy(planted_csr(3000, 700, mean_items=30, rank=8, seed=31, min_items=1, max_items=120))
+    u = np.repeat(np.arange(c['shape'][0]), np.diff(c['indptr']))
+    for vdt in (np.float32, None):
+        path = str(tmp_path / ('ds_%s' % (vdt.__name__ if vdt else 'ones')))
+        vals = c['values'] if vdt else np.ones(len(c['indices']), dtype=np.float32)
+        shards.write_csr_shards(path, c['indptr'], c['indices'], c['values'] if vdt else None, c['shape'][1], 4, value_dtype=vdt)
+        sd = ShardedArrayData.from_shards(path)
+        ad = ArrayData((u, c['indices'], vals), n_users=c['shape'][0], n_items=c['shape'][1], test=(u, c['indices'], vals))
+        res = []
+        for data in (sd, ad):
+            m = SVDModel(data, ops=hip_ops)
+            m.verbose = False
+            m.rank, m.topk = 12, 10
+            m.build()
+            res.append((m.factors['singular_values'], m.factors[data.fields.itemid], m.get_recommendations()))
+        assert np.allclose(res[0][0], res[1][0], rtol=1e-12)
+        assert np.abs(res[0][1] @ res[0][1].T - res[1][1] @ res[1][1].T).max() < 1e-9
+        assert np.array_equal(res[0][2], res[1][2])
+        A = sps.csr_matrix((vals.astype(np.float64), c['indices'], c['indptr']), shape=c['shape'])
+        _, s_ref, Vt = orc.svd_build(A, 12)
+        assert np.allclose(res[0][0], s_ref, rtol=1e-9)
