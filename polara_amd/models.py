@@ -12,7 +12,7 @@ from timeit import default_timer as timer
 import numpy as np
 
 from . import defaults
-from .operator import HostOperator
+from .operator import DeviceChain, HostOperator, SparseProduct
 from .csr import coo_to_csr, nnz_balanced_row_partition, popularity_order
 from .solver import svd_topk, NoComm
 from . import scoring
@@ -441,9 +441,10 @@ class SVDModel(RecommenderModel):
         return A, (0, n_users, n_users)
 
     def build(self, operator=None, return_factors='vh'):
-        """models.py:835-855.  `operator`: a SciPy LinearOperator used INSTEAD of the training matrix
-        (models.py:838-839; HybridSVD passes L_K^T A L_S) — its products run on the host, the block solver
-        around them on the device (polara_amd/operator.py); single process only."""
+        """models.py:835-855.  `operator` is used INSTEAD of the training matrix (models.py:838-839; HybridSVD
+        passes L_K^T A L_S): a SciPy sparse matrix or an `operator.SparseProduct` of sparse factors lives on
+        the device and the whole build runs there; any other LinearOperator's products run on the host with
+        the block solver around them on the device (polara_amd/operator.py).  Single process only."""
         ops = self.ops
         if operator is not None:
             if self.comm.world > 1:
@@ -452,7 +453,14 @@ class SVDModel(RecommenderModel):
             if tuple(operator.shape)[1] != shp[1]:
                 raise ValueError('operator has %d columns, the data %d items' % (operator.shape[1], shp[1]))
             self._item_rank, self._item_inv = popularity_order(idx[:, 1], shp[1])
-            A = HostOperator(ops, operator, col_perm=self._item_rank)
+            if hasattr(operator, 'tocsr'):          # a sparse matrix: one device CSR
+                operator = SparseProduct(operator)
+            if isinstance(operator, SparseProduct):
+                A = DeviceChain.from_scipy(ops, operator, col_perm=self._item_rank)
+                if len(A.factors) == 1:
+                    A = A.factors[0]
+            else:
+                A = HostOperator(ops, operator, col_perm=self._item_rank)
             lo, hi, n_users = 0, A.shape[0], A.shape[0]
         else:
             A, (lo, hi, n_users) = self._local_training_shard()

@@ -12,7 +12,6 @@ import numpy as np
 import torch
 
 from . import _lib
-from .operator import HostOperator
 from .csr import build_row_tasks, SPLIT_NNZ
 
 
@@ -284,7 +283,7 @@ class HipOps:
         or fp32 (the fp32 image of the item factors for the approximate fold-in).
         rows=(lo, hi): only rows [lo, hi) are computed (written to the same rows of the FULL-height `out`):
         the tasks of a row range are a contiguous slice of the plan, so a user batch is its own launch."""
-        if isinstance(A, HostOperator):   # build(operator=...): host LinearOperator, models.py:835-844
+        if hasattr(A, 'apply'):   # build(operator=...): a chain of device matrices or a host LinearOperator (operator.py)
             return A.apply(X, out)
         assert X.dtype in (torch.float64, torch.float32) and X.stride(-1) == 1 and X.shape[0] == A.shape[1]
         nc = X.shape[1]

@@ -76,8 +76,7 @@ class NumpyOps:
         return torch.randn(n, m, generator=g, dtype=torch.float64)
 
     def spmm(self, A, X, out=None, rows=None):
-        from polara_amd.operator import HostOperator
-        if isinstance(A, HostOperator):
+        if hasattr(A, 'apply'):
             return A.apply(X, out)
         r = torch.from_numpy(np.ascontiguousarray(A.m @ X.numpy().astype(np.float64)))
         if out is not None:

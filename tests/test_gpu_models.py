@@ -303,3 +303,41 @@ def test_presharded_dataset_on_device(hip_ops, tmp_path):
         A = sps.csr_matrix((vals.astype(np.float64), c['indices'], c['indptr']), shape=c['shape'])
         _, s_ref, Vt = orc.svd_build(A, 12)
         assert np.allclose(res[0][0], s_ref, rtol=1e-9)
+
+
+def test_build_with_device_resident_operator_product(hip_ops):
+    """build(operator=SparseProduct(L_K^T, A, L_S)) / operator=<sparse matrix>: factors on the device, the chain
+    of SpMMs as the operator (the device form of hybrid/models.py:357-381), against svds of the product."""
+    from scipy.sparse.linalg import svds
+    from polara_amd.operator import SparseProduct
+    c = csr_to_numpy(planted_csr(2500, 600, mean_items=25, rank=8, seed=41, min_items=1, max_items=100))
+    u = np.repeat(np.arange(c['shape'][0]), np.diff(c['indptr']))
+    data = ArrayData((u, c['indices'], c['values']), n_users=c['shape'][0], n_items=c['shape'][1],
+                     test=(u, c['indices'], c['values']))
+    A = sps.csr_matrix((c['values'].astype(np.float64), c['indices'], c['indptr']), shape=c['shape'])
+    rng = np.random.RandomState(7)
+    Ls = (sps.eye(600) + 0.3 * sps.tril(sps.random(600, 600, 0.02, random_state=rng), -1)).tocsr()
+    Lk = (sps.eye(2500) + 0.3 * sps.tril(sps.random(2500, 2500, 0.004, random_state=rng), -1)).tocsr()
+    full = (Lk.T @ A @ Ls).tocsr()
+    uu, s, vt = svds(full, k=10)
+    order = np.argsort(-s)
+    recs = []
+    for op in (SparseProduct(Lk.T, A, Ls), full):
+        m = SVDModel(data, ops=hip_ops)
+        m.verbose = False
+        m.rank, m.topk = 10, 10
+        m.build(operator=op, return_factors=True)
+        assert m.build_stats['converged']
+        assert np.allclose(m.factors['singular_values'], s[order], rtol=1e-9)
+        V, U = m.factors[data.fields.itemid], m.factors[data.fields.userid]
+        assert np.abs(V @ V.T - vt.T @ vt).max() < 1e-8 and np.abs(U @ U.T - uu @ uu.T).max() < 1e-8
+        recs.append(m.get_recommendations())
+    # same lists from both forms wherever the scores leave no doubt (the two operators differ in rounding only)
+    Vref = np.ascontiguousarray(vt.T[:, order])
+    scores = (A @ Vref) @ Vref.T
+    scores[u, c['indices']] = -np.inf
+    top = -np.sort(-scores, axis=1)[:, :11]
+    clear = (np.diff(-top, axis=1) > 1e-9 * np.abs(top[:, :1])).all(axis=1)
+    assert clear.mean() > 0.9 and np.array_equal(recs[0][clear], recs[1][clear])
+    want = np.argsort(-scores, axis=1, kind='stable')[:, :10]
+    assert np.array_equal(recs[0][clear], want[clear])

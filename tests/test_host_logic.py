@@ -260,3 +260,42 @@ def test_build_with_linear_operator_matches_svds():
     assert clear.mean() > 0.5 and np.array_equal(got[clear], want[clear])
     with pytest.raises(ValueError):
         m.build(operator=aslinearoperator(A[:, :-1]))
+
+
+def test_build_with_sparse_operator_forms_match_svds():
+    """build(operator=...) with the device-resident forms: a sparse matrix (HybridSVD's precomputed auxiliary
+    matrix, hybrid/models.py:357-363) and a SparseProduct of factors (the chained form, :364-381) give the
+    factorization scipy's svds gives for the multiplied-out matrix."""
+    from scipy.sparse.linalg import svds
+    import scipy.sparse as sps
+    from polara_amd.operator import SparseProduct
+    g = load_golden('svd_known')
+    data = GoldenData(g)
+    A = SVDModel(data, ops=NumpyOps()).get_training_matrix(dtype=np.float64)
+    rng = np.random.RandomState(5)
+    n_users, n_items = A.shape
+    # sparse lower-triangular "Cholesky-like" factors on both sides (unit diagonal + a few sub-diagonal entries)
+    Ls = (sps.eye(n_items) + 0.3 * sps.tril(sps.random(n_items, n_items, 0.02, random_state=rng), -1)).tocsr()
+    Lk = (sps.eye(n_users) + 0.3 * sps.tril(sps.random(n_users, n_users, 0.01, random_state=rng), -1)).tocsr()
+    full = (Lk.T @ A @ Ls).tocsr()
+    rank = int(g['rank'])
+    u, s, vt = svds(full, k=rank)
+    order = np.argsort(-s)
+    out = []
+    for op in (full, SparseProduct(Lk.T, A, Ls), SparseProduct(A, Ls.tocoo())):
+        m = SVDModel(data, ops=NumpyOps())
+        m.verbose = False
+        m.rank, m.topk = rank, int(g['topk'])
+        m.build(operator=op, return_factors=True)
+        out.append(m)
+    for m in out[:2]:
+        assert np.allclose(m.factors['singular_values'], s[order], rtol=1e-9)
+        V, U = m.factors[data.fields.itemid], m.factors[data.fields.userid]
+        assert np.abs(V @ V.T - vt.T @ vt).max() < 1e-8 and np.abs(U @ U.T - u @ u.T).max() < 1e-8
+    assert np.array_equal(out[0].recommendations, out[1].recommendations)
+    s2 = svds((A @ Ls).tocsr(), k=rank, return_singular_vectors=False)
+    assert np.allclose(out[2].factors['singular_values'], np.sort(s2)[::-1], rtol=1e-9)
+    with pytest.raises(ValueError):
+        SparseProduct(A, Lk)                      # shapes do not chain
+    with pytest.raises(ValueError):
+        out[0].build(operator=SparseProduct(A, Ls[:, :-1]))   # an item short
