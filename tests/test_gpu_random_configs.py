@@ -1,22 +1,29 @@
 """-m gpu: a seeded sweep of awkward shapes through the whole scoring pipeline (ids-only call with the certified
 approximate fold-in AND the exact call with scores) against a brute-force fp64 ranking: sizes around the tile /
 group / candidate-capacity boundaries, odd ranks, dense and empty rows, decaying and flat factor norms."""
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sps
 
 pytestmark = pytest.mark.gpu
 
+# Bug hunting beyond the committed sweep: PK_SWEEP_SEED=<int> draws a different set of configurations and
+# PK_SWEEP_N=<int> more of them (both sweeps); the defaults are what the suite runs.
+SWEEP_SEED = int(os.environ.get('PK_SWEEP_SEED', '0'))
+SWEEP_N = int(os.environ.get('PK_SWEEP_N', '0'))
+
 
 def _configs():
-    rng = np.random.RandomState(20260926)
+    rng = np.random.RandomState(20260926 + SWEEP_SEED)
     out = []
     ks = [1, 2, 7, 10, 16, 25, 26, 33, 50, 64, 100, 129, 200, 256]
     topks = [1, 5, 10, 11, 20, 24, 25, 50, 52]
-    for i in range(72):
+    for i in range(SWEEP_N or 72):
         n_items = int(rng.choice([31, 32, 33, 64, 95, 640, 1000, 2049, 5000, 12000]))
         topk = int(rng.choice([t for t in topks if t <= n_items]))
-        out.append(dict(seed=i, n_users=int(rng.choice([1, 31, 32, 33, 64, 100, 257, 700, 2100])), n_items=n_items,
+        out.append(dict(seed=i + 1000 * SWEEP_SEED, n_users=int(rng.choice([1, 31, 32, 33, 64, 100, 257, 700, 2100])), n_items=n_items,
                         K=int(rng.choice(ks)), topk=topk, decay=float(rng.choice([0.0, 0.4, 1.0, 1.5])),
                         per_row=int(rng.choice([0, 3, 20, 60, 150])), filter_seen=bool(rng.rand() < 0.8)))
     return out
@@ -83,13 +90,13 @@ def test_random_config_against_brute_force(hip_ops, cfg):
 
 
 def _svd_configs():
-    rng = np.random.RandomState(77)
+    rng = np.random.RandomState(77 + SWEEP_SEED)
     out = []
-    for i in range(14):
+    for i in range(SWEEP_N or 14):
         n_items = int(rng.choice([12, 40, 130, 500, 1500]))
         n_users = int(rng.choice([n_items, 3 * n_items, 2000]))
         k = int(rng.choice([1, 3, 10, 25, 50]))
-        out.append(dict(seed=i, n_users=max(n_users, n_items), n_items=n_items, k=min(k, n_items - 1 if i % 3 else n_items),
+        out.append(dict(seed=i + 1000 * SWEEP_SEED, n_users=max(n_users, n_items), n_items=n_items, k=min(k, n_items - 1 if i % 3 else n_items),
                         density=float(rng.choice([0.02, 0.1, 0.5])), kind=str(rng.choice(['plain', 'lowrank', 'dupcols']))))
     return out
 
