@@ -283,7 +283,7 @@ def main():
         return
     cand_avg_ms = float(np.mean(cand_ms))
     traffic = pmc_traffic() if (args.workload == 's1m' and args.scale == 1.0 and comm.world == 1) else {}
-    n_chunk_launches = int(ops.lib.pk_score_chunk_launches(n_items, rank, 1, 0, 0 if args.no_prune else 1))
+    n_chunk_launches = int(ops.lib.pk_score_chunk_launches(n_items, rank, stats.get('item_splits', 1), 0, 0 if args.no_prune else 1))
     flops = 2.0 * (hi - lo) * n_items * rank                     # the reference's dense contraction (models.py:860)
     swept = stats['tiles_scored'] / max(stats['tiles_total'], 1)    # share of the (user group x item tile) grid scored
     flops_exec = flops * swept

@@ -131,9 +131,10 @@ int32_t pk_candidate_capacity(int32_t topk);
 /* Streams all item tiles against 32-user groups; keeps the KC best (fp32 score, item) pairs of
  * each user among items NOT in the user's seen list (seen_ptr == NULL: no filtering).
  * cand_* are [splits x n_users_pad x KC] with n_users_pad = 32*ceil(n_users/32); unused slots have
- * idx -1.  `splits` > 1 cuts the catalogue into that many contiguous item ranges, each swept by its
- * own wave with its own threshold (more, smaller work items when there are few users); the per-range
- * lists are merged by pk_rescore_topk_f64.
+ * idx -1.  `splits` = S > 1 deals the 32-item tiles of the catalogue round-robin to S sweeps per user group
+ * (split h takes tiles h, h+S, ...), each with its own wave and threshold (more, smaller work items when
+ * there are few users; interleaved so that every sweep meets the high-norm head first and the exact pruning
+ * keeps working); the per-split lists are merged by pk_rescore_topk_f64.
  * seen lists must be sorted ascending per user (CSR canonical form).
  * The item range is swept in chunks of `tiles_per_chunk` 32-item tiles, one launch per chunk, so the
  * packed item factors of a chunk stay resident in the 4 MiB per-XCD L2 while every workgroup streams
@@ -174,8 +175,8 @@ int32_t pk_score_chunk_launches(int64_t n_items, int32_t K, int32_t splits, int3
  * The bound falls fastest when the internal item order is by descending popularity or norm. */
 /* After the pass, the state buffer holds, for split h and user group g (32 users), 64 records of 16
  * bytes starting at byte ((h * n_groups + g) * 64) * 16; the first int64 of each record is the tile at
- * which that group left the sweep (= end of its tile range when it was never pruned): the number of
- * tiles actually scored, for the roofline accounting of bench.py. */
+ * which that group left the sweep (absolute tile index; >= n_tiles - S + 1 when it was never pruned): split h
+ * scored ceil((that - h) / S) tiles, for the roofline accounting of bench.py. */
 int pk_row_norm_bound_f32(void *stream, int64_t n, int32_t K, const double *src_dev, int64_t ld, float *out_dev);
 /* pk_pack_frag_f32 and the row bound in one pass over the block (the user side of a scoring pass):
  * bound[r] >= ||src[r,:]||_2 + extra_scale * extra[r * extra_ld]   (extra_dev may be NULL). */

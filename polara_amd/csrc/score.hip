@@ -199,20 +199,24 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
     uint2(*ring)[64] = reinterpret_cast<uint2(*)[64]>(pk_score_lds + wave * (RG * 64));
     uint2 *top = pk_score_lds + 4 * RG * 64 + (TOP_LDS ? wave * (32 * KC) : 0);
 
-    // Item split: blockIdx.y = h owns the contiguous tile range [h*split_tiles, (h+1)*split_tiles) of
-    // the catalogue for ALL chunks, with its own threshold, rings, top lists and parked state, so
-    // that small user counts still fill the chip (the S partial top-KC lists are merged by the
-    // re-scoring kernel).  A launch sweeps tiles [chunk_begin, chunk_begin + chunk_tiles) of every split
-    // (relative to the split's first tile).
+    // Item split: blockIdx.y = h of S = gridDim.y owns every S-th tile of the catalogue, h, h+S, h+2S, ...
+    // (`split_tiles` = ceil(n_tiles / S) of them at most), with its own threshold, rings, top lists and parked
+    // state, so that small user counts still fill the chip (the S partial top-KC lists are merged by the
+    // re-scoring kernel).  Interleaved, not contiguous ranges: under the exact pruning every split meets the
+    // high-norm head of the catalogue first and builds a threshold nearly as good as the single sweep's, so all
+    // S of them leave early (a split owning a contiguous slice of the low-norm tail would have to sweep most of
+    // it before its own k-th best score beats the norm bound).  A launch sweeps the tiles number
+    // [chunk_begin, chunk_begin + chunk_tiles) of every split, i.e. one contiguous L2-sized piece of V.
     const int split = blockIdx.y;
+    const int S = gridDim.y;
     const int64_t n_groups = (n_users + 31) / 32;
-    const int t_lo = split * split_tiles;
-    const int t_hi = (t_lo + split_tiles < n_tiles) ? t_lo + split_tiles : n_tiles;
-    const int tile_begin = t_lo + chunk_begin;
-    const int tile_end = (tile_begin + chunk_tiles < t_hi) ? tile_begin + chunk_tiles : t_hi;
+    const int t_lo = split;
+    const int tile_begin = t_lo + chunk_begin * S;
+    const int tile_stop = (chunk_begin + chunk_tiles < split_tiles) ? t_lo + (chunk_begin + chunk_tiles) * S : n_tiles;
+    const int tile_end = (tile_stop < n_tiles) ? tile_stop : n_tiles;   // tiles tile_begin, +S, ... < tile_end
     const bool first = (chunk_begin == 0);
-    const bool last = (tile_end >= t_hi);
-    if (!first && tile_begin >= t_hi) return;  // this split finished in an earlier launch
+    const bool last = (tile_stop >= n_tiles);
+    if (!first && tile_begin >= n_tiles) return;  // this split finished in an earlier launch
 
     const int ul = lane & 31, hi = lane >> 5;
     const int64_t user = group * 32 + ul;
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
     uint2 *my_ring_state = st_ring + slot * (RING * 64);
     if (first) {
         if (has_seen && t_lo > 0) {
-            // skip the part of the stream that belongs to earlier splits: lower_bound(tile >= t_lo)
+            // skip the records before this split's first tile: lower_bound(tile >= t_lo)
             int64_t lo = sp, hi_ = se;
             while (lo < hi_) {
                 const int64_t mid = (lo + hi_) >> 1;
@@ -475,6 +479,18 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
         const int j0 = tile * 32, jend = j0 + 32;
         unsigned mask = 0;
         if (ablate & 1) return 0u;   // tuning only: skip the seen-list walk
+        if (S > 1) {
+            // records of tiles that belong to the other splits lie between two of mine: step over them
+            // (wave-uniform test; the three-record prefetch window keeps the common one-or-two steps cheap)
+            while (__any((unsigned)(nxt >> 32) < (unsigned)tile)) {
+                if ((unsigned)(nxt >> 32) < (unsigned)tile) {
+                    ++sp;
+                    nxt = nxt2;
+                    nxt2 = nxt3;
+                    nxt3 = (sp + 2 < se) ? seen_tiles[sp + 2] : PK_TILE_NONE;
+                }
+            }
+        }
         const bool hit = (unsigned)(nxt >> 32) == (unsigned)tile;
         if (__any(hit)) {
             if (hit) {
@@ -531,7 +547,8 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
         load_frags((tile_begin < n_tiles) ? tile_begin : 0, a_nxt);
         float tb = prune ? tile_bound[(tile_begin < n_tiles) ? tile_begin : 0] : 0.0f;
         PROF_ADD(4, prof_k0);
-        for (int tile = tile_begin; tile < tile_end; ++tile) {
+        int step = 0;
+        for (int tile = tile_begin; tile < tile_end; tile += S, ++step) {
             if (prune) {
                 // can any item from this tile on still enter a list of this wave?
                 const bool open = en * tb > tau;
@@ -543,16 +560,16 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
                 }
                 // tau is only refreshed by a flush; the last few users that keep the wave in the sweep
                 // get their pending ring entries merged so that their tau is exact (checked every 8 tiles)
-                if ((tile & 7) == 7 && __popcll(ob) <= 16) {
+                if ((step & 7) == 7 && __popcll(ob) <= 16) {
                     const unsigned long long pend = __ballot(cnt > 0);
                     flush_set((unsigned)(ob | (ob >> 32)) & (unsigned)(pend | (pend >> 32)));
                 }
-                tb = tile_bound[(tile + 1 < n_tiles) ? tile + 1 : tile];
+                tb = tile_bound[(tile + S < n_tiles) ? tile + S : tile];   // suffix maximum: covers my later tiles
             }
             float4 a[KQ];
 #pragma unroll
             for (int q = 0; q < KQ; ++q) a[q] = a_nxt[q];
-            load_frags((tile + 1 < tile_end) ? tile + 1 : tile, a_nxt);
+            load_frags((tile + S < tile_end) ? tile + S : tile, a_nxt);
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -611,7 +628,7 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
                 my_score[s] = __uint_as_float(r.x);
                 my_idx[s] = (int)r.y;
             }
-        PROF_INC(7, tile_end - tile_begin);
+        PROF_INC(7, (tile_end - tile_begin + S - 1) / S);
         PROF_ADD(0, prof_k0);
         PROF_FLUSH();
         return;
@@ -629,7 +646,7 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
             my_idx[s] = (int)r.y;
         }
     }
-    PROF_INC(7, exit_tile - tile_begin);
+    PROF_INC(7, (exit_tile - tile_begin + S - 1) / S);
     PROF_ADD(0, prof_k0);
     PROF_FLUSH();
     {
@@ -988,8 +1005,9 @@ extern "C" int64_t pk_score_state_bytes(int64_t n_users, int32_t splits) {
 
 // How many item splits to use.  Every split pays its own threshold warm-up (measured on the
 // ML-20M-shaped workload: 2 splits at 2.1 rounds of wave slots are NOT faster), so the catalogue is
-// only cut when the user groups alone cannot fill the chip's ~2048-3072 wave slots even once;
-// limited by the 64 candidates the re-scoring wave can merge.
+// only dealt out when the user groups alone cannot fill the chip's ~2048-3072 wave slots even once
+// (small request batches, the per-GPU share of a small user set at 8 GPUs); limited by the 64
+// candidates the re-scoring wave can merge.  Used with and without the pruning bound.
 extern "C" int32_t pk_score_splits(int64_t n_users, int32_t KC) {
     const int64_t groups = pk_ceil_div(n_users, 32);
     const int64_t slots = 256 * 8;

@@ -168,12 +168,12 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
         stats['item_splits'] = splits
         # tiles actually scored by the candidate sweep (pruning), for the roofline accounting
         n_tiles = -(-n_items // 32)
-        split_tiles = -(-n_tiles // splits)
-        ex = ops.score_exit_tiles(n_users, splits)
-        lo = torch.arange(splits, device=ex.device, dtype=torch.int64)[:, None] * split_tiles
-        stats['tiles_scored'] = int((ex - lo).clamp_min(0).sum().item())
+        ex = ops.score_exit_tiles(n_users, splits)                      # absolute tile index, per split and group
+        first = torch.arange(splits, device=ex.device, dtype=torch.int64)[:, None]   # split h owns tiles h, h+S, ...
+        scored = torch.div((ex - first).clamp_min(0) + splits - 1, splits, rounding_mode='floor')
+        stats['tiles_scored'] = int(scored.sum().item())
         stats['tiles_total'] = int(ex.shape[1]) * n_tiles
-        q = torch.quantile((ex - lo).clamp_min(0).flatten().double(),
+        q = torch.quantile(scored.flatten().double(),
                            torch.tensor([0.5, 0.9, 0.99, 0.999, 1.0], dtype=torch.float64, device=ex.device))
         stats['exit_tile_quantiles'] = dict(zip(('p50', 'p90', 'p99', 'p999', 'max'), [float(v) for v in q.tolist()]))
     if n_flag:
