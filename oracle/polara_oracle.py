@@ -1,8 +1,10 @@
 """CPU oracle: a NumPy/SciPy restatement of the evfro/polara PureSVD + CoFFee hot path.
 
 TEST INFRASTRUCTURE ONLY.  Nothing under `polara_amd/` may import this module; only `tests/`,
-`__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` do, and only as the checker /
-the timed CPU baseline, never as the thing shipped.
+`__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` do (and, in the same two roles, the
+side benchmarks `tools/bench_coffee.py` / `tools/bench_s50m_shard.py` that `bench.py`'s contract has no
+room for), and only as the checker / the timed CPU baseline, never as the thing shipped
+(`tests/test_abi.py::test_no_cpu_fallback_in_package` greps the package for it).
 
 Every function cites the reference file:line (relative to /root/reference) it restates.  The
 arithmetic that lives outside the reference tree is SciPy's `scipy.sparse.linalg.svds` (ARPACK,
