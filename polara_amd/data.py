@@ -176,8 +176,9 @@ class ShardedArrayData(ArrayData):
     per-user stays with the rank that owns the user: the user-factor rows, `get_recommendations()` and
     `evaluate()` cover the local users only (nothing of size n_users x topk is gathered; sum the hit counts
     over ranks for job-wide metrics).  score_all=True makes every local user a test user with its training
-    row as the known preferences (the reference's `test_ratio=0, warm_start=False` state with the holdout
-    users' rows recovered from training, data.py:820-832)."""
+    row as the known preferences; with a `holdout` (local user ids) the test users are the holdout's users and
+    their known preferences are recovered from the training rows (the reference's `test_ratio=0,
+    warm_start=False` state, data.py:820-832)."""
 
     def __init__(self, block, n_users_total, feedback_levels=None, score_all=True, holdout=None,
                  fields=('userid', 'itemid', 'rating')):
@@ -190,7 +191,7 @@ class ShardedArrayData(ArrayData):
         self.local_csr = block
         self._fixed_levels = None if feedback_levels is None else np.asarray(feedback_levels, dtype=np.float64)
         super().__init__((u, i, f), n_users=block.n_rows, n_items=block.n_cols,
-                         test=(u, i, f) if score_all else None, holdout=holdout, fields=fields)
+                         test=(u, i, f) if (score_all and holdout is None) else None, holdout=holdout, fields=fields)
 
     @classmethod
     def from_shards(cls, path, rank=0, world=1, **kwargs):

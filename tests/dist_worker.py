@@ -60,6 +60,27 @@ def presharded(comm):
         sel = (present >= lo) & (present < hi)
         ok = ok and rl.shape == (int(sel.sum()), 6) and np.array_equal(rl, rw[sel])
         out['presharded_' + cls.__name__] = bool(ok)
+    # evaluate() on a sharded dataset is rank-local: the hit counts of the ranks add up to the whole model's
+    rng = np.random.RandomState(3)
+    hu, hi_ = [], []
+    for u in present:
+        row = c['indices'][c['indptr'][u]:c['indptr'][u + 1]]
+        hu.append(u)
+        hi_.append(rng.choice(np.setdiff1d(np.arange(c['shape'][1]), row)))
+    hu, hi_ = np.asarray(hu), np.asarray(hi_)
+    mine = (hu >= lo) & (hu < hi)
+    counts = []
+    for data, cm, hold in ((ShardedArrayData.from_shards(path, comm.rank, comm.world, holdout=(hu[mine] - lo, hi_[mine], np.ones(mine.sum()))), comm, None),
+                           (ShardedArrayData.from_shards(path, holdout=(hu, hi_, np.ones(len(hu)))), None, None)):
+        m = SVDModel(data, ops=NumpyOps(), comm=cm)
+        m.verbose = False
+        m.rank, m.topk = 5, 20
+        m.build()
+        h = m.evaluate('hits')
+        counts.append(np.array([h.true_positive, h.false_negative], dtype=np.float64))
+    import torch
+    total = comm.allreduce(torch.from_numpy(counts[0].copy())).numpy()
+    out['presharded_evaluate'] = bool(np.array_equal(total, counts[1]) and counts[1].sum() == len(hu) and counts[1][0] > 0)
     return out
 
 
