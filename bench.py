@@ -18,7 +18,7 @@ collective is the all-reduce of the Gramian-step block, scoring has none.
 Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel of the timed region
 (score_candidates, MFMA-bound): `achieved`/`frac` on the MFMA flops actually executed (the pruned share of
 the reference's 2*n_users*n_items*rank), the dense-equivalent rate next to it; per-kernel durations come
-from three extra untimed passes with HIP events.  `roofline_build` describes the SpMM (HBM-bound; algorithmic
+from five extra untimed passes with HIP events.  `roofline_build` describes the SpMM (HBM-bound; algorithmic
 bytes per launch = nnz*(4+val_bytes) + 8*(n_rows+1) + nc*(x_bytes*n_cols + 8*n_rows)).
 `cpu_baseline` is the oracle (= the reference's SciPy/NumPy path restated) timed on this box's host
 cores on a bounded sample; the GPU lists of that sample are compared with it row by row.
@@ -254,16 +254,18 @@ def main():
         print('step ms:', ' '.join('%.2f' % (1e3 * (b_ - a_)) for a_, b_ in zip([t0] + step_marks[:-1], step_marks)),
               file=sys.stderr)
     # ---- untimed instrumented passes: one batch, HIP events around every kernel (the durations the roofline
-    # is computed from are those of the kernels running ALONE, not overlapped with another batch's fold-in)
+    # is computed from are those of the kernels running ALONE, not overlapped with another batch's fold-in).
+    # Five passes back to back in the rhythm of the timed loop — no statistics in between: the host work of
+    # reading them leaves the GPU idle long enough for its clocks to drop, and the next pass's kernels then time
+    # 4-8 % slower than in the timed loop — then one more pass for the sweep statistics.
     ops.timers = {}
-    stats = {}
     prof = None
     if os.environ.get('PK_SCORE_PROFILE'):   # tuning builds only (polara_amd/build_native.py)
         import ctypes
         buf = (ctypes.c_ulonglong * 8)()
         ops.lib.pk_debug_profile(None, 1)
-    for _ in range(3):
-        scoring.recommend(ops, F, A, topk, True, stats=stats, prune=not args.no_prune, batches=1)
+    for _ in range(5):
+        scoring.recommend(ops, F, A, topk, True, prune=not args.no_prune, batches=1)
     torch.cuda.synchronize()
     if os.environ.get('PK_SCORE_PROFILE'):
         ops.lib.pk_debug_profile(buf, 0)
@@ -272,6 +274,9 @@ def main():
     cand_ms = events_ms(ops.timers.get('score_candidates', []))
     fold_ms = events_ms(ops.timers.get('spmm', []))
     ops.timers = None
+    stats = {}
+    scoring.recommend(ops, F, A, topk, True, stats=stats, prune=not args.no_prune, batches=1)
+    torch.cuda.synchronize()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if debug_backend == 'gloo' else dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -307,7 +312,8 @@ def main():
                   'block': bstats['block'], 'converged': bstats['converged'], 'spmm_launches': len(spmm_ms),
                   'sigma_max': float(sigma[0].item()), 'sigma_min': float(sigma[-1].item())},
         'score': {'fold_in_ms': float(np.mean(fold_ms)) if fold_ms else None, 'candidates_ms': cand_avg_ms,
-                  'flagged_users_last_step': stats.get('flagged_users'), 'candidate_capacity': stats.get('candidate_capacity')},
+                  'flagged_users_last_step': stats.get('flagged_users'), 'refolded_users_last_step': stats.get('refolded_users'),
+                  'candidate_capacity': stats.get('candidate_capacity')},
         'roofline': {'kernel': 'score_candidates_kernel', 'bound': 'mfma', 'achieved': achieved_tf,
                      'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved_tf / PEAK_FP32_MFMA_TFLOPS,
                      'traffic': (traffic['score'] * n_chunk_launches if 'score' in traffic else None),

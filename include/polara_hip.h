@@ -201,11 +201,16 @@ int pk_rescore_topk_f64(void *stream, int64_t n_users, int64_t n_items, int32_t 
  * then within delta_u = 2^-24 w_u max||V_i|| of the exact ones, and flags bit2 (value 4) marks the users whose
  * order is NOT certified at that accuracy (two consecutive scores of the top-k, or the k-th and the best
  * excluded item, closer than 2 delta_u): the host recomputes their E rows exactly and calls again with
- * e_exact = 1 (the same e_err_dev: the non-candidates are still only known through the approximate sweep). */
+ * e_exact = 1 (the same e_err_dev: the non-candidates are still only known through the approximate sweep).
+ * V32_dev (or NULL): fl32 image of the item factors [n_items x ldv32]; used INSTEAD of V_dev in a first call over
+ * approximate E rows (e_err_dev given, e_exact = 0) — half the cache lines per gathered row; its rounding,
+ * 2^-24 ||E'_u|| max||V_i||, is added to delta_u.  Ignored when the E rows are exact. */
 int pk_rescore_topk_rows_f64(void *stream, int64_t n_rows, const int32_t *rows_dev,
                              const int32_t *n_rows_dev /* or NULL; else the list length is min(*n_rows_dev, n_rows) */,
                              int64_t n_users, int64_t n_items,
-                             int32_t K, const double *V_dev, int64_t ldv, const double *E_dev, int64_t lde,
+                             int32_t K, const double *V_dev, int64_t ldv,
+                             const float *V32_dev /* or NULL */, int64_t ldv32,
+                             const double *E_dev, int64_t lde,
                              const double *e_err_dev, int64_t e_err_ld /* e_err of user u at e_err_dev[u * e_err_ld] */,
                              int32_t e_exact /* 1: these E rows are exact, the candidates came
                              from a sweep over approximate ones (second call) */,

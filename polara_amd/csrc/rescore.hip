@@ -124,6 +124,56 @@ __device__ __forceinline__ double pk_dot_chains(const double *__restrict__ vr, c
     return s;
 }
 
+// Approximate score against the fp32 image of an item row (pk_rescore_topk_rows_f64 with V32_dev): lane q of
+// LPC takes the 16-byte pieces (four elements) q, q + LPC, ... of the row, fp64 fma chains, any order — these
+// scores are only trusted to within the delta the caller adds for them, never returned as exact ones.
+template <int LPC>
+__device__ __forceinline__ double pk_dot_f32row(const float *__restrict__ vr, const double *er, int K, int q,
+                                                bool vec, double *e_norm2) {
+    double a0 = 0.0, a1 = 0.0, n2 = 0.0;
+    const int nq = K >> 2;
+    if (vec) {
+        const float4 *v4 = reinterpret_cast<const float4 *>(vr);
+        const double2 *e2 = reinterpret_cast<const double2 *>(er);
+#pragma unroll 2
+        for (int p = q; p < nq; p += LPC) {
+            const float4 v = v4[p];
+            const double2 ea = e2[2 * p], eb = e2[2 * p + 1];
+            a0 = fma(ea.x, (double)v.x, a0);
+            a1 = fma(ea.y, (double)v.y, a1);
+            a0 = fma(eb.x, (double)v.z, a0);
+            a1 = fma(eb.y, (double)v.w, a1);
+            n2 = fma(ea.x, ea.x, fma(ea.y, ea.y, fma(eb.x, eb.x, fma(eb.y, eb.y, n2))));
+        }
+    } else {
+        for (int p = q; p < nq; p += LPC) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double e = er[4 * p + j];
+                a0 = fma(e, (double)vr[4 * p + j], a0);
+                n2 = fma(e, e, n2);
+            }
+        }
+    }
+    if (q == 0)
+        for (int j = 4 * nq; j < K; ++j) {   // the last K mod 4 elements
+            const double e = er[j];
+            a1 = fma(e, (double)vr[j], a1);
+            n2 = fma(e, e, n2);
+        }
+    double s = a0 + a1;
+    if constexpr (LPC >= 2) {
+        s += pk_lane_xor<1>(s);
+        n2 += pk_lane_xor<1>(n2);
+    }
+    if constexpr (LPC >= 4) {
+        s += pk_lane_xor<2>(s);
+        n2 += pk_lane_xor<2>(n2);
+    }
+    *e_norm2 = n2;
+    return s;
+}
+
 // LPC adjacent lanes own one candidate: they walk the candidate's item row in interleaved 16-byte pieces
 // (the candidates of a user are popular items, their rows sit in L2) against the user's E row with serial
 // fp64 FMA chains and add their LPC partial sums at the end (one or two lane exchanges); a segment of
@@ -135,7 +185,7 @@ __device__ __forceinline__ double pk_dot_chains(const double *__restrict__ vr, c
 template <int SEG, int LPC>
 __global__ __launch_bounds__(256) void rescore_topk_kernel(
     int64_t n_rows, const int32_t *__restrict__ rows, const int32_t *__restrict__ n_rows_dev, int64_t n_users,
-    int64_t n_items, int K, const double *__restrict__ V, int64_t ldv,
+    int64_t n_items, int K, const double *__restrict__ V, int64_t ldv, const float *__restrict__ V32, int64_t ldv32,
     const double *__restrict__ E, int64_t lde, const double *__restrict__ e_err, int64_t e_err_ld, int e_exact,
     const int64_t *__restrict__ seen_ptr, int KC, int splits,
     const float *__restrict__ cand_score, const int32_t *__restrict__ cand_idx, int topk, double vmax,
@@ -169,8 +219,16 @@ __global__ __launch_bounds__(256) void rescore_topk_kernel(
     const double *er = E + urow * lde;
     const bool vvec2 = (ldv & 1) == 0 && (((uintptr_t)V) & 15) == 0;
     const bool evec2 = (lde & 1) == 0 && (((uintptr_t)E) & 15) == 0;
-    double e2;
-    const double s = pk_dot_chains<LPC>(vr, er, K, q, vvec2, evec2, &e2);
+    // first pass over an approximate E: the fp32 image of the item rows will do (half the lines per gathered
+    // row), its rounding joins delta below; exact E rows (second pass, or no approximation at all): fp64 rows
+    const bool use32 = (V32 != nullptr) && (e_err != nullptr) && !e_exact;
+    double e2, s;
+    if (use32) {
+        const bool v32vec = evec2 && (ldv32 & 3) == 0 && (((uintptr_t)V32) & 15) == 0;
+        s = pk_dot_f32row<LPC>(V32 + (int64_t)(idx >= 0 ? idx : 0) * ldv32, er, K, q, v32vec, &e2);
+    } else {
+        s = pk_dot_chains<LPC>(vr, er, K, q, vvec2, evec2, &e2);
+    }
     const double enorm = sqrt(e2);
     double my_s = (idx >= 0) ? s : -INFINITY;
     int my_i = (idx >= 0) ? idx : PK_IDX_NONE;
@@ -185,7 +243,9 @@ __global__ __launch_bounds__(256) void rescore_topk_kernel(
     // consecutive scores are more than 2 delta apart (the k-th against the (k+1)-th too)
     // e_exact: the E rows given now ARE exact, but the candidates were selected by a sweep over the approximate
     // ones — only the bound on the non-candidates keeps a delta, there is nothing approximate left to order
-    const double delta = e_err ? e_err[urow * e_err_ld] * 5.9604644775390625e-08 * (1.0 + 1e-6) * vmax : 0.0;
+    // scored against fl32(V): |sum_j E'_j (fl32(V_ij) - V_ij)| <= 2^-24 ||E'_u|| ||V_i|| on top of that
+    const double delta = (e_err ? e_err[urow * e_err_ld] * 5.9604644775390625e-08 * (1.0 + 1e-6) * vmax : 0.0) +
+                         (use32 ? enorm * 5.9604644775390625e-08 * (1.0 + 1e-6) * vmax : 0.0);
     if (delta > 0.0 && !e_exact) {
         const int nxt_lane = lane + LPC;
         const double s_next = (t + 1 < SEG) ? __shfl(my_s, nxt_lane & 63, 64) : -INFINITY;
@@ -216,6 +276,7 @@ __global__ __launch_bounds__(256) void rescore_topk_kernel(
 extern "C" int pk_rescore_topk_rows_f64(void *stream, int64_t n_rows, const int32_t *rows_dev,
                                         const int32_t *n_rows_dev, int64_t n_users,
                                         int64_t n_items, int32_t K, const double *V_dev, int64_t ldv,
+                                        const float *V32_dev, int64_t ldv32,
                                         const double *E_dev, int64_t lde, const double *e_err_dev,
                                         int64_t e_err_ld, int32_t e_exact,
                                         const int64_t *seen_ptr_dev, int32_t KC, int32_t splits,
@@ -224,6 +285,7 @@ extern "C" int pk_rescore_topk_rows_f64(void *stream, int64_t n_rows, const int3
                                         int32_t *flags_dev) {
     PK_REQUIRE(n_users >= 1 && K >= 1 && K <= 256 && ldv >= K && lde >= K, "pk_rescore_topk_f64: bad sizes");
     PK_REQUIRE(n_rows >= 0 && n_rows <= n_users, "pk_rescore_topk_f64: bad row count");
+    PK_REQUIRE(V32_dev == nullptr || ldv32 >= K, "pk_rescore_topk_f64: ldv32 < K");
     PK_REQUIRE(KC >= 1 && splits >= 1 && KC * splits <= 64 && topk >= 1 && topk <= KC,
                "pk_rescore_topk_f64: need topk <= KC and KC*splits <= 64");
     if (n_rows == 0) return PK_OK;
@@ -232,7 +294,7 @@ extern "C" int pk_rescore_topk_rows_f64(void *stream, int64_t n_rows, const int3
     const int lpc_req = lpc_env ? atoi(lpc_env) : 0;
 #define PK_RESCORE(SEGV, LPCV)                                                                                    \
     hipLaunchKernelGGL((rescore_topk_kernel<SEGV, LPCV>), dim3((unsigned)pk_ceil_div(n_rows, 4 * (64 / (SEGV * LPCV)))), \
-                       dim3(256), 0, pk_stream(stream), n_rows, rows_dev, n_rows_dev, n_users, n_items, K, V_dev, ldv, E_dev, lde, \
+                       dim3(256), 0, pk_stream(stream), n_rows, rows_dev, n_rows_dev, n_users, n_items, K, V_dev, ldv, V32_dev, ldv32, E_dev, lde, \
                        e_err_dev, e_err_ld, e_exact, seen_ptr_dev, KC, splits, cand_score_dev, cand_idx_dev, topk, v_row_norm_max,   \
                        out_idx_dev, out_score_dev, flags_dev)
     if (seg == 16) {
@@ -256,7 +318,7 @@ extern "C" int pk_rescore_topk_f64(void *stream, int64_t n_users, int64_t n_item
                                    const int32_t *cand_idx_dev,
                                    int32_t topk, double v_row_norm_max, int64_t *out_idx_dev,
                                    double *out_score_dev, int32_t *flags_dev) {
-    return pk_rescore_topk_rows_f64(stream, n_users, nullptr, nullptr, n_users, n_items, K, V_dev, ldv, E_dev, lde,
+    return pk_rescore_topk_rows_f64(stream, n_users, nullptr, nullptr, n_users, n_items, K, V_dev, ldv, nullptr, 0, E_dev, lde,
                                     nullptr, 0, 0, seen_ptr_dev, KC, splits, cand_score_dev, cand_idx_dev, topk, v_row_norm_max,
                                     out_idx_dev, out_score_dev, flags_dev);
 }

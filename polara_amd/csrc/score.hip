@@ -167,7 +167,7 @@ __host__ __device__ constexpr size_t pk_score_lds_bytes(int nstep, int kc) {
     return (size_t)(4 * pk_ring_rows(kc) * 64 + (pk_top_in_lds(nstep, kc) ? 4 * 32 * kc : 1)) * sizeof(uint2);
 }
 
-template <int NSTEP, int KC>
+template <int NSTEP, int KC, bool STRIDED>
 __global__ __launch_bounds__(256) void score_candidates_kernel(
     const float4 *__restrict__ Vp, const float4 *__restrict__ Ep, int64_t n_users, int n_items,
     int n_tiles, int split_tiles, int chunk_begin, int chunk_tiles,
@@ -207,8 +207,10 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
     // S of them leave early (a split owning a contiguous slice of the low-norm tail would have to sweep most of
     // it before its own k-th best score beats the norm bound).  A launch sweeps the tiles number
     // [chunk_begin, chunk_begin + chunk_tiles) of every split, i.e. one contiguous L2-sized piece of V.
-    const int split = blockIdx.y;
-    const int S = gridDim.y;
+    // STRIDED = false is the single-sweep instance (S == 1 at compile time: the tile loop, the stream walk and
+    // the checkpoint test fold back to their unit-stride forms)
+    const int split = STRIDED ? (int)blockIdx.y : 0;
+    const int S = STRIDED ? (int)gridDim.y : 1;
     const int64_t n_groups = (n_users + 31) / 32;
     const int t_lo = split;
     const int tile_begin = t_lo + chunk_begin * S;
@@ -560,7 +562,7 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
                 }
                 // tau is only refreshed by a flush; the last few users that keep the wave in the sweep
                 // get their pending ring entries merged so that their tau is exact (checked every 8 tiles)
-                if ((step & 7) == 7 && __popcll(ob) <= 16) {
+                if (((STRIDED ? step : tile) & 7) == 7 && __popcll(ob) <= 16) {
                     const unsigned long long pend = __ballot(cnt > 0);
                     flush_set((unsigned)(ob | (ob >> 32)) & (unsigned)(pend | (pend >> 32)));
                 }
@@ -961,9 +963,13 @@ static int launch_candidates_n(hipStream_t st, int KC, int ablate, dim3 grid, co
     if (pk_score_lds_bytes(NSTEP, KCV) > 64 * 1024) {                                                           \
         static bool attr_set = false;   /* one flag per (NSTEP, KC) instance of this macro expansion */        \
         if (!attr_set) {                                                                                        \
-            hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&score_candidates_kernel<NSTEP, KCV>), \
+            hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&score_candidates_kernel<NSTEP, KCV, false>), \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize,                     \
                                                 (int)pk_score_lds_bytes(NSTEP, KCV));                           \
+            if (e1 == hipSuccess)                                                                               \
+                e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&score_candidates_kernel<NSTEP, KCV, true>), \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize,                            \
+                                         (int)pk_score_lds_bytes(NSTEP, KCV));                                  \
             if (e1 != hipSuccess) {                                                                             \
                 pk_set_error("pk_score_candidates_f32: cannot raise the LDS limit: %s", hipGetErrorString(e1)); \
                 return PK_E_LAUNCH;                                                                             \
@@ -971,9 +977,14 @@ static int launch_candidates_n(hipStream_t st, int KC, int ablate, dim3 grid, co
             attr_set = true;                                                                                    \
         }                                                                                                       \
     }                                                                                                           \
-    hipLaunchKernelGGL((score_candidates_kernel<NSTEP, KCV>), grid, dim3(256), pk_score_lds_bytes(NSTEP, KCV), st, Vp, Ep, n_users, \
-                       n_items, n_tiles, split_tiles, chunk_begin, chunk_tiles, seen_ptr, seen_tiles, seen_ntiles, cs, ci, st_lane, st_ring,  \
-                       user_bound, tile_bound, ablate)
+    if (grid.y > 1)                                                                                             \
+        hipLaunchKernelGGL((score_candidates_kernel<NSTEP, KCV, true>), grid, dim3(256), pk_score_lds_bytes(NSTEP, KCV), st, Vp, Ep, n_users, \
+                           n_items, n_tiles, split_tiles, chunk_begin, chunk_tiles, seen_ptr, seen_tiles, seen_ntiles, cs, ci, st_lane, st_ring,  \
+                           user_bound, tile_bound, ablate);                                                     \
+    else                                                                                                        \
+        hipLaunchKernelGGL((score_candidates_kernel<NSTEP, KCV, false>), grid, dim3(256), pk_score_lds_bytes(NSTEP, KCV), st, Vp, Ep, n_users, \
+                           n_items, n_tiles, split_tiles, chunk_begin, chunk_tiles, seen_ptr, seen_tiles, seen_ntiles, cs, ci, st_lane, st_ring,  \
+                           user_bound, tile_bound, ablate)
 #ifdef PK_FAST_BUILD
         if (KC != 16) return PK_E_UNSUPPORTED;
         PK_LAUNCH(16);

@@ -502,11 +502,13 @@ class HipOps:
         return rec[:, :, 0, 0].clone()
 
     def rescore_topk(self, V, E, n_items, seen_ptr, KC, cs, ci, topk, vmax, want_scores=True, splits=1, out=None,
-                     rows=None, n_rows_dev=None, e_err=None, e_exact=False):
+                     rows=None, n_rows_dev=None, e_err=None, e_exact=False, v32=None):
         """Exact fp64 re-scoring + certification.  rows (int32 tensor): only these users are re-done (outputs
         are still indexed by user: pass the full-size `out`); e_err: per-user error weight of an approximate E
-        (flags bit 4 = not certified at that accuracy)."""
+        (flags bit 4 = not certified at that accuracy); v32: fp32 image of V [n_items x >= K], gathered instead
+        of V while E is approximate (its rounding joins the certified error)."""
         assert V.stride(1) == 1 and E.stride(1) == 1
+        assert v32 is None or (v32.dtype == torch.float32 and v32.stride(1) == 1 and v32.shape[1] >= E.shape[1])
         n_users, K = E.shape
         if out is not None:
             out_idx, out_s, flags = out      # caller-owned (contiguous row slices of the full outputs)
@@ -519,7 +521,8 @@ class HipOps:
         e_ld = 0 if e_err is None else (e_err.stride(0) if e_err.numel() > 1 else 1)
         _lib.check(self.lib.pk_rescore_topk_rows_f64(self.stream(), n_rows, _ptr(rows), _ptr(n_rows_dev), n_users,
                                                      n_items, K, _ptr(V),
-                                                     V.stride(0), _ptr(E), E.stride(0), _ptr(e_err), e_ld,
+                                                     V.stride(0), _ptr(v32), 0 if v32 is None else v32.stride(0),
+                                                     _ptr(E), E.stride(0), _ptr(e_err), e_ld,
                                                      1 if e_exact else 0,
                                                      _ptr(seen_ptr),
                                                      KC, splits, _ptr(cs), _ptr(ci), topk, float(vmax),

@@ -125,7 +125,7 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
                                       seen_tiles=st)                                          # K3
         outs = (out_idx[u0:u1], out_s[u0:u1], flags[u0:u1])
         ops.rescore_topk(factors.V, Eb, n_items, sp, KC, cs, ci, topk, factors.vmax, want_scores=True,
-                         splits=splits, out=outs, e_err=w)
+                         splits=splits, out=outs, e_err=w, v32=factors.V32x if approx_fold_in else None)
         if approx_fold_in:
             # every flagged user — order not certified at the accuracy of the approximate fold-in (bit 4), or
             # bound for the exact-row kernel anyway (bits 1, 2), which must not see an approximate E — gets its

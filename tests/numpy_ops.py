@@ -202,7 +202,7 @@ class NumpyOps:
         return torch.zeros(splits, -(-n_users // 32), dtype=torch.int64)
 
     def rescore_topk(self, V, E, n_items, seen_ptr, KC, cs, ci, topk, vmax, want_scores=True, splits=1, out=None,
-                     rows=None, n_rows_dev=None, e_err=None, e_exact=False):
+                     rows=None, n_rows_dev=None, e_err=None, e_exact=False, v32=None):
         n_users, K = E.shape
         if rows is not None:
             # re-do of a user list: compute everybody, keep only the listed users' results
@@ -213,6 +213,9 @@ class NumpyOps:
                 dst[sel] = src[sel]
             return out
         Vn, En = V.numpy(), E.numpy()
+        use32 = v32 is not None and e_err is not None and not e_exact
+        if use32:
+            Vn = v32.numpy()[:, :K].astype(np.float64)      # scored against the fp32 image; its rounding joins delta
         cs = cs.numpy().reshape(-1, KC)
         ci = ci.numpy().reshape(-1, KC)
         out_idx = np.full((n_users, topk), -1, dtype=np.int64)
@@ -231,6 +234,8 @@ class NumpyOps:
             if n_items - n_seen < topk:
                 flags[u] |= 2
             delta = float(e_err[u]) * 2.0 ** -24 * (1 + 1e-6) * vmax if e_err is not None else 0.0
+            if use32:
+                delta += np.linalg.norm(En[u]) * 2.0 ** -24 * (1 + 1e-6) * vmax
             if delta > 0 and not e_exact:
                 ss = np.r_[s, -np.inf]
                 m = min(topk, len(s))
