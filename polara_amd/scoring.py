@@ -27,6 +27,11 @@ class FactorImage:
         self.n_items, self.K = self.V.shape
         self.Vp = ops.pack_frag(self.V)
         self.vmax = float(torch.linalg.vector_norm(self.V, dim=1).max().item())
+        if not np.isfinite(self.vmax) or (self.vmax != 0.0 and not 1e-30 < self.vmax < 1e30):
+            # the candidate sweep and the approximate fold-in work on fp32 images of the factors; their error
+            # bounds are norm-wise (2^-24 * max||V_i||) and hold as long as that scale is an fp32 NORMAL number
+            raise ValueError('item factors with max row norm %g are outside the range the fp32 candidate sweep '
+                             'works in (rescale the factors)' % self.vmax)
         self.tile_bound = ops.tile_norm_bound(self.V)   # exact pruning bound of the candidate sweep
         # fp32 image for the approximate fold-in: columns 0..K-1 = fl32(V), column K = an upper bound of the
         # row norm (so the same product also yields w_u = sum_j a_uj ||V_j||, the weight of the fold-in's

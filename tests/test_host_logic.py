@@ -299,3 +299,18 @@ def test_build_with_sparse_operator_forms_match_svds():
         SparseProduct(A, Lk)                      # shapes do not chain
     with pytest.raises(ValueError):
         out[0].build(operator=SparseProduct(A, Ls[:, :-1]))   # an item short
+
+
+def test_factor_image_rejects_factors_outside_the_fp32_range():
+    """The fp32 images behind the sweep and the fold-in need the factor scale to be an fp32 normal number: anything
+    else fails loudly instead of producing uncertified lists."""
+    import torch
+    from polara_amd import scoring
+    ops = NumpyOps()
+    rng = np.random.RandomState(0)
+    V = rng.randn(40, 5)
+    scoring.FactorImage(ops, torch.from_numpy(V))                       # fine
+    scoring.FactorImage(ops, torch.zeros(40, 5, dtype=torch.float64))   # a degenerate model is still a model
+    for scale in (1e-40, 1e35, np.inf, np.nan):
+        with pytest.raises(ValueError, match='fp32'):
+            scoring.FactorImage(ops, torch.from_numpy(V * scale))
