@@ -331,6 +331,108 @@ class RecommenderModel:
             scores = np.ascontiguousarray(scores[:, self._item_rank])   # back to external item order
         return scores, slice_data
 
+    # ---- single-user conveniences on top of slice_recommendations (models.py:277-356, 488-563) -------------
+    # These take and return caller-owned HOST arrays, like the reference's; the arithmetic runs on the model's
+    # device through torch (selection / reductions on a dense score block are plumbing here, not a kernel of the
+    # hot path: `get_recommendations` never goes through them — its masking and top-k are fused into the sweep).
+    def topsort(self, a, topk):
+        """models.py:488-491: indices of the `topk` largest entries of a vector, best first."""
+        return self.get_topk_elements(np.asarray(a)[None, :], topk)[0]
+
+    def downvote_seen_items(self, recs, idx_seen):
+        """models.py:494-519, dense branch, IN PLACE on `recs` like the reference: seen entries drop below the
+        minimum of the block, keeping their relative order (s <- min - (max_seen - s) - 1)."""
+        if hasattr(recs, 'tocsr'):
+            raise NotImplementedError('sparse score matrices are not produced by the factorization models')
+        if recs.ndim == 1:                                    # single-user scores (models.py:513-515)
+            flat = np.asarray(idx_seen[-1] if len(idx_seen) else [], dtype=np.int64)
+        else:
+            flat = np.ravel_multi_index(tuple(np.asarray(x, dtype=np.int64) for x in idx_seen[:2]), recs.shape)
+        if flat.size == 0:
+            return
+        ops = self.ops
+        t = ops.to_device(np.ascontiguousarray(recs, dtype=np.float64).reshape(-1))
+        seen = t[ops.to_device(flat)]
+        recs.flat[flat] = ops.to_host(t.min() - (seen.max() - seen) - 1)
+
+    def get_topk_elements(self, scores, topk=None):
+        """models.py:561-563, dense branch: [n_rows x topk] column ids by descending score."""
+        if hasattr(scores, 'tocsr'):
+            raise NotImplementedError('sparse score matrices are not produced by the factorization models')
+        topk = self.topk if topk is None else topk
+        scores = np.asarray(scores)
+        if topk > scores.shape[-1]:
+            raise ValueError('kth(=%d) out of bounds (%d)' % (scores.shape[-1] - topk, scores.shape[-1]))
+        import torch
+        t = self.ops.to_device(np.ascontiguousarray(scores, dtype=np.float64))
+        return self.ops.to_host(torch.topk(t, int(topk), dim=-1, largest=True, sorted=True).indices)
+
+    def _user_scores(self, i):
+        """models.py:277-293: dense scores of test user `i` (seen items downvoted when filter_seen) + its triplet."""
+        if not self._is_ready:
+            if self.verbose:
+                print('{} model is not ready. Rebuilding.'.format(self.method))
+            self.build()
+        test_data, test_shape, test_users = self._get_test_data()
+        if not self.data.warm_start:
+            i, = np.where(test_users == i)[0]
+        scores, seen_idx = self.slice_recommendations(test_data, test_shape, i, i + 1)
+        if self.filter_seen:
+            self.downvote_seen_items(scores, seen_idx)
+        return scores, seen_idx
+
+    def show_recommendations(self, user_info, topk=None):
+        """models.py:320-356: top items (external ids) for a test user given by its index, or for an ad-hoc user
+        given as a list of items / an {item: feedback} dict; returns (recommended items, the user's seen items)."""
+        if isinstance(user_info, (int, np.integer)):
+            scores, seen_idx = self._user_scores(int(user_info))
+        else:
+            with self._ad_hoc_test_user(user_info):
+                scores, seen_idx = self._user_scores(0)
+        top = self.get_topk_elements(scores, self.topk if topk is None else topk).squeeze()
+        seen = np.asarray(seen_idx[1])
+        index = getattr(self.data, 'get_entity_index', None)
+        if index is not None:                                 # Polara's data model: internal -> external item ids
+            old = index(self.data.fields.itemid).set_index('new')['old']
+            return old.loc[top].values, old.loc[seen].values
+        return top, seen
+
+    def _ad_hoc_test_user(self, user_info):
+        """Context manager that swaps in a one-user test set (models.py:296-317, 325-336) and restores the data
+        object's own on exit."""
+        import contextlib
+        data = self.data
+        userid, itemid, feedback = data.fields
+        if isinstance(user_info, dict):
+            items, fdbk = (list(x) for x in zip(*user_info.items()))
+        elif isinstance(user_info, (list, tuple, set, np.ndarray)):
+            items, fdbk = list(user_info), None
+        else:
+            raise ValueError('Unrecognized input for `user_info`.')
+
+        @contextlib.contextmanager
+        def swapped():
+            saved = data._test
+            try:
+                if hasattr(data, 'get_entity_index'):         # Polara: a one-user frame in internal item ids
+                    import pandas as pd
+                    try:
+                        item_index = data.index.itemid.training
+                    except AttributeError:
+                        item_index = data.index.itemid
+                    frame = {userid: [0] * len(items), itemid: item_index.set_index('old').loc[items, 'new'].values}
+                    if feedback is not None:
+                        frame[feedback] = fdbk if fdbk is not None else [data.training[feedback].max()] * len(items)
+                    data._test = type(saved)(pd.DataFrame(frame), None)
+                else:                                         # ArrayData: ids are internal already
+                    f = fdbk if fdbk is not None else [float(np.max(data.training.feedback))] * len(items)
+                    data.set_test_data(testset=(np.zeros(len(items), dtype=np.int64), np.asarray(items), np.asarray(f)),
+                                       notify=False)
+                yield
+            finally:
+                data._test = saved
+        return swapped()
+
     def evaluate(self, metric_type='all', topk=None, not_rated_penalty=None, switch_positive=None,
                  ignore_feedback=False, simple_rates=False, on_feedback_level=None):
         """models.py:408-485.  With a Polara `RecommenderData` (pandas holdout) the reference's own metric code

@@ -1,0 +1,143 @@
+"""Drop-in check against the REFERENCE ITSELF (build container only: skipped wherever /root/reference is absent,
+never part of -m gpu): Polara's own `RecommenderData` object drives Polara's `SVDModel` / `CoffeeModel` and ours
+(on the test-only NumPy double of the device ops) side by side — same data object, same events, same consumers
+(`recommendations`, `evaluate`, `show_recommendations`, rank truncation, data-change notifications)."""
+import contextlib
+import io
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REF = '/root/reference'
+HERE = os.path.dirname(os.path.abspath(__file__))
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, 'polara')), reason='reference tree not present')
+
+
+@pytest.fixture(scope='module')
+def polara():
+    sys.path.insert(0, os.path.join(HERE, 'golden', '_numba_shim'))   # numba is not installed: pass-through shim
+    sys.path.insert(0, REF)
+    import warnings
+    warnings.filterwarnings('ignore')
+    import polara as ref
+    yield ref
+    sys.path.remove(REF)
+
+
+def quiet(fn, *a, **kw):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **kw)
+
+
+def make_data(ref, seed=0, **cfg):
+    import pandas as pd
+    from polara_amd.synth import planted_csr, csr_to_coo_triplets
+    u, i, v = csr_to_coo_triplets(planted_csr(400, 150, 18, 5, levels=5, seed=11, min_items=6, max_items=60))
+    # external ids that are NOT the internal ones: the index translation must be exercised
+    df = pd.DataFrame({'userid': 1000 + 3 * u, 'itemid': 50000 - 7 * i, 'rating': v})
+    data = ref.RecommenderData(df, 'userid', 'itemid', 'rating', seed=seed)
+    data.verbose = False
+    for k, val in cfg.items():
+        setattr(data, k, val)
+    quiet(data.prepare)
+    return data
+
+
+def clear_rows(ref_model, topk):
+    """rows of the reference whose top-(k+1) scores are pairwise distinct (the others are implementation-defined)"""
+    test_data, shape, _ = ref_model._get_test_data()
+    scores, sd = ref_model.slice_recommendations(test_data, shape, 0, shape[0])
+    if ref_model.filter_seen:
+        ref_model.downvote_seen_items(scores, sd)
+    top = -np.sort(-scores, axis=1)[:, :topk + 1]
+    return (np.diff(-top, axis=1) > 1e-9 * np.abs(top[:, :1])).all(axis=1)
+
+
+@pytest.mark.parametrize('cfg', [dict(warm_start=True, holdout_size=3, test_ratio=0.2),
+                                 dict(test_fold=4, warm_start=False, holdout_size=2, test_ratio=0.25, random_holdout=True)],
+                         ids=['warm', 'known_users'])
+def test_svd_model_side_by_side(polara, cfg):
+    from numpy_ops import NumpyOps
+    from polara_amd.models import SVDModel
+    data = make_data(polara, **cfg)
+    ref_m = polara.SVDModel(data)
+    our_m = SVDModel(data, ops=NumpyOps())
+    for m in (ref_m, our_m):
+        m.verbose = False
+        m.rank, m.topk = 8, 7
+    np.random.seed(0)
+    quiet(ref_m.build)
+    our_m.build()
+    assert np.allclose(our_m.factors['singular_values'], ref_m.factors['singular_values'], rtol=1e-9)
+    clear = clear_rows(ref_m, 7)
+    assert clear.mean() > 0.9
+    assert np.array_equal(our_m.recommendations[clear], ref_m.recommendations[clear])
+    # evaluate(): the reference's own metric code runs on our lists (pandas holdout) -> identical hit counts
+    # wherever the lists are; give both the same lists on the tie rows to compare the numbers 1:1
+    our_m._recommendations[~clear] = ref_m.recommendations[~clear]
+    for a, b in zip(quiet(our_m.evaluate, 'hits'), quiet(ref_m.evaluate, 'hits')):
+        assert a == b
+    ra, rb = quiet(our_m.evaluate, 'relevance'), quiet(ref_m.evaluate, 'relevance')
+    assert np.isclose(ra.precision, rb.precision, rtol=1e-13) and np.isclose(ra.recall, rb.recall, rtol=1e-13)
+    # show_recommendations: a test user by index, and ad-hoc users by external item ids
+    test_users = ref_m._get_test_data()[2]       # warm start: row numbers; known users: internal ids of the holdout users
+    for row in (0, 5):
+        u = row if cfg['warm_start'] else int(test_users[row])
+        t_ref, s_ref = quiet(ref_m.show_recommendations, u)
+        t_our, s_our = our_m.show_recommendations(u)
+        assert np.array_equal(np.sort(s_ref), np.sort(s_our))
+        if clear[row]:
+            assert np.array_equal(t_ref, t_our)
+    ext_items = data.index.itemid.training['old'].values if hasattr(data.index.itemid, 'training') else data.index.itemid['old'].values
+    liked = list(ext_items[[3, 17, 42, 77]])
+    before = (data.test.testset, data.test.holdout)
+    t_ref, s_ref = quiet(ref_m.show_recommendations, liked, 5)
+    t_our, s_our = our_m.show_recommendations(liked, topk=5)
+    assert data.test.testset is before[0] and data.test.holdout is before[1]          # the data object is restored
+    assert np.array_equal(np.sort(s_ref), np.sort(s_our)) and set(s_our) == set(liked)
+    assert np.array_equal(t_ref, t_our) and len(t_our) == 5 and our_m.topk == 7
+    # the {item: feedback} form raises inside the reference under pandas 2 (`zip` hands `.loc` a tuple,
+    # models.py:300-318); ours takes it: with the list form's implied feedback (the training maximum) it must give
+    # the list form's answer, and other weights a different profile but the same seen items
+    with pytest.raises(Exception):
+        quiet(ref_m.show_recommendations, {liked[0]: 5.0, liked[2]: 1.0}, 5)
+    fmax = float(data.training['rating'].max())
+    t_dict, s_dict = our_m.show_recommendations({it: fmax for it in liked}, topk=5)
+    assert np.array_equal(t_dict, t_our) and set(s_dict) == set(liked)
+    _, s_w = our_m.show_recommendations({liked[0]: 5.0, liked[2]: 1.0}, topk=5)
+    assert set(s_w) == {liked[0], liked[2]}
+    # rank truncation keeps both models ready and equal (models.py:812-832)
+    ref_m.rank = our_m.rank = 4
+    assert our_m._is_ready and ref_m._is_ready
+    clear4 = clear_rows(ref_m, 7)
+    assert np.array_equal(our_m.recommendations[clear4], ref_m.recommendations[clear4])
+    # a change of the data (new split) reaches both models through the data object's events
+    data.test_fold = 2 if data.test_fold != 2 else 3
+    quiet(data.update)
+    assert not our_m._is_ready and not ref_m._is_ready and our_m._recommendations is None
+
+
+def test_coffee_model_side_by_side(polara):
+    from numpy_ops import NumpyOps
+    from polara_amd.models import CoffeeModel
+    from polara.recommender.models import CoffeeModel as RefCoffee
+    data = make_data(polara, test_fold=4, warm_start=False, holdout_size=2, test_ratio=0.25)
+    ref_m, our_m = RefCoffee(data), CoffeeModel(data, ops=NumpyOps())
+    for m in (ref_m, our_m):
+        m.verbose = False
+        m.mlrank, m.topk, m.seed = (6, 5, 3), 6, 2
+        m.growth_tol = 1e-6
+    quiet(ref_m.build)
+    our_m.build()
+    f = data.fields
+    for key in (f.userid, f.itemid, f.feedback):
+        a, b = our_m.factors[key], ref_m.factors[key]
+        assert np.abs(a @ a.T - b @ b.T).max() < 1e-7
+    assert np.isclose(np.linalg.norm(our_m.factors['core']), np.linalg.norm(ref_m.factors['core']), rtol=1e-8)
+    clear = clear_rows(ref_m, 6)
+    assert clear.mean() > 0.8 and np.array_equal(our_m.recommendations[clear], ref_m.recommendations[clear])
+    our_m._recommendations[~clear] = ref_m.recommendations[~clear]
+    for a, b in zip(quiet(our_m.evaluate, 'hits'), quiet(ref_m.evaluate, 'hits')):
+        assert a == b

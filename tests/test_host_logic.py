@@ -314,3 +314,61 @@ def test_factor_image_rejects_factors_outside_the_fp32_range():
     for scale in (1e-40, 1e35, np.inf, np.nan):
         with pytest.raises(ValueError, match='fp32'):
             scoring.FactorImage(ops, torch.from_numpy(V * scale))
+
+
+def test_single_user_conveniences_on_array_data():
+    """models.py:277-356, 488-563 on ArrayData (ids are internal): `_user_scores`, `show_recommendations` for a test
+    user and for ad-hoc users, `downvote_seen_items` / `get_topk_elements` / `topsort` against the oracle."""
+    g = load_golden('svd_known')
+    data = GoldenData(g)
+    m = SVDModel(data, ops=NumpyOps())
+    m.verbose = False
+    m.rank, m.topk = int(g['rank']), int(g['topk'])
+    m.build()
+    rng = np.random.RandomState(1)
+    sc = rng.randn(9, 60)
+    seen = (np.repeat(np.arange(9), 4), rng.randint(0, 60, 36), np.ones(36))
+    a, b = sc.copy(), sc.copy()
+    m.downvote_seen_items(a, seen)
+    orc.downvote_seen_items(b, seen)
+    assert np.array_equal(a, b)
+    assert np.array_equal(m.get_topk_elements(a, 7), orc.get_topk_elements(b, 7))
+    assert np.array_equal(m.topsort(sc[3], 5), orc.topsort(sc[3], 5))
+    one = sc[0].copy()
+    m.downvote_seen_items(one, (np.zeros(3, dtype=int), np.array([2, 5, 7])))      # single-user form
+    assert set(np.argsort(one)[:3]) == {2, 5, 7}
+    with pytest.raises(ValueError):
+        m.get_topk_elements(sc, 61)
+    notie = g['boundary_gap'] > 0
+    for row in np.flatnonzero(notie)[:5]:
+        top, seen_items = m.show_recommendations(int(row))
+        assert np.array_equal(top, g['recs'][row])
+        assert set(seen_items) == set(g['test_item'][g['test_user'] == row])
+    # an ad-hoc user: the test set is swapped in and restored, the cached lists stay untouched
+    # (a plain ArrayData: the golden wrapper above answers test queries from the fixture, whatever the test set is)
+    from polara_amd.data import ArrayData
+    idx = g['train_idx']
+    data = ArrayData((idx[:, 0], idx[:, 1], g['train_val']), n_users=int(g['train_shape'][0]), n_items=int(g['train_shape'][1]),
+                     test=(g['test_user'], g['test_item'], g['test_fdbk']))
+    m = SVDModel(data, ops=NumpyOps())
+    m.verbose = False
+    m.rank, m.topk = int(g['rank']), int(g['topk'])
+    m.build()
+    cached = m.recommendations
+    before = data.test
+    top, seen_items = m.show_recommendations([3, 9, 27], topk=4)
+    assert data.test is before and m.recommendations is cached and m.topk == int(g['topk'])
+    assert len(top) == 4 and set(seen_items) == {3, 9, 27} and not set(top) & {3, 9, 27}
+    V = m.factors[data.fields.itemid]
+    fmax = float(np.max(data.training.feedback))
+    prof = np.zeros(V.shape[0]); prof[[3, 9, 27]] = fmax
+    s = (prof @ V) @ V.T
+    s[[3, 9, 27]] = -np.inf
+    assert np.array_equal(top, np.argsort(-s, kind='stable')[:4])
+    top_w, _ = m.show_recommendations({3: 1.0, 9: 5.0}, topk=4)
+    prof = np.zeros(V.shape[0]); prof[3], prof[9] = 1.0, 5.0
+    s = (prof @ V) @ V.T
+    s[[3, 9]] = -np.inf
+    assert np.array_equal(top_w, np.argsort(-s, kind='stable')[:4])
+    with pytest.raises(ValueError):
+        m.show_recommendations('user')
