@@ -75,6 +75,7 @@ class RecommenderModel:
         self._ops = ops
         self.comm = comm or NoComm()
         self._factor_image = None
+        self._factor_src = None       # the host array in `factors` the cached image was made from
         # internal item order of the device path (csr.popularity_order): external id -> internal
         # position and back; None = identity.  `factors` and every result stay in EXTERNAL ids.
         self._item_rank = None
@@ -264,13 +265,17 @@ class RecommenderModel:
 
     # ---- recommend pipeline (models.py:359-405) ----------------------------------------------------------
     def _item_factors_device(self):
-        """FactorImage of the item factors in INTERNAL item order (rebuilt from `factors` when the
-        cached one was invalidated, e.g. by a rank truncation)."""
-        if self._factor_image is None:
-            v = np.ascontiguousarray(self.factors[self.data.fields.itemid])
+        """FactorImage of the item factors in INTERNAL item order.  The cached image belongs to ONE host array: it is
+        rebuilt whenever `factors` holds another one — after a rank truncation, or when a consumer swaps the
+        `factors` dict itself (the reference's rank-sweep pipelines restore it behind the model's back,
+        evaluation/pipelines.py:106-108)."""
+        src = self.factors[self.data.fields.itemid]
+        if self._factor_image is None or self._factor_src is not src:
+            v = np.ascontiguousarray(src)
             if self._item_inv is not None:
                 v = np.ascontiguousarray(v[self._item_inv])
             self._factor_image = scoring.FactorImage(self.ops, self.ops.to_device(v))
+            self._factor_src = src
         return self._factor_image
 
     def _test_weights(self, test_data):
@@ -595,6 +600,7 @@ class SVDModel(RecommenderModel):
         self.factors[self.data.fields.itemid] = item_factors
         self.factors['singular_values'] = ops.to_host(sigma)
         self._factor_image = scoring.FactorImage(ops, V) if item_factors is not None else None
+        self._factor_src = item_factors
 
 
 

@@ -165,3 +165,31 @@ def test_reference_pipelines_drive_our_model(polara):
     # rows with tied scores may differ between the two: a hit more or less among the 240 holdout items
     assert np.abs(scores_our.values - scores_ref.values).max() <= 2, (scores_our, scores_ref)
     assert best_our == best_ref or abs(scores_ref[best_our] - scores_ref[best_ref]) <= 2
+    # the pipeline put the rank-12 factors back behind the model's back: the next lists must be rank-12 lists
+    clear = clear_rows(ref_m, 10)
+    assert ref_m.rank == 12 and np.array_equal(our_m.recommendations[clear], ref_m.recommendations[clear])
+
+
+def test_reference_tucker_rank_pipeline_drives_our_model(polara):
+    """`find_optimal_tucker_ranks` (evaluation/pipelines.py:118-158): one HOOI build at the largest multilinear rank,
+    every smaller one through the `mlrank` setter (core rounding, models.py:949-980), factors restored by the
+    pipeline after each step."""
+    from numpy_ops import NumpyOps
+    from polara.evaluation.pipelines import find_optimal_tucker_ranks
+    from polara.recommender.models import CoffeeModel as RefCoffee
+    from polara_amd.models import CoffeeModel
+    data = make_data(polara, test_fold=4, warm_start=False, holdout_size=2, test_ratio=0.25)
+    ref_m, our_m = RefCoffee(data), CoffeeModel(data, ops=NumpyOps())
+    for m in (ref_m, our_m):
+        m.verbose = False
+        m.topk, m.seed, m.growth_tol = 8, 3, 1e-6
+    grid = [[3, 6], [3, 5], [2, 3]]
+    kw = dict(metric_type='hits', return_scores=True)
+    best_ref, scores_ref = quiet(find_optimal_tucker_ranks, ref_m, grid, 'true_positive', **kw)
+    best_our, scores_our = quiet(find_optimal_tucker_ranks, our_m, grid, 'true_positive', **kw)
+    assert list(scores_our.index) == list(scores_ref.index) and len(scores_our) == 8
+    assert len(our_m.training_time) == 1 and our_m.mlrank == (6, 5, 3)
+    assert np.abs(scores_our.values - scores_ref.values).max() <= 2, (scores_our, scores_ref)
+    assert best_our == best_ref or abs(scores_ref[best_our] - scores_ref[best_ref]) <= 2
+    clear = clear_rows(ref_m, 8)
+    assert np.array_equal(our_m.recommendations[clear], ref_m.recommendations[clear])
