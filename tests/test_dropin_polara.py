@@ -193,3 +193,27 @@ def test_reference_tucker_rank_pipeline_drives_our_model(polara):
     assert best_our == best_ref or abs(scores_ref[best_our] - scores_ref[best_ref]) <= 2
     clear = clear_rows(ref_m, 8)
     assert np.array_equal(our_m.recommendations[clear], ref_m.recommendations[clear])
+
+
+def test_reference_evaluation_engine_cross_validation(polara):
+    """`evaluation_engine.run_cv_experiment` with `topk_test` inside (evaluation_engine.py:104-144): the data object
+    moves from fold to fold (`data.update()` -> change events -> rebuild), the engine sets `topk` from large to small
+    (cached lists are cut, not recomputed, models.py:123-128) — both models in ONE experiment on the shared data."""
+    from numpy_ops import NumpyOps
+    from polara.evaluation import evaluation_engine as ee
+    from polara_amd.models import SVDModel
+    data = make_data(polara, warm_start=True, holdout_size=3, test_ratio=0.2)
+    ref_m, our_m = polara.SVDModel(data), SVDModel(data, ops=NumpyOps())
+    our_m.method = 'PureSVD-device'
+    for m in (ref_m, our_m):
+        m.verbose = False
+        m.rank = 7
+    np.random.seed(0)
+    res = quiet(ee.run_cv_experiment, [ref_m, our_m], folds=[1, 3], metrics='hits', fold_experiment=ee.topk_test,
+                topk_list=[3, 10, 5])
+    assert len(our_m.training_time) == 2 and len(ref_m.training_time) == 2      # one build per fold, none per topk
+    ref_rows, our_rows = res.xs('PureSVD', level='model'), res.xs('PureSVD-device', level='model')
+    assert list(ref_rows.index) == list(our_rows.index) and len(ref_rows) == 2 * 3          # folds x topk
+    cols = [('hits', 'true_positive'), ('hits', 'false_positive'), ('hits', 'false_negative')]
+    diff = np.abs(ref_rows[cols].values.astype(float) - our_rows[cols].values.astype(float))
+    assert diff.max() <= 2, res                                    # rows with tied scores: a hit more or less
