@@ -635,16 +635,27 @@ class ScaledMatrixMixin:
             self._row_scaling = new_value
             self._recommendations = None
 
-    def _training_csr(self, dtype=np.float64, ignore_feedback=False):
-        indptr, indices, values, shp = super()._training_csr(dtype=dtype, ignore_feedback=ignore_feedback)
+    def _scale_values(self, indptr, indices, values, shp):
+        """A' = D_r A D_c, D = (sqrt(nnz per row / column))^(scaling - 1); the column counts are those of the WHOLE
+        matrix (summed over ranks for a sharded dataset)."""
         row_nnz = np.diff(indptr).astype(np.float64)
         col_nnz = self._item_counts(indices, shp[1]).astype(np.float64)
         rs = np.ones_like(row_nnz)
         cs = np.ones_like(col_nnz)
         np.power(np.sqrt(row_nnz), self.row_scaling - 1, where=row_nnz != 0, out=rs)
         np.power(np.sqrt(col_nnz), self.col_scaling - 1, where=col_nnz != 0, out=cs)
-        values = (rs[np.repeat(np.arange(shp[0]), np.diff(indptr))] * values) * cs[indices]
-        return indptr, indices, values, shp
+        return (rs[np.repeat(np.arange(shp[0]), np.diff(indptr))] * values) * cs[indices]
+
+    def _training_csr(self, dtype=np.float64, ignore_feedback=False):
+        indptr, indices, values, shp = super()._training_csr(dtype=dtype, ignore_feedback=ignore_feedback)
+        return indptr, indices, self._scale_values(indptr, indices, values, shp), shp
+
+    def get_training_matrix(self, *args, **kwargs):
+        """models.py:889-893: the SCALED matrix, like the reference's mixin."""
+        m = super().get_training_matrix(*args, **kwargs)
+        csr = m.tocsr()
+        csr.data = self._scale_values(csr.indptr, csr.indices, csr.data.astype(np.float64), csr.shape)
+        return csr if m.format == 'csr' else csr.asformat(m.format)
 
     def _training_device_csr(self):
         indptr, indices, values, shp = self._training_csr(dtype=np.float64)

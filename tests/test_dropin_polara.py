@@ -217,3 +217,37 @@ def test_reference_evaluation_engine_cross_validation(polara):
     cols = [('hits', 'true_positive'), ('hits', 'false_positive'), ('hits', 'false_negative')]
     diff = np.abs(ref_rows[cols].values.astype(float) - our_rows[cols].values.astype(float))
     assert diff.max() <= 2, res                                    # rows with tied scores: a hit more or less
+
+
+@pytest.mark.parametrize('variant', ['scaled', 'threshold', 'nofilter'])
+def test_model_options_side_by_side(polara, variant):
+    """ScaledSVD's row/column scaling, a feedback threshold on a known-user split (below-threshold test feedback is
+    zeroed, not dropped: data.py:861) and `filter_seen=False`, each next to the reference on the same data object."""
+    from numpy_ops import NumpyOps
+    from polara.recommender.models import ScaledSVD as RefScaled
+    from polara_amd.models import SVDModel, ScaledSVD
+    cfg = dict(warm_start=True, holdout_size=3, test_ratio=0.2)
+    if variant == 'threshold':
+        cfg = dict(test_fold=4, warm_start=False, holdout_size=2, test_ratio=0.25)
+    data = make_data(polara, **cfg)
+    kw = dict(feedback_threshold=4) if variant == 'threshold' else {}
+    ref_m = (RefScaled if variant == 'scaled' else polara.SVDModel)(data, **kw)
+    our_m = (ScaledSVD if variant == 'scaled' else SVDModel)(data, ops=NumpyOps(), **kw)
+    for m in (ref_m, our_m):
+        m.verbose = False
+        m.rank, m.topk = 6, 9
+        if variant == 'scaled':
+            m.col_scaling, m.row_scaling = 0.3, 0.8
+        if variant == 'nofilter':
+            m.filter_seen = False
+    np.random.seed(0)
+    quiet(ref_m.build)
+    our_m.build()
+    assert our_m.method == ref_m.method
+    assert np.allclose(our_m.factors['singular_values'], ref_m.factors['singular_values'], rtol=1e-9)
+    clear = clear_rows(ref_m, 9)      # with the threshold, users left without positive feedback score 0 everywhere
+    assert clear.mean() > 0.6 and np.array_equal(our_m.recommendations[clear], ref_m.recommendations[clear])
+    A_ref, A_our = ref_m.get_training_matrix(), our_m.get_training_matrix()
+    assert (A_ref != A_our).nnz == 0 and A_ref.dtype == A_our.dtype
+    (m_ref, td_ref), (m_our, td_our) = ref_m.get_test_matrix(), our_m.get_test_matrix()
+    assert (m_ref != m_our).nnz == 0 and all(np.array_equal(a, b) for a, b in zip(td_ref, td_our))
