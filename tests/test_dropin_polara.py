@@ -251,3 +251,47 @@ def test_model_options_side_by_side(polara, variant):
     assert (A_ref != A_our).nnz == 0 and A_ref.dtype == A_our.dtype
     (m_ref, td_ref), (m_our, td_our) = ref_m.get_test_matrix(), our_m.get_test_matrix()
     assert (m_ref != m_our).nnz == 0 and all(np.array_equal(a, b) for a, b in zip(td_ref, td_our))
+
+
+def test_coffee_flatteners_and_rank_reduction_side_by_side(polara):
+    """One HOOI build each, then every way the reference flattens the feedback mode (models.py:983-1006) and a
+    reduction of the multilinear rank through the setter (core rounding, models.py:949-980)."""
+    from numpy_ops import NumpyOps
+    from polara.recommender.models import CoffeeModel as RefCoffee
+    from polara_amd.models import CoffeeModel
+    data = make_data(polara, test_fold=4, warm_start=False, holdout_size=2, test_ratio=0.25)
+    ref_m, our_m = RefCoffee(data), CoffeeModel(data, ops=NumpyOps())
+    for m in (ref_m, our_m):
+        m.verbose = False
+        m.mlrank, m.topk, m.seed, m.growth_tol = (7, 6, 4), 6, 5, 1e-6
+    quiet(ref_m.build)
+    our_m.build()
+    for flattener in (slice(0, None), [2, 3], 3, 'sum', (slice(1, None), 'mean'), lambda t: t[..., -1] - t[..., 0]):
+        ref_m.flattener = our_m.flattener = flattener
+        assert our_m._recommendations is None                      # the setter flushes the cache (models.py:936-940)
+        clear = clear_rows(ref_m, 6)
+        assert clear.mean() > 0.7, flattener
+        assert np.array_equal(our_m.recommendations[clear], ref_m.recommendations[clear]), flattener
+    # flatteners that are NOT linear in the feedback factor ('max', 'min', ...) see the sign of its columns, which is
+    # arbitrary in the reference (ARPACK's singular vectors): there the reference's own formula on OUR factors is the
+    # yardstick (the reference model given our factors)
+    for flattener in ((slice(1, None), 'max'), 'min'):
+        ref_m.flattener = our_m.flattener = flattener
+        saved = dict(**ref_m.factors)
+        try:
+            ref_m.factors = dict(**our_m.factors)
+            ref_m._recommendations = None
+            clear = clear_rows(ref_m, 6)
+            assert clear.mean() > 0.7 and np.array_equal(our_m.recommendations[clear], ref_m.recommendations[clear]), flattener
+        finally:
+            ref_m.factors = saved
+            ref_m._recommendations = None
+    ref_m.flattener = our_m.flattener = slice(0, None)
+    for mlrank in ((5, 6, 4), (5, 4, 3)):
+        ref_m.mlrank = our_m.mlrank = mlrank
+        assert our_m._is_ready and ref_m._is_ready
+        assert our_m.factors['core'].shape == ref_m.factors['core'].shape == mlrank
+        clear = clear_rows(ref_m, 6)
+        assert clear.mean() > 0.7 and np.array_equal(our_m.recommendations[clear], ref_m.recommendations[clear]), mlrank
+    ref_m.mlrank = our_m.mlrank = (8, 6, 4)                         # growing a rank invalidates the model
+    assert not our_m._is_ready and not ref_m._is_ready
