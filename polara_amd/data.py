@@ -190,6 +190,8 @@ class ShardedArrayData(ArrayData):
         self.n_users_total = int(n_users_total)
         self.local_csr = block
         self._fixed_levels = None if feedback_levels is None else np.asarray(feedback_levels, dtype=np.float64)
+        # the users to score are exactly the training rows: a model may score its device-resident training matrix
+        self.scores_training_rows = bool(score_all and holdout is None)
         super().__init__((u, i, f), n_users=block.n_rows, n_items=block.n_cols,
                          test=(u, i, f) if (score_all and holdout is None) else None, holdout=holdout, fields=fields)
 
@@ -201,6 +203,11 @@ class ShardedArrayData(ArrayData):
         block, manifest = load_rank_block(path, rank, world)
         kwargs.setdefault('feedback_levels', manifest.get('feedback_levels'))
         return cls(block, manifest['n_rows'], **kwargs)
+
+    def set_test_data(self, testset=None, holdout=None, notify=True):
+        if hasattr(self, 'scores_training_rows') and hasattr(self, '_test'):
+            self.scores_training_rows = False          # an explicit test set from now on
+        super().set_test_data(testset, holdout, notify)
 
     def set_training_data(self, training):
         raise NotImplementedError('a shard is immutable: write a new dataset (polara_amd.shards) instead')

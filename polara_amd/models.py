@@ -76,6 +76,7 @@ class RecommenderModel:
         self.comm = comm or NoComm()
         self._factor_image = None
         self._factor_src = None       # the host array in `factors` the cached image was made from
+        self._train_dev = None        # (device CSR of the training rows, its internal->external item map) when they double as the test rows
         # internal item order of the device path (csr.popularity_order): external id -> internal
         # position and back; None = identity.  `factors` and every result stay in EXTERNAL ids.
         self._item_rank = None
@@ -106,6 +107,7 @@ class RecommenderModel:
         self._recommendations = None
         self._is_ready = False
         self._factor_image = None
+        self._train_dev = None
 
     def _refresh_model(self):
         self._recommendations = None
@@ -282,16 +284,34 @@ class RecommenderModel:
         """Per-entry fold-in coefficients; None = the feedback values themselves."""
         return None
 
+    def _resident_test_csr(self):
+        """(test CSR in the current internal item order, mask of users with interactions) when the users to score
+        are the training rows already on the device (see _training_device_csr), else None.  A renaming of the
+        resident matrix's columns (one device gather) replaces frame -> triplets -> upload -> sort."""
+        if self._train_dev is None or not getattr(self.data, 'scores_training_rows', False) or self.feedback_threshold:
+            return None
+        A, inv_at_build = self._train_dev
+        # build-time internal id j = external item inv_at_build[j]; its current internal id is item_rank[that]
+        T = self.ops.csr_relabel_cols(A, self._item_rank[inv_at_build], sort=False)
+        nonempty = self.ops.to_host(A.indptr[1:] > A.indptr[:-1])
+        return T, nonempty
+
     def get_recommendations(self):
         if self.verify_integrity:
             self.verify_data_integrity()
-        test_data, test_shape, _ = self._get_test_data()
-        n_users, n_items = int(test_shape[0]), int(test_shape[1])
         ops, comm = self.ops, self.comm
-        w = self._test_weights(test_data)
-        vals = np.asarray(test_data[2] if w is None else w, dtype=np.float64)
-        cols = test_data[1] if self._item_rank is None else self._item_rank[np.asarray(test_data[1], dtype=np.intp)]
-        T = ops.csr_from_coo(test_data[0], cols, vals, (n_users, n_items))   # zeros kept: still "seen"
+        resident = self._resident_test_csr()
+        if resident is not None:
+            T, nonempty = resident
+            n_users, n_items = T.shape
+        else:
+            nonempty = None
+            test_data, test_shape, _ = self._get_test_data()
+            n_users, n_items = int(test_shape[0]), int(test_shape[1])
+            w = self._test_weights(test_data)
+            vals = np.asarray(test_data[2] if w is None else w, dtype=np.float64)
+            cols = test_data[1] if self._item_rank is None else self._item_rank[np.asarray(test_data[1], dtype=np.intp)]
+            T = ops.csr_from_coo(test_data[0], cols, vals, (n_users, n_items))   # zeros kept: still "seen"
         lo, hi = 0, n_users
         gather = comm.world > 1 and not self._presharded()   # a pre-sharded dataset: T already is this rank's users
         if gather:  # user-sharded scoring; V is replicated, no collective in the data path
@@ -309,6 +329,10 @@ class RecommenderModel:
         else:
             recs = np.empty((0, self.topk), dtype=np.int64)
         self.recommend_stats = stats
+        if nonempty is not None and not nonempty.all():
+            # the reference's test users are the users WITH interactions (rows of the rebased test triplet)
+            recs = np.ascontiguousarray(recs[nonempty])
+            recs_dev = None
         if gather:
             recs = comm.gather_rows(recs, n_users, self.topk)
             recs_dev = None
@@ -418,6 +442,7 @@ class RecommenderModel:
         @contextlib.contextmanager
         def swapped():
             saved = data._test
+            saved_flag = getattr(data, 'scores_training_rows', None)
             try:
                 if hasattr(data, 'get_entity_index'):         # Polara: a one-user frame in internal item ids
                     import pandas as pd
@@ -436,6 +461,8 @@ class RecommenderModel:
                 yield
             finally:
                 data._test = saved
+                if saved_flag is not None:
+                    data.scores_training_rows = saved_flag
         return swapped()
 
     def evaluate(self, metric_type='all', topk=None, not_rated_penalty=None, switch_positive=None,
@@ -529,7 +556,12 @@ class SVDModel(RecommenderModel):
             shp = (blk.n_rows, blk.n_cols)
             self._item_rank, self._item_inv = popularity_order(None, shp[1], counts=self._item_counts(blk.indices, shp[1]))
             values = np.ones(blk.nnz, dtype=np.float32) if blk.values is None else blk.values
-            return self.ops.csr_relabel_cols(self.ops.csr(blk.indptr, blk.indices, values, shp), self._item_rank)
+            A = self.ops.csr_relabel_cols(self.ops.csr(blk.indptr, blk.indices, values, shp), self._item_rank)
+            if getattr(self.data, 'scores_training_rows', False):
+                # the users to score ARE these rows (ShardedArrayData(score_all=True)): the matrix stays on the
+                # device, get_recommendations renames its columns instead of rebuilding it from triplets
+                self._train_dev = (A, self._item_inv)
+            return A
         idx, val, shp = self.data.to_coo(tensor_mode=False, feedback_threshold=self.feedback_threshold)
         self._item_rank, self._item_inv = popularity_order(None, shp[1], counts=self._item_counts(idx[:, 1], shp[1]))
         return self.ops.csr_from_coo(idx[:, 0], self._item_rank[idx[:, 1]], np.asarray(val, dtype=np.float64), shp)

@@ -60,7 +60,7 @@ class NumpyOps:
         ip, ix, vl = coo_to_csr(rows, cols, np.asarray(vals, dtype=np.float64), shape)
         return NpCSR(ip, ix, vl, shape)
 
-    def csr_relabel_cols(self, A, col_map):
+    def csr_relabel_cols(self, A, col_map, sort=True):
         m = A.m.tocoo()
         from polara_amd.csr import coo_to_csr
         ip, ix, vl = coo_to_csr(m.row, np.asarray(col_map)[m.col], m.data, A.shape, sum_duplicates=False)

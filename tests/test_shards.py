@@ -130,6 +130,15 @@ def test_presharded_single_block_equals_array_data(tmp_path):
             m.topk = 5
             m.build()
             out.append((m.factors[data.fields.itemid], m.get_recommendations()))
+            if data is sd:
+                # plain SVD scores the device-resident training matrix itself (no triplets, no sort); the scaled and
+                # the tensor model need other values per entry and take the general route
+                assert (m._train_dev is not None) == (cls is SVDModel) and sd.scores_training_rows
+                if cls is SVDModel:
+                    assert out[-1][1].shape[0] == int((np.diff(indptr) > 0).sum()) < shape[0]   # users without a row: no list
+                    top, seen = m.show_recommendations([1, 2, 3], topk=4)      # an ad-hoc user swaps the test set ...
+                    assert set(seen) == {1, 2, 3} and sd.scores_training_rows  # ... and everything is put back
+                    assert np.array_equal(m.get_recommendations(), out[-1][1])
         assert np.allclose(out[0][0] @ out[0][0].T, out[1][0] @ out[1][0].T, atol=1e-9)
         assert np.array_equal(out[0][1], out[1][1])
     # a block of a larger dataset cannot be modelled without its job's communicator
