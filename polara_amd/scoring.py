@@ -61,11 +61,11 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
     columns by descending score — the contract of models.py:400-405.
 
     approx_fold_in (default: on when only the ids are asked for and the feedback is non-negative): the fold-in
-    E = T V gathers the fp32 image of V (half the bytes of the product that is bound by them); the
-    re-scoring kernel then knows every score to within delta_u = 2^-24 w_u max||V_i|| and certifies the ORDER
-    only where consecutive scores are further apart than 2 delta_u; the (few) other users get their E row
-    recomputed from the fp64 factors and are re-scored exactly.  The returned ids are those of the exact
-    pipeline either way."""
+    E = T V gathers the fp32 image of V (half the bytes of the product that is bound by them), and so does the
+    first re-scoring of the candidates; the re-scoring kernel then knows every score to within
+    delta_u = 2^-24 (w_u + ||E'_u||) max||V_i|| and certifies the ORDER only where consecutive scores are further
+    apart than 2 delta_u; the (few) other users get their E row recomputed from the fp64 factors and are re-scored
+    exactly, against the fp64 item rows.  The returned ids are those of the exact pipeline either way."""
     n_users, n_items = T.shape
     if n_items != factors.n_items:
         raise ValueError('test matrix and item factors disagree on the number of items')
