@@ -182,58 +182,53 @@ class RecommenderModel:
             return False
 
     def _get_test_data(self, feedback_threshold=None):
-        """models.py:227-257."""
+        """The contract of models.py:227-257: ((user, item, feedback) sorted by user with users numbered 0..n-1
+        without gaps, test shape, the data-level id of the user behind every row)."""
         tensor_mode = self._tensor_mode()
-        test_shape = self.data.get_test_shape(tensor_mode=tensor_mode)
+        shape = self.data.get_test_shape(tensor_mode=tensor_mode)
         threshold = feedback_threshold or self.feedback_threshold
+        if self.data.warm_start and threshold:
+            print('Specifying threshold has no effect in warm start.')
+        elif (not self.data.warm_start) and self.data.test_sample and threshold is not None:
+            print('Specifying both threshold value and test_sample may change test data.')
         if self.data.warm_start:
-            if threshold:
-                print('Specifying threshold has no effect in warm start.')
             threshold = None
-        else:
-            if self.data.test_sample and (threshold is not None):
-                print('Specifying both threshold value and test_sample may change test data.')
-        user_idx, item_idx, feedback = self.data.test_to_coo(tensor_mode=tensor_mode, feedback_threshold=threshold)
-        idx_diff = np.diff(user_idx)
-        assert (idx_diff >= 0).all()  # calculations assume testset is sorted by users!
-        if (idx_diff > 1).any() or (user_idx.min() != 0):
-            test_users = user_idx[np.r_[0, np.where(idx_diff)[0] + 1]]
-            user_idx = np.r_[0, np.cumsum(idx_diff > 0)].astype(user_idx.dtype)
-        else:
-            test_users = np.arange(test_shape[0])
-        return (user_idx, item_idx, feedback), test_shape, test_users
+        users, items, feedback = self.data.test_to_coo(tensor_mode=tensor_mode, feedback_threshold=threshold)
+        users = np.asarray(users)
+        step = users[1:] - users[:-1]
+        if (step < 0).any():
+            raise AssertionError('the test set must be sorted by users')
+        if len(users) and users[0] == 0 and not (step > 1).any():
+            return (users, items, feedback), shape, np.arange(shape[0])      # already numbered without gaps
+        first = np.concatenate(([True], step > 0)) if len(users) else np.zeros(0, dtype=bool)
+        dense_ids = (np.cumsum(first) - 1).astype(users.dtype)               # row number of every entry
+        return (dense_ids, items, feedback), shape, users[first]
 
     @staticmethod
     def _slice_test_data(test_data, start, stop):
-        """models.py:260-270: the triplet of users [start, stop), users re-based to 0."""
-        user_coo, item_coo, fdbk_coo = test_data
-        slicer = (user_coo >= start) & (user_coo < stop)
-        return user_coo[slicer] - start, item_coo[slicer], fdbk_coo[slicer]
+        """models.py:260-270: the entries of rows [start, stop), rows renumbered from 0."""
+        users, items, feedback = test_data
+        inside = np.flatnonzero((users >= start) & (users < stop))
+        return users[inside] - start, items[inside], feedback[inside]
 
     def get_test_matrix(self, test_data=None, shape=None, user_slice=None, dtype=None, ignore_feedback=False):
-        """models.py:180-211 (host-side, API compatibility): the SciPy CSR of the test users (zero feedback
-        dropped from the matrix, kept in the returned triplet — it still counts as seen) + that triplet.
-        The device path builds its own test CSR (scoring.test_csr_from_triplet) and never chunks."""
+        """models.py:180-211 (host-side, API compatibility): the SciPy CSR of the test users — entries with zero
+        feedback left out of the matrix but kept in the returned triplet, where they still count as seen — and
+        that triplet.  The device path builds its own test CSR (ops.csr_from_coo) and never chunks."""
         from scipy.sparse import csr_matrix
         if test_data is None:
             test_data, shape, _ = self._get_test_data()
         elif shape is None:
             raise ValueError('Shape of test data must be provided')
-        num_users = shape[0]
-        coo_data = test_data
+        n_rows, triplet = shape[0], test_data
         if user_slice:
-            start, stop = user_slice
-            stop = min(stop, shape[0])
-            num_users = stop - start
-            coo_data = self._slice_test_data(test_data, start, stop)
-        user_coo, item_coo, fdbk_coo = coo_data
-        valid = fdbk_coo != 0
-        if not valid.all():
-            user_coo, item_coo, fdbk_coo = user_coo[valid], item_coo[valid], fdbk_coo[valid]
-        dtype = dtype or fdbk_coo.dtype
-        if ignore_feedback:
-            fdbk_coo = np.ones_like(fdbk_coo, dtype=dtype)
-        return csr_matrix((fdbk_coo, (user_coo, item_coo)), shape=(num_users, shape[1]), dtype=dtype), coo_data
+            lo, hi = user_slice[0], min(user_slice[1], shape[0])
+            n_rows, triplet = hi - lo, self._slice_test_data(test_data, lo, hi)
+        users, items, feedback = triplet
+        keep = np.flatnonzero(feedback)                                      # explicit zeros do not enter the matrix
+        dtype = dtype or feedback.dtype
+        vals = np.ones(len(keep), dtype=dtype) if ignore_feedback else feedback[keep]
+        return csr_matrix((vals, (users[keep], items[keep])), shape=(n_rows, shape[1]), dtype=dtype), triplet
 
     def verify_data_integrity(self):
         """models.py:581-604 reduced to the checks that do not need pandas."""
@@ -535,17 +530,15 @@ class SVDModel(RecommenderModel):
             self._factor_image = None
 
     def _check_reduced_rank(self, rank):
-        """models.py:819-832: smaller rank = column prefix of the cached factors, no rebuild."""
-        for entity, factor in self.factors.items():
-            if factor is None:
-                continue
-            if factor.shape[-1] < rank:
-                self._is_ready = False
-                self.factors = dict.fromkeys(self.factors.keys())
-                break
-            else:
-                self.factors = dict(**self.factors)
-                self.factors[entity] = factor[..., :rank]
+        """models.py:819-832: a smaller rank is the leading columns of the cached factors (and the leading singular
+        values) — no rebuild; a larger one empties them and marks the model as not ready."""
+        have = {k: f for k, f in self.factors.items() if f is not None}
+        if any(f.shape[-1] < rank for f in have.values()):
+            self._is_ready = False
+            self.factors = {k: None for k in self.factors}
+            return
+        # a NEW dict with views: whoever kept the old dict (the rank-sweep pipelines do) keeps the full factors
+        self.factors = {k: (f[..., :rank] if f is not None else None) for k, f in self.factors.items()}
 
     def _training_device_csr(self):
         """The training matrix as a device CSR (COO -> CSR on device, models.py:160-177)."""
@@ -700,20 +693,23 @@ class ScaledSVD(ScaledMatrixMixin, SVDModel):
 
 
 def flatten_scores(tensor_scores, flattener=None):
-    """models.py:983-1006 (tiny host glue on r2-length vectors)."""
-    flattener = flattener or slice(None)
-    if isinstance(flattener, str):
-        return getattr(np, flattener)(tensor_scores[..., slice(None)], axis=-1)
-    if isinstance(flattener, int):
-        return tensor_scores[..., flattener]
-    if isinstance(flattener, (list, slice)):
-        return np.sum(tensor_scores[..., flattener], axis=-1)
-    if isinstance(flattener, tuple):
-        slicer, method = flattener
-        return getattr(np, method)(tensor_scores[..., slicer or slice(None)], axis=-1)
+    """How the feedback mode is folded away (models.py:983-1006): a level index, a list/slice of levels (summed),
+    the name of a NumPy reduction, a (levels, reduction-name) pair, or any callable over the last axis."""
+    flattener = flattener or slice(None)       # None — and, as in the reference, a bare level 0 — mean "sum all levels"
     if callable(flattener):
         return flattener(tensor_scores)
-    raise ValueError('Unrecognized value for flattener attribute')
+    if isinstance(flattener, (int, np.integer)):
+        return tensor_scores[..., flattener]
+    levels, reduce_name = slice(None), 'sum'
+    if isinstance(flattener, str):
+        reduce_name = flattener
+    elif isinstance(flattener, tuple):
+        levels, reduce_name = flattener[0] or slice(None), flattener[1]
+    elif isinstance(flattener, (list, slice)):
+        levels = flattener
+    else:
+        raise ValueError('Unrecognized value for flattener attribute')
+    return getattr(np, reduce_name)(tensor_scores[..., levels], axis=-1)
 
 
 class CoffeeModel(RecommenderModel):
@@ -757,37 +753,29 @@ class CoffeeModel(RecommenderModel):
 
     @staticmethod
     def round_core(core, mode, rank):
-        """models.py:968-980."""
-        new_dims = [mode] + [m for m in range(core.ndim) if m != mode]
-        mode_dim = core.shape[mode]
-        flat_core = core.transpose(new_dims).reshape((mode_dim, -1), order='F')
-        u, s, vt = np.linalg.svd(flat_core, full_matrices=False)
-        rfactor = u[:, :rank]
-        inv = np.empty(len(new_dims), dtype=np.intp)
-        inv[np.array(new_dims)] = np.arange(len(new_dims))
-        new_core = (np.ascontiguousarray(s[:rank, np.newaxis] * vt[:rank, :])
-                    .reshape(rank, *[core.shape[i] for i in new_dims[1:]], order='F')
-                    .transpose(inv))
-        return rfactor, new_core
+        """Truncated SVD of the mode-`mode` unfolding of the core (models.py:968-980): returns the rotation of that
+        mode's factor [r_mode x rank] and the core with that mode cut to `rank`."""
+        unfolded = np.moveaxis(core, mode, 0)
+        rest = unfolded.shape[1:]
+        u, s, vt = np.linalg.svd(unfolded.reshape((core.shape[mode], -1), order='F'), full_matrices=False)
+        cut = np.ascontiguousarray(s[:rank, None] * vt[:rank]).reshape((rank,) + rest, order='F')
+        return u[:, :rank], np.moveaxis(cut, 0, mode)
 
     def _check_reduced_rank(self, mlrank):
-        """models.py:949-965."""
-        for mode, entity in enumerate(self.data.fields):
-            factor = self.factors.get(entity, None)
-            if factor is None:
-                continue
-            rank = mlrank[mode]
-            if factor.shape[1] < rank:
-                self._is_ready = False
-                self.factors = {}
-                break
-            elif factor.shape[1] == rank:
-                continue
-            else:
-                self.factors = dict(**self.factors)
-                rfactor, new_core = self.round_core(self.factors['core'], mode, rank)
-                self.factors[entity] = factor.dot(rfactor)
-                self.factors['core'] = new_core
+        """models.py:949-965: a smaller multilinear rank is served from the cached factors (each reduced mode is
+        rotated onto the leading singular directions of the core's unfolding, the core shrinks); a larger one
+        invalidates the model."""
+        cached = [(mode, entity, self.factors.get(entity, None)) for mode, entity in enumerate(self.data.fields)]
+        cached = [(mode, entity, f) for mode, entity, f in cached if f is not None]
+        if any(f.shape[1] < mlrank[mode] for mode, _, f in cached):
+            self._is_ready = False
+            self.factors = {}
+            return
+        for mode, entity, f in cached:
+            if f.shape[1] > mlrank[mode]:
+                self.factors = dict(**self.factors)          # never write into a dict somebody may have kept
+                rotation, self.factors['core'] = self.round_core(self.factors['core'], mode, mlrank[mode])
+                self.factors[entity] = f.dot(rotation)
 
     def build(self):
         """models.py:1009-1024."""
