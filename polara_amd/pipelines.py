@@ -23,30 +23,28 @@ def find_optimal_svd_rank(model, ranks, target_metric, return_scores=False, prot
                           metric_type='all', **evaluate_kwargs):
     """Returns the rank (of `ranks`) with the largest `target_metric` — a metric field name such as 'hr',
     'precision', 'map', 'ndcg', or a callable on the dict of all computed fields — and, with
-    return_scores=True, also the dict rank -> value in the order of `ranks`."""
+    return_scores=True, also the dict rank -> value in the order of `ranks`.
+    protect_factors: put the full-rank factors back when the sweep is over (the default, as in the reference)."""
     ranks = list(ranks)
-    model_verbose = model.verbose
-    model.rank = svd_rank = max(max(ranks), model.rank)
+    top = max(ranks + [model.rank])
+    model.rank = top                                  # growing the rank invalidates the model, shrinking never does
     if not model._is_ready:
-        model.verbose = verbose
-        model.build()
-    if protect_factors:
-        svd_factors = dict(**model.factors)      # the truncations below must not eat the full factors
-    res = {}
+        quiet, model.verbose = model.verbose, verbose
+        try:
+            model.build()
+        finally:
+            model.verbose = quiet
+    full = dict(model.factors) if protect_factors else None
+    value = {}
     try:
-        for rank in sorted(ranks, key=lambda x: -x):
-            model.rank = rank
-            res[rank] = _metric_value(model.evaluate(metric_type, **evaluate_kwargs), target_metric)
-            model._recommendations = None        # no stale lists across ranks
+        for r in sorted(set(ranks), reverse=True):    # every step is a truncation of what the previous one left
+            model.rank = r
+            model._recommendations = None             # lists of another rank are not this rank's lists
+            value[r] = _metric_value(model.evaluate(metric_type, **evaluate_kwargs), target_metric)
     finally:
-        if protect_factors:
-            model._rank = svd_rank
-            model.factors = svd_factors
-            model._recommendations = None
-            if hasattr(model, '_factor_image'):
-                model._factor_image = None
-        model.verbose = model_verbose
-    best_rank = max(ranks, key=lambda r: (res[r], -ranks.index(r)))
-    if return_scores:
-        return best_rank, {r: res[r] for r in ranks}
-    return best_rank
+        model._recommendations = None
+        if full is not None:
+            model._rank, model.factors = top, full    # behind the setter's back: nothing to truncate, nothing to rebuild
+    # ties go to the largest rank, as in the reference (idxmax over a table filled from the largest rank down)
+    best = max(sorted(set(ranks)), key=lambda r: (value[r], r))
+    return (best, {r: value[r] for r in ranks}) if return_scores else best
