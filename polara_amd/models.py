@@ -34,6 +34,21 @@ def _format_elapsed(seconds_total):
     return f'{hours:.0f}h:{minutes:>02.0f}m:{seconds:>02.0f}s'
 
 
+def _setting(name, on_change, doc):
+    """A configuration attribute stored as `_<name>` whose CHANGE (assigning an equal value is a no-op) calls the
+    model method `on_change` — the reference's cache rules (models.py:119-148, 870-887, 930-940) in one place."""
+    slot = '_' + name
+
+    def get(self):
+        return getattr(self, slot)
+
+    def put(self, value):
+        if getattr(self, slot) != value:
+            setattr(self, slot, value)
+            getattr(self, on_change)()
+    return property(get, put, doc=doc)
+
+
 class RecommenderModel:
     """Base class: configuration, caching and the recommend pipeline (models.py:70-604)."""
     _config = ('topk', 'filter_seen', 'switch_positive', 'feedback_threshold', 'verify_integrity')
@@ -118,29 +133,14 @@ class RecommenderModel:
 
     @topk.setter
     def topk(self, new_value):
-        if (self._recommendations is not None) and (new_value > self._recommendations.shape[1]):
+        # cached lists are cut when k shrinks (their leading columns) and dropped only when it grows (models.py:123-128)
+        cached = self._recommendations
+        if cached is not None and new_value > cached.shape[1]:
             self._recommendations = None
         self._topk = new_value
 
-    @property
-    def feedback_threshold(self):
-        return self._feedback_threshold
-
-    @feedback_threshold.setter
-    def feedback_threshold(self, new_value):
-        if self._feedback_threshold != new_value:
-            self._feedback_threshold = new_value
-            self._renew_model()
-
-    @property
-    def filter_seen(self):
-        return self._filter_seen
-
-    @filter_seen.setter
-    def filter_seen(self, new_value):
-        if self._filter_seen != new_value:
-            self._filter_seen = new_value
-            self._refresh_model()
+    feedback_threshold = _setting('feedback_threshold', '_renew_model', 'training entries below it are dropped: a new model')
+    filter_seen = _setting('filter_seen', '_refresh_model', 'whether seen items may be recommended: new lists, same model')
 
     def get_base_configuration(self):
         return {attr: getattr(self, attr) for attr in self._config}
@@ -640,25 +640,8 @@ class ScaledMatrixMixin:
         self._row_scaling = 1
         self.method = f'{self.method}-s'
 
-    @property
-    def col_scaling(self):
-        return self._col_scaling
-
-    @property
-    def row_scaling(self):
-        return self._row_scaling
-
-    @col_scaling.setter
-    def col_scaling(self, new_value):
-        if new_value != self._col_scaling:
-            self._col_scaling = new_value
-            self._recommendations = None
-
-    @row_scaling.setter
-    def row_scaling(self, new_value):
-        if new_value != self._row_scaling:
-            self._row_scaling = new_value
-            self._recommendations = None
+    col_scaling = _setting('col_scaling', '_refresh_model', 'exponent of the column (item) scaling, models.py:870-887')
+    row_scaling = _setting('row_scaling', '_refresh_model', 'exponent of the row (user) scaling')
 
     def _scale_values(self, indptr, indices, values, shp):
         """A' = D_r A D_c, D = (sqrt(nnz per row / column))^(scaling - 1); the column counts are those of the WHOLE
@@ -741,15 +724,7 @@ class CoffeeModel(RecommenderModel):
             self._recommendations = None
             self._factor_image = None
 
-    @property
-    def flattener(self):
-        return self._flattener
-
-    @flattener.setter
-    def flattener(self, new_value):
-        if new_value != self._flattener:
-            self._flattener = new_value
-            self._recommendations = None
+    flattener = _setting('flattener', '_refresh_model', 'how the feedback mode is folded away (see flatten_scores)')
 
     @staticmethod
     def round_core(core, mode, rank):
