@@ -16,6 +16,14 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+def free_port():
+    """A TCP port nobody listens on right now (rendezvous of the two-rank tests: a fixed number may be taken)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(('127.0.0.1', 0))
+        return sock.getsockname()[1]
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name + '.npz'))
 

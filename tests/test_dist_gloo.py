@@ -3,13 +3,13 @@ import os
 import subprocess
 import sys
 
-from conftest import ROOT
+from conftest import ROOT, free_port
 
 
 def test_two_rank_sharded_build_and_scoring():
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='2')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-           '--master-addr', '127.0.0.1', '--master-port', '29617', os.path.join(ROOT, 'tests', 'dist_worker.py')]
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.join(ROOT, 'tests', 'dist_worker.py')]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert 'DIST_RESULT' in r.stdout
