@@ -123,6 +123,7 @@ class RecommenderModel:
         self._is_ready = False
         self._factor_image = None
         self._train_dev = None
+        self._resident = None
 
     def _refresh_model(self):
         self._recommendations = None
@@ -286,9 +287,13 @@ class RecommenderModel:
         if self._train_dev is None or not getattr(self.data, 'scores_training_rows', False) or self.feedback_threshold:
             return None
         A, inv_at_build = self._train_dev
+        cached = getattr(self, '_resident', None)
+        if cached is not None and cached[0] is A and cached[1] is self._item_rank:
+            return cached[2], cached[3]               # same matrix, same serving order: keep its seen-tile streams
         # build-time internal id j = external item inv_at_build[j]; its current internal id is item_rank[that]
         T = self.ops.csr_relabel_cols(A, self._item_rank[inv_at_build], sort=False)
         nonempty = self.ops.to_host(A.indptr[1:] > A.indptr[:-1])
+        self._resident = (A, self._item_rank, T, nonempty)
         return T, nonempty
 
     def get_recommendations(self):
