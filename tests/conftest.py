@@ -61,3 +61,11 @@ class GoldenData:
                 s = tuple(int(x) for x in self.g['test_shape'])
                 return s if tensor_mode else s[:2]
         return _GD(g)
+
+
+def pytest_collection_modifyitems(config, items):
+    # the reference's own code raises pandas FutureWarnings by the dozen under pandas 2: not ours to fix, not worth a page of output
+    for item in items:
+        if 'test_dropin_polara' in item.nodeid:
+            item.add_marker(pytest.mark.filterwarnings('ignore::FutureWarning'))
+            item.add_marker(pytest.mark.filterwarnings('ignore::DeprecationWarning'))
