@@ -338,3 +338,42 @@ def test_data_events_reach_both_models_alike(polara, kind):
         assert state_our == state_ref, (attr, value, state_our, state_ref)
         lists_agree()
     assert len(our_m.training_time) == len(ref_m.training_time)            # rebuilt exactly as often
+
+
+@pytest.mark.parametrize('cfg', [dict(warm_start=True, holdout_size=3, test_ratio=0.2),
+                                 dict(test_fold=4, warm_start=False, holdout_size=2, test_ratio=0.25, random_holdout=True),
+                                 dict(warm_start=True, holdout_size=1, test_ratio=0.2)],
+                         ids=['warm_h3', 'known_h2', 'warm_h1'])
+def test_native_metrics_equal_the_reference_evaluate(polara, cfg):
+    """polara_amd.evaluation (what `evaluate()` runs on ArrayData / without Polara) against the reference's
+    `evaluate()` on the SAME lists and holdout, over topk, switch_positive and the metric families — every number
+    that does not pass through the reference's uninitialised-memory division (see evaluation.py's header)."""
+    from polara_amd import evaluation as ev
+    data = make_data(polara, **cfg)
+    ref_m = polara.SVDModel(data)
+    ref_m.verbose = False
+    ref_m.rank, ref_m.topk = 6, 12
+    np.random.seed(0)
+    quiet(ref_m.build)
+    recs = ref_m.recommendations
+    f = data.fields
+    h = data.test.holdout
+    hu, hi_, hf = h[f.userid].values, h[f.itemid].values, h[f.feedback].values.astype(np.float64)
+    hu = np.unique(hu, return_inverse=True)[1]                       # rows of the lists = the sorted holdout users
+    n_items = data.get_test_shape()[1] if hasattr(data, 'get_test_shape') else recs.max() + 1
+    for topk in (12, 5, 1):
+        for switch_positive in (None, 4):
+            kw = dict(topk=topk, switch_positive=switch_positive)
+            want = dict((type(s).__name__, s) for s in quiet(ref_m.evaluate, 'all', **kw))
+            got = dict((type(s).__name__, s) for s in ev.evaluate(recs, hu, hi_, hf, n_items, metric_type='all',
+                                                                    holdout_size=data.holdout_size, **kw))
+            assert got.keys() == want.keys()
+            for a, b in zip(got['Hits'], want['Hits']):
+                assert (a is None and b is None) or a == b, (topk, switch_positive, got['Hits'], want['Hits'])
+            assert np.isclose(got['Experience'].coverage, want['Experience'].coverage, rtol=1e-13)
+            rk_got, rk_want = got['Ranking']._asdict(), want['Ranking']._asdict()
+            for name in set(rk_got) & {'map', 'arhr', 'mrr'}:
+                assert np.isclose(rk_got[name], rk_want[name], rtol=1e-12), (name, topk, switch_positive)
+            rl_got, rl_want = got['Relevance']._asdict(), want['Relevance']._asdict()
+            if 'hr' in rl_got:
+                assert np.isclose(rl_got['hr'], rl_want['hr'], rtol=1e-13)
