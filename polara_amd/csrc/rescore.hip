@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256) void score_exact_rows_kernel(
     double *score = reinterpret_cast<double *>(work + (int64_t)blockIdx.x * per_row);
     unsigned char *cls = work + (int64_t)blockIdx.x * per_row + n_items * 8;
 
-    if (tid < K) s_e[tid] = E[user * lde + tid];
+    for (int c = tid; c < K; c += 256) s_e[c] = E[user * lde + c];
     __syncthreads();
     for (int64_t i = tid; i < n_items; i += 256) {
         const double *vr = V + i * ldv;
@@ -542,11 +542,11 @@ extern "C" int pk_score_exact_rows_f64(void *stream, int32_t n_rows, const int32
                                        int32_t K, const double *V_dev, int64_t ldv, const double *E_dev,
                                        int64_t lde, const int64_t *seen_ptr_dev, const int32_t *seen_idx_dev,
                                        int32_t topk, int64_t *out_idx_dev, double *out_score_dev, void *work_dev) {
-    PK_REQUIRE(n_rows >= 0 && n_items >= 1 && K >= 1 && K <= 256 && topk >= 1, "pk_score_exact_rows_f64: bad sizes");
+    PK_REQUIRE(n_rows >= 0 && n_items >= 1 && K >= 1 && K <= 8192 && topk >= 1, "pk_score_exact_rows_f64: bad sizes");
     PK_REQUIRE(ldv >= K && lde >= K && work_dev, "pk_score_exact_rows_f64: bad arguments");
     if (n_rows == 0) return PK_OK;
     const int64_t per_row = n_items * 8 + ((n_items + 15) / 16) * 16;
-    hipLaunchKernelGGL(score_exact_rows_kernel, dim3((unsigned)n_rows), dim3(256), 0, pk_stream(stream), rows_dev,
+    hipLaunchKernelGGL(score_exact_rows_kernel, dim3((unsigned)n_rows), dim3(256), (size_t)K * 8, pk_stream(stream), rows_dev,
                        n_items, K, V_dev, ldv, E_dev, lde, seen_ptr_dev, seen_idx_dev, topk, out_idx_dev,
                        out_score_dev, static_cast<unsigned char *>(work_dev), per_row);
     PK_CHECK_LAUNCH("score_exact_rows_kernel");
@@ -560,9 +560,9 @@ __global__ __launch_bounds__(256) void dense_scores_kernel(int n_rows, int64_t n
                                                            const double *__restrict__ V, int64_t ldv,
                                                            const double *__restrict__ E, int64_t lde,
                                                            double *__restrict__ out, int64_t ldo) {
-    __shared__ double s_e[256];
+    extern __shared__ double s_e[];   // K doubles
     const int r = blockIdx.y;
-    if (threadIdx.x < K) s_e[threadIdx.x] = E[(int64_t)r * lde + threadIdx.x];
+    for (int c = threadIdx.x; c < K; c += 256) s_e[c] = E[(int64_t)r * lde + c];
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n_items) return;
@@ -572,9 +572,9 @@ __global__ __launch_bounds__(256) void dense_scores_kernel(int n_rows, int64_t n
 
 extern "C" int pk_dense_scores_f64(void *stream, int32_t n_rows, int64_t n_items, int32_t K, const double *V_dev,
                                    int64_t ldv, const double *E_dev, int64_t lde, double *out_dev, int64_t ldo) {
-    PK_REQUIRE(n_rows >= 1 && n_rows <= 65535 && n_items >= 1 && K >= 1 && K <= 256 && ldo >= n_items,
+    PK_REQUIRE(n_rows >= 1 && n_rows <= 65535 && n_items >= 1 && K >= 1 && K <= 8192 && ldo >= n_items,
                "pk_dense_scores_f64: bad sizes");
-    hipLaunchKernelGGL(dense_scores_kernel, dim3((unsigned)pk_ceil_div(n_items, 256), (unsigned)n_rows), dim3(256), 0,
+    hipLaunchKernelGGL(dense_scores_kernel, dim3((unsigned)pk_ceil_div(n_items, 256), (unsigned)n_rows), dim3(256), (size_t)K * 8,
                        pk_stream(stream), n_rows, n_items, K, V_dev, ldv, E_dev, lde, out_dev, ldo);
     PK_CHECK_LAUNCH("dense_scores_kernel");
     return PK_OK;

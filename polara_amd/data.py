@@ -51,7 +51,12 @@ class ArrayData:
         self.fields = Fields(*fields)
         self.warm_start = bool(warm_start)
         self.test_sample = None
-        self.holdout_size = holdout_size if holdout_size is not None else (0 if holdout is None else 1)
+        # the reference takes holdout_size from the data configuration (data.py: `holdout_size`), where it always
+        # equals the number of items actually held out per user; here it is inferred from the holdout itself
+        # (largest number of holdout items of a user) unless given — and a given value must agree with the holdout,
+        # because evaluate() switches to the HR / reciprocal-rank family when it is 1 (models.py:453-462)
+        self._holdout_size_given = holdout_size
+        self.holdout_size = holdout_size if holdout_size is not None else 0
         self.on_change_event = 'on_change'
         self.on_update_event = 'on_update'
         self._notify = _Notifier([self.on_change_event, self.on_update_event])
@@ -88,8 +93,22 @@ class ArrayData:
             return Triplets(u[order].astype(np.int64), i[order].astype(np.int64),
                             np.asarray(f, dtype=np.float64)[order])
         self._test = TestData(norm(testset), norm(holdout))
+        self._set_holdout_size()
+        self._holdout_size_given = None      # the constructor's value described the constructor's holdout only
         if notify:
             self._notify(self.on_update_event)
+
+    def _set_holdout_size(self):
+        hold = self._test.holdout
+        per_user = 0
+        if hold is not None and len(hold.userid):
+            u = hold.userid
+            first = np.flatnonzero(np.r_[True, u[1:] != u[:-1]])          # sorted by user (set_test_data)
+            per_user = int(np.diff(np.r_[first, len(u)]).max())
+        given = getattr(self, '_holdout_size_given', None)
+        if given is not None and hold is not None and int(given) != per_user:
+            raise ValueError('holdout_size=%d, but the holdout has up to %d items per user' % (given, per_user))
+        self.holdout_size = int(given) if given is not None else per_user
 
     # ---- the hot-path protocol ----------------------------------------------------------------------
     @staticmethod

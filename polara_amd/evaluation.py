@@ -7,6 +7,12 @@ Inputs follow the reference's conventions: the holdout triplets are sorted by us
 least one holdout item, and row r of `recommendations` belongs to the r-th distinct holdout user
 (evaluation.py:47-62 builds its row pointers from `np.diff(keys)` under the same assumption).
 
+Holdout entries with feedback exactly 0 (when feedback is used): the reference's hit matrices are sparse products
+of the boolean image of the holdout matrix with the rank matrix (evaluation.py:75-84), so such an entry is never
+a hit or a miss; with a positive/negative split they also drop out of the per-class counts (`eliminate_zeros`,
+evaluation.py:60-73), without one they still count as holdout items (`eval_matrix.getnnz`, evaluation.py:188,131).
+Mirrored here through `_Matched.nz`.
+
 One deliberate difference: the reference divides through `np.divide(a, b, where=mask)` without `out=`
 (evaluation.py:19-21), so the rows a mask excludes hold UNINITIALISED memory and leak into the means of
 recall-type ratios (its own outputs show miss_rate + recall != 1 and NDCG > 1).  Here excluded rows contribute
@@ -43,7 +49,7 @@ class _Matched:
         if ranks is not None:
             self._from_ranks(recommendations, holdout_user, holdout_item, holdout_fdbk, is_positive, ranks, n_valid_recs)
             return
-        recs = np.array(recommendations, copy=False, ndmin=2)
+        recs = np.atleast_2d(np.asarray(recommendations))
         users = np.asarray(holdout_user)
         if (np.diff(users) < 0).any():
             raise ValueError('holdout must be sorted by user')
@@ -57,6 +63,7 @@ class _Matched:
         self.rel = np.ones(len(users)) if holdout_fdbk is None else np.asarray(holdout_fdbk, dtype=np.float64)
         self.positive = np.ones(len(users), bool) if is_positive is None else np.asarray(is_positive, bool)
         self.split = is_positive is not None
+        self.nz = self.rel != 0
         # rank of every holdout item in its user's list
         match = recs[row] == self.item[:, None]                      # [n_holdout x topk]
         self.rank = np.where(match.any(axis=1), match.argmax(axis=1) + 1, 0)
@@ -75,6 +82,7 @@ class _Matched:
         self.rel = np.ones(len(users)) if holdout_fdbk is None else np.asarray(holdout_fdbk, dtype=np.float64)
         self.positive = np.ones(len(users), bool) if is_positive is None else np.asarray(is_positive, bool)
         self.split = is_positive is not None
+        self.nz = self.rel != 0
         self.rank = np.asarray(ranks).astype(np.int64)
         self.n_valid_recs = (np.full(self.n_users, self.topk) if n_valid_recs is None else np.asarray(n_valid_recs))
 
@@ -84,7 +92,7 @@ class _Matched:
 
 
 def _relevance_counts(m, not_rated_penalty, per_key):
-    hit = m.positive & (m.rank > 0)
+    hit = m.positive & (m.rank > 0) & m.nz
     tp = m.per_user(None, hit)
     n_recs = m.n_valid_recs.astype(np.float64)
     n_hold = m.per_user(None, np.ones(len(m.row), bool))
@@ -93,10 +101,10 @@ def _relevance_counts(m, not_rated_penalty, per_key):
         fn = n_hold - tp
         tn = None
     else:
-        miss = ~m.positive & (m.rank > 0)
+        miss = ~m.positive & (m.rank > 0) & m.nz
         fp = m.per_user(None, miss)
-        tn = m.per_user(None, ~m.positive) - fp
-        fn = m.per_user(None, m.positive) - tp
+        tn = m.per_user(None, ~m.positive & m.nz) - fp
+        fn = m.per_user(None, m.positive & m.nz) - tp
         if not_rated_penalty > 0:
             fp = fp + not_rated_penalty * (n_recs - tp - fp)
     if per_key:
@@ -124,11 +132,11 @@ def get_relevance_scores(m, not_rated_penalty):
 
 
 def get_hr_score(m):
-    return RelevanceHR(m.per_user(None, m.positive & (m.rank > 0)).mean())
+    return RelevanceHR(m.per_user(None, m.positive & (m.rank > 0) & m.nz).mean())
 
 
 def _reciprocal_ranks(m):
-    hit = m.positive & (m.rank > 0)
+    hit = m.positive & (m.rank > 0) & m.nz
     rr = np.zeros(len(m.rank))
     rr[hit] = 1.0 / m.rank[hit]
     return hit, rr
@@ -151,7 +159,7 @@ def get_rr_scores(m):
 
 
 def get_map_score(m, topk):
-    hit = m.positive & (m.rank > 0)
+    hit = m.positive & (m.rank > 0) & m.nz
     # precision at the rank of every hit = (hits of that user ranked at or above it) / rank
     order = np.lexsort((m.rank[hit], m.row[hit]))
     rows, ranks = m.row[hit][order], m.rank[hit][order]
@@ -213,7 +221,7 @@ def evaluate(recommendations, holdout_user, holdout_item, holdout_fdbk, n_items,
         ranks, n_valid, shape, n_unique = device_ranks
         recs = None
     else:
-        recs = np.array(recommendations, copy=False, ndmin=2)[:, :topk]
+        recs = np.atleast_2d(np.asarray(recommendations))[:, :topk]
     if (switch_positive is None) or (holdout_fdbk is None):
         not_rated_penalty = 1 if not_rated_penalty is None else not_rated_penalty
         is_positive = None

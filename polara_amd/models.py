@@ -14,7 +14,7 @@ import numpy as np
 from . import defaults
 from .operator import DeviceChain, HostOperator, SparseProduct
 from .csr import coo_to_csr, nnz_balanced_row_partition, popularity_order
-from .solver import svd_topk, NoComm
+from .solver import svd_topk, NoComm, NoConvergence
 from . import scoring
 from . import tucker
 
@@ -520,6 +520,8 @@ class SVDModel(RecommenderModel):
         self.svd_tol = defaults.svd_tol
         self.svd_seed = defaults.svd_seed
         self.svd_block = defaults.svd_oversample
+        self.svd_max_outer = defaults.svd_max_outer
+        self.svd_on_no_convergence = 'raise'   # or 'warn': keep the best available factors (stats['converged'] False)
         self.build_stats = {}
 
     @property
@@ -604,11 +606,22 @@ class SVDModel(RecommenderModel):
         want_u = return_factors in (True, 'u')
         start = timer()
         U, sigma, V, stats = svd_topk(ops, A, self.rank, block=self.svd_block, tol=self.svd_tol,
-                                      seed=self.svd_seed, comm=self.comm, want_u=want_u,
+                                      max_outer=self.svd_max_outer, seed=self.svd_seed, comm=self.comm, want_u=want_u,
                                       verbose=False)
         ops.synchronize()
         self._track(start)
         self.build_stats = stats
+        if not stats['converged']:
+            # the reference's ARPACK raises ArpackNoConvergence here (models.py:844); every rank takes the same
+            # decision: `stats` derives from all-reduced quantities only
+            msg = ('%s: the block eigensolver did not converge in %d outer iterations (%d Gramian steps): worst '
+                   'relative residual %.2e of the leading %d pairs, tolerance %.1e' %
+                   (self.method, stats['outer'], stats['gramian_steps'], stats['final_rel_residual'], self.rank,
+                    self.svd_tol))
+            if self.svd_on_no_convergence == 'raise':
+                raise NoConvergence(msg, sigma=ops.to_host(sigma), V=ops.to_host(V), stats=stats)
+            import warnings
+            warnings.warn(msg, RuntimeWarning)
         user_factors = None
         if want_u:
             user_factors = ops.to_host(U)

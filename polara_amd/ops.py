@@ -289,6 +289,12 @@ class HipOps:
         nc = X.shape[1]
         if out is None:
             out = self.empty(A.shape[0], nc)
+        if nc > 256:
+            # the kernels hold one output row per wave in registers: at most 256 columns per launch; wider blocks
+            # (builds beyond rank ~200) go panel by panel through the leading dimensions
+            for c0 in range(0, nc, 256):
+                self.spmm(A, X[:, c0:c0 + 256], out=out[:, c0:c0 + 256], rows=rows)
+            return out
         x_kind = _lib.PK_VAL_F64 if X.dtype == torch.float64 else _lib.PK_VAL_F32
         p = A.plan
         t0, n_tasks, l0, n_long, nnz = 0, A.n_tasks, 0, A.n_long, A.nnz

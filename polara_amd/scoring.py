@@ -15,6 +15,7 @@ import torch
 from .csr import coo_to_csr
 
 EXACT_ROWS_BYTES = 2 << 30  # work-buffer budget per launch of the exact path
+MAX_FUSED_RANK = 256        # largest rank the MFMA candidate sweep is instantiated for (csrc/score.hip)
 
 
 class FactorImage:
@@ -25,13 +26,20 @@ class FactorImage:
         self.ops = ops
         self.V = V.contiguous()
         self.n_items, self.K = self.V.shape
-        self.Vp = ops.pack_frag(self.V)
+        # the fused sweep's MFMA instances stop at rank 256; beyond it every user goes through the exact fp64 row
+        # kernel (any rank) — the same lists, no fragment image needed
+        self.fused = self.K <= MAX_FUSED_RANK
+        self.Vp = ops.pack_frag(self.V) if self.fused else None
         self.vmax = float(torch.linalg.vector_norm(self.V, dim=1).max().item())
         if not np.isfinite(self.vmax) or (self.vmax != 0.0 and not 1e-30 < self.vmax < 1e30):
             # the candidate sweep and the approximate fold-in work on fp32 images of the factors; their error
             # bounds are norm-wise (2^-24 * max||V_i||) and hold as long as that scale is an fp32 NORMAL number
             raise ValueError('item factors with max row norm %g are outside the range the fp32 candidate sweep '
                              'works in (rescale the factors)' % self.vmax)
+        if not self.fused:
+            self.tile_bound = self.V32x = None
+            self.Kx = self.K
+            return
         self.tile_bound = ops.tile_norm_bound(self.V)   # exact pruning bound of the candidate sweep
         # fp32 image for the approximate fold-in: columns 0..K-1 = fl32(V), column K = an upper bound of the
         # row norm (so the same product also yields w_u = sum_j a_uj ||V_j||, the weight of the fold-in's
@@ -71,12 +79,12 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
         raise ValueError('test matrix and item factors disagree on the number of items')
     if topk > n_items:
         raise ValueError('kth(=%d) out of bounds (%d)' % (n_items - topk, n_items))  # numpy argpartition's error
-    KC = ops.candidate_capacity(topk)
+    KC = ops.candidate_capacity(topk) if factors.fused else 0
     K = factors.K
     if KC == 0:
         E = ops.spmm(T, factors.V)                   # fold-in, fp64 (K4)
-        # topk beyond the fused kernel's 52: every user goes through the exact fp64 row kernel
-        # (all items scored, two-class key) — slow but the same contract
+        # topk beyond the fused kernel's 52, or a rank beyond its 256: every user goes through the exact fp64 row
+        # kernel (all items scored, two-class key) — slow but the same contract
         seen_ptr = T.indptr if filter_seen else None
         seen_idx = T.indices if filter_seen else None
         out_idx = torch.empty(n_users, topk, dtype=torch.int64, device=E.device)

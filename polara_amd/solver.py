@@ -29,6 +29,16 @@ import numpy as np
 import torch
 
 
+class NoConvergence(RuntimeError):
+    """The block solver stopped at `max_outer` outer iterations with unconverged leading Ritz pairs — the
+    counterpart of ARPACK's `ArpackNoConvergence`, which the reference's `svds` call raises in that situation
+    (models.py:844).  Carries the best available factors like ARPACK's exception does."""
+
+    def __init__(self, msg, sigma=None, V=None, stats=None):
+        super().__init__(msg)
+        self.sigma, self.V, self.stats = sigma, V, stats
+
+
 class NoComm:
     """Single-process stand-in for the communicator interface (rank, world, allreduce)."""
     rank = 0
@@ -236,8 +246,9 @@ def svd_topk(ops, A, k, block=None, tol=1e-12, max_outer=200, m_max=24, spread=1
         Vk = Vk[:, torch.as_tensor(order, device=Vk.device)].contiguous()
         lam_k = lam_k[order]
     sigma_k = np.sqrt(lam_k)
-    stats['final_rel_residual'] = (float(res_host[:max(1, k - n_lock)].max() / max(lam_k[0], 1e-300))
-                                   if stats['converged'] else None)
+    # residual of the worst of the k leading pairs relative to theta_1 (locked pairs are below tol by construction)
+    stats['final_rel_residual'] = float(res_host[:max(1, min(k - n_lock, len(res_host)))].max() / max(lam_k[0], 1e-300))
+    stats['tol'] = tol
     U = None
     if want_u:
         U = ops.spmm(A, Vk)

@@ -377,3 +377,37 @@ def test_native_metrics_equal_the_reference_evaluate(polara, cfg):
             rl_got, rl_want = got['Relevance']._asdict(), want['Relevance']._asdict()
             if 'hr' in rl_got:
                 assert np.isclose(rl_got['hr'], rl_want['hr'], rtol=1e-13)
+
+
+@pytest.mark.parametrize('switch_positive', [None, 3])
+def test_zero_feedback_holdout_entries_count_like_the_reference(polara, switch_positive):
+    """Holdout entries with feedback exactly 0 (explicit zero ratings, ignore_feedback=False): never a hit or a miss in
+    the reference (boolean image x rank matrix), dropped from the per-class counts under a positive/negative split,
+    still holdout items without one (evaluation.py:60-84, 188-205)."""
+    import pandas as pd
+    from polara.recommender import evaluation as rev
+    from polara_amd import evaluation as ev
+    rng = np.random.RandomState(5)
+    n_users, n_items, topk, per = 60, 40, 8, 4
+    recs = np.stack([rng.permutation(n_items)[:topk] for _ in range(n_users)]).astype(np.int64)
+    hu = np.repeat(np.arange(n_users), per)
+    hi_ = np.concatenate([np.r_[recs[u, rng.permutation(topk)[:2]],                       # two recommended items ...
+                                rng.permutation(np.setdiff1d(np.arange(n_items), recs[u]))[:per - 2]]
+                          for u in range(n_users)])
+    hf = rng.randint(0, 6, len(hu)).astype(np.float64)                                    # ... some with feedback 0
+    assert (hf == 0).sum() > 10 and ((hf == 0) & (np.arange(len(hf)) % per < 2)).sum() > 3
+    holdout = pd.DataFrame({'userid': hu, 'itemid': hi_, 'rating': hf})
+    is_positive = None if switch_positive is None else (hf >= switch_positive)
+    penalty = 1 if switch_positive is None else 0
+    sd = rev.assemble_scoring_matrices(recs, holdout, 'userid', 'itemid', is_positive, feedback='rating')
+    want_hits = rev.get_hits(*sd, not_rated_penalty=penalty)
+    got = dict((type(s).__name__, s) for s in ev.evaluate(recs, hu, hi_, hf, n_items, metric_type='all',
+                                                            switch_positive=switch_positive, holdout_size=per))
+    for a, b in zip(got['Hits'], want_hits):
+        assert (a is None and b is None) or a == b, (got['Hits'], want_hits)
+    assert np.isclose(got['Ranking'].map, rev.get_map_score(sd[1], sd[3], topk), rtol=1e-12)
+    assert np.isclose(got['Ranking'].arhr, rev.get_arhr_score(sd[1]), rtol=1e-12)
+    single = dict((type(s).__name__, s) for s in ev.evaluate(recs, hu, hi_, hf, n_items, metric_type=['relevance', 'ranking'],
+                                                               switch_positive=switch_positive, simple_rates=True))
+    assert np.isclose(single['Relevance'].hr, rev.get_hr_score(sd[1]).hr, rtol=1e-13)
+    assert np.isclose(single['Ranking'].mrr, rev.get_mrr_score(sd[1]), rtol=1e-12)

@@ -167,3 +167,23 @@ def test_find_optimal_svd_rank_one_build():
         assert abs(fresh.evaluate('relevance').precision - table[r]) < 0.01
     m.rank = max(ranks)
     assert find_optimal_svd_rank(m, ranks, lambda t: -t['miss_rate'], metric_type='relevance') in ranks
+
+
+def test_array_data_infers_holdout_size_from_the_holdout():
+    """a 3-items-per-user holdout must not take the holdout_size == 1 (HR / MRR) branch of evaluate()."""
+    from polara_amd.data import ArrayData
+    u = np.repeat(np.arange(5), 4)
+    tr = (u, np.tile(np.arange(4), 5), np.ones(20))
+    hold3 = (np.repeat(np.arange(5), 3), np.tile(np.arange(4, 7), 5), np.ones(15))
+    d = ArrayData(tr, n_users=5, n_items=10, holdout=hold3)
+    assert d.holdout_size == 3
+    d.set_test_data(holdout=(np.arange(5), np.full(5, 7), np.ones(5)))
+    assert d.holdout_size == 1
+    assert ArrayData(tr, n_users=5, n_items=10).holdout_size == 0
+    assert ArrayData(tr, n_users=5, n_items=10, holdout=hold3, holdout_size=3).holdout_size == 3
+    with pytest.raises(ValueError):
+        ArrayData(tr, n_users=5, n_items=10, holdout=hold3, holdout_size=1)
+    # a list (not an ndarray) of recommendations is accepted (NumPy 2: np.array(copy=False) would raise)
+    r = ev.evaluate([[4, 5, 0], [6, 1, 2], [0, 1, 2], [5, 4, 6], [9, 8, 7]], hold3[0], hold3[1], hold3[2], 10,
+                    metric_type='hits', holdout_size=3)
+    assert r.true_positive == 2 + 1 + 0 + 3 + 0

@@ -372,3 +372,27 @@ def test_single_user_conveniences_on_array_data():
     assert np.array_equal(top_w, np.argsort(-s, kind='stable')[:4])
     with pytest.raises(ValueError):
         m.show_recommendations('user')
+
+
+def test_unconverged_build_raises_like_arpack():
+    """a build that stops at max_outer without converging must not mark the model ready silently; the
+    reference's svds raises ArpackNoConvergence (models.py:844)."""
+    import warnings
+    from polara_amd.solver import NoConvergence
+    g = load_golden('svd_warm')
+    m = SVDModel(GoldenData(g), ops=NumpyOps())
+    m.verbose = False
+    m.rank = int(g['rank'])
+    m.svd_max_outer = 1
+    with pytest.raises(NoConvergence) as err:
+        m.build()
+    assert not m._is_ready and err.value.stats['converged'] is False and err.value.V.shape[1] == m.rank
+    assert err.value.stats['final_rel_residual'] > m.svd_tol
+    m.svd_on_no_convergence = 'warn'
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        m.build()
+    assert m._is_ready and any('did not converge' in str(x.message) for x in w)
+    m.svd_max_outer = 200
+    m.build()
+    assert m.build_stats['converged'] and m.build_stats['final_rel_residual'] <= m.svd_tol
