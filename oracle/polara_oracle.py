@@ -259,9 +259,12 @@ def dttm_seq_loops(idx, val, u, v, mode0, mode1, mode2, res):
 def dttm_seq(idx, val, u, v, mode0, mode1, mode2, res):
     """sparse.py:203-216, vectorised: identical summation ORDER per output element
     (np.add.at applies updates in nnz order, one product `vv*uij*vik` evaluated left-to-right)."""
-    i0 = idx[:, mode0]
-    contrib = (val[:, None] * u[idx[:, mode1], :])[:, :, None] * v[idx[:, mode2], :][:, None, :]
-    np.add.at(res, i0, contrib)
+    # blocks of nnz bound the [block x r1 x r2] temporary; the order of updates per output element is unchanged
+    block = max(1, (64 << 20) // max(1, 8 * u.shape[1] * v.shape[1]))
+    for a in range(0, len(val), block):
+        b = min(len(val), a + block)
+        contrib = (val[a:b, None] * u[idx[a:b, mode1], :])[:, :, None] * v[idx[a:b, mode2], :][:, None, :]
+        np.add.at(res, idx[a:b, mode0], contrib)
 
 
 def ttm3d_seq(idx, val, shape, U, V, modes, dtype=None, loops=False):

@@ -1,0 +1,307 @@
+"""-m gpu: the BASELINE.json configurations that round 1 left without a GPU parity test, at their full sizes.
+
+  configs[2]  ML-20M-shaped 138 493 x 26 744, ~2e7 nnz: rank 100 / top-20 (the config) and rank 50 / top-10 (the
+              `metric` line) — full-size properties, the oracle on a >= 2 000-user sample, pruned == unpruned sweep;
+              at rank 50 also the oracle's own `svds` on the WHOLE matrix (sigma, projector samples);
+  configs[3]  CoFFee on the ML-1M-shaped tensor: mlrank (30,30,4) against tests/golden/coffee_ml1m.npz (pinned
+              oracle; `make_golden_large.py`), the rank reduction after the build against the
+              reference's own `round_core` applied to the oracle's factors, and (30,30,5) — where the reference
+              raises — through properties of a Tucker fit;
+  configs[4]  a 131 072-user shard of the 50M x 500K job: rank 200 build + top-50 lists vs the oracle on a sample.
+
+Inputs are re-created from seeds (`polara_amd.synth`); nothing here reads /root/reference.
+Tolerances: singular values / scores 1e-9 relative (contract: 1e-4); lists identical on every row whose reference
+result is well defined (k-th and (k+1)-th score apart)."""
+import hashlib
+
+import numpy as np
+import pytest
+import scipy.sparse as sps
+import torch
+
+from conftest import load_golden
+from oracle import polara_oracle as orc
+from polara_amd import scoring
+from polara_amd.csr import popularity_order
+from polara_amd.data import ArrayData
+from polara_amd.models import SVDModel, CoffeeModel
+from polara_amd.solver import svd_topk
+from polara_amd.synth import make_workload, planted_csr, csr_to_numpy, csr_to_coo_triplets
+
+pytestmark = pytest.mark.gpu
+
+
+def _no_seen_items(recs, A, n_items):
+    rows = torch.repeat_interleave(torch.arange(A.shape[0], device=recs.device), A.indptr[1:] - A.indptr[:-1])
+    keys = torch.sort(rows * n_items + A.indices.long()).values
+    q = (torch.arange(A.shape[0], device=recs.device)[:, None] * n_items + recs).flatten()
+    pos = torch.searchsorted(keys, q).clamp_max(keys.numel() - 1)
+    return not bool((keys[pos] == q).any())
+
+
+def _oracle_lists(c, V_ext, rows, topk):
+    """The reference path restated (chunked GEMM + downvote + per-row argpartition) on the users `rows`, external ids;
+    also the rows whose k-th / (k+1)-th scores are apart (the others are implementation-defined in the reference)."""
+    n_items = c['shape'][1]
+    cnt = np.diff(c['indptr'])[rows]
+    sel = np.concatenate([np.arange(c['indptr'][r], c['indptr'][r + 1]) for r in rows])
+    td = (np.repeat(np.arange(len(rows)), cnt), c['indices'][sel].astype(np.int64), c['values'][sel].astype(np.float64))
+    ref = orc.svd_recommendations(V_ext, td, (len(rows), n_items), topk, filter_seen=True)
+    clear = np.ones(len(rows), bool)
+    for a in range(0, len(rows), 500):
+        sc, sd = orc.svd_slice_recommendations(V_ext, td, (len(rows), n_items), a, min(len(rows), a + 500))
+        orc.downvote_seen_items(sc, sd)
+        clear[a:a + 500] = orc.boundary_gap(sc, topk) > 1e-9
+    return ref, clear
+
+
+@pytest.fixture(scope='module')
+def ml20m(hip_ops):
+    ops = hip_ops
+    csr, cfg = make_workload('ml20m', device=str(ops.device))
+    c = csr_to_numpy(csr)
+    del csr
+    n_users, n_items = c['shape']
+    rank_of, inv_order = popularity_order(c['indices'], n_items)
+    A = ops.csr_relabel_cols(ops.csr(c['indptr'], c['indices'], c['values'], c['shape']), rank_of)
+    return dict(c=c, cfg=cfg, A=A, rank_of=rank_of, inv_order=inv_order)
+
+
+@pytest.mark.parametrize('rank,topk', [(100, 20), (50, 10)], ids=['config2_rank100_top20', 'metric_rank50_top10'])
+def test_ml20m_shaped_full_size(hip_ops, ml20m, rank, topk):
+    ops, c, A, rank_of, inv_order = hip_ops, ml20m['c'], ml20m['A'], ml20m['rank_of'], ml20m['inv_order']
+    n_users, n_items = c['shape']
+    assert (n_users, n_items) == (138493, 26744) and 1.5e7 < c['indptr'][-1] < 2.6e7
+    _, sigma, V, st = svd_topk(ops, A, rank)
+    assert st['converged'] and st['final_rel_residual'] <= 1e-12
+    sig = ops.to_host(sigma)
+    assert np.all(np.diff(sig) < 0) and sig[-1] > 0
+    assert np.abs(ops.to_host(ops.gram(V)) - np.eye(rank)).max() < 1e-12          # orthonormal item factors
+    # singular pairs of the matrix itself: ||A^T A v - sigma^2 v|| small, column by column
+    Z = ops.spmm(A.T, ops.spmm(A, V))
+    res = torch.linalg.vector_norm(Z - V * (sigma ** 2)[None, :], dim=0) / sigma[0] ** 2
+    assert float(res.max()) < 1e-11
+    # serving order (descending factor norm), as the model / bench do
+    order2 = torch.argsort(torch.linalg.vector_norm(V, dim=1), descending=True, stable=True)
+    rank2 = torch.empty_like(order2)
+    rank2[order2] = torch.arange(n_items, device=order2.device)
+    Vs = V[order2].contiguous()
+    As = ops.csr_relabel_cols(A, rank2, sort=False)
+    F = scoring.FactorImage(ops, Vs)
+    stats = {}
+    recs, sc = scoring.recommend(ops, F, As, topk, True, return_scores=True, stats=stats)
+    assert recs.shape == (n_users, topk) and int(recs.min()) >= 0 and int(recs.max()) < n_items
+    assert stats['tiles_scored'] < 0.6 * stats['tiles_total']                    # the pruning bound works here too
+    assert bool((sc[:, 1:] <= sc[:, :-1]).all())                                 # descending scores
+    assert bool((torch.sort(recs, dim=1).values.diff(dim=1) > 0).all())          # no duplicates in a row
+    assert _no_seen_items(recs, As, n_items)
+    ids_only = scoring.recommend(ops, F, As, topk, True)                         # the approximate-fold-in route
+    assert bool((ids_only == recs).all())
+    # pruned == unpruned sweep on a slice
+    T = ops.csr_rows(As, 20000, 20000 + 16384)
+    r_full, s_full = scoring.recommend(ops, F, T, topk, True, prune=False, return_scores=True)
+    assert bool((r_full == recs[20000:20000 + 16384]).all()) and bool((s_full == sc[20000:20000 + 16384]).all())
+    # scores are E V^T at the recommended items (fp64)
+    E = ops.spmm(T, Vs)[:2048]
+    assert torch.allclose(torch.gather(E @ Vs.T, 1, r_full[:2048]), s_full[:2048], rtol=1e-12, atol=1e-12)
+    # the reference path (oracle) on 2 400 users spread over the matrix, external item ids
+    o2 = ops.to_host(order2)
+    back = np.empty_like(o2)
+    back[o2] = np.arange(n_items)
+    V_ext = np.ascontiguousarray(ops.to_host(Vs)[back][rank_of])
+    rows = np.unique(np.linspace(0, n_users - 1, 2400).astype(np.int64))
+    ref, clear = _oracle_lists(c, V_ext, rows, topk)
+    got = inv_order[o2[ops.to_host(recs)[rows]]]
+    assert clear.mean() > 0.99
+    assert np.array_equal(got[clear], ref[clear]), int((got[clear] != ref[clear]).any(axis=1).sum())
+    if rank == 50:
+        # the reference's own factorisation call (svds -> ARPACK, tol 0) on the WHOLE 2e7-nnz matrix
+        Afull = sps.csr_matrix((c['values'].astype(np.float64), c['indices'], c['indptr']), shape=c['shape'])
+        np.random.seed(0)
+        _, o_sigma, o_V = orc.svd_build(Afull, rank)
+        assert np.abs(sig / o_sigma - 1).max() < 1e-9
+        probe = np.unique(np.linspace(0, n_items - 1, 400).astype(np.int64))
+        P_ours = V_ext[probe] @ V_ext[probe].T
+        assert np.abs(P_ours - o_V[probe] @ o_V[probe].T).max() < 1e-8
+
+
+def test_ml20m_shaped_through_the_model_classes(hip_ops, ml20m):
+    """The plugin surface at configs[2]: SVDModel(data).build() + get_recommendations() on the whole matrix equals the
+    kernel-level pipeline above (external ids), and a rank truncation (a3) serves rank 50 from the rank-100 build."""
+    ops, c = hip_ops, ml20m['c']
+    n_users, n_items = c['shape']
+    u = np.repeat(np.arange(n_users, dtype=np.int64), np.diff(c['indptr']))
+    d = ArrayData((u, c['indices'], c['values']), n_users=n_users, n_items=n_items, test=(u, c['indices'], c['values']))
+    m = SVDModel(d, ops=ops)
+    m.verbose = False
+    m.rank, m.topk = 100, 20
+    m.build()
+    recs = m.get_recommendations()
+    assert recs.shape == (n_users, 20) and recs.dtype == np.int64
+    V = np.ascontiguousarray(m.factors[d.fields.itemid])
+    rows = np.unique(np.linspace(0, n_users - 1, 1200).astype(np.int64))
+    ref, clear = _oracle_lists(c, V, rows, 20)
+    assert np.array_equal(recs[rows][clear], ref[clear])
+    m.rank = 50
+    assert m._is_ready
+    m.topk = 10
+    recs50 = m.get_recommendations()
+    ref50, clear50 = _oracle_lists(c, np.ascontiguousarray(V[:, :50]), rows, 10)
+    assert np.array_equal(recs50[rows][clear50], ref50[clear50])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# configs[3]: CoFFee / HOOI on the ML-1M-shaped tensor
+# ---------------------------------------------------------------------------------------------------------------
+def _coffee_data():
+    csr, _ = make_workload('ml1m')                      # CPU generator: the same triplets as the fixture's
+    u, i, v = csr_to_coo_triplets(csr)
+    n_users, n_items = csr['shape']
+    hold = (np.arange(n_users), np.zeros(n_users, np.int64), np.ones(n_users))
+    return ArrayData((u, i, v), n_users=n_users, n_items=n_items, holdout=hold, warm_start=False)
+
+
+def _core_from_factors(idx, val, shp, u0, u1, u2):
+    """G[a,b,c] = sum_nnz val u0[i,a] u1[j,b] u2[f,c] through one sparse product per feedback level."""
+    core = np.zeros((u0.shape[1], u1.shape[1], u2.shape[1]))
+    for f in range(shp[2]):
+        sel = idx[:, 2] == f
+        Af = sps.csr_matrix((val[sel], (idx[sel, 0], idx[sel, 1])), shape=shp[:2])
+        core += (u0.T @ (Af @ u1))[:, :, None] * u2[f][None, None, :]
+    return core
+
+
+def test_coffee_ml1m_config3_vs_pinned_oracle_and_rank_reduction(hip_ops):
+    g = load_golden('coffee_ml1m')
+    d = _coffee_data()
+    idx, val, shp = d.to_coo(tensor_mode=True)
+    assert hashlib.sha1(np.ascontiguousarray(idx, dtype=np.int64).tobytes()).hexdigest() == str(g['digest']), \
+        'the synthetic ML-1M-shaped tensor differs from the one the fixture was made from (generator drift)'
+    m = CoffeeModel(d, ops=hip_ops)
+    m.verbose = False
+    m.mlrank, m.topk, m.seed = tuple(int(x) for x in g['mlrank']), int(g['topk']), int(g['seed'])
+    m.num_iters, m.growth_tol = int(g['num_iters']), float(g['growth_tol'])
+    m.build()
+    assert len(m.core_norm_trace) == len(g['core_norm_trace'])
+    assert np.allclose(m.core_norm_trace, g['core_norm_trace'], rtol=1e-9)
+    f = d.fields
+    u0, u1, u2, core = (m.factors[k] for k in (f.userid, f.itemid, f.feedback, 'core'))
+    pu, pi = g['probe_users'], g['probe_items']
+    assert np.abs(u0[pu] @ u0[pu].T - g['proj0']).max() < 1e-8
+    assert np.abs(u1[pi] @ u1[pi].T - g['proj1']).max() < 1e-8
+    assert np.abs(u2 @ u2.T - g['proj2']).max() < 1e-8
+    assert np.isclose(np.linalg.norm(core), float(g['core_norm']), rtol=1e-9)
+    assert np.allclose(np.linalg.svd(core.reshape(core.shape[0], -1), compute_uv=False), g['core_sv0'], rtol=1e-7, atol=1e-9)
+    recs = m.recommendations
+    clear = g['clear']
+    assert clear.mean() > 0.95 and np.array_equal(recs[clear], g['recs'][clear].astype(np.int64))
+    # ---- a15: lowering mlrank after the build is served from the cached factors (models.py:949-980) ----
+    built = len(m.training_time)
+    m.mlrank = tuple(int(x) for x in g['reduced'])
+    assert m._is_ready and len(m.training_time) == built                          # no rebuild
+    r0, r1, r2, rcore = (m.factors[k] for k in (f.userid, f.itemid, f.feedback, 'core'))
+    assert (r0.shape[1], r1.shape[1], r2.shape[1]) == tuple(g['reduced']) == rcore.shape
+    assert np.abs(r0[pu] @ r0[pu].T - g['r_proj0']).max() < 1e-8
+    assert np.abs(r1[pi] @ r1[pi].T - g['r_proj1']).max() < 1e-8
+    assert np.abs(r2 @ r2.T - g['r_proj2']).max() < 1e-8
+    assert np.isclose(np.linalg.norm(rcore), float(g['r_core_norm']), rtol=1e-9)
+    rrecs = m.recommendations
+    rclear = g['r_clear']
+    assert rclear.mean() > 0.95 and np.array_equal(rrecs[rclear], g['r_recs'][rclear].astype(np.int64))
+    # growing it again invalidates the model (models.py:957-960)
+    m.mlrank = (31, 30, 4)
+    assert not m._is_ready
+
+
+def test_coffee_ml1m_config3_full_feedback_rank(hip_ops):
+    """mlrank (30, 30, 5) on 5 rating levels — BASELINE.json configs[3] verbatim.  The reference raises here (svds
+    needs k < min(shape), lib/tensor.py:79); the device path takes the full eigen-decomposition of the 5 x 5 Gram
+    matrix.  Checked through properties of a Tucker fit at full size."""
+    d = _coffee_data()
+    m = CoffeeModel(d, ops=hip_ops)
+    m.verbose = False
+    m.mlrank, m.topk, m.seed = (30, 30, 5), 10, 0
+    m.build()
+    f = d.fields
+    u0, u1, u2, core = (m.factors[k] for k in (f.userid, f.itemid, f.feedback, 'core'))
+    assert u2.shape == (5, 5) and core.shape == (30, 30, 5)
+    for u in (u0, u1, u2):
+        assert np.abs(u.T @ u - np.eye(u.shape[1])).max() < 1e-9
+    idx, val, shp = d.to_coo(tensor_mode=True)
+    want = _core_from_factors(idx, val, shp, u0, u1, u2)
+    assert np.allclose(core, want, atol=1e-9 * np.abs(want).max())
+    assert np.isclose(np.linalg.norm(core), m.core_norm_trace[-1], rtol=1e-9)
+    assert all(b >= a * (1 - 1e-12) for a, b in zip(m.core_norm_trace, m.core_norm_trace[1:]))
+    # a complete feedback basis loses nothing along that mode: the fit is at least that of (30, 30, 4)
+    g = load_golden('coffee_ml1m')
+    assert m.core_norm_trace[-1] >= float(g['core_norm']) * (1 - 1e-6)
+    # lists: the oracle's scoring path GIVEN these factors (the reference's scoring code has no rank restriction)
+    tu, ti, tf = d.test_to_coo(tensor_mode=True)
+    tshape = d.get_test_shape(tensor_mode=True)
+    rows = np.arange(0, tshape[0], 9)[:600]
+    sel = np.isin(tu, rows)
+    td = (np.searchsorted(rows, tu[sel]), ti[sel], tf[sel])
+    ref = orc.coffee_recommendations(u1, u2, td, (len(rows),) + tuple(tshape[1:]), 10, True)
+    sc, sd = orc.coffee_slice_recommendations(u1, u2, td, (len(rows),) + tuple(tshape[1:]), 0, len(rows))
+    orc.downvote_seen_items(sc, sd)
+    clear = orc.boundary_gap(sc, 10) > 1e-9
+    assert np.array_equal(m.recommendations[rows][clear], ref[clear])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# configs[4]: a shard of the 50M x 500K, rank 200, top-50 job
+# ---------------------------------------------------------------------------------------------------------------
+def test_s50m_shard_config4_rank200_top50(hip_ops):
+    ops = hip_ops
+    n_users, n_items, rank, topk = 131072, 500_000, 200, 50
+    c = csr_to_numpy(planted_csr(n_users, n_items, 50, rank // 4, levels=5, seed=5, device=str(ops.device), min_items=20,
+                                 max_items=2000, chunk_rows=1024))
+    torch.cuda.empty_cache()
+    rank_of, inv_order = popularity_order(c['indices'], n_items)
+    A = ops.csr_relabel_cols(ops.csr(c['indptr'], c['indices'], c['values'], c['shape']), rank_of)
+    _, sigma, V, st = svd_topk(ops, A, rank)
+    assert st['converged'] and st['block'] == 256
+    assert np.abs(ops.to_host(ops.gram(V)) - np.eye(rank)).max() < 1e-12
+    order2 = torch.argsort(torch.linalg.vector_norm(V, dim=1), descending=True, stable=True)
+    rank2 = torch.empty_like(order2)
+    rank2[order2] = torch.arange(n_items, device=order2.device)
+    Vs = V[order2].contiguous()
+    As = ops.csr_relabel_cols(A, rank2, sort=False)
+    F = scoring.FactorImage(ops, Vs)
+    stats = {}
+    recs, sc = scoring.recommend(ops, F, As, topk, True, return_scores=True, stats=stats)
+    assert stats['candidate_capacity'] == 64
+    assert recs.shape == (n_users, topk) and int(recs.min()) >= 0 and int(recs.max()) < n_items
+    assert bool((sc[:, 1:] <= sc[:, :-1]).all())
+    assert bool((torch.sort(recs, dim=1).values.diff(dim=1) > 0).all())
+    assert _no_seen_items(recs, As, n_items)
+    assert bool((scoring.recommend(ops, F, As, topk, True) == recs).all())      # ids-only route, idempotent
+    T = ops.csr_rows(As, 4096, 4096 + 8192)
+    r_full = scoring.recommend(ops, F, T, topk, True, prune=False)
+    assert bool((r_full == recs[4096:4096 + 8192]).all())
+    o2 = ops.to_host(order2)
+    back = np.empty_like(o2)
+    back[o2] = np.arange(n_items)
+    V_ext = np.ascontiguousarray(ops.to_host(Vs)[back][rank_of])
+    rows = np.unique(np.linspace(0, n_users - 1, 400).astype(np.int64))
+    ref, clear = _oracle_lists(c, V_ext, rows, topk)
+    got = inv_order[o2[ops.to_host(recs)[rows]]]
+    assert clear.mean() > 0.9 and np.array_equal(got[clear], ref[clear])
+
+
+def test_rank_beyond_the_fused_sweep_goes_through_exact_rows(hip_ops):
+    """rank > 256: the fused sweep has no instance, every user is served by the exact fp64 row kernel;
+    the build runs its SpMM in 256-column panels.  Same contract, against the oracle."""
+    c = csr_to_numpy(planted_csr(900, 420, 60, 12, seed=8, min_items=20, max_items=200))
+    u, i, v = csr_to_coo_triplets(planted_csr(900, 420, 60, 12, seed=8, min_items=20, max_items=200))
+    d = ArrayData((u, i, v), n_users=900, n_items=420, test=(u, i, v))
+    m = SVDModel(d, ops=hip_ops)
+    m.verbose = False
+    m.rank, m.topk = 260, 10
+    m.build()
+    A = sps.csr_matrix((c['values'].astype(np.float64), c['indices'], c['indptr']), shape=c['shape'])
+    s_ref = np.linalg.svd(A.toarray(), compute_uv=False)[:260]
+    assert np.allclose(m.factors['singular_values'], s_ref, rtol=1e-9)
+    V = np.ascontiguousarray(m.factors[d.fields.itemid])
+    ref, clear = _oracle_lists(c, V, np.arange(900), 10)
+    assert np.array_equal(m.get_recommendations()[clear], ref[clear])

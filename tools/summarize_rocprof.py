@@ -15,8 +15,18 @@ def short(name, n=70):
     return name if len(name) <= n else name[:n - 3] + '...'
 
 
+def commit_line():
+    """the commit the profiled tree was snapshotted from (written to gpurun_in/COMMIT before the gpurun call: the
+    GPU box has no .git)"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        return '# commit ' + open(os.path.join(root, 'gpurun_in', 'COMMIT')).read().strip()
+    except OSError:
+        return '# commit unknown'
+
+
 def main(src, dst):
-    lines = []
+    lines = [commit_line()]
     for path in sorted(glob.glob(os.path.join(src, '**', '*.csv'), recursive=True)):
         base = os.path.basename(path)
         with open(path, newline='') as f:
