@@ -181,12 +181,17 @@ class Bench:
         sub = slice(int(c['indptr'][lo]), int(c['indptr'][hi]))
         A = ops.csr(c['indptr'][lo:hi + 1] - c['indptr'][lo], c['indices'][sub], c['values'][sub], (hi - lo, n_items))
         lap('upload_s')
-        # internal item order = descending popularity over the WHOLE matrix (identical on every rank)
-        rank_of, inv_order = popularity_order(c['indices'], n_items)
-        A = ops.csr_relabel_cols(A, rank_of)
+        # internal item order = descending popularity over the WHOLE matrix (identical on every rank): per-item counts
+        # of the local rows on the device (pk_count_i32), summed over ranks; the renaming itself is one gather
+        counts = ops.item_counts(A)
+        if comm.world > 1:
+            counts = ops.to_host(comm.allreduce(ops.to_device(counts)))
+        rank_of, inv_order = popularity_order(None, n_items, counts=counts)
+        A = ops.csr_relabel_cols(A, rank_of, sort=False)
         lap('relabel_popularity_s')
-        _ = A.T
-        lap('transpose_s')
+        A.transpose_operator()          # CSC image (user-blocked), built on the device (pk_csr_transpose)
+        _ = A.plan
+        lap('transpose_and_plans_s')
         ops.timers = {}
         _, sigma, V, bstats = svd_topk(ops, A, rank, comm=comm)
         lap('solver_s')

@@ -74,6 +74,74 @@ int pk_spmm_csr_x(void *stream,
                   const int32_t *indices_dev, const void *vals_dev, int val_kind,
                   const void *X_dev, int x_kind, int64_t ldx, int32_t nc,
                   double *out_dev, int64_t ldo, double *partial_dev);
+/* The general form behind both: task rows are numbered from `row_base` (task t writes output row task_row[t] -
+ * row_base — a row block of a larger plan runs as its own launch), and with accumulate != 0 the result is ADDED
+ * to out.  Used for the transposed product of the build, Z = A^T Y (models.py:844's rmatvec), cut into user
+ * blocks: the CSC of every block is one slice of a (block, item)-ordered plan (pk_csr_transpose with
+ * rows_per_block > 0), block b adds its share to Z in launch order (deterministic), and the rows of Y that one
+ * launch gathers stay cache-resident instead of spanning the whole user range. */
+int pk_spmm_csr_ex(void *stream,
+                   int64_t n_tasks, const int32_t *task_row_dev, const int64_t *task_begin_dev,
+                   const int64_t *task_end_dev, const int32_t *task_slot_dev,
+                   int64_t n_long, const int32_t *long_row_dev, const int32_t *long_slot_begin_dev,
+                   const int32_t *long_slot_end_dev,
+                   const int32_t *indices_dev, const void *vals_dev, int val_kind,
+                   const void *X_dev, int x_kind, int64_t ldx, int32_t nc,
+                   double *out_dev, int64_t ldo, double *partial_dev, int64_t row_base, int32_t accumulate);
+
+/* ------------------------------------------------------------------------------------------
+ * Ingest.  The index work around the hot path, on the device:
+ * `coo_matrix((val, (rows, cols))).tocsr()` of get_training_matrix / get_test_matrix
+ * (models.py:172-175, 198-203 <- data.py:794-817, 835-862: duplicates summed, rows sorted by column),
+ * the CSC image behind the transposed products of `svds` (models.py:844), and the wave-task plans.
+ * Building blocks: a stable LSD radix sort of (key, u32 payload) pairs and an exclusive scan.
+ * ------------------------------------------------------------------------------------------ */
+/* out[0..n] = exclusive prefix sums of in[0..n-1] (out[n] = total).  work >= pk_scan_work_bytes(n). */
+int64_t pk_scan_work_bytes(int64_t n);
+int pk_exclusive_scan_i32(void *stream, int64_t n, const int32_t *in_dev, int64_t *out_dev, void *work_dev);
+/* Stable ascending sort of n (key, payload) pairs by the low key_bits bits of the key (key_bytes = 4 or 8).
+ * The sorted pairs end in (keys, vals) when *result_in_tmp == 0, else in (keys_tmp, vals_tmp).
+ * work >= pk_radix_work_bytes(n). */
+int64_t pk_radix_work_bytes(int64_t n);
+int pk_radix_sort_pairs(void *stream, int64_t n, int32_t key_bytes, void *keys_dev, uint32_t *vals_dev,
+                        void *keys_tmp_dev, uint32_t *vals_tmp_dev, int32_t key_bits, void *work_dev,
+                        int32_t *result_in_tmp);
+/* COO triplets (device arrays, any order, duplicates allowed; entry i has row rows_dev[i * idx_stride] and column
+ * cols_dev[i * idx_stride] — idx_stride = 2 reads the interleaved int64 [nnz x 2] index array of `to_coo`,
+ * data.py:794-817, as it is) -> canonical CSR: indptr int64[n_rows + 1],
+ * indices int32 / values (val_kind) sized for nnz entries, of which the first *n_unique_dev are used (duplicates
+ * are summed in their original order).  err_dev[0] != 0 afterwards = an index was out of range.
+ * work >= pk_coo_to_csr_work_bytes(nnz). */
+int64_t pk_coo_to_csr_work_bytes(int64_t nnz);
+int pk_coo_to_csr(void *stream, int64_t nnz, const int64_t *rows_dev, const int64_t *cols_dev, int64_t idx_stride,
+                  const void *vals_dev,
+                  int val_kind, int64_t n_rows, int64_t n_cols, int64_t *indptr_dev, int32_t *indices_dev,
+                  void *values_dev, int64_t *n_unique_dev, int32_t *err_dev, void *work_dev);
+/* CSR -> CSC.  rows_per_block = 0: t_indptr int64[n_cols + 1].  rows_per_block > 0: the rows are cut into
+ * ceil(n_rows / rows_per_block) blocks and t_indptr has n_blocks * n_cols + 1 entries — entry b * n_cols + c starts
+ * column c restricted to the rows of block b (row ids stay global, ascending within a column segment). */
+int64_t pk_csr_transpose_work_bytes(int64_t nnz);
+int pk_csr_transpose(void *stream, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t *indptr_dev,
+                     const int32_t *indices_dev, const void *values_dev, int val_kind, int64_t rows_per_block,
+                     int64_t *t_indptr_dev, int32_t *t_indices_dev, void *t_values_dev, void *work_dev);
+/* Column renaming j -> col_map[j] with every row re-sorted by the new ids (row pointers unchanged). */
+int64_t pk_csr_relabel_work_bytes(int64_t nnz);
+int pk_csr_relabel_sorted(void *stream, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t *indptr_dev,
+                          const int32_t *indices_dev, const void *values_dev, int val_kind, const int32_t *col_map_dev,
+                          int32_t *indices_out_dev, void *values_out_dev, void *work_dev);
+/* counts[k] = number of keys equal to k (item popularity: the internal item order of the device path) */
+int pk_count_i32(void *stream, int64_t n, const int32_t *keys_dev, int64_t n_bins, int32_t *counts_dev);
+/* Wave-task plan of a CSR (one 64-lane wave per task, rows longer than `split` cut into near-equal tasks whose
+ * partial results are added in slot order): phase 1 leaves counts_dev[0..2] = (tasks, long rows, slots), phase 2
+ * fills the arrays sized from them.  row_first_task / row_long_index (int64[n_rows + 1], optional) = first task of
+ * a row / number of long rows before it, so that a row range can run as its own launch. */
+int64_t pk_row_plan_work_bytes(int64_t n_rows);
+int pk_row_plan_count(void *stream, int64_t n_rows, const int64_t *indptr_dev, int32_t split, int64_t *counts_dev,
+                      void *work_dev);
+int pk_row_plan_fill(void *stream, int64_t n_rows, const int64_t *indptr_dev, const void *work_dev,
+                     int32_t *task_row_dev, int64_t *task_begin_dev, int64_t *task_end_dev, int32_t *task_slot_dev,
+                     int32_t *long_row_dev, int32_t *long_slot_begin_dev, int32_t *long_slot_end_dev,
+                     int64_t *row_first_task_dev, int64_t *row_long_index_dev);
 
 /* ------------------------------------------------------------------------------------------
  * K2.  Dense tall-skinny fp64 pieces of the block eigensolver / HOOI.

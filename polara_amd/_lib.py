@@ -22,6 +22,22 @@ PROTOTYPES = {
                                   _vp, _i64, _i32, _vp, _i64, _vp]),
     'pk_spmm_csr_x': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, C.c_int,
                                 _vp, C.c_int, _i64, _i32, _vp, _i64, _vp]),
+    'pk_spmm_csr_ex': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, C.c_int,
+                                 _vp, C.c_int, _i64, _i32, _vp, _i64, _vp, _i64, _i32]),
+    'pk_scan_work_bytes': (_i64, [_i64]),
+    'pk_exclusive_scan_i32': (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
+    'pk_radix_work_bytes': (_i64, [_i64]),
+    'pk_radix_sort_pairs': (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, C.POINTER(_i32)]),
+    'pk_coo_to_csr_work_bytes': (_i64, [_i64]),
+    'pk_coo_to_csr': (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, C.c_int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'pk_csr_transpose_work_bytes': (_i64, [_i64]),
+    'pk_csr_transpose': (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, C.c_int, _i64, _vp, _vp, _vp, _vp]),
+    'pk_csr_relabel_work_bytes': (_i64, [_i64]),
+    'pk_csr_relabel_sorted': (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
+    'pk_count_i32': (C.c_int, [_vp, _i64, _vp, _i64, _vp]),
+    'pk_row_plan_work_bytes': (_i64, [_i64]),
+    'pk_row_plan_count': (C.c_int, [_vp, _i64, _vp, _i32, _vp, _vp]),
+    'pk_row_plan_fill': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'pk_gram_work_bytes': (_i64, [_i64, _i32, _i32]),
     'pk_gram_f64': (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     'pk_tsmm_f64': (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64]),

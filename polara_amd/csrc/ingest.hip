@@ -1,0 +1,655 @@
+// Data ingest on the device: COO -> canonical CSR, CSR -> CSC (optionally cut into row blocks),
+// and the wave-task plans of the SpMM / TTM kernels — the index work the reference does on ONE host thread through
+// SciPy (`coo_matrix(...).tocsr()`, models.py:172-175 <- data.py:794-817; the transposed products of `svds`,
+// models.py:844) — as hand-written gfx950 kernels:
+//
+//   * an LSD radix sort of (key, 32-bit payload) pairs, 8 bits per pass, STABLE: per pass a tile histogram
+//     (LDS atomics), one exclusive scan of the [digit x tile] table, and a scatter whose in-tile ranks come from
+//     wave ballots (8 ballots isolate the lanes holding the same digit; popcounts give rank and count) — no LDS
+//     sort, no atomics on the output, so the permutation is deterministic;
+//   * an exclusive scan (block sums -> one-workgroup scan of the sums -> block scans);
+//   * the small passes around them: key construction with bounds check, run heads / duplicate sums, row pointers
+//     from sorted keys (boundary detection, no atomics), row ids of CSR positions (binary search), payload gathers.
+//
+// HBM-streaming integer work: every pass reads and writes each element once, coalesced except for the radix
+// scatter (runs of ~tile/256 elements per digit).  Nothing here is shaped into a GEMM.
+#include "pk_common.h"
+
+#define PK_SCAN_TILE 4096      // elements per scan block (256 threads x 16)
+#define PK_RADIX_ITEMS 16      // keys per thread in a radix tile
+#define PK_RADIX_TILE (256 * PK_RADIX_ITEMS)
+
+// ------------------------------------------------------------------------------------------------------------
+// exclusive scan  int32[n] -> int64[n + 1]   (out[n] = total)
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void scan_block_sums_kernel(int64_t n, const int32_t *__restrict__ in,
+                                                              int64_t *__restrict__ block_sums) {
+    __shared__ int64_t s_w[4];
+    const int64_t base = (int64_t)blockIdx.x * PK_SCAN_TILE;
+    int64_t acc = 0;
+    for (int k = 0; k < 16; ++k) {
+        const int64_t i = base + k * 256 + threadIdx.x;
+        if (i < n) acc += in[i];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+// one workgroup: exclusive scan of block_sums in place, total appended at [n_blocks]
+__global__ __launch_bounds__(1024) void scan_sums_kernel(int64_t n_blocks, int64_t *__restrict__ block_sums) {
+    __shared__ int64_t s_w[16];
+    __shared__ int64_t s_carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n_blocks; base += 1024) {
+        const int64_t i = base + threadIdx.x;
+        const int64_t v = i < n_blocks ? block_sums[i] : 0;
+        int64_t incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int64_t t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) s_w[wave] = incl;
+        __syncthreads();
+        int64_t wbase = 0;
+        for (int w = 0; w < wave; ++w) wbase += s_w[w];
+        const int64_t carry = s_carry;
+        if (i < n_blocks) block_sums[i] = carry + wbase + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = carry + wbase + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) block_sums[n_blocks] = s_carry;
+}
+
+__global__ __launch_bounds__(256) void scan_final_kernel(int64_t n, const int32_t *__restrict__ in,
+                                                         const int64_t *__restrict__ block_sums,
+                                                         int64_t *__restrict__ out) {
+    __shared__ int64_t s_w[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t base = (int64_t)blockIdx.x * PK_SCAN_TILE + (int64_t)threadIdx.x * 16;   // 16 CONSECUTIVE items per thread
+    int32_t v[16];
+    int64_t tot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        v[k] = (base + k < n) ? in[base + k] : 0;
+        tot += v[k];
+    }
+    int64_t incl = tot;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int64_t t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    int64_t run = block_sums[blockIdx.x] + incl - tot;
+    for (int w = 0; w < wave; ++w) run += s_w[w];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        if (base + k < n) out[base + k] = run;
+        run += v[k];
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[n] = block_sums[gridDim.x];
+}
+
+extern "C" int64_t pk_scan_work_bytes(int64_t n) { return (pk_ceil_div(n > 0 ? n : 1, PK_SCAN_TILE) + 1) * 8; }
+
+static int pk_scan_launch(hipStream_t st, int64_t n, const int32_t *in, int64_t *out, void *work) {
+    const int64_t nb = pk_ceil_div(n, PK_SCAN_TILE);
+    int64_t *bs = static_cast<int64_t *>(work);
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nb), dim3(256), 0, st, n, in, bs);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, st, nb, bs);
+    hipLaunchKernelGGL(scan_final_kernel, dim3((unsigned)nb), dim3(256), 0, st, n, in, bs, out);
+    return PK_OK;
+}
+
+extern "C" int pk_exclusive_scan_i32(void *stream, int64_t n, const int32_t *in_dev, int64_t *out_dev, void *work_dev) {
+    PK_REQUIRE(n >= 0 && out_dev && (n == 0 || (in_dev && work_dev)), "pk_exclusive_scan_i32: bad arguments");
+    hipStream_t st = pk_stream(stream);
+    if (n == 0) {
+        (void)hipMemsetAsync(out_dev, 0, 8, st);
+        return PK_OK;
+    }
+    PK_REQUIRE(pk_ceil_div(n, PK_SCAN_TILE) < (1ll << 31), "pk_exclusive_scan_i32: n too large");
+    pk_scan_launch(st, n, in_dev, out_dev, work_dev);
+    PK_CHECK_LAUNCH("scan kernels");
+    return PK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// LSD radix sort of (key, u32 payload) pairs, 8 bits per pass, stable
+// ------------------------------------------------------------------------------------------------------------
+template <typename KT>
+__global__ __launch_bounds__(256) void radix_hist_kernel(int64_t n, const KT *__restrict__ keys, int shift,
+                                                         int64_t n_tiles, int32_t *__restrict__ ghist) {
+    __shared__ int32_t s_h[256];
+    s_h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * PK_RADIX_TILE;
+#pragma unroll
+    for (int k = 0; k < PK_RADIX_ITEMS; ++k) {
+        const int64_t i = base + k * 256 + threadIdx.x;
+        if (i < n) atomicAdd(&s_h[(int)((keys[i] >> shift) & 255)], 1);
+    }
+    __syncthreads();
+    ghist[(int64_t)threadIdx.x * n_tiles + blockIdx.x] = s_h[threadIdx.x];   // digit-major: one scan orders digits, then tiles
+}
+
+template <typename KT>
+__global__ __launch_bounds__(256) void radix_scatter_kernel(int64_t n, const KT *__restrict__ keys,
+                                                            const uint32_t *__restrict__ vals, int shift,
+                                                            int64_t n_tiles, const int64_t *__restrict__ goff,
+                                                            KT *__restrict__ keys_out, uint32_t *__restrict__ vals_out) {
+    __shared__ int64_t s_base[256];      // next output position of every digit for this tile
+    __shared__ int32_t s_wcnt[4][256];   // per wave: how many of the current 64 keys carry the digit
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    s_base[threadIdx.x] = goff[(int64_t)threadIdx.x * n_tiles + blockIdx.x];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) s_wcnt[w][threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * PK_RADIX_TILE;
+    const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    for (int k = 0; k < PK_RADIX_ITEMS; ++k) {
+        const int64_t i = base + k * 256 + threadIdx.x;     // element order inside the tile: k-major, then thread
+        const bool valid = i < n;
+        KT key = 0;
+        uint32_t val = 0;
+        if (valid) {
+            key = keys[i];
+            val = vals[i];
+        }
+        const int d = (int)((key >> shift) & 255);
+        // lanes of this wave holding the same digit
+        uint64_t eq = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const uint64_t m = __ballot((d >> b) & 1);
+            eq &= ((d >> b) & 1) ? m : ~m;
+        }
+        const int rank = __popcll(eq & lt);
+        if (valid && rank == 0) s_wcnt[wave][d] = __popcll(eq);
+        __syncthreads();
+        if (valid) {
+            int64_t pos = s_base[d] + rank;
+            for (int w = 0; w < wave; ++w) pos += s_wcnt[w][d];
+            keys_out[pos] = key;
+            vals_out[pos] = val;
+        }
+        __syncthreads();
+        {
+            const int t = threadIdx.x;
+            s_base[t] += s_wcnt[0][t] + s_wcnt[1][t] + s_wcnt[2][t] + s_wcnt[3][t];
+            s_wcnt[0][t] = 0; s_wcnt[1][t] = 0; s_wcnt[2][t] = 0; s_wcnt[3][t] = 0;
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int64_t pk_radix_work_bytes(int64_t n) {
+    const int64_t n_tiles = pk_ceil_div(n > 0 ? n : 1, PK_RADIX_TILE);
+    const int64_t table = 256 * n_tiles;
+    // int32 table + int64 scanned table + scan work, each padded to 256 bytes
+    return ((table * 4 + 255) / 256) * 256 + (((table + 1) * 8 + 255) / 256) * 256 + pk_scan_work_bytes(table) + 256;
+}
+
+template <typename KT>
+static int pk_radix_sort(hipStream_t st, int64_t n, KT *keys, uint32_t *vals, KT *keys_tmp, uint32_t *vals_tmp,
+                         int key_bits, void *work, int *result_in_tmp) {
+    const int64_t n_tiles = pk_ceil_div(n, PK_RADIX_TILE);
+    const int64_t table = 256 * n_tiles;
+    char *w = static_cast<char *>(work);
+    int32_t *ghist = reinterpret_cast<int32_t *>(w);
+    int64_t *goff = reinterpret_cast<int64_t *>(w + ((table * 4 + 255) / 256) * 256);
+    void *swork = w + ((table * 4 + 255) / 256) * 256 + (((table + 1) * 8 + 255) / 256) * 256;
+    const int passes = (key_bits + 7) / 8;
+    KT *ki = keys, *ko = keys_tmp;
+    uint32_t *vi = vals, *vo = vals_tmp;
+    for (int p = 0; p < passes; ++p) {
+        const int shift = 8 * p;
+        hipLaunchKernelGGL(radix_hist_kernel<KT>, dim3((unsigned)n_tiles), dim3(256), 0, st, n, ki, shift, n_tiles, ghist);
+        pk_scan_launch(st, table, ghist, goff, swork);
+        hipLaunchKernelGGL(radix_scatter_kernel<KT>, dim3((unsigned)n_tiles), dim3(256), 0, st, n, ki, vi, shift, n_tiles,
+                           goff, ko, vo);
+        KT *tk = ki; ki = ko; ko = tk;
+        uint32_t *tv = vi; vi = vo; vo = tv;
+    }
+    *result_in_tmp = passes & 1;
+    return PK_OK;
+}
+
+extern "C" int pk_radix_sort_pairs(void *stream, int64_t n, int32_t key_bytes, void *keys_dev, uint32_t *vals_dev,
+                                   void *keys_tmp_dev, uint32_t *vals_tmp_dev, int32_t key_bits, void *work_dev,
+                                   int32_t *result_in_tmp) {
+    PK_REQUIRE(n >= 0 && (key_bytes == 4 || key_bytes == 8) && key_bits >= 1 && key_bits <= 8 * key_bytes && result_in_tmp,
+               "pk_radix_sort_pairs: bad arguments (n=%lld key_bytes=%d key_bits=%d)", (long long)n, key_bytes, key_bits);
+    *result_in_tmp = 0;
+    if (n == 0) return PK_OK;
+    PK_REQUIRE(keys_dev && vals_dev && keys_tmp_dev && vals_tmp_dev && work_dev, "pk_radix_sort_pairs: null buffer");
+    PK_REQUIRE(pk_ceil_div(n, PK_RADIX_TILE) < (1ll << 31), "pk_radix_sort_pairs: n too large");
+    hipStream_t st = pk_stream(stream);
+    int in_tmp = 0;
+    if (key_bytes == 4)
+        pk_radix_sort<uint32_t>(st, n, static_cast<uint32_t *>(keys_dev), vals_dev, static_cast<uint32_t *>(keys_tmp_dev),
+                                vals_tmp_dev, key_bits, work_dev, &in_tmp);
+    else
+        pk_radix_sort<uint64_t>(st, n, static_cast<uint64_t *>(keys_dev), vals_dev, static_cast<uint64_t *>(keys_tmp_dev),
+                                vals_tmp_dev, key_bits, work_dev, &in_tmp);
+    *result_in_tmp = in_tmp;
+    PK_CHECK_LAUNCH("radix sort kernels");
+    return PK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// passes around the sort
+// ------------------------------------------------------------------------------------------------------------
+// key = row * n_cols + col (u64), payload = position; err[0] |= 1 when an index is out of range
+__global__ __launch_bounds__(256) void coo_keys_kernel(int64_t n, const int64_t *__restrict__ rows,
+                                                       const int64_t *__restrict__ cols, int64_t stride, int64_t n_rows, int64_t n_cols,
+                                                       uint64_t *__restrict__ keys, uint32_t *__restrict__ pos,
+                                                       int32_t *__restrict__ err) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t r = rows[i * stride], c = cols[i * stride];
+    const bool bad = r < 0 || r >= n_rows || c < 0 || c >= n_cols;
+    if (bad) atomicOr(err, 1);
+    keys[i] = bad ? 0ull : (uint64_t)r * (uint64_t)n_cols + (uint64_t)c;
+    pos[i] = (uint32_t)i;
+}
+
+// head[i] = 1 where a new (row, col) key starts
+__global__ __launch_bounds__(256) void run_heads_kernel(int64_t n, const uint64_t *__restrict__ keys,
+                                                        int32_t *__restrict__ head) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    head[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
+}
+
+// one thread per run head: column id, the run's values added in sorted (= original) order, and the row pointers
+// of every row that starts at or before this entry and after the previous one
+template <typename VT>
+__global__ __launch_bounds__(256) void coo_compact_kernel(int64_t n, const uint64_t *__restrict__ keys,
+                                                          const uint32_t *__restrict__ pos, const int32_t *__restrict__ head,
+                                                          const int64_t *__restrict__ out_index, const VT *__restrict__ vals,
+                                                          int64_t n_rows, int64_t n_cols, int64_t *__restrict__ indptr,
+                                                          int32_t *__restrict__ indices, VT *__restrict__ values) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !head[i]) return;
+    const uint64_t key = keys[i];
+    const int64_t o = out_index[i];
+    const int64_t r = (int64_t)(key / (uint64_t)n_cols);
+    indices[o] = (int32_t)(key - (uint64_t)r * (uint64_t)n_cols);
+    VT acc = vals[pos[i]];
+    int64_t j = i + 1;
+    for (; j < n && !head[j]; ++j) acc += vals[pos[j]];
+    values[o] = acc;
+    const int64_t r_prev = i == 0 ? -1 : (int64_t)(keys[i - 1] / (uint64_t)n_cols);
+    for (int64_t rr = r_prev + 1; rr <= r; ++rr) indptr[rr] = o;
+    if (j == n) {   // the last run closes the remaining rows
+        const int64_t total = out_index[n];
+        for (int64_t rr = r + 1; rr <= n_rows; ++rr) indptr[rr] = total;
+    }
+}
+
+// row pointers from ASCENDING 32-bit keys: indptr[b] = first position with key >= b
+__global__ __launch_bounds__(256) void sorted_keys_indptr_kernel(int64_t n, const uint32_t *__restrict__ keys,
+                                                                 int64_t n_bins, int64_t *__restrict__ indptr) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i > n) return;
+    const int64_t hi = i == n ? n_bins : (int64_t)keys[i];
+    const int64_t lo = i == 0 ? -1 : (int64_t)keys[i - 1];
+    for (int64_t b = lo + 1; b <= hi; ++b) indptr[b] = i;
+}
+
+// keys of the (blocked) transpose: (row / rows_per_block) * n_cols + col, payload = position; the row of a CSR
+// position by binary search in the row pointers
+__global__ __launch_bounds__(256) void csc_keys_kernel(int64_t nnz, int64_t n_rows, const int64_t *__restrict__ indptr,
+                                                       const int32_t *__restrict__ indices, int64_t n_cols,
+                                                       int64_t rows_per_block, uint32_t *__restrict__ keys,
+                                                       uint32_t *__restrict__ pos, int32_t *__restrict__ rows_out) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= nnz) return;
+    int64_t lo = 0, hi = n_rows;           // largest r with indptr[r] <= p
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (indptr[mid] <= p) lo = mid; else hi = mid;
+    }
+    rows_out[p] = (int32_t)lo;
+    const int64_t blk = rows_per_block > 0 ? lo / rows_per_block : 0;
+    keys[p] = (uint32_t)(blk * n_cols + indices[p]);
+    pos[p] = (uint32_t)p;
+}
+
+template <typename VT>
+__global__ __launch_bounds__(256) void csc_gather_kernel(int64_t nnz, const uint32_t *__restrict__ pos,
+                                                         const int32_t *__restrict__ rows, const VT *__restrict__ vals,
+                                                         int32_t *__restrict__ t_indices, VT *__restrict__ t_values) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nnz) return;
+    const uint32_t p = pos[i];
+    t_indices[i] = rows[p];
+    t_values[i] = vals[p];
+}
+
+// keys for re-sorting the rows of a CSR after a column renaming: row * n_cols + new column
+__global__ __launch_bounds__(256) void relabel_keys_kernel(int64_t nnz, int64_t n_rows, const int64_t *__restrict__ indptr,
+                                                           const int32_t *__restrict__ indices,
+                                                           const int32_t *__restrict__ col_map, int64_t n_cols,
+                                                           uint64_t *__restrict__ keys, uint32_t *__restrict__ pos) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= nnz) return;
+    int64_t lo = 0, hi = n_rows;
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (indptr[mid] <= p) lo = mid; else hi = mid;
+    }
+    keys[p] = (uint64_t)lo * (uint64_t)n_cols + (uint64_t)col_map[indices[p]];
+    pos[p] = (uint32_t)p;
+}
+
+template <typename VT>
+__global__ __launch_bounds__(256) void relabel_gather_kernel(int64_t nnz, const uint64_t *__restrict__ keys,
+                                                             const uint32_t *__restrict__ pos, int64_t n_cols,
+                                                             const int64_t *__restrict__ indptr, int64_t n_rows,
+                                                             const VT *__restrict__ vals, int32_t *__restrict__ indices_out,
+                                                             VT *__restrict__ values_out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nnz) return;
+    const uint64_t k = keys[i];
+    indices_out[i] = (int32_t)(k % (uint64_t)n_cols);
+    values_out[i] = vals[pos[i]];
+}
+
+static inline int pk_bits_for(uint64_t max_plus_one) {
+    int b = 1;
+    while (b < 64 && (max_plus_one - 1) >> b) ++b;
+    return b;
+}
+
+// -------- COO -> canonical CSR ---------------------------------------------------------------------------------
+extern "C" int64_t pk_coo_to_csr_work_bytes(int64_t nnz) {
+    const int64_t n = nnz > 0 ? nnz : 1;
+    // keys x2 (u64), pos x2 (u32), head (i32), out_index (i64, n+1), scan work, radix work, err
+    return 2 * n * 8 + 2 * n * 4 + n * 4 + (n + 1) * 8 + pk_scan_work_bytes(n) + pk_radix_work_bytes(n) + 8 * 256;
+}
+
+extern "C" int pk_coo_to_csr(void *stream, int64_t nnz, const int64_t *rows_dev, const int64_t *cols_dev, int64_t idx_stride,
+                             const void *vals_dev, int val_kind, int64_t n_rows, int64_t n_cols, int64_t *indptr_dev,
+                             int32_t *indices_dev, void *values_dev, int64_t *n_unique_dev, int32_t *err_dev,
+                             void *work_dev) {
+    PK_REQUIRE(nnz >= 0 && n_rows >= 1 && n_cols >= 1 && n_cols <= 0x7fffffffll && indptr_dev && n_unique_dev && err_dev &&
+               idx_stride >= 1, "pk_coo_to_csr: bad arguments");
+    PK_REQUIRE(val_kind == PK_VAL_F32 || val_kind == PK_VAL_F64, "pk_coo_to_csr: bad val_kind %d", val_kind);
+    PK_REQUIRE(nnz < 0xffffffffll, "pk_coo_to_csr: more than 2^32 - 1 entries per call");
+    PK_REQUIRE((double)n_rows * (double)n_cols < 1.8e19, "pk_coo_to_csr: n_rows * n_cols overflows the 64-bit key");
+    hipStream_t st = pk_stream(stream);
+    (void)hipMemsetAsync(err_dev, 0, 4, st);
+    if (nnz == 0) {
+        (void)hipMemsetAsync(indptr_dev, 0, (n_rows + 1) * 8, st);
+        (void)hipMemsetAsync(n_unique_dev, 0, 8, st);
+        return PK_OK;
+    }
+    PK_REQUIRE(rows_dev && cols_dev && vals_dev && indices_dev && values_dev && work_dev, "pk_coo_to_csr: null buffer");
+    const int64_t n = nnz;
+    char *w = static_cast<char *>(work_dev);
+    auto take = [&](int64_t bytes) {
+        char *p = w;
+        w += ((bytes + 255) / 256) * 256;
+        return p;
+    };
+    uint64_t *keys = reinterpret_cast<uint64_t *>(take(n * 8));
+    uint64_t *keys_t = reinterpret_cast<uint64_t *>(take(n * 8));
+    uint32_t *pos = reinterpret_cast<uint32_t *>(take(n * 4));
+    uint32_t *pos_t = reinterpret_cast<uint32_t *>(take(n * 4));
+    int32_t *head = reinterpret_cast<int32_t *>(take(n * 4));
+    int64_t *oidx = reinterpret_cast<int64_t *>(take((n + 1) * 8));
+    void *swork = take(pk_scan_work_bytes(n));
+    void *rwork = take(pk_radix_work_bytes(n));
+    const unsigned nb = (unsigned)pk_ceil_div(n, 256);
+    hipLaunchKernelGGL(coo_keys_kernel, dim3(nb), dim3(256), 0, st, n, rows_dev, cols_dev, idx_stride, n_rows, n_cols, keys, pos, err_dev);
+    int in_tmp = 0;
+    const int bits = pk_bits_for((uint64_t)n_rows * (uint64_t)n_cols);
+    pk_radix_sort<uint64_t>(st, n, keys, pos, keys_t, pos_t, bits, rwork, &in_tmp);
+    const uint64_t *ks = in_tmp ? keys_t : keys;
+    const uint32_t *ps = in_tmp ? pos_t : pos;
+    hipLaunchKernelGGL(run_heads_kernel, dim3(nb), dim3(256), 0, st, n, ks, head);
+    pk_scan_launch(st, n, head, oidx, swork);
+    if (val_kind == PK_VAL_F32)
+        hipLaunchKernelGGL(coo_compact_kernel<float>, dim3(nb), dim3(256), 0, st, n, ks, ps, head, oidx,
+                           static_cast<const float *>(vals_dev), n_rows, n_cols, indptr_dev, indices_dev,
+                           static_cast<float *>(values_dev));
+    else
+        hipLaunchKernelGGL(coo_compact_kernel<double>, dim3(nb), dim3(256), 0, st, n, ks, ps, head, oidx,
+                           static_cast<const double *>(vals_dev), n_rows, n_cols, indptr_dev, indices_dev,
+                           static_cast<double *>(values_dev));
+    (void)hipMemcpyAsync(n_unique_dev, oidx + n, 8, hipMemcpyDeviceToDevice, st);
+    PK_CHECK_LAUNCH("coo_to_csr kernels");
+    return PK_OK;
+}
+
+// -------- CSR -> CSC (optionally cut into row blocks) ------------------------------------------------------------
+extern "C" int64_t pk_csr_transpose_work_bytes(int64_t nnz) {
+    const int64_t n = nnz > 0 ? nnz : 1;
+    return 2 * n * 4 + 2 * n * 4 + n * 4 + pk_radix_work_bytes(n) + 8 * 256;
+}
+
+/* t_indptr has n_blocks * n_cols + 1 entries: entry b * n_cols + c = start of column c restricted to the rows of block b */
+extern "C" int pk_csr_transpose(void *stream, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t *indptr_dev,
+                                const int32_t *indices_dev, const void *values_dev, int val_kind, int64_t rows_per_block,
+                                int64_t *t_indptr_dev, int32_t *t_indices_dev, void *t_values_dev, void *work_dev) {
+    PK_REQUIRE(n_rows >= 1 && n_cols >= 1 && nnz >= 0 && indptr_dev && t_indptr_dev, "pk_csr_transpose: bad arguments");
+    PK_REQUIRE(val_kind == PK_VAL_F32 || val_kind == PK_VAL_F64, "pk_csr_transpose: bad val_kind %d", val_kind);
+    PK_REQUIRE(n_rows <= 0x7fffffffll && nnz < 0xffffffffll, "pk_csr_transpose: sizes beyond 32-bit ids");
+    const int64_t n_blocks = rows_per_block > 0 ? pk_ceil_div(n_rows, rows_per_block) : 1;
+    PK_REQUIRE((double)n_blocks * (double)n_cols < 4.2e9, "pk_csr_transpose: n_blocks * n_cols exceeds the 32-bit key");
+    hipStream_t st = pk_stream(stream);
+    const int64_t n_bins = n_blocks * n_cols;
+    if (nnz == 0) {
+        (void)hipMemsetAsync(t_indptr_dev, 0, (n_bins + 1) * 8, st);
+        return PK_OK;
+    }
+    PK_REQUIRE(indices_dev && values_dev && t_indices_dev && t_values_dev && work_dev, "pk_csr_transpose: null buffer");
+    char *w = static_cast<char *>(work_dev);
+    auto take = [&](int64_t bytes) {
+        char *p = w;
+        w += ((bytes + 255) / 256) * 256;
+        return p;
+    };
+    uint32_t *keys = reinterpret_cast<uint32_t *>(take(nnz * 4));
+    uint32_t *keys_t = reinterpret_cast<uint32_t *>(take(nnz * 4));
+    uint32_t *pos = reinterpret_cast<uint32_t *>(take(nnz * 4));
+    uint32_t *pos_t = reinterpret_cast<uint32_t *>(take(nnz * 4));
+    int32_t *rows = reinterpret_cast<int32_t *>(take(nnz * 4));
+    void *rwork = take(pk_radix_work_bytes(nnz));
+    const unsigned nb = (unsigned)pk_ceil_div(nnz, 256);
+    hipLaunchKernelGGL(csc_keys_kernel, dim3(nb), dim3(256), 0, st, nnz, n_rows, indptr_dev, indices_dev, n_cols,
+                       rows_per_block, keys, pos, rows);
+    int in_tmp = 0;
+    pk_radix_sort<uint32_t>(st, nnz, keys, pos, keys_t, pos_t, pk_bits_for((uint64_t)n_bins), rwork, &in_tmp);
+    const uint32_t *ks = in_tmp ? keys_t : keys;
+    const uint32_t *ps = in_tmp ? pos_t : pos;
+    hipLaunchKernelGGL(sorted_keys_indptr_kernel, dim3((unsigned)pk_ceil_div(nnz + 1, 256)), dim3(256), 0, st, nnz, ks,
+                       n_bins, t_indptr_dev);
+    if (val_kind == PK_VAL_F32)
+        hipLaunchKernelGGL(csc_gather_kernel<float>, dim3(nb), dim3(256), 0, st, nnz, ps, rows,
+                           static_cast<const float *>(values_dev), t_indices_dev, static_cast<float *>(t_values_dev));
+    else
+        hipLaunchKernelGGL(csc_gather_kernel<double>, dim3(nb), dim3(256), 0, st, nnz, ps, rows,
+                           static_cast<const double *>(values_dev), t_indices_dev, static_cast<double *>(t_values_dev));
+    PK_CHECK_LAUNCH("csr_transpose kernels");
+    return PK_OK;
+}
+
+// -------- column renaming with re-sorted rows ----------------------------------------------------------------------
+extern "C" int64_t pk_csr_relabel_work_bytes(int64_t nnz) {
+    const int64_t n = nnz > 0 ? nnz : 1;
+    return 2 * n * 8 + 2 * n * 4 + pk_radix_work_bytes(n) + 8 * 256;
+}
+
+extern "C" int pk_csr_relabel_sorted(void *stream, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t *indptr_dev,
+                                     const int32_t *indices_dev, const void *values_dev, int val_kind,
+                                     const int32_t *col_map_dev, int32_t *indices_out_dev, void *values_out_dev,
+                                     void *work_dev) {
+    PK_REQUIRE(n_rows >= 1 && n_cols >= 1 && nnz >= 0 && indptr_dev && col_map_dev, "pk_csr_relabel_sorted: bad arguments");
+    PK_REQUIRE(val_kind == PK_VAL_F32 || val_kind == PK_VAL_F64, "pk_csr_relabel_sorted: bad val_kind %d", val_kind);
+    PK_REQUIRE(nnz < 0xffffffffll, "pk_csr_relabel_sorted: more than 2^32 - 1 entries");
+    if (nnz == 0) return PK_OK;
+    PK_REQUIRE(indices_dev && values_dev && indices_out_dev && values_out_dev && work_dev, "pk_csr_relabel_sorted: null buffer");
+    hipStream_t st = pk_stream(stream);
+    char *w = static_cast<char *>(work_dev);
+    auto take = [&](int64_t bytes) {
+        char *p = w;
+        w += ((bytes + 255) / 256) * 256;
+        return p;
+    };
+    uint64_t *keys = reinterpret_cast<uint64_t *>(take(nnz * 8));
+    uint64_t *keys_t = reinterpret_cast<uint64_t *>(take(nnz * 8));
+    uint32_t *pos = reinterpret_cast<uint32_t *>(take(nnz * 4));
+    uint32_t *pos_t = reinterpret_cast<uint32_t *>(take(nnz * 4));
+    void *rwork = take(pk_radix_work_bytes(nnz));
+    const unsigned nb = (unsigned)pk_ceil_div(nnz, 256);
+    hipLaunchKernelGGL(relabel_keys_kernel, dim3(nb), dim3(256), 0, st, nnz, n_rows, indptr_dev, indices_dev, col_map_dev,
+                       n_cols, keys, pos);
+    int in_tmp = 0;
+    // the row part of the key is already ascending: only the column bits need sorting WITHIN rows, but an LSD sort
+    // of the full key is what keeps this one code path; bits = those of n_rows * n_cols
+    pk_radix_sort<uint64_t>(st, nnz, keys, pos, keys_t, pos_t, pk_bits_for((uint64_t)n_rows * (uint64_t)n_cols), rwork, &in_tmp);
+    const uint64_t *ks = in_tmp ? keys_t : keys;
+    const uint32_t *ps = in_tmp ? pos_t : pos;
+    if (val_kind == PK_VAL_F32)
+        hipLaunchKernelGGL(relabel_gather_kernel<float>, dim3(nb), dim3(256), 0, st, nnz, ks, ps, n_cols, indptr_dev, n_rows,
+                           static_cast<const float *>(values_dev), indices_out_dev, static_cast<float *>(values_out_dev));
+    else
+        hipLaunchKernelGGL(relabel_gather_kernel<double>, dim3(nb), dim3(256), 0, st, nnz, ks, ps, n_cols, indptr_dev, n_rows,
+                           static_cast<const double *>(values_dev), indices_out_dev, static_cast<double *>(values_out_dev));
+    PK_CHECK_LAUNCH("csr_relabel kernels");
+    return PK_OK;
+}
+
+// -------- per-column counts (item popularity) ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void count_i32_kernel(int64_t n, const int32_t *__restrict__ keys, int64_t n_bins,
+                                                        int32_t *__restrict__ counts) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int32_t k = keys[i];
+    if (k >= 0 && k < n_bins) atomicAdd(&counts[k], 1);   // integer adds commute: the result does not depend on the order
+}
+
+extern "C" int pk_count_i32(void *stream, int64_t n, const int32_t *keys_dev, int64_t n_bins, int32_t *counts_dev) {
+    PK_REQUIRE(n >= 0 && n_bins >= 1 && counts_dev, "pk_count_i32: bad arguments");
+    hipStream_t st = pk_stream(stream);
+    (void)hipMemsetAsync(counts_dev, 0, n_bins * 4, st);
+    if (n == 0) return PK_OK;
+    PK_REQUIRE(keys_dev, "pk_count_i32: null keys");
+    hipLaunchKernelGGL(count_i32_kernel, dim3((unsigned)pk_ceil_div(n, 256)), dim3(256), 0, st, n, keys_dev, n_bins, counts_dev);
+    PK_CHECK_LAUNCH("count_i32_kernel");
+    return PK_OK;
+}
+
+// -------- wave-task plan of a CSR on the device (polara_amd/csr.py: build_row_tasks restated) --------------------------
+// Every row gets max(1, ceil(nnz / split)) near-equal tasks; rows with more than one task ("long") write partial
+// results to consecutive slots.
+__global__ __launch_bounds__(256) void plan_counts_kernel(int64_t n_rows, const int64_t *__restrict__ indptr, int split,
+                                                          int32_t *__restrict__ n_chunks, int32_t *__restrict__ is_long,
+                                                          int32_t *__restrict__ long_chunks) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_rows) return;
+    const int64_t cnt = indptr[r + 1] - indptr[r];
+    const int64_t nc = cnt > split ? (cnt + split - 1) / split : 1;
+    n_chunks[r] = (int32_t)nc;
+    is_long[r] = nc > 1;
+    long_chunks[r] = nc > 1 ? (int32_t)nc : 0;
+}
+
+__global__ __launch_bounds__(256) void plan_fill_kernel(int64_t n_rows, const int64_t *__restrict__ indptr,
+                                                        const int32_t *__restrict__ n_chunks,
+                                                        const int64_t *__restrict__ first_task,
+                                                        const int64_t *__restrict__ long_index,
+                                                        const int64_t *__restrict__ slot_first,
+                                                        int32_t *__restrict__ task_row, int64_t *__restrict__ task_begin,
+                                                        int64_t *__restrict__ task_end, int32_t *__restrict__ task_slot,
+                                                        int32_t *__restrict__ long_row, int32_t *__restrict__ long_slot_begin,
+                                                        int32_t *__restrict__ long_slot_end) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_rows) return;
+    const int64_t p0 = indptr[r], p1 = indptr[r + 1];
+    const int nc = n_chunks[r];
+    const int64_t t0 = first_task[r];
+    const int64_t len = nc > 0 ? (p1 - p0 + nc - 1) / nc : 0;     // ceil(count / n_chunks)
+    const int64_t s0 = nc > 1 ? slot_first[r] : -1;
+    for (int k = 0; k < nc; ++k) {
+        int64_t b = p0 + (int64_t)k * len, e = b + len;
+        if (e > p1) e = p1;
+        if (b > e) b = e;
+        task_row[t0 + k] = (int32_t)r;
+        task_begin[t0 + k] = b;
+        task_end[t0 + k] = e;
+        task_slot[t0 + k] = nc > 1 ? (int32_t)(s0 + k) : -1;
+    }
+    if (nc > 1) {
+        const int64_t li = long_index[r];
+        long_row[li] = (int32_t)r;
+        long_slot_begin[li] = (int32_t)s0;
+        long_slot_end[li] = (int32_t)(s0 + nc);
+    }
+}
+
+extern "C" int64_t pk_row_plan_work_bytes(int64_t n_rows) {
+    const int64_t n = n_rows > 0 ? n_rows : 1;
+    return 3 * (((n * 4 + 255) / 256) * 256) + 3 * ((((n + 1) * 8 + 255) / 256) * 256) + pk_scan_work_bytes(n) + 256;
+}
+
+/* phase 1: counts[0..2] (device int64) = number of tasks, long rows, slots; the scanned tables stay in `work` */
+extern "C" int pk_row_plan_count(void *stream, int64_t n_rows, const int64_t *indptr_dev, int32_t split, int64_t *counts_dev,
+                                 void *work_dev) {
+    PK_REQUIRE(n_rows >= 1 && split >= 1 && indptr_dev && counts_dev && work_dev, "pk_row_plan_count: bad arguments");
+    hipStream_t st = pk_stream(stream);
+    char *w = static_cast<char *>(work_dev);
+    const int64_t a4 = ((n_rows * 4 + 255) / 256) * 256, a8 = (((n_rows + 1) * 8 + 255) / 256) * 256;
+    int32_t *n_chunks = reinterpret_cast<int32_t *>(w);
+    int32_t *is_long = reinterpret_cast<int32_t *>(w + a4);
+    int32_t *long_chunks = reinterpret_cast<int32_t *>(w + 2 * a4);
+    int64_t *first_task = reinterpret_cast<int64_t *>(w + 3 * a4);
+    int64_t *long_index = reinterpret_cast<int64_t *>(w + 3 * a4 + a8);
+    int64_t *slot_first = reinterpret_cast<int64_t *>(w + 3 * a4 + 2 * a8);
+    void *swork = w + 3 * a4 + 3 * a8;
+    hipLaunchKernelGGL(plan_counts_kernel, dim3((unsigned)pk_ceil_div(n_rows, 256)), dim3(256), 0, st, n_rows, indptr_dev, split,
+                       n_chunks, is_long, long_chunks);
+    pk_scan_launch(st, n_rows, n_chunks, first_task, swork);
+    pk_scan_launch(st, n_rows, is_long, long_index, swork);
+    pk_scan_launch(st, n_rows, long_chunks, slot_first, swork);
+    (void)hipMemcpyAsync(counts_dev, first_task + n_rows, 8, hipMemcpyDeviceToDevice, st);
+    (void)hipMemcpyAsync(counts_dev + 1, long_index + n_rows, 8, hipMemcpyDeviceToDevice, st);
+    (void)hipMemcpyAsync(counts_dev + 2, slot_first + n_rows, 8, hipMemcpyDeviceToDevice, st);
+    PK_CHECK_LAUNCH("row plan count kernels");
+    return PK_OK;
+}
+
+/* phase 2: fills the task arrays (sized from phase 1's counts); row_first_task_dev (int64[n_rows + 1]) and
+ * row_long_index_dev (int64[n_rows + 1]) receive the scanned tables (first task / number of long rows before a row) */
+extern "C" int pk_row_plan_fill(void *stream, int64_t n_rows, const int64_t *indptr_dev, const void *work_dev,
+                                int32_t *task_row_dev, int64_t *task_begin_dev, int64_t *task_end_dev, int32_t *task_slot_dev,
+                                int32_t *long_row_dev, int32_t *long_slot_begin_dev, int32_t *long_slot_end_dev,
+                                int64_t *row_first_task_dev, int64_t *row_long_index_dev) {
+    PK_REQUIRE(n_rows >= 1 && indptr_dev && work_dev && task_row_dev && task_begin_dev && task_end_dev && task_slot_dev,
+               "pk_row_plan_fill: bad arguments");
+    hipStream_t st = pk_stream(stream);
+    const char *w = static_cast<const char *>(work_dev);
+    const int64_t a4 = ((n_rows * 4 + 255) / 256) * 256, a8 = (((n_rows + 1) * 8 + 255) / 256) * 256;
+    const int32_t *n_chunks = reinterpret_cast<const int32_t *>(w);
+    const int64_t *first_task = reinterpret_cast<const int64_t *>(w + 3 * a4);
+    const int64_t *long_index = reinterpret_cast<const int64_t *>(w + 3 * a4 + a8);
+    const int64_t *slot_first = reinterpret_cast<const int64_t *>(w + 3 * a4 + 2 * a8);
+    hipLaunchKernelGGL(plan_fill_kernel, dim3((unsigned)pk_ceil_div(n_rows, 256)), dim3(256), 0, st, n_rows, indptr_dev, n_chunks,
+                       first_task, long_index, slot_first, task_row_dev, task_begin_dev, task_end_dev, task_slot_dev,
+                       long_row_dev, long_slot_begin_dev, long_slot_end_dev);
+    if (row_first_task_dev) (void)hipMemcpyAsync(row_first_task_dev, first_task, (n_rows + 1) * 8, hipMemcpyDeviceToDevice, st);
+    if (row_long_index_dev) (void)hipMemcpyAsync(row_long_index_dev, long_index, (n_rows + 1) * 8, hipMemcpyDeviceToDevice, st);
+    PK_CHECK_LAUNCH("row plan fill kernel");
+    return PK_OK;
+}

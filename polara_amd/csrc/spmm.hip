@@ -32,7 +32,8 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(
     int64_t n_tasks, const int32_t *__restrict__ task_row, const int64_t *__restrict__ task_begin,
     const int64_t *__restrict__ task_end, const int32_t *__restrict__ task_slot,
     const int32_t *__restrict__ indices, const VT *__restrict__ vals, const double *__restrict__ X,
-    int64_t ldx, int nc, double *__restrict__ out, int64_t ldo, double *__restrict__ partial) {
+    int64_t ldx, int nc, double *__restrict__ out, int64_t ldo, double *__restrict__ partial, int64_t row_base,
+    int accumulate) {
     const int lane = threadIdx.x & 63;
     // wave id made provably uniform so the task descriptors live in SGPRs
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -40,6 +41,7 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(
     if (task >= n_tasks) return;
     const int64_t p0 = task_begin[task];
     const int64_t p1 = task_end[task];
+    if (accumulate && p0 == p1 && task_slot[task] < 0) return;   // nothing to add
 
     int col[CPL];
     double acc[CPL];
@@ -104,11 +106,12 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(
     }
 
     const int slot = task_slot[task];
-    double *dst = slot < 0 ? out + (int64_t)task_row[task] * ldo : partial + (int64_t)slot * nc;
+    double *dst = slot < 0 ? out + ((int64_t)task_row[task] - row_base) * ldo : partial + (int64_t)slot * nc;
+    const bool add = accumulate && slot < 0;
 #pragma unroll
     for (int g = 0; g < CPL; ++g) {
         int c = lane + 64 * g;
-        if (c < nc) dst[c] = acc[g];
+        if (c < nc) dst[c] = add ? dst[c] + acc[g] : acc[g];
     }
 }
 
@@ -133,7 +136,8 @@ __global__ __launch_bounds__(256) void spmm_csr_groups_kernel(
     int64_t n_tasks, const int32_t *__restrict__ task_row, const int64_t *__restrict__ task_begin,
     const int64_t *__restrict__ task_end, const int32_t *__restrict__ task_slot,
     const int32_t *__restrict__ indices, const VT *__restrict__ vals, const XT *__restrict__ X,
-    int64_t ldx, int nc, double *__restrict__ out, int64_t ldo, double *__restrict__ partial) {
+    int64_t ldx, int nc, double *__restrict__ out, int64_t ldo, double *__restrict__ partial, int64_t row_base,
+    int accumulate) {
     constexpr bool XF = sizeof(XT) == 4;
     constexpr int LG = 64 / GROUPS;
     // wave steps per register set (two sets in flight); an fp32 row piece is one float4 per lane and step
@@ -147,6 +151,7 @@ __global__ __launch_bounds__(256) void spmm_csr_groups_kernel(
     if (task >= n_tasks) return;
     const int64_t p0 = task_begin[task];
     const int n = (int)(task_end[task] - p0);
+    if (accumulate && n == 0 && task_slot[task] < 0) return;   // nothing to add
     const int g = lane / LG, l = lane % LG;
     // columns (c0, c0+1) and (c1, c1+1) of this lane; nc is even (a multiple of 4 for fp32 X): a pair is in or
     // out as a whole
@@ -245,8 +250,18 @@ __global__ __launch_bounds__(256) void spmm_csr_groups_kernel(
         acc1.x += pk_lane_xor<32>(acc1.x); acc1.y += pk_lane_xor<32>(acc1.y);
     }
     const int slot = task_slot[task];
-    double *dst = slot < 0 ? out + (int64_t)task_row[task] * ldo : partial + (int64_t)slot * nc;
+    double *dst = slot < 0 ? out + ((int64_t)task_row[task] - row_base) * ldo : partial + (int64_t)slot * nc;
     if (g == 0) {
+        if (accumulate && slot < 0) {
+            if (ok0) {
+                acc0.x += dst[c0];
+                acc0.y += dst[c0 + 1];
+            }
+            if (ok1) {
+                acc1.x += dst[c1];
+                acc1.y += dst[c1 + 1];
+            }
+        }
         if (ok0) {
             dst[c0] = acc0.x;
             dst[c0 + 1] = acc0.y;
@@ -262,14 +277,15 @@ __global__ __launch_bounds__(256) void spmm_csr_groups_kernel(
 __global__ __launch_bounds__(256) void spmm_fixup_kernel(
     int64_t n_long, const int32_t *__restrict__ long_row, const int32_t *__restrict__ slot_begin,
     const int32_t *__restrict__ slot_end, const double *__restrict__ partial, int nc,
-    double *__restrict__ out, int64_t ldo) {
+    double *__restrict__ out, int64_t ldo, int64_t row_base, int accumulate) {
     const int64_t r = blockIdx.x;
     if (r >= n_long) return;
     const int s0 = slot_begin[r], s1 = slot_end[r];
+    double *dst = out + ((int64_t)long_row[r] - row_base) * ldo;
     for (int c = threadIdx.x; c < nc; c += blockDim.x) {
         double acc = 0.0;
         for (int s = s0; s < s1; ++s) acc += partial[(int64_t)s * nc + c];
-        out[(int64_t)long_row[r] * ldo + c] = acc;
+        dst[c] = accumulate ? dst[c] + acc : acc;
     }
 }
 
@@ -277,7 +293,7 @@ template <typename VT>
 static int launch_spmm(hipStream_t st, int64_t n_tasks, const int32_t *task_row, const int64_t *task_begin,
                        const int64_t *task_end, const int32_t *task_slot, const int32_t *indices,
                        const void *vals, const void *Xv, int x_kind, int64_t ldx, int nc, double *out, int64_t ldo,
-                       double *partial) {
+                       double *partial, int64_t row_base, int accumulate) {
     dim3 grid((unsigned)pk_ceil_div(n_tasks, 4)), block(256);
     const VT *v = static_cast<const VT *>(vals);
     if (x_kind == PK_VAL_F32) {
@@ -289,7 +305,7 @@ static int launch_spmm(hipStream_t st, int64_t n_tasks, const int32_t *task_row,
         }
 #define PK_SPMM_GROUPS_F(G)                                                                                     \
     hipLaunchKernelGGL((spmm_csr_groups_kernel<VT, G, float>), grid, block, 0, st, n_tasks, task_row, task_begin, \
-                       task_end, task_slot, indices, v, X, ldx, nc, out, ldo, partial)
+                       task_end, task_slot, indices, v, X, ldx, nc, out, ldo, partial, row_base, accumulate)
         if (nc <= 64) PK_SPMM_GROUPS_F(4);
         else if (nc <= 128) PK_SPMM_GROUPS_F(2);
         else PK_SPMM_GROUPS_F(1);
@@ -301,7 +317,7 @@ static int launch_spmm(hipStream_t st, int64_t n_tasks, const int32_t *task_row,
     if (paired) {
 #define PK_SPMM_GROUPS(G)                                                                                  \
     hipLaunchKernelGGL((spmm_csr_groups_kernel<VT, G, double>), grid, block, 0, st, n_tasks, task_row, task_begin,  \
-                       task_end, task_slot, indices, v, X, ldx, nc, out, ldo, partial)
+                       task_end, task_slot, indices, v, X, ldx, nc, out, ldo, partial, row_base, accumulate)
         if (nc <= 64) PK_SPMM_GROUPS(4);
         else if (nc <= 128) PK_SPMM_GROUPS(2);
         else PK_SPMM_GROUPS(1);
@@ -312,7 +328,7 @@ static int launch_spmm(hipStream_t st, int64_t n_tasks, const int32_t *task_row,
 #define PK_SPMM_CASE(C)                                                                              \
     case C:                                                                                          \
         hipLaunchKernelGGL((spmm_csr_kernel<VT, C>), grid, block, 0, st, n_tasks, task_row, task_begin, \
-                           task_end, task_slot, indices, v, X, ldx, nc, out, ldo, partial);          \
+                           task_end, task_slot, indices, v, X, ldx, nc, out, ldo, partial, row_base, accumulate);          \
         break;
     switch (cpl) {
         PK_SPMM_CASE(1)
@@ -327,27 +343,28 @@ static int launch_spmm(hipStream_t st, int64_t n_tasks, const int32_t *task_row,
     return PK_OK;
 }
 
-extern "C" int pk_spmm_csr_x(void *stream, int64_t n_tasks, const int32_t *task_row_dev,
-                             const int64_t *task_begin_dev, const int64_t *task_end_dev,
-                             const int32_t *task_slot_dev, int64_t n_long, const int32_t *long_row_dev,
-                             const int32_t *long_slot_begin_dev, const int32_t *long_slot_end_dev,
-                             const int32_t *indices_dev, const void *vals_dev, int val_kind,
-                             const void *X_dev, int x_kind, int64_t ldx, int32_t nc, double *out_dev, int64_t ldo,
-                             double *partial_dev) {
+extern "C" int pk_spmm_csr_ex(void *stream, int64_t n_tasks, const int32_t *task_row_dev,
+                              const int64_t *task_begin_dev, const int64_t *task_end_dev,
+                              const int32_t *task_slot_dev, int64_t n_long, const int32_t *long_row_dev,
+                              const int32_t *long_slot_begin_dev, const int32_t *long_slot_end_dev,
+                              const int32_t *indices_dev, const void *vals_dev, int val_kind,
+                              const void *X_dev, int x_kind, int64_t ldx, int32_t nc, double *out_dev, int64_t ldo,
+                              double *partial_dev, int64_t row_base, int32_t accumulate) {
     PK_REQUIRE(n_tasks >= 0 && nc >= 1 && nc <= 256, "pk_spmm_csr: bad sizes n_tasks=%lld nc=%d",
                (long long)n_tasks, nc);
     PK_REQUIRE(ldo >= nc && ldx >= nc, "pk_spmm_csr: ldo/ldx < nc");
     PK_REQUIRE(x_kind == PK_VAL_F32 || x_kind == PK_VAL_F64, "pk_spmm_csr_x: bad x_kind %d", x_kind);
     PK_REQUIRE(n_long == 0 || partial_dev != nullptr, "pk_spmm_csr: partial buffer required");
+    PK_REQUIRE(row_base >= 0, "pk_spmm_csr_ex: negative row_base");
     if (n_tasks == 0) return PK_OK;
     hipStream_t st = pk_stream(stream);
     int rc;
     if (val_kind == PK_VAL_F32)
         rc = launch_spmm<float>(st, n_tasks, task_row_dev, task_begin_dev, task_end_dev, task_slot_dev,
-                                indices_dev, vals_dev, X_dev, x_kind, ldx, nc, out_dev, ldo, partial_dev);
+                                indices_dev, vals_dev, X_dev, x_kind, ldx, nc, out_dev, ldo, partial_dev, row_base, accumulate);
     else if (val_kind == PK_VAL_F64)
         rc = launch_spmm<double>(st, n_tasks, task_row_dev, task_begin_dev, task_end_dev, task_slot_dev,
-                                 indices_dev, vals_dev, X_dev, x_kind, ldx, nc, out_dev, ldo, partial_dev);
+                                 indices_dev, vals_dev, X_dev, x_kind, ldx, nc, out_dev, ldo, partial_dev, row_base, accumulate);
     else {
         pk_set_error("pk_spmm_csr: bad val_kind %d", val_kind);
         return PK_E_INVALID;
@@ -356,10 +373,22 @@ extern "C" int pk_spmm_csr_x(void *stream, int64_t n_tasks, const int32_t *task_
     PK_CHECK_LAUNCH("spmm_csr_kernel");
     if (n_long > 0) {
         hipLaunchKernelGGL(spmm_fixup_kernel, dim3((unsigned)n_long), dim3(256), 0, st, n_long, long_row_dev,
-                           long_slot_begin_dev, long_slot_end_dev, partial_dev, nc, out_dev, ldo);
+                           long_slot_begin_dev, long_slot_end_dev, partial_dev, nc, out_dev, ldo, row_base, accumulate);
         PK_CHECK_LAUNCH("spmm_fixup_kernel");
     }
     return PK_OK;
+}
+
+extern "C" int pk_spmm_csr_x(void *stream, int64_t n_tasks, const int32_t *task_row_dev,
+                             const int64_t *task_begin_dev, const int64_t *task_end_dev,
+                             const int32_t *task_slot_dev, int64_t n_long, const int32_t *long_row_dev,
+                             const int32_t *long_slot_begin_dev, const int32_t *long_slot_end_dev,
+                             const int32_t *indices_dev, const void *vals_dev, int val_kind,
+                             const void *X_dev, int x_kind, int64_t ldx, int32_t nc, double *out_dev, int64_t ldo,
+                             double *partial_dev) {
+    return pk_spmm_csr_ex(stream, n_tasks, task_row_dev, task_begin_dev, task_end_dev, task_slot_dev, n_long,
+                          long_row_dev, long_slot_begin_dev, long_slot_end_dev, indices_dev, vals_dev, val_kind, X_dev,
+                          x_kind, ldx, nc, out_dev, ldo, partial_dev, 0, 0);
 }
 
 extern "C" int pk_spmm_csr_f64(void *stream, int64_t n_tasks, const int32_t *task_row_dev,
@@ -369,7 +398,7 @@ extern "C" int pk_spmm_csr_f64(void *stream, int64_t n_tasks, const int32_t *tas
                                const int32_t *indices_dev, const void *vals_dev, int val_kind,
                                const double *X_dev, int64_t ldx, int32_t nc, double *out_dev, int64_t ldo,
                                double *partial_dev) {
-    return pk_spmm_csr_x(stream, n_tasks, task_row_dev, task_begin_dev, task_end_dev, task_slot_dev, n_long,
-                         long_row_dev, long_slot_begin_dev, long_slot_end_dev, indices_dev, vals_dev, val_kind, X_dev,
-                         PK_VAL_F64, ldx, nc, out_dev, ldo, partial_dev);
+    return pk_spmm_csr_ex(stream, n_tasks, task_row_dev, task_begin_dev, task_end_dev, task_slot_dev, n_long,
+                          long_row_dev, long_slot_begin_dev, long_slot_end_dev, indices_dev, vals_dev, val_kind, X_dev,
+                          PK_VAL_F64, ldx, nc, out_dev, ldo, partial_dev, 0, 0);
 }

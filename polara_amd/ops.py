@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .csr import build_row_tasks, SPLIT_NNZ
+from .csr import SPLIT_NNZ
 
 
 def _ptr(t, offset=0):
@@ -21,11 +21,10 @@ def _ptr(t, offset=0):
 
 
 class DeviceCSR:
-    """A CSR matrix resident in HBM together with its row-task plan (and, lazily, its transpose)."""
+    """A CSR matrix resident in HBM together with its row-task plan (and, lazily, its transpose).  The plan
+    (one wave per task, long rows split) is built on the device (pk_row_plan_*): only three counters visit the host."""
 
     def __init__(self, ops, indptr, indices, values, shape, split=SPLIT_NNZ):
-        self.ops = ops
-        self.shape = (int(shape[0]), int(shape[1]))
         indptr = np.ascontiguousarray(indptr, dtype=np.int64)
         indices = np.ascontiguousarray(indices, dtype=np.int32)
         values = np.ascontiguousarray(values)
@@ -35,24 +34,64 @@ class DeviceCSR:
                 values = v32  # ratings are exactly representable: halve the value stream
         elif values.dtype != np.float32:
             values = values.astype(np.float64)
-        self.nnz = int(indptr[-1])
-        self._host = (indptr, indices, values)
-        self.val_kind = _lib.PK_VAL_F32 if values.dtype == np.float32 else _lib.PK_VAL_F64
         dev = ops.device
-        self.indptr = torch.from_numpy(indptr).to(dev)
-        self.indices = torch.from_numpy(indices).to(dev)
-        self.values = torch.from_numpy(values).to(dev)
-        plan = build_row_tasks(indptr, split)
-        self.row_first_task = plan.pop('row_first_task')   # host only
-        self.long_row_host = plan['long_row']
-        self.n_tasks = len(plan['task_row'])
-        self.n_long = len(plan['long_row'])
-        self.n_slots = plan['n_slots']
-        self.plan = {k: torch.from_numpy(v).to(dev) for k, v in plan.items() if isinstance(v, np.ndarray)}
+        self._setup(ops, torch.from_numpy(indptr).to(dev), torch.from_numpy(indices).to(dev),
+                    torch.from_numpy(values).to(dev), shape, split, nnz=int(indptr[-1]))
+        self._host = (indptr, indices, values)
+
+    def _setup(self, ops, indptr, indices, values, shape, split, nnz=None):
+        self.ops = ops
+        self.shape = (int(shape[0]), int(shape[1]))
+        self.indptr, self.indices, self.values = indptr, indices, values
+        self.val_kind = _lib.PK_VAL_F32 if values.dtype == torch.float32 else _lib.PK_VAL_F64
+        self._host = None
+        self.split = split
         self._partial = None
         self._T = None
         self._seen_tiles = None
         self.sorted_cols = True     # canonical CSR; False after a bare column renaming (csr_relabel_cols(sort=False))
+        self._nnz = nnz
+        self._plan = None
+
+    @property
+    def nnz(self):
+        if self._nnz is None:
+            self._nnz = int(self.indptr[-1].item()) - int(self.indptr[0].item())
+        return self._nnz
+
+    # ---- the wave-task plan (lazy: a matrix that is only re-indexed or transposed never needs one) ----------------
+    def _ensure_plan(self):
+        if self._plan is None:
+            self._plan = self.ops.row_plan(self.indptr, self.shape[0], self.split)
+        return self._plan
+
+    @property
+    def plan(self):
+        return self._ensure_plan()['arrays']
+
+    @property
+    def n_tasks(self):
+        return self._ensure_plan()['n_tasks']
+
+    @property
+    def n_long(self):
+        return self._ensure_plan()['n_long']
+
+    @property
+    def n_slots(self):
+        return self._ensure_plan()['n_slots']
+
+    def task_range(self, lo, hi):
+        """(first task, number of tasks, first long row, number of long rows) of rows [lo, hi): the tasks of a row range
+        are a contiguous slice of the plan.  Cached per range (one small device read each)."""
+        p = self._ensure_plan()
+        key = (int(lo), int(hi))
+        if key not in p['ranges']:
+            sel = torch.tensor(key, device=self.indptr.device)
+            t = p['row_first_task'][sel].tolist()
+            l = p['row_long_index'][sel].tolist()
+            p['ranges'][key] = (int(t[0]), int(t[1] - t[0]), int(l[0]), int(l[1] - l[0]))
+        return p['ranges'][key]
 
     def partial(self, nc):
         need = self.n_slots * nc
@@ -72,47 +111,28 @@ class DeviceCSR:
 
     @property
     def T(self):
-        """CSR of A^T (= CSC of A).  Format conversion runs on the device (a stable sort by column,
-        torch plumbing): a host argsort of 1e8 indices would take longer than the whole build."""
+        """CSR of A^T (= CSC of A), built on the device by pk_csr_transpose (a stable radix sort by column)."""
         if self._T is None:
-            dev = self.ops.device
-            n_rows, n_cols = self.shape
-            counts = (self.indptr[1:] - self.indptr[:-1])
-            rows = torch.repeat_interleave(torch.arange(n_rows, dtype=torch.int32, device=dev), counts)
-            order = torch.argsort(self.indices, stable=True)   # rows stay ascending within a column
-            t_indices = rows[order]
-            t_values = self.values[order]
-            t_counts = torch.bincount(self.indices.long(), minlength=n_cols)
-            t_indptr = torch.zeros(n_cols + 1, dtype=torch.int64, device=dev)
-            t_indptr[1:] = torch.cumsum(t_counts, 0)
-            del rows, order, counts, t_counts
-            self._T = DeviceCSR.from_device(self.ops, t_indptr, t_indices, t_values, (n_cols, n_rows))
+            self._T = self.ops.csr_transpose(self)
             self._T._T = self
         return self._T
 
+    def transpose_operator(self):
+        """What the eigensolver multiplies by for Z = A^T Y: the user-blocked image when the matrix has enough rows for
+        the blocking to matter, else the plain transpose."""
+        return self.T_blocked() if self.shape[0] >= 2 * BlockedTranspose.MIN_ROWS_PER_BLOCK else self.T
+
+    def T_blocked(self, rows_per_block=None):
+        """The transposed product cut into row (user) blocks: see BlockedTranspose."""
+        if getattr(self, '_Tb', None) is None or (rows_per_block and self._Tb.rows_per_block != rows_per_block):
+            self._Tb = BlockedTranspose(self.ops, self, rows_per_block)
+        return self._Tb
+
     @classmethod
     def from_device(cls, ops, indptr, indices, values, shape, split=SPLIT_NNZ):
-        """Wraps CSR arrays that already live in HBM (only the row pointers visit the host, to
-        build the task plan)."""
+        """Wraps CSR arrays that already live in HBM."""
         self = cls.__new__(cls)
-        self.ops = ops
-        self.shape = (int(shape[0]), int(shape[1]))
-        self.indptr, self.indices, self.values = indptr, indices, values
-        self.val_kind = _lib.PK_VAL_F32 if values.dtype == torch.float32 else _lib.PK_VAL_F64
-        host_ptr = indptr.cpu().numpy()
-        self.nnz = int(host_ptr[-1])
-        self._host = None
-        plan = build_row_tasks(host_ptr, split)
-        self.row_first_task = plan.pop('row_first_task')   # host only
-        self.long_row_host = plan['long_row']
-        self.n_tasks = len(plan['task_row'])
-        self.n_long = len(plan['long_row'])
-        self.n_slots = plan['n_slots']
-        self.plan = {k: torch.from_numpy(v).to(ops.device) for k, v in plan.items() if isinstance(v, np.ndarray)}
-        self._partial = None
-        self._T = None
-        self._seen_tiles = None
-        self.sorted_cols = True     # canonical CSR; False after a bare column renaming (csr_relabel_cols(sort=False))
+        self._setup(ops, indptr, indices, values, shape, split)
         return self
 
     def drop_host(self):
@@ -135,8 +155,45 @@ class DeviceCSR:
         new._host = None
         new._partial = None
         new._T = None
+        new._Tb = None
         new._seen_tiles = None
         return new
+
+
+class BlockedTranspose:
+    """Z = A^T Y with the rows of A (users) cut into blocks: the CSC of every block is one slice of a
+    (block, item)-ordered image (pk_csr_transpose with rows_per_block > 0), block b ADDS its share to Z in launch
+    order (deterministic).  The rows of Y one launch gathers span rows_per_block users instead of all of them, so
+    they stay cache-resident (ML-20M-shaped, nc = 64: 1.14 -> 0.63 ms per product at 16K users per block;
+    tools/probes/panel_probe.py).  Used by the eigensolver through HipOps.spmm (it has `.apply`)."""
+
+    MIN_ROWS_PER_BLOCK = 16384
+
+    def __init__(self, ops, A, rows_per_block=None):
+        n_rows, n_cols = A.shape
+        if not rows_per_block:
+            # small enough that a block's rows of Y (nc = 64 fp64) fit the L2s, large enough that a (block, item)
+            # task still holds ~64 entries on average (every task costs a descriptor and a wave)
+            rows_per_block = max(self.MIN_ROWS_PER_BLOCK, int(64.0 * n_cols * n_rows / max(A.nnz, 1)))
+            rows_per_block = -(-rows_per_block // 4096) * 4096
+        self.rows_per_block = int(min(rows_per_block, max(n_rows, 1)))
+        self.n_blocks = -(-n_rows // self.rows_per_block)
+        self.ops = ops
+        self.shape = (n_cols, n_rows)
+        self.image = ops.csr_transpose(A, rows_per_block=self.rows_per_block)   # DeviceCSR with n_blocks * n_cols rows
+        self.ranges = [self.image.task_range(b * n_cols, (b + 1) * n_cols) for b in range(self.n_blocks)]
+        edges = self.image.indptr[torch.arange(0, self.n_blocks + 1, device=self.image.indptr.device) * n_cols].tolist()
+        self.block_nnz = [int(b - a) for a, b in zip(edges[:-1], edges[1:])]
+
+    def apply(self, Y, out=None):
+        ops, M = self.ops, self.image
+        n_cols = self.shape[0]
+        if out is None:
+            out = ops.empty(n_cols, Y.shape[1])
+        for b, rng in enumerate(self.ranges):
+            ops._spmm_launch(M, Y, out, rng, row_base=b * n_cols, accumulate=b > 0,
+                             meta_shape=(n_cols if b == 0 else 0, self.rows_per_block, self.block_nnz[b]))
+        return out
 
 
 class HipOps:
@@ -203,35 +260,97 @@ class HipOps:
     def csr(self, indptr, indices, values, shape, split=SPLIT_NNZ):
         return DeviceCSR(self, indptr, indices, values, shape, split)
 
+    def _work(self, nbytes):
+        return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.device)
+
+    def row_plan(self, indptr, n_rows, split=SPLIT_NNZ):
+        """The wave-task plan of a CSR, built on the device (csr.build_row_tasks restated as kernels)."""
+        work = self._work(self.lib.pk_row_plan_work_bytes(n_rows))
+        counts = torch.empty(3, dtype=torch.int64, device=self.device)
+        _lib.check(self.lib.pk_row_plan_count(self.stream(), n_rows, _ptr(indptr), int(split), _ptr(counts), _ptr(work)),
+                   'pk_row_plan_count')
+        n_tasks, n_long, n_slots = (int(v) for v in counts.tolist())
+        i32 = lambda n: torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+        i64 = lambda n: torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
+        arr = dict(task_row=i32(n_tasks), task_begin=i64(n_tasks), task_end=i64(n_tasks), task_slot=i32(n_tasks),
+                   long_row=i32(n_long), long_slot_begin=i32(n_long), long_slot_end=i32(n_long))
+        rft, rli = i64(n_rows + 1), i64(n_rows + 1)
+        _lib.check(self.lib.pk_row_plan_fill(self.stream(), n_rows, _ptr(indptr), _ptr(work), _ptr(arr['task_row']),
+                                             _ptr(arr['task_begin']), _ptr(arr['task_end']), _ptr(arr['task_slot']),
+                                             _ptr(arr['long_row']), _ptr(arr['long_slot_begin']), _ptr(arr['long_slot_end']),
+                                             _ptr(rft), _ptr(rli)), 'pk_row_plan_fill')
+        return dict(arrays=arr, n_tasks=n_tasks, n_long=n_long, n_slots=n_slots, row_first_task=rft, row_long_index=rli,
+                    ranges={})
+
+    def item_counts(self, A):
+        """int64 [n_cols] (host): stored entries per column of a DeviceCSR (pk_count_i32) — the popularity of the items."""
+        counts = torch.empty(A.shape[1], dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.pk_count_i32(self.stream(), A.indices.numel(), _ptr(A.indices), A.shape[1], _ptr(counts)),
+                   'pk_count_i32')
+        return counts.cpu().numpy().astype(np.int64)
+
+    def csr_transpose(self, A, rows_per_block=0):
+        """CSR of A^T on the device (pk_csr_transpose).  rows_per_block > 0: the (block, column)-ordered image — a
+        DeviceCSR with n_blocks * n_cols rows whose row b * n_cols + c holds column c restricted to the rows of block b."""
+        n_rows, n_cols = A.shape
+        nnz = int(A.indices.numel())
+        n_blocks = -(-n_rows // rows_per_block) if rows_per_block else 1
+        t_indptr = torch.empty(n_blocks * n_cols + 1, dtype=torch.int64, device=self.device)
+        t_indices = torch.empty(max(nnz, 1), dtype=torch.int32, device=self.device)[:nnz]
+        t_values = torch.empty(max(nnz, 1), dtype=A.values.dtype, device=self.device)[:nnz]
+        work = self._work(self.lib.pk_csr_transpose_work_bytes(nnz))
+        with self._timed('transpose', (n_rows, n_cols, nnz)):
+            _lib.check(self.lib.pk_csr_transpose(self.stream(), n_rows, n_cols, nnz, _ptr(A.indptr), _ptr(A.indices),
+                                                 _ptr(A.values), A.val_kind, int(rows_per_block), _ptr(t_indptr),
+                                                 _ptr(t_indices), _ptr(t_values), _ptr(work)), 'pk_csr_transpose')
+        T = DeviceCSR.from_device(self, t_indptr, t_indices, t_values, (n_blocks * n_cols, n_rows), A.split)
+        T._nnz = nnz
+        return T
+
     def csr_relabel_cols(self, A, col_map, sort=True):
         """CSR with column j renamed to col_map[j].  `col_map`: int array or device tensor.  The row pointers —
-        and with them the row-task plan — are those of A.  sort=True re-sorts every row on device (canonical
-        CSR); sort=False only renames (one gather): enough for SpMM, the seen-tile builder and the exact-row
-        kernel, none of which needs ordered rows (the result carries sorted_cols = False)."""
+        and with them the row-task plan — are those of A.  sort=True re-sorts every row on the device
+        (pk_csr_relabel_sorted: canonical CSR); sort=False only renames (one gather): enough for SpMM, the transpose,
+        the seen-tile builder and the exact-row kernel, none of which needs ordered rows (the result carries
+        sorted_cols = False)."""
         dev = self.device
         if torch.is_tensor(col_map):
-            cm = col_map.to(device=dev, dtype=torch.int64)
+            cm = col_map.to(device=dev, dtype=torch.int32)
         else:
-            cm = torch.as_tensor(np.ascontiguousarray(col_map, dtype=np.int64)).to(dev)
+            cm = torch.as_tensor(np.ascontiguousarray(col_map, dtype=np.int32)).to(dev)
         if not sort:
-            new = A.with_columns(cm[A.indices.long()].to(torch.int32), A.values)
+            new = A.with_columns(cm[A.indices.long()], A.values)
             new.sorted_cols = False
             return new
-        counts = A.indptr[1:] - A.indptr[:-1]
-        rows = torch.repeat_interleave(torch.arange(A.shape[0], dtype=torch.int64, device=dev), counts)
-        key = rows * A.shape[1] + cm[A.indices.long()]
-        key, order = torch.sort(key)
-        cc = (key - rows * A.shape[1]).to(torch.int32)   # rows are unchanged by a within-row permutation
-        return A.with_columns(cc, A.values[order].contiguous())
+        nnz = int(A.indices.numel())
+        idx = torch.empty_like(A.indices)
+        val = torch.empty_like(A.values)
+        work = self._work(self.lib.pk_csr_relabel_work_bytes(nnz))
+        _lib.check(self.lib.pk_csr_relabel_sorted(self.stream(), A.shape[0], A.shape[1], nnz, _ptr(A.indptr), _ptr(A.indices),
+                                                  _ptr(A.values), A.val_kind, _ptr(cm.contiguous()), _ptr(idx), _ptr(val),
+                                                  _ptr(work)), 'pk_csr_relabel_sorted')
+        new = A.with_columns(idx, val)
+        new.sorted_cols = True
+        return new
 
     def csr_from_coo(self, rows, cols, vals, shape, split=SPLIT_NNZ):
-        """COO triplets (host arrays) -> canonical DeviceCSR built ON DEVICE: one radix sort of the
-        64-bit keys row*n_cols+col, duplicates summed (what `coo_matrix(...).tocsr()` does in
-        models.py:172-175).  A host argsort of 1e8 keys would cost more than the whole SVD build."""
+        """COO triplets (host arrays) -> canonical DeviceCSR built ON DEVICE (pk_coo_to_csr: one stable radix sort of
+        the 64-bit keys row * n_cols + col, duplicates summed in their original order — what
+        `coo_matrix(...).tocsr()` does in models.py:172-175).  `rows` / `cols` may be the two columns of one
+        C-contiguous int64 [nnz x 2] array (the `idx` of `to_coo`, data.py:794-817): it is uploaded as it is."""
         n_rows, n_cols = int(shape[0]), int(shape[1])
         dev = self.device
-        r = torch.as_tensor(np.ascontiguousarray(rows, dtype=np.int64)).to(dev)
-        c = torch.as_tensor(np.ascontiguousarray(cols, dtype=np.int64)).to(dev)
+        rows, cols = np.asarray(rows), np.asarray(cols)
+        nnz = int(rows.shape[0])
+        base = rows.base if (rows.base is not None and rows.base is cols.base) else None
+        if (base is not None and isinstance(base, np.ndarray) and base.dtype == np.int64 and base.ndim == 2 and
+                base.shape == (nnz, 2) and base.flags.c_contiguous and rows.strides == (16,) and cols.strides == (16,)
+                and rows.ctypes.data == base.ctypes.data and cols.ctypes.data == base.ctypes.data + 8):
+            both = torch.from_numpy(base).to(dev)
+            r_ptr, c_ptr, stride = _ptr(both), _ptr(both, 1), 2
+        else:
+            both = torch.from_numpy(np.stack([np.asarray(rows, dtype=np.int64), np.asarray(cols, dtype=np.int64)])).to(dev)
+            r_ptr, c_ptr, stride = _ptr(both), _ptr(both, nnz), 1
         v = np.ascontiguousarray(vals)
         if v.dtype == np.float64:
             v32 = v.astype(np.float32)
@@ -240,34 +359,30 @@ class HipOps:
         elif v.dtype != np.float32:
             v = v.astype(np.float64)
         v = torch.from_numpy(v).to(dev)
-        if r.numel():
-            if int(r.min()) < 0 or int(r.max()) >= n_rows or int(c.min()) < 0 or int(c.max()) >= n_cols:
-                raise ValueError('index out of bounds')
-        key = r * n_cols + c
-        key, order = torch.sort(key, stable=True)
-        v = v[order]
-        del r, c, order
-        if key.numel() > 1:
-            first = torch.ones_like(key, dtype=torch.bool)
-            first[1:] = key[1:] != key[:-1]
-            if not bool(first.all()):
-                seg = torch.cumsum(first, 0) - 1
-                out = torch.zeros(int(seg[-1]) + 1, dtype=v.dtype, device=dev)
-                out.index_add_(0, seg, v)   # sums in key order is not needed for exactness of ratings
-                v = out
-                key = key[first]
-        rr = torch.div(key, n_cols, rounding_mode='floor')
-        cc = (key - rr * n_cols).to(torch.int32)
-        indptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=dev)
-        indptr[1:] = torch.cumsum(torch.bincount(rr, minlength=n_rows), 0)
-        return DeviceCSR.from_device(self, indptr, cc, v.contiguous(), (n_rows, n_cols), split)
+        val_kind = _lib.PK_VAL_F32 if v.dtype == torch.float32 else _lib.PK_VAL_F64
+        indptr = torch.empty(n_rows + 1, dtype=torch.int64, device=dev)
+        indices = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
+        values = torch.empty(max(nnz, 1), dtype=v.dtype, device=dev)
+        info = torch.zeros(4, dtype=torch.int64, device=dev)     # [0] = n_unique, [1] (as int32) = error flag
+        work = self._work(self.lib.pk_coo_to_csr_work_bytes(nnz))
+        with self._timed('coo_to_csr', (n_rows, n_cols, nnz)):
+            _lib.check(self.lib.pk_coo_to_csr(self.stream(), nnz, r_ptr, c_ptr, stride, _ptr(v), val_kind, n_rows, n_cols,
+                                              _ptr(indptr), _ptr(indices), _ptr(values), _ptr(info), _ptr(info, 1),
+                                              _ptr(work)), 'pk_coo_to_csr')
+        n_unique, err = (int(x) for x in info[:2].tolist())
+        if err & 0xffffffff:
+            raise ValueError('index out of bounds')
+        new = DeviceCSR.from_device(self, indptr, indices[:n_unique], values[:n_unique], (n_rows, n_cols), split)
+        new._nnz = n_unique
+        return new
 
     def csr_rows(self, A, lo, hi):
         """Row block [lo, hi) of a DeviceCSR (device-side slice; used for user sharding)."""
         p0, p1 = int(A.indptr[lo]), int(A.indptr[hi])
         new = DeviceCSR.from_device(self, (A.indptr[lo:hi + 1] - p0).contiguous(), A.indices[p0:p1].contiguous(),
-                                    A.values[p0:p1].contiguous(), (hi - lo, A.shape[1]))
+                                    A.values[p0:p1].contiguous(), (hi - lo, A.shape[1]), A.split)
         new.sorted_cols = A.sorted_cols
+        new._nnz = p1 - p0
         return new
 
     def randn(self, n, m, seed):
@@ -295,22 +410,27 @@ class HipOps:
             for c0 in range(0, nc, 256):
                 self.spmm(A, X[:, c0:c0 + 256], out=out[:, c0:c0 + 256], rows=rows)
             return out
+        rng = (0, A.n_tasks, 0, A.n_long) if rows is None else A.task_range(int(rows[0]), int(rows[1]))
+        return self._spmm_launch(A, X, out, rng)
+
+    def _spmm_launch(self, A, X, out, rng, row_base=0, accumulate=False, meta_shape=None):
+        """one launch of the row-task kernel over the plan slice `rng` = (first task, tasks, first long row, long rows)"""
+        nc = X.shape[1]
         x_kind = _lib.PK_VAL_F64 if X.dtype == torch.float64 else _lib.PK_VAL_F32
         p = A.plan
-        t0, n_tasks, l0, n_long, nnz = 0, A.n_tasks, 0, A.n_long, A.nnz
+        t0, n_tasks, l0, n_long = rng
         tr, tb, te, ts = p['task_row'], p['task_begin'], p['task_end'], p['task_slot']
         lr, lb, le = p['long_row'], p['long_slot_begin'], p['long_slot_end']
-        if rows is not None:
-            lo, hi = int(rows[0]), int(rows[1])
-            t0, n_tasks = int(A.row_first_task[lo]), int(A.row_first_task[hi] - A.row_first_task[lo])
-            l0, l1 = (int(v) for v in np.searchsorted(A.long_row_host, [lo, hi]))
-            n_long = l1 - l0
-            nnz = None   # not needed by anyone for a partial launch
-        with self._timed('spmm', (A.shape[0], A.shape[1], nnz, nc, A.values.element_size(), X.element_size())):
-            _lib.check(self.lib.pk_spmm_csr_x(
+        meta = None
+        if self.timers is not None:   # (output rows, source rows, nnz, nc, value bytes, dense element bytes) of this launch
+            shp = meta_shape or (A.shape[0], A.shape[1], A.nnz)
+            meta = (shp[0], shp[1], shp[2], nc, A.values.element_size(), X.element_size())
+        with self._timed('spmm', meta):
+            _lib.check(self.lib.pk_spmm_csr_ex(
                 self.stream(), n_tasks, _ptr(tr, t0), _ptr(tb, t0), _ptr(te, t0), _ptr(ts, t0), n_long,
                 _ptr(lr, l0), _ptr(lb, l0), _ptr(le, l0), _ptr(A.indices), _ptr(A.values), A.val_kind,
-                _ptr(X), x_kind, X.stride(0), nc, _ptr(out), out.stride(0), _ptr(A.partial(nc))), 'pk_spmm_csr_x')
+                _ptr(X), x_kind, X.stride(0), nc, _ptr(out), out.stride(0), _ptr(A.partial(nc)), int(row_base),
+                1 if accumulate else 0), 'pk_spmm_csr_ex')
         return out
 
     # ---- K2 ---------------------------------------------------------------------------------
@@ -463,11 +583,19 @@ class HipOps:
         if not rows_sorted:
             max_row = int((seen_ptr[1:n_users + 1] - seen_ptr[:n_users]).max().item()) if n_users else 0
             if max_row > self.lib.pk_seen_tiles_max_unsorted_row():
-                counts = seen_ptr[1:n_users + 1] - seen_ptr[:n_users]
-                rows = torch.repeat_interleave(torch.arange(n_users, dtype=torch.int64, device=self.device), counts)
+                # rows too long for the in-LDS sort of the builder: re-sort them on the device (identity renaming)
                 lo, hi = int(seen_ptr[0]), int(seen_ptr[n_users])
-                key = torch.sort(rows * (1 << 31) + seen_idx[lo:hi].long()).values
-                seen_idx = torch.cat([seen_idx[:lo], (key & ((1 << 31) - 1)).to(torch.int32)])
+                n_cols = int(seen_idx[lo:hi].max().item()) + 1 if hi > lo else 1
+                ident = torch.arange(n_cols, dtype=torch.int32, device=self.device)
+                ptr0 = (seen_ptr[:n_users + 1] - lo).contiguous()
+                idx = seen_idx[lo:hi].contiguous()
+                out_i = torch.empty_like(idx)
+                dummy = torch.zeros(hi - lo, dtype=torch.float32, device=self.device)
+                work = self._work(self.lib.pk_csr_relabel_work_bytes(hi - lo))
+                _lib.check(self.lib.pk_csr_relabel_sorted(self.stream(), n_users, n_cols, hi - lo, _ptr(ptr0), _ptr(idx),
+                                                          _ptr(dummy), _lib.PK_VAL_F32, _ptr(ident), _ptr(out_i),
+                                                          _ptr(torch.empty_like(dummy)), _ptr(work)), 'pk_csr_relabel_sorted')
+                seen_idx = torch.cat([seen_idx[:lo], out_i])
                 rows_sorted = True
         with self._timed('seen_tiles', (n_users, int(seen_idx.numel()))):
             _lib.check(self.lib.pk_seen_tiles_build(self.stream(), n_users, _ptr(seen_ptr), _ptr(seen_idx),

@@ -149,7 +149,8 @@ def svd_topk(ops, A, k, block=None, tol=1e-12, max_outer=200, m_max=24, spread=1
         raise ValueError('k must satisfy 0 < k <= n_items')
     l = int(block or default_block(k, n_items))
     l = max(k, min(l, n_items))
-    At = A.T
+    # the operator of Z = A^T Y: a device matrix offers its user-blocked transpose (ops.BlockedTranspose)
+    At = A.transpose_operator() if hasattr(A, 'transpose_operator') else A.T
 
     X = orthonormalize(ops, ops.randn(n_items, l, seed))
     V_lock = None

@@ -1,0 +1,184 @@
+"""-m gpu: the ingest kernels (csrc/ingest.hip) through the C ABI against NumPy/SciPy: stable radix sort, exclusive
+scan, COO -> CSR with duplicate sums, CSR -> CSC (plain and user-blocked), sorted column renaming, per-item counts, the
+device-built wave-task plan, and the user-blocked transposed product.  Index results must be bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import scipy.sparse as sps
+import torch
+
+from polara_amd import _lib
+from polara_amd.csr import coo_to_csr, csr_transpose, build_row_tasks
+from polara_amd.ops import _ptr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('n', [0, 1, 63, 4096, 4097, 100003, 3_000_000])
+def test_exclusive_scan(hip_ops, n):
+    ops = hip_ops
+    rng = np.random.RandomState(n % 97)
+    a = rng.randint(0, 1000, n).astype(np.int32)
+    d = ops.to_device(a) if n else torch.empty(0, dtype=torch.int32, device=ops.device)
+    out = torch.empty(n + 1, dtype=torch.int64, device=ops.device)
+    work = ops._work(ops.lib.pk_scan_work_bytes(n))
+    _lib.check(ops.lib.pk_exclusive_scan_i32(ops.stream(), n, _ptr(d), _ptr(out), _ptr(work)), 'scan')
+    assert np.array_equal(ops.to_host(out), np.r_[0, np.cumsum(a.astype(np.int64))])
+
+
+@pytest.mark.parametrize('key_bytes,bits,n', [(4, 17, 50001), (4, 32, 300000), (8, 37, 777777), (8, 64, 4099), (4, 3, 70000),
+                                              (8, 9, 1)])
+def test_radix_sort_pairs_is_a_stable_sort(hip_ops, key_bytes, bits, n):
+    ops = hip_ops
+    rng = np.random.RandomState(bits)
+    if bits < 20:
+        keys = rng.randint(0, 1 << bits, n).astype(np.uint64)       # many duplicates: stability matters
+    else:
+        keys = rng.randint(0, 1 << 62, n, dtype=np.int64).astype(np.uint64) & np.uint64((1 << bits) - 1 if bits < 64 else 2 ** 64 - 1)
+    kt = np.uint32 if key_bytes == 4 else np.uint64
+    keys = keys.astype(kt)
+    vals = np.arange(n, dtype=np.uint32)
+    kd = torch.from_numpy(keys.view(np.int32 if key_bytes == 4 else np.int64)).to(ops.device)
+    vd = torch.from_numpy(vals.view(np.int32)).to(ops.device)
+    kt_d, vt_d = torch.empty_like(kd), torch.empty_like(vd)
+    work = ops._work(ops.lib.pk_radix_work_bytes(n))
+    in_tmp = C.c_int32(0)
+    _lib.check(ops.lib.pk_radix_sort_pairs(ops.stream(), n, key_bytes, _ptr(kd), _ptr(vd), _ptr(kt_d), _ptr(vt_d), bits,
+                                           _ptr(work), C.byref(in_tmp)), 'radix')
+    ks = (kt_d if in_tmp.value else kd).cpu().numpy().view(kt)
+    vs = (vt_d if in_tmp.value else vd).cpu().numpy().view(np.uint32)
+    order = np.argsort(keys, kind='stable')
+    assert np.array_equal(ks, keys[order]) and np.array_equal(vs, vals[order])
+
+
+@pytest.mark.parametrize('vdtype', [np.float32, np.float64])
+@pytest.mark.parametrize('interleaved', [False, True])
+def test_coo_to_csr_matches_numpy_and_sums_duplicates(hip_ops, vdtype, interleaved):
+    rng = np.random.RandomState(3)
+    n_rows, n_cols, nnz = 5000, 1300, 400000
+    rows = rng.randint(0, n_rows, nnz)
+    rows[rows % 17 == 3] = 11                                   # a long row; rows 3, 20, ... stay empty
+    cols = (rng.zipf(1.3, nnz) - 1) % n_cols                    # skewed: many duplicates
+    vals = rng.randint(1, 6, nnz).astype(vdtype) if vdtype == np.float32 else rng.randn(nnz)
+    if interleaved:
+        idx = np.ascontiguousarray(np.stack([rows, cols], axis=1).astype(np.int64))
+        A = hip_ops.csr_from_coo(idx[:, 0], idx[:, 1], vals, (n_rows, n_cols))
+    else:
+        A = hip_ops.csr_from_coo(rows.astype(np.int32), cols, vals, (n_rows, n_cols))
+    indptr, indices, values = coo_to_csr(rows, cols, vals.astype(np.float64), (n_rows, n_cols))
+    assert A.nnz == len(indices) < nnz
+    assert np.array_equal(hip_ops.to_host(A.indptr), indptr)
+    assert np.array_equal(hip_ops.to_host(A.indices), indices)
+    got = hip_ops.to_host(A.values).astype(np.float64)
+    if vdtype == np.float32:
+        assert np.array_equal(got, values)                      # small integers: exact in any order
+    else:
+        assert np.allclose(got, values, rtol=1e-13, atol=1e-13)
+    with pytest.raises(ValueError):
+        hip_ops.csr_from_coo(np.r_[rows, n_rows], np.r_[cols, 0], np.r_[vals, vals[:1]], (n_rows, n_cols))
+    E = hip_ops.csr_from_coo(np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0), (7, 5))
+    assert E.nnz == 0 and not hip_ops.to_host(E.indptr).any()
+
+
+def _rand_csr(seed, n_rows, n_cols, mean, vdtype=np.float32):
+    rng = np.random.RandomState(seed)
+    counts = rng.poisson(mean, n_rows).clip(0, n_cols)
+    counts[5] = min(n_cols, 3000)
+    counts[[0, 9, n_rows - 1]] = 0
+    indptr = np.r_[0, np.cumsum(counts)].astype(np.int64)
+    w = 1.0 / np.arange(1, n_cols + 1) ** 0.7
+    indices = np.concatenate([np.sort(rng.choice(n_cols, c, replace=False, p=w / w.sum())) for c in counts]).astype(np.int32)
+    values = rng.randint(1, 6, indptr[-1]).astype(vdtype) if vdtype == np.float32 else rng.randn(indptr[-1])
+    return indptr, indices, values
+
+
+@pytest.mark.parametrize('vdtype', [np.float32, np.float64])
+def test_csr_transpose_plain_and_blocked(hip_ops, vdtype):
+    ops = hip_ops
+    n_rows, n_cols = 9000, 4000
+    indptr, indices, values = _rand_csr(1, n_rows, n_cols, 40, vdtype)
+    A = ops.csr(indptr, indices, values, (n_rows, n_cols))
+    tp, ti, tv = csr_transpose(indptr, indices, values, n_cols)
+    T = A.T
+    assert T.shape == (n_cols, n_rows)
+    assert np.array_equal(ops.to_host(T.indptr), tp) and np.array_equal(ops.to_host(T.indices), ti)
+    assert np.array_equal(ops.to_host(T.values), tv)
+    # blocked image: row b * n_cols + c = column c restricted to rows [b * rpb, (b + 1) * rpb)
+    rpb = 2048
+    Tb = ops.csr_transpose(A, rows_per_block=rpb)
+    n_blocks = -(-n_rows // rpb)
+    assert Tb.shape == (n_blocks * n_cols, n_rows)
+    bp, bi, bv = (ops.to_host(x) for x in (Tb.indptr, Tb.indices, Tb.values))
+    S = sps.csr_matrix((values.astype(np.float64), indices, indptr), shape=(n_rows, n_cols))
+    for b in range(n_blocks):
+        sub = S[b * rpb:(b + 1) * rpb].tocsc()
+        sub.sort_indices()
+        lo, hi = bp[b * n_cols], bp[(b + 1) * n_cols]
+        assert np.array_equal(bp[b * n_cols:(b + 1) * n_cols + 1] - lo, sub.indptr)
+        assert np.array_equal(bi[lo:hi], sub.indices + b * rpb) and np.array_equal(bv[lo:hi].astype(np.float64), sub.data)
+    # the blocked product adds up to the plain one, whatever the block size
+    rng = np.random.RandomState(2)
+    for nc in (64, 51, 130):
+        Y = ops.to_device(rng.randn(n_rows, nc))
+        ref = S.T @ ops.to_host(Y)
+        for rows_per_block in (1024, 4096, 8192):
+            got = ops.to_host(ops.spmm(A.T_blocked(rows_per_block), Y))
+            assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-13
+        out = ops.empty(n_cols, nc + 3)
+        out.fill_(7.0)
+        ops.spmm(A.T_blocked(4096), Y, out=out[:, :nc])          # strided output, overwritten (not accumulated into)
+        assert np.abs(ops.to_host(out)[:, :nc] - ref).max() / np.abs(ref).max() < 1e-13 and float(out[:, nc:].min()) == 7.0
+
+
+def test_sorted_relabel_counts_and_device_plan(hip_ops):
+    ops = hip_ops
+    n_rows, n_cols = 7000, 2500
+    indptr, indices, values = _rand_csr(4, n_rows, n_cols, 30)
+    A = ops.csr(indptr, indices, values, (n_rows, n_cols), split=256)
+    # per-item counts
+    assert np.array_equal(ops.item_counts(A), np.bincount(indices, minlength=n_cols))
+    # renaming with re-sorted rows
+    perm = np.random.RandomState(5).permutation(n_cols).astype(np.int32)
+    B = ops.csr_relabel_cols(A, perm)
+    S = sps.csr_matrix((values.astype(np.float64), perm[indices], indptr), shape=(n_rows, n_cols))
+    S.sort_indices()
+    assert np.array_equal(ops.to_host(B.indices), S.indices) and np.array_equal(ops.to_host(B.values).astype(np.float64), S.data)
+    assert B.sorted_cols and np.array_equal(ops.to_host(B.indptr), indptr)
+    # the device-built plan equals the host restatement, array by array
+    want = build_row_tasks(indptr, 256)
+    assert (A.n_tasks, A.n_long, A.n_slots) == (len(want['task_row']), len(want['long_row']), want['n_slots'])
+    for k in ('task_row', 'task_begin', 'task_end', 'task_slot', 'long_row', 'long_slot_begin', 'long_slot_end'):
+        assert np.array_equal(ops.to_host(A.plan[k])[:len(want[k])], want[k]), k
+    t0, nt, l0, nl = A.task_range(3, 4000)
+    assert t0 == want['row_first_task'][3] and nt == want['row_first_task'][4000] - want['row_first_task'][3]
+    assert (l0, nl) == tuple(int(x) for x in (np.searchsorted(want['long_row'], 3),
+                                              np.searchsorted(want['long_row'], 4000) - np.searchsorted(want['long_row'], 3)))
+    # a row range as its own launch still computes those rows
+    X = ops.to_device(np.random.RandomState(6).randn(n_cols, 20))
+    full = ops.spmm(A, X)
+    part = torch.zeros_like(full)
+    ops.spmm(A, X, out=part, rows=(3, 4000))
+    assert torch.equal(part[3:4000], full[3:4000]) and float(part[4000:].abs().sum()) == 0.0
+
+
+def test_unsorted_long_rows_get_sorted_for_the_seen_tiles(hip_ops):
+    """rows longer than the in-LDS sort of the seen-tile builder after a bare renaming: re-sorted by the own kernels"""
+    ops = hip_ops
+    n_rows, n_cols = 40, 60000
+    rng = np.random.RandomState(8)
+    counts = np.full(n_rows, 50)
+    counts[7] = ops.lib.pk_seen_tiles_max_unsorted_row() + 500
+    indptr = np.r_[0, np.cumsum(counts)].astype(np.int64)
+    indices = np.concatenate([np.sort(rng.choice(n_cols, c, replace=False)) for c in counts]).astype(np.int32)
+    A = ops.csr(indptr, indices, np.ones(indptr[-1], np.float32), (n_rows, n_cols))
+    perm = rng.permutation(n_cols).astype(np.int32)
+    B = ops.csr_relabel_cols(A, perm, sort=False)
+    tiles, ntiles = B.seen_tiles()
+    C_ = ops.csr_relabel_cols(A, perm, sort=True)
+    tiles2, ntiles2 = C_.seen_tiles()
+    assert torch.equal(ntiles, ntiles2)
+    nt = ops.to_host(ntiles)
+    t1, t2 = ops.to_host(tiles), ops.to_host(tiles2)
+    for r in range(n_rows):
+        assert np.array_equal(t1[indptr[r]:indptr[r] + nt[r]], t2[indptr[r]:indptr[r] + nt[r]])
