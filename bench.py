@@ -187,7 +187,7 @@ class Bench:
         if comm.world > 1:
             counts = ops.to_host(comm.allreduce(ops.to_device(counts)))
         rank_of, inv_order = popularity_order(None, n_items, counts=counts)
-        A = ops.csr_relabel_cols(A, rank_of, sort=False)
+        A = ops.csr_relabel_cols(A, rank_of)     # rows re-sorted (pk_csr_relabel_sorted): ascending gathers in every SpMM
         lap('relabel_popularity_s')
         A.transpose_operator()          # CSC image (user-blocked), built on the device (pk_csr_transpose)
         _ = A.plan
@@ -207,7 +207,7 @@ class Bench:
             rank2 = torch.empty_like(order2)
             rank2[order2] = torch.arange(n_items, device=order2.device)
             V = V[order2].contiguous()
-            A_score = ops.csr_relabel_cols(A, rank2, sort=False)   # renaming only: nothing downstream needs ordered rows
+            A_score = ops.csr_relabel_cols(A, rank2, sort=os.environ.get('PK_BENCH_SORT_SERVING', '1') == '1')
         F = scoring.FactorImage(ops, V)
         A_score.seen_tiles()
         lap('reindex_and_images_s')

@@ -27,13 +27,13 @@ __device__ __forceinline__ double pk_bcast_val<double>(double a, int t) {
     return __hiloint2double(hi, lo);
 }
 
-template <typename VT, int CPL>
+// ACC = true: the launch is one row block of a larger plan (output row = task_row - row_base) and ADDS to out
+template <typename VT, int CPL, bool ACC>
 __global__ __launch_bounds__(256) void spmm_csr_kernel(
     int64_t n_tasks, const int32_t *__restrict__ task_row, const int64_t *__restrict__ task_begin,
     const int64_t *__restrict__ task_end, const int32_t *__restrict__ task_slot,
     const int32_t *__restrict__ indices, const VT *__restrict__ vals, const double *__restrict__ X,
-    int64_t ldx, int nc, double *__restrict__ out, int64_t ldo, double *__restrict__ partial, int64_t row_base,
-    int accumulate) {
+    int64_t ldx, int nc, double *__restrict__ out, int64_t ldo, double *__restrict__ partial, int64_t row_base) {
     const int lane = threadIdx.x & 63;
     // wave id made provably uniform so the task descriptors live in SGPRs
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -41,7 +41,9 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(
     if (task >= n_tasks) return;
     const int64_t p0 = task_begin[task];
     const int64_t p1 = task_end[task];
-    if (accumulate && p0 == p1 && task_slot[task] < 0) return;   // nothing to add
+    if constexpr (ACC) {
+        if (p0 == p1 && task_slot[task] < 0) return;   // nothing to add
+    }
 
     int col[CPL];
     double acc[CPL];
@@ -106,8 +108,8 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(
     }
 
     const int slot = task_slot[task];
-    double *dst = slot < 0 ? out + ((int64_t)task_row[task] - row_base) * ldo : partial + (int64_t)slot * nc;
-    const bool add = accumulate && slot < 0;
+    double *dst = slot < 0 ? out + ((int64_t)task_row[task] - (ACC ? row_base : 0)) * ldo : partial + (int64_t)slot * nc;
+    const bool add = ACC && slot < 0;
 #pragma unroll
     for (int g = 0; g < CPL; ++g) {
         int c = lane + 64 * g;
@@ -131,13 +133,12 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(
 // XT = float: the dense block is read in fp32 (the fp32 image of the item factors for the approximate fold-in
 // of the scoring pass, scoring.py); a lane's four columns are then consecutive (4l .. 4l+3) and arrive with
 // ONE 16-byte load.  Accumulation and output stay fp64.
-template <typename VT, int GROUPS, typename XT>
+template <typename VT, int GROUPS, typename XT, bool ACC>
 __global__ __launch_bounds__(256) void spmm_csr_groups_kernel(
     int64_t n_tasks, const int32_t *__restrict__ task_row, const int64_t *__restrict__ task_begin,
     const int64_t *__restrict__ task_end, const int32_t *__restrict__ task_slot,
     const int32_t *__restrict__ indices, const VT *__restrict__ vals, const XT *__restrict__ X,
-    int64_t ldx, int nc, double *__restrict__ out, int64_t ldo, double *__restrict__ partial, int64_t row_base,
-    int accumulate) {
+    int64_t ldx, int nc, double *__restrict__ out, int64_t ldo, double *__restrict__ partial, int64_t row_base) {
     constexpr bool XF = sizeof(XT) == 4;
     constexpr int LG = 64 / GROUPS;
     // wave steps per register set (two sets in flight); an fp32 row piece is one float4 per lane and step
@@ -151,7 +152,9 @@ __global__ __launch_bounds__(256) void spmm_csr_groups_kernel(
     if (task >= n_tasks) return;
     const int64_t p0 = task_begin[task];
     const int n = (int)(task_end[task] - p0);
-    if (accumulate && n == 0 && task_slot[task] < 0) return;   // nothing to add
+    if constexpr (ACC) {
+        if (n == 0 && task_slot[task] < 0) return;   // nothing to add
+    }
     const int g = lane / LG, l = lane % LG;
     // columns (c0, c0+1) and (c1, c1+1) of this lane; nc is even (a multiple of 4 for fp32 X): a pair is in or
     // out as a whole
@@ -250,9 +253,9 @@ __global__ __launch_bounds__(256) void spmm_csr_groups_kernel(
         acc1.x += pk_lane_xor<32>(acc1.x); acc1.y += pk_lane_xor<32>(acc1.y);
     }
     const int slot = task_slot[task];
-    double *dst = slot < 0 ? out + ((int64_t)task_row[task] - row_base) * ldo : partial + (int64_t)slot * nc;
+    double *dst = slot < 0 ? out + ((int64_t)task_row[task] - (ACC ? row_base : 0)) * ldo : partial + (int64_t)slot * nc;
     if (g == 0) {
-        if (accumulate && slot < 0) {
+        if (ACC && slot < 0) {
             if (ok0) {
                 acc0.x += dst[c0];
                 acc0.y += dst[c0 + 1];
@@ -303,9 +306,15 @@ static int launch_spmm(hipStream_t st, int64_t n_tasks, const int32_t *task_row,
             pk_set_error("pk_spmm_csr_x: an fp32 dense block needs nc %% 4 == 0, ldx %% 4 == 0 and 16-byte alignment");
             return PK_E_UNSUPPORTED;
         }
-#define PK_SPMM_GROUPS_F(G)                                                                                     \
-    hipLaunchKernelGGL((spmm_csr_groups_kernel<VT, G, float>), grid, block, 0, st, n_tasks, task_row, task_begin, \
-                       task_end, task_slot, indices, v, X, ldx, nc, out, ldo, partial, row_base, accumulate)
+#define PK_SPMM_GROUPS_F(G)                                                                                          \
+    do {                                                                                                             \
+        if (accumulate)                                                                                              \
+            hipLaunchKernelGGL((spmm_csr_groups_kernel<VT, G, float, true>), grid, block, 0, st, n_tasks, task_row,  \
+                               task_begin, task_end, task_slot, indices, v, X, ldx, nc, out, ldo, partial, row_base); \
+        else                                                                                                         \
+            hipLaunchKernelGGL((spmm_csr_groups_kernel<VT, G, float, false>), grid, block, 0, st, n_tasks, task_row, \
+                               task_begin, task_end, task_slot, indices, v, X, ldx, nc, out, ldo, partial, row_base); \
+    } while (0)
         if (nc <= 64) PK_SPMM_GROUPS_F(4);
         else if (nc <= 128) PK_SPMM_GROUPS_F(2);
         else PK_SPMM_GROUPS_F(1);
@@ -315,9 +324,15 @@ static int launch_spmm(hipStream_t st, int64_t n_tasks, const int32_t *task_row,
     const double *X = static_cast<const double *>(Xv);
     const bool paired = (nc % 2 == 0) && (ldx % 2 == 0) && (((uintptr_t)X) % 16 == 0) && !getenv("PK_SPMM_LANE_COLUMNS");
     if (paired) {
-#define PK_SPMM_GROUPS(G)                                                                                  \
-    hipLaunchKernelGGL((spmm_csr_groups_kernel<VT, G, double>), grid, block, 0, st, n_tasks, task_row, task_begin,  \
-                       task_end, task_slot, indices, v, X, ldx, nc, out, ldo, partial, row_base, accumulate)
+#define PK_SPMM_GROUPS(G)                                                                                             \
+    do {                                                                                                              \
+        if (accumulate)                                                                                               \
+            hipLaunchKernelGGL((spmm_csr_groups_kernel<VT, G, double, true>), grid, block, 0, st, n_tasks, task_row,  \
+                               task_begin, task_end, task_slot, indices, v, X, ldx, nc, out, ldo, partial, row_base); \
+        else                                                                                                          \
+            hipLaunchKernelGGL((spmm_csr_groups_kernel<VT, G, double, false>), grid, block, 0, st, n_tasks, task_row, \
+                               task_begin, task_end, task_slot, indices, v, X, ldx, nc, out, ldo, partial, row_base); \
+    } while (0)
         if (nc <= 64) PK_SPMM_GROUPS(4);
         else if (nc <= 128) PK_SPMM_GROUPS(2);
         else PK_SPMM_GROUPS(1);
@@ -325,10 +340,14 @@ static int launch_spmm(hipStream_t st, int64_t n_tasks, const int32_t *task_row,
         return PK_OK;
     }
     const int cpl = (nc + 63) / 64;
-#define PK_SPMM_CASE(C)                                                                              \
-    case C:                                                                                          \
-        hipLaunchKernelGGL((spmm_csr_kernel<VT, C>), grid, block, 0, st, n_tasks, task_row, task_begin, \
-                           task_end, task_slot, indices, v, X, ldx, nc, out, ldo, partial, row_base, accumulate);          \
+#define PK_SPMM_CASE(C)                                                                                            \
+    case C:                                                                                                        \
+        if (accumulate)                                                                                            \
+            hipLaunchKernelGGL((spmm_csr_kernel<VT, C, true>), grid, block, 0, st, n_tasks, task_row, task_begin,  \
+                               task_end, task_slot, indices, v, X, ldx, nc, out, ldo, partial, row_base);          \
+        else                                                                                                       \
+            hipLaunchKernelGGL((spmm_csr_kernel<VT, C, false>), grid, block, 0, st, n_tasks, task_row, task_begin, \
+                               task_end, task_slot, indices, v, X, ldx, nc, out, ldo, partial, row_base);          \
         break;
     switch (cpl) {
         PK_SPMM_CASE(1)
@@ -355,7 +374,7 @@ extern "C" int pk_spmm_csr_ex(void *stream, int64_t n_tasks, const int32_t *task
     PK_REQUIRE(ldo >= nc && ldx >= nc, "pk_spmm_csr: ldo/ldx < nc");
     PK_REQUIRE(x_kind == PK_VAL_F32 || x_kind == PK_VAL_F64, "pk_spmm_csr_x: bad x_kind %d", x_kind);
     PK_REQUIRE(n_long == 0 || partial_dev != nullptr, "pk_spmm_csr: partial buffer required");
-    PK_REQUIRE(row_base >= 0, "pk_spmm_csr_ex: negative row_base");
+    PK_REQUIRE(row_base >= 0 && (accumulate || row_base == 0), "pk_spmm_csr_ex: a row base needs accumulate (block 0 has base 0)");
     if (n_tasks == 0) return PK_OK;
     hipStream_t st = pk_stream(stream);
     int rc;

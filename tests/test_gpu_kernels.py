@@ -608,7 +608,11 @@ def test_errors_are_loud(hip_ops):
     from polara_amd._lib import PolaraHipError
     with pytest.raises(PolaraHipError):
         hip_ops.eigh_psd(hip_ops.zeros(2000, 2000))
-    X = hip_ops.zeros(10, 300)
+    import torch
     A = hip_ops.csr(np.array([0, 1], dtype=np.int64), np.array([0], dtype=np.int32), np.array([1.0]), (1, 10))
+    X32 = torch.zeros(10, 6, dtype=torch.float32, device=hip_ops.device)
     with pytest.raises(PolaraHipError):
-        hip_ops.spmm(A, X)   # nc > 256
+        hip_ops.spmm(A, X32)   # an fp32 dense block needs nc % 4 == 0
+    # more than 256 columns go panel by panel (ops.spmm), not to an error
+    X = hip_ops.to_device(np.arange(3000, dtype=np.float64).reshape(10, 300))
+    assert np.array_equal(hip_ops.to_host(hip_ops.spmm(A, X))[0], np.arange(300, dtype=np.float64))
