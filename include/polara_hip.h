@@ -309,6 +309,23 @@ int pk_score_exact_rows_f64(void *stream, int32_t n_rows, const int32_t *rows_de
  * recommendation array, 0 if absent.  Every hit/rank metric is a reduction of this holdout-sized vector. */
 int pk_eval_ranks(void *stream, int64_t n_holdout, const int64_t *recs_dev, int32_t topk,
                   const int64_t *hold_row_dev, const int64_t *hold_item_dev, int32_t *rank_out_dev);
+/* evaluate() on the device (models.py:408-485; formulas of recommender/evaluation.py:90-253).  One row of 16 doubles
+ * per test user: tp, fp, tn, fn (evaluation.py:176-205), precision, recall, fallout, specifity, miss_rate (:208-236),
+ * arhr, mrr (:108-118), map (:120-133), ndcg, ndcl (:136-173), valid recommendations, holdout items.
+ * recs: [n_users x ld] int64 (negative = padding); the holdout is CSR-like over the SAME user rows (hold_ptr int64
+ * [n_users + 1], items in the id space of recs, hold_rel = feedback or NULL (= ones: ignore_feedback), hold_pos =
+ * feedback >= switch_positive per entry or NULL (no positive/negative split)).  pk_eval_reduce adds the columns up
+ * in a fixed order (work >= pk_eval_reduce_work_bytes); the means are sums / n_users. */
+int32_t pk_eval_cols(void);
+int pk_eval_user_metrics(void *stream, int64_t n_users, int32_t topk, const int64_t *recs_dev, int64_t ld,
+                         const int64_t *hold_ptr_dev, const int64_t *hold_item_dev, const double *hold_rel_dev,
+                         const unsigned char *hold_pos_dev, double not_rated_penalty, double switch_positive,
+                         int32_t alternative, double *out_dev);
+int64_t pk_eval_reduce_work_bytes(int64_t n_users);
+int pk_eval_reduce(void *stream, int64_t n_users, const double *table_dev, double *sums_dev, void *work_dev);
+/* coverage (evaluation.py:239-242): count_dev[0] = number of distinct ids in [0, n_bins); flags_dev int32[n_bins] scratch */
+int pk_unique_count_i64(void *stream, int64_t n, const int64_t *ids_dev, int64_t n_bins, int32_t *flags_dev,
+                        int64_t *count_dev);
 /* Dense fp64 score rows (kept for `slice_recommendations`/`_user_scores`, models.py:277-291):
  * out[r, :] = E[r, :] V^T for r in [0, n_rows). */
 int pk_dense_scores_f64(void *stream, int32_t n_rows, int64_t n_items, int32_t K, const double *V_dev,

@@ -73,6 +73,11 @@ PROTOTYPES = {
     'pk_score_exact_rows_f64': (C.c_int, [_vp, _i32, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _i32,
                                           _vp, _vp, _vp]),
     'pk_eval_ranks': (C.c_int, [_vp, _i64, _vp, _i32, _vp, _vp, _vp]),
+    'pk_eval_cols': (_i32, []),
+    'pk_eval_user_metrics': (C.c_int, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _f64, _f64, _i32, _vp]),
+    'pk_eval_reduce_work_bytes': (_i64, [_i64]),
+    'pk_eval_reduce': (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
+    'pk_unique_count_i64': (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp]),
     'pk_dense_scores_f64': (C.c_int, [_vp, _i32, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _i64]),
     'pk_ttm_f64': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp,
                              _vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _vp]),

@@ -204,9 +204,41 @@ def get_experience_scores(recommendations, n_items):
     return Experience(len(np.unique(recommendations)) / n_items)
 
 
+# columns of the per-user table of pk_eval_user_metrics (csrc/evalmetrics.hip)
+_EV = dict(tp=0, fp=1, tn=2, fn=3, precision=4, recall=5, fallout=6, specifity=7, miss_rate=8, arhr=9, mrr=10, map=11,
+           ndcg=12, ndcl=13, n_recs=14, n_hold=15)
+
+
+def _from_device_sums(device_sums, metric_type, n_items, split, single):
+    """The namedtuples of `evaluate` from the sums that left the device: device_sums = (sums float64[16], n_users,
+    n_unique_items) — see HipOps.eval_metrics.  Every mean is sum / n_users."""
+    sums, n_users, n_unique = device_sums
+    g = lambda name: float(sums[_EV[name]])
+    mean = lambda name: g(name) / n_users
+    scores = []
+    if 'relevance' in metric_type:
+        if single:
+            scores.append(RelevanceHR(mean('tp')))
+        else:
+            scores.append(Relevance(mean('precision'), mean('recall'), mean('fallout') if split else None,
+                                    mean('specifity') if split else None, mean('miss_rate')))
+    if 'ranking' in metric_type:
+        if single:
+            scores.append(RankingRR(mean('arhr'), mean('mrr')))
+        else:
+            scores.append(Ranking(mean('ndcg'), mean('ndcl') if split else None, mean('map'), mean('arhr')))
+    if 'experience' in metric_type:
+        scores.append(Experience(n_unique / n_items))
+    if 'hits' in metric_type:
+        scores.append(Hits(g('tp'), g('fp'), g('tn') if split else None, g('fn')))
+    if not scores:
+        raise NotImplementedError
+    return scores[0] if len(scores) == 1 else scores
+
+
 def evaluate(recommendations, holdout_user, holdout_item, holdout_fdbk, n_items, metric_type='all', topk=None,
              not_rated_penalty=None, switch_positive=None, ignore_feedback=False, simple_rates=False,
-             holdout_size=None, ndcg_alternative=True, device_ranks=None):
+             holdout_size=None, ndcg_alternative=True, device_ranks=None, device_sums=None):
     """models.py:408-485 on arrays.  Returns the same namedtuples in the same order (relevance, ranking,
     experience, hits — whatever the order of `metric_type`); a single family returns the tuple itself."""
     if metric_type == 'all':
@@ -215,6 +247,9 @@ def evaluate(recommendations, holdout_user, holdout_item, holdout_fdbk, n_items,
         metric_type = ['relevance', 'ranking']
     if not isinstance(metric_type, (list, tuple)):
         metric_type = [metric_type]
+    if device_sums is not None:
+        return _from_device_sums(device_sums, metric_type, n_items, switch_positive is not None and holdout_fdbk is not None,
+                                 (holdout_size == 1) or simple_rates)
     if device_ranks is not None:
         # device_ranks = (ranks [n_holdout], n_valid_recs [n_users], (n_users, topk), n_unique_items): everything
         # the metrics need from a recommendation array that stayed on the device

@@ -487,23 +487,35 @@ class RecommenderModel:
         order = np.argsort(users, kind='stable')     # rows of `recommendations` follow the sorted test users
         users, items = np.asarray(users)[order], np.asarray(items)[order]
         n_items = self.data.get_test_shape(tensor_mode=False)[1]
-        device_ranks = None
+        device_sums = None
         cached = getattr(self, '_recs_dev', None)
+        fb = None if fdbk is None else np.asarray(fdbk, dtype=np.float64)[order]
+        sp = switch_positive or self.switch_positive
         if cached is not None and cached[0] is full and self._item_rank is not None:
-            # hit ranks straight from the device-resident list (pk_eval_ranks): only holdout-sized vectors and
-            # two counts per user leave the device
+            # every metric is a reduction over the device-resident list (pk_eval_user_metrics + pk_eval_reduce): the
+            # holdout goes up (a few items per user), 16 sums and one count come back
             import torch
             ops = self.ops
-            rd = cached[1][:, :topk].contiguous() if topk else cached[1]
+            rd = cached[1]
+            k_eff = int(topk) if topk else int(rd.shape[1])
             row = np.r_[0, np.cumsum(np.diff(users) != 0)] if len(users) else np.zeros(0, np.int64)
-            ranks = ops.to_host(ops.eval_ranks(rd, ops.to_device(row.astype(np.int64)),
-                                               ops.to_device(self._item_rank[items.astype(np.intp)].astype(np.int64))))
-            device_ranks = (ranks, ops.to_host((rd >= 0).sum(dim=1)), tuple(rd.shape), int(torch.unique(rd).numel()))
-        return evaluation.evaluate(recs, users, items,
-                                   None if fdbk is None else np.asarray(fdbk)[order], n_items,
-                                   device_ranks=device_ranks,
+            if len(users) and row[-1] + 1 != rd.shape[0]:
+                raise ValueError('recommendations have %d rows, the holdout %d users' % (rd.shape[0], row[-1] + 1))
+            hold_ptr = np.r_[0, np.cumsum(np.bincount(row, minlength=rd.shape[0]))].astype(np.int64)
+            split = sp is not None and fb is not None
+            penalty = (1 if not_rated_penalty is None else not_rated_penalty) if not split else (not_rated_penalty or 0)
+            sums = ops.eval_metrics(rd, k_eff, torch.from_numpy(hold_ptr),
+                                    torch.from_numpy(self._item_rank[items.astype(np.intp)].astype(np.int64)),
+                                    None if (ignore_feedback or fb is None) else torch.from_numpy(fb),
+                                    torch.from_numpy((fb >= sp).astype(np.uint8)) if split else None,
+                                    not_rated_penalty=penalty, switch_positive=sp if split else 0.0,
+                                    alternative=get_default('ndcg_alternative'))
+            n_unique = ops.unique_count(rd[:, :k_eff] if k_eff < rd.shape[1] else rd, n_items)
+            device_sums = (sums, int(rd.shape[0]), n_unique)
+        return evaluation.evaluate(recs, users, items, fb, n_items,
+                                   device_sums=device_sums,
                                    metric_type=metric_type, not_rated_penalty=not_rated_penalty,
-                                   switch_positive=switch_positive or self.switch_positive,
+                                   switch_positive=sp,
                                    ignore_feedback=ignore_feedback, simple_rates=simple_rates,
                                    holdout_size=self.data.holdout_size,
                                    ndcg_alternative=get_default('ndcg_alternative'))

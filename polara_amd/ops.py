@@ -703,6 +703,38 @@ class HipOps:
                                           _ptr(out)), 'pk_eval_ranks')
         return out
 
+    def eval_metrics(self, recs, topk, hold_ptr, hold_item, hold_rel=None, hold_pos=None, not_rated_penalty=0.0,
+                     switch_positive=0.0, alternative=True):
+        """float64 [16] (host): sums over the test users of the per-user metric table of pk_eval_user_metrics — tp, fp,
+        tn, fn, precision, recall, fallout, specifity, miss_rate, arhr, mrr, map, ndcg, ndcl, valid recs, holdout
+        items — from the device-resident recommendation array `recs` [n_users x >= topk] and the holdout (CSR-like
+        over the same rows; items in the id space of recs).  Only these 16 numbers leave the device."""
+        assert recs.dtype == torch.int64 and recs.stride(1) == 1
+        n_users = recs.shape[0]
+        dev = self.device
+        hp = hold_ptr.to(device=dev, dtype=torch.int64).contiguous()
+        hi = hold_item.to(device=dev, dtype=torch.int64).contiguous()
+        hr = None if hold_rel is None else hold_rel.to(device=dev, dtype=torch.float64).contiguous()
+        hpos = None if hold_pos is None else hold_pos.to(device=dev, dtype=torch.uint8).contiguous()
+        table = torch.empty(n_users, self.lib.pk_eval_cols(), dtype=torch.float64, device=dev)
+        _lib.check(self.lib.pk_eval_user_metrics(self.stream(), n_users, int(topk), _ptr(recs), recs.stride(0), _ptr(hp),
+                                                 _ptr(hi), _ptr(hr), _ptr(hpos), float(not_rated_penalty),
+                                                 float(switch_positive), 1 if alternative else 0, _ptr(table)),
+                   'pk_eval_user_metrics')
+        sums = torch.empty(16, dtype=torch.float64, device=dev)
+        work = self._work(self.lib.pk_eval_reduce_work_bytes(n_users))
+        _lib.check(self.lib.pk_eval_reduce(self.stream(), n_users, _ptr(table), _ptr(sums), _ptr(work)), 'pk_eval_reduce')
+        return sums.cpu().numpy()
+
+    def unique_count(self, ids, n_bins):
+        """number of distinct values in [0, n_bins) of an int64 device tensor (coverage, evaluation.py:239-242)"""
+        ids = ids.contiguous()
+        flags = torch.empty(n_bins, dtype=torch.int32, device=self.device)
+        cnt = torch.empty(1, dtype=torch.int64, device=self.device)
+        _lib.check(self.lib.pk_unique_count_i64(self.stream(), ids.numel(), _ptr(ids), int(n_bins), _ptr(flags), _ptr(cnt)),
+                   'pk_unique_count_i64')
+        return int(cnt.item())
+
     def dense_scores(self, V, E):
         n_rows, K = E.shape
         n_items = V.shape[0]

@@ -286,5 +286,34 @@ class NumpyOps:
         match = r[hr] == hi[:, None]
         return torch.from_numpy(np.where(match.any(1), match.argmax(1) + 1, 0).astype(np.int32))
 
+    def eval_metrics(self, recs, topk, hold_ptr, hold_item, hold_rel=None, hold_pos=None, not_rated_penalty=0.0,
+                     switch_positive=0.0, alternative=True):
+        """test double of HipOps.eval_metrics: the same 16 sums through the host formulas (polara_amd.evaluation)"""
+        from polara_amd import evaluation as ev
+        r = recs.numpy()[:, :topk]
+        ptr = hold_ptr.numpy()
+        users = np.repeat(np.arange(len(ptr) - 1), np.diff(ptr))
+        rel = None if hold_rel is None else hold_rel.numpy()
+        pos = None if hold_pos is None else hold_pos.numpy().astype(bool)
+        m = ev._Matched(r, users, hold_item.numpy(), rel, pos)
+        tp, fp, tn, fn = ev._relevance_counts(m, not_rated_penalty, per_key=True)
+        rs = ev.get_relevance_scores(m, not_rated_penalty)
+        n = m.n_users
+        out = np.zeros(16)
+        out[0], out[1], out[3] = tp.sum(), np.sum(fp), fn.sum()
+        out[2] = 0.0 if tn is None else tn.sum()
+        out[4], out[5], out[8] = rs.precision * n, rs.recall * n, rs.miss_rate * n
+        out[6] = 0.0 if rs.fallout is None else rs.fallout * n
+        out[7] = 0.0 if rs.specifity is None else rs.specifity * n
+        out[9], out[10] = ev.get_arhr_score(m) * n, ev.get_mrr_score(m) * n
+        rk = ev.get_ranking_scores(m, m.topk, switch_positive if pos is not None else None, alternative)
+        out[11], out[12] = rk.map * n, rk.ndcg * n
+        out[13] = 0.0 if rk.ndcl is None else rk.ndcl * n
+        out[14], out[15] = m.n_valid_recs.sum(), len(users)
+        return out
+
+    def unique_count(self, ids, n_bins):
+        return int(len(np.unique(ids.numpy())))
+
     def dense_scores(self, V, E):
         return E @ V.t()
