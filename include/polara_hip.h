@@ -323,7 +323,8 @@ int pk_eval_user_metrics(void *stream, int64_t n_users, int32_t topk, const int6
                          int32_t alternative, double *out_dev);
 int64_t pk_eval_reduce_work_bytes(int64_t n_users);
 int pk_eval_reduce(void *stream, int64_t n_users, const double *table_dev, double *sums_dev, void *work_dev);
-/* coverage (evaluation.py:239-242): count_dev[0] = number of distinct ids in [0, n_bins); flags_dev int32[n_bins] scratch */
+/* coverage (evaluation.py:239-242): count_dev[0] = number of distinct ids in [0, n_bins) (+1 when any id is negative: np.unique
+ * counts the padding constant too); flags_dev int32[n_bins + 1] scratch */
 int pk_unique_count_i64(void *stream, int64_t n, const int64_t *ids_dev, int64_t n_bins, int32_t *flags_dev,
                         int64_t *count_dev);
 /* Dense fp64 score rows (kept for `slice_recommendations`/`_user_scores`, models.py:277-291):

@@ -40,11 +40,14 @@ __global__ __launch_bounds__(256) void eval_user_metrics_kernel(
                 rank = t + 1;
                 break;
             }
-        // position of this entry when the user's holdout is ordered by descending relevance (ties: by position)
+        // position of this entry in `np.argsort(relevance)[::-1]` (evaluation.py:147): descending relevance, equal
+        // values in REVERSED holdout order (numpy sorts the few items of a user with a stable insertion sort, then the
+        // list is reversed).  The tie rule only matters when a tie spans the positive / negative split, i.e. with
+        // ignore_feedback (all relevances 1).
         int ideal = 0;
         for (int64_t f = h0; f < h1; ++f) {
             const double rf = hold_rel ? hold_rel[f] : 1.0;
-            ideal += (rf > rel) || (rf == rel && f < e);
+            ideal += (rf > rel) || (rf == rel && f > e);
         }
         const double disc = rank > 0 ? 1.0 / log2(1.0 + (double)rank) : 0.0;
         const double ideal_disc = 1.0 / log2(2.0 + (double)ideal);
@@ -178,6 +181,7 @@ __global__ __launch_bounds__(256) void mark_ids_kernel(int64_t n, const int64_t 
     if (i >= n) return;
     const int64_t id = ids[i];
     if (id >= 0 && id < n_bins) flags[id] = 1;      // every writer stores the same value
+    else if (id < 0) flags[n_bins] = 1;             // the padding constant of short lists is one more "item" to np.unique
 }
 
 __global__ __launch_bounds__(256) void count_flags_kernel(int64_t n, const int32_t *__restrict__ flags,
@@ -188,16 +192,17 @@ __global__ __launch_bounds__(256) void count_flags_kernel(int64_t n, const int32
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (unsigned long long)__popcll(m));   // integer adds: order-free
 }
 
-/* count_dev[0] (int64) = number of distinct values of ids in [0, n_bins); flags_dev: int32[n_bins] scratch */
+/* count_dev[0] (int64) = number of distinct values of ids in [0, n_bins), plus one when any id is negative (the reference's
+ * `len(np.unique(recommendations))` counts the padding constant of short lists too); flags_dev: int32[n_bins + 1] scratch */
 extern "C" int pk_unique_count_i64(void *stream, int64_t n, const int64_t *ids_dev, int64_t n_bins, int32_t *flags_dev,
                                    int64_t *count_dev) {
     PK_REQUIRE(n >= 0 && n_bins >= 1 && flags_dev && count_dev && (n == 0 || ids_dev), "pk_unique_count_i64: bad arguments");
     hipStream_t st = pk_stream(stream);
-    (void)hipMemsetAsync(flags_dev, 0, n_bins * 4, st);
+    (void)hipMemsetAsync(flags_dev, 0, (n_bins + 1) * 4, st);
     (void)hipMemsetAsync(count_dev, 0, 8, st);
     if (n > 0)
         hipLaunchKernelGGL(mark_ids_kernel, dim3((unsigned)pk_ceil_div(n, 256)), dim3(256), 0, st, n, ids_dev, n_bins, flags_dev);
-    hipLaunchKernelGGL(count_flags_kernel, dim3((unsigned)pk_ceil_div(n_bins, 256)), dim3(256), 0, st, n_bins, flags_dev,
+    hipLaunchKernelGGL(count_flags_kernel, dim3((unsigned)pk_ceil_div(n_bins + 1, 256)), dim3(256), 0, st, n_bins + 1, flags_dev,
                        reinterpret_cast<unsigned long long *>(count_dev));
     PK_CHECK_LAUNCH("unique_count kernels");
     return PK_OK;

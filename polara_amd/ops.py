@@ -729,7 +729,7 @@ class HipOps:
     def unique_count(self, ids, n_bins):
         """number of distinct values in [0, n_bins) of an int64 device tensor (coverage, evaluation.py:239-242)"""
         ids = ids.contiguous()
-        flags = torch.empty(n_bins, dtype=torch.int32, device=self.device)
+        flags = torch.empty(n_bins + 1, dtype=torch.int32, device=self.device)
         cnt = torch.empty(1, dtype=torch.int64, device=self.device)
         _lib.check(self.lib.pk_unique_count_i64(self.stream(), ids.numel(), _ptr(ids), int(n_bins), _ptr(flags), _ptr(cnt)),
                    'pk_unique_count_i64')

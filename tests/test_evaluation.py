@@ -202,9 +202,9 @@ def test_device_metric_reductions_equal_the_host_formulas(hip_ops, switch_positi
     recs[rng.rand(n_users) < 0.05, -3:] = -1                       # models may pad short lists with negative ids
     per = rng.randint(1, 10, n_users)
     hu = np.repeat(np.arange(n_users), per)
-    hi_ = np.concatenate([np.r_[r[rng.permutation(topk)[:min(p, 3)]], rng.randint(0, n_items, max(p - 3, 0))][:p]
-                          for r, p in zip(recs, per)])
-    hi_ = np.where(hi_ < 0, 0, hi_)
+    # up to three recommended items (never a padded slot) + items outside the list: no duplicates within a user
+    hi_ = np.concatenate([np.r_[r[rng.permutation(topk - 3)[:min(p, 3)]],
+                                rng.permutation(np.setdiff1d(np.arange(n_items), r))[:max(p - 3, 0)]] for r, p in zip(recs, per)])
     hf = rng.randint(0, 6, len(hu)).astype(np.float64)
     ptr = np.r_[0, np.cumsum(per)].astype(np.int64)
     rd = torch.from_numpy(recs).to(hip_ops.device)
