@@ -143,7 +143,7 @@ class ArrayData:
             val = f
             shp = (self.n_users, self.n_items)
         idx, val = self.threshold_data(idx, val, feedback_threshold)
-        return idx.astype(np.intp), np.ascontiguousarray(val), tuple(int(s) for s in shp)
+        return idx.astype(np.intp, copy=False), np.ascontiguousarray(val), tuple(int(s) for s in shp)
 
     def _recover_testset(self):
         """data.py:820-832: training rows of the holdout users, sorted by user."""

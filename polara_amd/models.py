@@ -92,6 +92,7 @@ class RecommenderModel:
         self._factor_image = None
         self._factor_src = None       # the host array in `factors` the cached image was made from
         self._train_dev = None        # (device CSR of the training rows, its internal->external item map) when they double as the test rows
+        self._test_dev = None         # (item order it was built for, device CSR of the test users, n_users, n_items): dropped by data events
         # internal item order of the device path (csr.popularity_order): external id -> internal
         # position and back; None = identity.  `factors` and every result stay in EXTERNAL ids.
         self._item_rank = None
@@ -124,9 +125,11 @@ class RecommenderModel:
         self._factor_image = None
         self._train_dev = None
         self._resident = None
+        self._test_dev = None
 
     def _refresh_model(self):
         self._recommendations = None
+        self._test_dev = None
 
     @property
     def topk(self):
@@ -296,6 +299,32 @@ class RecommenderModel:
         self._resident = (A, self._item_rank, T, nonempty)
         return T, nonempty
 
+    def _device_test_csr(self):
+        """The test users' known interactions as a device CSR in the current internal item order (zeros kept: still
+        "seen").  Built from the protocol's triplets (`_get_test_data`, models.py:227-257) by the ingest kernels —
+        external ids go up as they are, the renaming into the internal order runs on the device — and kept until a
+        data event (`on_update` / `on_change`), a threshold / flattener change or a new item order drops it: the
+        reference rebuilds its test matrix per chunk and per call (models.py:180-211)."""
+        key = self._test_csr_depends_on()
+        cached = self._test_dev
+        if cached is not None and len(cached[0]) == len(key) and all(a is b for a, b in zip(cached[0], key)):
+            return cached[1:]
+        ops = self.ops
+        test_data, test_shape, _ = self._get_test_data()
+        n_users, n_items = int(test_shape[0]), int(test_shape[1])
+        w = self._test_weights(test_data)
+        vals = np.asarray(test_data[2] if w is None else w, dtype=np.float64)
+        T = ops.csr_from_coo(test_data[0], test_data[1], vals, (n_users, n_items))
+        if self._item_rank is not None:
+            T = ops.csr_relabel_cols(T, self._item_rank)
+        self._test_dev = (key, T, n_users, n_items)
+        return T, n_users, n_items
+
+    def _test_csr_depends_on(self):
+        """What the cached device test CSR was built from besides the data (whose changes arrive as events): objects
+        compared by identity."""
+        return (self._item_rank,)
+
     def get_recommendations(self):
         if self.verify_integrity:
             self.verify_data_integrity()
@@ -306,12 +335,7 @@ class RecommenderModel:
             n_users, n_items = T.shape
         else:
             nonempty = None
-            test_data, test_shape, _ = self._get_test_data()
-            n_users, n_items = int(test_shape[0]), int(test_shape[1])
-            w = self._test_weights(test_data)
-            vals = np.asarray(test_data[2] if w is None else w, dtype=np.float64)
-            cols = test_data[1] if self._item_rank is None else self._item_rank[np.asarray(test_data[1], dtype=np.intp)]
-            T = ops.csr_from_coo(test_data[0], cols, vals, (n_users, n_items))   # zeros kept: still "seen"
+            T, n_users, n_items = self._device_test_csr()
         lo, hi = 0, n_users
         gather = comm.world > 1 and not self._presharded()   # a pre-sharded dataset: T already is this rank's users
         if gather:  # user-sharded scoring; V is replicated, no collective in the data path
@@ -443,6 +467,7 @@ class RecommenderModel:
         def swapped():
             saved = data._test
             saved_flag = getattr(data, 'scores_training_rows', None)
+            self._test_dev = None
             try:
                 if hasattr(data, 'get_entity_index'):         # Polara: a one-user frame in internal item ids
                     import pandas as pd
@@ -461,6 +486,7 @@ class RecommenderModel:
                 yield
             finally:
                 data._test = saved
+                self._test_dev = None
                 if saved_flag is not None:
                     data.scores_training_rows = saved_flag
         return swapped()
@@ -574,9 +600,15 @@ class SVDModel(RecommenderModel):
                 # device, get_recommendations renames its columns instead of rebuilding it from triplets
                 self._train_dev = (A, self._item_inv)
             return A
+        # COO -> CSR, per-item counts and the renaming into the internal (popularity) order all run on the device
+        # (csrc/ingest.hip): the index array of `to_coo` goes up as it is
         idx, val, shp = self.data.to_coo(tensor_mode=False, feedback_threshold=self.feedback_threshold)
-        self._item_rank, self._item_inv = popularity_order(None, shp[1], counts=self._item_counts(idx[:, 1], shp[1]))
-        return self.ops.csr_from_coo(idx[:, 0], self._item_rank[idx[:, 1]], np.asarray(val, dtype=np.float64), shp)
+        A = self.ops.csr_from_coo(idx[:, 0], idx[:, 1], val, shp)
+        counts = self.ops.item_counts(A)
+        if self._presharded() and self.comm.world > 1:
+            counts = self.ops.to_host(self.comm.allreduce(self.ops.to_device(counts)))
+        self._item_rank, self._item_inv = popularity_order(None, shp[1], counts=counts)
+        return self.ops.csr_relabel_cols(A, self._item_rank)
 
     def _local_training_shard(self):
         A = self._training_device_csr()
@@ -825,6 +857,11 @@ class CoffeeModel(RecommenderModel):
         self.factors['core'] = ops.to_host(core)
         self._factor_image = None
 
+
+    def _test_csr_depends_on(self):
+        # the per-entry weights come from the feedback factor and the flattener: a rank reduction or a restored
+        # `factors` dict (the rank-sweep pipelines do that) makes a cached test CSR stale
+        return (self._item_rank, self.factors.get(self.data.fields.feedback, None), self._flattener)
 
     def _test_weights(self, test_data):
         """models.py:1042-1054 folded algebraically: the per-nnz outer products,

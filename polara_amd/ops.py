@@ -349,16 +349,20 @@ class HipOps:
             both = torch.from_numpy(base).to(dev)
             r_ptr, c_ptr, stride = _ptr(both), _ptr(both, 1), 2
         else:
-            both = torch.from_numpy(np.stack([np.asarray(rows, dtype=np.int64), np.asarray(cols, dtype=np.int64)])).to(dev)
-            r_ptr, c_ptr, stride = _ptr(both), _ptr(both, nnz), 1
+            # two separate host arrays of any integer type: uploaded as they are (no host-side stacking or widening)
+            both = torch.empty(2, max(nnz, 1), dtype=torch.int64, device=dev)
+            if nnz:
+                both[0, :nnz].copy_(torch.from_numpy(np.ascontiguousarray(rows)).to(dev))
+                both[1, :nnz].copy_(torch.from_numpy(np.ascontiguousarray(cols)).to(dev))
+            r_ptr, c_ptr, stride = _ptr(both), _ptr(both, max(nnz, 1)), 1
         v = np.ascontiguousarray(vals)
-        if v.dtype == np.float64:
-            v32 = v.astype(np.float32)
-            if np.array_equal(v32.astype(np.float64), v):
-                v = v32
-        elif v.dtype != np.float32:
+        if v.dtype not in (np.float32, np.float64):
             v = v.astype(np.float64)
         v = torch.from_numpy(v).to(dev)
+        if v.dtype == torch.float64 and nnz:
+            v32 = v.to(torch.float32)
+            if bool((v32.to(torch.float64) == v).all().item()):
+                v = v32       # ratings are exactly representable: halve the value stream
         val_kind = _lib.PK_VAL_F32 if v.dtype == torch.float32 else _lib.PK_VAL_F64
         indptr = torch.empty(n_rows + 1, dtype=torch.int64, device=dev)
         indices = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)

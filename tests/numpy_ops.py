@@ -66,6 +66,9 @@ class NumpyOps:
         ip, ix, vl = coo_to_csr(m.row, np.asarray(col_map)[m.col], m.data, A.shape, sum_duplicates=False)
         return NpCSR(ip, ix, vl, A.shape)
 
+    def item_counts(self, A):
+        return np.bincount(A.m.indices, minlength=A.shape[1]).astype(np.int64)
+
     def csr_rows(self, A, lo, hi):
         sub = A.m[lo:hi]
         return NpCSR(sub.indptr, sub.indices, sub.data, sub.shape)
