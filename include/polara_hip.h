@@ -304,6 +304,13 @@ int pk_score_exact_rows_f64(void *stream, int32_t n_rows, const int32_t *rows_de
                             int32_t K, const double *V_dev, int64_t ldv, const double *E_dev, int64_t lde,
                             const int64_t *seen_ptr_dev, const int32_t *seen_idx_dev, int32_t topk,
                             int64_t *out_idx_dev, double *out_score_dev, void *work_dev);
+/* The same rows for a DEVICE-side list (pk_flag_compact output): users list_dev[0 .. *count_dev); results go to the rows
+ * of those users in the [n_users x topk] outputs.  n_wg workgroups walk the list (work >= pk_exact_work_bytes(n_wg,
+ * n_items)); the list never visits the host, so a scoring pass needs no synchronisation. */
+int pk_score_exact_list_f64(void *stream, int32_t n_wg, const int32_t *list_dev, const int32_t *count_dev, int64_t n_items,
+                            int32_t K, const double *V_dev, int64_t ldv, const double *E_dev, int64_t lde,
+                            const int64_t *seen_ptr_dev, const int32_t *seen_idx_dev, int32_t topk, int64_t *out_idx_dev,
+                            double *out_score_dev, void *work_dev);
 /* Evaluation support (models.py:408-485, evaluation.py:24-44 `build_rank_matrix` restricted to the holdout):
  * rank_out[e] = 1-based position of hold_item[e] in row hold_row[e] of the device-resident [n_users x topk]
  * recommendation array, 0 if absent.  Every hit/rank metric is a reduction of this holdout-sized vector. */

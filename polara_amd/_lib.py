@@ -72,6 +72,8 @@ PROTOTYPES = {
     'pk_exact_work_bytes': (_i64, [_i32, _i64]),
     'pk_score_exact_rows_f64': (C.c_int, [_vp, _i32, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _i32,
                                           _vp, _vp, _vp]),
+    'pk_score_exact_list_f64': (C.c_int, [_vp, _i32, _vp, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _i32,
+                                          _vp, _vp, _vp]),
     'pk_eval_ranks': (C.c_int, [_vp, _i64, _vp, _i32, _vp, _vp, _vp]),
     'pk_eval_cols': (_i32, []),
     'pk_eval_user_metrics': (C.c_int, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _f64, _f64, _i32, _vp]),

@@ -471,19 +471,27 @@ __device__ __forceinline__ bool best_before(const Best &a, const Best &b) {
     return a.idx < b.idx;
 }
 
+// Every workgroup walks the list with stride gridDim.x (one work slice per workgroup): the number of listed users may
+// live on the device (n_rows_dev), so that the caller never has to read it back before launching.  by_user: results go
+// to row `user` of the outputs instead of row r of the list.
 __global__ __launch_bounds__(256) void score_exact_rows_kernel(
-    const int32_t *__restrict__ rows, int64_t n_items, int K, const double *__restrict__ V, int64_t ldv,
+    int32_t n_rows_host, const int32_t *__restrict__ n_rows_dev, const int32_t *__restrict__ rows, int by_user,
+    int64_t n_items, int K, const double *__restrict__ V, int64_t ldv,
     const double *__restrict__ E, int64_t lde, const int64_t *__restrict__ seen_ptr,
     const int32_t *__restrict__ seen_idx, int topk, int64_t *__restrict__ out_idx,
     double *__restrict__ out_score, unsigned char *__restrict__ work, int64_t per_row) {
-    __shared__ double s_e[256];
+    extern __shared__ double s_e[];   // the user's E row: K doubles (dynamic: any rank fits — the fused sweep stops at 256)
     __shared__ int s_cls[256];
     __shared__ double s_s[256];
     __shared__ int s_i[256];
     const int tid = threadIdx.x;
-    const int64_t user = rows[blockIdx.x];
+    const int32_t n_rows = n_rows_dev ? *n_rows_dev : n_rows_host;
     double *score = reinterpret_cast<double *>(work + (int64_t)blockIdx.x * per_row);
     unsigned char *cls = work + (int64_t)blockIdx.x * per_row + n_items * 8;
+  for (int32_t r = blockIdx.x; r < n_rows; r += gridDim.x) {
+    const int64_t user = rows[r];
+    const int64_t orow = by_user ? user : (int64_t)r;
+    __syncthreads();   // the previous user's s_e / cls are no longer read
 
     for (int c = tid; c < K; c += 256) s_e[c] = E[user * lde + c];
     __syncthreads();
@@ -530,12 +538,13 @@ __global__ __launch_bounds__(256) void score_exact_rows_kernel(
         }
         if (tid == 0) {
             const bool ok = s_cls[0] < 2;
-            out_idx[(int64_t)blockIdx.x * topk + t] = ok ? (int64_t)s_i[0] : -1;
-            if (out_score) out_score[(int64_t)blockIdx.x * topk + t] = ok ? s_s[0] : -INFINITY;
+            out_idx[orow * topk + t] = ok ? (int64_t)s_i[0] : -1;
+            if (out_score) out_score[orow * topk + t] = ok ? s_s[0] : -INFINITY;
             if (ok) cls[s_i[0]] = 2;
         }
         __syncthreads();
     }
+  }
 }
 
 extern "C" int pk_score_exact_rows_f64(void *stream, int32_t n_rows, const int32_t *rows_dev, int64_t n_items,
@@ -546,8 +555,26 @@ extern "C" int pk_score_exact_rows_f64(void *stream, int32_t n_rows, const int32
     PK_REQUIRE(ldv >= K && lde >= K && work_dev, "pk_score_exact_rows_f64: bad arguments");
     if (n_rows == 0) return PK_OK;
     const int64_t per_row = n_items * 8 + ((n_items + 15) / 16) * 16;
-    hipLaunchKernelGGL(score_exact_rows_kernel, dim3((unsigned)n_rows), dim3(256), (size_t)K * 8, pk_stream(stream), rows_dev,
-                       n_items, K, V_dev, ldv, E_dev, lde, seen_ptr_dev, seen_idx_dev, topk, out_idx_dev,
+    hipLaunchKernelGGL(score_exact_rows_kernel, dim3((unsigned)n_rows), dim3(256), (size_t)K * 8, pk_stream(stream), n_rows,
+                       (const int32_t *)nullptr, rows_dev, 0, n_items, K, V_dev, ldv, E_dev, lde, seen_ptr_dev, seen_idx_dev, topk,
+                       out_idx_dev, out_score_dev, static_cast<unsigned char *>(work_dev), per_row);
+    PK_CHECK_LAUNCH("score_exact_rows_kernel");
+    return PK_OK;
+}
+
+/* The same kernel over a DEVICE-side list (pk_flag_compact): users list_dev[0 .. *count_dev), results written to the
+ * rows of those users in the [n_users x topk] outputs; n_wg workgroups share the list (work >= pk_exact_work_bytes(n_wg,
+ * n_items)).  Nothing about the list visits the host, so a scoring pass needs no synchronisation. */
+extern "C" int pk_score_exact_list_f64(void *stream, int32_t n_wg, const int32_t *list_dev, const int32_t *count_dev,
+                                       int64_t n_items, int32_t K, const double *V_dev, int64_t ldv, const double *E_dev,
+                                       int64_t lde, const int64_t *seen_ptr_dev, const int32_t *seen_idx_dev, int32_t topk,
+                                       int64_t *out_idx_dev, double *out_score_dev, void *work_dev) {
+    PK_REQUIRE(n_wg >= 1 && n_items >= 1 && K >= 1 && K <= 8192 && topk >= 1 && list_dev && count_dev,
+               "pk_score_exact_list_f64: bad sizes");
+    PK_REQUIRE(ldv >= K && lde >= K && work_dev && out_idx_dev, "pk_score_exact_list_f64: bad arguments");
+    const int64_t per_row = n_items * 8 + ((n_items + 15) / 16) * 16;
+    hipLaunchKernelGGL(score_exact_rows_kernel, dim3((unsigned)n_wg), dim3(256), (size_t)K * 8, pk_stream(stream), 0, count_dev,
+                       list_dev, 1, n_items, K, V_dev, ldv, E_dev, lde, seen_ptr_dev, seen_idx_dev, topk, out_idx_dev,
                        out_score_dev, static_cast<unsigned char *>(work_dev), per_row);
     PK_CHECK_LAUNCH("score_exact_rows_kernel");
     return PK_OK;

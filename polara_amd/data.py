@@ -179,7 +179,10 @@ class ArrayData:
     def get_test_shape(self, tensor_mode=False):
         """data.py:865-884."""
         src = self._test.holdout if self._test.holdout is not None else self._test.testset
-        num_users = len(np.unique(src.userid))
+        if getattr(self, '_n_test_users', None) is None or self._n_test_users[0] is not src:
+            u = src.userid                                   # sorted by user (set_test_data): distinct = boundaries + 1
+            self._n_test_users = (src, (int(np.count_nonzero(u[1:] != u[:-1])) + 1) if len(u) else 0)
+        num_users = self._n_test_users[1]
         shape = (num_users, self.n_items)
         if tensor_mode:
             shape = shape + (len(self._levels()),)

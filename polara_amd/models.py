@@ -87,6 +87,7 @@ class RecommenderModel:
         self.verbose = True
         self.training_time = []
         self.recommend_stats = {}
+        self.collect_recommend_stats = False   # sweep statistics cost host round trips: tuning / tests only
         self._ops = ops
         self.comm = comm or NoComm()
         self._factor_image = None
@@ -346,7 +347,8 @@ class RecommenderModel:
         stats = {}
         recs_dev = None
         if hi > lo:
-            recs_dev = scoring.recommend(ops, self._item_factors_device(), T, self.topk, self.filter_seen, stats=stats)
+            recs_dev = scoring.recommend(ops, self._item_factors_device(), T, self.topk, self.filter_seen,
+                                         stats=stats if self.collect_recommend_stats else None)
             recs = ops.to_host(recs_dev)
             if self._item_inv is not None:   # internal positions -> external item ids
                 recs = np.where(recs >= 0, self._item_inv[np.maximum(recs, 0)], -1).astype(np.int64)

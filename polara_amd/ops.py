@@ -696,6 +696,18 @@ class HipOps:
                    'pk_score_exact_rows_f64')
         return out_idx, out_s
 
+    def score_exact_list(self, lst, cnt, V, E, n_items, seen_ptr, seen_idx, topk, out_idx, out_s, n_wg=128):
+        """score_exact_rows for the device-side list (lst[:cnt]) straight into rows of out_idx / out_s: no host sync."""
+        K = E.shape[1]
+        key = ('exact_work', int(n_wg), int(n_items))
+        if getattr(self, '_exact_work', None) is None or self._exact_work[0] != key:
+            self._exact_work = (key, torch.empty(self.lib.pk_exact_work_bytes(n_wg, n_items), dtype=torch.uint8,
+                                                 device=self.device))
+        _lib.check(self.lib.pk_score_exact_list_f64(self.stream(), int(n_wg), _ptr(lst), _ptr(cnt), n_items, K, _ptr(V),
+                                                    V.stride(0), _ptr(E), E.stride(0), _ptr(seen_ptr), _ptr(seen_idx),
+                                                    topk, _ptr(out_idx), _ptr(out_s), _ptr(self._exact_work[1])),
+                   'pk_score_exact_list_f64')
+
     def eval_ranks(self, recs, hold_row, hold_item):
         """int32 [n_holdout]: 1-based rank of every holdout item in its user's row of the device-resident
         recommendation array (0 = not recommended)."""

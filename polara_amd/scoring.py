@@ -171,10 +171,12 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
                 run_batch(u0, min(n_users, u0 + per))
         for sdev in side:
             main.wait_stream(sdev)
-    rows = torch.nonzero(flags, as_tuple=False).flatten().to(torch.int32)
-    n_flag = int(rows.numel())
+    # users still flagged (fewer than k unseen items, or not certifiable) are re-done by the exact-row kernel from a
+    # device-side list: nothing of the pass visits the host, so consecutive passes queue up without a gap
+    lst, cnt = ops.flag_compact(flags, 0x7fffffff)
+    ops.score_exact_list(lst, cnt, factors.V, E, n_items, seen_ptr, seen_idx, topk, out_idx, out_s)
     if stats is not None:
-        stats['flagged_users'] = n_flag
+        stats['flagged_users'] = int(cnt.item())
         stats['refolded_users'] = int(sum(int(c.item()) for c in refolded))
         stats['approx_fold_in'] = bool(approx_fold_in)
         stats['candidate_capacity'] = KC
@@ -189,13 +191,6 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
         q = torch.quantile(scored.flatten().double(),
                            torch.tensor([0.5, 0.9, 0.99, 0.999, 1.0], dtype=torch.float64, device=ex.device))
         stats['exit_tile_quantiles'] = dict(zip(('p50', 'p90', 'p99', 'p999', 'max'), [float(v) for v in q.tolist()]))
-    if n_flag:
-        per = max(1, int(EXACT_ROWS_BYTES // (n_items * 9 + 16)))
-        for s in range(0, n_flag, per):
-            sub = rows[s:s + per].contiguous()
-            ex_idx, ex_s = ops.score_exact_rows(sub, factors.V, E, n_items, seen_ptr, seen_idx, topk)
-            out_idx[sub.long()] = ex_idx
-            out_s[sub.long()] = ex_s
     if return_scores:
         return out_idx, out_s
     return out_idx

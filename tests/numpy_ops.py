@@ -284,6 +284,13 @@ class NumpyOps:
             out_s[r, :len(order)] = s[order]
         return torch.from_numpy(out_idx), torch.from_numpy(out_s)
 
+    def score_exact_list(self, lst, cnt, V, E, n_items, seen_ptr, seen_idx, topk, out_idx, out_s, n_wg=128):
+        rows = lst[:int(cnt)]
+        if len(rows):
+            ex_idx, ex_s = self.score_exact_rows(rows, V, E, n_items, seen_ptr, seen_idx, topk)
+            out_idx[rows.long()] = ex_idx
+            out_s[rows.long()] = ex_s
+
     def eval_ranks(self, recs, hold_row, hold_item):
         r, hr, hi = recs.numpy(), hold_row.numpy(), hold_item.numpy()
         match = r[hr] == hi[:, None]

@@ -87,6 +87,7 @@ def test_svd_model_orchestration_matches_reference(name):
     m = SVDModel(GoldenData(g), ops=NumpyOps())
     m.verbose = False
     m.rank, m.topk, m.filter_seen = int(g['rank']), int(g['topk']), bool(g['filter_seen'])
+    m.collect_recommend_stats = True
     m.build()
     assert len(m.training_time) == 1 and m._is_ready
     assert np.allclose(m.factors['singular_values'], g['sigma'], rtol=1e-9)

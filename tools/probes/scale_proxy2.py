@@ -1,0 +1,88 @@
+"""Strong-scaling proxies on ONE GPU (round 2): the work rank 0 would own at N = 1, 2, 4, 8 GPUs.
+  scoring: the scoring pass (ids-only, result copied to the host, passes queued back to back like bench.py) on rank
+           0's nnz-balanced user shard — the pass has no collective, so N x (users of the shard) / time is the job's rate;
+  build:   the eigensolver on rank 0's row shard with the exchange stubbed (NoComm), per-kernel-class times from HIP
+           events, plus the MODELLED exchange: one sum all-reduce of Z [n_items x l] fp64 per Gramian step over a ring
+           of N GPUs at `--link-gbps` per direction (xGMI, 153 GB/s nominal; 100 GB/s achieved assumed) and one of the
+           l x l Gram matrix per Rayleigh-Ritz.
+usage: python tools/probes/scale_proxy2.py [ml20m|s1m] [rank] [topk]"""
+import sys, time, json, os
+sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '.'))
+import torch, numpy as np
+from polara_amd.ops import HipOps
+from polara_amd.synth import make_workload, csr_to_numpy
+from polara_amd.solver import svd_topk
+from polara_amd.csr import popularity_order, nnz_balanced_row_partition
+from polara_amd import scoring
+ops = HipOps('cuda:0')
+WL = sys.argv[1] if len(sys.argv) > 1 else 'ml20m'
+csr, cfg = make_workload(WL, device='cuda:0')
+rank = int(sys.argv[2]) if len(sys.argv) > 2 else {'ml20m': 50}.get(WL, cfg['rank'])
+topk = int(sys.argv[3]) if len(sys.argv) > 3 else {'ml20m': 10}.get(WL, cfg['topk'])
+LINK = 100e9
+c = csr_to_numpy(csr); del csr
+n_users, n_items = c['shape']
+A0 = ops.csr(c['indptr'], c['indices'], c['values'], c['shape'])
+rank_of, inv = popularity_order(None, n_items, counts=ops.item_counts(A0))
+A0 = ops.csr_relabel_cols(A0, rank_of)
+out = {'workload': WL, 'rank': rank, 'topk': topk, 'build': {}, 'scoring': {}}
+V = None
+for N in (1, 2, 4, 8):
+    bounds = nnz_balanced_row_partition(c['indptr'], N)
+    A = A0 if N == 1 else ops.csr_rows(A0, 0, int(bounds[1]))
+    A.transpose_operator(); _ = A.plan
+    svd_topk(ops, A, rank)                     # warm-up (allocations)
+    torch.cuda.synchronize()
+    ops.timers = {}
+    t0 = time.perf_counter()
+    _, s, Vn, st = svd_topk(ops, A, rank)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    spmm_ms = sum(a.elapsed_time(b) for a, b, _ in ops.timers.get('spmm', []))
+    ops.timers = None
+    l = st['block']
+    z_bytes = n_items * l * 8
+    ring = 0.0 if N == 1 else st['gramian_steps'] * (2.0 * (N - 1) / N * z_bytes / LINK + 2 * (N - 1) * 5e-6) \
+        + st['outer'] * (2 * (N - 1) * 5e-6)
+    out['build']['N=%d' % N] = dict(rows_on_rank0=A.shape[0], solver_wall_s=wall, spmm_ms=spmm_ms, non_spmm_ms=1e3 * wall - spmm_ms,
+                                    gramian_steps=st['gramian_steps'], modelled_exchange_ms=1e3 * ring,
+                                    modelled_total_s=wall + ring)
+    if N == 1:
+        V = Vn
+b1 = out['build']['N=1']['modelled_total_s']
+for k, v in out['build'].items():
+    v['speedup_vs_N1'] = b1 / v['modelled_total_s']
+order2 = torch.argsort(torch.linalg.vector_norm(V, dim=1), descending=True, stable=True)
+rank2 = torch.empty_like(order2); rank2[order2] = torch.arange(n_items, device=order2.device)
+V = V[order2].contiguous()
+As = ops.csr_relabel_cols(A0, rank2)
+F = scoring.FactorImage(ops, V)
+copy_stream = torch.cuda.Stream()
+for N in (1, 2, 4, 8):
+    bounds = nnz_balanced_row_partition(c['indptr'], N)
+    T = As if N == 1 else ops.csr_rows(As, 0, int(bounds[1]))
+    T.seen_tiles()
+    host = [torch.empty((T.shape[0], topk), dtype=torch.int64).pin_memory() for _ in range(2)]
+    done = [torch.cuda.Event() for _ in range(2)]
+    main = torch.cuda.current_stream()
+    def one(i):
+        recs = scoring.recommend(ops, F, T, topk, True)
+        ev = torch.cuda.Event(); ev.record(main)
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(ev)
+            host[i & 1].copy_(recs, non_blocking=True); recs.record_stream(copy_stream); done[i & 1].record(copy_stream)
+    for i in range(5): one(i)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    steps = 50
+    for i in range(steps):
+        if i >= 2: done[i & 1].synchronize()
+        one(i)
+    torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / steps * 1e3
+    st = {}
+    scoring.recommend(ops, F, T, topk, True, stats=st)
+    out['scoring']['N=%d' % N] = dict(users_on_rank0=T.shape[0], ms_per_pass=ms, job_users_per_s=n_users / (ms * 1e-3),
+                                      item_splits=st['item_splits'], swept_fraction=st['tiles_scored'] / max(st['tiles_total'], 1))
+s1 = out['scoring']['N=1']['ms_per_pass']
+for k, v in out['scoring'].items():
+    v['speedup_vs_N1'] = s1 / v['ms_per_pass']
+print(json.dumps(out))
