@@ -699,14 +699,19 @@ class HipOps:
     def score_exact_list(self, lst, cnt, V, E, n_items, seen_ptr, seen_idx, topk, out_idx, out_s, n_wg=128):
         """score_exact_rows for the device-side list (lst[:cnt]) straight into rows of out_idx / out_s: no host sync."""
         K = E.shape[1]
-        key = ('exact_work', int(n_wg), int(n_items))
-        if getattr(self, '_exact_work', None) is None or self._exact_work[0] != key:
-            self._exact_work = (key, torch.empty(self.lib.pk_exact_work_bytes(n_wg, n_items), dtype=torch.uint8,
-                                                 device=self.device))
+        # one work buffer per launch stream (two passes on different streams must not share it), regrown on demand
+        skey = torch.cuda.current_stream(self.device).cuda_stream
+        need = self.lib.pk_exact_work_bytes(n_wg, n_items)
+        if getattr(self, '_exact_work', None) is None:
+            self._exact_work = {}
+        if skey not in self._exact_work or self._exact_work[skey].numel() < need:
+            self._exact_work[skey] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        work = self._exact_work[skey]
         _lib.check(self.lib.pk_score_exact_list_f64(self.stream(), int(n_wg), _ptr(lst), _ptr(cnt), n_items, K, _ptr(V),
                                                     V.stride(0), _ptr(E), E.stride(0), _ptr(seen_ptr), _ptr(seen_idx),
-                                                    topk, _ptr(out_idx), _ptr(out_s), _ptr(self._exact_work[1])),
+                                                    topk, _ptr(out_idx), _ptr(out_s), _ptr(work)),
                    'pk_score_exact_list_f64')
+        return work
 
     def eval_ranks(self, recs, hold_row, hold_item):
         """int32 [n_holdout]: 1-based rank of every holdout item in its user's row of the device-resident

@@ -196,6 +196,43 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
     return out_idx
 
 
+class CapturedPass:
+    """One scoring pass over a FIXED (factors, test matrix, topk) captured in a hipGraph (torch.cuda.CUDAGraph) and
+    replayed: the ~14 kernel launches and the temporaries of `recommend` cost one graph launch.  The pass has no host
+    round trip inside (the lists of users to re-fold / re-do stay on the device), so the capture is the pass itself.
+    What it is for: user sets small enough that a pass is bound by its launch sequence instead of its kernels — a
+    rank's shard of ML-20M at 8 GPUs is 17K users, 0.49 ms per pass launched from Python against ~0.3 ms of kernels —
+    scored repeatedly: periodic re-scoring, the timed loop of bench.py.  A new test matrix, new factors or another
+    topk need a new capture (every launch's grid and arguments derive from them).
+    `replay()` returns the SAME device tensor every time (the graph's output buffer): copy it before the next replay."""
+
+    def __init__(self, ops, factors, T, topk, filter_seen=True, prune=True):
+        self.ops = ops
+        dev = ops.device
+        T.nonneg()
+        if filter_seen:
+            T.seen_tiles()
+        _ = T.plan
+        main = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):          # warm-up on the capture side: lazily created buffers exist afterwards
+            for _ in range(2):
+                recommend(ops, factors, T, topk, filter_seen, prune=prune, batches=1)
+        main.wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = recommend(ops, factors, T, topk, filter_seen, prune=prune, batches=1)
+        # everything the captured launches point at must outlive the graph: the operands, and the per-stream scratch
+        # buffers the capture created (they stay registered under the capture stream's key, which nobody else uses)
+        self._keep = (factors, T, dict(ops._score_states or {}), dict(getattr(ops, '_exact_work', None) or {}))
+
+    def replay(self):
+        self.graph.replay()
+        return self.out
+
+
 def dense_scores(ops, factors, T, start, stop):
     """Dense fp64 scores of test users [start, stop) — kept for `slice_recommendations` /
     `_user_scores` (models.py:277-291, 857-861); not used by get_recommendations."""

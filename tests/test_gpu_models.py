@@ -341,3 +341,30 @@ def test_build_with_device_resident_operator_product(hip_ops):
     assert clear.mean() > 0.9 and np.array_equal(recs[0][clear], recs[1][clear])
     want = np.argsort(-scores, axis=1, kind='stable')[:, :10]
     assert np.array_equal(recs[0][clear], want[clear])
+
+
+def test_captured_pass_replays_the_same_lists(hip_ops):
+    """scoring.CapturedPass: the pass captured in a hipGraph returns, replay after replay, what the launched pass
+    returns — including users that need the exact-row re-do (fewer than k unseen items), whose list never leaves the
+    device."""
+    import torch
+    from polara_amd import scoring
+    from polara_amd.solver import svd_topk
+    ops = hip_ops
+    for (n_users, n_items, mean, max_items, rank, topk) in ((6000, 900, 40, 300, 12, 10), (500, 40, 30, 39, 6, 10)):
+        c = csr_to_numpy(planted_csr(n_users, n_items, mean, rank, seed=77, min_items=5, max_items=max_items))
+        A = ops.csr(c['indptr'], c['indices'], c['values'], c['shape'])
+        _, _, V, st = svd_topk(ops, A, rank)
+        F = scoring.FactorImage(ops, V)
+        stats = {}
+        want = scoring.recommend(ops, F, A, topk, True, stats=stats)
+        if n_items == 40:
+            assert stats['flagged_users'] > 0            # the exact-row path is part of the captured pass
+        cap = scoring.CapturedPass(ops, F, A, topk, True)
+        for _ in range(3):
+            got = cap.replay().clone()
+            torch.cuda.synchronize()
+            assert torch.equal(got, want)
+        # the launched pass still works next to the graph (separate scratch buffers)
+        assert torch.equal(scoring.recommend(ops, F, A, topk, True), want)
+        assert torch.equal(cap.replay(), want)
