@@ -325,7 +325,7 @@ extern "C" int pk_rescore_topk_f64(void *stream, int64_t n_users, int64_t n_item
 
 // ---- re-doing flagged users without the host -------------------------------------------------------
 // list[0 .. count) = users u in [0, n) with (flags[u] & mask) != 0, in no particular order (count is zeroed by
-// the caller-side memset in pk_flag_compact).  cap = n: the list cannot overflow.
+// a one-thread kernel in pk_flag_compact).  cap = n: the list cannot overflow.
 __global__ __launch_bounds__(256) void flag_compact_kernel(int64_t n, const int32_t *__restrict__ flags, int mask,
                                                            int32_t *__restrict__ list, int32_t *__restrict__ count) {
     const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -340,14 +340,16 @@ __global__ __launch_bounds__(256) void flag_compact_kernel(int64_t n, const int3
     if (hit) list[base + __popcll(b & ((1ull << lane) - 1ull))] = (int32_t)u;
 }
 
+__global__ void zero_i32_kernel(int32_t *p) { *p = 0; }
+
 extern "C" int pk_flag_compact(void *stream, int64_t n, const int32_t *flags_dev, int32_t mask, int32_t *list_dev,
                                int32_t *count_dev) {
     PK_REQUIRE(n >= 1 && flags_dev && list_dev && count_dev, "pk_flag_compact: bad arguments");
     hipStream_t st = pk_stream(stream);
-    if (hipMemsetAsync(count_dev, 0, sizeof(int32_t), st) != hipSuccess) {
-        pk_set_error("pk_flag_compact: memset failed");
-        return PK_E_LAUNCH;
-    }
+    // the counter is zeroed by a kernel, not by hipMemsetAsync: a 4-byte memset NODE of a captured hipGraph faults on
+    // replay once another kernel has run in between (ROCm 7.2, MI355X; tools/probes/graph_debug4.py bisects the pass
+    // to this call) — and a scoring pass must stay capturable (scoring.CapturedPass)
+    hipLaunchKernelGGL(zero_i32_kernel, dim3(1), dim3(1), 0, st, count_dev);
     hipLaunchKernelGGL(flag_compact_kernel, dim3((unsigned)pk_ceil_div(n, 256)), dim3(256), 0, st, n, flags_dev, mask,
                        list_dev, count_dev);
     PK_CHECK_LAUNCH("flag_compact_kernel");

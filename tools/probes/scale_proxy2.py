@@ -65,8 +65,13 @@ for N in (1, 2, 4, 8):
     host = [torch.empty((T.shape[0], topk), dtype=torch.int64).pin_memory() for _ in range(2)]
     done = [torch.cuda.Event() for _ in range(2)]
     main = torch.cuda.current_stream()
+    cap = scoring.CapturedPass(ops, F, T, topk, True) if os.environ.get('PK_PROXY_GRAPH', '1') == '1' else None
+    stage = [torch.empty((T.shape[0], topk), dtype=torch.int64, device='cuda:0') for _ in range(2)]
     def one(i):
-        recs = scoring.recommend(ops, F, T, topk, True)
+        if cap is not None:
+            recs = stage[i & 1]; recs.copy_(cap.replay())
+        else:
+            recs = scoring.recommend(ops, F, T, topk, True)
         ev = torch.cuda.Event(); ev.record(main)
         with torch.cuda.stream(copy_stream):
             copy_stream.wait_event(ev)
@@ -80,7 +85,7 @@ for N in (1, 2, 4, 8):
     torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / steps * 1e3
     st = {}
     scoring.recommend(ops, F, T, topk, True, stats=st)
-    out['scoring']['N=%d' % N] = dict(users_on_rank0=T.shape[0], ms_per_pass=ms, job_users_per_s=n_users / (ms * 1e-3),
+    out['scoring']['N=%d' % N] = dict(users_on_rank0=T.shape[0], ms_per_pass=ms, launch='graph' if cap is not None else 'python', job_users_per_s=n_users / (ms * 1e-3),
                                       item_splits=st['item_splits'], swept_fraction=st['tiles_scored'] / max(st['tiles_total'], 1))
 s1 = out['scoring']['N=1']['ms_per_pass']
 for k, v in out['scoring'].items():
