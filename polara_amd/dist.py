@@ -43,13 +43,33 @@ class TorchComm:
             self.n_allreduce += 1
         return t
 
+    def _exchange_device(self):
+        """where collective payloads live: the GPU under RCCL, the host under gloo"""
+        if dist.get_backend(self.group) == 'nccl':
+            return torch.device('cuda', torch.cuda.current_device())
+        return torch.device('cpu')
+
     def gather_rows(self, local, n_total, width, dtype=np.int64):
-        """Concatenates per-rank row blocks (rank order = row order) on every rank (host arrays)."""
+        """Concatenates per-rank row blocks (rank order = row order) on every rank (host arrays): the block heights
+        travel in one small all-gather, the blocks — padded to the tallest — in one `all_gather_into_tensor`; typed
+        buffers end to end (no pickling: a [n_users x topk] result is tens of MB to GB)."""
         local = np.ascontiguousarray(local, dtype=dtype).reshape(-1, width)
-        parts = [None] * self.world
-        dist.all_gather_object(parts, local, group=self.group)
-        out = np.concatenate(parts, axis=0)
-        assert out.shape == (n_total, width)
+        if self.world == 1:
+            assert local.shape == (n_total, width)
+            return local
+        dev = self._exchange_device()
+        rows = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
+        all_rows = torch.empty(self.world, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(all_rows, rows, group=self.group)
+        heights = [int(x) for x in all_rows.tolist()]
+        tallest = max(max(heights), 1)
+        send = torch.zeros(tallest, width, dtype=torch.from_numpy(local[:0]).dtype, device=dev)
+        send[:local.shape[0]] = torch.from_numpy(local).to(dev)
+        recv = torch.empty(self.world * tallest, width, dtype=send.dtype, device=dev)
+        dist.all_gather_into_tensor(recv, send, group=self.group)
+        recv = recv.cpu().numpy().reshape(self.world, tallest, width)
+        out = np.concatenate([recv[r, :heights[r]] for r in range(self.world)], axis=0)
+        assert out.shape == (n_total, width), (out.shape, n_total, width)
         return out
 
     def barrier(self):

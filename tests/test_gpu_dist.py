@@ -1,4 +1,6 @@
-"""-m gpu: two ranks on the one visible GPU, real HIP kernels, all-reduce staged through gloo."""
+"""-m gpu: the N > 1 path on the product backend.  Two ranks on the one visible GPU (all-reduce staged through gloo), the
+bench under torchrun the same way, and — where the box has at least two GPUs — the real thing: one rank per GPU over
+RCCL ("nccl").  The GPU test box has ONE device: the RCCL test then SKIPS, loudly, rather than pretending."""
 import os
 import subprocess
 import sys
@@ -17,3 +19,36 @@ def test_two_rank_sharded_path_on_hip_backend():
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert 'DIST_GPU_RESULT' in r.stdout
+
+
+def _torchrun(script, n, extra_env=None, args=(), timeout=900):
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.update(extra_env or {})
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), script] + list(args)
+    return subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout)
+
+
+def test_sharded_path_over_rccl_when_two_gpus_are_visible():
+    import torch
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip('RCCL path NOT exercised: %d GPU visible, the nccl backend needs one process per GPU (>= 2)' % n)
+    r = _torchrun(os.path.join(ROOT, 'tests', 'dist_worker_nccl.py'), 2)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert 'DIST_NCCL_RESULT' in r.stdout
+    r = _torchrun(os.path.join(ROOT, 'bench.py'), 2, args=['--gpus', '2', '--steps', '3', '--warmup', '1', '--scale', '0.1'])
+    assert r.returncode == 0 and '"n_gpus": 2' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_bench_under_torchrun_two_ranks_one_gpu():
+    """bench.py as the driver launches it for N > 1 (torchrun, one JSON line from rank 0, MAX over ranks), with the
+    two ranks sharing the one GPU and the collectives staged through gloo (PK_BENCH_DEBUG_BACKEND): the path check
+    that can run on a one-GPU box."""
+    import json
+    r = _torchrun(os.path.join(ROOT, 'bench.py'), 2, extra_env={'PK_BENCH_DEBUG_BACKEND': 'gloo'},
+                  args=['--gpus', '2', '--steps', '3', '--warmup', '1', '--scale', '0.1', '--no-cpu-baseline'])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+    d = json.loads(line)
+    assert d['n_gpus'] == 2 and d['value'] > 0 and d['scaling'] == 'strong' and d['build']['converged']
