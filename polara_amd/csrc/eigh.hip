@@ -241,6 +241,102 @@ __global__ __launch_bounds__(EIGH_THREADS) void eigh_psd_kernel(int n, double *_
     }
 }
 
+// ---- n > EIGH_LDS_MAX: block Jacobi ------------------------------------------------------------------------
+// The work matrix no longer fits one CU's LDS (150 x 150 fp64 = 180 KB: the unfoldings of a (30, 30, 5) HOOI; 256 x
+// 256: the solver block of a rank-200 build).  Rotating it in global memory costs an L2 round trip per step of the
+// tournament (20.7 ms at n = 150, 59 ms at n = 256 — 92 % of the (30,30,5) build, profiles/r02_hooi_*).  Instead the
+// rows are cut into nb (even) blocks of w rows with 2 w n 8 B <= EIGH_BLOCK_LDS; a ROUND pairs the blocks by the circle
+// method (nb / 2 disjoint pairs = nb / 2 workgroups), each workgroup loads its 2 w rows into LDS, runs one full
+// round-robin sweep over ALL pairs of those rows there and writes them back; nb - 1 rounds make an outer sweep in
+// which every pair of rows has met at least once.  Rounds are separate launches (stream order is the grid barrier);
+// the rotation counts of an outer sweep go to a device counter, and every launch of a later sweep returns at once
+// when the previous sweep rotated nothing — the host never reads the counter.
+#define EIGH_BLOCK_LDS (144 * 1024)
+__global__ __launch_bounds__(EIGH_THREADS) void eigh_block_round_kernel(int n, double *__restrict__ Wg, int64_t ldwg, int w,
+                                                                        int nb, int round, int sweep,
+                                                                        int *__restrict__ counters, double tol) {
+    extern __shared__ __attribute__((aligned(16))) double eigh_smem[];
+    __shared__ int s_rot;
+    if (sweep > 0 && counters[sweep - 1] == 0) return;        // the previous outer sweep found every pair orthogonal
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bi, bj;
+    rr_pair(nb, round, blockIdx.x, bi, bj);
+    const int i0 = bi * w, j0 = bj * w;
+    const int ci = max(0, min(n, i0 + w) - i0), cj = max(0, min(n, j0 + w) - j0);
+    const int nr = ci + cj;                                    // rows of this pair of blocks
+    if (nr < 2) return;
+    double *W = eigh_smem;
+    for (int e = tid; e < nr * n; e += EIGH_THREADS) {
+        const int r = e / n, c = e - r * n;
+        const int gr = r < ci ? i0 + r : j0 + (r - ci);
+        W[e] = Wg[(int64_t)gr * ldwg + c];
+    }
+    if (tid == 0) s_rot = 0;
+    __syncthreads();
+    const int m = (nr + 1) & ~1;
+    const double tol2 = tol * tol;
+    for (int step = 0; step < m - 1; ++step) {
+        for (int k0 = wave * EIGH_PW; k0 < m / 2; k0 += EIGH_WAVES * EIGH_PW) {
+            const int slot = lane >> 4, t = lane & 15;
+            const int k = k0 + slot;
+            bool act = k < m / 2;
+            int p = 0, q = 0;
+            if (act) {
+                rr_pair(m, step, k, p, q);
+                act = q < nr;  // bye
+            }
+            double *wp = W + (int64_t)p * n, *wq = W + (int64_t)q * n;
+            double alpha = 0.0, beta = 0.0, gamma = 0.0;
+            if (act) {
+                for (int c = t; c < n; c += 16) {
+                    const double a = wp[c], b = wq[c];
+                    alpha = fma(a, a, alpha);
+                    beta = fma(b, b, beta);
+                    gamma = fma(a, b, gamma);
+                }
+            }
+            alpha = eigh_row16_sum(alpha);
+            beta = eigh_row16_sum(beta);
+            gamma = eigh_row16_sum(gamma);
+            const bool rot = act && gamma * gamma > tol2 * alpha * beta && gamma != 0.0;
+            if (rot) {
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double cs = 1.0 / sqrt(1.0 + tt * tt);
+                const double sn = cs * tt;
+                for (int c = t; c < n; c += 16) {
+                    const double a = wp[c], b = wq[c];
+                    wp[c] = cs * a - sn * b;
+                    wq[c] = sn * a + cs * b;
+                }
+            }
+            const unsigned long long rb = __ballot(rot && t == 0);
+            if (lane == 0 && rb) atomicAdd(&s_rot, __popcll(rb));
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < nr * n; e += EIGH_THREADS) {
+        const int r = e / n, c = e - r * n;
+        const int gr = r < ci ? i0 + r : j0 + (r - ci);
+        Wg[(int64_t)gr * ldwg + c] = W[e];
+    }
+    if (tid == 0 && s_rot) atomicAdd(&counters[sweep], s_rot);
+}
+
+__global__ void eigh_counters_init_kernel(int *counters, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) counters[i] = 0;
+}
+
+// info[0] = outer sweeps that rotated something (+ the clean one that certified convergence), info[1] = converged
+__global__ void eigh_block_info_kernel(const int *counters, int max_sweeps, int *info) {
+    int s = 0;
+    while (s < max_sweeps && counters[s] != 0) ++s;
+    info[0] = s < max_sweeps ? s + 1 : max_sweeps;
+    info[1] = s < max_sweeps;
+}
+
 extern "C" int pk_eigh_psd_f64(void *stream, int32_t n, double *S_dev, int64_t lds_, double *evecs_dev,
                                int64_t ldv, double *evals_dev, int32_t max_sweeps, double tol,
                                int32_t *info_dev) {
@@ -260,13 +356,41 @@ extern "C" int pk_eigh_psd_f64(void *stream, int32_t n, double *S_dev, int64_t l
         }
         attr_set = true;
     }
+    hipStream_t st = pk_stream(stream);
     if (n <= EIGH_LDS_MAX) {
         hipLaunchKernelGGL(eigh_psd_kernel<true>, dim3(1), dim3(EIGH_THREADS), (size_t)n * n * sizeof(double),
-                           pk_stream(stream), n, S_dev, lds_, evecs_dev, ldv, evals_dev, max_sweeps, tol, info_dev);
-    } else {
-        hipLaunchKernelGGL(eigh_psd_kernel<false>, dim3(1), dim3(EIGH_THREADS), 0, pk_stream(stream), n, S_dev,
-                           lds_, evecs_dev, ldv, evals_dev, max_sweeps, tol, info_dev);
+                           st, n, S_dev, lds_, evecs_dev, ldv, evals_dev, max_sweeps, tol, info_dev);
+        PK_CHECK_LAUNCH("eigh_psd_kernel");
+        return PK_OK;
     }
-    PK_CHECK_LAUNCH("eigh_psd_kernel");
+    // block Jacobi: nb (even) blocks of w rows, two blocks at a time in LDS
+    int nb = 4;
+    while ((int64_t)2 * ((n + nb - 1) / nb) * n * 8 > EIGH_BLOCK_LDS) nb += 2;
+    const int w = (n + nb - 1) / nb;
+    const size_t lds_bytes = (size_t)2 * w * n * sizeof(double);
+    static bool attr_set_b = false;
+    if (!attr_set_b) {
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&eigh_block_round_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, EIGH_BLOCK_LDS);
+        if (e1 != hipSuccess) {
+            pk_set_error("pk_eigh_psd_f64: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e1));
+            return PK_E_LAUNCH;
+        }
+        attr_set_b = true;
+    }
+    if (max_sweeps > 30) max_sweeps = 30;   // every (sweep, round) is a launch, early-exit ones included
+    // the rotation counters of the outer sweeps live in evals_dev until the final pass writes the eigenvalues there
+    // (n > 136 doubles: room for every counter)
+    int *counters = reinterpret_cast<int *>(evals_dev);
+    hipLaunchKernelGGL(eigh_counters_init_kernel, dim3(1), dim3(64), 0, st, counters, max_sweeps + 1);
+    for (int sweep = 0; sweep < max_sweeps; ++sweep)
+        for (int round = 0; round < nb - 1; ++round)
+            hipLaunchKernelGGL(eigh_block_round_kernel, dim3(nb / 2), dim3(EIGH_THREADS), lds_bytes, st, n, S_dev, lds_, w, nb,
+                               round, sweep, counters, tol);
+    if (info_dev) hipLaunchKernelGGL(eigh_block_info_kernel, dim3(1), dim3(1), 0, st, counters, max_sweeps, info_dev);
+    // norms, ordering, signs: the tail of the one-workgroup kernel (no sweeps of its own)
+    hipLaunchKernelGGL(eigh_psd_kernel<false>, dim3(1), dim3(EIGH_THREADS), 0, st, n, S_dev, lds_, evecs_dev, ldv, evals_dev,
+                       0, tol, (int *)nullptr);
+    PK_CHECK_LAUNCH("eigh block kernels");
     return PK_OK;
 }
