@@ -159,6 +159,12 @@ class Bench:
         torch.cuda.empty_cache()
         c['gen_s'] = time.perf_counter() - t0
         c['cfg'] = cfg
+        if os.environ.get('PK_BENCH_SORT_USERS'):       # experiment: users ordered by activity before they are grouped by 32
+            cnt = np.diff(c['indptr'])
+            order = np.argsort(-cnt if os.environ['PK_BENCH_SORT_USERS'] == 'desc' else cnt, kind='stable')
+            pos = np.concatenate([np.arange(c['indptr'][r], c['indptr'][r + 1]) for r in order])
+            c['indices'], c['values'] = c['indices'][pos], c['values'][pos]
+            c['indptr'] = np.r_[0, np.cumsum(cnt[order])].astype(np.int64)
         return c
 
     # ---- build: everything between "host CSR of my users" and "ready to score" -------------------------------
