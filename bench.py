@@ -94,28 +94,37 @@ def spmm_alg_bytes(meta):
 
 
 def pmc_traffic(tag):
-    """HBM/fabric bytes per launch of the two dominant kernels from the committed rocprofv3 --pmc passes of this
-    command (profiles/r02_<tag>_pmc_{fetch,write}_size.txt; separate passes, as the tool requires; the files carry
-    the commit they were taken at).  FETCH_SIZE is doubled: both kernels read with 16 B/lane loads, which gfx950
-    tallies at half their size (MI355X_MICROARCH.md §HBM).  Returns {} when the summaries are not there."""
+    """HBM/fabric bytes of the two dominant kernels from the committed rocprofv3 --pmc passes of this command
+    (profiles/r02_<tag>_pmc_{fetch,write}_size.txt; separate passes, as the tool requires; the files carry the
+    commit they were taken at).  FETCH_SIZE is doubled: both kernels read with 16 B/lane loads, which gfx950 tallies
+    at half their size (MI355X_MICROARCH.md §HBM).  Returns {} when the summaries are not there.
+      score       bytes per launch of score_candidates_kernel
+      spmm_total  bytes of ALL build SpMM launches of the profiled run (fp64 dense block: every instance of
+                  spmm_csr_groups_kernel<.., double, ..> and of the column-per-lane spmm_csr_kernel); the profiled
+                  command builds twice (cold + warm), the caller divides by its product count"""
     out = {}
     try:
-        def per_launch(fn, kernel):
-            commit = None
-            val = None
+        def rows(fn):
+            commit, found = None, []
             for line in open(os.path.join(ROOT, 'profiles', fn)):
                 if line.startswith('# commit'):
                     commit = line.split()[-1]
-                if kernel in line and ('FETCH_SIZE' in line or 'WRITE_SIZE' in line):
-                    val = float(line.split()[-1]) * 1024.0     # KB -> bytes
-            return val, commit
-        for key, kern in (('score', 'score_candidates_kernel'), ('spmm', 'spmm_csr_groups_kernel')):
-            f, commit = per_launch('r02_%s_pmc_fetch_size.txt' % tag, kern)
-            w, _ = per_launch('r02_%s_pmc_write_size.txt' % tag, kern)
-            if f is not None and w is not None:
-                out[key] = 2.0 * f + w
-                out['commit'] = commit
-    except OSError:
+                if 'FETCH_SIZE' in line or 'WRITE_SIZE' in line:
+                    parts = line.split()
+                    found.append((line, int(parts[-3]), float(parts[-2]) * 1024.0, float(parts[-1]) * 1024.0))   # launches, sum, per launch (KB -> B)
+            return commit, found
+        cf, fetch = rows('r02_%s_pmc_fetch_size.txt' % tag)
+        _, write = rows('r02_%s_pmc_write_size.txt' % tag)
+        pick = lambda table, pred: [r for r in table if pred(r[0])]
+        sc_f, sc_w = pick(fetch, lambda l: 'score_candidates_kernel' in l), pick(write, lambda l: 'score_candidates_kernel' in l)
+        if sc_f and sc_w:
+            out['score'] = 2.0 * sc_f[0][3] + sc_w[0][3]
+        is_build_spmm = lambda l: ('spmm_csr_kernel<' in l) or ('spmm_csr_groups_kernel<' in l and 'double' in l)
+        bf, bw = pick(fetch, is_build_spmm), pick(write, is_build_spmm)
+        if bf and bw:
+            out['spmm_total'] = 2.0 * sum(r[2] for r in bf) + sum(r[2] for r in bw)
+        out['commit'] = cf
+    except (OSError, ValueError, IndexError):
         pass
     return out
 
@@ -538,9 +547,14 @@ def main():
         head['roofline']['traffic_note'] = ('HBM/fabric bytes per scoring pass = item-chunk launches x (2*FETCH_SIZE + WRITE_SIZE) of a '
                                             'separate rocprofv3 --pmc run of this command at commit %s (profiles/r02_%s_pmc_*.txt)'
                                             % (traffic.get('commit'), tag))
-    if 'roofline_build' in head and 'spmm' in traffic:
-        head['roofline_build']['traffic'] = traffic['spmm']
-        head['roofline_build']['traffic_note'] = '2*FETCH_SIZE + WRITE_SIZE per launch, same source'
+    if 'roofline_build' in head and 'spmm_total' in traffic:
+        rb = head['roofline_build']
+        products = 2 * head['build']['gramian_steps']          # A.X and A^T.Y of every Gramian step
+        rb['traffic'] = traffic['spmm_total'] / (2 * products)   # the profiled command builds twice (cold + warm)
+        rb['algorithmic_bytes_per_product'] = rb['bytes_total'] / products
+        rb['traffic_note'] = ('HBM/fabric bytes per SpMM PRODUCT (A.X, or A^T.Y = the sum of its user-block launches): '
+                              '(2*FETCH_SIZE + WRITE_SIZE) summed over every build SpMM launch of the profiled run / its %d '
+                              'products; same source' % (2 * products))
     out = {
         'metric': 'users scored/sec + SVD build time, ML-20M rank-50 PureSVD', 'value': head['value'], 'unit': 'users/s',
         'n_gpus': comm.world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': head['ms_per_step'],

@@ -137,7 +137,7 @@ def _cheb_degree(theta_top, b, spread, m_max):
 
 
 def svd_topk(ops, A, k, block=None, tol=1e-12, max_outer=200, m_max=24, spread=1e7, seed=0,
-             comm=None, want_u=False, verbose=False):
+             comm=None, want_u=False, verbose=False, even_lock=True):
     """Returns (U_local | None, sigma[k] desc, V [n_items x k], stats) as device tensors of `ops`.
 
     A: ops-level CSR of the LOCAL row shard (n_local x n_items).  Convergence: every one of the k
@@ -188,6 +188,8 @@ def svd_topk(ops, A, k, block=None, tol=1e-12, max_outer=200, m_max=24, spread=1
         n_new = 0
         while n_new < len(res_host) and res_host[n_new] <= thr:
             n_new += 1
+        if n_new < need and (n_new & 1) and even_lock:
+            n_new -= 1       # keep the active block width even: odd widths fall off the paired-column SpMM kernel
         if verbose and comm.rank == 0:
             worst = float(res_host[:max(need, 1)].max() / lam1) if need > 0 else 0.0
             print('[svd] it %3d lock %3d+%-3d active %3d  worst rel.res(first %d) %.2e' %
