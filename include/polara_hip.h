@@ -33,6 +33,7 @@ extern "C" {
 #define PK_E_INVALID (-1)  /* bad argument                                  */
 #define PK_E_LAUNCH (-2)   /* HIP launch / runtime error                    */
 #define PK_E_UNSUPPORTED (-3)
+#define PK_E_NOCONV (-4)   /* pk_svd_build: stopped at max_outer without converging (ARPACK's ArpackNoConvergence) */
 
 #define PK_VAL_F32 0
 #define PK_VAL_F64 1
@@ -355,6 +356,56 @@ int pk_ttm_f64(void *stream,
                const int32_t *idx1_dev, const int32_t *idx2_dev, const double *vals_dev,
                const double *u_dev, int64_t ldu, int32_t ra, const double *v_dev, int64_t ldv_, int32_t rb,
                double *res_dev, int64_t ldr, double *partial_dev);
+
+/* ------------------------------------------------------------------------------------------
+ * Coarse entry points: what a host in ANY language binds to replace the two hot calls of the
+ * reference without re-writing the solver or the scoring pipeline — `SVDModel.build` (models.py:835-855: svds of the
+ * training matrix) and `get_recommendations` (models.py:391-405 with 857-861, 494-519, 488-491).  Host pointers in,
+ * caller-allocated HOST buffers out; device memory lives behind opaque handles owned by the library; every call
+ * on one context is serialised by a mutex inside it (the reference's thread pool, models.py:374-382, is safe),
+ * distinct contexts are independent; no torch, no Python.  Errors: negative return code + pk_ctx_error(ctx).
+ * (The kernel-granular functions above stay the interface of polara_amd's own Python layer, which keeps its device
+ * arrays in torch tensors and shards over RCCL; the coarse calls are single-GPU.)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct pk_ctx pk_ctx;   /* one device + one stream + one mutex */
+typedef struct pk_mat pk_mat;   /* a CSR matrix resident on the device with its task plan (and, lazily, its user-blocked transpose) */
+typedef struct pk_build_stats {
+    int32_t outer;              /* outer iterations (Rayleigh-Ritz + filter) */
+    int32_t gramian_steps;      /* applications of A^T A to the block */
+    int32_t block;              /* block width */
+    int32_t converged;          /* 1 = every leading pair met tol * sigma_1^2 */
+    double final_rel_residual;  /* worst ||A^T A v - sigma^2 v|| / sigma_1^2 of the leading k pairs */
+} pk_build_stats;
+int pk_ctx_create(int32_t device, pk_ctx **ctx_out);
+void pk_ctx_destroy(pk_ctx *ctx);
+const char *pk_ctx_error(pk_ctx *ctx);
+/* host CSR (indptr int64[n_rows + 1], indices int32, values f32 | f64) -> device matrix.  The rows of a TRAINING matrix
+ * are users (models.py:160-177); for pk_score_topk the rows are the test users' known interactions with explicit
+ * zeros kept — they contribute nothing to the fold-in but still count as seen (models.py:198-203, 494-519). */
+int pk_mat_from_csr(pk_ctx *ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t *indptr_host,
+                    const int32_t *indices_host, const void *values_host, int32_t val_kind, pk_mat **mat_out);
+/* host COO triplets, any order, duplicates summed (what `coo_matrix(...).tocsr()` does, models.py:172-175); entry i has
+ * row rows_host[i * idx_stride], column cols_host[i * idx_stride] (idx_stride = 2 with cols = rows + 1 reads the
+ * interleaved [nnz x 2] index array of `to_coo`, data.py:794-817, as it is) */
+int pk_mat_from_coo(pk_ctx *ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t *rows_host,
+                    const int64_t *cols_host, int64_t idx_stride, const void *values_host, int32_t val_kind,
+                    pk_mat **mat_out);
+void pk_mat_free(pk_ctx *ctx, pk_mat *mat);
+int64_t pk_mat_nnz(const pk_mat *mat);   /* stored entries (after duplicate sums) */
+/* Top-k singular triplets of A (models.py:841-853): sigma_out[k] descending, V_out[n_cols * k] COLUMN-major (the
+ * F-ordered `vh.T` of models.py:849: column j = right singular vector j), U_out[n_rows * k] column-major or NULL
+ * (`return_factors`, models.py:841,853).  block = 0: k + max(14, 0.28 k) rounded up to 8; tol <= 0: 1e-12 (relative to
+ * sigma_1^2, on ||A^T A v - sigma^2 v||); max_outer <= 0: 200.  Returns PK_E_NOCONV (with the best available factors
+ * written) when it stops unconverged — the reference's ARPACK raises there. */
+int pk_svd_build(pk_ctx *ctx, pk_mat *A, int32_t k, int32_t block, double tol, int32_t max_outer, uint64_t seed,
+                 double *sigma_out, double *V_out, double *U_out, pk_build_stats *stats_out);
+/* Recommendations for the users of T (rows: test users, columns: the n_items items): scores = (T V) V^T, seen items
+ * (every stored entry of T) pushed below all unseen ones when filter_seen, topk item ids per user by descending score
+ * -> out_idx[n_users * topk] int64 row-major (the `top_recs` of models.py:400-405; -1 pads a user with fewer than topk
+ * candidates when filter_seen = 0 is impossible: with filter_seen seen items re-enter after the unseen ones exactly as
+ * models.py:510-519 orders them).  V_host: [n_items * K] column-major.  out_scores: fp64 scores of those items or NULL. */
+int pk_score_topk(pk_ctx *ctx, int64_t n_items, int32_t K, const double *V_host, pk_mat *T, int32_t topk,
+                  int32_t filter_seen, int64_t *out_idx, double *out_scores);
 
 #ifdef __cplusplus
 }

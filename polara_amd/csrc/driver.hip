@@ -1,0 +1,866 @@
+// Coarse, host-language-neutral entry points: pk_ctx_* / pk_mat_* / pk_svd_build / pk_score_topk.
+//
+// Everything above the kernels that polara_amd's Python layer does with torch tensors — the block Chebyshev-filtered
+// eigensolver of `SVDModel.build` (models.py:835-855 -> svds) and the recommendation pass of `get_recommendations`
+// (models.py:391-405, 857-861, 494-519, 488-491) — restated in C++ on top of the same kernel launchers, with
+// caller-allocated HOST outputs, device memory owned by the library behind opaque handles, and one mutex per context
+// so that the reference's thread-pool pattern (models.py:374-382) is safe.  A host in any language binds five
+// functions and needs neither Python nor torch (tests/test_coarse_abi.py drives them through ctypes alone).
+//
+// The algorithms are those of polara_amd/solver.py and polara_amd/scoring.py, function by function; only the memory
+// management differs (hipMalloc'd buffers instead of torch tensors) and the start block of the eigensolver comes from
+// a host Mersenne twister instead of torch's Philox stream (the converged factors agree to the solver tolerance).
+#include "pk_common.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <numeric>
+#include <random>
+#include <string>
+#include <vector>
+
+struct pk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    std::string err;
+};
+
+namespace {
+
+int fail(pk_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    pk_set_error("%s", buf);
+    return code;
+}
+#define CK(call)                                                          \
+    do {                                                                  \
+        int rc_ = (call);                                                 \
+        if (rc_ != PK_OK) {                                               \
+            ctx->err = pk_last_error();                                   \
+            return rc_;                                                   \
+        }                                                                 \
+    } while (0)
+#define HIPCK(call)                                                                              \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) return fail(ctx, PK_E_LAUNCH, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+struct Dev {   // one device allocation
+    void *p = nullptr;
+    size_t bytes = 0;
+    Dev() {}
+    explicit Dev(size_t b) { alloc(b); }
+    Dev(const Dev &) = delete;
+    Dev &operator=(const Dev &) = delete;
+    Dev(Dev &&o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+    Dev &operator=(Dev &&o) noexcept {
+        if (this != &o) {
+            release();
+            p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0;
+        }
+        return *this;
+    }
+    ~Dev() { release(); }
+    bool alloc(size_t b) {
+        release();
+        bytes = b;
+        if (b == 0) return true;
+        if (hipMalloc(&p, b) != hipSuccess) { p = nullptr; bytes = 0; return false; }
+        return true;
+    }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; } bytes = 0; }
+    template <typename T> T *as() const { return static_cast<T *>(p); }
+};
+
+struct DMat {   // dense row-major fp64 [n x l], contiguous
+    Dev buf;
+    int64_t n = 0;
+    int l = 0;
+    DMat() {}
+    DMat(int64_t n_, int l_) : buf((size_t)std::max<int64_t>(n_, 1) * std::max(l_, 1) * 8), n(n_), l(l_) {}
+    double *p() const { return buf.as<double>(); }
+    bool ok() const { return buf.p != nullptr; }
+};
+
+struct Plan {
+    Dev task_row, task_begin, task_end, task_slot, long_row, long_sb, long_se, row_first_task, row_long_index, partial;
+    int64_t n_tasks = 0, n_long = 0, n_slots = 0;
+    bool built = false;
+};
+
+struct Csr {
+    int64_t n_rows = 0, n_cols = 0, nnz = 0;
+    int val_kind = PK_VAL_F32;
+    Dev indptr, indices, values;
+    Plan plan;
+};
+
+struct Range { int64_t t0, nt, l0, nl; };
+
+__global__ void transpose_small_kernel(int n, const double *__restrict__ in, double *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * n) return;
+    const int r = i / n, c = i - r * n;
+    out[(int64_t)c * n + r] = in[i];
+}
+
+// fp32 image of the item factors for the approximate fold-in: columns 0..K-1 = fl32(V), column K = the row-norm bound
+__global__ void v32_image_kernel(int64_t n, int K, int ld32, const double *__restrict__ V, const float *__restrict__ bound,
+                                 float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * ld32) return;
+    const int64_t r = i / ld32;
+    const int c = (int)(i - r * ld32);
+    out[i] = c < K ? (float)V[r * K + c] : (c == K ? bound[r] : 0.0f);
+}
+
+__global__ void iota_i32_kernel(int64_t n, int32_t *out, int32_t *count) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int32_t)i;
+    if (i == 0 && count) *count = (int32_t)n;
+}
+
+}  // namespace
+
+struct pk_mat {
+    Csr A;
+    std::unique_ptr<Csr> Tb;          // user-blocked transpose image
+    int64_t rows_per_block = 0, n_blocks = 0;
+    std::vector<Range> block_ranges;
+    bool nonneg = true;
+};
+
+namespace {
+
+int build_plan(pk_ctx *ctx, Csr &M, int split = 1024) {
+    if (M.plan.built) return PK_OK;
+    hipStream_t st = ctx->stream;
+    Dev work((size_t)pk_row_plan_work_bytes(M.n_rows)), counts(3 * 8);
+    if (!work.p || !counts.p) return fail(ctx, PK_E_LAUNCH, "out of device memory (row plan)");
+    CK(pk_row_plan_count(st, M.n_rows, M.indptr.as<int64_t>(), split, counts.as<int64_t>(), work.p));
+    int64_t h[3];
+    HIPCK(hipMemcpyAsync(h, counts.p, 24, hipMemcpyDeviceToHost, st));
+    HIPCK(hipStreamSynchronize(st));
+    Plan &P = M.plan;
+    P.n_tasks = h[0]; P.n_long = h[1]; P.n_slots = h[2];
+    const size_t nt = (size_t)std::max<int64_t>(P.n_tasks, 1), nl = (size_t)std::max<int64_t>(P.n_long, 1);
+    if (!P.task_row.alloc(nt * 4) || !P.task_begin.alloc(nt * 8) || !P.task_end.alloc(nt * 8) || !P.task_slot.alloc(nt * 4) ||
+        !P.long_row.alloc(nl * 4) || !P.long_sb.alloc(nl * 4) || !P.long_se.alloc(nl * 4) ||
+        !P.row_first_task.alloc((size_t)(M.n_rows + 1) * 8) || !P.row_long_index.alloc((size_t)(M.n_rows + 1) * 8))
+        return fail(ctx, PK_E_LAUNCH, "out of device memory (row plan arrays)");
+    CK(pk_row_plan_fill(st, M.n_rows, M.indptr.as<int64_t>(), work.p, P.task_row.as<int32_t>(), P.task_begin.as<int64_t>(),
+                        P.task_end.as<int64_t>(), P.task_slot.as<int32_t>(), P.long_row.as<int32_t>(), P.long_sb.as<int32_t>(),
+                        P.long_se.as<int32_t>(), P.row_first_task.as<int64_t>(), P.row_long_index.as<int64_t>()));
+    HIPCK(hipStreamSynchronize(st));   // `work` dies with this scope
+    P.built = true;
+    return PK_OK;
+}
+
+int task_range(pk_ctx *ctx, Csr &M, int64_t lo, int64_t hi, Range *out) {
+    int64_t t[2], l[2];
+    hipStream_t st = ctx->stream;
+    HIPCK(hipMemcpyAsync(&t[0], M.plan.row_first_task.as<int64_t>() + lo, 8, hipMemcpyDeviceToHost, st));
+    HIPCK(hipMemcpyAsync(&t[1], M.plan.row_first_task.as<int64_t>() + hi, 8, hipMemcpyDeviceToHost, st));
+    HIPCK(hipMemcpyAsync(&l[0], M.plan.row_long_index.as<int64_t>() + lo, 8, hipMemcpyDeviceToHost, st));
+    HIPCK(hipMemcpyAsync(&l[1], M.plan.row_long_index.as<int64_t>() + hi, 8, hipMemcpyDeviceToHost, st));
+    HIPCK(hipStreamSynchronize(st));
+    *out = Range{t[0], t[1] - t[0], l[0], l[1] - l[0]};
+    return PK_OK;
+}
+
+// out[.. x nc] (+)= M X over the plan slice `rg`
+int spmm(pk_ctx *ctx, Csr &M, const void *X, int x_kind, int64_t ldx, int nc, double *out, int64_t ldo, const Range &rg,
+         int64_t row_base = 0, int accumulate = 0) {
+    Plan &P = M.plan;
+    const size_t xe = x_kind == PK_VAL_F64 ? 8 : 4;
+    for (int c0 = 0; c0 < nc; c0 += 256) {
+        const int w = std::min(256, nc - c0);
+        const size_t need = (size_t)P.n_slots * w * 8;
+        if (need > P.partial.bytes && !P.partial.alloc(need)) return fail(ctx, PK_E_LAUNCH, "out of device memory (spmm partials)");
+        CK(pk_spmm_csr_ex(ctx->stream, rg.nt, P.task_row.as<int32_t>() + rg.t0, P.task_begin.as<int64_t>() + rg.t0,
+                          P.task_end.as<int64_t>() + rg.t0, P.task_slot.as<int32_t>() + rg.t0, rg.nl,
+                          P.long_row.as<int32_t>() + rg.l0, P.long_sb.as<int32_t>() + rg.l0, P.long_se.as<int32_t>() + rg.l0,
+                          M.indices.as<int32_t>(), M.values.p, M.val_kind, static_cast<const char *>(X) + (size_t)c0 * xe, x_kind, ldx,
+                          w, out + c0, ldo, P.partial.as<double>(), row_base, accumulate));
+    }
+    return PK_OK;
+}
+
+int spmm_full(pk_ctx *ctx, Csr &M, const DMat &X, DMat &out) {
+    return spmm(ctx, M, X.p(), PK_VAL_F64, X.l, X.l, out.p(), out.l, Range{0, M.plan.n_tasks, 0, M.plan.n_long});
+}
+
+int ensure_blocked_transpose(pk_ctx *ctx, pk_mat *m) {
+    if (m->Tb) return PK_OK;
+    Csr &A = m->A;
+    int64_t rpb = std::max<int64_t>(16384, (int64_t)(64.0 * (double)A.n_cols * (double)A.n_rows / (double)std::max<int64_t>(A.nnz, 1)));
+    rpb = ((rpb + 4095) / 4096) * 4096;
+    rpb = std::min<int64_t>(rpb, std::max<int64_t>(A.n_rows, 1));
+    if (A.n_rows < 2 * 16384) rpb = std::max<int64_t>(A.n_rows, 1);          // small matrices: one block = the plain transpose
+    const int64_t nb = (A.n_rows + rpb - 1) / rpb;
+    auto T = std::make_unique<Csr>();
+    T->n_rows = nb * A.n_cols; T->n_cols = A.n_rows; T->nnz = A.nnz; T->val_kind = A.val_kind;
+    const size_t ve = A.val_kind == PK_VAL_F32 ? 4 : 8;
+    if (!T->indptr.alloc((size_t)(T->n_rows + 1) * 8) || !T->indices.alloc((size_t)std::max<int64_t>(A.nnz, 1) * 4) ||
+        !T->values.alloc((size_t)std::max<int64_t>(A.nnz, 1) * ve))
+        return fail(ctx, PK_E_LAUNCH, "out of device memory (transpose)");
+    Dev work((size_t)pk_csr_transpose_work_bytes(A.nnz));
+    if (!work.p) return fail(ctx, PK_E_LAUNCH, "out of device memory (transpose work)");
+    CK(pk_csr_transpose(ctx->stream, A.n_rows, A.n_cols, A.nnz, A.indptr.as<int64_t>(), A.indices.as<int32_t>(), A.values.p,
+                        A.val_kind, nb > 1 ? rpb : 0, T->indptr.as<int64_t>(), T->indices.as<int32_t>(), T->values.p, work.p));
+    HIPCK(hipStreamSynchronize(ctx->stream));
+    CK(build_plan(ctx, *T));
+    m->block_ranges.resize((size_t)nb);
+    for (int64_t b = 0; b < nb; ++b) CK(task_range(ctx, *T, b * A.n_cols, (b + 1) * A.n_cols, &m->block_ranges[(size_t)b]));
+    m->rows_per_block = rpb; m->n_blocks = nb;
+    m->Tb = std::move(T);
+    return PK_OK;
+}
+
+// Z = A^T Y, user block by user block (block b > 0 adds)
+int spmm_t(pk_ctx *ctx, pk_mat *m, const DMat &Y, DMat &Z) {
+    for (int64_t b = 0; b < m->n_blocks; ++b)
+        CK(spmm(ctx, *m->Tb, Y.p(), PK_VAL_F64, Y.l, Y.l, Z.p(), Z.l, m->block_ranges[(size_t)b], b * m->A.n_cols, b > 0));
+    return PK_OK;
+}
+
+// ---- dense helpers (each returns a fresh matrix through `out`) -------------------------------------------------------
+struct Solver {
+    pk_ctx *ctx;
+    hipStream_t st;
+    Dev gram_work;
+
+    int gram(const DMat &A, const DMat &B, DMat &G) {
+        G = DMat(A.l, B.l);
+        const size_t need = (size_t)pk_gram_work_bytes(A.n, A.l, B.l);
+        if (need > gram_work.bytes && !gram_work.alloc(need)) return fail(ctx, PK_E_LAUNCH, "out of device memory (gram)");
+        CK(pk_gram_f64(st, A.n, A.l, B.l, A.p(), A.l, B.p(), B.l, G.p(), G.l, gram_work.p));
+        return PK_OK;
+    }
+    int tsmm(const DMat &X, const DMat &C, DMat &out) {
+        out = DMat(X.n, C.l);
+        if (!out.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (tsmm)");
+        CK(pk_tsmm_f64(st, X.n, X.l, C.l, X.p(), X.l, C.p(), C.l, out.p(), out.l));
+        return PK_OK;
+    }
+    int axpbypcz(double a, const DMat &Z, double b, const DMat *Y, double c, const DMat *X, DMat &out) {
+        out = DMat(Z.n, Z.l);
+        if (!out.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (axpbypcz)");
+        CK(pk_axpbypcz_f64(st, Z.n * Z.l, a, Z.p(), b, Y ? Y->p() : nullptr, c, X ? X->p() : nullptr, out.p()));
+        return PK_OK;
+    }
+    int project_out(const DMat &X, const DMat &V, DMat &out) {   // X - V (V^T X)
+        DMat G, T;
+        CK(gram(V, X, G));
+        CK(tsmm(V, G, T));
+        return axpbypcz(1.0, X, -1.0, &T, 0.0, nullptr, out);
+    }
+    int to_host(const void *dev, void *host, size_t bytes) {
+        HIPCK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st));
+        HIPCK(hipStreamSynchronize(st));
+        return PK_OK;
+    }
+    int upload(const void *host, void *dev, size_t bytes) {
+        HIPCK(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, st));
+        HIPCK(hipStreamSynchronize(st));
+        return PK_OK;
+    }
+    // eigen-decomposition of a small PSD matrix: lam (host, descending), C (device, COLUMN j = j-th eigenvector)
+    int eigh(const DMat &S, std::vector<double> &lam, DMat &C, Dev &lam_dev) {
+        const int n = S.l;
+        DMat W(n, n), R(n, n);
+        Dev info(8);
+        if (!lam_dev.alloc((size_t)n * 8) || !W.ok() || !R.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (eigh)");
+        HIPCK(hipMemcpyAsync(W.p(), S.p(), (size_t)n * n * 8, hipMemcpyDeviceToDevice, st));
+        CK(pk_eigh_psd_f64(st, n, W.p(), n, R.p(), n, lam_dev.as<double>(), 0, 0.0, info.as<int32_t>()));
+        C = DMat(n, n);
+        hipLaunchKernelGGL(transpose_small_kernel, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, st, n, R.p(), C.p());
+        lam.resize((size_t)n);
+        return to_host(lam_dev.p, lam.data(), (size_t)n * 8);
+    }
+    int col_slice(const DMat &X, int c0, int c1, DMat &out) {
+        out = DMat(X.n, c1 - c0);
+        if (!out.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (col_slice)");
+        HIPCK(hipMemcpy2DAsync(out.p(), (size_t)(c1 - c0) * 8, X.p() + c0, (size_t)X.l * 8, (size_t)(c1 - c0) * 8, (size_t)X.n,
+                               hipMemcpyDeviceToDevice, st));
+        return PK_OK;
+    }
+    int hcat(const DMat *A, const DMat &B, DMat &out) {
+        const int la = A ? A->l : 0;
+        out = DMat(B.n, la + B.l);
+        if (!out.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (hcat)");
+        if (A) HIPCK(hipMemcpy2DAsync(out.p(), (size_t)out.l * 8, A->p(), (size_t)la * 8, (size_t)la * 8, (size_t)B.n, hipMemcpyDeviceToDevice, st));
+        HIPCK(hipMemcpy2DAsync(out.p() + la, (size_t)out.l * 8, B.p(), (size_t)B.l * 8, (size_t)B.l * 8, (size_t)B.n, hipMemcpyDeviceToDevice, st));
+        return PK_OK;
+    }
+    int randn(int64_t n, int l, uint64_t seed, DMat &out) {
+        out = DMat(n, l);
+        if (!out.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (randn)");
+        std::vector<double> h((size_t)n * l);
+        std::mt19937_64 gen(seed * 0x9E3779B97F4A7C15ull + 12345);
+        std::normal_distribution<double> nd(0.0, 1.0);
+        for (auto &v : h) v = nd(gen);
+        return upload(h.data(), out.p(), h.size() * 8);
+    }
+    int scale_cols_host(DMat &X, const std::vector<double> &s) {
+        Dev sd(s.size() * 8);
+        if (!sd.p) return fail(ctx, PK_E_LAUNCH, "out of device memory (scale)");
+        CK(upload(s.data(), sd.p, s.size() * 8));
+        CK(pk_scale_cols_f64(st, X.n, X.l, X.p(), X.l, sd.as<double>()));
+        HIPCK(hipStreamSynchronize(st));
+        return PK_OK;
+    }
+    // orthonormal basis of span(X) (orthogonal to Vlock) by eigen-whitening, `passes` times (solver._whiten)
+    int whiten(DMat &X, const DMat *Vlock, int passes) {
+        for (int p = 0; p < passes; ++p) {
+            if (Vlock && Vlock->l > 0) { DMat t; CK(project_out(X, *Vlock, t)); X = std::move(t); }
+            DMat G, C, Y;
+            std::vector<double> lam;
+            Dev lam_dev;
+            CK(gram(X, X, G));
+            CK(eigh(G, lam, C, lam_dev));
+            std::vector<double> s(lam.size());
+            const double floor_ = std::max(1e-300, lam.empty() ? 0.0 : lam[0] * 1e-30);
+            for (size_t i = 0; i < lam.size(); ++i) s[i] = 1.0 / std::sqrt(std::max(lam[i], floor_));
+            CK(scale_cols_host(C, s));
+            CK(tsmm(X, C, Y));
+            X = std::move(Y);
+        }
+        return PK_OK;
+    }
+    // solver._refill: basis of the numerical range of X completed by fresh random vectors
+    int refill(const DMat &X0, const DMat *Vlock, uint64_t seed, DMat &out) {
+        DMat X;
+        if (Vlock && Vlock->l > 0) CK(project_out(X0, *Vlock, X)); else CK(col_slice(X0, 0, X0.l, X));
+        DMat G, C;
+        std::vector<double> lam;
+        Dev lam_dev;
+        CK(gram(X, X, G));
+        CK(eigh(G, lam, C, lam_dev));
+        int ng = 0;
+        if (!lam.empty() && lam[0] > 0) for (double v : lam) ng += v > lam[0] * 1e-20;
+        DMat good;
+        if (ng) {
+            DMat Cg, Xg;
+            CK(col_slice(C, 0, ng, Cg));
+            std::vector<double> s((size_t)ng);
+            for (int i = 0; i < ng; ++i) s[(size_t)i] = 1.0 / std::sqrt(lam[(size_t)i]);
+            CK(scale_cols_host(Cg, s));
+            CK(tsmm(X, Cg, Xg));
+            CK(whiten(Xg, Vlock, 1));
+            good = std::move(Xg);
+        }
+        if (ng < X.l) {
+            DMat R;
+            CK(randn(X.n, X.l - ng, seed, R));
+            for (int it = 0; it < 2; ++it) {
+                if (ng) { DMat t; CK(project_out(R, good, t)); R = std::move(t); }
+                CK(whiten(R, Vlock, 1));
+            }
+            if (ng) CK(hcat(&good, R, out)); else out = std::move(R);
+        } else {
+            out = std::move(good);
+        }
+        return PK_OK;
+    }
+    // solver.orthonormalize: shifted CholeskyQR3, verified; rank-deficient blocks go to refill
+    int orthonormalize(const DMat &X, const DMat *Vlock, uint64_t seed, DMat &out) {
+        const int64_t m = X.n;
+        const int l = X.l;
+        const double u = 1.1102230246251565e-16;
+        Dev info(3 * 4);
+        if (!info.p) return fail(ctx, PK_E_LAUNCH, "out of device memory");
+        HIPCK(hipMemsetAsync(info.p, 0, 12, st));
+        DMat Y;
+        CK(col_slice(X, 0, l, Y));
+        Dev chol_work((size_t)std::max<int64_t>(pk_chol_work_bytes(l), 8));
+        for (int p = 0; p < 3; ++p) {
+            if (Vlock && Vlock->l > 0) { DMat t; CK(project_out(Y, *Vlock, t)); Y = std::move(t); }
+            DMat G, Rinv(l, l), Yn;
+            CK(gram(Y, Y, G));
+            CK(pk_chol_rinv_f64(st, l, G.p(), l, p == 0 ? 11.0 * ((double)m * l + (double)l * (l + 1)) * u : 0.0, Rinv.p(), l,
+                                chol_work.p, info.as<int32_t>() + p));
+            CK(tsmm(Y, Rinv, Yn));
+            Y = std::move(Yn);
+        }
+        DMat G;
+        CK(gram(Y, Y, G));
+        std::vector<double> g((size_t)l * l);
+        int32_t inf[3];
+        CK(to_host(G.p(), g.data(), g.size() * 8));
+        CK(to_host(info.p, inf, 12));
+        double err = 0.0;
+        for (int i = 0; i < l; ++i)
+            for (int j = 0; j < l; ++j) err = std::max(err, std::fabs(g[(size_t)i * l + j] - (i == j ? 1.0 : 0.0)));
+        if (inf[0] || inf[1] || inf[2] || !(err < 1e-8)) return refill(X, Vlock, seed, out);
+        out = std::move(Y);
+        return PK_OK;
+    }
+    int resid(const DMat &Z, const DMat &X, const Dev &theta_dev, std::vector<double> &res) {
+        const int nb = pk_resid_blocks(Z.n);
+        Dev part((size_t)nb * Z.l * 8);
+        if (!part.p) return fail(ctx, PK_E_LAUNCH, "out of device memory (resid)");
+        CK(pk_resid_colnorm2_f64(st, Z.n, Z.l, Z.p(), Z.l, X.p(), X.l, theta_dev.as<double>(), part.as<double>()));
+        std::vector<double> h((size_t)nb * Z.l);
+        CK(to_host(part.p, h.data(), h.size() * 8));
+        res.assign((size_t)Z.l, 0.0);
+        for (int b = 0; b < nb; ++b)
+            for (int j = 0; j < Z.l; ++j) res[(size_t)j] += h[(size_t)b * Z.l + j];
+        for (auto &v : res) v = std::sqrt(std::max(v, 0.0));
+        return PK_OK;
+    }
+};
+
+int cheb_degree(double theta_top, double b, double spread, int m_max) {
+    if (b <= 0.0) return 2;
+    const double x_top = 2.0 * theta_top / b - 1.0;
+    if (x_top <= 1.0 + 1e-12) return m_max;
+    const int m = (int)(std::log(2.0 * spread) / std::acosh(x_top));
+    return std::max(2, std::min(m_max, m));
+}
+
+int upload_csr(pk_ctx *ctx, Csr &M, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t *indptr, const int32_t *indices,
+               const void *values, int val_kind) {
+    M.n_rows = n_rows; M.n_cols = n_cols; M.nnz = nnz; M.val_kind = val_kind;
+    const size_t ve = val_kind == PK_VAL_F32 ? 4 : 8;
+    if (!M.indptr.alloc((size_t)(n_rows + 1) * 8) || !M.indices.alloc((size_t)std::max<int64_t>(nnz, 1) * 4) ||
+        !M.values.alloc((size_t)std::max<int64_t>(nnz, 1) * ve))
+        return fail(ctx, PK_E_LAUNCH, "out of device memory (matrix)");
+    HIPCK(hipMemcpyAsync(M.indptr.p, indptr, (size_t)(n_rows + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (nnz) {
+        HIPCK(hipMemcpyAsync(M.indices.p, indices, (size_t)nnz * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCK(hipMemcpyAsync(M.values.p, values, (size_t)nnz * ve, hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIPCK(hipStreamSynchronize(ctx->stream));
+    return PK_OK;
+}
+
+}  // namespace
+
+// ============================================================================================================
+extern "C" int pk_ctx_create(int32_t device, pk_ctx **out) {
+    if (!out) return PK_E_INVALID;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) {
+        pk_set_error("pk_ctx_create: device %d not available (%d visible)", device, n);
+        return PK_E_LAUNCH;
+    }
+    auto *ctx = new pk_ctx();
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess) {
+        delete ctx;
+        pk_set_error("pk_ctx_create: cannot create a stream on device %d", device);
+        return PK_E_LAUNCH;
+    }
+    *out = ctx;
+    return PK_OK;
+}
+
+extern "C" void pk_ctx_destroy(pk_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" const char *pk_ctx_error(pk_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+extern "C" int pk_mat_from_csr(pk_ctx *ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t *indptr,
+                               const int32_t *indices, const void *values, int32_t val_kind, pk_mat **out) {
+    if (!ctx || !out) return PK_E_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    if (n_rows < 1 || n_cols < 1 || nnz < 0 || !indptr || (nnz && (!indices || !values)) ||
+        (val_kind != PK_VAL_F32 && val_kind != PK_VAL_F64))
+        return fail(ctx, PK_E_INVALID, "pk_mat_from_csr: bad arguments");
+    if (indptr[0] != 0 || indptr[n_rows] != nnz) return fail(ctx, PK_E_INVALID, "pk_mat_from_csr: indptr does not span [0, nnz]");
+    for (int64_t p = 0; p < nnz; ++p)
+        if (indices[p] < 0 || indices[p] >= n_cols) return fail(ctx, PK_E_INVALID, "pk_mat_from_csr: column index out of bounds");
+    auto m = std::make_unique<pk_mat>();
+    int rc = upload_csr(ctx, m->A, n_rows, n_cols, nnz, indptr, indices, values, val_kind);
+    if (rc != PK_OK) return rc;
+    m->nonneg = true;
+    if (val_kind == PK_VAL_F32) { const float *v = static_cast<const float *>(values); for (int64_t p = 0; p < nnz; ++p) if (v[p] < 0) { m->nonneg = false; break; } }
+    else { const double *v = static_cast<const double *>(values); for (int64_t p = 0; p < nnz; ++p) if (v[p] < 0) { m->nonneg = false; break; } }
+    rc = build_plan(ctx, m->A);
+    if (rc != PK_OK) return rc;
+    *out = m.release();
+    return PK_OK;
+}
+
+extern "C" int pk_mat_from_coo(pk_ctx *ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t *rows, const int64_t *cols,
+                               int64_t idx_stride, const void *values, int32_t val_kind, pk_mat **out) {
+    if (!ctx || !out) return PK_E_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    if (n_rows < 1 || n_cols < 1 || nnz < 0 || idx_stride < 1 || (nnz && (!rows || !cols || !values)) ||
+        (val_kind != PK_VAL_F32 && val_kind != PK_VAL_F64))
+        return fail(ctx, PK_E_INVALID, "pk_mat_from_coo: bad arguments");
+    hipStream_t st = ctx->stream;
+    const size_t ve = val_kind == PK_VAL_F32 ? 4 : 8, n1 = (size_t)std::max<int64_t>(nnz, 1);
+    // the index arrays go up as they lie in host memory: one interleaved block (stride 2) or two plain arrays
+    const bool interleaved = idx_stride == 2 && cols == rows + 1;
+    Dev idx(interleaved ? n1 * 16 : n1 * 16), vals(n1 * ve), info(16), work((size_t)pk_coo_to_csr_work_bytes(nnz));
+    auto m = std::make_unique<pk_mat>();
+    Csr &A = m->A;
+    A.n_rows = n_rows; A.n_cols = n_cols; A.val_kind = val_kind;
+    if (!idx.p || !vals.p || !info.p || !work.p || !A.indptr.alloc((size_t)(n_rows + 1) * 8) || !A.indices.alloc(n1 * 4) || !A.values.alloc(n1 * ve))
+        return fail(ctx, PK_E_LAUNCH, "out of device memory (pk_mat_from_coo)");
+    const int64_t *r_dev, *c_dev;
+    int64_t stride_dev;
+    if (nnz) {
+        if (interleaved) {
+            HIPCK(hipMemcpyAsync(idx.p, rows, (size_t)nnz * 16, hipMemcpyHostToDevice, st));
+            r_dev = idx.as<int64_t>(); c_dev = r_dev + 1; stride_dev = 2;
+        } else {
+            HIPCK(hipMemcpy2DAsync(idx.p, 8, rows, (size_t)idx_stride * 8, 8, (size_t)nnz, hipMemcpyHostToDevice, st));
+            HIPCK(hipMemcpy2DAsync(idx.as<int64_t>() + nnz, 8, cols, (size_t)idx_stride * 8, 8, (size_t)nnz, hipMemcpyHostToDevice, st));
+            r_dev = idx.as<int64_t>(); c_dev = r_dev + nnz; stride_dev = 1;
+        }
+        HIPCK(hipMemcpyAsync(vals.p, values, (size_t)nnz * ve, hipMemcpyHostToDevice, st));
+    } else {
+        r_dev = c_dev = idx.as<int64_t>(); stride_dev = 1;
+    }
+    CK(pk_coo_to_csr(st, nnz, r_dev, c_dev, stride_dev, vals.p, val_kind, n_rows, n_cols, A.indptr.as<int64_t>(), A.indices.as<int32_t>(),
+                     A.values.p, info.as<int64_t>(), reinterpret_cast<int32_t *>(info.as<int64_t>() + 1), work.p));
+    int64_t h[2];
+    HIPCK(hipMemcpyAsync(h, info.p, 16, hipMemcpyDeviceToHost, st));
+    HIPCK(hipStreamSynchronize(st));
+    if ((int32_t)(h[1] & 0xffffffff)) return fail(ctx, PK_E_INVALID, "pk_mat_from_coo: index out of bounds");
+    A.nnz = h[0];
+    m->nonneg = true;
+    if (val_kind == PK_VAL_F32) { const float *v = static_cast<const float *>(values); for (int64_t p = 0; p < nnz; ++p) if (v[p] < 0) { m->nonneg = false; break; } }
+    else { const double *v = static_cast<const double *>(values); for (int64_t p = 0; p < nnz; ++p) if (v[p] < 0) { m->nonneg = false; break; } }
+    int rc = build_plan(ctx, A);
+    if (rc != PK_OK) return rc;
+    *out = m.release();
+    return PK_OK;
+}
+
+extern "C" void pk_mat_free(pk_ctx *ctx, pk_mat *m) {
+    if (!m) return;
+    if (ctx) {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+        delete m;
+    } else {
+        delete m;
+    }
+}
+
+extern "C" int64_t pk_mat_nnz(const pk_mat *m) { return m ? m->A.nnz : -1; }
+
+// ------------------------------------------------------------------------------------------------------------
+// pk_svd_build: polara_amd/solver.py::svd_topk restated (models.py:835-855)
+// ------------------------------------------------------------------------------------------------------------
+extern "C" int pk_svd_build(pk_ctx *ctx, pk_mat *A, int32_t k, int32_t block, double tol, int32_t max_outer, uint64_t seed,
+                            double *sigma_out, double *V_out, double *U_out, pk_build_stats *stats_out) {
+    if (!ctx || !A) return PK_E_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    const int64_t n_items = A->A.n_cols, n_users = A->A.n_rows;
+    if (k < 1 || k > n_items || !sigma_out || !V_out) return fail(ctx, PK_E_INVALID, "pk_svd_build: k must satisfy 0 < k <= n_items; outputs required");
+    if (tol <= 0) tol = 1e-12;
+    if (max_outer <= 0) max_outer = 200;
+    const int m_max = 24;
+    const double spread = 1e7;
+    int l = block;
+    if (l <= 0) {
+        const int over = std::max(14, (28 * k + 99) / 100);
+        l = ((k + over + 7) / 8) * 8;
+    }
+    l = (int)std::max<int64_t>(k, std::min<int64_t>(l, n_items));
+    if (l > 1024) return fail(ctx, PK_E_UNSUPPORTED, "pk_svd_build: block width %d beyond the 1024 of the dense kernels", l);
+    CK(ensure_blocked_transpose(ctx, A));
+    Solver S{ctx, ctx->stream, Dev()};
+    pk_build_stats stats;
+    memset(&stats, 0, sizeof(stats));
+    stats.block = l;
+
+    DMat X;
+    {
+        DMat R;
+        CK(S.randn(n_items, l, seed, R));
+        CK(S.orthonormalize(R, nullptr, 12345, X));
+    }
+    DMat Vlock;           // [n_items x n_lock]
+    bool have_lock = false;
+    std::vector<double> lam_lock, theta_host, res_host;
+    int n_lock = 0;
+    DMat Vk;
+    std::vector<double> lam_k;
+
+    auto gramian = [&](const DMat &Xb, DMat &Z) -> int {
+        DMat Y(n_users, Xb.l);
+        Z = DMat(n_items, Xb.l);
+        if (!Y.ok() || !Z.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (gramian step)");
+        CK(spmm_full(ctx, A->A, Xb, Y));
+        CK(spmm_t(ctx, A, Y, Z));
+        stats.gramian_steps += 1;
+        return PK_OK;
+    };
+
+    bool done = false;
+    for (int it = 0; it < max_outer && !done; ++it) {
+        stats.outer = it + 1;
+        // ---- Rayleigh-Ritz on the active block
+        DMat Y(n_users, X.l), H, Cm, Xr, Yr, Z(n_items, X.l);
+        if (!Y.ok() || !Z.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (Rayleigh-Ritz)");
+        CK(spmm_full(ctx, A->A, X, Y));
+        CK(S.gram(Y, Y, H));
+        Dev theta_dev;
+        CK(S.eigh(H, theta_host, Cm, theta_dev));
+        CK(S.tsmm(X, Cm, Xr));
+        CK(S.tsmm(Y, Cm, Yr));
+        X = std::move(Xr);
+        CK(spmm_t(ctx, A, Yr, Z));
+        stats.gramian_steps += 1;
+        CK(S.resid(Z, X, theta_dev, res_host));
+        const double lam1 = lam_lock.empty() ? theta_host[0] : lam_lock[0];
+        const int need = k - n_lock;
+        const double thr = tol * lam1;
+        int n_new = 0;
+        while (n_new < (int)res_host.size() && res_host[(size_t)n_new] <= thr) ++n_new;
+        if (n_new < need && (n_new & 1)) --n_new;       // even active width: the paired-column SpMM kernel
+        if (n_new >= need) {
+            DMat Xk;
+            CK(S.col_slice(X, 0, need, Xk));
+            CK(S.hcat(have_lock ? &Vlock : nullptr, Xk, Vk));
+            lam_k = lam_lock;
+            lam_k.insert(lam_k.end(), theta_host.begin(), theta_host.begin() + need);
+            stats.converged = 1;
+            done = true;
+            break;
+        }
+        if (n_new > 0 && X.l - n_new >= std::max(8, need - n_new)) {
+            DMat newV, Vl, Xa, Za;
+            CK(S.col_slice(X, 0, n_new, newV));
+            CK(S.hcat(have_lock ? &Vlock : nullptr, newV, Vl));
+            Vlock = std::move(Vl);
+            have_lock = true;
+            lam_lock.insert(lam_lock.end(), theta_host.begin(), theta_host.begin() + n_new);
+            n_lock += n_new;
+            CK(S.col_slice(X, n_new, X.l, Xa));
+            CK(S.col_slice(Z, n_new, Z.l, Za));
+            X = std::move(Xa);
+            Z = std::move(Za);
+            theta_host.erase(theta_host.begin(), theta_host.begin() + n_new);
+        }
+        // ---- Chebyshev filter on P B P, damping [0, b]
+        const double b = theta_host.back(), a0 = theta_host.front();
+        const int m = cheb_degree(a0, b, spread, m_max);
+        const double e = 0.5 * b, c = 0.5 * b;
+        DMat Yc;
+        if (e <= 0.0 || a0 <= c) {
+            if (have_lock) CK(S.project_out(Z, Vlock, Yc)); else Yc = std::move(Z);
+        } else {
+            double sigma = e / (a0 - c);
+            const double tau = 2.0 / sigma;
+            DMat Zp;
+            if (have_lock) CK(S.project_out(Z, Vlock, Zp)); else Zp = std::move(Z);
+            DMat Xc;
+            CK(S.col_slice(X, 0, X.l, Xc));
+            CK(S.axpbypcz(sigma / e, Zp, -c * sigma / e, &Xc, 0.0, nullptr, Yc));
+            for (int s = 2; s <= m; ++s) {
+                const double sigma_new = 1.0 / (tau - sigma);
+                DMat Zc, Yn;
+                CK(gramian(Yc, Zc));
+                if (have_lock) { DMat t; CK(S.project_out(Zc, Vlock, t)); Zc = std::move(t); }
+                CK(S.axpbypcz(2.0 * sigma_new / e, Zc, -2.0 * sigma_new * c / e, &Yc, -sigma * sigma_new, &Xc, Yn));
+                Xc = std::move(Yc);
+                Yc = std::move(Yn);
+                sigma = sigma_new;
+            }
+        }
+        DMat Xn;
+        CK(S.orthonormalize(Yc, have_lock ? &Vlock : nullptr, seed + 1 + (uint64_t)it, Xn));
+        X = std::move(Xn);
+    }
+    if (!done) {
+        const int take = std::min(k - n_lock, X.l);
+        DMat Xk;
+        CK(S.col_slice(X, 0, take, Xk));
+        CK(S.hcat(have_lock ? &Vlock : nullptr, Xk, Vk));
+        lam_k = lam_lock;
+        lam_k.insert(lam_k.end(), theta_host.begin(), theta_host.begin() + take);
+    }
+    const int kk = std::min<int>(k, Vk.l);
+    // to the host: sigma descending, V column-major (the F-ordered `vh.T` of models.py:849)
+    std::vector<double> vh((size_t)n_items * Vk.l);
+    CK(S.to_host(Vk.p(), vh.data(), vh.size() * 8));
+    std::vector<int> order((size_t)kk);
+    std::iota(order.begin(), order.end(), 0);
+    for (auto &v : lam_k) v = std::max(v, 0.0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b2) { return lam_k[(size_t)a] > lam_k[(size_t)b2]; });
+    for (int j = 0; j < kk; ++j) {
+        sigma_out[j] = std::sqrt(lam_k[(size_t)order[(size_t)j]]);
+        for (int64_t i = 0; i < n_items; ++i) V_out[(size_t)j * n_items + i] = vh[(size_t)i * Vk.l + order[(size_t)j]];
+    }
+    for (int j = kk; j < k; ++j) sigma_out[j] = 0.0;
+    double worst = 0.0;
+    if (!res_host.empty()) {
+        const int cnt = std::max(1, std::min<int>(k - n_lock, (int)res_host.size()));
+        for (int j = 0; j < cnt; ++j) worst = std::max(worst, res_host[(size_t)j]);
+    }
+    stats.final_rel_residual = worst / std::max(lam_k.empty() ? 1.0 : *std::max_element(lam_k.begin(), lam_k.end()), 1e-300);
+    if (U_out) {
+        // U = A V Sigma^-1, column-major [n_users x k]
+        DMat Vs(n_items, kk), U(n_users, kk);
+        if (!Vs.ok() || !U.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (user factors)");
+        std::vector<double> vr((size_t)n_items * kk);
+        for (int j = 0; j < kk; ++j)
+            for (int64_t i = 0; i < n_items; ++i) vr[(size_t)i * kk + j] = V_out[(size_t)j * n_items + i];
+        CK(S.upload(vr.data(), Vs.p(), vr.size() * 8));
+        CK(spmm_full(ctx, A->A, Vs, U));
+        std::vector<double> uh((size_t)n_users * kk);
+        CK(S.to_host(U.p(), uh.data(), uh.size() * 8));
+        for (int j = 0; j < kk; ++j) {
+            const double inv = sigma_out[j] > 0 ? 1.0 / sigma_out[j] : 0.0;
+            for (int64_t i = 0; i < n_users; ++i) U_out[(size_t)j * n_users + i] = uh[(size_t)i * kk + j] * inv;
+        }
+    }
+    if (stats_out) *stats_out = stats;
+    if (!stats.converged) {
+        fail(ctx, PK_E_NOCONV, "pk_svd_build: not converged in %d outer iterations (worst relative residual %.3e, tolerance %.1e); "
+                               "the best available factors were written", stats.outer, stats.final_rel_residual, tol);
+        return PK_E_NOCONV;
+    }
+    return PK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// pk_score_topk: polara_amd/scoring.py::recommend restated (models.py:391-405, 857-861, 494-519, 488-491)
+// ------------------------------------------------------------------------------------------------------------
+extern "C" int pk_score_topk(pk_ctx *ctx, int64_t n_items, int32_t K, const double *V_host, pk_mat *T, int32_t topk,
+                             int32_t filter_seen, int64_t *out_idx, double *out_scores) {
+    if (!ctx || !T) return PK_E_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    hipStream_t st = ctx->stream;
+    if (n_items != T->A.n_cols) return fail(ctx, PK_E_INVALID, "pk_score_topk: test matrix and item factors disagree on the number of items");
+    if (K < 1 || K > 8192 || !V_host || !out_idx || topk < 1) return fail(ctx, PK_E_INVALID, "pk_score_topk: bad arguments");
+    if (topk > n_items) return fail(ctx, PK_E_INVALID, "kth(=%lld) out of bounds (%lld)", (long long)(n_items - topk), (long long)n_items);
+    const int64_t n_users = T->A.n_rows;
+    Solver S{ctx, st, Dev()};
+    // serving order: items by descending factor norm (the pruning bound is a suffix maximum of these norms)
+    std::vector<double> norm((size_t)n_items, 0.0);
+    for (int j = 0; j < K; ++j)
+        for (int64_t i = 0; i < n_items; ++i) { const double v = V_host[(size_t)j * n_items + i]; norm[(size_t)i] += v * v; }
+    double vmax = 0.0;
+    for (auto &v : norm) { v = std::sqrt(v); vmax = std::max(vmax, v); }
+    if (!std::isfinite(vmax) || (vmax != 0.0 && !(vmax > 1e-30 && vmax < 1e30)))
+        return fail(ctx, PK_E_INVALID, "pk_score_topk: item factors with max row norm %g are outside the fp32 range of the candidate sweep", vmax);
+    std::vector<int32_t> inv((size_t)n_items), rank_of((size_t)n_items);
+    std::iota(inv.begin(), inv.end(), 0);
+    std::stable_sort(inv.begin(), inv.end(), [&](int32_t a, int32_t b) { return norm[(size_t)a] > norm[(size_t)b]; });
+    for (int64_t i = 0; i < n_items; ++i) rank_of[(size_t)inv[(size_t)i]] = (int32_t)i;
+    std::vector<double> vr((size_t)n_items * K);
+    for (int64_t i = 0; i < n_items; ++i)
+        for (int j = 0; j < K; ++j) vr[(size_t)i * K + j] = V_host[(size_t)j * n_items + inv[(size_t)i]];
+    DMat V(n_items, K);
+    if (!V.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (factors)");
+    CK(S.upload(vr.data(), V.p(), vr.size() * 8));
+    // the test rows in the serving order (rows re-sorted: canonical CSR)
+    Csr Ts;
+    Ts.n_rows = n_users; Ts.n_cols = n_items; Ts.nnz = T->A.nnz; Ts.val_kind = T->A.val_kind;
+    const size_t ve = Ts.val_kind == PK_VAL_F32 ? 4 : 8, n1 = (size_t)std::max<int64_t>(Ts.nnz, 1);
+    {
+        Dev cmap((size_t)n_items * 4), work((size_t)pk_csr_relabel_work_bytes(Ts.nnz));
+        if (!cmap.p || !work.p || !Ts.indptr.alloc((size_t)(n_users + 1) * 8) || !Ts.indices.alloc(n1 * 4) || !Ts.values.alloc(n1 * ve))
+            return fail(ctx, PK_E_LAUNCH, "out of device memory (test matrix)");
+        CK(S.upload(rank_of.data(), cmap.p, (size_t)n_items * 4));
+        HIPCK(hipMemcpyAsync(Ts.indptr.p, T->A.indptr.p, (size_t)(n_users + 1) * 8, hipMemcpyDeviceToDevice, st));
+        CK(pk_csr_relabel_sorted(st, n_users, n_items, Ts.nnz, T->A.indptr.as<int64_t>(), T->A.indices.as<int32_t>(), T->A.values.p,
+                                 Ts.val_kind, cmap.as<int32_t>(), Ts.indices.as<int32_t>(), Ts.values.p, work.p));
+        HIPCK(hipStreamSynchronize(st));
+    }
+    CK(build_plan(ctx, Ts));
+    const Range all{0, Ts.plan.n_tasks, 0, Ts.plan.n_long};
+    const int64_t *seen_ptr = filter_seen ? Ts.indptr.as<int64_t>() : nullptr;
+    const int32_t *seen_idx = filter_seen ? Ts.indices.as<int32_t>() : nullptr;
+    Dev out_i((size_t)n_users * topk * 8), out_s((size_t)n_users * topk * 8), flags((size_t)n_users * 4), lst((size_t)std::max<int64_t>(n_users, 1) * 4), cnt(4);
+    if (!out_i.p || !out_s.p || !flags.p || !lst.p || !cnt.p) return fail(ctx, PK_E_LAUNCH, "out of device memory (outputs)");
+    const int KC = (K <= 256) ? pk_candidate_capacity(topk) : 0;
+    const int n_wg = 128;
+    Dev exact_work((size_t)pk_exact_work_bytes(n_wg, n_items));
+    if (!exact_work.p) return fail(ctx, PK_E_LAUNCH, "out of device memory (exact rows)");
+    if (KC == 0) {
+        // beyond the fused sweep (topk > 52 or rank > 256): every user through the exact fp64 row kernel
+        DMat E(n_users, K);
+        if (!E.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (E)");
+        CK(spmm(ctx, Ts, V.p(), PK_VAL_F64, K, K, E.p(), K, all));
+        hipLaunchKernelGGL(iota_i32_kernel, dim3((unsigned)((n_users + 255) / 256)), dim3(256), 0, st, n_users, lst.as<int32_t>(), cnt.as<int32_t>());
+        CK(pk_score_exact_list_f64(st, n_wg, lst.as<int32_t>(), cnt.as<int32_t>(), n_items, K, V.p(), K, E.p(), K, seen_ptr, seen_idx, topk,
+                                   out_i.as<int64_t>(), out_s.as<double>(), exact_work.p));
+        HIPCK(hipStreamSynchronize(st));
+    } else {
+        // factor images: MFMA fragments, tile bounds, fp32 image with the norm column
+        Dev Vp((size_t)pk_pack_elems(n_items, K) * 4), tile_bound((size_t)((n_items + 31) / 32) * 4), tb_work((size_t)n_items * 4),
+            rowb((size_t)n_items * 4);
+        if (!Vp.p || !tile_bound.p || !tb_work.p || !rowb.p) return fail(ctx, PK_E_LAUNCH, "out of device memory (factor images)");
+        CK(pk_pack_frag_f32(st, n_items, K, V.p(), K, Vp.as<float>()));
+        CK(pk_tile_norm_bound_f32(st, n_items, K, V.p(), K, tb_work.as<float>(), tile_bound.as<float>()));
+        const int Kx_full = ((K + 1 + 3) / 4) * 4;
+        const bool approx = !out_scores && Kx_full <= 256 && T->nonneg;
+        const int Kx = approx ? Kx_full : K;
+        const int ld32 = Kx_full > 16 ? ((Kx_full + 31) / 32) * 32 : (Kx_full <= 4 ? 4 : Kx_full <= 8 ? 8 : 16);
+        Dev V32;
+        if (approx) {
+            if (!V32.alloc((size_t)n_items * ld32 * 4)) return fail(ctx, PK_E_LAUNCH, "out of device memory (fp32 image)");
+            CK(pk_row_norm_bound_f32(st, n_items, K, V.p(), K, rowb.as<float>()));
+            hipLaunchKernelGGL(v32_image_kernel, dim3((unsigned)(((size_t)n_items * ld32 + 255) / 256)), dim3(256), 0, st, n_items, K, ld32,
+                               V.p(), rowb.as<float>(), V32.as<float>());
+        }
+        DMat Ex(n_users, Kx);
+        if (!Ex.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (E)");
+        if (approx) CK(spmm(ctx, Ts, V32.p, PK_VAL_F32, ld32, Kx, Ex.p(), Kx, all));
+        else CK(spmm(ctx, Ts, V.p(), PK_VAL_F64, K, K, Ex.p(), Kx, all));
+        const double *w = approx ? Ex.p() + K : nullptr;
+        Dev Ep((size_t)pk_pack_elems(n_users, K) * 4), ub((size_t)n_users * 4);
+        if (!Ep.p || !ub.p) return fail(ctx, PK_E_LAUNCH, "out of device memory (E fragments)");
+        CK(pk_pack_frag_bound_f32(st, n_users, K, Ex.p(), Kx, Ep.as<float>(), ub.as<float>(), w, approx ? Kx : 0, 1.2e-7));
+        Dev tiles, ntiles;
+        if (filter_seen) {
+            if (!tiles.alloc(n1 * 8) || !ntiles.alloc((size_t)n_users * 4)) return fail(ctx, PK_E_LAUNCH, "out of device memory (seen tiles)");
+            CK(pk_seen_tiles_build(st, n_users, Ts.indptr.as<int64_t>(), Ts.indices.as<int32_t>(), 1, 0, tiles.as<uint64_t>(), ntiles.as<int32_t>()));
+        }
+        int splits = ((n_users + 31) / 32) * 8 > 2048 ? 1 : pk_score_splits(n_users, KC);
+        const int64_t n_pad = ((n_users + 31) / 32) * 32;
+        Dev state((size_t)pk_score_state_bytes(n_users, splits)), cs((size_t)splits * n_pad * KC * 4), ci((size_t)splits * n_pad * KC * 4);
+        if (!state.p || !cs.p || !ci.p) return fail(ctx, PK_E_LAUNCH, "out of device memory (candidates)");
+        CK(pk_score_candidates_f32(st, n_users, n_items, K, Vp.as<float>(), Ep.as<float>(), seen_ptr, tiles.as<uint64_t>(), ntiles.as<int32_t>(),
+                                   KC, splits, cs.as<float>(), ci.as<int32_t>(), state.p, 0, ub.as<float>(), tile_bound.as<float>()));
+        CK(pk_rescore_topk_rows_f64(st, n_users, nullptr, nullptr, n_users, n_items, K, V.p(), K, approx ? V32.as<float>() : nullptr, approx ? ld32 : 0,
+                                    Ex.p(), Kx, w, approx ? Kx : 0, 0, seen_ptr, KC, splits, cs.as<float>(), ci.as<int32_t>(), topk, vmax,
+                                    out_i.as<int64_t>(), out_s.as<double>(), flags.as<int32_t>()));
+        if (approx) {
+            CK(pk_flag_compact(st, n_users, flags.as<int32_t>(), 7, lst.as<int32_t>(), cnt.as<int32_t>()));
+            CK(pk_fold_rows_f64(st, n_users, lst.as<int32_t>(), cnt.as<int32_t>(), 0, Ts.indptr.as<int64_t>(), Ts.indices.as<int32_t>(), Ts.values.p,
+                                Ts.val_kind, V.p(), K, K, Ex.p(), Kx));
+            CK(pk_rescore_topk_rows_f64(st, n_users, lst.as<int32_t>(), cnt.as<int32_t>(), n_users, n_items, K, V.p(), K, nullptr, 0, Ex.p(), Kx, w, Kx,
+                                        1, seen_ptr, KC, splits, cs.as<float>(), ci.as<int32_t>(), topk, vmax, out_i.as<int64_t>(), out_s.as<double>(),
+                                        flags.as<int32_t>()));
+        }
+        CK(pk_flag_compact(st, n_users, flags.as<int32_t>(), 0x7fffffff, lst.as<int32_t>(), cnt.as<int32_t>()));
+        CK(pk_score_exact_list_f64(st, n_wg, lst.as<int32_t>(), cnt.as<int32_t>(), n_items, K, V.p(), K, Ex.p(), Kx, seen_ptr, seen_idx, topk,
+                                   out_i.as<int64_t>(), out_s.as<double>(), exact_work.p));
+        HIPCK(hipStreamSynchronize(st));   // every temporary above is still alive here
+    }
+    std::vector<int64_t> hi((size_t)n_users * topk);
+    CK(S.to_host(out_i.p, hi.data(), hi.size() * 8));
+    for (size_t e = 0; e < hi.size(); ++e) out_idx[e] = hi[e] >= 0 ? (int64_t)inv[(size_t)hi[e]] : -1;   // serving order -> caller's item ids
+    if (out_scores) CK(S.to_host(out_s.p, out_scores, (size_t)n_users * topk * 8));
+    return PK_OK;
+}
