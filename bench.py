@@ -499,6 +499,56 @@ class Bench:
         return res, recs
 
 
+def coarse_c_path(B, c, rank, topk):
+    """The coarse C entry points (include/polara_hip.h: pk_mat_from_csr / pk_svd_build / pk_score_topk) on the same
+    matrix: host CSR in, host factors and lists out, the library's own device memory — what a non-Python host gets."""
+    import ctypes as C
+    from polara_amd import _lib
+    lib = _lib.load()
+    n_users, n_items = c['shape']
+    nnz = int(c['indptr'][-1])
+    vp = C.c_void_p
+
+    class Stats(C.Structure):
+        _fields_ = [('outer', C.c_int32), ('gramian_steps', C.c_int32), ('block', C.c_int32), ('converged', C.c_int32),
+                    ('final_rel_residual', C.c_double)]
+    ctx, A = vp(), vp()
+    _lib.check(lib.pk_ctx_create(torch.cuda.current_device(), C.byref(ctx)), 'pk_ctx_create')
+    ptr = lambda a: a.ctypes.data_as(vp)
+    indptr, indices, values = (np.ascontiguousarray(c['indptr'], dtype=np.int64), np.ascontiguousarray(c['indices'], dtype=np.int32),
+                               np.ascontiguousarray(c['values'], dtype=np.float32))
+    out = {}
+    t0 = time.perf_counter()
+    rc = lib.pk_mat_from_csr(ctx, n_users, n_items, nnz, ptr(indptr), ptr(indices), ptr(values), 0, C.byref(A))
+    assert rc == 0, lib.pk_ctx_error(ctx)
+    out['mat_from_csr_s'] = time.perf_counter() - t0
+    sigma = np.empty(rank)
+    V = np.empty((n_items, rank), order='F')
+    st = Stats()
+    for tag in ('cold', 'warm'):
+        t0 = time.perf_counter()
+        rc = lib.pk_svd_build(ctx, A, rank, 0, 0.0, 0, 0, ptr(sigma), ptr(V), None, C.byref(st))
+        assert rc == 0, lib.pk_ctx_error(ctx)
+        out['svd_build_%s_s' % tag] = time.perf_counter() - t0
+    out.update(gramian_steps=st.gramian_steps, outer=st.outer, final_rel_residual=st.final_rel_residual)
+    recs = np.empty((n_users, topk), dtype=np.int64)
+    for tag in ('first', 'again'):
+        t0 = time.perf_counter()
+        rc = lib.pk_score_topk(ctx, n_items, rank, ptr(V), A, topk, 1, ptr(recs), None)
+        assert rc == 0, lib.pk_ctx_error(ctx)
+        out['score_topk_%s_s' % tag] = time.perf_counter() - t0
+    out['users_per_s'] = n_users / out['score_topk_again_s']
+    n_chk = min(n_users, 5000)
+    t_cpu, cpu_recs = B.cpu_scoring(c, np.ascontiguousarray(V), topk, n_chk)
+    out['gpu_vs_cpu_identical_rows'] = float((recs[:n_chk] == cpu_recs).all(axis=1).mean())
+    out['note'] = ('pk_svd_build / pk_score_topk: every call takes host arrays, allocates its device buffers (hipMalloc) and returns host '
+                   'arrays; pk_score_topk also re-orders the catalogue by factor norm, re-sorts the test rows and builds the factor images and '
+                   'seen-tile streams inside the call')
+    lib.pk_mat_free(ctx, A)
+    lib.pk_ctx_destroy(ctx)
+    return out
+
+
 def main():
     args = parse()
     B = Bench(args)
@@ -520,6 +570,7 @@ def main():
         # the plugin surface, end to end
         mp, _ = B.model_path(c, headline_rank, headline_topk)
         subs['model_path'] = mp
+        subs['coarse_c_abi'] = coarse_c_path(B, c, headline_rank, headline_topk)
         # BASELINE.json configs[2]: rank 100, top-20
         s = B.measure(c, 'ml20m', 100, 20, sub_steps, 2, cpu=not args.no_cpu_baseline, cpu_users=5000, cpu_build=False)
         subs['configs2_ml20m_rank100_top20'] = s
