@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <numeric>
@@ -22,11 +23,46 @@
 #include <string>
 #include <vector>
 
+// Device memory of a context: freed blocks are kept and handed out again (best fit within 25 %): every buffer of the
+// solver lives for a few launches on the context's ONE stream, so reuse is stream-ordered and a build does not pay a
+// hipMalloc / hipFree (each a device synchronisation) per temporary.
+struct DevPool {
+    std::multimap<size_t, void *> free_blocks;
+    void *get(size_t &bytes) {          // may hand out a larger block: `bytes` becomes its size
+        auto it = free_blocks.lower_bound(bytes);
+        if (it != free_blocks.end() && it->first <= bytes + bytes / 4 + 4096) {
+            void *p = it->second;
+            bytes = it->first;
+            free_blocks.erase(it);
+            return p;
+        }
+        void *p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) {
+            trim();                                   // give the cached blocks back and try once more
+            if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+        }
+        return p;
+    }
+    void put(void *p, size_t bytes) { free_blocks.emplace(bytes, p); }
+    void trim() {
+        for (auto &kv : free_blocks) (void)hipFree(kv.second);
+        free_blocks.clear();
+    }
+};
+
 struct pk_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::mutex mu;
     std::string err;
+    DevPool pool;
+};
+
+static thread_local DevPool *g_pool = nullptr;   // the pool of the context whose call runs on this thread
+struct PoolScope {
+    DevPool *prev;
+    explicit PoolScope(pk_ctx *ctx) : prev(g_pool) { g_pool = &ctx->pool; }
+    ~PoolScope() { g_pool = prev; }
 };
 
 namespace {
@@ -55,18 +91,20 @@ int fail(pk_ctx *ctx, int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return fail(ctx, PK_E_LAUNCH, "%s: %s", #call, hipGetErrorString(e_)); \
     } while (0)
 
-struct Dev {   // one device allocation
+struct Dev {   // one device allocation (from the calling context's pool)
     void *p = nullptr;
     size_t bytes = 0;
+    size_t cap = 0;
+    DevPool *pool = nullptr;
     Dev() {}
     explicit Dev(size_t b) { alloc(b); }
     Dev(const Dev &) = delete;
     Dev &operator=(const Dev &) = delete;
-    Dev(Dev &&o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+    Dev(Dev &&o) noexcept : p(o.p), bytes(o.bytes), cap(o.cap), pool(o.pool) { o.p = nullptr; o.bytes = o.cap = 0; }
     Dev &operator=(Dev &&o) noexcept {
         if (this != &o) {
             release();
-            p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0;
+            p = o.p; bytes = o.bytes; cap = o.cap; pool = o.pool; o.p = nullptr; o.bytes = o.cap = 0;
         }
         return *this;
     }
@@ -75,10 +113,20 @@ struct Dev {   // one device allocation
         release();
         bytes = b;
         if (b == 0) return true;
-        if (hipMalloc(&p, b) != hipSuccess) { p = nullptr; bytes = 0; return false; }
+        pool = g_pool;
+        cap = ((b + 65535) / 65536) * 65536;
+        if (pool) p = pool->get(cap);
+        else if (hipMalloc(&p, cap) != hipSuccess) p = nullptr;
+        if (!p) { bytes = cap = 0; return false; }
         return true;
     }
-    void release() { if (p) { (void)hipFree(p); p = nullptr; } bytes = 0; }
+    void release() {
+        if (p) {
+            if (pool) pool->put(p, cap); else (void)hipFree(p);
+            p = nullptr;
+        }
+        bytes = cap = 0;
+    }
     template <typename T> T *as() const { return static_cast<T *>(p); }
 };
 
@@ -470,6 +518,7 @@ extern "C" void pk_ctx_destroy(pk_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    ctx->pool.trim();
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -480,6 +529,7 @@ extern "C" int pk_mat_from_csr(pk_ctx *ctx, int64_t n_rows, int64_t n_cols, int6
                                const int32_t *indices, const void *values, int32_t val_kind, pk_mat **out) {
     if (!ctx || !out) return PK_E_INVALID;
     std::lock_guard<std::mutex> lock(ctx->mu);
+    PoolScope pool_scope(ctx);
     (void)hipSetDevice(ctx->device);
     if (n_rows < 1 || n_cols < 1 || nnz < 0 || !indptr || (nnz && (!indices || !values)) ||
         (val_kind != PK_VAL_F32 && val_kind != PK_VAL_F64))
@@ -503,6 +553,7 @@ extern "C" int pk_mat_from_coo(pk_ctx *ctx, int64_t n_rows, int64_t n_cols, int6
                                int64_t idx_stride, const void *values, int32_t val_kind, pk_mat **out) {
     if (!ctx || !out) return PK_E_INVALID;
     std::lock_guard<std::mutex> lock(ctx->mu);
+    PoolScope pool_scope(ctx);
     (void)hipSetDevice(ctx->device);
     if (n_rows < 1 || n_cols < 1 || nnz < 0 || idx_stride < 1 || (nnz && (!rows || !cols || !values)) ||
         (val_kind != PK_VAL_F32 && val_kind != PK_VAL_F64))
@@ -554,9 +605,9 @@ extern "C" void pk_mat_free(pk_ctx *ctx, pk_mat *m) {
         std::lock_guard<std::mutex> lock(ctx->mu);
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
-        delete m;
+        delete m;                        // its blocks go back to the context's pool
     } else {
-        delete m;
+        delete m;                        // only valid while the creating context is alive
     }
 }
 
@@ -569,6 +620,7 @@ extern "C" int pk_svd_build(pk_ctx *ctx, pk_mat *A, int32_t k, int32_t block, do
                             double *sigma_out, double *V_out, double *U_out, pk_build_stats *stats_out) {
     if (!ctx || !A) return PK_E_INVALID;
     std::lock_guard<std::mutex> lock(ctx->mu);
+    PoolScope pool_scope(ctx);
     (void)hipSetDevice(ctx->device);
     const int64_t n_items = A->A.n_cols, n_users = A->A.n_rows;
     if (k < 1 || k > n_items || !sigma_out || !V_out) return fail(ctx, PK_E_INVALID, "pk_svd_build: k must satisfy 0 < k <= n_items; outputs required");
@@ -747,6 +799,7 @@ extern "C" int pk_score_topk(pk_ctx *ctx, int64_t n_items, int32_t K, const doub
                              int32_t filter_seen, int64_t *out_idx, double *out_scores) {
     if (!ctx || !T) return PK_E_INVALID;
     std::lock_guard<std::mutex> lock(ctx->mu);
+    PoolScope pool_scope(ctx);
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
     if (n_items != T->A.n_cols) return fail(ctx, PK_E_INVALID, "pk_score_topk: test matrix and item factors disagree on the number of items");
