@@ -8,8 +8,9 @@
 // functions and needs neither Python nor torch (tests/test_coarse_abi.py drives them through ctypes alone).
 //
 // The algorithms are those of polara_amd/solver.py and polara_amd/scoring.py, function by function; only the memory
-// management differs (hipMalloc'd buffers instead of torch tensors) and the start block of the eigensolver comes from
-// a host Mersenne twister instead of torch's Philox stream (the converged factors agree to the solver tolerance).
+// management differs (a per-context pool of hipMalloc'd blocks instead of torch tensors) and the start block of the
+// eigensolver comes from a counter-based device generator instead of torch's Philox stream (the converged factors agree
+// to the solver tolerance).
 #include "pk_common.h"
 #include <algorithm>
 #include <cmath>
@@ -170,6 +171,24 @@ __global__ void v32_image_kernel(int64_t n, int K, int ld32, const double *__res
     const int64_t r = i / ld32;
     const int c = (int)(i - r * ld32);
     out[i] = c < K ? (float)V[r * K + c] : (c == K ? bound[r] : 0.0f);
+}
+
+// standard normal start block: counter-based (splitmix64 of seed and element index -> two uniforms -> Box-Muller), so
+// the block depends on (seed, n, l) only — no host generator, no 14 MB upload
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__global__ void randn_kernel(int64_t n_elems, uint64_t seed, double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_elems) return;
+    const uint64_t a = splitmix64(seed * 0xD1342543DE82EF95ull + (uint64_t)(2 * i));
+    const uint64_t b = splitmix64(seed * 0xD1342543DE82EF95ull + (uint64_t)(2 * i + 1));
+    const double u1 = ((double)(a >> 11) + 1.0) * (1.0 / 9007199254740993.0);     // (0, 1)
+    const double u2 = (double)(b >> 11) * (1.0 / 9007199254740992.0);             // [0, 1)
+    out[i] = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
 }
 
 __global__ void iota_i32_kernel(int64_t n, int32_t *out, int32_t *count) {
@@ -354,11 +373,9 @@ struct Solver {
     int randn(int64_t n, int l, uint64_t seed, DMat &out) {
         out = DMat(n, l);
         if (!out.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (randn)");
-        std::vector<double> h((size_t)n * l);
-        std::mt19937_64 gen(seed * 0x9E3779B97F4A7C15ull + 12345);
-        std::normal_distribution<double> nd(0.0, 1.0);
-        for (auto &v : h) v = nd(gen);
-        return upload(h.data(), out.p(), h.size() * 8);
+        const int64_t ne = n * l;
+        hipLaunchKernelGGL(randn_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, ne, seed, out.p());
+        return PK_OK;
     }
     int scale_cols_host(DMat &X, const std::vector<double> &s) {
         Dev sd(s.size() * 8);
