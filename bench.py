@@ -229,7 +229,8 @@ class Bench:
             V = V[order2].contiguous()
             A_score = ops.csr_relabel_cols(A, rank2, sort=os.environ.get('PK_BENCH_SORT_SERVING', '1') == '1')
         F = scoring.FactorImage(ops, V)
-        A_score.seen_tiles()
+        # the test rows grouped by activity (what the scoring pass sweeps) and their seen-tile streams
+        (A_score.by_activity()[0] if A_score.shape[0] >= scoring.ORDER_USERS_MIN else A_score).seen_tiles()
         lap('reindex_and_images_s')
         t['total_s'] = marks[-1] - marks[0]
         state = dict(A=A_score, F=F, V=V, sigma=sigma, order2=order2, rank_of=rank_of, inv_order=inv_order, lo=lo, hi=hi,

@@ -130,6 +130,13 @@ int64_t pk_csr_relabel_work_bytes(int64_t nnz);
 int pk_csr_relabel_sorted(void *stream, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t *indptr_dev,
                           const int32_t *indices_dev, const void *values_dev, int val_kind, const int32_t *col_map_dev,
                           int32_t *indices_out_dev, void *values_out_dev, void *work_dev);
+/* The rows of a CSR ordered by DESCENDING stored-entry count (stable: ties by row id): perm_out[r] = the input row that
+ * becomes row r.  The scoring pass groups 32 consecutive users per wave and a group sweeps the catalogue until its LAST
+ * user is done; users of similar activity finish at similar depths (ML-20M-shaped: 12.3 -> 9.5 % of the tiles scored). */
+int64_t pk_csr_rows_by_length_work_bytes(int64_t n_rows);
+int pk_csr_rows_by_length(void *stream, int64_t n_rows, int64_t nnz, const int64_t *indptr_dev, const int32_t *indices_dev,
+                          const void *values_dev, int val_kind, int32_t *perm_out_dev, int64_t *new_indptr_dev,
+                          int32_t *indices_out_dev, void *values_out_dev, void *work_dev);
 /* counts[k] = number of keys equal to k (item popularity: the internal item order of the device path) */
 int pk_count_i32(void *stream, int64_t n, const int32_t *keys_dev, int64_t n_bins, int32_t *counts_dev);
 /* Wave-task plan of a CSR (one 64-lane wave per task, rows longer than `split` cut into near-equal tasks whose

@@ -531,6 +531,86 @@ extern "C" int pk_csr_relabel_sorted(void *stream, int64_t n_rows, int64_t n_col
     return PK_OK;
 }
 
+// -------- rows of a CSR in another order (users by activity before they are grouped by 32 for the sweep) ---------------------
+__global__ __launch_bounds__(256) void row_len_keys_kernel(int64_t n_rows, const int64_t *__restrict__ indptr, uint32_t max_len,
+                                                           uint32_t *__restrict__ keys, uint32_t *__restrict__ rows) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_rows) return;
+    const int64_t len = indptr[r + 1] - indptr[r];
+    keys[r] = max_len - (uint32_t)(len < (int64_t)max_len ? len : (int64_t)max_len);    // ascending key = descending length
+    rows[r] = (uint32_t)r;
+}
+
+__global__ __launch_bounds__(256) void perm_counts_kernel(int64_t n_rows, const int64_t *__restrict__ indptr,
+                                                          const uint32_t *__restrict__ perm, int32_t *__restrict__ counts) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_rows) return;
+    const uint32_t s = perm[r];
+    counts[r] = (int32_t)(indptr[s + 1] - indptr[s]);
+}
+
+template <typename VT>
+__global__ __launch_bounds__(256) void permute_rows_kernel(int64_t nnz, int64_t n_rows, const int64_t *__restrict__ new_indptr,
+                                                           const int64_t *__restrict__ indptr, const uint32_t *__restrict__ perm,
+                                                           const int32_t *__restrict__ indices, const VT *__restrict__ values,
+                                                           int32_t *__restrict__ indices_out, VT *__restrict__ values_out) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= nnz) return;
+    int64_t lo = 0, hi = n_rows;           // largest r with new_indptr[r] <= p
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (new_indptr[mid] <= p) lo = mid; else hi = mid;
+    }
+    const int64_t src = indptr[perm[lo]] + (p - new_indptr[lo]);
+    indices_out[p] = indices[src];
+    values_out[p] = values[src];
+}
+
+extern "C" int64_t pk_csr_rows_by_length_work_bytes(int64_t n_rows) {
+    const int64_t n = n_rows > 0 ? n_rows : 1;
+    return 4 * (((n * 4 + 255) / 256) * 256) + pk_radix_work_bytes(n) + pk_scan_work_bytes(n) + 512;
+}
+
+/* perm_out[r] = the row of the input that becomes row r when rows are ordered by DESCENDING stored-entry count (ties by
+ * row id: the sort is stable); new_indptr / indices_out / values_out: the CSR with its rows in that order (rows keep
+ * their internal order). */
+extern "C" int pk_csr_rows_by_length(void *stream, int64_t n_rows, int64_t nnz, const int64_t *indptr_dev,
+                                     const int32_t *indices_dev, const void *values_dev, int val_kind, int32_t *perm_out_dev,
+                                     int64_t *new_indptr_dev, int32_t *indices_out_dev, void *values_out_dev, void *work_dev) {
+    PK_REQUIRE(n_rows >= 1 && n_rows < 0xffffffffll && nnz >= 0 && indptr_dev && perm_out_dev && new_indptr_dev && work_dev,
+               "pk_csr_rows_by_length: bad arguments");
+    PK_REQUIRE(val_kind == PK_VAL_F32 || val_kind == PK_VAL_F64, "pk_csr_rows_by_length: bad val_kind %d", val_kind);
+    hipStream_t st = pk_stream(stream);
+    char *w = static_cast<char *>(work_dev);
+    const int64_t a4 = ((n_rows * 4 + 255) / 256) * 256;
+    uint32_t *keys = reinterpret_cast<uint32_t *>(w), *keys_t = reinterpret_cast<uint32_t *>(w + a4);
+    uint32_t *rows = reinterpret_cast<uint32_t *>(w + 2 * a4), *rows_t = reinterpret_cast<uint32_t *>(w + 3 * a4);
+    void *rwork = w + 4 * a4;
+    void *swork = w + 4 * a4 + ((pk_radix_work_bytes(n_rows) + 255) / 256) * 256;
+    const unsigned nb = (unsigned)pk_ceil_div(n_rows, 256);
+    const uint32_t max_len = (1u << 24) - 1;        // longer rows tie at the front
+    hipLaunchKernelGGL(row_len_keys_kernel, dim3(nb), dim3(256), 0, st, n_rows, indptr_dev, max_len, keys, rows);
+    int in_tmp = 0;
+    pk_radix_sort<uint32_t>(st, n_rows, keys, rows, keys_t, rows_t, 24, rwork, &in_tmp);
+    const uint32_t *perm = in_tmp ? rows_t : rows;
+    (void)hipMemcpyAsync(perm_out_dev, perm, (size_t)n_rows * 4, hipMemcpyDeviceToDevice, st);
+    int32_t *counts = reinterpret_cast<int32_t *>(in_tmp ? keys : keys_t);   // a key buffer that is free now
+    hipLaunchKernelGGL(perm_counts_kernel, dim3(nb), dim3(256), 0, st, n_rows, indptr_dev, perm, counts);
+    pk_scan_launch(st, n_rows, counts, new_indptr_dev, swork);
+    if (nnz > 0) {
+        PK_REQUIRE(indices_dev && values_dev && indices_out_dev && values_out_dev, "pk_csr_rows_by_length: null buffer");
+        const unsigned ne = (unsigned)pk_ceil_div(nnz, 256);
+        if (val_kind == PK_VAL_F32)
+            hipLaunchKernelGGL(permute_rows_kernel<float>, dim3(ne), dim3(256), 0, st, nnz, n_rows, new_indptr_dev, indptr_dev, perm,
+                               indices_dev, static_cast<const float *>(values_dev), indices_out_dev, static_cast<float *>(values_out_dev));
+        else
+            hipLaunchKernelGGL(permute_rows_kernel<double>, dim3(ne), dim3(256), 0, st, nnz, n_rows, new_indptr_dev, indptr_dev, perm,
+                               indices_dev, static_cast<const double *>(values_dev), indices_out_dev, static_cast<double *>(values_out_dev));
+    }
+    PK_CHECK_LAUNCH("csr_rows_by_length kernels");
+    return PK_OK;
+}
+
 // -------- per-column counts (item popularity) ------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void count_i32_kernel(int64_t n, const int32_t *__restrict__ keys, int64_t n_bins,
                                                         int32_t *__restrict__ counts) {

@@ -122,6 +122,13 @@ class DeviceCSR:
         the blocking to matter, else the plain transpose."""
         return self.T_blocked() if self.shape[0] >= 2 * BlockedTranspose.MIN_ROWS_PER_BLOCK else self.T
 
+    def by_activity(self):
+        """(this matrix with its rows ordered by descending entry count, perm int64: row r of the result = row perm[r]
+        of this one) — a format image like the transpose, built once (pk_csr_rows_by_length) and cached."""
+        if getattr(self, '_by_activity', None) is None:
+            self._by_activity = self.ops.csr_rows_by_length(self)
+        return self._by_activity
+
     def T_blocked(self, rows_per_block=None):
         """The transposed product cut into row (user) blocks: see BlockedTranspose."""
         if getattr(self, '_Tb', None) is None or (rows_per_block and self._Tb.rows_per_block != rows_per_block):
@@ -156,6 +163,7 @@ class DeviceCSR:
         new._partial = None
         new._T = None
         new._Tb = None
+        new._by_activity = None
         new._seen_tiles = None
         return new
 
@@ -209,7 +217,8 @@ class HipOps:
         self._score_states = None
         self._aux_streams = []
         self.score_tiles_per_chunk = 0   # 0 = auto (L2-sized item chunks); tests force tiny chunks
-        self.score_splits_override = 0   # 0 = auto (pk_score_splits)
+        import os
+        self.score_splits_override = int(os.environ.get('PK_SCORE_SPLITS', '0'))   # 0 = auto (pk_score_splits); tuning knob
         self._info = torch.zeros(2, dtype=torch.int32, device=self.device)
         # optional per-kernel HIP-event timing (bench.py): {'name': [(ev_start, ev_end, meta), ...]}
         self.timers = None
@@ -306,6 +315,23 @@ class HipOps:
         T = DeviceCSR.from_device(self, t_indptr, t_indices, t_values, (n_blocks * n_cols, n_rows), A.split)
         T._nnz = nnz
         return T
+
+    def csr_rows_by_length(self, A):
+        n_rows = A.shape[0]
+        nnz = int(A.indices.numel())
+        perm = torch.empty(n_rows, dtype=torch.int32, device=self.device)
+        indptr = torch.empty(n_rows + 1, dtype=torch.int64, device=self.device)
+        idx = torch.empty_like(A.indices)
+        val = torch.empty_like(A.values)
+        work = self._work(self.lib.pk_csr_rows_by_length_work_bytes(n_rows))
+        _lib.check(self.lib.pk_csr_rows_by_length(self.stream(), n_rows, nnz, _ptr(A.indptr), _ptr(A.indices), _ptr(A.values),
+                                                  A.val_kind, _ptr(perm), _ptr(indptr), _ptr(idx), _ptr(val), _ptr(work)),
+                   'pk_csr_rows_by_length')
+        P = DeviceCSR.from_device(self, indptr, idx, val, A.shape, A.split)
+        P._nnz = nnz
+        P.sorted_cols = A.sorted_cols
+        P._nonneg = getattr(A, '_nonneg', None)
+        return P, perm.long()
 
     def csr_relabel_cols(self, A, col_map, sort=True):
         """CSR with column j renamed to col_map[j].  `col_map`: int array or device tensor.  The row pointers —

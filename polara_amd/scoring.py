@@ -62,8 +62,11 @@ def test_csr_from_triplet(test_data, shape, weights=None):
     return coo_to_csr(users, items, vals, shape, sum_duplicates=True)
 
 
+ORDER_USERS_MIN = 8192      # below this a pass is a handful of workgroups: nothing to balance
+
+
 def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stats=None, prune=True, batches=None,
-              approx_fold_in=None):
+              approx_fold_in=None, order_users=True):
     """factors: FactorImage; T: ops-level CSR of the test users [n_users x n_items].
     Returns int64 device tensor [n_users x topk] (+ fp64 scores), rows in test-user order,
     columns by descending score — the contract of models.py:400-405.
@@ -79,6 +82,22 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
         raise ValueError('test matrix and item factors disagree on the number of items')
     if topk > n_items:
         raise ValueError('kth(=%d) out of bounds (%d)' % (n_items - topk, n_items))  # numpy argpartition's error
+    if order_users and prune and factors.fused and n_users >= ORDER_USERS_MIN and hasattr(T, 'by_activity'):
+        # A wave sweeps the catalogue for 32 consecutive users until the LAST of them can be pruned, so users are
+        # grouped by activity (the row order is a cached image of the test matrix); rows go back to their places at
+        # the end.  ML-20M-shaped: 12.3 -> 9.5 % of the tiles scored, sweep -14 %, fold-in -17 % (long rows first).
+        Tp, perm = T.by_activity()
+        res = recommend(ops, factors, Tp, topk, filter_seen, return_scores, stats, prune, batches, approx_fold_in,
+                        order_users=False)
+        if return_scores:
+            idx_p, sc_p = res
+            out_idx, out_s = torch.empty_like(idx_p), torch.empty_like(sc_p)
+            out_idx[perm] = idx_p
+            out_s[perm] = sc_p
+            return out_idx, out_s
+        out_idx = torch.empty_like(res)
+        out_idx[perm] = res
+        return out_idx
     KC = ops.candidate_capacity(topk) if factors.fused else 0
     K = factors.K
     if KC == 0:

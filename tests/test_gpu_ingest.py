@@ -182,3 +182,26 @@ def test_unsorted_long_rows_get_sorted_for_the_seen_tiles(hip_ops):
     t1, t2 = ops.to_host(tiles), ops.to_host(tiles2)
     for r in range(n_rows):
         assert np.array_equal(t1[indptr[r]:indptr[r] + nt[r]], t2[indptr[r]:indptr[r] + nt[r]])
+
+
+def test_rows_by_length_is_a_stable_descending_order(hip_ops):
+    ops = hip_ops
+    n_rows, n_cols = 20000, 3000
+    indptr, indices, values = _rand_csr(12, n_rows, n_cols, 25)
+    A = ops.csr(indptr, indices, values, (n_rows, n_cols))
+    P, perm = A.by_activity()
+    perm = ops.to_host(perm)
+    counts = np.diff(indptr)
+    assert np.array_equal(perm, np.argsort(-counts, kind='stable'))
+    assert np.array_equal(ops.to_host(P.indptr), np.r_[0, np.cumsum(counts[perm])])
+    S = sps.csr_matrix((values, indices, indptr), shape=(n_rows, n_cols))[perm]
+    assert np.array_equal(ops.to_host(P.indices), S.indices) and np.array_equal(ops.to_host(P.values), S.data)
+    # the scoring pass gives the same lists with and without the grouping
+    from polara_amd import scoring
+    rng = np.random.RandomState(0)
+    V = np.linalg.qr(rng.randn(n_cols, 16))[0] * np.linspace(3, 0.3, n_cols)[:, None]
+    F = scoring.FactorImage(ops, ops.to_device(V))
+    a, sa = scoring.recommend(ops, F, A, 10, True, return_scores=True)
+    b, sb = scoring.recommend(ops, F, A, 10, True, return_scores=True, order_users=False)
+    assert torch.equal(a, b) and torch.equal(sa, sb)
+    assert torch.equal(scoring.recommend(ops, F, A, 10, True), a)
