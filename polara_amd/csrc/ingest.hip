@@ -312,17 +312,17 @@ __global__ __launch_bounds__(256) void csc_keys_kernel(int64_t nnz, int64_t n_ro
                                                        const int32_t *__restrict__ indices, int64_t n_cols,
                                                        int64_t rows_per_block, uint32_t *__restrict__ keys,
                                                        uint32_t *__restrict__ pos, int32_t *__restrict__ rows_out) {
-    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= nnz) return;
-    int64_t lo = 0, hi = n_rows;           // largest r with indptr[r] <= p
-    while (hi - lo > 1) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (indptr[mid] <= p) lo = mid; else hi = mid;
+    // one wave per row: the row id of a position is the wave's, not a 20-step binary search per entry
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rows) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t p0 = indptr[r], p1 = indptr[r + 1];
+    const uint32_t base = (uint32_t)((rows_per_block > 0 ? r / rows_per_block : 0) * n_cols);
+    for (int64_t p = p0 + lane; p < p1; p += 64) {
+        rows_out[p] = (int32_t)r;
+        keys[p] = base + (uint32_t)indices[p];
+        pos[p] = (uint32_t)p;
     }
-    rows_out[p] = (int32_t)lo;
-    const int64_t blk = rows_per_block > 0 ? lo / rows_per_block : 0;
-    keys[p] = (uint32_t)(blk * n_cols + indices[p]);
-    pos[p] = (uint32_t)p;
 }
 
 template <typename VT>
@@ -341,15 +341,15 @@ __global__ __launch_bounds__(256) void relabel_keys_kernel(int64_t nnz, int64_t 
                                                            const int32_t *__restrict__ indices,
                                                            const int32_t *__restrict__ col_map, int64_t n_cols,
                                                            uint64_t *__restrict__ keys, uint32_t *__restrict__ pos) {
-    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= nnz) return;
-    int64_t lo = 0, hi = n_rows;
-    while (hi - lo > 1) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (indptr[mid] <= p) lo = mid; else hi = mid;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);     // one wave per row
+    if (r >= n_rows) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t p0 = indptr[r], p1 = indptr[r + 1];
+    const uint64_t base = (uint64_t)r * (uint64_t)n_cols;
+    for (int64_t p = p0 + lane; p < p1; p += 64) {
+        keys[p] = base + (uint64_t)col_map[indices[p]];
+        pos[p] = (uint32_t)p;
     }
-    keys[p] = (uint64_t)lo * (uint64_t)n_cols + (uint64_t)col_map[indices[p]];
-    pos[p] = (uint32_t)p;
 }
 
 template <typename VT>
@@ -467,8 +467,8 @@ extern "C" int pk_csr_transpose(void *stream, int64_t n_rows, int64_t n_cols, in
     int32_t *rows = reinterpret_cast<int32_t *>(take(nnz * 4));
     void *rwork = take(pk_radix_work_bytes(nnz));
     const unsigned nb = (unsigned)pk_ceil_div(nnz, 256);
-    hipLaunchKernelGGL(csc_keys_kernel, dim3(nb), dim3(256), 0, st, nnz, n_rows, indptr_dev, indices_dev, n_cols,
-                       rows_per_block, keys, pos, rows);
+    hipLaunchKernelGGL(csc_keys_kernel, dim3((unsigned)pk_ceil_div(n_rows, 4)), dim3(256), 0, st, nnz, n_rows, indptr_dev, indices_dev,
+                       n_cols, rows_per_block, keys, pos, rows);
     int in_tmp = 0;
     pk_radix_sort<uint32_t>(st, nnz, keys, pos, keys_t, pos_t, pk_bits_for((uint64_t)n_bins), rwork, &in_tmp);
     const uint32_t *ks = in_tmp ? keys_t : keys;
@@ -513,8 +513,8 @@ extern "C" int pk_csr_relabel_sorted(void *stream, int64_t n_rows, int64_t n_col
     uint32_t *pos_t = reinterpret_cast<uint32_t *>(take(nnz * 4));
     void *rwork = take(pk_radix_work_bytes(nnz));
     const unsigned nb = (unsigned)pk_ceil_div(nnz, 256);
-    hipLaunchKernelGGL(relabel_keys_kernel, dim3(nb), dim3(256), 0, st, nnz, n_rows, indptr_dev, indices_dev, col_map_dev,
-                       n_cols, keys, pos);
+    hipLaunchKernelGGL(relabel_keys_kernel, dim3((unsigned)pk_ceil_div(n_rows, 4)), dim3(256), 0, st, nnz, n_rows, indptr_dev,
+                       indices_dev, col_map_dev, n_cols, keys, pos);
     int in_tmp = 0;
     // the row part of the key is already ascending: only the column bits need sorting WITHIN rows, but an LSD sort
     // of the full key is what keeps this one code path; bits = those of n_rows * n_cols
@@ -554,16 +554,15 @@ __global__ __launch_bounds__(256) void permute_rows_kernel(int64_t nnz, int64_t 
                                                            const int64_t *__restrict__ indptr, const uint32_t *__restrict__ perm,
                                                            const int32_t *__restrict__ indices, const VT *__restrict__ values,
                                                            int32_t *__restrict__ indices_out, VT *__restrict__ values_out) {
-    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= nnz) return;
-    int64_t lo = 0, hi = n_rows;           // largest r with new_indptr[r] <= p
-    while (hi - lo > 1) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (new_indptr[mid] <= p) lo = mid; else hi = mid;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);     // one wave per NEW row
+    if (r >= n_rows) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t d0 = new_indptr[r], d1 = new_indptr[r + 1];
+    const int64_t s0 = indptr[perm[r]];
+    for (int64_t k = lane; k < d1 - d0; k += 64) {
+        indices_out[d0 + k] = indices[s0 + k];
+        values_out[d0 + k] = values[s0 + k];
     }
-    const int64_t src = indptr[perm[lo]] + (p - new_indptr[lo]);
-    indices_out[p] = indices[src];
-    values_out[p] = values[src];
 }
 
 extern "C" int64_t pk_csr_rows_by_length_work_bytes(int64_t n_rows) {
@@ -599,7 +598,7 @@ extern "C" int pk_csr_rows_by_length(void *stream, int64_t n_rows, int64_t nnz, 
     pk_scan_launch(st, n_rows, counts, new_indptr_dev, swork);
     if (nnz > 0) {
         PK_REQUIRE(indices_dev && values_dev && indices_out_dev && values_out_dev, "pk_csr_rows_by_length: null buffer");
-        const unsigned ne = (unsigned)pk_ceil_div(nnz, 256);
+        const unsigned ne = (unsigned)pk_ceil_div(n_rows, 4);
         if (val_kind == PK_VAL_F32)
             hipLaunchKernelGGL(permute_rows_kernel<float>, dim3(ne), dim3(256), 0, st, nnz, n_rows, new_indptr_dev, indptr_dev, perm,
                                indices_dev, static_cast<const float *>(values_dev), indices_out_dev, static_cast<float *>(values_out_dev));
