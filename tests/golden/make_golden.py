@@ -35,6 +35,23 @@ from polara.lib import sparse as ref_sparse
 from oracle import polara_oracle as orc
 from polara_amd.synth import planted_csr, csr_to_coo_triplets
 
+# The reference's `safe_divide` (recommender/evaluation.py:19-21) calls `np.divide(a, b, where=mask)` WITHOUT `out=`:
+# the rows the mask excludes come out of uninitialised memory, so its precision / recall / miss_rate / NDCG / NDCL /
+# fallout / specifity differ from run to run (NDCG = 8.2, 6.7, 14.1 ... on the same lists) and a fixture holding them
+# could not be reproduced.  For the generation only, the reference's metric code runs with that one function given a
+# zero-initialised output — in memory, nothing of the reference is copied or changed on disk — so that every metric
+# stored below is what its formulas define and this script reproduces its fixtures byte for byte.
+import polara.recommender.evaluation as _ref_evaluation
+
+
+def _safe_divide_zero_init(a, b, mask=None, dtype=None):
+    pos = mask if mask is not None else a > 0
+    out = np.zeros(np.broadcast(np.asarray(a), np.asarray(b)).shape, dtype=dtype or np.float64)
+    return np.divide(a, b, out=out, where=pos)
+
+
+_ref_evaluation.safe_divide = _safe_divide_zero_init
+
 
 def quiet(fn, *a, **kw):
     with contextlib.redirect_stdout(io.StringIO()):
