@@ -413,6 +413,17 @@ int pk_svd_build(pk_ctx *ctx, pk_mat *A, int32_t k, int32_t block, double tol, i
  * models.py:510-519 orders them).  V_host: [n_items * K] column-major.  out_scores: fp64 scores of those items or NULL. */
 int pk_score_topk(pk_ctx *ctx, int64_t n_items, int32_t K, const double *V_host, pk_mat *T, int32_t topk,
                   int32_t filter_seen, int64_t *out_idx, double *out_scores);
+/* Tucker / HOOI of a sparse 3-way tensor (`CoffeeModel.build` -> `hooi`, models.py:1009-1024, lib/tensor.py:37-96):
+ * idx_host [nnz x 3] row-major (user, item, feedback level), vals_host or NULL (= ones, data.py:805), shape[3],
+ * mlrank[3].  u1_start [n1 x r1] / u2_start [n2 x r2] (row-major, orthonormal columns): the start the reference draws
+ * from NumPy's RandomState + LAPACK QR (tensor.py:57-63) — pass it to follow the reference's iteration exactly; both
+ * NULL: a seeded device generator.  Outputs (host, row-major, C order like the reference's factors): u0 [n0 x r0],
+ * u1 [n1 x r1], u2 [n2 x r2], core [r0 x r1 x r2], trace_out[num_iters] = the core norm after every iteration
+ * (tensor.py:82-88), *iters_out = iterations run (stops when the core's growth falls below growth_tol). */
+int pk_hooi(pk_ctx *ctx, int64_t nnz, const int64_t *idx_host, const double *vals_host, const int64_t *shape,
+            const int32_t *mlrank, int32_t num_iters, double growth_tol, const double *u1_start, const double *u2_start,
+            uint64_t seed, double *u0_out, double *u1_out, double *u2_out, double *core_out, double *trace_out,
+            int32_t *iters_out);
 
 #ifdef __cplusplus
 }

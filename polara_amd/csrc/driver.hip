@@ -191,6 +191,14 @@ __global__ void randn_kernel(int64_t n_elems, uint64_t seed, double *__restrict_
     out[i] = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
 }
 
+__global__ void transpose_kernel(int64_t n, int m, const double *__restrict__ in, double *__restrict__ out) {   // [n x m] -> [m x n]
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * m) return;
+    const int64_t r = i / m;
+    const int c = (int)(i - r * m);
+    out[(int64_t)c * n + r] = in[i];
+}
+
 __global__ void iota_i32_kernel(int64_t n, int32_t *out, int32_t *count) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (int32_t)i;
@@ -932,5 +940,190 @@ extern "C" int pk_score_topk(pk_ctx *ctx, int64_t n_items, int32_t K, const doub
     CK(S.to_host(out_i.p, hi.data(), hi.size() * 8));
     for (size_t e = 0; e < hi.size(); ++e) out_idx[e] = hi[e] >= 0 ? (int64_t)inv[(size_t)hi[e]] : -1;   // serving order -> caller's item ids
     if (out_scores) CK(S.to_host(out_s.p, out_scores, (size_t)n_users * topk * 8));
+    return PK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// pk_hooi: polara_amd/tucker.py::hooi restated (CoffeeModel.build -> lib/tensor.py:37-96)
+// ------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct ModePlan {     // nnz ordered by one mode + the wave-task plan of pk_ttm_f64
+    Csr rows;         // only indptr + plan are used (n_rows = size of the output mode)
+    Dev idx_u, idx_v, vals;
+    bool ones = true;
+};
+
+int make_mode_plan(pk_ctx *ctx, int64_t nnz, const int64_t *idx, const double *vals, const int64_t shape[3], int mode0, int mode_u,
+                   int mode_v, ModePlan &mp) {
+    const int64_t n0 = shape[mode0];
+    std::vector<int64_t> indptr((size_t)n0 + 1, 0);
+    for (int64_t p = 0; p < nnz; ++p) indptr[(size_t)idx[3 * p + mode0] + 1] += 1;
+    for (int64_t r = 0; r < n0; ++r) indptr[(size_t)r + 1] += indptr[(size_t)r];
+    std::vector<int64_t> cursor(indptr.begin(), indptr.end() - 1);
+    std::vector<int32_t> iu((size_t)std::max<int64_t>(nnz, 1)), iv((size_t)std::max<int64_t>(nnz, 1));
+    std::vector<double> vv;
+    mp.ones = true;
+    if (vals) for (int64_t p = 0; p < nnz; ++p) if (vals[p] != 1.0) { mp.ones = false; break; }
+    if (!mp.ones) vv.resize((size_t)nnz);
+    for (int64_t p = 0; p < nnz; ++p) {          // stable counting sort by the output mode (nnz order kept inside a row)
+        const int64_t d = cursor[(size_t)idx[3 * p + mode0]]++;
+        iu[(size_t)d] = (int32_t)idx[3 * p + mode_u];
+        iv[(size_t)d] = (int32_t)idx[3 * p + mode_v];
+        if (!mp.ones) vv[(size_t)d] = vals[p];
+    }
+    Csr &R = mp.rows;
+    R.n_rows = n0; R.n_cols = 1; R.nnz = nnz;
+    const size_t n1 = (size_t)std::max<int64_t>(nnz, 1);
+    if (!R.indptr.alloc(((size_t)n0 + 1) * 8) || !mp.idx_u.alloc(n1 * 4) || !mp.idx_v.alloc(n1 * 4) || (!mp.ones && !mp.vals.alloc(n1 * 8)))
+        return fail(ctx, PK_E_LAUNCH, "out of device memory (tensor plan)");
+    hipStream_t st = ctx->stream;
+    HIPCK(hipMemcpyAsync(R.indptr.p, indptr.data(), ((size_t)n0 + 1) * 8, hipMemcpyHostToDevice, st));
+    if (nnz) {
+        HIPCK(hipMemcpyAsync(mp.idx_u.p, iu.data(), (size_t)nnz * 4, hipMemcpyHostToDevice, st));
+        HIPCK(hipMemcpyAsync(mp.idx_v.p, iv.data(), (size_t)nnz * 4, hipMemcpyHostToDevice, st));
+        if (!mp.ones) HIPCK(hipMemcpyAsync(mp.vals.p, vv.data(), (size_t)nnz * 8, hipMemcpyHostToDevice, st));
+    }
+    HIPCK(hipStreamSynchronize(st));
+    return build_plan(ctx, R, 256);
+}
+
+// res[n0 x (ra * rb)] = sum over the nnz of row i0 of val * u[i_u, :] (x) v[i_v, :]
+int ttm(pk_ctx *ctx, ModePlan &mp, const DMat &u, const DMat &v, DMat &res) {
+    Plan &P = mp.rows.plan;
+    const int ra = u.l, rb = v.l;
+    res = DMat(mp.rows.n_rows, ra * rb);
+    if (!res.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (ttm)");
+    const size_t need = (size_t)P.n_slots * ra * rb * 8;
+    if (need > P.partial.bytes && !P.partial.alloc(need)) return fail(ctx, PK_E_LAUNCH, "out of device memory (ttm partials)");
+    CK(pk_ttm_f64(ctx->stream, P.n_tasks, P.task_row.as<int32_t>(), P.task_begin.as<int64_t>(), P.task_end.as<int64_t>(),
+                  P.task_slot.as<int32_t>(), P.n_long, P.long_row.as<int32_t>(), P.long_sb.as<int32_t>(), P.long_se.as<int32_t>(),
+                  mp.idx_u.as<int32_t>(), mp.idx_v.as<int32_t>(), mp.ones ? nullptr : mp.vals.as<double>(), u.p(), u.l, ra, v.p(), v.l, rb,
+                  res.p(), res.l, P.partial.as<double>()));
+    return PK_OK;
+}
+
+// top-r left singular vectors / values of dense M (tucker.left_svd, single process): U [n x r], s (host), Vt [r x m] if asked
+int left_svd(Solver &S, const DMat &M, int r, DMat &U, std::vector<double> &s, DMat *Vt) {
+    pk_ctx *ctx = S.ctx;
+    const int64_t n = M.n;
+    const int m = M.l;
+    if (r > std::min<int64_t>(n, m)) return fail(ctx, PK_E_INVALID, "rank %d exceeds min(shape)=%lld", r, (long long)std::min<int64_t>(n, m));
+    std::vector<double> lam;
+    Dev lam_dev;
+    s.assign((size_t)r, 0.0);
+    if (n >= m) {
+        DMat G, C, W, Ur, Gu;
+        CK(S.gram(M, M, G));
+        CK(S.eigh(G, lam, C, lam_dev));
+        CK(S.col_slice(C, 0, r, W));
+        std::vector<double> inv((size_t)r);
+        for (int i = 0; i < r; ++i) { s[(size_t)i] = std::sqrt(std::max(lam[(size_t)i], 0.0)); inv[(size_t)i] = s[(size_t)i] > 0 ? 1.0 / s[(size_t)i] : 0.0; }
+        CK(S.tsmm(M, W, Ur));
+        CK(S.scale_cols_host(Ur, inv));
+        // one Newton-Schulz step: U <- U (1.5 I - 0.5 U^T U)
+        CK(S.gram(Ur, Ur, Gu));
+        std::vector<double> g((size_t)r * r);
+        CK(S.to_host(Gu.p(), g.data(), g.size() * 8));
+        for (int i = 0; i < r; ++i) for (int j = 0; j < r; ++j) g[(size_t)i * r + j] = (i == j ? 1.5 : 0.0) - 0.5 * g[(size_t)i * r + j];
+        DMat Cn(r, r);
+        CK(S.upload(g.data(), Cn.p(), g.size() * 8));
+        CK(S.tsmm(Ur, Cn, U));
+        if (Vt) {
+            *Vt = DMat(r, m);
+            hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)(((size_t)m * r + 255) / 256)), dim3(256), 0, S.st, (int64_t)m, r, W.p(), Vt->p());
+        }
+    } else {
+        DMat Mt(m, (int)n), G, C;
+        hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)(((size_t)n * m + 255) / 256)), dim3(256), 0, S.st, n, m, M.p(), Mt.p());
+        CK(S.gram(Mt, Mt, G));
+        CK(S.eigh(G, lam, C, lam_dev));
+        CK(S.col_slice(C, 0, r, U));
+        for (int i = 0; i < r; ++i) s[(size_t)i] = std::sqrt(std::max(lam[(size_t)i], 0.0));
+        if (Vt) {
+            *Vt = DMat(r, m);
+            CK(pk_dgemm_small_f64(S.st, 1, 0, r, m, (int)n, U.p(), U.l, M.p(), M.l, Vt->p(), m));    // U^T M = diag(s) V^T
+            std::vector<double> h((size_t)r * m);
+            CK(S.to_host(Vt->p(), h.data(), h.size() * 8));
+            for (int i = 0; i < r; ++i) { const double inv = s[(size_t)i] > 0 ? 1.0 / s[(size_t)i] : 0.0; for (int j = 0; j < m; ++j) h[(size_t)i * m + j] *= inv; }
+            CK(S.upload(h.data(), Vt->p(), h.size() * 8));
+        }
+    }
+    return PK_OK;
+}
+
+}  // namespace
+
+extern "C" int pk_hooi(pk_ctx *ctx, int64_t nnz, const int64_t *idx_host, const double *vals_host, const int64_t *shape,
+                       const int32_t *mlrank, int32_t num_iters, double growth_tol, const double *u1_start, const double *u2_start,
+                       uint64_t seed, double *u0_out, double *u1_out, double *u2_out, double *core_out, double *trace_out,
+                       int32_t *iters_out) {
+    if (!ctx) return PK_E_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    PoolScope pool_scope(ctx);
+    (void)hipSetDevice(ctx->device);
+    if (nnz < 1 || !idx_host || !shape || !mlrank || !u0_out || !u1_out || !u2_out || !core_out)
+        return fail(ctx, PK_E_INVALID, "pk_hooi: bad arguments");
+    const int64_t n0 = shape[0], n1 = shape[1], n2 = shape[2];
+    const int r0 = mlrank[0], r1 = mlrank[1], r2 = mlrank[2];
+    if (n0 < 1 || n1 < 1 || n2 < 1 || r0 < 1 || r1 < 1 || r2 < 1 || r0 > n0 || r1 > n1 || r2 > n2)
+        return fail(ctx, PK_E_INVALID, "pk_hooi: ranks must satisfy 1 <= r_k <= n_k");
+    if ((int64_t)r2 * r1 > 1024 || (int64_t)r2 * r0 > 1024 || (int64_t)r1 * r0 > 1024)
+        return fail(ctx, PK_E_UNSUPPORTED, "pk_hooi: a product of two ranks beyond 1024 (pk_ttm_f64 / the dense kernels)");
+    for (int64_t p = 0; p < nnz; ++p)
+        for (int k = 0; k < 3; ++k)
+            if (idx_host[3 * p + k] < 0 || idx_host[3 * p + k] >= shape[k]) return fail(ctx, PK_E_INVALID, "pk_hooi: index out of bounds");
+    if (num_iters <= 0) num_iters = 25;
+    Solver S{ctx, ctx->stream, Dev()};
+    // (output mode ; first matrix mode ; second matrix mode) as in lib/tensor.py:70,74,78
+    ModePlan mp0, mp1, mp2;
+    CK(make_mode_plan(ctx, nnz, idx_host, vals_host, shape, 0, 2, 1, mp0));
+    CK(make_mode_plan(ctx, nnz, idx_host, vals_host, shape, 1, 2, 0, mp1));
+    CK(make_mode_plan(ctx, nnz, idx_host, vals_host, shape, 2, 1, 0, mp2));
+    DMat u0, u1(n1, r1), u2(n2, r2);
+    if (!u1.ok() || !u2.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (factors)");
+    if (u1_start && u2_start) {       // the caller's start (the reference draws it from NumPy's RandomState + LAPACK QR, tensor.py:57-63)
+        CK(S.upload(u1_start, u1.p(), (size_t)n1 * r1 * 8));
+        CK(S.upload(u2_start, u2.p(), (size_t)n2 * r2 * 8));
+    } else {
+        DMat a, b;
+        CK(S.randn(n1, r1, seed, a));
+        CK(S.randn(n2, r2, seed + 1, b));
+        CK(S.orthonormalize(a, nullptr, seed + 2, u1));
+        CK(S.orthonormalize(b, nullptr, seed + 3, u2));
+    }
+    double g_old = 0.0;
+    std::vector<double> ss, s_tmp;
+    DMat vv;
+    int it = 0;
+    for (; it < num_iters; ++it) {
+        DMat T0, T1, T2, n0f, n1f, n2f;
+        CK(ttm(ctx, mp0, u2, u1, T0));
+        CK(left_svd(S, T0, r0, n0f, s_tmp, nullptr));
+        u0 = std::move(n0f);
+        CK(ttm(ctx, mp1, u2, u0, T1));
+        CK(left_svd(S, T1, r1, n1f, s_tmp, nullptr));
+        u1 = std::move(n1f);
+        CK(ttm(ctx, mp2, u1, u0, T2));
+        CK(left_svd(S, T2, r2, n2f, ss, &vv));
+        u2 = std::move(n2f);
+        double g_new = 0.0;
+        for (double v : ss) g_new += v * v;
+        g_new = std::sqrt(g_new);
+        const double growth = (g_new - g_old) / g_new;
+        g_old = g_new;
+        if (trace_out) trace_out[it] = g_new;
+        if (growth < growth_tol) { ++it; break; }
+    }
+    if (iters_out) *iters_out = it;
+    CK(S.to_host(u0.p(), u0_out, (size_t)n0 * r0 * 8));
+    CK(S.to_host(u1.p(), u1_out, (size_t)n1 * r1 * 8));
+    CK(S.to_host(u2.p(), u2_out, (size_t)n2 * r2 * 8));
+    // core[a, b, c] = ss[c] * vv[c, b * r0 + a]   ((ss * vv).reshape(r2, r1, r0).transpose(2, 1, 0), tensor.py:91-93)
+    std::vector<double> vh((size_t)r2 * r1 * r0);
+    CK(S.to_host(vv.p(), vh.data(), vh.size() * 8));
+    for (int a = 0; a < r0; ++a)
+        for (int b = 0; b < r1; ++b)
+            for (int c = 0; c < r2; ++c) core_out[((size_t)a * r1 + b) * r2 + c] = ss[(size_t)c] * vh[(size_t)c * r1 * r0 + (size_t)b * r0 + a];
     return PK_OK;
 }

@@ -31,6 +31,8 @@ lib.pk_mat_nnz.argtypes, lib.pk_mat_nnz.restype = [vp], i64
 lib.pk_svd_build.argtypes = [vp, vp, i32, i32, f64, i32, C.c_uint64, vp, vp, vp, C.POINTER(Stats)]
 lib.pk_svd_build.restype = C.c_int
 lib.pk_score_topk.argtypes, lib.pk_score_topk.restype = [vp, i64, i32, vp, vp, i32, i32, vp, vp], C.c_int
+lib.pk_hooi.argtypes = [vp, i64, vp, vp, vp, vp, i32, f64, vp, vp, C.c_uint64, vp, vp, vp, vp, vp, vp]
+lib.pk_hooi.restype = C.c_int
 
 
 def ptr(a):
@@ -111,6 +113,33 @@ def main():
     rc = lib.pk_svd_build(ctx, A, rank, 0, 1e-30, 1, 0, ptr(sigma), ptr(V), None, C.byref(st))
     assert rc == -4 and st.converged == 0 and b'not converged' in lib.pk_ctx_error(ctx)      # PK_E_NOCONV
     lib.pk_mat_free(ctx, A); lib.pk_mat_free(ctx, T)
+    # ---- pk_hooi against the reference's golden CoFFee fixture (same start block as lib/tensor.py:57-63) ----
+    for name in ('coffee_small', 'coffee_warm'):
+        g = np.load(os.path.join(ROOT, 'tests', 'golden', name + '.npz'))
+        idx = np.ascontiguousarray(g['train_idx'], dtype=np.int64)
+        val = np.ascontiguousarray(g['train_val'], dtype=np.float64)
+        shape = np.ascontiguousarray(g['train_shape'], dtype=np.int64)
+        mlrank = np.ascontiguousarray(g['mlrank'], dtype=np.int32)
+        rs = np.random.RandomState(int(g['seed']))
+        u1s = np.ascontiguousarray(np.linalg.qr(rs.rand(shape[1], mlrank[1]), mode='reduced')[0])
+        u2s = np.ascontiguousarray(np.linalg.qr(rs.rand(shape[2], mlrank[2]), mode='reduced')[0])
+        n_it = int(g['num_iters'])
+        u0 = np.empty((shape[0], mlrank[0])); u1 = np.empty((shape[1], mlrank[1])); u2 = np.empty((shape[2], mlrank[2]))
+        core = np.empty(tuple(mlrank)); trace = np.zeros(n_it); iters = i32(0)
+        check(ctx, lib.pk_hooi(ctx, len(val), ptr(idx), ptr(val), ptr(shape), ptr(mlrank), n_it, float(g['growth_tol']), ptr(u1s), ptr(u2s),
+                               0, ptr(u0), ptr(u1), ptr(u2), ptr(core), ptr(trace), C.byref(iters)), 'pk_hooi')
+        want = g['core_norm_trace']
+        assert iters.value == len(want) and np.allclose(trace[:iters.value], want, rtol=1e-9), (iters.value, trace, want)
+        for a, ref in ((u0, g['u0']), (u1, g['u1']), (u2, g['u2'])):
+            assert np.abs(a @ a.T - ref @ ref.T).max() < 1e-8
+        assert np.isclose(np.linalg.norm(core), np.linalg.norm(g['core']), rtol=1e-9)
+        # the core IS the tensor contracted with the factors
+        dense = np.zeros(tuple(shape)); np.add.at(dense, (idx[:, 0], idx[:, 1], idx[:, 2]), val)
+        assert np.allclose(core, np.einsum('uif,ua,ib,fc->abc', dense, u0, u1, u2, optimize=True), atol=1e-9 * np.abs(core).max())
+    # internal start (no start blocks given): a valid Tucker fit all the same
+    check(ctx, lib.pk_hooi(ctx, len(val), ptr(idx), None, ptr(shape), ptr(mlrank), n_it, float(g['growth_tol']), None, None, 7,
+                           ptr(u0), ptr(u1), ptr(u2), ptr(core), ptr(trace), C.byref(iters)), 'pk_hooi(seeded start)')
+    assert np.abs(u1.T @ u1 - np.eye(mlrank[1])).max() < 1e-9 and iters.value >= 1 and trace[iters.value - 1] > 0
     lib.pk_ctx_destroy(ctx)
     print('COARSE_ABI_OK steps', st.gramian_steps)
 
