@@ -257,8 +257,9 @@ __global__ __launch_bounds__(256) void rescore_topk_kernel(
     if (n_items - n_seen < topk) {
         flag |= 2;  // seen items must re-enter the list: exact path
     } else if (tau32 > -INFINITY) {
-        // |fl32(e.v) - e.v| <= (K + 3) u32 |e||v|  (input rounding + K-term fmaf chain), u32 = 2^-24
-        const double bound = (double)(K + 3) * 5.9604644775390625e-08 * enorm * vmax;
+        // the sweep's split-bf16 product (score.hip): |s32 - e.v| <= (3 * 2^-18 + (4 K + 10) * 2^-23) |e||v| — operands
+        // split into two bf16 each, the lo.lo term dropped, fp32 conversion of the inputs, accumulation roundings
+        const double bound = (3.0 * 3.814697265625e-06 + (double)(4 * K + 10) * 1.1920928955078125e-07) * enorm * vmax;
         // the candidate sweep orders scores that agree to 2^-16 relative arbitrarily (key-only flush sorts,
         // score.hip): a non-candidate may exceed the KC-th candidate by that much
         const double tau_cert = tau32 + fabs(tau32) * 3.0517578125e-05;

@@ -38,6 +38,7 @@
 #include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define RING 16          // lane-private candidate ring entries (8 for KC == 16, see PAIRED below)
 
@@ -159,9 +160,18 @@ struct LaneState {
 };
 #define PK_LANE_DONE (-1)
 
-// NSTEP = number of K=2 MFMA steps actually issued (ceil(rank/2) rounded up to a supported value);
-// the packed operands hold KQ = ceil(NSTEP/4) float4 groups, the tail group is only partly used.
-__host__ __device__ constexpr bool pk_top_in_lds(int nstep, int kc) { return kc <= 32 || nstep > 64; }
+// The candidate scores come from the bf16 matrix cores at fp32-class accuracy ("split bf16"): every fp32 operand is
+// stored as two bf16, x = hi + lo + d with |d| <= 2^-18 |x| (pk_split_bf16), and a 16-wide k-step of the product is
+// THREE v_mfma_f32_32x32x16_bf16 — hi.hi + hi.lo + lo.hi, fp32 accumulation, the lo.lo term (<= 2^-18 |a||b|) dropped.
+// gfx950's bf16 MFMA runs at 16x the rate of v_mfma_f32_32x32x2_f32 (which is the fp32 VECTOR rate, MI355X_MICROARCH.md),
+// so a rank-50 tile costs 12 x 32 = 384 MFMA cycles instead of 25 x 64 = 1600, a rank-200 tile 39 x 32 instead of
+// 100 x 64, at an error of  |s32 - e.v| <= (3 * 2^-18 + (4 K + 10) * 2^-23) ||e|| ||v||  (operand split, dropped term,
+// fp32 conversion of the fp64 inputs, at most 4 K + 10 accumulation roundings counted as truncations) that the exact
+// fp64 re-scoring pass certifies against (rescore.hip: `bound`).  The C / D layout of the instruction is that of the
+// f32 32x32x2 form, so everything after the MFMAs is unchanged.
+// NSTEP = number of 16-wide k-steps (rank padded with zeros to 16 * NSTEP, rounded up to a supported value); the packed
+// operands hold KQ = 2 * NSTEP 16-byte groups per lane and tile: the eight hi parts, then the eight lo parts of a step.
+__host__ __device__ constexpr bool pk_top_in_lds(int nstep, int kc) { return kc <= 32 || nstep > 8; }
 __host__ __device__ constexpr int pk_ring_rows(int kc) { return kc == 16 ? 8 : RING; }
 __host__ __device__ constexpr size_t pk_score_lds_bytes(int nstep, int kc) {
     return (size_t)(4 * pk_ring_rows(kc) * 64 + (pk_top_in_lds(nstep, kc) ? 4 * 32 * kc : 1)) * sizeof(uint2);
@@ -176,7 +186,7 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
     float *__restrict__ cand_score, int32_t *__restrict__ cand_idx,
     LaneState *__restrict__ st_lane, uint2 *__restrict__ st_ring,
     const float *__restrict__ user_bound, const float *__restrict__ tile_bound, int ablate) {
-    constexpr int KQ = (NSTEP + 3) / 4;
+    constexpr int KQ = 2 * NSTEP;   // 16-byte groups per lane and tile: (hi, lo) x 8 bf16 for every 16-wide k-step
     // KC == 16: rings of 8, so that a user's list + both rings are 32 entries and TWO users are merged
     // per flush, one in each half of the wave (15 sort stages per two users instead of 21 per user).
     constexpr bool PAIRED = (KC == 16);
@@ -186,7 +196,7 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
     // then never touches global memory (no vmcnt drain in the middle of the MFMA stream).  They are
     // copied from / to cand_score, cand_idx at the launch boundaries.
     // KC = 64 lists (16 KiB per wave) move to LDS too when the rank is high enough that the fragment
-    // registers already limit the SIMD to one wave (NSTEP > 64: 96 KiB per workgroup, one workgroup per CU).
+    // registers already limit the SIMD to one wave (NSTEP > 8, i.e. rank > 128: 96 KiB per workgroup, one workgroup per CU).
     constexpr bool TOP_LDS = pk_top_in_lds(NSTEP, KC);
     extern __shared__ uint2 pk_score_lds[];      // [4][RG][64] rings, then [4][32*KC] top lists (TOP_LDS)
 
@@ -575,12 +585,14 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            // split-bf16 product (see the header): per 16-wide k-step  hi.hi + hi.lo + lo.hi, accumulated in fp32
 #pragma unroll
-            for (int q = 0; q < KQ; ++q) {
-                if (4 * q + 0 < NSTEP) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, e[q].x, acc, 0, 0, 0);
-                if (4 * q + 1 < NSTEP) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, e[q].y, acc, 0, 0, 0);
-                if (4 * q + 2 < NSTEP) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, e[q].z, acc, 0, 0, 0);
-                if (4 * q + 3 < NSTEP) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, e[q].w, acc, 0, 0, 0);
+            for (int sidx = 0; sidx < NSTEP; ++sidx) {
+                const bf16x8 vh = __builtin_bit_cast(bf16x8, a[2 * sidx]), vl = __builtin_bit_cast(bf16x8, a[2 * sidx + 1]);
+                const bf16x8 eh = __builtin_bit_cast(bf16x8, e[2 * sidx]), el = __builtin_bit_cast(bf16x8, e[2 * sidx + 1]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, eh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, el, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, eh, acc, 0, 0, 0);
             }
             // The list cursor must advance every tile; the mask itself is only needed when some
             // RAW score beats the threshold (f32 MFMA shares the SIMD's FP32 lanes with the VALU, so
@@ -665,18 +677,19 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
 // ------------------------------------------------------------------------------------------
 // packing: f64 [n x K] -> f32 MFMA fragments, 32 rows per tile, K padded with zeros to 8*KQ
 // ------------------------------------------------------------------------------------------
-static const int kNstepSet[] = {5, 8, 13, 16, 25, 32, 50, 64, 100, 128};
+// NSTEP = number of 16-wide k-steps of the split-bf16 product (rank padded with zeros to 16 * NSTEP)
+static const int kNstepSet[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 13, 16};
 
 static int pk_nstep(int K) {
-    const int need = (K + 1) / 2;
+    const int need = (K + 15) / 16;
     for (int n : kNstepSet)
         if (n >= need) return n;
     return 0;
 }
 
-extern "C" int32_t pk_pack_kq(int32_t K) {
+extern "C" int32_t pk_pack_kq(int32_t K) {    // 16-byte groups per lane and 32-row tile
     const int n = pk_nstep(K);
-    return n ? (n + 3) / 4 : 0;
+    return n ? 2 * n : 0;
 }
 
 extern "C" int64_t pk_pack_elems(int64_t n, int32_t K) {
@@ -684,32 +697,55 @@ extern "C" int64_t pk_pack_elems(int64_t n, int32_t K) {
     return pk_ceil_div(n, 32) * kq * 64 * 4;
 }
 
-__global__ __launch_bounds__(256) void pack_frag_kernel(int64_t n, int K, int kq, const double *__restrict__ src,
-                                                        int64_t ld, float4 *__restrict__ dst, int64_t total) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one float4 per thread
-    if (t >= total) return;
-    const int lane = (int)(t & 63);
-    const int64_t tq = t >> 6;
-    const int q = (int)(tq % kq);
-    const int64_t tile = tq / kq;
-    const int64_t row = tile * 32 + (lane & 31);
-    const int h = lane >> 5;
-    float v[4];
+// split of an fp32 value into two bf16 (round to nearest even): x = hi + lo + d, |d| <= 2^-18 |x|
+__device__ __forceinline__ unsigned pk_bf16_rne(float x) {
+    unsigned u = __float_as_uint(x);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ void pk_split_bf16(float x, unsigned &hi, unsigned &lo) {
+    hi = pk_bf16_rne(x);
+    lo = pk_bf16_rne(x - __uint_as_float(hi << 16));
+}
+// lane (i = lane & 31, h = lane >> 5) of k-step s holds k = 16 s + 8 h + j, j = 0..7: the A / B operand layout of
+// v_mfma_f32_32x32x16_bf16.  Group 2 s = the eight hi parts, group 2 s + 1 = the eight lo parts.
+__device__ __forceinline__ void pk_pack_step(const double *__restrict__ r, bool live, int K, int s, int h, uint4 &ghi, uint4 &glo,
+                                             double *sumsq) {
+    unsigned hi[8], lo[8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int k = 8 * q + 2 * e + h;
-        v[e] = (row < n && k < K) ? (float)src[row * ld + k] : 0.0f;
+    for (int j = 0; j < 8; ++j) {
+        const int k = 16 * s + 8 * h + j;
+        const double x = (live && k < K) ? r[k] : 0.0;
+        if (sumsq) *sumsq = fma(x, x, *sumsq);
+        pk_split_bf16((float)x, hi[j], lo[j]);
     }
-    dst[t] = make_float4(v[0], v[1], v[2], v[3]);
+    ghi = make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16));
+    glo = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
+}
+
+__global__ __launch_bounds__(256) void pack_frag_kernel(int64_t n, int K, int kq, const double *__restrict__ src,
+                                                        int64_t ld, uint4 *__restrict__ dst, int64_t total) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one (k-step, lane) per thread
+    if (t >= total) return;
+    const int ns = kq / 2;
+    const int lane = (int)(t & 63);
+    const int64_t ts = t >> 6;
+    const int s = (int)(ts % ns);
+    const int64_t tile = ts / ns;
+    const int64_t row = tile * 32 + (lane & 31);
+    uint4 ghi, glo;
+    pk_pack_step(src + (row < n ? row : 0) * ld, row < n, K, s, lane >> 5, ghi, glo, nullptr);
+    dst[(tile * kq + 2 * s) * 64 + lane] = ghi;
+    dst[(tile * kq + 2 * s + 1) * 64 + lane] = glo;
 }
 
 // The same packing of a [n x K] fp64 block with the pruning bound of every row computed on the way (the user
 // side of a scoring pass: E is read once instead of twice).  One wave per 32-row tile: lane (i = lane & 31,
-// h = lane >> 5) produces its float4 of every q-group and accumulates the squares of what it read; the two
+// h = lane >> 5) produces its groups of every k-step and accumulates the squares of what it read; the two
 // halves of a row meet through one lane exchange.  bound[r] = ||src[r,:]|| (1 + 1e-6) + extra_scale * extra[r]
 // (extra: the error weight of an approximate fold-in, or NULL).
 __global__ __launch_bounds__(256) void pack_frag_bound_kernel(int64_t n, int K, int kq, const double *__restrict__ src,
-                                                              int64_t ld, float4 *__restrict__ dst,
+                                                              int64_t ld, uint4 *__restrict__ dst,
                                                               float *__restrict__ bound,
                                                               const double *__restrict__ extra, int64_t extra_ld,
                                                               double extra_scale, int64_t n_tiles) {
@@ -721,16 +757,11 @@ __global__ __launch_bounds__(256) void pack_frag_bound_kernel(int64_t n, int K, 
     const bool live = row < n;
     const double *r = src + (live ? row : 0) * ld;
     double ss = 0.0;
-    for (int q = 0; q < kq; ++q) {
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int k = 8 * q + 2 * e + h;
-            const double x = (live && k < K) ? r[k] : 0.0;
-            ss = fma(x, x, ss);
-            v[e] = (float)x;
-        }
-        dst[(tile * kq + q) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+    for (int s = 0; s < kq / 2; ++s) {
+        uint4 ghi, glo;
+        pk_pack_step(r, live, K, s, h, ghi, glo, &ss);
+        dst[(tile * kq + 2 * s) * 64 + lane] = ghi;
+        dst[(tile * kq + 2 * s + 1) * 64 + lane] = glo;
     }
     ss += pk_lane_xor<32>(ss);
     if (live && h == 0) {
@@ -748,7 +779,7 @@ extern "C" int pk_pack_frag_bound_f32(void *stream, int64_t n, int32_t K, const 
     PK_REQUIRE(ld >= K && ((uintptr_t)dst_dev % 16) == 0 && bound_dev, "pk_pack_frag_bound_f32: bad ld / alignment / pointers");
     const int64_t n_tiles = pk_ceil_div(n, 32);
     hipLaunchKernelGGL(pack_frag_bound_kernel, dim3((unsigned)pk_ceil_div(n_tiles, 4)), dim3(256), 0, pk_stream(stream), n,
-                       K, kq, src_dev, ld, reinterpret_cast<float4 *>(dst_dev), bound_dev, extra_dev, extra_ld,
+                       K, kq, src_dev, ld, reinterpret_cast<uint4 *>(dst_dev), bound_dev, extra_dev, extra_ld,
                        extra_scale, n_tiles);
     PK_CHECK_LAUNCH("pack_frag_bound_kernel");
     return PK_OK;
@@ -759,9 +790,9 @@ extern "C" int pk_pack_frag_f32(void *stream, int64_t n, int32_t K, const double
     const int kq = pk_pack_kq(K);
     PK_REQUIRE(n >= 1 && K >= 1 && kq > 0, "pk_pack_frag_f32: n=%lld K=%d unsupported (K <= 256)", (long long)n, K);
     PK_REQUIRE(ld >= K && ((uintptr_t)dst_dev % 16) == 0, "pk_pack_frag_f32: bad ld / alignment");
-    const int64_t total = pk_ceil_div(n, 32) * kq * 64;
+    const int64_t total = pk_ceil_div(n, 32) * (kq / 2) * 64;
     hipLaunchKernelGGL(pack_frag_kernel, dim3((unsigned)pk_ceil_div(total, 256)), dim3(256), 0, pk_stream(stream), n,
-                       K, kq, src_dev, ld, reinterpret_cast<float4 *>(dst_dev), total);
+                       K, kq, src_dev, ld, reinterpret_cast<uint4 *>(dst_dev), total);
     PK_CHECK_LAUNCH("pack_frag_kernel");
     return PK_OK;
 }
@@ -1091,18 +1122,19 @@ extern "C" int pk_score_candidates_f32(void *stream, int64_t n_users, int64_t n_
     const int ablate = abl_env ? atoi(abl_env) : 0;
     switch (nstep) {
 #ifdef PK_FAST_BUILD
-        PK_N_CASE(25)
+        PK_N_CASE(4)
 #else
+        PK_N_CASE(1)
+        PK_N_CASE(2)
+        PK_N_CASE(3)
+        PK_N_CASE(4)
         PK_N_CASE(5)
+        PK_N_CASE(6)
+        PK_N_CASE(7)
         PK_N_CASE(8)
+        PK_N_CASE(10)
         PK_N_CASE(13)
         PK_N_CASE(16)
-        PK_N_CASE(25)
-        PK_N_CASE(32)
-        PK_N_CASE(50)
-        PK_N_CASE(64)
-        PK_N_CASE(100)
-        PK_N_CASE(128)
 #endif
     }
 #undef PK_N_CASE

@@ -30,10 +30,10 @@ def test_python_prototypes_cover_the_header():
     lib = _lib.load()
     assert lib.pk_version() >= 100
     # pure host-side helpers are callable without a device
-    assert lib.pk_pack_kq(50) == 7 and lib.pk_pack_kq(100) == 13 and lib.pk_pack_kq(10) == 2
+    assert lib.pk_pack_kq(50) == 8 and lib.pk_pack_kq(100) == 14 and lib.pk_pack_kq(10) == 2 and lib.pk_pack_kq(200) == 26
     assert lib.pk_candidate_capacity(10) == 16 and lib.pk_candidate_capacity(20) == 32
     assert lib.pk_candidate_capacity(50) == 64 and lib.pk_candidate_capacity(100) == 0
-    assert lib.pk_pack_elems(33, 50) == 2 * 7 * 64 * 4
+    assert lib.pk_pack_elems(33, 50) == 2 * 8 * 64 * 4
     assert lib.pk_gram_work_bytes(1000, 64, 64) > 0
 
 
