@@ -623,7 +623,7 @@ def main():
         'n_gpus': comm.world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': head['ms_per_step'],
         'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'bf16x3',
         'dtype_detail': 'candidate scoring on bf16 MFMA with every operand split into two bf16 (3 MFMAs per product, fp32 accumulate, '
-                        'error <= ~2^-15 relative, certified); fold-in gathers fl32(V) with f64 accumulation, its rounding is part of the '
+                        'error <= 3 * 2^-16 + (4 K + 10) * 2^-23 relative to ||e|| ||v||, certified); fold-in gathers fl32(V) with f64 accumulation, its rounding is part of the '
                         'certification (uncertified users are re-folded in f64); EXACT f64 re-scoring of the candidates decides every '
                         'list; f64 SVD build',
         'data': 'synthetic (planted low-rank + Zipf popularity, seeded; generated on GPU)',

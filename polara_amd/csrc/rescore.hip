@@ -257,9 +257,9 @@ __global__ __launch_bounds__(256) void rescore_topk_kernel(
     if (n_items - n_seen < topk) {
         flag |= 2;  // seen items must re-enter the list: exact path
     } else if (tau32 > -INFINITY) {
-        // the sweep's split-bf16 product (score.hip): |s32 - e.v| <= (3 * 2^-18 + (4 K + 10) * 2^-23) |e||v| — operands
+        // the sweep's split-bf16 product (score.hip): |s32 - e.v| <= (3 * 2^-16 + (4 K + 10) * 2^-23) |e||v| — operands
         // split into two bf16 each, the lo.lo term dropped, fp32 conversion of the inputs, accumulation roundings
-        const double bound = (3.0 * 3.814697265625e-06 + (double)(4 * K + 10) * 1.1920928955078125e-07) * enorm * vmax;
+        const double bound = (3.0 * 1.52587890625e-05 + (double)(4 * K + 10) * 1.1920928955078125e-07) * enorm * vmax;
         // the candidate sweep orders scores that agree to 2^-16 relative arbitrarily (key-only flush sorts,
         // score.hip): a non-candidate may exceed the KC-th candidate by that much
         const double tau_cert = tau32 + fabs(tau32) * 3.0517578125e-05;

@@ -161,11 +161,11 @@ struct LaneState {
 #define PK_LANE_DONE (-1)
 
 // The candidate scores come from the bf16 matrix cores at fp32-class accuracy ("split bf16"): every fp32 operand is
-// stored as two bf16, x = hi + lo + d with |d| <= 2^-18 |x| (pk_split_bf16), and a 16-wide k-step of the product is
-// THREE v_mfma_f32_32x32x16_bf16 — hi.hi + hi.lo + lo.hi, fp32 accumulation, the lo.lo term (<= 2^-18 |a||b|) dropped.
+// stored as two bf16, x = hi + lo + d with |d| <= 2^-16 |x|, |lo| <= 2^-8 |x| (pk_split_bf16; bf16 has 8 significant bits), and a 16-wide k-step of the product is
+// THREE v_mfma_f32_32x32x16_bf16 — hi.hi + hi.lo + lo.hi, fp32 accumulation, the lo.lo term (<= 2^-16 |a||b|) dropped.
 // gfx950's bf16 MFMA runs at 16x the rate of v_mfma_f32_32x32x2_f32 (which is the fp32 VECTOR rate, MI355X_MICROARCH.md),
 // so a rank-50 tile costs 12 x 32 = 384 MFMA cycles instead of 25 x 64 = 1600, a rank-200 tile 39 x 32 instead of
-// 100 x 64, at an error of  |s32 - e.v| <= (3 * 2^-18 + (4 K + 10) * 2^-23) ||e|| ||v||  (operand split, dropped term,
+// 100 x 64, at an error of  |s32 - e.v| <= (3 * 2^-16 + (4 K + 10) * 2^-23) ||e|| ||v||  (operand split, dropped term,
 // fp32 conversion of the fp64 inputs, at most 4 K + 10 accumulation roundings counted as truncations) that the exact
 // fp64 re-scoring pass certifies against (rescore.hip: `bound`).  The C / D layout of the instruction is that of the
 // f32 32x32x2 form, so everything after the MFMAs is unchanged.
@@ -697,7 +697,7 @@ extern "C" int64_t pk_pack_elems(int64_t n, int32_t K) {
     return pk_ceil_div(n, 32) * kq * 64 * 4;
 }
 
-// split of an fp32 value into two bf16 (round to nearest even): x = hi + lo + d, |d| <= 2^-18 |x|
+// split of an fp32 value into two bf16 (round to nearest even): x = hi + lo + d, |hi - x| <= 2^-8 |x|, |d| <= 2^-16 |x|
 __device__ __forceinline__ unsigned pk_bf16_rne(float x) {
     unsigned u = __float_as_uint(x);
     u += 0x7fffu + ((u >> 16) & 1u);

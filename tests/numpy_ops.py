@@ -247,7 +247,7 @@ class NumpyOps:
             if n_items - n_seen < topk:
                 pass
             elif valid.all():
-                bound = (3 * 2.0 ** -18 + (4 * K + 10) * 2.0 ** -23) * np.linalg.norm(En[u]) * vmax   # rescore.hip: split-bf16 sweep
+                bound = (3 * 2.0 ** -16 + (4 * K + 10) * 2.0 ** -23) * np.linalg.norm(En[u]) * vmax   # rescore.hip: split-bf16 sweep
                 tau = float(cs[u, KC - 1]); tau += abs(tau) * 2.0 ** -15
                 slack = delta if e_exact else 2 * delta
                 if bound > 0 and not (s[topk - 1] - tau > bound + slack):
