@@ -2,13 +2,14 @@
 on ROCm; "gloo" in CPU tests).
 
 What is exchanged:
-  build   : users are row-sharded (nnz-balanced contiguous blocks).  Per Gramian step ONE sum
-            all-reduce of Z_p = A_p^T (A_p Q)  [n_items x l_active fp64] and, per Rayleigh-Ritz,
-            one of the l x l Gram matrix.  Everything on the item side (X, V_lock, the Jacobi eigh)
-            is replicated and recomputed identically on every rank — no broadcast needed.
+  build   : users are row-sharded (nnz-balanced contiguous blocks); the item-side blocks of the solver are
+            row-sharded as well (solver.ItemRows).  Per Gramian step ONE all-gather of the block X
+            [n_items x l_active fp64] in front of A_p X and ONE reduce-scatter of Z_p = A_p^T (A_p X) behind it
+            (= the volume of the sum all-reduce of the replicated layout), plus l x l all-reduces of the Gram
+            matrices.  The l x l kernels (Jacobi eigh, Cholesky) are recomputed identically on every rank.
   scoring : V is already replicated; test users are sharded; no collective in the data path.
             Only the final [n_users x topk] int64 result is gathered (host side).
-xGMI is point-to-point, so the Z all-reduce is launched as ONE large call per step (tens of MB):
+xGMI is point-to-point, so each exchange is launched as ONE large call per step (tens of MB):
 few, fat collectives rather than a bucketed stream.
 """
 import os
@@ -29,6 +30,8 @@ class TorchComm:
         self.world = dist.get_world_size(group)
         self.bytes_reduced = 0
         self.n_allreduce = 0
+        self.bytes_gathered = self.bytes_scattered = 0
+        self.n_allgather = self.n_reduce_scatter = 0
 
     def allreduce(self, t):
         if self.world > 1:
@@ -42,6 +45,39 @@ class TorchComm:
             self.bytes_reduced += t.numel() * t.element_size()
             self.n_allreduce += 1
         return t
+
+    def all_gather_rows(self, local):
+        """[rows x b] per rank -> [world*rows x b] on every rank, rank order = row order (the item-side blocks of the
+        solver in front of an SpMM: `solver.ItemRows.full`)."""
+        if self.world == 1:
+            return local
+        out = torch.empty((self.world * local.shape[0], local.shape[1]), dtype=local.dtype, device=local.device)
+        if local.is_cuda and dist.get_backend(self.group) == 'gloo':
+            h = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(h, local.cpu(), group=self.group)
+            out.copy_(h)
+        else:
+            dist.all_gather_into_tensor(out, local, group=self.group)
+        self.bytes_gathered += out.numel() * out.element_size()
+        self.n_allgather += 1
+        return out
+
+    def reduce_scatter_rows(self, full, rows):
+        """sum over the ranks of [world*rows x b] blocks, rank r keeps rows [r*rows, (r+1)*rows) (`ItemRows.product`).
+        RCCL: one reduce-scatter; gloo has none, so the CPU tests sum everything and slice."""
+        if self.world == 1:
+            return full
+        assert full.shape[0] == self.world * rows and full.is_contiguous()
+        if dist.get_backend(self.group) == 'nccl':
+            out = torch.empty((rows, full.shape[1]), dtype=full.dtype, device=full.device)
+            dist.reduce_scatter_tensor(out, full, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            h = full.cpu() if full.is_cuda else full
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            out = h[self.rank * rows:(self.rank + 1) * rows].to(full.device).contiguous()
+        self.bytes_scattered += full.numel() * full.element_size()
+        self.n_reduce_scatter += 1
+        return out
 
     def _exchange_device(self):
         """where collective payloads live: the GPU under RCCL, the host under gloo"""

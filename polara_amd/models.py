@@ -561,6 +561,7 @@ class SVDModel(RecommenderModel):
         self.svd_seed = defaults.svd_seed
         self.svd_block = defaults.svd_oversample
         self.svd_max_outer = defaults.svd_max_outer
+        self.svd_shard_items = defaults.svd_shard_items   # multi-GPU: row-shard the item-side blocks of the solver (solver.ItemRows)
         self.svd_on_no_convergence = 'raise'   # or 'warn': keep the best available factors (stats['converged'] False)
         self.build_stats = {}
 
@@ -653,7 +654,7 @@ class SVDModel(RecommenderModel):
         start = timer()
         U, sigma, V, stats = svd_topk(ops, A, self.rank, block=self.svd_block, tol=self.svd_tol,
                                       max_outer=self.svd_max_outer, seed=self.svd_seed, comm=self.comm, want_u=want_u,
-                                      verbose=False)
+                                      verbose=False, shard_items=self.svd_shard_items)
         ops.synchronize()
         self._track(start)
         self.build_stats = stats

@@ -1,0 +1,70 @@
+"""Worker for the gloo tests of the ROW-SHARDED item side of the eigensolver (solver.ItemRows): every rank owns a
+slice of the rows of X / Z / V_lock, the block is all-gathered in front of A X and A^T Y is reduce-scattered.  Uses
+the TEST-ONLY NumPy double of the device ops; what is under test is the layout + exchange orchestration, at item
+counts that do and do not divide by the world size, for a full-rank and a rank-deficient matrix (the `_refill` path)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+import numpy as np
+import scipy.sparse as sp
+
+from numpy_ops import NumpyOps
+from polara_amd.csr import nnz_balanced_row_partition
+from polara_amd.dist import init_from_env
+from polara_amd.solver import svd_topk
+from polara_amd.synth import planted_csr
+
+
+def matrices():
+    m = planted_csr(900, 257, 20, 12, levels=5, seed=5, min_items=4, max_items=60)
+    yield 'planted_257_items', sp.csr_matrix((m['values'], m['indices'], m['indptr']), shape=m['shape']), 12
+    rng = np.random.default_rng(3)
+    low = (rng.standard_normal((300, 6)) @ rng.standard_normal((6, 64)))
+    low[np.abs(low) < 1.2] = 0.0
+    low = sp.csr_matrix(low[:, :61])
+    yield 'dense_ish_61_items', low, 10
+    # rank 5 exactly, 9 vectors asked for: the filtered block is rank-deficient and goes through _refill
+    B = rng.standard_normal((200, 5)) @ rng.standard_normal((5, 47))
+    yield 'rank5_ask9_47_items', sp.csr_matrix(B), 9
+
+
+def main():
+    comm = init_from_env(backend='gloo')
+    ops = NumpyOps()
+    out = {}
+    for name, M, k in matrices():
+        whole = ops.csr(M.indptr.astype(np.int64), M.indices.astype(np.int32), M.data.astype(np.float64), M.shape)
+        _, s1, V1, st1 = svd_topk(ops, whole, k)
+        bounds = nnz_balanced_row_partition(M.indptr.astype(np.int64), comm.world)
+        P = M[int(bounds[comm.rank]):int(bounds[comm.rank + 1])]
+        part = ops.csr(P.indptr.astype(np.int64), P.indices.astype(np.int32), P.data.astype(np.float64), P.shape)
+        for shard_items in (True, False):
+            before = (comm.n_reduce_scatter, comm.n_allgather, comm.n_allreduce)
+            U, s, V, st = svd_topk(ops, part, k, comm=comm, want_u=True, shard_items=shard_items)
+            s, V, U = s.numpy(), V.numpy(), U.numpy()
+            nz = s1.numpy() > 1e-8 * s1.numpy()[0]
+            ok = (V.shape == (M.shape[1], k) and st['converged'] and st['items_sharded'] == shard_items
+                  and np.allclose(s[nz], s1.numpy()[nz], rtol=1e-9)
+                  and np.abs((V[:, nz] @ V[:, nz].T) - (V1.numpy()[:, nz] @ V1.numpy()[:, nz].T)).max() < 1e-8
+                  and np.abs(V.T @ V - np.eye(k)).max() < 1e-8
+                  and np.abs(P @ V[:, nz] - U[:, nz] * s[nz]).max() < 1e-8 * s[0])
+            if shard_items:
+                ok = ok and st['item_rows_per_rank'] == -(-M.shape[1] // comm.world) \
+                    and comm.n_reduce_scatter - before[0] == st['gramian_steps'] \
+                    and comm.n_allgather - before[1] >= st['gramian_steps']
+            else:
+                ok = ok and comm.n_reduce_scatter == before[0] and st['item_rows_per_rank'] == M.shape[1]
+            out['%s_%s' % (name, 'sharded' if shard_items else 'replicated')] = bool(ok)
+            out['%s_%s_steps' % (name, 'sharded' if shard_items else 'replicated')] = (st['gramian_steps'], st1['gramian_steps'])
+    comm.barrier()
+    if comm.rank == 0:
+        print('SOLVER_DIST_RESULT', out)
+    assert all(v for k, v in out.items() if not k.endswith('_steps')), out
+
+
+if __name__ == '__main__':
+    main()

@@ -13,3 +13,19 @@ def test_two_rank_sharded_build_and_scoring():
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert 'DIST_RESULT' in r.stdout
+
+
+import pytest
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_row_sharded_item_side_of_the_solver(world):
+    """solver.ItemRows: all-gather X / reduce-scatter Z / all-reduced Gram matrices give the factors of the whole
+    matrix, at item counts that are not multiples of the world size, and through the rank-deficient refill path."""
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='2')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world),
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()),
+           os.path.join(ROOT, 'tests', 'dist_worker_solver.py')]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert 'SOLVER_DIST_RESULT' in r.stdout

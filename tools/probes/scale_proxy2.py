@@ -2,9 +2,13 @@
   scoring: the scoring pass (ids-only, result copied to the host, passes queued back to back like bench.py) on rank
            0's nnz-balanced user shard — the pass has no collective, so N x (users of the shard) / time is the job's rate;
   build:   the eigensolver on rank 0's row shard with the exchange stubbed (NoComm), per-kernel-class times from HIP
-           events, plus the MODELLED exchange: one sum all-reduce of Z [n_items x l] fp64 per Gramian step over a ring
-           of N GPUs at `--link-gbps` per direction (xGMI, 153 GB/s nominal; 100 GB/s achieved assumed) and one of the
-           l x l Gram matrix per Rayleigh-Ritz.
+           events, plus the MODELLED exchange: per Gramian step one all-gather of X and one reduce-scatter of Z
+           [n_items x l] fp64 (= the volume of a sum all-reduce) over a ring of N GPUs at 100 GB/s per direction
+           (xGMI: 153 GB/s nominal per link; `busbw_300` re-prices it at the 300 GB/s bus bandwidth RCCL reaches when it
+           drives all seven links) and the l x l all-reduces.  The item-side dense kernels (Gram, tall-skinny GEMM,
+           recurrence, residual: solver.ItemRows shards their rows) are RECORDED from that run and REPLAYED at
+           n_items and at ceil(n_items / N) rows: `non_spmm_sharded_ms` = measured non-SpMM time - replay(n_items) +
+           replay(n_items / N).
 usage: python tools/probes/scale_proxy2.py [ml20m|s1m] [rank] [topk]"""
 import sys, time, json, os
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '.'))
@@ -27,6 +31,44 @@ rank_of, inv = popularity_order(None, n_items, counts=ops.item_counts(A0))
 A0 = ops.csr_relabel_cols(A0, rank_of)
 out = {'workload': WL, 'rank': rank, 'topk': topk, 'build': {}, 'scoring': {}}
 V = None
+ITEM_OPS = ('gram', 'tsmm', 'axpbypcz', 'resid_colnorm2', 'scale_cols')
+
+
+class Recorder:
+    """passes every call through to the device ops and logs the dense ones with their operand shapes"""
+
+    def __init__(self, inner):
+        self.inner, self.log = inner, []
+
+    def __getattr__(self, name):
+        f = getattr(self.inner, name)
+        if name not in ITEM_OPS:
+            return f
+
+        def call(*a, **k):
+            self.log.append((name, [tuple(x.shape) if torch.is_tensor(x) else x for x in a]))
+            return f(*a, **k)
+        return call
+
+
+def replay(log, rows):
+    """the logged item-side calls (first dimension n_items) at `rows` rows, on scratch operands; ms in total"""
+    calls = []
+    for name, args in log:
+        if not (isinstance(args[0 if name != 'axpbypcz' else 1], tuple) and args[0 if name != 'axpbypcz' else 1][0] == n_items):
+            continue
+        mk = lambda shp: torch.randn((rows,) + tuple(shp[1:]), dtype=torch.float64, device='cuda:0') if shp[0] == n_items \
+            else torch.randn(shp, dtype=torch.float64, device='cuda:0')
+        calls.append((name, [mk(a) if isinstance(a, tuple) else a for a in args]))
+    def run():
+        for name, a in calls:
+            getattr(ops, name)(*a)
+    run(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); run(); e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1), len(calls)
+
+
 for N in (1, 2, 4, 8):
     bounds = nnz_balanced_row_partition(c['indptr'], N)
     A = A0 if N == 1 else ops.csr_rows(A0, 0, int(bounds[1]))
@@ -38,20 +80,36 @@ for N in (1, 2, 4, 8):
     _, s, Vn, st = svd_topk(ops, A, rank)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
+    rec = Recorder(ops)
+    timers, ops.timers = ops.timers, None
+    svd_topk(rec, A, rank)
+    torch.cuda.synchronize()
+    ops.timers = timers
+    full_ms, n_calls = replay(rec.log, n_items)
+    shard_ms, _ = replay(rec.log, -(-n_items // N))
     spmm_ms = sum(a.elapsed_time(b) for a, b, _ in ops.timers.get('spmm', []))
     ops.timers = None
     l = st['block']
     z_bytes = n_items * l * 8
     ring = 0.0 if N == 1 else st['gramian_steps'] * (2.0 * (N - 1) / N * z_bytes / LINK + 2 * (N - 1) * 5e-6) \
         + st['outer'] * (2 * (N - 1) * 5e-6)
+    bus = 0.0 if N == 1 else st['gramian_steps'] * (2.0 * (N - 1) / N * z_bytes / 300e9 + 2 * (N - 1) * 5e-6) \
+        + st['outer'] * (2 * (N - 1) * 5e-6)
+    sharded_wall = wall - 1e-3 * (full_ms - shard_ms)
     out['build']['N=%d' % N] = dict(rows_on_rank0=A.shape[0], solver_wall_s=wall, spmm_ms=spmm_ms, non_spmm_ms=1e3 * wall - spmm_ms,
+                                    item_side_calls=n_calls, item_side_ms_replicated=full_ms, item_side_ms_sharded=shard_ms,
+                                    non_spmm_sharded_ms=1e3 * sharded_wall - spmm_ms,
                                     gramian_steps=st['gramian_steps'], modelled_exchange_ms=1e3 * ring,
-                                    modelled_total_s=wall + ring)
+                                    modelled_exchange_ms_busbw_300=1e3 * bus,
+                                    modelled_total_s_replicated=wall + ring,
+                                    modelled_total_s=sharded_wall + ring, modelled_total_s_busbw_300=sharded_wall + bus)
     if N == 1:
         V = Vn
 b1 = out['build']['N=1']['modelled_total_s']
 for k, v in out['build'].items():
     v['speedup_vs_N1'] = b1 / v['modelled_total_s']
+    v['speedup_vs_N1_replicated'] = b1 / v['modelled_total_s_replicated']
+    v['speedup_vs_N1_busbw_300'] = b1 / v['modelled_total_s_busbw_300']
 order2 = torch.argsort(torch.linalg.vector_norm(V, dim=1), descending=True, stable=True)
 rank2 = torch.empty_like(order2); rank2[order2] = torch.arange(n_items, device=order2.device)
 V = V[order2].contiguous()
