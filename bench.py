@@ -629,7 +629,7 @@ def main():
         'data': 'synthetic (planted low-rank + Zipf popularity, seeded; generated on GPU)',
         'config': {'workload': head['workload'], 'n_users': head['n_users'], 'n_items': head['n_items'], 'nnz': head['nnz'],
                    'rank': head['rank'], 'topk': head['topk'],
-                   'parallelism': 'users sharded over %d GPU(s); Gramian all-reduce in build only' % comm.world,
+                   'parallelism': 'users sharded over %d GPU(s); build only: all-gather X / reduce-scatter Z per Gramian step (item side row-sharded), no collective in scoring' % comm.world,
                    'scale': args.scale, 'prune': prune, 'score_order': head['score_order'], 'batches': args.batches or 'auto',
                    'launch': head['launch'],
                    'result': 'int64 [n_users x topk] copied to pinned host memory inside the timed region (double-buffered)'},

@@ -335,9 +335,17 @@ extern "C" int pk_dgemm_small_f64(void *stream, int transA, int transB, int32_t 
 // ---- Cholesky of a small Gram matrix + inverse of the factor (CholeskyQR orthonormalisation) ----------
 // G + shift_rel * trace(G) * I  (n x n, symmetric positive definite) = R^T R with R upper triangular; writes
 // Rinv = R^-1 (upper triangular, zeros below), so that X <- X Rinv has X^T X = I up to cond(G) * eps.
-// One workgroup: R lives in LDS for n <= PK_CHOL_LDS_MAX (global `work` otherwise).  The eigensolver
-// orthonormalises an n_items x l block 2-3 times per outer iteration; the eigen-whitening it used first
-// costs a full Jacobi eigh each time (2.2 ms at l = 128), this ~0.2 ms.
+// One workgroup, ONE barrier per column, no substitution phase: the elimination G = L D L^T is run on the augmented
+// matrix [G | I] — the row operations that clear column j below the diagonal turn I into L^-1 — and both halves
+// share one n x n array: the upper triangle (with the diagonal) holds D L^T, the strictly lower triangle L^-1
+// (unit diagonal implied; the symmetric lower half of G is never needed).  Step j, for every row i > j with
+// f = A[j][i] / d_j:   A[i][c] -= f * A[j][c]  for c < j (L^-1 part),  A[i][j] = -f,  A[i][k] -= f * A[j][k]  for
+// k >= i (trailing update); row j itself is not touched, so the only hazard is between steps.  At the end
+// R = D^1/2 L^T, hence Rinv[k][c] = Linv[c][k] / sqrt(d_c).  Threads form a (rows x columns) grid, a thread keeps its
+// column of the pivot row in a register.  The array lives in LDS for n <= PK_CHOL_LDS_MAX (leading dimension n + 1
+// against bank conflicts of the transposed read at the end), in global `work` otherwise.
+// Round 1 factorised with three barriers per column and back-substituted one thread per column through global
+// memory: 161 us at n = 64, 727 us at n = 128; the eigensolver orthonormalises 3 times per outer iteration.
 // info[0] = 0, or j + 1 if the pivot of column j is not positive (rank-deficient block: the caller falls
 // back to the eigen-whitening, which clamps).
 #define PK_CHOL_LDS_MAX 136
@@ -346,59 +354,55 @@ template <bool IN_LDS>
 __global__ __launch_bounds__(PK_CHOL_THREADS) void chol_rinv_kernel(int n, const double *__restrict__ G, int64_t ldg,
                                                                     double shift_rel, double *__restrict__ Rinv,
                                                                     int64_t ldr, double *__restrict__ work,
-                                                                    int32_t *__restrict__ info) {
+                                                                    int32_t *__restrict__ info, int tx_log2) {
     extern __shared__ double chol_lds[];
-    __shared__ int s_fail;
     __shared__ double s_shift;
-    double *R = IN_LDS ? chol_lds : work;
+    double *A = IN_LDS ? chol_lds : work;
+    const int ld = IN_LDS ? n + 1 : n;
     const int tid = threadIdx.x;
-    if (tid == 0) {
+    const int TX = 1 << tx_log2, TY = PK_CHOL_THREADS >> tx_log2;
+    const int tx = tid & (TX - 1), ty = tid >> tx_log2;
+    if (tid < 64) {
         double tr = 0.0;                             // shift = shift_rel * trace(G) >= shift_rel * ||X||_2^2
-        for (int i = 0; i < n; ++i) tr += G[(int64_t)i * ldg + i];
-        s_shift = shift_rel * tr;
+        for (int i = tid; i < n; i += 64) tr += G[(int64_t)i * ldg + i];
+        for (int o = 32; o > 0; o >>= 1) tr += __shfl_xor(tr, o);      // fixed order: the same sum on every rank
+        if (tid == 0) s_shift = shift_rel * tr;
     }
     __syncthreads();
     const double shift = s_shift;
-    for (int e = tid; e < n * n; e += PK_CHOL_THREADS) {
-        const int i = e / n, k = e % n;
-        R[e] = G[(int64_t)i * ldg + k] + ((i == k) ? shift : 0.0);
-    }
-    if (tid == 0) s_fail = 0;
-    __syncthreads();
-    // right-looking factorisation on the upper triangle: after step j, row j holds R[j][j..n)
+    for (int i = ty; i < n; i += TY)
+        for (int c = tx; c < n; c += TX)
+            A[i * ld + c] = (c > i) ? G[(int64_t)i * ldg + c] : (c == i ? G[(int64_t)i * ldg + c] + shift : 0.0);
+    int fail = 0;
     for (int j = 0; j < n; ++j) {
-        const double d = R[j * n + j];
+        __syncthreads();
+        const double d = A[j * ld + j];
         if (!(d > 0.0)) {
-            if (tid == 0) s_fail = j + 1;
+            fail = j + 1;
             break;                                   // uniform: every thread read the same d
         }
-        const double inv = 1.0 / sqrt(d);
-        __syncthreads();
-        for (int k = j + tid; k < n; k += PK_CHOL_THREADS) R[j * n + k] *= inv;
-        __syncthreads();
-        // trailing update A[i][k] -= R[j][i] R[j][k], i > j, k >= i
-        const int m = n - j - 1;
-        for (int e = tid; e < m * m; e += PK_CHOL_THREADS) {
-            const int i = j + 1 + e / m, k = j + 1 + e % m;
-            if (k >= i) R[i * n + k] = fma(-R[j * n + i], R[j * n + k], R[i * n + k]);
+        const double invd = 1.0 / d;
+        for (int c = tx; c < n; c += TX) {
+            const double pj = (c == j) ? 1.0 : A[j * ld + c];
+            for (int i = j + 1 + ty; i < n; i += TY)
+                if (c <= j || c >= i) {
+                    const double f = A[j * ld + i] * invd;
+                    A[i * ld + c] = fma(-f, pj, A[i * ld + c]);
+                }
         }
-        __syncthreads();
     }
     __syncthreads();
-    if (tid == 0) info[0] = s_fail;
-    if (s_fail) return;
-    // Rinv column c by back substitution, one thread per column:  sum_k R[i][k] Rinv[k][c] = delta_ic
-    for (int c = tid; c < n; c += PK_CHOL_THREADS) {
-        for (int i = n - 1; i >= 0; --i) {
-            double acc = (i == c) ? 1.0 : 0.0;
-            if (i <= c) {
-                for (int k = i + 1; k <= c; ++k) acc = fma(-R[i * n + k], Rinv[(int64_t)k * ldr + c], acc);
-                Rinv[(int64_t)i * ldr + c] = acc / R[i * n + i];
-            } else {
-                Rinv[(int64_t)i * ldr + c] = 0.0;
+    if (tid == 0) info[0] = fail;
+    if (fail) return;
+    for (int k = ty; k < n; k += TY)
+        for (int c = tx; c < n; c += TX) {
+            double v = 0.0;
+            if (c >= k) {
+                const double rs = 1.0 / sqrt(A[c * ld + c]);
+                v = (c == k) ? rs : A[c * ld + k] * rs;
             }
+            Rinv[(int64_t)k * ldr + c] = v;
         }
-    }
 }
 
 extern "C" int64_t pk_chol_work_bytes(int32_t n) { return (n > PK_CHOL_LDS_MAX) ? (int64_t)n * n * 8 : 0; }
@@ -411,20 +415,22 @@ extern "C" int pk_chol_rinv_f64(void *stream, int32_t n, const double *G_dev, in
     if (!attr_set) {
         hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&chol_rinv_kernel<true>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            PK_CHOL_LDS_MAX * PK_CHOL_LDS_MAX * 8);
+                                            PK_CHOL_LDS_MAX * (PK_CHOL_LDS_MAX + 1) * 8);
         if (e1 != hipSuccess) {
             pk_set_error("pk_chol_rinv_f64: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e1));
             return PK_E_LAUNCH;
         }
         attr_set = true;
     }
+    int tx_log2 = 4;                                 // columns of the thread grid: the power of two >= n, 16 ... 256
+    while ((1 << tx_log2) < n && tx_log2 < 8) ++tx_log2;
     if (n <= PK_CHOL_LDS_MAX)
-        hipLaunchKernelGGL(chol_rinv_kernel<true>, dim3(1), dim3(PK_CHOL_THREADS), (size_t)n * n * sizeof(double),
+        hipLaunchKernelGGL(chol_rinv_kernel<true>, dim3(1), dim3(PK_CHOL_THREADS), (size_t)n * (n + 1) * sizeof(double),
                            pk_stream(stream), n, G_dev, ldg, shift_rel, Rinv_dev, ldr, static_cast<double *>(work_dev),
-                           info_dev);
+                           info_dev, tx_log2);
     else
         hipLaunchKernelGGL(chol_rinv_kernel<false>, dim3(1), dim3(PK_CHOL_THREADS), 0, pk_stream(stream), n, G_dev,
-                           ldg, shift_rel, Rinv_dev, ldr, static_cast<double *>(work_dev), info_dev);
+                           ldg, shift_rel, Rinv_dev, ldr, static_cast<double *>(work_dev), info_dev, tx_log2);
     PK_CHECK_LAUNCH("chol_rinv_kernel");
     return PK_OK;
 }
