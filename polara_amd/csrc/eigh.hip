@@ -18,19 +18,56 @@
 #define EIGH_WAVES (EIGH_THREADS / 64)
 
 __device__ __forceinline__ void rr_pair(int m, int step, int k, int &p, int &q) {
-    // circle method on m (even) players: player m-1 fixed, the others rotate
+    // circle method on m (even) players: player m-1 fixed, the others rotate.  0 <= step < m - 1, 0 <= k < m / 2, so
+    // both sums stay below 2 (m - 1): one conditional subtraction instead of a division by a run-time value
+    const int r = m - 1;
     if (k == 0) {
-        p = m - 1;
-        q = step % (m - 1);
+        p = r;
+        q = step;
     } else {
-        p = (step + k) % (m - 1);
-        q = (step - k + (m - 1)) % (m - 1);
+        p = step + k;
+        p -= (p >= r) ? r : 0;
+        q = step - k + r;
+        q -= (q >= r) ? r : 0;
     }
     if (p > q) {
         int t = p;
         p = q;
         q = t;
     }
+}
+
+// Plane rotation that makes two rows with squared norms alpha, beta and inner product gamma orthogonal:
+//   t = sgn(d) 2 gamma / (|d| + sqrt(d^2 + 4 gamma^2)),  d = beta - alpha;   cs = 1 / sqrt(1 + t^2),  sn = cs t
+// (the textbook zeta = d / (2 gamma), t = sgn(zeta) / (|zeta| + sqrt(1 + zeta^2)) multiplied through by |2 gamma|: one square
+// root and one reciprocal less).  The whole chain sits on the critical path of a tournament step — 16 waves wait at the
+// barrier for it — so it runs on v_rsq_f64 / v_rcp_f64 seeds with Newton steps instead of the IEEE divide and sqrt
+// expansions (~5 x 15 dependent instructions).  The ANGLE only needs to be good enough for the pair to come out
+// orthogonal to working accuracy next time round (two Newton steps); cs is refined three times because cs^2 + sn^2 =
+// cs^2 (1 + t^2) must be 1 to rounding — a rotation that is not orthogonal would rescale the rows, i.e. the eigenvalues.
+// The inputs are scaled by a power of two so that nothing overflows or underflows whatever the scale of S.
+__device__ __forceinline__ double eigh_rsqrt(double x, int newton) {
+    double y = __builtin_amdgcn_rsq(x);
+    for (int i = 0; i < newton; ++i) y = y * fma(-0.5 * x, y * y, 1.5);
+    return y;
+}
+__device__ __forceinline__ bool eigh_rotation(double alpha, double beta, double gamma, double tol2, double &cs, double &sn) {
+    const int e = __builtin_amdgcn_frexp_exp(fmax(alpha, beta));       // 0 for a zero argument
+    alpha = ldexp(alpha, -e);
+    beta = ldexp(beta, -e);
+    gamma = ldexp(gamma, -e);
+    if (!(gamma * gamma > tol2 * alpha * beta) || gamma == 0.0) return false;
+    const double d = beta - alpha, g2 = 2.0 * gamma;
+    const double x = fma(d, d, g2 * g2);
+    const double h = x * eigh_rsqrt(x, 2);
+    const double s = fabs(d) + h;
+    double r = __builtin_amdgcn_rcp(s);
+    r = r * fma(-s, r, 2.0);
+    r = r * fma(-s, r, 2.0);
+    const double t = (d >= 0.0 ? g2 : -g2) * r;
+    cs = eigh_rsqrt(fma(t, t, 1.0), 3);
+    sn = cs * t;
+    return true;
 }
 
 // One-sided Jacobi needs no accumulated rotation matrix for a PSD input: at convergence the rows of
@@ -60,8 +97,68 @@ __device__ __forceinline__ double eigh_row16_sum(double v) {
     v = eigh_dpp_add<0x140>(v);  // row_mirror
     return v;
 }
+
+// One pair of a tournament step, done by a 16-lane DPP row: lane t owns columns t + 16 j.  NC > 0: the (at most NC)
+// columns of both rows a lane owns stay in registers between the three inner products and the rotation, so a step moves
+// every row through the LDS pipe twice (read, write) instead of three times — with one workgroup on one CU that pipe
+// (128 B/clk) is what bounds a step once n reaches ~100: 128 x 128 x 8 B x 3 = 3 072 clocks of a ~4 500-clock step.
+// NC == 0: any n, rows re-read for the rotation.  Same summation order either way.
+template <int NC>
+__device__ __forceinline__ bool eigh_pair_step(double *wp, double *wq, int n, int t, bool act, double tol2) {
+    double alpha = 0.0, beta = 0.0, gamma = 0.0;
+    double cs = 1.0, sn = 0.0;
+    if constexpr (NC > 0) {
+        double a[NC], b[NC];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const int c = t + 16 * j;
+            const bool in = act && c < n;
+            a[j] = in ? wp[c] : 0.0;
+            b[j] = in ? wq[c] : 0.0;
+            alpha = fma(a[j], a[j], alpha);
+            beta = fma(b[j], b[j], beta);
+            gamma = fma(a[j], b[j], gamma);
+        }
+        alpha = eigh_row16_sum(alpha);
+        beta = eigh_row16_sum(beta);
+        gamma = eigh_row16_sum(gamma);
+        const bool rot = act && eigh_rotation(alpha, beta, gamma, tol2, cs, sn);
+        if (rot) {
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                const int c = t + 16 * j;
+                if (c < n) {
+                    wp[c] = cs * a[j] - sn * b[j];
+                    wq[c] = sn * a[j] + cs * b[j];
+                }
+            }
+        }
+        return rot;
+    } else {
+        if (act) {
+            for (int c = t; c < n; c += 16) {
+                const double a = wp[c], b = wq[c];
+                alpha = fma(a, a, alpha);
+                beta = fma(b, b, beta);
+                gamma = fma(a, b, gamma);
+            }
+        }
+        alpha = eigh_row16_sum(alpha);
+        beta = eigh_row16_sum(beta);
+        gamma = eigh_row16_sum(gamma);
+        const bool rot = act && eigh_rotation(alpha, beta, gamma, tol2, cs, sn);
+        if (rot) {
+            for (int c = t; c < n; c += 16) {
+                const double a = wp[c], b = wq[c];
+                wp[c] = cs * a - sn * b;
+                wq[c] = sn * a + cs * b;
+            }
+        }
+        return rot;
+    }
+}
 #define EIGH_LDS_MAX 136
-template <bool IN_LDS>
+template <bool IN_LDS, int NC>
 __global__ __launch_bounds__(EIGH_THREADS) void eigh_psd_kernel(int n, double *__restrict__ Wg, int64_t ldwg,
                                                                 double *__restrict__ Rg, int64_t ldrg,
                                                                 double *__restrict__ evals, int max_sweeps,
@@ -101,31 +198,8 @@ __global__ __launch_bounds__(EIGH_THREADS) void eigh_psd_kernel(int n, double *_
                     act = q < n;  // bye
                 }
                 double *wp = W + (int64_t)p * ldw, *wq = W + (int64_t)q * ldw;
-                double alpha = 0.0, beta = 0.0, gamma = 0.0;
-                if (act) {
-                    for (int c = t; c < n; c += 16) {
-                        const double a = wp[c], b = wq[c];
-                        alpha = fma(a, a, alpha);
-                        beta = fma(b, b, beta);
-                        gamma = fma(a, b, gamma);
-                    }
-                }
-                alpha = eigh_row16_sum(alpha);
-                beta = eigh_row16_sum(beta);
-                gamma = eigh_row16_sum(gamma);
                 // rotate only if the pair is not yet orthogonal to relative accuracy tol
-                const bool rot = act && gamma * gamma > tol2 * alpha * beta && gamma != 0.0;
-                if (rot) {
-                    const double zeta = (beta - alpha) / (2.0 * gamma);
-                    const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                    const double cs = 1.0 / sqrt(1.0 + tt * tt);
-                    const double sn = cs * tt;
-                    for (int c = t; c < n; c += 16) {
-                        const double a = wp[c], b = wq[c];
-                        wp[c] = cs * a - sn * b;
-                        wq[c] = sn * a + cs * b;
-                    }
-                }
+                const bool rot = eigh_pair_step<NC>(wp, wq, n, t, act, tol2);
                 const unsigned long long rb = __ballot(rot && t == 0);
                 if (lane == 0 && rb) atomicAdd(&s_rot, __popcll(rb));
             }
@@ -252,6 +326,7 @@ __global__ __launch_bounds__(EIGH_THREADS) void eigh_psd_kernel(int n, double *_
 // the rotation counts of an outer sweep go to a device counter, and every launch of a later sweep returns at once
 // when the previous sweep rotated nothing — the host never reads the counter.
 #define EIGH_BLOCK_LDS (144 * 1024)
+template <int NC>
 __global__ __launch_bounds__(EIGH_THREADS) void eigh_block_round_kernel(int n, double *__restrict__ Wg, int64_t ldwg, int w,
                                                                         int nb, int round, int sweep,
                                                                         int *__restrict__ counters, double tol) {
@@ -288,30 +363,7 @@ __global__ __launch_bounds__(EIGH_THREADS) void eigh_block_round_kernel(int n, d
                 act = q < nr;  // bye
             }
             double *wp = W + (int64_t)p * n, *wq = W + (int64_t)q * n;
-            double alpha = 0.0, beta = 0.0, gamma = 0.0;
-            if (act) {
-                for (int c = t; c < n; c += 16) {
-                    const double a = wp[c], b = wq[c];
-                    alpha = fma(a, a, alpha);
-                    beta = fma(b, b, beta);
-                    gamma = fma(a, b, gamma);
-                }
-            }
-            alpha = eigh_row16_sum(alpha);
-            beta = eigh_row16_sum(beta);
-            gamma = eigh_row16_sum(gamma);
-            const bool rot = act && gamma * gamma > tol2 * alpha * beta && gamma != 0.0;
-            if (rot) {
-                const double zeta = (beta - alpha) / (2.0 * gamma);
-                const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                const double cs = 1.0 / sqrt(1.0 + tt * tt);
-                const double sn = cs * tt;
-                for (int c = t; c < n; c += 16) {
-                    const double a = wp[c], b = wq[c];
-                    wp[c] = cs * a - sn * b;
-                    wq[c] = sn * a + cs * b;
-                }
-            }
+            const bool rot = eigh_pair_step<NC>(wp, wq, n, t, act, tol2);
             const unsigned long long rb = __ballot(rot && t == 0);
             if (lane == 0 && rb) atomicAdd(&s_rot, __popcll(rb));
         }
@@ -345,20 +397,25 @@ extern "C" int pk_eigh_psd_f64(void *stream, int32_t n, double *S_dev, int64_t l
     PK_REQUIRE(S_dev && evecs_dev && evals_dev && S_dev != evecs_dev, "pk_eigh_psd_f64: bad pointers");
     if (max_sweeps <= 0) max_sweeps = 40;
     if (tol <= 0.0) tol = 2.0 * 2.220446049250313e-16 * sqrt((double)n);  // ~ LAPACK dgesvj's sqrt(m)*eps
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&eigh_psd_kernel<true>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            EIGH_LDS_MAX * EIGH_LDS_MAX * 8);
-        if (e1 != hipSuccess) {
-            pk_set_error("pk_eigh_psd_f64: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e1));
-            return PK_E_LAUNCH;
-        }
-        attr_set = true;
-    }
     hipStream_t st = pk_stream(stream);
     if (n <= EIGH_LDS_MAX) {
-        hipLaunchKernelGGL(eigh_psd_kernel<true>, dim3(1), dim3(EIGH_THREADS), (size_t)n * n * sizeof(double),
+        // instances by columns per lane of a 16-lane row (rows held in registers across a rotation)
+        using kern_t = void (*)(int, double *, int64_t, double *, int64_t, double *, int, double, int *);
+        kern_t kern = n <= 32 ? eigh_psd_kernel<true, 2> : n <= 64 ? eigh_psd_kernel<true, 4>
+                    : n <= 96 ? eigh_psd_kernel<true, 6> : n <= 128 ? eigh_psd_kernel<true, 8> : eigh_psd_kernel<true, 9>;
+        const int slot = n <= 32 ? 0 : n <= 64 ? 1 : n <= 96 ? 2 : n <= 128 ? 3 : 4;
+        static bool attr_set[5] = {false, false, false, false, false};
+        if (!attr_set[slot]) {
+            hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                EIGH_LDS_MAX * EIGH_LDS_MAX * 8);
+            if (e1 != hipSuccess) {
+                pk_set_error("pk_eigh_psd_f64: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e1));
+                return PK_E_LAUNCH;
+            }
+            attr_set[slot] = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(1), dim3(EIGH_THREADS), (size_t)n * n * sizeof(double),
                            st, n, S_dev, lds_, evecs_dev, ldv, evals_dev, max_sweeps, tol, info_dev);
         PK_CHECK_LAUNCH("eigh_psd_kernel");
         return PK_OK;
@@ -368,15 +425,18 @@ extern "C" int pk_eigh_psd_f64(void *stream, int32_t n, double *S_dev, int64_t l
     while ((int64_t)2 * ((n + nb - 1) / nb) * n * 8 > EIGH_BLOCK_LDS) nb += 2;
     const int w = (n + nb - 1) / nb;
     const size_t lds_bytes = (size_t)2 * w * n * sizeof(double);
-    static bool attr_set_b = false;
-    if (!attr_set_b) {
-        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&eigh_block_round_kernel),
+    using round_t = void (*)(int, double *, int64_t, int, int, int, int, int *, double);
+    round_t round_kern = n <= 160 ? eigh_block_round_kernel<10> : n <= 256 ? eigh_block_round_kernel<16> : eigh_block_round_kernel<0>;
+    const int slot_b = n <= 160 ? 0 : n <= 256 ? 1 : 2;
+    static bool attr_set_b[3] = {false, false, false};
+    if (!attr_set_b[slot_b]) {
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(round_kern),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, EIGH_BLOCK_LDS);
         if (e1 != hipSuccess) {
             pk_set_error("pk_eigh_psd_f64: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e1));
             return PK_E_LAUNCH;
         }
-        attr_set_b = true;
+        attr_set_b[slot_b] = true;
     }
     if (max_sweeps > 30) max_sweeps = 30;   // every (sweep, round) is a launch, early-exit ones included
     // the rotation counters of the outer sweeps live in evals_dev until the final pass writes the eigenvalues there
@@ -385,11 +445,11 @@ extern "C" int pk_eigh_psd_f64(void *stream, int32_t n, double *S_dev, int64_t l
     hipLaunchKernelGGL(eigh_counters_init_kernel, dim3(1), dim3(64), 0, st, counters, max_sweeps + 1);
     for (int sweep = 0; sweep < max_sweeps; ++sweep)
         for (int round = 0; round < nb - 1; ++round)
-            hipLaunchKernelGGL(eigh_block_round_kernel, dim3(nb / 2), dim3(EIGH_THREADS), lds_bytes, st, n, S_dev, lds_, w, nb,
+            hipLaunchKernelGGL(round_kern, dim3(nb / 2), dim3(EIGH_THREADS), lds_bytes, st, n, S_dev, lds_, w, nb,
                                round, sweep, counters, tol);
     if (info_dev) hipLaunchKernelGGL(eigh_block_info_kernel, dim3(1), dim3(1), 0, st, counters, max_sweeps, info_dev);
     // norms, ordering, signs: the tail of the one-workgroup kernel (no sweeps of its own)
-    hipLaunchKernelGGL(eigh_psd_kernel<false>, dim3(1), dim3(EIGH_THREADS), 0, st, n, S_dev, lds_, evecs_dev, ldv, evals_dev,
+    hipLaunchKernelGGL((eigh_psd_kernel<false, 0>), dim3(1), dim3(EIGH_THREADS), 0, st, n, S_dev, lds_, evecs_dev, ldv, evals_dev,
                        0, tol, (int *)nullptr);
     PK_CHECK_LAUNCH("eigh block kernels");
     return PK_OK;
