@@ -64,6 +64,10 @@ WORKLOAD_TEXT = {
 }
 
 
+def log(msg):
+    print('[bench] ' + msg, file=sys.stderr, flush=True)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -81,11 +85,14 @@ def parse():
     ap.add_argument('--batches', type=int, default=0,
                     help='user batches per scoring pass, round-robin on two HIP streams (0 = auto: one batch per 4M users)')
     ap.add_argument('--scale', type=float, default=1.0, help='shrink users/items (debug only; invalidates the number)')
-    ap.add_argument('--graph', action='store_true',
-                    help='capture the pass over this fixed user set once in a hipGraph and replay it (scoring.CapturedPass) '
-                         'instead of launching it kernel by kernel from Python; measured: no difference at any shard size '
-                         '(1.42 / 0.83 / 0.58 / 0.50 ms per pass for the ML-20M-shaped shards of 1 / 2 / 4 / 8 GPUs either '
-                         'way — the pass is bound by its kernels, not by its launches), hence off by default')
+    ap.add_argument('--no-graph', dest='graph', action='store_false',
+                    help='launch every pass kernel by kernel from Python, no questions asked.  Default: the pass over this '
+                         'fixed user set is also captured once in a hipGraph (scoring.CapturedPass; the replay is checked '
+                         'against a launched pass), both ways of launching are timed during warm-up and the timed region runs '
+                         'the faster one (config.launch says which; warmup_calibration_ms_per_step holds both).  Since the '
+                         'split-bf16 sweep an ML-20M-shaped pass is ~0.9 ms of kernels: ~14 Python launches cost 0.9-1.3 ms '
+                         'of host time depending on the box, a replay ~10 us per graph node: 1.03-1.17 ms')
+    ap.set_defaults(graph=True)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-users', type=int, default=0, help='users in the CPU scoring sample (0 = auto)')
     return ap.parse_args()
@@ -252,15 +259,24 @@ class Bench:
         kw = dict(prune=prune, batches=batches)
         main = torch.cuda.current_stream(self.dev)
         cap = stage = None
+        self.launch_mode = 'python, kernel by kernel'
         if self.args.graph and not batches:
-            cap = scoring.CapturedPass(ops, F, A, topk, True, prune=prune)
-            check = scoring.recommend(ops, F, A, topk, True, prune=prune)
-            assert bool((cap.replay() == check).all()), 'the replayed graph and the launched pass disagree'
-            stage = [torch.empty_like(cap.out) for _ in range(2)]    # the graph rewrites its output buffer every replay
+            try:
+                cap = scoring.CapturedPass(ops, F, A, topk, True, prune=prune)
+                check = scoring.recommend(ops, F, A, topk, True, prune=prune)
+                if not bool((cap.replay() == check).all()):
+                    raise RuntimeError('the replayed graph and the launched pass disagree')
+                stage = [torch.empty_like(cap.out) for _ in range(2)]    # the graph rewrites its output buffer every replay
+                self.launch_mode = 'hipGraph replay of the captured pass'
+            except Exception as exc:      # a capture problem must not cost the run its number
+                log('graph capture failed (%s: %s): launching kernel by kernel' % (type(exc).__name__, exc))
+                cap = stage = None
+                torch.cuda.synchronize()
+                self.launch_mode = 'python, kernel by kernel (hipGraph capture failed: %s)' % type(exc).__name__
 
-        def one(i):
+        def one(i, use_cap=True):
             b = i & 1
-            if cap is not None:
+            if cap is not None and use_cap:
                 recs = stage[b]
                 recs.copy_(cap.replay())       # device copy (microseconds): the D2H of pass i overlaps replay i + 1
             else:
@@ -273,17 +289,43 @@ class Bench:
                 recs.record_stream(self.copy_stream)
                 done[b].record(self.copy_stream)
             return recs
-        for i in range(warmup):
-            one(i)
+        def loop(n, use_cap):
+            r = None
+            for i in range(n):
+                if i >= 2:
+                    done[i & 1].synchronize()   # the buffer about to be overwritten has been consumed (two passes ago)
+                r = one(i, use_cap)
+            return r
+
+        # warm-up, untimed as far as `value` goes.  With a captured pass at hand the two ways of launching are
+        # calibrated here (graph replay costs ~10 us per node on this runtime, Python launches cost host time that
+        # varies with the box: either can win by 20 %) and the timed region below runs the faster one, all K steps
+        cal = {}
+        use_cap = cap is not None
+        if cap is not None:
+            n_cal = max(10, warmup)
+            for mode in (True, False):
+                loop(2, mode)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                loop(n_cal, mode)
+                torch.cuda.synchronize()
+                cal[mode] = 1e3 * (time.perf_counter() - t1) / n_cal
+            use_cap = cal[True] <= cal[False]
+            if self.world > 1:            # every rank launches the same way
+                flag = torch.tensor([1.0 if use_cap else 0.0], dtype=torch.float64,
+                                    device='cpu' if self.debug_backend == 'gloo' else self.dev)
+                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+                use_cap = bool(flag.item() > 0.5)
+            if not use_cap:
+                self.launch_mode = 'python, kernel by kernel (faster than replaying the captured pass on this box)'
+        loop(warmup, use_cap)
         gc.collect()
         gc_was = gc.isenabled()
         gc.disable()                      # no collector pauses inside the timed region
         self.barrier()
         t0 = time.perf_counter()
-        for i in range(steps):
-            if i >= 2:
-                done[i & 1].synchronize()   # the buffer about to be overwritten has been consumed (two passes ago)
-            recs = one(i)
+        recs = loop(steps, use_cap)
         self.barrier()
         elapsed = time.perf_counter() - t0
         if gc_was:
@@ -293,7 +335,7 @@ class Bench:
         for i in range(3):
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            one(i)
+            one(i, use_cap)
             torch.cuda.synchronize()
             lat.append(time.perf_counter() - t1)
         if self.world > 1:
@@ -301,8 +343,12 @@ class Bench:
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
             elapsed = float(tt.item())
         last = host[(steps - 1) & 1 if steps else 0]
-        return elapsed, recs, dict(latency_ms_per_pass=1e3 * float(np.median(lat)),
-                                   d2h_bytes_per_pass=int(n_local * topk * 8), host_result=last)
+        extras = dict(latency_ms_per_pass=1e3 * float(np.median(lat)), d2h_bytes_per_pass=int(n_local * topk * 8),
+                      host_result=last, launch=self.launch_mode)
+        if cal:
+            extras['python_launch_ms_per_step'] = cal[False]
+            extras['graph_replay_ms_per_step'] = cal[True]
+        return elapsed, recs, extras
 
     def kernel_times(self, st, topk, prune=True):
         """five untimed instrumented passes back to back (HIP events around every kernel, on the launch stream), then
@@ -400,7 +446,9 @@ class Bench:
                 'workload': '%s, PureSVD rank=%d, top-%d, all users scored' % (WORKLOAD_TEXT[workload], rank, topk),
                 'n_users': n_users, 'n_items': n_items, 'nnz': nnz, 'rank': rank, 'topk': topk, 'prune': prune,
                 'score_order': 'factor norm' if norm_order else 'popularity',
-                'launch': 'hipGraph replay of the captured pass' if (self.args.graph and not self.args.batches) else 'python, kernel by kernel',
+                'launch': extra.get('launch', 'python, kernel by kernel'),
+                'warmup_calibration_ms_per_step': {'python_launch': extra.get('python_launch_ms_per_step'),
+                                                   'graph_replay': extra.get('graph_replay_ms_per_step')},
                 'build_s': tb['total_s'], 'build': dict(tb, gramian_steps=bstats['gramian_steps'],
                                                          outer_iterations=bstats['outer'], block=bstats['block'],
                                                          converged=bstats['converged'],
@@ -634,6 +682,7 @@ def main():
                    'launch': head['launch'],
                    'result': 'int64 [n_users x topk] copied to pinned host memory inside the timed region (double-buffered)'},
         'latency_ms_per_pass': head['latency_ms_per_pass'], 'd2h_bytes_per_pass': head['d2h_bytes_per_pass'],
+        'warmup_calibration_ms_per_step': head.get('warmup_calibration_ms_per_step'),
         'build_s': head['build_s'], 'build': head['build'], 'build_cold': head.get('build_cold'),
         'score': head['score'], 'roofline': head.get('roofline'), 'roofline_build': head.get('roofline_build'),
         'gen_s': gen_s,

@@ -182,7 +182,11 @@ __device__ __forceinline__ double pk_dot_f32row(const float *__restrict__ vr, co
 // time) against the instructions of the segment sort, which serve fewer users per wave.
 // (The first version gave a whole wave to each user and paid a 6-step fp64 wave reduction per candidate
 // plus a 64-lane sort: 2.7 ms per 1M users; LPC = 1: 1.04 ms.)
-template <int SEG, int LPC>
+// SCORE4 (segments that fill a wave, SEG * LPC == 64): the scores are computed 16 candidates at a time by FOUR lanes
+// each (pk_dot_*<4>: the same bits) and handed to the lanes that sort them — a gather instruction then touches 16 item
+// rows of 64 contiguous bytes instead of 64 rows of 16 (LPC = 1, KC = 64) or 32 of 32: the texture path serves one line
+// per clock, and at rank 200 / 64 candidates the re-scoring was 11 ms of a 53 ms pass (S-50M shard).
+template <int SEG, int LPC, bool SCORE4>
 __global__ __launch_bounds__(256) void rescore_topk_kernel(
     int64_t n_rows, const int32_t *__restrict__ rows, const int32_t *__restrict__ n_rows_dev, int64_t n_users,
     int64_t n_items, int K, const double *__restrict__ V, int64_t ldv, const float *__restrict__ V32, int64_t ldv32,
@@ -223,7 +227,22 @@ __global__ __launch_bounds__(256) void rescore_topk_kernel(
     // row), its rounding joins delta below; exact E rows (second pass, or no approximation at all): fp64 rows
     const bool use32 = (V32 != nullptr) && (e_err != nullptr) && !e_exact;
     double e2, s;
-    if (use32) {
+    if constexpr (SCORE4) {
+        static_assert(SEG * LPC == 64, "SCORE4: one user per wave");
+        const bool v32vec = evec2 && (ldv32 & 3) == 0 && (((uintptr_t)V32) & 15) == 0;
+        const int q4 = lane & 3;
+        s = 0.0;
+#pragma unroll
+        for (int j = 0; j < SEG / 16; ++j) {
+            const int c = 16 * j + (lane >> 2);                    // the candidate this lane quad scores in pass j
+            const int cidx = __shfl(idx, c * LPC, 64);
+            const int64_t row = cidx >= 0 ? cidx : 0;
+            const double sj = use32 ? pk_dot_f32row<4>(V32 + row * ldv32, er, K, q4, v32vec, &e2)
+                                    : pk_dot_chains<4>(V + row * ldv, er, K, q4, vvec2, evec2, &e2);
+            const double got = __shfl(sj, 4 * (t & 15), 64);       // candidate t was scored in pass t / 16
+            if ((t >> 4) == j) s = got;
+        }
+    } else if (use32) {
         const bool v32vec = evec2 && (ldv32 & 3) == 0 && (((uintptr_t)V32) & 15) == 0;
         s = pk_dot_f32row<LPC>(V32 + (int64_t)(idx >= 0 ? idx : 0) * ldv32, er, K, q, v32vec, &e2);
     } else {
@@ -293,8 +312,11 @@ extern "C" int pk_rescore_topk_rows_f64(void *stream, int64_t n_rows, const int3
     const int seg = (KC * splits <= 16) ? 16 : (KC * splits <= 32) ? 32 : 64;
     const char *lpc_env = getenv("PK_RESCORE_LPC");      // kernel-tuning knob
     const int lpc_req = lpc_env ? atoi(lpc_env) : 0;
-#define PK_RESCORE(SEGV, LPCV)                                                                                    \
-    hipLaunchKernelGGL((rescore_topk_kernel<SEGV, LPCV>), dim3((unsigned)pk_ceil_div(n_rows, 4 * (64 / (SEGV * LPCV)))), \
+    const char *s4_env = getenv("PK_RESCORE_SCORE4");    // kernel-tuning knob: 0 = one scoring pass with LPC lanes per candidate
+    const bool score4 = s4_env ? atoi(s4_env) != 0 : true;
+#define PK_RESCORE(SEGV, LPCV) PK_RESCORE_X(SEGV, LPCV, false)
+#define PK_RESCORE_X(SEGV, LPCV, S4)                                                                                    \
+    hipLaunchKernelGGL((rescore_topk_kernel<SEGV, LPCV, S4>), dim3((unsigned)pk_ceil_div(n_rows, 4 * (64 / (SEGV * LPCV)))), \
                        dim3(256), 0, pk_stream(stream), n_rows, rows_dev, n_rows_dev, n_users, n_items, K, V_dev, ldv, V32_dev, ldv32, E_dev, lde, \
                        e_err_dev, e_err_ld, e_exact, seen_ptr_dev, KC, splits, cand_score_dev, cand_idx_dev, topk, v_row_norm_max,   \
                        out_idx_dev, out_score_dev, flags_dev)
@@ -304,11 +326,14 @@ extern "C" int pk_rescore_topk_rows_f64(void *stream, int64_t n_rows, const int3
         else PK_RESCORE(16, 2);
     } else if (seg == 32) {
         if (lpc_req == 1) PK_RESCORE(32, 1);
+        else if (score4) PK_RESCORE_X(32, 2, true);
         else PK_RESCORE(32, 2);
     } else {
-        PK_RESCORE(64, 1);
+        if (score4) PK_RESCORE_X(64, 1, true);
+        else PK_RESCORE(64, 1);
     }
 #undef PK_RESCORE
+#undef PK_RESCORE_X
     PK_CHECK_LAUNCH("rescore_topk_kernel");
     return PK_OK;
 }
@@ -358,18 +383,20 @@ extern "C" int pk_flag_compact(void *stream, int64_t n, const int32_t *flags_dev
 }
 
 // E[row_offset + list[r], 0:K] = sum_p vals[p] * V[indices[p], 0:K] in fp64 for the listed rows of a CSR.
-// A fixed grid of workgroups strides over the list (its length is only known on the device); the four waves
-// of a workgroup take every fourth 64-pair chunk of the row, eight independent row gathers in flight each
-// (a flagged row can have thousands of entries), and their partial sums are added in wave order.
+// A fixed grid of workgroups strides over the list (its length is only known on the device); the sixteen waves
+// of a workgroup take every sixteenth 64-pair chunk of the row, eight independent row gathers in flight each
+// (the rows that need re-folding are the long ones — thousands of entries — and the kernel lasts as long as the longest:
+// with four waves 54 us for 140 users of an ML-20M-shaped pass), and their partial sums are added in wave order.
 #define PK_FOLD_BLOCKS 2048
+#define PK_FOLD_WAVES 16
 template <typename VT, int CPL>
-__global__ __launch_bounds__(256) void fold_rows_kernel(int64_t cap, const int32_t *__restrict__ list,
+__global__ __launch_bounds__(64 * PK_FOLD_WAVES) void fold_rows_kernel(int64_t cap, const int32_t *__restrict__ list,
                                                         const int32_t *__restrict__ count, int64_t row_offset,
                                                         const int64_t *__restrict__ indptr,
                                                         const int32_t *__restrict__ indices,
                                                         const VT *__restrict__ vals, const double *__restrict__ V,
                                                         int64_t ldv, int K, double *__restrict__ E, int64_t lde) {
-    __shared__ double part[4][64 * CPL];
+    __shared__ double part[PK_FOLD_WAVES][64 * CPL];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int64_t n = (*count < cap) ? *count : cap;
@@ -385,7 +412,7 @@ __global__ __launch_bounds__(256) void fold_rows_kernel(int64_t cap, const int32
         double acc[CPL];
 #pragma unroll
         for (int g = 0; g < CPL; ++g) acc[g] = 0.0;
-        for (int64_t base = p0 + 64 * wave; base < p1; base += 256) {
+        for (int64_t base = p0 + 64 * wave; base < p1; base += 64 * PK_FOLD_WAVES) {
             int j = 0;
             double a = 0.0;             // padded lanes hold (0, 0.0): they add 0 * V[0, :]
             if (base + lane < p1) {
@@ -419,7 +446,12 @@ __global__ __launch_bounds__(256) void fold_rows_kernel(int64_t cap, const int32
 #pragma unroll
             for (int g = 0; g < CPL; ++g) {
                 const int c = lane + 64 * g;
-                if (c < K) E[row * lde + c] = ((part[0][c] + part[1][c]) + part[2][c]) + part[3][c];
+                if (c < K) {
+                    double tot = part[0][c];
+#pragma unroll
+                    for (int w = 1; w < PK_FOLD_WAVES; ++w) tot += part[w][c];
+                    E[row * lde + c] = tot;
+                }
             }
         }
         __syncthreads();
@@ -433,7 +465,7 @@ extern "C" int pk_fold_rows_f64(void *stream, int64_t cap, const int32_t *list_d
     PK_REQUIRE(cap >= 1 && K >= 1 && K <= 256 && ldv >= K && lde >= K, "pk_fold_rows_f64: bad sizes");
     // indices_dev / vals_dev may be NULL for a matrix without entries (never dereferenced then)
     PK_REQUIRE(list_dev && count_dev && indptr_dev, "pk_fold_rows_f64: bad pointers");
-    dim3 grid((unsigned)(cap < PK_FOLD_BLOCKS ? cap : PK_FOLD_BLOCKS)), block(256);
+    dim3 grid((unsigned)(cap < PK_FOLD_BLOCKS ? cap : PK_FOLD_BLOCKS)), block(64 * PK_FOLD_WAVES);
     PK_REQUIRE(val_kind == PK_VAL_F32 || val_kind == PK_VAL_F64, "pk_fold_rows_f64: bad val_kind %d", val_kind);
     const int cpl = (K + 63) / 64;
 #define PK_FOLD(VT, C)                                                                                           \
@@ -457,11 +489,18 @@ extern "C" int pk_fold_rows_f64(void *stream, int64_t cap, const int32_t *list_d
 // ------------------------------------------------------------------------------------------
 // exact rows: one workgroup per listed user
 // ------------------------------------------------------------------------------------------
-extern "C" int64_t pk_exact_work_bytes(int32_t n_rows, int64_t n_items) {
-    // fp64 score + 1 class byte per item, rows padded to 16 bytes
-    const int64_t per_row = n_items * 8 + ((n_items + 15) / 16) * 16;
-    return (int64_t)n_rows * per_row;
+#define PK_EXACT_CHUNK 1024
+#define PK_EXACT_TOPK_MAX 256
+#define PK_EXACT_CHUNKS_MAX 8192
+static int64_t exact_per_row(int64_t n_items) {
+    // one-workgroup kernel: fp64 score + 1 class byte per item; chunk kernels: per chunk of PK_EXACT_CHUNK items at most
+    // min(PK_EXACT_TOPK_MAX, n_items) candidates of 13 bytes (score, index, class); padded to 16 bytes
+    const int64_t slow = n_items * 8 + ((n_items + 15) / 16) * 16;
+    const int64_t kmax = n_items < PK_EXACT_TOPK_MAX ? n_items : PK_EXACT_TOPK_MAX;
+    const int64_t fast = ((pk_ceil_div(n_items, PK_EXACT_CHUNK) * kmax * 13 + 15) / 16) * 16;
+    return slow > fast ? slow : fast;
 }
+extern "C" int64_t pk_exact_work_bytes(int32_t n_rows, int64_t n_items) { return (int64_t)n_rows * exact_per_row(n_items); }
 
 struct Best {
     int cls;  // 0 = unseen (ranks first), 1 = seen, 2 = taken / none
@@ -474,12 +513,12 @@ __device__ __forceinline__ bool best_before(const Best &a, const Best &b) {
     return a.idx < b.idx;
 }
 
-// Every workgroup walks the list with stride gridDim.x (one work slice per workgroup): the number of listed users may
-// live on the device (n_rows_dev), so that the caller never has to read it back before launching.  by_user: results go
-// to row `user` of the outputs instead of row r of the list.
+// Every workgroup walks the list from `first_row` with stride gridDim.x (one work slice per workgroup): the number of
+// listed users may live on the device (n_rows_dev), so that the caller never has to read it back before launching.
+// by_user: results go to row `user` of the outputs instead of row r of the list.
 __global__ __launch_bounds__(256) void score_exact_rows_kernel(
-    int32_t n_rows_host, const int32_t *__restrict__ n_rows_dev, const int32_t *__restrict__ rows, int by_user,
-    int64_t n_items, int K, const double *__restrict__ V, int64_t ldv,
+    int32_t n_rows_host, const int32_t *__restrict__ n_rows_dev, int32_t first_row, const int32_t *__restrict__ rows,
+    int by_user, int64_t n_items, int K, const double *__restrict__ V, int64_t ldv,
     const double *__restrict__ E, int64_t lde, const int64_t *__restrict__ seen_ptr,
     const int32_t *__restrict__ seen_idx, int topk, int64_t *__restrict__ out_idx,
     double *__restrict__ out_score, unsigned char *__restrict__ work, int64_t per_row) {
@@ -491,7 +530,7 @@ __global__ __launch_bounds__(256) void score_exact_rows_kernel(
     const int32_t n_rows = n_rows_dev ? *n_rows_dev : n_rows_host;
     double *score = reinterpret_cast<double *>(work + (int64_t)blockIdx.x * per_row);
     unsigned char *cls = work + (int64_t)blockIdx.x * per_row + n_items * 8;
-  for (int32_t r = blockIdx.x; r < n_rows; r += gridDim.x) {
+  for (int32_t r = first_row + blockIdx.x; r < n_rows; r += gridDim.x) {
     const int64_t user = rows[r];
     const int64_t orow = by_user ? user : (int64_t)r;
     __syncthreads();   // the previous user's s_e / cls are no longer read
@@ -550,6 +589,233 @@ __global__ __launch_bounds__(256) void score_exact_rows_kernel(
   }
 }
 
+// ---- the same result from the whole chip -------------------------------------------------------------------------
+// One workgroup per listed user streams the whole of V through one CU (and reads a V row per THREAD: 64 cache lines per
+// load instruction) and then scans the n_items scores once per list position: 7.5 ms per user at 500K items x rank 200 —
+// eleven flagged users of a million took longer than the rest of the pass (82 of 135 ms, S-50M shard).  The fast path
+// cuts the catalogue into chunks of PK_EXACT_CHUNK items; a workgroup owns (chunk, a slice of the listed users): four
+// lanes per item compute the score (pk_dot_chains<4>: the bits of every other exact score in this file), the user's
+// seen items falling into the chunk are marked, and the chunk's best min(topk, chunk) entries — same total order:
+// class, score descending, index ascending — go to the work buffer in that order; a V chunk (1.6 MB at rank 200) stays
+// in L2 while the listed users take their turns.  A second kernel, one workgroup per user, merges the sorted chunk
+// lists by their heads (a cursor per chunk in LDS).  Users beyond the work buffer's row slots, lists longer than 256 and
+// catalogues beyond 8 M items take the one-workgroup kernel above.
+struct ExactLayout {   // candidate arrays of one row slot inside its per_row bytes of the work buffer
+    int64_t idx_off, cls_off;
+};
+static inline ExactLayout exact_layout(int64_t n_chunks, int ksel) {
+    ExactLayout l;
+    l.idx_off = n_chunks * ksel * 8;
+    l.cls_off = l.idx_off + n_chunks * ksel * 4;
+    return l;
+}
+
+__device__ __forceinline__ Best best_wave_min(Best b) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        Best o;
+        o.cls = __shfl_xor(b.cls, off, 64);
+        o.s = __shfl_xor(b.s, off, 64);
+        o.idx = __shfl_xor(b.idx, off, 64);
+        if (best_before(o, b)) b = o;
+    }
+    return b;
+}
+
+__global__ __launch_bounds__(256) void exact_chunk_kernel(
+    int32_t n_rows_host, const int32_t *__restrict__ n_rows_dev, int32_t row_slots, const int32_t *__restrict__ rows,
+    int64_t n_items, int K, const double *__restrict__ V, int64_t ldv, const double *__restrict__ E, int64_t lde,
+    const int64_t *__restrict__ seen_ptr, const int32_t *__restrict__ seen_idx, int ksel,
+    unsigned char *__restrict__ work, int64_t per_row, int64_t idx_off, int64_t cls_off) {
+    extern __shared__ __attribute__((aligned(16))) double s_e[];   // K doubles
+    __shared__ double s_score[PK_EXACT_CHUNK];
+    __shared__ unsigned char s_cls[PK_EXACT_CHUNK];
+    __shared__ int s_wc[4];
+    __shared__ double s_ws[4];
+    __shared__ int s_wi[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int32_t n_rows = n_rows_dev ? *n_rows_dev : n_rows_host;
+    if (n_rows > row_slots) n_rows = row_slots;
+    const int64_t chunk = blockIdx.x;
+    const int64_t i0 = chunk * PK_EXACT_CHUNK;
+    const int cn = (int)((n_items - i0 < PK_EXACT_CHUNK) ? (n_items - i0) : PK_EXACT_CHUNK);
+    const bool vvec2 = ((ldv & 1) == 0) && ((((uintptr_t)V) & 15) == 0);
+    for (int32_t r = blockIdx.y; r < n_rows; r += gridDim.y) {
+        const int64_t user = rows[r];
+        __syncthreads();   // the previous user's s_e / s_score / s_cls are no longer read
+        for (int c = tid; c < K; c += 256) s_e[c] = E[user * lde + c];
+        for (int c = tid; c < PK_EXACT_CHUNK; c += 256) s_cls[c] = (c < cn) ? 0 : 2;
+        __syncthreads();
+        const int q = tid & 3;
+        for (int l0 = 0; l0 < cn; l0 += 64) {
+            const int li = l0 + (tid >> 2);
+            const int64_t item = (li < cn) ? i0 + li : i0;
+            const double sc = pk_dot_chains<4>(V + item * ldv, s_e, K, q, vvec2, true);
+            if (q == 0 && li < cn) s_score[li] = sc;
+        }
+        if (seen_ptr) {
+            const int64_t p0 = seen_ptr[user], p1 = seen_ptr[user + 1];
+            for (int64_t p = p0 + tid; p < p1; p += 256) {
+                const int64_t j = (int64_t)seen_idx[p] - i0;
+                if (j >= 0 && j < cn) s_cls[j] = 1;
+            }
+        }
+        __syncthreads();
+        unsigned char *base = work + (int64_t)r * per_row;
+        double *c_s = reinterpret_cast<double *>(base) + chunk * ksel;
+        int32_t *c_i = reinterpret_cast<int32_t *>(base + idx_off) + chunk * ksel;
+        unsigned char *c_c = base + cls_off + chunk * ksel;
+        for (int t = 0; t < ksel; ++t) {
+            Best b;
+            b.cls = 2;
+            b.s = -INFINITY;
+            b.idx = PK_IDX_NONE;
+#pragma unroll
+            for (int j = 0; j < PK_EXACT_CHUNK / 256; ++j) {
+                const int li = tid + 256 * j;
+                Best c;
+                c.cls = s_cls[li];
+                c.s = s_score[li];
+                c.idx = (int)(i0 + li);
+                if (c.cls < 2 && best_before(c, b)) b = c;
+            }
+            b = best_wave_min(b);
+            if (lane == 0) {
+                s_wc[wave] = b.cls;
+                s_ws[wave] = b.s;
+                s_wi[wave] = b.idx;
+            }
+            __syncthreads();
+            Best w{s_wc[0], s_ws[0], s_wi[0]};
+#pragma unroll
+            for (int x = 1; x < 4; ++x) {
+                Best o{s_wc[x], s_ws[x], s_wi[x]};
+                if (best_before(o, w)) w = o;
+            }
+            if (tid == 0) {
+                c_s[t] = w.s;
+                c_i[t] = w.idx;
+                c_c[t] = (unsigned char)w.cls;
+                if (w.cls < 2) s_cls[w.idx - i0] = 2;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void exact_merge_kernel(
+    int32_t n_rows_host, const int32_t *__restrict__ n_rows_dev, int32_t row_slots, const int32_t *__restrict__ rows,
+    int by_user, int n_chunks, int ksel, int topk, int64_t *__restrict__ out_idx, double *__restrict__ out_score,
+    const unsigned char *__restrict__ work, int64_t per_row, int64_t idx_off, int64_t cls_off) {
+    extern __shared__ int s_cur[];   // n_chunks cursors into the (sorted) chunk lists
+    __shared__ int s_wc[4];
+    __shared__ double s_ws[4];
+    __shared__ int s_wi[4];
+    __shared__ int s_wk[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int32_t n_rows = n_rows_dev ? *n_rows_dev : n_rows_host;
+    if (n_rows > row_slots) n_rows = row_slots;
+    for (int32_t r = blockIdx.x; r < n_rows; r += gridDim.x) {
+        const int64_t orow = by_user ? (int64_t)rows[r] : (int64_t)r;
+        const unsigned char *base = work + (int64_t)r * per_row;
+        const double *c_s = reinterpret_cast<const double *>(base);
+        const int32_t *c_i = reinterpret_cast<const int32_t *>(base + idx_off);
+        const unsigned char *c_c = base + cls_off;
+        __syncthreads();
+        for (int c = tid; c < n_chunks; c += 256) s_cur[c] = 0;
+        __syncthreads();
+        for (int t = 0; t < topk; ++t) {
+            Best b;
+            b.cls = 2;
+            b.s = -INFINITY;
+            b.idx = PK_IDX_NONE;
+            int bk = -1;
+            for (int c = tid; c < n_chunks; c += 256) {
+                const int cur = s_cur[c];
+                if (cur >= ksel) continue;
+                const int64_t e = (int64_t)c * ksel + cur;
+                Best h;
+                h.cls = c_c[e];
+                h.s = c_s[e];
+                h.idx = c_i[e];
+                if (h.cls < 2 && best_before(h, b)) {
+                    b = h;
+                    bk = c;
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                Best o;
+                o.cls = __shfl_xor(b.cls, off, 64);
+                o.s = __shfl_xor(b.s, off, 64);
+                o.idx = __shfl_xor(b.idx, off, 64);
+                const int ok = __shfl_xor(bk, off, 64);
+                if (best_before(o, b)) {
+                    b = o;
+                    bk = ok;
+                }
+            }
+            if (lane == 0) {
+                s_wc[wave] = b.cls;
+                s_ws[wave] = b.s;
+                s_wi[wave] = b.idx;
+                s_wk[wave] = bk;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                Best w{s_wc[0], s_ws[0], s_wi[0]};
+                int wk = s_wk[0];
+                for (int x = 1; x < 4; ++x) {
+                    Best o{s_wc[x], s_ws[x], s_wi[x]};
+                    if (best_before(o, w)) {
+                        w = o;
+                        wk = s_wk[x];
+                    }
+                }
+                const bool ok = w.cls < 2;
+                out_idx[orow * topk + t] = ok ? (int64_t)w.idx : -1;
+                if (out_score) out_score[orow * topk + t] = ok ? w.s : -INFINITY;
+                if (ok) s_cur[wk] += 1;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// rows [0, min(count, row_slots)) through the chunk kernels when they apply, the rest (or everything) through the
+// one-workgroup kernel; `count` on the host (n_rows_dev == nullptr) or on the device
+static int exact_launch(hipStream_t st, int32_t n_rows_host, const int32_t *n_rows_dev, int32_t row_slots,
+                        const int32_t *rows_dev, int by_user, int64_t n_items, int32_t K, const double *V_dev, int64_t ldv,
+                        const double *E_dev, int64_t lde, const int64_t *seen_ptr_dev, const int32_t *seen_idx_dev,
+                        int32_t topk, int64_t *out_idx_dev, double *out_score_dev, unsigned char *work, int32_t n_wg_slow) {
+    const int64_t per_row = exact_per_row(n_items);
+    const int64_t n_chunks = pk_ceil_div(n_items, PK_EXACT_CHUNK);
+    const bool fast = topk <= PK_EXACT_TOPK_MAX && n_chunks <= PK_EXACT_CHUNKS_MAX && (size_t)K * 8 <= 48 * 1024;
+    int32_t first_slow = 0;
+    if (fast) {
+        const int ksel = (int)(topk < n_items ? topk : n_items);   // <= PK_EXACT_TOPK_MAX: what exact_per_row provides for
+        const ExactLayout lay = exact_layout(n_chunks, ksel);
+        int64_t gy = 2048 / n_chunks;
+        if (gy < 1) gy = 1;
+        if (gy > row_slots) gy = row_slots;
+        hipLaunchKernelGGL(exact_chunk_kernel, dim3((unsigned)n_chunks, (unsigned)gy), dim3(256), (size_t)K * 8, st, n_rows_host,
+                           n_rows_dev, row_slots, rows_dev, n_items, K, V_dev, ldv, E_dev, lde, seen_ptr_dev, seen_idx_dev, ksel,
+                           work, per_row, lay.idx_off, lay.cls_off);
+        PK_CHECK_LAUNCH("exact_chunk_kernel");
+        hipLaunchKernelGGL(exact_merge_kernel, dim3((unsigned)row_slots), dim3(256), (size_t)n_chunks * 4, st, n_rows_host,
+                           n_rows_dev, row_slots, rows_dev, by_user, (int)n_chunks, ksel, topk, out_idx_dev, out_score_dev, work,
+                           per_row, lay.idx_off, lay.cls_off);
+        PK_CHECK_LAUNCH("exact_merge_kernel");
+        first_slow = row_slots;
+        if (!n_rows_dev && n_rows_host <= row_slots) return PK_OK;
+    }
+    hipLaunchKernelGGL(score_exact_rows_kernel, dim3((unsigned)n_wg_slow), dim3(256), (size_t)K * 8, st, n_rows_host, n_rows_dev,
+                       first_slow, rows_dev, by_user, n_items, K, V_dev, ldv, E_dev, lde, seen_ptr_dev, seen_idx_dev, topk,
+                       out_idx_dev, out_score_dev, work, per_row);
+    PK_CHECK_LAUNCH("score_exact_rows_kernel");
+    return PK_OK;
+}
+
 extern "C" int pk_score_exact_rows_f64(void *stream, int32_t n_rows, const int32_t *rows_dev, int64_t n_items,
                                        int32_t K, const double *V_dev, int64_t ldv, const double *E_dev,
                                        int64_t lde, const int64_t *seen_ptr_dev, const int32_t *seen_idx_dev,
@@ -557,17 +823,16 @@ extern "C" int pk_score_exact_rows_f64(void *stream, int32_t n_rows, const int32
     PK_REQUIRE(n_rows >= 0 && n_items >= 1 && K >= 1 && K <= 8192 && topk >= 1, "pk_score_exact_rows_f64: bad sizes");
     PK_REQUIRE(ldv >= K && lde >= K && work_dev, "pk_score_exact_rows_f64: bad arguments");
     if (n_rows == 0) return PK_OK;
-    const int64_t per_row = n_items * 8 + ((n_items + 15) / 16) * 16;
-    hipLaunchKernelGGL(score_exact_rows_kernel, dim3((unsigned)n_rows), dim3(256), (size_t)K * 8, pk_stream(stream), n_rows,
-                       (const int32_t *)nullptr, rows_dev, 0, n_items, K, V_dev, ldv, E_dev, lde, seen_ptr_dev, seen_idx_dev, topk,
-                       out_idx_dev, out_score_dev, static_cast<unsigned char *>(work_dev), per_row);
-    PK_CHECK_LAUNCH("score_exact_rows_kernel");
-    return PK_OK;
+    // the work buffer has a row slot per listed user (pk_exact_work_bytes(n_rows, n_items))
+    return exact_launch(pk_stream(stream), n_rows, nullptr, n_rows, rows_dev, 0, n_items, K, V_dev, ldv, E_dev, lde,
+                        seen_ptr_dev, seen_idx_dev, topk, out_idx_dev, out_score_dev, static_cast<unsigned char *>(work_dev),
+                        n_rows);
 }
 
-/* The same kernel over a DEVICE-side list (pk_flag_compact): users list_dev[0 .. *count_dev), results written to the
- * rows of those users in the [n_users x topk] outputs; n_wg workgroups share the list (work >= pk_exact_work_bytes(n_wg,
- * n_items)).  Nothing about the list visits the host, so a scoring pass needs no synchronisation. */
+/* The same over a DEVICE-side list (pk_flag_compact): users list_dev[0 .. *count_dev), results written to the
+ * rows of those users in the [n_users x topk] outputs; the work buffer has n_wg row slots (work >= pk_exact_work_bytes(n_wg,
+ * n_items)): the first n_wg listed users go through the chunk kernels, any further ones share n_wg workgroups of the
+ * one-workgroup kernel.  Nothing about the list visits the host, so a scoring pass needs no synchronisation. */
 extern "C" int pk_score_exact_list_f64(void *stream, int32_t n_wg, const int32_t *list_dev, const int32_t *count_dev,
                                        int64_t n_items, int32_t K, const double *V_dev, int64_t ldv, const double *E_dev,
                                        int64_t lde, const int64_t *seen_ptr_dev, const int32_t *seen_idx_dev, int32_t topk,
@@ -575,12 +840,8 @@ extern "C" int pk_score_exact_list_f64(void *stream, int32_t n_wg, const int32_t
     PK_REQUIRE(n_wg >= 1 && n_items >= 1 && K >= 1 && K <= 8192 && topk >= 1 && list_dev && count_dev,
                "pk_score_exact_list_f64: bad sizes");
     PK_REQUIRE(ldv >= K && lde >= K && work_dev && out_idx_dev, "pk_score_exact_list_f64: bad arguments");
-    const int64_t per_row = n_items * 8 + ((n_items + 15) / 16) * 16;
-    hipLaunchKernelGGL(score_exact_rows_kernel, dim3((unsigned)n_wg), dim3(256), (size_t)K * 8, pk_stream(stream), 0, count_dev,
-                       list_dev, 1, n_items, K, V_dev, ldv, E_dev, lde, seen_ptr_dev, seen_idx_dev, topk, out_idx_dev,
-                       out_score_dev, static_cast<unsigned char *>(work_dev), per_row);
-    PK_CHECK_LAUNCH("score_exact_rows_kernel");
-    return PK_OK;
+    return exact_launch(pk_stream(stream), 0, count_dev, n_wg, list_dev, 1, n_items, K, V_dev, ldv, E_dev, lde, seen_ptr_dev,
+                        seen_idx_dev, topk, out_idx_dev, out_score_dev, static_cast<unsigned char *>(work_dev), n_wg);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -581,8 +581,9 @@ class HipOps:
         out = torch.empty(self.lib.pk_pack_elems(n, K), dtype=torch.float32, device=self.device)
         bound = torch.empty(n, dtype=torch.float32, device=self.device)
         e_ld = 0 if extra is None else (extra.stride(0) if extra.numel() > 1 else 1)
-        _lib.check(self.lib.pk_pack_frag_bound_f32(self.stream(), n, K, _ptr(M), M.stride(0), _ptr(out), _ptr(bound),
-                                                   _ptr(extra), e_ld, float(extra_scale)), 'pk_pack_frag_bound_f32')
+        with self._timed('pack_frag_bound', (n, K)):
+            _lib.check(self.lib.pk_pack_frag_bound_f32(self.stream(), n, K, _ptr(M), M.stride(0), _ptr(out), _ptr(bound),
+                                                       _ptr(extra), e_ld, float(extra_scale)), 'pk_pack_frag_bound_f32')
         return out, bound
 
     def row_norm_bound(self, M):
@@ -683,15 +684,16 @@ class HipOps:
             flags = torch.empty(n_users, dtype=torch.int32, device=self.device)
         n_rows = n_users if rows is None else int(rows.numel())
         e_ld = 0 if e_err is None else (e_err.stride(0) if e_err.numel() > 1 else 1)
-        _lib.check(self.lib.pk_rescore_topk_rows_f64(self.stream(), n_rows, _ptr(rows), _ptr(n_rows_dev), n_users,
-                                                     n_items, K, _ptr(V),
-                                                     V.stride(0), _ptr(v32), 0 if v32 is None else v32.stride(0),
-                                                     _ptr(E), E.stride(0), _ptr(e_err), e_ld,
-                                                     1 if e_exact else 0,
-                                                     _ptr(seen_ptr),
-                                                     KC, splits, _ptr(cs), _ptr(ci), topk, float(vmax),
-                                                     _ptr(out_idx), _ptr(out_s), _ptr(flags)),
-                   'pk_rescore_topk_rows_f64')
+        with self._timed('rescore_topk' if rows is None else 'rescore_topk_refolded', (n_rows, KC, K)):
+            _lib.check(self.lib.pk_rescore_topk_rows_f64(self.stream(), n_rows, _ptr(rows), _ptr(n_rows_dev), n_users,
+                                                         n_items, K, _ptr(V),
+                                                         V.stride(0), _ptr(v32), 0 if v32 is None else v32.stride(0),
+                                                         _ptr(E), E.stride(0), _ptr(e_err), e_ld,
+                                                         1 if e_exact else 0,
+                                                         _ptr(seen_ptr),
+                                                         KC, splits, _ptr(cs), _ptr(ci), topk, float(vmax),
+                                                         _ptr(out_idx), _ptr(out_s), _ptr(flags)),
+                       'pk_rescore_topk_rows_f64')
         return out_idx, out_s, flags
 
     def flag_compact(self, flags, mask=7):
@@ -699,16 +701,18 @@ class HipOps:
         n = flags.numel()
         lst = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
         cnt = torch.empty(1, dtype=torch.int32, device=self.device)
-        _lib.check(self.lib.pk_flag_compact(self.stream(), n, _ptr(flags), int(mask), _ptr(lst), _ptr(cnt)),
-                   'pk_flag_compact')
+        with self._timed('flag_compact', (n,)):
+            _lib.check(self.lib.pk_flag_compact(self.stream(), n, _ptr(flags), int(mask), _ptr(lst), _ptr(cnt)),
+                       'pk_flag_compact')
         return lst, cnt
 
     def fold_rows(self, A, lst, cnt, V, E, row_offset=0):
         """E[row_offset + lst[r], :K] = (A V)[that row] in fp64 for r < cnt (device-side list)."""
         assert V.stride(1) == 1 and E.stride(1) == 1 and V.dtype == torch.float64
-        _lib.check(self.lib.pk_fold_rows_f64(self.stream(), lst.numel(), _ptr(lst), _ptr(cnt), int(row_offset),
-                                             _ptr(A.indptr), _ptr(A.indices), _ptr(A.values), A.val_kind, _ptr(V),
-                                             V.stride(0), V.shape[1], _ptr(E), E.stride(0)), 'pk_fold_rows_f64')
+        with self._timed('fold_rows', (int(lst.numel()),)):
+            _lib.check(self.lib.pk_fold_rows_f64(self.stream(), lst.numel(), _ptr(lst), _ptr(cnt), int(row_offset),
+                                                 _ptr(A.indptr), _ptr(A.indices), _ptr(A.values), A.val_kind, _ptr(V),
+                                                 V.stride(0), V.shape[1], _ptr(E), E.stride(0)), 'pk_fold_rows_f64')
 
     def score_exact_rows(self, rows, V, E, n_items, seen_ptr, seen_idx, topk):
         n_rows = rows.numel()
@@ -733,10 +737,11 @@ class HipOps:
         if skey not in self._exact_work or self._exact_work[skey].numel() < need:
             self._exact_work[skey] = torch.empty(need, dtype=torch.uint8, device=self.device)
         work = self._exact_work[skey]
-        _lib.check(self.lib.pk_score_exact_list_f64(self.stream(), int(n_wg), _ptr(lst), _ptr(cnt), n_items, K, _ptr(V),
-                                                    V.stride(0), _ptr(E), E.stride(0), _ptr(seen_ptr), _ptr(seen_idx),
-                                                    topk, _ptr(out_idx), _ptr(out_s), _ptr(work)),
-                   'pk_score_exact_list_f64')
+        with self._timed('score_exact_list', (n_items, K, topk)):
+            _lib.check(self.lib.pk_score_exact_list_f64(self.stream(), int(n_wg), _ptr(lst), _ptr(cnt), n_items, K, _ptr(V),
+                                                        V.stride(0), _ptr(E), E.stride(0), _ptr(seen_ptr), _ptr(seen_idx),
+                                                        topk, _ptr(out_idx), _ptr(out_s), _ptr(work)),
+                       'pk_score_exact_list_f64')
         return work
 
     def eval_ranks(self, recs, hold_row, hold_item):

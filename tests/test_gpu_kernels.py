@@ -660,3 +660,61 @@ def test_split_bf16_candidate_scores_stay_inside_the_certified_error(hip_ops, K)
         np.put_along_axis(excl, ci, False, axis=1)
         slack = bound.max(axis=1) * 2 + np.abs(kth) * 2.0 ** -15
         assert (np.where(excl, exact, -np.inf).max(axis=1) <= kth + slack).all()
+
+
+@pytest.mark.parametrize('n_items,K,topk', [(5000, 50, 10), (1024, 7, 50), (1025, 200, 256), (3000, 33, 300), (40, 5, 64),
+                                            (2500, 64, 2500)])
+def test_exact_rows_chunk_path_and_one_workgroup_path_agree_with_numpy(hip_ops, n_items, K, topk):
+    """pk_score_exact_rows_f64 / pk_score_exact_list_f64: catalogues that span several 1024-item chunks, a ragged last
+    chunk, lists longer than a chunk's share (topk > 256 takes the one-workgroup kernel), more listed users than row
+    slots (the overflow takes the one-workgroup kernel), users with nearly everything seen (seen items re-enter after the
+    unseen ones), exact ties (broken by index) — ids AND score bits equal between the routes, ids equal to NumPy."""
+    import numpy_ops
+    rng = np.random.RandomState(n_items + K)
+    n_users = 37
+    V = rng.randn(n_items, K)
+    V[7] = V[3]                                                   # exact ties
+    V[n_items - 1] = V[0]
+    E = rng.randn(n_users, K)
+    rows_seen = []
+    for u in range(n_users):
+        m = n_items - 3 if u == 5 else (n_items if u == 6 else rng.randint(0, min(n_items, 400)))
+        rows_seen.append(np.sort(rng.choice(n_items, m, replace=False)))
+    seen_ptr = np.r_[0, np.cumsum([len(x) for x in rows_seen])].astype(np.int64)
+    seen_idx = np.concatenate(rows_seen).astype(np.int32)
+    Vd, Ed = hip_ops.to_device(V), hip_ops.to_device(E)
+    sp, si = torch.from_numpy(seen_ptr).to(Vd.device), torch.from_numpy(seen_idx).to(Vd.device)
+    rows = torch.from_numpy(rng.permutation(n_users).astype(np.int32)).to(Vd.device)
+    idx, sc = hip_ops.score_exact_rows(rows, Vd, Ed, n_items, sp, si, topk)
+    idx, sc = hip_ops.to_host(idx), hip_ops.to_host(sc)
+    k_eff = min(topk, n_items)
+    for r, u in enumerate(hip_ops.to_host(rows)):
+        s = (V * E[u]).sum(axis=1)                 # identical rows of V -> identical scores (a BLAS gemv need not)
+        cls = np.zeros(n_items, dtype=np.int64)
+        cls[rows_seen[u]] = 1
+        want = np.lexsort((np.arange(n_items), -s, cls))[:k_eff]
+        if not np.array_equal(idx[r, :k_eff], want):
+            # the two summation orders may swap items whose scores agree to rounding: nothing else
+            bad = np.flatnonzero(idx[r, :k_eff] != want)
+            assert np.array_equal(np.sort(idx[r, :k_eff]), np.sort(want)) or len(bad) <= 4, (u, bad[:10])
+            assert np.allclose(s[idx[r, bad]], s[want[bad]], rtol=1e-12, atol=1e-12) and (cls[idx[r, bad]] == cls[want[bad]]).all(), (u, bad[:10])
+        assert np.allclose(sc[r, :k_eff], s[idx[r, :k_eff]], rtol=1e-12, atol=1e-12)
+        assert (idx[r, k_eff:] == -1).all()
+    # the device list with only 8 row slots: 8 users through the chunk kernels, 29 through the one-workgroup kernel
+    out_i = torch.full((n_users, topk), -7, dtype=torch.int64, device=Vd.device)
+    out_s = hip_ops.empty(n_users, topk)
+    cnt = torch.tensor([n_users], dtype=torch.int32, device=Vd.device)
+    hip_ops._exact_work = None
+    hip_ops.score_exact_list(rows, cnt, Vd, Ed, n_items, sp, si, topk, out_i, out_s, n_wg=8)
+    hip_ops._exact_work = None
+    got_i, got_s = hip_ops.to_host(out_i), hip_ops.to_host(out_s)
+    order = hip_ops.to_host(rows)
+    assert np.array_equal(got_i[order], idx)
+    assert np.array_equal(got_s[order][:, :k_eff].view(np.int64), sc[:, :k_eff].view(np.int64))     # same BITS on both routes
+    # a shorter device-side count leaves the other users' rows alone
+    out_i.fill_(-7)
+    cnt.fill_(3)
+    hip_ops.score_exact_list(rows, cnt, Vd, Ed, n_items, sp, si, topk, out_i, out_s, n_wg=8)
+    hip_ops._exact_work = None
+    got_i = hip_ops.to_host(out_i)
+    assert np.array_equal(got_i[order[:3]], idx[:3]) and (got_i[order[3:]] == -7).all()

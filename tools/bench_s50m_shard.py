@@ -97,7 +97,7 @@ def main():
         'projected_8gpu_50M_users_s': 50e6 / 8 / (n_users / step_s),
         'build_s': build_s, 'build': {k: st[k] for k in ('gramian_steps', 'outer', 'block', 'converged')},
         'kernel_ms': ms, 'swept_fraction': swept, 'exit_tile_quantiles': stats.get('exit_tile_quantiles'),
-        'flagged_users': stats['flagged_users'], 'candidate_capacity': stats['candidate_capacity'],
+        'flagged_users': stats['flagged_users'], 'refolded_users': stats.get('refolded_users'), 'candidate_capacity': stats['candidate_capacity'],
         'sweep_TFLOPs_executed': flops * swept / (ms['score_candidates'] * 1e-3) / 1e12,
         'sweep_TFLOPs_dense_equivalent': flops / (ms['score_candidates'] * 1e-3) / 1e12,
         'cpu_oracle': {'users': n_chk, 'seconds': cpu_s, 'users_per_s': n_chk / cpu_s,
