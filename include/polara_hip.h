@@ -303,6 +303,12 @@ int pk_flag_compact(void *stream, int64_t n, const int32_t *flags_dev, int32_t m
 int pk_fold_rows_f64(void *stream, int64_t cap, const int32_t *list_dev, const int32_t *count_dev, int64_t row_offset,
                      const int64_t *indptr_dev, const int32_t *indices_dev, const void *vals_dev, int val_kind,
                      const double *V_dev, int64_t ldv, int32_t K, double *E_dev, int64_t lde);
+/* dst[perm_dev[r], :] = src_dev[r, :] for rows of `width` int64 (perm_dev == NULL: a plain copy): the lists of a pass whose
+ * users were grouped by activity go back to the caller's user order.  `dst` is device memory or MAPPED PINNED HOST memory:
+ * the host-side [n_users x topk] int64 array of get_recommendations (models.py:400-405) can be written by the kernel
+ * itself, without a copy-engine transfer behind the pass. */
+int pk_scatter_rows_i64(void *stream, int64_t n_rows, int32_t width, const int64_t *src_dev, const int64_t *perm_dev,
+                        int64_t *dst);
 /* Brute-force exact path for a list of users: all n_items fp64 scores, two-class key
  * (unseen above seen, then score; the reference's downvote semantics, models.py:510-519), top-k.
  * Outputs are compact [n_rows x topk] (row r belongs to user rows_dev[r]).

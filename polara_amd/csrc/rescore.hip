@@ -845,6 +845,32 @@ extern "C" int pk_score_exact_list_f64(void *stream, int32_t n_wg, const int32_t
 }
 
 // ------------------------------------------------------------------------------------------
+// rows of a result back in the caller's order: dst[perm[r], :] = src[r, :] (perm == NULL: a plain copy).  The scoring
+// pass groups its users by activity and scatters the lists back at the end (scoring.recommend); `dst` may be device
+// memory or MAPPED PINNED HOST memory — the [n_users x topk] array the reference returns on the host
+// (models.py:400-405) is then written by this kernel over PCIe and no copy-engine transfer follows the pass.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void scatter_rows_i64_kernel(int64_t n_rows, int width, const int64_t *__restrict__ src,
+                                                               const int64_t *__restrict__ perm, int64_t *__restrict__ dst) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_rows * width) return;
+    const int64_t r = e / width;
+    const int c = (int)(e - r * width);
+    const int64_t to = perm ? perm[r] : r;
+    dst[to * width + c] = src[e];
+}
+
+extern "C" int pk_scatter_rows_i64(void *stream, int64_t n_rows, int32_t width, const int64_t *src_dev, const int64_t *perm_dev,
+                                   int64_t *dst) {
+    PK_REQUIRE(n_rows >= 0 && width >= 1 && src_dev && dst, "pk_scatter_rows_i64: bad arguments");
+    if (n_rows == 0) return PK_OK;
+    hipLaunchKernelGGL(scatter_rows_i64_kernel, dim3((unsigned)pk_ceil_div(n_rows * width, 256)), dim3(256), 0, pk_stream(stream),
+                       n_rows, width, src_dev, perm_dev, dst);
+    PK_CHECK_LAUNCH("scatter_rows_i64_kernel");
+    return PK_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // dense fp64 score rows (slice_recommendations / _user_scores support, models.py:277-291, 857-861)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dense_scores_kernel(int n_rows, int64_t n_items, int K,

@@ -744,6 +744,19 @@ class HipOps:
                        'pk_score_exact_list_f64')
         return work
 
+    def scatter_rows(self, src, perm, out=None):
+        """out[perm[r], :] = src[r, :] for an int64 [n x width] result (perm None: a copy).  `out`: a device tensor, or a
+        PINNED HOST tensor — mapped into the device's address space, the kernel then writes the host-side array of
+        get_recommendations itself (no copy-engine transfer behind the pass)."""
+        assert src.dtype == torch.int64 and src.is_contiguous() and (perm is None or perm.dtype == torch.int64)
+        if out is None:
+            out = torch.empty_like(src)
+        assert out.dtype == torch.int64 and out.is_contiguous() and out.shape == src.shape
+        assert out.is_cuda or out.is_pinned(), 'scatter_rows: a host destination must be pinned (mapped) memory'
+        _lib.check(self.lib.pk_scatter_rows_i64(self.stream(), src.shape[0], src.shape[1], _ptr(src), _ptr(perm), _ptr(out)),
+                   'pk_scatter_rows_i64')
+        return out
+
     def eval_ranks(self, recs, hold_row, hold_item):
         """int32 [n_holdout]: 1-based rank of every holdout item in its user's row of the device-resident
         recommendation array (0 = not recommended)."""

@@ -95,9 +95,7 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
             out_idx[perm] = idx_p
             out_s[perm] = sc_p
             return out_idx, out_s
-        out_idx = torch.empty_like(res)
-        out_idx[perm] = res
-        return out_idx
+        return ops.scatter_rows(res, perm) if hasattr(ops, 'scatter_rows') else torch.empty_like(res).index_copy_(0, perm, res)
     KC = ops.candidate_capacity(topk) if factors.fused else 0
     K = factors.K
     if KC == 0:

@@ -718,3 +718,22 @@ def test_exact_rows_chunk_path_and_one_workgroup_path_agree_with_numpy(hip_ops, 
     hip_ops._exact_work = None
     got_i = hip_ops.to_host(out_i)
     assert np.array_equal(got_i[order[:3]], idx[:3]) and (got_i[order[3:]] == -7).all()
+
+
+def test_scatter_rows_to_device_and_to_pinned_host_memory(hip_ops):
+    """pk_scatter_rows_i64: the lists of a pass back in the caller's user order; the destination may be the pinned host
+    array itself (written by the kernel over PCIe)."""
+    rng = np.random.RandomState(3)
+    n, w = 1234, 7
+    src = torch.from_numpy(rng.randint(-5, 10**12, (n, w))).cuda()
+    perm = torch.from_numpy(rng.permutation(n)).cuda()
+    want = np.empty((n, w), dtype=np.int64)
+    want[perm.cpu().numpy()] = src.cpu().numpy()
+    assert np.array_equal(hip_ops.to_host(hip_ops.scatter_rows(src, perm)), want)
+    host = torch.zeros((n, w), dtype=torch.int64).pin_memory()
+    hip_ops.scatter_rows(src, perm, out=host)
+    torch.cuda.synchronize()
+    assert np.array_equal(host.numpy(), want)
+    assert np.array_equal(hip_ops.to_host(hip_ops.scatter_rows(src, None)), src.cpu().numpy())
+    with pytest.raises(AssertionError):
+        hip_ops.scatter_rows(src, perm, out=torch.zeros((n, w), dtype=torch.int64))     # pageable host memory
