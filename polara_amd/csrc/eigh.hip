@@ -162,7 +162,8 @@ template <bool IN_LDS, int NC>
 __global__ __launch_bounds__(EIGH_THREADS) void eigh_psd_kernel(int n, double *__restrict__ Wg, int64_t ldwg,
                                                                 double *__restrict__ Rg, int64_t ldrg,
                                                                 double *__restrict__ evals, int max_sweeps,
-                                                                double tol, int *__restrict__ info) {
+                                                                double tol, int *__restrict__ info, int precondition,
+                                                                const int *__restrict__ chol_flag) {
     extern __shared__ __attribute__((aligned(16))) double eigh_smem[];
     constexpr int NMAX = IN_LDS ? EIGH_LDS_MAX : 1024;
     __shared__ int s_rot;
@@ -179,6 +180,48 @@ __global__ __launch_bounds__(EIGH_THREADS) void eigh_psd_kernel(int n, double *_
         for (int e = tid; e < n * n; e += EIGH_THREADS) W[e] = Wg[(int64_t)(e / n) * ldwg + (e % n)];
     }
     __syncthreads();
+    // Cholesky preconditioning (Veselic-Hari): S = R^T R, then the Jacobi sweeps run on the rows of R instead of the
+    // rows of S.  The rows of the converged W are then sigma_i u_i^T with sigma_i^2 = lambda_i — the same eigenvectors —
+    // but R has the square root of the condition number of S, and the matrices that arrive here are graded (Ritz values
+    // over two to four orders of magnitude, HOOI Gram matrices over more): 23 sweeps become 10 on a 120 x 120 matrix
+    // with eigenvalues e^(-j/8) (CPU study with this tournament order), 11 become 5 on a graded Gram matrix; a flat
+    // spectrum gains nothing.  One barrier per column like chol_rinv_kernel (dense.hip).  A pivot that is not positive
+    // — S singular to rounding — restores S and the sweeps run on it as before (rows that vanish are rebuilt below).
+    // (n > EIGH_LDS_MAX: eigh_chol_global_kernel did this before the block rounds and left its verdict in chol_flag)
+    bool chol_ok = (!IN_LDS && chol_flag) ? (*chol_flag != 0) : false;
+    if (IN_LDS && n >= 4 && max_sweeps > 0 && precondition) {
+        int tx_log2 = 4;
+        while ((1 << tx_log2) < n) ++tx_log2;
+        const int TX = 1 << tx_log2, TY = EIGH_THREADS >> tx_log2;
+        const int tx = tid & (TX - 1), ty = tid >> tx_log2;
+        int fail = 0;
+        for (int j = 0; j < n; ++j) {
+            __syncthreads();
+            const double d = W[j * n + j];
+            if (!(d > 0.0)) {
+                fail = 1;
+                break;                               // uniform: every thread read the same d
+            }
+            const double invd = 1.0 / d;
+            for (int c = j + 1 + tx; c < n; c += TX) {
+                const double pj = W[j * n + c];
+                for (int i = j + 1 + ty; i <= c; i += TY) W[i * n + c] = fma(-W[j * n + i] * invd, pj, W[i * n + c]);
+            }
+        }
+        __syncthreads();
+        if (!fail) {
+            for (int i = tid; i < n; i += EIGH_THREADS) s_lam[i] = 1.0 / sqrt(W[i * n + i]);
+            __syncthreads();
+            for (int e = tid; e < n * n; e += EIGH_THREADS) {
+                const int i = e / n, c = e - i * n;
+                W[e] = (c >= i) ? W[e] * s_lam[i] : 0.0;
+            }
+            chol_ok = true;
+        } else {
+            for (int e = tid; e < n * n; e += EIGH_THREADS) W[e] = Wg[(int64_t)(e / n) * ldwg + (e % n)];
+        }
+        __syncthreads();
+    }
 
     const int m = (n + 1) & ~1;  // even number of players; index n (if any) is a bye
     const double tol2 = tol * tol;
@@ -209,7 +252,7 @@ __global__ __launch_bounds__(EIGH_THREADS) void eigh_psd_kernel(int n, double *_
         __syncthreads();
     }
 
-    // eigenvalues = row norms of W.  The rotation test gamma^2 > tol^2 alpha beta enforces mutual
+    // eigenvalues = row norms of W (squared when the sweeps ran on the Cholesky factor).  The rotation test gamma^2 > tol^2 alpha beta enforces mutual
     // orthogonality to RELATIVE accuracy for every pair of rows whose squared norms do not underflow
     // in that product; rows below 1e-100 * max (exactly singular S) escaped it, are not orthogonal
     // and are rebuilt below.  Everything above that — including rows at 1e-15 * max, which still carry
@@ -239,6 +282,10 @@ __global__ __launch_bounds__(EIGH_THREADS) void eigh_psd_kernel(int n, double *_
         if (lane == 0) s_rank[i] = ok ? 1 : 0;   // s_rank doubles as the "row is valid" flag here
     }
     __syncthreads();
+    if (chol_ok) {                               // the rows were those of R: lambda = sigma^2
+        for (int i = tid; i < n; i += EIGH_THREADS) s_lam[i] *= s_lam[i];
+        __syncthreads();
+    }
     // rebuild the invalid rows: Gram-Schmidt of unit vectors against all valid rows
     for (int i = 0; i < n; ++i) {
         if (s_rank[i]) continue;                       // uniform: shared memory
@@ -381,6 +428,49 @@ __global__ void eigh_counters_init_kernel(int *counters, int n) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) counters[i] = 0;
 }
 
+// Cholesky preconditioning of the block path (see eigh_psd_kernel): W := R with S = R^T R, in place in global memory,
+// one workgroup, one barrier per column; S is kept in `backup` (the eigenvector output buffer, free until the last
+// kernel) and restored if a pivot is not positive.  flag[0] = 1: the rounds run on R and the eigenvalues are the
+// squared row norms.
+__global__ __launch_bounds__(EIGH_THREADS) void eigh_chol_global_kernel(int n, double *__restrict__ W, int64_t ldw,
+                                                                        double *__restrict__ backup, int64_t ldb,
+                                                                        int *__restrict__ flag) {
+    __shared__ double s_inv[1024];
+    const int tid = threadIdx.x;
+    int tx_log2 = 4;
+    while ((1 << tx_log2) < n && tx_log2 < 8) ++tx_log2;
+    const int TX = 1 << tx_log2, TY = EIGH_THREADS >> tx_log2;
+    const int tx = tid & (TX - 1), ty = tid >> tx_log2;
+    for (int i = ty; i < n; i += TY)
+        for (int c = tx; c < n; c += TX) backup[(int64_t)i * ldb + c] = W[(int64_t)i * ldw + c];
+    int fail = 0;
+    for (int j = 0; j < n; ++j) {
+        __syncthreads();
+        const double d = W[(int64_t)j * ldw + j];
+        if (!(d > 0.0)) {
+            fail = 1;
+            break;
+        }
+        const double invd = 1.0 / d;
+        for (int c = j + 1 + tx; c < n; c += TX) {
+            const double pj = W[(int64_t)j * ldw + c];
+            for (int i = j + 1 + ty; i <= c; i += TY)
+                W[(int64_t)i * ldw + c] = fma(-W[(int64_t)j * ldw + i] * invd, pj, W[(int64_t)i * ldw + c]);
+        }
+    }
+    __syncthreads();
+    if (!fail) {
+        for (int i = tid; i < n; i += EIGH_THREADS) s_inv[i] = 1.0 / sqrt(W[(int64_t)i * ldw + i]);
+        __syncthreads();
+        for (int i = ty; i < n; i += TY)
+            for (int c = tx; c < n; c += TX) W[(int64_t)i * ldw + c] = (c >= i) ? W[(int64_t)i * ldw + c] * s_inv[i] : 0.0;
+    } else {
+        for (int i = ty; i < n; i += TY)
+            for (int c = tx; c < n; c += TX) W[(int64_t)i * ldw + c] = backup[(int64_t)i * ldb + c];
+    }
+    if (tid == 0) flag[0] = fail ? 0 : 1;
+}
+
 // info[0] = outer sweeps that rotated something (+ the clean one that certified convergence), info[1] = converged
 __global__ void eigh_block_info_kernel(const int *counters, int max_sweeps, int *info) {
     int s = 0;
@@ -397,10 +487,12 @@ extern "C" int pk_eigh_psd_f64(void *stream, int32_t n, double *S_dev, int64_t l
     PK_REQUIRE(S_dev && evecs_dev && evals_dev && S_dev != evecs_dev, "pk_eigh_psd_f64: bad pointers");
     if (max_sweeps <= 0) max_sweeps = 40;
     if (tol <= 0.0) tol = 2.0 * 2.220446049250313e-16 * sqrt((double)n);  // ~ LAPACK dgesvj's sqrt(m)*eps
+    const char *pc_env = getenv("PK_EIGH_CHOL");         // kernel-tuning knob: 0 = sweeps on S itself (round-1 behaviour)
+    const int precondition = pc_env ? atoi(pc_env) != 0 : 1;
     hipStream_t st = pk_stream(stream);
     if (n <= EIGH_LDS_MAX) {
         // instances by columns per lane of a 16-lane row (rows held in registers across a rotation)
-        using kern_t = void (*)(int, double *, int64_t, double *, int64_t, double *, int, double, int *);
+        using kern_t = void (*)(int, double *, int64_t, double *, int64_t, double *, int, double, int *, int, const int *);
         kern_t kern = n <= 32 ? eigh_psd_kernel<true, 2> : n <= 64 ? eigh_psd_kernel<true, 4>
                     : n <= 96 ? eigh_psd_kernel<true, 6> : n <= 128 ? eigh_psd_kernel<true, 8> : eigh_psd_kernel<true, 9>;
         const int slot = n <= 32 ? 0 : n <= 64 ? 1 : n <= 96 ? 2 : n <= 128 ? 3 : 4;
@@ -416,7 +508,8 @@ extern "C" int pk_eigh_psd_f64(void *stream, int32_t n, double *S_dev, int64_t l
             attr_set[slot] = true;
         }
         hipLaunchKernelGGL(kern, dim3(1), dim3(EIGH_THREADS), (size_t)n * n * sizeof(double),
-                           st, n, S_dev, lds_, evecs_dev, ldv, evals_dev, max_sweeps, tol, info_dev);
+                           st, n, S_dev, lds_, evecs_dev, ldv, evals_dev, max_sweeps, tol, info_dev, precondition,
+                           (const int *)nullptr);
         PK_CHECK_LAUNCH("eigh_psd_kernel");
         return PK_OK;
     }
@@ -442,7 +535,10 @@ extern "C" int pk_eigh_psd_f64(void *stream, int32_t n, double *S_dev, int64_t l
     // the rotation counters of the outer sweeps live in evals_dev until the final pass writes the eigenvalues there
     // (n > 136 doubles: room for every counter)
     int *counters = reinterpret_cast<int *>(evals_dev);
-    hipLaunchKernelGGL(eigh_counters_init_kernel, dim3(1), dim3(64), 0, st, counters, max_sweeps + 1);
+    hipLaunchKernelGGL(eigh_counters_init_kernel, dim3(1), dim3(64), 0, st, counters, max_sweeps + 2);
+    int *chol_flag = counters + max_sweeps + 1;          // zeroed above: "sweeps ran on S"
+    if (precondition)
+        hipLaunchKernelGGL(eigh_chol_global_kernel, dim3(1), dim3(EIGH_THREADS), 0, st, n, S_dev, lds_, evecs_dev, ldv, chol_flag);
     for (int sweep = 0; sweep < max_sweeps; ++sweep)
         for (int round = 0; round < nb - 1; ++round)
             hipLaunchKernelGGL(round_kern, dim3(nb / 2), dim3(EIGH_THREADS), lds_bytes, st, n, S_dev, lds_, w, nb,
@@ -450,7 +546,7 @@ extern "C" int pk_eigh_psd_f64(void *stream, int32_t n, double *S_dev, int64_t l
     if (info_dev) hipLaunchKernelGGL(eigh_block_info_kernel, dim3(1), dim3(1), 0, st, counters, max_sweeps, info_dev);
     // norms, ordering, signs: the tail of the one-workgroup kernel (no sweeps of its own)
     hipLaunchKernelGGL((eigh_psd_kernel<false, 0>), dim3(1), dim3(EIGH_THREADS), 0, st, n, S_dev, lds_, evecs_dev, ldv, evals_dev,
-                       0, tol, (int *)nullptr);
+                       0, tol, (int *)nullptr, 0, (const int *)chol_flag);
     PK_CHECK_LAUNCH("eigh block kernels");
     return PK_OK;
 }

@@ -80,7 +80,8 @@ class RecommenderModel:
         self._feedback_threshold = feedback_threshold or get_default('feedback_threshold')
         self.switch_positive = get_default('switch_positive')
         self.verify_integrity = get_default('verify_integrity')
-        self.max_test_workers = get_default('max_test_workers')  # accepted, unused: no host chunk loop
+        self.max_test_workers = get_default('max_test_workers')  # accepted, unused: no host chunk loop (passes issued by several
+        # host threads on one ops object are enqueued one at a time: scoring.recommend holds ops.pass_lock)
         self._prediction_key = self.data.fields.userid
         self._prediction_target = self.data.fields.itemid
         self._is_ready = False

@@ -215,6 +215,8 @@ class HipOps:
         self._gram_work = None
         self._score_state = None
         self._score_states = None
+        import threading
+        self.pass_lock = threading.RLock()   # scoring.recommend enqueues a pass as a whole (per-stream scratch state)
         self._aux_streams = []
         self.score_tiles_per_chunk = 0   # 0 = auto (L2-sized item chunks); tests force tiny chunks
         import os

@@ -9,6 +9,8 @@ turned into ONE canonical CSR whose explicit zeros are kept — zero-feedback en
 nothing to the fold-in (the reference drops them from `test_matrix`, models.py:198-203) but still
 count as seen (they stay in `slice_data`, models.py:494-519).
 """
+import threading
+
 import numpy as np
 import torch
 
@@ -63,6 +65,7 @@ def test_csr_from_triplet(test_data, shape, weights=None):
 
 
 ORDER_USERS_MIN = 8192      # below this a pass is a handful of workgroups: nothing to balance
+_in_pass = threading.local()
 
 
 def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stats=None, prune=True, batches=None,
@@ -77,6 +80,18 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
     delta_u = 2^-24 (w_u + ||E'_u||) max||V_i|| and certifies the ORDER only where consecutive scores are further
     apart than 2 delta_u; the (few) other users get their E row recomputed from the fp64 factors and are re-scored
     exactly, against the fp64 item rows.  The returned ids are those of the exact pipeline either way."""
+    lock = getattr(ops, 'pass_lock', None)
+    if lock is not None and not getattr(_in_pass, 'held', False):
+        # two host threads driving one ops object (the reference parallelises its chunk loop with a thread pool,
+        # models.py:374-382) would interleave their launches on the same stream and share the sweep's parked state and
+        # the exact path's work buffer: a pass is enqueued as a whole (enqueueing costs ~0.2 ms; the GPU is not waited for)
+        with lock:
+            _in_pass.held = True
+            try:
+                return recommend(ops, factors, T, topk, filter_seen, return_scores, stats, prune, batches, approx_fold_in,
+                                 order_users)
+            finally:
+                _in_pass.held = False
     n_users, n_items = T.shape
     if n_items != factors.n_items:
         raise ValueError('test matrix and item factors disagree on the number of items')

@@ -368,3 +368,42 @@ def test_captured_pass_replays_the_same_lists(hip_ops):
         # the launched pass still works next to the graph (separate scratch buffers)
         assert torch.equal(scoring.recommend(ops, F, A, topk, True), want)
         assert torch.equal(cap.replay(), want)
+
+
+def test_passes_from_several_host_threads_share_one_ops_object(hip_ops):
+    """The reference parallelises its chunk loop with a thread pool (models.py:374-382): host threads driving ONE ops
+    object on one stream must not interleave their passes (shared per-stream scratch state) — every thread gets the
+    lists of the serial run, for different test matrices and list lengths at once."""
+    import threading
+    import torch
+    from polara_amd import scoring
+    from polara_amd.solver import svd_topk
+    ops = hip_ops
+    c = csr_to_numpy(planted_csr(9000, 700, 40, 10, seed=21, min_items=5, max_items=300))
+    A = ops.csr(c['indptr'], c['indices'], c['values'], c['shape'])
+    _, _, V, st = svd_topk(ops, A, 10)
+    F = scoring.FactorImage(ops, V)
+    parts = [ops.csr_rows(A, lo, hi) for lo, hi in ((0, 9000), (0, 4500), (4500, 9000), (100, 8300))]
+    topks = [10, 5, 20, 10]
+    want = [scoring.recommend(ops, F, T, k, True).clone() for T, k in zip(parts, topks)]
+    torch.cuda.synchronize()
+    got = [[None] * 6 for _ in parts]
+    errors = []
+
+    def work(j):
+        try:
+            torch.cuda.set_device(ops.device)
+            for r in range(6):
+                got[j][r] = scoring.recommend(ops, F, parts[j], topks[j], True)
+        except Exception as exc:      # surfaces in the main thread
+            errors.append(exc)
+    threads = [threading.Thread(target=work, args=(j,)) for j in range(len(parts))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for j in range(len(parts)):
+        for r in range(6):
+            assert torch.equal(got[j][r], want[j]), (j, r)

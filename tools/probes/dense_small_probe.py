@@ -24,10 +24,14 @@ for l in (64, 128, 200, 256):
     X = torch.randn(n_items, l, dtype=torch.float64, device='cuda:0')
     Y = torch.randn(n_items, l, dtype=torch.float64, device='cuda:0')
     G = ops.gram(X)
+    Xg = X * torch.exp(-torch.arange(l, dtype=torch.float64, device='cuda:0') / (l / 12.0))     # graded columns: e^-12 over the block
+    Q, _ = torch.linalg.qr(torch.randn(l, l, dtype=torch.float64, device='cuda:0'))
+    Gg = ops.gram(Xg @ Q)                                                                           # ... in a rotated basis
     C = torch.randn(l, l, dtype=torch.float64, device='cuda:0')
     th = torch.rand(l, dtype=torch.float64, device='cuda:0')
     out['l=%d' % l] = dict(
         chol_rinv_us=timed(lambda: ops.chol_rinv(G)), eigh_psd_us=timed(lambda: ops.eigh_psd(G), reps=5),
+        eigh_psd_graded_us=timed(lambda: ops.eigh_psd(Gg), reps=5),
         gram_us=timed(lambda: ops.gram(X)), gram2_us=timed(lambda: ops.gram(X, Y)), tsmm_us=timed(lambda: ops.tsmm(X, C)),
         axpbypcz_us=timed(lambda: ops.axpbypcz(1.0, X, 2.0, Y, 3.0, X)), resid_us=timed(lambda: ops.resid_colnorm2(X, Y, th)))
 print(json.dumps(out))
