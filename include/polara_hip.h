@@ -309,6 +309,10 @@ int pk_fold_rows_f64(void *stream, int64_t cap, const int32_t *list_dev, const i
  * itself, without a copy-engine transfer behind the pass. */
 int pk_scatter_rows_i64(void *stream, int64_t n_rows, int32_t width, const int64_t *src_dev, const int64_t *perm_dev,
                         int64_t *dst);
+/* dst[e] = src_dev[e] >= 0 ? table_dev[src_dev[e]] : -1: internal item positions -> the item ids of the caller's index
+ * (the renaming get_recommendations applies to its result, models.py:400-405 return ids of data.index.itemid), on the
+ * device; `dst` is device or mapped pinned host memory. */
+int pk_map_ids_i64(void *stream, int64_t n, const int64_t *src_dev, const int64_t *table_dev, int64_t n_table, int64_t *dst);
 /* Brute-force exact path for a list of users: all n_items fp64 scores, two-class key
  * (unseen above seen, then score; the reference's downvote semantics, models.py:510-519), top-k.
  * Outputs are compact [n_rows x topk] (row r belongs to user rows_dev[r]).

@@ -72,6 +72,7 @@ PROTOTYPES = {
     'pk_rescore_topk_rows_f64': (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _i32, _i32,
                                            _vp, _vp, _i32, _f64, _vp, _vp, _vp]),
     'pk_scatter_rows_i64': (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp]),
+    'pk_map_ids_i64': (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp]),
     'pk_exact_work_bytes': (_i64, [_i32, _i64]),
     'pk_score_exact_rows_f64': (C.c_int, [_vp, _i32, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _i32,
                                           _vp, _vp, _vp]),

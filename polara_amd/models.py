@@ -350,9 +350,13 @@ class RecommenderModel:
         if hi > lo:
             recs_dev = scoring.recommend(ops, self._item_factors_device(), T, self.topk, self.filter_seen,
                                          stats=stats if self.collect_recommend_stats else None)
-            recs = ops.to_host(recs_dev)
-            if self._item_inv is not None:   # internal positions -> external item ids
-                recs = np.where(recs >= 0, self._item_inv[np.maximum(recs, 0)], -1).astype(np.int64)
+            if hasattr(ops, 'ids_to_host'):
+                # internal positions -> external item ids on the device, one transfer into pinned memory
+                recs = ops.ids_to_host(recs_dev, self._item_inv)
+            else:
+                recs = ops.to_host(recs_dev)
+                if self._item_inv is not None:   # internal positions -> external item ids
+                    recs = np.where(recs >= 0, self._item_inv[np.maximum(recs, 0)], -1).astype(np.int64)
         else:
             recs = np.empty((0, self.topk), dtype=np.int64)
         self.recommend_stats = stats

@@ -759,6 +759,25 @@ class HipOps:
                    'pk_scatter_rows_i64')
         return out
 
+    def ids_to_host(self, recs, table=None):
+        """The [n x topk] int64 result as a host array: renamed through `table` (host int64 array: internal position ->
+        caller's item id, -1 stays -1) on the device, then ONE transfer into pinned memory (the array returned is a view
+        of a pinned block of torch's caching host allocator: it goes back to the cache with the array)."""
+        assert recs.dtype == torch.int64 and recs.is_contiguous()
+        src = recs
+        if table is not None:
+            key = (table.__array_interface__['data'][0], table.shape[0])
+            if getattr(self, '_id_table', (None, None))[0] != key:     # one table at a time: the model's serving index
+                self._id_table = (key, torch.from_numpy(np.ascontiguousarray(table, dtype=np.int64)).to(self.device), table)
+            tab = self._id_table[1]
+            src = torch.empty_like(recs)
+            _lib.check(self.lib.pk_map_ids_i64(self.stream(), recs.numel(), _ptr(recs), _ptr(tab), tab.numel(), _ptr(src)),
+                       'pk_map_ids_i64')
+        host = torch.empty(recs.shape, dtype=torch.int64, pin_memory=True)
+        host.copy_(src, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        return host.numpy()
+
     def eval_ranks(self, recs, hold_row, hold_item):
         """int32 [n_holdout]: 1-based rank of every holdout item in its user's row of the device-resident
         recommendation array (0 = not recommended)."""

@@ -65,11 +65,13 @@ def test_csr_from_triplet(test_data, shape, weights=None):
 
 
 ORDER_USERS_MIN = 8192      # below this a pass is a handful of workgroups: nothing to balance
+import os as _os
+HEAD_USERS = int(_os.environ.get('PK_SCORE_HEAD', '0'))   # users of the head batch of an activity-ordered pass (0: none)
 _in_pass = threading.local()
 
 
 def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stats=None, prune=True, batches=None,
-              approx_fold_in=None, order_users=True):
+              approx_fold_in=None, order_users=True, head_users=None):
     """factors: FactorImage; T: ops-level CSR of the test users [n_users x n_items].
     Returns int64 device tensor [n_users x topk] (+ fp64 scores), rows in test-user order,
     columns by descending score — the contract of models.py:400-405.
@@ -89,7 +91,7 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
             _in_pass.held = True
             try:
                 return recommend(ops, factors, T, topk, filter_seen, return_scores, stats, prune, batches, approx_fold_in,
-                                 order_users)
+                                 order_users, head_users)
             finally:
                 _in_pass.held = False
     n_users, n_items = T.shape
@@ -102,8 +104,10 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
         # grouped by activity (the row order is a cached image of the test matrix); rows go back to their places at
         # the end.  ML-20M-shaped: 12.3 -> 9.5 % of the tiles scored, sweep -14 %, fold-in -17 % (long rows first).
         Tp, perm = T.by_activity()
+        if head_users is None:
+            head_users = HEAD_USERS
         res = recommend(ops, factors, Tp, topk, filter_seen, return_scores, stats, prune, batches, approx_fold_in,
-                        order_users=False)
+                        order_users=False, head_users=head_users)
         if return_scores:
             idx_p, sc_p = res
             out_idx, out_s = torch.empty_like(idx_p), torch.empty_like(sc_p)
@@ -149,6 +153,7 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
     def run_batch(u0, u1):
         """fold-in -> bounds/pack -> candidate sweep -> exact re-scoring of users [u0, u1) on the current stream"""
         nb = u1 - u0
+        splits = ops.score_splits(nb, KC, prune)     # of THIS batch: a small head batch is dealt out over item splits
         if approx_fold_in:
             ops.spmm(T, factors.V32x, out=Ex, rows=(u0, u1))               # fold-in against fl32(V) (K4)
             w = Ex[u0:u1, K]                                               # w_u = sum_j a_uj ||V_j|| (strided view)
@@ -188,19 +193,28 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
     # only used to bound the temporaries of very large user sets (4M users per batch).
     B = int(batches) if batches else -(-n_users // (1 << 22))
     B = max(1, min(B, n_users // 4096)) if n_users >= 4096 else 1
+    head = int(head_users or 0)
     if stats is not None:
-        B = 1                                # sweep statistics are read from the (single) state buffer
-    if B == 1:
+        B, head = 1, 0                       # sweep statistics are read from the (single) state buffer
+    if B == 1 and not (0 < head and 4 * head <= n_users):
         run_batch(0, n_users)
     else:
-        per = -(-(-(-n_users // B)) // 128) * 128          # batch size, multiple of 128 users (one workgroup)
+        if B == 1:
+            # the first `head` users on their own: with the users in activity order they are the ones whose groups stay
+            # longest in the sweep (mean exit tile 129 against 70, max 271 against ~130 of 836 on ML-20M-shaped) and the
+            # sweep kernel lasts as long as its slowest wave; a batch this small gets item splits (ops.score_splits), its
+            # chains are S times shorter and run next to the bulk of the users on the other stream
+            ranges = [(0, head), (head, n_users)]
+        else:
+            per = -(-(-(-n_users // B)) // 128) * 128          # batch size, multiple of 128 users (one workgroup)
+            ranges = [(u0, min(n_users, u0 + per)) for u0 in range(0, n_users, per)]
         main = torch.cuda.current_stream(E.device)
         side = ops.aux_streams(2)
         for sdev in side:
             sdev.wait_stream(main)
-        for b, u0 in enumerate(range(0, n_users, per)):
+        for b, (u0, u1) in enumerate(ranges):
             with torch.cuda.stream(side[b % 2]):
-                run_batch(u0, min(n_users, u0 + per))
+                run_batch(u0, u1)
         for sdev in side:
             main.wait_stream(sdev)
     # users still flagged (fewer than k unseen items, or not certifiable) are re-done by the exact-row kernel from a
