@@ -145,6 +145,14 @@ class ArrayData:
         idx, val = self.threshold_data(idx, val, feedback_threshold)
         return idx.astype(np.intp, copy=False), np.ascontiguousarray(val), tuple(int(s) for s in shp)
 
+    def matrix_triplets(self, feedback_threshold=None):
+        """(users, items, feedback, shape) of `to_coo(tensor_mode=False)` WITHOUT the [nnz x 2] index array: the three
+        columns as they lie in memory.  A shortcut for device models (the stacked copy of a 2e7-entry index is 35 ms of
+        host time next to a 55 ms solver); anything written against the reference's protocol calls `to_coo`."""
+        u, i, f = self._train
+        (u, i), f = self.threshold_data((u, i), f, feedback_threshold)
+        return u, i, np.ascontiguousarray(f), (int(self.n_users), int(self.n_items))
+
     def _recover_testset(self):
         """data.py:820-832: training rows of the holdout users, sorted by user."""
         users = np.unique(self._test.holdout.userid)

@@ -610,8 +610,14 @@ class SVDModel(RecommenderModel):
             return A
         # COO -> CSR, per-item counts and the renaming into the internal (popularity) order all run on the device
         # (csrc/ingest.hip): the index array of `to_coo` goes up as it is
-        idx, val, shp = self.data.to_coo(tensor_mode=False, feedback_threshold=self.feedback_threshold)
-        A = self.ops.csr_from_coo(idx[:, 0], idx[:, 1], val, shp)
+        from .data import ArrayData
+        if getattr(type(self.data), 'to_coo', None) is ArrayData.to_coo:   # our own data object (to_coo not overridden): the
+            # columns as they lie, no stacked index
+            rows, cols, val, shp = self.data.matrix_triplets(feedback_threshold=self.feedback_threshold)
+        else:
+            idx, val, shp = self.data.to_coo(tensor_mode=False, feedback_threshold=self.feedback_threshold)
+            rows, cols = idx[:, 0], idx[:, 1]
+        A = self.ops.csr_from_coo(rows, cols, val, shp)
         counts = self.ops.item_counts(A)
         if self._presharded() and self.comm.world > 1:
             counts = self.ops.to_host(self.comm.allreduce(self.ops.to_device(counts)))
