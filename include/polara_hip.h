@@ -88,7 +88,9 @@ int pk_spmm_csr_ex(void *stream,
                    const int32_t *long_slot_end_dev,
                    const int32_t *indices_dev, const void *vals_dev, int val_kind,
                    const void *X_dev, int x_kind, int64_t ldx, int32_t nc,
-                   double *out_dev, int64_t ldo, double *partial_dev, int64_t row_base, int32_t accumulate);
+                   double *out_dev, int64_t ldo, double *partial_dev, int64_t row_base, int32_t accumulate,
+                   int64_t x_rows /* rows of X (= columns of the sparse matrix), or 0 if unknown: with fewer than 2^24 rows
+                   and X below 4 GiB the kernels address X with 32-bit offsets (a quarter of the address arithmetic) */);
 
 /* ------------------------------------------------------------------------------------------
  * Ingest.  The index work around the hot path, on the device:

@@ -23,7 +23,7 @@ PROTOTYPES = {
     'pk_spmm_csr_x': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, C.c_int,
                                 _vp, C.c_int, _i64, _i32, _vp, _i64, _vp]),
     'pk_spmm_csr_ex': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, C.c_int,
-                                 _vp, C.c_int, _i64, _i32, _vp, _i64, _vp, _i64, _i32]),
+                                 _vp, C.c_int, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _i64]),
     'pk_scan_work_bytes': (_i64, [_i64]),
     'pk_exclusive_scan_i32': (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
     'pk_radix_work_bytes': (_i64, [_i64]),

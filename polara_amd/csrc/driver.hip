@@ -266,7 +266,7 @@ int spmm(pk_ctx *ctx, Csr &M, const void *X, int x_kind, int64_t ldx, int nc, do
                           P.task_end.as<int64_t>() + rg.t0, P.task_slot.as<int32_t>() + rg.t0, rg.nl,
                           P.long_row.as<int32_t>() + rg.l0, P.long_sb.as<int32_t>() + rg.l0, P.long_se.as<int32_t>() + rg.l0,
                           M.indices.as<int32_t>(), M.values.p, M.val_kind, static_cast<const char *>(X) + (size_t)c0 * xe, x_kind, ldx,
-                          w, out + c0, ldo, P.partial.as<double>(), row_base, accumulate));
+                          w, out + c0, ldo, P.partial.as<double>(), row_base, accumulate, 0));
     }
     return PK_OK;
 }

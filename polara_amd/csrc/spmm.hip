@@ -133,7 +133,11 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(
 // XT = float: the dense block is read in fp32 (the fp32 image of the item factors for the approximate fold-in
 // of the scoring pass, scoring.py); a lane's four columns are then consecutive (4l .. 4l+3) and arrive with
 // ONE 16-byte load.  Accumulation and output stay fp64.
-template <typename VT, int GROUPS, typename XT, bool ACC>
+// OFF32: every byte offset into X fits 32 bits, every row index and the row stride 24 (the launcher checks x_rows): the
+// offset of a row piece is one full-rate v_mad_u32_u24 on top of the UNIFORM base pointer, so the loads take the
+// scalar-base + 32-bit-offset form.  The 64-bit form costs two quarter-rate 32-bit multiplies, a 64-bit multiply-add
+// and three more VALU instructions per gathered row — 12 of the ~33 SIMD cycles a row costs in the fold-in.
+template <typename VT, int GROUPS, typename XT, bool ACC, bool OFF32>
 __global__ __launch_bounds__(256) void spmm_csr_groups_kernel(
     int64_t n_tasks, const int32_t *__restrict__ task_row, const int64_t *__restrict__ task_begin,
     const int64_t *__restrict__ task_end, const int32_t *__restrict__ task_slot,
@@ -181,13 +185,28 @@ __global__ __launch_bounds__(256) void spmm_csr_groups_kernel(
         jn = ip[64 + lane];
         an = vp[64 + lane];
     }
+    const char *Xb = reinterpret_cast<const char *>(X);
+    const unsigned stride_b = (unsigned)(ldx * (int64_t)sizeof(XT));           // row stride in bytes, < 2^24 (OFF32)
+    const unsigned lo0 = (unsigned)((ok0 ? c0 : 0) * (int)sizeof(XT)), lo1 = (unsigned)((ok1 ? c1 : 0) * (int)sizeof(XT));
     auto issue = [&](int jch, int st0, XA(&xa)[U], auto &xb) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int jj = __shfl(jch, (st0 + u) * GROUPS + g, 64);
-            const int64_t off = (int64_t)jj * ldx;
-            xa[u] = *reinterpret_cast<const XA *>(x0 + off);
-            if constexpr (!XF) xb[u] = *reinterpret_cast<const double2 *>(x1 + off);
+            if constexpr (OFF32) {
+                // byte offset = row * stride + column offset in ONE full-rate instruction (24-bit operands, 32-bit sum);
+                // written out because the compiler turns the C expression into a quarter-rate v_mad_u64_u32
+                unsigned o0, o1;
+                asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(o0) : "v"(jj), "v"(stride_b), "v"(lo0));
+                xa[u] = *reinterpret_cast<const XA *>(Xb + o0);
+                if constexpr (!XF) {
+                    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(o1) : "v"(jj), "v"(stride_b), "v"(lo1));
+                    xb[u] = *reinterpret_cast<const double2 *>(Xb + o1);
+                }
+            } else {
+                const int64_t off = (int64_t)jj * ldx;
+                xa[u] = *reinterpret_cast<const XA *>(x0 + off);
+                if constexpr (!XF) xb[u] = *reinterpret_cast<const double2 *>(x1 + off);
+            }
         }
     };
     auto consume = [&](VT ach, int st0, const XA(&xa)[U], const auto &xb) {
@@ -296,7 +315,7 @@ template <typename VT>
 static int launch_spmm(hipStream_t st, int64_t n_tasks, const int32_t *task_row, const int64_t *task_begin,
                        const int64_t *task_end, const int32_t *task_slot, const int32_t *indices,
                        const void *vals, const void *Xv, int x_kind, int64_t ldx, int nc, double *out, int64_t ldo,
-                       double *partial, int64_t row_base, int accumulate) {
+                       double *partial, int64_t row_base, int accumulate, int64_t x_rows) {
     dim3 grid((unsigned)pk_ceil_div(n_tasks, 4)), block(256);
     const VT *v = static_cast<const VT *>(vals);
     if (x_kind == PK_VAL_F32) {
@@ -306,37 +325,43 @@ static int launch_spmm(hipStream_t st, int64_t n_tasks, const int32_t *task_row,
             pk_set_error("pk_spmm_csr_x: an fp32 dense block needs nc %% 4 == 0, ldx %% 4 == 0 and 16-byte alignment");
             return PK_E_UNSUPPORTED;
         }
+        // 32-bit offsets: the caller told us how many rows X has, they number fewer than 2^24, a row is a whole number of
+        // 16-byte units and the last byte of X lies below 4 GiB
+        const bool off32 = x_rows > 0 && x_rows < (1 << 24) && ldx * 4 < (1 << 24) &&
+                           x_rows * ldx * 4 < ((int64_t)1 << 32) && !getenv("PK_SPMM_OFF64");
+#define PK_SPMM_LAUNCH_F(G, A, O)                                                                                   \
+    hipLaunchKernelGGL((spmm_csr_groups_kernel<VT, G, float, A, O>), grid, block, 0, st, n_tasks, task_row,         \
+                       task_begin, task_end, task_slot, indices, v, X, ldx, nc, out, ldo, partial, row_base)
 #define PK_SPMM_GROUPS_F(G)                                                                                          \
     do {                                                                                                             \
-        if (accumulate)                                                                                              \
-            hipLaunchKernelGGL((spmm_csr_groups_kernel<VT, G, float, true>), grid, block, 0, st, n_tasks, task_row,  \
-                               task_begin, task_end, task_slot, indices, v, X, ldx, nc, out, ldo, partial, row_base); \
-        else                                                                                                         \
-            hipLaunchKernelGGL((spmm_csr_groups_kernel<VT, G, float, false>), grid, block, 0, st, n_tasks, task_row, \
-                               task_begin, task_end, task_slot, indices, v, X, ldx, nc, out, ldo, partial, row_base); \
+        if (accumulate) { if (off32) PK_SPMM_LAUNCH_F(G, true, true); else PK_SPMM_LAUNCH_F(G, true, false); }       \
+        else { if (off32) PK_SPMM_LAUNCH_F(G, false, true); else PK_SPMM_LAUNCH_F(G, false, false); }                \
     } while (0)
         if (nc <= 64) PK_SPMM_GROUPS_F(4);
         else if (nc <= 128) PK_SPMM_GROUPS_F(2);
         else PK_SPMM_GROUPS_F(1);
 #undef PK_SPMM_GROUPS_F
+#undef PK_SPMM_LAUNCH_F
         return PK_OK;
     }
     const double *X = static_cast<const double *>(Xv);
     const bool paired = (nc % 2 == 0) && (ldx % 2 == 0) && (((uintptr_t)X) % 16 == 0) && !getenv("PK_SPMM_LANE_COLUMNS");
     if (paired) {
+        const bool off32 = x_rows > 0 && x_rows < (1 << 24) && ldx * 8 < (1 << 24) &&
+                           x_rows * ldx * 8 < ((int64_t)1 << 32) && !getenv("PK_SPMM_OFF64");
+#define PK_SPMM_LAUNCH_D(G, A, O)                                                                                   \
+    hipLaunchKernelGGL((spmm_csr_groups_kernel<VT, G, double, A, O>), grid, block, 0, st, n_tasks, task_row,        \
+                       task_begin, task_end, task_slot, indices, v, X, ldx, nc, out, ldo, partial, row_base)
 #define PK_SPMM_GROUPS(G)                                                                                             \
     do {                                                                                                              \
-        if (accumulate)                                                                                               \
-            hipLaunchKernelGGL((spmm_csr_groups_kernel<VT, G, double, true>), grid, block, 0, st, n_tasks, task_row,  \
-                               task_begin, task_end, task_slot, indices, v, X, ldx, nc, out, ldo, partial, row_base); \
-        else                                                                                                          \
-            hipLaunchKernelGGL((spmm_csr_groups_kernel<VT, G, double, false>), grid, block, 0, st, n_tasks, task_row, \
-                               task_begin, task_end, task_slot, indices, v, X, ldx, nc, out, ldo, partial, row_base); \
+        if (accumulate) { if (off32) PK_SPMM_LAUNCH_D(G, true, true); else PK_SPMM_LAUNCH_D(G, true, false); }        \
+        else { if (off32) PK_SPMM_LAUNCH_D(G, false, true); else PK_SPMM_LAUNCH_D(G, false, false); }                 \
     } while (0)
         if (nc <= 64) PK_SPMM_GROUPS(4);
         else if (nc <= 128) PK_SPMM_GROUPS(2);
         else PK_SPMM_GROUPS(1);
 #undef PK_SPMM_GROUPS
+#undef PK_SPMM_LAUNCH_D
         return PK_OK;
     }
     const int cpl = (nc + 63) / 64;
@@ -368,7 +393,7 @@ extern "C" int pk_spmm_csr_ex(void *stream, int64_t n_tasks, const int32_t *task
                               const int32_t *long_slot_begin_dev, const int32_t *long_slot_end_dev,
                               const int32_t *indices_dev, const void *vals_dev, int val_kind,
                               const void *X_dev, int x_kind, int64_t ldx, int32_t nc, double *out_dev, int64_t ldo,
-                              double *partial_dev, int64_t row_base, int32_t accumulate) {
+                              double *partial_dev, int64_t row_base, int32_t accumulate, int64_t x_rows) {
     PK_REQUIRE(n_tasks >= 0 && nc >= 1 && nc <= 256, "pk_spmm_csr: bad sizes n_tasks=%lld nc=%d",
                (long long)n_tasks, nc);
     PK_REQUIRE(ldo >= nc && ldx >= nc, "pk_spmm_csr: ldo/ldx < nc");
@@ -380,10 +405,10 @@ extern "C" int pk_spmm_csr_ex(void *stream, int64_t n_tasks, const int32_t *task
     int rc;
     if (val_kind == PK_VAL_F32)
         rc = launch_spmm<float>(st, n_tasks, task_row_dev, task_begin_dev, task_end_dev, task_slot_dev,
-                                indices_dev, vals_dev, X_dev, x_kind, ldx, nc, out_dev, ldo, partial_dev, row_base, accumulate);
+                                indices_dev, vals_dev, X_dev, x_kind, ldx, nc, out_dev, ldo, partial_dev, row_base, accumulate, x_rows);
     else if (val_kind == PK_VAL_F64)
         rc = launch_spmm<double>(st, n_tasks, task_row_dev, task_begin_dev, task_end_dev, task_slot_dev,
-                                 indices_dev, vals_dev, X_dev, x_kind, ldx, nc, out_dev, ldo, partial_dev, row_base, accumulate);
+                                 indices_dev, vals_dev, X_dev, x_kind, ldx, nc, out_dev, ldo, partial_dev, row_base, accumulate, x_rows);
     else {
         pk_set_error("pk_spmm_csr: bad val_kind %d", val_kind);
         return PK_E_INVALID;
@@ -407,7 +432,7 @@ extern "C" int pk_spmm_csr_x(void *stream, int64_t n_tasks, const int32_t *task_
                              double *partial_dev) {
     return pk_spmm_csr_ex(stream, n_tasks, task_row_dev, task_begin_dev, task_end_dev, task_slot_dev, n_long,
                           long_row_dev, long_slot_begin_dev, long_slot_end_dev, indices_dev, vals_dev, val_kind, X_dev,
-                          x_kind, ldx, nc, out_dev, ldo, partial_dev, 0, 0);
+                          x_kind, ldx, nc, out_dev, ldo, partial_dev, 0, 0, 0);
 }
 
 extern "C" int pk_spmm_csr_f64(void *stream, int64_t n_tasks, const int32_t *task_row_dev,
@@ -419,5 +444,5 @@ extern "C" int pk_spmm_csr_f64(void *stream, int64_t n_tasks, const int32_t *tas
                                double *partial_dev) {
     return pk_spmm_csr_ex(stream, n_tasks, task_row_dev, task_begin_dev, task_end_dev, task_slot_dev, n_long,
                           long_row_dev, long_slot_begin_dev, long_slot_end_dev, indices_dev, vals_dev, val_kind, X_dev,
-                          PK_VAL_F64, ldx, nc, out_dev, ldo, partial_dev, 0, 0);
+                          PK_VAL_F64, ldx, nc, out_dev, ldo, partial_dev, 0, 0, 0);
 }

@@ -462,7 +462,7 @@ class HipOps:
                 self.stream(), n_tasks, _ptr(tr, t0), _ptr(tb, t0), _ptr(te, t0), _ptr(ts, t0), n_long,
                 _ptr(lr, l0), _ptr(lb, l0), _ptr(le, l0), _ptr(A.indices), _ptr(A.values), A.val_kind,
                 _ptr(X), x_kind, X.stride(0), nc, _ptr(out), out.stride(0), _ptr(A.partial(nc)), int(row_base),
-                1 if accumulate else 0), 'pk_spmm_csr_ex')
+                1 if accumulate else 0, int(X.shape[0])), 'pk_spmm_csr_ex')
         return out
 
     # ---- K2 ---------------------------------------------------------------------------------
