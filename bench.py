@@ -607,6 +607,54 @@ def coarse_c_path(B, c, rank, topk):
     return out
 
 
+def coffee_block(B, cpu=True):
+    """BASELINE.json configs[3]: CoffeeModel (HOOI of the user x item x rating tensor) on the ML-1M-shaped data at the
+    multilinear ranks (30,30,4) — the largest the reference itself accepts, `lib/tensor.py:79` — and (30,30,5); warm build,
+    then `get_recommendations` for all users.  Parity lives in tests/test_gpu_configs.py (golden fixture from the pinned
+    oracle); the un-jitted CPU oracle needs 114 s for this build and is not re-timed here."""
+    from polara_amd.data import ArrayData
+    from polara_amd.models import CoffeeModel
+    from polara_amd.synth import make_workload, csr_to_coo_triplets
+    csr, cfg = make_workload('ml1m')
+    u, i, v = csr_to_coo_triplets(csr)
+    n_users, n_items = csr['shape']
+    hold = (np.arange(n_users), np.zeros(n_users, np.int64), np.ones(n_users))
+    d = ArrayData((u, i, v), n_users=n_users, n_items=n_items, holdout=hold, warm_start=False)
+    out = {'workload': 'ML-1M-shaped tensor %d x %d x %d, %d entries (BASELINE.json configs[3])' % (n_users, n_items, len(np.unique(v)), len(v))}
+    for mlrank in ((30, 30, 4), (30, 30, 5)):
+        m = CoffeeModel(d, ops=B.ops)
+        m.verbose = False
+        m.mlrank, m.seed, m.topk = mlrank, 0, 10
+        m.build()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        m.build()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        recs = m.get_recommendations()
+        t2 = time.perf_counter()
+        recs2 = m.get_recommendations()
+        t3 = time.perf_counter()
+        f = d.fields
+        orth = max(float(np.abs(m.factors[k].T @ m.factors[k] - np.eye(m.factors[k].shape[1])).max())
+                   for k in (f.userid, f.itemid, f.feedback))
+        out['mlrank_%d_%d_%d' % mlrank] = dict(build_s=t1 - t0, iterations=len(m.core_norm_trace),
+                                               core_norm=float(m.core_norm_trace[-1]), factors_orthonormal_to=orth,
+                                               get_recommendations_s=t2 - t1, get_recommendations_again_s=t3 - t2,
+                                               users_per_s=n_users / (t3 - t2), identical_between_calls=bool(np.array_equal(recs, recs2)))
+    return out
+
+
+def s50m_block(B, cpu=True):
+    """BASELINE.json configs[4] as the share one call can hold: 1M of the 50M users against the full 500K-item catalogue,
+    rank 200, top-50 (tools/bench_s50m_shard.py; rows checked against the CPU path on a 300-user sample)."""
+    import argparse
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools'))
+    import bench_s50m_shard
+    return bench_s50m_shard.run(argparse.Namespace(users=1_000_000, items=500_000, rank=200, topk=50, steps=3,
+                                                   check_users=300 if cpu else 0))
+
+
 def main():
     args = parse()
     B = Bench(args)
@@ -649,6 +697,18 @@ def main():
         s = B.measure(c1, 's1m', 50, 10, 2, 1, prune=False, cpu=False)
         subs['configs1_s1m_no_prune'] = {k: s[k] for k in ('value', 'ms_per_step', 'latency_ms_per_pass', 'score', 'roofline')}
         del c1
+        gc.collect()
+        torch.cuda.empty_cache()
+        # BASELINE.json configs[3] and configs[4]: not on the metric's path, measured here so that the driver's record
+        # holds them too; a failure in one of these blocks is reported in its place and does not cost the run its line
+        if comm.world == 1:
+            for name, fn in (('configs3_coffee_ml1m', coffee_block), ('configs4_s50m_shard', s50m_block)):
+                try:
+                    subs[name] = fn(B, cpu=not args.no_cpu_baseline)
+                except Exception as exc:
+                    subs[name] = {'error': '%s: %s' % (type(exc).__name__, exc)}
+                gc.collect()
+                torch.cuda.empty_cache()
     if comm.rank != 0:
         return
     tag = {'ml20m': 'ml20m', 's1m': 's1m'}.get(args.workload)

@@ -20,21 +20,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--users', type=int, default=1_000_000)
-    ap.add_argument('--items', type=int, default=500_000)
-    ap.add_argument('--rank', type=int, default=200)
-    ap.add_argument('--topk', type=int, default=50)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--check-users', type=int, default=300)
-    args = ap.parse_args()
+def run(args):
+    """the measurement as a dict (bench.py's `sub.configs4_s50m_shard` calls this with its own argument object)"""
     from polara_amd.ops import HipOps
     from polara_amd.synth import planted_csr, csr_to_numpy
     from polara_amd.csr import popularity_order
     from polara_amd.solver import svd_topk
     from polara_amd import scoring
-    from oracle import polara_oracle as orc
     dev = 'cuda:0'
     ops = HipOps(dev)
     t0 = time.perf_counter()
@@ -78,17 +70,23 @@ def main():
     flops = 2.0 * n_users * n_items * args.rank
     # CPU oracle on a sample (external item ids)
     n_chk = min(args.check_users, n_users)
-    p1 = int(c['indptr'][n_chk])
-    td = (np.repeat(np.arange(n_chk), np.diff(c['indptr'][:n_chk + 1])), c['indices'][:p1].astype(np.int64),
-          c['values'][:p1].astype(np.float64))
-    o2 = ops.to_host(order2)
-    back = np.empty_like(o2)
-    back[o2] = np.arange(n_items)
-    V_ext = np.ascontiguousarray(ops.to_host(V)[back][rank_of])
-    t0 = time.perf_counter()
-    ref = orc.svd_recommendations(V_ext, td, (n_chk, n_items), args.topk, filter_seen=True)
-    cpu_s = time.perf_counter() - t0
-    got = inv_order[o2[ops.to_host(recs[:n_chk])]]
+    cpu_oracle = None
+    if n_chk > 0:
+        # CPU reference path on a user sample (external item ids): the only use of oracle/ here, as the checker
+        from oracle import polara_oracle as orc
+        p1 = int(c['indptr'][n_chk])
+        td = (np.repeat(np.arange(n_chk), np.diff(c['indptr'][:n_chk + 1])), c['indices'][:p1].astype(np.int64),
+              c['values'][:p1].astype(np.float64))
+        o2 = ops.to_host(order2)
+        back = np.empty_like(o2)
+        back[o2] = np.arange(n_items)
+        V_ext = np.ascontiguousarray(ops.to_host(V)[back][rank_of])
+        t0 = time.perf_counter()
+        ref = orc.svd_recommendations(V_ext, td, (n_chk, n_items), args.topk, filter_seen=True)
+        cpu_s = time.perf_counter() - t0
+        got = inv_order[o2[ops.to_host(recs[:n_chk])]]
+        cpu_oracle = {'users': n_chk, 'seconds': cpu_s, 'users_per_s': n_chk / cpu_s,
+                      'identical_rows': float((got == ref).all(axis=1).mean())}
     out = {
         'workload': 'shard of BASELINE.json configs[4]: %d of 50M users x %d items, rank %d, top-%d, ~50 nnz/user'
                     % (n_users, n_items, args.rank, args.topk),
@@ -100,10 +98,20 @@ def main():
         'flagged_users': stats['flagged_users'], 'refolded_users': stats.get('refolded_users'), 'candidate_capacity': stats['candidate_capacity'],
         'sweep_TFLOPs_executed': flops * swept / (ms['score_candidates'] * 1e-3) / 1e12,
         'sweep_TFLOPs_dense_equivalent': flops / (ms['score_candidates'] * 1e-3) / 1e12,
-        'cpu_oracle': {'users': n_chk, 'seconds': cpu_s, 'users_per_s': n_chk / cpu_s,
-                       'identical_rows': float((got == ref).all(axis=1).mean())},
+        'cpu_oracle': cpu_oracle,
     }
-    print(json.dumps(out))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--users', type=int, default=1_000_000)
+    ap.add_argument('--items', type=int, default=500_000)
+    ap.add_argument('--rank', type=int, default=200)
+    ap.add_argument('--topk', type=int, default=50)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--check-users', type=int, default=300)
+    print(json.dumps(run(ap.parse_args())))
 
 
 if __name__ == '__main__':
