@@ -18,7 +18,14 @@ from .solver import NoComm
 class ModePlan:
     """nnz sorted by one output mode + the wave-task plan for pk_ttm_f64."""
 
-    def __init__(self, ops, idx, val, shape, mode0, mode_u, mode_v):
+    def __init__(self, ops, idx, val, shape, mode0, mode_u, mode_v, idx_dev=None):
+        if idx_dev is not None and hasattr(ops, 'mode_plan'):
+            # the device path: idx_dev = the [nnz x 3] index array already in HBM (uploaded once per build)
+            self.n0 = int(shape[mode0])
+            self.plan, self.idx_u, self.idx_v, order = ops.mode_plan(idx_dev, mode0, mode_u, mode_v, self.n0, split=256)
+            ones = val is None or bool(np.all(val == 1.0))
+            self.vals = None if ones else ops.to_device(np.asarray(val, dtype=np.float64)).index_select(0, order.long())
+            return
         order = np.argsort(idx[:, mode0], kind='stable')
         i0 = idx[order, mode0]
         n0 = int(shape[mode0])
@@ -123,9 +130,12 @@ def hooi(ops, idx, val, shape, core_shape, num_iters=25, growth_tol=0.01, seed=N
     u2 = ops.to_device(u2)
 
     # (mode0 ; first matrix mode ; second matrix mode) as in lib/tensor.py:70,74,78
-    mp0 = ModePlan(ops, idx, val, shape, 0, 2, 1)
-    mp1 = ModePlan(ops, idx, val, shape, 1, 2, 0)
-    mp2 = ModePlan(ops, idx, val, shape, 2, 1, 0)
+    idx_dev = None
+    if hasattr(ops, 'mode_plan'):
+        idx_dev = torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int64)).to(ops.device)
+    mp0 = ModePlan(ops, idx, val, shape, 0, 2, 1, idx_dev)
+    mp1 = ModePlan(ops, idx, val, shape, 1, 2, 0, idx_dev)
+    mp2 = ModePlan(ops, idx, val, shape, 2, 1, 0, idx_dev)
 
     g_norm_old = 0.0
     trace = []
