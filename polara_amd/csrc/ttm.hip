@@ -66,18 +66,31 @@ __global__ __launch_bounds__(256) void ttm_kernel(
     }
 }
 
+// Sum of the partial rows of a long row, in a FIXED order: a workgroup owns (long row, 32 output columns); its eight
+// 32-lane halves take every eighth slot (s0 + g, s0 + g + 8, ...) and the eight sums are added in g order.  (One thread
+// per column walking all slots: the feedback mode of a rating tensor has 5 rows of 2e5 entries — 770 slots each — and
+// the fix-up took 0.4 ms on 5 workgroups, as long as the TTM itself.)
 __global__ __launch_bounds__(256) void ttm_fixup_kernel(int64_t n_long, const int32_t *__restrict__ long_row,
                                                         const int32_t *__restrict__ slot_begin,
                                                         const int32_t *__restrict__ slot_end,
                                                         const double *__restrict__ partial, int nout,
                                                         double *__restrict__ res, int64_t ldr) {
+    __shared__ double s_part[8][32];
     const int64_t r = blockIdx.x;
     if (r >= n_long) return;
+    const int g = threadIdx.x >> 5, l = threadIdx.x & 31;
+    const int c = blockIdx.y * 32 + l;
     const int s0 = slot_begin[r], s1 = slot_end[r];
-    for (int c = threadIdx.x; c < nout; c += blockDim.x) {
-        double acc = 0.0;
-        for (int s = s0; s < s1; ++s) acc += partial[(int64_t)s * nout + c];
-        res[(int64_t)long_row[r] * ldr + c] = acc;
+    double acc = 0.0;
+    if (c < nout)
+        for (int s = s0 + g; s < s1; s += 8) acc += partial[(int64_t)s * nout + c];
+    s_part[g][l] = acc;
+    __syncthreads();
+    if (g == 0 && c < nout) {
+        double tot = s_part[0][l];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) tot += s_part[k][l];
+        res[(int64_t)long_row[r] * ldr + c] = tot;
     }
 }
 
@@ -108,7 +121,7 @@ extern "C" int pk_ttm_f64(void *stream, int64_t n_tasks, const int32_t *task_row
 #undef PK_TTM_LAUNCH
     PK_CHECK_LAUNCH("ttm_kernel");
     if (n_long > 0) {
-        hipLaunchKernelGGL(ttm_fixup_kernel, dim3((unsigned)n_long), dim3(256), 0, st, n_long, long_row_dev,
+        hipLaunchKernelGGL(ttm_fixup_kernel, dim3((unsigned)n_long, (unsigned)pk_ceil_div(nout, 32)), dim3(256), 0, st, n_long, long_row_dev,
                            long_slot_begin_dev, long_slot_end_dev, partial_dev, nout, res_dev, ldr);
         PK_CHECK_LAUNCH("ttm_fixup_kernel");
     }
