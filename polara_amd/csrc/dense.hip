@@ -85,21 +85,28 @@ __global__ __launch_bounds__(256) void gram_kernel(int64_t n, int la, int lb, co
     }
 }
 
-// 64 output elements per workgroup; the four waves take every fourth split and their sums are added in wave order
-__global__ __launch_bounds__(256) void gram_reduce_kernel(int la, int lb, int splits,
-                                                          const double *__restrict__ partial,
-                                                          double *__restrict__ G, int64_t ldg) {
-    __shared__ double s_part[4][64];
+// 64 output elements per workgroup; its sixteen waves take every sixteenth split and their sums are added in wave order
+// (with four waves a thread walked 104 partial tiles one after the other at n_items = 26 744: 32 us, more than the
+// products themselves)
+#define PK_GRAM_RED_WAVES 16
+__global__ __launch_bounds__(64 * PK_GRAM_RED_WAVES) void gram_reduce_kernel(int la, int lb, int splits,
+                                                                              const double *__restrict__ partial,
+                                                                              double *__restrict__ G, int64_t ldg) {
+    __shared__ double s_part[PK_GRAM_RED_WAVES][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t e = (int64_t)blockIdx.x * 64 + lane;
     const int64_t total = (int64_t)la * lb;
     double acc = 0.0;
     if (e < total)
-        for (int s = wave; s < splits; s += 4) acc += partial[(int64_t)s * total + e];
+        for (int s = wave; s < splits; s += PK_GRAM_RED_WAVES) acc += partial[(int64_t)s * total + e];
     s_part[wave][lane] = acc;
     __syncthreads();
-    if (wave == 0 && e < total)
-        G[(e / lb) * ldg + (e % lb)] = (s_part[0][lane] + s_part[1][lane]) + (s_part[2][lane] + s_part[3][lane]);
+    if (wave == 0 && e < total) {
+        double tot = s_part[0][lane];
+#pragma unroll
+        for (int w = 1; w < PK_GRAM_RED_WAVES; ++w) tot += s_part[w][lane];
+        G[(e / lb) * ldg + (e % lb)] = tot;
+    }
 }
 
 extern "C" int pk_gram_f64(void *stream, int64_t n, int32_t la, int32_t lb, const double *A_dev, int64_t lda,
@@ -115,7 +122,7 @@ extern "C" int pk_gram_f64(void *stream, int64_t n, int32_t la, int32_t lb, cons
     hipLaunchKernelGGL(gram_kernel, dim3(tiles_i * tiles_j, splits), dim3(256), 0, st, n, la, lb, A_dev, lda,
                        B_dev, ldb, static_cast<double *>(work_dev), tiles_j, rows_per_split);
     PK_CHECK_LAUNCH("gram_kernel");
-    hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)pk_ceil_div((int64_t)la * lb, 64)), dim3(256), 0, st,
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)pk_ceil_div((int64_t)la * lb, 64)), dim3(64 * PK_GRAM_RED_WAVES), 0, st,
                        la, lb, splits, static_cast<const double *>(work_dev), G_dev, ldg);
     PK_CHECK_LAUNCH("gram_reduce_kernel");
     return PK_OK;
