@@ -596,12 +596,31 @@ def coarse_c_path(B, c, rank, topk):
         assert rc == 0, lib.pk_ctx_error(ctx)
         out['score_topk_%s_s' % tag] = time.perf_counter() - t0
     out['users_per_s'] = n_users / out['score_topk_again_s']
+    # the serving handle: what pk_score_topk sets up per call stays on the device between calls
+    sv = vp()
+    t0 = time.perf_counter()
+    rc = lib.pk_serving_create(ctx, n_items, rank, ptr(V), A, C.byref(sv))
+    assert rc == 0, lib.pk_ctx_error(ctx)
+    out['serving_create_s'] = time.perf_counter() - t0
+    recs_sv = np.empty_like(recs)
+    times = []
+    for _ in range(6):
+        t0 = time.perf_counter()
+        rc = lib.pk_serving_score(ctx, sv, topk, 1, ptr(recs_sv), None)
+        assert rc == 0, lib.pk_ctx_error(ctx)
+        times.append(time.perf_counter() - t0)
+    lib.pk_serving_free(ctx, sv)
+    out['serving_score_first_s'] = times[0]
+    out['serving_score_again_s'] = float(np.median(times[1:]))
+    out['serving_users_per_s'] = n_users / out['serving_score_again_s']
+    out['serving_identical_to_score_topk'] = bool(np.array_equal(recs_sv, recs))
     n_chk = min(n_users, 5000)
     t_cpu, cpu_recs = B.cpu_scoring(c, np.ascontiguousarray(V), topk, n_chk)
     out['gpu_vs_cpu_identical_rows'] = float((recs[:n_chk] == cpu_recs).all(axis=1).mean())
     out['note'] = ('pk_svd_build / pk_score_topk: every call takes host arrays, allocates its device buffers (hipMalloc) and returns host '
                    'arrays; pk_score_topk also re-orders the catalogue by factor norm, re-sorts the test rows and builds the factor images and '
-                   'seen-tile streams inside the call')
+                   'seen-tile streams inside the call; pk_serving_create / pk_serving_score keep that state on the device between calls '
+                   '(pageable host result: the [n_users x topk] int64 array is copied into the caller\'s memory inside the call)')
     lib.pk_mat_free(ctx, A)
     lib.pk_ctx_destroy(ctx)
     return out

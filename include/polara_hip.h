@@ -425,6 +425,16 @@ int pk_svd_build(pk_ctx *ctx, pk_mat *A, int32_t k, int32_t block, double tol, i
  * models.py:510-519 orders them).  V_host: [n_items * K] column-major.  out_scores: fp64 scores of those items or NULL. */
 int pk_score_topk(pk_ctx *ctx, int64_t n_items, int32_t K, const double *V_host, pk_mat *T, int32_t topk,
                   int32_t filter_seen, int64_t *out_idx, double *out_scores);
+/* The same with the model-side state kept between calls — what a RecommenderModel keeps between get_recommendations()
+ * calls (models.py:391-405: the factors and the test data do not change from call to call): pk_serving_create orders the
+ * catalogue by factor norm, uploads the factors and their images, renames and re-sorts the rows of T and plans them;
+ * pk_serving_score runs one scoring pass (any topk / filter_seen) and writes the caller's item ids; pk_score_topk =
+ * create + score + free.  The handle belongs to `ctx`; T may be freed after pk_serving_create. */
+typedef struct pk_serving pk_serving;
+int pk_serving_create(pk_ctx *ctx, int64_t n_items, int32_t K, const double *V_host, pk_mat *T, pk_serving **out);
+int pk_serving_score(pk_ctx *ctx, pk_serving *serving, int32_t topk, int32_t filter_seen, int64_t *out_idx,
+                     double *out_scores);
+void pk_serving_free(pk_ctx *ctx, pk_serving *serving);
 /* Tucker / HOOI of a sparse 3-way tensor (`CoffeeModel.build` -> `hooi`, models.py:1009-1024, lib/tensor.py:37-96):
  * idx_host [nnz x 3] row-major (user, item, feedback level), vals_host or NULL (= ones, data.py:805), shape[3],
  * mlrank[3].  u1_start [n1 x r1] / u2_start [n2 x r2] (row-major, orthonormal columns): the start the reference draws

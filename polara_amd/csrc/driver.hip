@@ -818,20 +818,29 @@ extern "C" int pk_svd_build(pk_ctx *ctx, pk_mat *A, int32_t k, int32_t block, do
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// pk_score_topk: polara_amd/scoring.py::recommend restated (models.py:391-405, 857-861, 494-519, 488-491)
+// pk_serving_* / pk_score_topk: polara_amd/scoring.py::recommend restated (models.py:391-405, 857-861, 494-519, 488-491)
+// A serving handle keeps what a model keeps between get_recommendations() calls: the item factors in the serving
+// order (descending factor norm) with their images, and the test matrix renamed into that order with its task plan and
+// seen-tile streams.  pk_score_topk = create + score + free.
 // ------------------------------------------------------------------------------------------------------------
-extern "C" int pk_score_topk(pk_ctx *ctx, int64_t n_items, int32_t K, const double *V_host, pk_mat *T, int32_t topk,
-                             int32_t filter_seen, int64_t *out_idx, double *out_scores) {
-    if (!ctx || !T) return PK_E_INVALID;
-    std::lock_guard<std::mutex> lock(ctx->mu);
-    PoolScope pool_scope(ctx);
-    (void)hipSetDevice(ctx->device);
+struct pk_serving {
+    int64_t n_items = 0, n_users = 0;
+    int K = 0, ld32 = 0, Kx_full = 0;
+    double vmax = 0.0;
+    bool nonneg = true, have_tiles = false, have_v32 = false, fused = false;
+    Dev inv64;                 // serving position -> the caller's item id (int64, for pk_map_ids_i64)
+    DMat V;
+    Csr Ts;
+    Dev Vp, tile_bound, V32, tiles, ntiles;
+};
+
+namespace {
+
+int serving_build(pk_ctx *ctx, pk_serving *sv, int64_t n_items, int32_t K, const double *V_host, pk_mat *T) {
     hipStream_t st = ctx->stream;
-    if (n_items != T->A.n_cols) return fail(ctx, PK_E_INVALID, "pk_score_topk: test matrix and item factors disagree on the number of items");
-    if (K < 1 || K > 8192 || !V_host || !out_idx || topk < 1) return fail(ctx, PK_E_INVALID, "pk_score_topk: bad arguments");
-    if (topk > n_items) return fail(ctx, PK_E_INVALID, "kth(=%lld) out of bounds (%lld)", (long long)(n_items - topk), (long long)n_items);
     const int64_t n_users = T->A.n_rows;
     Solver S{ctx, st, Dev()};
+    sv->n_items = n_items; sv->n_users = n_users; sv->K = K; sv->nonneg = T->nonneg; sv->fused = K <= 256;
     // serving order: items by descending factor norm (the pruning bound is a suffix maximum of these norms)
     std::vector<double> norm((size_t)n_items, 0.0);
     for (int j = 0; j < K; ++j)
@@ -840,18 +849,25 @@ extern "C" int pk_score_topk(pk_ctx *ctx, int64_t n_items, int32_t K, const doub
     for (auto &v : norm) { v = std::sqrt(v); vmax = std::max(vmax, v); }
     if (!std::isfinite(vmax) || (vmax != 0.0 && !(vmax > 1e-30 && vmax < 1e30)))
         return fail(ctx, PK_E_INVALID, "pk_score_topk: item factors with max row norm %g are outside the fp32 range of the candidate sweep", vmax);
+    sv->vmax = vmax;
     std::vector<int32_t> inv((size_t)n_items), rank_of((size_t)n_items);
     std::iota(inv.begin(), inv.end(), 0);
     std::stable_sort(inv.begin(), inv.end(), [&](int32_t a, int32_t b) { return norm[(size_t)a] > norm[(size_t)b]; });
     for (int64_t i = 0; i < n_items; ++i) rank_of[(size_t)inv[(size_t)i]] = (int32_t)i;
+    {
+        std::vector<int64_t> inv_l(inv.begin(), inv.end());
+        if (!sv->inv64.alloc((size_t)n_items * 8)) return fail(ctx, PK_E_LAUNCH, "out of device memory (item ids)");
+        CK(S.upload(inv_l.data(), sv->inv64.p, (size_t)n_items * 8));
+    }
     std::vector<double> vr((size_t)n_items * K);
     for (int64_t i = 0; i < n_items; ++i)
         for (int j = 0; j < K; ++j) vr[(size_t)i * K + j] = V_host[(size_t)j * n_items + inv[(size_t)i]];
-    DMat V(n_items, K);
+    sv->V = DMat(n_items, K);
+    DMat &V = sv->V;
     if (!V.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (factors)");
     CK(S.upload(vr.data(), V.p(), vr.size() * 8));
     // the test rows in the serving order (rows re-sorted: canonical CSR)
-    Csr Ts;
+    Csr &Ts = sv->Ts;
     Ts.n_rows = n_users; Ts.n_cols = n_items; Ts.nnz = T->A.nnz; Ts.val_kind = T->A.val_kind;
     const size_t ve = Ts.val_kind == PK_VAL_F32 ? 4 : 8, n1 = (size_t)std::max<int64_t>(Ts.nnz, 1);
     {
@@ -865,12 +881,43 @@ extern "C" int pk_score_topk(pk_ctx *ctx, int64_t n_items, int32_t K, const doub
         HIPCK(hipStreamSynchronize(st));
     }
     CK(build_plan(ctx, Ts));
+    if (!sv->fused) return PK_OK;
+    // factor images: MFMA fragments, tile bounds, fp32 image with the norm column
+    Dev tb_work((size_t)n_items * 4), rowb((size_t)n_items * 4);
+    if (!sv->Vp.alloc((size_t)pk_pack_elems(n_items, K) * 4) || !sv->tile_bound.alloc((size_t)((n_items + 31) / 32) * 4) || !tb_work.p || !rowb.p)
+        return fail(ctx, PK_E_LAUNCH, "out of device memory (factor images)");
+    CK(pk_pack_frag_f32(st, n_items, K, V.p(), K, sv->Vp.as<float>()));
+    CK(pk_tile_norm_bound_f32(st, n_items, K, V.p(), K, tb_work.as<float>(), sv->tile_bound.as<float>()));
+    sv->Kx_full = ((K + 1 + 3) / 4) * 4;
+    sv->ld32 = sv->Kx_full > 16 ? ((sv->Kx_full + 31) / 32) * 32 : (sv->Kx_full <= 4 ? 4 : sv->Kx_full <= 8 ? 8 : 16);
+    if (sv->Kx_full <= 256 && sv->nonneg) {
+        if (!sv->V32.alloc((size_t)n_items * sv->ld32 * 4)) return fail(ctx, PK_E_LAUNCH, "out of device memory (fp32 image)");
+        CK(pk_row_norm_bound_f32(st, n_items, K, V.p(), K, rowb.as<float>()));
+        hipLaunchKernelGGL(v32_image_kernel, dim3((unsigned)(((size_t)n_items * sv->ld32 + 255) / 256)), dim3(256), 0, st, n_items, K, sv->ld32,
+                           V.p(), rowb.as<float>(), sv->V32.as<float>());
+        sv->have_v32 = true;
+    }
+    HIPCK(hipStreamSynchronize(st));   // tb_work / rowb go back to the pool
+    return PK_OK;
+}
+
+int serving_score(pk_ctx *ctx, pk_serving *sv, int32_t topk, int32_t filter_seen, int64_t *out_idx, double *out_scores) {
+    hipStream_t st = ctx->stream;
+    const int64_t n_items = sv->n_items, n_users = sv->n_users;
+    const int K = sv->K;
+    if (!out_idx || topk < 1) return fail(ctx, PK_E_INVALID, "pk_score_topk: bad arguments");
+    if (topk > n_items) return fail(ctx, PK_E_INVALID, "kth(=%lld) out of bounds (%lld)", (long long)(n_items - topk), (long long)n_items);
+    Solver S{ctx, st, Dev()};
+    DMat &V = sv->V;
+    Csr &Ts = sv->Ts;
+    const double vmax = sv->vmax;
+    const size_t n1 = (size_t)std::max<int64_t>(Ts.nnz, 1);
     const Range all{0, Ts.plan.n_tasks, 0, Ts.plan.n_long};
     const int64_t *seen_ptr = filter_seen ? Ts.indptr.as<int64_t>() : nullptr;
     const int32_t *seen_idx = filter_seen ? Ts.indices.as<int32_t>() : nullptr;
     Dev out_i((size_t)n_users * topk * 8), out_s((size_t)n_users * topk * 8), flags((size_t)n_users * 4), lst((size_t)std::max<int64_t>(n_users, 1) * 4), cnt(4);
     if (!out_i.p || !out_s.p || !flags.p || !lst.p || !cnt.p) return fail(ctx, PK_E_LAUNCH, "out of device memory (outputs)");
-    const int KC = (K <= 256) ? pk_candidate_capacity(topk) : 0;
+    const int KC = sv->fused ? pk_candidate_capacity(topk) : 0;
     const int n_wg = 128;
     Dev exact_work((size_t)pk_exact_work_bytes(n_wg, n_items));
     if (!exact_work.p) return fail(ctx, PK_E_LAUNCH, "out of device memory (exact rows)");
@@ -884,43 +931,30 @@ extern "C" int pk_score_topk(pk_ctx *ctx, int64_t n_items, int32_t K, const doub
                                    out_i.as<int64_t>(), out_s.as<double>(), exact_work.p));
         HIPCK(hipStreamSynchronize(st));
     } else {
-        // factor images: MFMA fragments, tile bounds, fp32 image with the norm column
-        Dev Vp((size_t)pk_pack_elems(n_items, K) * 4), tile_bound((size_t)((n_items + 31) / 32) * 4), tb_work((size_t)n_items * 4),
-            rowb((size_t)n_items * 4);
-        if (!Vp.p || !tile_bound.p || !tb_work.p || !rowb.p) return fail(ctx, PK_E_LAUNCH, "out of device memory (factor images)");
-        CK(pk_pack_frag_f32(st, n_items, K, V.p(), K, Vp.as<float>()));
-        CK(pk_tile_norm_bound_f32(st, n_items, K, V.p(), K, tb_work.as<float>(), tile_bound.as<float>()));
-        const int Kx_full = ((K + 1 + 3) / 4) * 4;
-        const bool approx = !out_scores && Kx_full <= 256 && T->nonneg;
-        const int Kx = approx ? Kx_full : K;
-        const int ld32 = Kx_full > 16 ? ((Kx_full + 31) / 32) * 32 : (Kx_full <= 4 ? 4 : Kx_full <= 8 ? 8 : 16);
-        Dev V32;
-        if (approx) {
-            if (!V32.alloc((size_t)n_items * ld32 * 4)) return fail(ctx, PK_E_LAUNCH, "out of device memory (fp32 image)");
-            CK(pk_row_norm_bound_f32(st, n_items, K, V.p(), K, rowb.as<float>()));
-            hipLaunchKernelGGL(v32_image_kernel, dim3((unsigned)(((size_t)n_items * ld32 + 255) / 256)), dim3(256), 0, st, n_items, K, ld32,
-                               V.p(), rowb.as<float>(), V32.as<float>());
-        }
+        const bool approx = !out_scores && sv->have_v32;
+        const int Kx = approx ? sv->Kx_full : K, ld32 = sv->ld32;
         DMat Ex(n_users, Kx);
         if (!Ex.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (E)");
-        if (approx) CK(spmm(ctx, Ts, V32.p, PK_VAL_F32, ld32, Kx, Ex.p(), Kx, all));
+        if (approx) CK(spmm(ctx, Ts, sv->V32.p, PK_VAL_F32, ld32, Kx, Ex.p(), Kx, all));
         else CK(spmm(ctx, Ts, V.p(), PK_VAL_F64, K, K, Ex.p(), Kx, all));
         const double *w = approx ? Ex.p() + K : nullptr;
         Dev Ep((size_t)pk_pack_elems(n_users, K) * 4), ub((size_t)n_users * 4);
         if (!Ep.p || !ub.p) return fail(ctx, PK_E_LAUNCH, "out of device memory (E fragments)");
         CK(pk_pack_frag_bound_f32(st, n_users, K, Ex.p(), Kx, Ep.as<float>(), ub.as<float>(), w, approx ? Kx : 0, 1.2e-7));
-        Dev tiles, ntiles;
-        if (filter_seen) {
-            if (!tiles.alloc(n1 * 8) || !ntiles.alloc((size_t)n_users * 4)) return fail(ctx, PK_E_LAUNCH, "out of device memory (seen tiles)");
-            CK(pk_seen_tiles_build(st, n_users, Ts.indptr.as<int64_t>(), Ts.indices.as<int32_t>(), 1, 0, tiles.as<uint64_t>(), ntiles.as<int32_t>()));
+        if (filter_seen && !sv->have_tiles) {
+            if (!sv->tiles.alloc(n1 * 8) || !sv->ntiles.alloc((size_t)n_users * 4)) return fail(ctx, PK_E_LAUNCH, "out of device memory (seen tiles)");
+            CK(pk_seen_tiles_build(st, n_users, Ts.indptr.as<int64_t>(), Ts.indices.as<int32_t>(), 1, 0, sv->tiles.as<uint64_t>(), sv->ntiles.as<int32_t>()));
+            sv->have_tiles = true;
         }
+        const uint64_t *tiles = filter_seen ? sv->tiles.as<uint64_t>() : nullptr;
+        const int32_t *ntiles = filter_seen ? sv->ntiles.as<int32_t>() : nullptr;
         int splits = ((n_users + 31) / 32) * 8 > 2048 ? 1 : pk_score_splits(n_users, KC);
         const int64_t n_pad = ((n_users + 31) / 32) * 32;
         Dev state((size_t)pk_score_state_bytes(n_users, splits)), cs((size_t)splits * n_pad * KC * 4), ci((size_t)splits * n_pad * KC * 4);
         if (!state.p || !cs.p || !ci.p) return fail(ctx, PK_E_LAUNCH, "out of device memory (candidates)");
-        CK(pk_score_candidates_f32(st, n_users, n_items, K, Vp.as<float>(), Ep.as<float>(), seen_ptr, tiles.as<uint64_t>(), ntiles.as<int32_t>(),
-                                   KC, splits, cs.as<float>(), ci.as<int32_t>(), state.p, 0, ub.as<float>(), tile_bound.as<float>()));
-        CK(pk_rescore_topk_rows_f64(st, n_users, nullptr, nullptr, n_users, n_items, K, V.p(), K, approx ? V32.as<float>() : nullptr, approx ? ld32 : 0,
+        CK(pk_score_candidates_f32(st, n_users, n_items, K, sv->Vp.as<float>(), Ep.as<float>(), seen_ptr, tiles, ntiles,
+                                   KC, splits, cs.as<float>(), ci.as<int32_t>(), state.p, 0, ub.as<float>(), sv->tile_bound.as<float>()));
+        CK(pk_rescore_topk_rows_f64(st, n_users, nullptr, nullptr, n_users, n_items, K, V.p(), K, approx ? sv->V32.as<float>() : nullptr, approx ? ld32 : 0,
                                     Ex.p(), Kx, w, approx ? Kx : 0, 0, seen_ptr, KC, splits, cs.as<float>(), ci.as<int32_t>(), topk, vmax,
                                     out_i.as<int64_t>(), out_s.as<double>(), flags.as<int32_t>()));
         if (approx) {
@@ -936,11 +970,66 @@ extern "C" int pk_score_topk(pk_ctx *ctx, int64_t n_items, int32_t K, const doub
                                    out_i.as<int64_t>(), out_s.as<double>(), exact_work.p));
         HIPCK(hipStreamSynchronize(st));   // every temporary above is still alive here
     }
-    std::vector<int64_t> hi((size_t)n_users * topk);
-    CK(S.to_host(out_i.p, hi.data(), hi.size() * 8));
-    for (size_t e = 0; e < hi.size(); ++e) out_idx[e] = hi[e] >= 0 ? (int64_t)inv[(size_t)hi[e]] : -1;   // serving order -> caller's item ids
+    // serving order -> the caller's item ids on the device, then one transfer into the caller's array
+    Dev ext((size_t)n_users * topk * 8);
+    if (!ext.p) return fail(ctx, PK_E_LAUNCH, "out of device memory (outputs)");
+    CK(pk_map_ids_i64(st, n_users * (int64_t)topk, out_i.as<int64_t>(), sv->inv64.as<int64_t>(), n_items, ext.as<int64_t>()));
+    CK(S.to_host(ext.p, out_idx, (size_t)n_users * topk * 8));
     if (out_scores) CK(S.to_host(out_s.p, out_scores, (size_t)n_users * topk * 8));
     return PK_OK;
+}
+
+}  // namespace
+
+extern "C" int pk_serving_create(pk_ctx *ctx, int64_t n_items, int32_t K, const double *V_host, pk_mat *T, pk_serving **out) {
+    if (!ctx || !T || !out) return PK_E_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    PoolScope pool_scope(ctx);
+    (void)hipSetDevice(ctx->device);
+    *out = nullptr;
+    if (n_items != T->A.n_cols) return fail(ctx, PK_E_INVALID, "pk_score_topk: test matrix and item factors disagree on the number of items");
+    if (K < 1 || K > 8192 || !V_host) return fail(ctx, PK_E_INVALID, "pk_score_topk: bad arguments");
+    std::unique_ptr<pk_serving> sv(new pk_serving());
+    const int rc = serving_build(ctx, sv.get(), n_items, K, V_host, T);
+    if (rc != PK_OK) return rc;
+    *out = sv.release();
+    return PK_OK;
+}
+
+extern "C" int pk_serving_score(pk_ctx *ctx, pk_serving *sv, int32_t topk, int32_t filter_seen, int64_t *out_idx, double *out_scores) {
+    if (!ctx || !sv) return PK_E_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    PoolScope pool_scope(ctx);
+    (void)hipSetDevice(ctx->device);
+    return serving_score(ctx, sv, topk, filter_seen, out_idx, out_scores);
+}
+
+extern "C" void pk_serving_free(pk_ctx *ctx, pk_serving *sv) {
+    if (!sv) return;
+    if (ctx) {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        PoolScope pool_scope(ctx);
+        (void)hipStreamSynchronize(ctx->stream);
+        delete sv;
+    } else {
+        delete sv;
+    }
+}
+
+extern "C" int pk_score_topk(pk_ctx *ctx, int64_t n_items, int32_t K, const double *V_host, pk_mat *T, int32_t topk,
+                             int32_t filter_seen, int64_t *out_idx, double *out_scores) {
+    if (!ctx || !T) return PK_E_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    PoolScope pool_scope(ctx);
+    (void)hipSetDevice(ctx->device);
+    if (n_items != T->A.n_cols) return fail(ctx, PK_E_INVALID, "pk_score_topk: test matrix and item factors disagree on the number of items");
+    if (K < 1 || K > 8192 || !V_host || !out_idx || topk < 1) return fail(ctx, PK_E_INVALID, "pk_score_topk: bad arguments");
+    if (topk > n_items) return fail(ctx, PK_E_INVALID, "kth(=%lld) out of bounds (%lld)", (long long)(n_items - topk), (long long)n_items);
+    pk_serving sv;
+    int rc = serving_build(ctx, &sv, n_items, K, V_host, T);
+    if (rc == PK_OK) rc = serving_score(ctx, &sv, topk, filter_seen, out_idx, out_scores);
+    (void)hipStreamSynchronize(ctx->stream);
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -31,6 +31,9 @@ lib.pk_mat_nnz.argtypes, lib.pk_mat_nnz.restype = [vp], i64
 lib.pk_svd_build.argtypes = [vp, vp, i32, i32, f64, i32, C.c_uint64, vp, vp, vp, C.POINTER(Stats)]
 lib.pk_svd_build.restype = C.c_int
 lib.pk_score_topk.argtypes, lib.pk_score_topk.restype = [vp, i64, i32, vp, vp, i32, i32, vp, vp], C.c_int
+lib.pk_serving_create.argtypes, lib.pk_serving_create.restype = [vp, i64, i32, vp, vp, C.POINTER(vp)], C.c_int
+lib.pk_serving_score.argtypes, lib.pk_serving_score.restype = [vp, vp, i32, i32, vp, vp], C.c_int
+lib.pk_serving_free.argtypes, lib.pk_serving_free.restype = [vp, vp], None
 lib.pk_hooi.argtypes = [vp, i64, vp, vp, vp, vp, i32, f64, vp, vp, C.c_uint64, vp, vp, vp, vp, vp, vp]
 lib.pk_hooi.restype = C.c_int
 
@@ -106,6 +109,25 @@ def main():
     sorted_scores = -np.sort(-(E @ Vc.T), axis=1)[:, :61]
     ok = (np.diff(-sorted_scores, axis=1) > 1e-9).all(axis=1)
     assert ok.mean() > 0.9 and np.array_equal(recs3[ok], top[ok])
+    # the serving handle: factors, images and the renamed test rows stay on the device between calls; the test matrix may
+    # be freed once the handle exists; every call returns what pk_score_topk returns
+    T2 = vp()
+    check(ctx, lib.pk_mat_from_csr(ctx, n_users, n_items, S.nnz, ptr(ptr64), ptr(ind), ptr(dat), 1, C.byref(T2)), 'pk_mat_from_csr')
+    sv = vp()
+    check(ctx, lib.pk_serving_create(ctx, n_items, rank, ptr(V), T2, C.byref(sv)), 'pk_serving_create')
+    lib.pk_mat_free(ctx, T2)
+    for rep in range(3):
+        r4 = np.full((n_users, topk), -5, dtype=np.int64)
+        check(ctx, lib.pk_serving_score(ctx, sv, topk, 1, ptr(r4), None), 'pk_serving_score')
+        assert np.array_equal(r4, recs), rep
+    r5 = np.empty_like(recs); sc5 = np.empty((n_users, topk))
+    check(ctx, lib.pk_serving_score(ctx, sv, topk, 1, ptr(r5), ptr(sc5)), 'pk_serving_score(scores)')
+    assert np.array_equal(r5, recs2) and np.array_equal(sc5, sc)
+    r6 = np.empty((n_users, 60), dtype=np.int64)
+    check(ctx, lib.pk_serving_score(ctx, sv, 60, 0, ptr(r6), None), 'pk_serving_score(top-60)')
+    assert np.array_equal(r6, recs3)
+    assert lib.pk_serving_score(ctx, sv, n_items + 1, 1, ptr(r6), None) != 0 and b'out of bounds' in lib.pk_ctx_error(ctx)
+    lib.pk_serving_free(ctx, sv)
     # errors are codes + messages, not crashes
     bad = np.empty((n_users, topk), dtype=np.int64)
     rc = lib.pk_score_topk(ctx, n_items + 1, rank, ptr(V), T, topk, 1, ptr(bad), None)
