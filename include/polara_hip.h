@@ -141,6 +141,10 @@ int pk_csr_rows_by_length(void *stream, int64_t n_rows, int64_t nnz, const int64
                           int32_t *indices_out_dev, void *values_out_dev, void *work_dev);
 /* counts[k] = number of keys equal to k (item popularity: the internal item order of the device path) */
 int pk_count_i32(void *stream, int64_t n, const int32_t *keys_dev, int64_t n_bins, int32_t *counts_dev);
+/* vals_out[p] = (row_scale[row of p] * vals[p]) * col_scale[indices[p]] (fp64): the diagonal rescaling A' = D_r A D_c of
+ * ScaledMatrixMixin (models.py:864-895, preprocessing/matrices.py:71-93) applied to the device CSR. */
+int pk_csr_scale_f64(void *stream, int64_t n_rows, const int64_t *indptr_dev, const int32_t *indices_dev, const void *vals_dev,
+                     int val_kind, const double *row_scale_dev, const double *col_scale_dev, double *vals_out_dev);
 /* Wave-task plan of a CSR (one 64-lane wave per task, rows longer than `split` cut into near-equal tasks whose
  * partial results are added in slot order): phase 1 leaves counts_dev[0..2] = (tasks, long rows, slots), phase 2
  * fills the arrays sized from them.  row_first_task / row_long_index (int64[n_rows + 1], optional) = first task of

@@ -37,6 +37,7 @@ PROTOTYPES = {
     'pk_csr_rows_by_length_work_bytes': (_i64, [_i64]),
     'pk_csr_rows_by_length': (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     'pk_count_i32': (C.c_int, [_vp, _i64, _vp, _i64, _vp]),
+    'pk_csr_scale_f64': (C.c_int, [_vp, _i64, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp]),
     'pk_row_plan_work_bytes': (_i64, [_i64]),
     'pk_row_plan_count': (C.c_int, [_vp, _i64, _vp, _i32, _vp, _vp]),
     'pk_row_plan_fill': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -630,6 +630,39 @@ extern "C" int pk_count_i32(void *stream, int64_t n, const int32_t *keys_dev, in
     return PK_OK;
 }
 
+// -------- diagonal scaling of a CSR: out = D_r A D_c (ScaledMatrixMixin, models.py:864-895; preprocessing/matrices.py:71-93) ----
+// One wave per row: out[p] = (rs[row] * vals[p]) * cs[indices[p]] in fp64 — the association of the reference's
+// `diags(rs) @ A @ diags(cs)` evaluated left to right.
+template <typename VT>
+__global__ __launch_bounds__(256) void csr_scale_kernel(int64_t n_rows, const int64_t *__restrict__ indptr,
+                                                        const int32_t *__restrict__ indices, const VT *__restrict__ vals,
+                                                        const double *__restrict__ rs, const double *__restrict__ cs,
+                                                        double *__restrict__ out) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const int lane = threadIdx.x & 63;
+    const double r = rs[row];
+    for (int64_t p = indptr[row] + lane; p < indptr[row + 1]; p += 64) out[p] = (r * (double)vals[p]) * cs[indices[p]];
+}
+
+extern "C" int pk_csr_scale_f64(void *stream, int64_t n_rows, const int64_t *indptr_dev, const int32_t *indices_dev,
+                                const void *vals_dev, int val_kind, const double *row_scale_dev, const double *col_scale_dev,
+                                double *vals_out_dev) {
+    PK_REQUIRE(n_rows >= 0 && indptr_dev && row_scale_dev && col_scale_dev, "pk_csr_scale_f64: bad arguments");
+    PK_REQUIRE(val_kind == PK_VAL_F32 || val_kind == PK_VAL_F64, "pk_csr_scale_f64: bad val_kind %d", val_kind);
+    if (n_rows == 0) return PK_OK;
+    hipStream_t st = pk_stream(stream);
+    const dim3 grid((unsigned)pk_ceil_div(n_rows, 4)), block(256);
+    if (val_kind == PK_VAL_F32)
+        hipLaunchKernelGGL(csr_scale_kernel<float>, grid, block, 0, st, n_rows, indptr_dev, indices_dev,
+                           static_cast<const float *>(vals_dev), row_scale_dev, col_scale_dev, vals_out_dev);
+    else
+        hipLaunchKernelGGL(csr_scale_kernel<double>, grid, block, 0, st, n_rows, indptr_dev, indices_dev,
+                           static_cast<const double *>(vals_dev), row_scale_dev, col_scale_dev, vals_out_dev);
+    PK_CHECK_LAUNCH("csr_scale_kernel");
+    return PK_OK;
+}
+
 // -------- wave-task plan of a CSR on the device (polara_amd/csr.py: build_row_tasks restated) --------------------------
 // Every row gets max(1, ceil(nnz / split)) near-equal tasks; rows with more than one task ("long") write partial
 // results to consecutive slots.

@@ -742,9 +742,25 @@ class ScaledMatrixMixin:
         return csr if m.format == 'csr' else csr.asformat(m.format)
 
     def _training_device_csr(self):
-        indptr, indices, values, shp = self._training_csr(dtype=np.float64)
-        self._item_rank, self._item_inv = popularity_order(None, shp[1], counts=self._item_counts(indices, shp[1]))
-        return self.ops.csr_relabel_cols(self.ops.csr(indptr, indices, values, shp), self._item_rank)
+        ops = self.ops
+        if not hasattr(ops, 'csr_scale'):
+            indptr, indices, values, shp = self._training_csr(dtype=np.float64)
+            self._item_rank, self._item_inv = popularity_order(None, shp[1], counts=self._item_counts(indices, shp[1]))
+            return ops.csr_relabel_cols(ops.csr(indptr, indices, values, shp), self._item_rank)
+        # device path: the unscaled matrix through the ingest kernels (COO -> CSR, counts, popularity order), then the two
+        # diagonals — vectors of n_users / n_items entries, computed on the host exactly as `_scale_values` does — applied
+        # by pk_csr_scale_f64 (the host version sorts and scales 2e7 entries in NumPy: seconds against milliseconds)
+        A = super()._training_device_csr()
+        row_nnz = np.diff(ops.to_host(A.indptr)).astype(np.float64)
+        col_nnz = ops.item_counts(A)
+        if self._presharded() and self.comm.world > 1:
+            col_nnz = ops.to_host(self.comm.allreduce(ops.to_device(col_nnz)))
+        col_nnz = col_nnz.astype(np.float64)
+        rs = np.ones_like(row_nnz)
+        cs = np.ones_like(col_nnz)
+        np.power(np.sqrt(row_nnz), self.row_scaling - 1, where=row_nnz != 0, out=rs)
+        np.power(np.sqrt(col_nnz), self.col_scaling - 1, where=col_nnz != 0, out=cs)
+        return ops.csr_scale(A, rs, cs)
 
 
 class ScaledSVD(ScaledMatrixMixin, SVDModel):

@@ -393,6 +393,19 @@ class HipOps:
         new.sorted_cols = True
         return new
 
+    def csr_scale(self, A, row_scale, col_scale):
+        """D_r A D_c with the diagonals given as host (or device) fp64 vectors: same pattern and plans, fp64 values
+        (pk_csr_scale_f64) — ScaledMatrixMixin's rescaling of the training matrix on the device."""
+        rs = torch.as_tensor(np.ascontiguousarray(row_scale, dtype=np.float64)).to(self.device) if not torch.is_tensor(row_scale) else row_scale
+        cs = torch.as_tensor(np.ascontiguousarray(col_scale, dtype=np.float64)).to(self.device) if not torch.is_tensor(col_scale) else col_scale
+        assert rs.numel() == A.shape[0] and cs.numel() == A.shape[1]
+        out = torch.empty(max(int(A.indices.numel()), 1), dtype=torch.float64, device=self.device)[:A.indices.numel()]
+        _lib.check(self.lib.pk_csr_scale_f64(self.stream(), A.shape[0], _ptr(A.indptr), _ptr(A.indices), _ptr(A.values), A.val_kind,
+                                             _ptr(rs), _ptr(cs), _ptr(out)), 'pk_csr_scale_f64')
+        new = A.with_columns(A.indices, out)
+        new.val_kind = _lib.PK_VAL_F64
+        return new
+
     def csr_from_coo(self, rows, cols, vals, shape, split=SPLIT_NNZ):
         """COO triplets (host arrays) -> canonical DeviceCSR built ON DEVICE (pk_coo_to_csr: one stable radix sort of
         the 64-bit keys row * n_cols + col, duplicates summed in their original order — what

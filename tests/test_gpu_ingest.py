@@ -205,3 +205,39 @@ def test_rows_by_length_is_a_stable_descending_order(hip_ops):
     b, sb = scoring.recommend(ops, F, A, 10, True, return_scores=True, order_users=False)
     assert torch.equal(a, b) and torch.equal(sa, sb)
     assert torch.equal(scoring.recommend(ops, F, A, 10, True), a)
+
+
+@pytest.mark.parametrize('vdtype', [np.float32, np.float64])
+def test_diagonal_scaling_and_mode_plan_match_numpy(hip_ops, vdtype):
+    """pk_csr_scale_f64 (ScaledMatrixMixin's D_r A D_c, bit-equal to the left-to-right NumPy product) and
+    HipOps.mode_plan (a tensor's entries ordered by one mode on the device: same stable order, row pointers and index
+    columns as the host's argsort(kind='stable'))."""
+    ops = hip_ops
+    n_rows, n_cols = 7000, 900
+    indptr, indices, values = _rand_csr(5, n_rows, n_cols, 30)
+    values = values.astype(vdtype)
+    A = ops.csr(indptr, indices, values, (n_rows, n_cols))
+    rng = np.random.RandomState(1)
+    rs, cs = rng.rand(n_rows) + 0.5, rng.rand(n_cols) + 0.5
+    B = ops.csr_scale(A, rs, cs)
+    rows = np.repeat(np.arange(n_rows), np.diff(indptr))
+    want = (rs[rows] * values.astype(np.float64)) * cs[indices]
+    assert B.values.dtype == torch.float64 and np.array_equal(ops.to_host(B.values).view(np.int64), want.view(np.int64))
+    assert torch.equal(B.indptr, A.indptr) and torch.equal(B.indices, A.indices)
+    X = rng.randn(n_cols, 8)
+    ref = sps.csr_matrix((want, indices, indptr), shape=(n_rows, n_cols)) @ X
+    assert np.allclose(ops.to_host(ops.spmm(B, ops.to_device(X))), ref, rtol=1e-12, atol=1e-12)
+    # mode plans
+    nnz, shape = 50000, (300, 47, 5)
+    idx = np.stack([rng.randint(0, s, nnz) for s in shape], 1).astype(np.int64)
+    idx[:4000, 1] = 3                                              # a long row of mode 1
+    idx_dev = torch.from_numpy(idx).to(ops.device)
+    for mode0, mu, mv in ((0, 2, 1), (1, 2, 0), (2, 1, 0)):
+        plan, iu, iv, order = ops.mode_plan(idx_dev, mode0, mu, mv, shape[mode0], split=256)
+        want_order = np.argsort(idx[:, mode0], kind='stable')
+        assert np.array_equal(ops.to_host(order), want_order)
+        assert np.array_equal(ops.to_host(iu), idx[want_order, mu]) and np.array_equal(ops.to_host(iv), idx[want_order, mv])
+        host = build_row_tasks(np.r_[0, np.cumsum(np.bincount(idx[:, mode0], minlength=shape[mode0]))].astype(np.int64), split=256)
+        assert plan['n_tasks'] == len(host['task_row']) and plan['n_long'] == len(host['long_row'])
+        for k in ('task_row', 'task_begin', 'task_end', 'task_slot', 'long_row', 'long_slot_begin', 'long_slot_end'):
+            assert np.array_equal(ops.to_host(plan[k])[:len(host[k])], host[k]), (mode0, k)
