@@ -407,3 +407,53 @@ def test_passes_from_several_host_threads_share_one_ops_object(hip_ops):
     for j in range(len(parts)):
         for r in range(6):
             assert torch.equal(got[j][r], want[j]), (j, r)
+
+
+def test_head_batch_and_device_id_renaming_change_nothing(hip_ops):
+    """(1) `head_users`: the heaviest users of an activity-ordered pass as a batch of their own (item splits, second
+    stream) return the lists of the single pass; (2) `HipOps.ids_to_host`: the renaming to external ids on the device
+    (pk_map_ids_i64) + pinned transfer equals the NumPy renaming, -1 padding included."""
+    import torch
+    from polara_amd import scoring
+    from polara_amd.solver import svd_topk
+    ops = hip_ops
+    c = csr_to_numpy(planted_csr(40000, 1500, 40, 12, seed=31, min_items=5, max_items=600))
+    A = ops.csr(c['indptr'], c['indices'], c['values'], c['shape'])
+    _, _, V, st = svd_topk(ops, A, 12)
+    F = scoring.FactorImage(ops, V)
+    want = scoring.recommend(ops, F, A, 10, True, head_users=0)
+    for head in (1024, 4096, 9984):
+        assert torch.equal(scoring.recommend(ops, F, A, 10, True, head_users=head), want), head
+    # a head larger than a quarter of the users is ignored
+    assert torch.equal(scoring.recommend(ops, F, A, 10, True, head_users=20000), want)
+    rng = np.random.RandomState(0)
+    table = rng.permutation(1500).astype(np.int64) * 7 + 3
+    recs = want.clone()
+    recs[::97, -2:] = -1
+    host = ops.ids_to_host(recs, table)
+    r = recs.cpu().numpy()
+    assert host.dtype == np.int64 and np.array_equal(host, np.where(r >= 0, table[np.maximum(r, 0)], -1))
+    assert np.array_equal(ops.ids_to_host(recs), r)
+    table2 = table[::-1].copy()                                    # another table: the cached device copy is replaced
+    assert np.array_equal(ops.ids_to_host(recs, table2), np.where(r >= 0, table2[np.maximum(r, 0)], -1))
+
+
+def test_scaled_svd_device_scaling_equals_the_host_formula(hip_ops):
+    """ScaledMatrixMixin on the device (pk_csr_scale_f64 after the device ingest) against its own host restatement
+    (`_scale_values` on the canonical CSR): the same singular values and lists."""
+    from polara_amd.models import ScaledSVD
+    u, i, v = csr_to_coo_triplets(planted_csr(3000, 500, 30, 8, seed=13, min_items=5, max_items=200))
+    d = ArrayData((u, i, v), n_users=3000, n_items=500, test=(u, i, v))
+    m = ScaledSVD(d, ops=hip_ops)
+    m.verbose = False
+    m.rank, m.topk, m.col_scaling, m.row_scaling = 8, 10, 0.3, 0.8
+    m.build()
+    sig_dev, recs_dev = m.factors['singular_values'].copy(), m.get_recommendations().copy()
+    S = m.get_training_matrix().astype(np.float64)                 # the host restatement of the scaled matrix
+    s_ref = np.linalg.svd(S.toarray(), compute_uv=False)[:8]
+    assert np.allclose(sig_dev, s_ref, rtol=1e-10)
+    V = np.ascontiguousarray(m.factors[d.fields.itemid])
+    c = csr_to_numpy(planted_csr(3000, 500, 30, 8, seed=13, min_items=5, max_items=200))
+    from test_gpu_configs import _oracle_lists
+    ref, clear = _oracle_lists(c, V, np.arange(3000), 10)
+    assert clear.mean() > 0.9 and np.array_equal(recs_dev[clear], ref[clear])
