@@ -493,6 +493,7 @@ extern "C" int pk_fold_rows_f64(void *stream, int64_t cap, const int32_t *list_d
 #define PK_EXACT_CHUNK 1024
 #define PK_EXACT_TOPK_MAX 256
 #define PK_EXACT_CHUNKS_MAX 8192
+#define PK_EXACT_FAST_ROWS 1024
 static int64_t exact_per_row(int64_t n_items) {
     // one-workgroup kernel: fp64 score + 1 class byte per item; chunk kernels: per chunk of PK_EXACT_CHUNK items at most
     // min(PK_EXACT_TOPK_MAX, n_items) candidates of 13 bytes (score, index, class); padded to 16 bytes
@@ -791,7 +792,7 @@ static int exact_launch(hipStream_t st, int32_t n_rows_host, const int32_t *n_ro
                         int32_t topk, int64_t *out_idx_dev, double *out_score_dev, unsigned char *work, int32_t n_wg_slow) {
     const int64_t per_row = exact_per_row(n_items);
     const int64_t n_chunks = pk_ceil_div(n_items, PK_EXACT_CHUNK);
-    const bool fast = topk <= PK_EXACT_TOPK_MAX && n_chunks <= PK_EXACT_CHUNKS_MAX && (size_t)K * 8 <= 48 * 1024;
+    const bool fast = row_slots > 0 && topk <= PK_EXACT_TOPK_MAX && n_chunks <= PK_EXACT_CHUNKS_MAX && (size_t)K * 8 <= 48 * 1024;
     int32_t first_slow = 0;
     if (fast) {
         const int ksel = (int)(topk < n_items ? topk : n_items);   // <= PK_EXACT_TOPK_MAX: what exact_per_row provides for
@@ -824,8 +825,12 @@ extern "C" int pk_score_exact_rows_f64(void *stream, int32_t n_rows, const int32
     PK_REQUIRE(n_rows >= 0 && n_items >= 1 && K >= 1 && K <= 8192 && topk >= 1, "pk_score_exact_rows_f64: bad sizes");
     PK_REQUIRE(ldv >= K && lde >= K && work_dev, "pk_score_exact_rows_f64: bad arguments");
     if (n_rows == 0) return PK_OK;
-    // the work buffer has a row slot per listed user (pk_exact_work_bytes(n_rows, n_items))
-    return exact_launch(pk_stream(stream), n_rows, nullptr, n_rows, rows_dev, 0, n_items, K, V_dev, ldv, E_dev, lde,
+    // the work buffer has a row slot per listed user (pk_exact_work_bytes(n_rows, n_items)).  The chunk kernels select
+    // min(topk, chunk) entries per (user, chunk) one at a time: they win when a FEW users need the whole chip (the flagged
+    // users of a pass), and lose by an order of magnitude when every user of a large set comes this way (topk > 52 or
+    // rank > 256 for 1e5 users: there the one-workgroup kernel already fills the chip with users)
+    const int32_t fast_rows = n_rows <= PK_EXACT_FAST_ROWS ? n_rows : 0;
+    return exact_launch(pk_stream(stream), n_rows, nullptr, fast_rows, rows_dev, 0, n_items, K, V_dev, ldv, E_dev, lde,
                         seen_ptr_dev, seen_idx_dev, topk, out_idx_dev, out_score_dev, static_cast<unsigned char *>(work_dev),
                         n_rows);
 }
