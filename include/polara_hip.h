@@ -243,7 +243,16 @@ int pk_score_candidates_f32(void *stream, int64_t n_users, int64_t n_items, int3
                             void *state_dev /* pk_score_state_bytes(n_users, splits) */,
                             int32_t tiles_per_chunk /* 0 = auto */,
                             const float *user_bound_dev /* [n_users] or NULL */,
-                            const float *tile_bound_dev /* [ceil(n_items/32)] or NULL */);
+                            const float *tile_bound_dev /* [ceil(n_items/32)] or NULL */,
+                            const uint32_t *seen_dense_dev, const int32_t *seen_skip_dev,
+                            int32_t dense_tiles /* pk_seen_dense_build output, or NULL, NULL, 0: the stream serves every tile */);
+/* Dense seen masks for the first dense_tiles tiles of the catalogue — where the sweep spends its time, and where a user
+ * has a record in nearly every tile: dense_dev[(u / 32 * dense_tiles + tile) * 32 + u % 32] = the user's 32-bit mask in
+ * that tile (one coalesced 128-byte load per tile and wave instead of a cursor walk with a scattered 8-byte load per
+ * lane), skip_dev[u] = the user's stream records below dense_tiles.  dense_dev: pk_seen_dense_bytes(n_users, dense_tiles). */
+int64_t pk_seen_dense_bytes(int64_t n_users, int32_t dense_tiles);
+int pk_seen_dense_build(void *stream, int64_t n_users, const int64_t *seen_ptr_dev, const uint64_t *seen_tiles_dev,
+                        const int32_t *seen_ntiles_dev, int32_t dense_tiles, uint32_t *dense_dev, int32_t *skip_dev);
 /* launches pk_score_candidates_f32 issues for these arguments (fixed item chunks; doubling chunks when the
  * pruning bounds are passed) */
 int32_t pk_score_chunk_launches(int64_t n_items, int32_t K, int32_t splits, int32_t tiles_per_chunk, int32_t pruned);

@@ -953,7 +953,7 @@ int serving_score(pk_ctx *ctx, pk_serving *sv, int32_t topk, int32_t filter_seen
         Dev state((size_t)pk_score_state_bytes(n_users, splits)), cs((size_t)splits * n_pad * KC * 4), ci((size_t)splits * n_pad * KC * 4);
         if (!state.p || !cs.p || !ci.p) return fail(ctx, PK_E_LAUNCH, "out of device memory (candidates)");
         CK(pk_score_candidates_f32(st, n_users, n_items, K, sv->Vp.as<float>(), Ep.as<float>(), seen_ptr, tiles, ntiles,
-                                   KC, splits, cs.as<float>(), ci.as<int32_t>(), state.p, 0, ub.as<float>(), sv->tile_bound.as<float>()));
+                                   KC, splits, cs.as<float>(), ci.as<int32_t>(), state.p, 0, ub.as<float>(), sv->tile_bound.as<float>(), nullptr, nullptr, 0));
         CK(pk_rescore_topk_rows_f64(st, n_users, nullptr, nullptr, n_users, n_items, K, V.p(), K, approx ? sv->V32.as<float>() : nullptr, approx ? ld32 : 0,
                                     Ex.p(), Kx, w, approx ? Kx : 0, 0, seen_ptr, KC, splits, cs.as<float>(), ci.as<int32_t>(), topk, vmax,
                                     out_i.as<int64_t>(), out_s.as<double>(), flags.as<int32_t>()));

@@ -177,6 +177,16 @@ __host__ __device__ constexpr size_t pk_score_lds_bytes(int nstep, int kc) {
     return (size_t)(4 * pk_ring_rows(kc) * 64 + (pk_top_in_lds(nstep, kc) ? 4 * 32 * kc : 1)) * sizeof(uint2);
 }
 
+// Dense seen masks of the head of the catalogue (pk_seen_dense_build): mask[(group * tiles + tile) * 32 + user % 32] =
+// the 32-bit seen mask of that user in that tile for tile < tiles, ONE coalesced 128-byte load per tile-wave that is
+// requested a tile ahead with the V fragments; skip[user] = the records of the user's seen-tile stream that lie in
+// those tiles (the stream cursor starts behind them).  tiles == 0: the stream serves every tile.
+struct SeenDense {
+    const unsigned *mask;
+    const int32_t *skip;
+    int tiles;
+};
+
 template <int NSTEP, int KC, bool STRIDED>
 __global__ __launch_bounds__(256) void score_candidates_kernel(
     const float4 *__restrict__ Vp, const float4 *__restrict__ Ep, int64_t n_users, int n_items,
@@ -185,7 +195,7 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
     const int32_t *__restrict__ seen_ntiles,
     float *__restrict__ cand_score, int32_t *__restrict__ cand_idx,
     LaneState *__restrict__ st_lane, uint2 *__restrict__ st_ring,
-    const float *__restrict__ user_bound, const float *__restrict__ tile_bound, int ablate) {
+    const float *__restrict__ user_bound, const float *__restrict__ tile_bound, int ablate, SeenDense dense) {
     constexpr int KQ = 2 * NSTEP;   // 16-byte groups per lane and tile: (hi, lo) x 8 bf16 for every 16-wide k-step
     // KC == 16: rings of 8, so that a user's list + both rings are 32 entries and TWO users are merged
     // per flush, one in each half of the wave (15 sort stages per two users instead of 21 per user).
@@ -257,6 +267,9 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
     }
     LaneState *my_state = st_lane + slot * 64 + lane;
     uint2 *my_ring_state = st_ring + slot * (RING * 64);
+    const int dense_tiles = (seen_ptr != nullptr) ? dense.tiles : 0;
+    const unsigned *dense_row = dense_tiles ? dense.mask + ((int64_t)group * dense_tiles) * 32 + ul : nullptr;
+    if (first && has_seen && dense_tiles) sp += dense.skip[user];   // those tiles are served by the dense masks
     if (first) {
         if (has_seen && t_lo > 0) {
             // skip the records before this split's first tile: lower_bound(tile >= t_lo)
@@ -487,10 +500,16 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
     // of its use.  (The first version walked the raw item list: in the popular head of the catalogue
     // a user has several seen items per tile, every one a dependent load — the sweep was latency
     // bound there once pruning had cut it down to the head.)
+    unsigned m_dense = 0;        // dense mask of the CURRENT tile (requested one tile ahead, see the loop)
     auto walk_mask = [&](int tile) -> unsigned {
         const int j0 = tile * 32, jend = j0 + 32;
         unsigned mask = 0;
         if (ablate & 1) return 0u;   // tuning only: skip the seen-list walk
+        if (tile < dense_tiles) {
+            mask = m_dense;
+            if (jend > n_items) mask |= ~0u << (n_items - j0);
+            return mask;
+        }
         if (S > 1) {
             // records of tiles that belong to the other splits lie between two of mine: step over them
             // (wave-uniform test; the three-record prefetch window keeps the common one-or-two steps cheap)
@@ -557,6 +576,7 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
         // 3.29 ms; four (120 VGPRs, no spill) is what the register allocator picks unprompted.
         float4 a_nxt[KQ];
         load_frags((tile_begin < n_tiles) ? tile_begin : 0, a_nxt);
+        unsigned m_nxt = (tile_begin < dense_tiles) ? dense_row[(int64_t)tile_begin * 32] : 0u;
         float tb = prune ? tile_bound[(tile_begin < n_tiles) ? tile_begin : 0] : 0.0f;
         PROF_ADD(4, prof_k0);
         int step = 0;
@@ -582,6 +602,8 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
 #pragma unroll
             for (int q = 0; q < KQ; ++q) a[q] = a_nxt[q];
             load_frags((tile + S < tile_end) ? tile + S : tile, a_nxt);
+            m_dense = m_nxt;
+            m_nxt = (tile + S < dense_tiles) ? dense_row[(int64_t)(tile + S) * 32] : 0u;
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -920,6 +942,54 @@ __global__ __launch_bounds__(256) void seen_tiles_kernel(int64_t n_users, const 
 
 extern "C" int32_t pk_seen_tiles_max_unsorted_row(void) { return PK_SEEN_CAP; }
 
+// Dense masks of the first `dense_tiles` tiles from the seen-tile stream: one wave per user copies the masks of its
+// records below dense_tiles into the [group][tile][32 users] array (every (user, tile) has at most one record: plain
+// stores) and counts them.  The array is zeroed here; built once per test matrix like the stream itself.
+__global__ __launch_bounds__(256) void seen_dense_kernel(int64_t n_users, const int64_t *__restrict__ seen_ptr,
+                                                         const unsigned long long *__restrict__ tiles,
+                                                         const int32_t *__restrict__ ntiles, int dense_tiles,
+                                                         unsigned *__restrict__ dense, int32_t *__restrict__ skip) {
+    const int lane = threadIdx.x & 63;
+    const int64_t user = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (user >= n_users) return;
+    const int64_t p0 = seen_ptr[user];
+    const int n = ntiles[user];
+    unsigned *row = dense + ((user >> 5) * dense_tiles) * 32 + (user & 31);
+    int cnt = 0;
+    for (int i = lane; i < n; i += 64) {
+        const unsigned long long rec = tiles[p0 + i];
+        const unsigned t = (unsigned)(rec >> 32);
+        if (t < (unsigned)dense_tiles) {
+            row[(int64_t)t * 32] = (unsigned)rec;
+            ++cnt;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if (lane == 0) skip[user] = cnt;
+}
+
+extern "C" int64_t pk_seen_dense_bytes(int64_t n_users, int32_t dense_tiles) {
+    return pk_ceil_div(n_users, 32) * (int64_t)dense_tiles * 32 * 4;
+}
+
+extern "C" int pk_seen_dense_build(void *stream, int64_t n_users, const int64_t *seen_ptr_dev, const uint64_t *seen_tiles_dev,
+                                   const int32_t *seen_ntiles_dev, int32_t dense_tiles, uint32_t *dense_dev, int32_t *skip_dev) {
+    PK_REQUIRE(n_users >= 1 && dense_tiles >= 1 && seen_ptr_dev && seen_ntiles_dev && dense_dev && skip_dev,
+               "pk_seen_dense_build: bad arguments");
+    hipStream_t st = pk_stream(stream);
+    const hipError_t e = hipMemsetAsync(dense_dev, 0, (size_t)pk_seen_dense_bytes(n_users, dense_tiles), st);
+    if (e != hipSuccess) {
+        pk_set_error("pk_seen_dense_build: memset: %s", hipGetErrorString(e));
+        return PK_E_LAUNCH;
+    }
+    hipLaunchKernelGGL(seen_dense_kernel, dim3((unsigned)pk_ceil_div(n_users, 4)), dim3(256), 0, st, n_users, seen_ptr_dev,
+                       reinterpret_cast<const unsigned long long *>(seen_tiles_dev), seen_ntiles_dev, dense_tiles, dense_dev,
+                       skip_dev);
+    PK_CHECK_LAUNCH("seen_dense_kernel");
+    return PK_OK;
+}
+
 extern "C" int pk_seen_tiles_build(void *stream, int64_t n_users, const int64_t *seen_ptr_dev,
                                    const int32_t *seen_idx_dev, int32_t rows_sorted, int64_t max_row_len,
                                    uint64_t *tiles_dev, int32_t *ntiles_dev) {
@@ -1019,7 +1089,8 @@ static int launch_candidates_n(hipStream_t st, int KC, int ablate, dim3 grid, co
                                int64_t n_users, int n_items, int n_tiles, int split_tiles, int tiles_per_chunk,
                                const int64_t *seen_ptr, const unsigned long long *seen_tiles,
                                const int32_t *seen_ntiles, float *cs, int32_t *ci,
-                               LaneState *st_lane, uint2 *st_ring, const float *user_bound, const float *tile_bound) {
+                               LaneState *st_lane, uint2 *st_ring, const float *user_bound, const float *tile_bound,
+                               SeenDense dense) {
     // Item chunks: tiles_per_chunk each while every group sweeps (the chunk's packed image stays in L2);
     // with pruning, groups leave the sweep early, so the chunks DOUBLE from launch to launch — the catalogue
     // is covered in O(log) launches and the few groups still sweeping late (low bandwidth demand) are not
@@ -1047,11 +1118,11 @@ static int launch_candidates_n(hipStream_t st, int KC, int ablate, dim3 grid, co
     if (grid.y > 1)                                                                                             \
         hipLaunchKernelGGL((score_candidates_kernel<NSTEP, KCV, true>), grid, dim3(256), pk_score_lds_bytes(NSTEP, KCV), st, Vp, Ep, n_users, \
                            n_items, n_tiles, split_tiles, chunk_begin, chunk_tiles, seen_ptr, seen_tiles, seen_ntiles, cs, ci, st_lane, st_ring,  \
-                           user_bound, tile_bound, ablate);                                                     \
+                           user_bound, tile_bound, ablate, dense);                                              \
     else                                                                                                        \
         hipLaunchKernelGGL((score_candidates_kernel<NSTEP, KCV, false>), grid, dim3(256), pk_score_lds_bytes(NSTEP, KCV), st, Vp, Ep, n_users, \
                            n_items, n_tiles, split_tiles, chunk_begin, chunk_tiles, seen_ptr, seen_tiles, seen_ntiles, cs, ci, st_lane, st_ring,  \
-                           user_bound, tile_bound, ablate)
+                           user_bound, tile_bound, ablate, dense)
 #ifdef PK_FAST_BUILD
         if (KC != 16) return PK_E_UNSUPPORTED;
         PK_LAUNCH(16);
@@ -1119,8 +1190,11 @@ extern "C" int pk_score_candidates_f32(void *stream, int64_t n_users, int64_t n_
                                        int32_t KC, int32_t splits,
                                        float *cand_score_dev, int32_t *cand_idx_dev, void *state_dev,
                                        int32_t tiles_per_chunk, const float *user_bound_dev,
-                                       const float *tile_bound_dev) {
+                                       const float *tile_bound_dev, const uint32_t *seen_dense_dev,
+                                       const int32_t *seen_skip_dev, int32_t dense_tiles) {
     PK_REQUIRE(n_users >= 1 && n_items >= 1 && n_items < 0x7fffff00LL, "pk_score_candidates_f32: bad sizes");
+    PK_REQUIRE(dense_tiles >= 0 && (dense_tiles == 0 || (seen_dense_dev && seen_skip_dev && seen_ptr_dev)),
+               "pk_score_candidates_f32: dense seen masks need seen_dense, seen_skip and the seen-tile stream");
     const int kq = pk_pack_kq(K);
     const int nstep = pk_nstep(K);
     PK_REQUIRE(kq > 0, "pk_score_candidates_f32: K=%d unsupported (K <= 256)", K);
@@ -1152,10 +1226,11 @@ extern "C" int pk_score_candidates_f32(void *stream, int64_t n_users, int64_t n_
                                     split_tiles, tiles_per_chunk, seen_ptr_dev,                                   \
                                     reinterpret_cast<const unsigned long long *>(seen_tiles_dev), seen_ntiles_dev, \
                                     cand_score_dev, cand_idx_dev,                                              \
-                                    st_lane, st_ring, user_bound_dev, tile_bound_dev);                         \
+                                    st_lane, st_ring, user_bound_dev, tile_bound_dev, dense);                  \
         break;
     const char *abl_env = getenv("PK_SCORE_ABLATE");   // kernel-tuning knob, never set in production
     const int ablate = abl_env ? atoi(abl_env) : 0;
+    SeenDense dense{seen_dense_dev, seen_skip_dev, seen_ptr_dev ? dense_tiles : 0};
     switch (nstep) {
 #ifdef PK_FAST_BUILD
         PK_N_CASE(4)

@@ -49,6 +49,7 @@ class DeviceCSR:
         self._partial = None
         self._T = None
         self._seen_tiles = None
+        self._seen_dense = None
         self.sorted_cols = True     # canonical CSR; False after a bare column renaming (csr_relabel_cols(sort=False))
         self._nnz = nnz
         self._plan = None
@@ -109,6 +110,27 @@ class DeviceCSR:
                                                    rows_sorted=self.sorted_cols)
         return self._seen_tiles
 
+    def seen_dense(self):
+        """(dense masks, skip counts, dense_tiles) of this matrix's rows for the head of the catalogue, or None: the
+        seen-tile stream unrolled into one 32-bit mask per (user, tile) for the first tiles — where the candidate sweep
+        spends its time (groups leave it after 70-270 of 836 tiles on ML-20M-shaped) and where nearly every tile holds
+        a record.  At most 256 tiles and 512 MB; PK_SEEN_DENSE_TILES overrides (0: off).  Cached like the stream."""
+        if getattr(self, '_seen_dense', None) is None:
+            import os
+            n_tiles = -(-self.shape[1] // 32)
+            groups = -(-self.shape[0] // 32)
+            env = os.environ.get('PK_SEEN_DENSE_TILES')
+            dt = min(n_tiles, 256) if env is None else min(n_tiles, int(env))
+            while dt > 32 and groups * dt * 128 > (512 << 20):
+                dt //= 2
+            if dt <= 0 or self.shape[0] == 0:
+                self._seen_dense = (None,)
+            else:
+                tiles, ntiles = self.seen_tiles()
+                dense, skip = self.ops.seen_dense(self.indptr, tiles, ntiles, self.shape[0], dt)
+                self._seen_dense = (dense, skip, dt)
+        return None if self._seen_dense[0] is None else self._seen_dense
+
     @property
     def T(self):
         """CSR of A^T (= CSC of A), built on the device by pk_csr_transpose (a stable radix sort by column)."""
@@ -165,6 +187,7 @@ class DeviceCSR:
         new._Tb = None
         new._by_activity = None
         new._seen_tiles = None
+        new._seen_dense = None
         return new
 
 
@@ -681,8 +704,17 @@ class HipOps:
                        'pk_seen_tiles_build')
         return tiles, ntiles
 
+    def seen_dense(self, seen_ptr, tiles, ntiles, n_users, dense_tiles):
+        """(dense uint32 [groups x dense_tiles x 32], skip int32 [n_users]) from a seen-tile stream (pk_seen_dense_build)."""
+        groups = -(-n_users // 32)
+        dense = torch.empty((groups, dense_tiles, 32), dtype=torch.int32, device=self.device)
+        skip = torch.empty(n_users, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.pk_seen_dense_build(self.stream(), n_users, _ptr(seen_ptr), _ptr(tiles), _ptr(ntiles), int(dense_tiles),
+                                                _ptr(dense), _ptr(skip)), 'pk_seen_dense_build')
+        return dense, skip
+
     def score_candidates(self, Vp, Ep, n_users, n_items, K, seen_ptr, seen_idx, KC, splits=1, tiles_per_chunk=0,
-                         user_bound=None, tile_bound=None, seen_tiles=None):
+                         user_bound=None, tile_bound=None, seen_tiles=None, seen_dense=None):
         n_pad = -(-n_users // 32) * 32
         need = self.lib.pk_score_state_bytes(n_users, splits)
         if self._score_states is None:
@@ -693,16 +725,19 @@ class HipOps:
         self._score_state = self._score_states[skey]
         cs = torch.empty(splits * n_pad * KC, dtype=torch.float32, device=self.device)
         ci = torch.empty(splits * n_pad * KC, dtype=torch.int32, device=self.device)
-        tiles = ntiles = None
+        tiles = ntiles = dense = skip = None
+        dtiles = 0
         if seen_ptr is not None:
             tiles, ntiles = seen_tiles if seen_tiles is not None else self.seen_tiles(seen_ptr, seen_idx, n_users)
+            if seen_dense is not None:
+                dense, skip, dtiles = seen_dense
         with self._timed('score_candidates', (n_users, n_items, K)):
             _lib.check(self.lib.pk_score_candidates_f32(self.stream(), n_users, n_items, K, _ptr(Vp), _ptr(Ep),
                                                         _ptr(seen_ptr), _ptr(tiles), _ptr(ntiles), KC, splits,
                                                         _ptr(cs), _ptr(ci),
                                                         _ptr(self._score_state),
                                                         tiles_per_chunk or self.score_tiles_per_chunk,
-                                                        _ptr(user_bound), _ptr(tile_bound)),
+                                                        _ptr(user_bound), _ptr(tile_bound), _ptr(dense), _ptr(skip), int(dtiles)),
                        'pk_score_candidates_f32')
         return cs, ci
 

@@ -143,6 +143,7 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
     seen_ptr = T.indptr if filter_seen else None
     seen_idx = T.indices if filter_seen else None
     seen_tiles = T.seen_tiles() if filter_seen else None
+    seen_dense = T.seen_dense() if (filter_seen and hasattr(T, 'seen_dense')) else None    # (masks, skip counts, tiles)
     splits = ops.score_splits(n_users, KC, prune)    # item ranges per user group (1 when pruning / users fill the chip)
     out_idx = torch.empty(n_users, topk, dtype=torch.int64, device=E.device)
     out_s = torch.empty(n_users, topk, dtype=torch.float64, device=E.device)
@@ -170,9 +171,11 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
             ub = None
         sp = seen_ptr[u0:u1 + 1] if filter_seen else None
         st = (seen_tiles[0], seen_tiles[1][u0:u1]) if seen_tiles is not None else None
+        sd = (seen_dense[0][u0 // 32:], seen_dense[1][u0:u1], seen_dense[2]) if seen_dense is not None else None
+        extra = {} if sd is None else {'seen_dense': sd}
         cs, ci = ops.score_candidates(factors.Vp, Ep, nb, n_items, K, sp, seen_idx, KC, splits,
                                       user_bound=ub, tile_bound=factors.tile_bound if prune else None,
-                                      seen_tiles=st)                                          # K3
+                                      seen_tiles=st, **extra)                                 # K3
         outs = (out_idx[u0:u1], out_s[u0:u1], flags[u0:u1])
         ops.rescore_topk(factors.V, Eb, n_items, sp, KC, cs, ci, topk, factors.vmax, want_scores=True,
                          splits=splits, out=outs, e_err=w, v32=factors.V32x if approx_fold_in else None)
