@@ -187,7 +187,9 @@ struct SeenDense {
     int tiles;
 };
 
-template <int NSTEP, int KC, bool STRIDED>
+// DENSE: the instance that reads them (the other one is the kernel as it was: in the throughput-bound regimes — full
+// sweeps, rank 200 — the extra registers and per-tile tests of a run-time switch cost 10 %).
+template <int NSTEP, int KC, bool STRIDED, bool DENSE>
 __global__ __launch_bounds__(256) void score_candidates_kernel(
     const float4 *__restrict__ Vp, const float4 *__restrict__ Ep, int64_t n_users, int n_items,
     int n_tiles, int split_tiles, int chunk_begin, int chunk_tiles,
@@ -267,9 +269,9 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
     }
     LaneState *my_state = st_lane + slot * 64 + lane;
     uint2 *my_ring_state = st_ring + slot * (RING * 64);
-    const int dense_tiles = (seen_ptr != nullptr) ? dense.tiles : 0;
+    const int dense_tiles = (DENSE && seen_ptr != nullptr) ? dense.tiles : 0;
     const unsigned *dense_row = dense_tiles ? dense.mask + ((int64_t)group * dense_tiles) * 32 + ul : nullptr;
-    if (first && has_seen && dense_tiles) sp += dense.skip[user];   // those tiles are served by the dense masks
+    if (DENSE && first && has_seen && dense_tiles) sp += dense.skip[user];   // those tiles are served by the dense masks
     if (first) {
         if (has_seen && t_lo > 0) {
             // skip the records before this split's first tile: lower_bound(tile >= t_lo)
@@ -505,10 +507,12 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
         const int j0 = tile * 32, jend = j0 + 32;
         unsigned mask = 0;
         if (ablate & 1) return 0u;   // tuning only: skip the seen-list walk
-        if (tile < dense_tiles) {
-            mask = m_dense;
-            if (jend > n_items) mask |= ~0u << (n_items - j0);
-            return mask;
+        if constexpr (DENSE) {
+            if (tile < dense_tiles) {
+                mask = m_dense;
+                if (jend > n_items) mask |= ~0u << (n_items - j0);
+                return mask;
+            }
         }
         if (S > 1) {
             // records of tiles that belong to the other splits lie between two of mine: step over them
@@ -576,7 +580,8 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
         // 3.29 ms; four (120 VGPRs, no spill) is what the register allocator picks unprompted.
         float4 a_nxt[KQ];
         load_frags((tile_begin < n_tiles) ? tile_begin : 0, a_nxt);
-        unsigned m_nxt = (tile_begin < dense_tiles) ? dense_row[(int64_t)tile_begin * 32] : 0u;
+        unsigned m_nxt = 0u;
+        if constexpr (DENSE) m_nxt = (tile_begin < dense_tiles) ? dense_row[(int64_t)tile_begin * 32] : 0u;
         float tb = prune ? tile_bound[(tile_begin < n_tiles) ? tile_begin : 0] : 0.0f;
         PROF_ADD(4, prof_k0);
         int step = 0;
@@ -602,8 +607,10 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
 #pragma unroll
             for (int q = 0; q < KQ; ++q) a[q] = a_nxt[q];
             load_frags((tile + S < tile_end) ? tile + S : tile, a_nxt);
-            m_dense = m_nxt;
-            m_nxt = (tile + S < dense_tiles) ? dense_row[(int64_t)(tile + S) * 32] : 0u;
+            if constexpr (DENSE) {
+                m_dense = m_nxt;
+                m_nxt = (tile + S < dense_tiles) ? dense_row[(int64_t)(tile + S) * 32] : 0u;
+            }
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -1095,17 +1102,21 @@ static int launch_candidates_n(hipStream_t st, int KC, int ablate, dim3 grid, co
     // with pruning, groups leave the sweep early, so the chunks DOUBLE from launch to launch — the catalogue
     // is covered in O(log) launches and the few groups still sweeping late (low bandwidth demand) are not
     // cut into hundreds of launches (rank 200: 100-tile chunks, 157 launches for 500K items otherwise).
+    // the dense seen masks: single-sweep instances up to rank 128 (with item splits or beyond that rank the stream serves
+    // every tile; a dense request is then simply not used — the stream cursor starts at the user's first record)
+    const bool use_dense = dense.tiles > 0 && NSTEP <= 8 && grid.y == 1;
+    const SeenDense no_dense{nullptr, nullptr, 0};
     int chunk_tiles = tiles_per_chunk;
     for (int chunk_begin = 0; chunk_begin < split_tiles; chunk_begin += chunk_tiles, chunk_tiles = (user_bound ? 2 * chunk_tiles : chunk_tiles)) {
 #define PK_LAUNCH(KCV)                                                                                          \
     if (pk_score_lds_bytes(NSTEP, KCV) > 64 * 1024) {                                                           \
         static bool attr_set = false;   /* one flag per (NSTEP, KC) instance of this macro expansion */        \
         if (!attr_set) {                                                                                        \
-            hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&score_candidates_kernel<NSTEP, KCV, false>), \
+            hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&score_candidates_kernel<NSTEP, KCV, false, false>), \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize,                     \
                                                 (int)pk_score_lds_bytes(NSTEP, KCV));                           \
             if (e1 == hipSuccess)                                                                               \
-                e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&score_candidates_kernel<NSTEP, KCV, true>), \
+                e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&score_candidates_kernel<NSTEP, KCV, true, false>), \
                                          hipFuncAttributeMaxDynamicSharedMemorySize,                            \
                                          (int)pk_score_lds_bytes(NSTEP, KCV));                                  \
             if (e1 != hipSuccess) {                                                                             \
@@ -1116,13 +1127,17 @@ static int launch_candidates_n(hipStream_t st, int KC, int ablate, dim3 grid, co
         }                                                                                                       \
     }                                                                                                           \
     if (grid.y > 1)                                                                                             \
-        hipLaunchKernelGGL((score_candidates_kernel<NSTEP, KCV, true>), grid, dim3(256), pk_score_lds_bytes(NSTEP, KCV), st, Vp, Ep, n_users, \
+        hipLaunchKernelGGL((score_candidates_kernel<NSTEP, KCV, true, false>), grid, dim3(256), pk_score_lds_bytes(NSTEP, KCV), st, Vp, Ep, n_users, \
+                           n_items, n_tiles, split_tiles, chunk_begin, chunk_tiles, seen_ptr, seen_tiles, seen_ntiles, cs, ci, st_lane, st_ring,  \
+                           user_bound, tile_bound, ablate, no_dense);                                           \
+    else if (use_dense)                                                                                         \
+        hipLaunchKernelGGL((score_candidates_kernel<NSTEP, KCV, false, (NSTEP <= 8)>), grid, dim3(256), pk_score_lds_bytes(NSTEP, KCV), st, Vp, Ep, n_users, \
                            n_items, n_tiles, split_tiles, chunk_begin, chunk_tiles, seen_ptr, seen_tiles, seen_ntiles, cs, ci, st_lane, st_ring,  \
                            user_bound, tile_bound, ablate, dense);                                              \
     else                                                                                                        \
-        hipLaunchKernelGGL((score_candidates_kernel<NSTEP, KCV, false>), grid, dim3(256), pk_score_lds_bytes(NSTEP, KCV), st, Vp, Ep, n_users, \
+        hipLaunchKernelGGL((score_candidates_kernel<NSTEP, KCV, false, false>), grid, dim3(256), pk_score_lds_bytes(NSTEP, KCV), st, Vp, Ep, n_users, \
                            n_items, n_tiles, split_tiles, chunk_begin, chunk_tiles, seen_ptr, seen_tiles, seen_ntiles, cs, ci, st_lane, st_ring,  \
-                           user_bound, tile_bound, ablate, dense)
+                           user_bound, tile_bound, ablate, no_dense)
 #ifdef PK_FAST_BUILD
         if (KC != 16) return PK_E_UNSUPPORTED;
         PK_LAUNCH(16);

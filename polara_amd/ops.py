@@ -123,6 +123,9 @@ class DeviceCSR:
             dt = min(n_tiles, 256) if env is None else min(n_tiles, int(env))
             while dt > 32 and groups * dt * 128 > (512 << 20):
                 dt //= 2
+            if env is None and n_tiles > 32 * dt:
+                dt = 0        # a catalogue this long is swept far beyond the window (S-50M shard, rank 200: groups leave at
+                              # tile 440 of 15 625 with a 128-tile window): the masks' loads then only cost (sweep +12 %)
             if dt <= 0 or self.shape[0] == 0:
                 self._seen_dense = (None,)
             else:
