@@ -737,3 +737,41 @@ def test_scatter_rows_to_device_and_to_pinned_host_memory(hip_ops):
     assert np.array_equal(hip_ops.to_host(hip_ops.scatter_rows(src, None)), src.cpu().numpy())
     with pytest.raises(AssertionError):
         hip_ops.scatter_rows(src, perm, out=torch.zeros((n, w), dtype=torch.int64))     # pageable host memory
+
+
+def test_dense_seen_masks_equal_the_stream(hip_ops, monkeypatch):
+    """pk_seen_dense_build against NumPy, and the sweep with a dense window of 1, 3, 8, all tiles against the sweep on
+    the seen-tile stream alone: same candidates, same lists (the window ends in the middle of the catalogue, so the
+    hand-over from the dense masks to the stream cursor is exercised; heavy users have a record in every tile)."""
+    from polara_amd import scoring
+    ops = hip_ops
+    rng = np.random.RandomState(8)
+    n_users, n_items, K, topk = 700, 1000, 16, 10
+    indptr, indices, values = rand_csr(rng, n_users, n_items, 40, long_rows=[(0, 900), (1, 640), (33, 990), (699, 500)])
+    V = np.linalg.qr(rng.randn(n_items, K))[0] * np.linspace(4, 0.2, n_items)[:, None]
+    F = scoring.FactorImage(ops, ops.to_device(V))
+    monkeypatch.setattr(ops, 'score_splits_override', 1)      # one sweep per group: item splits read the stream only
+
+    def lists(window):
+        monkeypatch.setenv('PK_SEEN_DENSE_TILES', str(window))
+        T = ops.csr(indptr, indices, values, (n_users, n_items))
+        sd = T.seen_dense()
+        idx, sc = scoring.recommend(ops, F, T, topk, True, return_scores=True)
+        ids = scoring.recommend(ops, F, T, topk, True)
+        return sd, ops.to_host(idx), ops.to_host(sc), ops.to_host(ids)
+
+    sd0, idx0, sc0, ids0 = lists(0)
+    assert sd0 is None
+    for window in (1, 3, 8, 32):
+        sd, idx, sc, ids = lists(window)
+        dense, skip, dt = sd
+        assert dt == min(window, -(-n_items // 32))
+        want = np.zeros((-(-n_users // 32), dt, 32), dtype=np.uint32)
+        want_skip = np.zeros(n_users, dtype=np.int32)
+        for u in range(n_users):
+            row = indices[indptr[u]:indptr[u + 1]]
+            row = row[row < 32 * dt]
+            np.bitwise_or.at(want[u // 32, :, u % 32], row // 32, (1 << (row % 32)).astype(np.uint32))
+            want_skip[u] = len(np.unique(row // 32))
+        assert np.array_equal(ops.to_host(dense).view(np.uint32), want) and np.array_equal(ops.to_host(skip), want_skip)
+        assert np.array_equal(idx, idx0) and np.array_equal(sc, sc0) and np.array_equal(ids, ids0), window
