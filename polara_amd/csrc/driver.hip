@@ -831,7 +831,8 @@ struct pk_serving {
     Dev inv64;                 // serving position -> the caller's item id (int64, for pk_map_ids_i64)
     DMat V;
     Csr Ts;
-    Dev Vp, tile_bound, V32, tiles, ntiles;
+    Dev Vp, tile_bound, V32, tiles, ntiles, dense, skip;
+    int dense_tiles = 0;          // window of the dense seen masks (0: none)
 };
 
 namespace {
@@ -945,6 +946,17 @@ int serving_score(pk_ctx *ctx, pk_serving *sv, int32_t topk, int32_t filter_seen
             if (!sv->tiles.alloc(n1 * 8) || !sv->ntiles.alloc((size_t)n_users * 4)) return fail(ctx, PK_E_LAUNCH, "out of device memory (seen tiles)");
             CK(pk_seen_tiles_build(st, n_users, Ts.indptr.as<int64_t>(), Ts.indices.as<int32_t>(), 1, 0, sv->tiles.as<uint64_t>(), sv->ntiles.as<int32_t>()));
             sv->have_tiles = true;
+            // dense masks for the head of the catalogue (ops.DeviceCSR.seen_dense: at most 256 tiles and 512 MB, not for
+            // catalogues of more than 32 windows)
+            const int64_t n_tiles_all = (n_items + 31) / 32, groups = (n_users + 31) / 32;
+            int dt = (int)std::min<int64_t>(n_tiles_all, 256);
+            while (dt > 32 && groups * dt * 128 > ((int64_t)512 << 20)) dt /= 2;
+            if (n_tiles_all <= 32 * (int64_t)dt && sv->dense.alloc((size_t)pk_seen_dense_bytes(n_users, dt)) &&
+                sv->skip.alloc((size_t)n_users * 4)) {
+                CK(pk_seen_dense_build(st, n_users, Ts.indptr.as<int64_t>(), sv->tiles.as<uint64_t>(), sv->ntiles.as<int32_t>(), dt,
+                                       sv->dense.as<uint32_t>(), sv->skip.as<int32_t>()));
+                sv->dense_tiles = dt;
+            }
         }
         const uint64_t *tiles = filter_seen ? sv->tiles.as<uint64_t>() : nullptr;
         const int32_t *ntiles = filter_seen ? sv->ntiles.as<int32_t>() : nullptr;
@@ -953,7 +965,9 @@ int serving_score(pk_ctx *ctx, pk_serving *sv, int32_t topk, int32_t filter_seen
         Dev state((size_t)pk_score_state_bytes(n_users, splits)), cs((size_t)splits * n_pad * KC * 4), ci((size_t)splits * n_pad * KC * 4);
         if (!state.p || !cs.p || !ci.p) return fail(ctx, PK_E_LAUNCH, "out of device memory (candidates)");
         CK(pk_score_candidates_f32(st, n_users, n_items, K, sv->Vp.as<float>(), Ep.as<float>(), seen_ptr, tiles, ntiles,
-                                   KC, splits, cs.as<float>(), ci.as<int32_t>(), state.p, 0, ub.as<float>(), sv->tile_bound.as<float>(), nullptr, nullptr, 0));
+                                   KC, splits, cs.as<float>(), ci.as<int32_t>(), state.p, 0, ub.as<float>(), sv->tile_bound.as<float>(),
+                                   (filter_seen && sv->dense_tiles) ? sv->dense.as<uint32_t>() : nullptr,
+                                   (filter_seen && sv->dense_tiles) ? sv->skip.as<int32_t>() : nullptr, filter_seen ? sv->dense_tiles : 0));
         CK(pk_rescore_topk_rows_f64(st, n_users, nullptr, nullptr, n_users, n_items, K, V.p(), K, approx ? sv->V32.as<float>() : nullptr, approx ? ld32 : 0,
                                     Ex.p(), Kx, w, approx ? Kx : 0, 0, seen_ptr, KC, splits, cs.as<float>(), ci.as<int32_t>(), topk, vmax,
                                     out_i.as<int64_t>(), out_s.as<double>(), flags.as<int32_t>()));
