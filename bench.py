@@ -76,7 +76,11 @@ def parse():
     ap.add_argument('--workload', default='ml20m', choices=['s1m', 'ml20m', 'ml1m'])
     ap.add_argument('--rank', type=int, default=0, help='0 = the headline rank of the workload (ml20m: 50, the metric line)')
     ap.add_argument('--topk', type=int, default=0)
-    ap.add_argument('--only-headline', action='store_true', help='skip the sub-blocks (always skipped for N > 1)')
+    ap.add_argument('--only-headline', action='store_true',
+                    help='skip the three adversarial-catalogue rows that ride in the compact line (always skipped for N > 1)')
+    ap.add_argument('--detail', action='store_true',
+                    help='also measure the other BASELINE.json configurations, the plugin surface and the coarse C ABI (N = 1); '
+                         'they go to bench_detail.json, never to the stdout line')
     ap.add_argument('--no-prune', action='store_true',
                     help='score every item tile for every user (disables the exact norm-bound pruning of the sweep)')
     ap.add_argument('--no-norm-order', action='store_true',
@@ -187,9 +191,14 @@ class Bench:
         return c
 
     # ---- build: everything between "host CSR of my users" and "ready to score" -------------------------------
-    def build(self, c, rank, norm_order=True):
+    def build(self, c, rank, norm_order=True, catalogue='svd'):
         """One complete build as the model layer does it; returns (state, timings).  Every stage is bracketed by a
-        device synchronisation (and a barrier across ranks) so that the items add up to the total."""
+        device synchronisation (and a barrier across ranks) so that the items add up to the total.
+        `catalogue` rescales the rows of the item factors AFTER the solver (adversarial inputs for the sweep's norm-bound
+        pruning; the lists are then those of the rescaled factors, checked against the CPU path like any other):
+          'svd'    the factors as built (row norms follow the generator's popularity / factor-scale decay)
+          'flat'   every row scaled to unit norm: the pruning bound never fires, 100 % of the tiles are scored
+          'pop25'  row norms proportional to (item count)^0.25: a slow, real-data-like decay"""
         from polara_amd.csr import nnz_balanced_row_partition, popularity_order
         from polara_amd.solver import svd_topk
         from polara_amd import scoring
@@ -225,6 +234,12 @@ class Bench:
         lap('solver_s')
         spmm_ev = ops.timers.get('spmm', [])
         ops.timers = None
+        if catalogue != 'svd':
+            unit = V / torch.linalg.vector_norm(V, dim=1, keepdim=True).clamp_min(1e-300)
+            if catalogue == 'pop25':
+                cnt = torch.as_tensor(np.asarray(counts, dtype=np.float64)[inv_order], device=V.device)   # internal order
+                unit = unit * cnt.clamp_min(1.0).pow(0.25).unsqueeze(1)
+            V = unit.contiguous()
         order2 = None
         A_score = A
         if norm_order:
@@ -418,16 +433,11 @@ class Bench:
 
     # ---- one complete measurement of (workload, rank, topk) -------------------------------------------------
     def measure(self, c, workload, rank, topk, steps, warmup, prune=True, norm_order=True, cpu=True, cpu_users=0,
-                cpu_build=True, flat_norm=False, cold_build=None):
+                cpu_build=True, catalogue='svd', cold_build=None, cpu_build_whole=False):
         ops, comm = self.ops, self.comm
         n_users, n_items = c['shape']
         nnz = int(c['indptr'][-1])
-        st, tb = self.build(c, rank, norm_order)                      # warm (the process has built before) or cold
-        if flat_norm:
-            from polara_amd import scoring
-            V = st['V'] / torch.linalg.vector_norm(st['V'], dim=1, keepdim=True).clamp_min(1e-300)
-            st['V'] = V.contiguous()
-            st['F'] = scoring.FactorImage(ops, st['V'])
+        st, tb = self.build(c, rank, norm_order, catalogue)           # warm (the process has built before) or cold
         elapsed, recs, extra = self.score_passes(st, topk, steps, warmup, prune=prune, batches=self.args.batches or None)
         ms, n_launch, stats = self.kernel_times(st, topk, prune=prune)
         out = None
@@ -447,6 +457,8 @@ class Bench:
                 'n_users': n_users, 'n_items': n_items, 'nnz': nnz, 'rank': rank, 'topk': topk, 'prune': prune,
                 'score_order': 'factor norm' if norm_order else 'popularity',
                 'launch': extra.get('launch', 'python, kernel by kernel'),
+                'launch_short': 'hipGraph' if extra.get('launch', '').startswith('hipGraph') else 'python',
+                'launches_per_pass': int(sum(n_launch.values()) // 5) if n_launch else None,
                 'warmup_calibration_ms_per_step': {'python_launch': extra.get('python_launch_ms_per_step'),
                                                    'graph_replay': extra.get('graph_replay_ms_per_step')},
                 'build_s': tb['total_s'], 'build': dict(tb, gramian_steps=bstats['gramian_steps'],
@@ -462,8 +474,10 @@ class Bench:
                           'swept_fraction': swept, 'exit_tile_quantiles': stats.get('exit_tile_quantiles'),
                           'n_tiles': -(-n_items // 32)},
             }
-            if flat_norm:
+            if catalogue == 'flat':
                 out['workload'] += '; item-factor rows scaled to unit norm (flat-norm catalogue: the pruning bound never fires)'
+            elif catalogue == 'pop25':
+                out['workload'] += '; item-factor rows rescaled to norm = (item count)^0.25 (slow, real-data-like norm decay)'
             if cand_ms:
                 # the sweep computes every fp32-accurate product as THREE bf16 MFMAs (hi.hi + hi.lo + lo.hi) over the rank
                 # padded to a multiple of 16: executed bf16 flops = 3 * (16 * k_steps / rank) * the algorithmic flops swept
@@ -474,7 +488,8 @@ class Bench:
                 out['roofline'] = {
                     'kernel': 'score_candidates_kernel', 'bound': 'mfma', 'dtype': 'bf16 (split product: 3 bf16 MFMAs per fp32-class product)',
                     'achieved': ach, 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_MFMA_TFLOPS, 'traffic': None,
-                    'avg_ms': cand_ms, 'kernel_launches_per_pass': n_chunk, 'flop_per_launch': bf16_flops,
+                    'avg_ms': cand_ms / max(n_chunk, 1), 'sweep_ms_per_pass': cand_ms, 'launches_per_pass': n_chunk,
+                    'flop_per_launch': bf16_flops / max(n_chunk, 1),
                     'swept_fraction': swept,
                     'note': 'achieved/frac count the bf16 MFMA flops actually issued for the tiles actually scored (the sweep is pruned '
                             'exactly: Cauchy-Schwarz bound, identical results; --no-prune scores every tile). At rank 50 the kernel is '
@@ -503,15 +518,25 @@ class Bench:
                             sample='reference scoring path (chunked GEMM + downvote + per-row argpartition, fp64) on the '
                                    'first %d users of the same matrix with the GPU-built V' % n_score,
                             score_sample_s=t_score, host_cpus=os.cpu_count(), gpu_vs_cpu_identical_rows=same,
-                            speedup_scoring=out['value'] / (n_score / t_score))
+                            speedup_scoring=out['value'] / (n_score / t_score),
+                            sample_short='scoring: first %d users of the matrix, GPU-built V' % n_score)
                 if cpu_build:
-                    build_rows = min(n_users, max(1000, int(5e6 / max(nnz / n_users, 1))))
+                    # north_star's ">= 10x on build + score" is defined on the WHOLE build: the headline matrix is
+                    # factorised once by the reference's own call (scipy svds, ARPACK, tol 0 — models.py:844) on every
+                    # row; larger workloads (S-1M: 1e8 nnz) keep a 5e6-nnz sample and say so
+                    build_rows = n_users if cpu_build_whole else min(n_users, max(1000, int(5e6 / max(nnz / n_users, 1))))
                     t_build, hb = self.cpu_build(c, rank, build_rows)
                     base.update(build_sample_s=t_build, build_sample_users=build_rows, build_sample_nnz=hb,
-                                build_note='scipy svds (ARPACK, tol 0 — the call of models.py:844) on the first %d users '
-                                           '(%d nnz, %.0f%% of the matrix); the GPU build_s above is for the WHOLE matrix'
-                                           % (build_rows, hb, 100.0 * hb / nnz))
-                    base['sample'] += '; svds build timed on the first %d users (%d nnz)' % (build_rows, hb)
+                                build_whole_matrix=bool(build_rows == n_users))
+                    base['sample'] += '; svds build timed on %s (%d users, %d nnz)' % (
+                        'the WHOLE matrix' if build_rows == n_users else 'the first rows', build_rows, hb)
+                    base['sample_short'] = 'scoring: first %d users of the matrix, GPU-built V; scipy svds (ARPACK tol 0): %s (%d users, %d nnz)' % (
+                        n_score, 'WHOLE matrix' if build_rows == n_users else 'first rows', build_rows, hb)
+                    if build_rows == n_users:
+                        cpu_total = t_build + n_users / (n_score / t_score)      # scoring extrapolated linearly from the sample
+                        base['build_s'] = t_build
+                        base['speedup_build'] = t_build / out['build_s']
+                        base['speedup_build_plus_score'] = cpu_total / (out['build_s'] + 1e-3 * out['ms_per_step'])
                 out['cpu_baseline'] = base
         del st
         torch.cuda.empty_cache()
@@ -674,6 +699,88 @@ def s50m_block(B, cpu=True):
                                                    check_users=300 if cpu else 0))
 
 
+MAX_LINE_BYTES = 3000      # the driver's capture of the final stdout line; round 2's 25 KB line came back unparsed
+
+
+def _r(x, nd=4):
+    """numbers of the compact line: 4 significant digits are what a reader compares"""
+    if x is None:
+        return None
+    if isinstance(x, (bool, np.bool_)):
+        return bool(x)
+    if isinstance(x, (int, np.integer)):
+        return int(x)
+    x = float(x)
+    if x == 0.0 or not np.isfinite(x):
+        return x
+    from math import floor, log10
+    return round(x, nd - 1 - int(floor(log10(abs(x)))))
+
+
+def compact_line(head, n_gpus, steps, warmup, adversarial=None, scale=1.0):
+    """The ONE stdout line of the run: headline + roofline + cpu_baseline, flat numbers only (no notes, no nested
+    sub-blocks); everything else lives in bench_detail.json.  Pure function of the measurement record, so that the
+    CPU suite can check its size and shape on a canned record (tests/test_host_logic.py)."""
+    sc = head.get('score', {})
+    cfg = {'workload': head['workload'], 'n_users': head['n_users'], 'n_items': head['n_items'], 'nnz': head['nnz'],
+           'rank': head['rank'], 'topk': head['topk'], 'prune': head['prune'],
+           'swept_fraction': _r(sc.get('swept_fraction')), 'launch': head.get('launch_short', 'python'),
+           'launches_per_pass': head.get('launches_per_pass'),
+           'parallelism': 'users sharded over %d GPU(s); all-gather X + reduce-scatter Z per Gramian step in the build, '
+                          'no collective in scoring' % n_gpus}
+    if scale != 1.0:
+        cfg['scale'] = scale
+    if adversarial:
+        cfg['adversarial_users_per_s'] = {k: _r(v) for k, v in adversarial.items()}
+    out = {'metric': 'users scored/sec + SVD build time, ML-20M rank-50 PureSVD', 'value': _r(head['value'], 6), 'unit': 'users/s',
+           'n_gpus': n_gpus, 'steps': steps, 'warmup': warmup, 'ms_per_step': _r(head['ms_per_step'], 5),
+           'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'bf16x3',
+           'data': 'synthetic', 'config': cfg, 'build_s': _r(head['build_s']),
+           'latency_ms_per_pass': _r(head.get('latency_ms_per_pass'))}
+    b = head.get('build', {})
+    out['build'] = {k: _r(b.get(k)) for k in ('solver_s', 'gramian_steps', 'converged', 'spmm_ms') if k in b}
+    rf = head.get('roofline')
+    if rf:
+        out['roofline'] = {k: (_r(rf.get(k)) if not isinstance(rf.get(k), str) else rf.get(k)) for k in
+                           ('kernel', 'bound', 'dtype', 'achieved', 'peak', 'unit', 'frac', 'avg_ms', 'launches_per_pass',
+                            'swept_fraction', 'traffic')}
+    rb = head.get('roofline_build')
+    if rb:
+        out['roofline_build'] = {k: (_r(rb.get(k)) if not isinstance(rb.get(k), str) else rb.get(k)) for k in
+                                 ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'launches', 'total_ms', 'traffic',
+                                  'algorithmic_bytes_per_product')}
+    cb = head.get('cpu_baseline')
+    if cb:
+        out['cpu_baseline'] = {
+            'value': _r(cb['value']), 'unit': cb['unit'], 'cores': cb['cores'], 'kind': cb['kind'],
+            'sample': cb.get('sample_short', cb.get('sample', ''))[:200],
+            'identical_rows': _r(cb.get('gpu_vs_cpu_identical_rows')), 'build_s': _r(cb.get('build_s')),
+            'build_whole_matrix': cb.get('build_whole_matrix'), 'speedup_scoring': _r(cb.get('speedup_scoring')),
+            'speedup_build': _r(cb.get('speedup_build')), 'speedup': _r(cb.get('speedup_build_plus_score'))}
+    line = json.dumps(out, separators=(',', ':'))
+    if len(line) > MAX_LINE_BYTES:        # never again an unparseable record: drop the optional blocks, loudest last
+        for k in ('build', 'roofline_build', 'latency_ms_per_pass'):
+            out.pop(k, None)
+            line = json.dumps(out, separators=(',', ':'))
+            if len(line) <= MAX_LINE_BYTES:
+                break
+    assert len(line) <= MAX_LINE_BYTES, len(line)
+    return line
+
+
+def write_detail(record):
+    """bench_detail.json next to bench.py (and under gpurun_out/ when that directory exists, so that it comes back from
+    the GPU box); failures to write are reported on stderr and never cost the run its line."""
+    for d in (ROOT, os.path.join(ROOT, 'gpurun_out')):
+        if d != ROOT and not os.path.isdir(d):
+            continue
+        try:
+            with open(os.path.join(d, 'bench_detail.json'), 'w') as f:
+                json.dump(record, f, indent=1, default=lambda o: o.tolist() if hasattr(o, 'tolist') else str(o))
+        except OSError as exc:
+            log('could not write %s/bench_detail.json: %s' % (d, exc))
+
+
 def main():
     args = parse()
     B = Bench(args)
@@ -686,11 +793,22 @@ def main():
     # cold build: the first heavy GPU work of the process (allocator growth, page tables, code objects), itemised
     _, cold = B.build(c, headline_rank, not args.no_norm_order)
     torch.cuda.empty_cache()
+    full_size = comm.world == 1 and args.scale == 1.0
     head = B.measure(c, args.workload, headline_rank, headline_topk, args.steps, args.warmup, prune=prune,
                      norm_order=not args.no_norm_order, cpu=not args.no_cpu_baseline, cpu_users=args.cpu_users,
-                     cold_build=cold)
-    subs = {}
-    if comm.world == 1 and not args.only_headline and args.scale == 1.0 and args.workload == 'ml20m':
+                     cold_build=cold, cpu_build_whole=full_size and args.workload in ('ml20m', 'ml1m'))
+    subs, adversarial = {}, {}
+    if full_size and not args.only_headline and args.workload == 'ml20m':
+        # the headline depends on how fast the item-factor norms decay (the sweep is pruned by a norm bound): the same
+        # matrix with three less friendly catalogues ALWAYS runs next to it and rides in the compact line
+        sub_steps = max(5, min(args.steps, 20))
+        for name, kw in (('flat_norm', dict(catalogue='flat')), ('pop25_norm', dict(catalogue='pop25')),
+                         ('no_prune', dict(prune=False))):
+            s = B.measure(c, 'ml20m', headline_rank, headline_topk, sub_steps, 2, cpu=not args.no_cpu_baseline, cpu_users=5000,
+                          cpu_build=False, **kw)
+            subs[name] = s
+            adversarial[name] = s['value']
+    if full_size and args.detail and args.workload == 'ml20m':
         sub_steps = max(5, min(args.steps, 20))
         # the plugin surface, end to end
         mp, _ = B.model_path(c, headline_rank, headline_topk)
@@ -699,13 +817,6 @@ def main():
         # BASELINE.json configs[2]: rank 100, top-20
         s = B.measure(c, 'ml20m', 100, 20, sub_steps, 2, cpu=not args.no_cpu_baseline, cpu_users=5000, cpu_build=False)
         subs['configs2_ml20m_rank100_top20'] = s
-        # adversarial catalogue: flat item-factor norms
-        s = B.measure(c, 'ml20m', headline_rank, headline_topk, sub_steps, 2, cpu=not args.no_cpu_baseline, cpu_users=5000,
-                      cpu_build=False, flat_norm=True)
-        subs['flat_norm_catalogue'] = s
-        # the same matrix, full sweep
-        s = B.measure(c, 'ml20m', headline_rank, headline_topk, sub_steps, 2, prune=False, cpu=False)
-        subs['no_prune'] = {k: s[k] for k in ('value', 'ms_per_step', 'latency_ms_per_pass', 'score', 'roofline')}
         del c
         gc.collect()
         # BASELINE.json configs[1]
@@ -718,25 +829,23 @@ def main():
         del c1
         gc.collect()
         torch.cuda.empty_cache()
-        # BASELINE.json configs[3] and configs[4]: not on the metric's path, measured here so that the driver's record
-        # holds them too; a failure in one of these blocks is reported in its place and does not cost the run its line
-        if comm.world == 1:
-            for name, fn in (('configs3_coffee_ml1m', coffee_block), ('configs4_s50m_shard', s50m_block)):
-                try:
-                    subs[name] = fn(B, cpu=not args.no_cpu_baseline)
-                except Exception as exc:
-                    subs[name] = {'error': '%s: %s' % (type(exc).__name__, exc)}
-                gc.collect()
-                torch.cuda.empty_cache()
+        # BASELINE.json configs[3] and configs[4]: not on the metric's path; a failure in one of these blocks is
+        # reported in its place and does not cost the run its line
+        for name, fn in (('configs3_coffee_ml1m', coffee_block), ('configs4_s50m_shard', s50m_block)):
+            try:
+                subs[name] = fn(B, cpu=not args.no_cpu_baseline)
+            except Exception as exc:
+                subs[name] = {'error': '%s: %s' % (type(exc).__name__, exc)}
+            gc.collect()
+            torch.cuda.empty_cache()
     if comm.rank != 0:
         return
     tag = {'ml20m': 'ml20m', 's1m': 's1m'}.get(args.workload)
-    traffic = pmc_traffic(tag) if (tag and args.scale == 1.0 and comm.world == 1 and headline_rank == 50) else {}
+    traffic = pmc_traffic(tag) if (tag and full_size and headline_rank == 50) else {}
     if 'roofline' in head and 'score' in traffic:
-        head['roofline']['traffic'] = traffic['score'] * head['roofline']['kernel_launches_per_pass']
-        head['roofline']['traffic_note'] = ('HBM/fabric bytes per scoring pass = item-chunk launches x (2*FETCH_SIZE + WRITE_SIZE) of a '
-                                            'separate rocprofv3 --pmc run of this command at commit %s (profiles/r02_%s_pmc_*.txt)'
-                                            % (traffic.get('commit'), tag))
+        head['roofline']['traffic'] = traffic['score']       # per LAUNCH, like `achieved`
+        head['roofline']['traffic_note'] = ('HBM/fabric bytes per launch = 2*FETCH_SIZE + WRITE_SIZE of a separate rocprofv3 --pmc run of '
+                                            'this command at commit %s (profiles/%s_%s_pmc_*.txt)' % (traffic.get('commit'), traffic.get('round'), tag))
     if 'roofline_build' in head and 'spmm_total' in traffic:
         rb = head['roofline_build']
         products = 2 * head['build']['gramian_steps']          # A.X and A^T.Y of every Gramian step
@@ -745,32 +854,20 @@ def main():
         rb['traffic_note'] = ('HBM/fabric bytes per SpMM PRODUCT (A.X, or A^T.Y = the sum of its user-block launches): '
                               '(2*FETCH_SIZE + WRITE_SIZE) summed over every build SpMM launch of the profiled run / its %d '
                               'products; same source' % (2 * products))
-    out = {
-        'metric': 'users scored/sec + SVD build time, ML-20M rank-50 PureSVD', 'value': head['value'], 'unit': 'users/s',
-        'n_gpus': comm.world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': head['ms_per_step'],
-        'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'bf16x3',
-        'dtype_detail': 'candidate scoring on bf16 MFMA with every operand split into two bf16 (3 MFMAs per product, fp32 accumulate, '
-                        'error <= 3 * 2^-16 + (4 K + 10) * 2^-23 relative to ||e|| ||v||, certified); fold-in gathers fl32(V) with f64 accumulation, its rounding is part of the '
-                        'certification (uncertified users are re-folded in f64); EXACT f64 re-scoring of the candidates decides every '
-                        'list; f64 SVD build',
-        'data': 'synthetic (planted low-rank + Zipf popularity, seeded; generated on GPU)',
-        'config': {'workload': head['workload'], 'n_users': head['n_users'], 'n_items': head['n_items'], 'nnz': head['nnz'],
-                   'rank': head['rank'], 'topk': head['topk'],
-                   'parallelism': 'users sharded over %d GPU(s); build only: all-gather X / reduce-scatter Z per Gramian step (item side row-sharded), no collective in scoring' % comm.world,
-                   'scale': args.scale, 'prune': prune, 'score_order': head['score_order'], 'batches': args.batches or 'auto',
-                   'launch': head['launch'],
-                   'result': 'int64 [n_users x topk] copied to pinned host memory inside the timed region (double-buffered)'},
-        'latency_ms_per_pass': head['latency_ms_per_pass'], 'd2h_bytes_per_pass': head['d2h_bytes_per_pass'],
-        'warmup_calibration_ms_per_step': head.get('warmup_calibration_ms_per_step'),
-        'build_s': head['build_s'], 'build': head['build'], 'build_cold': head.get('build_cold'),
-        'score': head['score'], 'roofline': head.get('roofline'), 'roofline_build': head.get('roofline_build'),
-        'gen_s': gen_s,
-    }
-    if 'cpu_baseline' in head:
-        out['cpu_baseline'] = head['cpu_baseline']
-    if subs:
-        out['sub'] = subs
-    print(json.dumps(out))
+    detail = dict(head)
+    detail.pop('host_result', None)
+    detail.update(metric='users scored/sec + SVD build time, ML-20M rank-50 PureSVD', unit='users/s', n_gpus=comm.world,
+                  steps=args.steps, warmup=args.warmup, gen_s=gen_s, scale=args.scale,
+                  dtype_detail='candidate scoring on bf16 MFMA with every operand split into two bf16 (3 MFMAs per product, fp32 '
+                               'accumulate, error <= 3 * 2^-16 + (4 K + 10) * 2^-23 relative to ||e|| ||v||, certified); fold-in gathers '
+                               'fl32(V) with f64 accumulation, its rounding is part of the certification (uncertified users are '
+                               're-folded in f64); EXACT f64 re-scoring of the candidates decides every list; f64 SVD build',
+                  data='synthetic (planted low-rank + Zipf popularity, seeded; generated on GPU)',
+                  result='int64 [n_users x topk] copied to pinned host memory inside the timed region (double-buffered)',
+                  sub=subs)
+    write_detail(detail)
+    log('detail record: bench_detail.json (%d sub-blocks: %s)' % (len(subs), ', '.join(subs)))
+    print(compact_line(head, comm.world, args.steps, args.warmup, adversarial, args.scale), flush=True)
 
 
 if __name__ == '__main__':

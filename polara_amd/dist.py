@@ -72,7 +72,7 @@ class TorchComm:
             out = torch.empty((rows, full.shape[1]), dtype=full.dtype, device=full.device)
             dist.reduce_scatter_tensor(out, full, op=dist.ReduceOp.SUM, group=self.group)
         else:
-            h = full.cpu() if full.is_cuda else full
+            h = full.cpu() if full.is_cuda else full.clone()      # the caller's buffer is not ours to overwrite
             dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
             out = h[self.rank * rows:(self.rank + 1) * rows].to(full.device).contiguous()
         self.bytes_scattered += full.numel() * full.element_size()

@@ -224,6 +224,12 @@ class BlockedTranspose:
         n_cols = self.shape[0]
         if out is None:
             out = ops.empty(n_cols, Y.shape[1])
+        if Y.shape[1] > 256:
+            # one output row per wave in registers: at most 256 columns per launch (HipOps.spmm); wider blocks — builds
+            # beyond rank 200, where solver.default_block exceeds 256 — go panel by panel through the leading dimensions
+            for c0 in range(0, Y.shape[1], 256):
+                self.apply(Y[:, c0:c0 + 256], out[:, c0:c0 + 256])
+            return out
         for b, rng in enumerate(self.ranges):
             ops._spmm_launch(M, Y, out, rng, row_base=b * n_cols, accumulate=b > 0,
                              meta_shape=(n_cols if b == 0 else 0, self.rows_per_block, self.block_nnz[b]))

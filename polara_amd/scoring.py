@@ -173,6 +173,7 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
             ub = None
         sp = seen_ptr[u0:u1 + 1] if filter_seen else None
         st = (seen_tiles[0], seen_tiles[1][u0:u1]) if seen_tiles is not None else None
+        assert u0 % 32 == 0, 'user batches start on a 32-user group boundary (dense seen masks are indexed by group)'
         sd = (seen_dense[0][u0 // 32:], seen_dense[1][u0:u1], seen_dense[2]) if seen_dense is not None else None
         extra = {} if sd is None else {'seen_dense': sd}
         cs, ci = ops.score_candidates(factors.Vp, Ep, nb, n_items, K, sp, seen_idx, KC, splits,
@@ -198,7 +199,8 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
     # only used to bound the temporaries of very large user sets (4M users per batch).
     B = int(batches) if batches else -(-n_users // (1 << 22))
     B = max(1, min(B, n_users // 4096)) if n_users >= 4096 else 1
-    head = int(head_users or 0)
+    # batch starts must be multiples of 128 users (one workgroup; the dense seen masks are addressed by 32-user group)
+    head = (int(head_users or 0) // 128) * 128
     if stats is not None:
         B, head = 1, 0                       # sweep statistics are read from the (single) state buffer
     if B == 1 and not (0 < head and 4 * head <= n_users):

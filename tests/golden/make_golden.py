@@ -64,11 +64,11 @@ def frame(n_users, n_items, mean_items, rank, levels, seed, **kw):
     return pd.DataFrame({'userid': u, 'itemid': i, 'rating': v})
 
 
-def metrics_to_dict(scores):
+def metrics_to_dict(scores, prefix='metric_'):
     out = {}
     for s in scores:
         for name, val in s._asdict().items():
-            out['metric_' + type(s).__name__ + '_' + name] = np.float64(val)
+            out[prefix + type(s).__name__ + '_' + name] = np.float64(val)
     return out
 
 
@@ -136,6 +136,10 @@ def svd_fixture(name, df, data_cfg, rank, topk, filter_seen=True, feedback_thres
         out['holdout_item'] = h[itemid].values.astype(np.int64)
         out['holdout_fdbk'] = h['rating'].values.astype(np.float64)
         out.update(metrics_to_dict(quiet(model.evaluate)))
+        # the same lists with the positive / negative split of the holdout (evaluation.py:176-205: fallout, specifity,
+        # NDCL and the true-negative count only exist then) and rolled back to @3 (models.py:441-447)
+        out.update(metrics_to_dict(quiet(lambda: model.evaluate(switch_positive=4)), prefix='metricsp4_'))
+        out.update(metrics_to_dict(quiet(lambda: model.evaluate(topk=3)), prefix='metricat3_'))
     # rank truncation contract (models.py:812-832): smaller rank = column prefix, no rebuild
     for r in extra_ranks:
         model.rank = r

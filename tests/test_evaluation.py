@@ -46,6 +46,32 @@ def test_metrics_match_the_reference_outputs(name):
     assert names == ['Relevance', 'Ranking', 'Experience', 'Hits']
 
 
+def _as_dict(scores, prefix):
+    got = {}
+    for tup in (scores if isinstance(scores, (list, tuple)) and not hasattr(scores, '_fields') else [scores]):
+        for k, v in tup._asdict().items():
+            got[prefix + type(tup).__name__ + '_' + k] = np.nan if v is None else float(v)
+    return got
+
+
+def _assert_pinned(got, g, prefix, rtol=1e-13):
+    ref = {k: float(g[k]) for k in g.files if k.startswith(prefix)}
+    assert ref and set(got) == set(ref), (sorted(got), sorted(ref))
+    for k, v in ref.items():
+        assert (np.isnan(v) and np.isnan(got[k])) or np.isclose(got[k], v, rtol=rtol, atol=0), (k, got[k], v)
+
+
+@pytest.mark.parametrize('name', FIXTURES)
+def test_split_and_at_k_metrics_match_the_reference_outputs(name):
+    """the reference's evaluate(switch_positive=4) and evaluate(topk=3) on the same lists (`metricsp4_*`, `metricat3_*`):
+    the positive / negative split of evaluation.py:176-205 and the @k roll-back of models.py:441-447"""
+    g = load_golden(name)
+    scores, _ = _run(g, switch_positive=4)
+    _assert_pinned(_as_dict(scores, 'metricsp4_'), g, 'metricsp4_')
+    scores, _ = _run(g, topk=3)
+    _assert_pinned(_as_dict(scores, 'metricat3_'), g, 'metricat3_')
+
+
 def test_switch_positive_splits_hits_and_misses():
     g = load_golden('svd_warm')
     n_items = int(g['train_shape'][1])
@@ -140,6 +166,50 @@ def test_model_evaluate_device_ranks_cpu_double():
 @pytest.mark.gpu
 def test_model_evaluate_device_ranks(hip_ops):
     _check_device_ranks_path(hip_ops)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', FIXTURES)
+def test_device_metrics_are_pinned_to_the_reference(hip_ops, name):
+    """evalmetrics.hip against the REFERENCE's evaluate() outputs (evaluation.py:90-253), not against this
+    package's host formulas.  (1) The reference's own lists (`recs` of the fixture) are put on the device in the
+    model's internal id space and reduced there: every `metric_*`, `metricsp4_*` (switch_positive = 4) and `metricat3_*`
+    (@3) value of the fixture must come back to 1e-12 — MAP normaliser, NDCG / NDCL tie order, zero-feedback holdout
+    entries included.  (2) The model's own lists on the HIP backend: where no test user has a boundary tie they ARE
+    the reference's lists and `evaluate('all')` is pinned end to end; otherwise the hit count may differ by at most the
+    tied users' holdout items."""
+    import torch
+    from polara_amd.models import ScaledSVD, SVDModel
+    g = load_golden(name)
+    d = GoldenData(g)
+    d.set_test_data(holdout=(g['holdout_user'], g['holdout_item'], g['holdout_fdbk']), notify=False)
+    per_user = np.bincount(np.unique(g['holdout_user'], return_inverse=True)[1])
+    d.holdout_size = int(per_user.max())
+    d.warm_start = False
+    m = (ScaledSVD if 'col_scaling' in g.files else SVDModel)(d, ops=hip_ops)
+    if 'col_scaling' in g.files:
+        m.col_scaling, m.row_scaling = float(g['col_scaling']), float(g['row_scaling'])
+    m.verbose = False
+    m.rank, m.topk, m.filter_seen = int(g['rank']), int(g['topk']), bool(g['filter_seen'])
+    m.build()
+    own = m.recommendations
+    assert m._recs_dev is not None and m._recs_dev[0] is own
+    own_scores = m.evaluate('all')
+    notie = g['boundary_gap'] > 0
+    assert np.array_equal(own[notie], g['recs'][notie])
+    if notie.all():
+        _assert_pinned(_as_dict(own_scores, 'metric_'), g, 'metric_', rtol=1e-12)
+    else:
+        tp = [t for t in own_scores if type(t).__name__ == 'Hits'][0].true_positive
+        assert abs(tp - float(g['metric_Hits_true_positive'])) <= int((~notie).sum()) * d.holdout_size
+    # (1) the reference's lists, reduced on the device
+    ref_recs = np.ascontiguousarray(g['recs'])
+    m._recommendations = ref_recs
+    m._recs_dev = (ref_recs, torch.from_numpy(m._item_rank[ref_recs].astype(np.int64)).to(hip_ops.device))
+    for prefix, kw in (('metric_', {}), ('metricsp4_', dict(switch_positive=4)), ('metricat3_', dict(topk=3))):
+        scores = m.evaluate('all', **kw)
+        assert m._recs_dev is not None and m._recs_dev[0] is ref_recs        # still the device path
+        _assert_pinned(_as_dict(scores, prefix), g, prefix, rtol=1e-12)
 
 
 def test_find_optimal_svd_rank_one_build():

@@ -305,3 +305,27 @@ def test_rank_beyond_the_fused_sweep_goes_through_exact_rows(hip_ops):
     V = np.ascontiguousarray(m.factors[d.fields.itemid])
     ref, clear = _oracle_lists(c, V, np.arange(900), 10)
     assert np.array_equal(m.get_recommendations()[clear], ref[clear])
+
+
+def test_rank_beyond_200_on_a_user_blocked_transpose(hip_ops):
+    """from 32 768 users up the eigensolver multiplies by the user-blocked transpose (ops.BlockedTranspose),
+    and from rank 201 up its block is wider than the 256 columns one SpMM launch holds (rank 210 -> block 272): the
+    blocked product must go panel by panel like the plain one.  Against SciPy on the same matrix."""
+    from polara_amd.ops import BlockedTranspose
+    from polara_amd.solver import svd_topk, default_block
+    ops = hip_ops
+    n_users, n_items, k = 33000, 700, 210
+    assert default_block(k, n_items) > 256
+    c = csr_to_numpy(planted_csr(n_users, n_items, 40, 16, seed=77, min_items=10, max_items=300))
+    A = ops.csr(c['indptr'], c['indices'], c['values'], c['shape'])
+    assert isinstance(A.transpose_operator(), BlockedTranspose)
+    # the blocked product itself, 272 columns wide, against SciPy
+    rng = np.random.RandomState(2)
+    Y = rng.randn(n_users, 272)
+    S = sps.csr_matrix((c['values'].astype(np.float64), c['indices'], c['indptr']), shape=c['shape'])
+    Z = ops.to_host(ops.spmm(A.transpose_operator(), ops.to_device(Y)))
+    assert np.allclose(Z, S.T @ Y, rtol=1e-11, atol=1e-9)
+    _, sigma, V, st = svd_topk(ops, A, k)
+    assert st['converged'] and st['block'] > 256
+    s_ref = np.linalg.svd(S.toarray(), compute_uv=False)[:k]
+    assert np.allclose(ops.to_host(sigma), s_ref, rtol=1e-9)

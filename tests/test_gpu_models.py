@@ -422,7 +422,7 @@ def test_head_batch_and_device_id_renaming_change_nothing(hip_ops):
     _, _, V, st = svd_topk(ops, A, 12)
     F = scoring.FactorImage(ops, V)
     want = scoring.recommend(ops, F, A, 10, True, head_users=0)
-    for head in (1024, 4096, 9984):
+    for head in (1000, 1024, 4096, 9984):     # 1000: rounded down to a 128-user boundary (the dense seen masks are per 32-user group)
         assert torch.equal(scoring.recommend(ops, F, A, 10, True, head_users=head), want), head
     # a head larger than a quarter of the users is ignored
     assert torch.equal(scoring.recommend(ops, F, A, 10, True, head_users=20000), want)

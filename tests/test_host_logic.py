@@ -397,3 +397,47 @@ def test_unconverged_build_raises_like_arpack():
     m.svd_max_outer = 200
     m.build()
     assert m.build_stats['converged'] and m.build_stats['final_rel_residual'] <= m.svd_tol
+
+
+def test_bench_compact_line_is_small_and_parses():
+    """the driver could not parse round 2's 25 KB stdout line.  bench.compact_line is a pure function of the
+    measurement record: on a canned record with every block present (and absurdly long free-text fields) the line stays
+    under 3 000 bytes, round-trips through json and carries the fields the driver and the judge read."""
+    import json
+    import bench
+    long_text = 'x' * 5000
+    head = {
+        'value': 158712345.678, 'ms_per_step': 0.87261234, 'latency_ms_per_pass': 1.1, 'workload': bench.WORKLOAD_TEXT['ml20m'] +
+        ', PureSVD rank=50, top-10, all users scored', 'n_users': 138493, 'n_items': 26744, 'nnz': 20000263, 'rank': 50,
+        'topk': 10, 'prune': True, 'launch': 'python, kernel by kernel ' + long_text, 'launch_short': 'python',
+        'launches_per_pass': 14, 'build_s': 0.0651234,
+        'build': {'solver_s': 0.052, 'gramian_steps': 37, 'converged': True, 'spmm_ms': 40.1, 'note': long_text},
+        'score': {'swept_fraction': 0.0946, 'kernel_ms': {'a': 1.0}},
+        'roofline': {'kernel': 'score_candidates_kernel', 'bound': 'mfma', 'dtype': 'bf16 (split product)', 'achieved': 363.2,
+                     'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': 0.1452, 'avg_ms': 0.1853, 'launches_per_pass': 2,
+                     'swept_fraction': 0.0946, 'traffic': 1.2e8, 'note': long_text},
+        'roofline_build': {'kernel': 'spmm_csr_groups_kernel', 'bound': 'hbm', 'achieved': 401.0, 'peak': 8000.0, 'unit': 'GB/s',
+                           'frac': 0.05, 'launches': 330, 'total_ms': 40.0, 'traffic': 1.64e9,
+                           'algorithmic_bytes_per_product': 2.16e8, 'gather_note': long_text},
+        'cpu_baseline': {'value': 9923.0, 'unit': 'users/s', 'cores': 128, 'kind': 'port', 'sample': long_text,
+                         'gpu_vs_cpu_identical_rows': 1.0, 'build_s': 21.3, 'build_whole_matrix': True,
+                         'speedup_scoring': 15994.0, 'speedup_build': 327.0, 'speedup_build_plus_score': 534.0},
+    }
+    line = bench.compact_line(head, 1, 20, 5, {'flat_norm': 44.9e6, 'pop25_norm': 80e6, 'no_prune': 60.7e6})
+    assert len(line) < 3000 and '\n' not in line
+    d = json.loads(line)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'build_s', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['steps'] == 20 and d['warmup'] == 5 and d['vs_baseline'] is None
+    assert d['config']['workload'].startswith('ML-20M') and d['config']['swept_fraction'] == 0.0946
+    assert set(d['config']['adversarial_users_per_s']) == {'flat_norm', 'pop25_norm', 'no_prune'}
+    assert {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'} <= set(d['roofline'])
+    assert {'value', 'unit', 'cores', 'kind', 'sample'} <= set(d['cpu_baseline']) and len(d['cpu_baseline']['sample']) <= 200
+    assert abs(d['roofline']['frac'] - d['roofline']['achieved'] / d['roofline']['peak']) < 1e-3
+    # no nested free text anywhere
+    assert long_text[:300] not in line
+    # a multi-GPU line (no cpu_baseline, no adversarial rows) has the same shape
+    head2 = {k: v for k, v in head.items() if k != 'cpu_baseline'}
+    d2 = json.loads(bench.compact_line(head2, 8, 20, 5, None, scale=1.0))
+    assert d2['n_gpus'] == 8 and 'cpu_baseline' not in d2 and 'users sharded over 8' in d2['config']['parallelism']
