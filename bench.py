@@ -446,7 +446,11 @@ class Bench:
             cand_ms = ms.get('score_candidates')
             flops = 2.0 * (hi - lo) * n_items * rank
             swept = stats['tiles_scored'] / max(stats['tiles_total'], 1)
-            n_chunk = int(ops.lib.pk_score_chunk_launches(n_items, rank, stats.get('item_splits', 1), 0, 1 if prune else 0))
+            tp = stats.get('two_phase')
+            if tp:      # head launch + the chunk launches of the seeded splits over the rest of the catalogue
+                n_chunk = 1 + int(ops.lib.pk_score_chunk_launches(n_items - 32 * tp['head_tiles'], rank, tp['splits'], 0, 1))
+            else:
+                n_chunk = int(ops.lib.pk_score_chunk_launches(n_items, rank, stats.get('item_splits', 1), 0, 1 if prune else 0))
             spmm_ms = events_ms(st['spmm_ev'])
             spmm_bytes = [spmm_alg_bytes(m) for _, _, m in st['spmm_ev']]
             bstats = st['bstats']
@@ -472,6 +476,7 @@ class Bench:
                           'flagged_users': stats.get('flagged_users'), 'refolded_users': stats.get('refolded_users'),
                           'candidate_capacity': stats.get('candidate_capacity'), 'item_splits': stats.get('item_splits'),
                           'swept_fraction': swept, 'exit_tile_quantiles': stats.get('exit_tile_quantiles'),
+                          'two_phase': stats.get('two_phase'),
                           'n_tiles': -(-n_items // 32)},
             }
             if catalogue == 'flat':

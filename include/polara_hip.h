@@ -220,7 +220,12 @@ int32_t pk_candidate_capacity(int32_t topk);
  * seen lists must be sorted ascending per user (CSR canonical form).
  * The item range is swept in chunks of `tiles_per_chunk` 32-item tiles, one launch per chunk, so the
  * packed item factors of a chunk stay resident in the 4 MiB per-XCD L2 while every workgroup streams
- * them; the per-user selection state is parked in `state_dev` between launches. */
+ * them; the per-user selection state is parked in `state_dev` between launches.
+ * Threshold bootstrap: a sweep that starts cold first scores its first 16 tiles WITHOUT selecting — every lane keeps the
+ * KC / 2 largest group maxima in a sorted register list — and starts from the smallest of a user's KC values, a lower
+ * bound of its final KC-th best score: a quarter of the pushes and flush sorts of a cold start (PK_SCORE_BOOT_TILES
+ * overrides; 0 = off).  Should such a sweep end without a full list, the last slot of the list holds idx -2 and
+ * pk_rescore_topk_* sends the user to the exact path. */
 int64_t pk_score_state_bytes(int64_t n_users, int32_t splits);
 /* recommended number of item splits for this many users (1 when the users alone fill the chip) */
 int32_t pk_score_splits(int64_t n_users, int32_t KC);
@@ -246,6 +251,30 @@ int pk_score_candidates_f32(void *stream, int64_t n_users, int64_t n_items, int3
                             const float *tile_bound_dev /* [ceil(n_items/32)] or NULL */,
                             const uint32_t *seen_dense_dev, const int32_t *seen_skip_dev,
                             int32_t dense_tiles /* pk_seen_dense_build output, or NULL, NULL, 0: the stream serves every tile */);
+/* The pruned sweep in TWO PHASES (replaces the same reference lines: the chunk loop body of models.py:359-371, with
+ * downvote_seen_items :494-519 and topsort :488-491 fused in).  A launch of the single sweep lasts as long as its slowest
+ * wave — the groups of the heaviest users stay ~270 tiles in the sweep, everybody else 70-130 — so the catalogue is
+ * cut: tiles [0, head_tiles) are swept once per group (lists + thresholds in slot 0), the remaining tiles are dealt
+ * round-robin to `splits` sweeps per group that all START from the head's threshold (a score below it cannot be among
+ * the KC best, whatever a split's own list holds), and the splits + 1 lists of a user are merged into ONE list of KC
+ * candidates with exact comparisons: the dependent chain of a group is head + tail / splits tiles at the same number
+ * of tile-waves.  The merged list is what pk_rescore_topk_* takes with splits = 1.
+ *   work_*   [(splits + 1)][n_users_pad][KC] raw lists;  cand_*  [n_users_pad][KC] merged;
+ *   state    pk_score_state_bytes(n_users, splits + 1): records of slot 0 = the head, slots 1.. = the splits (first int64
+ *            of a record: the tile at which the group left that sweep; a head exit below head_tiles means the group was
+ *            pruned inside the head and its splits did not run).
+ * pk_score_two_phase_plan: the default (head_tiles, splits) for a user set and a catalogue; head_tiles = 0: use the single
+ * sweep (user sets that fill the chip's wave slots on their own: there the sweep is bound by the work of the head tiles,
+ * not by its longest chain, and the scheme was measured slower). */
+int pk_score_two_phase_plan(int64_t n_users, int64_t n_items, int32_t KC, int32_t *head_tiles, int32_t *splits);
+int pk_score_two_phase_f32(void *stream, int64_t n_users, int64_t n_items, int32_t K,
+                           const float *Vp_dev, const float *Ep_dev,
+                           const int64_t *seen_ptr_dev, const uint64_t *seen_tiles_dev, const int32_t *seen_ntiles_dev,
+                           int32_t KC, int32_t head_tiles, int32_t splits /* (splits + 1) * KC <= 256 */,
+                           float *work_score_dev, int32_t *work_idx_dev, float *cand_score_dev, int32_t *cand_idx_dev,
+                           void *state_dev, int32_t tiles_per_chunk /* 0 = auto */,
+                           const float *user_bound_dev, const float *tile_bound_dev /* both required */,
+                           const uint32_t *seen_dense_dev, const int32_t *seen_skip_dev, int32_t dense_tiles);
 /* Dense seen masks for the first dense_tiles tiles of the catalogue — where the sweep spends its time, and where a user
  * has a record in nearly every tile: dense_dev[(u / 32 * dense_tiles + tile) * 32 + u % 32] = the user's 32-bit mask in
  * that tile (one coalesced 128-byte load per tile and wave instead of a cursor walk with a scattered 8-byte load per

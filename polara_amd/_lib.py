@@ -62,6 +62,9 @@ PROTOTYPES = {
     'pk_seen_tiles_max_unsorted_row': (_i32, []),
     'pk_score_candidates_f32': (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp,
                                           _i32, _vp, _vp, _vp, _vp, _i32]),
+    'pk_score_two_phase_plan': (C.c_int, [_i64, _i64, _i32, _vp, _vp]),
+    'pk_score_two_phase_f32': (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp,
+                                         _i32, _vp, _vp, _vp, _vp, _i32]),
     'pk_seen_dense_bytes': (_i64, [_i64, _i32]),
     'pk_seen_dense_build': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp]),
     'pk_score_chunk_launches': (_i32, [_i64, _i32, _i32, _i32, _i32]),

@@ -962,12 +962,27 @@ int serving_score(pk_ctx *ctx, pk_serving *sv, int32_t topk, int32_t filter_seen
         const int32_t *ntiles = filter_seen ? sv->ntiles.as<int32_t>() : nullptr;
         int splits = ((n_users + 31) / 32) * 8 > 2048 ? 1 : pk_score_splits(n_users, KC);
         const int64_t n_pad = ((n_users + 31) / 32) * 32;
-        Dev state((size_t)pk_score_state_bytes(n_users, splits)), cs((size_t)splits * n_pad * KC * 4), ci((size_t)splits * n_pad * KC * 4);
-        if (!state.p || !cs.p || !ci.p) return fail(ctx, PK_E_LAUNCH, "out of device memory (candidates)");
-        CK(pk_score_candidates_f32(st, n_users, n_items, K, sv->Vp.as<float>(), Ep.as<float>(), seen_ptr, tiles, ntiles,
-                                   KC, splits, cs.as<float>(), ci.as<int32_t>(), state.p, 0, ub.as<float>(), sv->tile_bound.as<float>(),
-                                   (filter_seen && sv->dense_tiles) ? sv->dense.as<uint32_t>() : nullptr,
-                                   (filter_seen && sv->dense_tiles) ? sv->skip.as<int32_t>() : nullptr, filter_seen ? sv->dense_tiles : 0));
+        // user sets that leave wave slots idle: head sweep + item splits seeded with its thresholds + merge (scoring.py)
+        int32_t head_tiles = 0, splits2 = 0;
+        CK(pk_score_two_phase_plan(n_users, n_items, KC, &head_tiles, &splits2));
+        const int slots = head_tiles ? splits2 + 1 : splits;
+        Dev state((size_t)pk_score_state_bytes(n_users, slots)), cs((size_t)slots * n_pad * KC * 4), ci((size_t)slots * n_pad * KC * 4);
+        Dev ms(head_tiles ? (size_t)n_pad * KC * 4 : 0), mi(head_tiles ? (size_t)n_pad * KC * 4 : 0);
+        if (!state.p || !cs.p || !ci.p || (head_tiles && (!ms.p || !mi.p))) return fail(ctx, PK_E_LAUNCH, "out of device memory (candidates)");
+        const uint32_t *dense_p = (filter_seen && sv->dense_tiles) ? sv->dense.as<uint32_t>() : nullptr;
+        const int32_t *skip_p = (filter_seen && sv->dense_tiles) ? sv->skip.as<int32_t>() : nullptr;
+        if (head_tiles) {
+            CK(pk_score_two_phase_f32(st, n_users, n_items, K, sv->Vp.as<float>(), Ep.as<float>(), seen_ptr, tiles, ntiles, KC, head_tiles,
+                                      splits2, cs.as<float>(), ci.as<int32_t>(), ms.as<float>(), mi.as<int32_t>(), state.p, 0, ub.as<float>(),
+                                      sv->tile_bound.as<float>(), dense_p, skip_p, filter_seen ? sv->dense_tiles : 0));
+            std::swap(cs, ms);      // the merged list is what the re-scoring takes: one list per user
+            std::swap(ci, mi);
+            splits = 1;
+        } else {
+            CK(pk_score_candidates_f32(st, n_users, n_items, K, sv->Vp.as<float>(), Ep.as<float>(), seen_ptr, tiles, ntiles,
+                                       KC, splits, cs.as<float>(), ci.as<int32_t>(), state.p, 0, ub.as<float>(), sv->tile_bound.as<float>(),
+                                       dense_p, skip_p, filter_seen ? sv->dense_tiles : 0));
+        }
         CK(pk_rescore_topk_rows_f64(st, n_users, nullptr, nullptr, n_users, n_items, K, V.p(), K, approx ? sv->V32.as<float>() : nullptr, approx ? ld32 : 0,
                                     Ex.p(), Kx, w, approx ? Kx : 0, 0, seen_ptr, KC, splits, cs.as<float>(), ci.as<int32_t>(), topk, vmax,
                                     out_i.as<int64_t>(), out_s.as<double>(), flags.as<int32_t>()));

@@ -213,10 +213,14 @@ __global__ __launch_bounds__(256) void rescore_topk_kernel(
     int idx = -1;
     if (live && t < KC * splits) idx = cand_idx[((int64_t)(t / KC) * n_pad + user) * KC + (t % KC)];
     double tau32 = -INFINITY;   // bound on the fp32 score of every NON-candidate item
+    bool unbounded = false;     // a sweep that started from a bootstrapped threshold ended without a full list (score.hip:
+                                // PK_IDX_FLOOR = -2 in the last slot): no bound on the items it left out -> exact path
     for (int h = 0; h < splits; ++h) {
         // a full list may have left items of its range out: they score at most its KC-th entry
         const int64_t last = ((int64_t)h * n_pad + urow) * KC + KC - 1;
-        if (cand_idx[last] >= 0) tau32 = fmax(tau32, (double)cand_score[last]);
+        const int li = cand_idx[last];
+        if (li >= 0) tau32 = fmax(tau32, (double)cand_score[last]);
+        else if (li == -2) unbounded = true;
     }
 
     const double *vr = V + (int64_t)(idx >= 0 ? idx : 0) * ldv;
@@ -275,6 +279,8 @@ __global__ __launch_bounds__(256) void rescore_topk_kernel(
     }
     if (n_items - n_seen < topk) {
         flag |= 2;  // seen items must re-enter the list: exact path
+    } else if (unbounded) {
+        flag |= 1;
     } else if (tau32 > -INFINITY) {
         // the sweep's split-bf16 product (score.hip): |s32 - e.v| <= (3 * 2^-16 + (4 K + 10) * 2^-23) |e||v| — operands
         // split into two bf16 each, the lo.lo term dropped, fp32 conversion of the inputs, accumulation roundings

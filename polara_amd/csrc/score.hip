@@ -44,7 +44,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #ifdef PK_SCORE_PROFILE
 // tuning builds only: wave-cycles spent in [0] whole kernel, [1] flushes, [2] seen-list walk, [3] push path,
-// [4] prologue (state restore), [5] epilogue; [6] flush count, [7] tiles
+// [4] prologue (state restore), [5] threshold bootstrap; [6] flush count, [7] tiles
 __device__ unsigned long long pk_prof[8];
 extern "C" int pk_debug_profile(unsigned long long *out, int reset) {
     if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(pk_prof), sizeof(pk_prof));
@@ -67,6 +67,7 @@ extern "C" int pk_debug_profile(unsigned long long *out, int reset) {
 #define PROF_FLUSH() do { } while (0)
 #endif
 #define PK_IDX_NONE 0x7fffffff
+#define PK_IDX_FLOOR (-2)       // last slot of a list: "not full although the sweep started from a threshold" (see the kernel's end)
 #define PK_TILE_NONE 0xffffffff00000000ull   // end of a seen-tile stream
 
 // Wave-wide key-only bitonic sort (descending) of 64*SLOTS 32-bit keys, element index i = lane + 64*slot.
@@ -197,7 +198,8 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
     const int32_t *__restrict__ seen_ntiles,
     float *__restrict__ cand_score, int32_t *__restrict__ cand_idx,
     LaneState *__restrict__ st_lane, uint2 *__restrict__ st_ring,
-    const float *__restrict__ user_bound, const float *__restrict__ tile_bound, int ablate, SeenDense dense) {
+    const float *__restrict__ user_bound, const float *__restrict__ tile_bound, int ablate, SeenDense dense,
+    int tile_base, int slot_base, const LaneState *__restrict__ floor_state, int boot_tiles) {
     constexpr int KQ = 2 * NSTEP;   // 16-byte groups per lane and tile: (hi, lo) x 8 bf16 for every 16-wide k-step
     // KC == 16: rings of 8, so that a user's list + both rings are 32 entries and TWO users are merged
     // per flush, one in each half of the wave (15 sort stages per two users instead of 21 per user).
@@ -234,7 +236,14 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
     const int split = STRIDED ? (int)blockIdx.y : 0;
     const int S = STRIDED ? (int)gridDim.y : 1;
     const int64_t n_groups = (n_users + 31) / 32;
-    const int t_lo = split;
+    // Two-phase sweep (pk_score_two_phase_f32): a first launch sweeps the head of the catalogue, tiles [0, tile_base), for
+    // every group as a single sweep (this kernel with n_tiles = tile_base; lists and thresholds land in slot 0); the
+    // splits of the second phase own the tiles tile_base + h, tile_base + h + S, ... and START from the head's threshold
+    // (`floor_state` = the head's parked lane records): a score below it cannot be among the user's KC best whatever
+    // the split's own list holds, so a split's tau = max(head tau, its own KC-th best) and its list only receives what
+    // beats the head's list.  The dependent chain of a group is head + tail / S tiles instead of head + tail at the same
+    // number of tile-waves (tools/probes/two_phase_study.py); the S + 1 lists are merged by merge_candidates_kernel.
+    const int t_lo = tile_base + split;
     const int tile_begin = t_lo + chunk_begin * S;
     const int tile_stop = (chunk_begin + chunk_tiles < split_tiles) ? t_lo + (chunk_begin + chunk_tiles) * S : n_tiles;
     const int tile_end = (tile_stop < n_tiles) ? tile_stop : n_tiles;   // tiles tile_begin, +S, ... < tile_end
@@ -244,7 +253,7 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
 
     const int ul = lane & 31, hi = lane >> 5;
     const int64_t user = group * 32 + ul;
-    const int64_t slot = (int64_t)split * n_groups + group;
+    const int64_t slot = (int64_t)(slot_base + split) * n_groups + group;
     float *my_score = cand_score + slot * 32 * KC;  // this wave's [32][KC] top lists of this split
     int32_t *my_idx = cand_idx + slot * 32 * KC;
 
@@ -269,11 +278,35 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
     }
     LaneState *my_state = st_lane + slot * 64 + lane;
     uint2 *my_ring_state = st_ring + slot * (RING * 64);
+    float tau_floor = -INFINITY;
+    if constexpr (STRIDED) {
+        if (floor_state) {
+            const LaneState fs = floor_state[group * 64 + lane];     // the head sweep's record of my user (slot 0)
+            if ((int)fs.sp < tile_base) {
+                // the group was pruned INSIDE the head (wave-uniform: every lane of the head wave wrote its exit tile):
+                // nothing beyond it can enter its lists — this split's list stays empty
+                if (first) {
+                    for (int s = lane; s < 32 * KC; s += 64) {
+                        my_score[s] = -INFINITY;
+                        my_idx[s] = -1;
+                    }
+                    LaneState ls;
+                    ls.sp = fs.sp;
+                    ls.tau = fs.tau;
+                    ls.cnt = PK_LANE_DONE;
+                    *my_state = ls;
+                }
+                return;
+            }
+            tau_floor = fs.tau;
+            tau = tau_floor;
+        }
+    }
     const int dense_tiles = (DENSE && seen_ptr != nullptr) ? dense.tiles : 0;
     const unsigned *dense_row = dense_tiles ? dense.mask + ((int64_t)group * dense_tiles) * 32 + ul : nullptr;
     if (DENSE && first && has_seen && dense_tiles) sp += dense.skip[user];   // those tiles are served by the dense masks
     if (first) {
-        if (has_seen && t_lo > 0) {
+        if (has_seen && t_lo > 0 && !(DENSE && dense_tiles >= t_lo)) {   // (behind the dense window the cursor already is)
             // skip the records before this split's first tile: lower_bound(tile >= t_lo)
             int64_t lo = sp, hi_ = se;
             while (lo < hi_) {
@@ -298,6 +331,7 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
             for (int s = lane; s < 32 * KC; s += 64) top[s] = make_uint2(__float_as_uint(my_score[s]), (unsigned)my_idx[s]);
         if (has_seen) sp = ls.sp;
         tau = ls.tau;
+        tau_floor = fmaxf(tau_floor, tau);   // a threshold once reached stays a lower bound of the final KC-th best
         cnt = ls.cnt;
         const int cmax = __builtin_amdgcn_readfirstlane((int)__reduce_max_sync(~0ull, cnt));
         for (int i = 0; i < cmax; ++i) ring[i][lane] = my_ring_state[i * 64 + lane];
@@ -410,7 +444,7 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
         const float ntau = __int_as_float(
             __builtin_amdgcn_readlane(__float_as_int(key[(KC - 1) / 64]), (KC - 1) & 63));
         if (ul == x) {
-            tau = ntau;
+            tau = fmaxf(ntau, tau_floor);
             cnt = 0;
         }
         __builtin_amdgcn_wave_barrier();
@@ -458,11 +492,11 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
         const float tx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(k), KC - 1));
         const float ty = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(k), 32 + KC - 1));
         if (ul == x) {
-            tau = tx;
+            tau = fmaxf(tx, tau_floor);
             cnt = 0;
         }
         if (y >= 0 && ul == y) {
-            tau = ty;
+            tau = fmaxf(ty, tau_floor);
             cnt = 0;
         }
         __builtin_amdgcn_wave_barrier();
@@ -565,6 +599,80 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
             }
         }
     };
+    // ---- threshold bootstrap ---------------------------------------------------------------------------------------
+    // A cold threshold makes the first tiles of a sweep the expensive ones: nearly every score is pushed, the rings fill
+    // and the flush sorts run (ML-20M-shaped: 75 of a user's 90 pushes and almost all of its ~7 flushes fall into the
+    // first 8 tiles; the 32-tile head took 242 of the sweep's 368 us, profiles/r03_trace_pass_*).  So the first
+    // `boot_tiles` tiles are scored once WITHOUT any selection: every lane keeps the KC / 2 largest of the maxima of
+    // KC / 8 groups of its 16 scores per tile in a sorted register list (branch-free insertion: a v_max + v_min per
+    // list entry and value).  The KC values of a user's two lanes belong to KC different unseen items, so the smallest
+    // of them is a lower bound of the user's final KC-th best score: the sweep
+    // then starts from that threshold (just below it, so that those items themselves are pushed and the list fills) and
+    // re-scores the same tiles — 12 MFMAs each — pushing a quarter of what it pushed from a cold start
+    // (tools/probes/warmup_study.py: 27 instead of 86-92 pushes, 1.6 instead of 6-7 flushes per user at 16 tiles).
+    if (first && boot_tiles > 0 && floor_state == nullptr && !(ablate & 8)) {
+        const unsigned long long prof_b0 = PROF_T();
+        constexpr int BL = KC / 2;      // values kept per lane: the user's two lanes hold KC of them
+        constexpr int BG = KC / 8;      // groups a lane's 16 scores of a tile are cut into (2, 4, 8): BL values after 4 tiles
+        float bl[BL];
+#pragma unroll
+        for (int i = 0; i < BL; ++i) bl[i] = -INFINITY;
+        const int64_t sp0 = sp;
+        const unsigned long long n0 = nxt, n1 = nxt2, n2 = nxt3;
+        float4 a_nxt[KQ];
+        load_frags((tile_begin < n_tiles) ? tile_begin : 0, a_nxt);
+        unsigned m_nxt = 0u;
+        if constexpr (DENSE) m_nxt = (tile_begin < dense_tiles) ? dense_row[(int64_t)tile_begin * 32] : 0u;
+        for (int i = 0, tile = tile_begin; i < boot_tiles && tile < tile_end; ++i, tile += S) {
+            float4 a[KQ];
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) a[q] = a_nxt[q];
+            load_frags((tile + S < tile_end) ? tile + S : tile, a_nxt);
+            if constexpr (DENSE) {
+                m_dense = m_nxt;
+                m_nxt = (tile + S < dense_tiles) ? dense_row[(int64_t)(tile + S) * 32] : 0u;
+            }
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+            for (int sidx = 0; sidx < NSTEP; ++sidx) {     // the SAME instruction sequence as the sweep below: the same bits
+                const bf16x8 vh = __builtin_bit_cast(bf16x8, a[2 * sidx]), vl = __builtin_bit_cast(bf16x8, a[2 * sidx + 1]);
+                const bf16x8 eh = __builtin_bit_cast(bf16x8, e[2 * sidx]), el = __builtin_bit_cast(bf16x8, e[2 * sidx + 1]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, eh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, el, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, eh, acc, 0, 0, 0);
+            }
+            const unsigned m2 = walk_mask(tile) >> (4 * hi);
+#pragma unroll
+            for (int g = 0; g < BG; ++g) {
+                float x = -INFINITY;
+#pragma unroll
+                for (int r = g * (16 / BG); r < (g + 1) * (16 / BG); ++r)
+                    x = fmaxf(x, (m2 & (1u << ((r & 3) + 8 * (r >> 2)))) ? -INFINITY : acc[r]);
+#pragma unroll
+                for (int i2 = 0; i2 < BL; ++i2) {      // sorted insertion, descending
+                    const float up = fmaxf(bl[i2], x);
+                    x = fminf(bl[i2], x);
+                    bl[i2] = up;
+                }
+            }
+        }
+        // the (KC / 2)-th value of each lane: together at least KC items of the user score that much
+        float t0 = bl[KC / 2 - 1];
+        t0 = fminf(t0, __int_as_float(pk_lane_xor<32>(__float_as_int(t0))));
+        if (t0 > -INFINITY) {
+            // strictly below it: the items that define it must pass the `score > tau` test of the sweep
+            t0 = fminf(t0 - fabsf(t0) * 2.4e-7f, t0 - 1e-37f);
+            tau_floor = fmaxf(tau_floor, t0);
+            tau = fmaxf(tau, tau_floor);
+        }
+        sp = sp0;
+        nxt = n0;
+        nxt2 = n1;
+        nxt3 = n2;
+        PROF_ADD(5, prof_b0);
+    }
     {
         // One tile per iteration; the fragments of the NEXT tile are requested before this tile's
         // MFMAs so their L2 latency hides behind them.  MFMA/epilogue overlap comes from the other
@@ -681,13 +789,25 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
         const unsigned long long some = __ballot(cnt > 0);
         flush_set((unsigned)(some | (some >> 32)));
     }
+    // A sweep that started from a bootstrapped threshold must end with a FULL list (at least KC items beat that threshold,
+    // and the sweep re-computes their scores with the same instructions).  Should it ever not — the bound "every
+    // non-candidate scores at most the KC-th entry" would silently not hold — the last slot says so (PK_IDX_FLOOR) and
+    // the re-scoring kernel sends the user to the exact path.
+    const unsigned long long floored = (floor_state == nullptr) ? __ballot(tau_floor > -INFINITY) : 0ull;   // bit x: user x
     if (TOP_LDS) {
         __builtin_amdgcn_wave_barrier();
         for (int s = lane; s < 32 * KC; s += 64) {
             const uint2 r = top[s];
+            int iv = (int)r.y;
+            if ((s % KC) == KC - 1 && iv < 0 && ((floored >> (s / KC)) & 1ull)) iv = PK_IDX_FLOOR;
             my_score[s] = __uint_as_float(r.x);
-            my_idx[s] = (int)r.y;
+            my_idx[s] = iv;
         }
+    } else if (floored) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (hi == 0 && tau_floor > -INFINITY && my_idx[ul * KC + KC - 1] < 0) my_idx[ul * KC + KC - 1] = PK_IDX_FLOOR;
     }
     PROF_INC(7, (exit_tile - tile_begin + S - 1) / S);
     PROF_ADD(0, prof_k0);
@@ -1091,21 +1211,32 @@ extern "C" int32_t pk_candidate_capacity(int32_t topk) {
 // tile) stays L2-resident while every resident workgroup sweeps it.
 #define PK_CHUNK_BYTES (2560 * 1024)
 
+// where a launch sequence sits in a two-phase sweep (all zero / null: the plain sweep)
+struct SweepPhase {
+    int tile_base;                  // first tile of the range the splits deal out (phase 2), else 0
+    int slot_base;                  // first list / state slot of this launch sequence (phase 2: 1, the head owns slot 0)
+    const LaneState *floor_state;   // phase 2: the head's lane records (threshold to start from), else nullptr
+    int boot_tiles;                 // tiles of the threshold bootstrap in front of a sweep that starts cold (0: none)
+};
+
 template <int NSTEP>
 static int launch_candidates_n(hipStream_t st, int KC, int ablate, dim3 grid, const float4 *Vp, const float4 *Ep,
                                int64_t n_users, int n_items, int n_tiles, int split_tiles, int tiles_per_chunk,
                                const int64_t *seen_ptr, const unsigned long long *seen_tiles,
                                const int32_t *seen_ntiles, float *cs, int32_t *ci,
                                LaneState *st_lane, uint2 *st_ring, const float *user_bound, const float *tile_bound,
-                               SeenDense dense) {
+                               SeenDense dense, SweepPhase ph) {
     // Item chunks: tiles_per_chunk each while every group sweeps (the chunk's packed image stays in L2);
     // with pruning, groups leave the sweep early, so the chunks DOUBLE from launch to launch — the catalogue
     // is covered in O(log) launches and the few groups still sweeping late (low bandwidth demand) are not
     // cut into hundreds of launches (rank 200: 100-tile chunks, 157 launches for 500K items otherwise).
-    // the dense seen masks: single-sweep instances up to rank 128 (with item splits or beyond that rank the stream serves
-    // every tile; a dense request is then simply not used — the stream cursor starts at the user's first record)
-    const bool use_dense = dense.tiles > 0 && NSTEP <= 8 && grid.y == 1;
+    // the dense seen masks: instances up to rank 128 — the single sweep, and the splits of a two-phase sweep (independent
+    // item splits and higher ranks let the stream serve every tile; a dense request is then simply not used — the stream
+    // cursor starts at the user's first record)
+    constexpr bool DENSE_OK = (NSTEP <= 8);
+    const bool use_dense = dense.tiles > 0 && DENSE_OK && (grid.y == 1 || ph.floor_state != nullptr);
     const SeenDense no_dense{nullptr, nullptr, 0};
+    const SeenDense dn = use_dense ? dense : no_dense;
     int chunk_tiles = tiles_per_chunk;
     for (int chunk_begin = 0; chunk_begin < split_tiles; chunk_begin += chunk_tiles, chunk_tiles = (user_bound ? 2 * chunk_tiles : chunk_tiles)) {
 #define PK_LAUNCH(KCV)                                                                                          \
@@ -1116,7 +1247,7 @@ static int launch_candidates_n(hipStream_t st, int KC, int ablate, dim3 grid, co
                                                 hipFuncAttributeMaxDynamicSharedMemorySize,                     \
                                                 (int)pk_score_lds_bytes(NSTEP, KCV));                           \
             if (e1 == hipSuccess)                                                                               \
-                e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&score_candidates_kernel<NSTEP, KCV, true, false>), \
+                e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&score_candidates_kernel<NSTEP, KCV, true, DENSE_OK>), \
                                          hipFuncAttributeMaxDynamicSharedMemorySize,                            \
                                          (int)pk_score_lds_bytes(NSTEP, KCV));                                  \
             if (e1 != hipSuccess) {                                                                             \
@@ -1126,18 +1257,18 @@ static int launch_candidates_n(hipStream_t st, int KC, int ablate, dim3 grid, co
             attr_set = true;                                                                                    \
         }                                                                                                       \
     }                                                                                                           \
-    if (grid.y > 1)                                                                                             \
-        hipLaunchKernelGGL((score_candidates_kernel<NSTEP, KCV, true, false>), grid, dim3(256), pk_score_lds_bytes(NSTEP, KCV), st, Vp, Ep, n_users, \
+    if (grid.y > 1 || ph.floor_state != nullptr)                                                                \
+        hipLaunchKernelGGL((score_candidates_kernel<NSTEP, KCV, true, DENSE_OK>), grid, dim3(256), pk_score_lds_bytes(NSTEP, KCV), st, Vp, Ep, n_users, \
                            n_items, n_tiles, split_tiles, chunk_begin, chunk_tiles, seen_ptr, seen_tiles, seen_ntiles, cs, ci, st_lane, st_ring,  \
-                           user_bound, tile_bound, ablate, no_dense);                                           \
+                           user_bound, tile_bound, ablate, dn, ph.tile_base, ph.slot_base, ph.floor_state, ph.boot_tiles); \
     else if (use_dense)                                                                                         \
-        hipLaunchKernelGGL((score_candidates_kernel<NSTEP, KCV, false, (NSTEP <= 8)>), grid, dim3(256), pk_score_lds_bytes(NSTEP, KCV), st, Vp, Ep, n_users, \
+        hipLaunchKernelGGL((score_candidates_kernel<NSTEP, KCV, false, DENSE_OK>), grid, dim3(256), pk_score_lds_bytes(NSTEP, KCV), st, Vp, Ep, n_users, \
                            n_items, n_tiles, split_tiles, chunk_begin, chunk_tiles, seen_ptr, seen_tiles, seen_ntiles, cs, ci, st_lane, st_ring,  \
-                           user_bound, tile_bound, ablate, dense);                                              \
+                           user_bound, tile_bound, ablate, dn, 0, ph.slot_base, nullptr, ph.boot_tiles);        \
     else                                                                                                        \
         hipLaunchKernelGGL((score_candidates_kernel<NSTEP, KCV, false, false>), grid, dim3(256), pk_score_lds_bytes(NSTEP, KCV), st, Vp, Ep, n_users, \
                            n_items, n_tiles, split_tiles, chunk_begin, chunk_tiles, seen_ptr, seen_tiles, seen_ntiles, cs, ci, st_lane, st_ring,  \
-                           user_bound, tile_bound, ablate, no_dense)
+                           user_bound, tile_bound, ablate, no_dense, 0, ph.slot_base, nullptr, ph.boot_tiles)
 #ifdef PK_FAST_BUILD
         if (KC != 16) return PK_E_UNSUPPORTED;
         PK_LAUNCH(16);
@@ -1199,38 +1330,26 @@ extern "C" int32_t pk_score_chunk_launches(int64_t n_items, int32_t K, int32_t s
     return n;
 }
 
-extern "C" int pk_score_candidates_f32(void *stream, int64_t n_users, int64_t n_items, int32_t K,
-                                       const float *Vp_dev, const float *Ep_dev, const int64_t *seen_ptr_dev,
-                                       const uint64_t *seen_tiles_dev, const int32_t *seen_ntiles_dev,
-                                       int32_t KC, int32_t splits,
-                                       float *cand_score_dev, int32_t *cand_idx_dev, void *state_dev,
-                                       int32_t tiles_per_chunk, const float *user_bound_dev,
-                                       const float *tile_bound_dev, const uint32_t *seen_dense_dev,
-                                       const int32_t *seen_skip_dev, int32_t dense_tiles) {
-    PK_REQUIRE(n_users >= 1 && n_items >= 1 && n_items < 0x7fffff00LL, "pk_score_candidates_f32: bad sizes");
-    PK_REQUIRE(dense_tiles >= 0 && (dense_tiles == 0 || (seen_dense_dev && seen_skip_dev && seen_ptr_dev)),
-               "pk_score_candidates_f32: dense seen masks need seen_dense, seen_skip and the seen-tile stream");
+// one launch sequence (item chunks) of the candidate sweep over the lists / state slots [ph.slot_base, ph.slot_base + splits)
+static int pk_sweep_launches(hipStream_t st, int64_t n_users, int64_t n_items, int n_tiles, int32_t K, const float *Vp_dev,
+                             const float *Ep_dev, const int64_t *seen_ptr_dev, const uint64_t *seen_tiles_dev,
+                             const int32_t *seen_ntiles_dev, int32_t KC, int32_t splits, int32_t total_slots,
+                             float *cand_score_dev, int32_t *cand_idx_dev, void *state_dev, int32_t tiles_per_chunk,
+                             const float *user_bound_dev, const float *tile_bound_dev, SeenDense dense, SweepPhase ph) {
     const int kq = pk_pack_kq(K);
     const int nstep = pk_nstep(K);
-    PK_REQUIRE(kq > 0, "pk_score_candidates_f32: K=%d unsupported (K <= 256)", K);
-    PK_REQUIRE(((uintptr_t)Vp_dev % 16) == 0 && ((uintptr_t)Ep_dev % 16) == 0, "pk_score_candidates_f32: alignment");
-    PK_REQUIRE(state_dev != nullptr && ((uintptr_t)state_dev % 16) == 0, "pk_score_candidates_f32: state buffer");
-    PK_REQUIRE(splits >= 1 && splits * KC <= 64, "pk_score_candidates_f32: need 1 <= splits and splits*KC <= 64");
-    PK_REQUIRE((seen_ptr_dev == nullptr) == (seen_tiles_dev == nullptr) &&
-                   (seen_ptr_dev == nullptr) == (seen_ntiles_dev == nullptr),
-               "pk_score_candidates_f32: seen_ptr, seen_tiles, seen_ntiles go together (all or none)");
-    PK_REQUIRE((user_bound_dev == nullptr) == (tile_bound_dev == nullptr),
-               "pk_score_candidates_f32: user_bound and tile_bound go together (both or neither)");
-    hipStream_t st = pk_stream(stream);
-    const int n_tiles = (int)pk_ceil_div(n_items, 32);
     const int64_t groups = pk_ceil_div(n_users, 32);
-    const int split_tiles = (int)pk_ceil_div(n_tiles, splits);
+    const int split_tiles = (int)pk_ceil_div(n_tiles - ph.tile_base, splits);
     if (tiles_per_chunk <= 0) {
         tiles_per_chunk = PK_CHUNK_BYTES / (kq * 1024) / splits;   // the S chunks of a launch share the L2
         if (tiles_per_chunk < 8) tiles_per_chunk = 8;
     }
     LaneState *st_lane = static_cast<LaneState *>(state_dev);
-    uint2 *st_ring = reinterpret_cast<uint2 *>(st_lane + groups * splits * 64);
+    uint2 *st_ring = reinterpret_cast<uint2 *>(st_lane + groups * total_slots * 64);
+    if (ph.floor_state) ph.floor_state = st_lane;      // the head's records: slot 0
+    // threshold bootstrap in front of every sweep that starts cold: 16 tiles (PK_SCORE_BOOT_TILES overrides, 0 = off)
+    const char *boot_env = getenv("PK_SCORE_BOOT_TILES");
+    ph.boot_tiles = ph.floor_state ? 0 : (boot_env ? atoi(boot_env) : 16);
     dim3 grid((unsigned)pk_ceil_div(groups, 4), (unsigned)splits);
     const float4 *Vp = reinterpret_cast<const float4 *>(Vp_dev);
     const float4 *Ep = reinterpret_cast<const float4 *>(Ep_dev);
@@ -1241,11 +1360,10 @@ extern "C" int pk_score_candidates_f32(void *stream, int64_t n_users, int64_t n_
                                     split_tiles, tiles_per_chunk, seen_ptr_dev,                                   \
                                     reinterpret_cast<const unsigned long long *>(seen_tiles_dev), seen_ntiles_dev, \
                                     cand_score_dev, cand_idx_dev,                                              \
-                                    st_lane, st_ring, user_bound_dev, tile_bound_dev, dense);                  \
+                                    st_lane, st_ring, user_bound_dev, tile_bound_dev, dense, ph);              \
         break;
     const char *abl_env = getenv("PK_SCORE_ABLATE");   // kernel-tuning knob, never set in production
     const int ablate = abl_env ? atoi(abl_env) : 0;
-    SeenDense dense{seen_dense_dev, seen_skip_dev, seen_ptr_dev ? dense_tiles : 0};
     switch (nstep) {
 #ifdef PK_FAST_BUILD
         PK_N_CASE(4)
@@ -1266,5 +1384,219 @@ extern "C" int pk_score_candidates_f32(void *stream, int64_t n_users, int64_t n_
 #undef PK_N_CASE
     if (rc != PK_OK) return rc;
     PK_CHECK_LAUNCH("score_candidates_kernel");
+    return PK_OK;
+}
+
+static int pk_score_check_args(const char *who, int64_t n_users, int64_t n_items, int32_t K, const float *Vp_dev,
+                               const float *Ep_dev, const int64_t *seen_ptr_dev, const uint64_t *seen_tiles_dev,
+                               const int32_t *seen_ntiles_dev, void *state_dev, const float *user_bound_dev,
+                               const float *tile_bound_dev, const uint32_t *seen_dense_dev, const int32_t *seen_skip_dev,
+                               int32_t dense_tiles) {
+    PK_REQUIRE(n_users >= 1 && n_items >= 1 && n_items < 0x7fffff00LL, "%s: bad sizes", who);
+    PK_REQUIRE(dense_tiles >= 0 && (dense_tiles == 0 || (seen_dense_dev && seen_skip_dev && seen_ptr_dev)),
+               "%s: dense seen masks need seen_dense, seen_skip and the seen-tile stream", who);
+    PK_REQUIRE(pk_pack_kq(K) > 0, "%s: K=%d unsupported (K <= 256)", who, K);
+    PK_REQUIRE(((uintptr_t)Vp_dev % 16) == 0 && ((uintptr_t)Ep_dev % 16) == 0, "%s: alignment", who);
+    PK_REQUIRE(state_dev != nullptr && ((uintptr_t)state_dev % 16) == 0, "%s: state buffer", who);
+    PK_REQUIRE((seen_ptr_dev == nullptr) == (seen_tiles_dev == nullptr) &&
+                   (seen_ptr_dev == nullptr) == (seen_ntiles_dev == nullptr),
+               "%s: seen_ptr, seen_tiles, seen_ntiles go together (all or none)", who);
+    PK_REQUIRE((user_bound_dev == nullptr) == (tile_bound_dev == nullptr),
+               "%s: user_bound and tile_bound go together (both or neither)", who);
+    return PK_OK;
+}
+
+extern "C" int pk_score_candidates_f32(void *stream, int64_t n_users, int64_t n_items, int32_t K,
+                                       const float *Vp_dev, const float *Ep_dev, const int64_t *seen_ptr_dev,
+                                       const uint64_t *seen_tiles_dev, const int32_t *seen_ntiles_dev,
+                                       int32_t KC, int32_t splits,
+                                       float *cand_score_dev, int32_t *cand_idx_dev, void *state_dev,
+                                       int32_t tiles_per_chunk, const float *user_bound_dev,
+                                       const float *tile_bound_dev, const uint32_t *seen_dense_dev,
+                                       const int32_t *seen_skip_dev, int32_t dense_tiles) {
+    const int rc = pk_score_check_args("pk_score_candidates_f32", n_users, n_items, K, Vp_dev, Ep_dev, seen_ptr_dev,
+                                       seen_tiles_dev, seen_ntiles_dev, state_dev, user_bound_dev, tile_bound_dev,
+                                       seen_dense_dev, seen_skip_dev, dense_tiles);
+    if (rc != PK_OK) return rc;
+    PK_REQUIRE(splits >= 1 && splits * KC <= 64, "pk_score_candidates_f32: need 1 <= splits and splits*KC <= 64");
+    SeenDense dense{seen_dense_dev, seen_skip_dev, seen_ptr_dev ? dense_tiles : 0};
+    return pk_sweep_launches(pk_stream(stream), n_users, n_items, (int)pk_ceil_div(n_items, 32), K, Vp_dev, Ep_dev,
+                             seen_ptr_dev, seen_tiles_dev, seen_ntiles_dev, KC, splits, splits, cand_score_dev, cand_idx_dev,
+                             state_dev, tiles_per_chunk, user_bound_dev, tile_bound_dev, dense, SweepPhase{0, 0, nullptr, 0});
+}
+
+// ---- two-phase sweep -------------------------------------------------------------------------------------------------
+// The S + 1 candidate lists of a user (head + splits, work arrays [list][n_pad users][KC]) -> ONE list of the KC best, by
+// (score descending, item ascending) with exact comparisons: one wave per user, bitonic network over 64 * SLOTS >=
+// (S + 1) * KC elements.  The lists cover disjoint tiles, so no item appears twice.  What the merged list bounds: an item
+// no list kept scored at most the KC-th entry of the list that dropped it (or the head's, which every split starts from),
+// and the merged KC-th entry is at least each of those — the re-scoring kernel certifies against it as against the
+// list of a single sweep (same key-sort tolerance: the merge itself compares exactly).
+template <int SLOTS>
+__global__ __launch_bounds__(256) void merge_candidates_kernel(int64_t n_users, int64_t n_pad, int KC, int lists,
+                                                               const float *__restrict__ work_score,
+                                                               const int32_t *__restrict__ work_idx,
+                                                               float *__restrict__ out_score, int32_t *__restrict__ out_idx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t user = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (user >= n_pad) return;
+    float key[SLOTS];
+    int val[SLOTS];
+    const int total = lists * KC;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int i = lane + 64 * s;
+        key[s] = -INFINITY;
+        val[s] = PK_IDX_NONE;
+        if (i < total && user < n_users) {
+            const int64_t at = ((int64_t)(i / KC) * n_pad + user) * KC + (i % KC);
+            const int iv = work_idx[at];
+            if (iv >= 0) {
+                key[s] = work_score[at];
+                val[s] = iv;
+            }
+        }
+    }
+    // the common case: nothing beat the head's list in the tail (ML-20M-shaped: 0.1 pushes per user beyond tile 32) — the
+    // head's list goes out as it is (the re-scoring kernel orders by exact scores and reads the bound from the last slot,
+    // exactly as it does for the list a single sweep leaves)
+    bool extra = false;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) extra = extra || (lane + 64 * s >= KC && val[s] != PK_IDX_NONE);
+    if (!__any(extra)) {
+        if (lane < KC) {
+            out_score[user * KC + lane] = (user < n_users) ? work_score[user * KC + lane] : -INFINITY;
+            out_idx[user * KC + lane] = (user < n_users) ? work_idx[user * KC + lane] : -1;
+        }
+        return;
+    }
+    // a precedes b: larger score, then smaller item id (empty entries: -inf, PK_IDX_NONE -> last)
+    auto before = [](float ka, int va, float kb, int vb) { return ka > kb || (ka == kb && va < vb); };
+    constexpr int N = 64 * SLOTS;
+    for (int k = 2; k <= N; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 64) {
+                const int ds = j >> 6;
+#pragma unroll
+                for (int s = 0; s < SLOTS; ++s) {
+                    if ((s & ds) == 0 && (s | ds) < SLOTS) {
+                        const int i = lane + 64 * s;
+                        const bool desc = (i & k) == 0;
+                        const int s2 = s | ds;
+                        const bool in_order = before(key[s], val[s], key[s2], val[s2]);
+                        if (in_order != desc) {
+                            const float tk = key[s];
+                            const int tv = val[s];
+                            key[s] = key[s2];
+                            val[s] = val[s2];
+                            key[s2] = tk;
+                            val[s2] = tv;
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < SLOTS; ++s) {
+                    const int i = lane + 64 * s;
+                    const float ok = __shfl_xor(key[s], j, 64);
+                    const int ov = __shfl_xor(val[s], j, 64);
+                    const bool desc = (i & k) == 0;
+                    const bool lower = (lane & j) == 0;                 // I hold the smaller index of the pair
+                    const bool mine_first = before(key[s], val[s], ok, ov);
+                    // the smaller index keeps the element that precedes in a descending run, the other one otherwise
+                    const bool keep = (mine_first == (lower == desc));
+                    if (!keep) {
+                        key[s] = ok;
+                        val[s] = ov;
+                    }
+                }
+            }
+        }
+    }
+    if (lane < KC) {     // KC <= 64: the best KC sit in slot 0
+        int iv = (val[0] == PK_IDX_NONE) ? -1 : val[0];
+        // the head's "not full although bootstrapped" mark survives the merge (only the head sweep can set it)
+        if (lane == KC - 1 && iv < 0 && user < n_users && work_idx[user * KC + KC - 1] == PK_IDX_FLOOR) iv = PK_IDX_FLOOR;
+        out_score[user * KC + lane] = key[0];
+        out_idx[user * KC + lane] = iv;
+    }
+}
+
+// Default shape of the two-phase sweep: *head_tiles = 0 when a single sweep is the better choice.
+// Measured (profiles/r03_sweep_variants_*.txt, ML-20M-shaped rank 50 / top-10): a 17 312-user shard (541 groups: the share
+// of one GPU of eight) sweeps in 0.274 ms as one sweep per group, 0.246 with the threshold bootstrap, 0.181 with a
+// 32-tile head + 3 seeded splits, 0.162 with 7 — its pass goes from 0.367 to 0.254 ms; at full size (4 328 groups, the
+// wave slots are full 1.4 times over) the same shapes are SLOWER (0.37 -> 0.43 - 0.48 ms; S-1M 1.71 -> 2.51 ms): there the
+// kernel is bound by the work of the head tiles, where the lists are built, not by its longest chain, and the extra
+// launches, waves and the merge only cost.  So the scheme is used when the groups alone leave wave slots idle:
+//   groups <= 1024 (32K users);  head = 32 tiles;  splits = 3 / 7 / 15 for > 768 / > 256 / fewer groups, capped by the
+//   (splits + 1) * KC <= 256 entries the merge holds (KC = 16: 15, 32: 7, 64: 3).
+// PK_SCORE_HEAD_TILES / PK_SCORE_PHASE2_SPLITS override (tuning and tests: any n_users); PK_SCORE_HEAD_TILES=0 switches it off.
+extern "C" int pk_score_two_phase_plan(int64_t n_users, int64_t n_items, int32_t KC, int32_t *head_tiles, int32_t *splits) {
+    PK_REQUIRE(head_tiles && splits, "pk_score_two_phase_plan: null output");
+    const int64_t n_tiles = pk_ceil_div(n_items, 32);
+    const int64_t groups = pk_ceil_div(n_users, 32);
+    int h = (groups <= 1024) ? 32 : 0;
+    int s = groups > 768 ? 3 : (groups > 256 ? 7 : 15);
+    if (const char *e = getenv("PK_SCORE_HEAD_TILES")) h = atoi(e);
+    if (const char *e = getenv("PK_SCORE_PHASE2_SPLITS")) s = atoi(e);
+    if (s < 1) s = 1;
+    while (s > 1 && (s + 1) * KC > 256) --s;
+    if (KC < 1 || KC > 64 || h < 1 || n_tiles < 4 * (int64_t)h) h = 0;     // short catalogues: the tail is no longer than the head
+    *head_tiles = h;
+    *splits = h ? s : 0;
+    return PK_OK;
+}
+
+// The pruned candidate sweep in two phases (see the kernel header): tiles [0, head_tiles) by one sweep per group, the rest
+// dealt round-robin to `splits` sweeps per group that start from the head's thresholds, then the merge.  Needs the
+// pruning bounds (without them nobody leaves early and a single sweep is the shortest chain there is).
+//   work_score / work_idx  [(splits + 1) * n_pad * KC]   the raw lists (slot 0: head), n_pad = n_users rounded up to 32
+//   cand_score / cand_idx  [n_pad * KC]                   the merged list: what pk_rescore_topk_* takes with splits = 1
+//   state                  pk_score_state_bytes(n_users, splits + 1)
+extern "C" int pk_score_two_phase_f32(void *stream, int64_t n_users, int64_t n_items, int32_t K,
+                                      const float *Vp_dev, const float *Ep_dev, const int64_t *seen_ptr_dev,
+                                      const uint64_t *seen_tiles_dev, const int32_t *seen_ntiles_dev,
+                                      int32_t KC, int32_t head_tiles, int32_t splits,
+                                      float *work_score_dev, int32_t *work_idx_dev,
+                                      float *cand_score_dev, int32_t *cand_idx_dev, void *state_dev,
+                                      int32_t tiles_per_chunk, const float *user_bound_dev,
+                                      const float *tile_bound_dev, const uint32_t *seen_dense_dev,
+                                      const int32_t *seen_skip_dev, int32_t dense_tiles) {
+    int rc = pk_score_check_args("pk_score_two_phase_f32", n_users, n_items, K, Vp_dev, Ep_dev, seen_ptr_dev,
+                                 seen_tiles_dev, seen_ntiles_dev, state_dev, user_bound_dev, tile_bound_dev,
+                                 seen_dense_dev, seen_skip_dev, dense_tiles);
+    if (rc != PK_OK) return rc;
+    const int n_tiles = (int)pk_ceil_div(n_items, 32);
+    PK_REQUIRE(user_bound_dev && tile_bound_dev, "pk_score_two_phase_f32: needs the pruning bounds");
+    PK_REQUIRE(KC >= 1 && KC <= 64 && splits >= 1 && (splits + 1) * KC <= 256 && head_tiles >= 1 && head_tiles < n_tiles,
+               "pk_score_two_phase_f32: need 1 <= head_tiles < n_tiles and (splits + 1) * KC <= 256");
+    PK_REQUIRE(work_score_dev && work_idx_dev && cand_score_dev && cand_idx_dev, "pk_score_two_phase_f32: null list buffers");
+    hipStream_t st = pk_stream(stream);
+    SeenDense dense{seen_dense_dev, seen_skip_dev, seen_ptr_dev ? dense_tiles : 0};
+    const int total_slots = splits + 1;
+    // phase 1: the head, a complete single sweep over a catalogue that ends at tile head_tiles (ONE launch: it finalises —
+    // rings merged, lists written, exit tile and threshold in the lane records — so the head must fit one item chunk)
+    rc = pk_sweep_launches(st, n_users, n_items, head_tiles, K, Vp_dev, Ep_dev, seen_ptr_dev, seen_tiles_dev, seen_ntiles_dev,
+                           KC, 1, total_slots, work_score_dev, work_idx_dev, state_dev, head_tiles, user_bound_dev,
+                           tile_bound_dev, dense, SweepPhase{0, 0, nullptr, 0});
+    if (rc != PK_OK) return rc;
+    // phase 2: the splits, from the head's thresholds
+    LaneState *st_lane = static_cast<LaneState *>(state_dev);
+    rc = pk_sweep_launches(st, n_users, n_items, n_tiles, K, Vp_dev, Ep_dev, seen_ptr_dev, seen_tiles_dev, seen_ntiles_dev,
+                           KC, splits, total_slots, work_score_dev, work_idx_dev, state_dev, tiles_per_chunk, user_bound_dev,
+                           tile_bound_dev, dense, SweepPhase{head_tiles, 1, st_lane, 0});
+    if (rc != PK_OK) return rc;
+    const int64_t n_pad = pk_ceil_div(n_users, 32) * 32;
+    const int slots = (int)pk_ceil_div((int64_t)total_slots * KC, 64);
+    dim3 grid((unsigned)pk_ceil_div(n_pad, 4));
+#define PK_MERGE(SL)                                                                                               \
+    hipLaunchKernelGGL((merge_candidates_kernel<SL>), grid, dim3(256), 0, st, n_users, n_pad, KC, total_slots,     \
+                       work_score_dev, work_idx_dev, cand_score_dev, cand_idx_dev)
+    if (slots <= 1) PK_MERGE(1);
+    else if (slots == 2) PK_MERGE(2);
+    else PK_MERGE(4);
+#undef PK_MERGE
+    PK_CHECK_LAUNCH("merge_candidates_kernel");
     return PK_OK;
 }

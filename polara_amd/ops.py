@@ -750,6 +750,45 @@ class HipOps:
                        'pk_score_candidates_f32')
         return cs, ci
 
+    def two_phase_plan(self, n_users, n_items, KC):
+        """(head_tiles, splits) of the two-phase pruned sweep for this user set and catalogue, or (0, 0): single sweep."""
+        h, s = C.c_int32(0), C.c_int32(0)
+        _lib.check(self.lib.pk_score_two_phase_plan(int(n_users), int(n_items), int(KC), C.byref(h), C.byref(s)),
+                   'pk_score_two_phase_plan')
+        return int(h.value), int(s.value)
+
+    def score_two_phase(self, Vp, Ep, n_users, n_items, K, seen_ptr, KC, head_tiles, splits, user_bound, tile_bound,
+                        seen_tiles=None, seen_dense=None, tiles_per_chunk=0):
+        """The pruned candidate sweep in two phases (pk_score_two_phase_f32): head sweep, `splits` sweeps of the tail from
+        the head's thresholds, merge.  Returns the merged (scores, ids) [n_pad x KC] — a single list per user."""
+        n_pad = -(-n_users // 32) * 32
+        total = splits + 1
+        need = self.lib.pk_score_state_bytes(n_users, total)
+        if self._score_states is None:
+            self._score_states = {}
+        skey = torch.cuda.current_stream(self.device).cuda_stream   # one state buffer per launch stream
+        if skey not in self._score_states or self._score_states[skey].numel() < need:
+            self._score_states[skey] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        self._score_state = self._score_states[skey]
+        ws = torch.empty(total * n_pad * KC, dtype=torch.float32, device=self.device)
+        wi = torch.empty(total * n_pad * KC, dtype=torch.int32, device=self.device)
+        cs = torch.empty(n_pad * KC, dtype=torch.float32, device=self.device)
+        ci = torch.empty(n_pad * KC, dtype=torch.int32, device=self.device)
+        tiles = ntiles = dense = skip = None
+        dtiles = 0
+        if seen_ptr is not None:
+            tiles, ntiles = seen_tiles
+            if seen_dense is not None:
+                dense, skip, dtiles = seen_dense
+        with self._timed('score_candidates', (n_users, n_items, K)):
+            _lib.check(self.lib.pk_score_two_phase_f32(self.stream(), n_users, n_items, K, _ptr(Vp), _ptr(Ep), _ptr(seen_ptr),
+                                                       _ptr(tiles), _ptr(ntiles), KC, int(head_tiles), int(splits),
+                                                       _ptr(ws), _ptr(wi), _ptr(cs), _ptr(ci), _ptr(self._score_state),
+                                                       tiles_per_chunk or self.score_tiles_per_chunk,
+                                                       _ptr(user_bound), _ptr(tile_bound), _ptr(dense), _ptr(skip), int(dtiles)),
+                       'pk_score_two_phase_f32')
+        return cs, ci
+
     def score_exit_tiles(self, n_users, splits=1):
         """int64 [splits x n_groups]: tile (absolute index) at which each group of 32 users left the last candidate
         sweep; split h of S owns tiles h, h+S, ... and scored ceil((exit - h) / S) of them."""

@@ -71,7 +71,7 @@ _in_pass = threading.local()
 
 
 def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stats=None, prune=True, batches=None,
-              approx_fold_in=None, order_users=True, head_users=None):
+              approx_fold_in=None, order_users=True, head_users=None, two_phase_ok=True):
     """factors: FactorImage; T: ops-level CSR of the test users [n_users x n_items].
     Returns int64 device tensor [n_users x topk] (+ fp64 scores), rows in test-user order,
     columns by descending score — the contract of models.py:400-405.
@@ -91,7 +91,7 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
             _in_pass.held = True
             try:
                 return recommend(ops, factors, T, topk, filter_seen, return_scores, stats, prune, batches, approx_fold_in,
-                                 order_users, head_users)
+                                 order_users, head_users, two_phase_ok)
             finally:
                 _in_pass.held = False
     n_users, n_items = T.shape
@@ -107,7 +107,7 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
         if head_users is None:
             head_users = HEAD_USERS
         res = recommend(ops, factors, Tp, topk, filter_seen, return_scores, stats, prune, batches, approx_fold_in,
-                        order_users=False, head_users=head_users)
+                        order_users=False, head_users=head_users, two_phase_ok=two_phase_ok)
         if return_scores:
             idx_p, sc_p = res
             out_idx, out_s = torch.empty_like(idx_p), torch.empty_like(sc_p)
@@ -147,6 +147,8 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
     # only pay for the second kernel instance: 1.69 -> 1.80 ms on ML-20M-shaped)
     seen_dense = T.seen_dense() if (filter_seen and prune and hasattr(T, 'seen_dense')) else None
     splits = ops.score_splits(n_users, KC, prune)    # item ranges per user group (1 when pruning / users fill the chip)
+    use_two_phase = bool(prune and two_phase_ok and hasattr(ops, 'two_phase_plan') and not getattr(ops, 'score_splits_override', 0))
+    two_phase = ops.two_phase_plan(n_users, n_items, KC) if use_two_phase else (0, 0)
     out_idx = torch.empty(n_users, topk, dtype=torch.int64, device=E.device)
     out_s = torch.empty(n_users, topk, dtype=torch.float64, device=E.device)
     flags = torch.empty(n_users, dtype=torch.int32, device=E.device)
@@ -157,6 +159,7 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
         """fold-in -> bounds/pack -> candidate sweep -> exact re-scoring of users [u0, u1) on the current stream"""
         nb = u1 - u0
         splits = ops.score_splits(nb, KC, prune)     # of THIS batch: a small head batch is dealt out over item splits
+        two_phase = ops.two_phase_plan(nb, n_items, KC) if use_two_phase else (0, 0)     # ... or swept in two phases
         if approx_fold_in:
             ops.spmm(T, factors.V32x, out=Ex, rows=(u0, u1))               # fold-in against fl32(V) (K4)
             w = Ex[u0:u1, K]                                               # w_u = sum_j a_uj ||V_j|| (strided view)
@@ -176,9 +179,16 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
         assert u0 % 32 == 0, 'user batches start on a 32-user group boundary (dense seen masks are indexed by group)'
         sd = (seen_dense[0][u0 // 32:], seen_dense[1][u0:u1], seen_dense[2]) if seen_dense is not None else None
         extra = {} if sd is None else {'seen_dense': sd}
-        cs, ci = ops.score_candidates(factors.Vp, Ep, nb, n_items, K, sp, seen_idx, KC, splits,
-                                      user_bound=ub, tile_bound=factors.tile_bound if prune else None,
-                                      seen_tiles=st, **extra)                                 # K3
+        if two_phase[0] and prune:
+            # pruned sweep in two phases: head of the catalogue for every group, then item splits that start from the
+            # head's thresholds, lists merged (K3; the chain of a group is head + tail / S tiles instead of head + tail)
+            cs, ci = ops.score_two_phase(factors.Vp, Ep, nb, n_items, K, sp, KC, two_phase[0], two_phase[1], ub,
+                                         factors.tile_bound, seen_tiles=st, seen_dense=sd)
+            splits = 1                                                                        # ONE merged list per user
+        else:
+            cs, ci = ops.score_candidates(factors.Vp, Ep, nb, n_items, K, sp, seen_idx, KC, splits,
+                                          user_bound=ub, tile_bound=factors.tile_bound if prune else None,
+                                          seen_tiles=st, **extra)                             # K3
         outs = (out_idx[u0:u1], out_s[u0:u1], flags[u0:u1])
         ops.rescore_topk(factors.V, Eb, n_items, sp, KC, cs, ci, topk, factors.vmax, want_scores=True,
                          splits=splits, out=outs, e_err=w, v32=factors.V32x if approx_fold_in else None)
@@ -236,9 +246,23 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
         stats['item_splits'] = splits
         # tiles actually scored by the candidate sweep (pruning), for the roofline accounting
         n_tiles = -(-n_items // 32)
-        ex = ops.score_exit_tiles(n_users, splits)                      # absolute tile index, per split and group
-        first = torch.arange(splits, device=ex.device, dtype=torch.int64)[:, None]   # split h owns tiles h, h+S, ...
-        scored = torch.div((ex - first).clamp_min(0) + splits - 1, splits, rounding_mode='floor')
+        if two_phase[0]:
+            # slot 0: the head sweep (tiles [0, H)); slots 1..S: split h owns tiles H + h, H + h + S, ...
+            H, S2 = two_phase
+            stats['item_splits'] = 1
+            stats['two_phase'] = {'head_tiles': H, 'splits': S2}
+            ex = ops.score_exit_tiles(n_users, S2 + 1)
+            first = H + torch.arange(S2, device=ex.device, dtype=torch.int64)[:, None]
+            tail = torch.div((ex[1:] - first).clamp_min(0) + S2 - 1, S2, rounding_mode='floor')
+            tail = torch.where(ex[:1] < H, torch.zeros_like(tail), tail)      # pruned inside the head: the splits did not run
+            scored = ex[0].clamp_max(H) + tail.sum(dim=0)                    # tiles scored per group, all sweeps together
+            chain = ex[0].clamp_max(H) + tail.max(dim=0).values              # the group's dependent chain (tile steps)
+            q2 = torch.quantile(chain.double(), torch.tensor([0.5, 0.99, 1.0], dtype=torch.float64, device=ex.device))
+            stats['two_phase']['chain_quantiles'] = dict(zip(('p50', 'p99', 'max'), [float(v) for v in q2.tolist()]))
+        else:
+            ex = ops.score_exit_tiles(n_users, splits)                      # absolute tile index, per split and group
+            first = torch.arange(splits, device=ex.device, dtype=torch.int64)[:, None]   # split h owns tiles h, h+S, ...
+            scored = torch.div((ex - first).clamp_min(0) + splits - 1, splits, rounding_mode='floor')
         stats['tiles_scored'] = int(scored.sum().item())
         stats['tiles_total'] = int(ex.shape[1]) * n_tiles
         q = torch.quantile(scored.flatten().double(),

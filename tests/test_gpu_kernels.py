@@ -413,11 +413,17 @@ def test_pruned_sweep_equals_full_sweep(hip_ops, cfg):
         hip_ops.score_splits_override = cfg.get('splits', 0)
         st_full, st = {}, {}
         ref, ref_s = scoring.recommend(hip_ops, F, T, topk, True, return_scores=True, stats=st_full, prune=False)
-        got, got_s = scoring.recommend(hip_ops, F, T, topk, True, return_scores=True, stats=st)
+        got, got_s = scoring.recommend(hip_ops, F, T, topk, True, return_scores=True, stats=st, two_phase_ok=False)
+        st2 = {}
+        got2, got2_s = scoring.recommend(hip_ops, F, T, topk, True, return_scores=True, stats=st2)   # default: two-phase
     finally:
         hip_ops.score_tiles_per_chunk = 0
         hip_ops.score_splits_override = 0
     assert st_full['tiles_scored'] == st_full['tiles_total']
+    # the default pruned route for a catalogue of >= 128 tiles is the two-phase sweep (unless splits are forced)
+    assert ('two_phase' in st2) == (not cfg.get('splits')) and st2['tiles_scored'] <= st2['tiles_total']
+    assert np.array_equal(hip_ops.to_host(ref), hip_ops.to_host(got2))
+    assert np.array_equal(hip_ops.to_host(ref_s), hip_ops.to_host(got2_s))
     # few users: the sweep is dealt out to several interleaved splits (auto: as many as fit the candidate budget);
     # each split prunes against the k-th best of its own items only, so the cut is weaker than a single sweep's
     want_splits = cfg.get('splits', hip_ops.lib.pk_score_splits(n_users, hip_ops.candidate_capacity(topk)))
@@ -431,6 +437,53 @@ def test_pruned_sweep_equals_full_sweep(hip_ops, cfg):
     want, _ = brute_topk(V, E, indptr, indices, topk, True)
     live = np.abs(E).sum(1) > 0
     assert (hip_ops.to_host(got)[live] == want[live]).mean() > 0.999
+
+
+@pytest.mark.parametrize('cfg', [dict(n_users=1500, n_items=9000, K=50, topk=10, head=32, splits=3, chunk=0),
+                                 dict(n_users=700, n_items=5200, K=50, topk=10, head=8, splits=3, chunk=5),
+                                 dict(n_users=333, n_items=9000, K=100, topk=20, head=16, splits=3, chunk=7),
+                                 dict(n_users=333, n_items=9000, K=100, topk=20, head=40, splits=1, chunk=0),
+                                 dict(n_users=200, n_items=6000, K=24, topk=50, head=32, splits=3, chunk=11),
+                                 dict(n_users=200, n_items=6000, K=24, topk=50, head=3, splits=2, chunk=0),
+                                 dict(n_users=900, n_items=12000, K=50, topk=10, head=32, splits=7, chunk=9),
+                                 dict(n_users=900, n_items=12000, K=160, topk=10, head=20, splits=15, chunk=0),
+                                 dict(n_users=257, n_items=4100, K=10, topk=3, head=1, splits=3, chunk=2)])
+def test_two_phase_sweep_equals_single_sweep(hip_ops, cfg, monkeypatch):
+    """pk_score_two_phase_f32 (head sweep -> item splits seeded with the head's thresholds -> exact merge of the S + 1
+    lists): the lists and scores of the pass are those of the single pruned sweep and of the full sweep, for heads of
+    1..40 tiles, 1..15 splits (merge over 64, 128 and 256 entries), tiny item chunks in phase 2 (state parked between
+    launches), ranks with and without the dense seen masks, users with very long rows (pruned inside the head: their
+    splits must not run) and empty rows; also the kernel-level contract: the merged list holds the KC best fp32 scores
+    of the union of the raw lists."""
+    from polara_amd import scoring
+    n_users, n_items, K, topk = cfg['n_users'], cfg['n_items'], cfg['K'], cfg['topk']
+    rng = np.random.RandomState(n_items + cfg['head'])
+    decay = (1.0 + np.arange(n_items)) ** -0.6
+    V = rng.randn(n_items, K) / np.sqrt(K) * decay[:, None]
+    V[rng.randint(n_items // 4, n_items // 2, 3)] *= 3.0
+    indptr, indices, values = rand_csr(rng, n_users, n_items, 40, long_rows=[(2, n_items // 2), (40, n_items - 3)], empty_rows=[7])
+    T = hip_ops.csr(indptr, indices, values, (n_users, n_items))
+    F = scoring.FactorImage(hip_ops, hip_ops.to_device(V))
+    monkeypatch.setenv('PK_SCORE_HEAD_TILES', str(cfg['head']))
+    monkeypatch.setenv('PK_SCORE_PHASE2_SPLITS', str(cfg['splits']))
+    KC = hip_ops.candidate_capacity(topk)
+    want_splits = cfg['splits']
+    while want_splits > 1 and (want_splits + 1) * KC > 256:
+        want_splits -= 1
+    assert hip_ops.two_phase_plan(n_users, n_items, KC) == (cfg['head'], want_splits)
+    try:
+        hip_ops.score_tiles_per_chunk = cfg['chunk']
+        st_full, st1, st2 = {}, {}, {}
+        ref, ref_s = scoring.recommend(hip_ops, F, T, topk, True, return_scores=True, stats=st_full, prune=False)
+        one, one_s = scoring.recommend(hip_ops, F, T, topk, True, return_scores=True, stats=st1, two_phase_ok=False)
+        two, two_s = scoring.recommend(hip_ops, F, T, topk, True, return_scores=True, stats=st2)
+        ids_only = scoring.recommend(hip_ops, F, T, topk, True)                    # approximate fold-in route
+    finally:
+        hip_ops.score_tiles_per_chunk = 0
+    assert 'two_phase' not in st1 and st2['two_phase'] == dict(st2['two_phase'], head_tiles=cfg['head'], splits=want_splits)
+    for a, b in ((ref, one), (ref, two), (ref_s, one_s), (ref_s, two_s), (ref, ids_only)):
+        assert np.array_equal(hip_ops.to_host(a), hip_ops.to_host(b))
+    assert st2["tiles_scored"] <= st2["tiles_total"]
 
 
 @pytest.mark.parametrize('cfg', [dict(K=50, topk=10, splits=4), dict(K=50, topk=10, splits=3),
@@ -775,3 +828,86 @@ def test_dense_seen_masks_equal_the_stream(hip_ops, monkeypatch):
             want_skip[u] = len(np.unique(row // 32))
         assert np.array_equal(ops.to_host(dense).view(np.uint32), want) and np.array_equal(ops.to_host(skip), want_skip)
         assert np.array_equal(idx, idx0) and np.array_equal(sc, sc0) and np.array_equal(ids, ids0), window
+
+
+@pytest.mark.parametrize('cfg', [dict(n_users=700, n_items=6000, K=50, topk=10, chunk=0),
+                                 dict(n_users=333, n_items=3000, K=100, topk=20, chunk=7),
+                                 dict(n_users=200, n_items=2600, K=24, topk=50, chunk=0),
+                                 dict(n_users=130, n_items=900, K=16, topk=5, chunk=3)])
+def test_threshold_bootstrap_changes_nothing(hip_ops, cfg, monkeypatch):
+    """The threshold bootstrap in front of a cold sweep (score.hip: the first tiles scored once without selecting, the
+    sweep then starts from a lower bound of every user's KC-th best score): ids AND scores of the pass equal those of
+    the cold start, for KC = 16 / 32 / 64, bootstraps shorter and longer than the catalogue, pruned and full sweeps,
+    `filter_seen` off, users who have seen nearly everything (their bootstrap finds fewer than KC unseen items and
+    yields no threshold) and empty users; the raw candidate lists of a bootstrapped sweep are full (no PK_IDX_FLOOR
+    mark) and hold the same KC best fp32 scores."""
+    from polara_amd import scoring
+    n_users, n_items, K, topk = cfg['n_users'], cfg['n_items'], cfg['K'], cfg['topk']
+    rng = np.random.RandomState(n_items)
+    decay = (1.0 + np.arange(n_items)) ** -0.5
+    V = rng.randn(n_items, K) / np.sqrt(K) * decay[:, None]
+    indptr, indices, values = rand_csr(rng, n_users, n_items, 40, long_rows=[(2, n_items // 2), (40, n_items - 3), (41, n_items - 20)],
+                                       empty_rows=[7])
+    T = hip_ops.csr(indptr, indices, values, (n_users, n_items))
+    F = scoring.FactorImage(hip_ops, hip_ops.to_device(V))
+    monkeypatch.setenv('PK_SCORE_HEAD_TILES', '0')
+    out = {}
+    try:
+        hip_ops.score_tiles_per_chunk = cfg['chunk']
+        for boot in (0, 16, 3, 4000):
+            monkeypatch.setenv('PK_SCORE_BOOT_TILES', str(boot))
+            st = {}
+            out[boot] = [scoring.recommend(hip_ops, F, T, topk, True, return_scores=True, stats=st),
+                         scoring.recommend(hip_ops, F, T, topk, True, return_scores=True, prune=False),
+                         scoring.recommend(hip_ops, F, T, topk, False, return_scores=True),
+                         scoring.recommend(hip_ops, F, T, topk, True)]
+            assert st['flagged_users'] <= 4, st          # the three nearly-all-seen users and nobody else goes the exact way
+    finally:
+        hip_ops.score_tiles_per_chunk = 0
+    for boot in (16, 3, 4000):
+        for a, b in zip(out[0], out[boot]):
+            if isinstance(a, tuple):
+                assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), boot
+            else:
+                assert torch.equal(a, b), boot
+    # kernel level: full lists, same candidates (as sets of fp32 scores) with and without the bootstrap
+    KC = hip_ops.candidate_capacity(topk)
+    E = hip_ops.spmm(T, F.V)
+    Ep, ub = hip_ops.pack_frag_bound(E)
+    lists = {}
+    for boot in (0, 16):
+        monkeypatch.setenv('PK_SCORE_BOOT_TILES', str(boot))
+        cs, ci = hip_ops.score_candidates(F.Vp, Ep, n_users, n_items, K, T.indptr, T.indices, KC, user_bound=ub,
+                                          tile_bound=F.tile_bound, seen_tiles=T.seen_tiles())
+        lists[boot] = (hip_ops.to_host(cs)[:n_users * KC].reshape(n_users, KC), hip_ops.to_host(ci)[:n_users * KC].reshape(n_users, KC))
+    assert (lists[16][1] != -2).all()
+    unseen = n_items - np.diff(indptr)
+    full = unseen >= KC
+    assert (lists[16][1][full] >= 0).all() and (lists[0][1][full] >= 0).all()
+    assert np.array_equal(np.sort(lists[0][1][full], axis=1), np.sort(lists[16][1][full], axis=1))
+
+
+def test_rescore_sends_unbounded_lists_to_the_exact_path(hip_ops):
+    """A list whose last slot carries PK_IDX_FLOOR (-2: the sweep started from a bootstrapped threshold and did not fill
+    the list — nothing bounds the items it left out) must be flagged for the exact path by the re-scoring kernel, and the
+    pass must then still return the exact lists."""
+    from polara_amd import scoring
+    rng = np.random.RandomState(5)
+    n_users, n_items, K, topk = 300, 2000, 20, 10
+    V = rng.randn(n_items, K)
+    indptr, indices, values = rand_csr(rng, n_users, n_items, 30)
+    T = hip_ops.csr(indptr, indices, values, (n_users, n_items))
+    F = scoring.FactorImage(hip_ops, hip_ops.to_device(V))
+    KC = hip_ops.candidate_capacity(topk)
+    E = hip_ops.spmm(T, F.V)
+    Ep, ub = hip_ops.pack_frag_bound(E)
+    cs, ci = hip_ops.score_candidates(F.Vp, Ep, n_users, n_items, K, T.indptr, T.indices, KC, seen_tiles=T.seen_tiles())
+    marked = torch.tensor([3, 64, 65, 299], device=ci.device)
+    ci2 = ci.clone()
+    ci2.view(-1, KC)[marked, KC - 1] = -2
+    idx0, s0, f0 = hip_ops.rescore_topk(F.V, E, n_items, T.indptr, KC, cs, ci, topk, F.vmax)
+    idx1, s1, f1 = hip_ops.rescore_topk(F.V, E, n_items, T.indptr, KC, cs, ci2, topk, F.vmax)
+    f0, f1 = hip_ops.to_host(f0), hip_ops.to_host(f1)
+    m = np.zeros(n_users, bool)
+    m[hip_ops.to_host(marked)] = True
+    assert (f1[m] & 1).all() and np.array_equal(f1[~m], f0[~m]) and not (f0[m] & 1).any()

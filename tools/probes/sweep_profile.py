@@ -21,18 +21,30 @@ order2 = torch.argsort(torch.linalg.vector_norm(V, dim=1), descending=True, stab
 rank2 = torch.empty_like(order2); rank2[order2] = torch.arange(n_items, device=order2.device)
 V = V[order2].contiguous(); A = ops.csr_relabel_cols(A, rank2)
 F = scoring.FactorImage(ops, V)
-for _ in range(3): scoring.recommend(ops, F, A, 10, True)
-torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 8)()
 ops.lib.pk_debug_profile.argtypes = [ctypes.c_void_p, ctypes.c_int]
-ops.lib.pk_debug_profile(None, 1)
-n = 5
-for _ in range(n): scoring.recommend(ops, F, A, 10, True)
-torch.cuda.synchronize()
-ops.lib.pk_debug_profile(buf, 0)
-names = ('kernel', 'flush', 'walk', 'push_incl_flush', 'prologue', 'epilogue', 'n_flush', 'tiles')
-d = {k: int(v) / n for k, v in zip(names, buf)}
-d['per_tile_wave_cycles'] = d['kernel'] / max(d['tiles'], 1)
-d['flush_share'] = d['flush'] / d['kernel']; d['walk_share'] = d['walk'] / d['kernel']; d['push_share'] = d['push_incl_flush'] / d['kernel']
-d['cycles_per_flush'] = d['flush'] / max(d['n_flush'], 1)
-print(json.dumps(d))
+names = ('kernel', 'flush', 'walk', 'push_incl_flush', 'prologue', 'bootstrap', 'n_flush', 'tiles')
+configs = [dict(boot=0, head=0), dict(boot=16, head=0), dict(boot=32, head=0), dict(boot=0, head=32), dict(boot=16, head=32)]
+if len(sys.argv) > 2:
+    configs = [dict(zip(('boot', 'head'), (int(x) for x in a.split(',')))) for a in sys.argv[2:]]
+for cfg in configs:
+    os.environ['PK_SCORE_BOOT_TILES'] = str(cfg['boot'])
+    os.environ['PK_SCORE_HEAD_TILES'] = str(cfg['head'])
+    for _ in range(3): scoring.recommend(ops, F, A, 10, True)
+    torch.cuda.synchronize()
+    ops.lib.pk_debug_profile(None, 1)
+    n = 5
+    for _ in range(n): scoring.recommend(ops, F, A, 10, True)
+    torch.cuda.synchronize()
+    ops.lib.pk_debug_profile(buf, 0)
+    d = {k: int(v) / n for k, v in zip(names, buf)}
+    d['per_tile_wave_cycles'] = d['kernel'] / max(d['tiles'], 1)
+    for k in ('flush', 'walk', 'push_incl_flush', 'prologue', 'bootstrap'):
+        d[k + '_share'] = round(d[k] / d['kernel'], 4)
+    d['cycles_per_flush'] = d['flush'] / max(d['n_flush'], 1)
+    ops.timers = {}
+    for _ in range(5): scoring.recommend(ops, F, A, 10, True, batches=1)
+    torch.cuda.synchronize()
+    d['sweep_ms'] = float(np.mean([e0.elapsed_time(e1) for e0, e1, _ in ops.timers['score_candidates']]))
+    ops.timers = None
+    print(json.dumps(dict(cfg, **d)), flush=True)
