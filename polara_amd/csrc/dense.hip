@@ -26,7 +26,15 @@ extern "C" int64_t pk_gram_work_bytes(int64_t n, int32_t la, int32_t lb) {
     return (int64_t)gram_splits(n, la, lb) * la * lb * (int64_t)sizeof(double);
 }
 
-// block (256 threads = 16x16) computes a 64x64 tile of A^T B over its row range
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// block (256 threads = 4 waves) computes a 64x64 tile of A^T B over its row range on the fp64 matrix cores:
+// v_mfma_f64_16x16x4_f64, D[16 x 16] += P[16 x 4] Q[4 x 16] with lane l holding P[l & 15][l >> 4], Q[l >> 4][l & 15] and
+// D[(l >> 4) + 4 r][l & 15] in register r (MI355X guide: NOT the f32 C/D map).  For a Gram product the contraction runs
+// over ROWS of the tall operands, so P = (A tile)^T: lane l reads sA[k0 + (l >> 4)][16 w + (l & 15)] — 16 consecutive
+// doubles per quarter-wave, conflict-free — and wave w owns output rows [16 w, 16 w + 16) of the tile against all four
+// 16-column blocks of B: 16 MFMAs per 16 staged rows instead of 256 scalar FMAs and 128 LDS reads per thread.
+// (BASELINE.json configs[3] / north_star: the dense contractions of the HOOI path on MFMA; lib/tensor.py:70-80.)
 __global__ __launch_bounds__(256) void gram_kernel(int64_t n, int la, int lb, const double *__restrict__ A,
                                                    int64_t lda, const double *__restrict__ B, int64_t ldb,
                                                    double *__restrict__ partial, int tiles_j,
@@ -34,17 +42,15 @@ __global__ __launch_bounds__(256) void gram_kernel(int64_t n, int la, int lb, co
     __shared__ double sA[16][64];
     __shared__ double sB[16][64];
     const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
     const int ti = blockIdx.x / tiles_j, tj = blockIdx.x % tiles_j;
     const int split = blockIdx.y;
     const int64_t r_begin = (int64_t)split * rows_per_split;
     int64_t r_end = r_begin + rows_per_split;
     if (r_end > n) r_end = n;
-    const int ty = tid >> 4, tx = tid & 15;
-    double acc[4][4];
+    f64x4 acc[4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+    for (int b = 0; b < 4; ++b) acc[b] = f64x4{0.0, 0.0, 0.0, 0.0};
 
     for (int64_t r0 = r_begin; r0 < r_end; r0 += 16) {
 #pragma unroll
@@ -58,29 +64,22 @@ __global__ __launch_bounds__(256) void gram_kernel(int64_t n, int la, int lb, co
         }
         __syncthreads();
 #pragma unroll
-        for (int rr = 0; rr < 16; ++rr) {
-            double a[4], b[4];
+        for (int k0 = 0; k0 < 16; k0 += 4) {
+            const double p = sA[k0 + (lane >> 4)][16 * wave + (lane & 15)];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                a[k] = sA[rr][ty * 4 + k];
-                b[k] = sB[rr][tx * 4 + k];
-            }
-#pragma unroll
-            for (int x = 0; x < 4; ++x)
-#pragma unroll
-                for (int y = 0; y < 4; ++y) acc[x][y] = fma(a[x], b[y], acc[x][y]);
+            for (int b = 0; b < 4; ++b)
+                acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(p, sB[k0 + (lane >> 4)][16 * b + (lane & 15)], acc[b], 0, 0, 0);
         }
         __syncthreads();
     }
     double *dst = partial + (int64_t)split * la * lb;
 #pragma unroll
-    for (int x = 0; x < 4; ++x) {
-        int i = ti * 64 + ty * 4 + x;
-        if (i >= la) continue;
+    for (int b = 0; b < 4; ++b) {
+        const int j = tj * 64 + 16 * b + (lane & 15);
 #pragma unroll
-        for (int y = 0; y < 4; ++y) {
-            int j = tj * 64 + tx * 4 + y;
-            if (j < lb) dst[(int64_t)i * lb + j] = acc[x][y];
+        for (int r = 0; r < 4; ++r) {
+            const int i = ti * 64 + 16 * wave + (lane >> 4) + 4 * r;
+            if (i < la && j < lb) dst[(int64_t)i * lb + j] = acc[b][r];
         }
     }
 }
@@ -129,21 +128,21 @@ extern "C" int pk_gram_f64(void *stream, int64_t n, int32_t la, int32_t lb, cons
 }
 
 // ------------------------------------------------------------------------------------------ tsmm
-// block computes 64 rows x 64 output columns; k advanced 16 at a time through LDS
+// block computes 64 rows x 64 output columns; k advanced 16 at a time through LDS; the products run on the fp64 matrix
+// cores (v_mfma_f64_16x16x4_f64, layout in gram_kernel): wave w owns rows [16 w, 16 w + 16) of the block, P[i][k] =
+// sX[16 w + i][k0 + k] (row stride 17: the 16 rows of a quarter-wave fall into different banks), Q[k][j] = sC[k0 + k][16 b + j].
 __global__ __launch_bounds__(256) void tsmm_kernel(int64_t n, int lin, int lout, const double *__restrict__ X,
                                                    int64_t ldx, const double *__restrict__ C, int64_t ldc,
                                                    double *__restrict__ out, int64_t ldo) {
     __shared__ double sX[64][17];
     __shared__ double sC[16][64];
     const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
     const int64_t row0 = (int64_t)blockIdx.x * 64;
     const int col0 = blockIdx.y * 64;
-    const int ty = tid >> 4, tx = tid & 15;
-    double acc[4][4];
+    f64x4 acc[4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+    for (int b = 0; b < 4; ++b) acc[b] = f64x4{0.0, 0.0, 0.0, 0.0};
 
     for (int k0 = 0; k0 < lin; k0 += 16) {
 #pragma unroll
@@ -161,28 +160,21 @@ __global__ __launch_bounds__(256) void tsmm_kernel(int64_t n, int lin, int lout,
         }
         __syncthreads();
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-            double a[4], b[4];
+        for (int kk = 0; kk < 16; kk += 4) {
+            const double p = sX[16 * wave + (lane & 15)][kk + (lane >> 4)];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                a[k] = sX[ty * 4 + k][kk];
-                b[k] = sC[kk][tx * 4 + k];
-            }
-#pragma unroll
-            for (int x = 0; x < 4; ++x)
-#pragma unroll
-                for (int y = 0; y < 4; ++y) acc[x][y] = fma(a[x], b[y], acc[x][y]);
+            for (int b = 0; b < 4; ++b)
+                acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(p, sC[kk + (lane >> 4)][16 * b + (lane & 15)], acc[b], 0, 0, 0);
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int x = 0; x < 4; ++x) {
-        int64_t row = row0 + ty * 4 + x;
-        if (row >= n) continue;
+    for (int b = 0; b < 4; ++b) {
+        const int c = col0 + 16 * b + (lane & 15);
 #pragma unroll
-        for (int y = 0; y < 4; ++y) {
-            int c = col0 + tx * 4 + y;
-            if (c < lout) out[row * ldo + c] = acc[x][y];
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = row0 + 16 * wave + (lane >> 4) + 4 * r;
+            if (row < n && c < lout) out[row * ldo + c] = acc[b][r];
         }
     }
 }

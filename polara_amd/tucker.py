@@ -1,8 +1,12 @@
 """HOOI / Tucker decomposition of a sparse 3-way tensor on device (CoFFee model build).
 
 Restates `polara.lib.tensor.hooi` (lib/tensor.py:37-96) with the hot pieces moved to HIP:
-  * `ttm3d_seq` -> `dttm_seq` (lib/tensor.py:7-19, lib/sparse.py:203-216)  -> pk_ttm_f64 (K5);
-  * `svds(unfolding, k=r)` (lib/tensor.py:71,75,79)                        -> Gram + Jacobi eigh (K2).
+  * `ttm3d_seq` -> `dttm_seq` (lib/tensor.py:7-19, lib/sparse.py:203-216)  -> factored: SpMM gathers over two CSR
+    images of the tensor (K1) + dense contractions on the fp64 matrix cores (K2 `tsmm`, `gram`), see
+    `factored_products`; the per-entry kernel pk_ttm_f64 (K5, `ttm` below) stays as the kernel-level restatement of
+    dttm_seq and as a cross-check in the tests;
+  * `svds(unfolding, k=r)` (lib/tensor.py:71,75,79)                        -> Gram + Jacobi eigh (K2), warm-started
+    from the previous iteration's eigenvectors.
 Same iteration structure, same random initialisation (NumPy RandomState + LAPACK QR on the host —
 tiny, and it makes the starting point identical to the reference's), same core-growth stopping rule.
 Factor columns are defined up to sign (as in the reference: ARPACK's start vector is random), so
@@ -48,6 +52,51 @@ def ttm(ops, mp, u, v):
     return ops.ttm(mp.plan, mp.idx_u, mp.idx_v, mp.vals, u.contiguous(), v.contiguous(), mp.n0)
 
 
+class Unfoldings:
+    """The sparse tensor as the two CSR matrices the factored products gather from (built once per build, on the device):
+         M0 [(n0 * L) x n1]   row i0 * L + l  holds the items user i0 rated at level l
+         M1 [(n1 * L) x n0]   row i1 * L + l  holds the users who rated item i1 at level l
+    (duplicate coordinates are summed, as the reference's += does).  L = shape[2], the feedback mode — a handful of
+    levels, which is what makes the factoring below pay."""
+
+    def __init__(self, ops, idx, val, shape):
+        n0, n1, L = (int(x) for x in shape)
+        self.shape = (n0, n1, L)
+        nnz = len(idx)
+        vals = np.ones(nnz, dtype=np.float32) if val is None else np.asarray(val)
+        i0, i1, i2 = (np.ascontiguousarray(idx[:, m], dtype=np.int64) for m in range(3))
+        self.M0 = ops.csr_from_coo(i0 * L + i2, i1, vals, (n0 * L, n1))
+        self.M1 = ops.csr_from_coo(i1 * L + i2, i0, vals, (n1 * L, n0))
+
+
+def factored_products(ops, uf, u0, u1, u2, which, comm=None, W1=None):
+    """The three mode products of `hooi` (lib/tensor.py:70,74,78 -> ttm3d_seq -> dttm_seq, lib/sparse.py:203-216) WITHOUT
+    a per-entry outer product.  The reference adds u[i_a, :] (x) v[i_b, :] — r_a * r_b numbers — for every stored entry;
+    one of the two factors always belongs to the feedback mode, which has L ~ 5-10 levels, so the sum factors:
+        mode 0:  res[i0, j * r1 + k] = sum_l u2[l, j] * W0[i0, l, k],   W0[i0, l, :] = sum over the items i1 of (i0, ., l) of u1[i1, :]
+        mode 1:  res[i1, j * r0 + k] = sum_l u2[l, j] * W1[i1, l, k],   W1[i1, l, :] = sum over the users i0 of (., i1, l) of u0[i0, :]
+        mode 2:  res[l, j * r0 + k]  = sum_i1 u1[i1, j] * W1[i1, l, k]
+    W0 / W1 are SpMMs over the unfolded CSR images (K1: r numbers gathered per entry instead of r_a * r_b multiply-adds:
+    30 instead of 150 - 900 for mlrank (30, 30, 5)); what is left is DENSE and runs on the fp64 matrix cores (K2: `tsmm`
+    against kron(u2, I) — the [n x L r] . [L r x r2 r] contraction — and one `gram` for the feedback mode, which reuses
+    the W1 of mode 1).  Users sharded over ranks: W1 sums over users and is all-reduced once; mode 2 then needs nothing.
+    Returns (res, W1)."""
+    n0, n1, L = uf.shape
+    eye = lambda r, like: torch.eye(r, dtype=torch.float64, device=like.device)
+    if which == 0:
+        W0 = ops.spmm(uf.M0, u1.contiguous()).view(-1, L * u1.shape[1])            # [n0_local x L r1]
+        return ops.tsmm(W0, torch.kron(u2.contiguous(), eye(u1.shape[1], u1)).contiguous()), None
+    if W1 is None:
+        W1 = ops.spmm(uf.M1, u0.contiguous()).view(n1, L * u0.shape[1])            # [n1 x L r0], summed over (local) users
+        if comm is not None and comm.world > 1:
+            W1 = comm.allreduce(W1.contiguous())
+    r0 = W1.shape[1] // L
+    if which == 1:
+        return ops.tsmm(W1, torch.kron(u2.contiguous(), eye(r0, u0)).contiguous()), W1
+    G = ops.gram(u1.contiguous(), W1)                                              # [r1 x L r0]
+    return G.view(u1.shape[1], L, r0).permute(1, 0, 2).reshape(L, u1.shape[1] * r0).contiguous(), W1
+
+
 def _polish(ops, U):
     """One Newton-Schulz step  U <- U (1.5 I - 0.5 U^T U): restores orthonormality lost to the
     squared condition number of the Gram route without rotating the basis."""
@@ -57,11 +106,32 @@ def _polish(ops, U):
     return ops.tsmm(U, Cm.contiguous())
 
 
-def left_svd(ops, M, r, want_v=False, comm=None, n_total=None):
+def _eigh_warm(ops, S, warm):
+    """eigh_psd of the Gram matrix S, started from the eigenvectors of the previous HOOI iteration's matrix of the same
+    mode.  The Jacobi kernel's cost is its sweep count (~10 from a cold start on these graded spectra: 2.96 ms at 120
+    columns, 3/4 of the kernel time of a build), and the unfoldings of consecutive HOOI iterations converge: in the basis
+    Q of the previous eigenvectors S' = Q^T S Q is nearly diagonal, the sweeps on it stop after 2-4, and Q S'-eigenvectors
+    are S-eigenvectors.  The rotation is two small products on the matrix cores (tsmm, gram).  `warm`: a dict that lives
+    as long as the iteration (None: cold every time)."""
+    Q = None if warm is None else warm.get('Q')
+    if Q is None or Q.shape != S.shape:
+        lam, Cm = ops.eigh_psd(S)
+    else:
+        S1 = ops.gram(Q, ops.tsmm(S.contiguous(), Q))         # Q^T (S Q)
+        S1 = (0.5 * (S1 + S1.t())).contiguous()
+        lam, C1 = ops.eigh_psd(S1)
+        Cm = ops.tsmm(Q, C1.contiguous())
+    if warm is not None:
+        warm['Q'] = Cm.contiguous()
+    return lam, Cm
+
+
+def left_svd(ops, M, r, want_v=False, comm=None, n_total=None, warm=None):
     """Top-r left singular vectors / values of dense M (n x m), descending; optionally V^T (r x m).
     Mirrors what `svds(M, k=r)` returns to hooi (after its [::-1] reordering).
     With `comm` the ROWS of M are sharded over ranks (the user mode): the m x m Gram matrix is
-    all-reduced, the eigenproblem is solved redundantly and each rank keeps its rows of U."""
+    all-reduced, the eigenproblem is solved redundantly and each rank keeps its rows of U.
+    `warm`: see _eigh_warm."""
     n, m = M.shape
     n_all = n if n_total is None else n_total
     if r > min(n_all, m):
@@ -69,7 +139,7 @@ def left_svd(ops, M, r, want_v=False, comm=None, n_total=None):
     if comm is not None and comm.world > 1:
         if n_all < m:
             raise NotImplementedError('row-sharded unfolding with fewer rows than columns')
-        lam, Cm = ops.eigh_psd(comm.allreduce(ops.gram(M)))
+        lam, Cm = _eigh_warm(ops, comm.allreduce(ops.gram(M)), warm)
         W = Cm[:, :r].contiguous()
         s = torch.sqrt(torch.clamp_min(lam[:r], 0.0))
         U = ops.tsmm(M, W)
@@ -79,7 +149,7 @@ def left_svd(ops, M, r, want_v=False, comm=None, n_total=None):
         U = ops.tsmm(U, Cn.contiguous())
         return U, s, (W.t().contiguous() if want_v else None)
     if n >= m:
-        lam, Cm = ops.eigh_psd(ops.gram(M))
+        lam, Cm = _eigh_warm(ops, ops.gram(M), warm)
         W = Cm[:, :r].contiguous()
         s = torch.sqrt(torch.clamp_min(lam[:r], 0.0))
         U = ops.tsmm(M, W)
@@ -88,7 +158,7 @@ def left_svd(ops, M, r, want_v=False, comm=None, n_total=None):
         Vt = W.t().contiguous() if want_v else None
     else:
         Mt = M.t().contiguous()
-        lam, Cm = ops.eigh_psd(ops.gram(Mt))
+        lam, Cm = _eigh_warm(ops, ops.gram(Mt), warm)
         U = Cm[:, :r].contiguous()
         s = torch.sqrt(torch.clamp_min(lam[:r], 0.0))
         Vt = None
@@ -100,7 +170,7 @@ def left_svd(ops, M, r, want_v=False, comm=None, n_total=None):
 
 
 def hooi(ops, idx, val, shape, core_shape, num_iters=25, growth_tol=0.01, seed=None, verbose=False,
-         comm=None, user_range=None, item_inv=None):
+         comm=None, user_range=None, item_inv=None, warm_start=True):
     """Returns (u0, u1, u2, core, trace): device fp64 factors [n_mode x r_mode] with orthonormal
     columns ordered by descending singular value, core [r0 x r1 x r2], and the per-iteration core
     norms (lib/tensor.py:82-88).
@@ -129,21 +199,21 @@ def hooi(ops, idx, val, shape, core_shape, num_iters=25, growth_tol=0.01, seed=N
     u1 = ops.to_device(u1)
     u2 = ops.to_device(u2)
 
-    # (mode0 ; first matrix mode ; second matrix mode) as in lib/tensor.py:70,74,78
-    idx_dev = None
-    if hasattr(ops, 'mode_plan'):
-        idx_dev = torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int64)).to(ops.device)
-    mp0 = ModePlan(ops, idx, val, shape, 0, 2, 1, idx_dev)
-    mp1 = ModePlan(ops, idx, val, shape, 1, 2, 0, idx_dev)
-    mp2 = ModePlan(ops, idx, val, shape, 2, 1, 0, idx_dev)
+    # the three mode products of lib/tensor.py:70,74,78 in factored form (see factored_products): two CSR images of the
+    # tensor built once on the device, SpMM gathers + dense contractions on the matrix cores
+    uf = Unfoldings(ops, idx, val, shape)
 
     g_norm_old = 0.0
     trace = []
     ss = vv = u0 = None
+    warm = ({}, {}, {}) if warm_start else (None, None, None)      # per mode: the previous iteration's eigenvectors
     for i in range(num_iters):
-        u0, _, _ = left_svd(ops, ttm(ops, mp0, u2, u1), r0, comm=comm, n_total=n0_total)   # rows = local users
-        u1, _, _ = left_svd(ops, comm.allreduce(ttm(ops, mp1, u2, u0)), r1)
-        u2, ss, vv = left_svd(ops, comm.allreduce(ttm(ops, mp2, u1, u0)), r2, want_v=True)
+        res0, _ = factored_products(ops, uf, None, u1, u2, 0)
+        u0, _, _ = left_svd(ops, res0, r0, comm=comm, n_total=n0_total, warm=warm[0])        # rows = local users
+        res1, W1 = factored_products(ops, uf, u0, u1, u2, 1, comm=comm)
+        u1, _, _ = left_svd(ops, res1, r1, warm=warm[1])
+        res2, _ = factored_products(ops, uf, u0, u1, u2, 2, W1=W1)
+        u2, ss, vv = left_svd(ops, res2, r2, want_v=True, warm=warm[2])
         g_norm_new = float(torch.linalg.vector_norm(ss).item())
         g_growth = (g_norm_new - g_norm_old) / g_norm_new
         g_norm_old = g_norm_new

@@ -63,3 +63,14 @@ def test_random_hooi_cpu_double(cfg):
 @pytest.mark.parametrize('cfg', _configs(), ids=lambda c: 's%d_%s_%s' % (c['seed'], 'x'.join(map(str, c['shape'])), 'x'.join(map(str, c['ranks']))))
 def test_random_hooi_gpu(hip_ops, cfg):
     _check(hip_ops, cfg)
+
+
+def test_factored_mode_products_cpu_double():
+    """the factored mode products of tucker.hooi against the reference's loop, through the NumPy double of the device
+    operators (the same host code drives the HIP kernels in tests/test_gpu_kernels.py)"""
+    from numpy_ops import NumpyOps
+    import importlib
+    chk = importlib.import_module('test_gpu_kernels').check_factored_products
+    for ranks in ((6, 5, 3), (4, 3, 5)):
+        for weighted in (False, True):
+            chk(NumpyOps(), ranks, weighted)
