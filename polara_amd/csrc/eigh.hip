@@ -373,29 +373,26 @@ __global__ __launch_bounds__(EIGH_THREADS) void eigh_psd_kernel(int n, double *_
 // the rotation counts of an outer sweep go to a device counter, and every launch of a later sweep returns at once
 // when the previous sweep rotated nothing — the host never reads the counter.
 #define EIGH_BLOCK_LDS (144 * 1024)
+// one round of the block method for the pair of row blocks (bi, bj): load 2 w rows, sweep all their pairs in LDS, store
 template <int NC>
-__global__ __launch_bounds__(EIGH_THREADS) void eigh_block_round_kernel(int n, double *__restrict__ Wg, int64_t ldwg, int w,
-                                                                        int nb, int round, int sweep,
-                                                                        int *__restrict__ counters, double tol) {
-    extern __shared__ __attribute__((aligned(16))) double eigh_smem[];
-    __shared__ int s_rot;
-    if (sweep > 0 && counters[sweep - 1] == 0) return;        // the previous outer sweep found every pair orthogonal
+__device__ __forceinline__ void eigh_block_round_body(int n, double *__restrict__ Wg, int64_t ldwg, int w, int nb, int round,
+                                                      int pair, int sweep, int *__restrict__ counters, double tol,
+                                                      double *W, int *s_rot) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bi, bj;
-    rr_pair(nb, round, blockIdx.x, bi, bj);
+    rr_pair(nb, round, pair, bi, bj);
     const int i0 = bi * w, j0 = bj * w;
     const int ci = max(0, min(n, i0 + w) - i0), cj = max(0, min(n, j0 + w) - j0);
     const int nr = ci + cj;                                    // rows of this pair of blocks
-    if (nr < 2) return;
-    double *W = eigh_smem;
+    if (nr < 2) return;                                        // workgroup-uniform
     for (int e = tid; e < nr * n; e += EIGH_THREADS) {
         const int r = e / n, c = e - r * n;
         const int gr = r < ci ? i0 + r : j0 + (r - ci);
         W[e] = Wg[(int64_t)gr * ldwg + c];
     }
-    if (tid == 0) s_rot = 0;
+    if (tid == 0) *s_rot = 0;
     __syncthreads();
     const int m = (nr + 1) & ~1;
     const double tol2 = tol * tol;
@@ -412,7 +409,7 @@ __global__ __launch_bounds__(EIGH_THREADS) void eigh_block_round_kernel(int n, d
             double *wp = W + (int64_t)p * n, *wq = W + (int64_t)q * n;
             const bool rot = eigh_pair_step<NC>(wp, wq, n, t, act, tol2);
             const unsigned long long rb = __ballot(rot && t == 0);
-            if (lane == 0 && rb) atomicAdd(&s_rot, __popcll(rb));
+            if (lane == 0 && rb) atomicAdd(s_rot, __popcll(rb));
         }
         __syncthreads();
     }
@@ -421,7 +418,67 @@ __global__ __launch_bounds__(EIGH_THREADS) void eigh_block_round_kernel(int n, d
         const int gr = r < ci ? i0 + r : j0 + (r - ci);
         Wg[(int64_t)gr * ldwg + c] = W[e];
     }
-    if (tid == 0 && s_rot) atomicAdd(&counters[sweep], s_rot);
+    if (tid == 0 && *s_rot) atomicAdd(&counters[sweep], *s_rot);
+}
+
+template <int NC>
+__global__ __launch_bounds__(EIGH_THREADS) void eigh_block_round_kernel(int n, double *__restrict__ Wg, int64_t ldwg, int w,
+                                                                        int nb, int round, int sweep,
+                                                                        int *__restrict__ counters, double tol) {
+    extern __shared__ __attribute__((aligned(16))) double eigh_smem[];
+    __shared__ int s_rot;
+    if (sweep > 0 && counters[sweep - 1] == 0) return;        // the previous outer sweep found every pair orthogonal
+    eigh_block_round_body<NC>(n, Wg, ldwg, w, nb, round, blockIdx.x, sweep, counters, tol, eigh_smem, &s_rot);
+}
+
+// All sweeps and rounds of the block method in ONE launch: nb / 2 workgroups (2 ... 6: one per CU, trivially co-resident),
+// a grid barrier between rounds.  The launch-per-round form above issued max_sweeps * (nb - 1) launches per solve whatever
+// the sweep count (the early-exit ones return at once but are still launched): 90 at 150 columns, 1 260 per (30,30,5)
+// HOOI build — a third of its wall time on the host.  Barrier: every thread releases its stores (the L2s of different XCDs
+// are not coherent within a kernel: agent-scope fences write back / invalidate), one thread counts the workgroup in on
+// a monotone counter and spins (bounded: a barrier that does not complete sets an error flag instead of hanging the GPU).
+__device__ __forceinline__ void eigh_grid_barrier(int *bar, int n_wg, int &epoch, int *err) {
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ++epoch;
+        __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const int target = epoch * n_wg;
+        long spins = 0;
+        while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1L << 24)) {       // ~ seconds: something is badly wrong (a workgroup never arrived)
+                atomicExch(err, 1);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    __threadfence();
+}
+
+template <int NC>
+__global__ __launch_bounds__(EIGH_THREADS) void eigh_block_persistent_kernel(int n, double *__restrict__ Wg, int64_t ldwg, int w,
+                                                                             int nb, int max_sweeps, int *__restrict__ counters,
+                                                                             double tol, int *__restrict__ bar) {
+    extern __shared__ __attribute__((aligned(16))) double eigh_smem[];
+    __shared__ int s_rot;
+    __shared__ int s_epoch;
+    if (threadIdx.x == 0) s_epoch = 0;
+    __syncthreads();
+    const int n_wg = gridDim.x;
+    for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+        // counters[sweep - 1] is complete: every workgroup added to it before the barrier that ended that sweep
+        if (sweep > 0 && __hip_atomic_load(&counters[sweep - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) break;
+        for (int round = 0; round < nb - 1; ++round) {
+            eigh_block_round_body<NC>(n, Wg, ldwg, w, nb, round, blockIdx.x, sweep, counters, tol, eigh_smem, &s_rot);
+            int epoch = s_epoch;
+            eigh_grid_barrier(bar, n_wg, epoch, bar + 1);
+            if (threadIdx.x == 0) s_epoch = epoch;
+            __syncthreads();
+            if (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;   // a barrier timed out: give up
+        }
+    }
 }
 
 __global__ void eigh_counters_init_kernel(int *counters, int n) {
@@ -472,11 +529,11 @@ __global__ __launch_bounds__(EIGH_THREADS) void eigh_chol_global_kernel(int n, d
 }
 
 // info[0] = outer sweeps that rotated something (+ the clean one that certified convergence), info[1] = converged
-__global__ void eigh_block_info_kernel(const int *counters, int max_sweeps, int *info) {
+__global__ void eigh_block_info_kernel(const int *counters, int max_sweeps, const int *bar, int *info) {
     int s = 0;
     while (s < max_sweeps && counters[s] != 0) ++s;
     info[0] = s < max_sweeps ? s + 1 : max_sweeps;
-    info[1] = s < max_sweeps;
+    info[1] = (s < max_sweeps) && bar[1] == 0;      // bar[1]: a grid barrier of the persistent kernel timed out
 }
 
 extern "C" int pk_eigh_psd_f64(void *stream, int32_t n, double *S_dev, int64_t lds_, double *evecs_dev,
@@ -531,19 +588,38 @@ extern "C" int pk_eigh_psd_f64(void *stream, int32_t n, double *S_dev, int64_t l
         }
         attr_set_b[slot_b] = true;
     }
-    if (max_sweeps > 30) max_sweeps = 30;   // every (sweep, round) is a launch, early-exit ones included
+    if (max_sweeps > 30) max_sweeps = 30;
     // the rotation counters of the outer sweeps live in evals_dev until the final pass writes the eigenvalues there
-    // (n > 136 doubles: room for every counter)
+    // (n > 136 doubles: room for every counter, the Cholesky flag and the two words of the grid barrier)
     int *counters = reinterpret_cast<int *>(evals_dev);
-    hipLaunchKernelGGL(eigh_counters_init_kernel, dim3(1), dim3(64), 0, st, counters, max_sweeps + 2);
+    hipLaunchKernelGGL(eigh_counters_init_kernel, dim3(1), dim3(64), 0, st, counters, max_sweeps + 4);
     int *chol_flag = counters + max_sweeps + 1;          // zeroed above: "sweeps ran on S"
+    int *bar = counters + max_sweeps + 2;                // [0] arrivals, [1] barrier time-out flag
     if (precondition)
         hipLaunchKernelGGL(eigh_chol_global_kernel, dim3(1), dim3(EIGH_THREADS), 0, st, n, S_dev, lds_, evecs_dev, ldv, chol_flag);
-    for (int sweep = 0; sweep < max_sweeps; ++sweep)
-        for (int round = 0; round < nb - 1; ++round)
-            hipLaunchKernelGGL(round_kern, dim3(nb / 2), dim3(EIGH_THREADS), lds_bytes, st, n, S_dev, lds_, w, nb,
-                               round, sweep, counters, tol);
-    if (info_dev) hipLaunchKernelGGL(eigh_block_info_kernel, dim3(1), dim3(1), 0, st, counters, max_sweeps, info_dev);
+    const char *pers_env = getenv("PK_EIGH_PERSISTENT");   // 0: one launch per (sweep, round), the round-2 form
+    if (pers_env == nullptr || atoi(pers_env) != 0) {
+        using pers_t = void (*)(int, double *, int64_t, int, int, int, int *, double, int *);
+        pers_t pers_kern = n <= 160 ? eigh_block_persistent_kernel<10> : n <= 256 ? eigh_block_persistent_kernel<16> : eigh_block_persistent_kernel<0>;
+        static bool attr_set_p[3] = {false, false, false};
+        if (!attr_set_p[slot_b]) {
+            hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(pers_kern),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, EIGH_BLOCK_LDS);
+            if (e1 != hipSuccess) {
+                pk_set_error("pk_eigh_psd_f64: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e1));
+                return PK_E_LAUNCH;
+            }
+            attr_set_p[slot_b] = true;
+        }
+        hipLaunchKernelGGL(pers_kern, dim3(nb / 2), dim3(EIGH_THREADS), lds_bytes, st, n, S_dev, lds_, w, nb, max_sweeps, counters,
+                           tol, bar);
+    } else {
+        for (int sweep = 0; sweep < max_sweeps; ++sweep)
+            for (int round = 0; round < nb - 1; ++round)
+                hipLaunchKernelGGL(round_kern, dim3(nb / 2), dim3(EIGH_THREADS), lds_bytes, st, n, S_dev, lds_, w, nb,
+                                   round, sweep, counters, tol);
+    }
+    if (info_dev) hipLaunchKernelGGL(eigh_block_info_kernel, dim3(1), dim3(1), 0, st, counters, max_sweeps, bar, info_dev);
     // norms, ordering, signs: the tail of the one-workgroup kernel (no sweeps of its own)
     hipLaunchKernelGGL((eigh_psd_kernel<false, 0>), dim3(1), dim3(EIGH_THREADS), 0, st, n, S_dev, lds_, evecs_dev, ldv, evals_dev,
                        0, tol, (int *)nullptr, 0, (const int *)chol_flag);
