@@ -460,6 +460,30 @@ int64_t pk_mat_nnz(const pk_mat *mat);   /* stored entries (after duplicate sums
  * written) when it stops unconverged — the reference's ARPACK raises there. */
 int pk_svd_build(pk_ctx *ctx, pk_mat *A, int32_t k, int32_t block, double tol, int32_t max_outer, uint64_t seed,
                  double *sigma_out, double *V_out, double *U_out, pk_build_stats *stats_out);
+/* The same build with the USERS sharded over `comm->world` ranks — one process (or thread) and one pk_ctx per GPU, the
+ * multi-device form of the coarse API (SURVEY 8b sketched `pk_ctx_create(device_ids, n_dev)`; with one process per GPU
+ * the devices meet through a communicator instead).  `A_local` holds this rank's rows (users) of the training matrix,
+ * all n_cols columns.  What is exchanged is exactly north_star's "all-reduce only for the Gramian step": after every
+ * Z = A_p^T (A_p X) the [n_cols x l] block is summed over ranks, and so is the l x l Rayleigh-Ritz matrix (A_p X)^T (A_p X);
+ * everything on the item side (orthonormalisation, filter recurrences, eigen-decompositions, locking decisions) is
+ * computed identically on every rank from all-reduced data and the same seed.  sigma_out / V_out are global and equal on
+ * all ranks; U_out (or NULL) holds this rank's rows.  Scoring needs no collective: every rank calls pk_score_topk /
+ * pk_serving_* on its own users with the replicated V.
+ * The library does not link a collective library: the host passes its communicator as a callback — with RCCL
+ *     int ar(void *user, void *buf, int64_t n, void *stream) {
+ *         return ncclAllReduce(buf, buf, n, ncclDouble, ncclSum, (ncclComm_t)user, (hipStream_t)stream) == ncclSuccess ? 0 : -1; }
+ * `stream` is the context's HIP stream: the call must be ordered on it (enqueue, or block until done). */
+typedef struct pk_comm {
+    int32_t rank, world;
+    int (*allreduce_sum_f64)(void *user, void *buf_dev, int64_t count, void *stream);   /* in place, DEVICE pointer; 0 = ok */
+    void *user;
+} pk_comm;
+int pk_svd_build_sharded(pk_ctx *ctx, pk_mat *A_local, const pk_comm *comm, int32_t k, int32_t block, double tol,
+                         int32_t max_outer, uint64_t seed, double *sigma_out, double *V_out, double *U_out_local,
+                         pk_build_stats *stats_out);
+/* the context's HIP stream (hipStream_t as void*): what a pk_comm callback is handed, for hosts that create the
+ * communicator's work on it */
+void *pk_ctx_stream(pk_ctx *ctx);
 /* Recommendations for the users of T (rows: test users, columns: the n_items items): scores = (T V) V^T, seen items
  * (every stored entry of T) pushed below all unseen ones when filter_seen, topk item ids per user by descending score
  * -> out_idx[n_users * topk] int64 row-major (the `top_recs` of models.py:400-405; -1 pads a user with fewer than topk

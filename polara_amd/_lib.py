@@ -99,6 +99,8 @@ PROTOTYPES = {
     'pk_mat_free': (None, [_vp, _vp]),
     'pk_mat_nnz': (_i64, [_vp]),
     'pk_svd_build': (C.c_int, [_vp, _vp, _i32, _i32, _f64, _i32, C.c_uint64, _vp, _vp, _vp, _vp]),
+    'pk_svd_build_sharded': (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f64, _i32, C.c_uint64, _vp, _vp, _vp, _vp]),
+    'pk_ctx_stream': (_vp, [_vp]),
     'pk_score_topk': (C.c_int, [_vp, _i64, _i32, _vp, _vp, _i32, _i32, _vp, _vp]),
     'pk_serving_create': (C.c_int, [_vp, _i64, _i32, _vp, _vp, C.POINTER(_vp)]),
     'pk_serving_score': (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp]),

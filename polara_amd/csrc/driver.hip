@@ -641,12 +641,38 @@ extern "C" int64_t pk_mat_nnz(const pk_mat *m) { return m ? m->A.nnz : -1; }
 // ------------------------------------------------------------------------------------------------------------
 // pk_svd_build: polara_amd/solver.py::svd_topk restated (models.py:835-855)
 // ------------------------------------------------------------------------------------------------------------
+static int svd_build_impl(pk_ctx *ctx, pk_mat *A, const pk_comm *comm, int32_t k, int32_t block, double tol, int32_t max_outer,
+                          uint64_t seed, double *sigma_out, double *V_out, double *U_out, pk_build_stats *stats_out);
+
 extern "C" int pk_svd_build(pk_ctx *ctx, pk_mat *A, int32_t k, int32_t block, double tol, int32_t max_outer, uint64_t seed,
                             double *sigma_out, double *V_out, double *U_out, pk_build_stats *stats_out) {
+    return svd_build_impl(ctx, A, nullptr, k, block, tol, max_outer, seed, sigma_out, V_out, U_out, stats_out);
+}
+
+extern "C" int pk_svd_build_sharded(pk_ctx *ctx, pk_mat *A_local, const pk_comm *comm, int32_t k, int32_t block, double tol,
+                                    int32_t max_outer, uint64_t seed, double *sigma_out, double *V_out, double *U_out_local,
+                                    pk_build_stats *stats_out) {
+    if (!comm || comm->world < 1 || comm->rank < 0 || comm->rank >= comm->world || (comm->world > 1 && !comm->allreduce_sum_f64))
+        return ctx ? fail(ctx, PK_E_INVALID, "pk_svd_build_sharded: bad communicator") : PK_E_INVALID;
+    return svd_build_impl(ctx, A_local, comm->world > 1 ? comm : nullptr, k, block, tol, max_outer, seed, sigma_out, V_out,
+                          U_out_local, stats_out);
+}
+
+extern "C" void *pk_ctx_stream(pk_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+static int svd_build_impl(pk_ctx *ctx, pk_mat *A, const pk_comm *comm, int32_t k, int32_t block, double tol, int32_t max_outer,
+                          uint64_t seed, double *sigma_out, double *V_out, double *U_out, pk_build_stats *stats_out) {
     if (!ctx || !A) return PK_E_INVALID;
     std::lock_guard<std::mutex> lock(ctx->mu);
     PoolScope pool_scope(ctx);
     (void)hipSetDevice(ctx->device);
+    // users sharded over ranks: the two places where a sum over USERS leaves the rank (solver.py: comm.allreduce)
+    auto allreduce = [&](DMat &M) -> int {
+        if (!comm) return PK_OK;
+        if (comm->allreduce_sum_f64(comm->user, M.p(), (int64_t)M.n * M.l, (void *)ctx->stream) != 0)
+            return fail(ctx, PK_E_LAUNCH, "pk_svd_build_sharded: the communicator's all-reduce failed");
+        return PK_OK;
+    };
     const int64_t n_items = A->A.n_cols, n_users = A->A.n_rows;
     if (k < 1 || k > n_items || !sigma_out || !V_out) return fail(ctx, PK_E_INVALID, "pk_svd_build: k must satisfy 0 < k <= n_items; outputs required");
     if (tol <= 0) tol = 1e-12;
@@ -685,6 +711,7 @@ extern "C" int pk_svd_build(pk_ctx *ctx, pk_mat *A, int32_t k, int32_t block, do
         if (!Y.ok() || !Z.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (gramian step)");
         CK(spmm_full(ctx, A->A, Xb, Y));
         CK(spmm_t(ctx, A, Y, Z));
+        CK(allreduce(Z));
         stats.gramian_steps += 1;
         return PK_OK;
     };
@@ -697,12 +724,14 @@ extern "C" int pk_svd_build(pk_ctx *ctx, pk_mat *A, int32_t k, int32_t block, do
         if (!Y.ok() || !Z.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (Rayleigh-Ritz)");
         CK(spmm_full(ctx, A->A, X, Y));
         CK(S.gram(Y, Y, H));
+        CK(allreduce(H));
         Dev theta_dev;
         CK(S.eigh(H, theta_host, Cm, theta_dev));
         CK(S.tsmm(X, Cm, Xr));
         CK(S.tsmm(Y, Cm, Yr));
         X = std::move(Xr);
         CK(spmm_t(ctx, A, Yr, Z));
+        CK(allreduce(Z));
         stats.gramian_steps += 1;
         CK(S.resid(Z, X, theta_dev, res_host));
         const double lam1 = lam_lock.empty() ? theta_host[0] : lam_lock[0];

@@ -7,7 +7,8 @@
               oracle; `make_golden_large.py`), the rank reduction after the build against the
               reference's own `round_core` applied to the oracle's factors, and (30,30,5) — where the reference
               raises — through properties of a Tucker fit;
-  configs[4]  a 131 072-user shard of the 50M x 500K job: rank 200 build + top-50 lists vs the oracle on a sample.
+  configs[4]  a 1M-user shard of the 50M x 500K job (1/6 of one GPU's share at 8 GPUs): rank 200 build + top-50 lists vs
+              the oracle on a sample.
 
 Inputs are re-created from seeds (`polara_amd.synth`); nothing here reads /root/reference.
 Tolerances: singular values / scores 1e-9 relative (contract: 1e-4); lists identical on every row whose reference
@@ -253,7 +254,7 @@ def test_coffee_ml1m_config3_full_feedback_rank(hip_ops):
 # ---------------------------------------------------------------------------------------------------------------
 def test_s50m_shard_config4_rank200_top50(hip_ops):
     ops = hip_ops
-    n_users, n_items, rank, topk = 131072, 500_000, 200, 50
+    n_users, n_items, rank, topk = 1_000_000, 500_000, 200, 50       # the shard at the size bench.py times
     c = csr_to_numpy(planted_csr(n_users, n_items, 50, rank // 4, levels=5, seed=5, device=str(ops.device), min_items=20,
                                  max_items=2000, chunk_rows=1024))
     torch.cuda.empty_cache()

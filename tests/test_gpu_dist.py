@@ -12,6 +12,25 @@ from conftest import ROOT, free_port
 pytestmark = pytest.mark.gpu
 
 
+def test_sharded_path_over_rccl_when_two_gpus_are_visible(capsys):
+    """FIRST in this file: wherever two GPUs are visible the real thing runs before anything else — one rank
+    per GPU over RCCL, the sharded build + scoring against the single-GPU lists (dist_worker_nccl.py), then bench.py as
+    the driver launches it.  The device count and RCCL's version banner (NCCL_DEBUG=VERSION) are printed either way."""
+    import torch
+    n = torch.cuda.device_count()
+    with capsys.disabled():
+        print('\n[dist] visible GPUs: %d (%s)' % (n, ', '.join(torch.cuda.get_device_name(i) for i in range(n))))
+    if n < 2:
+        pytest.skip('RCCL path NOT exercised: %d GPU visible, the nccl backend needs one process per GPU (>= 2)' % n)
+    r = _torchrun(os.path.join(ROOT, 'tests', 'dist_worker_nccl.py'), 2, extra_env={'NCCL_DEBUG': 'VERSION'})
+    with capsys.disabled():
+        print('[dist] ' + '\n[dist] '.join(l for l in (r.stdout + r.stderr).splitlines() if 'NCCL' in l or 'RCCL' in l or 'DIST_NCCL' in l))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert 'DIST_NCCL_RESULT' in r.stdout
+    r = _torchrun(os.path.join(ROOT, 'bench.py'), 2, args=['--gpus', '2', '--steps', '3', '--warmup', '1', '--scale', '0.1'])
+    assert r.returncode == 0 and '"n_gpus":2' in r.stdout.replace(' ', ''), r.stdout[-2000:] + r.stderr[-3000:]
+
+
 def test_two_rank_sharded_path_on_hip_backend():
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
@@ -27,18 +46,6 @@ def _torchrun(script, n, extra_env=None, args=(), timeout=900):
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
            '--master-addr', '127.0.0.1', '--master-port', str(free_port()), script] + list(args)
     return subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout)
-
-
-def test_sharded_path_over_rccl_when_two_gpus_are_visible():
-    import torch
-    n = torch.cuda.device_count()
-    if n < 2:
-        pytest.skip('RCCL path NOT exercised: %d GPU visible, the nccl backend needs one process per GPU (>= 2)' % n)
-    r = _torchrun(os.path.join(ROOT, 'tests', 'dist_worker_nccl.py'), 2)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert 'DIST_NCCL_RESULT' in r.stdout
-    r = _torchrun(os.path.join(ROOT, 'bench.py'), 2, args=['--gpus', '2', '--steps', '3', '--warmup', '1', '--scale', '0.1'])
-    assert r.returncode == 0 and '"n_gpus": 2' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
 def test_bench_under_torchrun_two_ranks_one_gpu():
