@@ -109,7 +109,7 @@ def spmm_alg_bytes(meta):
 
 def pmc_traffic(tag):
     """HBM/fabric bytes of the two dominant kernels from the committed rocprofv3 --pmc passes of this command
-    (profiles/r02_<tag>_pmc_{fetch,write}_size.txt; separate passes, as the tool requires; the files carry the
+    (profiles/r03_<tag>_pmc_{fetch,write}_size.txt, else round 2's; separate passes, as the tool requires; the files carry the
     commit they were taken at).  FETCH_SIZE is doubled: both kernels read with 16 B/lane loads, which gfx950 tallies
     at half their size (MI355X_MICROARCH.md §HBM).  Returns {} when the summaries are not there.
       score       bytes per launch of score_candidates_kernel
@@ -127,8 +127,10 @@ def pmc_traffic(tag):
                     parts = line.split()
                     found.append((line, int(parts[-3]), float(parts[-2]) * 1024.0, float(parts[-1]) * 1024.0))   # launches, sum, per launch (KB -> B)
             return commit, found
-        cf, fetch = rows('r02_%s_pmc_fetch_size.txt' % tag)
-        _, write = rows('r02_%s_pmc_write_size.txt' % tag)
+        rnd = 'r03' if os.path.exists(os.path.join(ROOT, 'profiles', 'r03_%s_pmc_fetch_size.txt' % tag)) else 'r02'
+        out['round'] = rnd
+        cf, fetch = rows('%s_%s_pmc_fetch_size.txt' % (rnd, tag))
+        _, write = rows('%s_%s_pmc_write_size.txt' % (rnd, tag))
         pick = lambda table, pred: [r for r in table if pred(r[0])]
         sc_f, sc_w = pick(fetch, lambda l: 'score_candidates_kernel' in l), pick(write, lambda l: 'score_candidates_kernel' in l)
         if sc_f and sc_w:
