@@ -23,6 +23,8 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-u
          '-mllvm', '-amdgpu-mfma-vgpr-form=1']
 if os.environ.get('PK_FAST_BUILD'):   # kernel-tuning builds: only the rank-50 / top-10 scoring instances
     FLAGS.append('-DPK_FAST_BUILD')
+if os.environ.get('PK_SWEEP_WAVES'):    # kernel-tuning builds: force the sweep's register budget to this many waves per SIMD
+    FLAGS.append('-DPK_SWEEP_WAVES=' + os.environ['PK_SWEEP_WAVES'])
 if os.environ.get('PK_SCORE_PROFILE'):   # kernel-tuning builds: cycle counters inside the candidate sweep
     FLAGS.append('-DPK_SCORE_PROFILE')
 

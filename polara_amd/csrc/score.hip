@@ -177,6 +177,19 @@ __host__ __device__ constexpr int pk_ring_rows(int kc) { return kc == 16 ? 8 : R
 __host__ __device__ constexpr size_t pk_score_lds_bytes(int nstep, int kc) {
     return (size_t)(4 * pk_ring_rows(kc) * 64 + (pk_top_in_lds(nstep, kc) ? 4 * 32 * kc : 1)) * sizeof(uint2);
 }
+// SHARED instance: the rings and lists of its NW waves + three packed V tiles (2 * nstep KB each).  NW = 16 at KC = 16
+// (8 KB of selection state per wave: 152 KB, ONE workgroup of 1 024 threads per CU = 4 waves per SIMD; two workgroups of
+// eight waves would need 2 x 80 KB + their counters: 32 bytes more than a CU has), 8 beyond
+__host__ __device__ constexpr int pk_shared_waves(int kc) { return kc == 16 ? 16 : 8; }
+__host__ __device__ constexpr size_t pk_score_lds_bytes_shared(int nstep, int kc) {
+    return (size_t)(pk_shared_waves(kc) * pk_ring_rows(kc) * 64 + pk_shared_waves(kc) * 32 * kc) * sizeof(uint2) +
+           (size_t)3 * (2 * nstep) * 64 * 16;
+}
+// instantiated for top-10 lists up to rank 128 (the regime it was meant for; it is opt-in — PK_SCORE_SHARED=1 — because it
+// did not pay, see DESIGN.md K3 round 3: at best equal to the register-fed kernel on dense sweeps, slower on pruned ones)
+__host__ __device__ constexpr bool pk_shared_ok(int nstep, int kc) {
+    return kc == 16 && nstep <= 8 && pk_top_in_lds(nstep, kc) && pk_score_lds_bytes_shared(nstep, kc) <= 160 * 1024 - 64;
+}
 
 // Dense seen masks of the head of the catalogue (pk_seen_dense_build): mask[(group * tiles + tile) * 32 + user % 32] =
 // the 32-bit seen mask of that user in that tile for tile < tiles, ONE coalesced 128-byte load per tile-wave that is
@@ -190,8 +203,21 @@ struct SeenDense {
 
 // DENSE: the instance that reads them (the other one is the kernel as it was: in the throughput-bound regimes — full
 // sweeps, rank 200 — the extra registers and per-tile tests of a run-time switch cost 10 %).
-template <int NSTEP, int KC, bool STRIDED, bool DENSE>
-__global__ __launch_bounds__(256) void score_candidates_kernel(
+#ifdef PK_SWEEP_WAVES      // kernel-tuning builds: force the register budget of PK_SWEEP_WAVES waves per SIMD
+#define PK_SWEEP_OCC __attribute__((amdgpu_waves_per_eu(PK_SWEEP_WAVES, PK_SWEEP_WAVES)))
+#else
+#define PK_SWEEP_OCC
+#endif
+// SHARED (round 3): the workgroup is 8 or 16 waves (pk_shared_waves) that step through the item tiles together; the packed V tile of a step is
+// staged ONCE per workgroup in LDS (global_load_lds_dwordx4: no register round trip, double-buffered, one workgroup
+// barrier per tile) and every wave feeds its MFMAs from there with two ds_read_b128 per k-step.  What it buys: the two
+// V-tile register buffers (64 VGPRs at rank 50, 208 at rank 200) leave the register file — more resident waves per SIMD
+// where LDS allows (rings + lists are 8 KB per wave at KC = 16: 80 KB per workgroup, two workgroups per CU = 4 waves per
+// SIMD instead of 3) — and the V traffic out of L2 falls 8x.  What it costs: a barrier per tile in a kernel that has
+// none, waves that idle once their group is pruned until the whole workgroup is, lock-step with the slowest wave of
+// a tile (a flush sort stalls seven others).  Single sweeps only (no item splits), lists in LDS.
+template <int NSTEP, int KC, bool STRIDED, bool DENSE, bool SHARED = false>
+__global__ __launch_bounds__(SHARED ? 64 * pk_shared_waves(KC) : 256) PK_SWEEP_OCC void score_candidates_kernel(
     const float4 *__restrict__ Vp, const float4 *__restrict__ Ep, int64_t n_users, int n_items,
     int n_tiles, int split_tiles, int chunk_begin, int chunk_tiles,
     const int64_t *__restrict__ seen_ptr, const unsigned long long *__restrict__ seen_tiles,
@@ -212,16 +238,24 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
     // KC = 64 lists (16 KiB per wave) move to LDS too when the rank is high enough that the fragment
     // registers already limit the SIMD to one wave (NSTEP > 8, i.e. rank > 128: 96 KiB per workgroup, one workgroup per CU).
     constexpr bool TOP_LDS = pk_top_in_lds(NSTEP, KC);
-    extern __shared__ uint2 pk_score_lds[];      // [4][RG][64] rings, then [4][32*KC] top lists (TOP_LDS)
+    extern __shared__ __attribute__((aligned(16))) uint2 pk_score_lds[];      // [NW][RG][64] rings, then [NW][32*KC] top lists (TOP_LDS), then (SHARED) 2 V tiles
+    constexpr int NW = SHARED ? pk_shared_waves(KC) : 4;           // waves (= user groups) per workgroup
+    static_assert(!SHARED || (TOP_LDS && !STRIDED), "SHARED: single sweeps with the lists in LDS");
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t group = (int64_t)blockIdx.x * 4 + wave;
-    if (group * 32 >= n_users) return;  // whole wave leaves; the kernel has no workgroup barrier
+    const int64_t group_raw = (int64_t)blockIdx.x * NW + wave;
+    // SHARED: a wave without users (the tail of the last workgroup) still stages tiles and meets the barriers; it reads
+    // as group 0 and never writes
+    const bool participate = group_raw * 32 < n_users;
+    if (!SHARED && !participate) return;  // whole wave leaves; this form of the kernel has no workgroup barrier
+    const int64_t group = participate ? group_raw : 0;
+    bool alive = participate;             // SHARED: this wave still sweeps (not pruned, not finished in an earlier launch)
     PROF_DECL;
     const unsigned long long prof_k0 = PROF_T();
     uint2(*ring)[64] = reinterpret_cast<uint2(*)[64]>(pk_score_lds + wave * (RG * 64));
-    uint2 *top = pk_score_lds + 4 * RG * 64 + (TOP_LDS ? wave * (32 * KC) : 0);
+    uint2 *top = pk_score_lds + NW * RG * 64 + (TOP_LDS ? wave * (32 * KC) : 0);
+    float4 *vbuf = reinterpret_cast<float4 *>(pk_score_lds + NW * RG * 64 + (TOP_LDS ? NW * (32 * KC) : 0));   // [3][KQ][64]
 
     // Item split: blockIdx.y = h of S = gridDim.y owns every S-th tile of the catalogue, h, h+S, h+2S, ...
     // (`split_tiles` = ceil(n_tiles / S) of them at most), with its own threshold, rings, top lists and parked
@@ -326,7 +360,10 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
     } else {
         // resume: restore the lane state and the ring image written by the previous chunk launch
         const LaneState ls = *my_state;
-        if (ls.cnt == PK_LANE_DONE) return;  // wave-uniform: this group was pruned in an earlier launch
+        if (ls.cnt == PK_LANE_DONE) {        // wave-uniform: this group was pruned in an earlier launch
+            if constexpr (SHARED) alive = false;
+            else return;
+        }
         if (TOP_LDS)
             for (int s = lane; s < 32 * KC; s += 64) top[s] = make_uint2(__float_as_uint(my_score[s]), (unsigned)my_idx[s]);
         if (has_seen) sp = ls.sp;
@@ -610,6 +647,61 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
     // then starts from that threshold (just below it, so that those items themselves are pushed and the list fills) and
     // re-scores the same tiles — 12 MFMAs each — pushing a quarter of what it pushed from a cold start
     // (tools/probes/warmup_study.py: 27 instead of 86-92 pushes, 1.6 instead of 6-7 flushes per user at 16 tiles).
+    // SHARED: wave w of the workgroup brings groups w, w + NW, ... of the packed tile into buffer `buf` (one
+    // global_load_lds_dwordx4 per group: a wave writes 64 x 16 contiguous bytes, the [q][lane] layout the MFMA operands
+    // are read back in); stage_wait: my loads have landed and everybody's are visible
+    auto stage_tile = [&](int tile, int buf) {
+        if constexpr (SHARED) {
+            const float4 *src = Vp + ((int64_t)tile * KQ) * 64 + lane;
+            for (int q = wave; q < KQ; q += NW)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + q * 64),
+                                                 (__attribute__((address_space(3))) void *)(vbuf + (buf * KQ + q) * 64), 16, 0, 0);
+        }
+    };
+    // Every wave issues its share of tile t + 2 LAST in iteration t and then waits for everything OLDER than those
+    // loads — vmcnt counts in order — i.e. for its share of tile t + 1 (issued an iteration ago) and for this iteration's
+    // own prefetches, without waiting for what it has just requested (an s_waitcnt 0 here made every tile pay a full
+    // memory round trip: 1.6x slower than the register-fed kernel).  Three buffers: tile t is read, t + 1 complete, t + 2 in flight.
+    const int my_stage_loads = SHARED ? (KQ - wave + NW - 1) / NW : 0;     // 0 when wave >= KQ
+    auto stage_wait = [&](bool just_staged) {
+        if constexpr (SHARED) {
+            const int keep = just_staged ? my_stage_loads : 0;
+            // s_waitcnt vmcnt(keep) only: expcnt and lgkmcnt fields left at their maxima (gfx9 encoding)
+            switch (keep) {
+                case 0: __builtin_amdgcn_s_waitcnt(0x0F70); break;
+                case 1: __builtin_amdgcn_s_waitcnt(0x0F71); break;
+                case 2: __builtin_amdgcn_s_waitcnt(0x0F72); break;
+                case 3: __builtin_amdgcn_s_waitcnt(0x0F73); break;
+                default: __builtin_amdgcn_s_waitcnt(0x0F74); break;
+            }
+            __syncthreads();
+        }
+    };
+    // the score tile of one step: split-bf16 product (see the header): per 16-wide k-step  hi.hi + hi.lo + lo.hi, fp32
+    // accumulation — ONE instruction sequence for the bootstrap and the sweep, registers or LDS: the same bits
+    auto score_tile = [&](const float4(&a)[SHARED ? 1 : KQ], int buf) -> f32x16 {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        const float4 *vb = vbuf + (buf * KQ) * 64 + lane;
+#pragma unroll
+        for (int sidx = 0; sidx < NSTEP; ++sidx) {
+            float4 fh, fl;
+            if constexpr (SHARED) {
+                fh = vb[(2 * sidx) * 64];
+                fl = vb[(2 * sidx + 1) * 64];
+            } else {
+                fh = a[2 * sidx];
+                fl = a[2 * sidx + 1];
+            }
+            const bf16x8 vh = __builtin_bit_cast(bf16x8, fh), vl = __builtin_bit_cast(bf16x8, fl);
+            const bf16x8 eh = __builtin_bit_cast(bf16x8, e[2 * sidx]), el = __builtin_bit_cast(bf16x8, e[2 * sidx + 1]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, eh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, el, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, eh, acc, 0, 0, 0);
+        }
+        return acc;
+    };
     if (first && boot_tiles > 0 && floor_state == nullptr && !(ablate & 8)) {
         const unsigned long long prof_b0 = PROF_T();
         constexpr int BL = KC / 2;      // values kept per lane: the user's two lanes hold KC of them
@@ -619,43 +711,49 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
         for (int i = 0; i < BL; ++i) bl[i] = -INFINITY;
         const int64_t sp0 = sp;
         const unsigned long long n0 = nxt, n1 = nxt2, n2 = nxt3;
-        float4 a_nxt[KQ];
-        load_frags((tile_begin < n_tiles) ? tile_begin : 0, a_nxt);
+        float4 a_nxt[SHARED ? 1 : KQ];
+        if constexpr (SHARED) {
+            stage_tile((tile_begin < n_tiles) ? tile_begin : 0, 0);
+            if (boot_tiles > 1 && tile_begin + S < tile_end) stage_tile(tile_begin + S, 1);
+            stage_wait(false);
+        } else {
+            load_frags((tile_begin < n_tiles) ? tile_begin : 0, a_nxt);
+        }
         unsigned m_nxt = 0u;
         if constexpr (DENSE) m_nxt = (tile_begin < dense_tiles) ? dense_row[(int64_t)tile_begin * 32] : 0u;
+        // (trip count uniform over the workgroup: SHARED has a barrier per tile)
         for (int i = 0, tile = tile_begin; i < boot_tiles && tile < tile_end; ++i, tile += S) {
-            float4 a[KQ];
+            float4 a[SHARED ? 1 : KQ];
+            if constexpr (!SHARED) {
 #pragma unroll
-            for (int q = 0; q < KQ; ++q) a[q] = a_nxt[q];
-            load_frags((tile + S < tile_end) ? tile + S : tile, a_nxt);
-            if constexpr (DENSE) {
-                m_dense = m_nxt;
-                m_nxt = (tile + S < dense_tiles) ? dense_row[(int64_t)(tile + S) * 32] : 0u;
+                for (int q = 0; q < KQ; ++q) a[q] = a_nxt[q];
+                load_frags((tile + S < tile_end) ? tile + S : tile, a_nxt);
             }
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-            for (int sidx = 0; sidx < NSTEP; ++sidx) {     // the SAME instruction sequence as the sweep below: the same bits
-                const bf16x8 vh = __builtin_bit_cast(bf16x8, a[2 * sidx]), vl = __builtin_bit_cast(bf16x8, a[2 * sidx + 1]);
-                const bf16x8 eh = __builtin_bit_cast(bf16x8, e[2 * sidx]), el = __builtin_bit_cast(bf16x8, e[2 * sidx + 1]);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, eh, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, el, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, eh, acc, 0, 0, 0);
-            }
-            const unsigned m2 = walk_mask(tile) >> (4 * hi);
-#pragma unroll
-            for (int g = 0; g < BG; ++g) {
-                float x = -INFINITY;
-#pragma unroll
-                for (int r = g * (16 / BG); r < (g + 1) * (16 / BG); ++r)
-                    x = fmaxf(x, (m2 & (1u << ((r & 3) + 8 * (r >> 2)))) ? -INFINITY : acc[r]);
-#pragma unroll
-                for (int i2 = 0; i2 < BL; ++i2) {      // sorted insertion, descending
-                    const float up = fmaxf(bl[i2], x);
-                    x = fminf(bl[i2], x);
-                    bl[i2] = up;
+            if (!SHARED || alive) {
+                if constexpr (DENSE) {
+                    m_dense = m_nxt;
+                    m_nxt = (tile + S < dense_tiles) ? dense_row[(int64_t)(tile + S) * 32] : 0u;
                 }
+                const f32x16 acc = score_tile(a, i % 3);
+                const unsigned m2 = walk_mask(tile) >> (4 * hi);
+#pragma unroll
+                for (int g = 0; g < BG; ++g) {
+                    float x = -INFINITY;
+#pragma unroll
+                    for (int r = g * (16 / BG); r < (g + 1) * (16 / BG); ++r)
+                        x = fmaxf(x, (m2 & (1u << ((r & 3) + 8 * (r >> 2)))) ? -INFINITY : acc[r]);
+#pragma unroll
+                    for (int i2 = 0; i2 < BL; ++i2) {      // sorted insertion, descending
+                        const float up = fmaxf(bl[i2], x);
+                        x = fminf(bl[i2], x);
+                        bl[i2] = up;
+                    }
+                }
+            }
+            if constexpr (SHARED) {
+                const bool more = i + 2 < boot_tiles && tile + 2 * S < tile_end;
+                if (more) stage_tile(tile + 2 * S, (i + 2) % 3);
+                stage_wait(more);
             }
         }
         // the (KC / 2)-th value of each lane: together at least KC items of the user score that much
@@ -686,81 +784,108 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
         // compiler drains vmcnt(0) at the loop head, which exposes the latency of the late loads.
         // Forcing five waves per SIMD (amdgpu_waves_per_eu: 96 VGPRs, 12 spilled) on the pruned sweep: 3.47 vs
         // 3.29 ms; four (120 VGPRs, no spill) is what the register allocator picks unprompted.
-        float4 a_nxt[KQ];
-        load_frags((tile_begin < n_tiles) ? tile_begin : 0, a_nxt);
+        float4 a_nxt[SHARED ? 1 : KQ];
+        // SHARED: who still sweeps is counted per iteration in one of three LDS counters (waves that stop in iteration
+        // `it` add to s_cnt[it % 3] before its barrier, everybody reads it behind the barrier, wave 0 clears the next one
+        // while nobody can touch it): the decision to leave the loop is the same in every wave
+        __shared__ int s_cnt[4];
+        int dead = 0;
+        if constexpr (SHARED) {
+            if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+            __syncthreads();
+            if (!alive && lane == 0) atomicAdd(&s_cnt[3], 1);
+            stage_tile((tile_begin < n_tiles) ? tile_begin : 0, 0);
+            if (tile_begin + S < tile_end) stage_tile(tile_begin + S, 1);
+            stage_wait(false);
+            dead = s_cnt[3];
+        } else {
+            load_frags((tile_begin < n_tiles) ? tile_begin : 0, a_nxt);
+        }
         unsigned m_nxt = 0u;
         if constexpr (DENSE) m_nxt = (tile_begin < dense_tiles) ? dense_row[(int64_t)tile_begin * 32] : 0u;
         float tb = prune ? tile_bound[(tile_begin < n_tiles) ? tile_begin : 0] : 0.0f;
         PROF_ADD(4, prof_k0);
         int step = 0;
-        for (int tile = tile_begin; tile < tile_end; tile += S, ++step) {
-            if (prune) {
+        for (int tile = tile_begin; tile < tile_end && dead < NW; tile += S, ++step) {
+            if constexpr (SHARED) {
+                if (threadIdx.x == 0) s_cnt[(step + 1) % 3] = 0;
+            }
+            if ((!SHARED || alive) && prune) {
                 // can any item from this tile on still enter a list of this wave?
                 const bool open = en * tb > tau;
                 const unsigned long long ob = __ballot(open);
                 if (ob == 0ull) {
                     pruned = true;
                     exit_tile = tile;
-                    break;
-                }
-                // tau is only refreshed by a flush; the last few users that keep the wave in the sweep
-                // get their pending ring entries merged so that their tau is exact (checked every 8 tiles)
-                if (((STRIDED ? step : tile) & 7) == 7 && __popcll(ob) <= 16) {
-                    const unsigned long long pend = __ballot(cnt > 0);
-                    flush_set((unsigned)(ob | (ob >> 32)) & (unsigned)(pend | (pend >> 32)));
-                }
-                tb = tile_bound[(tile + S < n_tiles) ? tile + S : tile];   // suffix maximum: covers my later tiles
-            }
-            float4 a[KQ];
-#pragma unroll
-            for (int q = 0; q < KQ; ++q) a[q] = a_nxt[q];
-            load_frags((tile + S < tile_end) ? tile + S : tile, a_nxt);
-            if constexpr (DENSE) {
-                m_dense = m_nxt;
-                m_nxt = (tile + S < dense_tiles) ? dense_row[(int64_t)(tile + S) * 32] : 0u;
-            }
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-            // split-bf16 product (see the header): per 16-wide k-step  hi.hi + hi.lo + lo.hi, accumulated in fp32
-#pragma unroll
-            for (int sidx = 0; sidx < NSTEP; ++sidx) {
-                const bf16x8 vh = __builtin_bit_cast(bf16x8, a[2 * sidx]), vl = __builtin_bit_cast(bf16x8, a[2 * sidx + 1]);
-                const bf16x8 eh = __builtin_bit_cast(bf16x8, e[2 * sidx]), el = __builtin_bit_cast(bf16x8, e[2 * sidx + 1]);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, eh, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, el, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, eh, acc, 0, 0, 0);
-            }
-            // The list cursor must advance every tile; the mask itself is only needed when some
-            // RAW score beats the threshold (f32 MFMA shares the SIMD's FP32 lanes with the VALU, so
-            // every VALU instruction here is paid in MFMA time: keep the common path to
-            // 8 v_max3 + 1 compare and mask lazily).
-            const unsigned long long prof_w0 = PROF_T();
-            const unsigned mask = walk_mask(tile);
-            PROF_ADD(2, prof_w0);
-            float m_all = fmaxf(acc[0], acc[1]);
-#pragma unroll
-            for (int r = 2; r < 16; ++r) m_all = fmaxf(m_all, acc[r]);
-            if (!(ablate & 2) && __any(m_all > tau)) {
-                const unsigned long long prof_p0 = PROF_T();
-                float sc[16];
-                float m = m_all;
-                if (__any(mask != 0)) {
-                    const unsigned m2 = mask >> (4 * hi);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        sc[r] = (m2 & (1u << ((r & 3) + 8 * (r >> 2)))) ? -INFINITY : acc[r];
-                    m = fmaxf(sc[0], sc[1]);
-#pragma unroll
-                    for (int r = 2; r < 16; ++r) m = fmaxf(m, sc[r]);
+                    if constexpr (SHARED) {
+                        alive = false;      // keeps staging and meeting the barriers until the whole workgroup is done
+                        if (lane == 0) atomicAdd(&s_cnt[step % 3], 1);
+                    } else {
+                        break;
+                    }
                 } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) sc[r] = acc[r];
+                    // tau is only refreshed by a flush; the last few users that keep the wave in the sweep
+                    // get their pending ring entries merged so that their tau is exact (checked every 8 tiles)
+                    if (((STRIDED ? step : tile) & 7) == 7 && __popcll(ob) <= 16) {
+                        const unsigned long long pend = __ballot(cnt > 0);
+                        flush_set((unsigned)(ob | (ob >> 32)) & (unsigned)(pend | (pend >> 32)));
+                    }
+                    tb = tile_bound[(tile + S < n_tiles) ? tile + S : tile];   // suffix maximum: covers my later tiles
                 }
-                if (__any(m > tau)) push_candidates(sc, tile * 32);
-                PROF_ADD(3, prof_p0);
+            }
+            float4 a[SHARED ? 1 : KQ];
+            if constexpr (!SHARED) {
+#pragma unroll
+                for (int q = 0; q < KQ; ++q) a[q] = a_nxt[q];
+                load_frags((tile + S < tile_end) ? tile + S : tile, a_nxt);
+            }
+            if (!SHARED || alive) {
+                if constexpr (DENSE) {
+                    m_dense = m_nxt;
+                    m_nxt = (tile + S < dense_tiles) ? dense_row[(int64_t)(tile + S) * 32] : 0u;
+                }
+                const f32x16 acc = score_tile(a, step % 3);
+                // The list cursor must advance every tile; the mask itself is only needed when some
+                // RAW score beats the threshold (f32 MFMA shares the SIMD's FP32 lanes with the VALU, so
+                // every VALU instruction here is paid in MFMA time: keep the common path to
+                // 8 v_max3 + 1 compare and mask lazily).
+                const unsigned long long prof_w0 = PROF_T();
+                const unsigned mask = walk_mask(tile);
+                PROF_ADD(2, prof_w0);
+                float m_all = fmaxf(acc[0], acc[1]);
+#pragma unroll
+                for (int r = 2; r < 16; ++r) m_all = fmaxf(m_all, acc[r]);
+                if (!(ablate & 2) && __any(m_all > tau)) {
+                    const unsigned long long prof_p0 = PROF_T();
+                    float sc[16];
+                    float m = m_all;
+                    if (__any(mask != 0)) {
+                        const unsigned m2 = mask >> (4 * hi);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            sc[r] = (m2 & (1u << ((r & 3) + 8 * (r >> 2)))) ? -INFINITY : acc[r];
+                        m = fmaxf(sc[0], sc[1]);
+#pragma unroll
+                        for (int r = 2; r < 16; ++r) m = fmaxf(m, sc[r]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sc[r] = acc[r];
+                    }
+                    if (__any(m > tau)) push_candidates(sc, tile * 32);
+                    PROF_ADD(3, prof_p0);
+                }
+            }
+            if constexpr (SHARED) {
+                const bool more = tile + 2 * S < tile_end;
+                if (more) stage_tile(tile + 2 * S, (step + 2) % 3);
+                stage_wait(more);
+                dead += s_cnt[step % 3];
             }
         }
+    }
+    if constexpr (SHARED) {
+        // nothing to write for a wave without users or one whose group had left the sweep before this launch
+        if (!participate || (!alive && !pruned)) return;
     }
 
     if (!last && !pruned) {
@@ -1217,6 +1342,7 @@ struct SweepPhase {
     int slot_base;                  // first list / state slot of this launch sequence (phase 2: 1, the head owns slot 0)
     const LaneState *floor_state;   // phase 2: the head's lane records (threshold to start from), else nullptr
     int boot_tiles;                 // tiles of the threshold bootstrap in front of a sweep that starts cold (0: none)
+    int shared;                     // single sweeps: the eight-wave workgroup with the V tiles staged in LDS
 };
 
 template <int NSTEP>
@@ -1255,6 +1381,25 @@ static int launch_candidates_n(hipStream_t st, int KC, int ablate, dim3 grid, co
                 return PK_E_LAUNCH;                                                                             \
             }                                                                                                   \
             attr_set = true;                                                                                    \
+        }                                                                                                       \
+    }                                                                                                           \
+    if constexpr (pk_shared_ok(NSTEP, KCV)) {                                                                   \
+        if (ph.shared && grid.y == 1 && ph.floor_state == nullptr) {                                            \
+            static bool attr_set_s = false;                                                                     \
+            if (!attr_set_s) {                                                                                  \
+                hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(&score_candidates_kernel<NSTEP, KCV, false, DENSE_OK, true>), \
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)pk_score_lds_bytes_shared(NSTEP, KCV)); \
+                if (e2 != hipSuccess) {                                                                         \
+                    pk_set_error("pk_score_candidates_f32: cannot raise the LDS limit (shared): %s", hipGetErrorString(e2)); \
+                    return PK_E_LAUNCH;                                                                         \
+                }                                                                                               \
+                attr_set_s = true;                                                                              \
+            }                                                                                                   \
+            hipLaunchKernelGGL((score_candidates_kernel<NSTEP, KCV, false, DENSE_OK, true>), dim3((grid.x * 4 + pk_shared_waves(KCV) - 1) / pk_shared_waves(KCV)), dim3(64 * pk_shared_waves(KCV)), \
+                               pk_score_lds_bytes_shared(NSTEP, KCV), st, Vp, Ep, n_users,                      \
+                               n_items, n_tiles, split_tiles, chunk_begin, chunk_tiles, seen_ptr, seen_tiles, seen_ntiles, cs, ci, st_lane, st_ring,  \
+                               user_bound, tile_bound, ablate, dn, 0, ph.slot_base, nullptr, ph.boot_tiles);    \
+            continue;                                                                                           \
         }                                                                                                       \
     }                                                                                                           \
     if (grid.y > 1 || ph.floor_state != nullptr)                                                                \
@@ -1350,6 +1495,8 @@ static int pk_sweep_launches(hipStream_t st, int64_t n_users, int64_t n_items, i
     // threshold bootstrap in front of every sweep that starts cold: 16 tiles (PK_SCORE_BOOT_TILES overrides, 0 = off)
     const char *boot_env = getenv("PK_SCORE_BOOT_TILES");
     ph.boot_tiles = ph.floor_state ? 0 : (boot_env ? atoi(boot_env) : 16);
+    const char *shared_env = getenv("PK_SCORE_SHARED");     // tuning: 1 = the LDS-staged eight-wave instance for single sweeps
+    ph.shared = shared_env ? atoi(shared_env) : 0;
     dim3 grid((unsigned)pk_ceil_div(groups, 4), (unsigned)splits);
     const float4 *Vp = reinterpret_cast<const float4 *>(Vp_dev);
     const float4 *Ep = reinterpret_cast<const float4 *>(Ep_dev);
@@ -1422,7 +1569,7 @@ extern "C" int pk_score_candidates_f32(void *stream, int64_t n_users, int64_t n_
     SeenDense dense{seen_dense_dev, seen_skip_dev, seen_ptr_dev ? dense_tiles : 0};
     return pk_sweep_launches(pk_stream(stream), n_users, n_items, (int)pk_ceil_div(n_items, 32), K, Vp_dev, Ep_dev,
                              seen_ptr_dev, seen_tiles_dev, seen_ntiles_dev, KC, splits, splits, cand_score_dev, cand_idx_dev,
-                             state_dev, tiles_per_chunk, user_bound_dev, tile_bound_dev, dense, SweepPhase{0, 0, nullptr, 0});
+                             state_dev, tiles_per_chunk, user_bound_dev, tile_bound_dev, dense, SweepPhase{0, 0, nullptr, 0, 0});
 }
 
 // ---- two-phase sweep -------------------------------------------------------------------------------------------------
@@ -1579,13 +1726,13 @@ extern "C" int pk_score_two_phase_f32(void *stream, int64_t n_users, int64_t n_i
     // rings merged, lists written, exit tile and threshold in the lane records — so the head must fit one item chunk)
     rc = pk_sweep_launches(st, n_users, n_items, head_tiles, K, Vp_dev, Ep_dev, seen_ptr_dev, seen_tiles_dev, seen_ntiles_dev,
                            KC, 1, total_slots, work_score_dev, work_idx_dev, state_dev, head_tiles, user_bound_dev,
-                           tile_bound_dev, dense, SweepPhase{0, 0, nullptr, 0});
+                           tile_bound_dev, dense, SweepPhase{0, 0, nullptr, 0, 0});
     if (rc != PK_OK) return rc;
     // phase 2: the splits, from the head's thresholds
     LaneState *st_lane = static_cast<LaneState *>(state_dev);
     rc = pk_sweep_launches(st, n_users, n_items, n_tiles, K, Vp_dev, Ep_dev, seen_ptr_dev, seen_tiles_dev, seen_ntiles_dev,
                            KC, splits, total_slots, work_score_dev, work_idx_dev, state_dev, tiles_per_chunk, user_bound_dev,
-                           tile_bound_dev, dense, SweepPhase{head_tiles, 1, st_lane, 0});
+                           tile_bound_dev, dense, SweepPhase{head_tiles, 1, st_lane, 0, 0});
     if (rc != PK_OK) return rc;
     const int64_t n_pad = pk_ceil_div(n_users, 32) * 32;
     const int slots = (int)pk_ceil_div((int64_t)total_slots * KC, 64);

@@ -951,3 +951,46 @@ def test_rescore_sends_unbounded_lists_to_the_exact_path(hip_ops):
     m = np.zeros(n_users, bool)
     m[hip_ops.to_host(marked)] = True
     assert (f1[m] & 1).all() and np.array_equal(f1[~m], f0[~m]) and not (f0[m] & 1).any()
+
+
+@pytest.mark.parametrize('cfg', [dict(n_users=3000, n_items=9000, K=50, topk=10, chunk=0),
+                                 dict(n_users=1100, n_items=5000, K=100, topk=10, chunk=7),
+                                 dict(n_users=70, n_items=2600, K=24, topk=5, chunk=3)])
+def test_lds_shared_tile_sweep_equals_the_register_fed_sweep(hip_ops, cfg, monkeypatch):
+    """The SHARED instance of the candidate sweep (PK_SCORE_SHARED=1: sixteen waves per workgroup step through the item
+    tiles together, the packed V tile staged once per workgroup in LDS by global_load_lds, three buffers, one barrier per
+    tile): ids and scores equal to the barrier-free kernel's — pruned (waves idle until their workgroup is done) and full
+    sweeps, tiny item chunks (state parked and resumed under the barrier scheme, groups that finished in an earlier launch),
+    a last workgroup with waves that own no users, with and without the threshold bootstrap."""
+    from polara_amd import scoring
+    n_users, n_items, K, topk = cfg['n_users'], cfg['n_items'], cfg['K'], cfg['topk']
+    rng = np.random.RandomState(n_items + 1)
+    decay = (1.0 + np.arange(n_items)) ** -0.6
+    V = rng.randn(n_items, K) / np.sqrt(K) * decay[:, None]
+    indptr, indices, values = rand_csr(rng, n_users, n_items, 40, long_rows=[(2, n_items // 2), (40, n_items - 3)], empty_rows=[7])
+    T = hip_ops.csr(indptr, indices, values, (n_users, n_items))
+    F = scoring.FactorImage(hip_ops, hip_ops.to_device(V))
+    monkeypatch.setenv('PK_SCORE_HEAD_TILES', '0')
+    out = {}
+    try:
+        hip_ops.score_tiles_per_chunk = cfg['chunk']
+        hip_ops.score_splits_override = 1
+        for shared in ('0', '1'):
+            monkeypatch.setenv('PK_SCORE_SHARED', shared)
+            res = []
+            for boot in ('16', '0'):
+                monkeypatch.setenv('PK_SCORE_BOOT_TILES', boot)
+                st = {}
+                res += [scoring.recommend(hip_ops, F, T, topk, True, return_scores=True, stats=st),
+                        scoring.recommend(hip_ops, F, T, topk, True, return_scores=True, prune=False),
+                        scoring.recommend(hip_ops, F, T, topk, False, return_scores=True)]
+                res.append(st['tiles_scored'])
+            out[shared] = res
+    finally:
+        hip_ops.score_tiles_per_chunk = 0
+        hip_ops.score_splits_override = 0
+    for a, b in zip(out['0'], out['1']):
+        if isinstance(a, tuple):
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        else:
+            assert a == b          # the same tiles scored: a group's exit does not depend on its workgroup

@@ -13,6 +13,7 @@ def main():
     rank = int(sys.argv[2]) if len(sys.argv) > 2 else 50
     topk = int(sys.argv[3]) if len(sys.argv) > 3 else 10
     catalogue = sys.argv[4] if len(sys.argv) > 4 else 'svd'
+    prune = os.environ.get('PRUNE', '1') == '1'
     sys.argv = sys.argv[:1]
     args = B.parse()
     bench = B.Bench(args)
@@ -24,7 +25,7 @@ def main():
                dict(boot=0, head=32, s2=3), dict(boot=16, head=32, s2=3), dict(boot=16, head=32, s2=7), dict(boot=16, head=64, s2=3),
                dict(boot=16, head=64, s2=7), dict(boot=16, head=16, s2=3), dict(boot=16, head=16, s2=7)]
     if os.environ.get('VARIANTS'):      # "boot,head,s2 boot,head,s2 ..."
-        configs = [dict(zip(('boot', 'head', 's2'), (int(x) for x in v.split(',')))) for v in os.environ['VARIANTS'].split()]
+        configs = [dict(zip(('boot', 'head', 's2', 'shared'), (int(x) for x in v.split(',')))) for v in os.environ['VARIANTS'].split()]
     n_users_cap = int(os.environ.get('USERS', '0'))
     if n_users_cap:                     # a shard: the first users of the activity-ordered matrix would not be typical; take every k-th
         A = st['A']
@@ -40,22 +41,23 @@ def main():
         os.environ['PK_SCORE_BOOT_TILES'] = str(cfg['boot'])
         os.environ['PK_SCORE_HEAD_TILES'] = str(cfg['head'])
         os.environ['PK_SCORE_PHASE2_SPLITS'] = str(cfg['s2'])
+        os.environ['PK_SCORE_SHARED'] = str(cfg.get('shared', 0))
         for _ in range(3):
-            recs = scoring.recommend(ops, st['F'], st['A'], topk, True)
+            recs = scoring.recommend(ops, st['F'], st['A'], topk, True, prune=prune)
         torch.cuda.synchronize()
         ops.timers = {}
         for _ in range(20):
-            scoring.recommend(ops, st['F'], st['A'], topk, True, batches=1)
+            scoring.recommend(ops, st['F'], st['A'], topk, True, batches=1, prune=prune)
         torch.cuda.synchronize()
         ms = {k: float(np.mean(B.events_ms(v))) for k, v in ops.timers.items()}
         ops.timers = None
         t0 = time.perf_counter()
         for _ in range(20):
-            recs = scoring.recommend(ops, st['F'], st['A'], topk, True)
+            recs = scoring.recommend(ops, st['F'], st['A'], topk, True, prune=prune)
         torch.cuda.synchronize()
         pass_ms = (time.perf_counter() - t0) / 20 * 1e3
         stats = {}
-        scoring.recommend(ops, st['F'], st['A'], topk, True, stats=stats, batches=1)
+        scoring.recommend(ops, st['F'], st['A'], topk, True, stats=stats, batches=1, prune=prune)
         same = None
         if ref is None:
             ref = recs.clone()
