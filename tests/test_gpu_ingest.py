@@ -241,3 +241,25 @@ def test_diagonal_scaling_and_mode_plan_match_numpy(hip_ops, vdtype):
         assert plan['n_tasks'] == len(host['task_row']) and plan['n_long'] == len(host['long_row'])
         for k in ('task_row', 'task_begin', 'task_end', 'task_slot', 'long_row', 'long_slot_begin', 'long_slot_end'):
             assert np.array_equal(ops.to_host(plan[k])[:len(host[k])], host[k]), (mode0, k)
+
+
+@pytest.mark.parametrize('n_bins', [1, 5, 32, 33, 1000, 26744, 36864, 36865, 100000])
+def test_count_i32_matches_bincount(hip_ops, n_bins):
+    """pk_count_i32 (item popularity, mode sizes): the LDS-histogram form (<= 36 864 bins; wave ballots for <= 32 bins), the
+    direct form beyond and for short inputs; skewed keys (every key in one bin), keys outside [0, n_bins) ignored."""
+    ops = hip_ops
+    rng = np.random.RandomState(n_bins)
+    for n in (1, 100, 5000, 3_000_001):
+        keys = (rng.zipf(1.3, n) % n_bins).astype(np.int32)
+        keys[::17] = n_bins - 1
+        keys[5::1001] = -3                       # out of range: not counted
+        keys[7::1003] = n_bins + 2
+        kd = torch.from_numpy(keys).to(ops.device)
+        out = torch.full((n_bins,), -1, dtype=torch.int32, device=ops.device)
+        _lib.check(ops.lib.pk_count_i32(ops.stream(), n, _ptr(kd), n_bins, _ptr(out)), 'pk_count_i32')
+        valid = keys[(keys >= 0) & (keys < n_bins)]
+        assert np.array_equal(ops.to_host(out), np.bincount(valid, minlength=n_bins))
+    one = torch.full((200000,), min(3, n_bins - 1), dtype=torch.int32, device=ops.device)
+    out = torch.empty(n_bins, dtype=torch.int32, device=ops.device)
+    _lib.check(ops.lib.pk_count_i32(ops.stream(), 200000, _ptr(one), n_bins, _ptr(out)), 'pk_count_i32')
+    assert int(out[min(3, n_bins - 1)].item()) == 200000 and int(out.sum().item()) == 200000
