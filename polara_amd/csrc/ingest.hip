@@ -615,8 +615,10 @@ extern "C" int pk_csr_rows_by_length(void *stream, int64_t n_rows, int64_t nnz, 
 // mode where every atomic hits one of five addresses (profiles/r02_hooi_*).  Now a workgroup counts its slice of the keys
 // in an LDS histogram (up to 36 864 bins = 144 KB; LDS atomics, and for <= 32 bins wave ballots instead of atomics: a
 // popcount per bin and wave) and adds only its non-zero bins to the global counters: 64 workgroups x n_bins global atomics
-// on distinct addresses instead of n.  More bins than that (S-1M: 100 K items) keep the direct form — contention falls as
-// the bins grow.  Integer adds commute: the result does not depend on the order either way.
+// on distinct addresses instead of n.  More bins than that (S-1M: 100 K items, S-50M: 500 K) are counted in bin RANGES of
+// 36 864, one grid row per range, each re-reading the keys (4 bytes per key and range: 14 ranges over the 5e7 item ids of an
+// S-50M shard are 2.8 GB of streaming reads) — the direct form took 237 ms for 1e8 Zipf-distributed keys over 100 K bins.
+// Integer adds commute: the result does not depend on the order either way.
 __global__ __launch_bounds__(256) void count_i32_kernel(int64_t n, const int32_t *__restrict__ keys, int64_t n_bins,
                                                         int32_t *__restrict__ counts) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -627,9 +629,15 @@ __global__ __launch_bounds__(256) void count_i32_kernel(int64_t n, const int32_t
 
 #define PK_COUNT_LDS_BINS 36864
 #define PK_COUNT_THREADS 1024
-__global__ __launch_bounds__(PK_COUNT_THREADS) void count_i32_lds_kernel(int64_t n, const int32_t *__restrict__ keys, int n_bins,
-                                                                         int32_t *__restrict__ counts) {
+__global__ __launch_bounds__(PK_COUNT_THREADS) void count_i32_lds_kernel(int64_t n, const int32_t *__restrict__ keys_all, int64_t n_bins_all,
+                                                                         int32_t *__restrict__ counts_all) {
     extern __shared__ int pk_hist[];
+    // grid row y counts the bins [y * PK_COUNT_LDS_BINS, ...): keys are compared after subtracting the range's first bin
+    const int64_t bin_lo = (int64_t)blockIdx.y * PK_COUNT_LDS_BINS;
+    const int n_bins = (int)((n_bins_all - bin_lo) < PK_COUNT_LDS_BINS ? (n_bins_all - bin_lo) : PK_COUNT_LDS_BINS);
+    int32_t *counts = counts_all + bin_lo;
+    const int32_t *keys = keys_all;
+    const int key_lo = (int)bin_lo;
     for (int b = threadIdx.x; b < n_bins; b += PK_COUNT_THREADS) pk_hist[b] = 0;
     __syncthreads();
     const int64_t per = (n + gridDim.x - 1) / gridDim.x;
@@ -640,7 +648,7 @@ __global__ __launch_bounds__(PK_COUNT_THREADS) void count_i32_lds_kernel(int64_t
         const int lane = threadIdx.x & 63;
         int mine = 0;                                   // lane b accumulates bin b
         for (int64_t i = lo + threadIdx.x; i - threadIdx.x < hi; i += PK_COUNT_THREADS) {
-            const int k = (i < hi) ? keys[i] : -1;
+            const int k = (i < hi) ? keys[i] - key_lo : -1;
             for (int b = 0; b < n_bins; ++b) {
                 const int c = __popcll(__ballot(k == b));
                 if (lane == b) mine += c;
@@ -649,7 +657,7 @@ __global__ __launch_bounds__(PK_COUNT_THREADS) void count_i32_lds_kernel(int64_t
         if (lane < n_bins && mine) atomicAdd(&pk_hist[lane], mine);
     } else {
         for (int64_t i = lo + threadIdx.x; i < hi; i += PK_COUNT_THREADS) {
-            const int k = keys[i];
+            const int k = keys[i] - key_lo;
             if (k >= 0 && k < n_bins) atomicAdd(&pk_hist[k], 1);
         }
     }
@@ -666,7 +674,7 @@ extern "C" int pk_count_i32(void *stream, int64_t n, const int32_t *keys_dev, in
     (void)hipMemsetAsync(counts_dev, 0, n_bins * 4, st);
     if (n == 0) return PK_OK;
     PK_REQUIRE(keys_dev, "pk_count_i32: null keys");
-    if (n_bins <= PK_COUNT_LDS_BINS && n >= 4096) {
+    if (n >= 4096 && n_bins <= (int64_t)64 * PK_COUNT_LDS_BINS) {
         static bool attr_set = false;
         if (!attr_set) {
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&count_i32_lds_kernel),
@@ -679,8 +687,10 @@ extern "C" int pk_count_i32(void *stream, int64_t n, const int32_t *keys_dev, in
         }
         int64_t blocks = pk_ceil_div(n, 65536);
         if (blocks > 64) blocks = 64;
-        hipLaunchKernelGGL(count_i32_lds_kernel, dim3((unsigned)blocks), dim3(PK_COUNT_THREADS), (size_t)n_bins * 4, st, n, keys_dev,
-                           (int)n_bins, counts_dev);
+        const int64_t ranges = pk_ceil_div(n_bins, PK_COUNT_LDS_BINS);
+        const size_t lds = (size_t)(n_bins < PK_COUNT_LDS_BINS ? n_bins : PK_COUNT_LDS_BINS) * 4;
+        hipLaunchKernelGGL(count_i32_lds_kernel, dim3((unsigned)blocks, (unsigned)ranges), dim3(PK_COUNT_THREADS), lds, st, n, keys_dev,
+                           n_bins, counts_dev);
         PK_CHECK_LAUNCH("count_i32_lds_kernel");
         return PK_OK;
     }

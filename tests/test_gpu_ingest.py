@@ -243,7 +243,7 @@ def test_diagonal_scaling_and_mode_plan_match_numpy(hip_ops, vdtype):
             assert np.array_equal(ops.to_host(plan[k])[:len(host[k])], host[k]), (mode0, k)
 
 
-@pytest.mark.parametrize('n_bins', [1, 5, 32, 33, 1000, 26744, 36864, 36865, 100000])
+@pytest.mark.parametrize('n_bins', [1, 5, 32, 33, 1000, 26744, 36864, 36865, 100000, 2_400_000])
 def test_count_i32_matches_bincount(hip_ops, n_bins):
     """pk_count_i32 (item popularity, mode sizes): the LDS-histogram form (<= 36 864 bins; wave ballots for <= 32 bins), the
     direct form beyond and for short inputs; skewed keys (every key in one bin), keys outside [0, n_bins) ignored."""
