@@ -574,12 +574,21 @@ extern "C" int pk_mat_from_csr(pk_ctx *ctx, int64_t n_rows, int64_t n_cols, int6
     return PK_OK;
 }
 
+static int mat_from_coo_impl(pk_ctx *ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t *rows, const int64_t *cols,
+                             int64_t idx_stride, const void *values, int32_t val_kind, pk_mat **out);
+
 extern "C" int pk_mat_from_coo(pk_ctx *ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t *rows, const int64_t *cols,
                                int64_t idx_stride, const void *values, int32_t val_kind, pk_mat **out) {
     if (!ctx || !out) return PK_E_INVALID;
     std::lock_guard<std::mutex> lock(ctx->mu);
     PoolScope pool_scope(ctx);
     (void)hipSetDevice(ctx->device);
+    return mat_from_coo_impl(ctx, n_rows, n_cols, nnz, rows, cols, idx_stride, values, val_kind, out);
+}
+
+// (the caller holds the context's mutex and pool scope: pk_hooi builds its two unfoldings through this)
+static int mat_from_coo_impl(pk_ctx *ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t *rows, const int64_t *cols,
+                             int64_t idx_stride, const void *values, int32_t val_kind, pk_mat **out) {
     if (n_rows < 1 || n_cols < 1 || nnz < 0 || idx_stride < 1 || (nnz && (!rows || !cols || !values)) ||
         (val_kind != PK_VAL_F32 && val_kind != PK_VAL_F64))
         return fail(ctx, PK_E_INVALID, "pk_mat_from_coo: bad arguments");
@@ -1151,7 +1160,28 @@ int ttm(pk_ctx *ctx, ModePlan &mp, const DMat &u, const DMat &v, DMat &res) {
 }
 
 // top-r left singular vectors / values of dense M (tucker.left_svd, single process): U [n x r], s (host), Vt [r x m] if asked
-int left_svd(Solver &S, const DMat &M, int r, DMat &U, std::vector<double> &s, DMat *Vt) {
+// eigh of the Gram matrix G started from the previous HOOI iteration's eigenvectors Q of the same mode (tucker._eigh_warm):
+// G' = Q^T G Q is nearly diagonal, the Jacobi sweeps on it stop after 3-4 instead of ~10, and Q C' are G's eigenvectors
+int eigh_warm(Solver &S, const DMat &G, DMat *Q, std::vector<double> &lam, DMat &C, Dev &lam_dev) {
+    pk_ctx *ctx = S.ctx;
+    if (!Q || !Q->ok() || Q->n != G.n || Q->l != G.l || Q->n < 1) {
+        CK(S.eigh(G, lam, C, lam_dev));
+    } else {
+        DMat GQ, G1, G1t, Gs, C1;
+        CK(S.tsmm(G, *Q, GQ));
+        CK(S.gram(*Q, GQ, G1));
+        G1t = DMat(G1.n, G1.l);
+        if (!G1t.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (eigh_warm)");
+        hipLaunchKernelGGL(transpose_small_kernel, dim3((unsigned)((G1.l * G1.l + 255) / 256)), dim3(256), 0, S.st, G1.l, G1.p(), G1t.p());
+        CK(S.axpbypcz(0.5, G1, 0.5, &G1t, 0.0, nullptr, Gs));
+        CK(S.eigh(Gs, lam, C1, lam_dev));
+        CK(S.tsmm(*Q, C1, C));
+    }
+    if (Q) CK(S.col_slice(C, 0, C.l, *Q));
+    return PK_OK;
+}
+
+int left_svd(Solver &S, const DMat &M, int r, DMat &U, std::vector<double> &s, DMat *Vt, DMat *warm = nullptr) {
     pk_ctx *ctx = S.ctx;
     const int64_t n = M.n;
     const int m = M.l;
@@ -1162,7 +1192,7 @@ int left_svd(Solver &S, const DMat &M, int r, DMat &U, std::vector<double> &s, D
     if (n >= m) {
         DMat G, C, W, Ur, Gu;
         CK(S.gram(M, M, G));
-        CK(S.eigh(G, lam, C, lam_dev));
+        CK(eigh_warm(S, G, warm, lam, C, lam_dev));
         CK(S.col_slice(C, 0, r, W));
         std::vector<double> inv((size_t)r);
         for (int i = 0; i < r; ++i) { s[(size_t)i] = std::sqrt(std::max(lam[(size_t)i], 0.0)); inv[(size_t)i] = s[(size_t)i] > 0 ? 1.0 / s[(size_t)i] : 0.0; }
@@ -1184,7 +1214,7 @@ int left_svd(Solver &S, const DMat &M, int r, DMat &U, std::vector<double> &s, D
         DMat Mt(m, (int)n), G, C;
         hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)(((size_t)n * m + 255) / 256)), dim3(256), 0, S.st, n, m, M.p(), Mt.p());
         CK(S.gram(Mt, Mt, G));
-        CK(S.eigh(G, lam, C, lam_dev));
+        CK(eigh_warm(S, G, warm, lam, C, lam_dev));
         CK(S.col_slice(C, 0, r, U));
         for (int i = 0; i < r; ++i) s[(size_t)i] = std::sqrt(std::max(lam[(size_t)i], 0.0));
         if (Vt) {
@@ -1222,11 +1252,77 @@ extern "C" int pk_hooi(pk_ctx *ctx, int64_t nnz, const int64_t *idx_host, const 
             if (idx_host[3 * p + k] < 0 || idx_host[3 * p + k] >= shape[k]) return fail(ctx, PK_E_INVALID, "pk_hooi: index out of bounds");
     if (num_iters <= 0) num_iters = 25;
     Solver S{ctx, ctx->stream, Dev()};
-    // (output mode ; first matrix mode ; second matrix mode) as in lib/tensor.py:70,74,78
+    // The three mode products of lib/tensor.py:70,74,78 in FACTORED form (polara_amd/tucker.py::factored_products): the
+    // tensor as two CSR unfoldings, M0 [(n0 L) x n1] with row i0 L + l and M1 [(n1 L) x n0] with row i1 L + l (L = n2, the
+    // feedback mode); SpMM gathers W0 = M0 u1, W1 = M1 u0, then dense contractions on the fp64 matrix cores (tsmm against
+    // kron(u2, I), one gram for the feedback mode).  PK_HOOI_TTM=1 keeps the per-entry kernel (pk_ttm_f64, dttm_seq restated).
+    const char *ttm_env = getenv("PK_HOOI_TTM");
+    const bool factored = !(ttm_env && atoi(ttm_env) != 0);
+    const int64_t L = n2;
     ModePlan mp0, mp1, mp2;
-    CK(make_mode_plan(ctx, nnz, idx_host, vals_host, shape, 0, 2, 1, mp0));
-    CK(make_mode_plan(ctx, nnz, idx_host, vals_host, shape, 1, 2, 0, mp1));
-    CK(make_mode_plan(ctx, nnz, idx_host, vals_host, shape, 2, 1, 0, mp2));
+    std::unique_ptr<pk_mat> M0, M1;
+    if (factored) {
+        std::vector<int64_t> rr((size_t)nnz), cc((size_t)nnz);
+        std::vector<double> ones;
+        const double *vals = vals_host;
+        if (!vals) { ones.assign((size_t)nnz, 1.0); vals = ones.data(); }
+        pk_mat *tmp = nullptr;
+        for (int64_t p = 0; p < nnz; ++p) { rr[(size_t)p] = idx_host[3 * p] * L + idx_host[3 * p + 2]; cc[(size_t)p] = idx_host[3 * p + 1]; }
+        CK(mat_from_coo_impl(ctx, n0 * L, n1, nnz, rr.data(), cc.data(), 1, vals, PK_VAL_F64, &tmp));
+        M0.reset(tmp);
+        for (int64_t p = 0; p < nnz; ++p) { rr[(size_t)p] = idx_host[3 * p + 1] * L + idx_host[3 * p + 2]; cc[(size_t)p] = idx_host[3 * p]; }
+        CK(mat_from_coo_impl(ctx, n1 * L, n0, nnz, rr.data(), cc.data(), 1, vals, PK_VAL_F64, &tmp));
+        M1.reset(tmp);
+    } else {
+        // (output mode ; first matrix mode ; second matrix mode) as in lib/tensor.py:70,74,78
+        CK(make_mode_plan(ctx, nnz, idx_host, vals_host, shape, 0, 2, 1, mp0));
+        CK(make_mode_plan(ctx, nnz, idx_host, vals_host, shape, 1, 2, 0, mp1));
+        CK(make_mode_plan(ctx, nnz, idx_host, vals_host, shape, 2, 1, 0, mp2));
+    }
+    // kron(u2, I_r) [L r x r2 r] on the device (u2 is L x r2: a few dozen numbers through the host)
+    auto kron_u2 = [&](const DMat &u2m, int r, DMat &K) -> int {
+        std::vector<double> h((size_t)L * r2), k((size_t)L * r * r2 * r, 0.0);
+        CK(S.to_host(u2m.p(), h.data(), h.size() * 8));
+        for (int64_t l = 0; l < L; ++l)
+            for (int j = 0; j < r2; ++j)
+                for (int c = 0; c < r; ++c) k[((size_t)l * r + c) * ((size_t)r2 * r) + (size_t)j * r + c] = h[(size_t)l * r2 + j];
+        K = DMat(L * r, r2 * r);
+        if (!K.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (kron)");
+        return S.upload(k.data(), K.p(), k.size() * 8);
+    };
+    DMat W1;                    // [n1 x L r0]: the gathers of mode 1, reused by mode 2
+    auto product = [&](int mode, const DMat &a0, const DMat &a1, const DMat &a2, DMat &res) -> int {
+        if (!factored) return mode == 0 ? ttm(ctx, mp0, a2, a1, res) : mode == 1 ? ttm(ctx, mp1, a2, a0, res) : ttm(ctx, mp2, a1, a0, res);
+        if (mode == 0) {
+            DMat W0(n0 * L, r1), K;
+            if (!W0.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (W0)");
+            CK(spmm_full(ctx, M0->A, a1, W0));
+            W0.n = n0; W0.l = (int)(L * r1);                      // the same memory read as [n0 x L r1]
+            CK(kron_u2(a2, r1, K));
+            return S.tsmm(W0, K, res);
+        }
+        if (mode == 1) {
+            DMat K;
+            W1 = DMat(n1 * L, r0);
+            if (!W1.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (W1)");
+            CK(spmm_full(ctx, M1->A, a0, W1));
+            W1.n = n1; W1.l = (int)(L * r0);
+            CK(kron_u2(a2, r0, K));
+            return S.tsmm(W1, K, res);
+        }
+        // mode 2: res[l, j r0 + k] = (u1^T W1)[j, l r0 + k]
+        DMat G;
+        CK(S.gram(a1, W1, G));
+        std::vector<double> g((size_t)r1 * L * r0), t((size_t)L * r1 * r0);
+        CK(S.to_host(G.p(), g.data(), g.size() * 8));
+        for (int j = 0; j < r1; ++j)
+            for (int64_t l = 0; l < L; ++l)
+                for (int k = 0; k < r0; ++k) t[((size_t)l * r1 + j) * r0 + k] = g[(size_t)j * (L * r0) + (size_t)l * r0 + k];
+        res = DMat(L, r1 * r0);
+        if (!res.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (mode-2 product)");
+        return S.upload(t.data(), res.p(), t.size() * 8);
+    };
+    DMat warm0, warm1, warm2;   // the previous iteration's eigenvectors per mode (eigh_warm)
     DMat u0, u1(n1, r1), u2(n2, r2);
     if (!u1.ok() || !u2.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (factors)");
     if (u1_start && u2_start) {       // the caller's start (the reference draws it from NumPy's RandomState + LAPACK QR, tensor.py:57-63)
@@ -1245,14 +1341,14 @@ extern "C" int pk_hooi(pk_ctx *ctx, int64_t nnz, const int64_t *idx_host, const 
     int it = 0;
     for (; it < num_iters; ++it) {
         DMat T0, T1, T2, n0f, n1f, n2f;
-        CK(ttm(ctx, mp0, u2, u1, T0));
-        CK(left_svd(S, T0, r0, n0f, s_tmp, nullptr));
+        CK(product(0, u0, u1, u2, T0));
+        CK(left_svd(S, T0, r0, n0f, s_tmp, nullptr, &warm0));
         u0 = std::move(n0f);
-        CK(ttm(ctx, mp1, u2, u0, T1));
-        CK(left_svd(S, T1, r1, n1f, s_tmp, nullptr));
+        CK(product(1, u0, u1, u2, T1));
+        CK(left_svd(S, T1, r1, n1f, s_tmp, nullptr, &warm1));
         u1 = std::move(n1f);
-        CK(ttm(ctx, mp2, u1, u0, T2));
-        CK(left_svd(S, T2, r2, n2f, ss, &vv));
+        CK(product(2, u0, u1, u2, T2));
+        CK(left_svd(S, T2, r2, n2f, ss, &vv, &warm2));
         u2 = std::move(n2f);
         double g_new = 0.0;
         for (double v : ss) g_new += v * v;

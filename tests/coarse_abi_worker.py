@@ -158,6 +158,16 @@ def main():
         # the core IS the tensor contracted with the factors
         dense = np.zeros(tuple(shape)); np.add.at(dense, (idx[:, 0], idx[:, 1], idx[:, 2]), val)
         assert np.allclose(core, np.einsum('uif,ua,ib,fc->abc', dense, u0, u1, u2, optimize=True), atol=1e-9 * np.abs(core).max())
+        # the default route factors the mode products (SpMM over two unfoldings + fp64-MFMA contractions); the per-entry
+        # kernel (pk_ttm_f64 = dttm_seq restated) must give the same iteration
+        os.environ['PK_HOOI_TTM'] = '1'
+        v0 = np.empty_like(u0); v1 = np.empty_like(u1); v2 = np.empty_like(u2); core2 = np.empty_like(core); trace2 = np.zeros(n_it); it2 = i32(0)
+        check(ctx, lib.pk_hooi(ctx, len(val), ptr(idx), ptr(val), ptr(shape), ptr(mlrank), n_it, float(g['growth_tol']), ptr(u1s), ptr(u2s),
+                               0, ptr(v0), ptr(v1), ptr(v2), ptr(core2), ptr(trace2), C.byref(it2)), 'pk_hooi (per-entry products)')
+        del os.environ['PK_HOOI_TTM']
+        assert it2.value == iters.value and np.allclose(trace2[:it2.value], trace[:iters.value], rtol=1e-10)
+        for a, b in ((u0, v0), (u1, v1), (u2, v2)):
+            assert np.abs(a @ a.T - b @ b.T).max() < 1e-8
     # internal start (no start blocks given): a valid Tucker fit all the same
     check(ctx, lib.pk_hooi(ctx, len(val), ptr(idx), None, ptr(shape), ptr(mlrank), n_it, float(g['growth_tol']), None, None, 7,
                            ptr(u0), ptr(u1), ptr(u2), ptr(core), ptr(trace), C.byref(iters)), 'pk_hooi(seeded start)')
