@@ -1,0 +1,49 @@
+"""What does the candidate sweep cost WITHOUT its selection work?  Times pk_score_candidates_f32 alone (headline workload)
+as it is, and with PK_SCORE_ABLATE=2 (no pushes: the thresholds stay at the bootstrap's lower bounds, so groups leave later
+— the swept fraction is printed next to the time), =1 (no seen masks), =3 (neither).  The lists of the ablated runs are
+wrong; only the time per tile-wave is of interest.  usage: python tools/probes/sweep_floor.py [ml20m|s1m]"""
+import os, sys, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, torch
+import bench as B
+
+
+def main():
+    wl = sys.argv[1] if len(sys.argv) > 1 else 'ml20m'
+    sys.argv = sys.argv[:1]
+    bench = B.Bench(B.parse())
+    ops = bench.ops
+    c = bench.generate(wl)
+    st, _ = bench.build(c, 50, True)
+    from polara_amd import scoring
+    F, A = st['F'], st['A']
+    T, perm = A.by_activity()
+    n_users, n_items = T.shape
+    E = ops.spmm(T, F.V)
+    Ep, ub = ops.pack_frag_bound(E)
+    KC = 16
+    args = dict(user_bound=ub, tile_bound=F.tile_bound, seen_tiles=T.seen_tiles(), seen_dense=T.seen_dense())
+    os.environ['PK_SCORE_HEAD_TILES'] = '0'
+    for boot in ('16', '0'):
+        for abl in ('0', '2', '1', '3'):
+            os.environ['PK_SCORE_BOOT_TILES'] = boot
+            os.environ['PK_SCORE_ABLATE'] = abl
+            for _ in range(3):
+                ops.score_candidates(F.Vp, Ep, n_users, n_items, 50, T.indptr, T.indices, KC, **args)
+            torch.cuda.synchronize()
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+            for a, b in ev:
+                a.record()
+                ops.score_candidates(F.Vp, Ep, n_users, n_items, 50, T.indptr, T.indices, KC, **args)
+                b.record()
+            torch.cuda.synchronize()
+            ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+            ex = ops.score_exit_tiles(n_users, 1)
+            swept = float(ex.clamp_min(0).sum().item()) / (ex.shape[1] * (-(-n_items // 32)))
+            tw = float(ex.clamp_min(0).sum().item())
+            print(json.dumps(dict(boot=int(boot), ablate=int(abl), sweep_ms=round(ms, 4), swept=round(swept, 4), tile_waves=int(tw),
+                                  ns_per_tile_wave_x1024simd=round(ms * 1e6 * 1024 / tw, 1))), flush=True)
+
+
+if __name__ == '__main__':
+    main()
