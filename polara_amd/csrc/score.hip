@@ -844,7 +844,14 @@ __global__ __launch_bounds__(SHARED ? 64 * pk_shared_waves(KC) : 256) PK_SWEEP_O
                     m_dense = m_nxt;
                     m_nxt = (tile + S < dense_tiles) ? dense_row[(int64_t)(tile + S) * 32] : 0u;
                 }
+#ifdef PK_SCORE_PROFILE2
+                const unsigned long long prof_m0 = PROF_T();
+#endif
                 const f32x16 acc = score_tile(a, step % 3);
+#ifdef PK_SCORE_PROFILE2
+                asm volatile("" ::"v"(acc[0]), "v"(acc[15]));     // the products are done before the clock is read
+                PROF_ADD(1, prof_m0);
+#endif
                 // The list cursor must advance every tile; the mask itself is only needed when some
                 // RAW score beats the threshold (f32 MFMA shares the SIMD's FP32 lanes with the VALU, so
                 // every VALU instruction here is paid in MFMA time: keep the common path to
