@@ -400,6 +400,11 @@ int pk_unique_count_i64(void *stream, int64_t n, const int64_t *ids_dev, int64_t
  * out[r, :] = E[r, :] V^T for r in [0, n_rows). */
 int pk_dense_scores_f64(void *stream, int32_t n_rows, int64_t n_items, int32_t K, const double *V_dev,
                         int64_t ldv, const double *E_dev, int64_t lde, double *out_dev, int64_t ldo);
+/* Top-k columns of dense score rows by (score descending, column ascending): get_topk_elements / topsort on an array
+ * (models.py:488-491, 561-563; where scores tie the reference's argpartition order is implementation-defined).
+ * out_idx_dev int64 [n_rows x topk]. */
+int pk_topk_rows_f64(void *stream, int64_t n_rows, int64_t n_cols, const double *scores_dev, int64_t ld, int32_t topk,
+                     int64_t *out_idx_dev);
 
 /* ------------------------------------------------------------------------------------------
  * K5.  Sparse tensor-times-matrix (CoFFee / HOOI).

@@ -91,6 +91,7 @@ PROTOTYPES = {
     'pk_eval_reduce': (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
     'pk_unique_count_i64': (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp]),
     'pk_dense_scores_f64': (C.c_int, [_vp, _i32, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _i64]),
+    'pk_topk_rows_f64': (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i32, _vp]),
     'pk_ctx_create': (C.c_int, [_i32, C.POINTER(_vp)]),
     'pk_ctx_destroy': (None, [_vp]),
     'pk_ctx_error': (C.c_char_p, [_vp]),

@@ -931,6 +931,72 @@ extern "C" int pk_dense_scores_f64(void *stream, int32_t n_rows, int64_t n_items
 }
 
 // ------------------------------------------------------------------------------------------
+// top-k columns of dense score rows: the array form of get_topk_elements / topsort (models.py:488-491, 561-563), for the
+// host-array conveniences of the model layer (_user_scores, show_recommendations).  One workgroup per row; position t
+// of the list is the best element that comes AFTER position t - 1 in the total order (score descending, column ascending)
+// — k block-wide selections over the row, nothing is modified.  NaN scores sort last.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void topk_rows_kernel(int64_t n_cols, const double *__restrict__ scores, int64_t ld, int topk,
+                                                        int64_t *__restrict__ out) {
+    __shared__ double s_val[4];
+    __shared__ long long s_idx[4];
+    const double *row = scores + (int64_t)blockIdx.x * ld;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double prev_s = INFINITY;
+    long long prev_i = -1;
+    for (int t = 0; t < topk; ++t) {
+        double best = -INFINITY;
+        long long bi = 0x7fffffffffffffffLL;
+        for (int64_t c = threadIdx.x; c < n_cols; c += 256) {
+            double v = row[c];
+            if (v != v) v = -INFINITY;                                  // NaN last
+            const bool after = (v < prev_s) || (v == prev_s && (long long)c > prev_i);
+            if (after && (v > best || (v == best && (long long)c < bi))) {
+                best = v;
+                bi = c;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ov = __shfl_xor(best, o, 64);
+            const long long oi = __shfl_xor(bi, o, 64);
+            if (ov > best || (ov == best && oi < bi)) {
+                best = ov;
+                bi = oi;
+            }
+        }
+        if (lane == 0) {
+            s_val[wave] = best;
+            s_idx[wave] = bi;
+        }
+        __syncthreads();
+        best = s_val[0];
+        bi = s_idx[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (s_val[w] > best || (s_val[w] == best && s_idx[w] < bi)) {
+                best = s_val[w];
+                bi = s_idx[w];
+            }
+        __syncthreads();
+        if (threadIdx.x == 0) out[(int64_t)blockIdx.x * topk + t] = (bi == 0x7fffffffffffffffLL) ? -1 : bi;
+        prev_s = best;
+        prev_i = bi;
+    }
+}
+
+extern "C" int pk_topk_rows_f64(void *stream, int64_t n_rows, int64_t n_cols, const double *scores_dev, int64_t ld, int32_t topk,
+                                int64_t *out_idx_dev) {
+    PK_REQUIRE(n_rows >= 0 && n_cols >= 1 && ld >= n_cols && topk >= 1 && topk <= n_cols && scores_dev && out_idx_dev,
+               "pk_topk_rows_f64: bad arguments (1 <= topk <= n_cols)");
+    if (n_rows == 0) return PK_OK;
+    hipLaunchKernelGGL(topk_rows_kernel, dim3((unsigned)n_rows), dim3(256), 0, pk_stream(stream), n_cols, scores_dev, ld, topk,
+                       out_idx_dev);
+    PK_CHECK_LAUNCH("topk_rows_kernel");
+    return PK_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // evaluation support (models.py:408-485 consume the [n_users x topk] array): the rank (1-based, 0 = absent) at
 // which every holdout item was recommended to its user, straight from the device-resident top-k buffer —
 // only this holdout-sized vector travels to the host, not the recommendation array (20 GB at 50M users x top-50).

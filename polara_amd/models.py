@@ -423,8 +423,11 @@ class RecommenderModel:
         scores = np.asarray(scores)
         if topk > scores.shape[-1]:
             raise ValueError('kth(=%d) out of bounds (%d)' % (scores.shape[-1] - topk, scores.shape[-1]))
-        import torch
         t = self.ops.to_device(np.ascontiguousarray(scores, dtype=np.float64))
+        if hasattr(self.ops, 'topk_rows'):       # the device backend: pk_topk_rows_f64
+            flat = t.reshape(-1, t.shape[-1])
+            return self.ops.to_host(self.ops.topk_rows(flat, int(topk))).reshape(scores.shape[:-1] + (int(topk),))
+        import torch
         return self.ops.to_host(torch.topk(t, int(topk), dim=-1, largest=True, sorted=True).indices)
 
     def _user_scores(self, i):

@@ -949,6 +949,15 @@ class HipOps:
                    'pk_unique_count_i64')
         return int(cnt.item())
 
+    def topk_rows(self, scores, topk):
+        """int64 [n_rows x topk]: columns of the largest scores per row of a dense fp64 device matrix, descending
+        (pk_topk_rows_f64: score descending, column ascending)."""
+        assert scores.dtype == torch.float64 and scores.stride(-1) == 1 and scores.dim() == 2
+        out = torch.empty(scores.shape[0], int(topk), dtype=torch.int64, device=self.device)
+        _lib.check(self.lib.pk_topk_rows_f64(self.stream(), scores.shape[0], scores.shape[1], _ptr(scores), scores.stride(0),
+                                             int(topk), _ptr(out)), 'pk_topk_rows_f64')
+        return out
+
     def dense_scores(self, V, E):
         n_rows, K = E.shape
         n_items = V.shape[0]

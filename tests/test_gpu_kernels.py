@@ -994,3 +994,22 @@ def test_lds_shared_tile_sweep_equals_the_register_fed_sweep(hip_ops, cfg, monke
             assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
         else:
             assert a == b          # the same tiles scored: a group's exit does not depend on its workgroup
+
+
+def test_topk_rows_matches_the_reference_topsort(hip_ops):
+    """pk_topk_rows_f64 (the array form of get_topk_elements / topsort, models.py:488-491, 561-563) against the oracle's
+    argpartition + argsort on rows without ties, and against (score desc, column asc) on rows with ties, NaNs last."""
+    rng = np.random.RandomState(12)
+    for n_rows, n_cols, k in ((7, 1000, 10), (1, 33, 33), (300, 257, 5), (3, 70000, 50)):
+        s = rng.randn(n_rows, n_cols)
+        got = hip_ops.to_host(hip_ops.topk_rows(hip_ops.to_device(s), k))
+        assert np.array_equal(got, orc.get_topk_elements(s.copy(), k))
+    s = np.round(rng.randn(50, 400), 1)                      # plenty of exact ties
+    s[3, 5] = np.nan
+    got = hip_ops.to_host(hip_ops.topk_rows(hip_ops.to_device(s), 25))
+    key = np.where(np.isnan(s), -np.inf, s)
+    want = np.stack([np.lexsort((np.arange(400), -key[r]))[:25] for r in range(50)])
+    assert np.array_equal(got, want)
+    # strided rows
+    w = hip_ops.to_device(rng.randn(9, 130))
+    assert np.array_equal(hip_ops.to_host(hip_ops.topk_rows(w[:, :100], 4)), orc.get_topk_elements(hip_ops.to_host(w)[:, :100].copy(), 4))
