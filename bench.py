@@ -97,6 +97,8 @@ def parse():
                          'split-bf16 sweep an ML-20M-shaped pass is ~0.9 ms of kernels: ~14 Python launches cost 0.9-1.3 ms '
                          'of host time depending on the box, a replay ~10 us per graph node: 1.03-1.17 ms')
     ap.set_defaults(graph=True)
+    ap.add_argument('--pass-streams', type=int, default=2,
+                    help='HIP streams consecutive scoring passes alternate between (python launches; 1 = strictly serial passes)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-users', type=int, default=0, help='users in the CPU scoring sample (0 = auto)')
     return ap.parse_args()
@@ -271,8 +273,9 @@ class Bench:
         ops = self.ops
         F, A = st['F'], st['A']
         n_local = A.shape[0]
-        host = [torch.empty((n_local, topk), dtype=torch.int64).pin_memory() for _ in range(2)]
-        done = [torch.cuda.Event() for _ in range(2)]
+        DEPTH = 4        # result buffers: the host may run this many passes ahead of the copy engine
+        host = [torch.empty((n_local, topk), dtype=torch.int64).pin_memory() for _ in range(DEPTH)]
+        done = [torch.cuda.Event() for _ in range(DEPTH)]
         kw = dict(prune=prune, batches=batches)
         main = torch.cuda.current_stream(self.dev)
         cap = stage = None
@@ -283,7 +286,7 @@ class Bench:
                 check = scoring.recommend(ops, F, A, topk, True, prune=prune)
                 if not bool((cap.replay() == check).all()):
                     raise RuntimeError('the replayed graph and the launched pass disagree')
-                stage = [torch.empty_like(cap.out) for _ in range(2)]    # the graph rewrites its output buffer every replay
+                stage = [torch.empty_like(cap.out) for _ in range(DEPTH)]    # the graph rewrites its output buffer every replay
                 self.launch_mode = 'hipGraph replay of the captured pass'
             except Exception as exc:      # a capture problem must not cost the run its number
                 log('graph capture failed (%s: %s): launching kernel by kernel' % (type(exc).__name__, exc))
@@ -291,15 +294,31 @@ class Bench:
                 torch.cuda.synchronize()
                 self.launch_mode = 'python, kernel by kernel (hipGraph capture failed: %s)' % type(exc).__name__
 
+        # Consecutive passes alternate between TWO HIP streams (python launches only): pass i + 1's fold-in fills the SIMDs
+        # that the tail of pass i's candidate sweep leaves idle (the sweep ends with its longest chains: a handful of
+        # waves on an otherwise empty chip).  Every pass still runs completely — its own operands, scratch state per
+        # stream, its own result buffer — and the K passes of the timed region all finish inside it; what overlaps is the
+        # END of one pass with the BEGINNING of the next, like the result copy already does.  0.79 -> 0.61-0.64 ms per
+        # pass on ML-20M-shaped, 4.34 -> 4.13 ms on S-1M (profiles/r03_two_stream_passes_ml20m.txt); `--pass-streams 1`
+        # is the strictly serial form, and `latency_ms_per_pass` stays the un-pipelined figure.
+        n_ps = max(1, int(getattr(self.args, 'pass_streams', 2)))
+        if not hasattr(self, 'pass_streams') or len(self.pass_streams) != n_ps:
+            self.pass_streams = [torch.cuda.Stream(device=self.dev) for _ in range(n_ps)] if n_ps > 1 else []
+
         def one(i, use_cap=True):
-            b = i & 1
+            b = i % DEPTH
+            src = main
             if cap is not None and use_cap:
                 recs = stage[b]
                 recs.copy_(cap.replay())       # device copy (microseconds): the D2H of pass i overlaps replay i + 1
+            elif self.pass_streams:
+                src = self.pass_streams[i % len(self.pass_streams)]
+                with torch.cuda.stream(src):
+                    recs = scoring.recommend(ops, F, A, topk, True, **kw)
             else:
                 recs = scoring.recommend(ops, F, A, topk, True, **kw)
             ready = torch.cuda.Event()
-            ready.record(main)
+            ready.record(src)
             with torch.cuda.stream(self.copy_stream):
                 self.copy_stream.wait_event(ready)
                 host[b].copy_(recs, non_blocking=True)
@@ -308,35 +327,55 @@ class Bench:
             return recs
         def loop(n, use_cap):
             r = None
+            for ps in self.pass_streams:
+                ps.wait_stream(main)            # whatever the main stream set up is visible to the pass streams
             for i in range(n):
-                if i >= 2:
-                    done[i & 1].synchronize()   # the buffer about to be overwritten has been consumed (two passes ago)
+                if i >= DEPTH:
+                    done[i % DEPTH].synchronize()   # the buffer about to be overwritten has been consumed (DEPTH passes ago)
                 r = one(i, use_cap)
             return r
 
-        # warm-up, untimed as far as `value` goes.  With a captured pass at hand the two ways of launching are
-        # calibrated here (graph replay costs ~10 us per node on this runtime, Python launches cost host time that
-        # varies with the box: either can win by 20 %) and the timed region below runs the faster one, all K steps
+        # warm-up, untimed as far as `value` goes.  Up to three ways of running the loop are calibrated here and the timed
+        # region below runs the fastest, all K steps: 'graph' (replay of the captured pass: ~70 us of host time per kernel
+        # node on this runtime), 'serial' (Python launches, passes strictly one after the other on one stream) and
+        # 'pipelined' (Python launches, consecutive passes alternating between the pass streams).  Each mode is settled
+        # first (the caching allocator's pools are per stream and the result copies defer the reuse of their blocks, so the
+        # first dozen passes of a mode still grow the pools: hipMalloc inside a pass).
+        all_streams = self.pass_streams
+        modes = (['graph'] if cap is not None else []) + ['serial'] + (['pipelined'] if all_streams else [])
+
+        def set_mode(mode):
+            self.pass_streams = all_streams if mode == 'pipelined' else []
+            return mode == 'graph'
+
         cal = {}
-        use_cap = cap is not None
-        if cap is not None:
-            n_cal = max(10, warmup)
-            for mode in (True, False):
-                loop(2, mode)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                loop(n_cal, mode)
-                torch.cuda.synchronize()
-                cal[mode] = 1e3 * (time.perf_counter() - t1) / n_cal
-            use_cap = cal[True] <= cal[False]
-            if self.world > 1:            # every rank launches the same way
-                flag = torch.tensor([1.0 if use_cap else 0.0], dtype=torch.float64,
-                                    device='cpu' if self.debug_backend == 'gloo' else self.dev)
-                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
-                use_cap = bool(flag.item() > 0.5)
-            if not use_cap:
-                self.launch_mode = 'python, kernel by kernel (faster than replaying the captured pass on this box)'
-        loop(warmup, use_cap)
+        n_cal = max(10, warmup)
+        for mode in modes:
+            uc = set_mode(mode)
+            loop(3 * DEPTH, uc)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            loop(n_cal, uc)
+            torch.cuda.synchronize()
+            cal[mode] = 1e3 * (time.perf_counter() - t1) / n_cal
+        if self.world > 1:            # every rank runs the same mode: the slowest rank's calibration decides
+            tt = torch.tensor([cal[m] for m in modes], dtype=torch.float64, device='cpu' if self.debug_backend == 'gloo' else self.dev)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            cal = dict(zip(modes, [float(v) for v in tt.tolist()]))
+        best = min(modes, key=lambda m: cal[m])
+        # the overlap of consecutive passes is real (0.79 -> 0.61-0.65 ms per pass with the host far ahead of the GPU,
+        # profiles/r03_two_stream_passes_ml20m.txt) but depends on how deep the host keeps both queues: inside this loop —
+        # result copies, at most DEPTH passes ahead — it came out between 0.74 and 0.94 ms on different boxes.  It is
+        # only taken when the warm-up shows a clear gain over the serial loop
+        if best == 'pipelined' and cal['pipelined'] > 0.93 * cal['serial']:
+            best = min([m for m in modes if m != 'pipelined'], key=lambda m: cal[m])
+        use_cap = set_mode(best)
+        self.launch_mode = {'graph': 'hipGraph replay of the captured pass',
+                            'serial': 'python, kernel by kernel, passes one after the other',
+                            'pipelined': 'python, kernel by kernel; consecutive passes alternate between %d HIP streams' % len(all_streams)}[best]
+        serial_ms = cal.get('serial')
+        loop(max(warmup, 3 * DEPTH), use_cap)
+        torch.cuda.synchronize()
         gc.collect()
         gc_was = gc.isenabled()
         gc.disable()                      # no collector pauses inside the timed region
@@ -359,12 +398,14 @@ class Bench:
             tt = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if self.debug_backend == 'gloo' else self.dev)
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
             elapsed = float(tt.item())
-        last = host[(steps - 1) & 1 if steps else 0]
+        last = host[(steps - 1) % DEPTH if steps else 0]
         extras = dict(latency_ms_per_pass=1e3 * float(np.median(lat)), d2h_bytes_per_pass=int(n_local * topk * 8),
                       host_result=last, launch=self.launch_mode)
-        if cal:
-            extras['python_launch_ms_per_step'] = cal[False]
-            extras['graph_replay_ms_per_step'] = cal[True]
+        extras['serial_ms_per_step'] = serial_ms
+        extras['python_launch_ms_per_step'] = cal.get('serial')
+        extras['graph_replay_ms_per_step'] = cal.get('graph')
+        extras['pipelined_ms_per_step'] = cal.get('pipelined')
+        self.pass_streams = all_streams
         return elapsed, recs, extras
 
     def kernel_times(self, st, topk, prune=True):
@@ -459,13 +500,16 @@ class Bench:
             out = {
                 'value': n_users / (elapsed / steps), 'ms_per_step': 1e3 * elapsed / steps,
                 'latency_ms_per_pass': extra['latency_ms_per_pass'], 'd2h_bytes_per_pass': extra['d2h_bytes_per_pass'],
+                'ms_per_step_serial': extra.get('serial_ms_per_step'),
                 'workload': '%s, PureSVD rank=%d, top-%d, all users scored' % (WORKLOAD_TEXT[workload], rank, topk),
                 'n_users': n_users, 'n_items': n_items, 'nnz': nnz, 'rank': rank, 'topk': topk, 'prune': prune,
                 'score_order': 'factor norm' if norm_order else 'popularity',
                 'launch': extra.get('launch', 'python, kernel by kernel'),
-                'launch_short': 'hipGraph' if extra.get('launch', '').startswith('hipGraph') else 'python',
+                'launch_short': 'hipGraph' if extra.get('launch', '').startswith('hipGraph') else (
+                    'python, passes on %d streams' % len(self.pass_streams) if 'alternate' in extra.get('launch', '') else 'python'),
                 'launches_per_pass': int(sum(n_launch.values()) // 5) if n_launch else None,
                 'warmup_calibration_ms_per_step': {'python_launch': extra.get('python_launch_ms_per_step'),
+                                                   'python_pipelined': extra.get('pipelined_ms_per_step'),
                                                    'graph_replay': extra.get('graph_replay_ms_per_step')},
                 'build_s': tb['total_s'], 'build': dict(tb, gramian_steps=bstats['gramian_steps'],
                                                          outer_iterations=bstats['outer'], block=bstats['block'],
@@ -743,7 +787,7 @@ def compact_line(head, n_gpus, steps, warmup, adversarial=None, scale=1.0):
            'n_gpus': n_gpus, 'steps': steps, 'warmup': warmup, 'ms_per_step': _r(head['ms_per_step'], 5),
            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'bf16x3',
            'data': 'synthetic', 'config': cfg, 'build_s': _r(head['build_s']),
-           'latency_ms_per_pass': _r(head.get('latency_ms_per_pass'))}
+           'latency_ms_per_pass': _r(head.get('latency_ms_per_pass')), 'ms_per_step_serial': _r(head.get('ms_per_step_serial'))}
     b = head.get('build', {})
     out['build'] = {k: _r(b.get(k)) for k in ('solver_s', 'gramian_steps', 'converged', 'spmm_ms') if k in b}
     rf = head.get('roofline')

@@ -95,12 +95,18 @@ class DeviceCSR:
         return p['ranges'][key]
 
     def partial(self, nc):
+        """scratch for the partial sums of split long rows — one buffer per launch stream: two passes over the same
+        matrix may be in flight on different streams (bench.py pipelines consecutive passes)"""
         need = self.n_slots * nc
         if need == 0:
             return None
-        if self._partial is None or self._partial.numel() < need:
-            self._partial = torch.empty(need, dtype=torch.float64, device=self.ops.device)
-        return self._partial
+        if not isinstance(self._partial, dict):
+            self._partial = {}
+        skey = torch.cuda.current_stream(self.ops.device).cuda_stream
+        buf = self._partial.get(skey)
+        if buf is None or buf.numel() < need:
+            buf = self._partial[skey] = torch.empty(need, dtype=torch.float64, device=self.ops.device)
+        return buf
 
     def seen_tiles(self):
         """(tiles, ntiles): this matrix's rows as seen-tile streams for the candidate sweep — a format image of
