@@ -168,7 +168,13 @@ class Bench:
         from polara_amd.ops import HipOps
         self.dev = 'cuda:%d' % torch.cuda.current_device()
         self.ops = HipOps(self.dev)
+        # The streams of the timed loop are taken NOW, one after the other: torch hands out streams from a pool of 32 that
+        # HIP maps round-robin onto a handful of hardware queues (4 by default), so two streams created at unrelated
+        # moments can share a queue — and then they do not overlap at all (a pass stream on the copy stream's queue cost
+        # the pipelined loop its whole gain: 0.83 instead of 0.69 ms per pass in the same process).  Taken back to back the
+        # copy stream and the pass streams sit on different queues.
         self.copy_stream = torch.cuda.Stream(device=self.dev)
+        self.pass_streams_all = [torch.cuda.Stream(device=self.dev) for _ in range(max(0, min(int(getattr(args, 'pass_streams', 2)), 3)))]
 
     def barrier(self):
         torch.cuda.synchronize()
@@ -280,19 +286,22 @@ class Bench:
         main = torch.cuda.current_stream(self.dev)
         cap = stage = None
         self.launch_mode = 'python, kernel by kernel'
-        if self.args.graph and not batches:
+
+        def capture():
+            # The pass in a hipGraph.  Only worth trying for SHORT passes: a replay costs the host ~70 us per kernel node on
+            # this runtime (1.15-1.3 ms for the 18 nodes of a pass whatever the kernels take), and an instantiated graph
+            # was seen to cost the pipelined loop its overlap (0.72 -> 0.80-0.85 ms per pass in the same process)
+            nonlocal cap, stage
             try:
                 cap = scoring.CapturedPass(ops, F, A, topk, True, prune=prune)
                 check = scoring.recommend(ops, F, A, topk, True, prune=prune)
                 if not bool((cap.replay() == check).all()):
                     raise RuntimeError('the replayed graph and the launched pass disagree')
                 stage = [torch.empty_like(cap.out) for _ in range(DEPTH)]    # the graph rewrites its output buffer every replay
-                self.launch_mode = 'hipGraph replay of the captured pass'
             except Exception as exc:      # a capture problem must not cost the run its number
                 log('graph capture failed (%s: %s): launching kernel by kernel' % (type(exc).__name__, exc))
                 cap = stage = None
                 torch.cuda.synchronize()
-                self.launch_mode = 'python, kernel by kernel (hipGraph capture failed: %s)' % type(exc).__name__
 
         # Consecutive passes alternate between TWO HIP streams (python launches only): pass i + 1's fold-in fills the SIMDs
         # that the tail of pass i's candidate sweep leaves idle (the sweep ends with its longest chains: a handful of
@@ -301,9 +310,8 @@ class Bench:
         # END of one pass with the BEGINNING of the next, like the result copy already does.  0.79 -> 0.61-0.64 ms per
         # pass on ML-20M-shaped, 4.34 -> 4.13 ms on S-1M (profiles/r03_two_stream_passes_ml20m.txt); `--pass-streams 1`
         # is the strictly serial form, and `latency_ms_per_pass` stays the un-pipelined figure.
-        n_ps = max(1, int(getattr(self.args, 'pass_streams', 2)))
-        if not hasattr(self, 'pass_streams') or len(self.pass_streams) != n_ps:
-            self.pass_streams = [torch.cuda.Stream(device=self.dev) for _ in range(n_ps)] if n_ps > 1 else []
+        n_ps = max(1, min(int(getattr(self.args, 'pass_streams', 2)), len(self.pass_streams_all)))
+        self.pass_streams = self.pass_streams_all[:n_ps] if n_ps > 1 else []
 
         def one(i, use_cap=True):
             b = i % DEPTH
@@ -342,7 +350,6 @@ class Bench:
         # first (the caching allocator's pools are per stream and the result copies defer the reuse of their blocks, so the
         # first dozen passes of a mode still grow the pools: hipMalloc inside a pass).
         all_streams = self.pass_streams
-        modes = (['graph'] if cap is not None else []) + ['serial'] + (['pipelined'] if all_streams else [])
 
         def set_mode(mode):
             self.pass_streams = all_streams if mode == 'pipelined' else []
@@ -350,7 +357,8 @@ class Bench:
 
         cal = {}
         n_cal = max(10, warmup)
-        for mode in modes:
+
+        def calibrate(mode):
             uc = set_mode(mode)
             loop(3 * DEPTH, uc)
             torch.cuda.synchronize()
@@ -358,15 +366,35 @@ class Bench:
             loop(n_cal, uc)
             torch.cuda.synchronize()
             cal[mode] = 1e3 * (time.perf_counter() - t1) / n_cal
+
+        set_mode('serial')
+        loop(max(warmup, 24), False)        # first passes of the process on this matrix: allocator growth, code objects
+        torch.cuda.synchronize()
+        modes = ['serial'] + (['pipelined'] if all_streams else [])
+        for mode in modes:
+            calibrate(mode)
+        try_graph = self.args.graph and not batches and cal['serial'] < 0.5
+        if self.world > 1:
+            flag = torch.tensor([1.0 if try_graph else 0.0], dtype=torch.float64, device='cpu' if self.debug_backend == 'gloo' else self.dev)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+            try_graph = bool(flag.item() > 0.5)
+        if try_graph:
+            capture()
+            ok = torch.tensor([1.0 if cap is not None else 0.0], dtype=torch.float64, device='cpu' if self.debug_backend == 'gloo' else self.dev)
+            if self.world > 1:
+                torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
+            if ok.item() > 0.5:
+                modes.append('graph')
+                calibrate('graph')
         if self.world > 1:            # every rank runs the same mode: the slowest rank's calibration decides
             tt = torch.tensor([cal[m] for m in modes], dtype=torch.float64, device='cpu' if self.debug_backend == 'gloo' else self.dev)
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
             cal = dict(zip(modes, [float(v) for v in tt.tolist()]))
         best = min(modes, key=lambda m: cal[m])
-        # the overlap of consecutive passes is real (0.79 -> 0.61-0.65 ms per pass with the host far ahead of the GPU,
-        # profiles/r03_two_stream_passes_ml20m.txt) but depends on how deep the host keeps both queues: inside this loop —
-        # result copies, at most DEPTH passes ahead — it came out between 0.74 and 0.94 ms on different boxes.  It is
-        # only taken when the warm-up shows a clear gain over the serial loop
+        # the overlap of consecutive passes (0.79 -> 0.61-0.65 ms per pass with the host far ahead of the GPU, 0.72-0.75 ms
+        # inside this loop with its result copies and DEPTH-deep throttle; profiles/r03_two_stream_passes_ml20m.txt) needs
+        # the pass streams and the copy stream on different hardware queues and no instantiated graph around; it is only
+        # taken when the warm-up shows a clear gain over the serial loop
         if best == 'pipelined' and cal['pipelined'] > 0.93 * cal['serial']:
             best = min([m for m in modes if m != 'pipelined'], key=lambda m: cal[m])
         use_cap = set_mode(best)
