@@ -8,7 +8,7 @@ OUT=$R/gpurun_out/prof_r03
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 rm -rf /tmp/prof_$TAG
-B="python $R/bench.py --only-headline --no-cpu-baseline $*"
+B="python $R/bench.py --only-headline --no-cpu-baseline --pass-streams 1 $*"   # serial passes: per-kernel durations without the overlap of consecutive passes
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG/kt -- $B --steps 20 --warmup 5 > $OUT/r03_${TAG}_line_under_rocprof.json 2>/dev/null
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/prof_$TAG/fetch -- $B --steps 2 --warmup 1 > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/prof_$TAG/write -- $B --steps 2 --warmup 1 > /dev/null 2>&1
