@@ -26,12 +26,23 @@ def _configs():
         out.append(dict(seed=i + 1000 * SWEEP_SEED, n_users=int(rng.choice([1, 31, 32, 33, 64, 100, 257, 700, 2100])), n_items=n_items,
                         K=int(rng.choice(ks)), topk=topk, decay=float(rng.choice([0.0, 0.4, 1.0, 1.5])),
                         per_row=int(rng.choice([0, 3, 20, 60, 150])), filter_seen=bool(rng.rand() < 0.8)))
+    # round 3: the shape of the sweep is drawn too (a second generator, so that the configurations above stay what they
+    # were): threshold bootstrap off / short / default, two-phase off / forced with tiny heads, 1-7 seeded splits, the
+    # LDS-shared instance, item chunks of a few tiles (state parked and resumed between launches)
+    rng2 = np.random.RandomState(777 + SWEEP_SEED)
+    for c in out:
+        c['knobs'] = dict(PK_SCORE_BOOT_TILES=str(rng2.choice([0, 2, 16])), PK_SCORE_HEAD_TILES=str(rng2.choice([0, 0, 1, 3, 8])),
+                          PK_SCORE_PHASE2_SPLITS=str(rng2.choice([1, 3, 7])), PK_SCORE_SHARED=str(rng2.choice([0, 0, 1])))
+        c['chunk'] = int(rng2.choice([0, 0, 2, 5]))
     return out
 
 
 @pytest.mark.parametrize('cfg', _configs(), ids=lambda c: 'u%d_i%d_K%d_k%d_s%d' % (c['n_users'], c['n_items'], c['K'], c['topk'], c['seed']))
-def test_random_config_against_brute_force(hip_ops, cfg):
+def test_random_config_against_brute_force(hip_ops, cfg, monkeypatch):
     from polara_amd import scoring
+    for k, v in cfg['knobs'].items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setattr(hip_ops, 'score_tiles_per_chunk', cfg['chunk'])
     rng = np.random.RandomState(cfg['seed'])
     n_users, n_items, K, topk = cfg['n_users'], cfg['n_items'], cfg['K'], cfg['topk']
     V = rng.randn(n_items, K) / np.sqrt(K) * ((1.0 + np.arange(n_items)) ** -cfg['decay'])[:, None]
