@@ -849,13 +849,26 @@ class CoffeeModel(RecommenderModel):
 
     def build(self):
         """models.py:1009-1024."""
-        idx, val, shp = self.data.to_coo(tensor_mode=True)
         ops, comm = self.ops, self.comm
-        self._item_rank, self._item_inv = popularity_order(None, shp[1], counts=self._item_counts(idx[:, 1], shp[1]))
-        idx = idx.copy()
-        idx[:, 1] = self._item_rank[idx[:, 1]]
-        user_range = None
         presharded = self._presharded()
+        from .data import ArrayData
+        if (getattr(type(self.data), 'to_coo', None) is ArrayData.to_coo and hasattr(self.data, 'tensor_triplets')
+                and (comm.world == 1 or presharded)):
+            # our own data object: the three columns go up as they lie; feedback levels, item counts and the renaming
+            # into the internal item order are device passes (no stacked index, no host pass over the entries)
+            u, i, f, levels, shp = self.data.tensor_triplets()
+            i0, i1, i2 = tucker.device_coordinates(ops, u, i, f, levels)
+            counts = ops.bincount(i1, shp[1])
+            if presharded and comm.world > 1:
+                counts = comm.allreduce(counts)
+            self._item_rank, self._item_inv = popularity_order(None, shp[1], counts=ops.to_host(counts))
+            idx, val = (i0, ops.to_device(np.asarray(self._item_rank, dtype=np.int64))[i1], i2), None
+        else:
+            idx, val, shp = self.data.to_coo(tensor_mode=True)
+            self._item_rank, self._item_inv = popularity_order(None, shp[1], counts=self._item_counts(idx[:, 1], shp[1]))
+            idx = idx.copy()
+            idx[:, 1] = self._item_rank[idx[:, 1]]
+        user_range = None
         if presharded:
             # the data object already is this rank's users (ids re-based to 0): only the shape is global
             user_range = tuple(int(x) for x in self.data.user_range)

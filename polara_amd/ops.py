@@ -370,6 +370,13 @@ class HipOps:
                    'pk_count_i32')
         return counts.cpu().numpy().astype(np.int64)
 
+    def bincount(self, keys, n_bins):
+        """int64 [n_bins] (device): occurrences of each key of a device int64 tensor (pk_count_i32 on the narrowed keys)."""
+        k32 = keys.to(torch.int32).contiguous()
+        counts = torch.empty(int(n_bins), dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.pk_count_i32(self.stream(), k32.numel(), _ptr(k32), int(n_bins), _ptr(counts)), 'pk_count_i32')
+        return counts.to(torch.int64)
+
     def csr_transpose(self, A, rows_per_block=0):
         """CSR of A^T on the device (pk_csr_transpose).  rows_per_block > 0: the (block, column)-ordered image — a
         DeviceCSR with n_blocks * n_cols rows whose row b * n_cols + c holds column c restricted to the rows of block b."""
@@ -451,10 +458,22 @@ class HipOps:
         C-contiguous int64 [nnz x 2] array (the `idx` of `to_coo`, data.py:794-817): it is uploaded as it is."""
         n_rows, n_cols = int(shape[0]), int(shape[1])
         dev = self.device
-        rows, cols = np.asarray(rows), np.asarray(cols)
+        on_device = torch.is_tensor(rows)
+        if on_device:
+            # coordinates that already live on the device (the tensor unfoldings of tucker.hooi): int64 tensors
+            assert torch.is_tensor(cols) and rows.dtype == cols.dtype == torch.int64 and rows.is_cuda and cols.is_cuda
+            base = None
+        else:
+            rows, cols = np.asarray(rows), np.asarray(cols)
+            base = rows.base if (rows.base is not None and rows.base is cols.base) else None
         nnz = int(rows.shape[0])
-        base = rows.base if (rows.base is not None and rows.base is cols.base) else None
-        if (base is not None and isinstance(base, np.ndarray) and base.dtype == np.int64 and base.ndim == 2 and
+        if on_device:
+            both = torch.empty(2, max(nnz, 1), dtype=torch.int64, device=dev)
+            if nnz:
+                both[0, :nnz].copy_(rows)
+                both[1, :nnz].copy_(cols)
+            r_ptr, c_ptr, stride = _ptr(both), _ptr(both, max(nnz, 1)), 1
+        elif (base is not None and isinstance(base, np.ndarray) and base.dtype == np.int64 and base.ndim == 2 and
                 base.shape == (nnz, 2) and base.flags.c_contiguous and rows.strides == (16,) and cols.strides == (16,)
                 and rows.ctypes.data == base.ctypes.data and cols.ctypes.data == base.ctypes.data + 8):
             both = torch.from_numpy(base).to(dev)
@@ -466,10 +485,15 @@ class HipOps:
                 both[0, :nnz].copy_(torch.from_numpy(np.ascontiguousarray(rows)).to(dev))
                 both[1, :nnz].copy_(torch.from_numpy(np.ascontiguousarray(cols)).to(dev))
             r_ptr, c_ptr, stride = _ptr(both), _ptr(both, max(nnz, 1)), 1
-        v = np.ascontiguousarray(vals)
-        if v.dtype not in (np.float32, np.float64):
-            v = v.astype(np.float64)
-        v = torch.from_numpy(v).to(dev)
+        if torch.is_tensor(vals):
+            v = vals.to(dev).contiguous()
+            if v.dtype not in (torch.float32, torch.float64):
+                v = v.to(torch.float64)
+        else:
+            v = np.ascontiguousarray(vals)
+            if v.dtype not in (np.float32, np.float64):
+                v = v.astype(np.float64)
+            v = torch.from_numpy(v).to(dev)
         if v.dtype == torch.float64 and nnz:
             v32 = v.to(torch.float32)
             if bool((v32.to(torch.float64) == v).all().item()):

@@ -52,6 +52,14 @@ def ttm(ops, mp, u, v):
     return ops.ttm(mp.plan, mp.idx_u, mp.idx_v, mp.vals, u.contiguous(), v.contiguous(), mp.n0)
 
 
+def device_coordinates(ops, users, items, feedback, levels):
+    """The coordinate columns of the (user, item, feedback level) tensor as device int64 tensors: users and items as they
+    lie, the level of every entry looked up in the sorted `levels` on the device (what `to_coo(tensor_mode=True)` does
+    with a host searchsorted and a stacked copy, data.py:794-817)."""
+    i2 = torch.searchsorted(ops.to_device(np.ascontiguousarray(levels)), ops.to_device(np.ascontiguousarray(feedback)))
+    return ops.to_device(np.ascontiguousarray(users, dtype=np.int64)), ops.to_device(np.ascontiguousarray(items, dtype=np.int64)), i2
+
+
 class Unfoldings:
     """The sparse tensor as the two CSR matrices the factored products gather from (built once per build, on the device):
          M0 [(n0 * L) x n1]   row i0 * L + l  holds the items user i0 rated at level l
@@ -62,9 +70,14 @@ class Unfoldings:
     def __init__(self, ops, idx, val, shape):
         n0, n1, L = (int(x) for x in shape)
         self.shape = (n0, n1, L)
-        nnz = len(idx)
-        vals = np.ones(nnz, dtype=np.float32) if val is None else np.asarray(val)
-        i0, i1, i2 = (np.ascontiguousarray(idx[:, m], dtype=np.int64) for m in range(3))
+        if isinstance(idx, tuple):
+            # the three coordinate columns as device int64 tensors (models.CoffeeModel.build): the unfolded row keys are
+            # two fused elementwise passes on the device instead of 8-byte host passes over the entries
+            i0, i1, i2 = idx
+            vals = torch.ones(i0.numel(), dtype=torch.float32, device=i0.device) if val is None else val
+        else:
+            vals = np.ones(len(idx), dtype=np.float32) if val is None else np.asarray(val)
+            i0, i1, i2 = (np.ascontiguousarray(idx[:, m], dtype=np.int64) for m in range(3))
         self.M0 = ops.csr_from_coo(i0 * L + i2, i1, vals, (n0 * L, n1))
         self.M1 = ops.csr_from_coo(i1 * L + i2, i0, vals, (n1 * L, n0))
 
@@ -181,7 +194,8 @@ def hooi(ops, idx, val, shape, core_shape, num_iters=25, growth_tol=0.01, seed=N
     all-reduced, and every rank holds identical u1, u2, core.
     `item_inv`: see the start-block comment below."""
     comm = comm or NoComm()
-    idx = np.asarray(idx)
+    if not isinstance(idx, tuple):        # tuple: (i0, i1, i2) device int64 tensors, see Unfoldings
+        idx = np.asarray(idx)
     r0, r1, r2 = (int(r) for r in core_shape)
     n0, n1, n2 = (int(s) for s in shape)
     n0_total = n0

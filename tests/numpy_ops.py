@@ -57,6 +57,7 @@ class NumpyOps:
 
     def csr_from_coo(self, rows, cols, vals, shape, split=None):
         from polara_amd.csr import coo_to_csr
+        rows, cols = (np.asarray(x) for x in (rows, cols))          # host arrays or CPU tensors
         ip, ix, vl = coo_to_csr(rows, cols, np.asarray(vals, dtype=np.float64), shape)
         return NpCSR(ip, ix, vl, shape)
 
@@ -65,6 +66,9 @@ class NumpyOps:
         from polara_amd.csr import coo_to_csr
         ip, ix, vl = coo_to_csr(m.row, np.asarray(col_map)[m.col], m.data, A.shape, sum_duplicates=False)
         return NpCSR(ip, ix, vl, A.shape)
+
+    def bincount(self, keys, n_bins):
+        return torch.bincount(keys, minlength=int(n_bins))[:int(n_bins)]
 
     def item_counts(self, A):
         return np.bincount(A.m.indices, minlength=A.shape[1]).astype(np.int64)

@@ -74,3 +74,33 @@ def test_factored_mode_products_cpu_double():
     for ranks in ((6, 5, 3), (4, 3, 5)):
         for weighted in (False, True):
             chk(NumpyOps(), ranks, weighted)
+
+
+def test_device_coordinate_build_equals_the_protocol_build():
+    """CoffeeModel.build on our own ArrayData sends the three coordinate columns up as they lie (levels, item counts and
+    the item renaming on the device, tucker.device_coordinates); a data object that overrides `to_coo` goes through the
+    reference's protocol (stacked [nnz x 3] index, data.py:794-817).  Same factors either way, bit for bit."""
+    from numpy_ops import NumpyOps
+    from polara_amd.data import ArrayData
+    from polara_amd.models import CoffeeModel
+
+    class ProtocolData(ArrayData):
+        def to_coo(self, *a, **k):
+            return ArrayData.to_coo(self, *a, **k)
+
+    rs = np.random.RandomState(5)
+    n_users, n_items, n = 300, 90, 6000
+    u, i = rs.randint(0, n_users, n), rs.randint(0, n_items, n)
+    f = rs.choice([0.5, 1.0, 2.5, 4.0, 5.0], n)
+    hold = (np.arange(n_users), np.zeros(n_users, np.int64), np.ones(n_users))
+    built = []
+    for cls in (ArrayData, ProtocolData):
+        m = CoffeeModel(cls((u, i, f), n_users=n_users, n_items=n_items, holdout=hold, warm_start=False), ops=NumpyOps())
+        m.verbose = False
+        m.mlrank, m.seed = (7, 6, 3), 1
+        m.build()
+        built.append(m)
+    a, b = built
+    assert a.core_norm_trace == b.core_norm_trace
+    for k in a.factors:
+        assert np.array_equal(a.factors[k], b.factors[k]), k

@@ -22,3 +22,19 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 uf = tucker.Unfoldings(ops, idx, None, shape)
 torch.cuda.synchronize(); t_unf = time.perf_counter() - t0
 print(json.dumps(dict(mlrank=mlrank, build_s=round(t_all, 4), iterations=len(out[4]), unfoldings_s=round(t_unf, 4))))
+
+# the model-level build around it (data object -> device coordinates -> hooi -> factors on the host)
+from polara_amd.data import ArrayData
+from polara_amd.models import CoffeeModel
+n_users, n_items = csr['shape']
+hold = (np.arange(n_users), np.zeros(n_users, np.int64), np.ones(n_users))
+d = ArrayData((u, i, v), n_users=n_users, n_items=n_items, holdout=hold, warm_start=False)
+m = CoffeeModel(d, ops=ops)
+m.verbose = False
+m.mlrank, m.seed = mlrank, 0
+ts = []
+for rep in range(4):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    m.build()
+    torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+print(json.dumps(dict(model_build_s=[round(t, 4) for t in ts], training_time_s=round(m.training_time[-1], 4))))
