@@ -414,6 +414,13 @@ class Bench:
         elapsed = time.perf_counter() - t0
         if gc_was:
             gc.enable()
+        # the same loop over a region 10x as long (not `value`): what a pass costs once the fill of the first passes and the
+        # drain of the last (its 0.8 ms latency + the 0.4 ms copy of its result) are spread over 200 instead of 20 steps
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        loop(10 * steps, use_cap)
+        torch.cuda.synchronize()
+        long_ms = 1e3 * (time.perf_counter() - t1) / max(10 * steps, 1)
         # un-pipelined latency of one pass: compute + copy + sync
         lat = []
         for i in range(3):
@@ -430,6 +437,7 @@ class Bench:
         extras = dict(latency_ms_per_pass=1e3 * float(np.median(lat)), d2h_bytes_per_pass=int(n_local * topk * 8),
                       host_result=last, launch=self.launch_mode)
         extras['serial_ms_per_step'] = serial_ms
+        extras['long_region_ms_per_step'] = long_ms
         extras['python_launch_ms_per_step'] = cal.get('serial')
         extras['graph_replay_ms_per_step'] = cal.get('graph')
         extras['pipelined_ms_per_step'] = cal.get('pipelined')
@@ -529,6 +537,7 @@ class Bench:
                 'value': n_users / (elapsed / steps), 'ms_per_step': 1e3 * elapsed / steps,
                 'latency_ms_per_pass': extra['latency_ms_per_pass'], 'd2h_bytes_per_pass': extra['d2h_bytes_per_pass'],
                 'ms_per_step_serial': extra.get('serial_ms_per_step'),
+                'ms_per_step_long_region': extra.get('long_region_ms_per_step'),
                 'workload': '%s, PureSVD rank=%d, top-%d, all users scored' % (WORKLOAD_TEXT[workload], rank, topk),
                 'n_users': n_users, 'n_items': n_items, 'nnz': nnz, 'rank': rank, 'topk': topk, 'prune': prune,
                 'score_order': 'factor norm' if norm_order else 'popularity',
@@ -815,7 +824,8 @@ def compact_line(head, n_gpus, steps, warmup, adversarial=None, scale=1.0):
            'n_gpus': n_gpus, 'steps': steps, 'warmup': warmup, 'ms_per_step': _r(head['ms_per_step'], 5),
            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'bf16x3',
            'data': 'synthetic', 'config': cfg, 'build_s': _r(head['build_s']),
-           'latency_ms_per_pass': _r(head.get('latency_ms_per_pass')), 'ms_per_step_serial': _r(head.get('ms_per_step_serial'))}
+           'latency_ms_per_pass': _r(head.get('latency_ms_per_pass')), 'ms_per_step_serial': _r(head.get('ms_per_step_serial')),
+           'ms_per_step_long_region': _r(head.get('ms_per_step_long_region'))}
     b = head.get('build', {})
     out['build'] = {k: _r(b.get(k)) for k in ('solver_s', 'gramian_steps', 'converged', 'spmm_ms') if k in b}
     rf = head.get('roofline')

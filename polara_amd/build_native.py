@@ -25,6 +25,8 @@ if os.environ.get('PK_FAST_BUILD'):   # kernel-tuning builds: only the rank-50 /
     FLAGS.append('-DPK_FAST_BUILD')
 if os.environ.get('PK_SWEEP_WAVES'):    # kernel-tuning builds: force the sweep's register budget to this many waves per SIMD
     FLAGS.append('-DPK_SWEEP_WAVES=' + os.environ['PK_SWEEP_WAVES'])
+if os.environ.get('PK_SHARED_WAVES'):   # kernel-tuning builds: waves per workgroup of the LDS-staged sweep instance
+    FLAGS.append('-DPK_SHARED_WAVES=' + os.environ['PK_SHARED_WAVES'])
 if os.environ.get('PK_SCORE_PROFILE2'):   # kernel-tuning builds: slot 1 of the cycle counters times the products of a tile
     FLAGS += ['-DPK_SCORE_PROFILE2', '-DPK_SCORE_PROFILE']
 if os.environ.get('PK_SCORE_PROFILE'):   # kernel-tuning builds: cycle counters inside the candidate sweep

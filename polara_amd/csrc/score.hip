@@ -177,13 +177,18 @@ __host__ __device__ constexpr int pk_ring_rows(int kc) { return kc == 16 ? 8 : R
 __host__ __device__ constexpr size_t pk_score_lds_bytes(int nstep, int kc) {
     return (size_t)(4 * pk_ring_rows(kc) * 64 + (pk_top_in_lds(nstep, kc) ? 4 * 32 * kc : 1)) * sizeof(uint2);
 }
-// SHARED instance: the rings and lists of its NW waves + three packed V tiles (2 * nstep KB each).  NW = 16 at KC = 16
-// (8 KB of selection state per wave: 152 KB, ONE workgroup of 1 024 threads per CU = 4 waves per SIMD; two workgroups of
-// eight waves would need 2 x 80 KB + their counters: 32 bytes more than a CU has), 8 beyond
-__host__ __device__ constexpr int pk_shared_waves(int kc) { return kc == 16 ? 16 : 8; }
+// SHARED instance: the rings and lists of its NW waves + TWO packed V tiles (2 * nstep KB each).  NW = 4 at KC = 16: 8 KB of
+// selection state per wave + 16 KB of tiles at rank 50 = 48 KB, THREE workgroups per CU; the four waves of a workgroup sit
+// on the four SIMDs, so the three waves of a SIMD belong to three workgroups that drift against each other like the
+// free-running waves of the register-fed kernel (a first version with 16 waves = one workgroup per CU kept all waves of a
+// SIMD in lock-step and lost the MFMA / VALU overlap that way).  PK_SHARED_WAVES: kernel-tuning builds.
+#ifndef PK_SHARED_WAVES
+#define PK_SHARED_WAVES 4
+#endif
+__host__ __device__ constexpr int pk_shared_waves(int kc) { return kc == 16 ? PK_SHARED_WAVES : 8; }
 __host__ __device__ constexpr size_t pk_score_lds_bytes_shared(int nstep, int kc) {
     return (size_t)(pk_shared_waves(kc) * pk_ring_rows(kc) * 64 + pk_shared_waves(kc) * 32 * kc) * sizeof(uint2) +
-           (size_t)3 * (2 * nstep) * 64 * 16;
+           (size_t)2 * (2 * nstep) * 64 * 16;
 }
 // instantiated for top-10 lists up to rank 128 (the regime it was meant for; it is opt-in — PK_SCORE_SHARED=1 — because it
 // did not pay, see DESIGN.md K3 round 3: at best equal to the register-fed kernel on dense sweeps, slower on pruned ones)
@@ -658,22 +663,12 @@ __global__ __launch_bounds__(SHARED ? 64 * pk_shared_waves(KC) : 256) PK_SWEEP_O
                                                  (__attribute__((address_space(3))) void *)(vbuf + (buf * KQ + q) * 64), 16, 0, 0);
         }
     };
-    // Every wave issues its share of tile t + 2 LAST in iteration t and then waits for everything OLDER than those
-    // loads — vmcnt counts in order — i.e. for its share of tile t + 1 (issued an iteration ago) and for this iteration's
-    // own prefetches, without waiting for what it has just requested (an s_waitcnt 0 here made every tile pay a full
-    // memory round trip: 1.6x slower than the register-fed kernel).  Three buffers: tile t is read, t + 1 complete, t + 2 in flight.
-    const int my_stage_loads = SHARED ? (KQ - wave + NW - 1) / NW : 0;     // 0 when wave >= KQ
-    auto stage_wait = [&](bool just_staged) {
+    // Two buffers: behind the barrier that ends iteration t - 1 every wave has finished reading tile t - 1 and tile t is
+    // complete; a wave then requests its share of tile t + 1 FIRST in iteration t (into the buffer of t - 1), works on
+    // tile t, and waits for its own loads only at the end of the iteration — a whole tile later — in front of the barrier.
+    auto stage_wait = [&]() {
         if constexpr (SHARED) {
-            const int keep = just_staged ? my_stage_loads : 0;
-            // s_waitcnt vmcnt(keep) only: expcnt and lgkmcnt fields left at their maxima (gfx9 encoding)
-            switch (keep) {
-                case 0: __builtin_amdgcn_s_waitcnt(0x0F70); break;
-                case 1: __builtin_amdgcn_s_waitcnt(0x0F71); break;
-                case 2: __builtin_amdgcn_s_waitcnt(0x0F72); break;
-                case 3: __builtin_amdgcn_s_waitcnt(0x0F73); break;
-                default: __builtin_amdgcn_s_waitcnt(0x0F74); break;
-            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0) only: expcnt and lgkmcnt fields left at their maxima (gfx9 encoding)
             __syncthreads();
         }
     };
@@ -714,8 +709,7 @@ __global__ __launch_bounds__(SHARED ? 64 * pk_shared_waves(KC) : 256) PK_SWEEP_O
         float4 a_nxt[SHARED ? 1 : KQ];
         if constexpr (SHARED) {
             stage_tile((tile_begin < n_tiles) ? tile_begin : 0, 0);
-            if (boot_tiles > 1 && tile_begin + S < tile_end) stage_tile(tile_begin + S, 1);
-            stage_wait(false);
+            stage_wait();
         } else {
             load_frags((tile_begin < n_tiles) ? tile_begin : 0, a_nxt);
         }
@@ -724,6 +718,9 @@ __global__ __launch_bounds__(SHARED ? 64 * pk_shared_waves(KC) : 256) PK_SWEEP_O
         // (trip count uniform over the workgroup: SHARED has a barrier per tile)
         for (int i = 0, tile = tile_begin; i < boot_tiles && tile < tile_end; ++i, tile += S) {
             float4 a[SHARED ? 1 : KQ];
+            if constexpr (SHARED) {
+                if (i + 1 < boot_tiles && tile + S < tile_end) stage_tile(tile + S, (i + 1) & 1);
+            }
             if constexpr (!SHARED) {
 #pragma unroll
                 for (int q = 0; q < KQ; ++q) a[q] = a_nxt[q];
@@ -734,7 +731,7 @@ __global__ __launch_bounds__(SHARED ? 64 * pk_shared_waves(KC) : 256) PK_SWEEP_O
                     m_dense = m_nxt;
                     m_nxt = (tile + S < dense_tiles) ? dense_row[(int64_t)(tile + S) * 32] : 0u;
                 }
-                const f32x16 acc = score_tile(a, i % 3);
+                const f32x16 acc = score_tile(a, i & 1);
                 const unsigned m2 = walk_mask(tile) >> (4 * hi);
 #pragma unroll
                 for (int g = 0; g < BG; ++g) {
@@ -750,11 +747,7 @@ __global__ __launch_bounds__(SHARED ? 64 * pk_shared_waves(KC) : 256) PK_SWEEP_O
                     }
                 }
             }
-            if constexpr (SHARED) {
-                const bool more = i + 2 < boot_tiles && tile + 2 * S < tile_end;
-                if (more) stage_tile(tile + 2 * S, (i + 2) % 3);
-                stage_wait(more);
-            }
+            if constexpr (SHARED) stage_wait();
         }
         // the (KC / 2)-th value of each lane: together at least KC items of the user score that much
         float t0 = bl[KC / 2 - 1];
@@ -795,8 +788,7 @@ __global__ __launch_bounds__(SHARED ? 64 * pk_shared_waves(KC) : 256) PK_SWEEP_O
             __syncthreads();
             if (!alive && lane == 0) atomicAdd(&s_cnt[3], 1);
             stage_tile((tile_begin < n_tiles) ? tile_begin : 0, 0);
-            if (tile_begin + S < tile_end) stage_tile(tile_begin + S, 1);
-            stage_wait(false);
+            stage_wait();
             dead = s_cnt[3];
         } else {
             load_frags((tile_begin < n_tiles) ? tile_begin : 0, a_nxt);
@@ -809,6 +801,7 @@ __global__ __launch_bounds__(SHARED ? 64 * pk_shared_waves(KC) : 256) PK_SWEEP_O
         for (int tile = tile_begin; tile < tile_end && dead < NW; tile += S, ++step) {
             if constexpr (SHARED) {
                 if (threadIdx.x == 0) s_cnt[(step + 1) % 3] = 0;
+                if (tile + S < tile_end) stage_tile(tile + S, (step + 1) & 1);
             }
             if ((!SHARED || alive) && prune) {
                 // can any item from this tile on still enter a list of this wave?
@@ -847,7 +840,7 @@ __global__ __launch_bounds__(SHARED ? 64 * pk_shared_waves(KC) : 256) PK_SWEEP_O
 #ifdef PK_SCORE_PROFILE2
                 const unsigned long long prof_m0 = PROF_T();
 #endif
-                const f32x16 acc = score_tile(a, step % 3);
+                const f32x16 acc = score_tile(a, step & 1);
 #ifdef PK_SCORE_PROFILE2
                 asm volatile("" ::"v"(acc[0]), "v"(acc[15]));     // the products are done before the clock is read
                 PROF_ADD(1, prof_m0);
@@ -883,9 +876,7 @@ __global__ __launch_bounds__(SHARED ? 64 * pk_shared_waves(KC) : 256) PK_SWEEP_O
                 }
             }
             if constexpr (SHARED) {
-                const bool more = tile + 2 * S < tile_end;
-                if (more) stage_tile(tile + 2 * S, (step + 2) % 3);
-                stage_wait(more);
+                stage_wait();
                 dead += s_cnt[step % 3];
             }
         }
