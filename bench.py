@@ -402,11 +402,13 @@ class Bench:
                             'serial': 'python, kernel by kernel, passes one after the other',
                             'pipelined': 'python, kernel by kernel; consecutive passes alternate between %d HIP streams' % len(all_streams)}[best]
         serial_ms = cal.get('serial')
-        loop(max(warmup, 3 * DEPTH), use_cap)
-        torch.cuda.synchronize()
         gc.collect()
         gc_was = gc.isenabled()
         gc.disable()                      # no collector pauses inside the timed region
+        # the settle passes run LAST before the timed region: a collector run (tens of ms of host time with an idle
+        # GPU) between them and the region would hand the first timed passes a chip that has clocked down
+        loop(max(warmup, 3 * DEPTH), use_cap)
+        torch.cuda.synchronize()
         self.barrier()
         t0 = time.perf_counter()
         recs = loop(steps, use_cap)
