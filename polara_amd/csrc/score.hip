@@ -213,14 +213,14 @@ struct SeenDense {
 #else
 #define PK_SWEEP_OCC
 #endif
-// SHARED (round 3): the workgroup is 8 or 16 waves (pk_shared_waves) that step through the item tiles together; the packed V tile of a step is
-// staged ONCE per workgroup in LDS (global_load_lds_dwordx4: no register round trip, double-buffered, one workgroup
-// barrier per tile) and every wave feeds its MFMAs from there with two ds_read_b128 per k-step.  What it buys: the two
-// V-tile register buffers (64 VGPRs at rank 50, 208 at rank 200) leave the register file — more resident waves per SIMD
-// where LDS allows (rings + lists are 8 KB per wave at KC = 16: 80 KB per workgroup, two workgroups per CU = 4 waves per
-// SIMD instead of 3) — and the V traffic out of L2 falls 8x.  What it costs: a barrier per tile in a kernel that has
-// none, waves that idle once their group is pruned until the whole workgroup is, lock-step with the slowest wave of
-// a tile (a flush sort stalls seven others).  Single sweeps only (no item splits), lists in LDS.
+// SHARED (round 3, opt-in): the workgroup is pk_shared_waves() waves (four at KC = 16: one per SIMD) that step through the
+// item tiles together; the packed V tile of a step is staged ONCE per workgroup in LDS (global_load_lds_dwordx4: no register
+// round trip, two buffers, one workgroup barrier per tile) and every wave feeds its MFMAs from there with two ds_read_b128
+// per k-step.  What it buys: the two V-tile register buffers (64 VGPRs at rank 50) leave the register file and the V
+// traffic out of L2 falls by the number of waves.  What it costs: a barrier per tile in a kernel that has none, waves
+// that idle once their group is pruned until the whole workgroup is, lock-step with the slowest wave of a tile.  Never
+// ahead of the register-fed kernel in any regime measured.  Single sweeps only (no item splits),
+// lists in LDS.
 template <int NSTEP, int KC, bool STRIDED, bool DENSE, bool SHARED = false>
 __global__ __launch_bounds__(SHARED ? 64 * pk_shared_waves(KC) : 256) PK_SWEEP_OCC void score_candidates_kernel(
     const float4 *__restrict__ Vp, const float4 *__restrict__ Ep, int64_t n_users, int n_items,
