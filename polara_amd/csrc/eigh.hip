@@ -572,6 +572,8 @@ extern "C" int pk_eigh_psd_f64(void *stream, int32_t n, double *S_dev, int64_t l
     }
     // block Jacobi: nb (even) blocks of w rows, two blocks at a time in LDS
     int nb = 4;
+    const char *nb_env = getenv("PK_EIGH_NB");             // kernel-tuning knob: at least this many row blocks
+    if (nb_env && atoi(nb_env) > nb) nb = atoi(nb_env) & ~1;
     while ((int64_t)2 * ((n + nb - 1) / nb) * n * 8 > EIGH_BLOCK_LDS) nb += 2;
     const int w = (n + nb - 1) / nb;
     const size_t lds_bytes = (size_t)2 * w * n * sizeof(double);

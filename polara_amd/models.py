@@ -312,6 +312,10 @@ class RecommenderModel:
         if cached is not None and len(cached[0]) == len(key) and all(a is b for a, b in zip(cached[0], key)):
             return cached[1:]
         ops = self.ops
+        fast = self._training_rows_test_csr()
+        if fast is not None:
+            self._test_dev = (key,) + fast
+            return fast
         test_data, test_shape, _ = self._get_test_data()
         n_users, n_items = int(test_shape[0]), int(test_shape[1])
         w = self._test_weights(test_data)
@@ -321,6 +325,35 @@ class RecommenderModel:
             T = ops.csr_relabel_cols(T, self._item_rank)
         self._test_dev = (key, T, n_users, n_items)
         return T, n_users, n_items
+
+    def _training_rows_test_csr(self):
+        """Shortcut of `_device_test_csr` for the standard evaluation set-up on our own data object: no explicit test
+        set, the holdout names EVERY user, so the test rows are the training rows (data.py:820-832 recovers them by a
+        stable sort of the training triplets by user plus three gathers: ~90 ms of NumPy for 2e7 entries in front of a
+        1 ms scoring pass).  The COO -> CSR kernels sort by (user, item) themselves, so the three training columns go up as
+        they lie.  Taken only when it provably gives the protocol's matrix: matrix models (no per-entry weights), no
+        threshold, no warm start, and every user has at least one interaction (else the protocol renumbers the rows
+        without gaps — checked on the device, one flag comes back).  None: not applicable."""
+        from .data import ArrayData
+        d = self.data
+        if not (isinstance(d, ArrayData) and type(d).test_to_coo is ArrayData.test_to_coo
+                and type(d)._recover_testset is ArrayData._recover_testset
+                and type(self)._get_test_data is RecommenderModel._get_test_data):
+            return None
+        test = getattr(d, '_test', None)
+        if (test is None or test.testset is not None or test.holdout is None or d.warm_start or self.feedback_threshold
+                or self._tensor_mode() or getattr(d, 'test_sample', None)):
+            return None
+        n_users, n_items = d.get_test_shape(tensor_mode=False)
+        if n_users != d.n_users:
+            return None                               # the holdout names only some users
+        u, i, f, shp = d.matrix_triplets()
+        T = self.ops.csr_from_coo(u, i, np.asarray(f, dtype=np.float64), (int(n_users), int(n_items)))
+        if not bool((T.indptr[1:] > T.indptr[:-1]).all().item()):
+            return None                               # users without interactions: rows are renumbered by the protocol
+        if self._item_rank is not None:
+            T = self.ops.csr_relabel_cols(T, self._item_rank)
+        return T, int(n_users), int(n_items)
 
     def _test_csr_depends_on(self):
         """What the cached device test CSR was built from besides the data (whose changes arrive as events): objects

@@ -441,3 +441,43 @@ def test_bench_compact_line_is_small_and_parses():
     head2 = {k: v for k, v in head.items() if k != 'cpu_baseline'}
     d2 = json.loads(bench.compact_line(head2, 8, 20, 5, None, scale=1.0))
     assert d2['n_gpus'] == 8 and 'cpu_baseline' not in d2 and 'users sharded over 8' in d2['config']['parallelism']
+
+
+def test_training_rows_shortcut_builds_the_protocol_test_matrix():
+    """models._training_rows_test_csr (holdout names every user, no explicit test set): the test CSR from the training
+    columns as they lie equals the one from the protocol's sorted triplets (`_get_test_data`, models.py:227-257) — same
+    lists — and the shortcut steps aside when a user has no interactions (the protocol renumbers rows then)."""
+    from numpy_ops import NumpyOps
+    from polara_amd.data import ArrayData
+    from polara_amd.models import SVDModel, RecommenderModel
+
+    class ProtocolData(ArrayData):                    # overriding test_to_coo switches the shortcut off
+        def test_to_coo(self, *a, **k):
+            return ArrayData.test_to_coo(self, *a, **k)
+
+    rs = np.random.RandomState(11)
+    n_users, n_items, n = 400, 120, 9000
+    u = np.r_[np.arange(n_users), rs.randint(0, n_users, n)]          # every user at least once, unsorted
+    i = rs.randint(0, n_items, len(u))
+    f = rs.choice([0.0, 1.0, 2.0, 3.5, 5.0], len(u))                  # explicit zeros: not scored, still seen
+    perm = rs.permutation(len(u))
+    u, i, f = u[perm], i[perm], f[perm]
+    hold = (np.arange(n_users), np.zeros(n_users, np.int64), np.ones(n_users))
+    recs, used = [], []
+    for cls in (ArrayData, ProtocolData):
+        m = SVDModel(cls((u, i, f), n_users=n_users, n_items=n_items, holdout=hold, warm_start=False), ops=NumpyOps())
+        m.verbose = False
+        m.rank, m.topk = 8, 7
+        m.build()
+        used.append(m._training_rows_test_csr() is not None)
+        recs.append(m.get_recommendations())
+    assert used == [True, False]
+    assert np.array_equal(recs[0], recs[1])
+    # a user without interactions: the shortcut declines, the protocol path runs
+    keep = u != 5
+    m = SVDModel(ArrayData((u[keep], i[keep], f[keep]), n_users=n_users, n_items=n_items, holdout=hold, warm_start=False), ops=NumpyOps())
+    m.verbose = False
+    m.rank, m.topk = 8, 7
+    m.build()
+    assert m._training_rows_test_csr() is None
+    assert m.get_recommendations().shape[1] == 7
