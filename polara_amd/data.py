@@ -45,7 +45,7 @@ class ArrayData:
     def __init__(self, training, n_users=None, n_items=None, test=None, holdout=None, warm_start=False,
                  fields=('userid', 'itemid', 'rating'), holdout_size=None):
         u, i, f = (np.asarray(a) for a in training)
-        self._train = Triplets(u.astype(np.int64), i.astype(np.int64), np.asarray(f, dtype=np.float64))
+        self._train = Triplets(u.astype(np.int64, copy=False), i.astype(np.int64, copy=False), np.asarray(f, dtype=np.float64))   # no copies of arrays that already have the working types
         self.n_users = int(n_users if n_users is not None else u.max() + 1)
         self.n_items = int(n_items if n_items is not None else i.max() + 1)
         self.fields = Fields(*fields)
@@ -80,7 +80,7 @@ class ArrayData:
 
     def set_training_data(self, training):
         u, i, f = (np.asarray(a) for a in training)
-        self._train = Triplets(u.astype(np.int64), i.astype(np.int64), np.asarray(f, dtype=np.float64))
+        self._train = Triplets(u.astype(np.int64, copy=False), i.astype(np.int64, copy=False), np.asarray(f, dtype=np.float64))   # no copies of arrays that already have the working types
         self._feedback_levels = None
         self._notify(self.on_change_event)
 
