@@ -174,6 +174,16 @@ int pk_tsmm_f64(void *stream, int64_t n, int32_t lin, int32_t lout, const double
  * info_dev[0] = sweeps used, info_dev[1] = 1 if converged.  n <= 1024. */
 int pk_eigh_psd_f64(void *stream, int32_t n, double *S_dev, int64_t lds_, double *evecs_dev, int64_t ldv,
                     double *evals_dev, int32_t max_sweeps, double tol, int32_t *info_dev);
+/* The r LEADING eigenpairs of a symmetric PSD matrix in one launch (Householder tridiagonalisation, Sturm-count
+ * multisection, inverse iteration, back-transformation; csrc/eigh_top.hip) — what the HOOI unfoldings need of their Gram
+ * matrices (the k = r of `svds(unfolding, k=r)`, lib/tensor.py:70-80).  S (n x n) is read only; evals[0..r) descending,
+ * ROW j of evecs = j-th eigenvector.  The kernel checks its result against S: info_dev[0] = 1 when it passed, 0 when
+ * nothing usable was written (degenerate or pathological input) — the caller then uses pk_eigh_psd_f64.
+ * pk_eigh_top_supported: 8 <= n <= 176, 1 <= r <= min(32, n).  work: pk_eigh_top_work_bytes(n) bytes. */
+int pk_eigh_top_supported(int32_t n, int32_t r);
+int64_t pk_eigh_top_work_bytes(int32_t n);
+int pk_eigh_top_f64(void *stream, int32_t n, const double *S_dev, int64_t lds_, int32_t r, double *evecs_dev, int64_t ldv,
+                    double *evals_dev, void *work_dev, int32_t *info_dev);
 /* Cholesky of a small SPD Gram matrix and the inverse of its factor: G + shift_rel*trace(G)*I = R^T R, Rinv = R^-1 (upper
  * triangular), so that X <- X Rinv is orthonormal (CholeskyQR; replaces LAPACK's QR inside svds / numpy.qr,
  * models.py:844, tensor.py:61).  info_dev[0] = 0 or (column + 1) of the first non-positive pivot.

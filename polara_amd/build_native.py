@@ -27,6 +27,8 @@ if os.environ.get('PK_SWEEP_WAVES'):    # kernel-tuning builds: force the sweep'
     FLAGS.append('-DPK_SWEEP_WAVES=' + os.environ['PK_SWEEP_WAVES'])
 if os.environ.get('PK_SHARED_WAVES'):   # kernel-tuning builds: waves per workgroup of the LDS-staged sweep instance
     FLAGS.append('-DPK_SHARED_WAVES=' + os.environ['PK_SHARED_WAVES'])
+if os.environ.get('PK_ETOP_PROFILE'):   # kernel-tuning builds: phase clocks of eigh_top_kernel in info[2..7]
+    FLAGS.append('-DETOP_PROFILE')
 if os.environ.get('PK_SCORE_PROFILE2'):   # kernel-tuning builds: slot 1 of the cycle counters times the products of a tile
     FLAGS += ['-DPK_SCORE_PROFILE2', '-DPK_SCORE_PROFILE']
 if os.environ.get('PK_SCORE_PROFILE'):   # kernel-tuning builds: cycle counters inside the candidate sweep

@@ -608,6 +608,25 @@ class HipOps:
                                             _ptr(self._info)), 'pk_eigh_psd_f64')
         return lam, R.t()  # rows of R are eigenvectors -> return as columns (a view; strides swapped)
 
+    def eigh_top(self, S, r):
+        """The r leading eigenpairs of symmetric PSD S: (evals desc [r], evecs [n x r]) — pk_eigh_top_f64 (one launch of a
+        direct method that checks its own result) where it applies and passes, else the Jacobi kernel's leading columns.
+        One small device -> host read per call (the kernel's verdict)."""
+        n = int(S.shape[0])
+        r = int(r)
+        if self.lib.pk_eigh_top_supported(n, r):
+            S = S.contiguous()
+            R = self.empty(r, n)
+            lam = self.empty(r)
+            info = torch.zeros(1, dtype=torch.int32, device=self.device)
+            work = self._work(self.lib.pk_eigh_top_work_bytes(n))
+            _lib.check(self.lib.pk_eigh_top_f64(self.stream(), n, _ptr(S), n, r, _ptr(R), n, _ptr(lam), _ptr(work), _ptr(info)),
+                       'pk_eigh_top_f64')
+            if int(info.item()) == 1:
+                return lam, R.t()
+        lam, C = self.eigh_psd(S)
+        return lam[:r], C[:, :r]
+
     def chol_rinv(self, G, shift_rel=0.0, info=None):
         """Rinv (l x l upper triangular) with G + shift_rel*trace(G)*I = R^T R; info: int32 device tensor[1]
         (0 = ok, j+1 = non-positive pivot at column j) — not read here, so no host sync."""

@@ -139,6 +139,17 @@ def _eigh_warm(ops, S, warm):
     return lam, Cm
 
 
+def _eigh_lead(ops, S, r, warm):
+    """(evals desc, eigenvectors as columns) of the Gram matrix S with AT LEAST the r leading pairs.  The unfoldings need
+    r = 30 of 120-150 pairs: `ops.eigh_top` computes just those with a direct method in one launch (csrc/eigh_top.hip;
+    it falls back to the Jacobi kernel by itself when its result does not pass its own check); without it — or for
+    shapes it does not take — the warm-started full Jacobi of `_eigh_warm`."""
+    n = int(S.shape[0])
+    if hasattr(ops, 'eigh_top') and 8 <= n <= 176 and r <= 32 and 2 * r <= n:
+        return ops.eigh_top(S.contiguous(), r)
+    return _eigh_warm(ops, S, warm)
+
+
 def left_svd(ops, M, r, want_v=False, comm=None, n_total=None, warm=None):
     """Top-r left singular vectors / values of dense M (n x m), descending; optionally V^T (r x m).
     Mirrors what `svds(M, k=r)` returns to hooi (after its [::-1] reordering).
@@ -152,7 +163,7 @@ def left_svd(ops, M, r, want_v=False, comm=None, n_total=None, warm=None):
     if comm is not None and comm.world > 1:
         if n_all < m:
             raise NotImplementedError('row-sharded unfolding with fewer rows than columns')
-        lam, Cm = _eigh_warm(ops, comm.allreduce(ops.gram(M)), warm)
+        lam, Cm = _eigh_lead(ops, comm.allreduce(ops.gram(M)), r, warm)
         W = Cm[:, :r].contiguous()
         s = torch.sqrt(torch.clamp_min(lam[:r], 0.0))
         U = ops.tsmm(M, W)
@@ -162,7 +173,7 @@ def left_svd(ops, M, r, want_v=False, comm=None, n_total=None, warm=None):
         U = ops.tsmm(U, Cn.contiguous())
         return U, s, (W.t().contiguous() if want_v else None)
     if n >= m:
-        lam, Cm = _eigh_warm(ops, ops.gram(M), warm)
+        lam, Cm = _eigh_lead(ops, ops.gram(M), r, warm)
         W = Cm[:, :r].contiguous()
         s = torch.sqrt(torch.clamp_min(lam[:r], 0.0))
         U = ops.tsmm(M, W)

@@ -108,6 +108,10 @@ class NumpyOps:
         v = v[:, ::-1].copy()
         return torch.from_numpy(w), torch.from_numpy(v)
 
+    def eigh_top(self, S, r):
+        lam, C = self.eigh_psd(S)
+        return lam[:r], C[:, :r]
+
     def chol_rinv(self, G, shift_rel=0.0, info=None):
         g = G.numpy()
         n = g.shape[0]
