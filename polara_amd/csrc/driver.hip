@@ -1181,6 +1181,33 @@ int eigh_warm(Solver &S, const DMat &G, DMat *Q, std::vector<double> &lam, DMat 
     return PK_OK;
 }
 
+// the r leading eigenpairs of the Gram matrix G: lam (host, >= r values), W [n x r] (columns).  pk_eigh_top_f64 where it
+// applies and passes its own check (tucker._eigh_lead), else the warm-started Jacobi route above
+int eigh_lead(Solver &S, const DMat &G, int r, DMat *warm, std::vector<double> &lam, DMat &W) {
+    pk_ctx *ctx = S.ctx;
+    const int n = G.l;
+    if (pk_eigh_top_supported(n, r) && 2 * r <= n) {
+        DMat R(r, n);
+        Dev lam_dev, info, work;
+        if (!R.ok() || !lam_dev.alloc((size_t)r * 8) || !info.alloc(8) || !work.alloc((size_t)pk_eigh_top_work_bytes(n)))
+            return fail(ctx, PK_E_LAUNCH, "out of device memory (eigh_lead)");
+        CK(pk_eigh_top_f64(S.st, n, G.p(), n, r, R.p(), n, lam_dev.as<double>(), work.p, info.as<int32_t>()));
+        int32_t verdict = 0;
+        CK(S.to_host(info.p, &verdict, sizeof(verdict)));
+        if (verdict == 1) {
+            W = DMat(n, r);
+            if (!W.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (eigh_lead)");
+            hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)(((size_t)r * n + 255) / 256)), dim3(256), 0, S.st, (int64_t)r, n, R.p(), W.p());
+            lam.resize((size_t)r);
+            return S.to_host(lam_dev.p, lam.data(), (size_t)r * 8);
+        }
+    }
+    DMat C;
+    Dev lam_dev;
+    CK(eigh_warm(S, G, warm, lam, C, lam_dev));
+    return S.col_slice(C, 0, r, W);
+}
+
 int left_svd(Solver &S, const DMat &M, int r, DMat &U, std::vector<double> &s, DMat *Vt, DMat *warm = nullptr) {
     pk_ctx *ctx = S.ctx;
     const int64_t n = M.n;
@@ -1190,10 +1217,9 @@ int left_svd(Solver &S, const DMat &M, int r, DMat &U, std::vector<double> &s, D
     Dev lam_dev;
     s.assign((size_t)r, 0.0);
     if (n >= m) {
-        DMat G, C, W, Ur, Gu;
+        DMat G, W, Ur, Gu;
         CK(S.gram(M, M, G));
-        CK(eigh_warm(S, G, warm, lam, C, lam_dev));
-        CK(S.col_slice(C, 0, r, W));
+        CK(eigh_lead(S, G, r, warm, lam, W));
         std::vector<double> inv((size_t)r);
         for (int i = 0; i < r; ++i) { s[(size_t)i] = std::sqrt(std::max(lam[(size_t)i], 0.0)); inv[(size_t)i] = s[(size_t)i] > 0 ? 1.0 / s[(size_t)i] : 0.0; }
         CK(S.tsmm(M, W, Ur));

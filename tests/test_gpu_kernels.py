@@ -1013,3 +1013,74 @@ def test_topk_rows_matches_the_reference_topsort(hip_ops):
     # strided rows
     w = hip_ops.to_device(rng.randn(9, 130))
     assert np.array_equal(hip_ops.to_host(hip_ops.topk_rows(w[:, :100], 4)), orc.get_topk_elements(hip_ops.to_host(w)[:, :100].copy(), 4))
+
+
+def _eigh_top_cases():
+    rs = np.random.RandomState(3)
+    cases = []
+    for n in (120, 150, 176, 64, 9, 33):
+        M = rs.randn(2000, n) * np.exp(-np.arange(n) / 12.0)[None, :]
+        M = M @ np.linalg.qr(rs.randn(n, n))[0]
+        cases.append(('graded_%d' % n, M.T @ M, min(30, n // 2)))
+    n = 150
+    Q = np.linalg.qr(rs.randn(n, n))[0]
+    w = np.r_[np.full(10, 5.0), np.full(10, 5.0 - 1e-9), np.linspace(4, 1, 20), rs.rand(n - 40) * 0.5]
+    cases.append(('ten_equal_ten_near', (Q * w) @ Q.T, 30))
+    w = np.r_[np.linspace(3, 1, 25), np.zeros(n - 25)]
+    cases.append(('rank_25_of_150_r_30', (Q * w) @ Q.T, 30))
+    A = rs.randn(n, n)
+    cases.append(('dense_r32', A @ A.T, 32))
+    cases.append(('scale_1e200', (A @ A.T) * 1e200, 30))
+    cases.append(('scale_1e-200', (A @ A.T) * 1e-200, 30))
+    cases.append(('r_1', A @ A.T, 1))
+    cases.append(('identity', np.eye(n), 30))
+    cases.append(('diagonal', np.diag(np.arange(n, 0, -1.0)), 30))
+    cases.append(('zero', np.zeros((n, n)), 30))
+    return cases
+
+
+@pytest.mark.parametrize('case', _eigh_top_cases(), ids=lambda c: c[0])
+def test_eigh_top_leading_pairs_vs_lapack(hip_ops, case):
+    """csrc/eigh_top.hip (the r leading eigenpairs of an unfolding's Gram matrix — the k of `svds(unfolding, k=r)`,
+    lib/tensor.py:70-80) against numpy.linalg.eigh: eigenvalues to 1e-13 ||S||, residuals and orthonormality to 1e-12,
+    the leading invariant subspace where the r-th gap defines one; graded, clustered, rank-deficient, badly scaled and
+    degenerate spectra; `ops.eigh_top` must hand back a valid answer whatever the direct kernel's own verdict was (the
+    zero matrix is refused by it: Jacobi fallback).  Same bits on a second call."""
+    name, S, r = case
+    n = S.shape[0]
+    Sd = hip_ops.to_device(S)
+    lam, C = hip_ops.eigh_top(Sd, r)
+    lam2, C2 = hip_ops.eigh_top(Sd, r)
+    lam, X = hip_ops.to_host(lam), hip_ops.to_host(C)
+    assert lam.shape == (r,) and X.shape == (n, r)
+    assert np.array_equal(lam, hip_ops.to_host(lam2)) and np.array_equal(X, hip_ops.to_host(C2))
+    w, V = np.linalg.eigh(S)
+    w, V = w[::-1], V[:, ::-1]
+    scale = max(abs(w).max(), 1e-300)
+    assert np.all(np.diff(lam) <= 0) and lam.min() >= 0
+    assert abs(lam - w[:r]).max() <= 1e-13 * scale, name
+    assert abs(S @ X - X * lam).max() <= 1e-12 * scale, name
+    assert abs(X.T @ X - np.eye(r)).max() <= 1e-12, name
+    if r < n and w[r - 1] - w[r] > 1e-6 * scale:
+        assert abs(X @ X.T - V[:, :r] @ V[:, :r].T).max() <= 1e-9, name
+    assert np.array_equal(hip_ops.to_host(Sd), S)                      # the input is read only
+
+
+def test_eigh_top_kernel_reports_what_it_cannot_do(hip_ops):
+    """The C entry point refuses shapes outside its range with an error message, and its verdict for the zero matrix is
+    0 (nothing written) — the contract `ops.eigh_top` and driver.hip's `eigh_lead` build their fallback on."""
+    from polara_amd import _lib
+    from polara_amd.ops import _ptr
+    lib = hip_ops.lib
+    assert lib.pk_eigh_top_supported(150, 30) == 1 and lib.pk_eigh_top_supported(177, 30) == 0
+    assert lib.pk_eigh_top_supported(150, 33) == 0 and lib.pk_eigh_top_supported(7, 2) == 0 and lib.pk_eigh_top_supported(20, 21) == 0
+    n, r = 150, 30
+    Sd = torch.zeros(n, n, dtype=torch.float64, device=hip_ops.device)
+    R = torch.full((r, n), 7.0, dtype=torch.float64, device=hip_ops.device)
+    lam = torch.full((r,), 7.0, dtype=torch.float64, device=hip_ops.device)
+    info = torch.full((4,), 5, dtype=torch.int32, device=hip_ops.device)
+    work = hip_ops._work(lib.pk_eigh_top_work_bytes(n))
+    rc = lib.pk_eigh_top_f64(hip_ops.stream(), n, _ptr(Sd), n, r, _ptr(R), n, _ptr(lam), _ptr(work), _ptr(info))
+    assert rc == 0 and int(info[0].item()) == 0 and float(R.min()) == 7.0 and float(lam.min()) == 7.0
+    rc = lib.pk_eigh_top_f64(hip_ops.stream(), 200, _ptr(Sd), 200, r, _ptr(R), 200, _ptr(lam), _ptr(work), _ptr(info))
+    assert rc != 0 and b'pk_eigh_top_f64' in lib.pk_last_error()
