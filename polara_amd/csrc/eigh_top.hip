@@ -137,45 +137,58 @@ __global__ __launch_bounds__(ETOP_THREADS) void eigh_top_kernel(int n, const dou
 
     ETOP_STAMP();
     // ---- P1: Householder tridiagonalisation (dsytd2, lower): T = Q^T A Q, reflector k kept in refl[k * n + .] ----------
+    // A step has two short serial parts — the reflector's scalars, and K / w between the product and the update — and
+    // they belong to ONE wave: done redundantly by all sixteen they cost every SIMD four times their instructions (the
+    // first version: 7.5 K clocks per step, most of it these parts and their wave reductions).
+    constexpr int XPL = (ETOP_NMAX + 63) / 64;            // entries of a column per lane of wave 0
     for (int k = 0; k < n - 2; ++k) {
         const int m = n - k - 1, g0 = k + 1;
-        // every wave forms the reflector's scalars itself (same data, same order: same bits) — no barrier for a scalar
-        double part = 0.0;
-        for (int i = 1 + lane; i < m; i += 64) {
-            const double x = A[etop_pk(g0 + i, k)];
-            part = fma(x, x, part);
-        }
-        const double xn2 = etop_wave_sum(part);
-        const double alpha = A[etop_pk(g0, k)];
-        double tau = 0.0, beta = alpha, inv = 0.0;
-        if (xn2 > 0.0) {
-            // sixteen waves each do this arithmetic: seeds + Newton steps instead of the IEEE sqrt / divide expansions
-            // (~100 instructions); entries are scaled to <= 1, nothing over- or underflows
-            const double ss = fma(alpha, alpha, xn2);
-            double y = __builtin_amdgcn_rsq(ss);
-            y = y * fma(-0.5 * ss, y * y, 1.5);
-            y = y * fma(-0.5 * ss, y * y, 1.5);
-            double nrm = ss * y;
-            nrm = fma(fma(-nrm, nrm, ss), 0.5 * y, nrm);
-            beta = -copysign(nrm, alpha);
-            double rb = etop_rcp(beta);
-            rb = rb * fma(-beta, rb, 2.0);
-            tau = (beta - alpha) * rb;
-            const double dd = alpha - beta;
-            inv = etop_rcp(dd);
-            inv = inv * fma(-dd, inv, 2.0);
-        }
-        if (tid < m) {
-            const double vi = (tid == 0) ? 1.0 : A[etop_pk(g0 + tid, k)] * inv;
-            v[tid] = vi;
-            refl[(int64_t)k * n + tid] = vi;
-        }
-        if (tid == 0) {
-            s_d[k] = A[etop_pk(k, k)];
-            s_e[k] = beta;
-            s_tau[k] = tau;
+        if (wave == 0) {
+            double x[XPL];
+            double part = 0.0;
+#pragma unroll
+            for (int u = 0; u < XPL; ++u) {
+                const int i = lane + 64 * u;
+                x[u] = (i < m) ? A[etop_pk(g0 + i, k)] : 0.0;
+                if (i >= 1) part = fma(x[u], x[u], part);
+            }
+            const double xn2 = etop_wave_sum(part);
+            const double alpha = __shfl(x[0], 0, 64);
+            double tau = 0.0, beta = alpha, inv = 0.0;
+            if (xn2 > 0.0) {
+                // seeds + Newton steps instead of the IEEE sqrt / divide expansions (~100 instructions on the critical
+                // path of every step); entries are scaled to <= 1, nothing over- or underflows
+                const double ss = fma(alpha, alpha, xn2);
+                double y = __builtin_amdgcn_rsq(ss);
+                y = y * fma(-0.5 * ss, y * y, 1.5);
+                y = y * fma(-0.5 * ss, y * y, 1.5);
+                double nrm = ss * y;
+                nrm = fma(fma(-nrm, nrm, ss), 0.5 * y, nrm);
+                beta = -copysign(nrm, alpha);
+                double rb = etop_rcp(beta);
+                rb = rb * fma(-beta, rb, 2.0);
+                tau = (beta - alpha) * rb;
+                const double dd = alpha - beta;
+                inv = etop_rcp(dd);
+                inv = inv * fma(-dd, inv, 2.0);
+            }
+#pragma unroll
+            for (int u = 0; u < XPL; ++u) {
+                const int i = lane + 64 * u;
+                if (i < m) {
+                    const double vi = (i == 0) ? 1.0 : x[u] * inv;
+                    v[i] = vi;
+                    refl[(int64_t)k * n + i] = vi;
+                }
+            }
+            if (lane == 0) {
+                s_d[k] = A[etop_pk(k, k)];
+                s_e[k] = beta;
+                s_tau[k] = tau;
+            }
         }
         __syncthreads();
+        const double tau = s_tau[k];
         if (tau != 0.0) {                       // uniform
             // p = A22 v: 4, 8 or 16 lanes per row (more as the trailing block shrinks), packed indices advanced by
             // additions (row r of the packed triangle starts r + 1 entries behind row r - 1)
@@ -203,18 +216,27 @@ __global__ __launch_bounds__(ETOP_THREADS) void eigh_top_kernel(int n, const dou
             acc += pk_lane_xor<2>(acc);
             if (tpr_log2 >= 3) acc += pk_lane_xor<4>(acc);
             if (tpr_log2 >= 4) acc += pk_lane_xor<8>(acc);
-            // p . v: the row owners' products summed per wave here, the sixteen partial sums added by everybody below
-            const double mine = (row < m && q == 0) ? acc * v[row] : 0.0;
-            const double wsum = etop_wave_sum(mine);
             if (row < m && q == 0) p[row] = acc;
-            if (lane == 0) s_red[wave] = wsum;
             __syncthreads();
-            // w = tau p - K v with K = tau^2 (p . v) / 2, written over p;  A22 -= v w^T + w v^T
-            double pv = 0.0;
+            // w = tau p - K v with K = tau^2 (p . v) / 2, written over p (wave 0);  A22 -= v w^T + w v^T (everybody)
+            if (wave == 0) {
+                double pl[XPL], vl[XPL];
+                double pv = 0.0;
 #pragma unroll
-            for (int w = 0; w < ETOP_THREADS / 64; ++w) pv += s_red[w];
-            const double K = 0.5 * tau * tau * pv;
-            if (tid < m) p[tid] = fma(tau, p[tid], -K * v[tid]);     // p[tid] is read by nobody else before the barrier
+                for (int u = 0; u < XPL; ++u) {
+                    const int i = lane + 64 * u;
+                    pl[u] = (i < m) ? p[i] : 0.0;
+                    vl[u] = (i < m) ? v[i] : 0.0;
+                    pv = fma(pl[u], vl[u], pv);
+                }
+                pv = etop_wave_sum(pv);
+                const double K = 0.5 * tau * tau * pv;
+#pragma unroll
+                for (int u = 0; u < XPL; ++u) {
+                    const int i = lane + 64 * u;
+                    if (i < m) p[i] = fma(tau, pl[u], -K * vl[u]);
+                }
+            }
             __syncthreads();
             if (row < m) {
                 const int gi = g0 + row;
@@ -274,7 +296,7 @@ __global__ __launch_bounds__(ETOP_THREADS) void eigh_top_kernel(int n, const dou
         if (j < r) {                                      // whole half waves: the exchanges below stay inside one
             const int want = n - j;
             double lo = s_lo[j], hi = s_hi[j];
-            for (int round = 0; round < 10; ++round) {
+            for (int round = 0; round < 9; ++round) {
                 const double x = lo + (hi - lo) * ((t + 1) * (1.0 / 33.0));
                 const int c = etop_count(s_d, s_e2, n, x, pivmin);
                 const unsigned long long b = __ballot(c >= want);
@@ -327,7 +349,7 @@ __global__ __launch_bounds__(ETOP_THREADS) void eigh_top_kernel(int n, const dou
         if (owner && (round == 0 || s_again[vj])) {
             const double sh = s_shift[vj];
             const double tl = fmax(tn * DBL_EPSILON, DBL_MIN);
-            const int iters = round == 0 ? 3 : 1;
+            const int iters = round == 0 ? 2 : 1;
             for (int it = 0; it < iters; ++it) {
                 double zmax = 0.0;
                 for (int i = 0; i < n; ++i) zmax = fmax(zmax, fabs(Z[i * ETOP_ZS + vj]));
