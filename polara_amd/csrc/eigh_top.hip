@@ -141,8 +141,17 @@ __global__ __launch_bounds__(ETOP_THREADS) void eigh_top_kernel(int n, const dou
     // they belong to ONE wave: done redundantly by all sixteen they cost every SIMD four times their instructions (the
     // first version: 7.5 K clocks per step, most of it these parts and their wave reductions).
     constexpr int XPL = (ETOP_NMAX + 63) / 64;            // entries of a column per lane of wave 0
+#ifdef ETOP_PROFILE
+    unsigned long long sub_t[4] = {0ull, 0ull, 0ull, 0ull}, sub_0;
+#define ETOP_SUB(i) { const unsigned long long now_ = __builtin_readcyclecounter(); sub_t[i] += now_ - sub_0; sub_0 = now_; }
+#else
+#define ETOP_SUB(i)
+#endif
     for (int k = 0; k < n - 2; ++k) {
         const int m = n - k - 1, g0 = k + 1;
+#ifdef ETOP_PROFILE
+        sub_0 = __builtin_readcyclecounter();
+#endif
         if (wave == 0) {
             double x[XPL];
             double part = 0.0;
@@ -188,6 +197,7 @@ __global__ __launch_bounds__(ETOP_THREADS) void eigh_top_kernel(int n, const dou
             }
         }
         __syncthreads();
+        ETOP_SUB(0)
         const double tau = s_tau[k];
         if (tau != 0.0) {                       // uniform
             // p = A22 v: 4, 8 or 16 lanes per row (more as the trailing block shrinks), packed indices advanced by
@@ -218,6 +228,7 @@ __global__ __launch_bounds__(ETOP_THREADS) void eigh_top_kernel(int n, const dou
             if (tpr_log2 >= 4) acc += pk_lane_xor<8>(acc);
             if (row < m && q == 0) p[row] = acc;
             __syncthreads();
+            ETOP_SUB(1)
             // w = tau p - K v with K = tau^2 (p . v) / 2, written over p (wave 0);  A22 -= v w^T + w v^T (everybody)
             if (wave == 0) {
                 double pl[XPL], vl[XPL];
@@ -238,6 +249,7 @@ __global__ __launch_bounds__(ETOP_THREADS) void eigh_top_kernel(int n, const dou
                 }
             }
             __syncthreads();
+            ETOP_SUB(2)
             if (row < m) {
                 const int gi = g0 + row;
                 double *ar = A + etop_pk(gi, g0);
@@ -245,8 +257,13 @@ __global__ __launch_bounds__(ETOP_THREADS) void eigh_top_kernel(int n, const dou
                 for (int j = q; j <= row; j += tpr) ar[j] = fma(-vi, p[j], fma(-wi, v[j], ar[j]));
             }
             __syncthreads();
+            ETOP_SUB(3)
         }
     }
+#ifdef ETOP_PROFILE
+    if (tid == 0)
+        for (int i = 0; i < 4; ++i) info[8 + i] = (int)(sub_t[i] / 100);      // P1: scalars, product, K / w, update
+#endif
     if (tid == 0) {
         s_d[n - 2] = A[etop_pk(n - 2, n - 2)];
         s_e[n - 2] = A[etop_pk(n - 1, n - 2)];

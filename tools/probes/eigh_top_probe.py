@@ -22,7 +22,7 @@ def run(name, S, r, reps=10):
     for _ in range(reps): call()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
     ok = int(info[0].item())
-    phases = info[2:8].tolist()
+    phases = info[2:8].tolist() + ['P1:'] + info[8:12].tolist()
     t0 = time.perf_counter()
     for _ in range(reps): ops.eigh_psd(Sd)
     torch.cuda.synchronize(); dj = (time.perf_counter() - t0) / reps
