@@ -27,7 +27,7 @@
 
 __host__ __device__ constexpr size_t etop_lds_bytes(int n) {
     const size_t p1 = ((size_t)n * (n + 1) / 2 + 2 * (size_t)n) * sizeof(double);           // packed lower triangle, v, p
-    const size_t p3 = (size_t)n * (ETOP_ZS + 2 * ETOP_RMAX) * sizeof(double) + (size_t)n * ETOP_RMAX;   // Z, U diagonal (reciprocal), U super-diagonal, interchange flags
+    const size_t p3 = (size_t)n * (ETOP_ZS + 2 * ETOP_RMAX) * sizeof(double);               // Z, U diagonal (reciprocal), U super-diagonal
     return p1 > p3 ? p1 : p3;
 }
 
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(ETOP_THREADS) void eigh_top_kernel(int n, const dou
                 const int gi = g0 + row;
                 double *ar = A + etop_pk(gi, g0);
                 const double vi = v[row], wi = p[row];
-                for (int j = q; j <= row; j += tpr) ar[j] = fma(-vi, p[j], fma(-wi, v[j], ar[j]));
+                for (int j = q; j <= row; j += tpr) ar[j] = fma(-vi, p[j], fma(-wi, v[j], ar[j]));     // (unrolling by four: no gain, the LDS pipe is the bound)
             }
             __syncthreads();
             ETOP_SUB(3)
@@ -332,11 +332,10 @@ __global__ __launch_bounds__(ETOP_THREADS) void eigh_top_kernel(int n, const dou
     }
 
     ETOP_STAMP();
-    // ---- P3: eigenvectors of T by inverse iteration (dstein): vector j on lane j / 16 of wave j % 16 ------------------
+    // ---- P3: eigenvectors of T by inverse iteration (dstein): vector j on lane j of wave 0 ---------------------------
     double *Z = etop_smem;                                  // [n][ETOP_ZS]
     double *Ua = Z + (size_t)n * ETOP_ZS;                   // [n][32]: reciprocal pivots of U
     double *Ub = Ua + (size_t)n * ETOP_RMAX;                // [n][32]: first super-diagonal of U
-    unsigned char *Pv = reinterpret_cast<unsigned char *>(Ub + (size_t)n * ETOP_RMAX);   // [n][32]: row k was interchanged
     const double ortol = 1e-3 * tn;
     if (tid == 0) {
         // shifts: equal eigenvalues are separated by 10 ulp so that their factorizations differ; clusters: runs of
@@ -353,8 +352,11 @@ __global__ __launch_bounds__(ETOP_THREADS) void eigh_top_kernel(int n, const dou
         for (int j = 0; j < r; ++j) s_again[j] = (s_cluster[j] != j) || (j + 1 < r && s_cluster[j + 1] == j);
     }
     __syncthreads();
-    const int vj = (tid & 63) * 16 + (tid >> 6);            // the vector this thread owns in P3 (lanes 0, 1 of every wave)
-    const bool owner = (tid & 63) < 2 && vj < r;
+    // all r vectors on the lanes of ONE wave: a wave instruction costs its issue slots whatever the number of active
+    // lanes, so two lanes on each of sixteen waves (the first version) made every SIMD issue the whole chain four times
+    // (0.68 M clocks for 30 vectors where one vector alone took 0.28 M)
+    const int vj = tid;
+    const bool owner = tid < r;
     if (owner) {
         unsigned h = 0x9E3779B9u * (unsigned)(vj + 1);
         for (int i = 0; i < n; ++i) {                       // start vector: fixed pseudo-random numbers in (-1, 1)
@@ -367,18 +369,18 @@ __global__ __launch_bounds__(ETOP_THREADS) void eigh_top_kernel(int n, const dou
             const double sh = s_shift[vj];
             const double tl = fmax(tn * DBL_EPSILON, DBL_MIN);
             const int iters = round == 0 ? 2 : 1;
+            double zs = 1.0;          // Z is read as Z * zs: 1 / max |z| of the previous sweep (start vectors are in (-1, 1))
+            double nn = 1.0;          // sum of squares of the last sweep's solution
             for (int it = 0; it < iters; ++it) {
-                double zmax = 0.0;
-                for (int i = 0; i < n; ++i) zmax = fmax(zmax, fabs(Z[i * ETOP_ZS + vj]));
-                const double zs = zmax > 0.0 ? 1.0 / zmax : 1.0;
                 // LU of T - sh I with partial pivoting (dlagtf), applied to the right-hand side on the fly; U keeps
-                // (1 / pivot, first super-diagonal) per row and the interchange bits (second super-diagonal = e[k+1] then)
-                // (branch-free: the two lanes of a wave take different pivots)
+                // (1 / pivot, first super-diagonal) per row in LDS and the interchange bits in three registers (second
+                // super-diagonal = e[k+1] then).  Branch-free: the two lanes of a wave take different pivots.  The
+                // operands of the NEXT step are requested before this step's division chain.
+                unsigned long long w0 = 0ull, w1 = 0ull, w2 = 0ull;
                 double a = s_d[0] - sh, b = s_e[0];
                 double yk = Z[vj] * zs;
                 double c = s_e[0], a1 = s_d[1] - sh, e1 = (1 < n - 1) ? s_e[1] : 0.0, y1 = Z[ETOP_ZS + vj] * zs;
                 for (int k = 0; k < n - 1; ++k) {
-                    // operands of the NEXT step, requested before this step's division chain
                     const int kn = (k + 1 < n - 1) ? k + 1 : k;
                     const double c_n = s_e[kn], a1_n = s_d[kn + 1] - sh, e1_n = (kn + 1 < n - 1) ? s_e[kn + 1] : 0.0;
                     const double y1_n = Z[(kn + 1) * ETOP_ZS + vj] * zs;
@@ -391,8 +393,11 @@ __global__ __launch_bounds__(ETOP_THREADS) void eigh_top_kernel(int n, const dou
                     const double ykeep = sw ? y1 : yk, yother = sw ? yk : y1;
                     Ua[k * ETOP_RMAX + vj] = rp;
                     Ub[k * ETOP_RMAX + vj] = ub;
-                    Pv[k * ETOP_RMAX + vj] = sw ? 1 : 0;
                     Z[k * ETOP_ZS + vj] = ykeep;
+                    const unsigned long long bit = (unsigned long long)sw << (k & 63);
+                    w0 |= (k < 64) ? bit : 0ull;
+                    w1 |= (k >= 64 && k < 128) ? bit : 0ull;
+                    w2 |= (k >= 128) ? bit : 0ull;
                     a = fma(-mlt, ub, sw ? b : a1);
                     b = sw ? -mlt * e1 : e1;
                     yk = fma(-mlt, ykeep, yother);
@@ -402,29 +407,45 @@ __global__ __launch_bounds__(ETOP_THREADS) void eigh_top_kernel(int n, const dou
                     y1 = y1_n;
                 }
                 if (fabs(a) < tl) a = (a < 0.0) ? -tl : tl;
-                // back substitution
+                // back substitution, operands one step ahead; the solution's largest entry and sum of squares on the way
+                // (entries are bounded by ~1 / (eps ||T||) per sweep on a right-hand side of size 1: squares cannot overflow)
                 double z1 = yk * etop_rcp(a), z2 = 0.0;     // z[k + 1], z[k + 2]
                 Z[(n - 1) * ETOP_ZS + vj] = z1;
+                double zmax = fabs(z1);
+                nn = z1 * z1;
+                int kp = n - 2;
+                double ub_n = Ub[kp * ETOP_RMAX + vj], ua_n = Ua[kp * ETOP_RMAX + vj], y_n = Z[kp * ETOP_ZS + vj], e_n = 0.0;
                 for (int k = n - 2; k >= 0; --k) {
-                    const double dd = (Pv[k * ETOP_RMAX + vj] && k + 1 < n - 1) ? s_e[k + 1] : 0.0;
-                    double y = Z[k * ETOP_ZS + vj];
-                    y = fma(-Ub[k * ETOP_RMAX + vj], z1, y);
+                    const double ub = ub_n, ua = ua_n, e_k1 = e_n;
+                    double y = y_n;
+                    kp = (k > 0) ? k - 1 : 0;
+                    ub_n = Ub[kp * ETOP_RMAX + vj];
+                    ua_n = Ua[kp * ETOP_RMAX + vj];
+                    y_n = Z[kp * ETOP_ZS + vj];
+                    e_n = s_e[kp + 1];                       // kp + 1 <= n - 2: a stored super-diagonal entry
+                    const unsigned long long w = (k >= 128) ? w2 : (k >= 64) ? w1 : w0;
+                    const double dd = ((w >> (k & 63)) & 1ull) ? e_k1 : 0.0;
+                    y = fma(-ub, z1, y);
                     y = fma(-dd, z2, y);
-                    y *= Ua[k * ETOP_RMAX + vj];
+                    y *= ua;
                     Z[k * ETOP_ZS + vj] = y;
+                    zmax = fmax(zmax, fabs(y));
+                    nn = fma(y, y, nn);
                     z2 = z1;
                     z1 = y;
                 }
+                zs = (zmax > 0.0 && zmax < INFINITY) ? etop_rcp(zmax) : 1.0;
             }
-            double nn = 0.0, zmax = 0.0;
-            for (int i = 0; i < n; ++i) zmax = fmax(zmax, fabs(Z[i * ETOP_ZS + vj]));
-            const double zs = (zmax > 0.0 && zmax < INFINITY) ? 1.0 / zmax : 1.0;
-            for (int i = 0; i < n; ++i) {
-                const double z = Z[i * ETOP_ZS + vj] * zs;
-                nn = fma(z, z, nn);
+            const double sc = 1.0 / sqrt(nn);               // a solution that is not finite gives NaN here: caught by the check
+            int i = 0;
+            for (; i + 4 <= n; i += 4) {
+                const double t0 = Z[i * ETOP_ZS + vj], t1 = Z[(i + 1) * ETOP_ZS + vj], t2 = Z[(i + 2) * ETOP_ZS + vj], t3 = Z[(i + 3) * ETOP_ZS + vj];
+                Z[i * ETOP_ZS + vj] = t0 * sc;
+                Z[(i + 1) * ETOP_ZS + vj] = t1 * sc;
+                Z[(i + 2) * ETOP_ZS + vj] = t2 * sc;
+                Z[(i + 3) * ETOP_ZS + vj] = t3 * sc;
             }
-            const double sc = zs / sqrt(nn);
-            for (int i = 0; i < n; ++i) Z[i * ETOP_ZS + vj] *= sc;
+            for (; i < n; ++i) Z[i * ETOP_ZS + vj] *= sc;
         }
         __syncthreads();
         // modified Gram-Schmidt inside the clusters: one wave per cluster, members in order
