@@ -309,20 +309,22 @@ __global__ __launch_bounds__(ETOP_THREADS) void eigh_top_kernel(int n, const dou
             s_hi[tid] = (hi_i >= ETOP_THREADS) ? ghi : glo + step * (hi_i + 1);
         }
         __syncthreads();
-        const int j = tid >> 5, t = tid & 31;
-        if (j < r) {                                      // whole half waves: the exchanges below stay inside one
+        // 16 lanes per eigenvalue, x 17 per round, eleven rounds: the recurrence is issue-bound (a wave instruction costs
+        // its slots whatever it computes), and 8 waves x 11 rounds are fewer wave-rounds than 16 x 9 with 32 lanes
+        const int j = tid >> 4, t = tid & 15;
+        if (j < r) {                                      // whole 16-lane groups: the exchanges below stay inside one
             const int want = n - j;
             double lo = s_lo[j], hi = s_hi[j];
-            for (int round = 0; round < 9; ++round) {
-                const double x = lo + (hi - lo) * ((t + 1) * (1.0 / 33.0));
+            for (int round = 0; round < 11; ++round) {
+                const double x = lo + (hi - lo) * ((t + 1) * (1.0 / 17.0));
                 const int c = etop_count(s_d, s_e2, n, x, pivmin);
                 const unsigned long long b = __ballot(c >= want);
-                const unsigned mine = (lane & 32) ? (unsigned)(b >> 32) : (unsigned)b;
-                const int first = mine ? __builtin_ctz(mine) : 32;
-                const int base = lane & 32;
-                const double x_first = __shfl(x, base + (first < 32 ? first : 0), 64);
+                const int base = lane & 48;
+                const unsigned mine = (unsigned)(b >> base) & 0xFFFFu;
+                const int first = mine ? __builtin_ctz(mine) : 16;
+                const double x_first = __shfl(x, base + (first < 16 ? first : 0), 64);
                 const double x_prev = __shfl(x, base + (first > 0 ? first - 1 : 0), 64);
-                const double nlo = (first > 0) ? x_prev : lo, nhi = (first < 32) ? x_first : hi;
+                const double nlo = (first > 0) ? x_prev : lo, nhi = (first < 16) ? x_first : hi;
                 lo = fmax(lo, nlo);
                 hi = fmin(hi, nhi);
             }
@@ -470,37 +472,42 @@ __global__ __launch_bounds__(ETOP_THREADS) void eigh_top_kernel(int n, const dou
 
     ETOP_STAMP();
     // ---- P4: back-transformation X = Q Z, vector j on half wave j (no workgroup barrier: a vector has one owner) --------
-    const int hj = tid >> 5, ht = tid & 31;
-    constexpr int VPL = (ETOP_NMAX + 31) / 32;              // reflector entries per lane
-    if (hj < r) {
-        double vn[VPL];
-        {
-            const int k = n - 3, m = n - k - 1;
+    // ~110 instructions per reflector and half wave, sixteen waves: issue-bound (tried: 16 lanes per vector — the longer
+    // per-lane chains cost more than the saved slots; reflectors three steps ahead — the ring's register moves cost more
+    // than the L2 latency they hide)
+    {
+        const int qj = tid >> 5, qt = tid & 31;
+        constexpr int VPL = (ETOP_NMAX + 31) / 32;          // reflector entries per lane
+        if (qj < r) {
+            double vn[VPL];
+            {
+                const int k = n - 3, m = n - k - 1;
 #pragma unroll
-            for (int u = 0; u < VPL; ++u) vn[u] = (k >= 0 && ht + 32 * u < m) ? refl[(int64_t)k * n + ht + 32 * u] : 0.0;
-        }
-        for (int k = n - 3; k >= 0; --k) {
-            const int m = n - k - 1;
-            double vc[VPL];
-#pragma unroll
-            for (int u = 0; u < VPL; ++u) vc[u] = vn[u];
-            if (k > 0) {
-#pragma unroll
-                for (int u = 0; u < VPL; ++u) vn[u] = (ht + 32 * u < m + 1) ? refl[(int64_t)(k - 1) * n + ht + 32 * u] : 0.0;
+                for (int u = 0; u < VPL; ++u) vn[u] = (k >= 0 && qt + 32 * u < m) ? refl[(int64_t)k * n + qt + 32 * u] : 0.0;
             }
-            const double tau = s_tau[k];
-            if (tau == 0.0) continue;
-            double s = 0.0;
+            for (int k = n - 3; k >= 0; --k) {
+                const int m = n - k - 1;
+                double vc[VPL];
 #pragma unroll
-            for (int u = 0; u < VPL; ++u) {
-                const int i = ht + 32 * u;
-                if (i < m) s = fma(vc[u], Z[(k + 1 + i) * ETOP_ZS + hj], s);
-            }
-            s = etop_half_sum(s) * tau;
+                for (int u = 0; u < VPL; ++u) vc[u] = vn[u];
+                if (k > 0) {
 #pragma unroll
-            for (int u = 0; u < VPL; ++u) {
-                const int i = ht + 32 * u;
-                if (i < m) Z[(k + 1 + i) * ETOP_ZS + hj] = fma(-s, vc[u], Z[(k + 1 + i) * ETOP_ZS + hj]);
+                    for (int u = 0; u < VPL; ++u) vn[u] = (qt + 32 * u < m + 1) ? refl[(int64_t)(k - 1) * n + qt + 32 * u] : 0.0;
+                }
+                const double tau = s_tau[k];
+                if (tau == 0.0) continue;
+                double sacc = 0.0;
+#pragma unroll
+                for (int u = 0; u < VPL; ++u) {
+                    const int i = qt + 32 * u;
+                    if (i < m) sacc = fma(vc[u], Z[(k + 1 + i) * ETOP_ZS + qj], sacc);
+                }
+                sacc = etop_half_sum(sacc) * tau;
+#pragma unroll
+                for (int u = 0; u < VPL; ++u) {
+                    const int i = qt + 32 * u;
+                    if (i < m) Z[(k + 1 + i) * ETOP_ZS + qj] = fma(-sacc, vc[u], Z[(k + 1 + i) * ETOP_ZS + qj]);
+                }
             }
         }
     }
@@ -508,16 +515,34 @@ __global__ __launch_bounds__(ETOP_THREADS) void eigh_top_kernel(int n, const dou
 
     ETOP_STAMP();
     // ---- P5: check against S itself, then write (rows of evecs = eigenvectors, largest |component| positive) ----------
+    const int hj = tid >> 5, ht = tid & 31;
     double worst_res = 0.0, worst_orth = 0.0;
     bool bad = false;
     if (hj < r) {
         const double lam = s_lam[hj];
-        for (int i = ht; i < n; i += 32) {
-            const double *si = S + (int64_t)i * lds_;
-            double acc = 0.0;
-            for (int c = 0; c < n; ++c) acc = fma(si[c], Z[c * ETOP_ZS + hj], acc);
-            const double rr = fabs(fma(-ldexp(lam, ex), Z[i * ETOP_ZS + hj], acc));
-            if (!(rr <= worst_res)) worst_res = rr;          // NaN propagates into worst_res
+        // (S x)_i = sum_c S[c][i] x_c (S is symmetric): lane ht owns rows ht, ht + 32, ...; for every c the lanes of the
+        // half wave read 32 consecutive entries of row c (coalesced) and x_c is one LDS broadcast
+        constexpr int RPL = (ETOP_NMAX + 31) / 32;
+        double acc[RPL];
+#pragma unroll
+        for (int u = 0; u < RPL; ++u) acc[u] = 0.0;
+#pragma unroll 4
+        for (int c = 0; c < n; ++c) {                     // (unrolled: the rows of S are an L2 round trip away)
+            const double xc = Z[c * ETOP_ZS + hj];
+            const double *sc = S + (int64_t)c * lds_;
+#pragma unroll
+            for (int u = 0; u < RPL; ++u) {
+                const int i = ht + 32 * u;
+                if (i < n) acc[u] = fma(sc[i], xc, acc[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RPL; ++u) {
+            const int i = ht + 32 * u;
+            if (i < n) {
+                const double rr = fabs(fma(-ldexp(lam, ex), Z[i * ETOP_ZS + hj], acc[u]));
+                if (!(rr <= worst_res)) worst_res = rr;          // NaN propagates into worst_res
+            }
         }
         for (int l = 0; l <= hj; ++l) {
             double dot = 0.0;
