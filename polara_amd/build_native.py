@@ -58,7 +58,8 @@ def _compile(src, force=False, extra=()):
     (content hashes, not mtimes: the snapshot that travels to the GPU box does not keep mtimes)."""
     obj = os.path.join(OBJDIR, src + '.o')
     spath = os.path.join(CSRC, src)
-    want = _digest([spath] + _headers(), ' '.join(FLAGS) + ' '.join(extra))
+    # (the repo's own location is not part of the stamp: the snapshot on the GPU box lives under another path)
+    want = _digest([spath] + _headers(), (' '.join(FLAGS) + ' '.join(extra)).replace(ROOT, '<repo>'))
     stamp = obj + '.sha1'
     if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == want:
         return obj, False

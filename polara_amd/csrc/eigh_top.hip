@@ -94,7 +94,6 @@ __global__ __launch_bounds__(ETOP_THREADS) void eigh_top_kernel(int n, const dou
     __shared__ int s_cluster[ETOP_RMAX], s_again[ETOP_RMAX];
     __shared__ int s_cnt[ETOP_THREADS];
     __shared__ double s_red[ETOP_THREADS / 64];
-    __shared__ double s_scal[4];
     __shared__ int s_fail;
     const int tid = threadIdx.x;
     const int lane = tid & 63;

@@ -327,13 +327,17 @@ class RecommenderModel:
         return T, n_users, n_items
 
     def _training_rows_test_csr(self):
-        """Shortcut of `_device_test_csr` for the standard evaluation set-up on our own data object: no explicit test
-        set, the holdout names EVERY user, so the test rows are the training rows (data.py:820-832 recovers them by a
-        stable sort of the training triplets by user plus three gathers: ~90 ms of NumPy for 2e7 entries in front of a
-        1 ms scoring pass).  The COO -> CSR kernels sort by (user, item) themselves, so the three training columns go up as
-        they lie.  Taken only when it provably gives the protocol's matrix: matrix models (no per-entry weights), no
-        threshold, no warm start, and every user has at least one interaction (else the protocol renumbers the rows
-        without gaps — checked on the device, one flag comes back).  None: not applicable."""
+        """Shortcuts of `_device_test_csr` on our own data object that skip the host passes of the protocol
+        (`_get_test_data`, models.py:227-257: a sortedness check, a gap check and a renumbering over every test entry;
+        data.py:820-832: a stable sort of the training triplets by user plus three gathers — together 45-110 ms of NumPy
+        for 2e7 entries in front of a 1 ms scoring pass).  The COO -> CSR kernels sort by (user, item) themselves, so the
+        columns go up as they lie and the protocol's checks run on the device:
+          * no explicit test set, the holdout names EVERY user: the test rows are the training rows;
+          * an explicit test set (kept sorted by user by `set_test_data`): its rows, renumbered without gaps on the device
+            where the protocol would.
+        Taken only when it provably gives the protocol's matrix: matrix models (no per-entry weights), no threshold, no
+        test sampling; in the first case also no warm start and every user with at least one interaction (else the
+        protocol renumbers rows of a RECOVERED set — left to it).  None: not applicable."""
         from .data import ArrayData
         d = self.data
         if not (isinstance(d, ArrayData) and type(d).test_to_coo is ArrayData.test_to_coo
@@ -341,19 +345,27 @@ class RecommenderModel:
                 and type(self)._get_test_data is RecommenderModel._get_test_data):
             return None
         test = getattr(d, '_test', None)
-        if (test is None or test.testset is not None or test.holdout is None or d.warm_start or self.feedback_threshold
-                or self._tensor_mode() or getattr(d, 'test_sample', None)):
+        if test is None or self.feedback_threshold or self._tensor_mode() or getattr(d, 'test_sample', None):
             return None
-        n_users, n_items = d.get_test_shape(tensor_mode=False)
-        if n_users != d.n_users:
-            return None                               # the holdout names only some users
-        u, i, f, shp = d.matrix_triplets()
-        T = self.ops.csr_from_coo(u, i, np.asarray(f, dtype=np.float64), (int(n_users), int(n_items)))
-        if not bool((T.indptr[1:] > T.indptr[:-1]).all().item()):
-            return None                               # users without interactions: rows are renumbered by the protocol
+        ops = self.ops
+        n_users, n_items = (int(x) for x in d.get_test_shape(tensor_mode=False))
+        if test.testset is not None:
+            u, i, f = test.testset
+            if len(u) == 0:
+                return None
+            rows = scoring.renumbered_test_rows(ops, u)       # raises like the protocol if the set is not sorted by user
+            T = ops.csr_from_coo(rows, ops.to_device(np.ascontiguousarray(i, dtype=np.int64)),
+                                 ops.to_device(np.asarray(f, dtype=np.float64)), (n_users, n_items))
+        else:
+            if test.holdout is None or d.warm_start or n_users != d.n_users:
+                return None                           # nothing to recover from / the holdout names only some users
+            u, i, f, shp = d.matrix_triplets()
+            T = ops.csr_from_coo(u, i, np.asarray(f, dtype=np.float64), (n_users, n_items))
+            if not bool((T.indptr[1:] > T.indptr[:-1]).all().item()):
+                return None                           # users without interactions: rows are renumbered by the protocol
         if self._item_rank is not None:
-            T = self.ops.csr_relabel_cols(T, self._item_rank)
-        return T, int(n_users), int(n_items)
+            T = ops.csr_relabel_cols(T, self._item_rank)
+        return T, n_users, n_items
 
     def _test_csr_depends_on(self):
         """What the cached device test CSR was built from besides the data (whose changes arrive as events): objects

@@ -70,6 +70,24 @@ HEAD_USERS = int(_os.environ.get('PK_SCORE_HEAD', '0'))   # users of the head ba
 _in_pass = threading.local()
 
 
+def renumbered_test_rows(ops, users):
+    """Device int64 row number of every test entry: `users` (host array, sorted by user) as they are when they run
+    0, 1, 2, ... without gaps, else renumbered that way — what models.py:244-255 does with `np.unique(..., return_inverse)` on
+    the host.  Raises like the protocol when the set is not sorted by user.  One flag pair comes back from the device."""
+    ud = ops.to_device(np.ascontiguousarray(users, dtype=np.int64))
+    if ud.numel() < 2:
+        return torch.zeros_like(ud)
+    step = ud[1:] - ud[:-1]
+    unsorted, gaps = torch.stack([(step < 0).any(), (step > 1).any() | (ud[0] != 0)]).tolist()
+    if unsorted:
+        raise AssertionError('the test set must be sorted by users')
+    if not gaps:
+        return ud
+    rows = torch.zeros_like(ud)
+    rows[1:] = torch.cumsum((step > 0).to(torch.int64), 0)
+    return rows
+
+
 def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stats=None, prune=True, batches=None,
               approx_fold_in=None, order_users=True, head_users=None, two_phase_ok=True):
     """factors: FactorImage; T: ops-level CSR of the test users [n_users x n_items].

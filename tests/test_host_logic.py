@@ -481,3 +481,44 @@ def test_training_rows_shortcut_builds_the_protocol_test_matrix():
     m.build()
     assert m._training_rows_test_csr() is None
     assert m.get_recommendations().shape[1] == 7
+
+
+@pytest.mark.parametrize('gaps', [False, True])
+def test_explicit_test_set_shortcut_builds_the_protocol_test_matrix(gaps):
+    """The other branch of models._training_rows_test_csr: an explicit (warm-start) test set goes to the device as it
+    lies, sortedness / gap checks and the gap-free renumbering of models.py:244-255 run there (scoring.renumbered_test_rows);
+    same lists as through the protocol's host passes, with and without gaps in the test users' ids, and the same
+    complaint about an unsorted set."""
+    from numpy_ops import NumpyOps
+    from polara_amd.data import ArrayData
+    from polara_amd.models import SVDModel
+    from polara_amd import scoring
+
+    class ProtocolData(ArrayData):
+        def test_to_coo(self, *a, **k):
+            return ArrayData.test_to_coo(self, *a, **k)
+
+    rs = np.random.RandomState(21)
+    n_users, n_items, n = 300, 100, 7000
+    u, i = rs.randint(0, n_users, n), rs.randint(0, n_items, n)
+    f = rs.choice([0.0, 1.0, 2.0, 4.5], n)
+    test_users = np.arange(0, 120, 2 if gaps else 1) + (7 if gaps else 0)        # ids 7, 9, 11, ... or 0, 1, 2, ...
+    tu = np.repeat(test_users, 6)
+    ti = rs.randint(0, n_items, len(tu))
+    tf = rs.choice([0.0, 1.0, 3.0], len(tu))
+    hold = (test_users, rs.randint(0, n_items, len(test_users)), np.ones(len(test_users)))
+    recs, used = [], []
+    for cls in (ArrayData, ProtocolData):
+        d = cls((u, i, f), n_users=n_users, n_items=n_items, test=(tu, ti, tf), holdout=hold, warm_start=True)
+        m = SVDModel(d, ops=NumpyOps())
+        m.verbose = False
+        m.rank, m.topk = 6, 5
+        m.build()
+        used.append(m._training_rows_test_csr() is not None)
+        recs.append(m.get_recommendations())
+    assert used == [True, False]
+    assert recs[0].shape == (len(test_users), 5) and np.array_equal(recs[0], recs[1])
+    with pytest.raises(AssertionError):
+        scoring.renumbered_test_rows(NumpyOps(), np.array([0, 2, 1]))
+    assert scoring.renumbered_test_rows(NumpyOps(), np.array([5])).tolist() == [0]
+    assert scoring.renumbered_test_rows(NumpyOps(), np.array([3, 3, 8, 8, 9])).tolist() == [0, 0, 1, 1, 2]
