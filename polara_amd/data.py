@@ -89,6 +89,9 @@ class ArrayData:
             if t is None:
                 return None
             u, i, f = (np.asarray(a) for a in t)
+            if len(u) < 2 or bool((u[1:] >= u[:-1]).all()):
+                # already sorted by user (the usual case): a stable sort would be the identity — no order array, no gathers
+                return Triplets(u.astype(np.int64, copy=False), i.astype(np.int64, copy=False), np.asarray(f, dtype=np.float64))
             order = np.argsort(u, kind='stable')  # data.py `_try_sort_test_data`
             return Triplets(u[order].astype(np.int64), i[order].astype(np.int64),
                             np.asarray(f, dtype=np.float64)[order])
