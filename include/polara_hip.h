@@ -348,6 +348,26 @@ int pk_rescore_topk_rows_f64(void *stream, int64_t n_rows, const int32_t *rows_d
                              const float *cand_score_dev, const int32_t *cand_idx_dev, int32_t topk,
                              double v_row_norm_max,
                              int64_t *out_idx_dev, double *out_score_dev /* or NULL */, int32_t *flags_dev);
+/* The same, and the users it flags are appended to a device-side list while it runs: flagged_list_dev[old *count ...] =
+ * flagged_offset + user for every user whose flag is not 0 (order arbitrary), *flagged_count_dev advanced by an atomic —
+ * what pk_flag_compact(mask = all) makes of the flags afterwards, without its two launches.  The counter is NOT zeroed
+ * here (several calls may append to one list: user batches): pk_zero_i32 (n <= 4096 counters, a kernel) first.
+ * list / count both NULL: plain pk_rescore_topk_rows_f64. */
+int pk_rescore_topk_rows_list_f64(void *stream, int64_t n_rows, const int32_t *rows_dev,
+                             const int32_t *n_rows_dev /* or NULL; else the list length is min(*n_rows_dev, n_rows) */,
+                             int64_t n_users, int64_t n_items,
+                             int32_t K, const double *V_dev, int64_t ldv,
+                             const float *V32_dev /* or NULL */, int64_t ldv32,
+                             const double *E_dev, int64_t lde,
+                             const double *e_err_dev, int64_t e_err_ld /* e_err of user u at e_err_dev[u * e_err_ld] */,
+                             int32_t e_exact /* 1: these E rows are exact, the candidates came
+                             from a sweep over approximate ones (second call) */,
+                             const int64_t *seen_ptr_dev, int32_t KC, int32_t splits,
+                             const float *cand_score_dev, const int32_t *cand_idx_dev, int32_t topk,
+                             double v_row_norm_max,
+                             int64_t *out_idx_dev, double *out_score_dev /* or NULL */, int32_t *flags_dev,
+                             int32_t *flagged_list_dev, int32_t *flagged_count_dev, int32_t flagged_offset);
+int pk_zero_i32(void *stream, int32_t *p_dev, int32_t n);
 /* The re-do of flagged users without a host round trip: pk_flag_compact lists the users with (flags & mask) != 0
  * (list capacity n, *count_dev = list length), pk_fold_rows_f64 recomputes the listed rows of E = A_test V in fp64
  * straight from the CSR (row = row_offset + list[r]), pk_rescore_topk_rows_f64 re-scores them (rows_dev = the list,

@@ -80,6 +80,9 @@ PROTOTYPES = {
     'pk_fold_rows_f64': (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, C.c_int, _vp, _i64, _i32, _vp, _i64]),
     'pk_rescore_topk_rows_f64': (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _i32, _i32,
                                            _vp, _vp, _i32, _f64, _vp, _vp, _vp]),
+    'pk_rescore_topk_rows_list_f64': (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _i32, _i32,
+                                           _vp, _vp, _i32, _f64, _vp, _vp, _vp, _vp, _vp, _i32]),
+    'pk_zero_i32': (C.c_int, [_vp, _vp, _i32]),
     'pk_scatter_rows_i64': (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp]),
     'pk_map_ids_i64': (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp]),
     'pk_exact_work_bytes': (_i64, [_i32, _i64]),

@@ -193,7 +193,8 @@ __global__ __launch_bounds__(256) void rescore_topk_kernel(
     const double *__restrict__ E, int64_t lde, const double *__restrict__ e_err, int64_t e_err_ld, int e_exact,
     const int64_t *__restrict__ seen_ptr, int KC, int splits,
     const float *__restrict__ cand_score, const int32_t *__restrict__ cand_idx, int topk, double vmax,
-    int64_t *__restrict__ out_idx, double *__restrict__ out_score, int32_t *__restrict__ flags) {
+    int64_t *__restrict__ out_idx, double *__restrict__ out_score, int32_t *__restrict__ flags,
+    int32_t *__restrict__ flagged_list, int32_t *__restrict__ flagged_count, int32_t flagged_offset) {
     constexpr int UPW = 64 / (SEG * LPC);
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -296,19 +297,27 @@ __global__ __launch_bounds__(256) void rescore_topk_kernel(
         out_idx[user * topk + t] = (my_i == PK_IDX_NONE) ? -1 : (int64_t)my_i;
         if (out_score) out_score[user * topk + t] = my_s;
     }
-    if (live && q == 0 && t == 0) flags[user] = flag;
+    if (live && q == 0 && t == 0) {
+        flags[user] = flag;
+        // the list of the users to re-do, built where the flag is: what a separate compaction pass over the flags (two
+        // more launches per list) did.  The order of the list is arbitrary either way — every listed user is re-done on
+        // its own rows — so the atomic counter costs no determinism of the results.
+        if (flag && flagged_list) flagged_list[atomicAdd(flagged_count, 1)] = flagged_offset + (int32_t)user;
+    }
 }
 
-extern "C" int pk_rescore_topk_rows_f64(void *stream, int64_t n_rows, const int32_t *rows_dev,
-                                        const int32_t *n_rows_dev, int64_t n_users,
-                                        int64_t n_items, int32_t K, const double *V_dev, int64_t ldv,
-                                        const float *V32_dev, int64_t ldv32,
-                                        const double *E_dev, int64_t lde, const double *e_err_dev,
-                                        int64_t e_err_ld, int32_t e_exact,
-                                        const int64_t *seen_ptr_dev, int32_t KC, int32_t splits,
-                                        const float *cand_score_dev, const int32_t *cand_idx_dev, int32_t topk,
-                                        double v_row_norm_max, int64_t *out_idx_dev, double *out_score_dev,
-                                        int32_t *flags_dev) {
+extern "C" int pk_rescore_topk_rows_list_f64(void *stream, int64_t n_rows, const int32_t *rows_dev,
+                                             const int32_t *n_rows_dev, int64_t n_users,
+                                             int64_t n_items, int32_t K, const double *V_dev, int64_t ldv,
+                                             const float *V32_dev, int64_t ldv32,
+                                             const double *E_dev, int64_t lde, const double *e_err_dev,
+                                             int64_t e_err_ld, int32_t e_exact,
+                                             const int64_t *seen_ptr_dev, int32_t KC, int32_t splits,
+                                             const float *cand_score_dev, const int32_t *cand_idx_dev, int32_t topk,
+                                             double v_row_norm_max, int64_t *out_idx_dev, double *out_score_dev,
+                                             int32_t *flags_dev, int32_t *flagged_list_dev, int32_t *flagged_count_dev,
+                                             int32_t flagged_offset) {
+    PK_REQUIRE((flagged_list_dev == nullptr) == (flagged_count_dev == nullptr), "pk_rescore_topk_f64: flagged list without its counter");
     PK_REQUIRE(n_users >= 1 && K >= 1 && K <= 256 && ldv >= K && lde >= K, "pk_rescore_topk_f64: bad sizes");
     PK_REQUIRE(n_rows >= 0 && n_rows <= n_users, "pk_rescore_topk_f64: bad row count");
     PK_REQUIRE(V32_dev == nullptr || ldv32 >= K, "pk_rescore_topk_f64: ldv32 < K");
@@ -325,7 +334,7 @@ extern "C" int pk_rescore_topk_rows_f64(void *stream, int64_t n_rows, const int3
     hipLaunchKernelGGL((rescore_topk_kernel<SEGV, LPCV, S4>), dim3((unsigned)pk_ceil_div(n_rows, 4 * (64 / (SEGV * LPCV)))), \
                        dim3(256), 0, pk_stream(stream), n_rows, rows_dev, n_rows_dev, n_users, n_items, K, V_dev, ldv, V32_dev, ldv32, E_dev, lde, \
                        e_err_dev, e_err_ld, e_exact, seen_ptr_dev, KC, splits, cand_score_dev, cand_idx_dev, topk, v_row_norm_max,   \
-                       out_idx_dev, out_score_dev, flags_dev)
+                       out_idx_dev, out_score_dev, flags_dev, flagged_list_dev, flagged_count_dev, flagged_offset)
     if (seg == 16) {
         if (lpc_req == 1) PK_RESCORE(16, 1);
         else if (lpc_req == 4) PK_RESCORE(16, 4);
@@ -343,6 +352,21 @@ extern "C" int pk_rescore_topk_rows_f64(void *stream, int64_t n_rows, const int3
 #undef PK_RESCORE_X
     PK_CHECK_LAUNCH("rescore_topk_kernel");
     return PK_OK;
+}
+
+extern "C" int pk_rescore_topk_rows_f64(void *stream, int64_t n_rows, const int32_t *rows_dev,
+                                        const int32_t *n_rows_dev, int64_t n_users,
+                                        int64_t n_items, int32_t K, const double *V_dev, int64_t ldv,
+                                        const float *V32_dev, int64_t ldv32,
+                                        const double *E_dev, int64_t lde, const double *e_err_dev,
+                                        int64_t e_err_ld, int32_t e_exact,
+                                        const int64_t *seen_ptr_dev, int32_t KC, int32_t splits,
+                                        const float *cand_score_dev, const int32_t *cand_idx_dev, int32_t topk,
+                                        double v_row_norm_max, int64_t *out_idx_dev, double *out_score_dev,
+                                        int32_t *flags_dev) {
+    return pk_rescore_topk_rows_list_f64(stream, n_rows, rows_dev, n_rows_dev, n_users, n_items, K, V_dev, ldv, V32_dev, ldv32, E_dev,
+                                         lde, e_err_dev, e_err_ld, e_exact, seen_ptr_dev, KC, splits, cand_score_dev, cand_idx_dev, topk,
+                                         v_row_norm_max, out_idx_dev, out_score_dev, flags_dev, nullptr, nullptr, 0);
 }
 
 extern "C" int pk_rescore_topk_f64(void *stream, int64_t n_users, int64_t n_items, int32_t K, const double *V_dev,
@@ -374,6 +398,17 @@ __global__ __launch_bounds__(256) void flag_compact_kernel(int64_t n, const int3
 }
 
 __global__ void zero_i32_kernel(int32_t *p) { *p = 0; }
+
+__global__ void zero_i32_n_kernel(int32_t *p, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0;
+}
+// zeroes n (<= 4096) device counters with a kernel (not a memset node: see pk_flag_compact)
+extern "C" int pk_zero_i32(void *stream, int32_t *p_dev, int32_t n) {
+    PK_REQUIRE(p_dev && n >= 1 && n <= 4096, "pk_zero_i32: bad arguments");
+    hipLaunchKernelGGL(zero_i32_n_kernel, dim3(1), dim3(64), 0, pk_stream(stream), p_dev, n);
+    PK_CHECK_LAUNCH("zero_i32_n_kernel");
+    return PK_OK;
+}
 
 extern "C" int pk_flag_compact(void *stream, int64_t n, const int32_t *flags_dev, int32_t mask, int32_t *list_dev,
                                int32_t *count_dev) {

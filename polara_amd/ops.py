@@ -846,11 +846,13 @@ class HipOps:
         return rec[:, :, 0, 0].clone()
 
     def rescore_topk(self, V, E, n_items, seen_ptr, KC, cs, ci, topk, vmax, want_scores=True, splits=1, out=None,
-                     rows=None, n_rows_dev=None, e_err=None, e_exact=False, v32=None):
+                     rows=None, n_rows_dev=None, e_err=None, e_exact=False, v32=None, flagged=None):
         """Exact fp64 re-scoring + certification.  rows (int32 tensor): only these users are re-done (outputs
         are still indexed by user: pass the full-size `out`); e_err: per-user error weight of an approximate E
         (flags bit 4 = not certified at that accuracy); v32: fp32 image of V [n_items x >= K], gathered instead
-        of V while E is approximate (its rounding joins the certified error)."""
+        of V while E is approximate (its rounding joins the certified error).  flagged = (list int32, count int32[1],
+        offset): every user that ends up flagged is appended to that device-side list as offset + user while the
+        kernel runs (the counter is the caller's to zero: `zero_counters`)."""
         assert V.stride(1) == 1 and E.stride(1) == 1
         assert v32 is None or (v32.dtype == torch.float32 and v32.stride(1) == 1 and v32.shape[1] >= E.shape[1])
         n_users, K = E.shape
@@ -864,16 +866,23 @@ class HipOps:
         n_rows = n_users if rows is None else int(rows.numel())
         e_ld = 0 if e_err is None else (e_err.stride(0) if e_err.numel() > 1 else 1)
         with self._timed('rescore_topk' if rows is None else 'rescore_topk_refolded', (n_rows, KC, K)):
-            _lib.check(self.lib.pk_rescore_topk_rows_f64(self.stream(), n_rows, _ptr(rows), _ptr(n_rows_dev), n_users,
-                                                         n_items, K, _ptr(V),
-                                                         V.stride(0), _ptr(v32), 0 if v32 is None else v32.stride(0),
-                                                         _ptr(E), E.stride(0), _ptr(e_err), e_ld,
-                                                         1 if e_exact else 0,
-                                                         _ptr(seen_ptr),
-                                                         KC, splits, _ptr(cs), _ptr(ci), topk, float(vmax),
-                                                         _ptr(out_idx), _ptr(out_s), _ptr(flags)),
-                       'pk_rescore_topk_rows_f64')
+            fl, fc, fo = flagged if flagged is not None else (None, None, 0)
+            _lib.check(self.lib.pk_rescore_topk_rows_list_f64(self.stream(), n_rows, _ptr(rows), _ptr(n_rows_dev), n_users,
+                                                              n_items, K, _ptr(V),
+                                                              V.stride(0), _ptr(v32), 0 if v32 is None else v32.stride(0),
+                                                              _ptr(E), E.stride(0), _ptr(e_err), e_ld,
+                                                              1 if e_exact else 0,
+                                                              _ptr(seen_ptr),
+                                                              KC, splits, _ptr(cs), _ptr(ci), topk, float(vmax),
+                                                              _ptr(out_idx), _ptr(out_s), _ptr(flags), _ptr(fl), _ptr(fc), int(fo)),
+                       'pk_rescore_topk_rows_list_f64')
         return out_idx, out_s, flags
+
+    def zero_counters(self, n):
+        """int32 [n] device counters, zeroed by a kernel on the current stream (one launch for all the lists of a pass)"""
+        c = torch.empty(int(n), dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.pk_zero_i32(self.stream(), _ptr(c), int(n)), 'pk_zero_i32')
+        return c
 
     def flag_compact(self, flags, mask=7):
         """(list int32[n], count int32[1]) of the users whose flags intersect `mask` — stays on the device."""

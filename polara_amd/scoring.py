@@ -172,6 +172,13 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
     flags = torch.empty(n_users, dtype=torch.int32, device=E.device)
 
     refolded = []                        # device counters of the users re-done with an exact fold-in
+    # The lists of users to re-do are built by the re-scoring kernel itself, where the flags are (ops.rescore_topk
+    # `flagged`): counter 0 belongs to the pass's final list (users for the exact-row kernel, global ids, every batch
+    # appends), counter 1 + b to batch b's re-fold list.  One launch zeroes them all; the flag compactions (two launches
+    # per list) are gone from the pass.  Backends without the fused form (test doubles) keep `flag_compact`.
+    fused_lists = hasattr(ops, 'zero_counters')
+    final_list = final_cnt = counters = None
+    batch_no = [0]
 
     def run_batch(u0, u1):
         """fold-in -> bounds/pack -> candidate sweep -> exact re-scoring of users [u0, u1) on the current stream"""
@@ -208,17 +215,28 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
                                           user_bound=ub, tile_bound=factors.tile_bound if prune else None,
                                           seen_tiles=st, **extra)                             # K3
         outs = (out_idx[u0:u1], out_s[u0:u1], flags[u0:u1])
+        to_final = (final_list, final_cnt, u0) if fused_lists else None
+        if approx_fold_in and fused_lists:
+            b = batch_no[0]
+            batch_no[0] += 1
+            lst, cnt = torch.empty(nb, dtype=torch.int32, device=E.device), counters[1 + b:2 + b]
+            first = (lst, cnt, 0)
+        else:
+            first = to_final
         ops.rescore_topk(factors.V, Eb, n_items, sp, KC, cs, ci, topk, factors.vmax, want_scores=True,
-                         splits=splits, out=outs, e_err=w, v32=factors.V32x if approx_fold_in else None)
+                         splits=splits, out=outs, e_err=w, v32=factors.V32x if approx_fold_in else None, **(
+                             {'flagged': first} if fused_lists else {}))
         if approx_fold_in:
             # every flagged user — order not certified at the accuracy of the approximate fold-in (bit 4), or
             # bound for the exact-row kernel anyway (bits 1, 2), which must not see an approximate E — gets its
             # E row recomputed from the fp64 factors and is re-scored; the list of those users never leaves the
-            # device (no host round trip inside the pass)
-            lst, cnt = ops.flag_compact(outs[2], 7)
+            # device (no host round trip inside the pass).  Who is STILL flagged after that goes to the final list.
+            if not fused_lists:
+                lst, cnt = ops.flag_compact(outs[2], 7)
             ops.fold_rows(T, lst, cnt, factors.V, Ex, row_offset=u0)
             ops.rescore_topk(factors.V, Eb, n_items, sp, KC, cs, ci, topk, factors.vmax, want_scores=True,
-                             splits=splits, out=outs, rows=lst, n_rows_dev=cnt, e_err=w, e_exact=True)
+                             splits=splits, out=outs, rows=lst, n_rows_dev=cnt, e_err=w, e_exact=True, **(
+                                 {'flagged': to_final} if fused_lists else {}))
             refolded.append(cnt)
 
     # User batches are independent: with B > 1 they run round-robin on two side streams.  Measured on
@@ -231,6 +249,10 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
     head = (int(head_users or 0) // 128) * 128
     if stats is not None:
         B, head = 1, 0                       # sweep statistics are read from the (single) state buffer
+    if fused_lists:
+        counters = ops.zero_counters(2 + max(B, 2))          # on the calling stream, before any batch stream forks from it
+        final_cnt = counters[0:1]
+        final_list = torch.empty(n_users, dtype=torch.int32, device=E.device)
     if B == 1 and not (0 < head and 4 * head <= n_users):
         run_batch(0, n_users)
     else:
@@ -254,7 +276,7 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
             main.wait_stream(sdev)
     # users still flagged (fewer than k unseen items, or not certifiable) are re-done by the exact-row kernel from a
     # device-side list: nothing of the pass visits the host, so consecutive passes queue up without a gap
-    lst, cnt = ops.flag_compact(flags, 0x7fffffff)
+    lst, cnt = (final_list, final_cnt) if fused_lists else ops.flag_compact(flags, 0x7fffffff)
     ops.score_exact_list(lst, cnt, factors.V, E, n_items, seen_ptr, seen_idx, topk, out_idx, out_s)
     if stats is not None:
         stats['flagged_users'] = int(cnt.item())
