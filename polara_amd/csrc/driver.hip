@@ -955,7 +955,8 @@ int serving_score(pk_ctx *ctx, pk_serving *sv, int32_t topk, int32_t filter_seen
     const int64_t *seen_ptr = filter_seen ? Ts.indptr.as<int64_t>() : nullptr;
     const int32_t *seen_idx = filter_seen ? Ts.indices.as<int32_t>() : nullptr;
     Dev out_i((size_t)n_users * topk * 8), out_s((size_t)n_users * topk * 8), flags((size_t)n_users * 4), lst((size_t)std::max<int64_t>(n_users, 1) * 4), cnt(4);
-    if (!out_i.p || !out_s.p || !flags.p || !lst.p || !cnt.p) return fail(ctx, PK_E_LAUNCH, "out of device memory (outputs)");
+    Dev lst2((size_t)std::max<int64_t>(n_users, 1) * 4), cnt2(8);
+    if (!out_i.p || !out_s.p || !flags.p || !lst.p || !cnt.p || !lst2.p || !cnt2.p) return fail(ctx, PK_E_LAUNCH, "out of device memory (outputs)");
     const int KC = sv->fused ? pk_candidate_capacity(topk) : 0;
     const int n_wg = 128;
     Dev exact_work((size_t)pk_exact_work_bytes(n_wg, n_items));
@@ -1021,19 +1022,22 @@ int serving_score(pk_ctx *ctx, pk_serving *sv, int32_t topk, int32_t filter_seen
                                        KC, splits, cs.as<float>(), ci.as<int32_t>(), state.p, 0, ub.as<float>(), sv->tile_bound.as<float>(),
                                        dense_p, skip_p, filter_seen ? sv->dense_tiles : 0));
         }
-        CK(pk_rescore_topk_rows_f64(st, n_users, nullptr, nullptr, n_users, n_items, K, V.p(), K, approx ? sv->V32.as<float>() : nullptr, approx ? ld32 : 0,
-                                    Ex.p(), Kx, w, approx ? Kx : 0, 0, seen_ptr, KC, splits, cs.as<float>(), ci.as<int32_t>(), topk, vmax,
-                                    out_i.as<int64_t>(), out_s.as<double>(), flags.as<int32_t>()));
+        // the lists of users to re-do are appended by the re-scoring kernel itself (scoring.py: fused lists): cnt2[0] counts
+        // the re-fold list (lst), cnt2[1] the final list for the exact-row kernel (lst2)
+        CK(pk_zero_i32(st, cnt2.as<int32_t>(), 2));
+        int32_t *c_refold = cnt2.as<int32_t>(), *c_final = cnt2.as<int32_t>() + 1;
+        CK(pk_rescore_topk_rows_list_f64(st, n_users, nullptr, nullptr, n_users, n_items, K, V.p(), K, approx ? sv->V32.as<float>() : nullptr, approx ? ld32 : 0,
+                                         Ex.p(), Kx, w, approx ? Kx : 0, 0, seen_ptr, KC, splits, cs.as<float>(), ci.as<int32_t>(), topk, vmax,
+                                         out_i.as<int64_t>(), out_s.as<double>(), flags.as<int32_t>(),
+                                         approx ? lst.as<int32_t>() : lst2.as<int32_t>(), approx ? c_refold : c_final, 0));
         if (approx) {
-            CK(pk_flag_compact(st, n_users, flags.as<int32_t>(), 7, lst.as<int32_t>(), cnt.as<int32_t>()));
-            CK(pk_fold_rows_f64(st, n_users, lst.as<int32_t>(), cnt.as<int32_t>(), 0, Ts.indptr.as<int64_t>(), Ts.indices.as<int32_t>(), Ts.values.p,
+            CK(pk_fold_rows_f64(st, n_users, lst.as<int32_t>(), c_refold, 0, Ts.indptr.as<int64_t>(), Ts.indices.as<int32_t>(), Ts.values.p,
                                 Ts.val_kind, V.p(), K, K, Ex.p(), Kx));
-            CK(pk_rescore_topk_rows_f64(st, n_users, lst.as<int32_t>(), cnt.as<int32_t>(), n_users, n_items, K, V.p(), K, nullptr, 0, Ex.p(), Kx, w, Kx,
-                                        1, seen_ptr, KC, splits, cs.as<float>(), ci.as<int32_t>(), topk, vmax, out_i.as<int64_t>(), out_s.as<double>(),
-                                        flags.as<int32_t>()));
+            CK(pk_rescore_topk_rows_list_f64(st, n_users, lst.as<int32_t>(), c_refold, n_users, n_items, K, V.p(), K, nullptr, 0, Ex.p(), Kx, w, Kx,
+                                             1, seen_ptr, KC, splits, cs.as<float>(), ci.as<int32_t>(), topk, vmax, out_i.as<int64_t>(), out_s.as<double>(),
+                                             flags.as<int32_t>(), lst2.as<int32_t>(), c_final, 0));
         }
-        CK(pk_flag_compact(st, n_users, flags.as<int32_t>(), 0x7fffffff, lst.as<int32_t>(), cnt.as<int32_t>()));
-        CK(pk_score_exact_list_f64(st, n_wg, lst.as<int32_t>(), cnt.as<int32_t>(), n_items, K, V.p(), K, Ex.p(), Kx, seen_ptr, seen_idx, topk,
+        CK(pk_score_exact_list_f64(st, n_wg, lst2.as<int32_t>(), c_final, n_items, K, V.p(), K, Ex.p(), Kx, seen_ptr, seen_idx, topk,
                                    out_i.as<int64_t>(), out_s.as<double>(), exact_work.p));
         HIPCK(hipStreamSynchronize(st));   // every temporary above is still alive here
     }
