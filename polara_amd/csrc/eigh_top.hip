@@ -517,24 +517,39 @@ __global__ __launch_bounds__(ETOP_THREADS) void eigh_top_kernel(int n, const dou
     const int hj = tid >> 5, ht = tid & 31;
     double worst_res = 0.0, worst_orth = 0.0;
     bool bad = false;
-    if (hj < r) {
-        const double lam = s_lam[hj];
-        // (S x)_i = sum_c S[c][i] x_c (S is symmetric): lane ht owns rows ht, ht + 32, ...; for every c the lanes of the
-        // half wave read 32 consecutive entries of row c (coalesced) and x_c is one LDS broadcast
-        constexpr int RPL = (ETOP_NMAX + 31) / 32;
-        double acc[RPL];
+    // (S x)_i = sum_c S[c][i] x_c (S is symmetric): half wave hj owns vector hj, its lane ht the rows ht, ht + 32, ...
+    // S comes through LDS in chunks of 16 rows fetched ONCE by the whole workgroup (the space of P3's factors is free): every
+    // half wave reading the rows from global memory itself was an L1 / L2 round trip per row and vector (0.22 M clocks)
+    constexpr int RPL = (ETOP_NMAX + 31) / 32;
+    constexpr int CH = 16;
+    double acc[RPL];
 #pragma unroll
-        for (int u = 0; u < RPL; ++u) acc[u] = 0.0;
-#pragma unroll 4
-        for (int c = 0; c < n; ++c) {                     // (unrolled: the rows of S are an L2 round trip away)
-            const double xc = Z[c * ETOP_ZS + hj];
-            const double *sc = S + (int64_t)c * lds_;
+    for (int u = 0; u < RPL; ++u) acc[u] = 0.0;
+    {
+        double *Sbuf = Z + (size_t)n * ETOP_ZS;            // CH * n doubles <= the two factor arrays (2 * 32 * n)
+        for (int c0 = 0; c0 < n; c0 += CH) {
+            const int rows = (n - c0 < CH) ? (n - c0) : CH;
+            __syncthreads();                                // the previous chunk has been consumed
+            for (int e = tid; e < rows * n; e += ETOP_THREADS) {
+                const int rr = e / n, cc = e - rr * n;
+                Sbuf[e] = S[(int64_t)(c0 + rr) * lds_ + cc];
+            }
+            __syncthreads();
+            if (hj < r) {
+                for (int rr = 0; rr < rows; ++rr) {
+                    const double xc = Z[(c0 + rr) * ETOP_ZS + hj];
+                    const double *sc = Sbuf + rr * n;
 #pragma unroll
-            for (int u = 0; u < RPL; ++u) {
-                const int i = ht + 32 * u;
-                if (i < n) acc[u] = fma(sc[i], xc, acc[u]);
+                    for (int u = 0; u < RPL; ++u) {
+                        const int i = ht + 32 * u;
+                        if (i < n) acc[u] = fma(sc[i], xc, acc[u]);
+                    }
+                }
             }
         }
+    }
+    if (hj < r) {
+        const double lam = s_lam[hj];
 #pragma unroll
         for (int u = 0; u < RPL; ++u) {
             const int i = ht + 32 * u;
