@@ -176,7 +176,7 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
     # `flagged`): counter 0 belongs to the pass's final list (users for the exact-row kernel, global ids, every batch
     # appends), counter 1 + b to batch b's re-fold list.  One launch zeroes them all; the flag compactions (two launches
     # per list) are gone from the pass.  Backends without the fused form (test doubles) keep `flag_compact`.
-    fused_lists = hasattr(ops, 'zero_counters')
+    fused_lists = hasattr(ops, 'zero_counters') and not _os.environ.get('PK_SCORE_SEPARATE_LISTS')      # (tuning: the old launches)
     final_list = final_cnt = counters = None
     batch_no = [0]
 
