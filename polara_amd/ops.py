@@ -627,6 +627,21 @@ class HipOps:
         lam, C = self.eigh_psd(S)
         return lam[:r], C[:, :r]
 
+    def eigh_top_deferred(self, S, r):
+        """`eigh_top` without the host read: (evals [r], evecs [n x r], verdict int32[1] on the device).  The results are
+        only valid where the verdict is 1 — the caller reads it later (tucker.hooi: once per iteration) and re-does the
+        work on the Jacobi route otherwise.  Shapes must satisfy pk_eigh_top_supported."""
+        n, r = int(S.shape[0]), int(r)
+        assert self.lib.pk_eigh_top_supported(n, r)
+        S = S.contiguous()
+        R = self.zeros(r, n)
+        lam = self.zeros(r)
+        info = torch.zeros(1, dtype=torch.int32, device=self.device)
+        work = self._work(self.lib.pk_eigh_top_work_bytes(n))
+        _lib.check(self.lib.pk_eigh_top_f64(self.stream(), n, _ptr(S), n, r, _ptr(R), n, _ptr(lam), _ptr(work), _ptr(info)),
+                   'pk_eigh_top_f64')
+        return lam, R.t(), info
+
     def chol_rinv(self, G, shift_rel=0.0, info=None):
         """Rinv (l x l upper triangular) with G + shift_rel*trace(G)*I = R^T R; info: int32 device tensor[1]
         (0 = ok, j+1 = non-positive pivot at column j) — not read here, so no host sync."""

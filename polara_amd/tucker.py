@@ -145,7 +145,14 @@ def _eigh_lead(ops, S, r, warm):
     it falls back to the Jacobi kernel by itself when its result does not pass its own check); without it — or for
     shapes it does not take — the warm-started full Jacobi of `_eigh_warm`."""
     n = int(S.shape[0])
-    if hasattr(ops, 'eigh_top') and 8 <= n <= 176 and r <= 32 and 2 * r <= n:
+    if (hasattr(ops, 'eigh_top') and 8 <= n <= 176 and r <= 32 and 2 * r <= n
+            and not (warm is not None and warm.get('no_direct'))):
+        if warm is not None and hasattr(ops, 'eigh_top_deferred'):
+            # no host round trip per solve: the kernel's verdict stays on the device and is read with the core norm at
+            # the end of the HOOI iteration (`hooi` re-does the iteration on the Jacobi route if a verdict was 0)
+            lam, Cm, verdict = ops.eigh_top_deferred(S.contiguous(), r)
+            warm.setdefault('verdicts', []).append(verdict)
+            return lam, Cm
         return ops.eigh_top(S.contiguous(), r)
     return _eigh_warm(ops, S, warm)
 
@@ -232,14 +239,28 @@ def hooi(ops, idx, val, shape, core_shape, num_iters=25, growth_tol=0.01, seed=N
     trace = []
     ss = vv = u0 = None
     warm = ({}, {}, {}) if warm_start else (None, None, None)      # per mode: the previous iteration's eigenvectors
-    for i in range(num_iters):
+    i = 0
+    while i < num_iters:
+        u1_in, u2_in = u1, u2
         res0, _ = factored_products(ops, uf, None, u1, u2, 0)
         u0, _, _ = left_svd(ops, res0, r0, comm=comm, n_total=n0_total, warm=warm[0])        # rows = local users
         res1, W1 = factored_products(ops, uf, u0, u1, u2, 1, comm=comm)
         u1, _, _ = left_svd(ops, res1, r1, warm=warm[1])
         res2, _ = factored_products(ops, uf, u0, u1, u2, 2, W1=W1)
         u2, ss, vv = left_svd(ops, res2, r2, want_v=True, warm=warm[2])
-        g_norm_new = float(torch.linalg.vector_norm(ss).item())
+        # ONE device -> host read per iteration: the core norm and the verdicts of this iteration's direct eigensolves
+        verdicts = [v for w in warm if w is not None for v in w.pop('verdicts', [])]
+        host = torch.cat([torch.linalg.vector_norm(ss).reshape(1).to(torch.float64)] +
+                         [v.reshape(1).to(torch.float64) for v in verdicts]).tolist()
+        if any(v != 1.0 for v in host[1:]):
+            # a direct solve did not pass its own check (degenerate Gram matrix): this iteration again, and every later
+            # one, on the Jacobi route — same inputs, nothing of the discarded attempt is kept
+            for w in warm:
+                if w is not None:
+                    w['no_direct'] = True
+            u1, u2 = u1_in, u2_in
+            continue
+        g_norm_new = float(host[0])
         g_growth = (g_norm_new - g_norm_old) / g_norm_new
         g_norm_old = g_norm_new
         trace.append(g_norm_new)
@@ -247,5 +268,6 @@ def hooi(ops, idx, val, shape, core_shape, num_iters=25, growth_tol=0.01, seed=N
             print('Step %i of %i, growth of the core: %f' % (i + 1, num_iters, g_growth))
         if g_growth < growth_tol:
             break
+        i += 1
     core = (ss[:, None] * vv).reshape(r2, r1, r0).permute(2, 1, 0).contiguous()
     return u0, u1, u2, core, trace

@@ -104,3 +104,53 @@ def test_device_coordinate_build_equals_the_protocol_build():
     assert a.core_norm_trace == b.core_norm_trace
     for k in a.factors:
         assert np.array_equal(a.factors[k], b.factors[k]), k
+
+
+@pytest.mark.gpu
+def test_hooi_redoes_an_iteration_when_a_direct_eigensolve_reports_failure(hip_ops, monkeypatch):
+    """tucker.hooi reads the verdicts of the direct eigensolves (csrc/eigh_top.hip) once per iteration, with the core
+    norm.  A verdict of 0 must discard the iteration and run it — and every later one — on the Jacobi route, from the
+    same inputs: the result is then, bit for bit, that of a build that never used the direct kernel; and the direct
+    route itself agrees with the Jacobi route to rounding."""
+    import torch
+    from polara_amd import tucker
+    rs = np.random.RandomState(9)
+    shape, ranks, nnz = (400, 260, 5), (20, 18, 4), 30000
+    idx = np.stack([rs.randint(0, s, nnz) for s in shape], 1).astype(np.int64)
+
+    def run():
+        u0, u1, u2, core, trace = tucker.hooi(hip_ops, idx, None, shape, ranks, num_iters=6, growth_tol=1e-9, seed=3)
+        return [hip_ops.to_host(x) for x in (u0, u1, u2, core)], trace
+
+    direct, trace_direct = run()
+    calls = []
+    real = type(hip_ops).eigh_top_deferred
+
+    def failing_once(self, S, r):
+        lam, C, verdict = real(self, S, r)
+        calls.append(1)
+        if len(calls) == 3:                              # the first solve of the second iteration "fails"
+            verdict = torch.zeros_like(verdict)
+        return lam, C, verdict
+    monkeypatch.setattr(type(hip_ops), 'eigh_top_deferred', failing_once)
+    retried, trace_retried = run()
+    monkeypatch.setattr(type(hip_ops), 'eigh_top_deferred', real)
+    assert len(calls) >= 4 and len(trace_retried) == len(trace_direct)          # the direct route ran, then stopped being used
+    n_direct_calls = len(calls)
+    # a build that is on the Jacobi route from its second iteration on: the first iteration direct, like the retried run
+    calls.clear()
+
+    def first_iteration_only(self, S, r):
+        calls.append(1)
+        lam, C, verdict = real(self, S, r)
+        return (lam, C, verdict) if len(calls) <= 2 else (lam, C, torch.zeros_like(verdict))
+    monkeypatch.setattr(type(hip_ops), 'eigh_top_deferred', first_iteration_only)
+    jacobi_after_one, trace_j = run()
+    assert n_direct_calls == 4 and len(calls) == 4          # two per iteration: the failed iteration finished its direct solves before the verdicts were read
+    for a, b in zip(retried, jacobi_after_one):
+        assert np.array_equal(a, b)
+    assert trace_retried == trace_j
+    # and the two routes agree to rounding (subspaces: the factors' projectors)
+    assert np.allclose(trace_direct, trace_retried, rtol=1e-10)
+    for a, b in zip(direct[:3], retried[:3]):
+        assert abs(a @ a.T - b @ b.T).max() < 1e-8
