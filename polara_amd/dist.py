@@ -22,19 +22,23 @@ import torch.distributed as dist
 class TorchComm:
     """Communicator interface used by solver.svd_topk and models (rank, world, allreduce, gather_rows)."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, exercise_collectives=False):
+        """exercise_collectives: issue every collective even in a group of ONE rank (the shortcuts below return the local
+        buffer instead).  A test switch: on a one-GPU box it is the only way to run the RCCL calls of this class — shapes,
+        dtypes, contiguity, in-place rules — against the real library (tests/test_gpu_dist.py)."""
         if not dist.is_initialized():
             raise RuntimeError('torch.distributed is not initialised; call init_from_env() first')
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+        self._always = bool(exercise_collectives)
         self.bytes_reduced = 0
         self.n_allreduce = 0
         self.bytes_gathered = self.bytes_scattered = 0
         self.n_allgather = self.n_reduce_scatter = 0
 
     def allreduce(self, t):
-        if self.world > 1:
+        if self.world > 1 or self._always:
             if t.is_cuda and dist.get_backend(self.group) == 'gloo':
                 # debugging aid: several ranks sharing one GPU cannot use RCCL; stage through the host
                 h = t.cpu()
@@ -49,7 +53,7 @@ class TorchComm:
     def all_gather_rows(self, local):
         """[rows x b] per rank -> [world*rows x b] on every rank, rank order = row order (the item-side blocks of the
         solver in front of an SpMM: `solver.ItemRows.full`)."""
-        if self.world == 1:
+        if self.world == 1 and not self._always:
             return local
         out = torch.empty((self.world * local.shape[0], local.shape[1]), dtype=local.dtype, device=local.device)
         if local.is_cuda and dist.get_backend(self.group) == 'gloo':
@@ -65,7 +69,7 @@ class TorchComm:
     def reduce_scatter_rows(self, full, rows):
         """sum over the ranks of [world*rows x b] blocks, rank r keeps rows [r*rows, (r+1)*rows) (`ItemRows.product`).
         RCCL: one reduce-scatter; gloo has none, so the CPU tests sum everything and slice."""
-        if self.world == 1:
+        if self.world == 1 and not self._always:
             return full
         assert full.shape[0] == self.world * rows and full.is_contiguous()
         if dist.get_backend(self.group) == 'nccl':
@@ -90,7 +94,7 @@ class TorchComm:
         travel in one small all-gather, the blocks — padded to the tallest — in one `all_gather_into_tensor`; typed
         buffers end to end (no pickling: a [n_users x topk] result is tens of MB to GB)."""
         local = np.ascontiguousarray(local, dtype=dtype).reshape(-1, width)
-        if self.world == 1:
+        if self.world == 1 and not self._always:
             assert local.shape == (n_total, width)
             return local
         dev = self._exchange_device()
@@ -109,7 +113,7 @@ class TorchComm:
         return out
 
     def barrier(self):
-        if self.world > 1:
+        if self.world > 1 or self._always:
             dist.barrier(group=self.group)
 
 

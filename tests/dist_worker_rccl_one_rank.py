@@ -1,0 +1,52 @@
+"""Worker for the one-GPU RCCL test: backend "nccl" (= RCCL) with a group of ONE rank and TorchComm's
+`exercise_collectives` switch, so that every collective of polara_amd/dist.py is actually issued to the library — the
+all-reduce of device buffers, `all_gather_into_tensor`, `reduce_scatter_tensor`, the typed result gather, the barrier — on
+the shapes the sharded solver uses, and the item-sharded solver itself runs through them.  With one rank every collective
+is the identity: results must equal the communicator-free run bit for bit."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+import numpy as np
+import torch
+
+from polara_amd.dist import init_from_env, TorchComm
+from polara_amd.ops import HipOps
+from polara_amd.solver import svd_topk
+from polara_amd.synth import planted_csr
+
+
+def main():
+    init_from_env()
+    assert torch.distributed.get_backend() == 'nccl' and torch.distributed.get_world_size() == 1
+    comm = TorchComm(exercise_collectives=True)
+    ops = HipOps('cuda:%d' % torch.cuda.current_device())
+    dev = ops.device
+    ok = {}
+    g = torch.Generator(device='cpu').manual_seed(1)
+    X = torch.randn(3001, 64, generator=g, dtype=torch.float64).to(dev)
+    ok['allreduce_f64'] = bool(torch.equal(comm.allreduce(X.clone()), X))
+    c = torch.arange(977, dtype=torch.int64, device=dev)
+    ok['allreduce_i64'] = bool(torch.equal(comm.allreduce(c.clone()), c))
+    ok['all_gather_rows'] = bool(torch.equal(comm.all_gather_rows(X), X))
+    ok['reduce_scatter_rows'] = bool(torch.equal(comm.reduce_scatter_rows(X.clone(), X.shape[0]), X))
+    recs = np.arange(500 * 10, dtype=np.int64).reshape(500, 10)
+    ok['gather_rows'] = bool(np.array_equal(comm.gather_rows(recs, 500, 10), recs))
+    comm.barrier()
+    # the item-sharded solver through those calls against the communicator-free run
+    csr = planted_csr(4000, 900, 30, rank=12, seed=5)
+    A = ops.csr(np.asarray(csr['indptr']), np.asarray(csr['indices']), np.asarray(csr['values']), csr['shape'])
+    _, s0, V0, st0 = svd_topk(ops, A, 10, seed=3)
+    n0 = comm.n_allreduce
+    _, s1, V1, st1 = svd_topk(ops, A, 10, seed=3, comm=comm)
+    ok['solver_sharded_layout_used'] = bool(st1['items_sharded']) and comm.n_allgather > 0 and comm.n_reduce_scatter > 0 and comm.n_allreduce > n0
+    ok['solver_same_bits'] = bool(torch.equal(s0, s1) and torch.equal(V0, V1)) and st0['gramian_steps'] == st1['gramian_steps']
+    print('RCCL_ONE_RANK_RESULT', ok, 'allgathers', comm.n_allgather, 'reduce_scatters', comm.n_reduce_scatter, 'allreduces', comm.n_allreduce)
+    assert all(ok.values()), ok
+
+
+if __name__ == '__main__':
+    main()

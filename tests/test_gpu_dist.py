@@ -59,3 +59,14 @@ def test_bench_under_torchrun_two_ranks_one_gpu():
     line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
     d = json.loads(line)
     assert d['n_gpus'] == 2 and d['value'] > 0 and d['scaling'] == 'strong' and d['build']['converged']
+
+
+def test_rccl_collectives_on_one_rank():
+    """The RCCL calls of polara_amd/dist.py issued for real on the one GPU this box has: backend "nccl", a group of one
+    rank, TorchComm(exercise_collectives=True) — all-reduce (fp64 blocks, int64 counts), all_gather_into_tensor,
+    reduce_scatter_tensor, the typed result gather, barrier — and the item-sharded solver through them, bit-equal to the
+    communicator-free run (tests/dist_worker_rccl_one_rank.py).  What it cannot show is more than one rank: that stays
+    with the two-GPU test above."""
+    r = _torchrun(os.path.join(ROOT, 'tests', 'dist_worker_rccl_one_rank.py'), 1, extra_env={'NCCL_DEBUG': 'VERSION'})
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert 'RCCL_ONE_RANK_RESULT' in r.stdout
