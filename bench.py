@@ -104,6 +104,38 @@ def parse():
     return ap.parse_args()
 
 
+def ensure_world(args):
+    """`--gpus N` means N ranks, one per GPU, over RCCL — whoever starts the script.  Under torchrun (WORLD_SIZE set) the
+    flag must agree with the launcher; started bare with N > 1 this process becomes the launcher: it checks that N GPUs
+    are visible (fails loudly otherwise — a silent one-GPU run would hand the driver a flat scaling curve) and re-executes
+    itself as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 …`, passing every
+    flag through; its exit code is the job's.  PK_BENCH_DEBUG_BACKEND=gloo (N ranks sharing ONE GPU, a path check, never
+    a number) lifts the GPU-count requirement."""
+    env_world = os.environ.get('WORLD_SIZE')
+    if env_world is not None:
+        if int(env_world) != int(args.gpus):
+            raise SystemExit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks; they must agree'
+                             % (args.gpus, env_world))
+        return
+    if args.gpus <= 1:
+        return
+    debug = os.environ.get('PK_BENCH_DEBUG_BACKEND')
+    visible = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if visible < args.gpus and not debug:
+        raise SystemExit('bench.py: --gpus %d needs %d visible GPUs (one rank per GPU over RCCL), this box shows %d; '
+                         'nothing was measured' % (args.gpus, args.gpus, visible))
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log('--gpus %d without a launcher: re-executing as %s' % (args.gpus, ' '.join(cmd[1:9])))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def spmm_alg_bytes(meta):
     n_rows, n_cols, nnz, nc, vbytes, xbytes = meta     # xbytes: element size of the dense input block
     return nnz * (4 + vbytes) + 8 * (n_rows + 1) + nc * (xbytes * n_cols + 8 * n_rows)
@@ -168,6 +200,16 @@ class Bench:
         from polara_amd.ops import HipOps
         self.dev = 'cuda:%d' % torch.cuda.current_device()
         self.ops = HipOps(self.dev)
+        self.dist_info = {'world': self.world, 'backend': 'none (one process)', 'device': torch.cuda.get_device_name(self.dev)}
+        if self.world > 1:
+            import torch.distributed as tdist
+            be = tdist.get_backend()
+            self.dist_info.update(world=tdist.get_world_size(), backend=be)
+            if be == 'nccl':
+                try:
+                    self.dist_info['rccl'] = '.'.join(str(x) for x in torch.cuda.nccl.version())
+                except Exception as exc:       # the version call is decoration; the collectives are not
+                    self.dist_info['rccl'] = 'unknown (%s)' % type(exc).__name__
         # The streams of the timed loop are taken NOW, one after the other: torch hands out streams from a pool of 32 that
         # HIP maps round-robin onto a handful of hardware queues (4 by default), so two streams created at unrelated
         # moments can share a queue — and then they do not overlap at all (a pass stream on the copy stream's queue cost
@@ -240,8 +282,13 @@ class Bench:
         _ = A.plan
         lap('transpose_and_plans_s')
         ops.timers = {}
+        counters = ('n_allgather', 'bytes_gathered', 'n_reduce_scatter', 'bytes_scattered', 'n_allreduce', 'bytes_reduced')
+        before = {k: getattr(comm, k, 0) for k in counters}
         _, sigma, V, bstats = svd_topk(ops, A, rank, comm=comm)
         lap('solver_s')
+        coll = {k: int(getattr(comm, k, 0) - before[k]) for k in counters}
+        shard = np.array([[comm.rank, hi - lo, int(c['indptr'][hi] - c['indptr'][lo]), torch.cuda.current_device()]], dtype=np.int64)
+        shards = comm.gather_rows(shard, comm.world, 4) if comm.world > 1 else shard
         spmm_ev = ops.timers.get('spmm', [])
         ops.timers = None
         if catalogue != 'svd':
@@ -267,7 +314,7 @@ class Bench:
         lap('reindex_and_images_s')
         t['total_s'] = marks[-1] - marks[0]
         state = dict(A=A_score, F=F, V=V, sigma=sigma, order2=order2, rank_of=rank_of, inv_order=inv_order, lo=lo, hi=hi,
-                     bstats=bstats, spmm_ev=spmm_ev)
+                     bstats=bstats, spmm_ev=spmm_ev, collectives=coll, shards=shards)
         del A
         return state, t
 
@@ -564,6 +611,14 @@ class Bench:
                           'two_phase': stats.get('two_phase'),
                           'n_tiles': -(-n_items // 32)},
             }
+            sh = np.asarray(st['shards'])
+            cl = st['collectives']
+            out['dist'] = dict(self.dist_info, users_per_rank=[int(x) for x in sh[:, 1]], nnz_per_rank=[int(x) for x in sh[:, 2]],
+                               device_of_rank=[int(x) for x in sh[:, 3]],
+                               build_collectives={'all_gather': cl['n_allgather'], 'reduce_scatter': cl['n_reduce_scatter'],
+                                                  'all_reduce': cl['n_allreduce'],
+                                                  'MB': (cl['bytes_gathered'] + cl['bytes_scattered'] + cl['bytes_reduced']) / 1e6},
+                               scoring_collectives=0)
             if catalogue == 'flat':
                 out['workload'] += '; item-factor rows scaled to unit norm (flat-norm catalogue: the pruning bound never fires)'
             elif catalogue == 'pop25':
@@ -822,6 +877,9 @@ def compact_line(head, n_gpus, steps, warmup, adversarial=None, scale=1.0):
         cfg['scale'] = scale
     if adversarial:
         cfg['adversarial_users_per_s'] = {k: _r(v) for k, v in adversarial.items()}
+    r100 = head.get('rank100_top20')
+    if r100:
+        cfg['configs2_rank100_top20'] = {k: _r(v) for k, v in r100.items()}
     out = {'metric': 'users scored/sec + SVD build time, ML-20M rank-50 PureSVD', 'value': _r(head['value'], 6), 'unit': 'users/s',
            'n_gpus': n_gpus, 'steps': steps, 'warmup': warmup, 'ms_per_step': _r(head['ms_per_step'], 5),
            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'bf16x3',
@@ -830,6 +888,12 @@ def compact_line(head, n_gpus, steps, warmup, adversarial=None, scale=1.0):
            'ms_per_step_long_region': _r(head.get('ms_per_step_long_region'))}
     b = head.get('build', {})
     out['build'] = {k: _r(b.get(k)) for k in ('solver_s', 'gramian_steps', 'converged', 'spmm_ms') if k in b}
+    di = head.get('dist')
+    if di:
+        bc = di.get('build_collectives', {})
+        out['dist'] = {'world': di.get('world'), 'backend': di.get('backend'), 'rccl': di.get('rccl'),
+                       'users_per_rank': di.get('users_per_rank'), 'nnz_per_rank': di.get('nnz_per_rank'),
+                       'build_collectives': {k: _r(v) for k, v in bc.items()}, 'scoring_collectives': di.get('scoring_collectives')}
     rf = head.get('roofline')
     if rf:
         out['roofline'] = {k: (_r(rf.get(k)) if not isinstance(rf.get(k), str) else rf.get(k)) for k in
@@ -850,7 +914,7 @@ def compact_line(head, n_gpus, steps, warmup, adversarial=None, scale=1.0):
             'speedup_build': _r(cb.get('speedup_build')), 'speedup': _r(cb.get('speedup_build_plus_score'))}
     line = json.dumps(out, separators=(',', ':'))
     if len(line) > MAX_LINE_BYTES:        # never again an unparseable record: drop the optional blocks, loudest last
-        for k in ('build', 'roofline_build', 'latency_ms_per_pass'):
+        for k in ('build', 'roofline_build', 'latency_ms_per_pass', 'dist'):
             out.pop(k, None)
             line = json.dumps(out, separators=(',', ':'))
             if len(line) <= MAX_LINE_BYTES:
@@ -874,6 +938,7 @@ def write_detail(record):
 
 def main():
     args = parse()
+    ensure_world(args)
     B = Bench(args)
     comm = B.comm
     headline_rank = args.rank or {'ml20m': 50, 's1m': 50, 'ml1m': 10}[args.workload]
@@ -889,6 +954,16 @@ def main():
                      norm_order=not args.no_norm_order, cpu=not args.no_cpu_baseline, cpu_users=args.cpu_users,
                      cold_build=cold, cpu_build_whole=full_size and args.workload in ('ml20m', 'ml1m'))
     subs, adversarial = {}, {}
+    if args.scale == 1.0 and not args.only_headline and args.workload == 'ml20m' and not args.rank:
+        # BASELINE.json configs[2] as written (rank 100, top-20) rides in the line at every N next to the metric's rank 50
+        s = B.measure(c, 'ml20m', 100, 20, max(5, min(args.steps, 20)), 2, cpu=not args.no_cpu_baseline, cpu_users=5000,
+                      cpu_build=False)
+        if comm.rank == 0:
+            subs['configs2_ml20m_rank100_top20'] = s
+            head['rank100_top20'] = {'users_per_s': s['value'], 'ms_per_step': s['ms_per_step'], 'build_s': s['build_s'],
+                                     'gramian_steps': s['build']['gramian_steps']}
+            if 'cpu_baseline' in s:
+                head['rank100_top20']['identical_rows'] = s['cpu_baseline'].get('gpu_vs_cpu_identical_rows')
     if full_size and not args.only_headline and args.workload == 'ml20m':
         # the headline depends on how fast the item-factor norms decay (the sweep is pruned by a norm bound): the same
         # matrix with three less friendly catalogues ALWAYS runs next to it and rides in the compact line
@@ -905,9 +980,6 @@ def main():
         mp, _ = B.model_path(c, headline_rank, headline_topk)
         subs['model_path'] = mp
         subs['coarse_c_abi'] = coarse_c_path(B, c, headline_rank, headline_topk)
-        # BASELINE.json configs[2]: rank 100, top-20
-        s = B.measure(c, 'ml20m', 100, 20, sub_steps, 2, cpu=not args.no_cpu_baseline, cpu_users=5000, cpu_build=False)
-        subs['configs2_ml20m_rank100_top20'] = s
         del c
         gc.collect()
         # BASELINE.json configs[1]

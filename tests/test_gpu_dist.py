@@ -70,3 +70,28 @@ def test_rccl_collectives_on_one_rank():
     r = _torchrun(os.path.join(ROOT, 'tests', 'dist_worker_rccl_one_rank.py'), 1, extra_env={'NCCL_DEBUG': 'VERSION'})
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert 'RCCL_ONE_RANK_RESULT' in r.stdout
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher.  Under the debug backend (two ranks sharing the one
+    GPU) it re-executes itself under torch.distributed.run and the line says n_gpus = 2 with the per-rank shards and the
+    build's collective counts; without the debug backend on a box with fewer than two GPUs it exits non-zero with a
+    message — it never again measures one GPU under an N-GPU flag."""
+    import json
+    import torch
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', PK_BENCH_DEBUG_BACKEND='gloo')
+    env.pop('WORLD_SIZE', None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--scale', '0.1',
+                        '--no-cpu-baseline'], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert d['n_gpus'] == 2 and d['dist']['world'] == 2 and d['dist']['backend'] == 'gloo'
+    assert len(d['dist']['users_per_rank']) == 2 and sum(d['dist']['users_per_rank']) == d['config']['n_users']
+    bc = d['dist']['build_collectives']
+    assert bc['reduce_scatter'] == d['build']['gramian_steps'] and bc['all_gather'] >= bc['reduce_scatter'] and bc['MB'] > 0
+    assert d['dist']['scoring_collectives'] == 0
+    if torch.cuda.device_count() < 2:
+        env.pop('PK_BENCH_DEBUG_BACKEND')
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--scale', '0.1'],
+                           capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode != 0 and 'needs 2 visible GPUs' in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith('{')]

@@ -439,8 +439,55 @@ def test_bench_compact_line_is_small_and_parses():
     assert long_text[:300] not in line
     # a multi-GPU line (no cpu_baseline, no adversarial rows) has the same shape
     head2 = {k: v for k, v in head.items() if k != 'cpu_baseline'}
-    d2 = json.loads(bench.compact_line(head2, 8, 20, 5, None, scale=1.0))
+    head2['dist'] = {'world': 8, 'backend': 'nccl', 'rccl': '2.26.6', 'device': 'AMD Instinct MI355X ' + long_text,
+                     'users_per_rank': [17312] * 8, 'nnz_per_rank': [2500033] * 8, 'device_of_rank': list(range(8)),
+                     'build_collectives': {'all_gather': 37, 'reduce_scatter': 37, 'all_reduce': 90, 'MB': 1013.123456},
+                     'scoring_collectives': 0}
+    head2['rank100_top20'] = {'users_per_s': 82.6e6, 'ms_per_step': 1.68, 'build_s': 0.135, 'gramian_steps': 52}
+    line2 = bench.compact_line(head2, 8, 20, 5, None, scale=1.0)
+    assert len(line2) < 3000 and long_text[:300] not in line2
+    d2 = json.loads(line2)
     assert d2['n_gpus'] == 8 and 'cpu_baseline' not in d2 and 'users sharded over 8' in d2['config']['parallelism']
+    assert d2['scaling'] == 'strong' and d2['dist']['world'] == 8 and d2['dist']['backend'] == 'nccl' and d2['dist']['rccl']
+    assert len(d2['dist']['users_per_rank']) == 8 and d2['dist']['build_collectives']['reduce_scatter'] == 37
+    assert d2['dist']['scoring_collectives'] == 0 and d2['config']['configs2_rank100_top20']['users_per_s'] == 82.6e6
+
+
+def test_bench_gpus_flag_launches_ranks_or_fails_loudly(monkeypatch):
+    """`--gpus N` was parsed and never read.  Started bare with N > 1 bench.py re-executes itself under
+    torch.distributed.run with N ranks; on a box with fewer GPUs it exits with a message instead of measuring one GPU;
+    under a launcher whose WORLD_SIZE disagrees with the flag it refuses."""
+    import argparse
+    import subprocess
+    import bench
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    monkeypatch.delenv('PK_BENCH_DEBUG_BACKEND', raising=False)
+    assert bench.ensure_world(argparse.Namespace(gpus=1)) is None
+    with pytest.raises(SystemExit) as e:          # this container has no GPU at all
+        bench.ensure_world(argparse.Namespace(gpus=2))
+    assert 'needs 2 visible GPUs' in str(e.value)
+    monkeypatch.setenv('WORLD_SIZE', '4')
+    with pytest.raises(SystemExit) as e:
+        bench.ensure_world(argparse.Namespace(gpus=8))
+    assert 'must agree' in str(e.value)
+    assert bench.ensure_world(argparse.Namespace(gpus=4)) is None
+    # the re-exec itself: the command line is torchrun's, every flag passed through, the child's exit code returned
+    monkeypatch.delenv('WORLD_SIZE')
+    monkeypatch.setenv('PK_BENCH_DEBUG_BACKEND', 'gloo')
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen['cmd'], seen['env'] = cmd, env
+        return 7
+    monkeypatch.setattr(subprocess, 'call', fake_call)
+    monkeypatch.setattr(bench.sys, 'argv', ['bench.py', '--gpus', '2', '--steps', '3'])
+    with pytest.raises(SystemExit) as e:
+        bench.ensure_world(argparse.Namespace(gpus=2))
+    assert e.value.code == 7
+    cmd = seen['cmd']
+    assert cmd[1:3] == ['-m', 'torch.distributed.run'] and '--nproc-per-node' in cmd and cmd[cmd.index('--nproc-per-node') + 1] == '2'
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and cmd[-4:] == ['--gpus', '2', '--steps', '3']
+    assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
 
 
 def test_training_rows_shortcut_builds_the_protocol_test_matrix():
