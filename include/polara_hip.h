@@ -174,6 +174,10 @@ int pk_tsmm_f64(void *stream, int64_t n, int32_t lin, int32_t lout, const double
  * info_dev[0] = sweeps used, info_dev[1] = 1 if converged.  n <= 1024. */
 int pk_eigh_psd_f64(void *stream, int32_t n, double *S_dev, int64_t lds_, double *evecs_dev, int64_t ldv,
                     double *evals_dev, int32_t max_sweeps, double tol, int32_t *info_dev);
+/* Same solve; beyond 136 columns (block Jacobi) every round is a launch of its own instead of ONE cooperative launch with
+ * grid barriers: the form to re-run when pk_eigh_psd_f64 reports info_dev[1] = 0 there (a barrier that did not complete). */
+int pk_eigh_psd_rounds_f64(void *stream, int32_t n, double *S_dev, int64_t lds_, double *evecs_dev, int64_t ldv,
+                           double *evals_dev, int32_t max_sweeps, double tol, int32_t *info_dev);
 /* The r LEADING eigenpairs of a symmetric PSD matrix in one launch (Householder tridiagonalisation, Sturm-count
  * multisection, inverse iteration, back-transformation; csrc/eigh_top.hip) — what the HOOI unfoldings need of their Gram
  * matrices (the k = r of `svds(unfolding, k=r)`, lib/tensor.py:70-80).  S (n x n) is read only; evals[0..r) descending,
@@ -351,7 +355,7 @@ int pk_rescore_topk_rows_f64(void *stream, int64_t n_rows, const int32_t *rows_d
 /* The same, and the users it flags are appended to a device-side list while it runs: flagged_list_dev[old *count ...] =
  * flagged_offset + user for every user whose flag is not 0 (order arbitrary), *flagged_count_dev advanced by an atomic —
  * what pk_flag_compact(mask = all) makes of the flags afterwards, without its two launches.  The counter is NOT zeroed
- * here (several calls may append to one list: user batches): pk_zero_i32 (n <= 4096 counters, a kernel) first.
+ * here (several calls may append to one list: user batches): pk_zero_i32 (n <= 2^20 counters, a kernel) first.
  * list / count both NULL: plain pk_rescore_topk_rows_f64. */
 int pk_rescore_topk_rows_list_f64(void *stream, int64_t n_rows, const int32_t *rows_dev,
                              const int32_t *n_rows_dev /* or NULL; else the list length is min(*n_rows_dev, n_rows) */,

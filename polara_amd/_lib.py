@@ -45,6 +45,7 @@ PROTOTYPES = {
     'pk_gram_f64': (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     'pk_tsmm_f64': (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64]),
     'pk_eigh_psd_f64': (C.c_int, [_vp, _i32, _vp, _i64, _vp, _i64, _vp, _i32, _f64, _vp]),
+    'pk_eigh_psd_rounds_f64': (C.c_int, [_vp, _i32, _vp, _i64, _vp, _i64, _vp, _i32, _f64, _vp]),
     'pk_eigh_top_supported': (C.c_int, [_i32, _i32]),
     'pk_eigh_top_work_bytes': (_i64, [_i32]),
     'pk_eigh_top_f64': (C.c_int, [_vp, _i32, _vp, _i64, _i32, _vp, _i64, _vp, _vp, _vp]),

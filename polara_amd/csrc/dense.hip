@@ -410,8 +410,8 @@ extern "C" int pk_chol_rinv_f64(void *stream, int32_t n, const double *G_dev, in
                                 double *Rinv_dev, int64_t ldr, void *work_dev, int32_t *info_dev) {
     PK_REQUIRE(n >= 1 && n <= 1024 && ldg >= n && ldr >= n, "pk_chol_rinv_f64: bad sizes");
     PK_REQUIRE(G_dev && Rinv_dev && info_dev && (n <= PK_CHOL_LDS_MAX || work_dev), "pk_chol_rinv_f64: bad pointers");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PkDeviceOnce attr_set;   
+    if (attr_set.pending()) {
         hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&chol_rinv_kernel<true>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize,
                                             PK_CHOL_LDS_MAX * (PK_CHOL_LDS_MAX + 1) * 8);
@@ -419,7 +419,7 @@ extern "C" int pk_chol_rinv_f64(void *stream, int32_t n, const double *G_dev, in
             pk_set_error("pk_chol_rinv_f64: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e1));
             return PK_E_LAUNCH;
         }
-        attr_set = true;
+        attr_set.done();   
     }
     int tx_log2 = 4;                                 // columns of the thread grid: the power of two >= n, 16 ... 256
     while ((1 << tx_log2) < n && tx_log2 < 8) ++tx_log2;

@@ -358,6 +358,18 @@ struct Solver {
         if (!lam_dev.alloc((size_t)n * 8) || !W.ok() || !R.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (eigh)");
         HIPCK(hipMemcpyAsync(W.p(), S.p(), (size_t)n * n * 8, hipMemcpyDeviceToDevice, st));
         CK(pk_eigh_psd_f64(st, n, W.p(), n, R.p(), n, lam_dev.as<double>(), 0, 0.0, info.as<int32_t>()));
+        if (n > 136) {
+            // block Jacobi (one cooperative launch with grid barriers): a verdict of 0 — a barrier that did not complete,
+            // or sweeps that ran out — must not hand half-rotated vectors on: re-do launch by launch
+            int32_t verdict[2] = {0, 0};
+            CK(to_host(info.p, verdict, sizeof verdict));
+            if (verdict[1] == 0) {
+                HIPCK(hipMemcpyAsync(W.p(), S.p(), (size_t)n * n * 8, hipMemcpyDeviceToDevice, st));
+                CK(pk_eigh_psd_rounds_f64(st, n, W.p(), n, R.p(), n, lam_dev.as<double>(), 0, 0.0, info.as<int32_t>()));
+                CK(to_host(info.p, verdict, sizeof verdict));
+                if (verdict[1] == 0) return fail(ctx, PK_E_LAUNCH, "eigh: the block Jacobi sweeps did not converge (n=%d)", n);
+            }
+        }
         C = DMat(n, n);
         hipLaunchKernelGGL(transpose_small_kernel, dim3((unsigned)((n * n + 255) / 256)), dim3(256), 0, st, n, R.p(), C.p());
         lam.resize((size_t)n);

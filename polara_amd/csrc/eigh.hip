@@ -536,9 +536,9 @@ __global__ void eigh_block_info_kernel(const int *counters, int max_sweeps, cons
     info[1] = (s < max_sweeps) && bar[1] == 0;      // bar[1]: a grid barrier of the persistent kernel timed out
 }
 
-extern "C" int pk_eigh_psd_f64(void *stream, int32_t n, double *S_dev, int64_t lds_, double *evecs_dev,
-                               int64_t ldv, double *evals_dev, int32_t max_sweeps, double tol,
-                               int32_t *info_dev) {
+static int eigh_psd_impl(void *stream, int32_t n, double *S_dev, int64_t lds_, double *evecs_dev,
+                         int64_t ldv, double *evals_dev, int32_t max_sweeps, double tol,
+                         int32_t *info_dev, int persistent) {
     PK_REQUIRE(n >= 1 && n <= 1024, "pk_eigh_psd_f64: n=%d out of range [1,1024]", n);
     PK_REQUIRE(lds_ >= n && ldv >= n, "pk_eigh_psd_f64: bad leading dimension");
     PK_REQUIRE(S_dev && evecs_dev && evals_dev && S_dev != evecs_dev, "pk_eigh_psd_f64: bad pointers");
@@ -553,8 +553,8 @@ extern "C" int pk_eigh_psd_f64(void *stream, int32_t n, double *S_dev, int64_t l
         kern_t kern = n <= 32 ? eigh_psd_kernel<true, 2> : n <= 64 ? eigh_psd_kernel<true, 4>
                     : n <= 96 ? eigh_psd_kernel<true, 6> : n <= 128 ? eigh_psd_kernel<true, 8> : eigh_psd_kernel<true, 9>;
         const int slot = n <= 32 ? 0 : n <= 64 ? 1 : n <= 96 ? 2 : n <= 128 ? 3 : 4;
-        static bool attr_set[5] = {false, false, false, false, false};
-        if (!attr_set[slot]) {
+        (void)slot;
+        {   // per call: the attribute is per DEVICE and the coarse ABI may hold contexts on several; it is cheap
             hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                                 EIGH_LDS_MAX * EIGH_LDS_MAX * 8);
@@ -562,7 +562,6 @@ extern "C" int pk_eigh_psd_f64(void *stream, int32_t n, double *S_dev, int64_t l
                 pk_set_error("pk_eigh_psd_f64: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e1));
                 return PK_E_LAUNCH;
             }
-            attr_set[slot] = true;
         }
         hipLaunchKernelGGL(kern, dim3(1), dim3(EIGH_THREADS), (size_t)n * n * sizeof(double),
                            st, n, S_dev, lds_, evecs_dev, ldv, evals_dev, max_sweeps, tol, info_dev, precondition,
@@ -580,15 +579,14 @@ extern "C" int pk_eigh_psd_f64(void *stream, int32_t n, double *S_dev, int64_t l
     using round_t = void (*)(int, double *, int64_t, int, int, int, int, int *, double);
     round_t round_kern = n <= 160 ? eigh_block_round_kernel<10> : n <= 256 ? eigh_block_round_kernel<16> : eigh_block_round_kernel<0>;
     const int slot_b = n <= 160 ? 0 : n <= 256 ? 1 : 2;
-    static bool attr_set_b[3] = {false, false, false};
-    if (!attr_set_b[slot_b]) {
+    (void)slot_b;
+    {
         hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(round_kern),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, EIGH_BLOCK_LDS);
         if (e1 != hipSuccess) {
             pk_set_error("pk_eigh_psd_f64: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e1));
             return PK_E_LAUNCH;
         }
-        attr_set_b[slot_b] = true;
     }
     if (max_sweeps > 30) max_sweeps = 30;
     // the rotation counters of the outer sweeps live in evals_dev until the final pass writes the eigenvalues there
@@ -600,22 +598,30 @@ extern "C" int pk_eigh_psd_f64(void *stream, int32_t n, double *S_dev, int64_t l
     if (precondition)
         hipLaunchKernelGGL(eigh_chol_global_kernel, dim3(1), dim3(EIGH_THREADS), 0, st, n, S_dev, lds_, evecs_dev, ldv, chol_flag);
     const char *pers_env = getenv("PK_EIGH_PERSISTENT");   // 0: one launch per (sweep, round), the round-2 form
-    if (pers_env == nullptr || atoi(pers_env) != 0) {
+    bool launched = false;
+    if (persistent && (pers_env == nullptr || atoi(pers_env) != 0)) {
         using pers_t = void (*)(int, double *, int64_t, int, int, int, int *, double, int *);
         pers_t pers_kern = n <= 160 ? eigh_block_persistent_kernel<10> : n <= 256 ? eigh_block_persistent_kernel<16> : eigh_block_persistent_kernel<0>;
-        static bool attr_set_p[3] = {false, false, false};
-        if (!attr_set_p[slot_b]) {
-            hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(pers_kern),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, EIGH_BLOCK_LDS);
-            if (e1 != hipSuccess) {
-                pk_set_error("pk_eigh_psd_f64: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e1));
-                return PK_E_LAUNCH;
-            }
-            attr_set_p[slot_b] = true;
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(pers_kern),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, EIGH_BLOCK_LDS);
+        if (e1 != hipSuccess) {
+            pk_set_error("pk_eigh_psd_f64: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e1));
+            return PK_E_LAUNCH;
         }
-        hipLaunchKernelGGL(pers_kern, dim3(nb / 2), dim3(EIGH_THREADS), lds_bytes, st, n, S_dev, lds_, w, nb, max_sweeps, counters,
-                           tol, bar);
-    } else {
+        // The kernel synchronises its nb / 2 workgroups with a grid barrier, so they must be CO-RESIDENT: a cooperative
+        // launch is the runtime's guarantee of that (a plain launch next to other streams' kernels has none,
+        // and a workgroup that is not resident turns the bounded spin into half-rotated vectors).  Where the runtime
+        // refuses the cooperative launch the solve takes the launch-per-round form below — stream order is its barrier.
+        int n_arg = n, w_arg = w, nb_arg = nb, ms_arg = max_sweeps;
+        int64_t ld_arg = lds_;
+        double tol_arg = tol;
+        void *args[] = {&n_arg, &S_dev, &ld_arg, &w_arg, &nb_arg, &ms_arg, &counters, &tol_arg, &bar};
+        hipError_t ce = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(pers_kern), dim3(nb / 2), dim3(EIGH_THREADS),
+                                                   args, (unsigned int)lds_bytes, st);
+        if (ce == hipSuccess) launched = true;
+        else (void)hipGetLastError();
+    }
+    if (!launched) {
         for (int sweep = 0; sweep < max_sweeps; ++sweep)
             for (int round = 0; round < nb - 1; ++round)
                 hipLaunchKernelGGL(round_kern, dim3(nb / 2), dim3(EIGH_THREADS), lds_bytes, st, n, S_dev, lds_, w, nb,
@@ -627,4 +633,18 @@ extern "C" int pk_eigh_psd_f64(void *stream, int32_t n, double *S_dev, int64_t l
                        0, tol, (int *)nullptr, 0, (const int *)chol_flag);
     PK_CHECK_LAUNCH("eigh block kernels");
     return PK_OK;
+}
+
+extern "C" int pk_eigh_psd_f64(void *stream, int32_t n, double *S_dev, int64_t lds_, double *evecs_dev,
+                               int64_t ldv, double *evals_dev, int32_t max_sweeps, double tol,
+                               int32_t *info_dev) {
+    return eigh_psd_impl(stream, n, S_dev, lds_, evecs_dev, ldv, evals_dev, max_sweeps, tol, info_dev, 1);
+}
+
+// The same solve with one launch per (sweep, round) beyond 136 columns — no grid barrier anywhere: what a caller re-runs
+// when the persistent form reports info[1] = 0 (identical below 137 columns, where one workgroup does everything).
+extern "C" int pk_eigh_psd_rounds_f64(void *stream, int32_t n, double *S_dev, int64_t lds_, double *evecs_dev,
+                                      int64_t ldv, double *evals_dev, int32_t max_sweeps, double tol,
+                                      int32_t *info_dev) {
+    return eigh_psd_impl(stream, n, S_dev, lds_, evecs_dev, ldv, evals_dev, max_sweeps, tol, info_dev, 0);
 }

@@ -616,15 +616,13 @@ extern "C" int pk_eigh_top_f64(void *stream, int32_t n, const double *S_dev, int
     PK_REQUIRE(pk_eigh_top_supported(n, r), "pk_eigh_top_f64: n=%d, r=%d outside [%d, %d] x [1, %d]", n, r, ETOP_NMIN, ETOP_NMAX, ETOP_RMAX);
     PK_REQUIRE(lds_ >= n && ldv >= n, "pk_eigh_top_f64: bad leading dimension");
     PK_REQUIRE(S_dev && evecs_dev && evals_dev && work_dev && info_dev, "pk_eigh_top_f64: bad pointers");
-    static bool attr_set = false;
-    if (!attr_set) {
+    {   // per call: the limit is a per-DEVICE attribute (several contexts on different GPUs in one process)
         hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(eigh_top_kernel),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)etop_lds_bytes(ETOP_NMAX));
         if (e1 != hipSuccess) {
             pk_set_error("pk_eigh_top_f64: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e1));
             return PK_E_LAUNCH;
         }
-        attr_set = true;
     }
     hipLaunchKernelGGL(eigh_top_kernel, dim3(1), dim3(ETOP_THREADS), etop_lds_bytes(n), pk_stream(stream), n, S_dev, lds_, r,
                        evecs_dev, ldv, evals_dev, reinterpret_cast<double *>(work_dev), info_dev);

@@ -675,15 +675,13 @@ extern "C" int pk_count_i32(void *stream, int64_t n, const int32_t *keys_dev, in
     if (n == 0) return PK_OK;
     PK_REQUIRE(keys_dev, "pk_count_i32: null keys");
     if (n >= 4096 && n_bins <= (int64_t)64 * PK_COUNT_LDS_BINS) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        {   // per call: the limit is a per-DEVICE attribute (several contexts on different GPUs in one process)
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&count_i32_lds_kernel),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, PK_COUNT_LDS_BINS * 4);
             if (e != hipSuccess) {
                 pk_set_error("pk_count_i32: cannot raise the LDS limit: %s", hipGetErrorString(e));
                 return PK_E_LAUNCH;
             }
-            attr_set = true;
         }
         int64_t blocks = pk_ceil_div(n, 65536);
         if (blocks > 64) blocks = 64;

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
 #include "../../include/polara_hip.h"
 
 #define PK_WAVE 64
@@ -30,6 +31,20 @@ void pk_set_error(const char *fmt, ...);
 static inline hipStream_t pk_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 static inline int64_t pk_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- "done once" flags for PER-DEVICE function attributes (hipFuncSetAttribute raises the dynamic-LDS limit of a kernel
+// on the CURRENT device only; the coarse ABI allows contexts on several devices in one process).  One bit per device
+// ordinal; two threads racing on the first call both set the attribute, which is idempotent.
+struct PkDeviceOnce {
+    std::atomic<uint64_t> mask{0};
+    uint64_t bit() const {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        return 1ull << (d & 63);
+    }
+    bool pending() const { return (mask.load(std::memory_order_acquire) & bit()) == 0; }
+    void done() { mask.fetch_or(bit(), std::memory_order_release); }
+};
 
 // ---- wave-level reductions (64 lanes) -----------------------------------------------------
 __device__ __forceinline__ double pk_wave_sum(double v) {

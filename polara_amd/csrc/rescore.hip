@@ -402,9 +402,10 @@ __global__ void zero_i32_kernel(int32_t *p) { *p = 0; }
 __global__ void zero_i32_n_kernel(int32_t *p, int n) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0;
 }
-// zeroes n (<= 4096) device counters with a kernel (not a memset node: see pk_flag_compact)
+// zeroes n device counters with a kernel (not a memset node: see pk_flag_compact); one workgroup loops over them — a
+// handful per pass, a few thousand when a caller asks for that many user batches
 extern "C" int pk_zero_i32(void *stream, int32_t *p_dev, int32_t n) {
-    PK_REQUIRE(p_dev && n >= 1 && n <= 4096, "pk_zero_i32: bad arguments");
+    PK_REQUIRE(p_dev && n >= 1 && n <= (1 << 20), "pk_zero_i32: bad arguments");
     hipLaunchKernelGGL(zero_i32_n_kernel, dim3(1), dim3(64), 0, pk_stream(stream), p_dev, n);
     PK_CHECK_LAUNCH("zero_i32_n_kernel");
     return PK_OK;

@@ -1365,8 +1365,8 @@ static int launch_candidates_n(hipStream_t st, int KC, int ablate, dim3 grid, co
     for (int chunk_begin = 0; chunk_begin < split_tiles; chunk_begin += chunk_tiles, chunk_tiles = (user_bound ? 2 * chunk_tiles : chunk_tiles)) {
 #define PK_LAUNCH(KCV)                                                                                          \
     if (pk_score_lds_bytes(NSTEP, KCV) > 64 * 1024) {                                                           \
-        static bool attr_set = false;   /* one flag per (NSTEP, KC) instance of this macro expansion */        \
-        if (!attr_set) {                                                                                        \
+        static PkDeviceOnce attr_set;      /* one flag per (NSTEP, KC) instance of this macro expansion */        \
+        if (attr_set.pending()) {                                                                                        \
             hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&score_candidates_kernel<NSTEP, KCV, false, false>), \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize,                     \
                                                 (int)pk_score_lds_bytes(NSTEP, KCV));                           \
@@ -1378,20 +1378,20 @@ static int launch_candidates_n(hipStream_t st, int KC, int ablate, dim3 grid, co
                 pk_set_error("pk_score_candidates_f32: cannot raise the LDS limit: %s", hipGetErrorString(e1)); \
                 return PK_E_LAUNCH;                                                                             \
             }                                                                                                   \
-            attr_set = true;                                                                                    \
+            attr_set.done();                                                                                       \
         }                                                                                                       \
     }                                                                                                           \
     if constexpr (pk_shared_ok(NSTEP, KCV)) {                                                                   \
         if (ph.shared && grid.y == 1 && ph.floor_state == nullptr) {                                            \
-            static bool attr_set_s = false;                                                                     \
-            if (!attr_set_s) {                                                                                  \
+            static PkDeviceOnce attr_set_s;                                                                        \
+            if (attr_set_s.pending()) {                                                                                  \
                 hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(&score_candidates_kernel<NSTEP, KCV, false, DENSE_OK, true>), \
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)pk_score_lds_bytes_shared(NSTEP, KCV)); \
                 if (e2 != hipSuccess) {                                                                         \
                     pk_set_error("pk_score_candidates_f32: cannot raise the LDS limit (shared): %s", hipGetErrorString(e2)); \
                     return PK_E_LAUNCH;                                                                         \
                 }                                                                                               \
-                attr_set_s = true;                                                                              \
+                attr_set_s.done();                                                                                 \
             }                                                                                                   \
             hipLaunchKernelGGL((score_candidates_kernel<NSTEP, KCV, false, DENSE_OK, true>), dim3((grid.x * 4 + pk_shared_waves(KCV) - 1) / pk_shared_waves(KCV)), dim3(64 * pk_shared_waves(KCV)), \
                                pk_score_lds_bytes_shared(NSTEP, KCV), st, Vp, Ep, n_users,                      \

@@ -42,10 +42,27 @@ class ArrayData:
     (warm_start=False: the testset is recovered from the training rows of the holdout users,
     data.py:820-832).  holdout: triplets hidden from the model (consumed by evaluation only)."""
 
+    @staticmethod
+    def _frozen(u, i, f):
+        """The stored columns: arrays that already have the working types are ALIASED, not copied (480 MB at 2e7 entries).
+        The contract: the caller does not write to them afterwards — cached level sets, test-user counts and
+        device images would go stale with no change event.  The stored views are marked read-only, so a write through
+        `data.training` / `data.test` raises; a write through the caller's own reference cannot be caught — call
+        `set_training_data` / `set_test_data` with the new arrays instead."""
+        out = []
+        for a, dt in ((u, np.int64), (i, np.int64), (f, np.float64)):
+            a = np.asarray(a)
+            v = a.astype(dt, copy=False)
+            if v is a or v.base is not None:
+                v = v.view()
+            v.setflags(write=False)
+            out.append(v)
+        return Triplets(*out)
+
     def __init__(self, training, n_users=None, n_items=None, test=None, holdout=None, warm_start=False,
                  fields=('userid', 'itemid', 'rating'), holdout_size=None):
         u, i, f = (np.asarray(a) for a in training)
-        self._train = Triplets(u.astype(np.int64, copy=False), i.astype(np.int64, copy=False), np.asarray(f, dtype=np.float64))   # no copies of arrays that already have the working types
+        self._train = self._frozen(u, i, f)
         self.n_users = int(n_users if n_users is not None else u.max() + 1)
         self.n_items = int(n_items if n_items is not None else i.max() + 1)
         self.fields = Fields(*fields)
@@ -80,7 +97,7 @@ class ArrayData:
 
     def set_training_data(self, training):
         u, i, f = (np.asarray(a) for a in training)
-        self._train = Triplets(u.astype(np.int64, copy=False), i.astype(np.int64, copy=False), np.asarray(f, dtype=np.float64))   # no copies of arrays that already have the working types
+        self._train = self._frozen(u, i, f)
         self._feedback_levels = None
         self._notify(self.on_change_event)
 
@@ -91,7 +108,7 @@ class ArrayData:
             u, i, f = (np.asarray(a) for a in t)
             if len(u) < 2 or bool((u[1:] >= u[:-1]).all()):
                 # already sorted by user (the usual case): a stable sort would be the identity — no order array, no gathers
-                return Triplets(u.astype(np.int64, copy=False), i.astype(np.int64, copy=False), np.asarray(f, dtype=np.float64))
+                return self._frozen(u, i, f)
             order = np.argsort(u, kind='stable')  # data.py `_try_sort_test_data`
             return Triplets(u[order].astype(np.int64), i[order].astype(np.int64),
                             np.asarray(f, dtype=np.float64)[order])

@@ -10,6 +10,7 @@ without the library or a GPU raises.
 from timeit import default_timer as timer
 
 import numpy as np
+import torch
 
 from . import defaults
 from .operator import DeviceChain, HostOperator, SparseProduct
@@ -902,11 +903,15 @@ class CoffeeModel(RecommenderModel):
             # our own data object: the three columns go up as they lie; feedback levels, item counts and the renaming
             # into the internal item order are device passes (no stacked index, no host pass over the entries)
             u, i, f, levels, shp = self.data.tensor_triplets()
-            i0, i1, i2 = tucker.device_coordinates(ops, u, i, f, levels)
+            i0, i1, i2, bad = tucker.device_coordinates(ops, u, i, f, levels)
             counts = ops.bincount(i1, shp[1])
             if presharded and comm.world > 1:
                 counts = comm.allreduce(counts)
-            self._item_rank, self._item_inv = popularity_order(None, shp[1], counts=ops.to_host(counts))
+            counts_bad = ops.to_host(torch.cat([counts.to(torch.int64), bad.reshape(1)]))     # one host read for both
+            if int(counts_bad[-1]):
+                raise ValueError('Not all values of feedback are present in the feedback levels of the training data '
+                                 '(%d entries)' % int(counts_bad[-1]))
+            self._item_rank, self._item_inv = popularity_order(None, shp[1], counts=counts_bad[:-1])
             idx, val = (i0, ops.to_device(np.asarray(self._item_rank, dtype=np.int64))[i1], i2), None
         else:
             idx, val, shp = self.data.to_coo(tensor_mode=True)

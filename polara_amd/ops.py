@@ -604,8 +604,20 @@ class HipOps:
         W = S.clone().contiguous()
         R = self.empty(n, n)
         lam = self.empty(n)
+        info = self._info if n <= 136 else torch.zeros(2, dtype=torch.int32, device=self.device)
         _lib.check(self.lib.pk_eigh_psd_f64(self.stream(), n, _ptr(W), n, _ptr(R), n, _ptr(lam), max_sweeps, tol,
-                                            _ptr(self._info)), 'pk_eigh_psd_f64')
+                                            _ptr(info)), 'pk_eigh_psd_f64')
+        if n > 136:
+            # block Jacobi: ONE cooperative launch whose workgroups meet at grid barriers.  Its verdict is read (a few
+            # solves per build go this way, each followed by a host read of the eigenvalues anyway): 0 = a barrier did
+            # not complete or the sweeps ran out — the vectors are then not eigenvectors and the solve is
+            # re-done with one launch per round, where stream order is the barrier
+            if int(info[1].item()) == 0:
+                W.copy_(S)
+                _lib.check(self.lib.pk_eigh_psd_rounds_f64(self.stream(), n, _ptr(W), n, _ptr(R), n, _ptr(lam), max_sweeps, tol,
+                                                           _ptr(info)), 'pk_eigh_psd_rounds_f64')
+                if int(info[1].item()) == 0:
+                    raise RuntimeError('pk_eigh_psd_f64: the block Jacobi sweeps did not converge (n=%d)' % n)
         return lam, R.t()  # rows of R are eigenvectors -> return as columns (a view; strides swapped)
 
     def eigh_top(self, S, r):

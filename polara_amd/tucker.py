@@ -56,8 +56,18 @@ def device_coordinates(ops, users, items, feedback, levels):
     """The coordinate columns of the (user, item, feedback level) tensor as device int64 tensors: users and items as they
     lie, the level of every entry looked up in the sorted `levels` on the device (what `to_coo(tensor_mode=True)` does
     with a host searchsorted and a stacked copy, data.py:794-817)."""
-    i2 = torch.searchsorted(ops.to_device(np.ascontiguousarray(levels)), ops.to_device(np.ascontiguousarray(feedback)))
-    return ops.to_device(np.ascontiguousarray(users, dtype=np.int64)), ops.to_device(np.ascontiguousarray(items, dtype=np.int64)), i2
+    lev = ops.to_device(np.ascontiguousarray(levels))
+    fb = ops.to_device(np.ascontiguousarray(feedback))
+    i2 = torch.searchsorted(lev, fb)
+    # entries whose feedback value is not one of `levels` (a fixed level set that does not cover this shard's values,
+    # ShardedArrayData._fixed_levels): i2 == L would alias into (user + 1, level 0), a value between two levels into the
+    # upper one — counted here on the device, read by the caller with the item counts (ONE host read) and raised like
+    # test_to_coo does
+    L = int(lev.numel())
+    bad = ((i2 >= L) | (lev[i2.clamp_max(max(L - 1, 0))] != fb)).sum().to(torch.int64) if L else torch.zeros((), dtype=torch.int64, device=fb.device)
+    i2 = i2.clamp_max(max(L - 1, 0))
+    return (ops.to_device(np.ascontiguousarray(users, dtype=np.int64)), ops.to_device(np.ascontiguousarray(items, dtype=np.int64)),
+            i2, bad)
 
 
 class Unfoldings:

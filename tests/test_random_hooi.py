@@ -106,6 +106,35 @@ def test_device_coordinate_build_equals_the_protocol_build():
         assert np.array_equal(a.factors[k], b.factors[k]), k
 
 
+def test_device_coordinate_build_rejects_feedback_outside_the_level_set():
+    """with a FIXED level set (ShardedArrayData: the manifest's levels, so that every rank uses the same ones)
+    a shard value that is not a level used to alias silently — above the last level into (user + 1, level 0), between two
+    levels into the upper one.  The device check rides in the one host read of the item counts and raises like the
+    reference's test_to_coo does ('Not all values of feedback are present')."""
+    from numpy_ops import NumpyOps
+    from polara_amd.data import ArrayData
+    from polara_amd.models import CoffeeModel
+
+    class FixedLevels(ArrayData):
+        def _levels(self):
+            return np.array([1.0, 2.0, 3.0])
+
+    rs = np.random.RandomState(6)
+    n_users, n_items, n = 120, 40, 2500
+    u, i = rs.randint(0, n_users, n), rs.randint(0, n_items, n)
+    hold = (np.arange(n_users), np.zeros(n_users, np.int64), np.ones(n_users))
+    for f, ok in ((rs.choice([1.0, 2.0, 3.0], n), True), (rs.choice([1.0, 2.0, 3.0, 4.0], n), False),
+                  (rs.choice([1.0, 2.5, 3.0], n), False)):
+        m = CoffeeModel(FixedLevels((u, i, f), n_users=n_users, n_items=n_items, holdout=hold, warm_start=False), ops=NumpyOps())
+        m.verbose = False
+        m.mlrank, m.seed = (5, 4, 2), 1
+        if ok:
+            m.build()
+        else:
+            with pytest.raises(ValueError, match='Not all values of feedback'):
+                m.build()
+
+
 @pytest.mark.gpu
 def test_hooi_redoes_an_iteration_when_a_direct_eigensolve_reports_failure(hip_ops, monkeypatch):
     """tucker.hooi reads the verdicts of the direct eigensolves (csrc/eigh_top.hip) once per iteration, with the core
