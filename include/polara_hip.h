@@ -169,6 +169,10 @@ int pk_gram_f64(void *stream, int64_t n, int32_t la, int32_t lb, const double *A
 /* out[n x lout] = X[n x lin] * C[lin x lout]   (out must not alias X) */
 int pk_tsmm_f64(void *stream, int64_t n, int32_t lin, int32_t lout, const double *X_dev, int64_t ldx,
                 const double *C_dev, int64_t ldc, double *out_dev, int64_t ldo);
+/* out[n x lout] = Z[n x lout] - X[n x lin] * C[lin x lout]  (out may alias Z, not X): the projection X - V (V^T X) of the
+ * solvers in one pass */
+int pk_tsmm_sub_f64(void *stream, int64_t n, int32_t lin, int32_t lout, const double *X_dev, int64_t ldx,
+                    const double *C_dev, int64_t ldc, const double *Z_dev, int64_t ldz, double *out_dev, int64_t ldo);
 /* Symmetric positive semi-definite eigen-decomposition by one-sided Jacobi, single workgroup.
  * S (n x n, destroyed) -> evals[n] descending, evecs (n x n, ROW i = i-th eigenvector).
  * info_dev[0] = sweeps used, info_dev[1] = 1 if converged.  n <= 1024. */
@@ -520,6 +524,18 @@ typedef struct pk_comm {
 int pk_svd_build_sharded(pk_ctx *ctx, pk_mat *A_local, const pk_comm *comm, int32_t k, int32_t block, double tol,
                          int32_t max_outer, uint64_t seed, double *sigma_out, double *V_out, double *U_out_local,
                          pk_build_stats *stats_out);
+/* The k leading eigenpairs of a small dense symmetric PSD matrix T [n x n] (DEVICE, row-major, leading dimension ldt) — the
+ * projected problem Q^T (A^T A) Q of the block Lanczos build (polara_amd/solver.py::_block_lanczos; inside the reference's
+ * `svds` ARPACK solves the same kind of projected problem, models.py:844).  Filtered subspace iteration with locking on
+ * the operator T, block width l (k <= l <= min(n, 1024)), run on `stream` (NULL: the context's) with temporaries from the
+ * context's pool.  X0_dev: orthonormal start block [x0_rows x l] (rows x0_rows..n-1 are taken as zero: the warm start from
+ * the pairs of a leading principal submatrix), or NULL = the first l unit vectors.  Convergence: ||T y - theta y|| <= tol *
+ * theta_1 for the k leading pairs.  Outputs: basis_out_dev [n x l] (locked vectors, then the active block; column j belongs
+ * to lam_out_host[j]), res_out_host[0 .. counts[1]) = residual norms of the active block, counts_out[5] = {locked vectors,
+ * width of the active block, converged, outer iterations, products with T}.  Synchronises `stream` before it returns. */
+int pk_sym_eig_topk_f64(pk_ctx *ctx, void *stream, int32_t n, const double *T_dev, int64_t ldt, int32_t k, int32_t l,
+                        const double *X0_dev, int64_t ldx0, int32_t x0_rows, double tol, int32_t max_outer, uint64_t seed,
+                        double *basis_out_dev, int64_t ldb, double *lam_out_host, double *res_out_host, int32_t *counts_out);
 /* the context's HIP stream (hipStream_t as void*): what a pk_comm callback is handed, for hosts that create the
  * communicator's work on it */
 void *pk_ctx_stream(pk_ctx *ctx);

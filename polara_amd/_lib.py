@@ -44,6 +44,7 @@ PROTOTYPES = {
     'pk_gram_work_bytes': (_i64, [_i64, _i32, _i32]),
     'pk_gram_f64': (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     'pk_tsmm_f64': (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64]),
+    'pk_tsmm_sub_f64': (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64]),
     'pk_eigh_psd_f64': (C.c_int, [_vp, _i32, _vp, _i64, _vp, _i64, _vp, _i32, _f64, _vp]),
     'pk_eigh_psd_rounds_f64': (C.c_int, [_vp, _i32, _vp, _i64, _vp, _i64, _vp, _i32, _f64, _vp]),
     'pk_eigh_top_supported': (C.c_int, [_i32, _i32]),
@@ -107,6 +108,8 @@ PROTOTYPES = {
     'pk_mat_free': (None, [_vp, _vp]),
     'pk_mat_nnz': (_i64, [_vp]),
     'pk_svd_build': (C.c_int, [_vp, _vp, _i32, _i32, _f64, _i32, C.c_uint64, _vp, _vp, _vp, _vp]),
+    'pk_sym_eig_topk_f64': (C.c_int, [_vp, _vp, _i32, _vp, _i64, _i32, _i32, _vp, _i64, _i32, _f64, _i32, C.c_uint64,
+                                      _vp, _i64, _vp, _vp, _vp]),
     'pk_svd_build_sharded': (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f64, _i32, C.c_uint64, _vp, _vp, _vp, _vp]),
     'pk_ctx_stream': (_vp, [_vp]),
     'pk_score_topk': (C.c_int, [_vp, _i64, _i32, _vp, _vp, _i32, _i32, _vp, _vp]),

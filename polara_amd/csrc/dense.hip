@@ -131,9 +131,11 @@ extern "C" int pk_gram_f64(void *stream, int64_t n, int32_t la, int32_t lb, cons
 // block computes 64 rows x 64 output columns; k advanced 16 at a time through LDS; the products run on the fp64 matrix
 // cores (v_mfma_f64_16x16x4_f64, layout in gram_kernel): wave w owns rows [16 w, 16 w + 16) of the block, P[i][k] =
 // sX[16 w + i][k0 + k] (row stride 17: the 16 rows of a quarter-wave fall into different banks), Q[k][j] = sC[k0 + k][16 b + j].
+template <bool SUB>
 __global__ __launch_bounds__(256) void tsmm_kernel(int64_t n, int lin, int lout, const double *__restrict__ X,
                                                    int64_t ldx, const double *__restrict__ C, int64_t ldc,
-                                                   double *__restrict__ out, int64_t ldo) {
+                                                   double *__restrict__ out, int64_t ldo, const double *__restrict__ Zin,
+                                                   int64_t ldz) {
     __shared__ double sX[64][17];
     __shared__ double sC[16][64];
     const int tid = threadIdx.x;
@@ -174,7 +176,10 @@ __global__ __launch_bounds__(256) void tsmm_kernel(int64_t n, int lin, int lout,
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int64_t row = row0 + 16 * wave + (lane >> 4) + 4 * r;
-            if (row < n && c < lout) out[row * ldo + c] = acc[b][r];
+            if (row < n && c < lout) {
+                if constexpr (SUB) out[row * ldo + c] = Zin[row * ldz + c] - acc[b][r];     // out may alias Zin: same element, same thread
+                else out[row * ldo + c] = acc[b][r];
+            }
         }
     }
 }
@@ -184,9 +189,22 @@ extern "C" int pk_tsmm_f64(void *stream, int64_t n, int32_t lin, int32_t lout, c
     PK_REQUIRE(n >= 1 && lin >= 1 && lout >= 1, "pk_tsmm_f64: bad sizes");
     PK_REQUIRE(ldx >= lin && ldc >= lout && ldo >= lout, "pk_tsmm_f64: bad leading dimension");
     PK_REQUIRE(X_dev != out_dev, "pk_tsmm_f64: out must not alias X");
-    hipLaunchKernelGGL(tsmm_kernel, dim3((unsigned)pk_ceil_div(n, 64), (unsigned)pk_ceil_div(lout, 64)), dim3(256),
-                       0, pk_stream(stream), n, lin, lout, X_dev, ldx, C_dev, ldc, out_dev, ldo);
+    hipLaunchKernelGGL(tsmm_kernel<false>, dim3((unsigned)pk_ceil_div(n, 64), (unsigned)pk_ceil_div(lout, 64)), dim3(256),
+                       0, pk_stream(stream), n, lin, lout, X_dev, ldx, C_dev, ldc, out_dev, ldo, (const double *)nullptr, (int64_t)0);
     PK_CHECK_LAUNCH("tsmm_kernel");
+    return PK_OK;
+}
+
+// out = Z - X C in one pass (the projection step X - V (V^T X) of the solvers without the product's round trip through
+// memory: block Lanczos re-orthogonalises every new block against the whole basis, twice per step)
+extern "C" int pk_tsmm_sub_f64(void *stream, int64_t n, int32_t lin, int32_t lout, const double *X_dev, int64_t ldx,
+                               const double *C_dev, int64_t ldc, const double *Z_dev, int64_t ldz, double *out_dev, int64_t ldo) {
+    PK_REQUIRE(n >= 1 && lin >= 1 && lout >= 1, "pk_tsmm_sub_f64: bad sizes");
+    PK_REQUIRE(ldx >= lin && ldc >= lout && ldo >= lout && ldz >= lout, "pk_tsmm_sub_f64: bad leading dimension");
+    PK_REQUIRE(X_dev != out_dev && Z_dev && C_dev && X_dev && out_dev, "pk_tsmm_sub_f64: bad pointers (out must not alias X)");
+    hipLaunchKernelGGL(tsmm_kernel<true>, dim3((unsigned)pk_ceil_div(n, 64), (unsigned)pk_ceil_div(lout, 64)), dim3(256),
+                       0, pk_stream(stream), n, lin, lout, X_dev, ldx, C_dev, ldc, out_dev, ldo, Z_dev, ldz);
+    PK_CHECK_LAUNCH("tsmm_kernel<sub>");
     return PK_OK;
 }
 

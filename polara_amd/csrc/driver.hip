@@ -163,6 +163,14 @@ __global__ void transpose_small_kernel(int n, const double *__restrict__ in, dou
     out[(int64_t)c * n + r] = in[i];
 }
 
+// H <- (H + H^T) / 2 (out of place): a Rayleigh-Ritz matrix X^T (T X) is symmetric to rounding only
+__global__ void symmetrize_kernel(int n, const double *__restrict__ in, double *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * n) return;
+    const int r = i / n, c = i - r * n;
+    out[i] = 0.5 * (in[i] + in[(int64_t)c * n + r]);
+}
+
 // fp32 image of the item factors for the approximate fold-in: columns 0..K-1 = fl32(V), column K = the row-norm bound
 __global__ void v32_image_kernel(int64_t n, int K, int ld32, const double *__restrict__ V, const float *__restrict__ bound,
                                  float *__restrict__ out) {
@@ -681,19 +689,168 @@ extern "C" int pk_svd_build_sharded(pk_ctx *ctx, pk_mat *A_local, const pk_comm 
 
 extern "C" void *pk_ctx_stream(pk_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
+// ---- the filtered subspace iteration, generic in the operator (solver.py::_subspace_iteration) -----------------------
+struct SubspaceOut {
+    DMat basis;                          // locked vectors, then the active block
+    std::vector<double> lam_all;         // Ritz values of the basis columns
+    std::vector<double> res_act;         // residual norms of the active block
+    int n_lock = 0, outer = 0;
+    bool converged = false;
+};
+
+// Op: ritz(X, H, carrier) -> H = X^T B X and a carrier from which B (X C) follows; rotate(carrier, C, Z) -> Z = B X C;
+// apply(X, Z) -> Z = B X.  X: orthonormal start block (consumed).
+template <class Op>
+int subspace_iteration(pk_ctx *ctx, Solver &S, Op &op, int k, DMat X, double tol, int max_outer, int m_max, double spread,
+                       uint64_t seed, bool even_lock, SubspaceOut &out) {
+    DMat Vlock;           // [rows x n_lock]
+    bool have_lock = false;
+    std::vector<double> lam_lock, theta_host, res_host;
+    int n_lock = 0;
+    bool done = false;
+    for (int it = 0; it < max_outer && !done; ++it) {
+        out.outer += 1;
+        // ---- Rayleigh-Ritz on the active block
+        DMat H, carrier, Cm, Xr, Z;
+        CK(op.ritz(X, H, carrier));
+        Dev theta_dev;
+        CK(S.eigh(H, theta_host, Cm, theta_dev));
+        CK(S.tsmm(X, Cm, Xr));
+        X = std::move(Xr);
+        CK(op.rotate(carrier, Cm, Z));
+        CK(S.resid(Z, X, theta_dev, res_host));
+        const double lam1 = lam_lock.empty() ? theta_host[0] : lam_lock[0];
+        const int need = k - n_lock;
+        const double thr = tol * lam1;
+        int n_new = 0;
+        while (n_new < (int)res_host.size() && res_host[(size_t)n_new] <= thr) ++n_new;
+        if (n_new < need && (n_new & 1) && even_lock) --n_new;       // even active width: the paired-column SpMM kernel
+        if (n_new >= need) {
+            done = true;
+            break;
+        }
+        if (n_new > 0 && X.l - n_new >= std::max(8, need - n_new)) {
+            DMat newV, Vl, Xa, Za;
+            CK(S.col_slice(X, 0, n_new, newV));
+            CK(S.hcat(have_lock ? &Vlock : nullptr, newV, Vl));
+            Vlock = std::move(Vl);
+            have_lock = true;
+            lam_lock.insert(lam_lock.end(), theta_host.begin(), theta_host.begin() + n_new);
+            n_lock += n_new;
+            CK(S.col_slice(X, n_new, X.l, Xa));
+            CK(S.col_slice(Z, n_new, Z.l, Za));
+            X = std::move(Xa);
+            Z = std::move(Za);
+            theta_host.erase(theta_host.begin(), theta_host.begin() + n_new);
+            res_host.erase(res_host.begin(), res_host.begin() + n_new);
+        }
+        // ---- Chebyshev filter on P B P, damping [0, b]
+        const double b = theta_host.back(), a0 = theta_host.front();
+        const int m = cheb_degree(a0, b, spread, m_max);
+        const double e = 0.5 * b, c = 0.5 * b;
+        DMat Yc;
+        if (e <= 0.0 || a0 <= c) {
+            if (have_lock) CK(S.project_out(Z, Vlock, Yc)); else Yc = std::move(Z);
+        } else {
+            double sigma = e / (a0 - c);
+            const double tau = 2.0 / sigma;
+            DMat Zp;
+            if (have_lock) CK(S.project_out(Z, Vlock, Zp)); else Zp = std::move(Z);
+            DMat Xc;
+            CK(S.col_slice(X, 0, X.l, Xc));
+            CK(S.axpbypcz(sigma / e, Zp, -c * sigma / e, &Xc, 0.0, nullptr, Yc));
+            for (int s = 2; s <= m; ++s) {
+                const double sigma_new = 1.0 / (tau - sigma);
+                DMat Zc, Yn;
+                CK(op.apply(Yc, Zc));
+                if (have_lock) { DMat t; CK(S.project_out(Zc, Vlock, t)); Zc = std::move(t); }
+                CK(S.axpbypcz(2.0 * sigma_new / e, Zc, -2.0 * sigma_new * c / e, &Yc, -sigma * sigma_new, &Xc, Yn));
+                Xc = std::move(Yc);
+                Yc = std::move(Yn);
+                sigma = sigma_new;
+            }
+        }
+        DMat Xn;
+        CK(S.orthonormalize(Yc, have_lock ? &Vlock : nullptr, seed + 1 + (uint64_t)it, Xn));
+        X = std::move(Xn);
+    }
+    CK(S.hcat(have_lock ? &Vlock : nullptr, X, out.basis));
+    out.lam_all = lam_lock;
+    out.lam_all.insert(out.lam_all.end(), theta_host.begin(), theta_host.end());
+    out.res_act = res_host;
+    out.n_lock = n_lock;
+    out.converged = done;
+    return PK_OK;
+}
+
+// B = A^T A of the (row-sharded) sparse matrix: solver.py::_Gramian
+struct GramianOp {
+    pk_ctx *ctx;
+    Solver &S;
+    pk_mat *A;
+    const pk_comm *comm;
+    int steps = 0;
+    int allreduce(DMat &M) {
+        if (!comm) return PK_OK;
+        if (comm->allreduce_sum_f64(comm->user, M.p(), (int64_t)M.n * M.l, (void *)ctx->stream) != 0)
+            return fail(ctx, PK_E_LAUNCH, "pk_svd_build_sharded: the communicator's all-reduce failed");
+        return PK_OK;
+    }
+    int ritz(const DMat &X, DMat &H, DMat &Y) {
+        Y = DMat(A->A.n_rows, X.l);
+        if (!Y.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (Rayleigh-Ritz)");
+        CK(spmm_full(ctx, A->A, X, Y));
+        CK(S.gram(Y, Y, H));
+        return allreduce(H);
+    }
+    int rotate(const DMat &Y, const DMat &Cm, DMat &Z) {
+        DMat Yr;
+        CK(S.tsmm(Y, Cm, Yr));
+        Z = DMat(A->A.n_cols, Yr.l);
+        if (!Z.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (Rayleigh-Ritz)");
+        CK(spmm_t(ctx, A, Yr, Z));
+        ++steps;
+        return allreduce(Z);
+    }
+    int apply(const DMat &Xb, DMat &Z) {
+        DMat Y(A->A.n_rows, Xb.l);
+        Z = DMat(A->A.n_cols, Xb.l);
+        if (!Y.ok() || !Z.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (gramian step)");
+        CK(spmm_full(ctx, A->A, Xb, Y));
+        CK(spmm_t(ctx, A, Y, Z));
+        ++steps;
+        return allreduce(Z);
+    }
+};
+
+// a small dense symmetric PSD matrix as the operator: solver.py::_Dense (T X = T^T X is one gram launch)
+struct DenseOp {
+    pk_ctx *ctx;
+    Solver &S;
+    const DMat &T;
+    int products = 0;
+    int apply(const DMat &X, DMat &Z) {
+        ++products;
+        return S.gram(T, X, Z);
+    }
+    int ritz(const DMat &X, DMat &H, DMat &Z) {
+        DMat G;
+        CK(apply(X, Z));
+        CK(S.gram(X, Z, G));
+        H = DMat(G.l, G.l);
+        if (!H.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (Rayleigh-Ritz)");
+        hipLaunchKernelGGL(symmetrize_kernel, dim3((unsigned)((G.l * G.l + 255) / 256)), dim3(256), 0, S.st, G.l, G.p(), H.p());
+        return PK_OK;
+    }
+    int rotate(const DMat &Z, const DMat &Cm, DMat &out) { return S.tsmm(Z, Cm, out); }
+};
+
 static int svd_build_impl(pk_ctx *ctx, pk_mat *A, const pk_comm *comm, int32_t k, int32_t block, double tol, int32_t max_outer,
                           uint64_t seed, double *sigma_out, double *V_out, double *U_out, pk_build_stats *stats_out) {
     if (!ctx || !A) return PK_E_INVALID;
     std::lock_guard<std::mutex> lock(ctx->mu);
     PoolScope pool_scope(ctx);
     (void)hipSetDevice(ctx->device);
-    // users sharded over ranks: the two places where a sum over USERS leaves the rank (solver.py: comm.allreduce)
-    auto allreduce = [&](DMat &M) -> int {
-        if (!comm) return PK_OK;
-        if (comm->allreduce_sum_f64(comm->user, M.p(), (int64_t)M.n * M.l, (void *)ctx->stream) != 0)
-            return fail(ctx, PK_E_LAUNCH, "pk_svd_build_sharded: the communicator's all-reduce failed");
-        return PK_OK;
-    };
     const int64_t n_items = A->A.n_cols, n_users = A->A.n_rows;
     if (k < 1 || k > n_items || !sigma_out || !V_out) return fail(ctx, PK_E_INVALID, "pk_svd_build: k must satisfy 0 < k <= n_items; outputs required");
     if (tol <= 0) tol = 1e-12;
@@ -719,110 +876,20 @@ static int svd_build_impl(pk_ctx *ctx, pk_mat *A, const pk_comm *comm, int32_t k
         CK(S.randn(n_items, l, seed, R));
         CK(S.orthonormalize(R, nullptr, 12345, X));
     }
-    DMat Vlock;           // [n_items x n_lock]
-    bool have_lock = false;
-    std::vector<double> lam_lock, theta_host, res_host;
-    int n_lock = 0;
+    GramianOp gop{ctx, S, A, comm};
+    SubspaceOut so;
+    CK(subspace_iteration(ctx, S, gop, k, std::move(X), tol, max_outer, m_max, spread, seed, true, so));
+    stats.outer = so.outer;
+    stats.gramian_steps = gop.steps;
+    stats.converged = so.converged ? 1 : 0;
+    const int n_lock = so.n_lock;
+    const std::vector<double> &res_host = so.res_act;
     DMat Vk;
-    std::vector<double> lam_k;
-
-    auto gramian = [&](const DMat &Xb, DMat &Z) -> int {
-        DMat Y(n_users, Xb.l);
-        Z = DMat(n_items, Xb.l);
-        if (!Y.ok() || !Z.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (gramian step)");
-        CK(spmm_full(ctx, A->A, Xb, Y));
-        CK(spmm_t(ctx, A, Y, Z));
-        CK(allreduce(Z));
-        stats.gramian_steps += 1;
-        return PK_OK;
-    };
-
-    bool done = false;
-    for (int it = 0; it < max_outer && !done; ++it) {
-        stats.outer = it + 1;
-        // ---- Rayleigh-Ritz on the active block
-        DMat Y(n_users, X.l), H, Cm, Xr, Yr, Z(n_items, X.l);
-        if (!Y.ok() || !Z.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (Rayleigh-Ritz)");
-        CK(spmm_full(ctx, A->A, X, Y));
-        CK(S.gram(Y, Y, H));
-        CK(allreduce(H));
-        Dev theta_dev;
-        CK(S.eigh(H, theta_host, Cm, theta_dev));
-        CK(S.tsmm(X, Cm, Xr));
-        CK(S.tsmm(Y, Cm, Yr));
-        X = std::move(Xr);
-        CK(spmm_t(ctx, A, Yr, Z));
-        CK(allreduce(Z));
-        stats.gramian_steps += 1;
-        CK(S.resid(Z, X, theta_dev, res_host));
-        const double lam1 = lam_lock.empty() ? theta_host[0] : lam_lock[0];
-        const int need = k - n_lock;
-        const double thr = tol * lam1;
-        int n_new = 0;
-        while (n_new < (int)res_host.size() && res_host[(size_t)n_new] <= thr) ++n_new;
-        if (n_new < need && (n_new & 1)) --n_new;       // even active width: the paired-column SpMM kernel
-        if (n_new >= need) {
-            DMat Xk;
-            CK(S.col_slice(X, 0, need, Xk));
-            CK(S.hcat(have_lock ? &Vlock : nullptr, Xk, Vk));
-            lam_k = lam_lock;
-            lam_k.insert(lam_k.end(), theta_host.begin(), theta_host.begin() + need);
-            stats.converged = 1;
-            done = true;
-            break;
-        }
-        if (n_new > 0 && X.l - n_new >= std::max(8, need - n_new)) {
-            DMat newV, Vl, Xa, Za;
-            CK(S.col_slice(X, 0, n_new, newV));
-            CK(S.hcat(have_lock ? &Vlock : nullptr, newV, Vl));
-            Vlock = std::move(Vl);
-            have_lock = true;
-            lam_lock.insert(lam_lock.end(), theta_host.begin(), theta_host.begin() + n_new);
-            n_lock += n_new;
-            CK(S.col_slice(X, n_new, X.l, Xa));
-            CK(S.col_slice(Z, n_new, Z.l, Za));
-            X = std::move(Xa);
-            Z = std::move(Za);
-            theta_host.erase(theta_host.begin(), theta_host.begin() + n_new);
-        }
-        // ---- Chebyshev filter on P B P, damping [0, b]
-        const double b = theta_host.back(), a0 = theta_host.front();
-        const int m = cheb_degree(a0, b, spread, m_max);
-        const double e = 0.5 * b, c = 0.5 * b;
-        DMat Yc;
-        if (e <= 0.0 || a0 <= c) {
-            if (have_lock) CK(S.project_out(Z, Vlock, Yc)); else Yc = std::move(Z);
-        } else {
-            double sigma = e / (a0 - c);
-            const double tau = 2.0 / sigma;
-            DMat Zp;
-            if (have_lock) CK(S.project_out(Z, Vlock, Zp)); else Zp = std::move(Z);
-            DMat Xc;
-            CK(S.col_slice(X, 0, X.l, Xc));
-            CK(S.axpbypcz(sigma / e, Zp, -c * sigma / e, &Xc, 0.0, nullptr, Yc));
-            for (int s = 2; s <= m; ++s) {
-                const double sigma_new = 1.0 / (tau - sigma);
-                DMat Zc, Yn;
-                CK(gramian(Yc, Zc));
-                if (have_lock) { DMat t; CK(S.project_out(Zc, Vlock, t)); Zc = std::move(t); }
-                CK(S.axpbypcz(2.0 * sigma_new / e, Zc, -2.0 * sigma_new * c / e, &Yc, -sigma * sigma_new, &Xc, Yn));
-                Xc = std::move(Yc);
-                Yc = std::move(Yn);
-                sigma = sigma_new;
-            }
-        }
-        DMat Xn;
-        CK(S.orthonormalize(Yc, have_lock ? &Vlock : nullptr, seed + 1 + (uint64_t)it, Xn));
-        X = std::move(Xn);
+    {
+        const int take = std::min<int>(k, so.basis.l);
+        CK(S.col_slice(so.basis, 0, take, Vk));
     }
-    if (!done) {
-        const int take = std::min(k - n_lock, X.l);
-        DMat Xk;
-        CK(S.col_slice(X, 0, take, Xk));
-        CK(S.hcat(have_lock ? &Vlock : nullptr, Xk, Vk));
-        lam_k = lam_lock;
-        lam_k.insert(lam_k.end(), theta_host.begin(), theta_host.begin() + take);
-    }
+    std::vector<double> lam_k(so.lam_all.begin(), so.lam_all.begin() + std::min<size_t>((size_t)k, so.lam_all.size()));
     const int kk = std::min<int>(k, Vk.l);
     // to the host: sigma descending, V column-major (the F-ordered `vh.T` of models.py:849)
     std::vector<double> vh((size_t)n_items * Vk.l);
@@ -864,6 +931,63 @@ static int svd_build_impl(pk_ctx *ctx, pk_mat *A, const pk_comm *comm, int32_t k
                                "the best available factors were written", stats.outer, stats.final_rel_residual, tol);
         return PK_E_NOCONV;
     }
+    return PK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// pk_sym_eig_topk_f64: the k leading eigenpairs of a small dense symmetric PSD matrix that lives on the device — the
+// projected problem T = Q^T (A^T A) Q of the block Lanczos build (solver.py::_block_lanczos; the reference's svds solves
+// the same projected problem inside ARPACK, models.py:844).  It is the filtered subspace iteration above with T as the
+// operator, run from C++: a nested solve is a few hundred launches of kernels that take microseconds, and from Python
+// every one of them costs the host ~20 us — 20 of the 48 ms of the first Lanczos build.
+// ------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ void unit_block_kernel(int64_t n, int l, double *__restrict__ out) {     // out[n x l] = first l unit vectors
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * l) return;
+    const int64_t r = i / l;
+    out[i] = (r == i - r * l) ? 1.0 : 0.0;
+}
+}  // namespace
+
+extern "C" int pk_sym_eig_topk_f64(pk_ctx *ctx, void *stream, int32_t n, const double *T_dev, int64_t ldt, int32_t k, int32_t l,
+                                   const double *X0_dev, int64_t ldx0, int32_t x0_rows, double tol, int32_t max_outer, uint64_t seed,
+                                   double *basis_out_dev, int64_t ldb, double *lam_out_host, double *res_out_host,
+                                   int32_t *counts_out) {
+    if (!ctx) return PK_E_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    PoolScope pool_scope(ctx);
+    (void)hipSetDevice(ctx->device);
+    if (n < 1 || k < 1 || l < k || l > n || l > 1024 || !T_dev || ldt < n || !basis_out_dev || ldb < l || !lam_out_host || !res_out_host ||
+        !counts_out || (X0_dev && (x0_rows < 1 || x0_rows > n || ldx0 < l)))
+        return fail(ctx, PK_E_INVALID, "pk_sym_eig_topk_f64: bad arguments (n=%d, k=%d, l=%d)", n, k, l);
+    if (tol <= 0) tol = 1e-13;
+    if (max_outer <= 0) max_outer = 200;
+    hipStream_t st = stream ? pk_stream(stream) : ctx->stream;
+    Solver S{ctx, st, Dev()};
+    DMat T(n, n), X(n, l);
+    if (!T.ok() || !X.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (pk_sym_eig_topk_f64)");
+    HIPCK(hipMemcpy2DAsync(T.p(), (size_t)n * 8, T_dev, (size_t)ldt * 8, (size_t)n * 8, (size_t)n, hipMemcpyDeviceToDevice, st));
+    if (X0_dev) {
+        HIPCK(hipMemsetAsync(X.p(), 0, (size_t)n * l * 8, st));
+        HIPCK(hipMemcpy2DAsync(X.p(), (size_t)l * 8, X0_dev, (size_t)ldx0 * 8, (size_t)l * 8, (size_t)x0_rows, hipMemcpyDeviceToDevice, st));
+    } else {
+        hipLaunchKernelGGL(unit_block_kernel, dim3((unsigned)(((int64_t)n * l + 255) / 256)), dim3(256), 0, st, (int64_t)n, l, X.p());
+    }
+    DenseOp dop{ctx, S, T};
+    SubspaceOut so;
+    CK(subspace_iteration(ctx, S, dop, k, std::move(X), tol, max_outer, 24, 1e7, seed, false, so));
+    const int w = std::min<int>(l, so.basis.l);
+    HIPCK(hipMemcpy2DAsync(basis_out_dev, (size_t)ldb * 8, so.basis.p(), (size_t)so.basis.l * 8, (size_t)w * 8, (size_t)n,
+                           hipMemcpyDeviceToDevice, st));
+    HIPCK(hipStreamSynchronize(st));
+    for (int j = 0; j < l; ++j) lam_out_host[j] = j < (int)so.lam_all.size() ? so.lam_all[(size_t)j] : 0.0;
+    for (int j = 0; j < l; ++j) res_out_host[j] = j < (int)so.res_act.size() ? so.res_act[(size_t)j] : 0.0;
+    counts_out[0] = so.n_lock;
+    counts_out[1] = w - so.n_lock;
+    counts_out[2] = so.converged ? 1 : 0;
+    counts_out[3] = so.outer;
+    counts_out[4] = dop.products;
     return PK_OK;
 }
 

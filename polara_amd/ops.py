@@ -260,6 +260,7 @@ class HipOps:
         import os
         self.score_splits_override = int(os.environ.get('PK_SCORE_SPLITS', '0'))   # 0 = auto (pk_score_splits); tuning knob
         self._info = torch.zeros(2, dtype=torch.int32, device=self.device)
+        self._ctx = None     # a coarse-ABI context (its pool of device blocks) for the C++-driven nested eigen-solve
         # optional per-kernel HIP-event timing (bench.py): {'name': [(ev_start, ev_end, meta), ...]}
         self.timers = None
 
@@ -298,7 +299,13 @@ class HipOps:
         return torch.zeros(*shape, dtype=dtype, device=self.device)
 
     def to_device(self, a, dtype=None):
-        t = torch.as_tensor(np.ascontiguousarray(a))
+        a = np.ascontiguousarray(a)
+        import warnings
+        with warnings.catch_warnings():
+            # ArrayData stores read-only views of the caller's columns; torch warns that a tensor over one must not be
+            # written to — it is only the source of the copy below
+            warnings.simplefilter('ignore', UserWarning)
+            t = torch.as_tensor(a)
         if dtype is not None:
             t = t.to(dtype)
         return t.to(self.device)
@@ -619,6 +626,51 @@ class HipOps:
                 if int(info[1].item()) == 0:
                     raise RuntimeError('pk_eigh_psd_f64: the block Jacobi sweeps did not converge (n=%d)' % n)
         return lam, R.t()  # rows of R are eigenvectors -> return as columns (a view; strides swapped)
+
+    def tsmm_sub(self, Z, X, Cm, out=None):
+        """Z - X @ C in one pass (out may be Z itself)."""
+        assert X.stride(1) == 1 and Cm.stride(1) == 1 and Z.stride(1) == 1 and Cm.shape[0] == X.shape[1] and Z.shape == (X.shape[0], Cm.shape[1])
+        n, lin = X.shape
+        lout = Cm.shape[1]
+        if out is None:
+            out = self.empty(n, lout)
+        _lib.check(self.lib.pk_tsmm_sub_f64(self.stream(), n, lin, lout, _ptr(X), X.stride(0), _ptr(Cm), Cm.stride(0),
+                                            _ptr(Z), Z.stride(0), _ptr(out), out.stride(0)), 'pk_tsmm_sub_f64')
+        return out
+
+    def sym_eig_topk(self, T, k, X0=None, tol=1e-13, max_outer=200, seed=0, stats=None):
+        """The k leading eigenpairs of the small dense symmetric PSD device matrix T [n x n] — pk_sym_eig_topk_f64: the
+        filtered subspace iteration of solver.py with T as the operator, driven from C++ (hundreds of microsecond
+        kernels: from Python each would cost the host ~20 us).  X0: orthonormal start block [rows <= n x l] (missing rows
+        are zero) or None.  Returns (basis [n x l] device, Ritz values of its columns (host), residual norms of the active
+        block (host), n_lock, converged) — the tuple of solver._subspace_iteration."""
+        n = int(T.shape[0])
+        assert T.stride(1) == 1 and T.shape[1] == n
+        if X0 is not None:
+            X0 = X0.contiguous()
+            l = int(X0.shape[1])
+        else:
+            l = min(n, max(int(k), 8))
+        if self._ctx is None:
+            ctx = C.c_void_p()
+            _lib.check(self.lib.pk_ctx_create(self.device.index or 0, C.byref(ctx)), 'pk_ctx_create')
+            self._ctx = ctx
+        basis = self.empty(n, l)
+        lam = np.zeros(l)
+        res = np.zeros(l)
+        counts = np.zeros(5, dtype=np.int32)
+        rc = self.lib.pk_sym_eig_topk_f64(self._ctx, self.stream(), n, _ptr(T), T.stride(0), int(k), l,
+                                          _ptr(X0) if X0 is not None else None, l, int(X0.shape[0]) if X0 is not None else 0,
+                                          float(tol), int(max_outer), int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(basis), l,
+                                          lam.ctypes.data_as(C.c_void_p), res.ctypes.data_as(C.c_void_p),
+                                          counts.ctypes.data_as(C.c_void_p))
+        if rc != 0:
+            raise RuntimeError('pk_sym_eig_topk_f64: ' + (self.lib.pk_ctx_error(self._ctx) or b'').decode())
+        if stats is not None:
+            stats['outer'] = stats.get('outer', 0) + int(counts[3])
+            stats['steps'] = stats.get('steps', 0) + int(counts[4])
+        n_lock, n_act = int(counts[0]), int(counts[1])
+        return basis[:, :n_lock + n_act], lam[:n_lock + n_act], res[:n_act], n_lock, bool(counts[2])
 
     def eigh_top(self, S, r):
         """The r leading eigenpairs of symmetric PSD S: (evals desc [r], evecs [n x r]) — pk_eigh_top_f64 (one launch of a

@@ -160,13 +160,17 @@ def _refill(lay, X, V_lock, seed):
     return parts[0] if len(parts) == 1 else torch.cat(parts, dim=1).contiguous()
 
 
-def orthonormalize(lay, X, V_lock=None, seed=12345):
+def orthonormalize(lay, X, V_lock=None, seed=12345, defer=None, first_gram=None):
     """Orthonormal basis of span(X), orthogonal to V_lock.  Shifted CholeskyQR3: X <- X R^-1 with
     G + s I = R^T R three times (shift s = 11 (m l + l (l + 1)) u trace(G) on the first pass only), each
     pass one Gram matrix, one l x l Cholesky kernel and one tall-skinny GEMM — the filtered blocks have a
     condition number up to the filter spread (1e7), which the shifted first pass is made for.  The result is
     verified (||Y^T Y - I||): a block that is numerically rank-deficient — a Cholesky pivot breaks down, or the
-    three passes end without an orthonormal block — is rebuilt by `_refill`."""
+    three passes end without an orthonormal block — is rebuilt by `_refill`.
+    `defer` (a device tensor of 2 doubles): no host read here — the Cholesky verdicts are ADDED to defer[0] and the
+    orthonormality error is max-ed into defer[1]; the caller reads them when it next talks to the host anyway and owns
+    the consequences (block Lanczos: one read per convergence check).  `first_gram` (a list): receives the Gram matrix of
+    the block after its first projection — the coupling matrix of the Lanczos residual block."""
     if not isinstance(lay, ItemRows):     # a bare ops object: one process, whole blocks
         lay = ItemRows(lay, NoComm(), X.shape[0])
     ops = lay.ops
@@ -178,10 +182,16 @@ def orthonormalize(lay, X, V_lock=None, seed=12345):
         if V_lock is not None and V_lock.shape[1] > 0:
             Y = _project_out(lay, Y, V_lock)
         G = lay.gram(Y)
+        if p == 0 and first_gram is not None:
+            first_gram.append(G)
         Rinv, _ = ops.chol_rinv(G, 11.0 * (m * l + l * (l + 1)) * u if p == 0 else 0.0, info=info[p:p + 1])
         Y = ops.tsmm(Y, Rinv)
     G = lay.gram(Y)
     err = (G - torch.eye(l, dtype=G.dtype, device=G.device)).abs().max()
+    if defer is not None:
+        defer[0] += info.abs().sum().to(defer.dtype)
+        defer[1] = torch.maximum(defer[1], torch.nan_to_num(err, nan=1.0, posinf=1.0).to(defer.dtype))
+        return Y
     if int(info.abs().sum().item()) != 0 or not (float(err.item()) < 1e-8):
         return _refill(lay, X, V_lock, seed)
     return Y
@@ -199,49 +209,73 @@ def _cheb_degree(theta_top, b, spread, m_max):
     return max(2, min(m_max, m))
 
 
-def svd_topk(ops, A, k, block=None, tol=1e-12, max_outer=200, m_max=24, spread=1e7, seed=0,
-             comm=None, want_u=False, verbose=False, even_lock=True, shard_items=True):
-    """Returns (U_local | None, sigma[k] desc, V [n_items x k], stats) as device tensors of `ops`.
+class _Gramian:
+    """B = A^T A of the (row-sharded) sparse matrix: the operator of the build.  `ritz` hands back H = X^T B X together
+    with the carrier Y = A X, from which B (X C) = A^T (Y C) follows with ONE more product — Rayleigh-Ritz and the first
+    filter step share a Gramian step."""
 
-    A: ops-level CSR of the LOCAL row shard (n_local x n_items).  Convergence: every one of the k
-    leading Ritz pairs has ||B x - theta x|| <= tol * theta_1  (B = A^T A, theta = sigma^2).
-    """
-    comm = comm or NoComm()
-    n_items = A.shape[1]
-    if not (0 < k <= n_items):
-        raise ValueError('k must satisfy 0 < k <= n_items')
-    l = int(block or default_block(k, n_items))
-    l = max(k, min(l, n_items))
-    # the operator of Z = A^T Y: a device matrix offers its user-blocked transpose (ops.BlockedTranspose)
-    At = A.transpose_operator() if hasattr(A, 'transpose_operator') else A.T
+    def __init__(self, ops, A, At, lay, comm, stats):
+        self.ops, self.A, self.At, self.lay, self.comm, self.stats = ops, A, At, lay, comm, stats
 
-    lay = ItemRows(ops, comm, n_items, shard_items)
-    X = orthonormalize(lay, lay.randn(l, seed))
+    def _count(self, cols):
+        self.stats['gramian_steps'] += 1
+        self.stats['spmm_cols'] += cols
+
+    def ritz(self, X):
+        Y = self.ops.spmm(self.A, self.lay.full(X))
+        return self.comm.allreduce(self.ops.gram(Y)), Y
+
+    def rotate(self, Y, Cm):
+        Z = self.lay.product(self.At, self.ops.tsmm(Y, Cm))
+        self._count(Cm.shape[1])
+        return Z
+
+    def apply(self, X):
+        Z = self.lay.product(self.At, self.ops.spmm(self.A, self.lay.full(X)))
+        self._count(X.shape[1])
+        return Z
+
+
+class _Dense:
+    """A small symmetric PSD matrix T (replicated on every rank) as the operator: the projected problem of the block
+    Lanczos method.  T X = T^T X is one `gram` launch."""
+
+    def __init__(self, ops, T, stats):
+        self.ops, self.T, self.stats = ops, T, stats
+
+    def ritz(self, X):
+        Z = self.ops.gram(self.T, X)
+        H = self.ops.gram(X, Z)
+        self.stats['steps'] += 1
+        return 0.5 * (H + H.t()), Z
+
+    def rotate(self, Z, Cm):
+        return self.ops.tsmm(Z, Cm)
+
+    def apply(self, X):
+        self.stats['steps'] += 1
+        return self.ops.gram(self.T, X)
+
+
+def _subspace_iteration(op, lay, k, X, tol, max_outer, m_max, spread, seed, stats, verbose=False, even_lock=True,
+                        rank0=True):
+    """Chebyshev-filtered subspace iteration with locking on the operator `op` (ritz / rotate / apply), from the
+    orthonormal start block X (rows of `lay` x l).  Returns (basis [rows x >= k]: locked vectors then the active block,
+    Ritz values of the basis columns (host), residual norms of the active block (host), n_lock, converged)."""
+    ops = lay.ops
     V_lock = None
     lam_lock = []
     n_lock = 0
-    stats = dict(outer=0, gramian_steps=0, spmm_cols=0, degrees=[], locked_at=[], block=l, converged=False,
-                 item_rows_per_rank=lay.rows, items_sharded=lay.sharded)
     theta_host = res_host = None
-
-    def gramian(Xb):
-        Z = lay.product(At, ops.spmm(A, lay.full(Xb)))
-        stats['gramian_steps'] += 1
-        stats['spmm_cols'] += Xb.shape[1]
-        return Z
-
+    converged = False
     for it in range(max_outer):
-        stats['outer'] = it + 1
+        stats['outer'] = stats.get('outer', 0) + 1
         # ---- Rayleigh-Ritz on the active block ------------------------------------------------
-        Y = ops.spmm(A, lay.full(X))
-        H = comm.allreduce(ops.gram(Y))
+        H, carrier = op.ritz(X)
         theta, Cm = ops.eigh_psd(H)
         Cm = Cm.contiguous()
         X = ops.tsmm(X, Cm)
-        Y = ops.tsmm(Y, Cm)
-        Z = lay.product(At, Y)
-        stats['gramian_steps'] += 1
-        stats['spmm_cols'] += X.shape[1]
+        Z = op.rotate(carrier, Cm)
         res2 = lay.total(ops.resid_colnorm2(Z, X, theta))
         theta_host = ops.to_host(theta).astype(np.float64)
         res_host = np.sqrt(np.maximum(ops.to_host(res2), 0.0))
@@ -254,31 +288,28 @@ def svd_topk(ops, A, k, block=None, tol=1e-12, max_outer=200, m_max=24, spread=1
             n_new += 1
         if n_new < need and (n_new & 1) and even_lock:
             n_new -= 1       # keep the active block width even: odd widths fall off the paired-column SpMM kernel
-        if verbose and comm.rank == 0:
+        if verbose and rank0:
             worst = float(res_host[:max(need, 1)].max() / lam1) if need > 0 else 0.0
             print('[svd] it %3d lock %3d+%-3d active %3d  worst rel.res(first %d) %.2e' %
                   (it, n_lock, n_new, X.shape[1], need, worst))
         if n_new >= need:
-            # done: assemble the k leading vectors
-            take = need
-            Vk = X[:, :take] if V_lock is None else torch.cat([V_lock, X[:, :take]], dim=1)
-            lam_k = np.r_[np.asarray(lam_lock, dtype=np.float64), theta_host[:take]]
-            stats['converged'] = True
+            converged = True
             break
         if n_new > 0 and X.shape[1] - n_new >= max(8, need - n_new):
             newV = X[:, :n_new].contiguous()
             V_lock = newV if V_lock is None else torch.cat([V_lock, newV], dim=1).contiguous()
             lam_lock.extend(float(t) for t in theta_host[:n_new])
             n_lock += n_new
-            stats['locked_at'].append((it, n_lock))
+            stats.setdefault('locked_at', []).append((it, n_lock))
             X = X[:, n_new:].contiguous()
             Z = Z[:, n_new:].contiguous()
             theta_host = theta_host[n_new:]
+            res_host = res_host[n_new:]
         # ---- Chebyshev filter on P B P, damping [0, b] --------------------------------------------
         b = float(theta_host[-1])
         a0 = float(theta_host[0])
         m = _cheb_degree(a0, b, spread, m_max)
-        stats['degrees'].append(m)
+        stats.setdefault('degrees', []).append(m)
         e = 0.5 * b
         c = 0.5 * b
         if e <= 0.0 or a0 <= c:
@@ -292,7 +323,7 @@ def svd_topk(ops, A, k, block=None, tol=1e-12, max_outer=200, m_max=24, spread=1
             Yc = ops.axpbypcz(sigma / e, Zp, -c * sigma / e, Xc)
             for _ in range(2, m + 1):
                 sigma_new = 1.0 / (tau - sigma)
-                Zc = gramian(Yc)
+                Zc = op.apply(Yc)
                 if V_lock is not None:
                     Zc = _project_out(lay, Zc, V_lock)
                 Yn = ops.axpbypcz(2.0 * sigma_new / e, Zc, -2.0 * sigma_new * c / e, Yc,
@@ -300,21 +331,232 @@ def svd_topk(ops, A, k, block=None, tol=1e-12, max_outer=200, m_max=24, spread=1
                 Xc, Yc = Yc, Yn
                 sigma = sigma_new
         X = orthonormalize(lay, Yc, V_lock, seed=seed + 1 + it)
-    else:
-        # not converged: return the best available (flagged in stats)
-        take = min(k - n_lock, X.shape[1])
-        Vk = X[:, :take] if V_lock is None else torch.cat([V_lock, X[:, :take]], dim=1)
-        lam_k = np.r_[np.asarray(lam_lock, dtype=np.float64), theta_host[:take]]
+    basis = X if V_lock is None else torch.cat([V_lock, X], dim=1)
+    lam_all = np.r_[np.asarray(lam_lock, dtype=np.float64), theta_host]
+    return basis, lam_all, res_host, n_lock, converged
+
+
+def _next_lanczos_block(lay, W, Qall, C, flags):
+    """The next block of the Krylov basis from W = B Q_j and C = Q^T W (already all-reduced: the block column of T):
+    shifted CholeskyQR3 of the projected block, RE-projected against the whole basis in every pass — near convergence the
+    residual block has singular values over ten orders of magnitude, and what a pass scales up by 1/sigma it also scales up
+    along Q; a projection after the scaling is what keeps Q^T Q = I to rounding (`orthonormalize` does the same for the
+    filtered blocks).  Per pass: one Gram matrix against the basis, one fused `Z - Q C` product, one l x l Gram matrix,
+    one Cholesky kernel, one tall-skinny product.  No host read: the Cholesky verdicts and the distance of the last
+    pass's Gram matrix from I (a pass brings delta to ~delta^2) go to `flags`.
+    Returns (Q_next, S) with S = W_perp^T W_perp, the coupling behind the residuals of the Ritz pairs of T_j."""
+    ops = lay.ops
+    m, l = lay.n, W.shape[1]
+    u = 1.1102230246251565e-16
+    info = torch.zeros(3, dtype=torch.int32, device=W.device)
+    Y, S, G = W, None, None
+    for p in range(3):
+        Cp = C if p == 0 else lay.gram(Qall, Y)
+        Y = ops.tsmm_sub(Y, Qall, Cp, out=Y if p else None)
+        G = lay.gram(Y)
+        if p == 0:
+            S = G
+        Rinv, _ = ops.chol_rinv(G, 11.0 * (m * l + l * (l + 1)) * u if p == 0 else 0.0, info=info[p:p + 1])
+        Y = ops.tsmm(Y, Rinv)
+    err = (G - torch.eye(l, dtype=G.dtype, device=G.device)).abs().max()
+    flags[0] += info.abs().sum().to(flags.dtype)
+    flags[1] = torch.maximum(flags[1], torch.nan_to_num(err, nan=1.0, posinf=1.0).to(flags.dtype))
+    return Y, S
+
+
+class _LanczosBreakdown(RuntimeError):
+    """The block Krylov recurrence cannot continue (rank-deficient residual block, lost orthogonality, space exhausted):
+    `svd_topk` then runs the filtered subspace iteration, which has a rebuild path for exactly these matrices."""
+
+
+def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_steps, m_max, spread, even_lock):
+    """Block Lanczos on B = A^T A with FULL reorthogonalisation and Rayleigh-Ritz over the WHOLE Krylov space
+    span[X, B X, ..., B^(q-1) X] — the Krylov-class method behind the reference's `svds` (ARPACK: single-vector implicitly
+    restarted Lanczos on the same operator, models.py:844), in the block form a GPU wants.  One Gramian step per block:
+        W = B Q_j;   T[:, j] = Q^T W;   Q_(j+1) R = W - Q T[:, j]   (projection + shifted CholeskyQR3)
+    The projected matrix T = Q^T B Q (block tridiagonal up to rounding; every block column is COMPUTED, not assumed) is
+    a small dense symmetric matrix on the device; its k leading pairs come from the filtered subspace iteration below
+    with T as the operator (`_Dense`: a product is one small `gram` launch), warm-started from the previous check.  A
+    Ritz pair (theta, Q y) has the residual  Q (T y - theta y) + Q_(j+1) R y_last, so
+        ||B x - theta x||^2 = ||T y - theta y||^2 + y_last^T (W_perp^T W_perp) y_last
+    — everything in coefficient space; checks are scheduled by the observed convergence rate (each costs a few ms of small
+    launches, a Gramian step ~1 ms), and the accepted pairs are VERIFIED by one true product B V (same certificate as the
+    subspace iteration's: `final_rel_residual` is measured, not estimated).
+    On the ML-20M-shaped matrix, rank 50, block 64: 14 Gramian steps + 1 verification against 37 of the filtered
+    subspace iteration (the Krylov space keeps every block: its Ritz values beyond the block width deflate the tail of
+    the planted spectrum, which a fixed-width filter has to damp uniformly)."""
+    n = lay.n
+    b = l
+    qcap = n // b
+    if qcap < 4 or max_steps < 4:
+        raise _LanczosBreakdown('Krylov space of at most %d blocks' % qcap)
+    qcap = min(qcap, max_steps)
+    gop = _Gramian(ops, A, At, lay, comm, stats)
+    cap = min(qcap, 20)
+    Qbuf = ops.empty(lay.rows, cap * b)
+    T = ops.zeros(cap * b, cap * b)
+    flags = ops.zeros(2)                  # [sum of Cholesky verdicts, max orthonormality error] of the deferred passes
+    Q1 = orthonormalize(lay, lay.randn(b, seed))
+    Qbuf[:, :b] = Q1
+    warm = None
+    inner = dict(steps=0, outer=0, checks=0)
+    stats['nested'] = inner
+    hist = []                              # (step, worst relative residual of the k leading pairs)
+    first = max(4, -(-2 * k // b) + 2)
+    next_check = min(first, qcap)
+    est_tol = tol
+    result = None
+    j = 0
+    while j < qcap:
+        j += 1
+        N = j * b
+        if min(j + 1, qcap) * b > Qbuf.shape[1]:      # grow the basis and the projected matrix (rare: slow convergence)
+            cap2 = min(qcap, max(j + 1, int(1.5 * cap) + 1))
+            Qn_, Tn_ = ops.empty(lay.rows, cap2 * b), ops.zeros(cap2 * b, cap2 * b)
+            Qn_[:, :cap * b] = Qbuf
+            Tn_[:cap * b, :cap * b] = T
+            Qbuf, T, cap = Qn_, Tn_, cap2
+        Qj = Qbuf[:, N - b:N].contiguous()
+        W = gop.apply(Qj)
+        Qall = Qbuf[:, :N]
+        C = lay.gram(Qall, W)                                      # block column j of T, rows of all blocks so far
+        T[:N, N - b:N] = C
+        T[N - b:N, :N - b] = C[:N - b].t()
+        last = j == qcap
+        if not last:
+            Qnext, S = _next_lanczos_block(lay, W, Qall, C, flags)
+            Qbuf[:, N:N + b] = Qnext
+        if j != next_check and not last:
+            continue
+        # ---- convergence check: the k leading Ritz pairs of T_j and their residuals ------------------------------
+        if last:                           # the last block the space can hold: the coupling of W_perp directly
+            S = lay.gram(ops.tsmm_sub(W, Qall, C))
+        Tj = T[:N, :N]
+        Tj = (0.5 * (Tj + Tj.t())).contiguous()
+        fl = ops.to_host(flags)
+        if fl[0] != 0 or not (fl[1] < 1e-4):     # the Gram matrix BEFORE the last pass: 1e-4 there is 1e-8 after it
+            raise _LanczosBreakdown('residual block lost rank at step <= %d (Cholesky verdicts %g, orthonormality %.1e)' % (j, fl[0], fl[1]))
+        inner['checks'] += 1
+        X0 = warm            # rows beyond the previous check's dimension are zero; None: the first b unit vectors —
+        if X0 is None:       # orthonormal, and the seed of this very Krylov space
+            X0 = ops.zeros(b, b)
+            X0[:b] = torch.eye(b, dtype=X0.dtype, device=X0.device)
+        # The pairs of T_j in stages: while the outer method is far from converged an ESTIMATE of the residuals is all a
+        # check needs, so the nested iteration first runs to a loose tolerance and is tightened (warm) only while its own
+        # residual, not the coupling to the next block, is what limits the estimate.
+        t_in = max(0.125 * est_tol, 1e-4 if not hist else 0.03 * hist[-1][1])
+        while True:
+            basis, lam_all, res_in, n_lock, conv_in = ops.sym_eig_topk(Tj, k, X0, t_in, 200, seed + 1000 * j, inner)
+            X0 = basis.contiguous()
+            Yk = X0[:, :k].contiguous()
+            TY = ops.gram(Tj, Yk)
+            lam_k = torch.as_tensor(lam_all[:k].copy(), device=Yk.device)
+            r_in2 = ops.resid_colnorm2(TY, Yk, lam_k)
+            yl = Yk[N - b:].contiguous()
+            c2 = (yl * ops.small_mm(S, yl)).sum(0)
+            both = ops.to_host(torch.stack([r_in2, c2]))
+            lam1 = max(float(lam_all[0]), 1e-300)
+            est = np.sqrt(np.maximum(both[0] + both[1], 0.0)) / lam1
+            coupling = float(np.sqrt(max(both[1].max(), 0.0)) / lam1)
+            if t_in <= 0.125 * est_tol or coupling >= 4.0 * t_in or not conv_in:
+                break
+            t_in = max(0.125 * est_tol, 0.1 * coupling)
+        warm = X0
+        worst = float(est.max())
+        hist.append((j, worst))
+        if verbose and comm.rank == 0:
+            print('[svd] lanczos step %2d  dim %4d  worst rel.res (first %d) %.2e  nested: %d outer, %d products, inner converged %s'
+                  % (j, N, k, worst, inner['outer'], inner['steps'], conv_in))
+        if worst <= est_tol and conv_in:
+            # ---- verification: one true product on the k Ritz vectors -----------------------------------------
+            Vk = ops.tsmm(Qall, Yk)
+            Z = gop.apply(Vk)
+            res2 = lay.total(ops.resid_colnorm2(Z, Vk, lam_k))
+            res_true = np.sqrt(np.maximum(ops.to_host(res2), 0.0)) / max(float(lam_all[0]), 1e-300)
+            stats['verified_rel_residual'] = float(res_true.max())
+            if float(res_true.max()) <= tol:
+                result = (Vk, lam_all[:k].copy(), res_true * float(lam_all[0]))
+                break
+            est_tol *= 0.1                 # the estimate was optimistic (orthogonality): ask for more, keep going
+        if last:
+            break
+        # ---- schedule the next check by the observed rate ------------------------------------------------------
+        rate = 1.6                         # natural log per step until two checks have been seen (~ x5 per step)
+        if len(hist) >= 2 and hist[-2][1] > hist[-1][1] > 0:
+            rate = max(0.4, np.log(hist[-2][1] / hist[-1][1]) / (hist[-1][0] - hist[-2][0]))
+        remaining = np.log(max(worst, est_tol) / est_tol) / rate
+        if len(hist) < 2:
+            remaining *= 0.5               # one point says nothing about the rate: look again half way
+        next_check = min(qcap, j + max(1, int(remaining)))
+    stats['lanczos_steps'] = j
+    stats['outer'] = len(hist)
+    stats['krylov_dim'] = j * b
+    stats['checks'] = hist
+    if result is None:
+        raise _LanczosBreakdown('not converged in %d blocks' % j)
+    return result
+
+
+def svd_topk(ops, A, k, block=None, tol=1e-12, max_outer=200, m_max=24, spread=1e7, seed=0,
+             comm=None, want_u=False, verbose=False, even_lock=True, shard_items=True, method=None, max_steps=64):
+    """Returns (U_local | None, sigma[k] desc, V [n_items x k], stats) as device tensors of `ops`.
+
+    A: ops-level CSR of the LOCAL row shard (n_local x n_items).  Convergence: every one of the k
+    leading Ritz pairs has ||B x - theta x|| <= tol * theta_1  (B = A^T A, theta = sigma^2), measured on a true product.
+    method: 'lanczos' (default; PK_SVD_METHOD overrides) = block Lanczos with full reorthogonalisation and Rayleigh-Ritz
+    over the whole Krylov space (`_block_lanczos`), falling back to 'subspace' = Chebyshev-filtered subspace iteration
+    with locking (`_subspace_iteration`) when the recurrence breaks down (rank-deficient matrices, tiny item counts).
+    """
+    import os
+    comm = comm or NoComm()
+    n_items = A.shape[1]
+    if not (0 < k <= n_items):
+        raise ValueError('k must satisfy 0 < k <= n_items')
+    l = int(block or default_block(k, n_items))
+    l = max(k, min(l, n_items))
+    method = method or os.environ.get('PK_SVD_METHOD', 'lanczos')
+    if method not in ('lanczos', 'subspace'):
+        raise ValueError("method must be 'lanczos' or 'subspace'")
+    # the operator of Z = A^T Y: a device matrix offers its user-blocked transpose (ops.BlockedTranspose)
+    At = A.transpose_operator() if hasattr(A, 'transpose_operator') else A.T
+
+    lay = ItemRows(ops, comm, n_items, shard_items)
+    stats = dict(outer=0, gramian_steps=0, spmm_cols=0, degrees=[], locked_at=[], block=l, converged=False,
+                 item_rows_per_rank=lay.rows, items_sharded=lay.sharded, method=method)
+    Vk = lam_k = res_k = None
+    if method == 'lanczos':
+        try:
+            # `max_outer` bounds the work of either method: an outer iteration of the subspace method is worth a few blocks
+            Vk, lam_k, res_k = _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose,
+                                              min(max_steps, 4 * max_outer), m_max, spread, even_lock)
+            stats['converged'] = True
+        except _LanczosBreakdown as exc:
+            stats['lanczos_fallback'] = str(exc)
+            stats['method'] = 'subspace (after a Lanczos breakdown)'
+            if verbose and comm.rank == 0:
+                print('[svd] block Lanczos gave up (%s): filtered subspace iteration' % exc)
+    if Vk is None:
+        X = orthonormalize(lay, lay.randn(l, seed))
+        gop = _Gramian(ops, A, At, lay, comm, stats)
+        basis, lam_all, res_act, n_lock, conv = _subspace_iteration(
+            gop, lay, k, X, tol, max_outer, m_max, spread, seed, stats, verbose=verbose, even_lock=even_lock,
+            rank0=comm.rank == 0)
+        stats['converged'] = bool(conv)
+        take = min(k, basis.shape[1])
+        Vk = basis[:, :take]
+        lam_k = lam_all[:take]
+        # residuals of the k leading pairs: locked pairs are below tol by construction
+        res_k = res_act[:max(1, min(k - n_lock, len(res_act)))]
 
     Vk = lay.full(Vk[:, :k].contiguous()).contiguous()      # the factors are replicated: scoring needs every item row
-    lam_k = np.maximum(lam_k[:k], 0.0)
+    lam_k = np.maximum(np.asarray(lam_k, dtype=np.float64)[:k], 0.0)
     order = np.argsort(-lam_k, kind='stable')
     if not np.array_equal(order, np.arange(len(order))):
         Vk = Vk[:, torch.as_tensor(order, device=Vk.device)].contiguous()
         lam_k = lam_k[order]
     sigma_k = np.sqrt(lam_k)
-    # residual of the worst of the k leading pairs relative to theta_1 (locked pairs are below tol by construction)
-    stats['final_rel_residual'] = float(res_host[:max(1, min(k - n_lock, len(res_host)))].max() / max(lam_k[0], 1e-300))
+    # residual of the worst of the k leading pairs relative to theta_1
+    stats['final_rel_residual'] = float(np.max(res_k) / max(lam_k[0], 1e-300))
     stats['tol'] = tol
     U = None
     if want_u:

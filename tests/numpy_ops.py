@@ -46,7 +46,13 @@ class NumpyOps:
         return torch.zeros(*shape, dtype=dtype)
 
     def to_device(self, a, dtype=None):
-        t = torch.as_tensor(np.ascontiguousarray(a))
+        a = np.ascontiguousarray(a)
+        import warnings
+        with warnings.catch_warnings():
+            # ArrayData stores read-only views of the caller's columns; torch warns that a tensor over one must not be
+            # written to — it is only the source of the copy below
+            warnings.simplefilter('ignore', UserWarning)
+            t = torch.as_tensor(a)
         return t.to(dtype) if dtype is not None else t
 
     def to_host(self, t):
@@ -107,6 +113,29 @@ class NumpyOps:
         w = np.maximum(w[::-1], 0.0).copy()
         v = v[:, ::-1].copy()
         return torch.from_numpy(w), torch.from_numpy(v)
+
+    def tsmm_sub(self, Z, X, Cm, out=None):
+        r = Z - X @ Cm
+        if out is not None:
+            out.copy_(r)
+            return out
+        return r
+
+    def sym_eig_topk(self, T, k, X0=None, tol=1e-13, max_outer=200, seed=0, stats=None):
+        # the product path runs this loop in C++ (pk_sym_eig_topk_f64); the double runs the Python statement of it
+        from polara_amd.solver import _subspace_iteration, _Dense, ItemRows, NoComm
+        n = T.shape[0]
+        if X0 is None:
+            l = min(n, max(int(k), 8))
+            X = torch.zeros(n, l, dtype=torch.float64)
+            X[:l] = torch.eye(l, dtype=torch.float64)
+        else:
+            X = torch.zeros(n, X0.shape[1], dtype=torch.float64)
+            X[:X0.shape[0]] = X0
+        st = stats if stats is not None else {}
+        st.setdefault('steps', 0)
+        return _subspace_iteration(_Dense(self, T.contiguous(), st), ItemRows(self, NoComm(), n), k, X, tol, max_outer, 24, 1e7,
+                                   seed, st, even_lock=False)
 
     def eigh_top(self, S, r):
         lam, C = self.eigh_psd(S)
