@@ -442,7 +442,7 @@ class Bench:
         # inside this loop with its result copies and DEPTH-deep throttle; profiles/r03_two_stream_passes_ml20m.txt) needs
         # the pass streams and the copy stream on different hardware queues and no instantiated graph around; it is only
         # taken when the warm-up shows a clear gain over the serial loop
-        if best == 'pipelined' and cal['pipelined'] > 0.93 * cal['serial']:
+        if best == 'pipelined' and cal['pipelined'] > 0.97 * cal['serial']:
             best = min([m for m in modes if m != 'pipelined'], key=lambda m: cal[m])
         use_cap = set_mode(best)
         self.launch_mode = {'graph': 'hipGraph replay of the captured pass',

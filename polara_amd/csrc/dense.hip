@@ -14,10 +14,17 @@ static int gram_splits(int64_t n, int la, int lb) {
     // least 64 rows per split; the partial tiles are added by gram_reduce_kernel in split order (deterministic).
     // (105 splits of 256 rows left 60 % of the CUs idle at n_items = 26 744, l = 64: 52 + 38 us per Gram matrix.)
     int64_t tiles = pk_ceil_div(la, 64) * pk_ceil_div(lb, 64);
-    int64_t s = pk_ceil_div(2048, tiles);
+    // wide left operands (block Lanczos: the whole Krylov basis against one block): every split writes la x lb partial
+    // sums, so half as many workgroups there — 147 splits of a 896 x 64 product wrote and re-read 2 x 67 MB of partials
+    // next to 110 MB of operands
+    int64_t s = pk_ceil_div(tiles >= 4 ? 1024 : 2048, tiles);
     int64_t max_by_rows = pk_ceil_div(n, 64);
     if (s > max_by_rows) s = max_by_rows;
     if (s > 1024) s = 1024;
+    // at most two steps of rows: ONE pass, the workgroup of a tile writes it — no partial sums, no reduce launch.  (Tried
+    // for every product of <= 1024 rows — the projected problems of the block Lanczos build: a single workgroup walking
+    // 896 rows is slower than 14 of them and a reduce launch: nested solve 34 -> 39.7 ms per build.)
+    if (n <= 64) s = 1;
     if (s < 1) s = 1;
     return (int)s;
 }
@@ -39,8 +46,11 @@ __global__ __launch_bounds__(256) void gram_kernel(int64_t n, int la, int lb, co
                                                    int64_t lda, const double *__restrict__ B, int64_t ldb,
                                                    double *__restrict__ partial, int tiles_j,
                                                    int64_t rows_per_split) {
-    __shared__ double sA[16][64];
-    __shared__ double sB[16][64];
+    // Round 4: 32 rows per step, the rows of step t + 1 requested (16-byte loads into registers) before the products of
+    // step t (the first version loaded 16 rows with 8-byte loads, synchronised, multiplied, synchronised)
+    constexpr int RT = 32;
+    __shared__ __attribute__((aligned(16))) double sA[RT][64];
+    __shared__ __attribute__((aligned(16))) double sB[RT][64];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int ti = blockIdx.x / tiles_j, tj = blockIdx.x % tiles_j;
@@ -48,23 +58,48 @@ __global__ __launch_bounds__(256) void gram_kernel(int64_t n, int la, int lb, co
     const int64_t r_begin = (int64_t)split * rows_per_split;
     int64_t r_end = r_begin + rows_per_split;
     if (r_end > n) r_end = n;
+    const bool vec = ((lda | ldb) & 1) == 0 && ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0 && (la & 1) == 0 && (lb & 1) == 0;
     f64x4 acc[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[b] = f64x4{0.0, 0.0, 0.0, 0.0};
-
-    for (int64_t r0 = r_begin; r0 < r_end; r0 += 16) {
+    double2 ra[4], rb[4];          // slot = tid + 256 q: row = slot >> 5, column pair = slot & 31
+    auto fetch = [&](int64_t r0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            int idx = tid + 256 * q;
-            int rr = idx >> 6, c = idx & 63;
-            int64_t row = r0 + rr;
-            int ca = ti * 64 + c, cb = tj * 64 + c;
-            sA[rr][c] = (row < r_end && ca < la) ? A[row * lda + ca] : 0.0;
-            sB[rr][c] = (row < r_end && cb < lb) ? B[row * ldb + cb] : 0.0;
+            const int slot = tid + 256 * q;
+            const int rr = slot >> 5, c = (slot & 31) * 2;
+            const int64_t row = r0 + rr;
+            const int ca = ti * 64 + c, cb = tj * 64 + c;
+            double2 va = make_double2(0.0, 0.0), vb = make_double2(0.0, 0.0);
+            if (row < r_end) {
+                const double *pa = A + row * lda + ca, *pb = B + row * ldb + cb;
+                if (vec && ca + 1 < la) va = *reinterpret_cast<const double2 *>(pa);
+                else {
+                    if (ca < la) va.x = pa[0];
+                    if (ca + 1 < la) va.y = pa[1];
+                }
+                if (vec && cb + 1 < lb) vb = *reinterpret_cast<const double2 *>(pb);
+                else {
+                    if (cb < lb) vb.x = pb[0];
+                    if (cb + 1 < lb) vb.y = pb[1];
+                }
+            }
+            ra[q] = va;
+            rb[q] = vb;
+        }
+    };
+    if (r_begin < r_end) fetch(r_begin);
+    for (int64_t r0 = r_begin; r0 < r_end; r0 += RT) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int slot = tid + 256 * q;
+            *reinterpret_cast<double2 *>(&sA[slot >> 5][(slot & 31) * 2]) = ra[q];
+            *reinterpret_cast<double2 *>(&sB[slot >> 5][(slot & 31) * 2]) = rb[q];
         }
         __syncthreads();
+        if (r0 + RT < r_end) fetch(r0 + RT);
 #pragma unroll
-        for (int k0 = 0; k0 < 16; k0 += 4) {
+        for (int k0 = 0; k0 < RT; k0 += 4) {
             const double p = sA[k0 + (lane >> 4)][16 * wave + (lane & 15)];
 #pragma unroll
             for (int b = 0; b < 4; ++b)
@@ -117,7 +152,13 @@ extern "C" int pk_gram_f64(void *stream, int64_t n, int32_t la, int32_t lb, cons
     const int splits = gram_splits(n, la, lb);
     const int tiles_i = (int)pk_ceil_div(la, 64), tiles_j = (int)pk_ceil_div(lb, 64);
     int64_t rows_per_split = pk_ceil_div(n, splits);
-    rows_per_split = pk_ceil_div(rows_per_split, 16) * 16;
+    rows_per_split = pk_ceil_div(rows_per_split, 32) * 32;
+    if (splits == 1 && ldg == lb) {       // single pass straight into G (the partial layout of split 0 IS G when ldg = lb)
+        hipLaunchKernelGGL(gram_kernel, dim3(tiles_i * tiles_j, 1), dim3(256), 0, st, n, la, lb, A_dev, lda,
+                           B_dev, ldb, G_dev, tiles_j, rows_per_split);
+        PK_CHECK_LAUNCH("gram_kernel");
+        return PK_OK;
+    }
     hipLaunchKernelGGL(gram_kernel, dim3(tiles_i * tiles_j, splits), dim3(256), 0, st, n, la, lb, A_dev, lda,
                        B_dev, ldb, static_cast<double *>(work_dev), tiles_j, rows_per_split);
     PK_CHECK_LAUNCH("gram_kernel");
@@ -128,41 +169,83 @@ extern "C" int pk_gram_f64(void *stream, int64_t n, int32_t la, int32_t lb, cons
 }
 
 // ------------------------------------------------------------------------------------------ tsmm
-// block computes 64 rows x 64 output columns; k advanced 16 at a time through LDS; the products run on the fp64 matrix
+// block computes 64 rows x 64 output columns; k advanced 32 at a time through LDS; the products run on the fp64 matrix
 // cores (v_mfma_f64_16x16x4_f64, layout in gram_kernel): wave w owns rows [16 w, 16 w + 16) of the block, P[i][k] =
-// sX[16 w + i][k0 + k] (row stride 17: the 16 rows of a quarter-wave fall into different banks), Q[k][j] = sC[k0 + k][16 b + j].
+// sX[16 w + i][k0 + k] (row stride 33: the 16 rows of a quarter-wave fall into different banks), Q[k][j] = sC[k0 + k][16 b + j].
+// Round 4: the tile of step t + 1 is requested (16-byte loads into registers) BEFORE the products of step t, and stored to
+// LDS after them.  The first version loaded, synchronised, multiplied, synchronised: with n / 16 waves in all (1.6 per SIMD
+// at 26 744 rows) nothing covered the load latency — 117 us for a 26 744 x 448 operand (0.8 TB/s), three times per block of
+// the block Lanczos build (re-orthogonalisation against the whole Krylov basis).
 template <bool SUB>
 __global__ __launch_bounds__(256) void tsmm_kernel(int64_t n, int lin, int lout, const double *__restrict__ X,
                                                    int64_t ldx, const double *__restrict__ C, int64_t ldc,
                                                    double *__restrict__ out, int64_t ldo, const double *__restrict__ Zin,
                                                    int64_t ldz) {
-    __shared__ double sX[64][17];
-    __shared__ double sC[16][64];
+    constexpr int KT = 32;
+    __shared__ double sX[64][KT + 1];
+    __shared__ __attribute__((aligned(16))) double sC[KT][64];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int64_t row0 = (int64_t)blockIdx.x * 64;
     const int col0 = blockIdx.y * 64;
+    // 16-byte loads need even offsets: ldx / ldc even and 16-byte aligned bases (checked by the launcher: VEC)
+    const bool vec = ((ldx | ldc) & 1) == 0 && ((((uintptr_t)X) | ((uintptr_t)C)) & 15) == 0 && (lin & 1) == 0 && (lout & 1) == 0;
     f64x4 acc[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[b] = f64x4{0.0, 0.0, 0.0, 0.0};
-
-    for (int k0 = 0; k0 < lin; k0 += 16) {
+    // per thread and k-tile: 4 double2 of X (slot = tid + 256 q: row = slot >> 4, k pair = slot & 15) and 4 double2 of C
+    // (slot: k = slot >> 5, column pair = slot & 31)
+    double2 rx[4], rc[4];
+    auto fetch = [&](int k0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            int idx = tid + 256 * q;
+            const int slot = tid + 256 * q;
             {
-                int r = idx >> 4, kk = idx & 15;
-                int64_t row = row0 + r;
-                sX[r][kk] = (row < n && k0 + kk < lin) ? X[row * ldx + k0 + kk] : 0.0;
+                const int r = slot >> 4, kk = (slot & 15) * 2;
+                const int64_t row = row0 + r;
+                double2 v = make_double2(0.0, 0.0);
+                if (row < n) {
+                    const double *src = X + row * ldx + k0 + kk;
+                    if (vec && k0 + kk + 1 < lin) v = *reinterpret_cast<const double2 *>(src);
+                    else {
+                        if (k0 + kk < lin) v.x = src[0];
+                        if (k0 + kk + 1 < lin) v.y = src[1];
+                    }
+                }
+                rx[q] = v;
             }
             {
-                int kk = idx >> 6, c = idx & 63;
-                sC[kk][c] = (k0 + kk < lin && col0 + c < lout) ? C[(int64_t)(k0 + kk) * ldc + col0 + c] : 0.0;
+                const int kk = slot >> 5, c = (slot & 31) * 2;
+                double2 v = make_double2(0.0, 0.0);
+                if (k0 + kk < lin) {
+                    const double *src = C + (int64_t)(k0 + kk) * ldc + col0 + c;
+                    if (vec && col0 + c + 1 < lout) v = *reinterpret_cast<const double2 *>(src);
+                    else {
+                        if (col0 + c < lout) v.x = src[0];
+                        if (col0 + c + 1 < lout) v.y = src[1];
+                    }
+                }
+                rc[q] = v;
             }
         }
-        __syncthreads();
+    };
+    auto stage = [&]() {
 #pragma unroll
-        for (int kk = 0; kk < 16; kk += 4) {
+        for (int q = 0; q < 4; ++q) {
+            const int slot = tid + 256 * q;
+            const int r = slot >> 4, kk = (slot & 15) * 2;
+            sX[r][kk] = rx[q].x;
+            sX[r][kk + 1] = rx[q].y;
+            *reinterpret_cast<double2 *>(&sC[slot >> 5][(slot & 31) * 2]) = rc[q];
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < lin; k0 += KT) {
+        stage();
+        __syncthreads();
+        if (k0 + KT < lin) fetch(k0 + KT);          // in flight during the products below
+#pragma unroll
+        for (int kk = 0; kk < KT; kk += 4) {
             const double p = sX[16 * wave + (lane & 15)][kk + (lane >> 4)];
 #pragma unroll
             for (int b = 0; b < 4; ++b)

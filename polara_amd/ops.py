@@ -587,11 +587,17 @@ class HipOps:
         n, la = A.shape
         lb = B.shape[1]
         need = self.lib.pk_gram_work_bytes(n, la, lb)
-        if self._gram_work is None or self._gram_work.numel() * 8 < need:
-            self._gram_work = self.empty((need + 7) // 8)
+        # the partial sums of the row splits: one scratch buffer PER STREAM (a monitor of the block Lanczos build runs its
+        # small Gram products on a side stream while the main stream's are in flight)
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        if self._gram_work is None:
+            self._gram_work = {}
+        work = self._gram_work.get(key)
+        if work is None or work.numel() * 8 < need:
+            work = self._gram_work[key] = self.empty((need + 7) // 8)
         G = self.empty(la, lb)
         _lib.check(self.lib.pk_gram_f64(self.stream(), n, la, lb, _ptr(A), A.stride(0), _ptr(B), B.stride(0),
-                                        _ptr(G), G.stride(0), _ptr(self._gram_work)), 'pk_gram_f64')
+                                        _ptr(G), G.stride(0), _ptr(work)), 'pk_gram_f64')
         return G
 
     def tsmm(self, X, Cm, out=None):

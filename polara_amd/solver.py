@@ -369,22 +369,96 @@ class _LanczosBreakdown(RuntimeError):
     `svd_topk` then runs the filtered subspace iteration, which has a rebuild path for exactly these matrices."""
 
 
+def _ritz_check(ops, Tj, S, X0, k, b, est_tol, prior, seed, inner):
+    """The k leading Ritz pairs of T_j and estimates of their residuals (one per pair, relative to theta_1).
+    The pairs come in stages: while the outer method is far from converged an ESTIMATE is all a check needs, so the nested
+    iteration first runs to a loose tolerance and is tightened (warm) only while its own residual, not the coupling to the
+    next block, is what limits the estimate.  Returns dict(est, coupling, conv, basis, lam_all, Yk, lam_k)."""
+    N = Tj.shape[0]
+    if X0 is None:           # the first b unit vectors: orthonormal, and the seed of this very Krylov space
+        X0 = ops.zeros(b, b)
+        X0[:b] = torch.eye(b, dtype=X0.dtype, device=X0.device)
+    t_in = max(0.3 * est_tol, 1e-4 if prior is None else 0.03 * prior)
+    while True:
+        basis, lam_all, res_in, n_lock, conv_in = ops.sym_eig_topk(Tj, k, X0, t_in, 200, seed, inner)
+        X0 = basis.contiguous()
+        Yk = X0[:, :k].contiguous()
+        TY = ops.gram(Tj, Yk)
+        lam_k = torch.as_tensor(lam_all[:k].copy(), device=Yk.device)
+        r_in2 = ops.resid_colnorm2(TY, Yk, lam_k)
+        yl = Yk[N - b:].contiguous()
+        c2 = (yl * ops.small_mm(S, yl)).sum(0)
+        both = ops.to_host(torch.stack([r_in2, c2]))
+        lam1 = max(float(lam_all[0]), 1e-300)
+        est = np.sqrt(np.maximum(both[0] + both[1], 0.0)) / lam1
+        coupling = float(np.sqrt(max(both[1].max(), 0.0)) / lam1)
+        if t_in <= 0.3 * est_tol or coupling >= 4.0 * t_in or not conv_in:
+            break
+        t_in = max(0.3 * est_tol, 0.1 * coupling)
+    return dict(est=est, worst=float(est.max()), coupling=coupling, conv=bool(conv_in), basis=X0, lam_all=lam_all, Yk=Yk,
+                lam_k=lam_k)
+
+
+class _Monitor:
+    """A convergence check of the block Lanczos build that runs NEXT TO the following Gramian steps: a worker thread
+    drives the nested solve (one C call that releases the interpreter lock, hundreds of microsecond kernels) on a side
+    stream while the main thread keeps enqueueing the sparse products, which leave most of the chip's launch slots to it.
+    The result is collected at a FIXED number of steps after the launch (blocking if need be), so every rank of a sharded
+    build takes its decisions at the same steps from the same numbers."""
+
+    def __init__(self, ops, j, Tj, S, X0, k, b, est_tol, prior, seed, inner):
+        import threading
+        self.j = j
+        self.out = self.err = None
+        dev = getattr(ops, 'device', None)
+        cuda = dev is not None and getattr(dev, 'type', 'cpu') == 'cuda'
+        side = None
+        if cuda:
+            side = ops.aux_streams(1)[0]
+            side.wait_stream(torch.cuda.current_stream(dev))      # the snapshot of T_j and S is complete
+            for t in (Tj, S, X0):
+                if t is not None:
+                    t.record_stream(side)
+
+        def work():
+            try:
+                if cuda:
+                    torch.cuda.set_device(dev)
+                    with torch.cuda.stream(side):
+                        self.out = _ritz_check(ops, Tj, S, X0, k, b, est_tol, prior, seed, inner)
+                        side.synchronize()
+                else:
+                    self.out = _ritz_check(ops, Tj, S, X0, k, b, est_tol, prior, seed, inner)
+            except BaseException as exc:        # re-raised by join() in the thread that owns the build
+                self.err = exc
+        self.thread = threading.Thread(target=work, name='pk-lanczos-monitor', daemon=True)
+        self.thread.start()
+
+    def join(self):
+        self.thread.join()
+        if self.err is not None:
+            raise self.err
+        return self.out
+
+
 def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_steps, m_max, spread, even_lock):
     """Block Lanczos on B = A^T A with FULL reorthogonalisation and Rayleigh-Ritz over the WHOLE Krylov space
     span[X, B X, ..., B^(q-1) X] — the Krylov-class method behind the reference's `svds` (ARPACK: single-vector implicitly
     restarted Lanczos on the same operator, models.py:844), in the block form a GPU wants.  One Gramian step per block:
-        W = B Q_j;   T[:, j] = Q^T W;   Q_(j+1) R = W - Q T[:, j]   (projection + shifted CholeskyQR3)
+        W = B Q_j;   T[:, j] = Q^T W;   Q_(j+1) R = W - Q T[:, j]   (projection + shifted CholeskyQR3, `_next_lanczos_block`)
     The projected matrix T = Q^T B Q (block tridiagonal up to rounding; every block column is COMPUTED, not assumed) is
-    a small dense symmetric matrix on the device; its k leading pairs come from the filtered subspace iteration below
-    with T as the operator (`_Dense`: a product is one small `gram` launch), warm-started from the previous check.  A
-    Ritz pair (theta, Q y) has the residual  Q (T y - theta y) + Q_(j+1) R y_last, so
+    a small dense symmetric matrix on the device; its k leading pairs come from the filtered subspace iteration with T as
+    the operator (`ops.sym_eig_topk`: driven from C++, warm-started from the previous check).  A Ritz pair (theta, Q y) has
+    the residual  Q (T y - theta y) + Q_(j+1) R y_last, so
         ||B x - theta x||^2 = ||T y - theta y||^2 + y_last^T (W_perp^T W_perp) y_last
-    — everything in coefficient space; checks are scheduled by the observed convergence rate (each costs a few ms of small
-    launches, a Gramian step ~1 ms), and the accepted pairs are VERIFIED by one true product B V (same certificate as the
-    subspace iteration's: `final_rel_residual` is measured, not estimated).
+    — everything in coefficient space.  Checks while the method is still far from converged are MONITORS: they run on a side
+    stream next to the following Gramian steps (`_Monitor`) and only serve to predict the step at which the pairs will
+    have converged; at that step the pairs are computed on the main stream (warm from the last monitor) and VERIFIED by one
+    true product B V (same certificate as the subspace iteration's: `final_rel_residual` is measured, not estimated).
     On the ML-20M-shaped matrix, rank 50, block 64: 14 Gramian steps + 1 verification against 37 of the filtered
     subspace iteration (the Krylov space keeps every block: its Ritz values beyond the block width deflate the tail of
     the planted spectrum, which a fixed-width filter has to damp uniformly)."""
+    import os
     n = lay.n
     b = l
     qcap = n // b
@@ -395,99 +469,118 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
     cap = min(qcap, 20)
     Qbuf = ops.empty(lay.rows, cap * b)
     T = ops.zeros(cap * b, cap * b)
-    flags = ops.zeros(2)                  # [sum of Cholesky verdicts, max orthonormality error] of the deferred passes
+    flags = ops.zeros(2)                  # [sum of Cholesky verdicts, max distance of the last pass's Gram matrix from I]
     Q1 = orthonormalize(lay, lay.randn(b, seed))
     Qbuf[:, :b] = Q1
     warm = None
     inner = dict(steps=0, outer=0, checks=0)
     stats['nested'] = inner
-    hist = []                              # (step, worst relative residual of the k leading pairs)
+    hist = []                              # (step, worst relative residual estimate of the k leading pairs)
+    LAG = int(os.environ.get('PK_LANCZOS_LAG', '3'))          # steps between the launch of a monitor and its collection
+    use_monitor = LAG > 0
     first = max(4, -(-2 * k // b) + 2)
-    next_check = min(first, qcap)
+    next_look = min(first, qcap)           # the step of the next monitor, or of the final check once the rate is known
+    look_is_final = not use_monitor
     est_tol = tol
     result = None
+    monitor = None
     j = 0
-    while j < qcap:
-        j += 1
-        N = j * b
-        if min(j + 1, qcap) * b > Qbuf.shape[1]:      # grow the basis and the projected matrix (rare: slow convergence)
-            cap2 = min(qcap, max(j + 1, int(1.5 * cap) + 1))
-            Qn_, Tn_ = ops.empty(lay.rows, cap2 * b), ops.zeros(cap2 * b, cap2 * b)
-            Qn_[:, :cap * b] = Qbuf
-            Tn_[:cap * b, :cap * b] = T
-            Qbuf, T, cap = Qn_, Tn_, cap2
-        Qj = Qbuf[:, N - b:N].contiguous()
-        W = gop.apply(Qj)
-        Qall = Qbuf[:, :N]
-        C = lay.gram(Qall, W)                                      # block column j of T, rows of all blocks so far
-        T[:N, N - b:N] = C
-        T[N - b:N, :N - b] = C[:N - b].t()
-        last = j == qcap
-        if not last:
-            Qnext, S = _next_lanczos_block(lay, W, Qall, C, flags)
-            Qbuf[:, N:N + b] = Qnext
-        if j != next_check and not last:
-            continue
-        # ---- convergence check: the k leading Ritz pairs of T_j and their residuals ------------------------------
-        if last:                           # the last block the space can hold: the coupling of W_perp directly
-            S = lay.gram(ops.tsmm_sub(W, Qall, C))
+
+    def snapshot(N):
         Tj = T[:N, :N]
-        Tj = (0.5 * (Tj + Tj.t())).contiguous()
+        return (0.5 * (Tj + Tj.t())).contiguous()
+
+    def breakdown_check(j):
         fl = ops.to_host(flags)
         if fl[0] != 0 or not (fl[1] < 1e-4):     # the Gram matrix BEFORE the last pass: 1e-4 there is 1e-8 after it
             raise _LanczosBreakdown('residual block lost rank at step <= %d (Cholesky verdicts %g, orthonormality %.1e)' % (j, fl[0], fl[1]))
-        inner['checks'] += 1
-        X0 = warm            # rows beyond the previous check's dimension are zero; None: the first b unit vectors —
-        if X0 is None:       # orthonormal, and the seed of this very Krylov space
-            X0 = ops.zeros(b, b)
-            X0[:b] = torch.eye(b, dtype=X0.dtype, device=X0.device)
-        # The pairs of T_j in stages: while the outer method is far from converged an ESTIMATE of the residuals is all a
-        # check needs, so the nested iteration first runs to a loose tolerance and is tightened (warm) only while its own
-        # residual, not the coupling to the next block, is what limits the estimate.
-        t_in = max(0.125 * est_tol, 1e-4 if not hist else 0.03 * hist[-1][1])
-        while True:
-            basis, lam_all, res_in, n_lock, conv_in = ops.sym_eig_topk(Tj, k, X0, t_in, 200, seed + 1000 * j, inner)
-            X0 = basis.contiguous()
-            Yk = X0[:, :k].contiguous()
-            TY = ops.gram(Tj, Yk)
-            lam_k = torch.as_tensor(lam_all[:k].copy(), device=Yk.device)
-            r_in2 = ops.resid_colnorm2(TY, Yk, lam_k)
-            yl = Yk[N - b:].contiguous()
-            c2 = (yl * ops.small_mm(S, yl)).sum(0)
-            both = ops.to_host(torch.stack([r_in2, c2]))
-            lam1 = max(float(lam_all[0]), 1e-300)
-            est = np.sqrt(np.maximum(both[0] + both[1], 0.0)) / lam1
-            coupling = float(np.sqrt(max(both[1].max(), 0.0)) / lam1)
-            if t_in <= 0.125 * est_tol or coupling >= 4.0 * t_in or not conv_in:
-                break
-            t_in = max(0.125 * est_tol, 0.1 * coupling)
-        warm = X0
-        worst = float(est.max())
-        hist.append((j, worst))
-        if verbose and comm.rank == 0:
-            print('[svd] lanczos step %2d  dim %4d  worst rel.res (first %d) %.2e  nested: %d outer, %d products, inner converged %s'
-                  % (j, N, k, worst, inner['outer'], inner['steps'], conv_in))
-        if worst <= est_tol and conv_in:
-            # ---- verification: one true product on the k Ritz vectors -----------------------------------------
-            Vk = ops.tsmm(Qall, Yk)
-            Z = gop.apply(Vk)
-            res2 = lay.total(ops.resid_colnorm2(Z, Vk, lam_k))
-            res_true = np.sqrt(np.maximum(ops.to_host(res2), 0.0)) / max(float(lam_all[0]), 1e-300)
-            stats['verified_rel_residual'] = float(res_true.max())
-            if float(res_true.max()) <= tol:
-                result = (Vk, lam_all[:k].copy(), res_true * float(lam_all[0]))
-                break
-            est_tol *= 0.1                 # the estimate was optimistic (orthogonality): ask for more, keep going
-        if last:
-            break
-        # ---- schedule the next check by the observed rate ------------------------------------------------------
-        rate = 1.6                         # natural log per step until two checks have been seen (~ x5 per step)
+
+    def plan(j_now):
+        """the step of the next look from the history of estimates; (step, final?)"""
+        jl, worst = hist[-1]
+        rate = 1.6                         # natural log per step until two estimates have been seen (~ x5 per step)
         if len(hist) >= 2 and hist[-2][1] > hist[-1][1] > 0:
             rate = max(0.4, np.log(hist[-2][1] / hist[-1][1]) / (hist[-1][0] - hist[-2][0]))
         remaining = np.log(max(worst, est_tol) / est_tol) / rate
-        if len(hist) < 2:
+        known = len(hist) >= 2
+        if not known:
             remaining *= 0.5               # one point says nothing about the rate: look again half way
-        next_check = min(qcap, j + max(1, int(remaining)))
+        step = min(qcap, max(j_now + 1, jl + max(1, int(remaining))))
+        return step, (known or not use_monitor)
+
+    try:
+        while j < qcap:
+            j += 1
+            N = j * b
+            if min(j + 1, qcap) * b > Qbuf.shape[1]:      # grow the basis and the projected matrix (rare: slow convergence)
+                cap2 = min(qcap, max(j + 1, int(1.5 * cap) + 1))
+                Qn_, Tn_ = ops.empty(lay.rows, cap2 * b), ops.zeros(cap2 * b, cap2 * b)
+                Qn_[:, :cap * b] = Qbuf
+                Tn_[:cap * b, :cap * b] = T
+                Qbuf, T, cap = Qn_, Tn_, cap2
+            Qj = Qbuf[:, N - b:N].contiguous()
+            W = gop.apply(Qj)
+            Qall = Qbuf[:, :N]
+            C = lay.gram(Qall, W)                                      # block column j of T, rows of all blocks so far
+            T[:N, N - b:N] = C
+            T[N - b:N, :N - b] = C[:N - b].t()
+            last = j == qcap
+            if not last:
+                Qnext, S = _next_lanczos_block(lay, W, Qall, C, flags)
+                Qbuf[:, N:N + b] = Qnext
+            else:                              # the last block the space can hold: the coupling of W_perp directly
+                S = lay.gram(ops.tsmm_sub(W, Qall, C))
+            # ---- a monitor that is due: collect it and plan the next look --------------------------------------
+            if monitor is not None and (j >= monitor.j + LAG or last or j + 1 >= next_look):
+                out = monitor.join()
+                jm, monitor = monitor.j, None
+                warm = out['basis']
+                hist.append((jm, out['worst']))
+                if verbose and comm.rank == 0:
+                    print('[svd] lanczos monitor of step %2d (seen at %2d)  worst rel.res (first %d) %.2e  nested so far: %d outer, %d products'
+                          % (jm, j, k, out['worst'], inner['outer'], inner['steps']))
+                next_look, look_is_final = plan(j)
+            if j < next_look and not last:
+                continue
+            if monitor is not None:            # (a look is due while a monitor is still out: cannot happen — joined above)
+                continue
+            inner['checks'] += 1
+            if not (look_is_final or last):
+                # ---- launch a monitor on the side stream and keep stepping -------------------------------------
+                breakdown_check(j)
+                monitor = _Monitor(ops, j, snapshot(N), S, warm, k, b, est_tol, hist[-1][1] if hist else None,
+                                   seed + 1000 * j, inner)
+                next_look = qcap + 1           # decided when the monitor comes back
+                continue
+            # ---- the pairs of T_j on the main stream, and their verification ------------------------------------
+            breakdown_check(j)
+            out = _ritz_check(ops, snapshot(N), S, warm, k, b, est_tol, hist[-1][1] if hist else None, seed + 1000 * j, inner)
+            warm = out['basis']
+            hist.append((j, out['worst']))
+            if verbose and comm.rank == 0:
+                print('[svd] lanczos step %2d  dim %4d  worst rel.res (first %d) %.2e  nested so far: %d outer, %d products, inner converged %s'
+                      % (j, N, k, out['worst'], inner['outer'], inner['steps'], out['conv']))
+            if out['worst'] <= est_tol and out['conv']:
+                Vk = ops.tsmm(Qall, out['Yk'])
+                Z = gop.apply(Vk)                  # one true product on the k Ritz vectors
+                lam1 = max(float(out['lam_all'][0]), 1e-300)
+                res2 = lay.total(ops.resid_colnorm2(Z, Vk, out['lam_k']))
+                res_true = np.sqrt(np.maximum(ops.to_host(res2), 0.0)) / lam1
+                stats['verified_rel_residual'] = float(res_true.max())
+                if float(res_true.max()) <= tol:
+                    result = (Vk, out['lam_all'][:k].copy(), res_true * lam1)
+                    break
+                est_tol *= 0.1                 # the estimate was optimistic (orthogonality): ask for more, keep going
+            if last:
+                break
+            next_look, look_is_final = plan(j)
+            look_is_final = True               # from here on every look is on the main stream: convergence is near
+    finally:
+        if monitor is not None:                # never leave a worker behind (exceptions, early exits)
+            try:
+                monitor.join()
+            except BaseException:
+                pass
     stats['lanczos_steps'] = j
     stats['outer'] = len(hist)
     stats['krylov_dim'] = j * b
