@@ -163,6 +163,13 @@ __global__ void transpose_small_kernel(int n, const double *__restrict__ in, dou
     out[(int64_t)c * n + r] = in[i];
 }
 
+__global__ void unit_block_kernel(int64_t n, int l, double *__restrict__ out) {     // out[n x l] = first l unit vectors
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * l) return;
+    const int64_t r = i / l;
+    out[i] = (r == i - r * l) ? 1.0 : 0.0;
+}
+
 // H <- (H + H^T) / 2 (out of place): a Rayleigh-Ritz matrix X^T (T X) is symmetric to rounding only
 __global__ void symmetrize_kernel(int n, const double *__restrict__ in, double *__restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -845,6 +852,251 @@ struct DenseOp {
     int rotate(const DMat &Z, const DMat &Cm, DMat &out) { return S.tsmm(Z, Cm, out); }
 };
 
+// ---- block Lanczos with full reorthogonalisation: solver.py::_block_lanczos restated (synchronous looks: the form the
+// Python layer runs with PK_LANCZOS_LAG=0; its side-stream monitors are a host-side scheduling matter) -------------------
+struct LanczosOut {
+    DMat Vk;                      // [n_items x k]
+    std::vector<double> lam_k, res_k;   // Ritz values; TRUE residual norms of the accepted pairs
+    int steps = 0, looks = 0, nested_outer = 0, nested_products = 0;
+    bool ok = false;              // false: the recurrence broke down or did not converge — the caller runs the subspace iteration
+};
+
+// one look: the k leading Ritz pairs of T (N x N) and the residual estimates  sqrt(||T y - th y||^2 + y_last^T S y_last) / th_1
+struct RitzLook {
+    DMat basis, Yk;
+    std::vector<double> lam_all, est;
+    Dev lam_k_dev;
+    double worst = 0.0;
+    bool conv = false;
+};
+
+static int ritz_look(pk_ctx *ctx, Solver &S, const DMat &T, const DMat &Sc, const DMat *warm, int k, int b, double est_tol,
+                     double prior, uint64_t seed, LanczosOut &lo, RitzLook &out) {
+    const int N = (int)T.n;
+    DMat X0;
+    auto pad = [&](const DMat *src, int l) -> int {
+        X0 = DMat(N, l);
+        if (!X0.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (ritz_look)");
+        if (src) {
+            HIPCK(hipMemsetAsync(X0.p(), 0, (size_t)N * l * 8, S.st));
+            HIPCK(hipMemcpy2DAsync(X0.p(), (size_t)l * 8, src->p(), (size_t)src->l * 8, (size_t)l * 8, (size_t)src->n, hipMemcpyDeviceToDevice, S.st));
+        } else {
+            hipLaunchKernelGGL(unit_block_kernel, dim3((unsigned)(((int64_t)N * l + 255) / 256)), dim3(256), 0, S.st, (int64_t)N, l, X0.p());
+        }
+        return PK_OK;
+    };
+    CK(pad(warm, warm ? warm->l : b));
+    double t_in = std::max(0.3 * est_tol, prior < 0 ? 1e-4 : 0.03 * prior);
+    for (;;) {
+        DenseOp dop{ctx, S, T};
+        SubspaceOut so;
+        CK(subspace_iteration(ctx, S, dop, k, std::move(X0), t_in, 200, 24, 1e7, seed, false, so));
+        lo.nested_outer += so.outer;
+        lo.nested_products += dop.products;
+        out.basis = std::move(so.basis);
+        out.lam_all = so.lam_all;
+        out.conv = so.converged;
+        CK(S.col_slice(out.basis, 0, k, out.Yk));
+        DMat TY;
+        CK(S.gram(T, out.Yk, TY));
+        if (!out.lam_k_dev.alloc((size_t)k * 8)) return fail(ctx, PK_E_LAUNCH, "out of device memory (ritz_look)");
+        CK(S.upload(out.lam_all.data(), out.lam_k_dev.p, (size_t)k * 8));
+        std::vector<double> r_in;
+        CK(S.resid(TY, out.Yk, out.lam_k_dev, r_in));
+        // coupling: y_last^T S y_last per pair, y_last = the last b rows of Yk
+        DMat yl(b, k), M(b, k);
+        if (!yl.ok() || !M.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (ritz_look)");
+        HIPCK(hipMemcpyAsync(yl.p(), out.Yk.p() + (size_t)(N - b) * k, (size_t)b * k * 8, hipMemcpyDeviceToDevice, S.st));
+        CK(pk_dgemm_small_f64(S.st, 0, 0, b, k, b, Sc.p(), b, yl.p(), k, M.p(), k));
+        std::vector<double> hy((size_t)b * k), hm((size_t)b * k);
+        CK(S.to_host(yl.p(), hy.data(), hy.size() * 8));
+        CK(S.to_host(M.p(), hm.data(), hm.size() * 8));
+        const double lam1 = std::max(out.lam_all.empty() ? 0.0 : out.lam_all[0], 1e-300);
+        out.est.assign((size_t)k, 0.0);
+        double cmax = 0.0;
+        out.worst = 0.0;
+        for (int j = 0; j < k; ++j) {
+            double c2 = 0.0;
+            for (int i = 0; i < b; ++i) c2 += hy[(size_t)i * k + j] * hm[(size_t)i * k + j];
+            c2 = std::max(c2, 0.0);
+            cmax = std::max(cmax, c2);
+            out.est[(size_t)j] = std::sqrt(r_in[(size_t)j] * r_in[(size_t)j] + c2) / lam1;
+            out.worst = std::max(out.worst, out.est[(size_t)j]);
+        }
+        const double coupling = std::sqrt(cmax) / lam1;
+        if (t_in <= 0.3 * est_tol || coupling >= 4.0 * t_in || !out.conv) break;
+        t_in = std::max(0.3 * est_tol, 0.1 * coupling);
+        CK(pad(&out.basis, out.basis.l));
+    }
+    lo.looks += 1;
+    return PK_OK;
+}
+
+__global__ void sym_block_kernel(int N, int ld, const double *__restrict__ T, double *__restrict__ out) {   // out[N x N] = (T + T^T) / 2 of a strided T
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * N) return;
+    const int r = i / N, c = i - r * N;
+    out[i] = 0.5 * (T[(int64_t)r * ld + c] + T[(int64_t)c * ld + r]);
+}
+// T[rows + c][r] = C[r][c] for r < rows, c < b: the mirror image of a block column of the projected matrix
+__global__ void mirror_block_kernel(int rows, int b, int ldt, const double *__restrict__ C, double *__restrict__ T) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * b) return;
+    const int r = i / b, c = i - r * b;
+    T[(int64_t)(rows + c) * ldt + r] = C[i];
+}
+__global__ void lanczos_flags_kernel(int l, const double *__restrict__ G, const int32_t *__restrict__ info, double *__restrict__ flags) {
+    // flags[0] += Cholesky verdicts of the three passes; flags[1] = max(flags[1], |G - I|_max)  (one workgroup)
+    __shared__ double s_max[256];
+    double m = 0.0;
+    for (int i = threadIdx.x; i < l * l; i += blockDim.x) {
+        const int r = i / l, c = i - r * l;
+        const double d = fabs(G[i] - (r == c ? 1.0 : 0.0));
+        m = (d == d) ? fmax(m, d) : 1.0;
+    }
+    s_max[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) s_max[threadIdx.x] = fmax(s_max[threadIdx.x], s_max[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        flags[0] += (double)(abs(info[0]) + abs(info[1]) + abs(info[2]));
+        flags[1] = fmax(flags[1], s_max[0]);
+    }
+}
+
+static int block_lanczos(pk_ctx *ctx, Solver &S, GramianOp &gop, int64_t n, int k, int b, double tol, uint64_t seed, int max_steps,
+                         LanczosOut &out) {
+    int qcap = (int)(n / b);
+    if (qcap < 4 || max_steps < 4) return PK_OK;          // out.ok stays false: no room for a Krylov space
+    qcap = std::min(qcap, max_steps);
+    int cap = std::min(qcap, 20);
+    DMat Q(n, cap * b), T(cap * b, cap * b);
+    Dev flags(16), info(12), chol_work((size_t)std::max<int64_t>(pk_chol_work_bytes(b), 8));
+    if (!Q.ok() || !T.ok() || !flags.p || !info.p || !chol_work.p) return fail(ctx, PK_E_LAUNCH, "out of device memory (block Lanczos)");
+    HIPCK(hipMemsetAsync(T.p(), 0, (size_t)T.n * T.l * 8, S.st));
+    HIPCK(hipMemsetAsync(flags.p, 0, 16, S.st));
+    {
+        DMat R, Q1;
+        CK(S.randn(n, b, seed, R));
+        CK(S.orthonormalize(R, nullptr, 12345, Q1));
+        HIPCK(hipMemcpy2DAsync(Q.p(), (size_t)Q.l * 8, Q1.p(), (size_t)b * 8, (size_t)b * 8, (size_t)n, hipMemcpyDeviceToDevice, S.st));
+    }
+    const double u = 1.1102230246251565e-16;
+    std::vector<std::pair<int, double>> hist;
+    RitzLook look;
+    bool have_warm = false;
+    double est_tol = tol;
+    int next_look = std::min(std::max(4, (2 * k + b - 1) / b + 2), qcap);
+    int j = 0;
+    while (j < qcap) {
+        ++j;
+        const int N = j * b;
+        if (std::min(j + 1, qcap) * b > Q.l) {           // grow the basis and the projected matrix (rare: slow convergence)
+            const int cap2 = std::min(qcap, std::max(j + 1, (int)(1.5 * cap) + 1));
+            DMat Q2(n, cap2 * b), T2(cap2 * b, cap2 * b);
+            if (!Q2.ok() || !T2.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (block Lanczos)");
+            HIPCK(hipMemsetAsync(T2.p(), 0, (size_t)T2.n * T2.l * 8, S.st));
+            HIPCK(hipMemcpy2DAsync(Q2.p(), (size_t)Q2.l * 8, Q.p(), (size_t)Q.l * 8, (size_t)Q.l * 8, (size_t)n, hipMemcpyDeviceToDevice, S.st));
+            HIPCK(hipMemcpy2DAsync(T2.p(), (size_t)T2.l * 8, T.p(), (size_t)T.l * 8, (size_t)T.l * 8, (size_t)T.n, hipMemcpyDeviceToDevice, S.st));
+            Q = std::move(Q2);
+            T = std::move(T2);
+            cap = cap2;
+        }
+        const int ldq = Q.l, ldt = T.l;
+        DMat Qj(n, b), W;
+        if (!Qj.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (block Lanczos)");
+        HIPCK(hipMemcpy2DAsync(Qj.p(), (size_t)b * 8, Q.p() + (N - b), (size_t)ldq * 8, (size_t)b * 8, (size_t)n, hipMemcpyDeviceToDevice, S.st));
+        CK(gop.apply(Qj, W));
+        // block column j of T = Q^T W, rows of all blocks so far (and its mirror image)
+        DMat C(N, b);
+        const size_t need = (size_t)pk_gram_work_bytes(n, N, b);
+        if (!C.ok() || (need > S.gram_work.bytes && !S.gram_work.alloc(need))) return fail(ctx, PK_E_LAUNCH, "out of device memory (gram)");
+        CK(pk_gram_f64(S.st, n, N, b, Q.p(), ldq, W.p(), b, C.p(), b, S.gram_work.p));
+        HIPCK(hipMemcpy2DAsync(T.p() + (N - b), (size_t)ldt * 8, C.p(), (size_t)b * 8, (size_t)b * 8, (size_t)N, hipMemcpyDeviceToDevice, S.st));
+        if (N > b)
+            hipLaunchKernelGGL(mirror_block_kernel, dim3((unsigned)(((int64_t)(N - b) * b + 255) / 256)), dim3(256), 0, S.st, N - b, b, ldt, C.p(),
+                               T.p());
+        const bool last = j == qcap;
+        DMat Sc;
+        if (!last) {
+            // solver.py::_next_lanczos_block: shifted CholeskyQR3, re-projected against the whole basis in every pass
+            HIPCK(hipMemsetAsync(info.p, 0, 12, S.st));
+            DMat Y = std::move(W), G;
+            for (int p = 0; p < 3; ++p) {
+                DMat Cp;
+                const DMat *coef = &C;
+                if (p > 0) {
+                    Cp = DMat(N, b);
+                    if (!Cp.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (block Lanczos)");
+                    CK(pk_gram_f64(S.st, n, N, b, Q.p(), ldq, Y.p(), b, Cp.p(), b, S.gram_work.p));
+                    coef = &Cp;
+                }
+                DMat Yp(n, b), Rinv(b, b), Yn;
+                if (!Yp.ok() || !Rinv.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (block Lanczos)");
+                CK(pk_tsmm_sub_f64(S.st, n, N, b, Q.p(), ldq, coef->p(), b, Y.p(), b, Yp.p(), b));
+                CK(S.gram(Yp, Yp, G));
+                if (p == 0) CK(S.col_slice(G, 0, b, Sc));
+                CK(pk_chol_rinv_f64(S.st, b, G.p(), b, p == 0 ? 11.0 * ((double)n * b + (double)b * (b + 1)) * u : 0.0, Rinv.p(), b, chol_work.p,
+                                    info.as<int32_t>() + p));
+                CK(S.tsmm(Yp, Rinv, Yn));
+                Y = std::move(Yn);
+            }
+            hipLaunchKernelGGL(lanczos_flags_kernel, dim3(1), dim3(256), 0, S.st, b, G.p(), info.as<int32_t>(), flags.as<double>());
+            HIPCK(hipMemcpy2DAsync(Q.p() + N, (size_t)ldq * 8, Y.p(), (size_t)b * 8, (size_t)b * 8, (size_t)n, hipMemcpyDeviceToDevice, S.st));
+        } else {
+            DMat Wp(n, b);
+            if (!Wp.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (block Lanczos)");
+            CK(pk_tsmm_sub_f64(S.st, n, N, b, Q.p(), ldq, C.p(), b, W.p(), b, Wp.p(), b));
+            CK(S.gram(Wp, Wp, Sc));
+        }
+        out.steps = j;
+        if (j < next_look && !last) continue;
+        // ---- a look: breakdown flags, the pairs of T_j, verification ---------------------------------------------------
+        double fl[2];
+        CK(S.to_host(flags.p, fl, 16));
+        if (fl[0] != 0.0 || !(fl[1] < 1e-4)) return PK_OK;        // the residual block lost rank: out.ok stays false
+        DMat Tj(N, N);
+        if (!Tj.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (block Lanczos)");
+        hipLaunchKernelGGL(sym_block_kernel, dim3((unsigned)(((int64_t)N * N + 255) / 256)), dim3(256), 0, S.st, N, ldt, T.p(), Tj.p());
+        RitzLook nl;
+        CK(ritz_look(ctx, S, Tj, Sc, have_warm ? &look.basis : nullptr, k, b, est_tol, hist.empty() ? -1.0 : hist.back().second,
+                     seed + 1000ull * (uint64_t)j, out, nl));
+        look = std::move(nl);
+        have_warm = true;
+        hist.emplace_back(j, look.worst);
+        if (look.worst <= est_tol && look.conv) {
+            // one true product on the k Ritz vectors: V = Q Y
+            DMat Vk(n, k), Z;
+            if (!Vk.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (block Lanczos)");
+            CK(pk_tsmm_f64(S.st, n, N, k, Q.p(), ldq, look.Yk.p(), k, Vk.p(), k));
+            CK(gop.apply(Vk, Z));
+            std::vector<double> res;
+            CK(S.resid(Z, Vk, look.lam_k_dev, res));
+            const double lam1 = std::max(look.lam_all[0], 1e-300);
+            double worst = 0.0;
+            for (double r : res) worst = std::max(worst, r / lam1);
+            if (worst <= tol) {
+                out.Vk = std::move(Vk);
+                out.lam_k.assign(look.lam_all.begin(), look.lam_all.begin() + k);
+                out.res_k = res;
+                out.ok = true;
+                return PK_OK;
+            }
+            est_tol *= 0.1;
+        }
+        if (last) break;
+        double rate = 1.6;
+        if (hist.size() >= 2 && hist[hist.size() - 2].second > hist.back().second && hist.back().second > 0)
+            rate = std::max(0.4, std::log(hist[hist.size() - 2].second / hist.back().second) / (hist.back().first - hist[hist.size() - 2].first));
+        double remaining = std::log(std::max(look.worst, est_tol) / est_tol) / rate;
+        if (hist.size() < 2) remaining *= 0.5;
+        next_look = std::min(qcap, j + std::max(1, (int)remaining));
+    }
+    return PK_OK;
+}
+
 static int svd_build_impl(pk_ctx *ctx, pk_mat *A, const pk_comm *comm, int32_t k, int32_t block, double tol, int32_t max_outer,
                           uint64_t seed, double *sigma_out, double *V_out, double *U_out, pk_build_stats *stats_out) {
     if (!ctx || !A) return PK_E_INVALID;
@@ -877,19 +1129,51 @@ static int svd_build_impl(pk_ctx *ctx, pk_mat *A, const pk_comm *comm, int32_t k
         CK(S.orthonormalize(R, nullptr, 12345, X));
     }
     GramianOp gop{ctx, S, A, comm};
-    SubspaceOut so;
-    CK(subspace_iteration(ctx, S, gop, k, std::move(X), tol, max_outer, m_max, spread, seed, true, so));
-    stats.outer = so.outer;
-    stats.gramian_steps = gop.steps;
-    stats.converged = so.converged ? 1 : 0;
-    const int n_lock = so.n_lock;
-    const std::vector<double> &res_host = so.res_act;
-    DMat Vk;
+    // the method, as solver.py::svd_topk chooses it: block Lanczos where a Gramian step is heavy (stored entries x block
+    // width, summed over the ranks), the filtered subspace iteration on small matrices and whenever the Krylov recurrence
+    // breaks down (PK_SVD_METHOD = lanczos | subspace overrides)
+    bool use_lanczos;
     {
+        const char *me = getenv("PK_SVD_METHOD");
+        double work = (double)A->A.nnz;
+        if (comm) {
+            Dev wd(8);
+            if (!wd.p) return fail(ctx, PK_E_LAUNCH, "out of device memory");
+            CK(S.upload(&work, wd.p, 8));
+            if (comm->allreduce_sum_f64(comm->user, wd.p, 1, (void *)ctx->stream) != 0)
+                return fail(ctx, PK_E_LAUNCH, "pk_svd_build_sharded: the communicator's all-reduce failed");
+            CK(S.to_host(wd.p, &work, 8));
+        }
+        use_lanczos = me && !strcmp(me, "lanczos") ? true : me && !strcmp(me, "subspace") ? false : work * l >= 2e8;
+    }
+    DMat Vk;
+    std::vector<double> lam_k, res_host;
+    int n_lock = 0;
+    bool have = false;
+    if (use_lanczos) {
+        LanczosOut lo;
+        CK(block_lanczos(ctx, S, gop, n_items, k, l, tol, seed, std::min(64, 4 * max_outer), lo));
+        stats.outer = lo.looks;
+        if (lo.ok) {
+            Vk = std::move(lo.Vk);
+            lam_k = lo.lam_k;
+            res_host = lo.res_k;
+            stats.converged = 1;
+            have = true;
+        }
+    }
+    if (!have) {
+        SubspaceOut so;
+        CK(subspace_iteration(ctx, S, gop, k, std::move(X), tol, max_outer, m_max, spread, seed, true, so));
+        stats.outer = so.outer;
+        stats.converged = so.converged ? 1 : 0;
+        n_lock = so.n_lock;
+        res_host = so.res_act;
         const int take = std::min<int>(k, so.basis.l);
         CK(S.col_slice(so.basis, 0, take, Vk));
+        lam_k.assign(so.lam_all.begin(), so.lam_all.begin() + std::min<size_t>((size_t)k, so.lam_all.size()));
     }
-    std::vector<double> lam_k(so.lam_all.begin(), so.lam_all.begin() + std::min<size_t>((size_t)k, so.lam_all.size()));
+    stats.gramian_steps = gop.steps;
     const int kk = std::min<int>(k, Vk.l);
     // to the host: sigma descending, V column-major (the F-ordered `vh.T` of models.py:849)
     std::vector<double> vh((size_t)n_items * Vk.l);
@@ -941,15 +1225,6 @@ static int svd_build_impl(pk_ctx *ctx, pk_mat *A, const pk_comm *comm, int32_t k
 // operator, run from C++: a nested solve is a few hundred launches of kernels that take microseconds, and from Python
 // every one of them costs the host ~20 us — 20 of the 48 ms of the first Lanczos build.
 // ------------------------------------------------------------------------------------------------------------
-namespace {
-__global__ void unit_block_kernel(int64_t n, int l, double *__restrict__ out) {     // out[n x l] = first l unit vectors
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n * l) return;
-    const int64_t r = i / l;
-    out[i] = (r == i - r * l) ? 1.0 : 0.0;
-}
-}  // namespace
-
 extern "C" int pk_sym_eig_topk_f64(pk_ctx *ctx, void *stream, int32_t n, const double *T_dev, int64_t ldt, int32_t k, int32_t l,
                                    const double *X0_dev, int64_t ldx0, int32_t x0_rows, double tol, int32_t max_outer, uint64_t seed,
                                    double *basis_out_dev, int64_t ldb, double *lam_out_host, double *res_out_host,

@@ -540,6 +540,10 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
                     print('[svd] lanczos monitor of step %2d (seen at %2d)  worst rel.res (first %d) %.2e  nested so far: %d outer, %d products'
                           % (jm, j, k, out['worst'], inner['outer'], inner['steps']))
                 next_look, look_is_final = plan(j)
+                if not last and not (look_is_final and next_look <= j + LAG):
+                    # convergence is not imminent: the next monitor starts at once, warm from the one just collected
+                    # (a chain of short nested solves next to the Gramian steps; only the final look is on the main stream)
+                    next_look, look_is_final = j, False
             if j < next_look and not last:
                 continue
             if monitor is not None:            # (a look is due while a monitor is still out: cannot happen — joined above)
@@ -607,15 +611,29 @@ def svd_topk(ops, A, k, block=None, tol=1e-12, max_outer=200, m_max=24, spread=1
         raise ValueError('k must satisfy 0 < k <= n_items')
     l = int(block or default_block(k, n_items))
     l = max(k, min(l, n_items))
-    method = method or os.environ.get('PK_SVD_METHOD', 'lanczos')
-    if method not in ('lanczos', 'subspace'):
-        raise ValueError("method must be 'lanczos' or 'subspace'")
+    method = method or os.environ.get('PK_SVD_METHOD', 'auto')
+    if method not in ('lanczos', 'subspace', 'auto'):
+        raise ValueError("method must be 'lanczos', 'subspace' or 'auto'")
+    if method == 'auto':
+        # Block Lanczos saves Gramian steps and pays for them with its projected eigenproblems (a few ms of small
+        # launches whatever the matrix): it wins where a Gramian step costs a millisecond (ML-20M-shaped rank 50: 47.7 ->
+        # 32.3 ms, S-1M: 289 -> 172 ms) and loses on small matrices (ML-1M-shaped rank 10: 4.6 -> 9.1 ms).  The switch is
+        # the work of a step — stored entries x block width, summed over the ranks so that every rank decides alike;
+        # operators that do not say how many entries they hold (host-side LinearOperators: their products are the
+        # expensive kind) count as large.
+        nnz = getattr(A, 'nnz', None)
+        work = float('inf')
+        if nnz is not None:
+            t = ops.to_device(np.array([float(nnz)]))
+            work = float(ops.to_host(comm.allreduce(t))[0]) * l
+        method = 'lanczos' if work >= 2e8 else 'subspace'
+    stats_method = method
     # the operator of Z = A^T Y: a device matrix offers its user-blocked transpose (ops.BlockedTranspose)
     At = A.transpose_operator() if hasattr(A, 'transpose_operator') else A.T
 
     lay = ItemRows(ops, comm, n_items, shard_items)
     stats = dict(outer=0, gramian_steps=0, spmm_cols=0, degrees=[], locked_at=[], block=l, converged=False,
-                 item_rows_per_rank=lay.rows, items_sharded=lay.sharded, method=method)
+                 item_rows_per_rank=lay.rows, items_sharded=lay.sharded, method=stats_method)
     Vk = lam_k = res_k = None
     if method == 'lanczos':
         try:

@@ -82,6 +82,19 @@ def main():
     assert np.allclose(sigma, s_ref, rtol=1e-9), np.abs(sigma / s_ref - 1).max()
     assert np.abs(V.T @ V - np.eye(rank)).max() < 1e-10 and np.abs(U.T @ U - np.eye(rank)).max() < 1e-9
     assert np.abs(S @ V - U * sigma).max() < 1e-8 * sigma[0]
+    # the same build by block Lanczos (what pk_svd_build picks by itself once a Gramian step is heavy; forced here): the
+    # factors of the filtered subspace iteration to the solver tolerance, in fewer Gramian steps, residual VERIFIED
+    os.environ['PK_SVD_METHOD'] = 'lanczos'
+    sigma_l = np.empty(rank); V_l = np.empty((n_items, rank), order='F'); st_l = Stats()
+    check(ctx, lib.pk_svd_build(ctx, A, rank, 0, 0.0, 0, 0, ptr(sigma_l), ptr(V_l), None, C.byref(st_l)), 'pk_svd_build(lanczos)')
+    os.environ['PK_SVD_METHOD'] = 'subspace'
+    st_s = Stats()
+    check(ctx, lib.pk_svd_build(ctx, A, rank, 0, 0.0, 0, 0, ptr(sigma), ptr(V), ptr(U), C.byref(st_s)), 'pk_svd_build(subspace)')
+    del os.environ['PK_SVD_METHOD']
+    assert st_l.converged == 1 and st_l.final_rel_residual <= 1e-12 and st_l.gramian_steps < st_s.gramian_steps, (
+        st_l.gramian_steps, st_s.gramian_steps, st_l.final_rel_residual)
+    assert np.allclose(sigma_l, s_ref, rtol=1e-10) and np.abs(V_l @ V_l.T - V @ V.T).max() < 1e-8
+    print('coarse build: %d Gramian steps (block Lanczos) / %d (subspace iteration)' % (st_l.gramian_steps, st_s.gramian_steps))
     # CSR route for the test rows (= the training rows here), ids only (approximate fold-in route) and with scores
     T = vp()
     ind = S.indices.astype(np.int32); ptr64 = S.indptr.astype(np.int64); dat = S.data.astype(np.float64)

@@ -18,11 +18,13 @@ def test_two_rank_sharded_build_and_scoring():
 import pytest
 
 
-@pytest.mark.parametrize('world', [2, 3])
-def test_row_sharded_item_side_of_the_solver(world):
+@pytest.mark.parametrize('world,method', [(2, 'subspace'), (3, 'subspace'), (2, 'lanczos'), (3, 'lanczos')])
+def test_row_sharded_item_side_of_the_solver(world, method):
     """solver.ItemRows: all-gather X / reduce-scatter Z / all-reduced Gram matrices give the factors of the whole
-    matrix, at item counts that are not multiples of the world size, and through the rank-deficient refill path."""
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='2')
+    matrix, at item counts that are not multiples of the world size, and through the rank-deficient refill path —
+    for the filtered subspace iteration and for the block Lanczos method (whose Krylov basis is row-sharded the same
+    way; the rank-deficient and the 61-item cases exercise its hand-over to the subspace iteration)."""
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='2', PK_SVD_METHOD=method)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world),
            '--master-addr', '127.0.0.1', '--master-port', str(free_port()),
            os.path.join(ROOT, 'tests', 'dist_worker_solver.py')]

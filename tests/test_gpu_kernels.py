@@ -127,6 +127,69 @@ def test_gram_and_tsmm(hip_ops, shape):
     assert np.abs(out - A @ Cm).max() / np.abs(A @ Cm).max() < 1e-13
 
 
+@pytest.mark.parametrize('shape', [(26744, 896, 64), (5001, 130, 50), (640, 640, 64), (900, 64, 64), (333, 7, 9), (70000, 256, 128)])
+def test_wide_gram_strided_operands_and_fused_projection(hip_ops, shape):
+    """The products of the block Lanczos build: the whole Krylov basis (a column slice of a wider buffer: leading
+    dimension > width) against one block, the fused Z - X C (pk_tsmm_sub_f64, in place), and the small square products of
+    the projected problem."""
+    n, la, lb = shape
+    rng = np.random.RandomState(la + lb)
+    buf = hip_ops.to_device(rng.randn(n, la + 64))
+    A = buf[:, :la]                                   # strided view
+    B = hip_ops.to_device(rng.randn(n, lb))
+    An, Bn = hip_ops.to_host(A), hip_ops.to_host(B)
+    G = hip_ops.gram(A, B)
+    ref = An.T @ Bn
+    assert np.abs(hip_ops.to_host(G) - ref).max() / np.abs(ref).max() < 1e-13
+    assert np.array_equal(hip_ops.to_host(hip_ops.gram(A, B)), hip_ops.to_host(G))        # deterministic
+    Cm = hip_ops.to_device(rng.randn(la, lb))
+    want = Bn - An @ hip_ops.to_host(Cm)
+    out = hip_ops.tsmm_sub(B, A, Cm)
+    assert np.abs(hip_ops.to_host(out) - want).max() / np.abs(want).max() < 1e-13
+    Z = B.clone()
+    hip_ops.tsmm_sub(Z, A, Cm, out=Z)                 # in place
+    assert np.array_equal(hip_ops.to_host(Z), hip_ops.to_host(out))
+    assert np.abs(hip_ops.to_host(hip_ops.tsmm(A, Cm)) - An @ hip_ops.to_host(Cm)).max() / np.abs(An @ hip_ops.to_host(Cm)).max() < 1e-13
+
+
+@pytest.mark.parametrize('case', [(500, 20, 32, 'graded'), (896, 50, 64, 'planted'), (130, 10, 24, 'flat'), (64, 8, 16, 'graded'),
+                                  (300, 12, 24, 'rank40')])
+def test_sym_eig_topk_against_lapack(hip_ops, case):
+    """pk_sym_eig_topk_f64 (the projected problem of the block Lanczos build, solved from C++): the k leading pairs of a
+    dense PSD matrix against numpy's eigh — eigenvalues to 1e-12 of the largest, residuals below the tolerance asked for,
+    orthonormal vectors; a warm start from the pairs of the leading principal submatrix; same bits on a second call."""
+    n, k, l, kind = case
+    rng = np.random.RandomState(n + k)
+    Q, _ = np.linalg.qr(rng.randn(n, n))
+    if kind == 'graded':
+        lam = np.exp(-np.arange(n) / 12.0) * 1e6
+    elif kind == 'planted':
+        lam = np.r_[1e6 / (1 + np.arange(100)), 3e3 * rng.rand(n - 100)]
+    elif kind == 'flat':
+        lam = 1.0 + rng.rand(n)
+    else:
+        lam = np.r_[np.linspace(5, 1, 40), np.zeros(n - 40)]
+    T = (Q * lam) @ Q.T
+    T = 0.5 * (T + T.T)
+    w = np.sort(np.linalg.eigvalsh(T))[::-1]
+    Td = hip_ops.to_device(T)
+    tol = 1e-13
+    basis, lam_all, res, n_lock, conv = hip_ops.sym_eig_topk(Td, k, hip_ops.to_device(np.eye(n, l)), tol)
+    assert conv and basis.shape == (n, l) and len(lam_all) == l
+    Y = hip_ops.to_host(basis)[:, :k]
+    assert np.abs(lam_all[:k] - w[:k]).max() <= 1e-12 * w[0]
+    assert np.abs(Y.T @ Y - np.eye(k)).max() < 1e-10
+    assert np.linalg.norm(T @ Y - Y * lam_all[:k], axis=0).max() <= 4 * tol * w[0]
+    b2, l2, _, _, _ = hip_ops.sym_eig_topk(Td, k, hip_ops.to_device(np.eye(n, l)), tol)
+    assert np.array_equal(hip_ops.to_host(b2), hip_ops.to_host(basis)) and np.array_equal(l2, lam_all)
+    # warm start: the pairs of the leading principal submatrix, padded with zero rows by the callee
+    m = n - max(8, n // 8)
+    bs, ls, _, _, cs = hip_ops.sym_eig_topk(hip_ops.to_device(np.ascontiguousarray(T[:m, :m])), k, hip_ops.to_device(np.eye(m, l)), tol)
+    st = {}
+    bw, lw, _, _, cw = hip_ops.sym_eig_topk(Td, k, bs, tol, stats=st)
+    assert cs and cw and np.abs(lw[:k] - w[:k]).max() <= 1e-12 * w[0] and st['outer'] >= 1 and st['steps'] >= 1
+
+
 @pytest.mark.parametrize('n', [1, 2, 5, 24, 63, 64, 72, 128, 136, 137, 150, 200, 256, 301, 520])
 def test_eigh_psd_jacobi(hip_ops, n):
     rng = np.random.RandomState(n)

@@ -375,6 +375,60 @@ def test_single_user_conveniences_on_array_data():
         m.show_recommendations('user')
 
 
+def test_block_lanczos_matches_the_subspace_iteration_and_arpack(monkeypatch):
+    """solver._block_lanczos (Rayleigh-Ritz over the whole Krylov space, nested solve of the projected problem, monitors
+    on a worker thread) against the filtered subspace iteration and against the reference's own call (scipy svds = ARPACK,
+    tol 0): singular values to 1e-10, projectors to 1e-8, fewer Gramian steps, a VERIFIED residual below the tolerance;
+    the same factors with the monitors switched off (PK_LANCZOS_LAG=0: every look on the calling thread)."""
+    from scipy.sparse.linalg import svds
+    from polara_amd.synth import planted_csr
+    m = planted_csr(5000, 2000, 50, 16, levels=5, seed=7, min_items=6, max_items=300)
+    ops = NumpyOps()
+    A = ops.csr(m['indptr'].numpy(), m['indices'].numpy(), m['values'].numpy().astype(np.float64), m['shape'])
+    k = 16
+    out = {}
+    for meth in ('subspace', 'lanczos'):
+        _, s, V, st = svd_topk(ops, A, k, method=meth)
+        out[meth] = (s.numpy(), V.numpy(), st)
+        assert st['converged'] and st['final_rel_residual'] <= 1e-12
+    sl, Vl, stl = out['lanczos']
+    ss, Vs, sts = out['subspace']
+    assert stl['method'] == 'lanczos' and 'lanczos_fallback' not in stl and stl['verified_rel_residual'] <= 1e-12
+    assert stl['gramian_steps'] < sts['gramian_steps'] and stl['gramian_steps'] == stl['lanczos_steps'] + 1
+    assert np.allclose(sl, ss, rtol=1e-10) and np.abs(Vl @ Vl.T - Vs @ Vs.T).max() < 1e-8
+    np.random.seed(0)
+    _, s_ref, vt = svds(A.m, k=k, tol=0)
+    assert np.allclose(np.sort(s_ref)[::-1], sl, rtol=1e-10) and np.abs(vt.T @ vt - Vl @ Vl.T).max() < 1e-8
+    monkeypatch.setenv('PK_LANCZOS_LAG', '0')
+    _, s0, V0, st0 = svd_topk(ops, A, k, method='lanczos')
+    assert np.allclose(s0.numpy(), sl, rtol=1e-12) and np.abs(V0.numpy() @ V0.numpy().T - Vl @ Vl.T).max() < 1e-9
+    monkeypatch.delenv('PK_LANCZOS_LAG')
+    # 'auto' keeps small matrices on the subspace iteration (the projected eigenproblems cost more than they save there)
+    _, _, _, sta = svd_topk(ops, A, k)
+    assert sta['method'] == 'subspace'
+
+
+def test_block_lanczos_hands_rank_deficient_matrices_to_the_subspace_iteration():
+    """Matrices the Krylov recurrence cannot finish on — exact rank below the block width (the residual block loses rank
+    at once), an identity-like Gramian, fewer than four blocks of room — go to the filtered subspace iteration, whose
+    rebuild path is made for them; the factors are those of a dense SVD either way."""
+    rng = np.random.default_rng(5)
+    ops = NumpyOps()
+    cases = {'rank6_ask10': (sps.csr_matrix(rng.standard_normal((400, 6)) @ rng.standard_normal((6, 300))), 10),
+             'orthogonal_rows': (sps.csr_matrix(np.eye(260)[:, :200] * 3.0), 5),
+             'narrow': (sps.random(300, 60, density=0.2, random_state=3, format='csr'), 12)}
+    for name, (M, k) in cases.items():
+        M = sps.csr_matrix(M)
+        M.sort_indices()
+        A = ops.csr(M.indptr.astype(np.int64), M.indices.astype(np.int32), M.data.astype(np.float64), M.shape)
+        _, s, V, st = svd_topk(ops, A, k, method='lanczos')
+        sd = np.linalg.svd(M.toarray(), compute_uv=False)[:k]
+        assert st['converged'], (name, st)
+        if name != 'orthogonal_rows':      # (a multiple of the identity: T_1 already holds the answer, the first look accepts it)
+            assert 'lanczos_fallback' in st and st['method'].startswith('subspace'), (name, st)
+        assert np.allclose(s.numpy(), sd, rtol=1e-9, atol=1e-9 * sd[0]), name
+
+
 def test_unconverged_build_raises_like_arpack():
     """a build that stops at max_outer without converging must not mark the model ready silently; the
     reference's svds raises ArpackNoConvergence (models.py:844)."""
