@@ -151,17 +151,20 @@ def pmc_traffic(tag):
                   spmm_csr_groups_kernel<.., double, ..> and of the column-per-lane spmm_csr_kernel); the profiled
                   command builds twice (cold + warm), the caller divides by its product count"""
     out = {}
+    hashes = {}
     try:
         def rows(fn):
             commit, found = None, []
             for line in open(os.path.join(ROOT, 'profiles', fn)):
                 if line.startswith('# commit'):
                     commit = line.split()[-1]
+                if line.startswith('# sha256'):
+                    hashes[line.split()[2]] = line.split()[3]
                 if 'FETCH_SIZE' in line or 'WRITE_SIZE' in line:
                     parts = line.split()
                     found.append((line, int(parts[-3]), float(parts[-2]) * 1024.0, float(parts[-1]) * 1024.0))   # launches, sum, per launch (KB -> B)
             return commit, found
-        rnd = 'r03' if os.path.exists(os.path.join(ROOT, 'profiles', 'r03_%s_pmc_fetch_size.txt' % tag)) else 'r02'
+        rnd = next((r for r in ('r04', 'r03', 'r02') if os.path.exists(os.path.join(ROOT, 'profiles', '%s_%s_pmc_fetch_size.txt' % (r, tag)))), 'r02')
         out['round'] = rnd
         cf, fetch = rows('%s_%s_pmc_fetch_size.txt' % (rnd, tag))
         _, write = rows('%s_%s_pmc_write_size.txt' % (rnd, tag))
@@ -174,6 +177,15 @@ def pmc_traffic(tag):
         if bf and bw:
             out['spmm_total'] = 2.0 * sum(r[2] for r in bf) + sum(r[2] for r in bw)
         out['commit'] = cf
+        # a profile describes the kernels of the tree it was taken in: compare the hashes it carries with the sources
+        # here.  No hashes (profiles of rounds 2-3) or a different score.hip / spmm.hip: STALE — the counters then do not
+        # go into the record (a kernel change without re-profiling must not ship old counters in a
+        # fresh-looking line)
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        from summarize_rocprof import kernel_source_hashes
+        now = kernel_source_hashes(ROOT)
+        out['stale_score'] = hashes.get('score.hip') != now.get('score.hip')
+        out['stale_spmm'] = hashes.get('spmm.hip') != now.get('spmm.hip')
     except (OSError, ValueError, IndexError):
         pass
     return out
@@ -898,12 +910,12 @@ def compact_line(head, n_gpus, steps, warmup, adversarial=None, scale=1.0):
     if rf:
         out['roofline'] = {k: (_r(rf.get(k)) if not isinstance(rf.get(k), str) else rf.get(k)) for k in
                            ('kernel', 'bound', 'dtype', 'achieved', 'peak', 'unit', 'frac', 'avg_ms', 'launches_per_pass',
-                            'swept_fraction', 'traffic')}
+                            'swept_fraction', 'traffic', 'traffic_commit', 'stale') if k in rf or k == 'traffic'}
     rb = head.get('roofline_build')
     if rb:
         out['roofline_build'] = {k: (_r(rb.get(k)) if not isinstance(rb.get(k), str) else rb.get(k)) for k in
                                  ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'launches', 'total_ms', 'traffic',
-                                  'algorithmic_bytes_per_product')}
+                                  'algorithmic_bytes_per_product', 'traffic_commit', 'stale') if k in rb or k == 'traffic'}
     cb = head.get('cpu_baseline')
     if cb:
         out['cpu_baseline'] = {
@@ -1005,11 +1017,17 @@ def main():
         return
     tag = {'ml20m': 'ml20m', 's1m': 's1m'}.get(args.workload)
     traffic = pmc_traffic(tag) if (tag and full_size and headline_rank == 50) else {}
-    if 'roofline' in head and 'score' in traffic:
+    if 'roofline' in head and traffic:
+        head['roofline']['traffic_commit'] = traffic.get('commit')
+        head['roofline']['stale'] = bool(traffic.get('stale_score', True))
+    if 'roofline_build' in head and traffic:
+        head['roofline_build']['traffic_commit'] = traffic.get('commit')
+        head['roofline_build']['stale'] = bool(traffic.get('stale_spmm', True))
+    if 'roofline' in head and 'score' in traffic and not traffic.get('stale_score', True):
         head['roofline']['traffic'] = traffic['score']       # per LAUNCH, like `achieved`
         head['roofline']['traffic_note'] = ('HBM/fabric bytes per launch = 2*FETCH_SIZE + WRITE_SIZE of a separate rocprofv3 --pmc run of '
                                             'this command at commit %s (profiles/%s_%s_pmc_*.txt)' % (traffic.get('commit'), traffic.get('round'), tag))
-    if 'roofline_build' in head and 'spmm_total' in traffic:
+    if 'roofline_build' in head and 'spmm_total' in traffic and not traffic.get('stale_spmm', True):
         rb = head['roofline_build']
         products = 2 * head['build']['gramian_steps']          # A.X and A^T.Y of every Gramian step
         rb['traffic'] = traffic['spmm_total'] / (2 * products)   # the profiled command builds twice (cold + warm)

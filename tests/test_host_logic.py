@@ -2,6 +2,7 @@
 orchestration (solver, scoring pipeline, HOOI driver, model classes) driven through the TEST-ONLY
 NumPy double of the device operator set (tests/numpy_ops.py) against the reference's golden vectors.
 This proves the orchestration; the HIP kernels themselves are proven by the -m gpu tests."""
+import os
 import numpy as np
 import pytest
 import scipy.sparse as sps
@@ -505,6 +506,45 @@ def test_bench_compact_line_is_small_and_parses():
     assert d2['scaling'] == 'strong' and d2['dist']['world'] == 8 and d2['dist']['backend'] == 'nccl' and d2['dist']['rccl']
     assert len(d2['dist']['users_per_rank']) == 8 and d2['dist']['build_collectives']['reduce_scatter'] == 37
     assert d2['dist']['scoring_collectives'] == 0 and d2['config']['configs2_rank100_top20']['users_per_s'] == 82.6e6
+
+
+def test_bench_refuses_counters_of_a_profile_taken_on_other_kernel_sources(tmp_path, monkeypatch):
+    """`roofline.traffic` comes from committed rocprofv3 --pmc summaries.  A summary carries the hashes of the
+    kernel sources of the tree it was taken in (tools/summarize_rocprof.py); bench.py compares them with the sources here
+    and marks the profile stale — and leaves the counters out of the record — when score.hip / spmm.hip differ or the
+    summary has no hashes (rounds 2-3)."""
+    import shutil
+    import bench
+    sys_tools = os.path.join(bench.ROOT, 'tools')
+    import sys
+    sys.path.insert(0, sys_tools)
+    from summarize_rocprof import kernel_source_hashes
+    now = kernel_source_hashes(bench.ROOT)
+    assert set(now) >= {'score.hip', 'spmm.hip'}
+    root = tmp_path / 'repo'
+    (root / 'profiles').mkdir(parents=True)
+    (root / 'tools').mkdir()
+    shutil.copy(os.path.join(sys_tools, 'summarize_rocprof.py'), root / 'tools')
+    shutil.copytree(os.path.join(bench.ROOT, 'polara_amd', 'csrc'), root / 'polara_amd' / 'csrc', ignore=shutil.ignore_patterns('_obj'))
+    row = '%-72s %-22s %10d %18.1f %18.1f\n'
+
+    def write(hashes):
+        head = '# commit abc1234\n' + ''.join('# sha256 %s %s\n' % kv for kv in hashes.items())
+        for kind, per in (('fetch', 400000.0), ('write', 50000.0)):
+            with open(root / 'profiles' / ('r04_ml20m_pmc_%s_size.txt' % kind), 'w') as f:
+                f.write(head)
+                f.write(row % ('void score_candidates_kernel<4, 16, false, true, false>', kind.upper() + '_SIZE', 4, 4 * per, per))
+                f.write(row % ('void spmm_csr_groups_kernel<float, 4, double, false, true>', kind.upper() + '_SIZE', 60, 60 * per, per))
+    monkeypatch.setattr(bench, 'ROOT', str(root))
+    write(now)
+    t = bench.pmc_traffic('ml20m')
+    assert t['round'] == 'r04' and t['commit'] == 'abc1234' and t['stale_score'] is False and t['stale_spmm'] is False and t['score'] > 0
+    write(dict(now, **{'score.hip': '0' * 16}))
+    t = bench.pmc_traffic('ml20m')
+    assert t['stale_score'] is True and t['stale_spmm'] is False
+    write({})
+    t = bench.pmc_traffic('ml20m')
+    assert t['stale_score'] is True and t['stale_spmm'] is True
 
 
 def test_bench_gpus_flag_launches_ranks_or_fails_loudly(monkeypatch):

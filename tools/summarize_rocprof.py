@@ -15,14 +15,30 @@ def short(name, n=70):
     return name if len(name) <= n else name[:n - 3] + '...'
 
 
+def kernel_source_hashes(root=None):
+    """sha256 (first 16 hex digits) of the kernel sources a profile describes — computed from the tree the profiled
+    command ran in, so a profile can be matched against the sources of any later checkout (bench.py: `stale`)."""
+    import hashlib
+    root = root or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for name in ('score.hip', 'spmm.hip', 'rescore.hip', 'dense.hip'):
+        try:
+            with open(os.path.join(root, 'polara_amd', 'csrc', name), 'rb') as f:
+                out[name] = hashlib.sha256(f.read()).hexdigest()[:16]
+        except OSError:
+            pass
+    return out
+
+
 def commit_line():
     """the commit the profiled tree was snapshotted from (written to gpurun_in/COMMIT before the gpurun call: the
-    GPU box has no .git)"""
+    GPU box has no .git), and the hashes of the kernel sources of that tree"""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     try:
-        return '# commit ' + open(os.path.join(root, 'gpurun_in', 'COMMIT')).read().strip()
+        line = '# commit ' + open(os.path.join(root, 'gpurun_in', 'COMMIT')).read().strip()
     except OSError:
-        return '# commit unknown'
+        line = '# commit unknown'
+    return line + ''.join('\n# sha256 %s %s' % kv for kv in sorted(kernel_source_hashes(root).items()))
 
 
 def main(src, dst):
