@@ -238,12 +238,24 @@ class Bench:
 
     # ---- data ---------------------------------------------------------------------------------------------
     def generate(self, workload, scale=1.0):
-        from polara_amd.synth import make_workload, csr_to_numpy
+        from polara_amd.synth import make_workload, csr_to_numpy, WORKLOADS
+        from polara_amd.datasets import find_movielens, load_movielens
         t0 = time.perf_counter()
-        csr, cfg = make_workload(workload, device=self.dev, scale=scale)
-        c = csr_to_numpy(csr)
-        del csr
-        torch.cuda.empty_cache()
+        real = find_movielens(workload, ROOT) if scale == 1.0 and not os.environ.get('PK_BENCH_SYNTHETIC') else None
+        if real:
+            # the REAL matrix when somebody put it there (data/ml-20m.zip, data/ml-20m/ratings.csv, ...; there is no
+            # network here): same metric, same code path, `data: "real"` in the line
+            c = load_movielens(real)
+            c = {k: c[k] for k in ('indptr', 'indices', 'values', 'shape')}
+            cfg = dict(rank=WORKLOADS[workload]['rank'], topk=WORKLOADS[workload]['topk'], levels=int(len(np.unique(c['values']))))
+            c['data'] = 'real (%s)' % os.path.relpath(real, ROOT)
+            log('real data: %s  %d x %d, %d ratings' % (real, c['shape'][0], c['shape'][1], len(c['values'])))
+        else:
+            csr, cfg = make_workload(workload, device=self.dev, scale=scale)
+            c = csr_to_numpy(csr)
+            del csr
+            torch.cuda.empty_cache()
+            c['data'] = 'synthetic'
         c['gen_s'] = time.perf_counter() - t0
         c['cfg'] = cfg
         if os.environ.get('PK_BENCH_SORT_USERS'):       # experiment: users ordered by activity before they are grouped by 32
@@ -599,7 +611,10 @@ class Bench:
                 'latency_ms_per_pass': extra['latency_ms_per_pass'], 'd2h_bytes_per_pass': extra['d2h_bytes_per_pass'],
                 'ms_per_step_serial': extra.get('serial_ms_per_step'),
                 'ms_per_step_long_region': extra.get('long_region_ms_per_step'),
-                'workload': '%s, PureSVD rank=%d, top-%d, all users scored' % (WORKLOAD_TEXT[workload], rank, topk),
+                'workload': '%s, PureSVD rank=%d, top-%d, all users scored' % (
+                    WORKLOAD_TEXT[workload] if c.get('data', 'synthetic') == 'synthetic' else
+                    'MovieLens ratings from %s, %d x %d' % (c['data'], n_users, n_items), rank, topk),
+                'data': c.get('data', 'synthetic'),
                 'n_users': n_users, 'n_items': n_items, 'nnz': nnz, 'rank': rank, 'topk': topk, 'prune': prune,
                 'score_order': 'factor norm' if norm_order else 'popularity',
                 'launch': extra.get('launch', 'python, kernel by kernel'),
@@ -895,7 +910,7 @@ def compact_line(head, n_gpus, steps, warmup, adversarial=None, scale=1.0):
     out = {'metric': 'users scored/sec + SVD build time, ML-20M rank-50 PureSVD', 'value': _r(head['value'], 6), 'unit': 'users/s',
            'n_gpus': n_gpus, 'steps': steps, 'warmup': warmup, 'ms_per_step': _r(head['ms_per_step'], 5),
            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'bf16x3',
-           'data': 'synthetic', 'config': cfg, 'build_s': _r(head['build_s']),
+           'data': head.get('data', 'synthetic'), 'config': cfg, 'build_s': _r(head['build_s']),
            'latency_ms_per_pass': _r(head.get('latency_ms_per_pass')), 'ms_per_step_serial': _r(head.get('ms_per_step_serial')),
            'ms_per_step_long_region': _r(head.get('ms_per_step_long_region'))}
     b = head.get('build', {})
@@ -1043,7 +1058,8 @@ def main():
                                'accumulate, error <= 3 * 2^-16 + (4 K + 10) * 2^-23 relative to ||e|| ||v||, certified); fold-in gathers '
                                'fl32(V) with f64 accumulation, its rounding is part of the certification (uncertified users are '
                                're-folded in f64); EXACT f64 re-scoring of the candidates decides every list; f64 SVD build',
-                  data='synthetic (planted low-rank + Zipf popularity, seeded; generated on GPU)',
+                  data=('synthetic (planted low-rank + Zipf popularity, seeded; generated on GPU)' if head.get('data', 'synthetic') == 'synthetic'
+                        else head['data']),
                   result='int64 [n_users x topk] copied to pinned host memory inside the timed region (double-buffered)',
                   sub=subs)
     write_detail(detail)

@@ -460,6 +460,15 @@ int pk_ttm_f64(void *stream,
                const int32_t *idx1_dev, const int32_t *idx2_dev, const double *vals_dev,
                const double *u_dev, int64_t ldu, int32_t ra, const double *v_dev, int64_t ldv_, int32_t rb,
                double *res_dev, int64_t ldr, double *partial_dev);
+/* CoffeeModel.predict_feedback (models.py:1068-1091): for each of n holdout (user, item) pairs the index of the feedback
+ * level f with the largest reconstructed score  sum_abc core[a, b, c] u[user, a] v[item, b] w[f, c]  (first maximum, as
+ * np.argmax).  u [n_users x r0], v [n_items x r1], w [L x r2] row-major fp64, core [r0 x r1 x r2] C-ordered, r2 <= 16.
+ * pred_dev int64[n]; scores_dev [n x L] or NULL. */
+int pk_tucker_predict_f64(void *stream, int64_t n, const int64_t *users_dev, const int64_t *items_dev,
+                          const double *u_dev, int64_t ldu, const double *v_dev, int64_t ldv_, const double *w_dev,
+                          int64_t ldw, const double *core_dev, int32_t r0, int32_t r1, int32_t r2, int32_t L,
+                          int64_t *pred_dev, double *scores_dev);
+
 
 /* ------------------------------------------------------------------------------------------
  * Coarse entry points: what a host in ANY language binds to replace the two hot calls of the

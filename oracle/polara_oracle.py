@@ -377,6 +377,49 @@ def coffee_recommendations(v, w, test_data, test_shape, topk, filter_seen=True,
 # ----------------------------------------------------------------------------------------------
 # checker helpers (not restatements): tie flags and set comparison
 # ----------------------------------------------------------------------------------------------
+# ----------------------------------------------------------------------------------------------
+# CoffeeModel extras: unfolded test slices, holdout slices, feedback prediction
+# polara/lib/sparse.py:178-187, polara/recommender/models.py:1027-1039, 1056-1092
+# ----------------------------------------------------------------------------------------------
+def unfold_tensor_coordinates(index, shape, mode):
+    """lib/sparse.py:178-187: coordinates of the mode-`mode` unfolding with `mode` as the COLUMN index and the two
+    other modes (in their order) flattened C-style into the row index."""
+    modes = [m for m in (0, 1, 2) if m != mode] + [mode]
+    mode_shape = tuple(shape[m] for m in modes)
+    mode_index = tuple(index[m] for m in modes)
+    flat_index = np.ravel_multi_index(mode_index, mode_shape)
+    unfold_shape = (mode_shape[0] * mode_shape[1], mode_shape[2])
+    return np.unravel_index(flat_index, unfold_shape), unfold_shape
+
+
+def unfold_test_tensor_slice(test_data, shape, start, stop, mode):
+    """models.py:1027-1039: the binary test tensor of users [start, stop) unfolded along `mode` (uint8 CSR)."""
+    slice_idx = slice_test_data(test_data, start, stop)
+    slice_shp = (stop - start, shape[1], shape[2])
+    idx, shp = unfold_tensor_coordinates(slice_idx, slice_shp, mode)
+    val = np.ones_like(slice_idx[2], dtype=np.uint8)
+    return csr_matrix((val, idx), shape=shp, dtype=val.dtype), slice_idx
+
+
+def get_holdout_slice(holdout_users, holdout_items, start, stop):
+    """models.py:1056-1065: the holdout entries of users [start, stop), user ids re-based to the slice."""
+    holdout_users = np.asarray(holdout_users)
+    sel = (holdout_users >= start) & (holdout_users < stop)
+    return holdout_users[sel].astype(np.int64) - start, np.asarray(holdout_items)[sel].astype(np.int64)
+
+
+def coffee_predict_feedback(u, v, w, g, holdout_users, holdout_items):
+    """models.py:1068-1091: for every holdout (user, item) the feedback level with the largest reconstructed score,
+    scores[h, f] = sum_abc g[a, b, c] u[user_h, a] v[item_h, b] w[f, c]; returns the level INDICES (the reference maps
+    them to feedback values through data.index.feedback)."""
+    holdout_users = np.asarray(holdout_users, dtype=np.int64)
+    holdout_items = np.asarray(holdout_items, dtype=np.int64)
+    gv = np.tensordot(g, v[holdout_items, :], (1, 1))
+    gu = (gv * u[holdout_users, None, :].T).sum(axis=0)
+    scores = w.dot(gu).T
+    return np.argmax(scores, axis=-1), scores
+
+
 def boundary_gap(scores, topk):
     """Per-row gap between the k-th and (k+1)-th largest value of a dense (already down-voted)
     score block.  Rows with gap == 0 have an implementation-defined reference top-k (introselect)."""

@@ -119,6 +119,7 @@ PROTOTYPES = {
     'pk_hooi': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _f64, _vp, _vp, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp]),
     'pk_ttm_f64': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp,
                              _vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _vp]),
+    'pk_tucker_predict_f64': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
 }
 
 

@@ -84,6 +84,20 @@ __device__ __forceinline__ int etop_count(const double *d, const double *e2, int
     return c;
 }
 
+// The same count with IEEE division (one thread, once per solve): the completeness check below must not share the
+// approximate reciprocal whose rounding it guards against
+__device__ __forceinline__ int etop_count_exact(const double *d, const double *e2, int n, double x, double pivmin) {
+    double q = d[0] - x;
+    if (fabs(q) < pivmin) q = -pivmin;
+    int c = q < 0.0;
+    for (int i = 1; i < n; ++i) {
+        q = (d[i] - x) - e2[i - 1] / q;
+        if (fabs(q) < pivmin) q = -pivmin;
+        c += q < 0.0;
+    }
+    return c;
+}
+
 __global__ __launch_bounds__(ETOP_THREADS) void eigh_top_kernel(int n, const double *__restrict__ S, int64_t lds_, int r,
                                                                 double *__restrict__ evecs, int64_t ldv,
                                                                 double *__restrict__ evals, double *refl,
@@ -328,6 +342,16 @@ __global__ __launch_bounds__(ETOP_THREADS) void eigh_top_kernel(int n, const dou
                 hi = fmin(hi, nhi);
             }
             if (t == 0) s_lam[j] = 0.5 * (lo + hi);
+        }
+        __syncthreads();
+        // COMPLETENESS: residuals and orthonormality (P5) say the r pairs are eigenpairs, not that they are the
+        // LEADING ones — a count that the approximate reciprocal made non-monotone near an eigenvalue could bracket the
+        // wrong slot.  With exact division: at most r eigenvalues may lie above a point just below the r-th value found
+        // (more: a leading pair was skipped — or the (r+1)-th is equal to rounding, where "leading" is not defined: both go
+        // to the Jacobi route, which computes every pair).
+        if (tid == 0) {
+            const double x = s_lam[r - 1] - 1e-11 * tn - 4.0 * pivmin;
+            if (n - etop_count_exact(s_d, s_e2, n, x, pivmin) > r) s_fail = 1;
         }
         __syncthreads();
     }

@@ -127,3 +127,63 @@ extern "C" int pk_ttm_f64(void *stream, int64_t n_tasks, const int32_t *task_row
     }
     return PK_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// pk_tucker_predict_f64: CoffeeModel.predict_feedback (models.py:1068-1091) — for every holdout (user, item) pair the
+// feedback level f maximising  sum_abc g[a, b, c] u[user, a] v[item, b] w[f, c]  (np.argmax: the first maximum wins).
+// One thread per pair: the r0 x r1 x r2 core is read through uniform (scalar) loads, the pair's contraction against the
+// feedback mode is r2 <= 16 accumulators in registers, then L <= 64 dot products of length r2.  A few million
+// multiply-adds for an ML-1M-sized holdout: latency-bound, tens of microseconds.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tucker_predict_kernel(int64_t n, const int64_t *__restrict__ users,
+                                                             const int64_t *__restrict__ items, const double *__restrict__ u,
+                                                             int64_t ldu, const double *__restrict__ v, int64_t ldv,
+                                                             const double *__restrict__ w, int64_t ldw,
+                                                             const double *__restrict__ g, int r0, int r1, int r2, int L,
+                                                             int64_t *__restrict__ pred, double *__restrict__ scores) {
+    const int64_t h = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= n) return;
+    const double *ur = u + users[h] * ldu, *vr = v + items[h] * ldv;
+    double acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = 0.0;
+    for (int a = 0; a < r0; ++a) {
+        const double ua = ur[a];
+        for (int b = 0; b < r1; ++b) {
+            const double p = ua * vr[b];
+            const double *gc = g + ((int64_t)a * r1 + b) * r2;
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+                if (c < r2) acc[c] = fma(gc[c], p, acc[c]);
+        }
+    }
+    int best = 0;
+    double best_s = 0.0;
+    for (int f = 0; f < L; ++f) {
+        double sc = 0.0;
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (c < r2) sc = fma(w[(int64_t)f * ldw + c], acc[c], sc);
+        if (scores) scores[h * L + f] = sc;
+        if (f == 0 || sc > best_s) {
+            best_s = sc;
+            best = f;
+        }
+    }
+    pred[h] = best;
+}
+
+extern "C" int pk_tucker_predict_f64(void *stream, int64_t n, const int64_t *users_dev, const int64_t *items_dev,
+                                     const double *u_dev, int64_t ldu, const double *v_dev, int64_t ldv_, const double *w_dev,
+                                     int64_t ldw, const double *core_dev, int32_t r0, int32_t r1, int32_t r2, int32_t L,
+                                     int64_t *pred_dev, double *scores_dev) {
+    PK_REQUIRE(n >= 0 && r0 >= 1 && r1 >= 1 && r2 >= 1 && r2 <= 16 && L >= 1 && L <= 4096,
+               "pk_tucker_predict_f64: need 1 <= r2 <= 16 feedback-mode columns (got %d), L = %d", r2, L);
+    PK_REQUIRE(ldu >= r0 && ldv_ >= r1 && ldw >= r2, "pk_tucker_predict_f64: bad leading dimension");
+    if (n == 0) return PK_OK;
+    PK_REQUIRE(users_dev && items_dev && u_dev && v_dev && w_dev && core_dev && pred_dev, "pk_tucker_predict_f64: null pointer");
+    hipLaunchKernelGGL(tucker_predict_kernel, dim3((unsigned)pk_ceil_div(n, 256)), dim3(256), 0, pk_stream(stream), n, users_dev,
+                       items_dev, u_dev, ldu, v_dev, ldv_, w_dev, ldw, core_dev, r0, r1, r2, L, pred_dev, scores_dev);
+    PK_CHECK_LAUNCH("tucker_predict_kernel");
+    return PK_OK;
+}

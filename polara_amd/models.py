@@ -954,6 +954,60 @@ class CoffeeModel(RecommenderModel):
         self._factor_image = None
 
 
+    # ---- the extras of the reference's class (models.py:1027-1092) ------------------------------------------------
+    def _holdout_pairs(self):
+        """(users, items) of the holdout as int64 arrays: Polara's frame (models.py:1075-1077) or ArrayData's triplets."""
+        hold = self.data.test.holdout
+        if hold is None:
+            raise ValueError('the data object has no holdout')
+        f = self.data.fields
+        if hasattr(hold, 'userid') and not hasattr(hold, 'loc'):          # ArrayData: Triplets
+            return np.asarray(hold.userid, dtype=np.int64), np.asarray(hold.itemid, dtype=np.int64)
+        return hold[f.userid].values.astype(np.int64), hold[f.itemid].values.astype(np.int64)
+
+    def get_holdout_slice(self, start, stop):
+        """models.py:1056-1065: the holdout entries of test users [start, stop), user ids re-based to the slice."""
+        users, items = self._holdout_pairs()
+        sel = (users >= start) & (users < stop)
+        return users[sel] - start, items[sel]
+
+    def unfold_test_tensor_slice(self, test_data, shape, start, stop, mode):
+        """models.py:1027-1039: the binary test tensor of users [start, stop) unfolded along `mode` — `mode` is the column
+        index, the two other modes (in order) are flattened C-style into the row index (lib/sparse.py:178-187) — as a
+        uint8 SciPy CSR matrix, with the slice's coordinates.  Index bookkeeping on the host, like the reference's."""
+        import scipy.sparse as sps
+        slice_idx = self._slice_test_data(test_data, start, stop)
+        slice_shp = (stop - start, shape[1], shape[2])
+        modes = [m for m in (0, 1, 2) if m != mode] + [mode]
+        rows = np.asarray(slice_idx[modes[0]], dtype=np.int64) * slice_shp[modes[1]] + np.asarray(slice_idx[modes[1]], dtype=np.int64)
+        cols = np.asarray(slice_idx[modes[2]], dtype=np.int64)
+        val = np.ones(len(rows), dtype=np.uint8)
+        unfolded = sps.csr_matrix((val, (rows, cols)), shape=(slice_shp[modes[0]] * slice_shp[modes[1]], slice_shp[modes[2]]),
+                                  dtype=np.uint8)
+        return unfolded, slice_idx
+
+    def predict_feedback(self):
+        """models.py:1068-1091: the feedback value the Tucker model reconstructs best for every holdout (user, item) pair
+        — argmax over the feedback levels of  sum_abc core[a,b,c] u[user,a] v[item,b] w[f,c], on the device
+        (pk_tucker_predict_f64: the factor rows are gathered and contracted there; the reference builds an
+        [r0 x n_holdout x r2] intermediate with tensordot).  Returns the ORIGINAL feedback values, like the reference."""
+        if self.data.warm_start:
+            raise NotImplementedError
+        if not self._is_ready:
+            if self.verbose:
+                print('{} model is not ready. Rebuilding.'.format(self.method))
+            self.build()
+        f = self.data.fields
+        users, items = self._holdout_pairs()
+        pred, _ = self.ops.tucker_predict(users, items, self.factors[f.userid], self.factors[f.itemid], self.factors[f.feedback],
+                                          self.factors['core'])
+        pred = self.ops.to_host(pred)
+        index = getattr(self.data, 'index', None)
+        fb = getattr(index, 'feedback', None) if index is not None else None
+        if fb is not None and hasattr(fb, 'set_index'):                   # Polara: data.index.feedback maps new -> old
+            return fb.set_index('new').loc[pred, 'old'].values
+        return np.asarray(self.data._levels())[pred]
+
     def _test_csr_depends_on(self):
         # the per-entry weights come from the feedback factor and the flattener: a rank reduction or a restored
         # `factors` dict (the rank-sweep pipelines do that) makes a cached test CSR stale

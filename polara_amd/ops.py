@@ -489,8 +489,8 @@ class HipOps:
             # two separate host arrays of any integer type: uploaded as they are (no host-side stacking or widening)
             both = torch.empty(2, max(nnz, 1), dtype=torch.int64, device=dev)
             if nnz:
-                both[0, :nnz].copy_(torch.from_numpy(np.ascontiguousarray(rows)).to(dev))
-                both[1, :nnz].copy_(torch.from_numpy(np.ascontiguousarray(cols)).to(dev))
+                both[0, :nnz].copy_(self.to_device(rows))       # (to_device: read-only views of the caller's columns are fine)
+                both[1, :nnz].copy_(self.to_device(cols))
             r_ptr, c_ptr, stride = _ptr(both), _ptr(both, max(nnz, 1)), 1
         if torch.is_tensor(vals):
             v = vals.to(dev).contiguous()
@@ -1122,6 +1122,23 @@ class HipOps:
             _ptr(u), u.stride(0), ra, _ptr(v), v.stride(0), rb, _ptr(res), res.stride(0), _ptr(partial)),
             'pk_ttm_f64')
         return res
+
+    def tucker_predict(self, users, items, u, v, w, core, want_scores=False):
+        """pk_tucker_predict_f64: for each (user, item) pair the index of the feedback level with the largest
+        reconstructed Tucker score (CoffeeModel.predict_feedback, models.py:1068-1091).  users / items: host or device
+        int64; u, v, w, core: host arrays or device tensors.  Returns (pred int64 device tensor, scores | None)."""
+        dev = lambda a, dt: (a if torch.is_tensor(a) else self.to_device(np.ascontiguousarray(a, dtype=dt))).contiguous()
+        users, items = dev(users, np.int64), dev(items, np.int64)
+        u, v, w, core = (dev(a, np.float64) for a in (u, v, w, core))
+        r0, r1, r2 = (int(x) for x in core.shape)
+        assert u.shape[1] == r0 and v.shape[1] == r1 and w.shape[1] == r2 and users.numel() == items.numel()
+        n, L = int(users.numel()), int(w.shape[0])
+        pred = torch.empty(n, dtype=torch.int64, device=self.device)
+        scores = self.empty(n, L) if want_scores else None
+        _lib.check(self.lib.pk_tucker_predict_f64(self.stream(), n, _ptr(users), _ptr(items), _ptr(u), u.stride(0), _ptr(v),
+                                                  v.stride(0), _ptr(w), w.stride(0), _ptr(core), r0, r1, r2, L, _ptr(pred),
+                                                  _ptr(scores)), 'pk_tucker_predict_f64')
+        return pred, scores
 
     def synchronize(self):
         torch.cuda.synchronize(self.device)

@@ -108,8 +108,9 @@ def main():
     st = Stats()
     check(ctx, lib.pk_svd_build_sharded(ctx, Ml, C.byref(comm), k, 0, 0.0, 0, 7, ptr(sigma), ptr(V), ptr(U), C.byref(st)),
           'pk_svd_build_sharded')
-    # one all-reduce of Z per Gramian step + one of the Rayleigh-Ritz matrix per outer iteration: nothing else leaves the rank
-    assert st.converged == 1 and calls['n'] == st.gramian_steps + st.outer, (calls, st.gramian_steps, st.outer)
+    # one all-reduce of Z per Gramian step + one of the Rayleigh-Ritz matrix per outer iteration (+ ONE scalar at the start:
+    # the entry count of the whole matrix, from which every rank picks the same method): nothing else leaves the rank
+    assert st.converged == 1 and calls['n'] == st.gramian_steps + st.outer + 1, (calls, st.gramian_steps, st.outer)
     # the same on every rank, bit for bit (all-reduced inputs, identical arithmetic)
     both = [torch.empty(n_items * k + k, dtype=torch.float64) for _ in range(world)]
     dist.all_gather(both, torch.from_numpy(np.r_[sigma, V.ravel(order='F')]))

@@ -69,3 +69,34 @@ def pytest_collection_modifyitems(config, items):
         if 'test_dropin_polara' in item.nodeid:
             item.add_marker(pytest.mark.filterwarnings('ignore::FutureWarning'))
             item.add_marker(pytest.mark.filterwarnings('ignore::DeprecationWarning'))
+
+
+def check_coffee_extras(m, g):
+    """The extras of the reference's CoffeeModel (models.py:1027-1092) on a built model fed a golden fixture: unfolded
+    test-tensor slices and the holdout slice equal to the reference's, `predict_feedback` equal to the reference's
+    predictions wherever the best and the second-best level are apart (our factors differ from the reference's by the
+    signs the reference leaves arbitrary; the reconstructed scores do not)."""
+    import scipy.sparse as sps
+    a, b = (int(x) for x in g['unfold_range'])
+    td = (g['test_user'], g['test_item'], g['test_fdbk'])
+    shape = tuple(int(x) for x in g['test_shape'])
+    for mode in (0, 1, 2):
+        unf, sl = m.unfold_test_tensor_slice(td, shape, a, b, mode)
+        ref = sps.csr_matrix((g['unfold%d_data' % mode], g['unfold%d_indices' % mode], g['unfold%d_indptr' % mode]),
+                             shape=tuple(int(x) for x in g['unfold%d_shape' % mode]))
+        assert unf.dtype == np.uint8 and unf.shape == ref.shape and (unf.astype(np.int64) != ref).nnz == 0, mode
+        assert all(np.array_equal(x, y) for x, y in zip(sl, m._slice_test_data(td, a, b)))
+    hold = (g['hold_user'], g['hold_item'], np.ones(len(g['hold_user'])))
+    m.data.set_test_data(holdout=hold, notify=False)
+    hu, hi = m.get_holdout_slice(a, b)
+    assert np.array_equal(hu, g['hold_slice_user']) and np.array_equal(hi, g['hold_slice_item'])
+    if 'predicted_feedback' in g:
+        m.data._feedback_levels = g['feedback_levels']          # the original feedback values of the levels
+        pred = m.predict_feedback()
+        clear = g['predict_gap'] > 1e-9
+        assert clear.mean() > 0.99 and pred.shape == g['predicted_feedback'].shape
+        assert np.array_equal(pred[clear], g['predicted_feedback'][clear])
+    else:
+        m.data.warm_start = True
+        with pytest.raises(NotImplementedError):
+            m.predict_feedback()

@@ -193,13 +193,41 @@ def coffee_fixture(name, df, data_cfg, mlrank, topk, seed=0, num_iters=25, growt
     raw_probe = full_scores[:4].copy()
     orc.downvote_seen_items(full_scores, sd)
     gap = orc.boundary_gap(full_scores, topk)
+    # ---- the CoffeeModel extras (models.py:1027-1092): unfolded test slice, holdout slice, feedback prediction ----
+    extras = {}
+    a, b = 3, min(40, tshape[0])
+    for mode in (0, 1, 2):
+        ref_unf, ref_sl = model.unfold_test_tensor_slice((tu, ti, tf), tshape, a, b, mode)
+        o_unf, o_sl = orc.unfold_test_tensor_slice((tu, ti, tf), tshape, a, b, mode)
+        assert ref_unf.shape == o_unf.shape and (ref_unf != o_unf).nnz == 0 and all(np.array_equal(x, y) for x, y in zip(ref_sl, o_sl)), name
+        ref_unf.sum_duplicates()
+        ref_unf.sort_indices()
+        extras['unfold%d_indptr' % mode] = ref_unf.indptr.astype(np.int64)
+        extras['unfold%d_indices' % mode] = ref_unf.indices.astype(np.int64)
+        extras['unfold%d_data' % mode] = ref_unf.data.astype(np.int64)
+        extras['unfold%d_shape' % mode] = np.array(ref_unf.shape, np.int64)
+    extras['unfold_range'] = np.array([a, b], np.int64)
+    hold = data.test.holdout
+    hu, hi = hold[userid].values.astype(np.int64), hold[itemid].values.astype(np.int64)
+    ref_hs = model.get_holdout_slice(a, b)
+    o_hs = orc.get_holdout_slice(hu, hi, a, b)
+    assert all(np.array_equal(x, y) for x, y in zip(ref_hs, o_hs)), name
+    extras.update(hold_user=hu, hold_item=hi, hold_slice_user=ref_hs[0], hold_slice_item=ref_hs[1])
+    if not data.warm_start:
+        ref_pred = model.predict_feedback()
+        levels = data.index.feedback.sort_values('new')['old'].values
+        o_idx, o_scores = orc.coffee_predict_feedback(u0, u1, u2, core, hu, hi)
+        assert np.array_equal(levels[o_idx], ref_pred), name
+        srt = np.sort(o_scores, axis=1)
+        extras.update(feedback_levels=levels.astype(np.float64), predicted_feedback=np.asarray(ref_pred, dtype=np.float64),
+                      predicted_level=o_idx.astype(np.int64), predict_gap=srt[:, -1] - srt[:, -2])
     out = dict(train_idx=idx.astype(np.int64), train_val=val, train_shape=np.array(shp, np.int64),
                test_user=tu.astype(np.int64), test_item=ti.astype(np.int64), test_fdbk=tf.astype(np.int64),
                test_shape=np.array(tshape, np.int64), mlrank=np.array(mlrank, np.int64),
                topk=np.int64(topk), seed=np.int64(seed), num_iters=np.int64(num_iters),
                growth_tol=np.float64(growth_tol),
                u0=u0, u1=u1, u2=u2, core=np.ascontiguousarray(core), core_norm_trace=np.array(trace),
-               ttm_mode0=ref_res, recs=recs, probe_scores=raw_probe, boundary_gap=gap)
+               ttm_mode0=ref_res, recs=recs, probe_scores=raw_probe, boundary_gap=gap, **extras)
     np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
     print(name, 'nnz', len(val), 'iters', len(trace), 'test users', tshape[0], 'ties', int((gap == 0).sum()))
 

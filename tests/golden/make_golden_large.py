@@ -12,7 +12,7 @@ interpreted iterations.  The oracle's `dttm_seq` applies the same updates in the
 The inputs are not stored (1e6 triplets): they are `polara_amd.synth.make_workload('ml1m')` on the CPU generator,
 re-created by the test; a digest of the triplets is stored so that a generator drift is reported as such.
 
-usage:  python tests/golden/make_golden_large.py        (build container, ~3 minutes)
+usage:  python tests/golden/make_golden_large.py        (build container, a few minutes on one BLAS thread)
 """
 import hashlib
 import os
@@ -28,6 +28,12 @@ sys.path.insert(0, ROOT)
 warnings.filterwarnings('ignore')
 
 import numpy as np
+from threadpoolctl import threadpool_limits
+
+# ONE BLAS thread: with a threaded BLAS the reductions inside `svds` / `dot` change their summation order from run to run
+# and the float arrays of the fixture move in their last digits (5e-16 ... 3e-15 relative between two
+# generations; every integer array was equal).  Single-threaded, the script reproduces its fixture byte for byte.
+_one_thread = threadpool_limits(limits=1)
 
 from polara.recommender.models import CoffeeModel as RefCoffee   # the reference (round_core only)
 

@@ -172,6 +172,14 @@ class NumpyOps:
         X.mul_(s[None, :])
         return X
 
+    def tucker_predict(self, users, items, u, v, w, core, want_scores=False):
+        users, items = (np.asarray(a, dtype=np.int64) for a in (users, items))
+        u, v, w, core = (np.asarray(a, dtype=np.float64) for a in (u, v, w, core))
+        t = np.einsum('abc,hb->hac', core, v[items])
+        gu = np.einsum('hac,ha->hc', t, u[users])
+        scores = gu @ w.T
+        return torch.from_numpy(np.argmax(scores, axis=1).astype(np.int64)), (torch.from_numpy(scores) if want_scores else None)
+
     def synchronize(self):
         pass
 

@@ -141,6 +141,19 @@ def test_coffee_model_side_by_side(polara):
     our_m._recommendations[~clear] = ref_m.recommendations[~clear]
     for a, b in zip(quiet(our_m.evaluate, 'hits'), quiet(ref_m.evaluate, 'hits')):
         assert a == b
+    # the extras of the class (models.py:1027-1092) on Polara's own data object: the holdout is a pandas frame there and
+    # the level -> feedback value map is data.index.feedback
+    td, shape, _ = ref_m._get_test_data()
+    for mode in (0, 1, 2):
+        r_unf, r_sl = ref_m.unfold_test_tensor_slice(td, shape, 2, 31, mode)
+        o_unf, o_sl = our_m.unfold_test_tensor_slice(td, shape, 2, 31, mode)
+        assert r_unf.shape == o_unf.shape and (r_unf != o_unf).nnz == 0 and all(np.array_equal(x, y) for x, y in zip(r_sl, o_sl))
+    assert all(np.array_equal(x, y) for x, y in zip(ref_m.get_holdout_slice(2, 31), our_m.get_holdout_slice(2, 31)))
+    ref_pred, our_pred = ref_m.predict_feedback(), our_m.predict_feedback()
+    assert our_pred.shape == ref_pred.shape and (our_pred == ref_pred).mean() > 0.99      # (near-ties between two levels aside)
+    # given OUR factors the reference's own code predicts exactly what the device kernel predicts
+    ref_m.factors = dict(our_m.factors)
+    assert np.array_equal(ref_m.predict_feedback(), our_pred)
 
 
 def test_reference_pipelines_drive_our_model(polara):

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import scipy.sparse as sps
 
-from conftest import load_golden, GoldenData
+from conftest import check_coffee_extras, load_golden, GoldenData
 from oracle import polara_oracle as orc
 from polara_amd.data import ArrayData
 from polara_amd.models import SVDModel, CoffeeModel, ScaledSVD
@@ -75,6 +75,7 @@ def test_coffee_model_vs_reference_golden(hip_ops, name):
     assert np.isclose(np.linalg.norm(m.factors['core']), np.linalg.norm(g['core']), rtol=1e-9)
     notie = g['boundary_gap'] > 0
     assert np.array_equal(m.recommendations[notie], g['recs'][notie])
+    check_coffee_extras(m, g)          # unfolded slices, holdout slice, predict_feedback (pk_tucker_predict_f64)
 
 
 def _check_full_feedback_mode(m, g):

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import scipy.sparse as sps
 
-from conftest import load_golden, GoldenData
+from conftest import check_coffee_extras, load_golden, GoldenData
 from numpy_ops import NumpyOps
 from oracle import polara_oracle as orc
 from polara_amd import csr as pcsr
@@ -143,6 +143,7 @@ def test_coffee_model_orchestration_matches_reference(name):
     assert m.factors['core'].shape == tuple(g['mlrank'])
     notie = g['boundary_gap'] > 0
     assert np.array_equal(m.recommendations[notie], g['recs'][notie])
+    check_coffee_extras(m, g)          # models.py:1027-1092: unfolded slices, holdout slice, predict_feedback
 
 
 def _check_full_feedback_mode(m, g):
@@ -545,6 +546,33 @@ def test_bench_refuses_counters_of_a_profile_taken_on_other_kernel_sources(tmp_p
     write({})
     t = bench.pmc_traffic('ml20m')
     assert t['stale_score'] is True and t['stale_spmm'] is True
+
+
+def test_local_movielens_files_become_the_bench_matrix(tmp_path):
+    """datasets.load_movielens (the reference's loader, datasets/movielens.py:11-80, minus the download): old `::` format
+    without a header, new comma format with one, plain file or zip archive; users / items renumbered in sorted id
+    order, duplicate pairs summed, canonical CSR — what bench.py runs on when data/ml-20m* or data/ml-1m* exists."""
+    import zipfile
+    from polara_amd.datasets import load_movielens, find_movielens
+    rows = [(7, 300, 4.0, 1), (2, 100, 5.0, 2), (7, 100, 0.5, 3), (9, 200, 3.5, 4), (2, 300, 1.0, 5), (2, 100, 1.0, 6)]
+    want = sps.coo_matrix(([r[2] for r in rows], ([{2: 0, 7: 1, 9: 2}[r[0]] for r in rows], [{100: 0, 200: 1, 300: 2}[r[1]] for r in rows])),
+                          shape=(3, 3)).tocsr()
+    (tmp_path / 'data' / 'ml-1m').mkdir(parents=True)
+    dat = tmp_path / 'data' / 'ml-1m' / 'ratings.dat'
+    dat.write_text(''.join('%d::%d::%g::%d\n' % r for r in rows))
+    (tmp_path / 'data' / 'ml-20m').mkdir()
+    csv = tmp_path / 'data' / 'ml-20m' / 'ratings.csv'
+    csv.write_text('userId,movieId,rating,timestamp\n' + ''.join('%d,%d,%g,%d\n' % r for r in rows))
+    z = tmp_path / 'ml-20m.zip'
+    with zipfile.ZipFile(z, 'w') as zf:
+        zf.write(csv, 'ml-20m/ratings.csv')
+    assert find_movielens('ml1m', str(tmp_path)) == str(dat) and find_movielens('ml20m', str(tmp_path)) == str(csv)
+    assert find_movielens('s1m', str(tmp_path)) is None
+    for path in (dat, csv, z):
+        c = load_movielens(str(path))
+        got = sps.csr_matrix((c['values'], c['indices'], c['indptr']), shape=c['shape'])
+        assert c['shape'] == (3, 3) and (got != want).nnz == 0 and got.has_sorted_indices
+        assert list(c['users']) == [2, 7, 9] and list(c['items']) == [100, 200, 300] and c['indices'].dtype == np.int32
 
 
 def test_bench_gpus_flag_launches_ranks_or_fails_loudly(monkeypatch):

@@ -102,3 +102,23 @@ def test_micro_semantics():
         assert np.array_equal(orc.array_split(shp, k, mult, available_memory=8 << 30), g['split_' + tag])
     with pytest.raises(MemoryError):  # the 50M x 500K top-50 config cannot be chunked
         orc.array_split((50_000_000, 500_000), 50, 1, available_memory=64 << 30)
+
+
+@pytest.mark.parametrize('name', ['coffee_small', 'coffee_warm'])
+def test_coffee_extras_match_reference(name):
+    """models.py:1027-1092 restated (unfold_test_tensor_slice, get_holdout_slice, predict_feedback): the oracle against
+    what the reference's own methods returned when the fixture was made."""
+    import scipy.sparse as sps
+    g = load_golden(name)
+    a, b = (int(x) for x in g['unfold_range'])
+    td = (g['test_user'], g['test_item'], g['test_fdbk'])
+    for mode in (0, 1, 2):
+        unf, _ = orc.unfold_test_tensor_slice(td, tuple(g['test_shape']), a, b, mode)
+        ref = sps.csr_matrix((g['unfold%d_data' % mode], g['unfold%d_indices' % mode], g['unfold%d_indptr' % mode]),
+                             shape=tuple(int(x) for x in g['unfold%d_shape' % mode]))
+        assert unf.shape == ref.shape and (unf.astype(np.int64) != ref).nnz == 0
+    hu, hi = orc.get_holdout_slice(g['hold_user'], g['hold_item'], a, b)
+    assert np.array_equal(hu, g['hold_slice_user']) and np.array_equal(hi, g['hold_slice_item'])
+    if 'predicted_feedback' in g:
+        idx, scores = orc.coffee_predict_feedback(g['u0'], g['u1'], g['u2'], g['core'], g['hold_user'], g['hold_item'])
+        assert np.array_equal(idx, g['predicted_level']) and np.array_equal(g['feedback_levels'][idx], g['predicted_feedback'])

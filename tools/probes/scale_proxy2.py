@@ -31,7 +31,7 @@ rank_of, inv = popularity_order(None, n_items, counts=ops.item_counts(A0))
 A0 = ops.csr_relabel_cols(A0, rank_of)
 out = {'workload': WL, 'rank': rank, 'topk': topk, 'build': {}, 'scoring': {}}
 V = None
-ITEM_OPS = ('gram', 'tsmm', 'axpbypcz', 'resid_colnorm2', 'scale_cols')
+ITEM_OPS = ('gram', 'tsmm', 'tsmm_sub', 'axpbypcz', 'resid_colnorm2', 'scale_cols')
 
 
 class Recorder:
@@ -69,20 +69,23 @@ def replay(log, rows):
     return e0.elapsed_time(e1), len(calls)
 
 
+METHOD = None
 for N in (1, 2, 4, 8):
     bounds = nnz_balanced_row_partition(c['indptr'], N)
     A = A0 if N == 1 else ops.csr_rows(A0, 0, int(bounds[1]))
     A.transpose_operator(); _ = A.plan
-    svd_topk(ops, A, rank)                     # warm-up (allocations)
+    _, _, _, st0 = svd_topk(ops, A, rank, method=METHOD)                     # warm-up (allocations)
+    if N == 1:
+        METHOD = st0['method'].split()[0]      # the JOB's choice (the all-reduced entry count decides, not the shard's)
     torch.cuda.synchronize()
     ops.timers = {}
     t0 = time.perf_counter()
-    _, s, Vn, st = svd_topk(ops, A, rank)
+    _, s, Vn, st = svd_topk(ops, A, rank, method=METHOD)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     rec = Recorder(ops)
     timers, ops.timers = ops.timers, None
-    svd_topk(rec, A, rank)
+    svd_topk(rec, A, rank, method=METHOD)
     torch.cuda.synchronize()
     ops.timers = timers
     full_ms, n_calls = replay(rec.log, n_items)
@@ -91,15 +94,19 @@ for N in (1, 2, 4, 8):
     ops.timers = None
     l = st['block']
     z_bytes = n_items * l * 8
+    # small all-reduces per step: block Lanczos reduces the block column of T and the l x l Gram matrices of its three
+    # orthogonalisation passes (5 per step, <= 0.5 MB each); the subspace iteration about as many per filter step
+    small = (5 if st.get('method') == 'lanczos' else 3) * st['gramian_steps'] + 4 * st['outer']
     ring = 0.0 if N == 1 else st['gramian_steps'] * (2.0 * (N - 1) / N * z_bytes / LINK + 2 * (N - 1) * 5e-6) \
-        + st['outer'] * (2 * (N - 1) * 5e-6)
+        + small * (2 * (N - 1) * 5e-6)
     bus = 0.0 if N == 1 else st['gramian_steps'] * (2.0 * (N - 1) / N * z_bytes / 300e9 + 2 * (N - 1) * 5e-6) \
-        + st['outer'] * (2 * (N - 1) * 5e-6)
+        + small * (2 * (N - 1) * 5e-6)
     sharded_wall = wall - 1e-3 * (full_ms - shard_ms)
     out['build']['N=%d' % N] = dict(rows_on_rank0=A.shape[0], solver_wall_s=wall, spmm_ms=spmm_ms, non_spmm_ms=1e3 * wall - spmm_ms,
                                     item_side_calls=n_calls, item_side_ms_replicated=full_ms, item_side_ms_sharded=shard_ms,
                                     non_spmm_sharded_ms=1e3 * sharded_wall - spmm_ms,
-                                    gramian_steps=st['gramian_steps'], modelled_exchange_ms=1e3 * ring,
+                                    gramian_steps=st['gramian_steps'], method=st.get('method'), small_allreduces=small,
+                                    modelled_exchange_ms=1e3 * ring,
                                     modelled_exchange_ms_busbw_300=1e3 * bus,
                                     modelled_total_s_replicated=wall + ring,
                                     modelled_total_s=sharded_wall + ring, modelled_total_s_busbw_300=sharded_wall + bus)
