@@ -369,7 +369,7 @@ class _LanczosBreakdown(RuntimeError):
     `svd_topk` then runs the filtered subspace iteration, which has a rebuild path for exactly these matrices."""
 
 
-def _ritz_check(ops, Tj, S, X0, k, b, est_tol, prior, seed, inner):
+def _ritz_check(ops, Tj, S, X0, k, b, est_tol, prior, seed, inner, final=False):
     """The k leading Ritz pairs of T_j and estimates of their residuals (one per pair, relative to theta_1).
     The pairs come in stages: while the outer method is far from converged an ESTIMATE is all a check needs, so the nested
     iteration first runs to a loose tolerance and is tightened (warm) only while its own residual, not the coupling to the
@@ -379,6 +379,8 @@ def _ritz_check(ops, Tj, S, X0, k, b, est_tol, prior, seed, inner):
         X0 = ops.zeros(b, b)
         X0[:b] = torch.eye(b, dtype=X0.dtype, device=X0.device)
     t_in = max(0.3 * est_tol, 1e-4 if prior is None else 0.03 * prior)
+    if final:                # the look at the step the pairs are predicted to have converged at: straight to the end
+        t_in = 0.3 * est_tol
     while True:
         basis, lam_all, res_in, n_lock, conv_in = ops.sym_eig_topk(Tj, k, X0, t_in, 200, seed, inner)
         X0 = basis.contiguous()
@@ -558,7 +560,8 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
                 continue
             # ---- the pairs of T_j on the main stream, and their verification ------------------------------------
             breakdown_check(j)
-            out = _ritz_check(ops, snapshot(N), S, warm, k, b, est_tol, hist[-1][1] if hist else None, seed + 1000 * j, inner)
+            out = _ritz_check(ops, snapshot(N), S, warm, k, b, est_tol, hist[-1][1] if hist else None, seed + 1000 * j, inner,
+                              final=len(hist) >= 2)
             warm = out['basis']
             hist.append((j, out['worst']))
             if verbose and comm.rank == 0:
