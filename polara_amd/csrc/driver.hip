@@ -1144,7 +1144,15 @@ static int svd_build_impl(pk_ctx *ctx, pk_mat *A, const pk_comm *comm, int32_t k
                 return fail(ctx, PK_E_LAUNCH, "pk_svd_build_sharded: the communicator's all-reduce failed");
             CK(S.to_host(wd.p, &work, 8));
         }
-        use_lanczos = me && !strcmp(me, "lanczos") ? true : me && !strcmp(me, "subspace") ? false : work * l >= 2e8;
+        // solver.py::choose_method: a step's products against the re-orthogonalisation over the Krylov basis and the
+        // projected eigenproblems
+        const int world = comm ? comm->world : 1;
+        double t_step = work * l * 16.0 / 15e12 / world;
+        if (world > 1) t_step += 2.0 * (world - 1) / world * (double)n_items * l * 8.0 / 100e9 + 2 * (world - 1) * 5e-6;
+        const double t_reorth = 96.0 * (double)n_items * l * l / 20e12,
+                     t_nested = 8e-3 * std::max(1.0, (l / 64.0) * (l / 64.0)) / 16.0;
+        const bool model = !(work * l < 2e8 || t_reorth + t_nested >= 2.0 * t_step);
+        use_lanczos = me && !strcmp(me, "lanczos") ? true : me && !strcmp(me, "subspace") ? false : model;
     }
     DMat Vk;
     std::vector<double> lam_k, res_host;

@@ -597,6 +597,29 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
     return result
 
 
+def choose_method(nnz, n_items, l, world=1):
+    """'lanczos' or 'subspace' from a cost model of one Gramian step (the same rule in csrc/driver.hip::svd_build_impl).
+    Block Lanczos needs ~2.5x fewer Gramian steps and pays for them per step with the re-orthogonalisation against the
+    whole Krylov basis (three Gram products and three projections over ~8 blocks on average: ~96 n_items l^2 flop on the
+    fp64 matrix cores at ~20 TFLOP/s) and with its projected eigenproblems (a few ms per build, growing with l^2):
+      ML-20M-shaped rank 50 (l = 64): step 1.4 ms, re-orthogonalisation 0.5 ms      47.7 -> 32.3 ms
+      ML-20M-shaped rank 100 (l = 128): 2.7 / 2.1 ms                                112 -> 85 ms
+      S-1M rank 50: 6.8 / 2.0 ms                                                   289 -> 172 ms
+      ML-1M-shaped rank 10 (l = 24): a step is 0.05 ms, the eigenproblems are not: 4.6 -> 9.1 ms          => subspace
+      S-50M shard, rank 200 (l = 256, 500 K items): 14.5 ms against 157 ms of re-orthogonalisation: 1.4 -> 2.2 s => subspace
+    Sharded over `world` ranks the products shrink by the number of ranks and the exchange of the block joins every step of
+    either method; the re-orthogonalisation launches and the (replicated) eigenproblems do not shrink: ML-20M-shaped on 8
+    ranks is back on the subspace iteration (both ~33 ms in the scaling proxy: 17 K users per rank is a latency problem)."""
+    t_step = nnz * l * 16.0 / 15e12 / world               # both products of a step: gathers of l fp64 columns per entry
+    if world > 1:    # every step of either method also pays its exchange (all-gather + reduce-scatter of an [n_items x l] block)
+        t_step += 2.0 * (world - 1) / world * n_items * l * 8.0 / 100e9 + 2 * (world - 1) * 5e-6
+    t_reorth = 96.0 * n_items * float(l) * l / 20e12
+    t_nested = 8e-3 * max(1.0, (l / 64.0) ** 2) / 16.0
+    if nnz * l < 2e8 or t_reorth + t_nested >= 2.0 * t_step:
+        return 'subspace'
+    return 'lanczos'
+
+
 def svd_topk(ops, A, k, block=None, tol=1e-12, max_outer=200, m_max=24, spread=1e7, seed=0,
              comm=None, want_u=False, verbose=False, even_lock=True, shard_items=True, method=None, max_steps=64):
     """Returns (U_local | None, sigma[k] desc, V [n_items x k], stats) as device tensors of `ops`.
@@ -618,18 +641,14 @@ def svd_topk(ops, A, k, block=None, tol=1e-12, max_outer=200, m_max=24, spread=1
     if method not in ('lanczos', 'subspace', 'auto'):
         raise ValueError("method must be 'lanczos', 'subspace' or 'auto'")
     if method == 'auto':
-        # Block Lanczos saves Gramian steps and pays for them with its projected eigenproblems (a few ms of small
-        # launches whatever the matrix): it wins where a Gramian step costs a millisecond (ML-20M-shaped rank 50: 47.7 ->
-        # 32.3 ms, S-1M: 289 -> 172 ms) and loses on small matrices (ML-1M-shaped rank 10: 4.6 -> 9.1 ms).  The switch is
-        # the work of a step — stored entries x block width, summed over the ranks so that every rank decides alike;
-        # operators that do not say how many entries they hold (host-side LinearOperators: their products are the
-        # expensive kind) count as large.
+        # every rank decides alike: the entry count is summed over the ranks; operators that do not say how many entries
+        # they hold (host-side LinearOperators: their products are the expensive kind) count as large
         nnz = getattr(A, 'nnz', None)
-        work = float('inf')
+        total = float('inf')
         if nnz is not None:
             t = ops.to_device(np.array([float(nnz)]))
-            work = float(ops.to_host(comm.allreduce(t))[0]) * l
-        method = 'lanczos' if work >= 2e8 else 'subspace'
+            total = float(ops.to_host(comm.allreduce(t))[0])
+        method = choose_method(total, n_items, l, comm.world)
     stats_method = method
     # the operator of Z = A^T Y: a device matrix offers its user-blocked transpose (ops.BlockedTranspose)
     At = A.transpose_operator() if hasattr(A, 'transpose_operator') else A.T

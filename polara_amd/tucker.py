@@ -265,6 +265,8 @@ def hooi(ops, idx, val, shape, core_shape, num_iters=25, growth_tol=0.01, seed=N
         if any(v != 1.0 for v in host[1:]):
             # a direct solve did not pass its own check (degenerate Gram matrix): this iteration again, and every later
             # one, on the Jacobi route — same inputs, nothing of the discarded attempt is kept
+            if verbose:
+                print('[hooi] iteration %d: direct eigensolve verdicts %s -> Jacobi route from here on' % (i, host[1:]))
             for w in warm:
                 if w is not None:
                     w['no_direct'] = True
