@@ -37,6 +37,9 @@ extern "C" {
 
 #define PK_VAL_F32 0
 #define PK_VAL_F64 1
+/* x_kind flag of pk_spmm_csr_ex: PK_VAL_F32 | PK_X_HEAD asks for the persistent fold-in instance that stages the first rows
+ * of the fp32 dense block in LDS (opt-in: measured slower than the plain kernel, see csrc/spmm.hip; same bits) */
+#define PK_X_HEAD 16
 
 const char *pk_last_error(void);
 int pk_version(void);

@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpolarahip.so')
 
 PK_VAL_F32, PK_VAL_F64 = 0, 1
+PK_X_HEAD = 16      # x_kind flag of pk_spmm_csr_ex: the persistent fold-in instance with the head of X in LDS (opt-in)
 
 _vp, _i32, _i64, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
 

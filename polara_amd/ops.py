@@ -539,7 +539,7 @@ class HipOps:
         return torch.randn(n, m, generator=g, dtype=torch.float64, device=self.device)
 
     # ---- K1/K4 ------------------------------------------------------------------------------
-    def spmm(self, A, X, out=None, rows=None):
+    def spmm(self, A, X, out=None, rows=None, head_in_lds=False):
         """out[n_rows x nc] = A @ X (fp64 accumulate, fp64 out).  A: DeviceCSR, X: [n_cols x nc] row-major, fp64
         or fp32 (the fp32 image of the item factors for the approximate fold-in).
         rows=(lo, hi): only rows [lo, hi) are computed (written to the same rows of the FULL-height `out`):
@@ -557,12 +557,14 @@ class HipOps:
                 self.spmm(A, X[:, c0:c0 + 256], out=out[:, c0:c0 + 256], rows=rows)
             return out
         rng = (0, A.n_tasks, 0, A.n_long) if rows is None else A.task_range(int(rows[0]), int(rows[1]))
-        return self._spmm_launch(A, X, out, rng)
+        return self._spmm_launch(A, X, out, rng, head_in_lds=head_in_lds)
 
-    def _spmm_launch(self, A, X, out, rng, row_base=0, accumulate=False, meta_shape=None):
+    def _spmm_launch(self, A, X, out, rng, row_base=0, accumulate=False, meta_shape=None, head_in_lds=False):
         """one launch of the row-task kernel over the plan slice `rng` = (first task, tasks, first long row, long rows)"""
         nc = X.shape[1]
         x_kind = _lib.PK_VAL_F64 if X.dtype == torch.float64 else _lib.PK_VAL_F32
+        if head_in_lds and X.dtype == torch.float32:
+            x_kind |= _lib.PK_X_HEAD        # the persistent instance with the first rows of X in LDS (opt-in, see spmm.hip)
         p = A.plan
         t0, n_tasks, l0, n_long = rng
         tr, tb, te, ts = p['task_row'], p['task_begin'], p['task_end'], p['task_slot']

@@ -79,6 +79,41 @@ def test_spmm_fp32_dense_block(hip_ops, nc):
     assert np.allclose(hip_ops.to_host(out)[:, :nc], ref, rtol=1e-13, atol=1e-13) and float(out[:, nc:].abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize('n_cols,nc,ld', [(3000, 52, 64), (300, 52, 64), (20000, 64, 64), (1500, 12, 16)])
+def test_fold_in_with_the_head_of_the_image_in_lds(hip_ops, n_cols, nc, ld):
+    """The persistent fold-in instance (fold_in_head_kernel: the first rows of the fp32 factor image staged in LDS; opt-in —
+    it measured slower than the plain kernel, csrc/spmm.hip): against SciPy, and BIT-identical to the plain groups kernel
+    (same mapping, same summation order) — over catalogues shorter than the LDS window (everything is head), long rows
+    (split tasks + fix-up), empty rows, strided image and strided output."""
+    import torch
+    rng = np.random.RandomState(n_cols + nc)
+    n_rows = 20000
+    pop = 1.0 / (1.0 + np.arange(n_cols)) ** 0.8            # popular items first: most entries fall into the head
+    pop /= pop.sum()
+    counts = rng.poisson(25, n_rows).clip(0, n_cols)
+    counts[[5, 777]] = 0
+    counts[[9, 4000]] = min(n_cols, 2500)                    # rows longer than a task (1024 entries)
+    indptr = np.r_[0, np.cumsum(counts)].astype(np.int64)
+    indices = np.concatenate([np.sort(rng.choice(n_cols, c, replace=False, p=pop)) for c in counts]).astype(np.int32)
+    values = rng.randint(1, 11, indptr[-1]).astype(np.float32) * 0.5
+    A = hip_ops.csr(indptr, indices, values, (n_rows, n_cols))
+    img = torch.zeros(n_cols, ld, dtype=torch.float32, device=hip_ops.device)[:, :nc]      # strided like FactorImage.V32x
+    X32 = rng.randn(n_cols, nc).astype(np.float32)
+    img.copy_(hip_ops.to_device(X32))
+    out = torch.zeros(n_rows, nc + 4, dtype=torch.float64, device=hip_ops.device)
+    hip_ops.spmm(A, img, out=out[:, :nc], head_in_lds=True)  # one launch: the LDS-head instance
+    got = hip_ops.to_host(out)
+    ref = sps.csr_matrix((values.astype(np.float64), indices, indptr), shape=(n_rows, n_cols)) @ X32.astype(np.float64)
+    assert np.allclose(got[:, :nc], ref, rtol=1e-13, atol=1e-13) and np.abs(got[:, nc:]).sum() == 0.0
+    parts = torch.zeros(n_rows, nc, dtype=torch.float64, device=hip_ops.device)
+    for lo in range(0, n_rows, 4000):                       # the plain kernel, in user batches
+        hip_ops.spmm(A, img, out=parts, rows=(lo, min(n_rows, lo + 4000)))
+    assert np.array_equal(hip_ops.to_host(parts), got[:, :nc])
+    again = torch.zeros_like(out)
+    hip_ops.spmm(A, img, out=again[:, :nc], head_in_lds=True)
+    assert np.array_equal(hip_ops.to_host(again), got)
+
+
 def test_device_coo_to_csr_matches_scipy(hip_ops):
     rng = np.random.RandomState(4)
     n_rows, n_cols, nnz = 5000, 3000, 400000
