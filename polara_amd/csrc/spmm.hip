@@ -149,7 +149,10 @@ __global__ __launch_bounds__(256) void spmm_csr_groups_kernel(
     // wave steps per register set (two sets in flight); an fp32 row piece is one float4 per lane and step
     // (half the registers of the fp64 pair), so twice as many steps fit in flight: fold-in 2.20 -> 1.98 ms.
     // (16 steps: slower, occupancy; 8 steps for the fp64 block: slower too, 3.30 -> 4.07 ms.)
-    constexpr int U = XF ? 8 : 4;
+    // narrow instances (round 4): GROUPS = 8 / 16 — 8 / 4 lanes per gathered row for <= 32 / <= 16 fp64 columns, so
+    // that a narrow panel does not idle three quarters of every gather instruction's lanes the way GROUPS = 4 does at nc = 16
+    constexpr int U = XF ? 8 : (GROUPS == 16 ? 2 : 4);
+    static_assert(!XF || GROUPS <= 4, "the fp32 dense block runs on GROUPS <= 4 only");
     using XA = typename std::conditional<XF, float4, double2>::type;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -263,7 +266,15 @@ __global__ __launch_bounds__(256) void spmm_csr_groups_kernel(
     }
 
     // add the GROUPS partial sums in group order (fixed): after the exchange every lane holds the total
-    if constexpr (GROUPS == 4) {
+    if constexpr (GROUPS == 16) {
+        acc0.x += pk_lane_xor<4>(acc0.x); acc0.y += pk_lane_xor<4>(acc0.y);
+        acc1.x += pk_lane_xor<4>(acc1.x); acc1.y += pk_lane_xor<4>(acc1.y);
+    }
+    if constexpr (GROUPS >= 8) {
+        acc0.x += pk_lane_xor<8>(acc0.x); acc0.y += pk_lane_xor<8>(acc0.y);
+        acc1.x += pk_lane_xor<8>(acc1.x); acc1.y += pk_lane_xor<8>(acc1.y);
+    }
+    if constexpr (GROUPS >= 4) {
         // (g0 + g1) and (g2 + g3) first, then the two pairs: the same association in every lane
         acc0.x += pk_lane_xor<16>(acc0.x); acc0.y += pk_lane_xor<16>(acc0.y);
         acc1.x += pk_lane_xor<16>(acc1.x); acc1.y += pk_lane_xor<16>(acc1.y);
@@ -519,7 +530,10 @@ static int launch_spmm(hipStream_t st, int64_t n_tasks, const int32_t *task_row,
         if (accumulate) { if (off32) PK_SPMM_LAUNCH_D(G, true, true); else PK_SPMM_LAUNCH_D(G, true, false); }        \
         else { if (off32) PK_SPMM_LAUNCH_D(G, false, true); else PK_SPMM_LAUNCH_D(G, false, false); }                 \
     } while (0)
-        if (nc <= 64) PK_SPMM_GROUPS(4);
+        static const int narrow = []() { const char *e = getenv("PK_SPMM_NARROW"); return e ? atoi(e) : 1; }();     // 0: GROUPS = 4 for every nc <= 64
+        if (narrow && nc <= 16) PK_SPMM_GROUPS(16);
+        else if (narrow && nc <= 32) PK_SPMM_GROUPS(8);
+        else if (nc <= 64) PK_SPMM_GROUPS(4);
         else if (nc <= 128) PK_SPMM_GROUPS(2);
         else PK_SPMM_GROUPS(1);
 #undef PK_SPMM_GROUPS
