@@ -25,6 +25,10 @@ if os.environ.get('PK_FAST_BUILD'):   # kernel-tuning builds: only the rank-50 /
     FLAGS.append('-DPK_FAST_BUILD')
 if os.environ.get('PK_SWEEP_WAVES'):    # kernel-tuning builds: force the sweep's register budget to this many waves per SIMD
     FLAGS.append('-DPK_SWEEP_WAVES=' + os.environ['PK_SWEEP_WAVES'])
+if os.environ.get('PK_SCORE_ROLL') == '4':     # kernel-tuning builds: the rolling-buffer sweep forced to four waves per SIMD (rank <= 64, top-10)
+    FLAGS.append('-DPK_SCORE_ROLL4=1')
+if os.environ.get('PK_SCORE_TWO_BUFFERS'):     # kernel-tuning builds: the two-buffer tile loop of rounds 1-3
+    FLAGS.append('-DPK_SCORE_TWO_BUFFERS=1')
 if os.environ.get('PK_SHARED_WAVES'):   # kernel-tuning builds: waves per workgroup of the LDS-staged sweep instance
     FLAGS.append('-DPK_SHARED_WAVES=' + os.environ['PK_SHARED_WAVES'])
 if os.environ.get('PK_ETOP_PROFILE'):   # kernel-tuning builds: phase clocks of eigh_top_kernel in info[2..7]

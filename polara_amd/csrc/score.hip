@@ -41,6 +41,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define RING 16          // lane-private candidate ring entries (8 for KC == 16, see PAIRED below)
+#if !defined(PK_SCORE_TWO_BUFFERS) && !defined(PK_SCORE_ROLL)
+#define PK_SCORE_ROLL 1  // the rolling fragment buffer of the tile loop (round 4; see score_tile_roll)
+#endif
 
 #ifdef PK_SCORE_PROFILE
 // tuning builds only: wave-cycles spent in [0] whole kernel, [1] flushes, [2] seen-list walk, [3] push path,
@@ -210,6 +213,8 @@ struct SeenDense {
 // sweeps, rank 200 — the extra registers and per-tile tests of a run-time switch cost 10 %).
 #ifdef PK_SWEEP_WAVES      // kernel-tuning builds: force the register budget of PK_SWEEP_WAVES waves per SIMD
 #define PK_SWEEP_OCC __attribute__((amdgpu_waves_per_eu(PK_SWEEP_WAVES, PK_SWEEP_WAVES)))
+#elif defined(PK_SCORE_ROLL4)   // with the rolling buffer the rank <= 64, top-10 instances are 8 registers from four waves per SIMD
+#define PK_SWEEP_OCC __attribute__((amdgpu_waves_per_eu((NSTEP <= 4 && KC == 16 && !SHARED) ? 4 : 1)))
 #else
 #define PK_SWEEP_OCC
 #endif
@@ -697,6 +702,34 @@ __global__ __launch_bounds__(SHARED ? 64 * pk_shared_waves(KC) : 256) PK_SWEEP_O
         }
         return acc;
     };
+#ifdef PK_SCORE_ROLL
+    // Round 4: ONE fragment buffer.  The registers of k-step s are re-requested for the next tile right after the three MFMAs
+    // that read them: KQ instead of 2 KQ fragment registers (rank 50: 166 -> 136 VGPRs, rank 100: 243 -> 186), no
+    // `s_waitcnt vmcnt(0)` + sixteen v_mov_b64 (a <- a_nxt) at the end of every tile — the compiler now waits per k-step with
+    // vmcnt(7) / vmcnt(6) on loads issued a whole tile earlier (round 1 saw it drain vmcnt(0) at the loop head with this
+    // form; ROCm 7.2 does not).  Measured (bench.py, same box, two-buffer -> rolling): rank 100 / top-20 1.97 -> 1.63 ms per
+    // pass (70 -> 85 M users/s), no-prune 71 -> 75 M, pop^0.25 73 -> 80 M, flat-norm 61 -> 63 M users/s, pruned headline sweep
+    // 0.378 -> 0.377 ms (it is not bound by the tile loop).  Forcing the rank-50 instance from 136 to 128 registers for four
+    // waves per SIMD (PK_SCORE_ROLL=4 builds: 4 spills) made everything slower again (no-prune 75 -> 68 M): occupancy is not
+    // what this kernel lacks.  -DPK_SCORE_TWO_BUFFERS builds the old loop.
+    auto score_tile_roll = [&](float4(&a)[SHARED ? 1 : KQ], int next_tile) -> f32x16 {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        const float4 *vp = Vp + ((int64_t)next_tile * KQ) * 64 + lane;
+#pragma unroll
+        for (int sidx = 0; sidx < (SHARED ? 0 : NSTEP); ++sidx) {
+            const bf16x8 vh = __builtin_bit_cast(bf16x8, a[2 * sidx]), vl = __builtin_bit_cast(bf16x8, a[2 * sidx + 1]);
+            const bf16x8 eh = __builtin_bit_cast(bf16x8, e[2 * sidx]), el = __builtin_bit_cast(bf16x8, e[2 * sidx + 1]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, eh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, el, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, eh, acc, 0, 0, 0);
+            a[2 * sidx] = vp[(2 * sidx) * 64];
+            a[2 * sidx + 1] = vp[(2 * sidx + 1) * 64];
+        }
+        return acc;
+    };
+#endif
     if (first && boot_tiles > 0 && floor_state == nullptr && !(ablate & 8)) {
         const unsigned long long prof_b0 = PROF_T();
         constexpr int BL = KC / 2;      // values kept per lane: the user's two lanes hold KC of them
@@ -717,21 +750,31 @@ __global__ __launch_bounds__(SHARED ? 64 * pk_shared_waves(KC) : 256) PK_SWEEP_O
         if constexpr (DENSE) m_nxt = (tile_begin < dense_tiles) ? dense_row[(int64_t)tile_begin * 32] : 0u;
         // (trip count uniform over the workgroup: SHARED has a barrier per tile)
         for (int i = 0, tile = tile_begin; i < boot_tiles && tile < tile_end; ++i, tile += S) {
+#ifndef PK_SCORE_ROLL
             float4 a[SHARED ? 1 : KQ];
+#endif
             if constexpr (SHARED) {
                 if (i + 1 < boot_tiles && tile + S < tile_end) stage_tile(tile + S, (i + 1) & 1);
             }
+#ifndef PK_SCORE_ROLL
             if constexpr (!SHARED) {
 #pragma unroll
                 for (int q = 0; q < KQ; ++q) a[q] = a_nxt[q];
                 load_frags((tile + S < tile_end) ? tile + S : tile, a_nxt);
             }
+#endif
             if (!SHARED || alive) {
                 if constexpr (DENSE) {
                     m_dense = m_nxt;
                     m_nxt = (tile + S < dense_tiles) ? dense_row[(int64_t)(tile + S) * 32] : 0u;
                 }
+#ifdef PK_SCORE_ROLL
+                f32x16 acc;
+                if constexpr (SHARED) acc = score_tile(a_nxt, i & 1);
+                else acc = score_tile_roll(a_nxt, (tile + S < tile_end) ? tile + S : tile);
+#else
                 const f32x16 acc = score_tile(a, i & 1);
+#endif
                 const unsigned m2 = walk_mask(tile) >> (4 * hi);
 #pragma unroll
                 for (int g = 0; g < BG; ++g) {
@@ -826,12 +869,14 @@ __global__ __launch_bounds__(SHARED ? 64 * pk_shared_waves(KC) : 256) PK_SWEEP_O
                     tb = tile_bound[(tile + S < n_tiles) ? tile + S : tile];   // suffix maximum: covers my later tiles
                 }
             }
+#ifndef PK_SCORE_ROLL
             float4 a[SHARED ? 1 : KQ];
             if constexpr (!SHARED) {
 #pragma unroll
                 for (int q = 0; q < KQ; ++q) a[q] = a_nxt[q];
                 load_frags((tile + S < tile_end) ? tile + S : tile, a_nxt);
             }
+#endif
             if (!SHARED || alive) {
                 if constexpr (DENSE) {
                     m_dense = m_nxt;
@@ -840,7 +885,13 @@ __global__ __launch_bounds__(SHARED ? 64 * pk_shared_waves(KC) : 256) PK_SWEEP_O
 #ifdef PK_SCORE_PROFILE2
                 const unsigned long long prof_m0 = PROF_T();
 #endif
+#ifdef PK_SCORE_ROLL
+                f32x16 acc;
+                if constexpr (SHARED) acc = score_tile(a_nxt, step & 1);
+                else acc = score_tile_roll(a_nxt, (tile + S < tile_end) ? tile + S : tile);
+#else
                 const f32x16 acc = score_tile(a, step & 1);
+#endif
 #ifdef PK_SCORE_PROFILE2
                 asm volatile("" ::"v"(acc[0]), "v"(acc[15]));     // the products are done before the clock is read
                 PROF_ADD(1, prof_m0);
