@@ -721,9 +721,19 @@ __global__ __launch_bounds__(SHARED ? 64 * pk_shared_waves(KC) : 256) PK_SWEEP_O
         for (int sidx = 0; sidx < (SHARED ? 0 : NSTEP); ++sidx) {
             const bf16x8 vh = __builtin_bit_cast(bf16x8, a[2 * sidx]), vl = __builtin_bit_cast(bf16x8, a[2 * sidx + 1]);
             const bf16x8 eh = __builtin_bit_cast(bf16x8, e[2 * sidx]), el = __builtin_bit_cast(bf16x8, e[2 * sidx + 1]);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, eh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, el, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, eh, acc, 0, 0, 0);
+#ifdef PK_SCORE_DIAG       // kernel-tuning builds: ablate & 32 = no products (the fragments are still waited for), & 16 = no re-loads
+            if (ablate & 32) {
+                acc[sidx] += a[2 * sidx].x + a[2 * sidx + 1].y;
+            } else
+#endif
+            {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, eh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, el, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, eh, acc, 0, 0, 0);
+            }
+#ifdef PK_SCORE_DIAG
+            if (ablate & 16) continue;
+#endif
             a[2 * sidx] = vp[(2 * sidx) * 64];
             a[2 * sidx + 1] = vp[(2 * sidx + 1) * 64];
         }
@@ -994,6 +1004,439 @@ __global__ __launch_bounds__(SHARED ? 64 * pk_shared_waves(KC) : 256) PK_SWEEP_O
         ls.tau = tau;
         ls.cnt = PK_LANE_DONE;
         *my_state = ls;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// score_candidates_pair_kernel (round 4): TWO user groups per wave.
+// The dense regimes of the sweep are bound by the fragment loads, not by the matrix cores: a PK_SCORE_DIAG build of the
+// full ML-20M-shaped sweep (no pushes) takes 1.98 ms as it is, 1.18 ms without the fragment re-loads, 1.79 ms without the
+// PRODUCTS (loads still waited for) and 0.83 ms without either (tools/probes/sweep_floor.py, PK_FLOOR_DIAG) — 3.6 M
+// tile-waves x 8 KB = 30 GB through the L1 path at ~17 TB/s, the same ceiling the SpMM gathers hit (64 lanes x 16 B per
+// load instruction).  More waves do not help (four forced waves: slower), staging tiles in LDS costs a barrier per tile
+// (round 3); what halves the bytes per product is using every loaded fragment for TWO groups of 32 users: this kernel.
+// A wave owns groups 2 w and 2 w + 1 (adjacent in activity order: they leave the sweep at similar tiles); per k-step six
+// MFMAs on two independent accumulator chains, then the step's fragment registers are re-requested for the next tile
+// (the rolling buffer of score_tile_roll); selection state, rings and lists exist once per group (GS), the epilogue of a
+// tile runs once per group that is still sweeping.  Single sweeps with the lists in LDS and KC = 16 (top-10 lists: two
+// groups' rings and lists are 16 KB per wave, 64 KB per workgroup; KC = 32 would leave one wave per SIMD), same parked
+// state and list layout as score_candidates_kernel, same scores bit for bit (the MFMA sequence of a group is unchanged).
+// MEASURED (bench.py, ML-20M-shaped, one group -> two groups per wave; 240 VGPRs, two waves per SIMD): pruned headline
+// sweep 0.377 -> 0.617 ms, flat-norm catalogue 63.5 -> 50.2 M users/s, no-prune 74 -> 71 M, pop^0.25 79 -> 71 M: SLOWER in
+// every regime — half the fragment bytes per product buy nothing, so the "loads" of the diagnostic build are waiting
+// time that three free-running waves overlap better than two fat ones, not bytes.  OPT-IN (PK_SCORE_PAIR=1), kept as the
+// record of the experiment like the LDS-staged instance; lists identical (tests/test_gpu_kernels.py).
+// ------------------------------------------------------------------------------------------
+template <int NSTEP, int KC, bool DENSE>
+__global__ __launch_bounds__(256) void score_candidates_pair_kernel(
+    const float4 *__restrict__ Vp, const float4 *__restrict__ Ep, int64_t n_users, int n_items,
+    int n_tiles, int split_tiles, int chunk_begin, int chunk_tiles,
+    const int64_t *__restrict__ seen_ptr, const unsigned long long *__restrict__ seen_tiles,
+    const int32_t *__restrict__ seen_ntiles,
+    float *__restrict__ cand_score, int32_t *__restrict__ cand_idx,
+    LaneState *__restrict__ st_lane, uint2 *__restrict__ st_ring,
+    const float *__restrict__ user_bound, const float *__restrict__ tile_bound, int ablate, SeenDense dense,
+    int slot_base, int boot_tiles) {
+    constexpr int KQ = 2 * NSTEP;
+    static_assert(KC == 16 && pk_top_in_lds(NSTEP, KC), "pair kernel: top-10 lists (KC = 16) in LDS");
+    constexpr int RG = pk_ring_rows(KC);
+    constexpr int NG = 2, NW = 4;
+    extern __shared__ __attribute__((aligned(16))) uint2 pk_score_lds[];      // [NW * NG][RG][64] rings, then [NW * NG][32 * KC] lists
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t n_groups = (n_users + 31) / 32;
+    const int tile_begin = chunk_begin;
+    const int tile_stop = (chunk_begin + chunk_tiles < split_tiles) ? chunk_begin + chunk_tiles : n_tiles;
+    const int tile_end = (tile_stop < n_tiles) ? tile_stop : n_tiles;
+    const bool first = (chunk_begin == 0);
+    const bool last = (tile_stop >= n_tiles);
+    if (!first && tile_begin >= n_tiles) return;
+    const int ul = lane & 31, hi = lane >> 5;
+    const bool prune = (user_bound != nullptr && tile_bound != nullptr) && !(ablate & 4);
+    const int dense_tiles = (DENSE && seen_ptr != nullptr) ? dense.tiles : 0;
+
+    struct GS {
+        float4 e[KQ];
+        int64_t sp, se;
+        unsigned long long nxt, nxt2, nxt3;
+        float tau, tau_floor, en;
+        int cnt, exit_tile;
+        bool live, alive, pruned, has_seen;      // live: takes part in this launch; alive: still sweeping
+        float *my_score;
+        int32_t *my_idx;
+        LaneState *my_state;
+        uint2 *my_ring_state;
+        const unsigned *dense_row;
+        unsigned m_dense, m_nxt;
+        uint2 (*ring)[64];
+        uint2 *top;
+    };
+    GS gs[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        GS &s = gs[g];
+        const int64_t group_raw = ((int64_t)blockIdx.x * NW + wave) * NG + g;
+        s.live = group_raw * 32 < n_users;
+        const int64_t group = s.live ? group_raw : 0;
+        const int64_t user = group * 32 + ul;
+        const int64_t slot = (int64_t)slot_base * n_groups + group;
+        s.my_score = cand_score + slot * 32 * KC;
+        s.my_idx = cand_idx + slot * 32 * KC;
+        s.my_state = st_lane + slot * 64 + lane;
+        s.my_ring_state = st_ring + slot * (RING * 64);
+        s.ring = reinterpret_cast<uint2(*)[64]>(pk_score_lds + (wave * NG + g) * (RG * 64));
+        s.top = pk_score_lds + NW * NG * RG * 64 + (wave * NG + g) * (32 * KC);
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) s.e[q] = Ep[(group * KQ + q) * 64 + lane];
+        s.sp = s.se = 0;
+        s.nxt = s.nxt2 = s.nxt3 = PK_TILE_NONE;
+        s.tau = -INFINITY;
+        s.tau_floor = -INFINITY;
+        s.cnt = 0;
+        s.en = (prune && s.live && user < n_users) ? user_bound[user] : -1.0f;
+        s.pruned = false;
+        s.exit_tile = tile_end;
+        s.has_seen = (seen_ptr != nullptr && s.live && user < n_users);
+        if (s.has_seen) {
+            s.sp = seen_ptr[user];
+            s.se = s.sp + seen_ntiles[user];
+        }
+        s.dense_row = dense_tiles ? dense.mask + ((int64_t)group * dense_tiles) * 32 + ul : nullptr;
+        s.m_dense = s.m_nxt = 0u;
+        if (DENSE && first && s.has_seen && dense_tiles) s.sp += dense.skip[user];
+        s.alive = s.live;
+        if (s.live) {
+            if (first) {
+                for (int t = lane; t < 32 * KC; t += 64) s.top[t] = make_uint2(__float_as_uint(-INFINITY), 0xffffffffu);
+            } else {
+                const LaneState ls = *s.my_state;
+                if (ls.cnt == PK_LANE_DONE) {              // wave-uniform: this group was pruned in an earlier launch
+                    s.live = s.alive = false;
+                } else {
+                    for (int t = lane; t < 32 * KC; t += 64) s.top[t] = make_uint2(__float_as_uint(s.my_score[t]), (unsigned)s.my_idx[t]);
+                    if (s.has_seen) s.sp = ls.sp;
+                    s.tau = ls.tau;
+                    s.tau_floor = fmaxf(s.tau_floor, s.tau);
+                    s.cnt = ls.cnt;
+                    const int cmax = __builtin_amdgcn_readfirstlane((int)__reduce_max_sync(~0ull, s.cnt));
+                    for (int i = 0; i < cmax; ++i) s.ring[i][lane] = s.my_ring_state[i * 64 + lane];
+                }
+            }
+        }
+        if (s.has_seen && s.live) {
+            if (s.sp < s.se) s.nxt = seen_tiles[s.sp];
+            if (s.sp + 1 < s.se) s.nxt2 = seen_tiles[s.sp + 1];
+            if (s.sp + 2 < s.se) s.nxt3 = seen_tiles[s.sp + 2];
+        }
+    }
+    if (!gs[0].live && !gs[1].live) return;
+
+    // users x (lanes 0..31) and y (lanes 32..63; y < 0: nobody) of group s merged in one 32-wide sort each (flush_pair of
+    // score_candidates_kernel, state through s)
+    auto flush_pair = [&](GS &s, int x, int y) {
+        __builtin_amdgcn_wave_barrier();
+        const int t = lane & 31;
+        const int yy = (y >= 0) ? y : x;
+        const int cx_lo = __builtin_amdgcn_readlane(s.cnt, x), cx_hi = __builtin_amdgcn_readlane(s.cnt, x + 32);
+        const int cy_lo = __builtin_amdgcn_readlane(s.cnt, yy), cy_hi = __builtin_amdgcn_readlane(s.cnt, yy + 32);
+        const int u = hi ? yy : x;
+        const int c_lo = hi ? cy_lo : cx_lo, c_hi = hi ? cy_hi : cx_hi;
+        const bool act = !hi || y >= 0;
+        float k = -INFINITY;
+        int v = PK_IDX_NONE;
+        if (act) {
+            if (t < KC) {
+                const uint2 r = s.top[u * KC + t];
+                if ((int)r.y >= 0) {
+                    k = __uint_as_float(r.x);
+                    v = (int)r.y;
+                }
+            } else if (t < KC + RG) {
+                if (t - KC < c_lo) {
+                    const uint2 r = s.ring[t - KC][u];
+                    k = __uint_as_float(r.x);
+                    v = (int)r.y;
+                }
+            } else if (t - KC - RG < c_hi) {
+                const uint2 r = s.ring[t - KC - RG][u + 32];
+                k = __uint_as_float(r.x);
+                v = (int)r.y;
+            }
+        }
+        unsigned key = (pk_float_order(k) & ~31u) | (unsigned)t;
+        pk_sort32_half_levels<32>(key);
+        const int src = (lane & 32) | (int)(key & 31u);
+        k = __shfl(k, src, 64);
+        v = __shfl(v, src, 64);
+        if (act && t < KC) s.top[u * KC + t] = make_uint2(__float_as_uint(k), (unsigned)((v == PK_IDX_NONE) ? -1 : v));
+        const float tx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(k), KC - 1));
+        const float ty = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(k), 32 + KC - 1));
+        if (ul == x) {
+            s.tau = fmaxf(tx, s.tau_floor);
+            s.cnt = 0;
+        }
+        if (y >= 0 && ul == y) {
+            s.tau = fmaxf(ty, s.tau_floor);
+            s.cnt = 0;
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto flush_set = [&](GS &s, unsigned um) {
+        while (um) {
+            const int x = __builtin_ctz(um);
+            um &= um - 1;
+            int y = -1;
+            if (um) {
+                y = __builtin_ctz(um);
+                um &= um - 1;
+            }
+            flush_pair(s, x, y);
+        }
+    };
+    auto walk_mask = [&](GS &s, int tile) -> unsigned {
+        const int j0 = tile * 32, jend = j0 + 32;
+        unsigned mask = 0;
+        if (ablate & 1) return 0u;
+        if constexpr (DENSE) {
+            if (tile < dense_tiles) {
+                mask = s.m_dense;
+                if (jend > n_items) mask |= ~0u << (n_items - j0);
+                return mask;
+            }
+        }
+        const bool hit = (unsigned)(s.nxt >> 32) == (unsigned)tile;
+        if (__any(hit)) {
+            if (hit) {
+                mask = (unsigned)s.nxt;
+                ++s.sp;
+                s.nxt = s.nxt2;
+                s.nxt2 = s.nxt3;
+                s.nxt3 = (s.sp + 2 < s.se) ? seen_tiles[s.sp + 2] : PK_TILE_NONE;
+            }
+        }
+        if (jend > n_items) mask |= ~0u << (n_items - j0);
+        return mask;
+    };
+    auto push_candidates = [&](GS &s, const float(&acc)[16], int j0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            bool c = acc[r] > s.tau;
+            if (__any(c)) {
+                if (__any(c && s.cnt == RG)) {
+                    const unsigned long long full = __ballot(s.cnt == RG);
+                    unsigned um = (unsigned)(full | (full >> 32));
+                    if (__builtin_popcount(um) & 1) {
+                        const unsigned long long part = __ballot(2 * s.cnt >= RG);
+                        const unsigned cand = (unsigned)(part | (part >> 32)) & ~um;
+                        if (cand) um |= 1u << __builtin_ctz(cand);
+                    }
+                    flush_set(s, um);
+                    c = acc[r] > s.tau;
+                }
+                if (c) {
+                    s.ring[s.cnt][lane] = make_uint2(__float_as_uint(acc[r]), (unsigned)(j0 + (r & 3) + 8 * (r >> 2) + 4 * hi));
+                    ++s.cnt;
+                }
+            }
+        }
+    };
+    // both groups' score tiles of one step: per k-step three MFMAs per group (two independent accumulator chains), then
+    // the step's fragment registers are re-requested for the next tile
+    float4 a[KQ];
+    auto score_pair = [&](int next_tile, f32x16 &acc0, f32x16 &acc1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc0[r] = 0.0f;
+            acc1[r] = 0.0f;
+        }
+        const float4 *vp = Vp + ((int64_t)next_tile * KQ) * 64 + lane;
+#pragma unroll
+        for (int sidx = 0; sidx < NSTEP; ++sidx) {
+            const bf16x8 vh = __builtin_bit_cast(bf16x8, a[2 * sidx]), vl = __builtin_bit_cast(bf16x8, a[2 * sidx + 1]);
+            const bf16x8 eh0 = __builtin_bit_cast(bf16x8, gs[0].e[2 * sidx]), el0 = __builtin_bit_cast(bf16x8, gs[0].e[2 * sidx + 1]);
+            const bf16x8 eh1 = __builtin_bit_cast(bf16x8, gs[1].e[2 * sidx]), el1 = __builtin_bit_cast(bf16x8, gs[1].e[2 * sidx + 1]);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, eh0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, eh1, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, el0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, el1, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, eh0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, eh1, acc1, 0, 0, 0);
+            a[2 * sidx] = vp[(2 * sidx) * 64];
+            a[2 * sidx + 1] = vp[(2 * sidx + 1) * 64];
+        }
+    };
+    auto load_frags = [&](int tile) {
+        const float4 *vp = Vp + ((int64_t)tile * KQ) * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) a[q] = vp[q * 64];
+    };
+
+    // ---- threshold bootstrap (see score_candidates_kernel): the first boot_tiles tiles scored once without selecting ----
+    if (first && boot_tiles > 0 && !(ablate & 8)) {
+        constexpr int BL = KC / 2, BG = KC / 8;
+        float bl[NG][BL];
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int i = 0; i < BL; ++i) bl[g][i] = -INFINITY;
+        int64_t sp0[NG];
+        unsigned long long n0[NG], n1[NG], n2[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            sp0[g] = gs[g].sp;
+            n0[g] = gs[g].nxt;
+            n1[g] = gs[g].nxt2;
+            n2[g] = gs[g].nxt3;
+            if constexpr (DENSE) gs[g].m_nxt = (gs[g].live && tile_begin < dense_tiles) ? gs[g].dense_row[(int64_t)tile_begin * 32] : 0u;
+        }
+        load_frags((tile_begin < n_tiles) ? tile_begin : 0);
+        for (int i = 0, tile = tile_begin; i < boot_tiles && tile < tile_end; ++i, ++tile) {
+            if constexpr (DENSE) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    gs[g].m_dense = gs[g].m_nxt;
+                    gs[g].m_nxt = (gs[g].live && tile + 1 < dense_tiles) ? gs[g].dense_row[(int64_t)(tile + 1) * 32] : 0u;
+                }
+            }
+            f32x16 acc[NG];
+            score_pair((tile + 1 < tile_end) ? tile + 1 : tile, acc[0], acc[1]);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                GS &s = gs[g];
+                if (!s.live) continue;
+                const unsigned m2 = walk_mask(s, tile) >> (4 * hi);
+#pragma unroll
+                for (int gg = 0; gg < BG; ++gg) {
+                    float x = -INFINITY;
+#pragma unroll
+                    for (int r = gg * (16 / BG); r < (gg + 1) * (16 / BG); ++r)
+                        x = fmaxf(x, (m2 & (1u << ((r & 3) + 8 * (r >> 2)))) ? -INFINITY : acc[g][r]);
+#pragma unroll
+                    for (int i2 = 0; i2 < BL; ++i2) {
+                        const float up = fmaxf(bl[g][i2], x);
+                        x = fminf(bl[g][i2], x);
+                        bl[g][i2] = up;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            GS &s = gs[g];
+            float t0 = bl[g][KC / 2 - 1];
+            t0 = fminf(t0, __int_as_float(pk_lane_xor<32>(__float_as_int(t0))));
+            if (t0 > -INFINITY) {
+                t0 = fminf(t0 - fabsf(t0) * 2.4e-7f, t0 - 1e-37f);
+                s.tau_floor = fmaxf(s.tau_floor, t0);
+                s.tau = fmaxf(s.tau, s.tau_floor);
+            }
+            s.sp = sp0[g];
+            s.nxt = n0[g];
+            s.nxt2 = n1[g];
+            s.nxt3 = n2[g];
+        }
+    }
+    // ---- the sweep ------------------------------------------------------------------------------------------------------------
+    load_frags((tile_begin < n_tiles) ? tile_begin : 0);
+    if constexpr (DENSE) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) gs[g].m_nxt = (gs[g].live && tile_begin < dense_tiles) ? gs[g].dense_row[(int64_t)tile_begin * 32] : 0u;
+    }
+    float tb = prune ? tile_bound[(tile_begin < n_tiles) ? tile_begin : 0] : 0.0f;
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
+        if (prune) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                GS &s = gs[g];
+                if (!s.alive) continue;
+                const bool open = s.en * tb > s.tau;
+                const unsigned long long ob = __ballot(open);
+                if (ob == 0ull) {
+                    s.pruned = true;
+                    s.exit_tile = tile;
+                    s.alive = false;
+                } else if ((tile & 7) == 7 && __popcll(ob) <= 16) {
+                    const unsigned long long pend = __ballot(s.cnt > 0);
+                    flush_set(s, (unsigned)(ob | (ob >> 32)) & (unsigned)(pend | (pend >> 32)));
+                }
+            }
+            if (!gs[0].alive && !gs[1].alive) break;
+            tb = tile_bound[(tile + 1 < n_tiles) ? tile + 1 : tile];
+        }
+        if constexpr (DENSE) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                gs[g].m_dense = gs[g].m_nxt;
+                gs[g].m_nxt = (gs[g].live && tile + 1 < dense_tiles) ? gs[g].dense_row[(int64_t)(tile + 1) * 32] : 0u;
+            }
+        }
+        f32x16 acc[NG];
+        score_pair((tile + 1 < tile_end) ? tile + 1 : tile, acc[0], acc[1]);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            GS &s = gs[g];
+            if (!s.alive) continue;
+            const unsigned mask = walk_mask(s, tile);
+            float m_all = fmaxf(acc[g][0], acc[g][1]);
+#pragma unroll
+            for (int r = 2; r < 16; ++r) m_all = fmaxf(m_all, acc[g][r]);
+            if (!(ablate & 2) && __any(m_all > s.tau)) {
+                float sc[16];
+                float m = m_all;
+                if (__any(mask != 0)) {
+                    const unsigned m2 = mask >> (4 * hi);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sc[r] = (m2 & (1u << ((r & 3) + 8 * (r >> 2)))) ? -INFINITY : acc[g][r];
+                    m = fmaxf(sc[0], sc[1]);
+#pragma unroll
+                    for (int r = 2; r < 16; ++r) m = fmaxf(m, sc[r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sc[r] = acc[g][r];
+                }
+                if (__any(m > s.tau)) push_candidates(s, sc, tile * 32);
+            }
+        }
+    }
+    // ---- end of the launch: park, or merge what is left and write the lists ----------------------------------------------------
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        GS &s = gs[g];
+        if (!s.live) continue;
+        if (!last && !s.pruned) {
+            LaneState ls;
+            ls.sp = s.sp;
+            ls.tau = s.tau;
+            ls.cnt = s.cnt;
+            *s.my_state = ls;
+            const int cmax = __builtin_amdgcn_readfirstlane((int)__reduce_max_sync(~0ull, s.cnt));
+            __builtin_amdgcn_wave_barrier();
+            for (int i = 0; i < cmax; ++i) s.my_ring_state[i * 64 + lane] = s.ring[i][lane];
+            for (int t = lane; t < 32 * KC; t += 64) {
+                const uint2 r = s.top[t];
+                s.my_score[t] = __uint_as_float(r.x);
+                s.my_idx[t] = (int)r.y;
+            }
+            continue;
+        }
+        {
+            const unsigned long long some = __ballot(s.cnt > 0);
+            flush_set(s, (unsigned)(some | (some >> 32)));
+        }
+        const unsigned long long floored = __ballot(s.tau_floor > -INFINITY);
+        __builtin_amdgcn_wave_barrier();
+        for (int t = lane; t < 32 * KC; t += 64) {
+            const uint2 r = s.top[t];
+            int iv = (int)r.y;
+            if ((t % KC) == KC - 1 && iv < 0 && ((floored >> (t / KC)) & 1ull)) iv = PK_IDX_FLOOR;
+            s.my_score[t] = __uint_as_float(r.x);
+            s.my_idx[t] = iv;
+        }
+        LaneState ls;
+        ls.sp = s.exit_tile;
+        ls.tau = s.tau;
+        ls.cnt = PK_LANE_DONE;
+        *s.my_state = ls;
     }
 }
 
@@ -1392,6 +1835,7 @@ struct SweepPhase {
     const LaneState *floor_state;   // phase 2: the head's lane records (threshold to start from), else nullptr
     int boot_tiles;                 // tiles of the threshold bootstrap in front of a sweep that starts cold (0: none)
     int shared;                     // single sweeps: the eight-wave workgroup with the V tiles staged in LDS
+    int pair;                       // single sweeps with KC = 16: two user groups per wave (score_candidates_pair_kernel)
 };
 
 template <int NSTEP>
@@ -1448,6 +1892,21 @@ static int launch_candidates_n(hipStream_t st, int KC, int ablate, dim3 grid, co
                                pk_score_lds_bytes_shared(NSTEP, KCV), st, Vp, Ep, n_users,                      \
                                n_items, n_tiles, split_tiles, chunk_begin, chunk_tiles, seen_ptr, seen_tiles, seen_ntiles, cs, ci, st_lane, st_ring,  \
                                user_bound, tile_bound, ablate, dn, 0, ph.slot_base, nullptr, ph.boot_tiles);    \
+            continue;                                                                                           \
+        }                                                                                                       \
+    }                                                                                                           \
+    if constexpr (KCV == 16 && NSTEP <= 8) {                                                                    \
+        if (ph.pair && grid.y == 1 && ph.floor_state == nullptr) {                                              \
+            const dim3 pgrid((grid.x + 1) / 2);                                                                 \
+            const size_t plds = 2 * pk_score_lds_bytes(NSTEP, KCV);                                             \
+            if (use_dense)                                                                                      \
+                hipLaunchKernelGGL((score_candidates_pair_kernel<NSTEP, KCV, true>), pgrid, dim3(256), plds, st, Vp, Ep, n_users, \
+                                   n_items, n_tiles, split_tiles, chunk_begin, chunk_tiles, seen_ptr, seen_tiles, seen_ntiles, cs, ci, st_lane, st_ring, \
+                                   user_bound, tile_bound, ablate, dn, ph.slot_base, ph.boot_tiles);            \
+            else                                                                                                \
+                hipLaunchKernelGGL((score_candidates_pair_kernel<NSTEP, KCV, false>), pgrid, dim3(256), plds, st, Vp, Ep, n_users, \
+                                   n_items, n_tiles, split_tiles, chunk_begin, chunk_tiles, seen_ptr, seen_tiles, seen_ntiles, cs, ci, st_lane, st_ring, \
+                                   user_bound, tile_bound, ablate, no_dense, ph.slot_base, ph.boot_tiles);      \
             continue;                                                                                           \
         }                                                                                                       \
     }                                                                                                           \
@@ -1546,6 +2005,8 @@ static int pk_sweep_launches(hipStream_t st, int64_t n_users, int64_t n_items, i
     ph.boot_tiles = ph.floor_state ? 0 : (boot_env ? atoi(boot_env) : 16);
     const char *shared_env = getenv("PK_SCORE_SHARED");     // tuning: 1 = the LDS-staged eight-wave instance for single sweeps
     ph.shared = shared_env ? atoi(shared_env) : 0;
+    const char *pair_env = getenv("PK_SCORE_PAIR");         // tuning: 1 = two user groups per wave for single sweeps with KC = 16
+    ph.pair = pair_env ? atoi(pair_env) : 0;
     dim3 grid((unsigned)pk_ceil_div(groups, 4), (unsigned)splits);
     const float4 *Vp = reinterpret_cast<const float4 *>(Vp_dev);
     const float4 *Ep = reinterpret_cast<const float4 *>(Ep_dev);

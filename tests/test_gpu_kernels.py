@@ -1094,6 +1094,49 @@ def test_lds_shared_tile_sweep_equals_the_register_fed_sweep(hip_ops, cfg, monke
             assert a == b          # the same tiles scored: a group's exit does not depend on its workgroup
 
 
+@pytest.mark.parametrize('cfg', [dict(n_users=3000, n_items=9000, K=50, topk=10, chunk=0),
+                                 dict(n_users=1130, n_items=5000, K=100, topk=10, chunk=7),
+                                 dict(n_users=97, n_items=2600, K=24, topk=5, chunk=3)])
+def test_two_user_groups_per_wave_sweep_equals_the_single_group_sweep(hip_ops, cfg, monkeypatch):
+    """score_candidates_pair_kernel (PK_SCORE_PAIR=1, round 4: every loaded V fragment serves TWO groups of 32 users — six
+    MFMAs per k-step on two accumulator chains, selection state per group; opt-in, it measured slower): ids and scores equal
+    to the one-group-per-wave kernel's — pruned and full sweeps, tiny item chunks (both groups' state parked and resumed,
+    one group of a wave pruned launches before the other), a last wave that owns only one group (odd group counts), with and
+    without the threshold bootstrap, with and without seen-item filtering — and the same tiles scored."""
+    from polara_amd import scoring
+    n_users, n_items, K, topk = cfg['n_users'], cfg['n_items'], cfg['K'], cfg['topk']
+    rng = np.random.RandomState(n_items + 2)
+    decay = (1.0 + np.arange(n_items)) ** -0.6
+    V = rng.randn(n_items, K) / np.sqrt(K) * decay[:, None]
+    indptr, indices, values = rand_csr(rng, n_users, n_items, 40, long_rows=[(2, n_items // 2), (40, n_items - 3)], empty_rows=[7])
+    T = hip_ops.csr(indptr, indices, values, (n_users, n_items))
+    F = scoring.FactorImage(hip_ops, hip_ops.to_device(V))
+    monkeypatch.setenv('PK_SCORE_HEAD_TILES', '0')
+    out = {}
+    try:
+        hip_ops.score_tiles_per_chunk = cfg['chunk']
+        hip_ops.score_splits_override = 1
+        for pair in ('0', '1'):
+            monkeypatch.setenv('PK_SCORE_PAIR', pair)
+            res = []
+            for boot in ('16', '0'):
+                monkeypatch.setenv('PK_SCORE_BOOT_TILES', boot)
+                st = {}
+                res += [scoring.recommend(hip_ops, F, T, topk, True, return_scores=True, stats=st),
+                        scoring.recommend(hip_ops, F, T, topk, True, return_scores=True, prune=False),
+                        scoring.recommend(hip_ops, F, T, topk, False, return_scores=True)]
+                res.append(st['tiles_scored'])
+            out[pair] = res
+    finally:
+        hip_ops.score_tiles_per_chunk = 0
+        hip_ops.score_splits_override = 0
+    for a, b in zip(out['0'], out['1']):
+        if isinstance(a, tuple):
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        else:
+            assert a == b          # the same tiles scored: a group's exit does not depend on the wave it shares
+
+
 def test_topk_rows_matches_the_reference_topsort(hip_ops):
     """pk_topk_rows_f64 (the array form of get_topk_elements / topsort, models.py:488-491, 561-563) against the oracle's
     argpartition + argsort on rows without ties, and against (score desc, column asc) on rows with ties, NaNs last."""

@@ -24,8 +24,11 @@ def main():
     KC = 16
     args = dict(user_bound=ub, tile_bound=F.tile_bound, seen_tiles=T.seen_tiles(), seen_dense=T.seen_dense())
     os.environ['PK_SCORE_HEAD_TILES'] = '0'
-    for boot in ('16', '0'):
-        for abl in ('0', '2', '1', '3'):
+    combos = [(b, a) for b in ('16', '0') for a in ('0', '2', '1', '3')]
+    if os.environ.get('PK_FLOOR_DIAG'):      # a PK_SCORE_DIAG build: the FULL sweep (4) without pushes (2), then without re-loads (16) / products (32) / both
+        combos = [('0', a) for a in ('6', '22', '38', '54', '7', '23')]
+    for boot, abl in combos:
+        if True:
             os.environ['PK_SCORE_BOOT_TILES'] = boot
             os.environ['PK_SCORE_ABLATE'] = abl
             for _ in range(3):
