@@ -27,6 +27,8 @@ if os.environ.get('PK_SWEEP_WAVES'):    # kernel-tuning builds: force the sweep'
     FLAGS.append('-DPK_SWEEP_WAVES=' + os.environ['PK_SWEEP_WAVES'])
 if os.environ.get('PK_SCORE_ROLL') == '4':     # kernel-tuning builds: the rolling-buffer sweep forced to four waves per SIMD (rank <= 64, top-10)
     FLAGS.append('-DPK_SCORE_ROLL4=1')
+if os.environ.get('PK_SCORE_DEPTH2'):     # kernel-tuning builds: two alternating rolling fragment buffers (loads two tiles ahead)
+    FLAGS.append('-DPK_SCORE_DEPTH2=1')
 if os.environ.get('PK_SCORE_DIAG'):     # kernel-tuning builds: PK_SCORE_ABLATE bits 16 (no fragment re-loads) and 32 (no products) in the sweep
     FLAGS.append('-DPK_SCORE_DIAG=1')
 if os.environ.get('PK_SCORE_TWO_BUFFERS'):     # kernel-tuning builds: the two-buffer tile loop of rounds 1-3

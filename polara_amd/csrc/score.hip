@@ -215,6 +215,8 @@ struct SeenDense {
 #define PK_SWEEP_OCC __attribute__((amdgpu_waves_per_eu(PK_SWEEP_WAVES, PK_SWEEP_WAVES)))
 #elif defined(PK_SCORE_ROLL4)   // with the rolling buffer the rank <= 64, top-10 instances are 8 registers from four waves per SIMD
 #define PK_SWEEP_OCC __attribute__((amdgpu_waves_per_eu((NSTEP <= 4 && KC == 16 && !SHARED) ? 4 : 1)))
+#elif defined(PK_SCORE_DEPTH2)  // two rolling buffers: the rank <= 64 instances land at 171-172 registers, 3 short of three waves per SIMD
+#define PK_SWEEP_OCC __attribute__((amdgpu_waves_per_eu((NSTEP <= 4 && KC <= 32 && !SHARED) ? 3 : 1)))
 #else
 #define PK_SWEEP_OCC
 #endif
@@ -830,6 +832,87 @@ __global__ __launch_bounds__(SHARED ? 64 * pk_shared_waves(KC) : 256) PK_SWEEP_O
         // compiler drains vmcnt(0) at the loop head, which exposes the latency of the late loads.
         // Forcing five waves per SIMD (amdgpu_waves_per_eu: 96 VGPRs, 12 spilled) on the pruned sweep: 3.47 vs
         // 3.29 ms; four (120 VGPRs, no spill) is what the register allocator picks unprompted.
+#if defined(PK_SCORE_ROLL) && defined(PK_SCORE_DEPTH2)
+        if constexpr (!SHARED) {
+            // Round 4, depth 2 (PK_SCORE_DEPTH2 builds only): TWO rolling fragment buffers that alternate from tile to tile (the
+            // tile body is instantiated twice; no copies): the registers a k-step of tile t has just read are re-requested for
+            // tile t + 2, so every fragment load has TWO tiles of compute to land in and a wave keeps 16 KB instead of 8 KB in
+            // flight (168 VGPRs, three waves per SIMD).  MEASURED against the one-buffer loop: pruned headline sweep 0.377 ->
+            // 0.355 ms, but no-prune 74 -> 69 M users/s, flat-norm 63.5 -> 60.4 M, pop^0.25 79 -> 77 M, and the library grows by
+            // half (two copies of the push / flush code per instance): the full sweeps already move their 30 GB of fragments at
+            // the ~17 TB/s the L1 path gives (the ceiling of the SpMM gathers as well) — more requests in flight only queue.
+            // Not the default.
+            float4 aA[KQ], aB[KQ];
+            {
+                const int t0 = (tile_begin < n_tiles) ? tile_begin : 0;
+                const int t1 = (tile_begin + S < tile_end) ? tile_begin + S : t0;
+                load_frags(t0, aA);
+                load_frags(t1, aB);
+            }
+            unsigned m_nxt = 0u, m_nxt2 = 0u;
+            if constexpr (DENSE) {
+                m_nxt = (tile_begin < dense_tiles) ? dense_row[(int64_t)tile_begin * 32] : 0u;
+                m_nxt2 = (tile_begin + S < dense_tiles) ? dense_row[(int64_t)(tile_begin + S) * 32] : 0u;
+            }
+            float tb = prune ? tile_bound[(tile_begin < n_tiles) ? tile_begin : 0] : 0.0f;
+            PROF_ADD(4, prof_k0);
+            auto tile_body = [&](int tile, int step, float4(&a)[KQ]) -> bool {
+                if (prune) {
+                    const bool open = en * tb > tau;
+                    const unsigned long long ob = __ballot(open);
+                    if (ob == 0ull) {
+                        pruned = true;
+                        exit_tile = tile;
+                        return false;
+                    }
+                    if (((STRIDED ? step : tile) & 7) == 7 && __popcll(ob) <= 16) {
+                        const unsigned long long pend = __ballot(cnt > 0);
+                        flush_set((unsigned)(ob | (ob >> 32)) & (unsigned)(pend | (pend >> 32)));
+                    }
+                    tb = tile_bound[(tile + S < n_tiles) ? tile + S : tile];
+                }
+                if constexpr (DENSE) {
+                    m_dense = m_nxt;
+                    m_nxt = m_nxt2;
+                    m_nxt2 = (tile + 2 * S < dense_tiles) ? dense_row[(int64_t)(tile + 2 * S) * 32] : 0u;
+                }
+                const f32x16 acc = score_tile_roll(a, (tile + 2 * S < tile_end) ? tile + 2 * S : tile);
+                const unsigned mask = walk_mask(tile);
+                float m_all = fmaxf(acc[0], acc[1]);
+#pragma unroll
+                for (int r = 2; r < 16; ++r) m_all = fmaxf(m_all, acc[r]);
+                if (!(ablate & 2) && __any(m_all > tau)) {
+                    float sc[16];
+                    float m = m_all;
+                    if (__any(mask != 0)) {
+                        const unsigned m2 = mask >> (4 * hi);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            sc[r] = (m2 & (1u << ((r & 3) + 8 * (r >> 2)))) ? -INFINITY : acc[r];
+                        m = fmaxf(sc[0], sc[1]);
+#pragma unroll
+                        for (int r = 2; r < 16; ++r) m = fmaxf(m, sc[r]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sc[r] = acc[r];
+                    }
+                    if (__any(m > tau)) push_candidates(sc, tile * 32);
+                }
+                return true;
+            };
+            int step = 0;
+            for (int tile = tile_begin; tile < tile_end;) {
+                if (!tile_body(tile, step, aA)) break;
+                tile += S;
+                ++step;
+                if (tile >= tile_end) break;
+                if (!tile_body(tile, step, aB)) break;
+                tile += S;
+                ++step;
+            }
+        } else
+#endif
+        {
         float4 a_nxt[SHARED ? 1 : KQ];
         // SHARED: who still sweeps is counted per iteration in one of three LDS counters (waves that stop in iteration
         // `it` add to s_cnt[it % 3] before its barrier, everybody reads it behind the barrier, wave 0 clears the next one
@@ -940,6 +1023,7 @@ __global__ __launch_bounds__(SHARED ? 64 * pk_shared_waves(KC) : 256) PK_SWEEP_O
                 stage_wait();
                 dead += s_cnt[step % 3];
             }
+        }
         }
     }
     if constexpr (SHARED) {
