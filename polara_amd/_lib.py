@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libpolarahip.so')
+# POLARA_HIP_LIB: a kernel-tuning build of the same library (tools/probes: diagnostic instances of the sweep); still no CPU path
+LIB_PATH = os.environ.get('POLARA_HIP_LIB') or os.path.join(_HERE, 'libpolarahip.so')
 
 PK_VAL_F32, PK_VAL_F64 = 0, 1
 PK_X_HEAD = 16      # x_kind flag of pk_spmm_csr_ex: the persistent fold-in instance with the head of X in LDS (opt-in)
