@@ -675,6 +675,9 @@ __global__ __launch_bounds__(SHARED ? 64 * pk_shared_waves(KC) : 256) PK_SWEEP_O
     // tile t, and waits for its own loads only at the end of the iteration — a whole tile later — in front of the barrier.
     auto stage_wait = [&]() {
         if constexpr (SHARED) {
+#ifdef PK_SCORE_DIAG       // kernel-tuning builds: ablate & 64 = neither the wait nor the barrier (wrong scores; what would the LDS-fed loop cost if its waves ran free?)
+            if (ablate & 64) return;
+#endif
             __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0) only: expcnt and lgkmcnt fields left at their maxima (gfx9 encoding)
             __syncthreads();
         }

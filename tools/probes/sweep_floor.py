@@ -27,7 +27,19 @@ def main():
     combos = [(b, a) for b in ('16', '0') for a in ('0', '2', '1', '3')]
     if os.environ.get('PK_FLOOR_DIAG'):      # a PK_SCORE_DIAG build: the FULL sweep (4) without pushes (2), then without re-loads (16) / products (32) / both
         combos = [('0', a) for a in ('6', '22', '38', '54', '7', '23')]
-    for boot, abl in combos:
+    shared = [None] * len(combos)
+    if os.environ.get('PK_FLOOR_DIAG') == '2':   # the LDS-staged instance: as it is, and with its per-tile wait + barrier removed (scores wrong)
+        combos = [('0', '6'), ('0', '6'), ('0', '70'), ('0', '22')]
+        shared = ['0', '1', '1', '0']
+    if os.environ.get('PK_FLOOR_DIAG') == '3':   # the same with the pushes ON (full sweep, bootstrap on): the regime of the unpruned bench lines
+        combos = [('16', '4'), ('16', '4'), ('16', '68')]
+        shared = ['0', '1', '1']
+    if os.environ.get('PK_FLOOR_DIAG') == '4':   # default build: register-fed against LDS-staged, full sweep with and without pushes
+        combos = [('16', '4'), ('16', '4'), ('0', '6'), ('0', '6')]
+        shared = ['0', '1', '0', '1']
+    for (boot, abl), sh in zip(combos, shared):
+        if sh is not None:
+            os.environ['PK_SCORE_SHARED'] = sh
         if True:
             os.environ['PK_SCORE_BOOT_TILES'] = boot
             os.environ['PK_SCORE_ABLATE'] = abl
@@ -44,7 +56,7 @@ def main():
             ex = ops.score_exit_tiles(n_users, 1)
             swept = float(ex.clamp_min(0).sum().item()) / (ex.shape[1] * (-(-n_items // 32)))
             tw = float(ex.clamp_min(0).sum().item())
-            print(json.dumps(dict(boot=int(boot), ablate=int(abl), sweep_ms=round(ms, 4), swept=round(swept, 4), tile_waves=int(tw),
+            print(json.dumps(dict(shared=sh, boot=int(boot), ablate=int(abl), sweep_ms=round(ms, 4), swept=round(swept, 4), tile_waves=int(tw),
                                   ns_per_tile_wave_x1024simd=round(ms * 1e6 * 1024 / tw, 1))), flush=True)
 
 
