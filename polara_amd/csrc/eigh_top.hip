@@ -268,6 +268,13 @@ __global__ __launch_bounds__(ETOP_THREADS) void eigh_top_kernel(int n, const dou
                 double *ar = A + etop_pk(gi, g0);
                 const double vi = v[row], wi = p[row];
                 for (int j = q; j <= row; j += tpr) ar[j] = fma(-vi, p[j], fma(-wi, v[j], ar[j]));     // (unrolling by four: no gain, the LDS pipe is the bound)
+                // Round 4: FOUR ROWS PER THREAD (16 lanes per group of four rows; v[j] / (w[j], v[j]) read once per four matrix
+                // elements: 8 -> 5 LDS instructions per four products, 16 -> 10 per four updated elements) was built, gave the same
+                // eigenpairs, and was SLOWER: sub-phase clocks at 150 columns, product 3 663 -> 5 174, update 3 175 -> 5 846 (x 100),
+                // a solve 0.83 -> 1.01 ms.  One row per thread has the 16 rows of a wave read CONSECUTIVE addresses in the column
+                // part (a(j, gi) for adjacent gi) and short 32-byte runs in the row part; four rows per thread turn the column part
+                // into 64 lanes on 16 different packed rows with a stride of ~150 doubles and the row part into four 128-byte runs
+                // whose banks overlap pairwise: the LDS pipe is the bound, but by bank cycles, not by instruction count.
             }
             __syncthreads();
             ETOP_SUB(3)
