@@ -208,6 +208,62 @@ def test_reference_tucker_rank_pipeline_drives_our_model(polara):
     assert np.array_equal(our_m.recommendations[clear], ref_m.recommendations[clear])
 
 
+def test_native_pipelines_equal_the_reference_pipelines_on_the_same_model(polara):
+    """polara_amd.pipelines restates `find_optimal_tucker_ranks`, `find_optimal_config` and `random_grid`
+    (evaluation/pipelines.py:23-53,119-214) without pandas: on ONE model object the reference's functions and ours must
+    visit the same points, produce the same values and pick the same winner; the model is left as the reference leaves it."""
+    from numpy_ops import NumpyOps
+    from polara.evaluation import pipelines as ref_p
+    from polara_amd import pipelines as our_p
+    from polara_amd.models import CoffeeModel, SVDModel
+    data = make_data(polara, test_fold=4, warm_start=False, holdout_size=2, test_ratio=0.25)
+    m = CoffeeModel(data, ops=NumpyOps())
+    m.verbose = False
+    m.topk, m.seed, m.growth_tol = 8, 3, 1e-6
+    grid = [[3, 6], [3, 5], [2, 3]]
+    best_ref, scores_ref = quiet(ref_p.find_optimal_tucker_ranks, m, grid, 'true_positive', metric_type='hits', return_scores=True)
+    state_ref = (m.mlrank, {k: v.copy() for k, v in m.factors.items()})
+    best_our, scores_our = quiet(our_p.find_optimal_tucker_ranks, m, grid, 'true_positive', metric_type='hits', return_scores=True)
+    assert list(scores_our) == list(scores_ref.index) and len(scores_our) == 8
+    assert [scores_our[r] for r in scores_our] == list(scores_ref.values) and best_our == best_ref
+    assert m.mlrank == state_ref[0] == (6, 5, 3) and len(m.training_time) == 1
+    assert all(np.array_equal(m.factors[k], state_ref[1][k]) for k in state_ref[1])
+    # same_space and the infeasible combinations are skipped alike
+    b1, s1 = quiet(ref_p.find_optimal_tucker_ranks, m, [[1, 5], [1, 5], [2, 4]], 'true_positive', metric_type='hits',
+                   return_scores=True, same_space=True)
+    b2, s2 = quiet(our_p.find_optimal_tucker_ranks, m, [[1, 5], [1, 5], [2, 4]], 'true_positive', metric_type='hits',
+                   return_scores=True, same_space=True)
+    assert list(s2) == list(s1.index) == [(5, 5, 2), (5, 5, 4)] and b1 == b2
+    assert [s2[r] for r in s2] == list(s1.values)
+
+    sv = SVDModel(data, ops=NumpyOps())
+    sv.verbose = False
+    sv.topk = 8
+    pts = [(3,), (9,), (6,)]
+    cfg_ref, sc_ref = quiet(ref_p.find_optimal_config, sv, pts, ('rank',), 'true_positive', metric_type='hits', return_scores=True)
+    cfg_our, sc_our = quiet(our_p.find_optimal_config, sv, pts, ('rank',), 'true_positive', metric_type='hits', return_scores=True,
+                            reset_config={'rank': 4})
+    assert cfg_our == cfg_ref and [sc_our[p] for p in pts] == [sc_ref[p] for p in pts]
+    assert sv.rank == 4                                  # reset_config applied after the last point
+    # a single (non-tuple) parameter name, as the reference allows
+    cfg1 = quiet(our_p.find_optimal_config, sv, [5, 7], 'rank', 'true_positive', metric_type='hits')
+    assert set(cfg1) == {'rank'} and cfg1['rank'] in (5, 7)
+
+    params = {'rank': [2, 4, 8, 16], 'topk': [5, 10], 'seed': [0, 1, 2]}
+    g, names = our_p.random_grid(params, n=10, rng=np.random.RandomState(0))
+    assert names == tuple(params) and len(g) == 10 and all(len(pt) == 3 and pt[0] in params['rank'] for pt in g)
+    g_all, _ = our_p.random_grid(params, n=0, rng=np.random.RandomState(1))
+    assert len(g_all) == 24                              # n = 0: the whole grid, like the reference
+    g_skip, _ = our_p.random_grid(params, n=0, skip_config=lambda pt: pt[0] == 16, rng=np.random.RandomState(2))
+    assert len(g_skip) == 18 and all(pt[0] != 16 for pt in g_skip)
+    g_ref, names_ref = ref_p.random_grid(params, n=0)
+    assert g_ref == g_all and names_ref == names
+    with pytest.raises(TypeError):
+        our_p.random_grid(params, n=2.5)
+    with pytest.raises(ValueError):
+        our_p.random_grid(params, n=-1)
+
+
 def test_reference_evaluation_engine_cross_validation(polara):
     """`evaluation_engine.run_cv_experiment` with `topk_test` inside (evaluation_engine.py:104-144): the data object
     moves from fold to fold (`data.update()` -> change events -> rebuild), the engine sets `topk` from large to small
