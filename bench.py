@@ -282,7 +282,7 @@ class Bench:
           'svd'    the factors as built (row norms follow the generator's popularity / factor-scale decay)
           'flat'   every row scaled to unit norm: the pruning bound never fires, 100 % of the tiles are scored
           'pop25'  row norms proportional to (item count)^0.25: a slow, real-data-like decay"""
-        from polara_amd.csr import nnz_balanced_row_partition, popularity_order
+        from polara_amd.csr import nnz_balanced_row_partition
         from polara_amd.solver import svd_topk
         from polara_amd import scoring
         ops, comm = self.ops, self.comm
@@ -303,11 +303,8 @@ class Bench:
         lap('upload_s')
         # internal item order = descending popularity over the WHOLE matrix (identical on every rank): per-item counts
         # of the local rows on the device (pk_count_i32), summed over ranks; the renaming itself is one gather
-        counts = ops.item_counts(A)
-        if comm.world > 1:
-            counts = ops.to_host(comm.allreduce(ops.to_device(counts)))
-        rank_of, inv_order = popularity_order(None, n_items, counts=counts)
-        A = ops.csr_relabel_cols(A, rank_of)     # rows re-sorted (pk_csr_relabel_sorted): ascending gathers in every SpMM
+        rank_of, inv_order, counts, rank_dev = ops.item_order(A, comm)     # counts, order and its inverse on the device: one copy back
+        A = ops.csr_relabel_cols(A, rank_dev)    # rows re-sorted (pk_csr_relabel_sorted): ascending gathers in every SpMM
         lap('relabel_popularity_s')
         A.transpose_operator()          # CSC image (user-blocked), built on the device (pk_csr_transpose)
         _ = A.plan

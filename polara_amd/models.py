@@ -667,11 +667,8 @@ class SVDModel(RecommenderModel):
             idx, val, shp = self.data.to_coo(tensor_mode=False, feedback_threshold=self.feedback_threshold)
             rows, cols = idx[:, 0], idx[:, 1]
         A = self.ops.csr_from_coo(rows, cols, val, shp)
-        counts = self.ops.item_counts(A)
-        if self._presharded() and self.comm.world > 1:
-            counts = self.ops.to_host(self.comm.allreduce(self.ops.to_device(counts)))
-        self._item_rank, self._item_inv = popularity_order(None, shp[1], counts=counts)
-        return self.ops.csr_relabel_cols(A, self._item_rank)
+        self._item_rank, self._item_inv, _, rank_dev = self.ops.item_order(A, self.comm if self._presharded() else None)
+        return self.ops.csr_relabel_cols(A, rank_dev)
 
     def _local_training_shard(self):
         A = self._training_device_csr()

@@ -377,6 +377,34 @@ class HipOps:
                    'pk_count_i32')
         return counts.cpu().numpy().astype(np.int64)
 
+    def item_order(self, A, comm=None):
+        """The internal item order of the device path (csr.popularity_order: descending entry count, ties by id) WITHOUT the
+        host in the middle: per-column counts (pk_count_i32), summed over the ranks of `comm` when the rows are sharded, an
+        own stable radix sort of (largest count - count, id) pairs, the inverse by one scatter; ONE copy brings back
+        (rank int32[n_cols]: id -> position, inv int32[n_cols]: position -> id, counts int64[n_cols]) — plus the rank map
+        as a device tensor for the renaming.  (numpy's stable argsort of 26 744 counts takes 1.5 ms, of 100 000: 7 ms — more
+        than the renaming itself since the rows are sorted in LDS.)"""
+        n = int(A.shape[1])
+        counts = torch.empty(n, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.pk_count_i32(self.stream(), A.indices.numel(), _ptr(A.indices), n, _ptr(counts)), 'pk_count_i32')
+        total = int(A.indices.numel())
+        if comm is not None and getattr(comm, 'world', 1) > 1:
+            counts = comm.allreduce(counts.to(torch.int64)).to(torch.int32)
+            total *= int(comm.world)            # an upper bound of any count is all the sort needs
+        keys = (counts.max() - counts).contiguous()
+        pos = torch.arange(n, dtype=torch.int32, device=self.device)
+        keys_tmp, pos_tmp = torch.empty_like(keys), torch.empty_like(pos)
+        in_tmp = C.c_int32(0)
+        work = self._work(self.lib.pk_radix_work_bytes(n))
+        bits = min(32, max(1, total.bit_length()))
+        _lib.check(self.lib.pk_radix_sort_pairs(self.stream(), n, 4, _ptr(keys), _ptr(pos), _ptr(keys_tmp), _ptr(pos_tmp),
+                                                bits, _ptr(work), C.byref(in_tmp)), 'pk_radix_sort_pairs')
+        inv = pos_tmp if in_tmp.value else pos
+        rank = torch.empty_like(inv)
+        rank[inv.long()] = torch.arange(n, dtype=torch.int32, device=self.device)
+        host = torch.cat([rank, inv, counts]).cpu().numpy()
+        return host[:n].copy(), host[n:2 * n].copy(), host[2 * n:].astype(np.int64), rank
+
     def bincount(self, keys, n_bins):
         """int64 [n_bins] (device): occurrences of each key of a device int64 tensor (pk_count_i32 on the narrowed keys)."""
         k32 = keys.to(torch.int32).contiguous()

@@ -79,6 +79,14 @@ class NumpyOps:
     def item_counts(self, A):
         return np.bincount(A.m.indices, minlength=A.shape[1]).astype(np.int64)
 
+    def item_order(self, A, comm=None):
+        from polara_amd.csr import popularity_order
+        counts = self.item_counts(A)
+        if comm is not None and getattr(comm, 'world', 1) > 1:
+            counts = self.to_host(comm.allreduce(self.to_device(counts)))
+        rank, inv = popularity_order(None, A.shape[1], counts=counts)
+        return rank, inv, counts, torch.from_numpy(rank)
+
     def csr_rows(self, A, lo, hi):
         sub = A.m[lo:hi]
         return NpCSR(sub.indptr, sub.indices, sub.data, sub.shape)

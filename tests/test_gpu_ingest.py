@@ -162,6 +162,51 @@ def test_sorted_relabel_counts_and_device_plan(hip_ops):
     assert torch.equal(part[3:4000], full[3:4000]) and float(part[4000:].abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+def test_row_sort_of_the_renaming_at_every_row_length_class(hip_ops, dtype):
+    """pk_csr_relabel_sorted sorts the rows where they are (round 4): empty rows, one and two entries, the one-wave
+    workgroups' limit (1 024) and one beyond it, the LDS limit of the long-row workgroups (16 384) and one beyond it
+    (global scratch), a 40 000-entry row — values follow their columns, bit for bit, in both value kinds."""
+    ops = hip_ops
+    rng = np.random.RandomState(3)
+    n_cols = 70000
+    lens = [0, 1, 2, 3, 63, 64, 65, 0, 1023, 1024, 1025, 2047, 2048, 5000, 16383, 16384, 16385, 40000, 0, 7] + list(rng.randint(0, 300, 500))
+    indptr = np.r_[0, np.cumsum(lens)].astype(np.int64)
+    indices = np.concatenate([np.sort(rng.choice(n_cols, c, replace=False)) for c in lens]).astype(np.int32)
+    values = rng.rand(int(indptr[-1])).astype(dtype) + 0.5
+    A = ops.csr(indptr, indices, values, (len(lens), n_cols))
+    perm = rng.permutation(n_cols).astype(np.int32)
+    B = ops.csr_relabel_cols(A, perm)
+    S = sps.csr_matrix((values.copy(), perm[indices], indptr), shape=(len(lens), n_cols))     # (sort_indices works in place)
+    S.sort_indices()
+    assert np.array_equal(ops.to_host(B.indices), S.indices)
+    assert np.array_equal(ops.to_host(B.values), S.data.astype(dtype))
+    assert np.array_equal(ops.to_host(B.indptr), indptr) and B.sorted_cols
+    # a second renaming of the result (the serving order after the popularity order) — and back
+    inv = np.empty_like(perm)
+    inv[perm] = np.arange(n_cols, dtype=np.int32)
+    C_ = ops.csr_relabel_cols(B, inv)
+    assert np.array_equal(ops.to_host(C_.indices), indices) and np.array_equal(ops.to_host(C_.values), values)
+
+
+def test_item_order_on_the_device_equals_the_host_order(hip_ops):
+    """HipOps.item_order (counts -> own stable radix sort -> inverse, one copy back) against csr.popularity_order on the
+    same counts: descending popularity, ties by id — including many ties (most items of a long tail share a count)."""
+    from polara_amd.csr import popularity_order
+    ops = hip_ops
+    for seed, n_rows, n_cols, avg in ((1, 5000, 3000, 12), (2, 300, 20000, 3), (3, 12, 5, 2)):
+        indptr, indices, values = _rand_csr(seed, n_rows, n_cols, avg)
+        A = ops.csr(indptr, indices, values, (n_rows, n_cols))
+        rank, inv, counts, rank_dev = ops.item_order(A)
+        want_counts = np.bincount(indices, minlength=n_cols)
+        want_rank, want_inv = popularity_order(None, n_cols, counts=want_counts)
+        assert np.array_equal(counts, want_counts) and counts.dtype == np.int64
+        assert np.array_equal(rank, want_rank) and np.array_equal(inv, want_inv) and rank.dtype == np.int32
+        assert np.array_equal(ops.to_host(rank_dev), want_rank)
+        B = ops.csr_relabel_cols(A, rank_dev)
+        assert np.array_equal(ops.to_host(B.indices), ops.to_host(ops.csr_relabel_cols(A, want_rank).indices))
+
+
 def test_unsorted_long_rows_get_sorted_for_the_seen_tiles(hip_ops):
     """rows longer than the in-LDS sort of the seen-tile builder after a bare renaming: re-sorted by the own kernels"""
     ops = hip_ops
