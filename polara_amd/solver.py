@@ -401,6 +401,12 @@ def _ritz_check(ops, Tj, S, X0, k, b, est_tol, prior, seed, inner, final=False):
                 lam_k=lam_k)
 
 
+def _raise_on_breakdown(fl, j):
+    """fl = [sum of Cholesky verdicts, max distance of the last pass's Gram matrix from I] of the block recurrence"""
+    if fl[0] != 0 or not (fl[1] < 1e-4):     # the Gram matrix BEFORE the last pass: 1e-4 there is 1e-8 after it
+        raise _LanczosBreakdown('residual block lost rank at step <= %d (Cholesky verdicts %g, orthonormality %.1e)' % (j, fl[0], fl[1]))
+
+
 class _Monitor:
     """A convergence check of the block Lanczos build that runs NEXT TO the following Gramian steps: a worker thread
     drives the nested solve (one C call that releases the interpreter lock, hundreds of microsecond kernels) on a side
@@ -408,17 +414,20 @@ class _Monitor:
     The result is collected at a FIXED number of steps after the launch (blocking if need be), so every rank of a sharded
     build takes its decisions at the same steps from the same numbers."""
 
-    def __init__(self, ops, j, Tj, S, X0, k, b, est_tol, prior, seed, inner):
+    def __init__(self, ops, j, Tj, S, X0, k, b, est_tol, prior, seed, inner, flags=None):
         import threading
         self.j = j
         self.out = self.err = None
+        # the recurrence's breakdown flags as they stand after step j: read by the WORKER (a host read on the calling
+        # thread would drain the main stream at every launch of a monitor and leave it empty while the next step is enqueued)
+        fsnap = flags.clone() if flags is not None else None
         dev = getattr(ops, 'device', None)
         cuda = dev is not None and getattr(dev, 'type', 'cpu') == 'cuda'
         side = None
         if cuda:
             side = ops.aux_streams(1)[0]
             side.wait_stream(torch.cuda.current_stream(dev))      # the snapshot of T_j and S is complete
-            for t in (Tj, S, X0):
+            for t in (Tj, S, X0, fsnap):
                 if t is not None:
                     t.record_stream(side)
 
@@ -427,9 +436,13 @@ class _Monitor:
                 if cuda:
                     torch.cuda.set_device(dev)
                     with torch.cuda.stream(side):
+                        if fsnap is not None:
+                            _raise_on_breakdown(ops.to_host(fsnap), j)
                         self.out = _ritz_check(ops, Tj, S, X0, k, b, est_tol, prior, seed, inner)
                         side.synchronize()
                 else:
+                    if fsnap is not None:
+                        _raise_on_breakdown(ops.to_host(fsnap), j)
                     self.out = _ritz_check(ops, Tj, S, X0, k, b, est_tol, prior, seed, inner)
             except BaseException as exc:        # re-raised by join() in the thread that owns the build
                 self.err = exc
@@ -493,9 +506,7 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
         return (0.5 * (Tj + Tj.t())).contiguous()
 
     def breakdown_check(j):
-        fl = ops.to_host(flags)
-        if fl[0] != 0 or not (fl[1] < 1e-4):     # the Gram matrix BEFORE the last pass: 1e-4 there is 1e-8 after it
-            raise _LanczosBreakdown('residual block lost rank at step <= %d (Cholesky verdicts %g, orthonormality %.1e)' % (j, fl[0], fl[1]))
+        _raise_on_breakdown(ops.to_host(flags), j)
 
     def plan(j_now):
         """the step of the next look from the history of estimates; (step, final?)"""
@@ -552,10 +563,9 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
                 continue
             inner['checks'] += 1
             if not (look_is_final or last):
-                # ---- launch a monitor on the side stream and keep stepping -------------------------------------
-                breakdown_check(j)
+                # ---- launch a monitor on the side stream and keep stepping (it reads the breakdown flags too) ---
                 monitor = _Monitor(ops, j, snapshot(N), S, warm, k, b, est_tol, hist[-1][1] if hist else None,
-                                   seed + 1000 * j, inner)
+                                   seed + 1000 * j, inner, flags=flags)
                 next_look = qcap + 1           # decided when the monitor comes back
                 continue
             # ---- the pairs of T_j on the main stream, and their verification ------------------------------------
