@@ -31,6 +31,8 @@ if os.environ.get('PK_SCORE_DEPTH2'):     # kernel-tuning builds: two alternatin
     FLAGS.append('-DPK_SCORE_DEPTH2=1')
 if os.environ.get('PK_SCORE_DIAG'):     # kernel-tuning builds: PK_SCORE_ABLATE bits 16 (no fragment re-loads) and 32 (no products) in the sweep
     FLAGS.append('-DPK_SCORE_DIAG=1')
+if os.environ.get('PK_SCORE_TWO_CHAINS'):     # kernel-tuning builds: two accumulator chains in the rolling tile loop (rank <= 64)
+    FLAGS.append('-DPK_SCORE_TWO_CHAINS=1')
 if os.environ.get('PK_SCORE_TWO_BUFFERS'):     # kernel-tuning builds: the two-buffer tile loop of rounds 1-3
     FLAGS.append('-DPK_SCORE_TWO_BUFFERS=1')
 if os.environ.get('PK_SHARED_WAVES'):   # kernel-tuning builds: waves per workgroup of the LDS-staged sweep instance

@@ -722,6 +722,15 @@ __global__ __launch_bounds__(SHARED ? 64 * pk_shared_waves(KC) : 256) PK_SWEEP_O
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
         const float4 *vp = Vp + ((int64_t)next_tile * KQ) * 64 + lane;
+#ifdef PK_SCORE_TWO_CHAINS     // kernel-tuning builds: even and odd k-steps accumulate into two independent chains (rank <= 64)
+        // (the rolling buffer left room for a second accumulator at three waves per SIMD: 152 registers.  MEASURED, full sweep of
+        // ML-20M-shaped: 1.38 -> 1.41 ms without pushes, 1.61 -> 1.67 with them — the dependent accumulator chain is not what
+        // the tile loop waits for either.  Not the default.)
+        constexpr bool TWO = (NSTEP >= 2 && NSTEP <= 4);
+        f32x16 acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[r] = 0.0f;
+#endif
 #pragma unroll
         for (int sidx = 0; sidx < (SHARED ? 0 : NSTEP); ++sidx) {
             const bf16x8 vh = __builtin_bit_cast(bf16x8, a[2 * sidx]), vl = __builtin_bit_cast(bf16x8, a[2 * sidx + 1]);
@@ -732,9 +741,18 @@ __global__ __launch_bounds__(SHARED ? 64 * pk_shared_waves(KC) : 256) PK_SWEEP_O
             } else
 #endif
             {
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, eh, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, el, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, eh, acc, 0, 0, 0);
+#ifdef PK_SCORE_TWO_CHAINS
+                if (TWO && (sidx & 1)) {
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, eh, acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, el, acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, eh, acc1, 0, 0, 0);
+                } else
+#endif
+                {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, eh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, el, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, eh, acc, 0, 0, 0);
+                }
             }
 #ifdef PK_SCORE_DIAG
             if (ablate & 16) continue;
@@ -742,6 +760,12 @@ __global__ __launch_bounds__(SHARED ? 64 * pk_shared_waves(KC) : 256) PK_SWEEP_O
             a[2 * sidx] = vp[(2 * sidx) * 64];
             a[2 * sidx + 1] = vp[(2 * sidx + 1) * 64];
         }
+#ifdef PK_SCORE_TWO_CHAINS
+        if (TWO) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += acc1[r];
+        }
+#endif
         return acc;
     };
 #endif
