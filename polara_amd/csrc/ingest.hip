@@ -526,6 +526,51 @@ __device__ __forceinline__ void relabel_sort_row(uint64_t *s, int64_t b, int len
     }
 }
 
+// the same network for ONE wave and a compile-time length (rows of at most 256 entries: 86 % of ML-20M-shaped's rows): the
+// strides are constants and the loops unroll (relabel of ML-20M-shaped 0.92 -> 0.88 ms, S-1M 2.75 -> 2.48 ms).  Tried on top and
+// dropped: all compare-exchanges of a lane in a stage reading before any of them writes, with 512 / 1 024-entry instances
+// (0.66 -> 0.73 ms / 2.23 -> 2.68 ms: the registers of the batches cost more than the round trips they hide).
+template <typename VT, int P>
+__device__ __forceinline__ void relabel_sort_row_fixed(uint64_t *s, int64_t b, int len, const int32_t *__restrict__ indices,
+                                                       const VT *__restrict__ values, const int32_t *__restrict__ col_map,
+                                                       int32_t *__restrict__ indices_out, VT *__restrict__ values_out) {
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int i0 = 0; i0 < P; i0 += 64) {
+        const int i = i0 + lane;
+        if (P >= 64 || i < P) s[i] = i < len ? (((uint64_t)(uint32_t)col_map[indices[b + i]]) << 32) | (uint32_t)i : ~0ull;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 2; k <= P; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+            for (int t0 = 0; t0 < (P >> 1); t0 += 64) {
+                const int t = t0 + lane;
+                if ((P >> 1) >= 64 || t < (P >> 1)) {
+                    const int i = 2 * t - (t & (j - 1));
+                    const uint64_t a = s[i], c = s[i + j];
+                    if ((a > c) == ((i & k) == 0)) {
+                        s[i] = c;
+                        s[i + j] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int i0 = 0; i0 < P; i0 += 64) {
+        const int i = i0 + lane;
+        if (i < len) {
+            const uint64_t e = s[i];
+            indices_out[b + i] = (int32_t)(e >> 32);
+            values_out[b + i] = values[b + (int64_t)(uint32_t)e];
+        }
+    }
+}
+
 template <typename VT>
 __global__ __launch_bounds__(64) void relabel_rows_short_kernel(int64_t n_rows, const int64_t *__restrict__ indptr,
                                                                 const int32_t *__restrict__ indices, const VT *__restrict__ values,
@@ -547,7 +592,22 @@ __global__ __launch_bounds__(64) void relabel_rows_short_kernel(int64_t n_rows, 
         }
         return;
     }
-    relabel_sort_row<VT, 64>(s, b, (int)len, indices, values, col_map, indices_out, values_out);
+    const int n = (int)len;
+#define PK_RL_FIXED(PP)                                                                                     \
+    if (n <= PP) {                                                                                          \
+        relabel_sort_row_fixed<VT, PP>(s, b, n, indices, values, col_map, indices_out, values_out);         \
+        return;                                                                                             \
+    }
+    PK_RL_FIXED(2)
+    PK_RL_FIXED(4)
+    PK_RL_FIXED(8)
+    PK_RL_FIXED(16)
+    PK_RL_FIXED(32)
+    PK_RL_FIXED(64)
+    PK_RL_FIXED(128)
+    PK_RL_FIXED(256)
+#undef PK_RL_FIXED
+    relabel_sort_row<VT, 64>(s, b, n, indices, values, col_map, indices_out, values_out);
 }
 
 template <typename VT>
@@ -563,8 +623,13 @@ __global__ __launch_bounds__(1024) void relabel_rows_long_kernel(const int64_t *
         const int64_t b = indptr[r], len = indptr[r + 1] - b;
         // a row too long for LDS: the same network over its own region of the scratch buffer (2 * nnz entries: the padded
         // length is below twice the row's length, so the regions [2 b, 2 b + P) of different rows do not meet)
-        uint64_t *s = len <= PK_RL_LONG ? pk_relabel_lds : scratch + 2 * b;
-        relabel_sort_row<VT, 1024>(s, b, (int)len, indices, values, col_map, indices_out, values_out);
+        // (two call sites, not one call through a selected pointer: the network must see an LDS pointer to be compiled to
+        // ds_read / ds_write — through a pointer that may be either it becomes flat loads and stores: relabel of
+        // ML-20M-shaped 0.88 -> 0.66 ms with the two call sites)
+        if (len <= PK_RL_LONG)
+            relabel_sort_row<VT, 1024>(pk_relabel_lds, b, (int)len, indices, values, col_map, indices_out, values_out);
+        else
+            relabel_sort_row<VT, 1024>(scratch + 2 * b, b, (int)len, indices, values, col_map, indices_out, values_out);
         __syncthreads();                  // the buffer is reused by the next row of this workgroup
     }
 }
