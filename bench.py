@@ -310,7 +310,7 @@ class Bench:
         _ = A.plan
         lap('transpose_and_plans_s')
         ops.timers = {}
-        counters = ('n_allgather', 'bytes_gathered', 'n_reduce_scatter', 'bytes_scattered', 'n_allreduce', 'bytes_reduced')
+        counters = ('n_allgather', 'bytes_gathered', 'n_reduce_scatter', 'bytes_scattered', 'n_allreduce', 'bytes_reduced', 'n_panel_exchanges')
         before = {k: getattr(comm, k, 0) for k in counters}
         _, sigma, V, bstats = svd_topk(ops, A, rank, comm=comm)
         lap('solver_s')
@@ -647,7 +647,7 @@ class Bench:
             out['dist'] = dict(self.dist_info, users_per_rank=[int(x) for x in sh[:, 1]], nnz_per_rank=[int(x) for x in sh[:, 2]],
                                device_of_rank=[int(x) for x in sh[:, 3]],
                                build_collectives={'all_gather': cl['n_allgather'], 'reduce_scatter': cl['n_reduce_scatter'],
-                                                  'all_reduce': cl['n_allreduce'],
+                                                  'all_reduce': cl['n_allreduce'], 'overlapped_panels': cl.get('n_panel_exchanges', 0),
                                                   'MB': (cl['bytes_gathered'] + cl['bytes_scattered'] + cl['bytes_reduced']) / 1e6},
                                scoring_collectives=0)
             if catalogue == 'flat':

@@ -36,6 +36,7 @@ class TorchComm:
         self.n_allreduce = 0
         self.bytes_gathered = self.bytes_scattered = 0
         self.n_allgather = self.n_reduce_scatter = 0
+        self.n_panel_exchanges = 0            # exchanges started through the *_start forms (two per product: solver.ItemRows.product)
 
     def allreduce(self, t):
         if self.world > 1 or self._always:
@@ -82,6 +83,60 @@ class TorchComm:
         self.bytes_scattered += full.numel() * full.element_size()
         self.n_reduce_scatter += 1
         return out
+
+    # ---- asynchronous forms: the exchange of one column panel runs next to the products of the next one ------------------
+    class _Ready:
+        def __init__(self, value):
+            self.value = value
+
+        def wait(self):
+            return self.value
+
+    class _Pending:
+        """an RCCL collective in flight on the library's own stream; wait() makes the CURRENT stream wait for it (the host
+        does not block) and hands the result over"""
+
+        def __init__(self, work, value):
+            self.work, self.value = work, value
+
+        def wait(self):
+            self.work.wait()
+            return self.value
+
+    def _is_async(self):
+        return dist.get_backend(self.group) == 'nccl' and (self.world > 1 or self._always)
+
+    def allreduce_start(self, t, count=True):
+        """`allreduce`, started only: under RCCL the call returns at once and the kernels the caller enqueues next run
+        while the blocks travel; `count=False` for the further panels of ONE logical exchange (the collective counters of the
+        bench line count exchanges, not panels)."""
+        self.n_panel_exchanges += 1
+        if not self._is_async():
+            before = self.n_allreduce
+            out = self.allreduce(t)
+            if not count:
+                self.n_allreduce = before
+            return TorchComm._Ready(out)
+        work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.bytes_reduced += t.numel() * t.element_size()
+        self.n_allreduce += 1 if count else 0
+        return TorchComm._Pending(work, t)
+
+    def reduce_scatter_rows_start(self, full, rows, count=True):
+        """`reduce_scatter_rows`, started only (see allreduce_start)."""
+        self.n_panel_exchanges += 1
+        if not self._is_async():
+            before = self.n_reduce_scatter
+            out = self.reduce_scatter_rows(full, rows)
+            if not count:
+                self.n_reduce_scatter = before
+            return TorchComm._Ready(out)
+        assert full.shape[0] == self.world * rows and full.is_contiguous()
+        out = torch.empty((rows, full.shape[1]), dtype=full.dtype, device=full.device)
+        work = dist.reduce_scatter_tensor(out, full, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.bytes_scattered += full.numel() * full.element_size()
+        self.n_reduce_scatter += 1 if count else 0
+        return TorchComm._Pending(work, out)
 
     def _exchange_device(self):
         """where collective payloads live: the GPU under RCCL, the host under gloo"""

@@ -30,6 +30,8 @@ same control decisions because they derive from all-reduced data and determinist
 `shard_items=False` keeps the round-1 layout (item side replicated, one all-reduce of Z per step).
 """
 import math
+import os
+
 import numpy as np
 import torch
 
@@ -86,15 +88,33 @@ class ItemRows:
         return self.comm.all_gather_rows(X.contiguous())[:self.n]
 
     def product(self, At, Y):
-        """this rank's rows of  sum_p A_p^T Y_p"""
-        ops = self.ops
+        """this rank's rows of  sum_p A_p^T Y_p.
+        More than one rank: the block goes in TWO column panels — the products of the second panel run while the first
+        one's sum travels (RCCL: the collective is started asynchronously on the library's stream; under gloo the panels
+        are exchanged one after the other, same results).  A panel of 32 columns costs half a launch of 64 since the
+        narrow SpMM instances, so the split is free on the compute side.  PK_DIST_OVERLAP=0: one
+        exchange per product, as in rounds 1-3."""
+        ops, comm = self.ops, self.comm
+        nc = Y.shape[1]
+        mode = os.environ.get('PK_DIST_OVERLAP', '1')      # 'force': also in a group of ONE rank that exercises its collectives (tests)
+        split = ((comm.world > 1 or (mode == 'force' and getattr(comm, '_always', False))) and nc >= 32 and nc % 16 == 0
+                 and hasattr(comm, 'allreduce_start') and mode != '0' and not hasattr(At, 'matvec'))
+        panels = ((0, nc // 2), (nc // 2, nc)) if split else ((0, nc),)
         if not self.sharded:
-            return self.comm.allreduce(ops.spmm(At, Y))
-        buf = ops.empty(self.padded, Y.shape[1])
-        if self.padded > self.n:
-            buf[self.n:].zero_()
-        ops.spmm(At, Y, out=buf[:self.n])
-        return self.comm.reduce_scatter_rows(buf, self.rows)
+            if not split:
+                return comm.allreduce(ops.spmm(At, Y))
+            pending = [comm.allreduce_start(ops.spmm(At, Y[:, c0:c1]), count=(c0 == 0)) for c0, c1 in panels]
+            return torch.cat([h.wait() for h in pending], 1)
+        pending = []
+        for c0, c1 in panels:
+            buf = ops.empty(self.padded, c1 - c0)
+            if self.padded > self.n:
+                buf[self.n:].zero_()
+            ops.spmm(At, Y if not split else Y[:, c0:c1], out=buf[:self.n])
+            if not split:
+                return comm.reduce_scatter_rows(buf, self.rows)
+            pending.append(comm.reduce_scatter_rows_start(buf, self.rows, count=(c0 == 0)))
+        return torch.cat([h.wait() for h in pending], 1)
 
     def gram(self, A, B=None):
         G = self.ops.gram(A, B)
