@@ -89,16 +89,21 @@ class ItemRows:
 
     def product(self, At, Y):
         """this rank's rows of  sum_p A_p^T Y_p.
-        More than one rank: the block goes in TWO column panels — the products of the second panel run while the first
-        one's sum travels (RCCL: the collective is started asynchronously on the library's stream; under gloo the panels
-        are exchanged one after the other, same results).  A panel of 32 columns costs half a launch of 64 since the
-        narrow SpMM instances, so the split is free on the compute side.  PK_DIST_OVERLAP=0: one
-        exchange per product, as in rounds 1-3."""
+        More than one rank, blocks whose exchange is long enough to be worth hiding: the block goes in TWO column panels — the
+        products of the second panel run while the first one's sum travels (RCCL: the collective is started asynchronously
+        on the library's stream; under gloo the panels are exchanged one after the other, same results).  The split is not
+        free: two launches of A^T Y per user block instead of one, and a 32-column panel of A^T Y costs ~0.7 of a 64-column
+        launch, not half (the narrow instances pay off for A X, whose dense block sits on chip):
+        +0.23 ms per step on ML-20M-shaped (tools/probes/overlap_one_rank.py).  So it is taken when the modelled exchange of
+        the block — 2 (N-1)/N n_items nc 8 bytes at 100 GB/s — reaches 0.4 ms (S-1M on 8 ranks: 0.9 ms; ML-20M-shaped:
+        0.14-0.24 ms, not taken).  PK_DIST_OVERLAP: 0 = never, force = whenever there is something to exchange (tests)."""
         ops, comm = self.ops, self.comm
         nc = Y.shape[1]
-        mode = os.environ.get('PK_DIST_OVERLAP', '1')      # 'force': also in a group of ONE rank that exercises its collectives (tests)
-        split = ((comm.world > 1 or (mode == 'force' and getattr(comm, '_always', False))) and nc >= 32 and nc % 16 == 0
-                 and hasattr(comm, 'allreduce_start') and mode != '0' and not hasattr(At, 'matvec'))
+        mode = os.environ.get('PK_DIST_OVERLAP', '1')
+        exchanging = comm.world > 1 or (mode == 'force' and getattr(comm, '_always', False))
+        worth = mode == 'force' or 2.0 * (comm.world - 1) / max(comm.world, 1) * self.n * nc * 8.0 / 100e9 >= 4e-4
+        split = (exchanging and worth and mode != '0' and nc >= 32 and nc % 16 == 0 and hasattr(comm, 'allreduce_start')
+                 and not hasattr(At, 'matvec'))
         panels = ((0, nc // 2), (nc // 2, nc)) if split else ((0, nc),)
         if not self.sharded:
             if not split:

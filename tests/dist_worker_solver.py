@@ -69,16 +69,16 @@ def main():
     part = ops.csr(P.indptr.astype(np.int64), P.indices.astype(np.int32), P.data.astype(np.float64), P.shape)
     for shard_items in (True, False):
         res = {}
-        for overlap in ('1', '0'):
+        for overlap in ('force', '0'):
             os.environ['PK_DIST_OVERLAP'] = overlap
             p0 = comm.n_panel_exchanges
             _, s, V, st = svd_topk(ops, part, k, comm=comm, shard_items=shard_items)
             res[overlap] = (s.numpy(), V.numpy(), comm.n_panel_exchanges - p0, st['gramian_steps'])
         os.environ.pop('PK_DIST_OVERLAP')
         out['panels_%s' % ('sharded' if shard_items else 'replicated')] = bool(
-            np.allclose(res['1'][0], res['0'][0], rtol=1e-12) and np.abs(res['1'][1] @ res['1'][1].T - res['0'][1] @ res['0'][1].T).max() < 1e-10
-            and 0 < res['1'][2] <= 2 * res['1'][3] and res['1'][2] % 2 == 0 and res['0'][2] == 0 and res['1'][3] == res['0'][3])
-        out['panels_%s_steps' % ('sharded' if shard_items else 'replicated')] = (res['1'][2], res['1'][3])     # (not every block of a locking iteration is 16-divisible)
+            np.allclose(res['force'][0], res['0'][0], rtol=1e-12) and np.abs(res['force'][1] @ res['force'][1].T - res['0'][1] @ res['0'][1].T).max() < 1e-10
+            and 0 < res['force'][2] <= 2 * res['force'][3] and res['force'][2] % 2 == 0 and res['0'][2] == 0 and res['force'][3] == res['0'][3])
+        out['panels_%s_steps' % ('sharded' if shard_items else 'replicated')] = (res['force'][2], res['force'][3])     # (not every block of a locking iteration is 16-divisible)
     comm.barrier()
     if comm.rank == 0:
         print('SOLVER_DIST_RESULT', out)
