@@ -388,6 +388,33 @@ int pk_flag_compact(void *stream, int64_t n, const int32_t *flags_dev, int32_t m
 int pk_fold_rows_f64(void *stream, int64_t cap, const int32_t *list_dev, const int32_t *count_dev, int64_t row_offset,
                      const int64_t *indptr_dev, const int32_t *indices_dev, const void *vals_dev, int val_kind,
                      const double *V_dev, int64_t ldv, int32_t K, double *E_dev, int64_t lde);
+
+/* ------------------------------------------------------------------------------------------
+ * K4q.  The approximate fold-in of an ids-only scoring pass against a PACKED image of the item factors
+ * (csrc/foldq.hip): E'[u, 0:K] = sum_j a_uj decode(image row j), E'[u, K] = w_u = sum_j a_uj D_j with
+ * ||E'_u - E_u|| <= 2^-24 w_u PROVEN (D_j is computed by the encoder from the bits it wrote), columns K+1 .. Kx-1 = 0.
+ * Replaces `test_matrix.dot(v)` (models.py:857-860) wherever the pass certifies its lists against that bound
+ * (pk_rescore_topk_rows_list_f64 with e_err = column K; users it cannot certify are re-folded in fp64 by
+ * pk_fold_rows_f64).  A rank-K row takes pk_q20_lanes(K) * 16 bytes (128 for K <= 50: ONE cache line per gathered
+ * entry where the fp32 image takes two); ranks above 202 have no packed image (pk_q20_lanes returns 0).
+ * pk_q20_encode_f64: V [n x K] fp64 row-major -> image (pk_q20_image_bytes, 128-byte aligned), the bracket scale table
+ * tab_dev (96 doubles), info_dev (int32: 0 = ok, else the factors are outside the format's range: use the fp32 image);
+ * work_dev: 768 bytes.  pk_q20_decode_f64: the rows exactly as the fold-in reads them, [n x (K + 1)], column K = D_j
+ * (tests, diagnostics).  pk_fold_q20: the row-task plan of pk_spmm_csr_ex; non-negative values only (w_u is a bound
+ * for a_uj >= 0); the partial buffer holds Kx doubles per slot. */
+int32_t pk_q20_lanes(int32_t K);
+double pk_q20_kappa(int32_t K);
+int64_t pk_q20_image_bytes(int64_t n, int32_t K);
+int pk_q20_encode_f64(void *stream, int64_t n, int32_t K, const double *V_dev, int64_t ldv, void *img_dev,
+                      double *tab_dev, void *work_dev, int32_t *info_dev);
+int pk_q20_decode_f64(void *stream, int64_t n, int32_t K, const void *img_dev, const double *tab_dev, double *out_dev,
+                      int64_t ldo);
+int pk_fold_q20(void *stream, int64_t n_tasks, const int32_t *task_row_dev, const int64_t *task_begin_dev,
+                const int64_t *task_end_dev, const int32_t *task_slot_dev, int64_t n_long,
+                const int32_t *long_row_dev, const int32_t *long_slot_begin_dev, const int32_t *long_slot_end_dev,
+                const int32_t *indices_dev, const void *vals_dev, int val_kind, const void *img_dev,
+                const double *tab_dev, int64_t n_items, int32_t K, int32_t Kx, double *out_dev, int64_t ldo,
+                double *partial_dev);
 /* dst[perm_dev[r], :] = src_dev[r, :] for rows of `width` int64 (perm_dev == NULL: a plain copy): the lists of a pass whose
  * users were grouped by activity go back to the caller's user order.  `dst` is device memory or MAPPED PINNED HOST memory:
  * the host-side [n_users x topk] int64 array of get_recommendations (models.py:400-405) can be written by the kernel

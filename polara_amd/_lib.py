@@ -82,6 +82,13 @@ PROTOTYPES = {
                                       _i32, _f64, _vp, _vp, _vp]),
     'pk_flag_compact': (C.c_int, [_vp, _i64, _vp, _i32, _vp, _vp]),
     'pk_fold_rows_f64': (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, C.c_int, _vp, _i64, _i32, _vp, _i64]),
+    'pk_q20_lanes': (_i32, [_i32]),
+    'pk_q20_kappa': (_f64, [_i32]),
+    'pk_q20_image_bytes': (_i64, [_i64, _i32]),
+    'pk_q20_encode_f64': (C.c_int, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _vp]),
+    'pk_q20_decode_f64': (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _i64]),
+    'pk_fold_q20': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _i64, _i32, _i32,
+                              _vp, _i64, _vp]),
     'pk_rescore_topk_rows_f64': (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _i32, _i32,
                                            _vp, _vp, _i32, _f64, _vp, _vp, _vp]),
     'pk_rescore_topk_rows_list_f64': (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _i32, _i32,

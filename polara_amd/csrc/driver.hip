@@ -968,7 +968,9 @@ __global__ void lanczos_flags_kernel(int l, const double *__restrict__ G, const 
 
 static int block_lanczos(pk_ctx *ctx, Solver &S, GramianOp &gop, int64_t n, int k, int b, double tol, uint64_t seed, int max_steps,
                          LanczosOut &out) {
-    int qcap = (int)(n / b);
+    // pk_gram_f64 takes operands of at most 4096 columns: a Krylov space that would outgrow them ends the recurrence like
+    // any other breakdown (out.ok stays false -> filtered subspace iteration), as solver.py::_block_lanczos does
+    int qcap = (int)std::min<int64_t>(n / b, 4096 / b);
     if (qcap < 4 || max_steps < 4) return PK_OK;          // out.ok stays false: no room for a Krylov space
     qcap = std::min(qcap, max_steps);
     int cap = std::min(qcap, 20);

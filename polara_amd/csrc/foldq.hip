@@ -1,0 +1,451 @@
+// K4q: the fold-in of the scoring pass, E = A_test * V (models.py:857-860 `test_matrix.dot(v)`), against a PACKED image
+// of the item factors: one 128-byte cache line per rank-50 row instead of the two lines of the fp32 image.
+//
+// Why: the row-wise SpMM is bound by what the L1 / texture path delivers per gathered row (every width
+// moves ~19 TB/s of row pieces, a 256-byte row costs twice a 128-byte one), so the lever left is bytes per gathered
+// entry.  The ids-only scoring pass does not need E exactly: it needs E' with a PROVEN bound ||E'_u - E_u|| <= 2^-24 w_u
+// (rescore.hip certifies the order of the lists against it and re-folds the users it cannot certify in fp64).
+//
+// Format ("Q20").  A row of K values is cut into L = 2 / 4 / 8 / 16 / 32 lane pieces of 16 bytes (K <= 12 / 25 / 50 /
+// 101 / 202).  A piece is a 128-bit stream, most significant bit first:
+//     [ digit : 8 ][ v0 : 20 ][ v1 : 20 ][ v2 : 20 ][ v3 : 20 ][ v4 : 20 ][ v5 : 20 ]
+// v0..v5 are columns 6l .. 6l+5 of the row as 20-bit two's-complement fixed point.  A value is DECODED as the 32-bit
+// window of the stream that starts at its first bit, read as an int32 (one v_alignbit_b32 per value, none for the
+// digit): the 12 bits below a value belong to its neighbour, the encoder knows them and rounds the value so that the
+// WHOLE window is nearest to the target (error <= half a 20-bit step, as if the low bits were not there).  Real value =
+// window * s(b), s = the scale of the row's BRACKET b (rows are cut into brackets by index, four per octave: the
+// catalogue is in popularity order, so a bracket's rows have similar norms; the scale multiplies the user's value once
+// per entry, in the stage that fetches the (index, value) pairs — no per-row scale has to be gathered or decoded).
+// The 8-bit digits carry what does not fit the 6 L main columns: column 6L + e is a three-digit signed number spread
+// over the digits of lanes 3e, 3e+1, 3e+2 (23 bits at half scale; each lane accumulates its own digit's window, the three
+// sums are joined once per row task), and the digit of lane L-1 is the row's ERROR WEIGHT: D_j >= 2^24 ||V_j - decode(row j)||
+// computed by the encoder from the bits it wrote — exact, not a worst case — so that the same product yields
+// w_u = sum_j a_uj D_j (column K of the output), the certified bound of the fold-in's error.
+//
+// Mapping: one wave per row task (the plan of spmm.hip), the wave cut into 64 / L groups of L lanes, group g takes
+// entries g, g + GROUPS, ... of the task; one dwordx4 load per lane and entry; fp64 accumulation; group sums added in a
+// fixed order (deterministic).
+#include "pk_common.h"
+#include <math.h>
+
+#define PK_Q20_TAB 96
+
+__host__ __device__ __forceinline__ int pk_q20_bracket(unsigned j) {
+    if (j < 4u) return (int)j;
+#ifdef __HIP_DEVICE_COMPILE__
+    const int e = 31 - __clz((int)j);
+#else
+    const int e = 31 - __builtin_clz(j);
+#endif
+    return 4 * (e - 1) + (int)((j >> (e - 2)) & 3u);
+}
+
+static inline int q20_lanes(int K) {
+    if (K <= 12) return 2;
+    if (K <= 25) return 4;
+    if (K <= 50) return 8;
+    if (K <= 101) return 16;
+    if (K <= 202) return 32;
+    return 0;
+}
+
+extern "C" int32_t pk_q20_lanes(int32_t K) { return K >= 1 ? q20_lanes(K) : 0; }
+
+// number of extra columns (beyond the 6 L main ones) an L-lane row can carry
+__host__ __device__ __forceinline__ int pk_q20_extras(int L) { return (L - 1) / 3; }
+
+// ---------------------------------------------------------------------------------------------- encoder
+// bracket maxima of |V| (positive doubles order like their bit patterns)
+__global__ __launch_bounds__(256) void q20_bracket_max_kernel(int64_t n, int K, const double *__restrict__ V, int64_t ldv,
+                                                              unsigned long long *__restrict__ bmax_bits) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const int lane = threadIdx.x & 63;
+    double m = 0.0;
+    for (int c = lane; c < K; c += 64) {
+        const double a = fabs(V[row * ldv + c]);
+        m = (a <= 1e300) ? fmax(m, a) : INFINITY;              // NaN and overflowing magnitudes: no image (q20_scale_kernel flags it)
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
+    if (lane == 0 && m > 0.0) atomicMax(bmax_bits + pk_q20_bracket((unsigned)row), (unsigned long long)__double_as_longlong(m));
+}
+
+__global__ void q20_scale_kernel(const unsigned long long *__restrict__ bmax_bits, double *__restrict__ tab, int32_t *__restrict__ info) {
+    const int b = threadIdx.x;
+    if (b >= PK_Q20_TAB) return;
+    const double m = __longlong_as_double((long long)bmax_bits[b]);
+    // a window spans +-2^31 and a target stays 8192 units inside it; non-finite or subnormal-scale factors: no image
+    double s = m * (1.0 + 9.5367431640625e-07) / (2147483648.0 - 8192.0);
+    if (!(m < 1e300) || (m > 0.0 && s < 1e-290)) {
+        atomicOr(info, 1);
+        s = 0.0;
+    }
+    tab[b] = s;
+}
+
+template <int L>
+__global__ __launch_bounds__(256) void q20_encode_kernel(int64_t n, int K, const double *__restrict__ V, int64_t ldv,
+                                                         const double *__restrict__ tab, double kappa,
+                                                         uint4 *__restrict__ img, int32_t *__restrict__ info) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t row_raw = gid / L;
+    const bool live = row_raw < n;
+    const int64_t row = live ? row_raw : n - 1;
+    const int l = (int)(gid % L);
+    const double s = tab[pk_q20_bracket((unsigned)row)];
+    const double inv = s > 0.0 ? 1.0 / s : 0.0;
+    const double *vr = V + row * ldv;
+    unsigned p[6];
+    double sq = 0.0;
+    unsigned g = 0;
+#pragma unroll
+    for (int t = 5; t >= 0; --t) {
+        const int c = 6 * l + t;
+        const double v = c < K ? vr[c] : 0.0;
+        double f = rint((v * inv - (double)g) * 0.000244140625);
+        f = fmin(fmax(f, -524288.0), 524287.0);
+        const double window = f * 4096.0 + (double)g;          // what the kernel decodes (an int32, exact in fp64)
+        if (c < K) {
+            const double err = fma(-window, s, v);
+            sq = fma(err, err, sq);
+        }
+        p[t] = ((unsigned)(int)f) & 0xFFFFFu;
+        g = p[t] >> 8;
+    }
+    const double G = (double)((p[0] << 4) | (p[1] >> 16));      // the 24 bits below this lane's digit
+    // ---- digits of the extra columns: lanes 3e (top), 3e+1, 3e+2 carry column 6L + e.  Every lane computes the three
+    // digits as if it were a top lane (with the bits below its neighbours' digits, G1 and G2); the lower lanes fetch theirs.
+    const int lane = threadIdx.x & 63;
+    const int e = l / 3, lvl = l % 3;
+    const bool has_extra = (3 * e + 2 <= L - 2) && (6 * L + e < K);
+    const double xv = (has_extra && lvl == 0) ? vr[6 * L + e] : 0.0;
+    const double G1 = __shfl(G, lane + 1, 64), G2 = __shfl(G, lane + 2, 64);
+    // target in window units of the top digit, at HALF scale (a digit's window spans [-2^31, 2^31 - 2^24 + G]: a bracket's
+    // largest entry sitting in an extra column would not be representable at full scale; 23 bits are still eight times
+    // finer than the main columns' 20).  A digit is chosen so that the remainder lies in the range the lower digits
+    // can represent (floor against that range's lower end), the last one to nearest.
+    const double X = xv * inv * 0.5;
+    const double lo2 = (-2147483648.0 + G2) * 1.52587890625e-05;
+    const double lo1 = (-2147483648.0 + G1) * 0.00390625 + lo2;
+    const double d0 = fmin(fmax(floor((X - G - lo1) * 5.9604644775390625e-08), -128.0), 127.0);
+    const double R0 = X - (d0 * 16777216.0 + G);
+    const double d1 = fmin(fmax(floor(((R0 - lo2) * 256.0 - G1) * 5.9604644775390625e-08), -128.0), 127.0);
+    const double R1 = R0 - (d1 * 16777216.0 + G1) * 0.00390625;
+    const double d2 = fmin(fmax(rint((R1 * 65536.0 - G2) * 5.9604644775390625e-08), -128.0), 127.0);
+    const double d1_up = __shfl(d1, lane - 1, 64), d2_up = __shfl(d2, lane - 2, 64);
+    double dig = 0.0;
+    if (has_extra) dig = lvl == 0 ? d0 : (lvl == 1 ? d1_up : d2_up);
+    if (has_extra && lvl == 0) {
+        const double rep = (d0 * 16777216.0 + G) + (d1 * 16777216.0 + G1) * 0.00390625 + (d2 * 16777216.0 + G2) * 1.52587890625e-05;   // exact
+        const double err = fma(-2.0 * rep, s, xv);
+        sq = fma(err, err, sq);
+    }
+    // ---- the row's error weight in the digit of lane L - 1
+#pragma unroll
+    for (int off = 1; off < L; off <<= 1) sq += __shfl_xor(sq, off, 64);
+    if (l == L - 1) {
+        // D = 2^24 * ||error|| with a margin for the roundings of this computation and of the kernel's fp64 sums
+        const double D = sqrt(sq) * (1.0 + 0.001953125) * 16777216.0;
+        dig = 0.0;
+        if (s > 0.0) {
+            const double Y = D / (s * kappa);
+            dig = ceil((Y - G) * 5.9604644775390625e-08);
+            if (dig > 127.0) {
+                atomicOr(info, 2);      // kappa too small for this row (cannot happen with pk_q20_kappa's choice): no image
+                dig = 127.0;
+            }
+            dig = fmax(dig, -128.0);
+        }
+    }
+    const unsigned db = ((unsigned)(int)dig) & 0xFFu;
+    uint4 o;
+    o.x = (db << 24) | (p[0] << 4) | (p[1] >> 16);
+    o.y = ((p[1] & 0xFFFFu) << 16) | (p[2] >> 4);
+    o.z = ((p[2] & 0xFu) << 28) | (p[3] << 8) | (p[4] >> 12);
+    o.w = ((p[4] & 0xFFFu) << 20) | p[5];
+    if (live) img[row * L + l] = o;
+}
+
+static double q20_kappa(int K) { return sqrt((double)K) * 2048.0 * 1.08 / 126.0; }
+
+extern "C" double pk_q20_kappa(int32_t K) { return q20_kappa(K); }
+
+// image bytes of n rows
+extern "C" int64_t pk_q20_image_bytes(int64_t n, int32_t K) {
+    const int L = q20_lanes(K);
+    return L ? n * L * 16 : 0;
+}
+
+extern "C" int pk_q20_encode_f64(void *stream, int64_t n, int32_t K, const double *V_dev, int64_t ldv, void *img_dev,
+                                 double *tab_dev, void *work_dev, int32_t *info_dev) {
+    const int L = q20_lanes(K);
+    PK_REQUIRE(L != 0 && n >= 1 && ldv >= K, "pk_q20_encode_f64: rank %d has no packed image (max 202) or bad sizes", K);
+    PK_REQUIRE(n < (1 << 24) && n * L * 16 < ((int64_t)1 << 32), "pk_q20_encode_f64: the image must stay below 4 GiB and 2^24 rows");
+    PK_REQUIRE(V_dev && img_dev && tab_dev && work_dev && info_dev && (((uintptr_t)img_dev) & 127) == 0, "pk_q20_encode_f64: bad pointers (image 128-byte aligned)");
+    hipStream_t st = pk_stream(stream);
+    unsigned long long *bmax = static_cast<unsigned long long *>(work_dev);        // PK_Q20_TAB * 8 bytes
+    if (hipMemsetAsync(bmax, 0, PK_Q20_TAB * 8, st) != hipSuccess || hipMemsetAsync(info_dev, 0, 4, st) != hipSuccess) {
+        pk_set_error("pk_q20_encode_f64: memset failed");
+        return PK_E_LAUNCH;
+    }
+    hipLaunchKernelGGL(q20_bracket_max_kernel, dim3((unsigned)pk_ceil_div(n, 4)), dim3(256), 0, st, n, K, V_dev, ldv, bmax);
+    hipLaunchKernelGGL(q20_scale_kernel, dim3(1), dim3(128), 0, st, bmax, tab_dev, info_dev);
+    const double kappa = q20_kappa(K);
+    const dim3 grid((unsigned)pk_ceil_div(n * L, 256));
+    uint4 *img = static_cast<uint4 *>(img_dev);
+    switch (L) {
+        case 2: hipLaunchKernelGGL(q20_encode_kernel<2>, grid, dim3(256), 0, st, n, K, V_dev, ldv, tab_dev, kappa, img, info_dev); break;
+        case 4: hipLaunchKernelGGL(q20_encode_kernel<4>, grid, dim3(256), 0, st, n, K, V_dev, ldv, tab_dev, kappa, img, info_dev); break;
+        case 8: hipLaunchKernelGGL(q20_encode_kernel<8>, grid, dim3(256), 0, st, n, K, V_dev, ldv, tab_dev, kappa, img, info_dev); break;
+        case 16: hipLaunchKernelGGL(q20_encode_kernel<16>, grid, dim3(256), 0, st, n, K, V_dev, ldv, tab_dev, kappa, img, info_dev); break;
+        default: hipLaunchKernelGGL(q20_encode_kernel<32>, grid, dim3(256), 0, st, n, K, V_dev, ldv, tab_dev, kappa, img, info_dev); break;
+    }
+    PK_CHECK_LAUNCH("q20_encode_kernel");
+    return PK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- decoder (tests, re-scoring)
+// fp64 rows of the image exactly as the fold-in kernel reads them: out[n x (K + 1)], column K = D_j
+template <int L>
+__global__ __launch_bounds__(256) void q20_decode_kernel(int64_t n, int K, const uint4 *__restrict__ img, const double *__restrict__ tab,
+                                                         double kappa, double *__restrict__ out, int64_t ldo) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t row_raw = gid / L;
+    const bool live = row_raw < n;
+    const int64_t row = live ? row_raw : n - 1;
+    const int l = (int)(gid % L);
+    const uint4 d = img[row * L + l];
+    const double s = tab[pk_q20_bracket((unsigned)row)];
+    const int w[7] = {(int)__builtin_amdgcn_alignbit(d.x, d.y, 24), (int)__builtin_amdgcn_alignbit(d.x, d.y, 4),
+                      (int)__builtin_amdgcn_alignbit(d.y, d.z, 16), (int)__builtin_amdgcn_alignbit(d.z, d.w, 28),
+                      (int)__builtin_amdgcn_alignbit(d.z, d.w, 8), (int)(d.w << 12), (int)d.x};
+    double *o = out + row * ldo;
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+        if (live && 6 * l + t < K) o[6 * l + t] = (double)w[t] * s;
+    const double a6 = (double)w[6] * s;
+    const int lane = threadIdx.x & 63;
+    const double a1 = __shfl(a6, lane + 1, 64), a2 = __shfl(a6, lane + 2, 64);
+    const int e = l / 3;
+    if (live && l % 3 == 0 && 3 * e + 2 <= L - 2 && 6 * L + e < K) o[6 * L + e] = 2.0 * (a6 + a1 * 0.00390625 + a2 * 1.52587890625e-05);
+    if (live && l == L - 1) o[K] = kappa * a6;
+}
+
+extern "C" int pk_q20_decode_f64(void *stream, int64_t n, int32_t K, const void *img_dev, const double *tab_dev, double *out_dev,
+                                 int64_t ldo) {
+    const int L = q20_lanes(K);
+    PK_REQUIRE(L != 0 && n >= 1 && ldo >= K + 1, "pk_q20_decode_f64: bad sizes");
+    hipStream_t st = pk_stream(stream);
+    const dim3 grid((unsigned)pk_ceil_div(n * L, 256));
+    const uint4 *img = static_cast<const uint4 *>(img_dev);
+    const double kappa = q20_kappa(K);
+    switch (L) {
+        case 2: hipLaunchKernelGGL(q20_decode_kernel<2>, grid, dim3(256), 0, st, n, K, img, tab_dev, kappa, out_dev, ldo); break;
+        case 4: hipLaunchKernelGGL(q20_decode_kernel<4>, grid, dim3(256), 0, st, n, K, img, tab_dev, kappa, out_dev, ldo); break;
+        case 8: hipLaunchKernelGGL(q20_decode_kernel<8>, grid, dim3(256), 0, st, n, K, img, tab_dev, kappa, out_dev, ldo); break;
+        case 16: hipLaunchKernelGGL(q20_decode_kernel<16>, grid, dim3(256), 0, st, n, K, img, tab_dev, kappa, out_dev, ldo); break;
+        default: hipLaunchKernelGGL(q20_decode_kernel<32>, grid, dim3(256), 0, st, n, K, img, tab_dev, kappa, out_dev, ldo); break;
+    }
+    PK_CHECK_LAUNCH("q20_decode_kernel");
+    return PK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- the fold-in
+template <int J>
+__device__ __forceinline__ void q20_group_sum(double (&acc)[7]) {
+#pragma unroll
+    for (int t = 0; t < 7; ++t) acc[t] += pk_lane_xor<J>(acc[t]);
+}
+
+template <typename VT, int L>
+__global__ __launch_bounds__(256) void fold_q20_kernel(
+    int64_t n_tasks, const int32_t *__restrict__ task_row, const int64_t *__restrict__ task_begin,
+    const int64_t *__restrict__ task_end, const int32_t *__restrict__ task_slot,
+    const int32_t *__restrict__ indices, const VT *__restrict__ vals, const uint4 *__restrict__ img,
+    const double *__restrict__ tab, double kappa, int K, int Kx, double *__restrict__ out, int64_t ldo,
+    double *__restrict__ partial) {
+    constexpr int GROUPS = 64 / L;
+    constexpr int SPC = L;                                   // wave steps per 64-pair chunk
+    constexpr int U = L >= 8 ? 4 : (L == 4 ? 2 : 1);         // steps per register set (two sets in flight)
+    constexpr int SETS = SPC / U;
+    static_assert(SETS >= 2 && SETS % 2 == 0, "the two register sets alternate");
+    constexpr int LOG_RB = L == 2 ? 5 : (L == 4 ? 6 : (L == 8 ? 7 : (L == 16 ? 8 : 9)));   // log2(row bytes)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t task = (int64_t)blockIdx.x * 4 + wave;
+    if (task >= n_tasks) return;
+    const int64_t p0 = task_begin[task];
+    const int n = (int)(task_end[task] - p0);
+    const int g = lane / L, l = lane % L;
+    const int32_t *ip = indices + p0;
+    const VT *vp = vals + p0;
+    const char *Xb = reinterpret_cast<const char *>(img);
+    const unsigned lo0 = (unsigned)l << 4;
+
+    double acc[7];
+#pragma unroll
+    for (int t = 0; t < 7; ++t) acc[t] = 0.0;
+
+    // pairs: current chunk (index, value * bracket scale), next chunk (index, raw value; its scales requested at the
+    // top of the iteration before it), the chunk after that in flight
+    int jc = 0, jn = 0;
+    VT araw = (VT)0, an = (VT)0;
+    if (lane < n) {
+        jc = ip[lane];
+        araw = vp[lane];
+    }
+    if (64 + lane < n) {
+        jn = ip[64 + lane];
+        an = vp[64 + lane];
+    }
+    auto issue = [&](int jch, int st0, uint4(&x)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int jj = __shfl(jch, (st0 + u) * GROUPS + g, 64);
+            unsigned off;
+            asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(off) : "v"(jj), "n"(LOG_RB), "v"(lo0));
+            x[u] = *reinterpret_cast<const uint4 *>(Xb + off);
+        }
+    };
+    auto consume = [&](int alo, int ahi, int st0, const uint4(&x)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int src = (st0 + u) * GROUPS + g;
+            const double aa = __hiloint2double(__shfl(ahi, src, 64), __shfl(alo, src, 64));
+            const uint4 d = x[u];
+            acc[0] = fma(aa, (double)(int)__builtin_amdgcn_alignbit(d.x, d.y, 24), acc[0]);
+            acc[1] = fma(aa, (double)(int)__builtin_amdgcn_alignbit(d.x, d.y, 4), acc[1]);
+            acc[2] = fma(aa, (double)(int)__builtin_amdgcn_alignbit(d.y, d.z, 16), acc[2]);
+            acc[3] = fma(aa, (double)(int)__builtin_amdgcn_alignbit(d.z, d.w, 28), acc[3]);
+            acc[4] = fma(aa, (double)(int)__builtin_amdgcn_alignbit(d.z, d.w, 8), acc[4]);
+            acc[5] = fma(aa, (double)(int)(d.w << 12), acc[5]);
+            acc[6] = fma(aa, (double)(int)d.x, acc[6]);
+        }
+    };
+    uint4 x0[U], x1[U];
+    issue(jc, 0, x0);                                        // the first gathers do not wait for the scale
+    double ac = (double)araw * tab[pk_q20_bracket((unsigned)jc)];
+    for (int p = 0; p < n; p += 64) {
+        const int cnt = (n - p) < 64 ? (n - p) : 64;         // pairs of this chunk; padded lanes hold (0, 0.0)
+        const bool more = p + 64 < n;
+        int jf = 0;
+        VT af = (VT)0;
+        if (p + 128 + lane < n) {                            // pairs two chunks ahead
+            jf = ip[p + 128 + lane];
+            af = vp[p + 128 + lane];
+        }
+        double sn = 0.0;
+        if (more) sn = tab[pk_q20_bracket((unsigned)jn)];     // the next chunk's scales (its indices arrived a chunk ago)
+        const int alo = __double2loint(ac), ahi = __double2hiint(ac);
+#pragma unroll
+        for (int k = 0; k < SETS; ++k) {
+            const bool have = k * U * GROUPS < cnt;
+            const bool have_next = (k + 1 < SETS) ? ((k + 1) * U * GROUPS < cnt) : more;
+            if ((k & 1) == 0) {
+                if (have_next) {
+                    if (k + 1 < SETS) issue(jc, (k + 1) * U, x1);
+                    else issue(jn, 0, x1);
+                }
+                if (have) consume(alo, ahi, k * U, x0);
+            } else {
+                if (have_next) {
+                    if (k + 1 < SETS) issue(jc, (k + 1) * U, x0);
+                    else issue(jn, 0, x0);
+                }
+                if (have) consume(alo, ahi, k * U, x1);
+            }
+        }
+        jc = jn;
+        ac = (double)an * sn;
+        jn = jf;
+        an = af;
+    }
+
+    // add the GROUPS partial sums in group order (fixed): after the exchange every lane holds the total
+    if constexpr (L <= 2) q20_group_sum<2>(acc);
+    if constexpr (L <= 4) q20_group_sum<4>(acc);
+    if constexpr (L <= 8) q20_group_sum<8>(acc);
+    if constexpr (L <= 16) q20_group_sum<16>(acc);
+    q20_group_sum<32>(acc);
+
+    // the three digit sums of an extra column meet in its top lane
+    const double a1 = __shfl(acc[6], lane + 1, 64), a2 = __shfl(acc[6], lane + 2, 64);
+    const int slot = task_slot[task];
+    double *dst = slot < 0 ? out + (int64_t)task_row[task] * ldo : partial + (int64_t)slot * Kx;
+    if (g == 0) {
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+            if (6 * l + t < K) dst[6 * l + t] = acc[t];
+        const int e = l / 3;
+        if (l % 3 == 0 && 3 * e + 2 <= L - 2 && 6 * L + e < K) dst[6 * L + e] = 2.0 * (acc[6] + a1 * 0.00390625 + a2 * 1.52587890625e-05);
+        if (l == L - 1) {
+            dst[K] = kappa * acc[6];
+            for (int c = K + 1; c < Kx; ++c) dst[c] = 0.0;
+        }
+    }
+}
+
+// out[row, :] = sum of the row's partial slots (fixed order): the tail of a row split into several tasks
+__global__ __launch_bounds__(256) void fold_q20_fixup_kernel(int64_t n_long, const int32_t *__restrict__ long_row,
+                                                             const int32_t *__restrict__ slot_begin, const int32_t *__restrict__ slot_end,
+                                                             const double *__restrict__ partial, int nc, double *__restrict__ out, int64_t ldo) {
+    const int64_t r = blockIdx.x;
+    if (r >= n_long) return;
+    const int s0 = slot_begin[r], s1 = slot_end[r];
+    double *dst = out + (int64_t)long_row[r] * ldo;
+    for (int c = threadIdx.x; c < nc; c += blockDim.x) {
+        double a = 0.0;
+        for (int s = s0; s < s1; ++s) a += partial[(int64_t)s * nc + c];
+        dst[c] = a;
+    }
+}
+
+template <typename VT>
+static void launch_fold_q20(hipStream_t st, int L, int64_t n_tasks, const int32_t *task_row, const int64_t *task_begin,
+                            const int64_t *task_end, const int32_t *task_slot, const int32_t *indices, const void *vals,
+                            const uint4 *img, const double *tab, double kappa, int K, int Kx, double *out, int64_t ldo, double *partial) {
+    const dim3 grid((unsigned)pk_ceil_div(n_tasks, 4)), block(256);
+    const VT *v = static_cast<const VT *>(vals);
+#define PK_FOLDQ(LL)                                                                                                     \
+    hipLaunchKernelGGL((fold_q20_kernel<VT, LL>), grid, block, 0, st, n_tasks, task_row, task_begin, task_end, task_slot, \
+                       indices, v, img, tab, kappa, K, Kx, out, ldo, partial)
+    switch (L) {
+        case 2: PK_FOLDQ(2); break;
+        case 4: PK_FOLDQ(4); break;
+        case 8: PK_FOLDQ(8); break;
+        case 16: PK_FOLDQ(16); break;
+        default: PK_FOLDQ(32); break;
+    }
+#undef PK_FOLDQ
+}
+
+extern "C" int pk_fold_q20(void *stream, int64_t n_tasks, const int32_t *task_row_dev, const int64_t *task_begin_dev,
+                           const int64_t *task_end_dev, const int32_t *task_slot_dev, int64_t n_long,
+                           const int32_t *long_row_dev, const int32_t *long_slot_begin_dev, const int32_t *long_slot_end_dev,
+                           const int32_t *indices_dev, const void *vals_dev, int val_kind, const void *img_dev,
+                           const double *tab_dev, int64_t n_items, int32_t K, int32_t Kx, double *out_dev, int64_t ldo,
+                           double *partial_dev) {
+    const int L = q20_lanes(K);
+    PK_REQUIRE(L != 0 && n_tasks >= 0 && Kx >= K + 1 && ldo >= Kx, "pk_fold_q20: bad sizes (K=%d, Kx=%d)", K, Kx);
+    PK_REQUIRE(n_items >= 1 && n_items < (1 << 24) && n_items * L * 16 < ((int64_t)1 << 32), "pk_fold_q20: image beyond 32-bit offsets");
+    PK_REQUIRE(n_long == 0 || partial_dev != nullptr, "pk_fold_q20: partial buffer required");
+    PK_REQUIRE(val_kind == PK_VAL_F32 || val_kind == PK_VAL_F64, "pk_fold_q20: bad val_kind %d", val_kind);
+    if (n_tasks == 0) return PK_OK;
+    hipStream_t st = pk_stream(stream);
+    const uint4 *img = static_cast<const uint4 *>(img_dev);
+    const double kappa = q20_kappa(K);
+    if (val_kind == PK_VAL_F32)
+        launch_fold_q20<float>(st, L, n_tasks, task_row_dev, task_begin_dev, task_end_dev, task_slot_dev, indices_dev, vals_dev, img,
+                               tab_dev, kappa, K, Kx, out_dev, ldo, partial_dev);
+    else
+        launch_fold_q20<double>(st, L, n_tasks, task_row_dev, task_begin_dev, task_end_dev, task_slot_dev, indices_dev, vals_dev, img,
+                                tab_dev, kappa, K, Kx, out_dev, ldo, partial_dev);
+    PK_CHECK_LAUNCH("fold_q20_kernel");
+    if (n_long > 0) {
+        hipLaunchKernelGGL(fold_q20_fixup_kernel, dim3((unsigned)n_long), dim3(256), 0, st, n_long, long_row_dev, long_slot_begin_dev,
+                           long_slot_end_dev, partial_dev, Kx, out_dev, ldo);
+        PK_CHECK_LAUNCH("fold_q20_fixup_kernel");
+    }
+    return PK_OK;
+}

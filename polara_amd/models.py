@@ -902,9 +902,12 @@ class CoffeeModel(RecommenderModel):
             u, i, f, levels, shp = self.data.tensor_triplets()
             i0, i1, i2, bad = tucker.device_coordinates(ops, u, i, f, levels)
             counts = ops.bincount(i1, shp[1])
+            counts_bad = torch.cat([counts.to(torch.int64), bad.reshape(1).to(torch.int64)])
             if presharded and comm.world > 1:
-                counts = comm.allreduce(counts)
-            counts_bad = ops.to_host(torch.cat([counts.to(torch.int64), bad.reshape(1)]))     # one host read for both
+                # the count of entries outside the level set rides in the same sum: EVERY rank raises below, not only
+                # the one that holds the offending entries (the others would wait in the next collective for ever)
+                counts_bad = comm.allreduce(counts_bad)
+            counts_bad = ops.to_host(counts_bad)                                              # one host read for both
             if int(counts_bad[-1]):
                 raise ValueError('Not all values of feedback are present in the feedback levels of the training data '
                                  '(%d entries)' % int(counts_bad[-1]))

@@ -387,10 +387,13 @@ class HipOps:
         n = int(A.shape[1])
         counts = torch.empty(n, dtype=torch.int32, device=self.device)
         _lib.check(self.lib.pk_count_i32(self.stream(), A.indices.numel(), _ptr(A.indices), n, _ptr(counts)), 'pk_count_i32')
-        total = int(A.indices.numel())
-        if comm is not None and getattr(comm, 'world', 1) > 1:
+        sharded = comm is not None and getattr(comm, 'world', 1) > 1
+        if sharded:
             counts = comm.allreduce(counts.to(torch.int64)).to(torch.int32)
-            total *= int(comm.world)            # an upper bound of any count is all the sort needs
+        # the sort's key width must be the SAME on every rank and cover every key: on one rank the local entry count
+        # bounds the counts; over shards of unequal size (ShardedArrayData) no local quantity does, and the keys are
+        # int32 anyway — all 32 bits then (an n_items-sized sort: microseconds)
+        total = int(A.indices.numel()) if not sharded else (1 << 32) - 1
         keys = (counts.max() - counts).contiguous()
         pos = torch.arange(n, dtype=torch.int32, device=self.device)
         keys_tmp, pos_tmp = torch.empty_like(keys), torch.empty_like(pos)
@@ -607,6 +610,60 @@ class HipOps:
                 _ptr(lr, l0), _ptr(lb, l0), _ptr(le, l0), _ptr(A.indices), _ptr(A.values), A.val_kind,
                 _ptr(X), x_kind, X.stride(0), nc, _ptr(out), out.stride(0), _ptr(A.partial(nc)), int(row_base),
                 1 if accumulate else 0, int(X.shape[0])), 'pk_spmm_csr_ex')
+        return out
+
+    # ---- K4q: packed image of the item factors for the approximate fold-in (csrc/foldq.hip) -------------
+    def q20_supported(self, n_items, K):
+        """does a [n_items x K] factor matrix have a packed image (rank <= 202, below 2^24 rows and 4 GiB)?"""
+        L = self.lib.pk_q20_lanes(int(K))
+        return L != 0 and n_items < (1 << 24) and n_items * L * 16 < (1 << 32)
+
+    def q20_encode(self, V):
+        """(image uint8 [n x L*16], bracket scales fp64 [96]) of fp64 V, or None when the factors do not fit the
+        format (non-finite / extreme magnitudes): the caller keeps the fp32 image."""
+        assert V.stride(1) == 1 and V.dtype == torch.float64
+        n, K = V.shape
+        if not self.q20_supported(n, K):
+            return None
+        nbytes = self.lib.pk_q20_image_bytes(n, K)
+        raw = torch.empty(nbytes + 128, dtype=torch.uint8, device=self.device)
+        off = (-raw.data_ptr()) % 128
+        img = raw[off:off + nbytes].view(n, nbytes // n)
+        tab = torch.empty(96, dtype=torch.float64, device=self.device)
+        work = torch.empty(768, dtype=torch.uint8, device=self.device)
+        info = torch.empty(1, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.pk_q20_encode_f64(self.stream(), n, K, _ptr(V), V.stride(0), _ptr(img), _ptr(tab), _ptr(work),
+                                              _ptr(info)), 'pk_q20_encode_f64')
+        if int(info.item()) != 0:
+            return None
+        return img, tab
+
+    def q20_decode(self, image, K):
+        """fp64 [n x (K + 1)]: the rows as the fold-in kernel decodes them, column K = the rows' error weights D_j"""
+        img, tab = image
+        n = img.shape[0]
+        out = self.empty(n, K + 1)
+        _lib.check(self.lib.pk_q20_decode_f64(self.stream(), n, K, _ptr(img), _ptr(tab), _ptr(out), out.stride(0)),
+                   'pk_q20_decode_f64')
+        return out
+
+    def fold_q20(self, A, image, K, out, rows=None):
+        """out[:, :K] = A @ decode(image), out[:, K] = w = A @ D (the certified weight of the image's error),
+        zeros up to out's width.  A: DeviceCSR with non-negative values; rows as in `spmm`."""
+        img, tab = image
+        Kx = out.shape[1]
+        assert out.dtype == torch.float64 and out.stride(1) == 1 and Kx >= K + 1 and img.shape[0] == A.shape[1]
+        t0, n_tasks, l0, n_long = (0, A.n_tasks, 0, A.n_long) if rows is None else A.task_range(int(rows[0]), int(rows[1]))
+        p = A.plan
+        meta = None
+        if self.timers is not None:
+            meta = (A.shape[0], A.shape[1], A.nnz, Kx, A.values.element_size(), img.shape[1])
+        with self._timed('fold_q20', meta):
+            _lib.check(self.lib.pk_fold_q20(
+                self.stream(), n_tasks, _ptr(p['task_row'], t0), _ptr(p['task_begin'], t0), _ptr(p['task_end'], t0),
+                _ptr(p['task_slot'], t0), n_long, _ptr(p['long_row'], l0), _ptr(p['long_slot_begin'], l0),
+                _ptr(p['long_slot_end'], l0), _ptr(A.indices), _ptr(A.values), A.val_kind, _ptr(img), _ptr(tab),
+                int(A.shape[1]), int(K), int(Kx), _ptr(out), out.stride(0), _ptr(A.partial(Kx))), 'pk_fold_q20')
         return out
 
     # ---- K2 ---------------------------------------------------------------------------------

@@ -161,10 +161,14 @@ def find_optimal_config(model, param_grid, param_names, target_metric, return_sc
                         raise NotImplementedError
     finally:
         model.verbose = quiet
-    best = max(value, key=lambda p: value[p]) if value else None
-    for p in value:                                     # first maximum, like pandas' idxmax
-        if value[p] == value[best]:
+    if not value:
+        raise ValueError('find_optimal_config: empty param_grid')
+    finite = [p for p in value if value[p] == value[p]]    # pandas' idxmax skips NaN; first maximum in grid order
+    if not finite:
+        raise ValueError('find_optimal_config: the target metric is NaN at every grid point')
+    best = finite[0]
+    for p in finite:
+        if value[p] > value[best]:
             best = p
-            break
     best_config = _params_to_dict(param_names, best)
     return (best_config, value) if return_scores else best_config

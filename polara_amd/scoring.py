@@ -18,6 +18,7 @@ from .csr import coo_to_csr
 
 EXACT_ROWS_BYTES = 2 << 30  # work-buffer budget per launch of the exact path
 MAX_FUSED_RANK = 256        # largest rank the MFMA candidate sweep is instantiated for (csrc/score.hip)
+PACKED_FOLD_IN = True       # the approximate fold-in gathers the packed (one line per rank-50 row) image where one exists
 
 
 class FactorImage:
@@ -38,6 +39,7 @@ class FactorImage:
             # bounds are norm-wise (2^-24 * max||V_i||) and hold as long as that scale is an fp32 NORMAL number
             raise ValueError('item factors with max row norm %g are outside the range the fp32 candidate sweep '
                              'works in (rescale the factors)' % self.vmax)
+        self.Q20 = None
         if not self.fused:
             self.tile_bound = self.V32x = None
             self.Kx = self.K
@@ -54,6 +56,10 @@ class FactorImage:
         self.V32x = torch.zeros(self.n_items, ld, dtype=torch.float32, device=self.V.device)[:, :self.Kx]
         self.V32x[:, :self.K] = self.V.to(torch.float32)
         self.V32x[:, self.K] = ops.row_norm_bound(self.V)
+        # packed image for the approximate fold-in (csrc/foldq.hip): 20-bit block fixed point, half the bytes and lines
+        # per gathered entry of the fp32 image; its own error weights D_j (exact, from the bits written) take the
+        # place of the norm column, so column K of the product is again a w_u with ||E' - E|| <= 2^-24 w_u
+        self.Q20 = ops.q20_encode(self.V) if (PACKED_FOLD_IN and hasattr(ops, 'q20_encode')) else None
 
 
 def test_csr_from_triplet(test_data, shape, weights=None):
@@ -186,8 +192,11 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
         splits = ops.score_splits(nb, KC, prune)     # of THIS batch: a small head batch is dealt out over item splits
         two_phase = ops.two_phase_plan(nb, n_items, KC) if use_two_phase else (0, 0)     # ... or swept in two phases
         if approx_fold_in:
-            ops.spmm(T, factors.V32x, out=Ex, rows=(u0, u1))               # fold-in against fl32(V) (K4)
-            w = Ex[u0:u1, K]                                               # w_u = sum_j a_uj ||V_j|| (strided view)
+            if factors.Q20 is not None and PACKED_FOLD_IN:
+                ops.fold_q20(T, factors.Q20, K, out=Ex, rows=(u0, u1))     # fold-in against the packed image (K4q)
+            else:
+                ops.spmm(T, factors.V32x, out=Ex, rows=(u0, u1))           # fold-in against fl32(V) (K4)
+            w = Ex[u0:u1, K]                                               # w_u: ||E' - E|| <= 2^-24 w_u (strided view)
         else:
             ops.spmm(T, factors.V, out=Ex, rows=(u0, u1))                  # fold-in, fp64 (K4)
             w = None

@@ -35,6 +35,8 @@ import os
 import numpy as np
 import torch
 
+MAX_KRYLOV_COLS = 4096     # widest operand of pk_gram_f64 (csrc/dense.hip): the Krylov basis of a block Lanczos build stays below it
+
 
 class NoConvergence(RuntimeError):
     """The block solver stopped at `max_outer` outer iterations with unconverged leading Ritz pairs — the
@@ -501,7 +503,10 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
     import os
     n = lay.n
     b = l
-    qcap = n // b
+    # the Gram products against the whole basis (Q^T W, the re-projections, the nested T X) take at most
+    # MAX_KRYLOV_COLS columns (pk_gram_f64's limit): a space that would outgrow them is a breakdown like any other —
+    # the filtered subspace iteration takes over — not an error out of a kernel launcher (rank 100: b = 128, 32 blocks)
+    qcap = min(n // b, MAX_KRYLOV_COLS // b)
     if qcap < 4 or max_steps < 4:
         raise _LanczosBreakdown('Krylov space of at most %d blocks' % qcap)
     qcap = min(qcap, max_steps)

@@ -431,6 +431,28 @@ def test_block_lanczos_hands_rank_deficient_matrices_to_the_subspace_iteration()
         assert np.allclose(s.numpy(), sd, rtol=1e-9, atol=1e-9 * sd[0]), name
 
 
+def test_block_lanczos_stops_at_the_widest_gram_operand_and_falls_back(monkeypatch):
+    """the Krylov basis is an operand of pk_gram_f64 (at most 4096 columns).  A recurrence that would outgrow
+    it (rank 100: block 128, 32 blocks) must end as a breakdown — the subspace iteration takes over — not as an error
+    out of the kernel launcher.  The limit is lowered here so that the planted matrix hits it after four blocks."""
+    from polara_amd import solver
+    from polara_amd.synth import planted_csr
+    m = planted_csr(3000, 1200, 40, 12, levels=5, seed=11, min_items=6, max_items=200)
+    ops = NumpyOps()
+    A = ops.csr(m['indptr'].numpy(), m['indices'].numpy(), m['values'].numpy().astype(np.float64), m['shape'])
+    k = 12
+    _, s_ref, _, st_ref = svd_topk(ops, A, k, method='subspace')
+    b = st_ref['block']
+    monkeypatch.setattr(solver, 'MAX_KRYLOV_COLS', 4 * b)          # room for exactly four blocks: too few to converge
+    _, s, V, st = svd_topk(ops, A, k, method='lanczos')
+    assert st['converged'] and 'lanczos_fallback' in st and 'not converged in 4 blocks' in st['lanczos_fallback'], st
+    assert st.get('krylov_dim', 0) <= 4 * b
+    assert np.allclose(s.numpy(), s_ref.numpy(), rtol=1e-10)
+    monkeypatch.setattr(solver, 'MAX_KRYLOV_COLS', 3 * b)          # fewer than four blocks: no Krylov space at all
+    _, s3, _, st3 = svd_topk(ops, A, k, method='lanczos')
+    assert 'at most 3 blocks' in st3['lanczos_fallback'] and np.allclose(s3.numpy(), s_ref.numpy(), rtol=1e-10)
+
+
 def test_unconverged_build_raises_like_arpack():
     """a build that stops at max_outer without converging must not mark the model ready silently; the
     reference's svds raises ArpackNoConvergence (models.py:844)."""
