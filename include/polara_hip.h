@@ -45,6 +45,10 @@ const char *pk_last_error(void);
 int pk_version(void);
 /* number of visible HIP devices (>=1 required by every compute call); fills name of `device`. */
 int pk_device_info(int device, char *name, int name_len, int *cu_count, int64_t *hbm_bytes);
+/* Loads every code object of the library on the current device (the runtime would otherwise load each translation
+ * unit's at the first launch of one of its kernels — inside the caller's first build).  Called by pk_ctx_create and by
+ * the Python layer's HipOps(); idempotent, a few milliseconds once per process and device. */
+int pk_warm_up(void);
 
 /* ------------------------------------------------------------------------------------------
  * K1 / K4.  CSR x dense  (fp64 accumulate):   out[r, 0:nc] = sum_p vals[p] * X[indices[p], 0:nc]
@@ -378,6 +382,21 @@ int pk_rescore_topk_rows_list_f64(void *stream, int64_t n_rows, const int32_t *r
                              double v_row_norm_max,
                              int64_t *out_idx_dev, double *out_score_dev /* or NULL */, int32_t *flags_dev,
                              int32_t *flagged_list_dev, int32_t *flagged_count_dev, int32_t flagged_offset);
+/* The same with the items' own norm bounds: item_norm_dev[i] >= ||V_i|| (fp32, e.g. pk_row_norm_bound_f32) — the order of
+ * two neighbouring entries is then certified against cu (||V_i|| + ||V_i'||) instead of 2 cu max ||V||
+ * (cu = 2^-24 (e_err[u] + ||E'_u||)): fewer users to re-fold for the same proof.  NULL: pk_rescore_topk_rows_list_f64. */
+int pk_rescore_topk_rows_norms_f64(void *stream, int64_t n_rows, const int32_t *rows_dev,
+                             const int32_t *n_rows_dev, int64_t n_users, int64_t n_items,
+                             int32_t K, const double *V_dev, int64_t ldv,
+                             const float *V32_dev, int64_t ldv32,
+                             const double *E_dev, int64_t lde,
+                             const double *e_err_dev, int64_t e_err_ld, int32_t e_exact,
+                             const int64_t *seen_ptr_dev, int32_t KC, int32_t splits,
+                             const float *cand_score_dev, const int32_t *cand_idx_dev, int32_t topk,
+                             double v_row_norm_max,
+                             int64_t *out_idx_dev, double *out_score_dev, int32_t *flags_dev,
+                             int32_t *flagged_list_dev, int32_t *flagged_count_dev, int32_t flagged_offset,
+                             const float *item_norm_dev);
 int pk_zero_i32(void *stream, int32_t *p_dev, int32_t n);
 /* The re-do of flagged users without a host round trip: pk_flag_compact lists the users with (flags & mask) != 0
  * (list capacity n, *count_dev = list length), pk_fold_rows_f64 recomputes the listed rows of E = A_test V in fp64
@@ -388,6 +407,18 @@ int pk_flag_compact(void *stream, int64_t n, const int32_t *flags_dev, int32_t m
 int pk_fold_rows_f64(void *stream, int64_t cap, const int32_t *list_dev, const int32_t *count_dev, int64_t row_offset,
                      const int64_t *indptr_dev, const int32_t *indices_dev, const void *vals_dev, int val_kind,
                      const double *V_dev, int64_t ldv, int32_t K, double *E_dev, int64_t lde);
+
+/* The product restricted to FLAGGED rows: only the tasks of rows r with (row_flags_dev[r] & flag_mask) != 0 run, every
+ * other row of `out` is left alone.  The exact re-fold of the users an ids-only pass could not certify at the accuracy
+ * of its approximate fold-in (pk_rescore_topk_rows_list_f64 leaves the flags on the device): same plan, mapping and
+ * summation order as pk_spmm_csr_ex with an fp64 dense block, so a re-folded row has the bits of the exact product.
+ * Even nc and ldx, X 16-byte aligned (odd ranks: pk_fold_rows_f64). */
+int pk_spmm_csr_flagged_f64(void *stream, int64_t n_tasks, const int32_t *task_row_dev, const int64_t *task_begin_dev,
+                            const int64_t *task_end_dev, const int32_t *task_slot_dev, int64_t n_long,
+                            const int32_t *long_row_dev, const int32_t *long_slot_begin_dev,
+                            const int32_t *long_slot_end_dev, const int32_t *indices_dev, const void *vals_dev,
+                            int val_kind, const double *X_dev, int64_t ldx, int32_t nc, double *out_dev, int64_t ldo,
+                            double *partial_dev, int64_t x_rows, const int32_t *row_flags_dev, int32_t flag_mask);
 
 /* ------------------------------------------------------------------------------------------
  * K4q.  The approximate fold-in of an ids-only scoring pass against a PACKED image of the item factors

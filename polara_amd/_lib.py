@@ -19,6 +19,7 @@ _vp, _i32, _i64, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
 PROTOTYPES = {
     'pk_last_error': (C.c_char_p, []),
     'pk_version': (C.c_int, []),
+    'pk_warm_up': (C.c_int, []),
     'pk_device_info': (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(_i64)]),
     'pk_spmm_csr_f64': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, C.c_int,
                                   _vp, _i64, _i32, _vp, _i64, _vp]),
@@ -82,6 +83,8 @@ PROTOTYPES = {
                                       _i32, _f64, _vp, _vp, _vp]),
     'pk_flag_compact': (C.c_int, [_vp, _i64, _vp, _i32, _vp, _vp]),
     'pk_fold_rows_f64': (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, C.c_int, _vp, _i64, _i32, _vp, _i64]),
+    'pk_spmm_csr_flagged_f64': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _i64, _i32,
+                                          _vp, _i64, _vp, _i64, _vp, _i32]),
     'pk_q20_lanes': (_i32, [_i32]),
     'pk_q20_kappa': (_f64, [_i32]),
     'pk_q20_image_bytes': (_i64, [_i64, _i32]),
@@ -93,6 +96,8 @@ PROTOTYPES = {
                                            _vp, _vp, _i32, _f64, _vp, _vp, _vp]),
     'pk_rescore_topk_rows_list_f64': (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _i32, _i32,
                                            _vp, _vp, _i32, _f64, _vp, _vp, _vp, _vp, _vp, _i32]),
+    'pk_rescore_topk_rows_norms_f64': (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _i32, _i32,
+                                           _vp, _vp, _i32, _f64, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     'pk_zero_i32': (C.c_int, [_vp, _vp, _i32]),
     'pk_scatter_rows_i64': (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp]),
     'pk_map_ids_i64': (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp]),

@@ -534,3 +534,10 @@ extern "C" int pk_chol_rinv_f64(void *stream, int32_t n, const double *G_dev, in
     PK_CHECK_LAUNCH("chol_rinv_kernel");
     return PK_OK;
 }
+
+// eager load of this translation unit's code object (pk_warm_up, api.cpp): the runtime loads a code object at the first
+// launch of one of its kernels — or when a kernel's attributes are asked for, which costs no launch
+hipError_t pk_tu_load_dense() {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&gram_reduce_kernel));
+}

@@ -562,6 +562,12 @@ extern "C" int pk_ctx_create(int32_t device, pk_ctx **out) {
         pk_set_error("pk_ctx_create: cannot create a stream on device %d", device);
         return PK_E_LAUNCH;
     }
+    // every code object of the library is loaded now, not inside the first build of this context (api.cpp)
+    if (pk_warm_up() != PK_OK) {
+        (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return PK_E_LAUNCH;
+    }
     *out = ctx;
     return PK_OK;
 }
@@ -1820,4 +1826,11 @@ extern "C" int pk_hooi(pk_ctx *ctx, int64_t nnz, const int64_t *idx_host, const 
         for (int b = 0; b < r1; ++b)
             for (int c = 0; c < r2; ++c) core_out[((size_t)a * r1 + b) * r2 + c] = ss[(size_t)c] * vh[(size_t)c * r1 * r0 + (size_t)b * r0 + a];
     return PK_OK;
+}
+
+// eager load of this translation unit's code object (pk_warm_up, api.cpp): the runtime loads a code object at the first
+// launch of one of its kernels — or when a kernel's attributes are asked for, which costs no launch
+hipError_t pk_tu_load_driver() {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&transpose_small_kernel));
 }

@@ -660,3 +660,10 @@ extern "C" int pk_eigh_top_f64(void *stream, int32_t n, const double *S_dev, int
     PK_CHECK_LAUNCH("eigh_top_kernel");
     return PK_OK;
 }
+
+// eager load of this translation unit's code object (pk_warm_up, api.cpp): the runtime loads a code object at the first
+// launch of one of its kernels — or when a kernel's attributes are asked for, which costs no launch
+hipError_t pk_tu_load_eigh_top() {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&eigh_top_kernel));
+}

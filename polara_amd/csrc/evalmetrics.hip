@@ -207,3 +207,10 @@ extern "C" int pk_unique_count_i64(void *stream, int64_t n, const int64_t *ids_d
     PK_CHECK_LAUNCH("unique_count kernels");
     return PK_OK;
 }
+
+// eager load of this translation unit's code object (pk_warm_up, api.cpp): the runtime loads a code object at the first
+// launch of one of its kernels — or when a kernel's attributes are asked for, which costs no launch
+hipError_t pk_tu_load_evalmetrics() {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&eval_user_metrics_kernel));
+}

@@ -1024,3 +1024,10 @@ extern "C" int pk_row_plan_fill(void *stream, int64_t n_rows, const int64_t *ind
     PK_CHECK_LAUNCH("row plan fill kernel");
     return PK_OK;
 }
+
+// eager load of this translation unit's code object (pk_warm_up, api.cpp): the runtime loads a code object at the first
+// launch of one of its kernels — or when a kernel's attributes are asked for, which costs no launch
+hipError_t pk_tu_load_ingest() {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&scan_sums_kernel));
+}

@@ -194,7 +194,8 @@ __global__ __launch_bounds__(256) void rescore_topk_kernel(
     const int64_t *__restrict__ seen_ptr, int KC, int splits,
     const float *__restrict__ cand_score, const int32_t *__restrict__ cand_idx, int topk, double vmax,
     int64_t *__restrict__ out_idx, double *__restrict__ out_score, int32_t *__restrict__ flags,
-    int32_t *__restrict__ flagged_list, int32_t *__restrict__ flagged_count, int32_t flagged_offset) {
+    int32_t *__restrict__ flagged_list, int32_t *__restrict__ flagged_count, int32_t flagged_offset,
+    const float *__restrict__ item_norm) {
     constexpr int UPW = 64 / (SEG * LPC);
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -268,15 +269,26 @@ __global__ __launch_bounds__(256) void rescore_topk_kernel(
     // e_exact: the E rows given now ARE exact, but the candidates were selected by a sweep over the approximate
     // ones — only the bound on the non-candidates keeps a delta, there is nothing approximate left to order
     // scored against fl32(V): |sum_j E'_j (fl32(V_ij) - V_ij)| <= 2^-24 ||E'_u|| ||V_i|| on top of that
-    const double delta = (e_err ? e_err[urow * e_err_ld] * 5.9604644775390625e-08 * (1.0 + 1e-6) * vmax : 0.0) +
-                         (use32 ? enorm * 5.9604644775390625e-08 * (1.0 + 1e-6) * vmax : 0.0);
+    // item by item: |s'_i - s_i| <= ||E' - E|| ||V_i|| + 2^-24 ||E'|| ||V_i|| = cu * ||V_i||, so two neighbours of the list
+    // are in their exact order once they are further apart than cu (||V_i|| + ||V_i'||) — with the items' OWN norms
+    // (item_norm: fp32 upper bounds) where the caller has them, with the catalogue's largest norm otherwise.  The
+    // candidates of a user are rarely the catalogue's heaviest rows: their own norms certify about twice as many
+    // users as vmax does, which matters since the packed fold-in image (csrc/foldq.hip) made cu ~40 times larger.
+    const double cu = (e_err ? e_err[urow * e_err_ld] * 5.9604644775390625e-08 * (1.0 + 1e-6) : 0.0) +
+                      (use32 ? enorm * 5.9604644775390625e-08 * (1.0 + 1e-6) : 0.0);
+    const double delta = cu * vmax;
+    double d_k = delta;              // the k-th entry's own error bound (the threshold test below)
     if (delta > 0.0 && !e_exact) {
+        double d_me = delta;
+        if (item_norm && my_i != PK_IDX_NONE && my_i >= 0) d_me = cu * fmin(vmax, (double)item_norm[my_i] * (1.0 + 1e-6));
         const int nxt_lane = lane + LPC;
         const double s_next = (t + 1 < SEG) ? __shfl(my_s, nxt_lane & 63, 64) : -INFINITY;
-        const bool close = (t < topk) && !(my_s - s_next > 2.0 * delta);
+        const double d_next = (t + 1 < SEG) ? __shfl(d_me, nxt_lane & 63, 64) : delta;
+        const bool close = (t < topk) && !(my_s - s_next > d_me + d_next);
         const unsigned long long cb = __ballot(close);
         const unsigned long long seg_mask = (SEG * LPC == 64) ? ~0ull : (((1ull << (SEG * LPC)) - 1ull) << (ul * SEG * LPC));
         if (cb & seg_mask) flag |= 4;
+        d_k = __shfl(d_me, (ul * SEG + topk - 1) * LPC, 64);
     }
     if (n_items - n_seen < topk) {
         flag |= 2;  // seen items must re-enter the list: exact path
@@ -289,7 +301,8 @@ __global__ __launch_bounds__(256) void rescore_topk_kernel(
         // the candidate sweep orders scores that agree to 2^-16 relative arbitrarily (key-only flush sorts,
         // score.hip): a non-candidate may exceed the KC-th candidate by that much
         const double tau_cert = tau32 + fabs(tau32) * 3.0517578125e-05;
-        const double slack = e_exact ? delta : 2.0 * delta;
+        // the k-th entry's own error + what the approximate E can hide of an item the sweep left out (any norm up to vmax)
+        const double slack = e_exact ? delta : d_k + delta;
         if (bound > 0.0 && !(s_k - tau_cert > bound + slack))
             flag |= (!e_exact && delta > 0.0 && s_k - tau_cert > bound + delta) ? 4 : 1;
     }
@@ -306,7 +319,7 @@ __global__ __launch_bounds__(256) void rescore_topk_kernel(
     }
 }
 
-extern "C" int pk_rescore_topk_rows_list_f64(void *stream, int64_t n_rows, const int32_t *rows_dev,
+extern "C" int pk_rescore_topk_rows_norms_f64(void *stream, int64_t n_rows, const int32_t *rows_dev,
                                              const int32_t *n_rows_dev, int64_t n_users,
                                              int64_t n_items, int32_t K, const double *V_dev, int64_t ldv,
                                              const float *V32_dev, int64_t ldv32,
@@ -316,7 +329,7 @@ extern "C" int pk_rescore_topk_rows_list_f64(void *stream, int64_t n_rows, const
                                              const float *cand_score_dev, const int32_t *cand_idx_dev, int32_t topk,
                                              double v_row_norm_max, int64_t *out_idx_dev, double *out_score_dev,
                                              int32_t *flags_dev, int32_t *flagged_list_dev, int32_t *flagged_count_dev,
-                                             int32_t flagged_offset) {
+                                             int32_t flagged_offset, const float *item_norm_dev) {
     PK_REQUIRE((flagged_list_dev == nullptr) == (flagged_count_dev == nullptr), "pk_rescore_topk_f64: flagged list without its counter");
     PK_REQUIRE(n_users >= 1 && K >= 1 && K <= 256 && ldv >= K && lde >= K, "pk_rescore_topk_f64: bad sizes");
     PK_REQUIRE(n_rows >= 0 && n_rows <= n_users, "pk_rescore_topk_f64: bad row count");
@@ -334,7 +347,7 @@ extern "C" int pk_rescore_topk_rows_list_f64(void *stream, int64_t n_rows, const
     hipLaunchKernelGGL((rescore_topk_kernel<SEGV, LPCV, S4>), dim3((unsigned)pk_ceil_div(n_rows, 4 * (64 / (SEGV * LPCV)))), \
                        dim3(256), 0, pk_stream(stream), n_rows, rows_dev, n_rows_dev, n_users, n_items, K, V_dev, ldv, V32_dev, ldv32, E_dev, lde, \
                        e_err_dev, e_err_ld, e_exact, seen_ptr_dev, KC, splits, cand_score_dev, cand_idx_dev, topk, v_row_norm_max,   \
-                       out_idx_dev, out_score_dev, flags_dev, flagged_list_dev, flagged_count_dev, flagged_offset)
+                       out_idx_dev, out_score_dev, flags_dev, flagged_list_dev, flagged_count_dev, flagged_offset, item_norm_dev)
     if (seg == 16) {
         if (lpc_req == 1) PK_RESCORE(16, 1);
         else if (lpc_req == 4) PK_RESCORE(16, 4);
@@ -352,6 +365,23 @@ extern "C" int pk_rescore_topk_rows_list_f64(void *stream, int64_t n_rows, const
 #undef PK_RESCORE_X
     PK_CHECK_LAUNCH("rescore_topk_kernel");
     return PK_OK;
+}
+
+extern "C" int pk_rescore_topk_rows_list_f64(void *stream, int64_t n_rows, const int32_t *rows_dev,
+                                             const int32_t *n_rows_dev, int64_t n_users,
+                                             int64_t n_items, int32_t K, const double *V_dev, int64_t ldv,
+                                             const float *V32_dev, int64_t ldv32,
+                                             const double *E_dev, int64_t lde, const double *e_err_dev,
+                                             int64_t e_err_ld, int32_t e_exact,
+                                             const int64_t *seen_ptr_dev, int32_t KC, int32_t splits,
+                                             const float *cand_score_dev, const int32_t *cand_idx_dev, int32_t topk,
+                                             double v_row_norm_max, int64_t *out_idx_dev, double *out_score_dev,
+                                             int32_t *flags_dev, int32_t *flagged_list_dev, int32_t *flagged_count_dev,
+                                             int32_t flagged_offset) {
+    return pk_rescore_topk_rows_norms_f64(stream, n_rows, rows_dev, n_rows_dev, n_users, n_items, K, V_dev, ldv, V32_dev, ldv32, E_dev,
+                                          lde, e_err_dev, e_err_ld, e_exact, seen_ptr_dev, KC, splits, cand_score_dev, cand_idx_dev, topk,
+                                          v_row_norm_max, out_idx_dev, out_score_dev, flags_dev, flagged_list_dev, flagged_count_dev,
+                                          flagged_offset, nullptr);
 }
 
 extern "C" int pk_rescore_topk_rows_f64(void *stream, int64_t n_rows, const int32_t *rows_dev,
@@ -1063,4 +1093,11 @@ extern "C" int pk_eval_ranks(void *stream, int64_t n_holdout, const int64_t *rec
                        n_holdout, recs_dev, topk, hold_row_dev, hold_item_dev, rank_out_dev);
     PK_CHECK_LAUNCH("eval_ranks_kernel");
     return PK_OK;
+}
+
+// eager load of this translation unit's code object (pk_warm_up, api.cpp): the runtime loads a code object at the first
+// launch of one of its kernels — or when a kernel's attributes are asked for, which costs no launch
+hipError_t pk_tu_load_rescore() {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&zero_i32_kernel));
 }

@@ -2368,3 +2368,10 @@ extern "C" int pk_score_two_phase_f32(void *stream, int64_t n_users, int64_t n_i
     PK_CHECK_LAUNCH("merge_candidates_kernel");
     return PK_OK;
 }
+
+// eager load of this translation unit's code object (pk_warm_up, api.cpp): the runtime loads a code object at the first
+// launch of one of its kernels — or when a kernel's attributes are asked for, which costs no launch
+hipError_t pk_tu_load_score() {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&pack_frag_kernel));
+}

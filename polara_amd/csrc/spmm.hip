@@ -138,12 +138,16 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(
 // offset of a row piece is one full-rate v_mad_u32_u24 on top of the UNIFORM base pointer, so the loads take the
 // scalar-base + 32-bit-offset form.  The 64-bit form costs two quarter-rate 32-bit multiplies, a 64-bit multiply-add
 // and three more VALU instructions per gathered row — 12 of the ~33 SIMD cycles a row costs in the fold-in.
-template <typename VT, int GROUPS, typename XT, bool ACC, bool OFF32>
+// PRED: only the tasks of rows whose flag word intersects `flag_mask` run (row_flags[row]; every other wave leaves at
+// once): the exact re-fold of the users a scoring pass could not certify — the flags are where the re-scoring kernel
+// left them, on the device, and the plan, the mapping and the summation order are those of the full product.
+template <typename VT, int GROUPS, typename XT, bool ACC, bool OFF32, bool PRED = false>
 __global__ __launch_bounds__(256) void spmm_csr_groups_kernel(
     int64_t n_tasks, const int32_t *__restrict__ task_row, const int64_t *__restrict__ task_begin,
     const int64_t *__restrict__ task_end, const int32_t *__restrict__ task_slot,
     const int32_t *__restrict__ indices, const VT *__restrict__ vals, const XT *__restrict__ X,
-    int64_t ldx, int nc, double *__restrict__ out, int64_t ldo, double *__restrict__ partial, int64_t row_base) {
+    int64_t ldx, int nc, double *__restrict__ out, int64_t ldo, double *__restrict__ partial, int64_t row_base,
+    const int32_t *__restrict__ row_flags = nullptr, int flag_mask = 0) {
     constexpr bool XF = sizeof(XT) == 4;
     constexpr int LG = 64 / GROUPS;
     // wave steps per register set (two sets in flight); an fp32 row piece is one float4 per lane and step
@@ -158,6 +162,9 @@ __global__ __launch_bounds__(256) void spmm_csr_groups_kernel(
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t task = (int64_t)blockIdx.x * 4 + wave;
     if (task >= n_tasks) return;
+    if constexpr (PRED) {
+        if (!(row_flags[task_row[task]] & flag_mask)) return;
+    }
     const int64_t p0 = task_begin[task];
     const int n = (int)(task_end[task] - p0);
     if constexpr (ACC) {
@@ -437,9 +444,11 @@ __global__ __launch_bounds__(1024) void fold_in_head_kernel(
 __global__ __launch_bounds__(256) void spmm_fixup_kernel(
     int64_t n_long, const int32_t *__restrict__ long_row, const int32_t *__restrict__ slot_begin,
     const int32_t *__restrict__ slot_end, const double *__restrict__ partial, int nc,
-    double *__restrict__ out, int64_t ldo, int64_t row_base, int accumulate) {
+    double *__restrict__ out, int64_t ldo, int64_t row_base, int accumulate,
+    const int32_t *__restrict__ row_flags = nullptr, int flag_mask = 0) {
     const int64_t r = blockIdx.x;
     if (r >= n_long) return;
+    if (row_flags && !(row_flags[long_row[r]] & flag_mask)) return;     // (flagged product: this row's tasks did not run)
     const int s0 = slot_begin[r], s1 = slot_end[r];
     double *dst = out + ((int64_t)long_row[r] - row_base) * ldo;
     for (int c = threadIdx.x; c < nc; c += blockDim.x) {
@@ -621,4 +630,62 @@ extern "C" int pk_spmm_csr_f64(void *stream, int64_t n_tasks, const int32_t *tas
     return pk_spmm_csr_ex(stream, n_tasks, task_row_dev, task_begin_dev, task_end_dev, task_slot_dev, n_long,
                           long_row_dev, long_slot_begin_dev, long_slot_end_dev, indices_dev, vals_dev, val_kind, X_dev,
                           PK_VAL_F64, ldx, nc, out_dev, ldo, partial_dev, 0, 0, 0);
+}
+
+// ---- the product restricted to flagged rows (fp64 dense block) ---------------------------------------------------------
+template <typename VT>
+static int launch_spmm_flagged(hipStream_t st, int64_t n_tasks, const int32_t *task_row, const int64_t *task_begin,
+                               const int64_t *task_end, const int32_t *task_slot, const int32_t *indices, const void *vals,
+                               const double *X, int64_t ldx, int nc, double *out, int64_t ldo, double *partial, int64_t x_rows,
+                               const int32_t *row_flags, int flag_mask) {
+    dim3 grid((unsigned)pk_ceil_div(n_tasks, 4)), block(256);
+    const VT *v = static_cast<const VT *>(vals);
+    const bool off32 = x_rows > 0 && x_rows < (1 << 24) && ldx * 8 < (1 << 24) && x_rows * ldx * 8 < ((int64_t)1 << 32);
+#define PK_SPMM_LAUNCH_P(G, O)                                                                                          \
+    hipLaunchKernelGGL((spmm_csr_groups_kernel<VT, G, double, false, O, true>), grid, block, 0, st, n_tasks, task_row,  \
+                       task_begin, task_end, task_slot, indices, v, X, ldx, nc, out, ldo, partial, (int64_t)0, row_flags, flag_mask)
+#define PK_SPMM_GROUPS_P(G) do { if (off32) PK_SPMM_LAUNCH_P(G, true); else PK_SPMM_LAUNCH_P(G, false); } while (0)
+    if (nc <= 16) PK_SPMM_GROUPS_P(16);
+    else if (nc <= 32) PK_SPMM_GROUPS_P(8);
+    else if (nc <= 64) PK_SPMM_GROUPS_P(4);
+    else if (nc <= 128) PK_SPMM_GROUPS_P(2);
+    else PK_SPMM_GROUPS_P(1);
+#undef PK_SPMM_GROUPS_P
+#undef PK_SPMM_LAUNCH_P
+    return PK_OK;
+}
+
+extern "C" int pk_spmm_csr_flagged_f64(void *stream, int64_t n_tasks, const int32_t *task_row_dev, const int64_t *task_begin_dev,
+                                       const int64_t *task_end_dev, const int32_t *task_slot_dev, int64_t n_long,
+                                       const int32_t *long_row_dev, const int32_t *long_slot_begin_dev,
+                                       const int32_t *long_slot_end_dev, const int32_t *indices_dev, const void *vals_dev,
+                                       int val_kind, const double *X_dev, int64_t ldx, int32_t nc, double *out_dev, int64_t ldo,
+                                       double *partial_dev, int64_t x_rows, const int32_t *row_flags_dev, int32_t flag_mask) {
+    PK_REQUIRE(n_tasks >= 0 && nc >= 2 && nc <= 256 && nc % 2 == 0, "pk_spmm_csr_flagged_f64: nc=%d (even, 2..256)", nc);
+    PK_REQUIRE(ldo >= nc && ldx >= nc && ldx % 2 == 0 && (((uintptr_t)X_dev) % 16) == 0, "pk_spmm_csr_flagged_f64: ldx even, X 16-byte aligned");
+    PK_REQUIRE(row_flags_dev != nullptr, "pk_spmm_csr_flagged_f64: row flags required");
+    PK_REQUIRE(n_long == 0 || partial_dev != nullptr, "pk_spmm_csr_flagged_f64: partial buffer required");
+    PK_REQUIRE(val_kind == PK_VAL_F32 || val_kind == PK_VAL_F64, "pk_spmm_csr_flagged_f64: bad val_kind %d", val_kind);
+    if (n_tasks == 0) return PK_OK;
+    hipStream_t st = pk_stream(stream);
+    if (val_kind == PK_VAL_F32)
+        launch_spmm_flagged<float>(st, n_tasks, task_row_dev, task_begin_dev, task_end_dev, task_slot_dev, indices_dev, vals_dev, X_dev,
+                                   ldx, nc, out_dev, ldo, partial_dev, x_rows, row_flags_dev, flag_mask);
+    else
+        launch_spmm_flagged<double>(st, n_tasks, task_row_dev, task_begin_dev, task_end_dev, task_slot_dev, indices_dev, vals_dev, X_dev,
+                                    ldx, nc, out_dev, ldo, partial_dev, x_rows, row_flags_dev, flag_mask);
+    PK_CHECK_LAUNCH("spmm_csr_groups_kernel (flagged rows)");
+    if (n_long > 0) {
+        hipLaunchKernelGGL(spmm_fixup_kernel, dim3((unsigned)n_long), dim3(256), 0, st, n_long, long_row_dev, long_slot_begin_dev,
+                           long_slot_end_dev, partial_dev, nc, out_dev, ldo, (int64_t)0, 0, row_flags_dev, flag_mask);
+        PK_CHECK_LAUNCH("spmm_fixup_kernel (flagged rows)");
+    }
+    return PK_OK;
+}
+
+// eager load of this translation unit's code object (pk_warm_up, api.cpp): the runtime loads a code object at the first
+// launch of one of its kernels — or when a kernel's attributes are asked for, which costs no launch
+hipError_t pk_tu_load_spmm() {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&spmm_fixup_kernel));
 }

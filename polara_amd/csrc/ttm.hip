@@ -187,3 +187,10 @@ extern "C" int pk_tucker_predict_f64(void *stream, int64_t n, const int64_t *use
     PK_CHECK_LAUNCH("tucker_predict_kernel");
     return PK_OK;
 }
+
+// eager load of this translation unit's code object (pk_warm_up, api.cpp): the runtime loads a code object at the first
+// launch of one of its kernels — or when a kernel's attributes are asked for, which costs no launch
+hipError_t pk_tu_load_ttm() {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&ttm_fixup_kernel));
+}

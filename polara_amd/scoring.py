@@ -41,7 +41,7 @@ class FactorImage:
                              'works in (rescale the factors)' % self.vmax)
         self.Q20 = None
         if not self.fused:
-            self.tile_bound = self.V32x = None
+            self.tile_bound = self.V32x = self.vnorm = None
             self.Kx = self.K
             return
         self.tile_bound = ops.tile_norm_bound(self.V)   # exact pruning bound of the candidate sweep
@@ -55,7 +55,8 @@ class FactorImage:
         ld = -(-self.Kx // 32) * 32 if self.Kx > 16 else (4 if self.Kx <= 4 else 8 if self.Kx <= 8 else 16)
         self.V32x = torch.zeros(self.n_items, ld, dtype=torch.float32, device=self.V.device)[:, :self.Kx]
         self.V32x[:, :self.K] = self.V.to(torch.float32)
-        self.V32x[:, self.K] = ops.row_norm_bound(self.V)
+        self.vnorm = ops.row_norm_bound(self.V)       # fp32 upper bounds of the rows' norms (fold-in weight column, certification)
+        self.V32x[:, self.K] = self.vnorm
         # packed image for the approximate fold-in (csrc/foldq.hip): 20-bit block fixed point, half the bytes and lines
         # per gathered entry of the fp32 image; its own error weights D_j (exact, from the bits written) take the
         # place of the norm column, so column K of the product is again a w_u with ||E' - E|| <= 2^-24 w_u
@@ -234,7 +235,7 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
             first = to_final
         ops.rescore_topk(factors.V, Eb, n_items, sp, KC, cs, ci, topk, factors.vmax, want_scores=True,
                          splits=splits, out=outs, e_err=w, v32=factors.V32x if approx_fold_in else None, **(
-                             {'flagged': first} if fused_lists else {}))
+                             {'flagged': first, 'item_norm': factors.vnorm if approx_fold_in else None} if fused_lists else {}))
         if approx_fold_in:
             # every flagged user — order not certified at the accuracy of the approximate fold-in (bit 4), or
             # bound for the exact-row kernel anyway (bits 1, 2), which must not see an approximate E — gets its
@@ -242,7 +243,13 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
             # device (no host round trip inside the pass).  Who is STILL flagged after that goes to the final list.
             if not fused_lists:
                 lst, cnt = ops.flag_compact(outs[2], 7)
-            ops.fold_rows(T, lst, cnt, factors.V, Ex, row_offset=u0)
+            if hasattr(ops, 'spmm_flagged') and ops.spmm_flagged_ok(factors.V):
+                # the full product's plan with every wave of an unflagged row leaving at once: thousands of flagged users
+                # (the packed image's weights are ~40x an fp32 rounding) cost what their entries cost, not a
+                # workgroup-with-barriers per row (fold_rows: 86 us for 3 320 users of an ML-20M-shaped pass)
+                ops.spmm_flagged(T, factors.V, Ex, flags, 7, rows=(u0, u1))
+            else:
+                ops.fold_rows(T, lst, cnt, factors.V, Ex, row_offset=u0)
             ops.rescore_topk(factors.V, Eb, n_items, sp, KC, cs, ci, topk, factors.vmax, want_scores=True,
                              splits=splits, out=outs, rows=lst, n_rows_dev=cnt, e_err=w, e_exact=True, **(
                                  {'flagged': to_final} if fused_lists else {}))

@@ -14,8 +14,18 @@ def lanes(K):
     return 0
 
 
+def steps(L):
+    """entries a lane multiplies in fp32 before its partial sums go to fp64 (csrc/foldq.hip: q20_steps)"""
+    return 4 if L >= 8 else (2 if L == 4 else 1)
+
+
 def kappa(K):
-    return np.sqrt(float(K)) * 2048.0 * 1.08 / 126.0
+    return np.sqrt(float(K) + 32.0) * (2112.0 + (steps(lanes(K)) + 2.0) * 128.0) * 1.03 / 126.0
+
+
+def f32(x):
+    """fp32 rounding of int32 windows held in float64 / int64 arrays (what v_cvt_f32_i32 does), back in float64"""
+    return np.asarray(x, dtype=np.int64).astype(np.int32).astype(np.float32).astype(np.float64)
 
 
 def bracket(j):
@@ -50,7 +60,7 @@ def decode(img, tab, K):
     n = img.shape[0]
     L = lanes(K)
     d = np.ascontiguousarray(img).view(np.uint32).reshape(n, L, 4)
-    w = _windows(d)
+    w = f32(_windows(d))
     s = tab[bracket(np.arange(n))]
     out = np.zeros((n, K + 1))
     for l in range(L):
@@ -76,16 +86,18 @@ def encode(V):
     s = tab[bracket(np.arange(n))]
     inv = np.where(s > 0, 1.0 / np.where(s > 0, s, 1.0), 0.0)
     p = np.zeros((n, L, 6), dtype=np.int64)
-    sq = np.zeros(n)
+    sq = np.zeros(n)           # squared quantisation error (real units)
+    mag = np.zeros(n)          # squared magnitude of what the kernel multiplies (window units)
     for l in range(L):
         g = np.zeros(n)
         for t in range(5, -1, -1):
             c = 6 * l + t
             v = V[:, c] if c < K else np.zeros(n)
             f = np.clip(np.rint((v * inv - g) / 4096.0), -524288.0, 524287.0)
-            window = f * 4096.0 + g
+            window = f32(f * 4096.0 + g)
             if c < K:
                 sq += (v - window * s) ** 2
+                mag += window ** 2
             p[:, l, t] = f.astype(np.int64) & 0xFFFFF
             g = (p[:, l, t] >> 8).astype(np.float64)
     G = ((p[:, :, 0] << 4) | (p[:, :, 1] >> 16)).astype(np.float64)
@@ -101,16 +113,22 @@ def encode(V):
         lo2 = (-2147483648.0 + G2) / 65536.0
         lo1 = (-2147483648.0 + G1) / 256.0 + lo2
         d0 = np.clip(np.floor((X - G0 - lo1) / 16777216.0), -128.0, 127.0)
-        R0 = X - (d0 * 16777216.0 + G0)
+        w0 = f32(d0 * 16777216.0 + G0)
+        R0 = X - w0
         d1 = np.clip(np.floor(((R0 - lo2) * 256.0 - G1) / 16777216.0), -128.0, 127.0)
-        R1 = R0 - (d1 * 16777216.0 + G1) / 256.0
+        w1 = f32(d1 * 16777216.0 + G1)
+        R1 = R0 - w1 / 256.0
         d2 = np.clip(np.rint((R1 * 65536.0 - G2) / 16777216.0), -128.0, 127.0)
-        rep = (d0 * 16777216.0 + G0) + (d1 * 16777216.0 + G1) / 256.0 + (d2 * 16777216.0 + G2) / 65536.0    # exact
+        w2 = f32(d2 * 16777216.0 + G2)
+        rep = w0 + w1 / 256.0 + w2 / 65536.0
         dig[:, 3 * e], dig[:, 3 * e + 1], dig[:, 3 * e + 2] = d0, d1, d2
         sq += (xv - 2.0 * rep * s) ** 2
-    D = np.sqrt(sq) * (1.0 + 2.0 ** -9) * 16777216.0
+        mag += (2.0 * (np.abs(w0) + np.abs(w1) / 256.0 + np.abs(w2) / 65536.0)) ** 2
+    D = (np.sqrt(sq) * 16777216.0 + (steps(L) + 2.0) * np.sqrt(mag) * s) * (1.0 + 2.0 ** -9)
     Y = np.where(s > 0, D / np.where(s > 0, s * kappa(K), 1.0), 0.0)
-    dw = np.where(s > 0, np.ceil((Y - G[:, L - 1]) / 16777216.0), 0.0)
+    GL = G[:, L - 1]
+    dw = np.where(s > 0, np.ceil((Y - GL) / 16777216.0), 0.0)
+    dw = np.where((s > 0) & (dw <= 127.0) & (f32(np.clip(dw, -128, 127) * 16777216.0 + GL) < Y), dw + 1.0, dw)
     assert dw.max() <= 127.0, 'kappa too small'
     dig[:, L - 1] = np.maximum(dw, -128.0)
     db = dig.astype(np.int64) & 0xFF

@@ -63,7 +63,7 @@ def main(src, dst):
                 agg[k][0] += float(r['Counter_Value'])
                 agg[k][1].add(r.get('Dispatch_Id', len(agg[k][1])))
             lines.append('%-72s %-22s %10s %18s %18s' % ('kernel', 'counter', 'launches', 'sum', 'per_launch'))
-            ours = ('score_', 'spmm_', 'rescore_', 'eigh_', 'gram_', 'tsmm_', 'ttm_', 'pack_', 'axpby', 'resid', 'exact')
+            ours = ('score_', 'spmm_', 'rescore_', 'eigh_', 'gram_', 'tsmm_', 'ttm_', 'pack_', 'axpby', 'resid', 'exact', 'fold_', 'q20_', 'lanczos', 'chol')
             mine = {k: v for k, v in agg.items() if any(o in k[0] for o in ours)}
             for (kn, cn), (tot, disp) in sorted(mine.items()):
                 n = max(len(disp), 1)
