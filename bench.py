@@ -171,7 +171,7 @@ def pmc_traffic(tag):
                     parts = line.split()
                     found.append((line, int(parts[-3]), float(parts[-2]) * 1024.0, float(parts[-1]) * 1024.0))   # launches, sum, per launch (KB -> B)
             return commit, found
-        rnd = next((r for r in ('r04', 'r03', 'r02') if os.path.exists(os.path.join(ROOT, 'profiles', '%s_%s_pmc_fetch_size.txt' % (r, tag)))), 'r02')
+        rnd = next((r for r in ('r05', 'r04', 'r03', 'r02') if os.path.exists(os.path.join(ROOT, 'profiles', '%s_%s_pmc_fetch_size.txt' % (r, tag)))), 'r02')
         out['round'] = rnd
         cf, fetch = rows('%s_%s_pmc_fetch_size.txt' % (rnd, tag))
         _, write = rows('%s_%s_pmc_write_size.txt' % (rnd, tag))
@@ -183,6 +183,10 @@ def pmc_traffic(tag):
         bf, bw = pick(fetch, is_build_spmm), pick(write, is_build_spmm)
         if bf and bw:
             out['spmm_total'] = 2.0 * sum(r[2] for r in bf) + sum(r[2] for r in bw)
+        is_fold = lambda l: 'fold_q20_kernel' in l
+        ff, fw = pick(fetch, is_fold), pick(write, is_fold)
+        if ff and fw:
+            out['fold'] = 2.0 * ff[0][3] + fw[0][3]          # per launch
         out['commit'] = cf
         # a profile describes the kernels of the tree it was taken in: compare the hashes it carries with the sources
         # here.  No hashes (profiles of rounds 2-3) or a different score.hip / spmm.hip: STALE — the counters then do not
@@ -193,6 +197,7 @@ def pmc_traffic(tag):
         now = kernel_source_hashes(ROOT)
         out['stale_score'] = hashes.get('score.hip') != now.get('score.hip')
         out['stale_spmm'] = hashes.get('spmm.hip') != now.get('spmm.hip')
+        out['stale_fold'] = hashes.get('foldq.hip') != now.get('foldq.hip')
     except (OSError, ValueError, IndexError):
         pass
     return out
@@ -218,7 +223,11 @@ class Bench:
             self.comm = NoComm()
         from polara_amd.ops import HipOps
         self.dev = 'cuda:%d' % torch.cuda.current_device()
-        self.ops = HipOps(self.dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        self.ops = HipOps(self.dev)        # loads the library's code objects and runs the miniature pipeline (ops.warm_up)
+        torch.cuda.synchronize()
+        self.ops_create_s = time.perf_counter() - t0
         self.dist_info = {'world': self.world, 'backend': 'none (one process)', 'device': torch.cuda.get_device_name(self.dev)}
         if self.world > 1:
             import torch.distributed as tdist
@@ -682,6 +691,24 @@ class Bench:
                     'bytes_total': float(sum(spmm_bytes)),
                     'gather_GBps': float(sum(m[2] * m[3] * float(m[5]) for _, _, m in st['spmm_ev']) / (sum(spmm_ms) * 1e-3) / 1e9),
                     'gather_note': 'nnz*nc*8 bytes of dense-row gathers per launch / time: the traffic that actually bounds this kernel'}
+            fold_name = 'fold_q20' if ms.get('fold_q20') else 'spmm'
+            fold_ms = ms.get(fold_name)
+            if fold_ms:
+                # the fold-in E' = A_test * image(V): HBM-bound by SURVEY §8(d)'s reckoning — the CSR stream of the test rows,
+                # the image once, the E rows out — and in practice bound by the latency of its row gathers
+                T = st['A']
+                vb = T.values.element_size()
+                packed = fold_name == 'fold_q20'
+                row_bytes = int(st['F'].Q20[0].shape[1]) if packed else int(st['F'].V32x.stride(0) * 4)
+                alg = float(T.nnz * (4 + vb) + 8 * (T.shape[0] + 1) + n_items * row_bytes + T.shape[0] * st['F'].Kx * 8)
+                gbps = alg / (fold_ms * 1e-3) / 1e9
+                out['roofline_foldin'] = {
+                    'kernel': 'fold_q20_kernel' if packed else 'spmm_csr_groups_kernel<float, 4, float>', 'bound': 'hbm',
+                    'achieved': gbps, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'frac': gbps / PEAK_HBM_GBPS, 'traffic': None,
+                    'avg_ms': fold_ms, 'algorithmic_bytes': alg, 'image_row_bytes': row_bytes,
+                    'gather_GBps': float(T.nnz) * row_bytes / (fold_ms * 1e-3) / 1e9,
+                    'refolded_users': stats.get('refolded_users'),
+                    'refold_ms': (ms.get('spmm_flagged') or ms.get('fold_rows') or 0.0) + (ms.get('rescore_topk_refolded') or 0.0)}
             if cold_build is not None:
                 out['build_cold'] = cold_build
             if cpu and comm.world == 1:
@@ -933,6 +960,14 @@ def compact_line(head, n_gpus, steps, warmup, adversarial=None, scale=1.0):
         out['roofline'] = {k: (_r(rf.get(k)) if not isinstance(rf.get(k), str) else rf.get(k)) for k in
                            ('kernel', 'bound', 'dtype', 'achieved', 'peak', 'unit', 'frac', 'avg_ms', 'launches_per_pass',
                             'swept_fraction', 'traffic', 'traffic_commit', 'stale') if k in rf or k == 'traffic'}
+    rfo = head.get('roofline_foldin')
+    if rfo:
+        out['roofline_foldin'] = {k: (_r(rfo.get(k)) if not isinstance(rfo.get(k), str) else rfo.get(k)) for k in
+                                  ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'avg_ms', 'traffic', 'refolded_users',
+                                   'refold_ms', 'traffic_commit', 'stale') if k in rfo or k == 'traffic'}
+    cold = head.get('cold')
+    if cold:
+        out['cold'] = {k: _r(v) for k, v in cold.items()}
     rb = head.get('roofline_build')
     if rb:
         out['roofline_build'] = {k: (_r(rb.get(k)) if not isinstance(rb.get(k), str) else rb.get(k)) for k in
@@ -948,7 +983,7 @@ def compact_line(head, n_gpus, steps, warmup, adversarial=None, scale=1.0):
             'speedup_build': _r(cb.get('speedup_build')), 'speedup': _r(cb.get('speedup_build_plus_score'))}
     line = json.dumps(out, separators=(',', ':'))
     if len(line) > MAX_LINE_BYTES:        # never again an unparseable record: drop the optional blocks, loudest last
-        for k in ('build', 'roofline_build', 'latency_ms_per_pass', 'dist'):
+        for k in ('build', 'roofline_build', 'latency_ms_per_pass', 'dist', 'roofline_foldin'):
             out.pop(k, None)
             line = json.dumps(out, separators=(',', ':'))
             if len(line) <= MAX_LINE_BYTES:
@@ -981,12 +1016,27 @@ def main():
     c = B.generate(args.workload, args.scale)
     gen_s = c['gen_s']
     # cold build: the first heavy GPU work of the process (allocator growth, page tables, code objects), itemised
-    _, cold = B.build(c, headline_rank, not args.no_norm_order)
+    st_cold, cold = B.build(c, headline_rank, not args.no_norm_order)
+    # ... and the first scoring pass of the process on it (host wall time, device idle before and after)
+    from polara_amd import scoring as _scoring, runtime_info as _runtime_info
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    _scoring.recommend(B.ops, st_cold['F'], st_cold['A'], headline_topk, True, prune=prune)
+    torch.cuda.synchronize()
+    first_pass_ms = 1e3 * (time.perf_counter() - t0)
+    del st_cold
     torch.cuda.empty_cache()
     full_size = comm.world == 1 and args.scale == 1.0
     head = B.measure(c, args.workload, headline_rank, headline_topk, args.steps, args.warmup, prune=prune,
                      norm_order=not args.no_norm_order, cpu=not args.no_cpu_baseline, cpu_users=args.cpu_users,
                      cold_build=cold, cpu_build_whole=full_size and args.workload in ('ml20m', 'ml1m'))
+    if comm.rank == 0:
+        # what a process pays ONCE: creating the operator set (code objects + the miniature pipeline of ops.warm_up), its
+        # first build and its first pass — next to the warm figures of the line (`build_s`, `ms_per_step`)
+        rt = _runtime_info()
+        head['cold'] = {'ops_create_s': B.ops_create_s, 'warm_up_s': B.ops.warm_up_s, 'build_cold_s': cold['total_s'],
+                        'solver_cold_s': cold['solver_s'], 'first_pass_ms': first_pass_ms, 'hw_queues': rt['hw_queues'],
+                        'hw_queues_in_time': rt['in_time']}
     subs, adversarial = {}, {}
     if args.scale == 1.0 and not args.only_headline and args.workload == 'ml20m' and not args.rank:
         # BASELINE.json configs[2] as written (rank 100, top-20) rides in the line at every N next to the metric's rank 50
@@ -1045,6 +1095,11 @@ def main():
     if 'roofline_build' in head and traffic:
         head['roofline_build']['traffic_commit'] = traffic.get('commit')
         head['roofline_build']['stale'] = bool(traffic.get('stale_spmm', True))
+    if 'roofline_foldin' in head and traffic and head['roofline_foldin']['kernel'] == 'fold_q20_kernel':
+        head['roofline_foldin']['traffic_commit'] = traffic.get('commit')
+        head['roofline_foldin']['stale'] = bool(traffic.get('stale_fold', True))
+        if 'fold' in traffic and not traffic.get('stale_fold', True):
+            head['roofline_foldin']['traffic'] = traffic['fold']
     if 'roofline' in head and 'score' in traffic and not traffic.get('stale_score', True):
         head['roofline']['traffic'] = traffic['score']       # per LAUNCH, like `achieved`
         head['roofline']['traffic_note'] = ('HBM/fabric bytes per launch = 2*FETCH_SIZE + WRITE_SIZE of a separate rocprofv3 --pmc run of '

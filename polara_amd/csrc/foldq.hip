@@ -290,14 +290,28 @@ extern "C" int pk_q20_decode_f64(void *stream, int64_t n, int32_t K, const void 
 }
 
 // ---------------------------------------------------------------------------------------------- the fold-in
-template <int J>
-__device__ __forceinline__ void q20_group_sum(double (&acc)[7]) {
-#pragma unroll
-    for (int t = 0; t < 7; ++t) acc[t] += pk_lane_xor<J>(acc[t]);
+// ---- the sum over the lane groups: recursive halving, not a butterfly.
+// v_permlane32_swap exchanges the upper half of one register with the lower half of another: after swap(x, y) the first
+// register holds [x.low, y.low] and the second [x.high, y.high], so ONE addition leaves the pair sum of x in the lower 32
+// lanes and the pair sum of y in the upper 32.  Seven partial sums per lane become four (x, y) = (slot k, slot k + 4), then
+// two with v_permlane16_swap ((k, k + 2)); the 8 / 4 / 2-lane distances that are left go through DPP butterflies on those
+// two values.  26 instructions where the butterfly over all seven sums took ~160 — a third of this kernel's VALU work is
+// its per-task prologue and epilogue (SQ_INSTS_VALU: 104 M per ML-20M-shaped launch, 2.5 M wave steps of ~24).
+__device__ __forceinline__ double q20_swap_add32(double x, double y) {
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ double q20_swap_add16(double x, double y) {
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
 }
 
 typedef float pk_f2 __attribute__((ext_vector_type(2)));
 
+// (Measured and not kept, round 5: the fp64 accumulators in LDS with the register allocation held to 6 or 8 waves per SIMD
+// — 0.245 ms against 0.232 with the accumulators in registers and 5 waves: occupancy is not what this kernel waits for.)
 template <typename VT, int L, int U>
 __global__ __launch_bounds__(256) void fold_q20_kernel(
     int64_t n_tasks, const int32_t *__restrict__ task_row, const int64_t *__restrict__ task_begin,
@@ -338,9 +352,12 @@ __global__ __launch_bounds__(256) void fold_q20_kernel(
         jn = ip[64 + lane];
         an = vp[64 + lane];
     }
-    auto issue = [&](int jch, int st0, uint4(&x)[U]) {
+    // (a step whose eight pairs all lie beyond the chunk's count is skipped — loads and products: rows are 20 .. 9 000
+    // entries long and a short row's last register set is mostly padding)
+    auto issue = [&](int jch, int st0, int cnt_ch, uint4(&x)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+            if (u > 0 && (st0 + u) * GROUPS >= cnt_ch) break;
             const int jj = __shfl(jch, (st0 + u) * GROUPS + g, 64);
             unsigned off;
             asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(off) : "v"(jj), "n"(LOG_RB), "v"(lo0));
@@ -348,11 +365,12 @@ __global__ __launch_bounds__(256) void fold_q20_kernel(
         }
     };
     // one register set: U entries multiplied and summed in fp32 (two columns per v_pk_fma_f32), then added to the fp64 sums
-    auto consume = [&](float ach, int st0, const uint4(&x)[U]) {
+    auto consume = [&](float ach, int st0, int cnt_ch, const uint4(&x)[U]) {
         pk_f2 s01 = {0.0f, 0.0f}, s23 = {0.0f, 0.0f}, s45 = {0.0f, 0.0f};
         float s6 = 0.0f;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+            if (u > 0 && (st0 + u) * GROUPS >= cnt_ch) break;
             const float a = __shfl(ach, (st0 + u) * GROUPS + g, 64);
             const pk_f2 aa = {a, a};
             const uint4 d = x[u];
@@ -373,7 +391,7 @@ __global__ __launch_bounds__(256) void fold_q20_kernel(
         acc[6] += (double)s6;
     };
     uint4 x0[U], x1[U];
-    issue(jc, 0, x0);                                        // the first gathers do not wait for the scale
+    issue(jc, 0, n < 64 ? n : 64, x0);                       // the first gathers do not wait for the scale
     float ac = (float)((double)araw * tab[pk_q20_bracket((unsigned)jc)]);
     // one 64-pair chunk whose first set sits in register file P (the sets alternate between the two files; with an odd
     // number of sets per chunk the next chunk starts in the other one)
@@ -381,6 +399,7 @@ __global__ __launch_bounds__(256) void fold_q20_kernel(
         constexpr int P0 = decltype(P)::value;
         const int cnt = (n - p) < 64 ? (n - p) : 64;         // pairs of this chunk; padded lanes hold (0, 0.0)
         const bool more = p + 64 < n;
+        const int cnt_next = (n - p - 64) < 64 ? (n - p - 64) : 64;
         int jf = 0;
         VT af = (VT)0;
         if (p + 128 + lane < n) {                            // pairs two chunks ahead
@@ -395,16 +414,16 @@ __global__ __launch_bounds__(256) void fold_q20_kernel(
             const bool have_next = (k + 1 < SETS) ? ((k + 1) * U * GROUPS < cnt) : more;
             if (((k + P0) & 1) == 0) {
                 if (have_next) {
-                    if (k + 1 < SETS) issue(jc, (k + 1) * U, x1);
-                    else issue(jn, 0, x1);
+                    if (k + 1 < SETS) issue(jc, (k + 1) * U, cnt, x1);
+                    else issue(jn, 0, cnt_next, x1);
                 }
-                if (have) consume(ac, k * U, x0);
+                if (have) consume(ac, k * U, cnt, x0);
             } else {
                 if (have_next) {
-                    if (k + 1 < SETS) issue(jc, (k + 1) * U, x0);
-                    else issue(jn, 0, x0);
+                    if (k + 1 < SETS) issue(jc, (k + 1) * U, cnt, x0);
+                    else issue(jn, 0, cnt_next, x0);
                 }
-                if (have) consume(ac, k * U, x1);
+                if (have) consume(ac, k * U, cnt, x1);
             }
         }
         jc = jn;
@@ -422,26 +441,48 @@ __global__ __launch_bounds__(256) void fold_q20_kernel(
         }
     }
 
-    // add the GROUPS partial sums in group order (fixed): after the exchange every lane holds the total
-    if constexpr (L <= 2) q20_group_sum<2>(acc);
-    if constexpr (L <= 4) q20_group_sum<4>(acc);
-    if constexpr (L <= 8) q20_group_sum<8>(acc);
-    if constexpr (L <= 16) q20_group_sum<16>(acc);
-    q20_group_sum<32>(acc);
-
+    // ---- sum over the groups (fixed order: deterministic).  After the halving rounds a lane holds the totals of TWO column
+    // slots (four for L = 32): slot t0 = 4 * bit5(lane) + 2 * bit4(lane) and t0 + 1; slot 6 is the digit's sum.
+    double w[4];
+    w[0] = q20_swap_add32(acc[0], acc[4]);
+    w[1] = q20_swap_add32(acc[1], acc[5]);
+    w[2] = q20_swap_add32(acc[2], acc[6]);
+    w[3] = q20_swap_add32(acc[3], 0.0);
+    constexpr int NW = L <= 16 ? 2 : 4;
+    if constexpr (L <= 16) {
+        w[0] = q20_swap_add16(w[0], w[2]);
+        w[1] = q20_swap_add16(w[1], w[3]);
+    }
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        if constexpr (L <= 8) w[i] += pk_lane_xor<8>(w[i]);
+        if constexpr (L <= 4) w[i] += pk_lane_xor<4>(w[i]);
+        if constexpr (L <= 2) w[i] += pk_lane_xor<2>(w[i]);
+    }
+    const int b5 = (lane >> 5) & 1, b4 = (lane >> 4) & 1;
+    const int t0 = L <= 16 ? 4 * b5 + 2 * b4 : 4 * b5;          // first column slot this lane holds
+    // the digit's sum (slot 6) sits in w[0] of the lanes with t0 == 6 (L <= 16) or in w[2] of the upper half (L = 32);
     // the three digit sums of an extra column meet in its top lane
-    const double a1 = __shfl(acc[6], lane + 1, 64), a2 = __shfl(acc[6], lane + 2, 64);
+    const double dsum = L <= 16 ? w[0] : w[2];
+    const double a1 = __shfl(dsum, lane + 1, 64), a2 = __shfl(dsum, lane + 2, 64);
     const int slot = task_slot[task];
     double *dst = slot < 0 ? out + (int64_t)task_row[task] * ldo : partial + (int64_t)slot * Kx;
-    if (g == 0) {
+    // one lane per (row piece l, slot pair) stores: the lanes whose group bits below bit 4 are zero
+    const bool owner = L <= 16 ? (((lane & 15) / L) == 0) : true;
+    if (owner) {
 #pragma unroll
-        for (int t = 0; t < 6; ++t)
-            if (6 * l + t < K) dst[6 * l + t] = acc[t];
-        const int e = l / 3;
-        if (l % 3 == 0 && 3 * e + 2 <= L - 2 && 6 * L + e < K) dst[6 * L + e] = 2.0 * (acc[6] + a1 * 0.00390625 + a2 * 1.52587890625e-05);
-        if (l == L - 1) {
-            dst[K] = kappa * acc[6];
-            for (int c = K + 1; c < Kx; ++c) dst[c] = 0.0;
+        for (int i = 0; i < NW; ++i) {
+            const int t = t0 + i;
+            if (t < 6 && 6 * l + t < K) dst[6 * l + t] = w[i];
+        }
+        const bool digit_lane = L <= 16 ? (t0 == 6) : (b5 == 1);
+        if (digit_lane) {
+            const int e = l / 3;
+            if (l % 3 == 0 && 3 * e + 2 <= L - 2 && 6 * L + e < K) dst[6 * L + e] = 2.0 * (dsum + a1 * 0.00390625 + a2 * 1.52587890625e-05);
+            if (l == L - 1) {
+                dst[K] = kappa * dsum;
+                for (int c = K + 1; c < Kx; ++c) dst[c] = 0.0;
+            }
         }
     }
 }

@@ -141,8 +141,14 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(
 // PRED: only the tasks of rows whose flag word intersects `flag_mask` run (row_flags[row]; every other wave leaves at
 // once): the exact re-fold of the users a scoring pass could not certify — the flags are where the re-scoring kernel
 // left them, on the device, and the plan, the mapping and the summation order are those of the full product.
+#ifndef PK_SPMM_U_F64
+#define PK_SPMM_U_F64 4        // wave steps per register set of the fp64 dense block (GROUPS <= 8)
+#endif
+#ifndef PK_SPMM_WPE
+#define PK_SPMM_WPE 1          // waves per SIMD the register allocation is held to (1: whatever the kernel needs)
+#endif
 template <typename VT, int GROUPS, typename XT, bool ACC, bool OFF32, bool PRED = false>
-__global__ __launch_bounds__(256) void spmm_csr_groups_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PK_SPMM_WPE, 8))) void spmm_csr_groups_kernel(
     int64_t n_tasks, const int32_t *__restrict__ task_row, const int64_t *__restrict__ task_begin,
     const int64_t *__restrict__ task_end, const int32_t *__restrict__ task_slot,
     const int32_t *__restrict__ indices, const VT *__restrict__ vals, const XT *__restrict__ X,
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(256) void spmm_csr_groups_kernel(
     // (16 steps: slower, occupancy; 8 steps for the fp64 block: slower too, 3.30 -> 4.07 ms.)
     // narrow instances (round 4): GROUPS = 8 / 16 — 8 / 4 lanes per gathered row for <= 32 / <= 16 fp64 columns, so
     // that a narrow panel does not idle three quarters of every gather instruction's lanes the way GROUPS = 4 does at nc = 16
-    constexpr int U = XF ? 8 : (GROUPS == 16 ? 2 : 4);
+    constexpr int U = XF ? 8 : (GROUPS == 16 ? 2 : PK_SPMM_U_F64);
     static_assert(!XF || GROUPS <= 4, "the fp32 dense block runs on GROUPS <= 4 only");
     using XA = typename std::conditional<XF, float4, double2>::type;
     const int lane = threadIdx.x & 63;

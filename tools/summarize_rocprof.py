@@ -21,7 +21,7 @@ def kernel_source_hashes(root=None):
     import hashlib
     root = root or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = {}
-    for name in ('score.hip', 'spmm.hip', 'rescore.hip', 'dense.hip'):
+    for name in ('score.hip', 'spmm.hip', 'rescore.hip', 'dense.hip', 'foldq.hip'):
         try:
             with open(os.path.join(root, 'polara_amd', 'csrc', name), 'rb') as f:
                 out[name] = hashlib.sha256(f.read()).hexdigest()[:16]
