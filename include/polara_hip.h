@@ -37,9 +37,6 @@ extern "C" {
 
 #define PK_VAL_F32 0
 #define PK_VAL_F64 1
-/* x_kind flag of pk_spmm_csr_ex: PK_VAL_F32 | PK_X_HEAD asks for the persistent fold-in instance that stages the first rows
- * of the fp32 dense block in LDS (opt-in: measured slower than the plain kernel, see csrc/spmm.hip; same bits) */
-#define PK_X_HEAD 16
 
 const char *pk_last_error(void);
 int pk_version(void);
@@ -180,6 +177,16 @@ int pk_tsmm_f64(void *stream, int64_t n, int32_t lin, int32_t lout, const double
  * solvers in one pass */
 int pk_tsmm_sub_f64(void *stream, int64_t n, int32_t lin, int32_t lout, const double *X_dev, int64_t ldx,
                     const double *C_dev, int64_t ldc, const double *Z_dev, int64_t ldz, double *out_dev, int64_t ldo);
+/* out = alpha X C + beta Z1 + gamma Z2 in one pass (Z1 / Z2 may be NULL): one step of the Chebyshev recurrence on a small
+ * dense operator — the projected problems of the block Lanczos build (ARPACK solves the same projected problem inside
+ * svds, models.py:844) — in ONE launch instead of a Gram product, its reduction and the recurrence. */
+int pk_tsmm_axpby_f64(void *stream, int64_t n, int32_t lin, int32_t lout, const double *X_dev, int64_t ldx,
+                      const double *C_dev, int64_t ldc, double alpha, double beta, const double *Z1_dev, int64_t ldz1,
+                      double gamma, const double *Z2_dev, int64_t ldz2, double *out_dev, int64_t ldo);
+/* The bookkeeping of an orthonormalisation pass on the device, one launch: flags[0] += sum |info[i]| (Cholesky verdicts),
+ * flags[1] = max(flags[1], max |G - I|) (NaN / inf count as 1), info[0..n_info) zeroed for the next block. */
+int pk_orth_check_f64(void *stream, int32_t l, const double *G_dev, int64_t ldg, int32_t *info_dev, int32_t n_info,
+                      double *flags_dev);
 /* Symmetric positive semi-definite eigen-decomposition by one-sided Jacobi, single workgroup.
  * S (n x n, destroyed) -> evals[n] descending, evecs (n x n, ROW i = i-th eigenvector).
  * info_dev[0] = sweeps used, info_dev[1] = 1 if converged.  n <= 1024. */

@@ -11,7 +11,6 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('POLARA_HIP_LIB') or os.path.join(_HERE, 'libpolarahip.so')
 
 PK_VAL_F32, PK_VAL_F64 = 0, 1
-PK_X_HEAD = 16      # x_kind flag of pk_spmm_csr_ex: the persistent fold-in instance with the head of X in LDS (opt-in)
 
 _vp, _i32, _i64, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
 
@@ -48,6 +47,8 @@ PROTOTYPES = {
     'pk_gram_f64': (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     'pk_tsmm_f64': (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64]),
     'pk_tsmm_sub_f64': (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64]),
+    'pk_tsmm_axpby_f64': (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _f64, _f64, _vp, _i64, _f64, _vp, _i64, _vp, _i64]),
+    'pk_orth_check_f64': (C.c_int, [_vp, _i32, _vp, _i64, _vp, _i32, _vp]),
     'pk_eigh_psd_f64': (C.c_int, [_vp, _i32, _vp, _i64, _vp, _i64, _vp, _i32, _f64, _vp]),
     'pk_eigh_psd_rounds_f64': (C.c_int, [_vp, _i32, _vp, _i64, _vp, _i64, _vp, _i32, _f64, _vp]),
     'pk_eigh_top_supported': (C.c_int, [_i32, _i32]),

@@ -21,29 +21,8 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-u
          # MFMA accumulators in arch VGPRs (gfx950 has a unified register file): the scoring
          # epilogue reads them with v_max3 directly instead of 16 v_accvgpr_read per tile
          '-mllvm', '-amdgpu-mfma-vgpr-form=1']
-if os.environ.get('PK_FAST_BUILD'):   # kernel-tuning builds: only the rank-50 / top-10 scoring instances
-    FLAGS.append('-DPK_FAST_BUILD')
-if os.environ.get('PK_SWEEP_WAVES'):    # kernel-tuning builds: force the sweep's register budget to this many waves per SIMD
-    FLAGS.append('-DPK_SWEEP_WAVES=' + os.environ['PK_SWEEP_WAVES'])
-if os.environ.get('PK_SCORE_ROLL') == '4':     # kernel-tuning builds: the rolling-buffer sweep forced to four waves per SIMD (rank <= 64, top-10)
-    FLAGS.append('-DPK_SCORE_ROLL4=1')
-if os.environ.get('PK_SCORE_DEPTH2'):     # kernel-tuning builds: two alternating rolling fragment buffers (loads two tiles ahead)
-    FLAGS.append('-DPK_SCORE_DEPTH2=1')
-if os.environ.get('PK_SCORE_DIAG'):     # kernel-tuning builds: PK_SCORE_ABLATE bits 16 (no fragment re-loads) and 32 (no products) in the sweep
-    FLAGS.append('-DPK_SCORE_DIAG=1')
-if os.environ.get('PK_SCORE_TWO_CHAINS'):     # kernel-tuning builds: two accumulator chains in the rolling tile loop (rank <= 64)
-    FLAGS.append('-DPK_SCORE_TWO_CHAINS=1')
-if os.environ.get('PK_SCORE_TWO_BUFFERS'):     # kernel-tuning builds: the two-buffer tile loop of rounds 1-3
-    FLAGS.append('-DPK_SCORE_TWO_BUFFERS=1')
-if os.environ.get('PK_SHARED_WAVES'):   # kernel-tuning builds: waves per workgroup of the LDS-staged sweep instance
-    FLAGS.append('-DPK_SHARED_WAVES=' + os.environ['PK_SHARED_WAVES'])
-if os.environ.get('PK_ETOP_PROFILE'):   # kernel-tuning builds: phase clocks of eigh_top_kernel in info[2..7]
-    FLAGS.append('-DETOP_PROFILE')
-if os.environ.get('PK_SCORE_PROFILE2'):   # kernel-tuning builds: slot 1 of the cycle counters times the products of a tile
-    FLAGS += ['-DPK_SCORE_PROFILE2', '-DPK_SCORE_PROFILE']
-if os.environ.get('PK_SCORE_PROFILE'):   # kernel-tuning builds: cycle counters inside the candidate sweep
-    FLAGS.append('-DPK_SCORE_PROFILE')
-
+# (kernel-tuning builds — the rejected sweep / fold-in variants of csrc/experiments/ with their -D switches — are made by
+# tools/build_probe_lib.py into a library of their own, selected with POLARA_HIP_LIB: never into libpolarahip.so)
 
 def sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(('.hip', '.cpp')))

@@ -176,11 +176,15 @@ extern "C" int pk_gram_f64(void *stream, int64_t n, int32_t la, int32_t lb, cons
 // LDS after them.  The first version loaded, synchronised, multiplied, synchronised: with n / 16 waves in all (1.6 per SIMD
 // at 26 744 rows) nothing covered the load latency — 117 us for a 26 744 x 448 operand (0.8 TB/s), three times per block of
 // the block Lanczos build (re-orthogonalisation against the whole Krylov basis).
-template <bool SUB>
+// SUB = 2: the general epilogue out = alpha X C + beta Zin + gamma Z2 (Zin / Z2 may be NULL) — one step of the Chebyshev
+// recurrence on a small dense operator in ONE launch (driver.hip: DenseOp::filter_step; the projected problems of a block
+// Lanczos build are solved by ~90 of those steps, each three launches before: Gram product, its reduction, the recurrence)
+template <int SUB>
 __global__ __launch_bounds__(256) void tsmm_kernel(int64_t n, int lin, int lout, const double *__restrict__ X,
                                                    int64_t ldx, const double *__restrict__ C, int64_t ldc,
                                                    double *__restrict__ out, int64_t ldo, const double *__restrict__ Zin,
-                                                   int64_t ldz) {
+                                                   int64_t ldz, double alpha = 0.0, double beta = 0.0, double gamma = 0.0,
+                                                   const double *__restrict__ Z2 = nullptr, int64_t ldz2 = 0) {
     constexpr int KT = 32;
     __shared__ double sX[64][KT + 1];
     __shared__ __attribute__((aligned(16))) double sC[KT][64];
@@ -260,8 +264,13 @@ __global__ __launch_bounds__(256) void tsmm_kernel(int64_t n, int lin, int lout,
         for (int r = 0; r < 4; ++r) {
             const int64_t row = row0 + 16 * wave + (lane >> 4) + 4 * r;
             if (row < n && c < lout) {
-                if constexpr (SUB) out[row * ldo + c] = Zin[row * ldz + c] - acc[b][r];     // out may alias Zin: same element, same thread
-                else out[row * ldo + c] = acc[b][r];
+                if constexpr (SUB == 1) out[row * ldo + c] = Zin[row * ldz + c] - acc[b][r];     // out may alias Zin: same element, same thread
+                else if constexpr (SUB == 2) {
+                    double v = alpha * acc[b][r];
+                    if (Zin) v = fma(beta, Zin[row * ldz + c], v);
+                    if (Z2) v = fma(gamma, Z2[row * ldz2 + c], v);
+                    out[row * ldo + c] = v;
+                } else out[row * ldo + c] = acc[b][r];
             }
         }
     }
@@ -272,7 +281,7 @@ extern "C" int pk_tsmm_f64(void *stream, int64_t n, int32_t lin, int32_t lout, c
     PK_REQUIRE(n >= 1 && lin >= 1 && lout >= 1, "pk_tsmm_f64: bad sizes");
     PK_REQUIRE(ldx >= lin && ldc >= lout && ldo >= lout, "pk_tsmm_f64: bad leading dimension");
     PK_REQUIRE(X_dev != out_dev, "pk_tsmm_f64: out must not alias X");
-    hipLaunchKernelGGL(tsmm_kernel<false>, dim3((unsigned)pk_ceil_div(n, 64), (unsigned)pk_ceil_div(lout, 64)), dim3(256),
+    hipLaunchKernelGGL(tsmm_kernel<0>, dim3((unsigned)pk_ceil_div(n, 64), (unsigned)pk_ceil_div(lout, 64)), dim3(256),
                        0, pk_stream(stream), n, lin, lout, X_dev, ldx, C_dev, ldc, out_dev, ldo, (const double *)nullptr, (int64_t)0);
     PK_CHECK_LAUNCH("tsmm_kernel");
     return PK_OK;
@@ -285,9 +294,62 @@ extern "C" int pk_tsmm_sub_f64(void *stream, int64_t n, int32_t lin, int32_t lou
     PK_REQUIRE(n >= 1 && lin >= 1 && lout >= 1, "pk_tsmm_sub_f64: bad sizes");
     PK_REQUIRE(ldx >= lin && ldc >= lout && ldo >= lout && ldz >= lout, "pk_tsmm_sub_f64: bad leading dimension");
     PK_REQUIRE(X_dev != out_dev && Z_dev && C_dev && X_dev && out_dev, "pk_tsmm_sub_f64: bad pointers (out must not alias X)");
-    hipLaunchKernelGGL(tsmm_kernel<true>, dim3((unsigned)pk_ceil_div(n, 64), (unsigned)pk_ceil_div(lout, 64)), dim3(256),
+    hipLaunchKernelGGL(tsmm_kernel<1>, dim3((unsigned)pk_ceil_div(n, 64), (unsigned)pk_ceil_div(lout, 64)), dim3(256),
                        0, pk_stream(stream), n, lin, lout, X_dev, ldx, C_dev, ldc, out_dev, ldo, Z_dev, ldz);
     PK_CHECK_LAUNCH("tsmm_kernel<sub>");
+    return PK_OK;
+}
+
+// out = alpha X C + beta Z1 + gamma Z2 in one pass (Z1 / Z2 may be NULL; out must alias none of the inputs)
+extern "C" int pk_tsmm_axpby_f64(void *stream, int64_t n, int32_t lin, int32_t lout, const double *X_dev, int64_t ldx,
+                                 const double *C_dev, int64_t ldc, double alpha, double beta, const double *Z1_dev, int64_t ldz1,
+                                 double gamma, const double *Z2_dev, int64_t ldz2, double *out_dev, int64_t ldo) {
+    PK_REQUIRE(n >= 1 && lin >= 1 && lout >= 1, "pk_tsmm_axpby_f64: bad sizes");
+    PK_REQUIRE(ldx >= lin && ldc >= lout && ldo >= lout && (!Z1_dev || ldz1 >= lout) && (!Z2_dev || ldz2 >= lout),
+               "pk_tsmm_axpby_f64: bad leading dimension");
+    PK_REQUIRE(X_dev && C_dev && out_dev && X_dev != out_dev && C_dev != out_dev && Z1_dev != out_dev && Z2_dev != out_dev,
+               "pk_tsmm_axpby_f64: bad pointers (out aliases an input)");
+    hipLaunchKernelGGL(tsmm_kernel<2>, dim3((unsigned)pk_ceil_div(n, 64), (unsigned)pk_ceil_div(lout, 64)), dim3(256),
+                       0, pk_stream(stream), n, lin, lout, X_dev, ldx, C_dev, ldc, out_dev, ldo, Z1_dev, ldz1, alpha, beta, gamma,
+                       Z2_dev, ldz2);
+    PK_CHECK_LAUNCH("tsmm_kernel<axpby>");
+    return PK_OK;
+}
+
+// ---- the bookkeeping of an orthonormalisation pass without the host and without a dozen one-element launches:
+// flags[0] += sum_i |info[i]|  (the Cholesky verdicts of the passes),  flags[1] = max(flags[1], max |G - I|) with NaN / inf
+// counted as 1 (G: the l x l Gram matrix of the finished block), and info[] is ZEROED for the next block.  One workgroup.
+__global__ __launch_bounds__(256) void orth_check_kernel(int l, const double *__restrict__ G, int64_t ldg, int32_t *__restrict__ info,
+                                                         int n_info, double *__restrict__ flags) {
+    __shared__ double s_max[256];
+    double m = 0.0;
+    for (int e = threadIdx.x; e < l * l; e += 256) {
+        const int i = e / l, j = e - i * l;
+        const double d = fabs(G[(int64_t)i * ldg + j] - (i == j ? 1.0 : 0.0));
+        m = (d <= 1e300) ? fmax(m, d) : fmax(m, 1.0);          // NaN and inf count as 1 (a lost block)
+    }
+    s_max[threadIdx.x] = m;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) s_max[threadIdx.x] = fmax(s_max[threadIdx.x], s_max[threadIdx.x + w]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int bad = 0;
+        for (int i = 0; i < n_info; ++i) {
+            bad += info[i] < 0 ? -info[i] : info[i];
+            info[i] = 0;
+        }
+        flags[0] += (double)bad;
+        flags[1] = fmax(flags[1], s_max[0]);
+    }
+}
+
+extern "C" int pk_orth_check_f64(void *stream, int32_t l, const double *G_dev, int64_t ldg, int32_t *info_dev, int32_t n_info,
+                                 double *flags_dev) {
+    PK_REQUIRE(l >= 1 && l <= 4096 && ldg >= l && G_dev && info_dev && n_info >= 0 && n_info <= 64 && flags_dev, "pk_orth_check_f64: bad arguments");
+    hipLaunchKernelGGL(orth_check_kernel, dim3(1), dim3(256), 0, pk_stream(stream), l, G_dev, ldg, info_dev, n_info, flags_dev);
+    PK_CHECK_LAUNCH("orth_check_kernel");
     return PK_OK;
 }
 

@@ -22,6 +22,7 @@
 #include <numeric>
 #include <random>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 // Device memory of a context: freed blocks are kept and handed out again (best fit within 25 %): every buffer of the
@@ -341,6 +342,13 @@ struct Solver {
         out = DMat(X.n, C.l);
         if (!out.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (tsmm)");
         CK(pk_tsmm_f64(st, X.n, X.l, C.l, X.p(), X.l, C.p(), C.l, out.p(), out.l));
+        return PK_OK;
+    }
+    int tsmm_axpby(const DMat &X, const DMat &C, double a, double b, const DMat *Z1, double c, const DMat *Z2, DMat &out) {
+        out = DMat(X.n, C.l);       // out = a X C + b Z1 + c Z2 in one launch
+        if (!out.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (tsmm_axpby)");
+        CK(pk_tsmm_axpby_f64(st, X.n, X.l, C.l, X.p(), X.l, C.p(), C.l, a, b, Z1 ? Z1->p() : nullptr, Z1 ? Z1->l : 0, c,
+                             Z2 ? Z2->p() : nullptr, Z2 ? Z2->l : 0, out.p(), out.l));
         return PK_OK;
     }
     int axpbypcz(double a, const DMat &Z, double b, const DMat *Y, double c, const DMat *X, DMat &out) {
@@ -713,6 +721,12 @@ struct SubspaceOut {
 
 // Op: ritz(X, H, carrier) -> H = X^T B X and a carrier from which B (X C) follows; rotate(carrier, C, Z) -> Z = B X C;
 // apply(X, Z) -> Z = B X.  X: orthonormal start block (consumed).
+// does the operator offer the Chebyshev step as one launch (DenseOp)?
+template <typename T, typename = void>
+struct has_filter_step : std::false_type {};
+template <typename T>
+struct has_filter_step<T, std::void_t<decltype(&T::filter_step)>> : std::true_type {};
+
 template <class Op>
 int subspace_iteration(pk_ctx *ctx, Solver &S, Op &op, int k, DMat X, double tol, int max_outer, int m_max, double spread,
                        uint64_t seed, bool even_lock, SubspaceOut &out) {
@@ -775,6 +789,15 @@ int subspace_iteration(pk_ctx *ctx, Solver &S, Op &op, int k, DMat X, double tol
             for (int s = 2; s <= m; ++s) {
                 const double sigma_new = 1.0 / (tau - sigma);
                 DMat Zc, Yn;
+                if constexpr (has_filter_step<Op>::value) {
+                    if (!have_lock) {          // product and recurrence in one launch (dense operators)
+                        CK(op.filter_step(Yc, 2.0 * sigma_new / e, -2.0 * sigma_new * c / e, -sigma * sigma_new, Xc, Yn));
+                        Xc = std::move(Yc);
+                        Yc = std::move(Yn);
+                        sigma = sigma_new;
+                        continue;
+                    }
+                }
                 CK(op.apply(Yc, Zc));
                 if (have_lock) { DMat t; CK(S.project_out(Zc, Vlock, t)); Zc = std::move(t); }
                 CK(S.axpbypcz(2.0 * sigma_new / e, Zc, -2.0 * sigma_new * c / e, &Yc, -sigma * sigma_new, &Xc, Yn));
@@ -842,9 +865,15 @@ struct DenseOp {
     Solver &S;
     const DMat &T;
     int products = 0;
+    // T is symmetric: T X is one tall-skinny product over T's rows (ONE launch; the split Gram product + its reduction
+    // were two), and a step of the Chebyshev recurrence  Yn = a T Yc + b Yc + c Xc  is that product with an epilogue
     int apply(const DMat &X, DMat &Z) {
         ++products;
-        return S.gram(T, X, Z);
+        return S.tsmm(T, X, Z);
+    }
+    int filter_step(const DMat &Yc, double a, double b, double c, const DMat &Xc, DMat &Yn) {
+        ++products;
+        return S.tsmm_axpby(T, Yc, a, b, &Yc, c, &Xc, Yn);
     }
     int ritz(const DMat &X, DMat &H, DMat &Z) {
         DMat G;
@@ -1048,11 +1077,14 @@ static int block_lanczos(pk_ctx *ctx, Solver &S, GramianOp &gop, int64_t n, int 
                 if (p == 0) CK(S.col_slice(G, 0, b, Sc));
                 CK(pk_chol_rinv_f64(S.st, b, G.p(), b, p == 0 ? 11.0 * ((double)n * b + (double)b * (b + 1)) * u : 0.0, Rinv.p(), b, chol_work.p,
                                     info.as<int32_t>() + p));
-                CK(S.tsmm(Yp, Rinv, Yn));
-                Y = std::move(Yn);
+                if (p < 2) {
+                    CK(S.tsmm(Yp, Rinv, Yn));
+                    Y = std::move(Yn);
+                } else {      // the last pass writes the new block where it lives: columns [N, N + b) of the basis
+                    CK(pk_tsmm_f64(S.st, n, b, b, Yp.p(), b, Rinv.p(), b, Q.p() + N, ldq));
+                }
             }
             hipLaunchKernelGGL(lanczos_flags_kernel, dim3(1), dim3(256), 0, S.st, b, G.p(), info.as<int32_t>(), flags.as<double>());
-            HIPCK(hipMemcpy2DAsync(Q.p() + N, (size_t)ldq * 8, Y.p(), (size_t)b * 8, (size_t)b * 8, (size_t)n, hipMemcpyDeviceToDevice, S.st));
         } else {
             DMat Wp(n, b);
             if (!Wp.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (block Lanczos)");

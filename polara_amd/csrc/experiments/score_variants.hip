@@ -1,3 +1,7 @@
+// EXPERIMENT TREE — not part of libpolarahip.so.  score.hip as it stood at the end of round 4 (commit c50a3c5 + the per-TU loader of round 5): every sweep / fold-in variant that was built,
+// verified against the default kernel and measured slower or mixed (profiles/r03_* r04_*) stays buildable here,
+// behind its -D switches and run-time knobs, through `python tools/build_probe_lib.py out.so [-D...]` + POLARA_HIP_LIB=out.so.
+// The product sources carry only the kernels that ship.
 // K3: fused  scores = E V^T  (fp32 MFMA)  +  seen-item masking  +  per-user top-k candidates.
 //
 // Replaces the body of RecommenderModel._slice_recommender (models.py:359-371):
@@ -41,7 +45,34 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define RING 16          // lane-private candidate ring entries (8 for KC == 16, see PAIRED below)
+#if !defined(PK_SCORE_TWO_BUFFERS) && !defined(PK_SCORE_ROLL)
+#define PK_SCORE_ROLL 1  // the rolling fragment buffer of the tile loop (round 4; see score_tile_roll)
+#endif
 
+#ifdef PK_SCORE_PROFILE
+// tuning builds only: wave-cycles spent in [0] whole kernel, [1] flushes, [2] seen-list walk, [3] push path,
+// [4] prologue (state restore), [5] threshold bootstrap; [6] flush count, [7] tiles
+__device__ unsigned long long pk_prof[8];
+extern "C" int pk_debug_profile(unsigned long long *out, int reset) {
+    if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(pk_prof), sizeof(pk_prof));
+    if (reset) {
+        unsigned long long z[8] = {0};
+        hipMemcpyToSymbol(HIP_SYMBOL(pk_prof), z, sizeof(z));
+    }
+    return 0;
+}
+#define PROF_T() __builtin_readcyclecounter()
+#define PROF_DECL unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PROF_ADD(i, t0) do { prof_acc[i] += (unsigned long long)(__builtin_readcyclecounter() - (t0)); } while (0)
+#define PROF_INC(i, n) do { prof_acc[i] += (unsigned long long)(n); } while (0)
+#define PROF_FLUSH() do { if (lane == 0) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&pk_prof[i_], prof_acc[i_]); } while (0)
+#else
+#define PROF_T() 0ull
+#define PROF_DECL
+#define PROF_ADD(i, t0) do { (void)(t0); } while (0)
+#define PROF_INC(i, n) do { } while (0)
+#define PROF_FLUSH() do { } while (0)
+#endif
 #define PK_IDX_NONE 0x7fffffff
 #define PK_IDX_FLOOR (-2)       // last slot of a list: "not full although the sweep started from a threshold" (see the kernel's end)
 #define PK_TILE_NONE 0xffffffff00000000ull   // end of a seen-tile stream
@@ -153,6 +184,25 @@ __host__ __device__ constexpr int pk_ring_rows(int kc) { return kc == 16 ? 8 : R
 __host__ __device__ constexpr size_t pk_score_lds_bytes(int nstep, int kc) {
     return (size_t)(4 * pk_ring_rows(kc) * 64 + (pk_top_in_lds(nstep, kc) ? 4 * 32 * kc : 1)) * sizeof(uint2);
 }
+// SHARED instance: the rings and lists of its NW waves + TWO packed V tiles (2 * nstep KB each).  NW = 4 at KC = 16: 8 KB of
+// selection state per wave + 16 KB of tiles at rank 50 = 48 KB, THREE workgroups per CU; the four waves of a workgroup sit
+// on the four SIMDs, so the three waves of a SIMD belong to three workgroups that drift against each other like the
+// free-running waves of the register-fed kernel (a first version with 16 waves = one workgroup per CU kept all waves of a
+// SIMD in lock-step and lost the MFMA / VALU overlap that way).  PK_SHARED_WAVES: kernel-tuning builds.
+#ifndef PK_SHARED_WAVES
+#define PK_SHARED_WAVES 4
+#endif
+__host__ __device__ constexpr int pk_shared_waves(int kc) { return kc == 16 ? PK_SHARED_WAVES : 8; }
+__host__ __device__ constexpr size_t pk_score_lds_bytes_shared(int nstep, int kc) {
+    return (size_t)(pk_shared_waves(kc) * pk_ring_rows(kc) * 64 + pk_shared_waves(kc) * 32 * kc) * sizeof(uint2) +
+           (size_t)2 * (2 * nstep) * 64 * 16;
+}
+// instantiated for top-10 lists up to rank 128 (the regime it was meant for; it is opt-in — PK_SCORE_SHARED=1 — because it
+// did not pay, see DESIGN.md K3 round 3: at best equal to the register-fed kernel on dense sweeps, slower on pruned ones)
+__host__ __device__ constexpr bool pk_shared_ok(int nstep, int kc) {
+    return kc == 16 && nstep <= 8 && pk_top_in_lds(nstep, kc) && pk_score_lds_bytes_shared(nstep, kc) <= 160 * 1024 - 64;
+}
+
 // Dense seen masks of the head of the catalogue (pk_seen_dense_build): mask[(group * tiles + tile) * 32 + user % 32] =
 // the 32-bit seen mask of that user in that tile for tile < tiles, ONE coalesced 128-byte load per tile-wave that is
 // requested a tile ahead with the V fragments; skip[user] = the records of the user's seen-tile stream that lie in
@@ -165,11 +215,25 @@ struct SeenDense {
 
 // DENSE: the instance that reads them (the other one is the kernel as it was: in the throughput-bound regimes — full
 // sweeps, rank 200 — the extra registers and per-tile tests of a run-time switch cost 10 %).
-// (The LDS-staged forms of this sweep — 16- and 4-wave workgroups stepping through the tiles together — the two-groups-per-wave
-// kernel and the two-buffer / depth-2 / two-chain tile loops were built, verified and measured slower or mixed in rounds 3-4:
-// they live in csrc/experiments/score_variants.hip with their records in profiles/ and DESIGN.md K3, not in the product library.)
-template <int NSTEP, int KC, bool STRIDED, bool DENSE>
-__global__ __launch_bounds__(256) void score_candidates_kernel(
+#ifdef PK_SWEEP_WAVES      // kernel-tuning builds: force the register budget of PK_SWEEP_WAVES waves per SIMD
+#define PK_SWEEP_OCC __attribute__((amdgpu_waves_per_eu(PK_SWEEP_WAVES, PK_SWEEP_WAVES)))
+#elif defined(PK_SCORE_ROLL4)   // with the rolling buffer the rank <= 64, top-10 instances are 8 registers from four waves per SIMD
+#define PK_SWEEP_OCC __attribute__((amdgpu_waves_per_eu((NSTEP <= 4 && KC == 16 && !SHARED) ? 4 : 1)))
+#elif defined(PK_SCORE_DEPTH2)  // two rolling buffers: the rank <= 64 instances land at 171-172 registers, 3 short of three waves per SIMD
+#define PK_SWEEP_OCC __attribute__((amdgpu_waves_per_eu((NSTEP <= 4 && KC <= 32 && !SHARED) ? 3 : 1)))
+#else
+#define PK_SWEEP_OCC
+#endif
+// SHARED (round 3, opt-in): the workgroup is pk_shared_waves() waves (four at KC = 16: one per SIMD) that step through the
+// item tiles together; the packed V tile of a step is staged ONCE per workgroup in LDS (global_load_lds_dwordx4: no register
+// round trip, two buffers, one workgroup barrier per tile) and every wave feeds its MFMAs from there with two ds_read_b128
+// per k-step.  What it buys: the two V-tile register buffers (64 VGPRs at rank 50) leave the register file and the V
+// traffic out of L2 falls by the number of waves.  What it costs: a barrier per tile in a kernel that has none, waves
+// that idle once their group is pruned until the whole workgroup is, lock-step with the slowest wave of a tile.  Never
+// ahead of the register-fed kernel in any regime measured.  Single sweeps only (no item splits),
+// lists in LDS.
+template <int NSTEP, int KC, bool STRIDED, bool DENSE, bool SHARED = false>
+__global__ __launch_bounds__(SHARED ? 64 * pk_shared_waves(KC) : 256) PK_SWEEP_OCC void score_candidates_kernel(
     const float4 *__restrict__ Vp, const float4 *__restrict__ Ep, int64_t n_users, int n_items,
     int n_tiles, int split_tiles, int chunk_begin, int chunk_tiles,
     const int64_t *__restrict__ seen_ptr, const unsigned long long *__restrict__ seen_tiles,
@@ -190,16 +254,24 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
     // KC = 64 lists (16 KiB per wave) move to LDS too when the rank is high enough that the fragment
     // registers already limit the SIMD to one wave (NSTEP > 8, i.e. rank > 128: 96 KiB per workgroup, one workgroup per CU).
     constexpr bool TOP_LDS = pk_top_in_lds(NSTEP, KC);
-    extern __shared__ __attribute__((aligned(16))) uint2 pk_score_lds[];      // [NW][RG][64] rings, then [NW][32*KC] top lists (TOP_LDS)
-    constexpr int NW = 4;           // waves (= user groups) per workgroup
+    extern __shared__ __attribute__((aligned(16))) uint2 pk_score_lds[];      // [NW][RG][64] rings, then [NW][32*KC] top lists (TOP_LDS), then (SHARED) 2 V tiles
+    constexpr int NW = SHARED ? pk_shared_waves(KC) : 4;           // waves (= user groups) per workgroup
+    static_assert(!SHARED || (TOP_LDS && !STRIDED), "SHARED: single sweeps with the lists in LDS");
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t group_raw = (int64_t)blockIdx.x * NW + wave;
-    if (group_raw * 32 >= n_users) return;  // whole wave leaves; the kernel has no workgroup barrier
-    const int64_t group = group_raw;
+    // SHARED: a wave without users (the tail of the last workgroup) still stages tiles and meets the barriers; it reads
+    // as group 0 and never writes
+    const bool participate = group_raw * 32 < n_users;
+    if (!SHARED && !participate) return;  // whole wave leaves; this form of the kernel has no workgroup barrier
+    const int64_t group = participate ? group_raw : 0;
+    bool alive = participate;             // SHARED: this wave still sweeps (not pruned, not finished in an earlier launch)
+    PROF_DECL;
+    const unsigned long long prof_k0 = PROF_T();
     uint2(*ring)[64] = reinterpret_cast<uint2(*)[64]>(pk_score_lds + wave * (RG * 64));
     uint2 *top = pk_score_lds + NW * RG * 64 + (TOP_LDS ? wave * (32 * KC) : 0);
+    float4 *vbuf = reinterpret_cast<float4 *>(pk_score_lds + NW * RG * 64 + (TOP_LDS ? NW * (32 * KC) : 0));   // [3][KQ][64]
 
     // Item split: blockIdx.y = h of S = gridDim.y owns every S-th tile of the catalogue, h, h+S, h+2S, ...
     // (`split_tiles` = ceil(n_tiles / S) of them at most), with its own threshold, rings, top lists and parked
@@ -305,7 +377,8 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
         // resume: restore the lane state and the ring image written by the previous chunk launch
         const LaneState ls = *my_state;
         if (ls.cnt == PK_LANE_DONE) {        // wave-uniform: this group was pruned in an earlier launch
-            return;
+            if constexpr (SHARED) alive = false;
+            else return;
         }
         if (TOP_LDS)
             for (int s = lane; s < 32 * KC; s += 64) top[s] = make_uint2(__float_as_uint(my_score[s]), (unsigned)my_idx[s]);
@@ -324,6 +397,8 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
 
     // merge the rings of user x (lanes x, x+32) and its top list; refresh list, tau, counters
     auto flush_user = [&](int x) {
+        const unsigned long long prof_f0 = PROF_T();
+        PROF_INC(6, 1);
         if (TOP_LDS) {
             // LDS only: program order within the wave + the LDS pipe's in-order execution suffice;
             // the barrier keeps the compiler from moving LDS accesses across the hand-off
@@ -426,9 +501,12 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
             cnt = 0;
         }
         __builtin_amdgcn_wave_barrier();
+        PROF_ADD(1, prof_f0);
     };
     // KC == 16: users x (lanes 0..31) and y (lanes 32..63; y < 0: nobody) merged in one 32-wide sort each
     auto flush_pair = [&](int x, int y) {
+        const unsigned long long prof_f0 = PROF_T();
+        PROF_INC(6, 1);
         __builtin_amdgcn_wave_barrier();
         const int t = lane & 31;
         const int yy = (y >= 0) ? y : x;
@@ -475,6 +553,7 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
             cnt = 0;
         }
         __builtin_amdgcn_wave_barrier();
+        PROF_ADD(1, prof_f0);
     };
     // merge every user of the bit set `um`
     auto flush_set = [&](unsigned um) {
@@ -584,8 +663,55 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
     // then starts from that threshold (just below it, so that those items themselves are pushed and the list fills) and
     // re-scores the same tiles — 12 MFMAs each — pushing a quarter of what it pushed from a cold start
     // (tools/probes/warmup_study.py: 27 instead of 86-92 pushes, 1.6 instead of 6-7 flushes per user at 16 tiles).
+    // SHARED: wave w of the workgroup brings groups w, w + NW, ... of the packed tile into buffer `buf` (one
+    // global_load_lds_dwordx4 per group: a wave writes 64 x 16 contiguous bytes, the [q][lane] layout the MFMA operands
+    // are read back in); stage_wait: my loads have landed and everybody's are visible
+    auto stage_tile = [&](int tile, int buf) {
+        if constexpr (SHARED) {
+            const float4 *src = Vp + ((int64_t)tile * KQ) * 64 + lane;
+            for (int q = wave; q < KQ; q += NW)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + q * 64),
+                                                 (__attribute__((address_space(3))) void *)(vbuf + (buf * KQ + q) * 64), 16, 0, 0);
+        }
+    };
+    // Two buffers: behind the barrier that ends iteration t - 1 every wave has finished reading tile t - 1 and tile t is
+    // complete; a wave then requests its share of tile t + 1 FIRST in iteration t (into the buffer of t - 1), works on
+    // tile t, and waits for its own loads only at the end of the iteration — a whole tile later — in front of the barrier.
+    auto stage_wait = [&]() {
+        if constexpr (SHARED) {
+#ifdef PK_SCORE_DIAG       // kernel-tuning builds: ablate & 64 = neither the wait nor the barrier (wrong scores; what would the LDS-fed loop cost if its waves ran free?)
+            if (ablate & 64) return;
+#endif
+            __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0) only: expcnt and lgkmcnt fields left at their maxima (gfx9 encoding)
+            __syncthreads();
+        }
+    };
     // the score tile of one step: split-bf16 product (see the header): per 16-wide k-step  hi.hi + hi.lo + lo.hi, fp32
-    // accumulation — ONE instruction sequence for the bootstrap and the sweep: the same bits.
+    // accumulation — ONE instruction sequence for the bootstrap and the sweep, registers or LDS: the same bits
+    auto score_tile = [&](const float4(&a)[SHARED ? 1 : KQ], int buf) -> f32x16 {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        const float4 *vb = vbuf + (buf * KQ) * 64 + lane;
+#pragma unroll
+        for (int sidx = 0; sidx < NSTEP; ++sidx) {
+            float4 fh, fl;
+            if constexpr (SHARED) {
+                fh = vb[(2 * sidx) * 64];
+                fl = vb[(2 * sidx + 1) * 64];
+            } else {
+                fh = a[2 * sidx];
+                fl = a[2 * sidx + 1];
+            }
+            const bf16x8 vh = __builtin_bit_cast(bf16x8, fh), vl = __builtin_bit_cast(bf16x8, fl);
+            const bf16x8 eh = __builtin_bit_cast(bf16x8, e[2 * sidx]), el = __builtin_bit_cast(bf16x8, e[2 * sidx + 1]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, eh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, el, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, eh, acc, 0, 0, 0);
+        }
+        return acc;
+    };
+#ifdef PK_SCORE_ROLL
     // Round 4: ONE fragment buffer.  The registers of k-step s are re-requested for the next tile right after the three MFMAs
     // that read them: KQ instead of 2 KQ fragment registers (rank 50: 166 -> 136 VGPRs, rank 100: 243 -> 186), no
     // `s_waitcnt vmcnt(0)` + sixteen v_mov_b64 (a <- a_nxt) at the end of every tile — the compiler now waits per k-step with
@@ -594,25 +720,61 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
     // pass (70 -> 85 M users/s), no-prune 71 -> 75 M, pop^0.25 73 -> 80 M, flat-norm 61 -> 63 M users/s, pruned headline sweep
     // 0.378 -> 0.377 ms (it is not bound by the tile loop).  Forcing the rank-50 instance from 136 to 128 registers for four
     // waves per SIMD (PK_SCORE_ROLL=4 builds: 4 spills) made everything slower again (no-prune 75 -> 68 M): occupancy is not
-    // what this kernel lacks.  (The two-buffer loop of rounds 1-3: csrc/experiments/score_variants.hip.)
-    auto score_tile_roll = [&](float4(&a)[KQ], int next_tile) -> f32x16 {
+    // what this kernel lacks.  -DPK_SCORE_TWO_BUFFERS builds the old loop.
+    auto score_tile_roll = [&](float4(&a)[SHARED ? 1 : KQ], int next_tile) -> f32x16 {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
         const float4 *vp = Vp + ((int64_t)next_tile * KQ) * 64 + lane;
+#ifdef PK_SCORE_TWO_CHAINS     // kernel-tuning builds: even and odd k-steps accumulate into two independent chains (rank <= 64)
+        // (the rolling buffer left room for a second accumulator at three waves per SIMD: 152 registers.  MEASURED, full sweep of
+        // ML-20M-shaped: 1.38 -> 1.41 ms without pushes, 1.61 -> 1.67 with them — the dependent accumulator chain is not what
+        // the tile loop waits for either.  Not the default.)
+        constexpr bool TWO = (NSTEP >= 2 && NSTEP <= 4);
+        f32x16 acc1;
 #pragma unroll
-        for (int sidx = 0; sidx < NSTEP; ++sidx) {
+        for (int r = 0; r < 16; ++r) acc1[r] = 0.0f;
+#endif
+#pragma unroll
+        for (int sidx = 0; sidx < (SHARED ? 0 : NSTEP); ++sidx) {
             const bf16x8 vh = __builtin_bit_cast(bf16x8, a[2 * sidx]), vl = __builtin_bit_cast(bf16x8, a[2 * sidx + 1]);
             const bf16x8 eh = __builtin_bit_cast(bf16x8, e[2 * sidx]), el = __builtin_bit_cast(bf16x8, e[2 * sidx + 1]);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, eh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, el, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, eh, acc, 0, 0, 0);
+#ifdef PK_SCORE_DIAG       // kernel-tuning builds: ablate & 32 = no products (the fragments are still waited for), & 16 = no re-loads
+            if (ablate & 32) {
+                acc[sidx] += a[2 * sidx].x + a[2 * sidx + 1].y;
+            } else
+#endif
+            {
+#ifdef PK_SCORE_TWO_CHAINS
+                if (TWO && (sidx & 1)) {
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, eh, acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, el, acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, eh, acc1, 0, 0, 0);
+                } else
+#endif
+                {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, eh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, el, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, eh, acc, 0, 0, 0);
+                }
+            }
+#ifdef PK_SCORE_DIAG
+            if (ablate & 16) continue;
+#endif
             a[2 * sidx] = vp[(2 * sidx) * 64];
             a[2 * sidx + 1] = vp[(2 * sidx + 1) * 64];
         }
+#ifdef PK_SCORE_TWO_CHAINS
+        if (TWO) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += acc1[r];
+        }
+#endif
         return acc;
     };
+#endif
     if (first && boot_tiles > 0 && floor_state == nullptr && !(ablate & 8)) {
+        const unsigned long long prof_b0 = PROF_T();
         constexpr int BL = KC / 2;      // values kept per lane: the user's two lanes hold KC of them
         constexpr int BG = KC / 8;      // groups a lane's 16 scores of a tile are cut into (2, 4, 8): BL values after 4 tiles
         float bl[BL];
@@ -620,18 +782,42 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
         for (int i = 0; i < BL; ++i) bl[i] = -INFINITY;
         const int64_t sp0 = sp;
         const unsigned long long n0 = nxt, n1 = nxt2, n2 = nxt3;
-        float4 a_nxt[KQ];
-        load_frags((tile_begin < n_tiles) ? tile_begin : 0, a_nxt);
+        float4 a_nxt[SHARED ? 1 : KQ];
+        if constexpr (SHARED) {
+            stage_tile((tile_begin < n_tiles) ? tile_begin : 0, 0);
+            stage_wait();
+        } else {
+            load_frags((tile_begin < n_tiles) ? tile_begin : 0, a_nxt);
+        }
         unsigned m_nxt = 0u;
         if constexpr (DENSE) m_nxt = (tile_begin < dense_tiles) ? dense_row[(int64_t)tile_begin * 32] : 0u;
+        // (trip count uniform over the workgroup: SHARED has a barrier per tile)
         for (int i = 0, tile = tile_begin; i < boot_tiles && tile < tile_end; ++i, tile += S) {
-            {
+#ifndef PK_SCORE_ROLL
+            float4 a[SHARED ? 1 : KQ];
+#endif
+            if constexpr (SHARED) {
+                if (i + 1 < boot_tiles && tile + S < tile_end) stage_tile(tile + S, (i + 1) & 1);
+            }
+#ifndef PK_SCORE_ROLL
+            if constexpr (!SHARED) {
+#pragma unroll
+                for (int q = 0; q < KQ; ++q) a[q] = a_nxt[q];
+                load_frags((tile + S < tile_end) ? tile + S : tile, a_nxt);
+            }
+#endif
+            if (!SHARED || alive) {
                 if constexpr (DENSE) {
                     m_dense = m_nxt;
                     m_nxt = (tile + S < dense_tiles) ? dense_row[(int64_t)(tile + S) * 32] : 0u;
                 }
+#ifdef PK_SCORE_ROLL
                 f32x16 acc;
-                acc = score_tile_roll(a_nxt, (tile + S < tile_end) ? tile + S : tile);
+                if constexpr (SHARED) acc = score_tile(a_nxt, i & 1);
+                else acc = score_tile_roll(a_nxt, (tile + S < tile_end) ? tile + S : tile);
+#else
+                const f32x16 acc = score_tile(a, i & 1);
+#endif
                 const unsigned m2 = walk_mask(tile) >> (4 * hi);
 #pragma unroll
                 for (int g = 0; g < BG; ++g) {
@@ -647,6 +833,7 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
                     }
                 }
             }
+            if constexpr (SHARED) stage_wait();
         }
         // the (KC / 2)-th value of each lane: together at least KC items of the user score that much
         float t0 = bl[KC / 2 - 1];
@@ -661,6 +848,7 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
         nxt = n0;
         nxt2 = n1;
         nxt3 = n2;
+        PROF_ADD(5, prof_b0);
     }
     {
         // One tile per iteration; the fragments of the NEXT tile are requested before this tile's
@@ -675,43 +863,51 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
         // compiler drains vmcnt(0) at the loop head, which exposes the latency of the late loads.
         // Forcing five waves per SIMD (amdgpu_waves_per_eu: 96 VGPRs, 12 spilled) on the pruned sweep: 3.47 vs
         // 3.29 ms; four (120 VGPRs, no spill) is what the register allocator picks unprompted.
-        {
-        float4 a_nxt[KQ];
-        load_frags((tile_begin < n_tiles) ? tile_begin : 0, a_nxt);
-        unsigned m_nxt = 0u;
-        if constexpr (DENSE) m_nxt = (tile_begin < dense_tiles) ? dense_row[(int64_t)tile_begin * 32] : 0u;
-        float tb = prune ? tile_bound[(tile_begin < n_tiles) ? tile_begin : 0] : 0.0f;
-        int step = 0;
-        for (int tile = tile_begin; tile < tile_end; tile += S, ++step) {
-            if (prune) {
-                // can any item from this tile on still enter a list of this wave?
-                const bool open = en * tb > tau;
-                const unsigned long long ob = __ballot(open);
-                if (ob == 0ull) {
-                    pruned = true;
-                    exit_tile = tile;
-                    break;
-                } else {
-                    // tau is only refreshed by a flush; the last few users that keep the wave in the sweep
-                    // get their pending ring entries merged so that their tau is exact (checked every 8 tiles)
+#if defined(PK_SCORE_ROLL) && defined(PK_SCORE_DEPTH2)
+        if constexpr (!SHARED) {
+            // Round 4, depth 2 (PK_SCORE_DEPTH2 builds only): TWO rolling fragment buffers that alternate from tile to tile (the
+            // tile body is instantiated twice; no copies): the registers a k-step of tile t has just read are re-requested for
+            // tile t + 2, so every fragment load has TWO tiles of compute to land in and a wave keeps 16 KB instead of 8 KB in
+            // flight (168 VGPRs, three waves per SIMD).  MEASURED against the one-buffer loop: pruned headline sweep 0.377 ->
+            // 0.355 ms, but no-prune 74 -> 69 M users/s, flat-norm 63.5 -> 60.4 M, pop^0.25 79 -> 77 M, and the library grows by
+            // half (two copies of the push / flush code per instance): the full sweeps already move their 30 GB of fragments at
+            // the ~17 TB/s the L1 path gives (the ceiling of the SpMM gathers as well) — more requests in flight only queue.
+            // Not the default.
+            float4 aA[KQ], aB[KQ];
+            {
+                const int t0 = (tile_begin < n_tiles) ? tile_begin : 0;
+                const int t1 = (tile_begin + S < tile_end) ? tile_begin + S : t0;
+                load_frags(t0, aA);
+                load_frags(t1, aB);
+            }
+            unsigned m_nxt = 0u, m_nxt2 = 0u;
+            if constexpr (DENSE) {
+                m_nxt = (tile_begin < dense_tiles) ? dense_row[(int64_t)tile_begin * 32] : 0u;
+                m_nxt2 = (tile_begin + S < dense_tiles) ? dense_row[(int64_t)(tile_begin + S) * 32] : 0u;
+            }
+            float tb = prune ? tile_bound[(tile_begin < n_tiles) ? tile_begin : 0] : 0.0f;
+            PROF_ADD(4, prof_k0);
+            auto tile_body = [&](int tile, int step, float4(&a)[KQ]) -> bool {
+                if (prune) {
+                    const bool open = en * tb > tau;
+                    const unsigned long long ob = __ballot(open);
+                    if (ob == 0ull) {
+                        pruned = true;
+                        exit_tile = tile;
+                        return false;
+                    }
                     if (((STRIDED ? step : tile) & 7) == 7 && __popcll(ob) <= 16) {
                         const unsigned long long pend = __ballot(cnt > 0);
                         flush_set((unsigned)(ob | (ob >> 32)) & (unsigned)(pend | (pend >> 32)));
                     }
-                    tb = tile_bound[(tile + S < n_tiles) ? tile + S : tile];   // suffix maximum: covers my later tiles
+                    tb = tile_bound[(tile + S < n_tiles) ? tile + S : tile];
                 }
-            }
-            {
                 if constexpr (DENSE) {
                     m_dense = m_nxt;
-                    m_nxt = (tile + S < dense_tiles) ? dense_row[(int64_t)(tile + S) * 32] : 0u;
+                    m_nxt = m_nxt2;
+                    m_nxt2 = (tile + 2 * S < dense_tiles) ? dense_row[(int64_t)(tile + 2 * S) * 32] : 0u;
                 }
-                f32x16 acc;
-                acc = score_tile_roll(a_nxt, (tile + S < tile_end) ? tile + S : tile);
-                // The list cursor must advance every tile; the mask itself is only needed when some
-                // RAW score beats the threshold (f32 MFMA shares the SIMD's FP32 lanes with the VALU, so
-                // every VALU instruction here is paid in MFMA time: keep the common path to
-                // 8 v_max3 + 1 compare and mask lazily).
+                const f32x16 acc = score_tile_roll(a, (tile + 2 * S < tile_end) ? tile + 2 * S : tile);
                 const unsigned mask = walk_mask(tile);
                 float m_all = fmaxf(acc[0], acc[1]);
 #pragma unroll
@@ -733,9 +929,137 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
                     }
                     if (__any(m > tau)) push_candidates(sc, tile * 32);
                 }
+                return true;
+            };
+            int step = 0;
+            for (int tile = tile_begin; tile < tile_end;) {
+                if (!tile_body(tile, step, aA)) break;
+                tile += S;
+                ++step;
+                if (tile >= tile_end) break;
+                if (!tile_body(tile, step, aB)) break;
+                tile += S;
+                ++step;
+            }
+        } else
+#endif
+        {
+        float4 a_nxt[SHARED ? 1 : KQ];
+        // SHARED: who still sweeps is counted per iteration in one of three LDS counters (waves that stop in iteration
+        // `it` add to s_cnt[it % 3] before its barrier, everybody reads it behind the barrier, wave 0 clears the next one
+        // while nobody can touch it): the decision to leave the loop is the same in every wave
+        __shared__ int s_cnt[4];
+        int dead = 0;
+        if constexpr (SHARED) {
+            if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+            __syncthreads();
+            if (!alive && lane == 0) atomicAdd(&s_cnt[3], 1);
+            stage_tile((tile_begin < n_tiles) ? tile_begin : 0, 0);
+            stage_wait();
+            dead = s_cnt[3];
+        } else {
+            load_frags((tile_begin < n_tiles) ? tile_begin : 0, a_nxt);
+        }
+        unsigned m_nxt = 0u;
+        if constexpr (DENSE) m_nxt = (tile_begin < dense_tiles) ? dense_row[(int64_t)tile_begin * 32] : 0u;
+        float tb = prune ? tile_bound[(tile_begin < n_tiles) ? tile_begin : 0] : 0.0f;
+        PROF_ADD(4, prof_k0);
+        int step = 0;
+        for (int tile = tile_begin; tile < tile_end && dead < NW; tile += S, ++step) {
+            if constexpr (SHARED) {
+                if (threadIdx.x == 0) s_cnt[(step + 1) % 3] = 0;
+                if (tile + S < tile_end) stage_tile(tile + S, (step + 1) & 1);
+            }
+            if ((!SHARED || alive) && prune) {
+                // can any item from this tile on still enter a list of this wave?
+                const bool open = en * tb > tau;
+                const unsigned long long ob = __ballot(open);
+                if (ob == 0ull) {
+                    pruned = true;
+                    exit_tile = tile;
+                    if constexpr (SHARED) {
+                        alive = false;      // keeps staging and meeting the barriers until the whole workgroup is done
+                        if (lane == 0) atomicAdd(&s_cnt[step % 3], 1);
+                    } else {
+                        break;
+                    }
+                } else {
+                    // tau is only refreshed by a flush; the last few users that keep the wave in the sweep
+                    // get their pending ring entries merged so that their tau is exact (checked every 8 tiles)
+                    if (((STRIDED ? step : tile) & 7) == 7 && __popcll(ob) <= 16) {
+                        const unsigned long long pend = __ballot(cnt > 0);
+                        flush_set((unsigned)(ob | (ob >> 32)) & (unsigned)(pend | (pend >> 32)));
+                    }
+                    tb = tile_bound[(tile + S < n_tiles) ? tile + S : tile];   // suffix maximum: covers my later tiles
+                }
+            }
+#ifndef PK_SCORE_ROLL
+            float4 a[SHARED ? 1 : KQ];
+            if constexpr (!SHARED) {
+#pragma unroll
+                for (int q = 0; q < KQ; ++q) a[q] = a_nxt[q];
+                load_frags((tile + S < tile_end) ? tile + S : tile, a_nxt);
+            }
+#endif
+            if (!SHARED || alive) {
+                if constexpr (DENSE) {
+                    m_dense = m_nxt;
+                    m_nxt = (tile + S < dense_tiles) ? dense_row[(int64_t)(tile + S) * 32] : 0u;
+                }
+#ifdef PK_SCORE_PROFILE2
+                const unsigned long long prof_m0 = PROF_T();
+#endif
+#ifdef PK_SCORE_ROLL
+                f32x16 acc;
+                if constexpr (SHARED) acc = score_tile(a_nxt, step & 1);
+                else acc = score_tile_roll(a_nxt, (tile + S < tile_end) ? tile + S : tile);
+#else
+                const f32x16 acc = score_tile(a, step & 1);
+#endif
+#ifdef PK_SCORE_PROFILE2
+                asm volatile("" ::"v"(acc[0]), "v"(acc[15]));     // the products are done before the clock is read
+                PROF_ADD(1, prof_m0);
+#endif
+                // The list cursor must advance every tile; the mask itself is only needed when some
+                // RAW score beats the threshold (f32 MFMA shares the SIMD's FP32 lanes with the VALU, so
+                // every VALU instruction here is paid in MFMA time: keep the common path to
+                // 8 v_max3 + 1 compare and mask lazily).
+                const unsigned long long prof_w0 = PROF_T();
+                const unsigned mask = walk_mask(tile);
+                PROF_ADD(2, prof_w0);
+                float m_all = fmaxf(acc[0], acc[1]);
+#pragma unroll
+                for (int r = 2; r < 16; ++r) m_all = fmaxf(m_all, acc[r]);
+                if (!(ablate & 2) && __any(m_all > tau)) {
+                    const unsigned long long prof_p0 = PROF_T();
+                    float sc[16];
+                    float m = m_all;
+                    if (__any(mask != 0)) {
+                        const unsigned m2 = mask >> (4 * hi);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            sc[r] = (m2 & (1u << ((r & 3) + 8 * (r >> 2)))) ? -INFINITY : acc[r];
+                        m = fmaxf(sc[0], sc[1]);
+#pragma unroll
+                        for (int r = 2; r < 16; ++r) m = fmaxf(m, sc[r]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sc[r] = acc[r];
+                    }
+                    if (__any(m > tau)) push_candidates(sc, tile * 32);
+                    PROF_ADD(3, prof_p0);
+                }
+            }
+            if constexpr (SHARED) {
+                stage_wait();
+                dead += s_cnt[step % 3];
             }
         }
         }
+    }
+    if constexpr (SHARED) {
+        // nothing to write for a wave without users or one whose group had left the sweep before this launch
+        if (!participate || (!alive && !pruned)) return;
     }
 
     if (!last && !pruned) {
@@ -754,6 +1078,9 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
                 my_score[s] = __uint_as_float(r.x);
                 my_idx[s] = (int)r.y;
             }
+        PROF_INC(7, (tile_end - tile_begin + S - 1) / S);
+        PROF_ADD(0, prof_k0);
+        PROF_FLUSH();
         return;
     }
     // final merge of whatever is left in the rings
@@ -781,6 +1108,9 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         if (hi == 0 && tau_floor > -INFINITY && my_idx[ul * KC + KC - 1] < 0) my_idx[ul * KC + KC - 1] = PK_IDX_FLOOR;
     }
+    PROF_INC(7, (exit_tile - tile_begin + S - 1) / S);
+    PROF_ADD(0, prof_k0);
+    PROF_FLUSH();
     {
         // finished (possibly early): later chunk launches must not touch this group again; sp records
         // the tile at which the group left the sweep (pk_score_state layout: see polara_hip.h)
@@ -789,6 +1119,439 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
         ls.tau = tau;
         ls.cnt = PK_LANE_DONE;
         *my_state = ls;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// score_candidates_pair_kernel (round 4): TWO user groups per wave.
+// The dense regimes of the sweep are bound by the fragment loads, not by the matrix cores: a PK_SCORE_DIAG build of the
+// full ML-20M-shaped sweep (no pushes) takes 1.98 ms as it is, 1.18 ms without the fragment re-loads, 1.79 ms without the
+// PRODUCTS (loads still waited for) and 0.83 ms without either (tools/probes/sweep_floor.py, PK_FLOOR_DIAG) — 3.6 M
+// tile-waves x 8 KB = 30 GB through the L1 path at ~17 TB/s, the same ceiling the SpMM gathers hit (64 lanes x 16 B per
+// load instruction).  More waves do not help (four forced waves: slower), staging tiles in LDS costs a barrier per tile
+// (round 3); what halves the bytes per product is using every loaded fragment for TWO groups of 32 users: this kernel.
+// A wave owns groups 2 w and 2 w + 1 (adjacent in activity order: they leave the sweep at similar tiles); per k-step six
+// MFMAs on two independent accumulator chains, then the step's fragment registers are re-requested for the next tile
+// (the rolling buffer of score_tile_roll); selection state, rings and lists exist once per group (GS), the epilogue of a
+// tile runs once per group that is still sweeping.  Single sweeps with the lists in LDS and KC = 16 (top-10 lists: two
+// groups' rings and lists are 16 KB per wave, 64 KB per workgroup; KC = 32 would leave one wave per SIMD), same parked
+// state and list layout as score_candidates_kernel, same scores bit for bit (the MFMA sequence of a group is unchanged).
+// MEASURED (bench.py, ML-20M-shaped, one group -> two groups per wave; 240 VGPRs, two waves per SIMD): pruned headline
+// sweep 0.377 -> 0.617 ms, flat-norm catalogue 63.5 -> 50.2 M users/s, no-prune 74 -> 71 M, pop^0.25 79 -> 71 M: SLOWER in
+// every regime — half the fragment bytes per product buy nothing, so the "loads" of the diagnostic build are waiting
+// time that three free-running waves overlap better than two fat ones, not bytes.  OPT-IN (PK_SCORE_PAIR=1), kept as the
+// record of the experiment like the LDS-staged instance; lists identical (tests/test_gpu_kernels.py).
+// ------------------------------------------------------------------------------------------
+template <int NSTEP, int KC, bool DENSE>
+__global__ __launch_bounds__(256) void score_candidates_pair_kernel(
+    const float4 *__restrict__ Vp, const float4 *__restrict__ Ep, int64_t n_users, int n_items,
+    int n_tiles, int split_tiles, int chunk_begin, int chunk_tiles,
+    const int64_t *__restrict__ seen_ptr, const unsigned long long *__restrict__ seen_tiles,
+    const int32_t *__restrict__ seen_ntiles,
+    float *__restrict__ cand_score, int32_t *__restrict__ cand_idx,
+    LaneState *__restrict__ st_lane, uint2 *__restrict__ st_ring,
+    const float *__restrict__ user_bound, const float *__restrict__ tile_bound, int ablate, SeenDense dense,
+    int slot_base, int boot_tiles) {
+    constexpr int KQ = 2 * NSTEP;
+    static_assert(KC == 16 && pk_top_in_lds(NSTEP, KC), "pair kernel: top-10 lists (KC = 16) in LDS");
+    constexpr int RG = pk_ring_rows(KC);
+    constexpr int NG = 2, NW = 4;
+    extern __shared__ __attribute__((aligned(16))) uint2 pk_score_lds[];      // [NW * NG][RG][64] rings, then [NW * NG][32 * KC] lists
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t n_groups = (n_users + 31) / 32;
+    const int tile_begin = chunk_begin;
+    const int tile_stop = (chunk_begin + chunk_tiles < split_tiles) ? chunk_begin + chunk_tiles : n_tiles;
+    const int tile_end = (tile_stop < n_tiles) ? tile_stop : n_tiles;
+    const bool first = (chunk_begin == 0);
+    const bool last = (tile_stop >= n_tiles);
+    if (!first && tile_begin >= n_tiles) return;
+    const int ul = lane & 31, hi = lane >> 5;
+    const bool prune = (user_bound != nullptr && tile_bound != nullptr) && !(ablate & 4);
+    const int dense_tiles = (DENSE && seen_ptr != nullptr) ? dense.tiles : 0;
+
+    struct GS {
+        float4 e[KQ];
+        int64_t sp, se;
+        unsigned long long nxt, nxt2, nxt3;
+        float tau, tau_floor, en;
+        int cnt, exit_tile;
+        bool live, alive, pruned, has_seen;      // live: takes part in this launch; alive: still sweeping
+        float *my_score;
+        int32_t *my_idx;
+        LaneState *my_state;
+        uint2 *my_ring_state;
+        const unsigned *dense_row;
+        unsigned m_dense, m_nxt;
+        uint2 (*ring)[64];
+        uint2 *top;
+    };
+    GS gs[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        GS &s = gs[g];
+        const int64_t group_raw = ((int64_t)blockIdx.x * NW + wave) * NG + g;
+        s.live = group_raw * 32 < n_users;
+        const int64_t group = s.live ? group_raw : 0;
+        const int64_t user = group * 32 + ul;
+        const int64_t slot = (int64_t)slot_base * n_groups + group;
+        s.my_score = cand_score + slot * 32 * KC;
+        s.my_idx = cand_idx + slot * 32 * KC;
+        s.my_state = st_lane + slot * 64 + lane;
+        s.my_ring_state = st_ring + slot * (RING * 64);
+        s.ring = reinterpret_cast<uint2(*)[64]>(pk_score_lds + (wave * NG + g) * (RG * 64));
+        s.top = pk_score_lds + NW * NG * RG * 64 + (wave * NG + g) * (32 * KC);
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) s.e[q] = Ep[(group * KQ + q) * 64 + lane];
+        s.sp = s.se = 0;
+        s.nxt = s.nxt2 = s.nxt3 = PK_TILE_NONE;
+        s.tau = -INFINITY;
+        s.tau_floor = -INFINITY;
+        s.cnt = 0;
+        s.en = (prune && s.live && user < n_users) ? user_bound[user] : -1.0f;
+        s.pruned = false;
+        s.exit_tile = tile_end;
+        s.has_seen = (seen_ptr != nullptr && s.live && user < n_users);
+        if (s.has_seen) {
+            s.sp = seen_ptr[user];
+            s.se = s.sp + seen_ntiles[user];
+        }
+        s.dense_row = dense_tiles ? dense.mask + ((int64_t)group * dense_tiles) * 32 + ul : nullptr;
+        s.m_dense = s.m_nxt = 0u;
+        if (DENSE && first && s.has_seen && dense_tiles) s.sp += dense.skip[user];
+        s.alive = s.live;
+        if (s.live) {
+            if (first) {
+                for (int t = lane; t < 32 * KC; t += 64) s.top[t] = make_uint2(__float_as_uint(-INFINITY), 0xffffffffu);
+            } else {
+                const LaneState ls = *s.my_state;
+                if (ls.cnt == PK_LANE_DONE) {              // wave-uniform: this group was pruned in an earlier launch
+                    s.live = s.alive = false;
+                } else {
+                    for (int t = lane; t < 32 * KC; t += 64) s.top[t] = make_uint2(__float_as_uint(s.my_score[t]), (unsigned)s.my_idx[t]);
+                    if (s.has_seen) s.sp = ls.sp;
+                    s.tau = ls.tau;
+                    s.tau_floor = fmaxf(s.tau_floor, s.tau);
+                    s.cnt = ls.cnt;
+                    const int cmax = __builtin_amdgcn_readfirstlane((int)__reduce_max_sync(~0ull, s.cnt));
+                    for (int i = 0; i < cmax; ++i) s.ring[i][lane] = s.my_ring_state[i * 64 + lane];
+                }
+            }
+        }
+        if (s.has_seen && s.live) {
+            if (s.sp < s.se) s.nxt = seen_tiles[s.sp];
+            if (s.sp + 1 < s.se) s.nxt2 = seen_tiles[s.sp + 1];
+            if (s.sp + 2 < s.se) s.nxt3 = seen_tiles[s.sp + 2];
+        }
+    }
+    if (!gs[0].live && !gs[1].live) return;
+
+    // users x (lanes 0..31) and y (lanes 32..63; y < 0: nobody) of group s merged in one 32-wide sort each (flush_pair of
+    // score_candidates_kernel, state through s)
+    auto flush_pair = [&](GS &s, int x, int y) {
+        __builtin_amdgcn_wave_barrier();
+        const int t = lane & 31;
+        const int yy = (y >= 0) ? y : x;
+        const int cx_lo = __builtin_amdgcn_readlane(s.cnt, x), cx_hi = __builtin_amdgcn_readlane(s.cnt, x + 32);
+        const int cy_lo = __builtin_amdgcn_readlane(s.cnt, yy), cy_hi = __builtin_amdgcn_readlane(s.cnt, yy + 32);
+        const int u = hi ? yy : x;
+        const int c_lo = hi ? cy_lo : cx_lo, c_hi = hi ? cy_hi : cx_hi;
+        const bool act = !hi || y >= 0;
+        float k = -INFINITY;
+        int v = PK_IDX_NONE;
+        if (act) {
+            if (t < KC) {
+                const uint2 r = s.top[u * KC + t];
+                if ((int)r.y >= 0) {
+                    k = __uint_as_float(r.x);
+                    v = (int)r.y;
+                }
+            } else if (t < KC + RG) {
+                if (t - KC < c_lo) {
+                    const uint2 r = s.ring[t - KC][u];
+                    k = __uint_as_float(r.x);
+                    v = (int)r.y;
+                }
+            } else if (t - KC - RG < c_hi) {
+                const uint2 r = s.ring[t - KC - RG][u + 32];
+                k = __uint_as_float(r.x);
+                v = (int)r.y;
+            }
+        }
+        unsigned key = (pk_float_order(k) & ~31u) | (unsigned)t;
+        pk_sort32_half_levels<32>(key);
+        const int src = (lane & 32) | (int)(key & 31u);
+        k = __shfl(k, src, 64);
+        v = __shfl(v, src, 64);
+        if (act && t < KC) s.top[u * KC + t] = make_uint2(__float_as_uint(k), (unsigned)((v == PK_IDX_NONE) ? -1 : v));
+        const float tx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(k), KC - 1));
+        const float ty = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(k), 32 + KC - 1));
+        if (ul == x) {
+            s.tau = fmaxf(tx, s.tau_floor);
+            s.cnt = 0;
+        }
+        if (y >= 0 && ul == y) {
+            s.tau = fmaxf(ty, s.tau_floor);
+            s.cnt = 0;
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto flush_set = [&](GS &s, unsigned um) {
+        while (um) {
+            const int x = __builtin_ctz(um);
+            um &= um - 1;
+            int y = -1;
+            if (um) {
+                y = __builtin_ctz(um);
+                um &= um - 1;
+            }
+            flush_pair(s, x, y);
+        }
+    };
+    auto walk_mask = [&](GS &s, int tile) -> unsigned {
+        const int j0 = tile * 32, jend = j0 + 32;
+        unsigned mask = 0;
+        if (ablate & 1) return 0u;
+        if constexpr (DENSE) {
+            if (tile < dense_tiles) {
+                mask = s.m_dense;
+                if (jend > n_items) mask |= ~0u << (n_items - j0);
+                return mask;
+            }
+        }
+        const bool hit = (unsigned)(s.nxt >> 32) == (unsigned)tile;
+        if (__any(hit)) {
+            if (hit) {
+                mask = (unsigned)s.nxt;
+                ++s.sp;
+                s.nxt = s.nxt2;
+                s.nxt2 = s.nxt3;
+                s.nxt3 = (s.sp + 2 < s.se) ? seen_tiles[s.sp + 2] : PK_TILE_NONE;
+            }
+        }
+        if (jend > n_items) mask |= ~0u << (n_items - j0);
+        return mask;
+    };
+    auto push_candidates = [&](GS &s, const float(&acc)[16], int j0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            bool c = acc[r] > s.tau;
+            if (__any(c)) {
+                if (__any(c && s.cnt == RG)) {
+                    const unsigned long long full = __ballot(s.cnt == RG);
+                    unsigned um = (unsigned)(full | (full >> 32));
+                    if (__builtin_popcount(um) & 1) {
+                        const unsigned long long part = __ballot(2 * s.cnt >= RG);
+                        const unsigned cand = (unsigned)(part | (part >> 32)) & ~um;
+                        if (cand) um |= 1u << __builtin_ctz(cand);
+                    }
+                    flush_set(s, um);
+                    c = acc[r] > s.tau;
+                }
+                if (c) {
+                    s.ring[s.cnt][lane] = make_uint2(__float_as_uint(acc[r]), (unsigned)(j0 + (r & 3) + 8 * (r >> 2) + 4 * hi));
+                    ++s.cnt;
+                }
+            }
+        }
+    };
+    // both groups' score tiles of one step: per k-step three MFMAs per group (two independent accumulator chains), then
+    // the step's fragment registers are re-requested for the next tile
+    float4 a[KQ];
+    auto score_pair = [&](int next_tile, f32x16 &acc0, f32x16 &acc1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc0[r] = 0.0f;
+            acc1[r] = 0.0f;
+        }
+        const float4 *vp = Vp + ((int64_t)next_tile * KQ) * 64 + lane;
+#pragma unroll
+        for (int sidx = 0; sidx < NSTEP; ++sidx) {
+            const bf16x8 vh = __builtin_bit_cast(bf16x8, a[2 * sidx]), vl = __builtin_bit_cast(bf16x8, a[2 * sidx + 1]);
+            const bf16x8 eh0 = __builtin_bit_cast(bf16x8, gs[0].e[2 * sidx]), el0 = __builtin_bit_cast(bf16x8, gs[0].e[2 * sidx + 1]);
+            const bf16x8 eh1 = __builtin_bit_cast(bf16x8, gs[1].e[2 * sidx]), el1 = __builtin_bit_cast(bf16x8, gs[1].e[2 * sidx + 1]);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, eh0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, eh1, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, el0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, el1, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, eh0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, eh1, acc1, 0, 0, 0);
+            a[2 * sidx] = vp[(2 * sidx) * 64];
+            a[2 * sidx + 1] = vp[(2 * sidx + 1) * 64];
+        }
+    };
+    auto load_frags = [&](int tile) {
+        const float4 *vp = Vp + ((int64_t)tile * KQ) * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) a[q] = vp[q * 64];
+    };
+
+    // ---- threshold bootstrap (see score_candidates_kernel): the first boot_tiles tiles scored once without selecting ----
+    if (first && boot_tiles > 0 && !(ablate & 8)) {
+        constexpr int BL = KC / 2, BG = KC / 8;
+        float bl[NG][BL];
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int i = 0; i < BL; ++i) bl[g][i] = -INFINITY;
+        int64_t sp0[NG];
+        unsigned long long n0[NG], n1[NG], n2[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            sp0[g] = gs[g].sp;
+            n0[g] = gs[g].nxt;
+            n1[g] = gs[g].nxt2;
+            n2[g] = gs[g].nxt3;
+            if constexpr (DENSE) gs[g].m_nxt = (gs[g].live && tile_begin < dense_tiles) ? gs[g].dense_row[(int64_t)tile_begin * 32] : 0u;
+        }
+        load_frags((tile_begin < n_tiles) ? tile_begin : 0);
+        for (int i = 0, tile = tile_begin; i < boot_tiles && tile < tile_end; ++i, ++tile) {
+            if constexpr (DENSE) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    gs[g].m_dense = gs[g].m_nxt;
+                    gs[g].m_nxt = (gs[g].live && tile + 1 < dense_tiles) ? gs[g].dense_row[(int64_t)(tile + 1) * 32] : 0u;
+                }
+            }
+            f32x16 acc[NG];
+            score_pair((tile + 1 < tile_end) ? tile + 1 : tile, acc[0], acc[1]);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                GS &s = gs[g];
+                if (!s.live) continue;
+                const unsigned m2 = walk_mask(s, tile) >> (4 * hi);
+#pragma unroll
+                for (int gg = 0; gg < BG; ++gg) {
+                    float x = -INFINITY;
+#pragma unroll
+                    for (int r = gg * (16 / BG); r < (gg + 1) * (16 / BG); ++r)
+                        x = fmaxf(x, (m2 & (1u << ((r & 3) + 8 * (r >> 2)))) ? -INFINITY : acc[g][r]);
+#pragma unroll
+                    for (int i2 = 0; i2 < BL; ++i2) {
+                        const float up = fmaxf(bl[g][i2], x);
+                        x = fminf(bl[g][i2], x);
+                        bl[g][i2] = up;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            GS &s = gs[g];
+            float t0 = bl[g][KC / 2 - 1];
+            t0 = fminf(t0, __int_as_float(pk_lane_xor<32>(__float_as_int(t0))));
+            if (t0 > -INFINITY) {
+                t0 = fminf(t0 - fabsf(t0) * 2.4e-7f, t0 - 1e-37f);
+                s.tau_floor = fmaxf(s.tau_floor, t0);
+                s.tau = fmaxf(s.tau, s.tau_floor);
+            }
+            s.sp = sp0[g];
+            s.nxt = n0[g];
+            s.nxt2 = n1[g];
+            s.nxt3 = n2[g];
+        }
+    }
+    // ---- the sweep ------------------------------------------------------------------------------------------------------------
+    load_frags((tile_begin < n_tiles) ? tile_begin : 0);
+    if constexpr (DENSE) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) gs[g].m_nxt = (gs[g].live && tile_begin < dense_tiles) ? gs[g].dense_row[(int64_t)tile_begin * 32] : 0u;
+    }
+    float tb = prune ? tile_bound[(tile_begin < n_tiles) ? tile_begin : 0] : 0.0f;
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
+        if (prune) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                GS &s = gs[g];
+                if (!s.alive) continue;
+                const bool open = s.en * tb > s.tau;
+                const unsigned long long ob = __ballot(open);
+                if (ob == 0ull) {
+                    s.pruned = true;
+                    s.exit_tile = tile;
+                    s.alive = false;
+                } else if ((tile & 7) == 7 && __popcll(ob) <= 16) {
+                    const unsigned long long pend = __ballot(s.cnt > 0);
+                    flush_set(s, (unsigned)(ob | (ob >> 32)) & (unsigned)(pend | (pend >> 32)));
+                }
+            }
+            if (!gs[0].alive && !gs[1].alive) break;
+            tb = tile_bound[(tile + 1 < n_tiles) ? tile + 1 : tile];
+        }
+        if constexpr (DENSE) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                gs[g].m_dense = gs[g].m_nxt;
+                gs[g].m_nxt = (gs[g].live && tile + 1 < dense_tiles) ? gs[g].dense_row[(int64_t)(tile + 1) * 32] : 0u;
+            }
+        }
+        f32x16 acc[NG];
+        score_pair((tile + 1 < tile_end) ? tile + 1 : tile, acc[0], acc[1]);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            GS &s = gs[g];
+            if (!s.alive) continue;
+            const unsigned mask = walk_mask(s, tile);
+            float m_all = fmaxf(acc[g][0], acc[g][1]);
+#pragma unroll
+            for (int r = 2; r < 16; ++r) m_all = fmaxf(m_all, acc[g][r]);
+            if (!(ablate & 2) && __any(m_all > s.tau)) {
+                float sc[16];
+                float m = m_all;
+                if (__any(mask != 0)) {
+                    const unsigned m2 = mask >> (4 * hi);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sc[r] = (m2 & (1u << ((r & 3) + 8 * (r >> 2)))) ? -INFINITY : acc[g][r];
+                    m = fmaxf(sc[0], sc[1]);
+#pragma unroll
+                    for (int r = 2; r < 16; ++r) m = fmaxf(m, sc[r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sc[r] = acc[g][r];
+                }
+                if (__any(m > s.tau)) push_candidates(s, sc, tile * 32);
+            }
+        }
+    }
+    // ---- end of the launch: park, or merge what is left and write the lists ----------------------------------------------------
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        GS &s = gs[g];
+        if (!s.live) continue;
+        if (!last && !s.pruned) {
+            LaneState ls;
+            ls.sp = s.sp;
+            ls.tau = s.tau;
+            ls.cnt = s.cnt;
+            *s.my_state = ls;
+            const int cmax = __builtin_amdgcn_readfirstlane((int)__reduce_max_sync(~0ull, s.cnt));
+            __builtin_amdgcn_wave_barrier();
+            for (int i = 0; i < cmax; ++i) s.my_ring_state[i * 64 + lane] = s.ring[i][lane];
+            for (int t = lane; t < 32 * KC; t += 64) {
+                const uint2 r = s.top[t];
+                s.my_score[t] = __uint_as_float(r.x);
+                s.my_idx[t] = (int)r.y;
+            }
+            continue;
+        }
+        {
+            const unsigned long long some = __ballot(s.cnt > 0);
+            flush_set(s, (unsigned)(some | (some >> 32)));
+        }
+        const unsigned long long floored = __ballot(s.tau_floor > -INFINITY);
+        __builtin_amdgcn_wave_barrier();
+        for (int t = lane; t < 32 * KC; t += 64) {
+            const uint2 r = s.top[t];
+            int iv = (int)r.y;
+            if ((t % KC) == KC - 1 && iv < 0 && ((floored >> (t / KC)) & 1ull)) iv = PK_IDX_FLOOR;
+            s.my_score[t] = __uint_as_float(r.x);
+            s.my_idx[t] = iv;
+        }
+        LaneState ls;
+        ls.sp = s.exit_tile;
+        ls.tau = s.tau;
+        ls.cnt = PK_LANE_DONE;
+        *s.my_state = ls;
     }
 }
 
@@ -1186,6 +1949,8 @@ struct SweepPhase {
     int slot_base;                  // first list / state slot of this launch sequence (phase 2: 1, the head owns slot 0)
     const LaneState *floor_state;   // phase 2: the head's lane records (threshold to start from), else nullptr
     int boot_tiles;                 // tiles of the threshold bootstrap in front of a sweep that starts cold (0: none)
+    int shared;                     // single sweeps: the eight-wave workgroup with the V tiles staged in LDS
+    int pair;                       // single sweeps with KC = 16: two user groups per wave (score_candidates_pair_kernel)
 };
 
 template <int NSTEP>
@@ -1226,6 +1991,40 @@ static int launch_candidates_n(hipStream_t st, int KC, int ablate, dim3 grid, co
             attr_set.done();                                                                                       \
         }                                                                                                       \
     }                                                                                                           \
+    if constexpr (pk_shared_ok(NSTEP, KCV)) {                                                                   \
+        if (ph.shared && grid.y == 1 && ph.floor_state == nullptr) {                                            \
+            static PkDeviceOnce attr_set_s;                                                                        \
+            if (attr_set_s.pending()) {                                                                                  \
+                hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(&score_candidates_kernel<NSTEP, KCV, false, DENSE_OK, true>), \
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)pk_score_lds_bytes_shared(NSTEP, KCV)); \
+                if (e2 != hipSuccess) {                                                                         \
+                    pk_set_error("pk_score_candidates_f32: cannot raise the LDS limit (shared): %s", hipGetErrorString(e2)); \
+                    return PK_E_LAUNCH;                                                                         \
+                }                                                                                               \
+                attr_set_s.done();                                                                                 \
+            }                                                                                                   \
+            hipLaunchKernelGGL((score_candidates_kernel<NSTEP, KCV, false, DENSE_OK, true>), dim3((grid.x * 4 + pk_shared_waves(KCV) - 1) / pk_shared_waves(KCV)), dim3(64 * pk_shared_waves(KCV)), \
+                               pk_score_lds_bytes_shared(NSTEP, KCV), st, Vp, Ep, n_users,                      \
+                               n_items, n_tiles, split_tiles, chunk_begin, chunk_tiles, seen_ptr, seen_tiles, seen_ntiles, cs, ci, st_lane, st_ring,  \
+                               user_bound, tile_bound, ablate, dn, 0, ph.slot_base, nullptr, ph.boot_tiles);    \
+            continue;                                                                                           \
+        }                                                                                                       \
+    }                                                                                                           \
+    if constexpr (KCV == 16 && NSTEP <= 8) {                                                                    \
+        if (ph.pair && grid.y == 1 && ph.floor_state == nullptr) {                                              \
+            const dim3 pgrid((grid.x + 1) / 2);                                                                 \
+            const size_t plds = 2 * pk_score_lds_bytes(NSTEP, KCV);                                             \
+            if (use_dense)                                                                                      \
+                hipLaunchKernelGGL((score_candidates_pair_kernel<NSTEP, KCV, true>), pgrid, dim3(256), plds, st, Vp, Ep, n_users, \
+                                   n_items, n_tiles, split_tiles, chunk_begin, chunk_tiles, seen_ptr, seen_tiles, seen_ntiles, cs, ci, st_lane, st_ring, \
+                                   user_bound, tile_bound, ablate, dn, ph.slot_base, ph.boot_tiles);            \
+            else                                                                                                \
+                hipLaunchKernelGGL((score_candidates_pair_kernel<NSTEP, KCV, false>), pgrid, dim3(256), plds, st, Vp, Ep, n_users, \
+                                   n_items, n_tiles, split_tiles, chunk_begin, chunk_tiles, seen_ptr, seen_tiles, seen_ntiles, cs, ci, st_lane, st_ring, \
+                                   user_bound, tile_bound, ablate, no_dense, ph.slot_base, ph.boot_tiles);      \
+            continue;                                                                                           \
+        }                                                                                                       \
+    }                                                                                                           \
     if (grid.y > 1 || ph.floor_state != nullptr)                                                                \
         hipLaunchKernelGGL((score_candidates_kernel<NSTEP, KCV, true, DENSE_OK>), grid, dim3(256), pk_score_lds_bytes(NSTEP, KCV), st, Vp, Ep, n_users, \
                            n_items, n_tiles, split_tiles, chunk_begin, chunk_tiles, seen_ptr, seen_tiles, seen_ntiles, cs, ci, st_lane, st_ring,  \
@@ -1238,6 +2037,10 @@ static int launch_candidates_n(hipStream_t st, int KC, int ablate, dim3 grid, co
         hipLaunchKernelGGL((score_candidates_kernel<NSTEP, KCV, false, false>), grid, dim3(256), pk_score_lds_bytes(NSTEP, KCV), st, Vp, Ep, n_users, \
                            n_items, n_tiles, split_tiles, chunk_begin, chunk_tiles, seen_ptr, seen_tiles, seen_ntiles, cs, ci, st_lane, st_ring,  \
                            user_bound, tile_bound, ablate, no_dense, 0, ph.slot_base, nullptr, ph.boot_tiles)
+#ifdef PK_FAST_BUILD
+        if (KC != 16) return PK_E_UNSUPPORTED;
+        PK_LAUNCH(16);
+#else
         switch (KC) {
             case 16:
                 PK_LAUNCH(16);
@@ -1252,6 +2055,7 @@ static int launch_candidates_n(hipStream_t st, int KC, int ablate, dim3 grid, co
                 pk_set_error("pk_score_candidates_f32: KC=%d unsupported (16, 32, 64)", KC);
                 return PK_E_UNSUPPORTED;
         }
+#endif
 #undef PK_LAUNCH
     }
     return PK_OK;
@@ -1314,6 +2118,10 @@ static int pk_sweep_launches(hipStream_t st, int64_t n_users, int64_t n_items, i
     // threshold bootstrap in front of every sweep that starts cold: 16 tiles (PK_SCORE_BOOT_TILES overrides, 0 = off)
     const char *boot_env = getenv("PK_SCORE_BOOT_TILES");
     ph.boot_tiles = ph.floor_state ? 0 : (boot_env ? atoi(boot_env) : 16);
+    const char *shared_env = getenv("PK_SCORE_SHARED");     // tuning: 1 = the LDS-staged eight-wave instance for single sweeps
+    ph.shared = shared_env ? atoi(shared_env) : 0;
+    const char *pair_env = getenv("PK_SCORE_PAIR");         // tuning: 1 = two user groups per wave for single sweeps with KC = 16
+    ph.pair = pair_env ? atoi(pair_env) : 0;
     dim3 grid((unsigned)pk_ceil_div(groups, 4), (unsigned)splits);
     const float4 *Vp = reinterpret_cast<const float4 *>(Vp_dev);
     const float4 *Ep = reinterpret_cast<const float4 *>(Ep_dev);
@@ -1329,6 +2137,9 @@ static int pk_sweep_launches(hipStream_t st, int64_t n_users, int64_t n_items, i
     const char *abl_env = getenv("PK_SCORE_ABLATE");   // kernel-tuning knob, never set in production
     const int ablate = abl_env ? atoi(abl_env) : 0;
     switch (nstep) {
+#ifdef PK_FAST_BUILD
+        PK_N_CASE(4)
+#else
         PK_N_CASE(1)
         PK_N_CASE(2)
         PK_N_CASE(3)
@@ -1340,6 +2151,7 @@ static int pk_sweep_launches(hipStream_t st, int64_t n_users, int64_t n_items, i
         PK_N_CASE(10)
         PK_N_CASE(13)
         PK_N_CASE(16)
+#endif
     }
 #undef PK_N_CASE
     if (rc != PK_OK) return rc;
@@ -1382,7 +2194,7 @@ extern "C" int pk_score_candidates_f32(void *stream, int64_t n_users, int64_t n_
     SeenDense dense{seen_dense_dev, seen_skip_dev, seen_ptr_dev ? dense_tiles : 0};
     return pk_sweep_launches(pk_stream(stream), n_users, n_items, (int)pk_ceil_div(n_items, 32), K, Vp_dev, Ep_dev,
                              seen_ptr_dev, seen_tiles_dev, seen_ntiles_dev, KC, splits, splits, cand_score_dev, cand_idx_dev,
-                             state_dev, tiles_per_chunk, user_bound_dev, tile_bound_dev, dense, SweepPhase{0, 0, nullptr, 0});
+                             state_dev, tiles_per_chunk, user_bound_dev, tile_bound_dev, dense, SweepPhase{0, 0, nullptr, 0, 0});
 }
 
 // ---- two-phase sweep -------------------------------------------------------------------------------------------------
@@ -1539,13 +2351,13 @@ extern "C" int pk_score_two_phase_f32(void *stream, int64_t n_users, int64_t n_i
     // rings merged, lists written, exit tile and threshold in the lane records — so the head must fit one item chunk)
     rc = pk_sweep_launches(st, n_users, n_items, head_tiles, K, Vp_dev, Ep_dev, seen_ptr_dev, seen_tiles_dev, seen_ntiles_dev,
                            KC, 1, total_slots, work_score_dev, work_idx_dev, state_dev, head_tiles, user_bound_dev,
-                           tile_bound_dev, dense, SweepPhase{0, 0, nullptr, 0});
+                           tile_bound_dev, dense, SweepPhase{0, 0, nullptr, 0, 0});
     if (rc != PK_OK) return rc;
     // phase 2: the splits, from the head's thresholds
     LaneState *st_lane = static_cast<LaneState *>(state_dev);
     rc = pk_sweep_launches(st, n_users, n_items, n_tiles, K, Vp_dev, Ep_dev, seen_ptr_dev, seen_tiles_dev, seen_ntiles_dev,
                            KC, splits, total_slots, work_score_dev, work_idx_dev, state_dev, tiles_per_chunk, user_bound_dev,
-                           tile_bound_dev, dense, SweepPhase{head_tiles, 1, st_lane, 0});
+                           tile_bound_dev, dense, SweepPhase{head_tiles, 1, st_lane, 0, 0});
     if (rc != PK_OK) return rc;
     const int64_t n_pad = pk_ceil_div(n_users, 32) * 32;
     const int slots = (int)pk_ceil_div((int64_t)total_slots * KC, 64);

@@ -1,3 +1,8 @@
+// EXPERIMENT TREE — not part of libpolarahip.so.  spmm.hip as it stood in round 5 before the LDS-head fold-in left the product library: every sweep / fold-in variant that was built,
+// verified against the default kernel and measured slower or mixed (profiles/r03_* r04_*) stays buildable here,
+// behind its -D switches and run-time knobs, through `python tools/build_probe_lib.py out.so [-D...]` + POLARA_HIP_LIB=out.so.
+// The product sources carry only the kernels that ship.
+#define PK_X_HEAD 16   // (x_kind flag of the LDS-head fold-in instance; gone from the product header)
 // K1/K4: CSR x dense (fp64 accumulate) for gfx950.
 //
 // out[r, :] = sum_p vals[p] * X[indices[p], :]      (scipy csr_matvecs restated for a block of
@@ -320,8 +325,132 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PK_SPMM_WPE
     }
 }
 
-// (The persistent fold-in instance with the head of the factor image in LDS — round 4, measured slower: 0.305 against 0.273 ms
-// — lives in csrc/experiments/spmm_variants.hip; record: profiles/r04_fold_head_probe_ml20m.txt)
+// ---- fold-in with the head of the factor image in LDS (round 4; DESIGN r3 §9.2) -----------------------------
+// The fold-in of the scoring pass, E = A_test * fl32(V), is bound by the rate at which a CU turns row gathers around (8.8
+// clocks per 256-byte row out of L2, whatever the row holds).  The catalogue is in descending factor-norm (~ popularity)
+// order, so the first few hundred rows of the image take a quarter to a third of all gathers (738 rows = 31 % on the
+// ML-20M-shaped matrix).  This instance is PERSISTENT: one 1 024-thread workgroup per CU stages the first `head_rows`
+// rows of X (compact, nc floats each: up to 150 KB) into LDS once and then works through row tasks slot by slot
+// (task = slot, slot + slots, ...: the plan is in activity order, long rows first, so round-robin is balanced); an entry
+// whose item lies in the head reads its row piece with one ds_read_b128 (2 clocks per row), everything else gathers
+// from L2 as before.  Rows are sorted by item, so the head entries of a row are its first steps and a wave step is
+// normally all-head or all-tail (mixed steps issue both instructions under exec masks).  Same mapping, same summation
+// order as spmm_csr_groups_kernel<VT, 4, float, false, true>: the results are bit-identical.
+template <typename VT>
+__global__ __launch_bounds__(1024) void fold_in_head_kernel(
+    int64_t n_tasks, const int32_t *__restrict__ task_row, const int64_t *__restrict__ task_begin,
+    const int64_t *__restrict__ task_end, const int32_t *__restrict__ task_slot,
+    const int32_t *__restrict__ indices, const VT *__restrict__ vals, const float *__restrict__ X,
+    int64_t ldx, int nc, double *__restrict__ out, int64_t ldo, double *__restrict__ partial, int head_rows) {
+    extern __shared__ __attribute__((aligned(16))) float4 pk_fold_head[];      // [head_rows][nc / 4]
+    constexpr int GROUPS = 4, LG = 16, U = 8;
+    const int q = nc >> 2;
+    {
+        const float4 *X4 = reinterpret_cast<const float4 *>(X);
+        const int64_t ld4 = ldx >> 2;
+        for (int i = threadIdx.x; i < head_rows * q; i += 1024) {
+            const int r = i / q, c = i - r * q;
+            pk_fold_head[i] = X4[(int64_t)r * ld4 + c];
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int g = lane / LG, l = lane % LG;
+    const int c0 = 4 * l;
+    const bool ok0 = c0 < nc;
+    const int lq = ok0 ? l : 0;                                   // idle lanes read piece 0 (never written back)
+    const char *Xb = reinterpret_cast<const char *>(X);
+    const unsigned stride_b = (unsigned)(ldx * 4);
+    const unsigned lo0 = (unsigned)(lq * 16);
+    const int64_t n_slots = (int64_t)gridDim.x * 16;
+    for (int64_t task = (int64_t)blockIdx.x * 16 + wave; task < n_tasks; task += n_slots) {
+        const int64_t p0 = task_begin[task];
+        const int n = (int)(task_end[task] - p0);
+        const int32_t *ip = indices + p0;
+        const VT *vp = vals + p0;
+        double2 acc0 = make_double2(0.0, 0.0), acc1 = make_double2(0.0, 0.0);
+        constexpr int SPC = 64 / GROUPS, SETS = SPC / U;
+        int jc = 0, jn = 0;
+        VT ac = (VT)0, an = (VT)0;
+        if (lane < n) {
+            jc = ip[lane];
+            ac = vp[lane];
+        }
+        if (64 + lane < n) {
+            jn = ip[64 + lane];
+            an = vp[64 + lane];
+        }
+        auto issue = [&](int jch, int st0, float4(&xa)[U]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int jj = __shfl(jch, (st0 + u) * GROUPS + g, 64);
+                if (jj < head_rows) {
+                    xa[u] = pk_fold_head[jj * q + lq];
+                } else {
+                    unsigned o0;
+                    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(o0) : "v"(jj), "v"(stride_b), "v"(lo0));
+                    xa[u] = *reinterpret_cast<const float4 *>(Xb + o0);
+                }
+            }
+        };
+        auto consume = [&](VT ach, int st0, const float4(&xa)[U]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const double aa = (double)__shfl(ach, (st0 + u) * GROUPS + g, 64);
+                acc0.x = fma(aa, (double)xa[u].x, acc0.x);
+                acc0.y = fma(aa, (double)xa[u].y, acc0.y);
+                acc1.x = fma(aa, (double)xa[u].z, acc1.x);
+                acc1.y = fma(aa, (double)xa[u].w, acc1.y);
+            }
+        };
+        float4 xa0[U], xa1[U];
+        issue(jc, 0, xa0);
+        for (int p = 0; p < n; p += 64) {
+            const int cnt = (n - p) < 64 ? (n - p) : 64;
+            const bool more = p + 64 < n;
+            int jf = 0;
+            VT af = (VT)0;
+            if (p + 128 + lane < n) {
+                jf = ip[p + 128 + lane];
+                af = vp[p + 128 + lane];
+            }
+#pragma unroll
+            for (int k = 0; k < SETS; ++k) {
+                const bool have = k * U * GROUPS < cnt;
+                const bool have_next = (k + 1 < SETS) ? ((k + 1) * U * GROUPS < cnt) : more;
+                if ((k & 1) == 0) {
+                    if (have_next) {
+                        if (k + 1 < SETS) issue(jc, (k + 1) * U, xa1);
+                        else issue(jn, 0, xa1);
+                    }
+                    if (have) consume(ac, k * U, xa0);
+                } else {
+                    if (have_next) {
+                        if (k + 1 < SETS) issue(jc, (k + 1) * U, xa0);
+                        else issue(jn, 0, xa0);
+                    }
+                    if (have) consume(ac, k * U, xa1);
+                }
+            }
+            jc = jn; ac = an;
+            jn = jf; an = af;
+        }
+        acc0.x += pk_lane_xor<16>(acc0.x); acc0.y += pk_lane_xor<16>(acc0.y);
+        acc1.x += pk_lane_xor<16>(acc1.x); acc1.y += pk_lane_xor<16>(acc1.y);
+        acc0.x += pk_lane_xor<32>(acc0.x); acc0.y += pk_lane_xor<32>(acc0.y);
+        acc1.x += pk_lane_xor<32>(acc1.x); acc1.y += pk_lane_xor<32>(acc1.y);
+        const int slot = task_slot[task];
+        double *dst = slot < 0 ? out + (int64_t)task_row[task] * ldo : partial + (int64_t)slot * nc;
+        if (g == 0 && ok0) {
+            dst[c0] = acc0.x;
+            dst[c0 + 1] = acc0.y;
+            dst[c0 + 2] = acc1.x;
+            dst[c0 + 3] = acc1.y;
+        }
+    }
+}
+
 // out[row, :] = sum_{s in [slot_begin, slot_end)} partial[s, :]   (fixed order)
 __global__ __launch_bounds__(256) void spmm_fixup_kernel(
     int64_t n_long, const int32_t *__restrict__ long_row, const int32_t *__restrict__ slot_begin,
@@ -347,6 +476,8 @@ static int launch_spmm(hipStream_t st, int64_t n_tasks, const int32_t *task_row,
                        double *partial, int64_t row_base, int accumulate, int64_t x_rows) {
     dim3 grid((unsigned)pk_ceil_div(n_tasks, 4)), block(256);
     const VT *v = static_cast<const VT *>(vals);
+    const bool force_head = (x_kind & PK_X_HEAD) != 0;
+    x_kind &= ~PK_X_HEAD;
     if (x_kind == PK_VAL_F32) {
         // fp32 dense block: groups mapping only (one 16-byte load = 4 columns)
         const float *X = static_cast<const float *>(Xv);
@@ -366,6 +497,39 @@ static int launch_spmm(hipStream_t st, int64_t n_tasks, const int32_t *task_row,
         if (accumulate) { if (off32) PK_SPMM_LAUNCH_F(G, true, true); else PK_SPMM_LAUNCH_F(G, true, false); }       \
         else { if (off32) PK_SPMM_LAUNCH_F(G, false, true); else PK_SPMM_LAUNCH_F(G, false, false); }                \
     } while (0)
+        // the persistent instance with the head of X in LDS: large launches over an image of <= 64 columns whose rows can
+        // be addressed with 32-bit offsets (PK_FOLD_HEAD=0: the plain kernel)
+        {
+            // OPT-IN (PK_FOLD_HEAD=1, or x_kind PK_VAL_F32 | PK_X_HEAD from a caller that wants exactly this instance): measured
+            // on the ML-20M-shaped fold-in the persistent form alone costs 18 % (0.273 -> 0.323 ms: 34 row tasks per wave one
+            // after the other instead of a fresh wave per task) and the 738 head rows in LDS give 5.5 % of that back
+            // (0.305 ms) — the gathers of the popular rows were not what the kernel waits for (tools/probes/fold_head_probe.py)
+            static const bool head_on = []() { const char *e = getenv("PK_FOLD_HEAD"); return e && atoi(e) != 0; }();
+            if ((head_on || force_head) && !accumulate && off32 && nc <= 64 && (n_tasks >= 8192 || force_head)) {
+                const int lds_budget = 150 * 1024;
+                int head_rows = lds_budget / (nc * 4);
+                if (const char *hr = getenv("PK_FOLD_HEAD_ROWS")) head_rows = std::min(head_rows, atoi(hr));     // kernel-tuning knob
+                if ((int64_t)head_rows > x_rows) head_rows = (int)x_rows;
+                static PkDeviceOnce attr_set;
+                if (attr_set.pending()) {
+                    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&fold_in_head_kernel<VT>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_budget);
+                    if (e1 != hipSuccess) {
+                        pk_set_error("pk_spmm_csr_ex: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e1));
+                        return PK_E_LAUNCH;
+                    }
+                    attr_set.done();
+                }
+                int dev = 0, cus = 256;
+                (void)hipGetDevice(&dev);
+                (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+                int64_t wgs = pk_ceil_div(n_tasks, 16);
+                if (wgs > cus) wgs = cus;
+                hipLaunchKernelGGL((fold_in_head_kernel<VT>), dim3((unsigned)wgs), dim3(1024), (size_t)head_rows * nc * 4, st, n_tasks,
+                                   task_row, task_begin, task_end, task_slot, indices, v, X, ldx, nc, out, ldo, partial, head_rows);
+                return PK_OK;
+            }
+        }
         if (nc <= 64) PK_SPMM_GROUPS_F(4);
         else if (nc <= 128) PK_SPMM_GROUPS_F(2);
         else PK_SPMM_GROUPS_F(1);
@@ -429,7 +593,7 @@ extern "C" int pk_spmm_csr_ex(void *stream, int64_t n_tasks, const int32_t *task
     PK_REQUIRE(n_tasks >= 0 && nc >= 1 && nc <= 256, "pk_spmm_csr: bad sizes n_tasks=%lld nc=%d",
                (long long)n_tasks, nc);
     PK_REQUIRE(ldo >= nc && ldx >= nc, "pk_spmm_csr: ldo/ldx < nc");
-    PK_REQUIRE(x_kind == PK_VAL_F32 || x_kind == PK_VAL_F64, "pk_spmm_csr_x: bad x_kind %d", x_kind);
+    PK_REQUIRE((x_kind & ~PK_X_HEAD) == PK_VAL_F32 || x_kind == PK_VAL_F64, "pk_spmm_csr_x: bad x_kind %d", x_kind);
     PK_REQUIRE(n_long == 0 || partial_dev != nullptr, "pk_spmm_csr: partial buffer required");
     PK_REQUIRE(row_base >= 0 && (accumulate || row_base == 0), "pk_spmm_csr_ex: a row base needs accumulate (block 0 has base 0)");
     if (n_tasks == 0) return PK_OK;

@@ -635,7 +635,7 @@ class HipOps:
         return torch.randn(n, m, generator=g, dtype=torch.float64, device=self.device)
 
     # ---- K1/K4 ------------------------------------------------------------------------------
-    def spmm(self, A, X, out=None, rows=None, head_in_lds=False):
+    def spmm(self, A, X, out=None, rows=None):
         """out[n_rows x nc] = A @ X (fp64 accumulate, fp64 out).  A: DeviceCSR, X: [n_cols x nc] row-major, fp64
         or fp32 (the fp32 image of the item factors for the approximate fold-in).
         rows=(lo, hi): only rows [lo, hi) are computed (written to the same rows of the FULL-height `out`):
@@ -653,14 +653,12 @@ class HipOps:
                 self.spmm(A, X[:, c0:c0 + 256], out=out[:, c0:c0 + 256], rows=rows)
             return out
         rng = (0, A.n_tasks, 0, A.n_long) if rows is None else A.task_range(int(rows[0]), int(rows[1]))
-        return self._spmm_launch(A, X, out, rng, head_in_lds=head_in_lds)
+        return self._spmm_launch(A, X, out, rng)
 
-    def _spmm_launch(self, A, X, out, rng, row_base=0, accumulate=False, meta_shape=None, head_in_lds=False):
+    def _spmm_launch(self, A, X, out, rng, row_base=0, accumulate=False, meta_shape=None):
         """one launch of the row-task kernel over the plan slice `rng` = (first task, tasks, first long row, long rows)"""
         nc = X.shape[1]
         x_kind = _lib.PK_VAL_F64 if X.dtype == torch.float64 else _lib.PK_VAL_F32
-        if head_in_lds and X.dtype == torch.float32:
-            x_kind |= _lib.PK_X_HEAD        # the persistent instance with the first rows of X in LDS (opt-in, see spmm.hip)
         p = A.plan
         t0, n_tasks, l0, n_long = rng
         tr, tb, te, ts = p['task_row'], p['task_begin'], p['task_end'], p['task_slot']
@@ -898,6 +896,13 @@ class HipOps:
         _lib.check(self.lib.pk_chol_rinv_f64(self.stream(), n, _ptr(G), G.stride(0), float(shift_rel), _ptr(Rinv), n,
                                              _ptr(work), _ptr(info)), 'pk_chol_rinv_f64')
         return Rinv, info
+
+    def orth_check(self, G, info, flags):
+        """flags[0] += sum |info|, flags[1] = max(flags[1], max |G - I|) (NaN counts as 1), info zeroed — the bookkeeping
+        of an orthonormalisation pass in one launch (a dozen one-element torch launches before)."""
+        assert G.stride(1) == 1 and G.shape[0] == G.shape[1] and info.dtype == torch.int32 and flags.dtype == torch.float64
+        _lib.check(self.lib.pk_orth_check_f64(self.stream(), G.shape[0], _ptr(G), G.stride(0), _ptr(info), info.numel(),
+                                              _ptr(flags)), 'pk_orth_check_f64')
 
     def axpbypcz(self, alpha, Z, beta=0.0, Y=None, gamma=0.0, X=None, out=None):
         assert Z.is_contiguous() and (Y is None or Y.is_contiguous()) and (X is None or X.is_contiguous())

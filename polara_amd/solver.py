@@ -363,7 +363,7 @@ def _subspace_iteration(op, lay, k, X, tol, max_outer, m_max, spread, seed, stat
     return basis, lam_all, res_host, n_lock, converged
 
 
-def _next_lanczos_block(lay, W, Qall, C, flags):
+def _next_lanczos_block(lay, W, Qall, C, flags, out=None):
     """The next block of the Krylov basis from W = B Q_j and C = Q^T W (already all-reduced: the block column of T):
     shifted CholeskyQR3 of the projected block, RE-projected against the whole basis in every pass — near convergence the
     residual block has singular values over ten orders of magnitude, and what a pass scales up by 1/sigma it also scales up
@@ -371,11 +371,18 @@ def _next_lanczos_block(lay, W, Qall, C, flags):
     filtered blocks).  Per pass: one Gram matrix against the basis, one fused `Z - Q C` product, one l x l Gram matrix,
     one Cholesky kernel, one tall-skinny product.  No host read: the Cholesky verdicts and the distance of the last
     pass's Gram matrix from I (a pass brings delta to ~delta^2) go to `flags`.
+    `out`: where the new block goes (a column slice of the basis buffer: the last product writes it in place).
     Returns (Q_next, S) with S = W_perp^T W_perp, the coupling behind the residuals of the Ritz pairs of T_j."""
     ops = lay.ops
     m, l = lay.n, W.shape[1]
     u = 1.1102230246251565e-16
-    info = torch.zeros(3, dtype=torch.int32, device=W.device)
+    fused = hasattr(ops, 'orth_check')
+    if fused:      # the Cholesky verdicts of the three passes: a buffer the check kernel leaves zeroed for the next block
+        info = getattr(ops, '_orth_info', None)
+        if info is None:
+            info = ops._orth_info = torch.zeros(3, dtype=torch.int32, device=W.device)
+    else:
+        info = torch.zeros(3, dtype=torch.int32, device=W.device)
     Y, S, G = W, None, None
     for p in range(3):
         Cp = C if p == 0 else lay.gram(Qall, Y)
@@ -384,10 +391,13 @@ def _next_lanczos_block(lay, W, Qall, C, flags):
         if p == 0:
             S = G
         Rinv, _ = ops.chol_rinv(G, 11.0 * (m * l + l * (l + 1)) * u if p == 0 else 0.0, info=info[p:p + 1])
-        Y = ops.tsmm(Y, Rinv)
-    err = (G - torch.eye(l, dtype=G.dtype, device=G.device)).abs().max()
-    flags[0] += info.abs().sum().to(flags.dtype)
-    flags[1] = torch.maximum(flags[1], torch.nan_to_num(err, nan=1.0, posinf=1.0).to(flags.dtype))
+        Y = ops.tsmm(Y, Rinv, out=out if p == 2 else None)
+    if fused:
+        ops.orth_check(G, info, flags)       # one launch: verdicts summed, max |G - I|, `info` cleared
+    else:
+        err = (G - torch.eye(l, dtype=G.dtype, device=G.device)).abs().max()
+        flags[0] += info.abs().sum().to(flags.dtype)
+        flags[1] = torch.maximum(flags[1], torch.nan_to_num(err, nan=1.0, posinf=1.0).to(flags.dtype))
     return Y, S
 
 
@@ -561,7 +571,7 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
                 Qn_[:, :cap * b] = Qbuf
                 Tn_[:cap * b, :cap * b] = T
                 Qbuf, T, cap = Qn_, Tn_, cap2
-            Qj = Qbuf[:, N - b:N].contiguous()
+            Qj = Qbuf[:, N - b:N].contiguous()     # (a compact copy: the SpMM gathers rows of it — 512-byte rows 10 KB apart would spread the gathers over twenty times the pages)
             W = gop.apply(Qj)
             Qall = Qbuf[:, :N]
             C = lay.gram(Qall, W)                                      # block column j of T, rows of all blocks so far
@@ -569,8 +579,7 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
             T[N - b:N, :N - b] = C[:N - b].t()
             last = j == qcap
             if not last:
-                Qnext, S = _next_lanczos_block(lay, W, Qall, C, flags)
-                Qbuf[:, N:N + b] = Qnext
+                _, S = _next_lanczos_block(lay, W, Qall, C, flags, out=Qbuf[:, N:N + b])
             else:                              # the last block the space can hold: the coupling of W_perp directly
                 S = lay.gram(ops.tsmm_sub(W, Qall, C))
             # ---- a monitor that is due: collect it and plan the next look --------------------------------------

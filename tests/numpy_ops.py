@@ -114,6 +114,9 @@ class NumpyOps:
         return A.t() @ B
 
     def tsmm(self, X, Cm, out=None):
+        if out is not None:
+            out.copy_(X @ Cm)
+            return out
         return (X @ Cm).contiguous()
 
     def eigh_psd(self, S, max_sweeps=0, tol=0.0):

@@ -32,7 +32,8 @@ def _configs():
     rng2 = np.random.RandomState(777 + SWEEP_SEED)
     for c in out:
         c['knobs'] = dict(PK_SCORE_BOOT_TILES=str(rng2.choice([0, 2, 16])), PK_SCORE_HEAD_TILES=str(rng2.choice([0, 0, 1, 3, 8])),
-                          PK_SCORE_PHASE2_SPLITS=str(rng2.choice([1, 3, 7])), PK_SCORE_SHARED=str(rng2.choice([0, 0, 1])))
+                          PK_SCORE_PHASE2_SPLITS=str(rng2.choice([1, 3, 7])))
+        rng2.choice([0, 0, 1])     # (the draw of the LDS-shared instance, rounds 3-4: it left the product library; the sequence stays)
         c['chunk'] = int(rng2.choice([0, 0, 2, 5]))
     return out
 
