@@ -1060,31 +1060,32 @@ static int block_lanczos(pk_ctx *ctx, Solver &S, GramianOp &gop, int64_t n, int 
         if (!last) {
             // solver.py::_next_lanczos_block: shifted CholeskyQR3, re-projected against the whole basis in every pass
             HIPCK(hipMemsetAsync(info.p, 0, 12, S.st));
-            DMat Y = std::move(W), G;
+            // The block lives where it will stay — columns [N, N + b) of the basis — so that a re-projection pass needs ONE Gram
+            // product: [Q | Y]^T Y = (the coefficients Q^T Y of the re-projection; the Gram matrix of Y before it).
+            DMat G, M(N + b, b);
+            if (!M.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (block Lanczos)");
+            const double *Gp = nullptr;
+            int64_t ldgp = b;
             for (int p = 0; p < 3; ++p) {
-                DMat Cp;
-                const DMat *coef = &C;
-                if (p > 0) {
-                    Cp = DMat(N, b);
-                    if (!Cp.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (block Lanczos)");
-                    CK(pk_gram_f64(S.st, n, N, b, Q.p(), ldq, Y.p(), b, Cp.p(), b, S.gram_work.p));
-                    coef = &Cp;
-                }
-                DMat Yp(n, b), Rinv(b, b), Yn;
+                DMat Yp(n, b), Rinv(b, b);
                 if (!Yp.ok() || !Rinv.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (block Lanczos)");
-                CK(pk_tsmm_sub_f64(S.st, n, N, b, Q.p(), ldq, coef->p(), b, Y.p(), b, Yp.p(), b));
-                CK(S.gram(Yp, Yp, G));
-                if (p == 0) CK(S.col_slice(G, 0, b, Sc));
-                CK(pk_chol_rinv_f64(S.st, b, G.p(), b, p == 0 ? 11.0 * ((double)n * b + (double)b * (b + 1)) * u : 0.0, Rinv.p(), b, chol_work.p,
-                                    info.as<int32_t>() + p));
-                if (p < 2) {
-                    CK(S.tsmm(Yp, Rinv, Yn));
-                    Y = std::move(Yn);
-                } else {      // the last pass writes the new block where it lives: columns [N, N + b) of the basis
-                    CK(pk_tsmm_f64(S.st, n, b, b, Yp.p(), b, Rinv.p(), b, Q.p() + N, ldq));
+                if (p == 0) {
+                    CK(pk_tsmm_sub_f64(S.st, n, N, b, Q.p(), ldq, C.p(), b, W.p(), b, Yp.p(), b));
+                    CK(S.gram(Yp, Yp, G));
+                    CK(S.col_slice(G, 0, b, Sc));
+                    Gp = G.p();
+                } else {
+                    const size_t need = (size_t)pk_gram_work_bytes(n, N + b, b);
+                    if (need > S.gram_work.bytes && !S.gram_work.alloc(need)) return fail(ctx, PK_E_LAUNCH, "out of device memory (gram)");
+                    CK(pk_gram_f64(S.st, n, N + b, b, Q.p(), ldq, Q.p() + N, ldq, M.p(), b, S.gram_work.p));
+                    CK(pk_tsmm_sub_f64(S.st, n, N, b, Q.p(), ldq, M.p(), b, Q.p() + N, ldq, Yp.p(), b));
+                    Gp = M.p() + (size_t)N * b;
                 }
+                CK(pk_chol_rinv_f64(S.st, b, Gp, ldgp, p == 0 ? 11.0 * ((double)n * b + (double)b * (b + 1)) * u : 0.0, Rinv.p(), b, chol_work.p,
+                                    info.as<int32_t>() + p));
+                CK(pk_tsmm_f64(S.st, n, b, b, Yp.p(), b, Rinv.p(), b, Q.p() + N, ldq));
             }
-            hipLaunchKernelGGL(lanczos_flags_kernel, dim3(1), dim3(256), 0, S.st, b, G.p(), info.as<int32_t>(), flags.as<double>());
+            hipLaunchKernelGGL(lanczos_flags_kernel, dim3(1), dim3(256), 0, S.st, b, Gp, info.as<int32_t>(), flags.as<double>());
         } else {
             DMat Wp(n, b);
             if (!Wp.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (block Lanczos)");
@@ -1186,11 +1187,15 @@ static int svd_build_impl(pk_ctx *ctx, pk_mat *A, const pk_comm *comm, int32_t k
         }
         // solver.py::choose_method: a step's products against the re-orthogonalisation over the Krylov basis and the
         // projected eigenproblems
+        // (the constants: polara_amd/machine_model.py — measured rates with their records under profiles/, and the two
+        // multi-GPU figures that are assumptions because no N > 1 run exists)
+        constexpr double kSpmmGatherBps = 15e12, kDenseF64Flops = 20e12, kNestedSolveS = 8e-3 / 16.0;
+        constexpr double kXgmiBusBps = 100e9 /* assumed */, kCollectiveStepS = 5e-6 /* assumed */;
         const int world = comm ? comm->world : 1;
-        double t_step = work * l * 16.0 / 15e12 / world;
-        if (world > 1) t_step += 2.0 * (world - 1) / world * (double)n_items * l * 8.0 / 100e9 + 2 * (world - 1) * 5e-6;
-        const double t_reorth = 96.0 * (double)n_items * l * l / 20e12,
-                     t_nested = 8e-3 * std::max(1.0, (l / 64.0) * (l / 64.0)) / 16.0;
+        double t_step = work * l * 16.0 / kSpmmGatherBps / world;
+        if (world > 1) t_step += 2.0 * (world - 1) / world * (double)n_items * l * 8.0 / kXgmiBusBps + 2 * (world - 1) * kCollectiveStepS;
+        const double t_reorth = 96.0 * (double)n_items * l * l / kDenseF64Flops,
+                     t_nested = kNestedSolveS * std::max(1.0, (l / 64.0) * (l / 64.0));
         const bool model = !(work * l < 2e8 || t_reorth + t_nested >= 2.0 * t_step);
         use_lanczos = me && !strcmp(me, "lanczos") ? true : me && !strcmp(me, "subspace") ? false : model;
     }
@@ -1329,6 +1334,8 @@ struct pk_serving {
     DMat V;
     Csr Ts;
     Dev Vp, tile_bound, V32, tiles, ntiles, dense, skip;
+    Dev vnorm, q20_raw, q20_tab;     // fp32 norm bounds of the item rows; the packed fold-in image (csrc/foldq.hip) and its bracket scales
+    char *q20_img = nullptr;      // 128-byte aligned start of the image inside q20_raw (nullptr: no packed image)
     int dense_tiles = 0;          // window of the dense seen masks (0: none)
 };
 
@@ -1394,6 +1401,22 @@ int serving_build(pk_ctx *ctx, pk_serving *sv, int64_t n_items, int32_t K, const
         hipLaunchKernelGGL(v32_image_kernel, dim3((unsigned)(((size_t)n_items * sv->ld32 + 255) / 256)), dim3(256), 0, st, n_items, K, sv->ld32,
                            V.p(), rowb.as<float>(), sv->V32.as<float>());
         sv->have_v32 = true;
+        // the items' own norm bounds for the certification (scoring.py: FactorImage.vnorm) ...
+        if (!sv->vnorm.alloc((size_t)n_items * 4)) return fail(ctx, PK_E_LAUNCH, "out of device memory (item norms)");
+        HIPCK(hipMemcpyAsync(sv->vnorm.p, rowb.p, (size_t)n_items * 4, hipMemcpyDeviceToDevice, st));
+        // ... and the packed image of the approximate fold-in (FactorImage.Q20): one cache line per rank-50 row
+        const int64_t qbytes = pk_q20_image_bytes(n_items, K);
+        if (qbytes > 0 && n_items < (1 << 24) && qbytes < ((int64_t)1 << 32)) {
+            Dev qwork(768), qinfo(4);
+            if (!sv->q20_raw.alloc((size_t)qbytes + 128) || !sv->q20_tab.alloc(96 * 8) || !qwork.p || !qinfo.p)
+                return fail(ctx, PK_E_LAUNCH, "out of device memory (packed image)");
+            char *img = static_cast<char *>(sv->q20_raw.p);
+            img += (128 - (reinterpret_cast<uintptr_t>(img) & 127)) & 127;
+            CK(pk_q20_encode_f64(st, n_items, K, V.p(), K, img, sv->q20_tab.as<double>(), qwork.p, qinfo.as<int32_t>()));
+            int32_t info = 0;
+            CK(S.to_host(qinfo.p, &info, 4));
+            if (info == 0) sv->q20_img = img;      // (else: factors outside the format's range — the fp32 image serves)
+        }
     }
     HIPCK(hipStreamSynchronize(st));   // tb_work / rowb go back to the pool
     return PK_OK;
@@ -1434,7 +1457,17 @@ int serving_score(pk_ctx *ctx, pk_serving *sv, int32_t topk, int32_t filter_seen
         const int Kx = approx ? sv->Kx_full : K, ld32 = sv->ld32;
         DMat Ex(n_users, Kx);
         if (!Ex.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (E)");
-        if (approx) CK(spmm(ctx, Ts, sv->V32.p, PK_VAL_F32, ld32, Kx, Ex.p(), Kx, all));
+        if (approx && sv->q20_img) {
+            // K4q: the packed image — E'[:, :K], the certified weight w in column K, zeros behind it
+            Plan &P = Ts.plan;
+            const size_t need = (size_t)P.n_slots * Kx * 8;
+            if (need > P.partial.bytes && !P.partial.alloc(need)) return fail(ctx, PK_E_LAUNCH, "out of device memory (fold-in partials)");
+            CK(pk_fold_q20(st, all.nt, P.task_row.as<int32_t>() + all.t0, P.task_begin.as<int64_t>() + all.t0,
+                           P.task_end.as<int64_t>() + all.t0, P.task_slot.as<int32_t>() + all.t0, all.nl,
+                           P.long_row.as<int32_t>() + all.l0, P.long_sb.as<int32_t>() + all.l0, P.long_se.as<int32_t>() + all.l0,
+                           Ts.indices.as<int32_t>(), Ts.values.p, Ts.val_kind, sv->q20_img, sv->q20_tab.as<double>(), n_items, K, Kx,
+                           Ex.p(), Kx, P.partial.as<double>()));
+        } else if (approx) CK(spmm(ctx, Ts, sv->V32.p, PK_VAL_F32, ld32, Kx, Ex.p(), Kx, all));
         else CK(spmm(ctx, Ts, V.p(), PK_VAL_F64, K, K, Ex.p(), Kx, all));
         const double *w = approx ? Ex.p() + K : nullptr;
         Dev Ep((size_t)pk_pack_elems(n_users, K) * 4), ub((size_t)n_users * 4);
@@ -1485,11 +1518,24 @@ int serving_score(pk_ctx *ctx, pk_serving *sv, int32_t topk, int32_t filter_seen
         // the re-fold list (lst), cnt2[1] the final list for the exact-row kernel (lst2)
         CK(pk_zero_i32(st, cnt2.as<int32_t>(), 2));
         int32_t *c_refold = cnt2.as<int32_t>(), *c_final = cnt2.as<int32_t>() + 1;
-        CK(pk_rescore_topk_rows_list_f64(st, n_users, nullptr, nullptr, n_users, n_items, K, V.p(), K, approx ? sv->V32.as<float>() : nullptr, approx ? ld32 : 0,
-                                         Ex.p(), Kx, w, approx ? Kx : 0, 0, seen_ptr, KC, splits, cs.as<float>(), ci.as<int32_t>(), topk, vmax,
-                                         out_i.as<int64_t>(), out_s.as<double>(), flags.as<int32_t>(),
-                                         approx ? lst.as<int32_t>() : lst2.as<int32_t>(), approx ? c_refold : c_final, 0));
+        CK(pk_rescore_topk_rows_norms_f64(st, n_users, nullptr, nullptr, n_users, n_items, K, V.p(), K, approx ? sv->V32.as<float>() : nullptr, approx ? ld32 : 0,
+                                          Ex.p(), Kx, w, approx ? Kx : 0, 0, seen_ptr, KC, splits, cs.as<float>(), ci.as<int32_t>(), topk, vmax,
+                                          out_i.as<int64_t>(), out_s.as<double>(), flags.as<int32_t>(),
+                                          approx ? lst.as<int32_t>() : lst2.as<int32_t>(), approx ? c_refold : c_final, 0,
+                                          approx ? sv->vnorm.as<float>() : nullptr));
         if (approx) {
+            // the exact re-fold of the flagged users: the product's own plan, every wave of an unflagged row leaving at once
+            // (even ranks; odd ones keep the one-workgroup-per-row kernel)
+            if ((K & 1) == 0 && K >= 2) {
+                Plan &P = Ts.plan;
+                const size_t need = (size_t)P.n_slots * K * 8;
+                if (need > P.partial.bytes && !P.partial.alloc(need)) return fail(ctx, PK_E_LAUNCH, "out of device memory (re-fold partials)");
+                CK(pk_spmm_csr_flagged_f64(st, all.nt, P.task_row.as<int32_t>() + all.t0, P.task_begin.as<int64_t>() + all.t0,
+                                           P.task_end.as<int64_t>() + all.t0, P.task_slot.as<int32_t>() + all.t0, all.nl,
+                                           P.long_row.as<int32_t>() + all.l0, P.long_sb.as<int32_t>() + all.l0, P.long_se.as<int32_t>() + all.l0,
+                                           Ts.indices.as<int32_t>(), Ts.values.p, Ts.val_kind, V.p(), K, K, Ex.p(), Kx, P.partial.as<double>(),
+                                           n_items, flags.as<int32_t>(), 7));
+            } else
             CK(pk_fold_rows_f64(st, n_users, lst.as<int32_t>(), c_refold, 0, Ts.indptr.as<int64_t>(), Ts.indices.as<int32_t>(), Ts.values.p,
                                 Ts.val_kind, V.p(), K, K, Ex.p(), Kx));
             CK(pk_rescore_topk_rows_list_f64(st, n_users, lst.as<int32_t>(), c_refold, n_users, n_items, K, V.p(), K, nullptr, 0, Ex.p(), Kx, w, Kx,

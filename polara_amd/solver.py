@@ -62,8 +62,15 @@ class ItemRows:
     pass-through.  N ranks: rank r holds rows [r*rows, (r+1)*rows) of the (zero-padded to N*rows) item axis; the
     padding rows are zero in every block and stay zero through every kernel of the solver (linear, row-wise)."""
 
-    def __init__(self, ops, comm, n_items, shard_items=True):
+    def __init__(self, ops, comm, n_items, shard_items=True, exchange_dtype=None):
         self.ops, self.comm, self.n = ops, comm, int(n_items)
+        # payload of the two big exchanges of a Gramian step (all-gather of X, reduce-scatter / all-reduce of Z): None = the
+        # blocks as they are (fp64); torch.float32 = rounded to fp32 on the wire (half the bytes, north_star's "fp32 Gramian
+        # all-reduce").  An fp32 payload perturbs every product by ~6e-8 of its norm: good for builds to a tolerance of 1e-6
+        # (the contract's 1e-4 on singular values and scores with two digits to spare), NOT for the default 1e-12 — the
+        # inexact-Krylov experiment of round 4 (DESIGN §9.5) stalled at 5e-12 with rounded products.  svd_topk picks it from
+        # the tolerance (`exchange='auto'`); the small l x l all-reduces stay fp64 either way.
+        self.exchange_dtype = exchange_dtype
         self.sharded = (bool(shard_items) and (comm.world > 1 or getattr(comm, '_always', False))      # _always: TorchComm's test switch
                         and hasattr(comm, 'reduce_scatter_rows'))
         self.rows = -(-self.n // comm.world) if self.sharded else self.n
@@ -87,6 +94,8 @@ class ItemRows:
         """[n_items x b] on every rank (what the SpMM gathers from)"""
         if not self.sharded:
             return X
+        if self.exchange_dtype is not None and X.dtype != self.exchange_dtype:
+            return self.comm.all_gather_rows(X.to(self.exchange_dtype).contiguous())[:self.n].to(X.dtype)
         return self.comm.all_gather_rows(X.contiguous())[:self.n]
 
     def product(self, At, Y):
@@ -103,15 +112,20 @@ class ItemRows:
         nc = Y.shape[1]
         mode = os.environ.get('PK_DIST_OVERLAP', '1')
         exchanging = comm.world > 1 or (mode == 'force' and getattr(comm, '_always', False))
-        worth = mode == 'force' or 2.0 * (comm.world - 1) / max(comm.world, 1) * self.n * nc * 8.0 / 100e9 >= 4e-4
+        from .machine_model import value as mm
+        worth = mode == 'force' or 2.0 * (comm.world - 1) / max(comm.world, 1) * self.n * nc * 8.0 / mm('xgmi_bus_Bps') >= 4e-4
         split = (exchanging and worth and mode != '0' and nc >= 32 and nc % 16 == 0 and hasattr(comm, 'allreduce_start')
                  and not hasattr(At, 'matvec'))
         panels = ((0, nc // 2), (nc // 2, nc)) if split else ((0, nc),)
+        moving = comm.world > 1 or getattr(comm, '_always', False)
+        xd = self.exchange_dtype if (moving and self.exchange_dtype is not None) else None
+        wire = (lambda t: t.to(xd)) if xd is not None else (lambda t: t)          # the block as it travels
+        home = (lambda t: t.to(torch.float64)) if xd is not None else (lambda t: t)
         if not self.sharded:
             if not split:
-                return comm.allreduce(ops.spmm(At, Y))
-            pending = [comm.allreduce_start(ops.spmm(At, Y[:, c0:c1]), count=(c0 == 0)) for c0, c1 in panels]
-            return torch.cat([h.wait() for h in pending], 1)
+                return home(comm.allreduce(wire(ops.spmm(At, Y))))
+            pending = [comm.allreduce_start(wire(ops.spmm(At, Y[:, c0:c1])), count=(c0 == 0)) for c0, c1 in panels]
+            return home(torch.cat([h.wait() for h in pending], 1))
         pending = []
         for c0, c1 in panels:
             buf = ops.empty(self.padded, c1 - c0)
@@ -119,9 +133,9 @@ class ItemRows:
                 buf[self.n:].zero_()
             ops.spmm(At, Y if not split else Y[:, c0:c1], out=buf[:self.n])
             if not split:
-                return comm.reduce_scatter_rows(buf, self.rows)
-            pending.append(comm.reduce_scatter_rows_start(buf, self.rows, count=(c0 == 0)))
-        return torch.cat([h.wait() for h in pending], 1)
+                return home(comm.reduce_scatter_rows(wire(buf), self.rows))
+            pending.append(comm.reduce_scatter_rows_start(wire(buf), self.rows, count=(c0 == 0)))
+        return home(torch.cat([h.wait() for h in pending], 1))
 
     def gram(self, A, B=None):
         G = self.ops.gram(A, B)
@@ -363,16 +377,20 @@ def _subspace_iteration(op, lay, k, X, tol, max_outer, m_max, spread, seed, stat
     return basis, lam_all, res_host, n_lock, converged
 
 
-def _next_lanczos_block(lay, W, Qall, C, flags, out=None):
+def _next_lanczos_block(lay, W, Qbuf, N, C, flags):
     """The next block of the Krylov basis from W = B Q_j and C = Q^T W (already all-reduced: the block column of T):
     shifted CholeskyQR3 of the projected block, RE-projected against the whole basis in every pass — near convergence the
     residual block has singular values over ten orders of magnitude, and what a pass scales up by 1/sigma it also scales up
     along Q; a projection after the scaling is what keeps Q^T Q = I to rounding (`orthonormalize` does the same for the
-    filtered blocks).  Per pass: one Gram matrix against the basis, one fused `Z - Q C` product, one l x l Gram matrix,
-    one Cholesky kernel, one tall-skinny product.  No host read: the Cholesky verdicts and the distance of the last
-    pass's Gram matrix from I (a pass brings delta to ~delta^2) go to `flags`.
-    `out`: where the new block goes (a column slice of the basis buffer: the last product writes it in place).
-    Returns (Q_next, S) with S = W_perp^T W_perp, the coupling behind the residuals of the Ritz pairs of T_j."""
+    filtered blocks).  The block lives where it will stay — columns [N, N + b) of the basis buffer `Qbuf` — so that a
+    re-projection pass needs ONE Gram product: [Q | Y]^T Y gives the coefficients C_p = Q^T Y of the re-projection AND the
+    l x l Gram matrix of Y in one launch and, row-sharded, ONE all-reduce (four per step instead of six).  The Gram matrix
+    of a pass is that of Y BEFORE its re-projection; the two differ by C_p^T C_p, and C_p is what a pass LEFT along Q: at
+    most ~1e-6 after the first pass (u times the condition of the residual block), so 1e-12 relative — a pass brings
+    delta to ~delta^2 either way, and the pairs are verified by a true product at the end.
+    Per pass: that Gram product (pass 0: the l x l one of the projected block), one fused `Y - Q C` product, one Cholesky
+    kernel, one tall-skinny product.  No host read: the Cholesky verdicts and the distance of the last pass's Gram matrix
+    from I go to `flags` (one launch).  Returns S = W_perp^T W_perp, the coupling behind the residuals of the Ritz pairs."""
     ops = lay.ops
     m, l = lay.n, W.shape[1]
     u = 1.1102230246251565e-16
@@ -383,22 +401,25 @@ def _next_lanczos_block(lay, W, Qall, C, flags, out=None):
             info = ops._orth_info = torch.zeros(3, dtype=torch.int32, device=W.device)
     else:
         info = torch.zeros(3, dtype=torch.int32, device=W.device)
-    Y, S, G = W, None, None
+    Qall, Ydst = Qbuf[:, :N], Qbuf[:, N:N + l]
+    S = G = None
     for p in range(3):
-        Cp = C if p == 0 else lay.gram(Qall, Y)
-        Y = ops.tsmm_sub(Y, Qall, Cp, out=Y if p else None)
-        G = lay.gram(Y)
         if p == 0:
-            S = G
+            Yp = ops.tsmm_sub(W, Qall, C)
+            S = G = lay.gram(Yp)
+        else:
+            M = lay.gram(Qbuf[:, :N + l], Ydst)        # rows [0, N): Q^T Y; rows [N, N + l): Y^T Y
+            G = M[N:]
+            Yp = ops.tsmm_sub(Ydst, Qall, M[:N])
         Rinv, _ = ops.chol_rinv(G, 11.0 * (m * l + l * (l + 1)) * u if p == 0 else 0.0, info=info[p:p + 1])
-        Y = ops.tsmm(Y, Rinv, out=out if p == 2 else None)
+        ops.tsmm(Yp, Rinv, out=Ydst)
     if fused:
         ops.orth_check(G, info, flags)       # one launch: verdicts summed, max |G - I|, `info` cleared
     else:
         err = (G - torch.eye(l, dtype=G.dtype, device=G.device)).abs().max()
         flags[0] += info.abs().sum().to(flags.dtype)
         flags[1] = torch.maximum(flags[1], torch.nan_to_num(err, nan=1.0, posinf=1.0).to(flags.dtype))
-    return Y, S
+    return S
 
 
 class _LanczosBreakdown(RuntimeError):
@@ -579,7 +600,7 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
             T[N - b:N, :N - b] = C[:N - b].t()
             last = j == qcap
             if not last:
-                _, S = _next_lanczos_block(lay, W, Qall, C, flags, out=Qbuf[:, N:N + b])
+                S = _next_lanczos_block(lay, W, Qbuf, N, C, flags)
             else:                              # the last block the space can hold: the coupling of W_perp directly
                 S = lay.gram(ops.tsmm_sub(W, Qall, C))
             # ---- a monitor that is due: collect it and plan the next look --------------------------------------
@@ -659,18 +680,20 @@ def choose_method(nnz, n_items, l, world=1):
     Sharded over `world` ranks the products shrink by the number of ranks and the exchange of the block joins every step of
     either method; the re-orthogonalisation launches and the (replicated) eigenproblems do not shrink: ML-20M-shaped on 8
     ranks is back on the subspace iteration (both ~33 ms in the scaling proxy: 17 K users per rank is a latency problem)."""
-    t_step = nnz * l * 16.0 / 15e12 / world               # both products of a step: gathers of l fp64 columns per entry
+    from .machine_model import value as mm          # one table, with the provenance of every number (measured / assumed)
+    t_step = nnz * l * 16.0 / mm('spmm_gather_Bps') / world    # both products of a step: gathers of l fp64 columns per entry
     if world > 1:    # every step of either method also pays its exchange (all-gather + reduce-scatter of an [n_items x l] block)
-        t_step += 2.0 * (world - 1) / world * n_items * l * 8.0 / 100e9 + 2 * (world - 1) * 5e-6
-    t_reorth = 96.0 * n_items * float(l) * l / 20e12
-    t_nested = 8e-3 * max(1.0, (l / 64.0) ** 2) / 16.0
+        t_step += 2.0 * (world - 1) / world * n_items * l * 8.0 / mm('xgmi_bus_Bps') + 2 * (world - 1) * mm('collective_step_s')
+    t_reorth = 96.0 * n_items * float(l) * l / mm('dense_f64_flops')
+    t_nested = mm('nested_solve_s') * max(1.0, (l / 64.0) ** 2)
     if nnz * l < 2e8 or t_reorth + t_nested >= 2.0 * t_step:
         return 'subspace'
     return 'lanczos'
 
 
 def svd_topk(ops, A, k, block=None, tol=1e-12, max_outer=200, m_max=24, spread=1e7, seed=0,
-             comm=None, want_u=False, verbose=False, even_lock=True, shard_items=True, method=None, max_steps=64):
+             comm=None, want_u=False, verbose=False, even_lock=True, shard_items=True, method=None, max_steps=64,
+             exchange='auto'):
     """Returns (U_local | None, sigma[k] desc, V [n_items x k], stats) as device tensors of `ops`.
 
     A: ops-level CSR of the LOCAL row shard (n_local x n_items).  Convergence: every one of the k
@@ -702,8 +725,13 @@ def svd_topk(ops, A, k, block=None, tol=1e-12, max_outer=200, m_max=24, spread=1
     # the operator of Z = A^T Y: a device matrix offers its user-blocked transpose (ops.BlockedTranspose)
     At = A.transpose_operator() if hasattr(A, 'transpose_operator') else A.T
 
-    lay = ItemRows(ops, comm, n_items, shard_items)
-    stats = dict(outer=0, gramian_steps=0, spmm_cols=0, degrees=[], locked_at=[], block=l, converged=False,
+    # payload of the block exchanges on more than one rank: 'f64', 'f32', or 'auto' = fp32 where the tolerance leaves room
+    # for its 6e-8 (tol >= 1e-6), fp64 otherwise (the default 1e-12 build)
+    if exchange not in ('auto', 'f64', 'f32'):
+        raise ValueError("exchange must be 'auto', 'f64' or 'f32'")
+    xdt = torch.float32 if (exchange == 'f32' or (exchange == 'auto' and tol >= 1e-6)) else None
+    lay = ItemRows(ops, comm, n_items, shard_items, exchange_dtype=xdt)
+    stats = dict(exchange='f32' if xdt is not None else 'f64', outer=0, gramian_steps=0, spmm_cols=0, degrees=[], locked_at=[], block=l, converged=False,
                  item_rows_per_rank=lay.rows, items_sharded=lay.sharded, method=stats_method)
     Vk = lam_k = res_k = None
     if method == 'lanczos':

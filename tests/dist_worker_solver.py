@@ -79,6 +79,25 @@ def main():
             np.allclose(res['force'][0], res['0'][0], rtol=1e-12) and np.abs(res['force'][1] @ res['force'][1].T - res['0'][1] @ res['0'][1].T).max() < 1e-10
             and 0 < res['force'][2] <= 2 * res['force'][3] and res['force'][2] % 2 == 0 and res['0'][2] == 0 and res['force'][3] == res['0'][3])
         out['panels_%s_steps' % ('sharded' if shard_items else 'replicated')] = (res['force'][2], res['force'][3])     # (not every block of a locking iteration is 16-divisible)
+    # fp32 on the wire (north_star's fp32 Gramian exchange): picked by `exchange='auto'` for a build to 1e-6, never for the
+    # default 1e-12 one; half the bytes per exchanged block, factors of the whole matrix to the tolerance of that build
+    for shard_items in (True, False):
+        # the block exchanges: all-gather + reduce-scatter (row-sharded item side) or the all-reduce of Z (replicated; the
+        # l x l all-reduces of the Gram matrices ride in the same counter there and stay fp64)
+        moved = (lambda: comm.bytes_gathered + comm.bytes_scattered) if shard_items else (lambda: comm.bytes_reduced)
+        b0 = moved()
+        _, s64, V64, st64 = svd_topk(ops, part, k, comm=comm, shard_items=shard_items)
+        b1 = moved()
+        _, s32, V32, st32 = svd_topk(ops, part, k, comm=comm, shard_items=shard_items, tol=1e-6)
+        b2 = moved()
+        _, s32x, V32x, st32x = svd_topk(ops, part, k, comm=comm, shard_items=shard_items, tol=1e-6, exchange='f64')
+        per64 = (b1 - b0) / max(st64['gramian_steps'], 1)
+        per32 = (b2 - b1) / max(st32['gramian_steps'], 1)
+        out['fp32_exchange_%s' % ('sharded' if shard_items else 'replicated')] = bool(
+            st64['exchange'] == 'f64' and st32['exchange'] == 'f32' and st32x['exchange'] == 'f64' and st32['converged']
+            and np.allclose(s32.numpy(), s64.numpy(), rtol=1e-5) and np.abs(V32.numpy() @ V32.numpy().T - V64.numpy() @ V64.numpy().T).max() < 1e-4
+            and per32 < 0.75 * per64)
+        out['fp32_exchange_%s_steps' % ('sharded' if shard_items else 'replicated')] = (round(per64), round(per32), st32['gramian_steps'], st32x['gramian_steps'])
     comm.barrier()
     if comm.rank == 0:
         print('SOLVER_DIST_RESULT', out)
