@@ -708,7 +708,7 @@ class Bench:
                     'avg_ms': fold_ms, 'algorithmic_bytes': alg, 'image_row_bytes': row_bytes,
                     'gather_GBps': float(T.nnz) * row_bytes / (fold_ms * 1e-3) / 1e9,
                     'refolded_users': stats.get('refolded_users'),
-                    'refold_ms': (ms.get('spmm_flagged') or ms.get('fold_rows') or 0.0) + (ms.get('rescore_topk_refolded') or 0.0)}
+                    'refold_ms': (ms.get('spmm_rows_list') or ms.get('spmm_flagged') or ms.get('fold_rows') or 0.0) + (ms.get('rescore_topk_refolded') or 0.0)}
             if cold_build is not None:
                 out['build_cold'] = cold_build
             if cpu and comm.world == 1:

@@ -427,6 +427,19 @@ int pk_spmm_csr_flagged_f64(void *stream, int64_t n_tasks, const int32_t *task_r
                             int val_kind, const double *X_dev, int64_t ldx, int32_t nc, double *out_dev, int64_t ldo,
                             double *partial_dev, int64_t x_rows, const int32_t *row_flags_dev, int32_t flag_mask);
 
+/* The same product on LISTED rows: list_dev[0 .. min(*count_dev, cap)) names the rows (row = row_offset + list[i]; the list
+ * the re-scoring kernel appends the uncertified users to), a wave walks the tasks [row_first_task[row], row_first_task[row + 1])
+ * of a listed row — the task arrays are those of the WHOLE plan (pk_row_plan_fill), the long-row arrays those of the row
+ * range whose split rows may be listed (their partial sums are added under the same flag predicate as above).  Costs what the
+ * listed rows cost: the flag-predicated form launches a wave per task of every row (0.23 ms of early exits on S-1M). */
+int pk_spmm_csr_rows_list_f64(void *stream, int64_t cap, const int32_t *list_dev, const int32_t *count_dev, int64_t row_offset,
+                              const int64_t *row_first_task_dev, const int32_t *task_row_dev, const int64_t *task_begin_dev,
+                              const int64_t *task_end_dev, const int32_t *task_slot_dev, int64_t n_long,
+                              const int32_t *long_row_dev, const int32_t *long_slot_begin_dev, const int32_t *long_slot_end_dev,
+                              const int32_t *indices_dev, const void *vals_dev, int val_kind, const double *X_dev, int64_t ldx,
+                              int32_t nc, double *out_dev, int64_t ldo, double *partial_dev, int64_t x_rows,
+                              const int32_t *row_flags_dev, int32_t flag_mask);
+
 /* ------------------------------------------------------------------------------------------
  * K4q.  The approximate fold-in of an ids-only scoring pass against a PACKED image of the item factors
  * (csrc/foldq.hip): E'[u, 0:K] = sum_j a_uj decode(image row j), E'[u, K] = w_u = sum_j a_uj D_j with

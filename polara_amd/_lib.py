@@ -86,6 +86,8 @@ PROTOTYPES = {
     'pk_fold_rows_f64': (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, C.c_int, _vp, _i64, _i32, _vp, _i64]),
     'pk_spmm_csr_flagged_f64': (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _i64, _i32,
                                           _vp, _i64, _vp, _i64, _vp, _i32]),
+    'pk_spmm_csr_rows_list_f64': (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, C.c_int,
+                                            _vp, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _i32]),
     'pk_q20_lanes': (_i32, [_i32]),
     'pk_q20_kappa': (_f64, [_i32]),
     'pk_q20_image_bytes': (_i64, [_i64, _i32]),

@@ -1524,17 +1524,17 @@ int serving_score(pk_ctx *ctx, pk_serving *sv, int32_t topk, int32_t filter_seen
                                           approx ? lst.as<int32_t>() : lst2.as<int32_t>(), approx ? c_refold : c_final, 0,
                                           approx ? sv->vnorm.as<float>() : nullptr));
         if (approx) {
-            // the exact re-fold of the flagged users: the product's own plan, every wave of an unflagged row leaving at once
+            // the exact re-fold of the listed users on the product's own row tasks (scoring.py: ops.spmm_rows_list)
             // (even ranks; odd ones keep the one-workgroup-per-row kernel)
             if ((K & 1) == 0 && K >= 2) {
                 Plan &P = Ts.plan;
                 const size_t need = (size_t)P.n_slots * K * 8;
                 if (need > P.partial.bytes && !P.partial.alloc(need)) return fail(ctx, PK_E_LAUNCH, "out of device memory (re-fold partials)");
-                CK(pk_spmm_csr_flagged_f64(st, all.nt, P.task_row.as<int32_t>() + all.t0, P.task_begin.as<int64_t>() + all.t0,
-                                           P.task_end.as<int64_t>() + all.t0, P.task_slot.as<int32_t>() + all.t0, all.nl,
-                                           P.long_row.as<int32_t>() + all.l0, P.long_sb.as<int32_t>() + all.l0, P.long_se.as<int32_t>() + all.l0,
-                                           Ts.indices.as<int32_t>(), Ts.values.p, Ts.val_kind, V.p(), K, K, Ex.p(), Kx, P.partial.as<double>(),
-                                           n_items, flags.as<int32_t>(), 7));
+                CK(pk_spmm_csr_rows_list_f64(st, n_users, lst.as<int32_t>(), c_refold, 0, P.row_first_task.as<int64_t>(), P.task_row.as<int32_t>(),
+                                             P.task_begin.as<int64_t>(), P.task_end.as<int64_t>(), P.task_slot.as<int32_t>(), all.nl,
+                                             P.long_row.as<int32_t>() + all.l0, P.long_sb.as<int32_t>() + all.l0, P.long_se.as<int32_t>() + all.l0,
+                                             Ts.indices.as<int32_t>(), Ts.values.p, Ts.val_kind, V.p(), K, K, Ex.p(), Kx, P.partial.as<double>(),
+                                             n_items, flags.as<int32_t>(), 7));
             } else
             CK(pk_fold_rows_f64(st, n_users, lst.as<int32_t>(), c_refold, 0, Ts.indptr.as<int64_t>(), Ts.indices.as<int32_t>(), Ts.values.p,
                                 Ts.val_kind, V.p(), K, K, Ex.p(), Kx));

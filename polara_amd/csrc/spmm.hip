@@ -147,13 +147,14 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(
 #ifndef PK_SPMM_WPE
 #define PK_SPMM_WPE 1          // waves per SIMD the register allocation is held to (1: whatever the kernel needs)
 #endif
-template <typename VT, int GROUPS, typename XT, bool ACC, bool OFF32, bool PRED = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PK_SPMM_WPE, 8))) void spmm_csr_groups_kernel(
-    int64_t n_tasks, const int32_t *__restrict__ task_row, const int64_t *__restrict__ task_begin,
+// one row task on one wave: the body of spmm_csr_groups_kernel (a function of its own so that the list-driven kernel below
+// can walk the tasks of LISTED rows with exactly the same mapping, loads and summation order)
+template <typename VT, int GROUPS, typename XT, bool ACC, bool OFF32>
+__device__ __forceinline__ void spmm_groups_task(
+    const int64_t task, const int lane, const int32_t *__restrict__ task_row, const int64_t *__restrict__ task_begin,
     const int64_t *__restrict__ task_end, const int32_t *__restrict__ task_slot,
     const int32_t *__restrict__ indices, const VT *__restrict__ vals, const XT *__restrict__ X,
-    int64_t ldx, int nc, double *__restrict__ out, int64_t ldo, double *__restrict__ partial, int64_t row_base,
-    const int32_t *__restrict__ row_flags = nullptr, int flag_mask = 0) {
+    int64_t ldx, int nc, double *__restrict__ out, int64_t ldo, double *__restrict__ partial, int64_t row_base) {
     constexpr bool XF = sizeof(XT) == 4;
     constexpr int LG = 64 / GROUPS;
     // wave steps per register set (two sets in flight); an fp32 row piece is one float4 per lane and step
@@ -164,13 +165,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PK_SPMM_WPE
     constexpr int U = XF ? 8 : (GROUPS == 16 ? 2 : PK_SPMM_U_F64);
     static_assert(!XF || GROUPS <= 4, "the fp32 dense block runs on GROUPS <= 4 only");
     using XA = typename std::conditional<XF, float4, double2>::type;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t task = (int64_t)blockIdx.x * 4 + wave;
-    if (task >= n_tasks) return;
-    if constexpr (PRED) {
-        if (!(row_flags[task_row[task]] & flag_mask)) return;
-    }
     const int64_t p0 = task_begin[task];
     const int n = (int)(task_end[task] - p0);
     if constexpr (ACC) {
@@ -319,6 +313,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PK_SPMM_WPE
         }
     }
 }
+
+template <typename VT, int GROUPS, typename XT, bool ACC, bool OFF32, bool PRED = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PK_SPMM_WPE, 8))) void spmm_csr_groups_kernel(
+    int64_t n_tasks, const int32_t *__restrict__ task_row, const int64_t *__restrict__ task_begin,
+    const int64_t *__restrict__ task_end, const int32_t *__restrict__ task_slot,
+    const int32_t *__restrict__ indices, const VT *__restrict__ vals, const XT *__restrict__ X,
+    int64_t ldx, int nc, double *__restrict__ out, int64_t ldo, double *__restrict__ partial, int64_t row_base,
+    const int32_t *__restrict__ row_flags = nullptr, int flag_mask = 0) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t task = (int64_t)blockIdx.x * 4 + wave;
+    if (task >= n_tasks) return;
+    if constexpr (PRED) {
+        if (!(row_flags[task_row[task]] & flag_mask)) return;
+    }
+    spmm_groups_task<VT, GROUPS, XT, ACC, OFF32>(task, lane, task_row, task_begin, task_end, task_slot, indices, vals, X, ldx, nc, out,
+                                                 ldo, partial, row_base);
+}
+
+// The product on LISTED rows: list[0 .. *count) (device-side, e.g. the users a scoring pass could not certify), row =
+// row_offset + list[i]; a wave takes listed rows in turn and walks the row's tasks [row_first_task[row], row_first_task[row + 1])
+// one after the other.  What the flag-predicated launch of the full plan costs — a wave per task of EVERY row, 250 K
+// workgroups that leave at once on S-1M: 0.23 ms for 7 650 listed users — this does not: its grid is a few thousand waves.
+template <typename VT, int GROUPS, bool OFF32>
+__global__ __launch_bounds__(256) void spmm_csr_rows_list_kernel(
+    int64_t cap, const int32_t *__restrict__ list, const int32_t *__restrict__ count, int64_t row_offset,
+    const int64_t *__restrict__ row_first_task, const int32_t *__restrict__ task_row, const int64_t *__restrict__ task_begin,
+    const int64_t *__restrict__ task_end, const int32_t *__restrict__ task_slot,
+    const int32_t *__restrict__ indices, const VT *__restrict__ vals, const double *__restrict__ X,
+    int64_t ldx, int nc, double *__restrict__ out, int64_t ldo, double *__restrict__ partial) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t n = ((int64_t)*count < cap) ? (int64_t)*count : cap;
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < n; i += n_waves) {
+        // (wave-uniform by construction; said so, so that the task descriptors stay in scalar registers as in the plan-driven kernel)
+        const int64_t row = row_offset + __builtin_amdgcn_readfirstlane(list[i]);
+        const int64_t t0 = row_first_task[row], t1 = row_first_task[row + 1];
+        const int tb = __builtin_amdgcn_readfirstlane((int)t0), te = __builtin_amdgcn_readfirstlane((int)t1);
+        for (int64_t t = tb; t < te; ++t)
+            spmm_groups_task<VT, GROUPS, double, false, OFF32>(t, lane, task_row, task_begin, task_end, task_slot, indices, vals, X, ldx,
+                                                               nc, out, ldo, partial, 0);
+    }
+}
+
 
 // (The persistent fold-in instance with the head of the factor image in LDS — round 4, measured slower: 0.305 against 0.273 ms
 // — lives in csrc/experiments/spmm_variants.hip; record: profiles/r04_fold_head_probe_ml20m.txt)
@@ -535,4 +574,48 @@ extern "C" int pk_spmm_csr_flagged_f64(void *stream, int64_t n_tasks, const int3
 hipError_t pk_tu_load_spmm() {
     hipFuncAttributes a;
     return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&spmm_fixup_kernel));
+}
+
+// ---- the product on listed rows ------------------------------------------------------------------------------------------
+extern "C" int pk_spmm_csr_rows_list_f64(void *stream, int64_t cap, const int32_t *list_dev, const int32_t *count_dev, int64_t row_offset,
+                                         const int64_t *row_first_task_dev, const int32_t *task_row_dev, const int64_t *task_begin_dev,
+                                         const int64_t *task_end_dev, const int32_t *task_slot_dev, int64_t n_long,
+                                         const int32_t *long_row_dev, const int32_t *long_slot_begin_dev, const int32_t *long_slot_end_dev,
+                                         const int32_t *indices_dev, const void *vals_dev, int val_kind, const double *X_dev, int64_t ldx,
+                                         int32_t nc, double *out_dev, int64_t ldo, double *partial_dev, int64_t x_rows,
+                                         const int32_t *row_flags_dev, int32_t flag_mask) {
+    PK_REQUIRE(cap >= 1 && nc >= 2 && nc <= 256 && nc % 2 == 0, "pk_spmm_csr_rows_list_f64: nc=%d (even, 2..256)", nc);
+    PK_REQUIRE(ldo >= nc && ldx >= nc && ldx % 2 == 0 && (((uintptr_t)X_dev) % 16) == 0, "pk_spmm_csr_rows_list_f64: ldx even, X 16-byte aligned");
+    PK_REQUIRE(list_dev && count_dev && row_first_task_dev && task_row_dev, "pk_spmm_csr_rows_list_f64: bad pointers");
+    PK_REQUIRE(n_long == 0 || (partial_dev != nullptr && row_flags_dev != nullptr), "pk_spmm_csr_rows_list_f64: split rows need the partial buffer and the row flags");
+    PK_REQUIRE(val_kind == PK_VAL_F32 || val_kind == PK_VAL_F64, "pk_spmm_csr_rows_list_f64: bad val_kind %d", val_kind);
+    hipStream_t st = pk_stream(stream);
+    int64_t wgs = pk_ceil_div(cap, 4);
+    if (wgs > 2048) wgs = 2048;
+    const dim3 grid((unsigned)wgs), block(256);
+    const bool off32 = x_rows > 0 && x_rows < (1 << 24) && ldx * 8 < (1 << 24) && x_rows * ldx * 8 < ((int64_t)1 << 32);
+#define PK_LIST_LAUNCH(VT, G, O)                                                                                             \
+    hipLaunchKernelGGL((spmm_csr_rows_list_kernel<VT, G, O>), grid, block, 0, st, cap, list_dev, count_dev, row_offset,      \
+                       row_first_task_dev, task_row_dev, task_begin_dev, task_end_dev, task_slot_dev, indices_dev,           \
+                       static_cast<const VT *>(vals_dev), X_dev, ldx, nc, out_dev, ldo, partial_dev)
+#define PK_LIST_GROUPS(VT, G) do { if (off32) PK_LIST_LAUNCH(VT, G, true); else PK_LIST_LAUNCH(VT, G, false); } while (0)
+#define PK_LIST_NC(VT)                                                                                                       \
+    do {                                                                                                                     \
+        if (nc <= 16) PK_LIST_GROUPS(VT, 16);                                                                                \
+        else if (nc <= 32) PK_LIST_GROUPS(VT, 8);                                                                            \
+        else if (nc <= 64) PK_LIST_GROUPS(VT, 4);                                                                            \
+        else if (nc <= 128) PK_LIST_GROUPS(VT, 2);                                                                           \
+        else PK_LIST_GROUPS(VT, 1);                                                                                          \
+    } while (0)
+    if (val_kind == PK_VAL_F32) PK_LIST_NC(float); else PK_LIST_NC(double);
+#undef PK_LIST_NC
+#undef PK_LIST_GROUPS
+#undef PK_LIST_LAUNCH
+    PK_CHECK_LAUNCH("spmm_csr_rows_list_kernel");
+    if (n_long > 0) {
+        hipLaunchKernelGGL(spmm_fixup_kernel, dim3((unsigned)n_long), dim3(256), 0, st, n_long, long_row_dev, long_slot_begin_dev,
+                           long_slot_end_dev, partial_dev, nc, out_dev, ldo, (int64_t)0, 0, row_flags_dev, flag_mask);
+        PK_CHECK_LAUNCH("spmm_fixup_kernel (listed rows)");
+    }
+    return PK_OK;
 }

@@ -692,6 +692,26 @@ class HipOps:
                 'pk_spmm_csr_flagged_f64')
         return out
 
+    def spmm_rows_list(self, A, X, out, lst, cnt, row_flags, mask=7, rows=None):
+        """out[r, :nc] = (A @ X)[r] for the LISTED rows r = rows[0] + lst[i], i < cnt (device-side list and count; fp64 X, even
+        nc): the exact re-fold of the users a pass could not certify, at the cost of their entries.  row_flags (int32, all
+        rows of A, the listed ones flagged under `mask`) tells the fix-up pass which split rows were redone."""
+        assert X.dtype == torch.float64 and X.stride(1) == 1 and X.shape[0] == A.shape[1] and out.stride(1) == 1
+        assert lst.dtype == torch.int32 and cnt.dtype == torch.int32 and row_flags.dtype == torch.int32 and row_flags.numel() == A.shape[0]
+        nc = X.shape[1]
+        lo = 0 if rows is None else int(rows[0])
+        _, _, l0, n_long = (0, A.n_tasks, 0, A.n_long) if rows is None else A.task_range(int(rows[0]), int(rows[1]))
+        p = A.plan
+        rft = A._ensure_plan()['row_first_task']
+        with self._timed('spmm_rows_list', (int(lst.numel()), nc)):
+            _lib.check(self.lib.pk_spmm_csr_rows_list_f64(
+                self.stream(), int(lst.numel()), _ptr(lst), _ptr(cnt), lo, _ptr(rft), _ptr(p['task_row']), _ptr(p['task_begin']),
+                _ptr(p['task_end']), _ptr(p['task_slot']), n_long, _ptr(p['long_row'], l0), _ptr(p['long_slot_begin'], l0),
+                _ptr(p['long_slot_end'], l0), _ptr(A.indices), _ptr(A.values), A.val_kind, _ptr(X), X.stride(0), nc,
+                _ptr(out), out.stride(0), _ptr(A.partial(nc)), int(X.shape[0]), _ptr(row_flags), int(mask)),
+                'pk_spmm_csr_rows_list_f64')
+        return out
+
     def spmm_flagged_ok(self, X):
         """can `spmm_flagged` take this dense block (even width and stride, 16-byte aligned)?"""
         return X.dtype == torch.float64 and X.shape[1] % 2 == 0 and X.stride(0) % 2 == 0 and X.data_ptr() % 16 == 0 and 2 <= X.shape[1] <= 256

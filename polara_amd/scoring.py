@@ -244,10 +244,14 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
             if not fused_lists:
                 lst, cnt = ops.flag_compact(outs[2], 7)
             if hasattr(ops, 'spmm_flagged') and ops.spmm_flagged_ok(factors.V):
-                # the full product's plan with every wave of an unflagged row leaving at once: thousands of flagged users
-                # (the packed image's weights are ~40x an fp32 rounding) cost what their entries cost, not a
-                # workgroup-with-barriers per row (fold_rows: 86 us for 3 320 users of an ML-20M-shaped pass)
-                ops.spmm_flagged(T, factors.V, Ex, flags, 7, rows=(u0, u1))
+                # the product's own row tasks (mapping, summation order) on the LISTED users: thousands of them (the packed
+                # image's weights are ~40x an fp32 rounding) cost what their entries cost — not a workgroup with barriers
+                # per row (fold_rows: 86 us for 3 320 users of an ML-20M-shaped pass), nor a wave per task of EVERY row
+                # (the flag-predicated launch of the whole plan: 0.23 ms of early exits on S-1M)
+                if hasattr(ops, 'spmm_rows_list'):
+                    ops.spmm_rows_list(T, factors.V, Ex, lst, cnt, flags, 7, rows=(u0, u1))
+                else:
+                    ops.spmm_flagged(T, factors.V, Ex, flags, 7, rows=(u0, u1))
             else:
                 ops.fold_rows(T, lst, cnt, factors.V, Ex, row_offset=u0)
             ops.rescore_topk(factors.V, Eb, n_items, sp, KC, cs, ci, topk, factors.vmax, want_scores=True,

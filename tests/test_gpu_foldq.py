@@ -156,3 +156,32 @@ def test_flagged_product_redoes_exactly_the_flagged_rows(hip_ops, nc, vdtype):
     got2 = hip_ops.to_host(out2)
     inside = hit & (np.arange(n_rows) >= 6) & (np.arange(n_rows) < 2500)
     assert np.array_equal(got2[inside], full[inside]) and (got2[~inside] == -3.0).all()
+
+
+@pytest.mark.parametrize('nc', [2, 16, 50, 64, 100, 256])
+def test_product_on_listed_rows_equals_the_full_product_on_them(hip_ops, nc):
+    """pk_spmm_csr_rows_list_f64: a device-side list of rows (with its count on the device, shorter than the list's capacity)
+    gets the bits of the full product — split long rows included —, every other row keeps what it held; a row range
+    addresses the list relative to its first row, as the scoring pass's user batches do."""
+    rng = np.random.RandomState(100 + nc)
+    n_rows, n_cols = 3000, 1500
+    indptr, indices, values = rand_csr(rng, n_rows, n_cols, 25, long_rows=[(5, 1400), (17, 1100), (2999, 1300)], empty_rows=[0, 7, 2998])
+    A = hip_ops.csr(indptr, indices, values, (n_rows, n_cols), split=256)
+    X = hip_ops.to_device(rng.randn(n_cols, nc))
+    full = hip_ops.to_host(hip_ops.spmm(A, X))
+    for lo, hi in ((0, n_rows), (4, 2600)):
+        rows = np.unique(np.r_[rng.choice(np.arange(lo, hi), 300, replace=False), [5, 7, 17]])
+        rows = rows[(rows >= lo) & (rows < hi)]
+        flags = np.zeros(n_rows, dtype=np.int32)
+        flags[rows] = 4
+        lst = np.zeros(1000, dtype=np.int32)
+        perm = rng.permutation(len(rows))
+        lst[:len(rows)] = (rows - lo)[perm]
+        lst[len(rows):] = 1                       # beyond the count: never read
+        out = torch.full((n_rows, nc + 2), -3.0, dtype=torch.float64, device=hip_ops.device)
+        hip_ops.spmm_rows_list(A, X, out, hip_ops.to_device(lst), hip_ops.to_device(np.array([len(rows)], dtype=np.int32)),
+                               hip_ops.to_device(flags), 7, rows=(lo, hi))
+        got = hip_ops.to_host(out)
+        hit = np.zeros(n_rows, dtype=bool)
+        hit[rows] = True
+        assert np.array_equal(got[hit, :nc], full[hit]) and (got[~hit] == -3.0).all() and (got[:, nc:] == -3.0).all()
