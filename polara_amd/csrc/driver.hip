@@ -1457,7 +1457,7 @@ int serving_score(pk_ctx *ctx, pk_serving *sv, int32_t topk, int32_t filter_seen
         const int Kx = approx ? sv->Kx_full : K, ld32 = sv->ld32;
         DMat Ex(n_users, Kx);
         if (!Ex.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (E)");
-        if (approx && sv->q20_img) {
+        if (approx && sv->q20_img && topk <= 20) {      // (scoring.py: PACKED_MAX_TOPK — longer lists keep the fp32 image)
             // K4q: the packed image — E'[:, :K], the certified weight w in column K, zeros behind it
             Plan &P = Ts.plan;
             const size_t need = (size_t)P.n_slots * Kx * 8;

@@ -19,6 +19,11 @@ from .csr import coo_to_csr
 EXACT_ROWS_BYTES = 2 << 30  # work-buffer budget per launch of the exact path
 MAX_FUSED_RANK = 256        # largest rank the MFMA candidate sweep is instantiated for (csrc/score.hip)
 PACKED_FOLD_IN = True       # the approximate fold-in gathers the packed (one line per rank-50 row) image where one exists
+# ... for lists of at most this many entries: the packed image's error weights are ~40x an fp32 rounding, and every one of a
+# list's topk gaps must clear them — at top-10 0.9 % of the users are re-folded exactly (ML-20M-shaped), at rank 100 / top-20
+# 6.5 % (a wash: 1.62 ms per pass either way), at rank 200 / top-50 46 % (S-50M shard: fold-in 4.9 -> 2.9 ms, but re-fold and
+# second re-scoring 1.7 -> 8.2 ms: 45.7 -> 50.3 ms per pass) — so longer lists keep the fp32 image
+PACKED_MAX_TOPK = 20
 
 
 class FactorImage:
@@ -193,7 +198,7 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
         splits = ops.score_splits(nb, KC, prune)     # of THIS batch: a small head batch is dealt out over item splits
         two_phase = ops.two_phase_plan(nb, n_items, KC) if use_two_phase else (0, 0)     # ... or swept in two phases
         if approx_fold_in:
-            if factors.Q20 is not None and PACKED_FOLD_IN:
+            if factors.Q20 is not None and PACKED_FOLD_IN and topk <= PACKED_MAX_TOPK:
                 ops.fold_q20(T, factors.Q20, K, out=Ex, rows=(u0, u1))     # fold-in against the packed image (K4q)
             else:
                 ops.spmm(T, factors.V32x, out=Ex, rows=(u0, u1))           # fold-in against fl32(V) (K4)
