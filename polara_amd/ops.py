@@ -301,7 +301,12 @@ class HipOps:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.pk_warm_up(), 'pk_warm_up')
             if pipeline:
-                self._warm_pipeline()
+                try:
+                    self._warm_pipeline()
+                except Exception as exc:       # a warm-up must never cost a process its operator set: say so and go on cold
+                    import warnings
+                    warnings.warn('polara_amd: the warm-up pipeline failed (%s: %s); the first build and pass of this process '
+                                  'will pay their first-call costs themselves' % (type(exc).__name__, exc), RuntimeWarning)
             torch.cuda.synchronize(self.device)
         HipOps._warmed.add(key)
         self.warm_up_s = time.perf_counter() - t0
