@@ -333,11 +333,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PK_SPMM_WPE
 }
 
 // The product on LISTED rows: list[0 .. *count) (device-side, e.g. the users a scoring pass could not certify), row =
-// row_offset + list[i]; a wave takes listed rows in turn and walks the row's tasks [row_first_task[row], row_first_task[row + 1])
-// one after the other.  What the flag-predicated launch of the full plan costs — a wave per task of EVERY row, 250 K
-// workgroups that leave at once on S-1M: 0.23 ms for 7 650 listed users — this does not: its grid is a few thousand waves.
+// row_offset + list[i].  A workgroup of PK_LIST_WAVES waves takes listed rows in turn; its waves share the row's tasks
+// [row_first_task[row], row_first_task[row + 1]) (wave w: task t0 + w, t0 + w + PK_LIST_WAVES, ...): the users that need
+// re-folding are the heavy ones — a 9 000-entry row is nine tasks, and one wave walking them one after the other made the
+// whole launch last as long as that row (95 us for 1 267 listed users, first version).  What the flag-predicated launch
+// of the full plan costs — a wave per task of EVERY row, 250 K workgroups that leave at once on S-1M: 0.23 ms for 7 650
+// listed users — this does not: its grid is the list.
+#define PK_LIST_WAVES 8
 template <typename VT, int GROUPS, bool OFF32>
-__global__ __launch_bounds__(256) void spmm_csr_rows_list_kernel(
+__global__ __launch_bounds__(64 * PK_LIST_WAVES) void spmm_csr_rows_list_kernel(
     int64_t cap, const int32_t *__restrict__ list, const int32_t *__restrict__ count, int64_t row_offset,
     const int64_t *__restrict__ row_first_task, const int32_t *__restrict__ task_row, const int64_t *__restrict__ task_begin,
     const int64_t *__restrict__ task_end, const int32_t *__restrict__ task_slot,
@@ -346,13 +350,12 @@ __global__ __launch_bounds__(256) void spmm_csr_rows_list_kernel(
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t n = ((int64_t)*count < cap) ? (int64_t)*count : cap;
-    const int64_t n_waves = (int64_t)gridDim.x * 4;
-    for (int64_t i = (int64_t)blockIdx.x * 4 + wave; i < n; i += n_waves) {
+    for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
         // (wave-uniform by construction; said so, so that the task descriptors stay in scalar registers as in the plan-driven kernel)
         const int64_t row = row_offset + __builtin_amdgcn_readfirstlane(list[i]);
         const int64_t t0 = row_first_task[row], t1 = row_first_task[row + 1];
         const int tb = __builtin_amdgcn_readfirstlane((int)t0), te = __builtin_amdgcn_readfirstlane((int)t1);
-        for (int64_t t = tb; t < te; ++t)
+        for (int64_t t = tb + wave; t < te; t += PK_LIST_WAVES)
             spmm_groups_task<VT, GROUPS, double, false, OFF32>(t, lane, task_row, task_begin, task_end, task_slot, indices, vals, X, ldx,
                                                                nc, out, ldo, partial, 0);
     }
@@ -590,9 +593,9 @@ extern "C" int pk_spmm_csr_rows_list_f64(void *stream, int64_t cap, const int32_
     PK_REQUIRE(n_long == 0 || (partial_dev != nullptr && row_flags_dev != nullptr), "pk_spmm_csr_rows_list_f64: split rows need the partial buffer and the row flags");
     PK_REQUIRE(val_kind == PK_VAL_F32 || val_kind == PK_VAL_F64, "pk_spmm_csr_rows_list_f64: bad val_kind %d", val_kind);
     hipStream_t st = pk_stream(stream);
-    int64_t wgs = pk_ceil_div(cap, 4);
-    if (wgs > 2048) wgs = 2048;
-    const dim3 grid((unsigned)wgs), block(256);
+    int64_t wgs = cap;                 // one workgroup per listed row, at most 4 096 of them in flight (the rest in turn)
+    if (wgs > 4096) wgs = 4096;
+    const dim3 grid((unsigned)wgs), block(64 * PK_LIST_WAVES);
     const bool off32 = x_rows > 0 && x_rows < (1 << 24) && ldx * 8 < (1 << 24) && x_rows * ldx * 8 < ((int64_t)1 << 32);
 #define PK_LIST_LAUNCH(VT, G, O)                                                                                             \
     hipLaunchKernelGGL((spmm_csr_rows_list_kernel<VT, G, O>), grid, block, 0, st, cap, list_dev, count_dev, row_offset,      \

@@ -18,4 +18,5 @@ cd $R
 for k in kt:kernel_stats fetch:pmc_fetch_size write:pmc_write_size sq1:pmc_sq1 sq2:pmc_sq2; do
   python tools/summarize_rocprof.py /tmp/prof_$TAG/${k%%:*} $OUT/r05_${TAG}_${k##*:}.txt > /dev/null
 done
+python tools/summarize_rocprof.py --cross-check $OUT/r05_${TAG}_kernel_stats.txt $OUT/r05_${TAG}_pmc_sq1.txt
 ls -la $OUT
