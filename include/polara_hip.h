@@ -252,7 +252,9 @@ int32_t pk_candidate_capacity(int32_t topk);
  * seen lists must be sorted ascending per user (CSR canonical form).
  * The item range is swept in chunks of `tiles_per_chunk` 32-item tiles, one launch per chunk, so the
  * packed item factors of a chunk stay resident in the 4 MiB per-XCD L2 while every workgroup streams
- * them; the per-user selection state is parked in `state_dev` between launches.
+ * them; the per-user selection state is parked in `state_dev` between launches.  0 = auto: L2-sized chunks for a
+ * full sweep, ONE launch for a pruned one (its groups are spread over the head of the catalogue whatever the launches
+ * do, and every boundary parks and restores the lists; pk_score_chunk_launches tells the count).
  * Threshold bootstrap: a sweep that starts cold first scores its first 16 tiles WITHOUT selecting — every lane keeps the
  * KC / 2 largest group maxima in a sorted register list — and starts from the smallest of a user's KC values, a lower
  * bound of its final KC-th best score: a quarter of the pushes and flush sorts of a cold start (PK_SCORE_BOOT_TILES

@@ -746,7 +746,19 @@ __global__ __launch_bounds__(SHARED ? 64 * pk_shared_waves(KC) : 256) PK_SWEEP_O
 #endif
             {
 #ifdef PK_SCORE_TWO_CHAINS
-                if (TWO && (sidx & 1)) {
+                if (NSTEP > 8) {
+                    // round 5, ranks above 128 (ONE wave per SIMD: nobody else fills the matrix core while a dependent MFMA
+                    // waits for its accumulator): consecutive MFMAs alternate between the two chains
+                    if (sidx & 1) {
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, eh, acc1, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, el, acc, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, eh, acc1, 0, 0, 0);
+                    } else {
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, eh, acc, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, el, acc1, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, eh, acc, 0, 0, 0);
+                    }
+                } else if (TWO && (sidx & 1)) {
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, eh, acc1, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, el, acc1, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, eh, acc1, 0, 0, 0);
@@ -765,7 +777,7 @@ __global__ __launch_bounds__(SHARED ? 64 * pk_shared_waves(KC) : 256) PK_SWEEP_O
             a[2 * sidx + 1] = vp[(2 * sidx + 1) * 64];
         }
 #ifdef PK_SCORE_TWO_CHAINS
-        if (TWO) {
+        if (TWO || NSTEP > 8) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] += acc1[r];
         }

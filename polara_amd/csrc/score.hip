@@ -1277,6 +1277,20 @@ extern "C" int32_t pk_score_splits(int64_t n_users, int32_t KC) {
     return (int32_t)s;
 }
 
+// Item chunks of a sweep when the caller names none.  A FULL sweep (no pruning bounds) is cut into chunks whose packed
+// image fits the L2: its waves all walk the whole catalogue, and a launch boundary per chunk keeps them on the same few MB.
+// A PRUNED sweep is ONE launch (round 5): its groups leave at different tiles and start at different times (more groups
+// than wave slots), so they are spread over the head of the catalogue whatever the launches do (L2 hit rate 92 % at rank
+// 200 with or without chunks, profiles/r05_rank200_sweep.txt) — the chunk boundaries only cost: every wave parks and
+// restores its lists and rings (24 KB at 64 candidates), and a launch waits for its slowest wave.  Measured, chunks that
+// double from launch to launch (rounds 1-4) -> one launch: rank 200 / top-50 sweep 10.3 -> 9.3 ms per 300K users, S-1M pass
+// 3.87 -> 3.73 ms, ML-20M-shaped 0.620 -> 0.610 ms per step (its second launch found every group gone).
+static int pk_auto_chunk_tiles(int kq, int splits, int split_tiles, bool pruned) {
+    if (pruned) return split_tiles > 8 ? split_tiles : 8;
+    int t = PK_CHUNK_BYTES / (kq * 1024) / splits;   // the S chunks of a launch share the L2
+    return t < 8 ? 8 : t;
+}
+
 // number of kernel launches pk_score_candidates_f32 issues for these arguments (item chunks; bench.py's
 // per-pass traffic accounting multiplies the per-launch PMC averages by it)
 extern "C" int32_t pk_score_chunk_launches(int64_t n_items, int32_t K, int32_t splits, int32_t tiles_per_chunk,
@@ -1285,10 +1299,7 @@ extern "C" int32_t pk_score_chunk_launches(int64_t n_items, int32_t K, int32_t s
     if (kq <= 0 || n_items < 1 || splits < 1) return 0;
     const int n_tiles = (int)pk_ceil_div(n_items, 32);
     const int split_tiles = (int)pk_ceil_div(n_tiles, splits);
-    if (tiles_per_chunk <= 0) {
-        tiles_per_chunk = PK_CHUNK_BYTES / (kq * 1024) / splits;
-        if (tiles_per_chunk < 8) tiles_per_chunk = 8;
-    }
+    if (tiles_per_chunk <= 0) tiles_per_chunk = pk_auto_chunk_tiles(kq, splits, split_tiles, pruned != 0);
     int n = 0, ct = tiles_per_chunk;
     for (int b = 0; b < split_tiles; b += ct, ct = (pruned ? 2 * ct : ct)) ++n;
     return n;
@@ -1304,10 +1315,7 @@ static int pk_sweep_launches(hipStream_t st, int64_t n_users, int64_t n_items, i
     const int nstep = pk_nstep(K);
     const int64_t groups = pk_ceil_div(n_users, 32);
     const int split_tiles = (int)pk_ceil_div(n_tiles - ph.tile_base, splits);
-    if (tiles_per_chunk <= 0) {
-        tiles_per_chunk = PK_CHUNK_BYTES / (kq * 1024) / splits;   // the S chunks of a launch share the L2
-        if (tiles_per_chunk < 8) tiles_per_chunk = 8;
-    }
+    if (tiles_per_chunk <= 0) tiles_per_chunk = pk_auto_chunk_tiles(kq, splits, split_tiles, user_bound_dev != nullptr);
     LaneState *st_lane = static_cast<LaneState *>(state_dev);
     uint2 *st_ring = reinterpret_cast<uint2 *>(st_lane + groups * total_slots * 64);
     if (ph.floor_state) ph.floor_state = st_lane;      // the head's records: slot 0

@@ -261,7 +261,8 @@ class HipOps:
         import threading
         self.pass_lock = threading.RLock()   # scoring.recommend enqueues a pass as a whole (per-stream scratch state)
         self._aux_streams = []
-        self.score_tiles_per_chunk = 0   # 0 = auto (L2-sized item chunks); tests force tiny chunks
+        # 0 = auto (L2-sized item chunks); tests force tiny chunks; PK_SCORE_TILES_PER_CHUNK: tuning knob of the measurements
+        self.score_tiles_per_chunk = int(os.environ.get('PK_SCORE_TILES_PER_CHUNK', '0'))
         self.score_splits_override = int(os.environ.get('PK_SCORE_SPLITS', '0'))   # 0 = auto (pk_score_splits); tuning knob
         self._info = torch.zeros(2, dtype=torch.int32, device=self.device)
         self._ctx = None     # a coarse-ABI context (its pool of device blocks) for the C++-driven nested eigen-solve

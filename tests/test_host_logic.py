@@ -497,6 +497,11 @@ def test_bench_compact_line_is_small_and_parses():
         'roofline_build': {'kernel': 'spmm_csr_groups_kernel', 'bound': 'hbm', 'achieved': 401.0, 'peak': 8000.0, 'unit': 'GB/s',
                            'frac': 0.05, 'launches': 330, 'total_ms': 40.0, 'traffic': 1.64e9,
                            'algorithmic_bytes_per_product': 2.16e8, 'gather_note': long_text},
+        'roofline_foldin': {'kernel': 'fold_q20_kernel', 'bound': 'hbm', 'achieved': 1102.0, 'peak': 8000.0, 'unit': 'GB/s',
+                            'frac': 0.1378, 'avg_ms': 0.2014, 'traffic': 3.795e8, 'refolded_users': 1267, 'refold_ms': 0.052,
+                            'algorithmic_bytes': 1.84e8, 'image_row_bytes': 128, 'gather_GBps': 12700.0, 'note': long_text},
+        'cold': {'ops_create_s': 0.2719, 'warm_up_s': 0.1787, 'build_cold_s': 0.04363, 'solver_cold_s': 0.03505,
+                 'first_pass_ms': 1.364, 'hw_queues': 8, 'hw_queues_in_time': True},
         'cpu_baseline': {'value': 9923.0, 'unit': 'users/s', 'cores': 128, 'kind': 'port', 'sample': long_text,
                          'gpu_vs_cpu_identical_rows': 1.0, 'build_s': 21.3, 'build_whole_matrix': True,
                          'speedup_scoring': 15994.0, 'speedup_build': 327.0, 'speedup_build_plus_score': 534.0},
@@ -511,6 +516,11 @@ def test_bench_compact_line_is_small_and_parses():
     assert d['config']['workload'].startswith('ML-20M') and d['config']['swept_fraction'] == 0.0946
     assert set(d['config']['adversarial_users_per_s']) == {'flat_norm', 'pop25_norm', 'no_prune'}
     assert {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'} <= set(d['roofline'])
+    # round 5: the fold-in's own roofline and what a process pays once ride in the line
+    assert {'kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'avg_ms', 'traffic', 'refolded_users', 'refold_ms'} <= set(d['roofline_foldin'])
+    assert abs(d['roofline_foldin']['frac'] - d['roofline_foldin']['achieved'] / d['roofline_foldin']['peak']) < 1e-3
+    assert d['cold'] == {'ops_create_s': 0.2719, 'warm_up_s': 0.1787, 'build_cold_s': 0.04363, 'solver_cold_s': 0.03505,
+                         'first_pass_ms': 1.364, 'hw_queues': 8, 'hw_queues_in_time': True}
     assert {'value', 'unit', 'cores', 'kind', 'sample'} <= set(d['cpu_baseline']) and len(d['cpu_baseline']['sample']) <= 200
     assert abs(d['roofline']['frac'] - d['roofline']['achieved'] / d['roofline']['peak']) < 1e-3
     # no nested free text anywhere

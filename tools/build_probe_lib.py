@@ -3,12 +3,14 @@ their experiment trees (polara_amd/csrc/experiments/: the LDS-staged sweeps, the
 two-buffer / depth-2 / two-chain tile loops, the cycle-counter and ablation switches, the LDS-head fold-in — built,
 verified and measured in rounds 3-4, records in profiles/ and DESIGN.md).  The product library never contains them.
 
-    python tools/build_probe_lib.py out.so [-DPK_SCORE_PROFILE -DPK_FAST_BUILD ...]
+    python tools/build_probe_lib.py out.so [--trees score,spmm] [-DPK_SCORE_PROFILE -DPK_FAST_BUILD ...]
     POLARA_HIP_LIB=out.so python tools/probes/sweep_profile.py ...
 
 The experiment trees export the product ABI of the round they were frozen in (round 4) plus their run-time switches
-(PK_SCORE_SHARED, PK_SCORE_PAIR, PK_FOLD_HEAD, PK_SCORE_ABLATE); entry points added later (the packed fold-in, the
-flagged product) come from the product objects."""
+(PK_SCORE_SHARED, PK_SCORE_PAIR, PK_FOLD_HEAD, PK_SCORE_ABLATE); entry points added later (the packed fold-in) come from the
+product objects.  --trees picks the experiment trees to swap in (default: score only — the product's spmm.hip has grown
+entry points since, the flagged and the list-driven products, that driver.hip needs at link time; `--trees score,spmm`
+links only against a driver that does not call them, i.e. a checkout of round 4's serving path)."""
 import os
 import subprocess
 import sys
@@ -21,12 +23,16 @@ from polara_amd import build_native as bn      # noqa: E402
 def main():
     out = os.path.abspath(sys.argv[1])
     defs = [a for a in sys.argv[2:] if a.startswith('-D')]
+    trees = 'score'
+    if '--trees' in sys.argv:
+        trees = sys.argv[sys.argv.index('--trees') + 1]
+    trees = set(trees.split(','))
     bn.build(verbose=False)
     exp = os.path.join(bn.CSRC, 'experiments')
     objs = []
     for src in bn.sources():
         alt = os.path.join(exp, src.replace('.hip', '_variants.hip'))
-        if os.path.exists(alt):
+        if os.path.exists(alt) and src.replace('.hip', '') in trees:
             obj = os.path.join(bn.OBJDIR, 'probe_' + src + '.o')
             cmd = [bn.HIPCC] + bn.FLAGS + defs + ['-I', bn.CSRC, '-x', 'hip', '-c', alt, '-o', obj]
             r = subprocess.run(cmd, capture_output=True, text=True)
