@@ -149,9 +149,12 @@ struct LaneState {
 // NSTEP = number of 16-wide k-steps (rank padded with zeros to 16 * NSTEP, rounded up to a supported value); the packed
 // operands hold KQ = 2 * NSTEP 16-byte groups per lane and tile: the eight hi parts, then the eight lo parts of a step.
 __host__ __device__ constexpr bool pk_top_in_lds(int nstep, int kc) { return kc <= 32 || nstep > 8; }
-__host__ __device__ constexpr int pk_ring_rows(int kc) { return kc == 16 ? 8 : RING; }
+// Ranks above 128 with 64 candidates (one wave per SIMD, one workgroup per CU whatever the LDS): 32 ring entries per lane —
+// a flush sorts 128 elements there anyway (64 + 2 x 16 padded to 128), now they are all real: half as many flush sorts
+// (five per user and a quarter of the sweep's wave-cycles at rank 200 / top-50, profiles/r05_rank200_sweep.txt).
+__host__ __device__ constexpr int pk_ring_rows(int nstep, int kc) { return kc == 16 ? 8 : ((nstep > 8 && kc == 64) ? 2 * RING : RING); }
 __host__ __device__ constexpr size_t pk_score_lds_bytes(int nstep, int kc) {
-    return (size_t)(4 * pk_ring_rows(kc) * 64 + (pk_top_in_lds(nstep, kc) ? 4 * 32 * kc : 1)) * sizeof(uint2);
+    return (size_t)(4 * pk_ring_rows(nstep, kc) * 64 + (pk_top_in_lds(nstep, kc) ? 4 * 32 * kc : 1)) * sizeof(uint2);
 }
 // Dense seen masks of the head of the catalogue (pk_seen_dense_build): mask[(group * tiles + tile) * 32 + user % 32] =
 // the 32-bit seen mask of that user in that tile for tile < tiles, ONE coalesced 128-byte load per tile-wave that is
@@ -182,7 +185,7 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
     // KC == 16: rings of 8, so that a user's list + both rings are 32 entries and TWO users are merged
     // per flush, one in each half of the wave (15 sort stages per two users instead of 21 per user).
     constexpr bool PAIRED = (KC == 16);
-    constexpr int RG = pk_ring_rows(KC);
+    constexpr int RG = pk_ring_rows(NSTEP, KC);
     constexpr int SLOTS = (2 * RG + KC + 63) / 64;
     // The running top-KC lists of the wave's 32 users live in LDS when they fit (KC <= 32): a flush
     // then never touches global memory (no vmcnt drain in the middle of the MFMA stream).  They are
@@ -511,6 +514,18 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
     // a user has several seen items per tile, every one a dependent load — the sweep was latency
     // bound there once pruning had cut it down to the head.)
     unsigned m_dense = 0;        // dense mask of the CURRENT tile (requested one tile ahead, see the loop)
+    // Round 5: the record that refills the window after a hit is REQUESTED at the hit and TAKEN at the next one (`pend`).
+    // Written as `nxt3 = seen_tiles[sp + 2]` inside the divergent `if (hit)` the value had to be in its register before the
+    // branch closed: the compiler put `s_waitcnt vmcnt(0)` right behind the load — a whole memory round trip on every tile in
+    // which some lane hit, and with it (loads return in order) the wait for all the fragment loads of the NEXT tile that
+    // had just been requested.  Now the load is issued for all lanes (lanes without a refill read record 0) and nobody
+    // looks at it before the lane's next hit, at least a tile later: `s_waitcnt vmcnt(<the fragment loads issued since>)`.
+    unsigned long long pend = PK_TILE_NONE;
+    bool has_pend = false;
+    auto take_pending = [&]() {       // sp has not moved since the request
+        if (has_pend) nxt3 = (sp + 2 < se) ? pend : PK_TILE_NONE;
+        has_pend = false;
+    };
     auto walk_mask = [&](int tile) -> unsigned {
         const int j0 = tile * 32, jend = j0 + 32;
         unsigned mask = 0;
@@ -526,6 +541,7 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
             // records of tiles that belong to the other splits lie between two of mine: step over them
             // (wave-uniform test; the three-record prefetch window keeps the common one-or-two steps cheap)
             while (__any((unsigned)(nxt >> 32) < (unsigned)tile)) {
+                take_pending();
                 if ((unsigned)(nxt >> 32) < (unsigned)tile) {
                     ++sp;
                     nxt = nxt2;
@@ -536,13 +552,16 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
         }
         const bool hit = (unsigned)(nxt >> 32) == (unsigned)tile;
         if (__any(hit)) {
+            take_pending();
             if (hit) {
                 mask = (unsigned)nxt;
                 ++sp;
                 nxt = nxt2;
                 nxt2 = nxt3;
-                nxt3 = (sp + 2 < se) ? seen_tiles[sp + 2] : PK_TILE_NONE;
+                nxt3 = PK_TILE_NONE;         // until the request below is taken (not before this lane's next hit)
             }
+            pend = seen_tiles[(hit && sp + 2 < se) ? sp + 2 : 0];
+            has_pend = hit;
         }
         if (jend > n_items) mask |= ~0u << (n_items - j0);  // padding items of the last tile
         return mask;
@@ -661,6 +680,7 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
         nxt = n0;
         nxt2 = n1;
         nxt3 = n2;
+        has_pend = false;
     }
     {
         // One tile per iteration; the fragments of the NEXT tile are requested before this tile's
@@ -739,7 +759,12 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
     }
 
     if (!last && !pruned) {
-        // park the state for the next item chunk (rings stay unsorted: no flush cost per chunk)
+        // park the state for the next item chunk (rings stay unsorted: no flush cost per chunk; the parked image holds RING
+        // rows per lane — an instance with longer rings merges the users beyond that first)
+        if constexpr (RG > RING) {
+            const unsigned long long over = __ballot(cnt > RING);
+            flush_set((unsigned)(over | (over >> 32)));
+        }
         LaneState ls;
         ls.sp = sp;
         ls.tau = tau;
