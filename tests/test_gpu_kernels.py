@@ -338,26 +338,39 @@ def test_fused_scoring_pipeline_exact(hip_ops, cfg):
                     assert not (set(recs[u]) & seen), (u, cfg)
 
 
+@pytest.mark.parametrize('shape', [(50, 10), (200, 50), (160, 24)], ids=lambda s: 'K%d_top%d' % s)
 @pytest.mark.parametrize('tiles_per_chunk', [1, 3, 17])
-def test_chunked_item_sweep_equals_single_sweep(hip_ops, tiles_per_chunk):
-    """The per-user selection state parked between item-chunk launches must make the result
-    independent of the chunking."""
+def test_chunked_item_sweep_equals_single_sweep(hip_ops, tiles_per_chunk, shape):
+    """The per-user selection state parked between item-chunk launches must make the result independent of the chunking —
+    also for the rank > 128 / 64-candidate instance, whose rings hold 32 entries per lane while the parked image holds 16
+    (longer rings are merged before parking), and whatever the automatic choice is (round 5: a pruned sweep is ONE launch,
+    a full sweep L2-sized chunks)."""
     from polara_amd import scoring
-    rng = np.random.RandomState(11)
-    n_users, n_items, K, topk = 150, 3000, 50, 10
-    V = np.linalg.qr(rng.randn(n_items, K))[0]
+    K, topk = shape
+    rng = np.random.RandomState(11 + K)
+    n_users, n_items = 150, 3000
+    V = np.linalg.qr(rng.randn(n_items, K))[0] * ((1.0 + np.arange(n_items)) ** -0.3)[:, None]
     indptr, indices, values = rand_csr(rng, n_users, n_items, 40, long_rows=[(2, 2500)], empty_rows=[5])
     T = hip_ops.csr(indptr, indices, values, (n_users, n_items))
     F = scoring.FactorImage(hip_ops, hip_ops.to_device(V))
     hip_ops.score_tiles_per_chunk = 10 ** 6
     try:
-        ref, ref_s = scoring.recommend(hip_ops, F, T, topk, True, return_scores=True)
-        hip_ops.score_tiles_per_chunk = tiles_per_chunk
-        got, got_s = scoring.recommend(hip_ops, F, T, topk, True, return_scores=True)
+        ref, ref_s = scoring.recommend(hip_ops, F, T, topk, True, return_scores=True, two_phase_ok=False)
+        for prune in (True, False):
+            hip_ops.score_tiles_per_chunk = tiles_per_chunk
+            got, got_s = scoring.recommend(hip_ops, F, T, topk, True, return_scores=True, prune=prune, two_phase_ok=False)
+            hip_ops.score_tiles_per_chunk = 0
+            auto, auto_s = scoring.recommend(hip_ops, F, T, topk, True, return_scores=True, prune=prune, two_phase_ok=False)
+            for a, b in ((ref, got), (ref_s, got_s), (ref, auto), (ref_s, auto_s)):
+                assert np.array_equal(hip_ops.to_host(a), hip_ops.to_host(b)), prune
     finally:
         hip_ops.score_tiles_per_chunk = 0
-    assert np.array_equal(hip_ops.to_host(ref), hip_ops.to_host(got))
-    assert np.array_equal(hip_ops.to_host(ref_s), hip_ops.to_host(got_s))
+    # the launch count behind the automatic choice
+    n_tiles = -(-n_items // 32)
+    assert hip_ops.lib.pk_score_chunk_launches(n_items, K, 1, 0, 1) == 1
+    assert hip_ops.lib.pk_score_chunk_launches(n_items, K, 1, 0, 0) >= 1
+    assert hip_ops.lib.pk_score_chunk_launches(10 ** 6, 50, 1, 0, 0) > 1 and hip_ops.lib.pk_score_chunk_launches(10 ** 6, 50, 1, 0, 1) == 1
+    assert hip_ops.lib.pk_score_chunk_launches(n_items, K, 1, 7, 0) == -(-n_tiles // 7)
 
 
 def test_seen_tile_stream(hip_ops):
