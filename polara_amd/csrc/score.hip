@@ -338,6 +338,71 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
         const int c_lo = __builtin_amdgcn_readlane(cnt, x);
         const int c_hi = __builtin_amdgcn_readlane(cnt, x + 32);
         if (!TOP_LDS) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if constexpr (SLOTS == 2 && KC == 64) {
+            // 64 candidates (round 5): SORT the <= 64 ring entries (one element per lane, 21 stages), MERGE with the list.
+            // The list lies sorted in lane order; reversed ring entries behind it make a bitonic sequence, so ONE
+            // compare-exchange lane by lane leaves the 64 best of the 128 in the list's lanes (the 64 losers are dropped
+            // unsorted) and six more stages sort them: 28 one-element stages instead of the 28 two-element stages of a full
+            // 128-element sort (~half the flush; rank 200 / top-50: a fifth of the sweep's wave-cycles were flush sorts).
+            // Keys as before (ordered score, low 7 bits = where the element came from): a ring entry's code is its lane
+            // (0..63), list entry t's is 127 - t — descending along the list also where truncated scores tie, which is what
+            // keeps the list a sorted run under the NEW keys (it was written in the order of the previous flush's keys).
+            constexpr unsigned SRC_MASK = 127u;
+            float ka = -INFINITY, kb = -INFINITY;
+            int va = PK_IDX_NONE, vb = PK_IDX_NONE;
+            if (TOP_LDS) {
+                const uint2 r = top[x * KC + lane];
+                if ((int)r.y >= 0) {
+                    ka = __uint_as_float(r.x);
+                    va = (int)r.y;
+                }
+            } else {
+                const int iv = my_idx[x * KC + lane];
+                if (iv >= 0) {
+                    ka = my_score[x * KC + lane];
+                    va = iv;
+                }
+            }
+            if (lane < RG) {
+                if (lane < c_lo) {
+                    const uint2 r = ring[lane][x];
+                    kb = __uint_as_float(r.x);
+                    vb = (int)r.y;
+                }
+            } else if (lane < 2 * RG) {
+                if (lane - RG < c_hi) {
+                    const uint2 r = ring[lane - RG][x + 32];
+                    kb = __uint_as_float(r.x);
+                    vb = (int)r.y;
+                }
+            }
+            unsigned qa = (pk_float_order(ka) & ~SRC_MASK) | (unsigned)(127 - lane);
+            unsigned qb[1] = {(pk_float_order(kb) & ~SRC_MASK) | (unsigned)lane};
+            pk_sort32_wave_desc<1>(qb);
+            const unsigned qr = (unsigned)__shfl((int)qb[0], 63 - lane, 64);     // ring keys ascending
+            unsigned q[1] = {qa > qr ? qa : qr};                                   // the 64 best: a bitonic sequence
+            pk_sort32_merge<1, 64, 32>(q);
+            const int code = (int)(q[0] & SRC_MASK);
+            const int src = (code >= 64) ? 127 - code : code;
+            const float fa = __shfl(ka, src, 64), fb = __shfl(kb, src, 64);
+            const int ia = __shfl(va, src, 64), ib = __shfl(vb, src, 64);
+            const float fk = (code >= 64) ? fa : fb;
+            const int fv = (code >= 64) ? ia : ib;
+            const int iv = (fv == PK_IDX_NONE) ? -1 : fv;
+            if (TOP_LDS) {
+                top[x * KC + lane] = make_uint2(__float_as_uint(fk), (unsigned)iv);
+            } else {
+                my_score[x * KC + lane] = fk;
+                my_idx[x * KC + lane] = iv;
+            }
+            const float ntau = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fk), KC - 1));
+            if (ul == x) {
+                tau = fmaxf(ntau, tau_floor);
+                cnt = 0;
+            }
+            __builtin_amdgcn_wave_barrier();
+            return;
+        }
         float key[SLOTS];
         int val[SLOTS];
 #pragma unroll
