@@ -44,7 +44,7 @@ def main():
     r = subprocess.run([bn.HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out] + objs, capture_output=True, text=True)
     if r.returncode != 0:
         raise SystemExit('link failed:\n' + r.stderr)
-    print('%s (%d bytes; experiment trees: %s)' % (out, os.path.getsize(out), ', '.join(sorted(os.listdir(exp)))))
+    print('%s (%d bytes; experiment trees swapped in: %s)' % (out, os.path.getsize(out), ', '.join(sorted(trees))))
 
 
 if __name__ == '__main__':
