@@ -607,7 +607,11 @@ int pk_svd_build(pk_ctx *ctx, pk_mat *A, int32_t k, int32_t block, double tol, i
  * The library does not link a collective library: the host passes its communicator as a callback — with RCCL
  *     int ar(void *user, void *buf, int64_t n, void *stream) {
  *         return ncclAllReduce(buf, buf, n, ncclDouble, ncclSum, (ncclComm_t)user, (hipStream_t)stream) == ncclSuccess ? 0 : -1; }
- * `stream` is the context's HIP stream: the call must be ordered on it (enqueue, or block until done). */
+ * `stream` is the HIP stream the call must be ordered on (enqueue there, or block until done): the context's stream, or
+ * — when the exchange of a Gramian product is long enough to be worth hiding (modelled all-reduce >= 0.4 ms; PK_DIST_OVERLAP=
+ * 0 / force) — a side stream of the library for the FIRST of the product's two column panels, whose sum then travels
+ * while the second panel is computed (the same rule and the same two panels as polara_amd/solver.py::ItemRows.product).
+ * Every rank issues its calls in the same order. */
 typedef struct pk_comm {
     int32_t rank, world;
     int (*allreduce_sum_f64)(void *user, void *buf_dev, int64_t count, void *stream);   /* in place, DEVICE pointer; 0 = ok */

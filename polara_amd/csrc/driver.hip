@@ -325,6 +325,13 @@ int spmm_t(pk_ctx *ctx, pk_mat *m, const DMat &Y, DMat &Z) {
     return PK_OK;
 }
 
+// Z [n_cols x w] = A^T Y[:, c0 : c0 + w]: one column panel of the product (the panels of GramianOp::apply)
+int spmm_t_cols(pk_ctx *ctx, pk_mat *m, const DMat &Y, int c0, int w, DMat &Z) {
+    for (int64_t b = 0; b < m->n_blocks; ++b)
+        CK(spmm(ctx, *m->Tb, Y.p() + c0, PK_VAL_F64, Y.l, w, Z.p(), Z.l, m->block_ranges[(size_t)b], b * m->A.n_cols, b > 0));
+    return PK_OK;
+}
+
 // ---- dense helpers (each returns a fresh matrix through `out`) -------------------------------------------------------
 struct Solver {
     pk_ctx *ctx;
@@ -826,11 +833,38 @@ struct GramianOp {
     pk_mat *A;
     const pk_comm *comm;
     int steps = 0;
-    int allreduce(DMat &M) {
+    int overlapped_panels = 0;
+    // the exchange of a product's first column panel travels on this stream while the second panel is computed
+    hipStream_t side = nullptr;
+    hipEvent_t ev_panel = nullptr, ev_summed = nullptr;
+    GramianOp(pk_ctx *c, Solver &s, pk_mat *a, const pk_comm *cm) : ctx(c), S(s), A(a), comm(cm) {}
+    GramianOp(const GramianOp &) = delete;
+    GramianOp &operator=(const GramianOp &) = delete;
+    ~GramianOp() {
+        if (side) {
+            (void)hipStreamSynchronize(side);
+            (void)hipStreamDestroy(side);
+        }
+        if (ev_panel) (void)hipEventDestroy(ev_panel);
+        if (ev_summed) (void)hipEventDestroy(ev_summed);
+    }
+    int allreduce(DMat &M, hipStream_t on = nullptr) {
         if (!comm) return PK_OK;
-        if (comm->allreduce_sum_f64(comm->user, M.p(), (int64_t)M.n * M.l, (void *)ctx->stream) != 0)
+        if (comm->allreduce_sum_f64(comm->user, M.p(), (int64_t)M.n * M.l, (void *)(on ? on : ctx->stream)) != 0)
             return fail(ctx, PK_E_LAUNCH, "pk_svd_build_sharded: the communicator's all-reduce failed");
         return PK_OK;
+    }
+    // Is the exchange of an [n_cols x l] block long enough to be worth hiding behind half of its own products?  The rule of
+    // solver.py::ItemRows.product (one statement of the solver, two languages): the modelled all-reduce reaches 0.4 ms —
+    // the split costs two launches of A^T Y per user block instead of one, and a half-width panel costs ~0.7 of the full
+    // launch, not half.  PK_DIST_OVERLAP: 0 = never, force = whenever there is something to exchange (tests).
+    bool split_product(int l) const {
+        if (!comm || comm->world < 2 || l < 32 || l % 16 != 0) return false;
+        const char *mode = getenv("PK_DIST_OVERLAP");
+        if (mode && strcmp(mode, "0") == 0) return false;
+        if (mode && strcmp(mode, "force") == 0) return true;
+        constexpr double kXgmiBusBps = 100e9 /* assumed: machine_model.py xgmi_bus_Bps */;
+        return 2.0 * (comm->world - 1) / comm->world * (double)A->A.n_cols * l * 8.0 / kXgmiBusBps >= 4e-4;
     }
     int ritz(const DMat &X, DMat &H, DMat &Y) {
         Y = DMat(A->A.n_rows, X.l);
@@ -850,12 +884,39 @@ struct GramianOp {
     }
     int apply(const DMat &Xb, DMat &Z) {
         DMat Y(A->A.n_rows, Xb.l);
-        Z = DMat(A->A.n_cols, Xb.l);
-        if (!Y.ok() || !Z.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (gramian step)");
+        if (!Y.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (gramian step)");
         CK(spmm_full(ctx, A->A, Xb, Y));
-        CK(spmm_t(ctx, A, Y, Z));
         ++steps;
-        return allreduce(Z);
+        if (!split_product(Xb.l)) {
+            Z = DMat(A->A.n_cols, Xb.l);
+            if (!Z.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (gramian step)");
+            CK(spmm_t(ctx, A, Y, Z));
+            return allreduce(Z);
+        }
+        // TWO column panels (solver.py::ItemRows.product): the first panel's sum is handed to the communicator on the SIDE
+        // stream — the callback's contract is "ordered on the stream it is given": RCCL enqueues there — and the second
+        // panel's products are enqueued behind the first's on the context's stream, so they run while that sum travels;
+        // the second sum goes on the context's stream, which then waits for the first.  Every rank issues the two sums in
+        // the same order.  The panels are contiguous buffers (what a collective wants), joined afterwards.
+        if (!side) {
+            HIPCK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+            HIPCK(hipEventCreateWithFlags(&ev_panel, hipEventDisableTiming));
+            HIPCK(hipEventCreateWithFlags(&ev_summed, hipEventDisableTiming));
+        }
+        const int w0 = Xb.l / 2, w1 = Xb.l - w0;
+        DMat Z0(A->A.n_cols, w0), Z1(A->A.n_cols, w1);
+        if (!Z0.ok() || !Z1.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (gramian step panels)");
+        CK(spmm_t_cols(ctx, A, Y, 0, w0, Z0));
+        HIPCK(hipEventRecord(ev_panel, ctx->stream));
+        HIPCK(hipStreamWaitEvent(side, ev_panel, 0));
+        CK(allreduce(Z0, side));
+        CK(spmm_t_cols(ctx, A, Y, w0, w1, Z1));
+        CK(allreduce(Z1));
+        HIPCK(hipEventRecord(ev_summed, side));
+        HIPCK(hipStreamWaitEvent(ctx->stream, ev_summed, 0));
+        CK(S.hcat(&Z0, Z1, Z));
+        ++overlapped_panels;
+        return PK_OK;
     }
 };
 

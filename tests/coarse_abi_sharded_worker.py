@@ -103,6 +103,7 @@ def main():
         check(ctx, lib.pk_mat_from_csr(ctx, M.shape[0], M.shape[1], M.nnz, ptr(ip), ptr(ix), ptr(vv), 1, C.byref(h)), 'pk_mat_from_csr')
         return h
     Ml = upload(Al)
+    os.environ['PK_DIST_OVERLAP'] = '0'
     sigma, V = np.empty(k), np.empty((n_items, k), order='F')
     U = np.empty((hi - lo, k), order='F')
     st = Stats()
@@ -111,6 +112,38 @@ def main():
     # one all-reduce of Z per Gramian step + one of the Rayleigh-Ritz matrix per outer iteration (+ ONE scalar at the start:
     # the entry count of the whole matrix, from which every rank picks the same method): nothing else leaves the rank
     assert st.converged == 1 and calls['n'] == st.gramian_steps + st.outer + 1, (calls, st.gramian_steps, st.outer)
+    # The same build with every Gramian product cut into TWO column panels (PK_DIST_OVERLAP=force; on its own the library
+    # splits when the modelled exchange reaches 0.4 ms): the first panel's sum is handed to the callback on a SIDE stream
+    # while the second panel's products are enqueued — twice the all-reduce calls for the steps, the same bytes, the same
+    # factors.
+    n0, b0 = calls['n'], calls['bytes']
+    os.environ['PK_DIST_OVERLAP'] = 'force'
+    sigma2, V2 = np.empty(k), np.empty((n_items, k), order='F')
+    st2 = Stats()
+    streams = set()
+    side_calls = [0]
+    inner = allreduce
+    main_stream = lib.pk_ctx_stream(ctx)
+
+    def allreduce_seen(user, buf, count, stream):
+        streams.add(stream)
+        side_calls[0] += int(stream != main_stream)
+        return inner(user, buf, count, stream)
+    cb2 = ALLREDUCE(allreduce_seen)
+    comm2 = Comm(rank, world, cb2, None)
+    check(ctx, lib.pk_svd_build_sharded(ctx, Ml, C.byref(comm2), k, 0, 0.0, 0, 7, ptr(sigma2), ptr(V2), None, C.byref(st2)),
+          'pk_svd_build_sharded (two panels)')
+    os.environ['PK_DIST_OVERLAP'] = '0'
+    assert st2.converged == 1 and st2.gramian_steps == st.gramian_steps and st2.outer == st.outer
+    # every product of a full-width block went in two panels (blocks narrowed by locking, and the rotations of the
+    # Rayleigh-Ritz steps, go whole): one more call per split product, the first panel's on the side stream
+    assert side_calls[0] >= 1 and calls['n'] - n0 == st2.gramian_steps + st2.outer + 1 + side_calls[0], (calls, n0, side_calls)
+    assert calls['bytes'] - b0 == b0
+    assert len(streams) == 2 and main_stream in streams, streams     # the context's stream and the side stream
+    # (a half-width panel runs another instance of the product kernel — more lane groups per row, another summation order:
+    # the factors agree to rounding, not bit for bit)
+    assert np.allclose(sigma, sigma2, rtol=1e-11, atol=0.0), np.abs(sigma - sigma2).max()
+    assert np.abs(V @ V.T - V2 @ V2.T).max() < 1e-9
     # the same on every rank, bit for bit (all-reduced inputs, identical arithmetic)
     both = [torch.empty(n_items * k + k, dtype=torch.float64) for _ in range(world)]
     dist.all_gather(both, torch.from_numpy(np.r_[sigma, V.ravel(order='F')]))
