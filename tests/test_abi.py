@@ -35,6 +35,12 @@ def test_python_prototypes_cover_the_header():
     assert lib.pk_candidate_capacity(50) == 64 and lib.pk_candidate_capacity(100) == 0
     assert lib.pk_pack_elems(33, 50) == 2 * 8 * 64 * 4
     assert lib.pk_gram_work_bytes(1000, 64, 64) > 0
+    # launches of a candidate sweep (round 5): a pruned sweep is ONE launch whatever the catalogue; a full sweep is cut into
+    # L2-sized item chunks; an explicit chunk length is honoured (doubling from launch to launch when pruned)
+    assert lib.pk_score_chunk_launches(26744, 50, 1, 0, 1) == 1 and lib.pk_score_chunk_launches(500000, 200, 1, 0, 1) == 1
+    assert lib.pk_score_chunk_launches(100000, 50, 1, 0, 0) == -(-3125 // 320)
+    assert lib.pk_score_chunk_launches(26744, 50, 1, 100, 0) == 9 and lib.pk_score_chunk_launches(26744, 50, 1, 100, 1) == 4
+    assert lib.pk_score_splits(138493, 16) == 1 and lib.pk_score_splits(2000, 16) == 4
 
 
 def test_no_cpu_fallback_in_package():
