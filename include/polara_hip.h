@@ -285,6 +285,18 @@ int pk_score_candidates_f32(void *stream, int64_t n_users, int64_t n_items, int3
                             const float *tile_bound_dev /* [ceil(n_items/32)] or NULL */,
                             const uint32_t *seen_dense_dev, const int32_t *seen_skip_dev,
                             int32_t dense_tiles /* pk_seen_dense_build output, or NULL, NULL, 0: the stream serves every tile */);
+/* The same sweep with the users' side read from the fp64 ROWS of E = test_matrix.dot(v) (models.py:860) as the fold-in
+ * leaves them: every wave builds its 32 users' MFMA fragments and pruning bounds in its prologue — the arithmetic of
+ * pk_pack_frag_bound_f32, bit for bit: bound_u = ||E[u, :K]|| (1 + 1e-6) + extra_scale * extra[u * extra_ld] — so a pass
+ * needs neither the packing launch nor a packed copy of E.  E_dev 16-byte aligned, lde even and >= K; extra_dev: the
+ * error weight column of an approximate fold-in, or NULL; tile_bound_dev == NULL: full sweep (no pruning). */
+int pk_score_candidates_rows_f32(void *stream, int64_t n_users, int64_t n_items, int32_t K, const float *Vp_dev,
+                                 const double *E_dev, int64_t lde, const double *extra_dev, int64_t extra_ld,
+                                 double extra_scale, const int64_t *seen_ptr_dev, const uint64_t *seen_tiles_dev,
+                                 const int32_t *seen_ntiles_dev, int32_t KC, int32_t splits, float *cand_score_dev,
+                                 int32_t *cand_idx_dev, void *state_dev, int32_t tiles_per_chunk /* 0 = auto */,
+                                 const float *tile_bound_dev /* or NULL */, const uint32_t *seen_dense_dev,
+                                 const int32_t *seen_skip_dev, int32_t dense_tiles);
 /* The pruned sweep in TWO PHASES (replaces the same reference lines: the chunk loop body of models.py:359-371, with
  * downvote_seen_items :494-519 and topsort :488-491 fused in).  A launch of the single sweep lasts as long as its slowest
  * wave — the groups of the heaviest users stay ~270 tiles in the sweep, everybody else 70-130 — so the catalogue is
@@ -309,6 +321,14 @@ int pk_score_two_phase_f32(void *stream, int64_t n_users, int64_t n_items, int32
                            void *state_dev, int32_t tiles_per_chunk /* 0 = auto */,
                            const float *user_bound_dev, const float *tile_bound_dev /* both required */,
                            const uint32_t *seen_dense_dev, const int32_t *seen_skip_dev, int32_t dense_tiles);
+/* ... with the users' side from the rows of E (see pk_score_candidates_rows_f32; tile_bound_dev required) */
+int pk_score_two_phase_rows_f32(void *stream, int64_t n_users, int64_t n_items, int32_t K, const float *Vp_dev,
+                                const double *E_dev, int64_t lde, const double *extra_dev, int64_t extra_ld,
+                                double extra_scale, const int64_t *seen_ptr_dev, const uint64_t *seen_tiles_dev,
+                                const int32_t *seen_ntiles_dev, int32_t KC, int32_t head_tiles, int32_t splits,
+                                float *work_score_dev, int32_t *work_idx_dev, float *cand_score_dev, int32_t *cand_idx_dev,
+                                void *state_dev, int32_t tiles_per_chunk, const float *tile_bound_dev,
+                                const uint32_t *seen_dense_dev, const int32_t *seen_skip_dev, int32_t dense_tiles);
 /* Dense seen masks for the first dense_tiles tiles of the catalogue — where the sweep spends its time, and where a user
  * has a record in nearly every tile: dense_dev[(u / 32 * dense_tiles + tile) * 32 + u % 32] = the user's 32-bit mask in
  * that tile (one coalesced 128-byte load per tile and wave instead of a cursor walk with a scattered 8-byte load per

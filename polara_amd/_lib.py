@@ -71,6 +71,10 @@ PROTOTYPES = {
     'pk_seen_tiles_max_unsorted_row': (_i32, []),
     'pk_score_candidates_f32': (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp,
                                           _i32, _vp, _vp, _vp, _vp, _i32]),
+    'pk_score_candidates_rows_f32': (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _i64, _vp, _i64, _f64, _vp, _vp, _vp, _i32, _i32,
+                                               _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32]),
+    'pk_score_two_phase_rows_f32': (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _i64, _vp, _i64, _f64, _vp, _vp, _vp, _i32, _i32, _i32,
+                                              _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32]),
     'pk_score_two_phase_plan': (C.c_int, [_i64, _i64, _i32, _vp, _vp]),
     'pk_score_two_phase_f32': (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp,
                                          _i32, _vp, _vp, _vp, _vp, _i32]),

@@ -1531,9 +1531,15 @@ int serving_score(pk_ctx *ctx, pk_serving *sv, int32_t topk, int32_t filter_seen
         } else if (approx) CK(spmm(ctx, Ts, sv->V32.p, PK_VAL_F32, ld32, Kx, Ex.p(), Kx, all));
         else CK(spmm(ctx, Ts, V.p(), PK_VAL_F64, K, K, Ex.p(), Kx, all));
         const double *w = approx ? Ex.p() + K : nullptr;
-        Dev Ep((size_t)pk_pack_elems(n_users, K) * 4), ub((size_t)n_users * 4);
-        if (!Ep.p || !ub.p) return fail(ctx, PK_E_LAUNCH, "out of device memory (E fragments)");
-        CK(pk_pack_frag_bound_f32(st, n_users, K, Ex.p(), Kx, Ep.as<float>(), ub.as<float>(), w, approx ? Kx : 0, 1.2e-7));
+        // the users' fragments and pruning bounds: built by the sweep's own waves from the rows of E when those are aligned
+        // (scoring.py: SWEEP_FROM_ROWS — no packing launch, no packed copy), else by the packing kernel
+        const bool from_rows = (Kx % 2 == 0) && (((uintptr_t)Ex.p()) % 16 == 0);
+        Dev Ep, ub;
+        if (!from_rows) {
+            if (!Ep.alloc((size_t)pk_pack_elems(n_users, K) * 4) || !ub.alloc((size_t)n_users * 4))
+                return fail(ctx, PK_E_LAUNCH, "out of device memory (E fragments)");
+            CK(pk_pack_frag_bound_f32(st, n_users, K, Ex.p(), Kx, Ep.as<float>(), ub.as<float>(), w, approx ? Kx : 0, 1.2e-7));
+        }
         if (filter_seen && !sv->have_tiles) {
             if (!sv->tiles.alloc(n1 * 8) || !sv->ntiles.alloc((size_t)n_users * 4)) return fail(ctx, PK_E_LAUNCH, "out of device memory (seen tiles)");
             CK(pk_seen_tiles_build(st, n_users, Ts.indptr.as<int64_t>(), Ts.indices.as<int32_t>(), 1, 0, sv->tiles.as<uint64_t>(), sv->ntiles.as<int32_t>()));
@@ -1564,12 +1570,22 @@ int serving_score(pk_ctx *ctx, pk_serving *sv, int32_t topk, int32_t filter_seen
         const uint32_t *dense_p = (filter_seen && sv->dense_tiles) ? sv->dense.as<uint32_t>() : nullptr;
         const int32_t *skip_p = (filter_seen && sv->dense_tiles) ? sv->skip.as<int32_t>() : nullptr;
         if (head_tiles) {
-            CK(pk_score_two_phase_f32(st, n_users, n_items, K, sv->Vp.as<float>(), Ep.as<float>(), seen_ptr, tiles, ntiles, KC, head_tiles,
-                                      splits2, cs.as<float>(), ci.as<int32_t>(), ms.as<float>(), mi.as<int32_t>(), state.p, 0, ub.as<float>(),
-                                      sv->tile_bound.as<float>(), dense_p, skip_p, filter_seen ? sv->dense_tiles : 0));
+            if (from_rows)
+                CK(pk_score_two_phase_rows_f32(st, n_users, n_items, K, sv->Vp.as<float>(), Ex.p(), Kx, w, approx ? Kx : 0, 1.2e-7, seen_ptr,
+                                               tiles, ntiles, KC, head_tiles, splits2, cs.as<float>(), ci.as<int32_t>(), ms.as<float>(),
+                                               mi.as<int32_t>(), state.p, 0, sv->tile_bound.as<float>(), dense_p, skip_p,
+                                               filter_seen ? sv->dense_tiles : 0));
+            else
+                CK(pk_score_two_phase_f32(st, n_users, n_items, K, sv->Vp.as<float>(), Ep.as<float>(), seen_ptr, tiles, ntiles, KC, head_tiles,
+                                          splits2, cs.as<float>(), ci.as<int32_t>(), ms.as<float>(), mi.as<int32_t>(), state.p, 0, ub.as<float>(),
+                                          sv->tile_bound.as<float>(), dense_p, skip_p, filter_seen ? sv->dense_tiles : 0));
             std::swap(cs, ms);      // the merged list is what the re-scoring takes: one list per user
             std::swap(ci, mi);
             splits = 1;
+        } else if (from_rows) {
+            CK(pk_score_candidates_rows_f32(st, n_users, n_items, K, sv->Vp.as<float>(), Ex.p(), Kx, w, approx ? Kx : 0, 1.2e-7, seen_ptr,
+                                            tiles, ntiles, KC, splits, cs.as<float>(), ci.as<int32_t>(), state.p, 0,
+                                            sv->tile_bound.as<float>(), dense_p, skip_p, filter_seen ? sv->dense_tiles : 0));
         } else {
             CK(pk_score_candidates_f32(st, n_users, n_items, K, sv->Vp.as<float>(), Ep.as<float>(), seen_ptr, tiles, ntiles,
                                        KC, splits, cs.as<float>(), ci.as<int32_t>(), state.p, 0, ub.as<float>(), sv->tile_bound.as<float>(),

@@ -129,6 +129,17 @@ __device__ __forceinline__ unsigned pk_float_order(float x) {   // a > b  <=>  o
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// split of an fp32 value into two bf16 (round to nearest even): x = hi + lo + d, |hi - x| <= 2^-8 |x|, |d| <= 2^-16 |x|
+__device__ __forceinline__ unsigned pk_bf16_rne(float x) {
+    unsigned u = __float_as_uint(x);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ void pk_split_bf16(float x, unsigned &hi, unsigned &lo) {
+    hi = pk_bf16_rne(x);
+    lo = pk_bf16_rne(x - __uint_as_float(hi << 16));
+}
+
 // Per-lane state carried between the item-chunk launches of one scoring pass (global memory).
 struct LaneState {
     int64_t sp;   // position in the user's seen-tile stream
@@ -166,6 +177,19 @@ struct SeenDense {
     int tiles;
 };
 
+// The users' side of a sweep straight from the fp64 rows of E (round 5; E == nullptr: the pre-packed fragments `Ep` and
+// `user_bound` as before).  A wave builds its 32 users' MFMA fragments and their pruning bounds in its prologue — the
+// arithmetic of pack_frag_bound_kernel, bit for bit — so a pass needs no packing launch and no packed copy of E:
+// bound = ||E[u, :K]|| (1 + 1e-6) + extra_scale * extra[u * extra_ld]   (extra: an approximate fold-in's error weight, or NULL)
+struct UserRows {
+    const double *E;
+    int64_t ld;
+    int K;
+    const double *extra;
+    int64_t extra_ld;
+    double extra_scale;
+};
+
 // DENSE: the instance that reads them (the other one is the kernel as it was: in the throughput-bound regimes — full
 // sweeps, rank 200 — the extra registers and per-tile tests of a run-time switch cost 10 %).
 // (The LDS-staged forms of this sweep — 16- and 4-wave workgroups stepping through the tiles together — the two-groups-per-wave
@@ -180,7 +204,7 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
     float *__restrict__ cand_score, int32_t *__restrict__ cand_idx,
     LaneState *__restrict__ st_lane, uint2 *__restrict__ st_ring,
     const float *__restrict__ user_bound, const float *__restrict__ tile_bound, int ablate, SeenDense dense,
-    int tile_base, int slot_base, const LaneState *__restrict__ floor_state, int boot_tiles) {
+    int tile_base, int slot_base, const LaneState *__restrict__ floor_state, int boot_tiles, UserRows rows) {
     constexpr int KQ = 2 * NSTEP;   // 16-byte groups per lane and tile: (hi, lo) x 8 bf16 for every 16-wide k-step
     // KC == 16: rings of 8, so that a user's list + both rings are 32 entries and TWO users are merged
     // per flush, one in each half of the wave (15 sort stages per two users instead of 21 per user).
@@ -239,17 +263,61 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
     int32_t *my_idx = cand_idx + slot * 32 * KC;
 
     float4 e[KQ];
+    float en_rows = -1.0f;
+    if (rows.E) {
+        // fragments + bound from the rows of E.  Eight lanes fetch the 128 bytes a row contributes to a k-step with one
+        // 16-byte load each (a lane reading its own row would touch 64 lines per load instruction), the k-step goes through
+        // the wave's ring area (4 KB, still empty) and every lane picks up its 64 bytes from there.
+        double *buf = reinterpret_cast<double *>(&ring[0][0]);
+        double ss = 0.0;
 #pragma unroll
-    for (int q = 0; q < KQ; ++q) e[q] = Ep[(group * KQ + q) * 64 + lane];
+        for (int s = 0; s < NSTEP; ++s) {
+            __builtin_amdgcn_wave_barrier();             // the previous k-step's reads are done (in-order LDS pipe)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int rr = 8 * p + (lane >> 3);      // row of the group this lane fetches from in pass p
+                const int kk = 16 * s + 2 * (lane & 7);  // first of its two columns
+                const int64_t grow = group * 32 + rr;
+                double2 v = make_double2(0.0, 0.0);
+                if (grow < n_users && kk < rows.K) {
+                    const double *g = rows.E + grow * rows.ld + kk;
+                    if (kk + 1 < rows.K) v = *reinterpret_cast<const double2 *>(g);
+                    else v.x = g[0];
+                }
+                *reinterpret_cast<double2 *>(buf + rr * 16 + 2 * (lane & 7)) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+            unsigned bh[8], bl[8];
+            const double *mine = buf + ul * 16 + 8 * hi;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const double x = mine[j];
+                ss = fma(x, x, ss);
+                pk_split_bf16((float)x, bh[j], bl[j]);
+            }
+            e[2 * s] = __builtin_bit_cast(float4, make_uint4(bh[0] | (bh[1] << 16), bh[2] | (bh[3] << 16), bh[4] | (bh[5] << 16), bh[6] | (bh[7] << 16)));
+            e[2 * s + 1] = __builtin_bit_cast(float4, make_uint4(bl[0] | (bl[1] << 16), bl[2] | (bl[3] << 16), bl[4] | (bl[5] << 16), bl[6] | (bl[7] << 16)));
+        }
+        __builtin_amdgcn_wave_barrier();                 // the ring area is free again
+        ss += pk_lane_xor<32>(ss);
+        if (user < n_users) {
+            double b = sqrt(ss) * (1.0 + 1e-6);
+            if (rows.extra) b += rows.extra_scale * rows.extra[user * rows.extra_ld];
+            en_rows = (float)(b * (1.0 + 1e-7));         // the conversion rounds to nearest: keep it an upper bound
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) e[q] = Ep[(group * KQ + q) * 64 + lane];
+    }
 
     int64_t sp = 0, se = 0;
     // next three (tile, mask) records of the user's seen-tile stream (prefetch window)
     unsigned long long nxt = PK_TILE_NONE, nxt2 = PK_TILE_NONE, nxt3 = PK_TILE_NONE;
     float tau = -INFINITY;
     int cnt = 0;
-    const bool prune = (user_bound != nullptr && tile_bound != nullptr) && !(ablate & 4);
+    const bool prune = ((user_bound != nullptr || rows.E != nullptr) && tile_bound != nullptr) && !(ablate & 4);
     // padding lanes of the last group never keep the wave in the sweep
-    const float en = (prune && user < n_users) ? user_bound[user] : -1.0f;
+    const float en = (prune && user < n_users) ? (rows.E ? en_rows : user_bound[user]) : -1.0f;
     bool pruned = false;
     int exit_tile = tile_end;
     const bool has_seen = (seen_ptr != nullptr && user < n_users);
@@ -905,16 +973,6 @@ extern "C" int64_t pk_pack_elems(int64_t n, int32_t K) {
     return pk_ceil_div(n, 32) * kq * 64 * 4;
 }
 
-// split of an fp32 value into two bf16 (round to nearest even): x = hi + lo + d, |hi - x| <= 2^-8 |x|, |d| <= 2^-16 |x|
-__device__ __forceinline__ unsigned pk_bf16_rne(float x) {
-    unsigned u = __float_as_uint(x);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
-}
-__device__ __forceinline__ void pk_split_bf16(float x, unsigned &hi, unsigned &lo) {
-    hi = pk_bf16_rne(x);
-    lo = pk_bf16_rne(x - __uint_as_float(hi << 16));
-}
 // lane (i = lane & 31, h = lane >> 5) of k-step s holds k = 16 s + 8 h + j, j = 0..7: the A / B operand layout of
 // v_mfma_f32_32x32x16_bf16.  Group 2 s = the eight hi parts, group 2 s + 1 = the eight lo parts.
 __device__ __forceinline__ void pk_pack_step(const double *__restrict__ r, bool live, int K, int s, int h, uint4 &ghi, uint4 &glo,
@@ -1284,7 +1342,7 @@ static int launch_candidates_n(hipStream_t st, int KC, int ablate, dim3 grid, co
                                const int64_t *seen_ptr, const unsigned long long *seen_tiles,
                                const int32_t *seen_ntiles, float *cs, int32_t *ci,
                                LaneState *st_lane, uint2 *st_ring, const float *user_bound, const float *tile_bound,
-                               SeenDense dense, SweepPhase ph) {
+                               SeenDense dense, SweepPhase ph, UserRows rows) {
     // Item chunks: tiles_per_chunk each while every group sweeps (the chunk's packed image stays in L2);
     // with pruning, groups leave the sweep early, so the chunks DOUBLE from launch to launch — the catalogue
     // is covered in O(log) launches and the few groups still sweeping late (low bandwidth demand) are not
@@ -1297,7 +1355,7 @@ static int launch_candidates_n(hipStream_t st, int KC, int ablate, dim3 grid, co
     const SeenDense no_dense{nullptr, nullptr, 0};
     const SeenDense dn = use_dense ? dense : no_dense;
     int chunk_tiles = tiles_per_chunk;
-    for (int chunk_begin = 0; chunk_begin < split_tiles; chunk_begin += chunk_tiles, chunk_tiles = (user_bound ? 2 * chunk_tiles : chunk_tiles)) {
+    for (int chunk_begin = 0; chunk_begin < split_tiles; chunk_begin += chunk_tiles, chunk_tiles = (tile_bound ? 2 * chunk_tiles : chunk_tiles)) {
 #define PK_LAUNCH(KCV)                                                                                          \
     if (pk_score_lds_bytes(NSTEP, KCV) > 64 * 1024) {                                                           \
         static PkDeviceOnce attr_set;      /* one flag per (NSTEP, KC) instance of this macro expansion */        \
@@ -1319,15 +1377,15 @@ static int launch_candidates_n(hipStream_t st, int KC, int ablate, dim3 grid, co
     if (grid.y > 1 || ph.floor_state != nullptr)                                                                \
         hipLaunchKernelGGL((score_candidates_kernel<NSTEP, KCV, true, DENSE_OK>), grid, dim3(256), pk_score_lds_bytes(NSTEP, KCV), st, Vp, Ep, n_users, \
                            n_items, n_tiles, split_tiles, chunk_begin, chunk_tiles, seen_ptr, seen_tiles, seen_ntiles, cs, ci, st_lane, st_ring,  \
-                           user_bound, tile_bound, ablate, dn, ph.tile_base, ph.slot_base, ph.floor_state, ph.boot_tiles); \
+                           user_bound, tile_bound, ablate, dn, ph.tile_base, ph.slot_base, ph.floor_state, ph.boot_tiles, rows); \
     else if (use_dense)                                                                                         \
         hipLaunchKernelGGL((score_candidates_kernel<NSTEP, KCV, false, DENSE_OK>), grid, dim3(256), pk_score_lds_bytes(NSTEP, KCV), st, Vp, Ep, n_users, \
                            n_items, n_tiles, split_tiles, chunk_begin, chunk_tiles, seen_ptr, seen_tiles, seen_ntiles, cs, ci, st_lane, st_ring,  \
-                           user_bound, tile_bound, ablate, dn, 0, ph.slot_base, nullptr, ph.boot_tiles);        \
+                           user_bound, tile_bound, ablate, dn, 0, ph.slot_base, nullptr, ph.boot_tiles, rows);  \
     else                                                                                                        \
         hipLaunchKernelGGL((score_candidates_kernel<NSTEP, KCV, false, false>), grid, dim3(256), pk_score_lds_bytes(NSTEP, KCV), st, Vp, Ep, n_users, \
                            n_items, n_tiles, split_tiles, chunk_begin, chunk_tiles, seen_ptr, seen_tiles, seen_ntiles, cs, ci, st_lane, st_ring,  \
-                           user_bound, tile_bound, ablate, no_dense, 0, ph.slot_base, nullptr, ph.boot_tiles)
+                           user_bound, tile_bound, ablate, no_dense, 0, ph.slot_base, nullptr, ph.boot_tiles, rows)
         switch (KC) {
             case 16:
                 PK_LAUNCH(16);
@@ -1400,12 +1458,13 @@ static int pk_sweep_launches(hipStream_t st, int64_t n_users, int64_t n_items, i
                              const float *Ep_dev, const int64_t *seen_ptr_dev, const uint64_t *seen_tiles_dev,
                              const int32_t *seen_ntiles_dev, int32_t KC, int32_t splits, int32_t total_slots,
                              float *cand_score_dev, int32_t *cand_idx_dev, void *state_dev, int32_t tiles_per_chunk,
-                             const float *user_bound_dev, const float *tile_bound_dev, SeenDense dense, SweepPhase ph) {
+                             const float *user_bound_dev, const float *tile_bound_dev, SeenDense dense, SweepPhase ph,
+                             UserRows rows = UserRows{nullptr, 0, 0, nullptr, 0, 0.0}) {
     const int kq = pk_pack_kq(K);
     const int nstep = pk_nstep(K);
     const int64_t groups = pk_ceil_div(n_users, 32);
     const int split_tiles = (int)pk_ceil_div(n_tiles - ph.tile_base, splits);
-    if (tiles_per_chunk <= 0) tiles_per_chunk = pk_auto_chunk_tiles(kq, splits, split_tiles, user_bound_dev != nullptr);
+    if (tiles_per_chunk <= 0) tiles_per_chunk = pk_auto_chunk_tiles(kq, splits, split_tiles, tile_bound_dev != nullptr);
     LaneState *st_lane = static_cast<LaneState *>(state_dev);
     uint2 *st_ring = reinterpret_cast<uint2 *>(st_lane + groups * total_slots * 64);
     if (ph.floor_state) ph.floor_state = st_lane;      // the head's records: slot 0
@@ -1422,7 +1481,7 @@ static int pk_sweep_launches(hipStream_t st, int64_t n_users, int64_t n_items, i
                                     split_tiles, tiles_per_chunk, seen_ptr_dev,                                   \
                                     reinterpret_cast<const unsigned long long *>(seen_tiles_dev), seen_ntiles_dev, \
                                     cand_score_dev, cand_idx_dev,                                              \
-                                    st_lane, st_ring, user_bound_dev, tile_bound_dev, dense, ph);              \
+                                    st_lane, st_ring, user_bound_dev, tile_bound_dev, dense, ph, rows);        \
         break;
     const char *abl_env = getenv("PK_SCORE_ABLATE");   // kernel-tuning knob, never set in production
     const int ablate = abl_env ? atoi(abl_env) : 0;
@@ -1449,8 +1508,14 @@ static int pk_score_check_args(const char *who, int64_t n_users, int64_t n_items
                                const float *Ep_dev, const int64_t *seen_ptr_dev, const uint64_t *seen_tiles_dev,
                                const int32_t *seen_ntiles_dev, void *state_dev, const float *user_bound_dev,
                                const float *tile_bound_dev, const uint32_t *seen_dense_dev, const int32_t *seen_skip_dev,
-                               int32_t dense_tiles) {
+                               int32_t dense_tiles, const UserRows *rows = nullptr) {
     PK_REQUIRE(n_users >= 1 && n_items >= 1 && n_items < 0x7fffff00LL, "%s: bad sizes", who);
+    if (rows) {
+        // the users' side comes from rows of E: 16-byte aligned, even leading dimension (a lane fetches two columns per load)
+        PK_REQUIRE(rows->E != nullptr && rows->ld >= K && rows->ld % 2 == 0 && ((uintptr_t)rows->E % 16) == 0 && rows->K == K,
+                   "%s: E rows must be 16-byte aligned with an even leading dimension >= K", who);
+        PK_REQUIRE(rows->extra == nullptr || rows->extra_ld >= 1, "%s: bad stride of the extra term", who);
+    }
     PK_REQUIRE(dense_tiles >= 0 && (dense_tiles == 0 || (seen_dense_dev && seen_skip_dev && seen_ptr_dev)),
                "%s: dense seen masks need seen_dense, seen_skip and the seen-tile stream", who);
     PK_REQUIRE(pk_pack_kq(K) > 0, "%s: K=%d unsupported (K <= 256)", who, K);
@@ -1459,9 +1524,26 @@ static int pk_score_check_args(const char *who, int64_t n_users, int64_t n_items
     PK_REQUIRE((seen_ptr_dev == nullptr) == (seen_tiles_dev == nullptr) &&
                    (seen_ptr_dev == nullptr) == (seen_ntiles_dev == nullptr),
                "%s: seen_ptr, seen_tiles, seen_ntiles go together (all or none)", who);
-    PK_REQUIRE((user_bound_dev == nullptr) == (tile_bound_dev == nullptr),
+    PK_REQUIRE(rows != nullptr || (user_bound_dev == nullptr) == (tile_bound_dev == nullptr),
                "%s: user_bound and tile_bound go together (both or neither)", who);
     return PK_OK;
+}
+
+static int pk_score_candidates_impl(const char *who, void *stream, int64_t n_users, int64_t n_items, int32_t K,
+                                    const float *Vp_dev, const float *Ep_dev, const UserRows *rows, const int64_t *seen_ptr_dev,
+                                    const uint64_t *seen_tiles_dev, const int32_t *seen_ntiles_dev, int32_t KC, int32_t splits,
+                                    float *cand_score_dev, int32_t *cand_idx_dev, void *state_dev, int32_t tiles_per_chunk,
+                                    const float *user_bound_dev, const float *tile_bound_dev, const uint32_t *seen_dense_dev,
+                                    const int32_t *seen_skip_dev, int32_t dense_tiles) {
+    const int rc = pk_score_check_args(who, n_users, n_items, K, Vp_dev, Ep_dev, seen_ptr_dev, seen_tiles_dev, seen_ntiles_dev,
+                                       state_dev, user_bound_dev, tile_bound_dev, seen_dense_dev, seen_skip_dev, dense_tiles, rows);
+    if (rc != PK_OK) return rc;
+    PK_REQUIRE(splits >= 1 && splits * KC <= 64, "%s: need 1 <= splits and splits*KC <= 64", who);
+    SeenDense dense{seen_dense_dev, seen_skip_dev, seen_ptr_dev ? dense_tiles : 0};
+    return pk_sweep_launches(pk_stream(stream), n_users, n_items, (int)pk_ceil_div(n_items, 32), K, Vp_dev, Ep_dev,
+                             seen_ptr_dev, seen_tiles_dev, seen_ntiles_dev, KC, splits, splits, cand_score_dev, cand_idx_dev,
+                             state_dev, tiles_per_chunk, user_bound_dev, tile_bound_dev, dense, SweepPhase{0, 0, nullptr, 0},
+                             rows ? *rows : UserRows{nullptr, 0, 0, nullptr, 0, 0.0});
 }
 
 extern "C" int pk_score_candidates_f32(void *stream, int64_t n_users, int64_t n_items, int32_t K,
@@ -1472,15 +1554,24 @@ extern "C" int pk_score_candidates_f32(void *stream, int64_t n_users, int64_t n_
                                        int32_t tiles_per_chunk, const float *user_bound_dev,
                                        const float *tile_bound_dev, const uint32_t *seen_dense_dev,
                                        const int32_t *seen_skip_dev, int32_t dense_tiles) {
-    const int rc = pk_score_check_args("pk_score_candidates_f32", n_users, n_items, K, Vp_dev, Ep_dev, seen_ptr_dev,
-                                       seen_tiles_dev, seen_ntiles_dev, state_dev, user_bound_dev, tile_bound_dev,
-                                       seen_dense_dev, seen_skip_dev, dense_tiles);
-    if (rc != PK_OK) return rc;
-    PK_REQUIRE(splits >= 1 && splits * KC <= 64, "pk_score_candidates_f32: need 1 <= splits and splits*KC <= 64");
-    SeenDense dense{seen_dense_dev, seen_skip_dev, seen_ptr_dev ? dense_tiles : 0};
-    return pk_sweep_launches(pk_stream(stream), n_users, n_items, (int)pk_ceil_div(n_items, 32), K, Vp_dev, Ep_dev,
-                             seen_ptr_dev, seen_tiles_dev, seen_ntiles_dev, KC, splits, splits, cand_score_dev, cand_idx_dev,
-                             state_dev, tiles_per_chunk, user_bound_dev, tile_bound_dev, dense, SweepPhase{0, 0, nullptr, 0});
+    return pk_score_candidates_impl("pk_score_candidates_f32", stream, n_users, n_items, K, Vp_dev, Ep_dev, nullptr, seen_ptr_dev,
+                                    seen_tiles_dev, seen_ntiles_dev, KC, splits, cand_score_dev, cand_idx_dev, state_dev,
+                                    tiles_per_chunk, user_bound_dev, tile_bound_dev, seen_dense_dev, seen_skip_dev, dense_tiles);
+}
+
+// The same sweep with the users' side taken from the fp64 rows of E (no packed copy of E, no packing launch: every wave
+// builds its 32 users' fragments and pruning bounds in its prologue — see UserRows).  tile_bound_dev == NULL: full sweep.
+extern "C" int pk_score_candidates_rows_f32(void *stream, int64_t n_users, int64_t n_items, int32_t K, const float *Vp_dev,
+                                            const double *E_dev, int64_t lde, const double *extra_dev, int64_t extra_ld,
+                                            double extra_scale, const int64_t *seen_ptr_dev, const uint64_t *seen_tiles_dev,
+                                            const int32_t *seen_ntiles_dev, int32_t KC, int32_t splits, float *cand_score_dev,
+                                            int32_t *cand_idx_dev, void *state_dev, int32_t tiles_per_chunk,
+                                            const float *tile_bound_dev, const uint32_t *seen_dense_dev,
+                                            const int32_t *seen_skip_dev, int32_t dense_tiles) {
+    const UserRows rows{E_dev, lde, K, extra_dev, extra_ld, extra_scale};
+    return pk_score_candidates_impl("pk_score_candidates_rows_f32", stream, n_users, n_items, K, Vp_dev, nullptr, &rows,
+                                    seen_ptr_dev, seen_tiles_dev, seen_ntiles_dev, KC, splits, cand_score_dev, cand_idx_dev,
+                                    state_dev, tiles_per_chunk, nullptr, tile_bound_dev, seen_dense_dev, seen_skip_dev, dense_tiles);
 }
 
 // ---- two-phase sweep -------------------------------------------------------------------------------------------------
@@ -1612,24 +1703,25 @@ extern "C" int pk_score_two_phase_plan(int64_t n_users, int64_t n_items, int32_t
 //   work_score / work_idx  [(splits + 1) * n_pad * KC]   the raw lists (slot 0: head), n_pad = n_users rounded up to 32
 //   cand_score / cand_idx  [n_pad * KC]                   the merged list: what pk_rescore_topk_* takes with splits = 1
 //   state                  pk_score_state_bytes(n_users, splits + 1)
-extern "C" int pk_score_two_phase_f32(void *stream, int64_t n_users, int64_t n_items, int32_t K,
-                                      const float *Vp_dev, const float *Ep_dev, const int64_t *seen_ptr_dev,
-                                      const uint64_t *seen_tiles_dev, const int32_t *seen_ntiles_dev,
-                                      int32_t KC, int32_t head_tiles, int32_t splits,
-                                      float *work_score_dev, int32_t *work_idx_dev,
-                                      float *cand_score_dev, int32_t *cand_idx_dev, void *state_dev,
-                                      int32_t tiles_per_chunk, const float *user_bound_dev,
-                                      const float *tile_bound_dev, const uint32_t *seen_dense_dev,
-                                      const int32_t *seen_skip_dev, int32_t dense_tiles) {
-    int rc = pk_score_check_args("pk_score_two_phase_f32", n_users, n_items, K, Vp_dev, Ep_dev, seen_ptr_dev,
+static int pk_score_two_phase_impl(const char *who, void *stream, int64_t n_users, int64_t n_items, int32_t K,
+                                   const float *Vp_dev, const float *Ep_dev, const UserRows *rows_in, const int64_t *seen_ptr_dev,
+                                   const uint64_t *seen_tiles_dev, const int32_t *seen_ntiles_dev,
+                                   int32_t KC, int32_t head_tiles, int32_t splits,
+                                   float *work_score_dev, int32_t *work_idx_dev,
+                                   float *cand_score_dev, int32_t *cand_idx_dev, void *state_dev,
+                                   int32_t tiles_per_chunk, const float *user_bound_dev,
+                                   const float *tile_bound_dev, const uint32_t *seen_dense_dev,
+                                   const int32_t *seen_skip_dev, int32_t dense_tiles) {
+    int rc = pk_score_check_args(who, n_users, n_items, K, Vp_dev, Ep_dev, seen_ptr_dev,
                                  seen_tiles_dev, seen_ntiles_dev, state_dev, user_bound_dev, tile_bound_dev,
-                                 seen_dense_dev, seen_skip_dev, dense_tiles);
+                                 seen_dense_dev, seen_skip_dev, dense_tiles, rows_in);
     if (rc != PK_OK) return rc;
+    const UserRows rows = rows_in ? *rows_in : UserRows{nullptr, 0, 0, nullptr, 0, 0.0};
     const int n_tiles = (int)pk_ceil_div(n_items, 32);
-    PK_REQUIRE(user_bound_dev && tile_bound_dev, "pk_score_two_phase_f32: needs the pruning bounds");
+    PK_REQUIRE((user_bound_dev || rows_in) && tile_bound_dev, "%s: needs the pruning bounds", who);
     PK_REQUIRE(KC >= 1 && KC <= 64 && splits >= 1 && (splits + 1) * KC <= 256 && head_tiles >= 1 && head_tiles < n_tiles,
-               "pk_score_two_phase_f32: need 1 <= head_tiles < n_tiles and (splits + 1) * KC <= 256");
-    PK_REQUIRE(work_score_dev && work_idx_dev && cand_score_dev && cand_idx_dev, "pk_score_two_phase_f32: null list buffers");
+               "%s: need 1 <= head_tiles < n_tiles and (splits + 1) * KC <= 256", who);
+    PK_REQUIRE(work_score_dev && work_idx_dev && cand_score_dev && cand_idx_dev, "%s: null list buffers", who);
     hipStream_t st = pk_stream(stream);
     SeenDense dense{seen_dense_dev, seen_skip_dev, seen_ptr_dev ? dense_tiles : 0};
     const int total_slots = splits + 1;
@@ -1637,13 +1729,13 @@ extern "C" int pk_score_two_phase_f32(void *stream, int64_t n_users, int64_t n_i
     // rings merged, lists written, exit tile and threshold in the lane records — so the head must fit one item chunk)
     rc = pk_sweep_launches(st, n_users, n_items, head_tiles, K, Vp_dev, Ep_dev, seen_ptr_dev, seen_tiles_dev, seen_ntiles_dev,
                            KC, 1, total_slots, work_score_dev, work_idx_dev, state_dev, head_tiles, user_bound_dev,
-                           tile_bound_dev, dense, SweepPhase{0, 0, nullptr, 0});
+                           tile_bound_dev, dense, SweepPhase{0, 0, nullptr, 0}, rows);
     if (rc != PK_OK) return rc;
     // phase 2: the splits, from the head's thresholds
     LaneState *st_lane = static_cast<LaneState *>(state_dev);
     rc = pk_sweep_launches(st, n_users, n_items, n_tiles, K, Vp_dev, Ep_dev, seen_ptr_dev, seen_tiles_dev, seen_ntiles_dev,
                            KC, splits, total_slots, work_score_dev, work_idx_dev, state_dev, tiles_per_chunk, user_bound_dev,
-                           tile_bound_dev, dense, SweepPhase{head_tiles, 1, st_lane, 0});
+                           tile_bound_dev, dense, SweepPhase{head_tiles, 1, st_lane, 0}, rows);
     if (rc != PK_OK) return rc;
     const int64_t n_pad = pk_ceil_div(n_users, 32) * 32;
     const int slots = (int)pk_ceil_div((int64_t)total_slots * KC, 64);
@@ -1657,6 +1749,37 @@ extern "C" int pk_score_two_phase_f32(void *stream, int64_t n_users, int64_t n_i
 #undef PK_MERGE
     PK_CHECK_LAUNCH("merge_candidates_kernel");
     return PK_OK;
+}
+
+extern "C" int pk_score_two_phase_f32(void *stream, int64_t n_users, int64_t n_items, int32_t K,
+                                      const float *Vp_dev, const float *Ep_dev, const int64_t *seen_ptr_dev,
+                                      const uint64_t *seen_tiles_dev, const int32_t *seen_ntiles_dev,
+                                      int32_t KC, int32_t head_tiles, int32_t splits,
+                                      float *work_score_dev, int32_t *work_idx_dev,
+                                      float *cand_score_dev, int32_t *cand_idx_dev, void *state_dev,
+                                      int32_t tiles_per_chunk, const float *user_bound_dev,
+                                      const float *tile_bound_dev, const uint32_t *seen_dense_dev,
+                                      const int32_t *seen_skip_dev, int32_t dense_tiles) {
+    return pk_score_two_phase_impl("pk_score_two_phase_f32", stream, n_users, n_items, K, Vp_dev, Ep_dev, nullptr, seen_ptr_dev,
+                                   seen_tiles_dev, seen_ntiles_dev, KC, head_tiles, splits, work_score_dev, work_idx_dev,
+                                   cand_score_dev, cand_idx_dev, state_dev, tiles_per_chunk, user_bound_dev, tile_bound_dev,
+                                   seen_dense_dev, seen_skip_dev, dense_tiles);
+}
+
+// the two-phase sweep with the users' side from the rows of E (see pk_score_candidates_rows_f32)
+extern "C" int pk_score_two_phase_rows_f32(void *stream, int64_t n_users, int64_t n_items, int32_t K, const float *Vp_dev,
+                                           const double *E_dev, int64_t lde, const double *extra_dev, int64_t extra_ld,
+                                           double extra_scale, const int64_t *seen_ptr_dev, const uint64_t *seen_tiles_dev,
+                                           const int32_t *seen_ntiles_dev, int32_t KC, int32_t head_tiles, int32_t splits,
+                                           float *work_score_dev, int32_t *work_idx_dev, float *cand_score_dev,
+                                           int32_t *cand_idx_dev, void *state_dev, int32_t tiles_per_chunk,
+                                           const float *tile_bound_dev, const uint32_t *seen_dense_dev,
+                                           const int32_t *seen_skip_dev, int32_t dense_tiles) {
+    const UserRows rows{E_dev, lde, K, extra_dev, extra_ld, extra_scale};
+    return pk_score_two_phase_impl("pk_score_two_phase_rows_f32", stream, n_users, n_items, K, Vp_dev, nullptr, &rows, seen_ptr_dev,
+                                   seen_tiles_dev, seen_ntiles_dev, KC, head_tiles, splits, work_score_dev, work_idx_dev,
+                                   cand_score_dev, cand_idx_dev, state_dev, tiles_per_chunk, nullptr, tile_bound_dev,
+                                   seen_dense_dev, seen_skip_dev, dense_tiles);
 }
 
 // eager load of this translation unit's code object (pk_warm_up, api.cpp): the runtime loads a code object at the first

@@ -1060,8 +1060,23 @@ class HipOps:
                                                 _ptr(dense), _ptr(skip)), 'pk_seen_dense_build')
         return dense, skip
 
+    def sweep_takes_rows(self, E):
+        """can the candidate sweep read the users' side from these fp64 rows of E (16-byte aligned, even row stride)?  Then
+        `score_candidates` / `score_two_phase` take `E_rows=(E, extra, extra_scale)` instead of packed fragments + bounds."""
+        return (E.dtype == torch.float64 and E.dim() == 2 and E.stride(1) == 1 and E.stride(0) % 2 == 0 and E.data_ptr() % 16 == 0)
+
+    @staticmethod
+    def _rows_args(E_rows, K):
+        E, extra, scale = E_rows
+        assert E.shape[1] >= K
+        e_ld = 0 if extra is None else (extra.stride(0) if extra.dim() == 1 else extra.stride(0))
+        return _ptr(E), E.stride(0), _ptr(extra), int(e_ld), float(scale if extra is not None else 0.0)
+
     def score_candidates(self, Vp, Ep, n_users, n_items, K, seen_ptr, seen_idx, KC, splits=1, tiles_per_chunk=0,
-                         user_bound=None, tile_bound=None, seen_tiles=None, seen_dense=None):
+                         user_bound=None, tile_bound=None, seen_tiles=None, seen_dense=None, E_rows=None):
+        """E_rows = (E fp64 [n_users x >= K], extra column or None, extra_scale): the users' fragments and pruning bounds are
+        built inside the sweep (pk_score_candidates_rows_f32; Ep and user_bound are not used, tile_bound alone switches the
+        pruning on)."""
         n_pad = -(-n_users // 32) * 32
         need = self.lib.pk_score_state_bytes(n_users, splits)
         if self._score_states is None:
@@ -1078,6 +1093,16 @@ class HipOps:
             tiles, ntiles = seen_tiles if seen_tiles is not None else self.seen_tiles(seen_ptr, seen_idx, n_users)
             if seen_dense is not None:
                 dense, skip, dtiles = seen_dense
+        if E_rows is not None:
+            ep, lde, xp, xld, xs = self._rows_args(E_rows, K)
+            with self._timed('score_candidates', (n_users, n_items, K)):
+                _lib.check(self.lib.pk_score_candidates_rows_f32(self.stream(), n_users, n_items, K, _ptr(Vp), ep, lde, xp, xld, xs,
+                                                                 _ptr(seen_ptr), _ptr(tiles), _ptr(ntiles), KC, splits,
+                                                                 _ptr(cs), _ptr(ci), _ptr(self._score_state),
+                                                                 tiles_per_chunk or self.score_tiles_per_chunk,
+                                                                 _ptr(tile_bound), _ptr(dense), _ptr(skip), int(dtiles)),
+                           'pk_score_candidates_rows_f32')
+            return cs, ci
         with self._timed('score_candidates', (n_users, n_items, K)):
             _lib.check(self.lib.pk_score_candidates_f32(self.stream(), n_users, n_items, K, _ptr(Vp), _ptr(Ep),
                                                         _ptr(seen_ptr), _ptr(tiles), _ptr(ntiles), KC, splits,
@@ -1096,7 +1121,7 @@ class HipOps:
         return int(h.value), int(s.value)
 
     def score_two_phase(self, Vp, Ep, n_users, n_items, K, seen_ptr, KC, head_tiles, splits, user_bound, tile_bound,
-                        seen_tiles=None, seen_dense=None, tiles_per_chunk=0):
+                        seen_tiles=None, seen_dense=None, tiles_per_chunk=0, E_rows=None):
         """The pruned candidate sweep in two phases (pk_score_two_phase_f32): head sweep, `splits` sweeps of the tail from
         the head's thresholds, merge.  Returns the merged (scores, ids) [n_pad x KC] — a single list per user."""
         n_pad = -(-n_users // 32) * 32
@@ -1118,6 +1143,17 @@ class HipOps:
             tiles, ntiles = seen_tiles
             if seen_dense is not None:
                 dense, skip, dtiles = seen_dense
+        if E_rows is not None:
+            ep, lde, xp, xld, xs = self._rows_args(E_rows, K)
+            with self._timed('score_candidates', (n_users, n_items, K)):
+                _lib.check(self.lib.pk_score_two_phase_rows_f32(self.stream(), n_users, n_items, K, _ptr(Vp), ep, lde, xp, xld, xs,
+                                                                _ptr(seen_ptr), _ptr(tiles), _ptr(ntiles), KC, int(head_tiles),
+                                                                int(splits), _ptr(ws), _ptr(wi), _ptr(cs), _ptr(ci),
+                                                                _ptr(self._score_state),
+                                                                tiles_per_chunk or self.score_tiles_per_chunk,
+                                                                _ptr(tile_bound), _ptr(dense), _ptr(skip), int(dtiles)),
+                           'pk_score_two_phase_rows_f32')
+            return cs, ci
         with self._timed('score_candidates', (n_users, n_items, K)):
             _lib.check(self.lib.pk_score_two_phase_f32(self.stream(), n_users, n_items, K, _ptr(Vp), _ptr(Ep), _ptr(seen_ptr),
                                                        _ptr(tiles), _ptr(ntiles), KC, int(head_tiles), int(splits),

@@ -9,6 +9,7 @@ turned into ONE canonical CSR whose explicit zeros are kept — zero-feedback en
 nothing to the fold-in (the reference drops them from `test_matrix`, models.py:198-203) but still
 count as seen (they stay in `slice_data`, models.py:494-519).
 """
+import os
 import threading
 
 import numpy as np
@@ -24,6 +25,8 @@ PACKED_FOLD_IN = True       # the approximate fold-in gathers the packed (one li
 # 6.5 % (a wash: 1.62 ms per pass either way), at rank 200 / top-50 46 % (S-50M shard: fold-in 4.9 -> 2.9 ms, but re-fold and
 # second re-scoring 1.7 -> 8.2 ms: 45.7 -> 50.3 ms per pass) — so longer lists keep the fp32 image
 PACKED_MAX_TOPK = 20
+# the sweep reads the users' side from the rows of E when they are aligned (no packing launch); PK_SWEEP_FROM_ROWS=0: A/B runs
+SWEEP_FROM_ROWS = os.environ.get('PK_SWEEP_FROM_ROWS', '1') != '0'
 
 
 class FactorImage:
@@ -211,7 +214,16 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
         # of 32 users leaves the sweep once no later item can beat any of its thresholds), one pass over E;
         # with the approximate fold-in ||E|| <= ||E'|| + 2^-24 w.  `prune=False` forces the full sweep (same
         # result, tuning / tests only)
-        Ep, ub = ops.pack_frag_bound(Eb, extra=w, extra_scale=1.2e-7)
+        # Round 5: when the rows of E are aligned (the approximate fold-in's [n x Kx] block always is) the SWEEP builds both in
+        # the prologue of its waves, bit for bit what the packing kernel writes: no packing launch, no packed copy of E.
+        rows_kw = {}
+        # (pruned passes: they are ONE launch; a full sweep is cut into item chunks and every launch would rebuild the
+        # fragments — S-1M unpruned: 39.1 -> 39.7 ms — so it keeps the packed copy)
+        if SWEEP_FROM_ROWS and prune and hasattr(ops, 'sweep_takes_rows') and ops.sweep_takes_rows(Eb):
+            Ep = ub = None
+            rows_kw = {'E_rows': (Eb, w, 1.2e-7)}
+        else:
+            Ep, ub = ops.pack_frag_bound(Eb, extra=w, extra_scale=1.2e-7)
         if not prune:
             ub = None
         sp = seen_ptr[u0:u1 + 1] if filter_seen else None
@@ -223,12 +235,12 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
             # pruned sweep in two phases: head of the catalogue for every group, then item splits that start from the
             # head's thresholds, lists merged (K3; the chain of a group is head + tail / S tiles instead of head + tail)
             cs, ci = ops.score_two_phase(factors.Vp, Ep, nb, n_items, K, sp, KC, two_phase[0], two_phase[1], ub,
-                                         factors.tile_bound, seen_tiles=st, seen_dense=sd)
+                                         factors.tile_bound, seen_tiles=st, seen_dense=sd, **rows_kw)
             splits = 1                                                                        # ONE merged list per user
         else:
             cs, ci = ops.score_candidates(factors.Vp, Ep, nb, n_items, K, sp, seen_idx, KC, splits,
                                           user_bound=ub, tile_bound=factors.tile_bound if prune else None,
-                                          seen_tiles=st, **extra)                             # K3
+                                          seen_tiles=st, **extra, **rows_kw)                  # K3
         outs = (out_idx[u0:u1], out_s[u0:u1], flags[u0:u1])
         to_final = (final_list, final_cnt, u0) if fused_lists else None
         if approx_fold_in and fused_lists:

@@ -562,6 +562,61 @@ def test_two_phase_sweep_equals_single_sweep(hip_ops, cfg, monkeypatch):
     assert st2["tiles_scored"] <= st2["tiles_total"]
 
 
+@pytest.mark.parametrize('cfg', [dict(n_users=1000, n_items=9000, K=50, topk=10), dict(n_users=333, n_items=5200, K=100, topk=20),
+                                 dict(n_users=95, n_items=4100, K=200, topk=50), dict(n_users=70, n_items=3000, K=7, topk=5),
+                                 dict(n_users=2100, n_items=2000, K=24, topk=10)])
+def test_sweep_from_the_rows_of_E_equals_the_packed_route(hip_ops, cfg, monkeypatch):
+    """Round 5: the sweep's waves build their users' MFMA fragments and pruning bounds from the fp64 rows of E in their
+    prologue (pk_score_candidates_rows_f32 / pk_score_two_phase_rows_f32) instead of reading what pk_pack_frag_bound_f32
+    wrote.  Kernel level: the raw candidate lists (scores bit for bit, ids) of both routes are EQUAL — pruned and full,
+    with the error-weight column of an approximate fold-in in the bound, partial last groups, strided rows.  Pass level:
+    `scoring.recommend` with the route switched off and on returns the same ids and scores (exact and ids-only passes,
+    the two-phase route included)."""
+    import torch
+    from polara_amd import scoring
+    n_users, n_items, K, topk = cfg['n_users'], cfg['n_items'], cfg['K'], cfg['topk']
+    rng = np.random.RandomState(n_items + K)
+    decay = (1.0 + np.arange(n_items)) ** -0.6
+    V = rng.randn(n_items, K) / np.sqrt(K) * decay[:, None]
+    indptr, indices, values = rand_csr(rng, n_users, n_items, 40, long_rows=[(2, n_items // 2)], empty_rows=[7])
+    T = hip_ops.csr(indptr, indices, values, (n_users, n_items))
+    F = scoring.FactorImage(hip_ops, hip_ops.to_device(V))
+    KC = hip_ops.candidate_capacity(topk)
+    Kx = -(-(K + 1) // 4) * 4
+    Ex = hip_ops.to_device(np.ascontiguousarray(np.c_[rng.randn(n_users, K) * np.exp(rng.randn(n_users, 1)), np.abs(rng.randn(n_users, Kx - K)) * 1e3]))
+    Ex[5, :K] = 0.0
+    E, w = Ex[:, :K], Ex[:, K]
+    assert hip_ops.sweep_takes_rows(E) and not hip_ops.sweep_takes_rows(Ex[:, 1:K + 1])
+    Ep, ub = hip_ops.pack_frag_bound(E, extra=w, extra_scale=1.2e-7)
+    st = T.seen_tiles()
+    for tb in (F.tile_bound, None):
+        a = hip_ops.score_candidates(F.Vp, Ep, n_users, n_items, K, T.indptr, T.indices, KC, user_bound=ub if tb is not None else None,
+                                     tile_bound=tb, seen_tiles=st)
+        a = (a[0].clone(), a[1].clone())
+        b = hip_ops.score_candidates(F.Vp, None, n_users, n_items, K, T.indptr, T.indices, KC, tile_bound=tb, seen_tiles=st,
+                                     E_rows=(E, w, 1.2e-7))
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), tb is None
+    if n_items >= 4 * 32 * 8:
+        a = hip_ops.score_two_phase(F.Vp, Ep, n_users, n_items, K, T.indptr, KC, 8, 3, ub, F.tile_bound, seen_tiles=st)
+        a = (a[0].clone(), a[1].clone())
+        b = hip_ops.score_two_phase(F.Vp, None, n_users, n_items, K, T.indptr, KC, 8, 3, None, F.tile_bound, seen_tiles=st,
+                                    E_rows=(E, w, 1.2e-7))
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    res = {}
+    for on in (False, True):
+        monkeypatch.setattr(scoring, 'SWEEP_FROM_ROWS', on)
+        hip_ops.timers = {}
+        ids, sc = scoring.recommend(hip_ops, F, T, topk, True, return_scores=True)
+        ids_only = scoring.recommend(hip_ops, F, T, topk, True)
+        res[on] = (hip_ops.to_host(ids), hip_ops.to_host(sc), hip_ops.to_host(ids_only), set(hip_ops.timers))
+        hip_ops.timers = None
+    assert np.array_equal(res[False][0], res[True][0]) and np.array_equal(res[False][1], res[True][1])
+    assert np.array_equal(res[False][2], res[True][2]) and np.array_equal(res[True][0], res[True][2])
+    assert 'pack_frag_bound' in res[False][3]
+    if K % 2 == 0:
+        assert 'pack_frag_bound' not in res[True][3]      # (odd ranks: the exact pass's rows have an odd stride and keep the packing kernel)
+
+
 @pytest.mark.parametrize('cfg', [dict(K=50, topk=10, splits=4), dict(K=50, topk=10, splits=3),
                                  dict(K=100, topk=20, splits=2), dict(K=24, topk=5, splits=2)])
 def test_item_splits_equal_single_range(hip_ops, cfg):
