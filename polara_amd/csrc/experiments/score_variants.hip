@@ -2385,6 +2385,24 @@ extern "C" int pk_score_two_phase_f32(void *stream, int64_t n_users, int64_t n_i
     return PK_OK;
 }
 
+// The rows entries of the product (round 5: the sweep builds the users' fragments from the rows of E) do not exist in this
+// frozen tree; the Python layer keeps the packed route under a probe library (ops.sweep_takes_rows), the symbols are here so
+// that the product's driver.hip links.
+extern "C" int pk_score_candidates_rows_f32(void *, int64_t, int64_t, int32_t, const float *, const double *, int64_t, const double *,
+                                            int64_t, double, const int64_t *, const uint64_t *, const int32_t *, int32_t, int32_t,
+                                            float *, int32_t *, void *, int32_t, const float *, const uint32_t *, const int32_t *,
+                                            int32_t) {
+    pk_set_error("pk_score_candidates_rows_f32: not part of the experiment tree (probe library)");
+    return PK_E_UNSUPPORTED;
+}
+extern "C" int pk_score_two_phase_rows_f32(void *, int64_t, int64_t, int32_t, const float *, const double *, int64_t, const double *,
+                                           int64_t, double, const int64_t *, const uint64_t *, const int32_t *, int32_t, int32_t,
+                                           int32_t, float *, int32_t *, float *, int32_t *, void *, int32_t, const float *,
+                                           const uint32_t *, const int32_t *, int32_t) {
+    pk_set_error("pk_score_two_phase_rows_f32: not part of the experiment tree (probe library)");
+    return PK_E_UNSUPPORTED;
+}
+
 // eager load of this translation unit's code object (pk_warm_up, api.cpp): the runtime loads a code object at the first
 // launch of one of its kernels — or when a kernel's attributes are asked for, which costs no launch
 hipError_t pk_tu_load_score() {

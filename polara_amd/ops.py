@@ -1063,6 +1063,8 @@ class HipOps:
     def sweep_takes_rows(self, E):
         """can the candidate sweep read the users' side from these fp64 rows of E (16-byte aligned, even row stride)?  Then
         `score_candidates` / `score_two_phase` take `E_rows=(E, extra, extra_scale)` instead of packed fragments + bounds."""
+        if os.environ.get('POLARA_HIP_LIB'):      # a probe library carries round 4's sweep tree: packed fragments only
+            return False
         return (E.dtype == torch.float64 and E.dim() == 2 and E.stride(1) == 1 and E.stride(0) % 2 == 0 and E.data_ptr() % 16 == 0)
 
     @staticmethod
