@@ -1071,7 +1071,7 @@ class HipOps:
     def _rows_args(E_rows, K):
         E, extra, scale = E_rows
         assert E.shape[1] >= K
-        e_ld = 0 if extra is None else (extra.stride(0) if extra.dim() == 1 else extra.stride(0))
+        e_ld = 0 if extra is None else extra.stride(0)      # a column of E's own block: one entry per row, rows `stride` apart
         return _ptr(E), E.stride(0), _ptr(extra), int(e_ld), float(scale if extra is not None else 0.0)
 
     def score_candidates(self, Vp, Ep, n_users, n_items, K, seen_ptr, seen_idx, KC, splits=1, tiles_per_chunk=0,
