@@ -652,6 +652,38 @@ int pk_svd_build_sharded(pk_ctx *ctx, pk_mat *A_local, const pk_comm *comm, int3
 int pk_sym_eig_topk_f64(pk_ctx *ctx, void *stream, int32_t n, const double *T_dev, int64_t ldt, int32_t k, int32_t l,
                         const double *X0_dev, int64_t ldx0, int32_t x0_rows, double tol, int32_t max_outer, uint64_t seed,
                         double *basis_out_dev, int64_t ldb, double *lam_out_host, double *res_out_host, int32_t *counts_out);
+/* What a host may choose about the builds of a context — explicit calls, not environment variables (round 6):
+ *   "svd_method"   0 = the cost model (solver.py::choose_method restated), 1 = block Lanczos, 2 = filtered subspace iteration
+ *   "krylov_block" 0 = the cost model (solver.py::choose_krylov_block restated), else the width of a Krylov block (<= block)
+ *   "dist_overlap" two-panel exchange of a sharded product: 0 = never, 1 = by the cost model, 2 = whenever possible (tests)
+ *   "hooi_ttm"     1 = pk_hooi runs the per-entry mode products (pk_ttm_f64) instead of the factored form
+ *   "time_spmm"    1 = HIP events around every SpMM launch of the context's builds, read with pk_ctx_spmm_timings
+ * Unknown names and values out of range are PK_E_INVALID. */
+int pk_ctx_set_option(pk_ctx *ctx, const char *name, int32_t value);
+/* The SpMM launches recorded since the last call (option "time_spmm"; bench.py's roofline of the build): waits for them,
+ * writes min(count, cap) records — ms_out[i] = duration in ms, meta_out[6 i ..] = {rows written, rows gathered from, stored
+ * entries, columns, bytes per stored value, bytes per element of the dense block} — forgets them all, returns the count. */
+int64_t pk_ctx_spmm_timings(pk_ctx *ctx, double *ms_out, int64_t *meta_out, int64_t cap);
+/* The recurrence of the block Lanczos build for a host layer that keeps the looks (polara_amd/solver.py::_block_lanczos; the
+ * reference's `svds` call, models.py:841-844, runs ARPACK's recurrence in its place).  All three run on `stream` (a
+ * hipStream_t; 0 = the null stream) with temporaries from the context's pool — use ONE stream per context.
+ * pk_mat_wrap_device: a NON-OWNING matrix over CSR arrays that already live in HBM (indptr int64[n_rows + 1], indices int32,
+ * values f32 | f64 — they must outlive the handle), with its task plan and the user-blocked transpose image sized for
+ * products with `block_cols`-column blocks (0: 64).  pk_mat_free releases the handle, never the borrowed arrays.
+ * pk_lanczos_steps: steps j0 + 1 .. j0 + m of the recurrence  W = A^T A Q_j;  T[:, j] = Q^T W;  Q_(j+1) R = W - Q T[:, j]
+ * (shifted CholeskyQR3, re-projected against the whole basis in every pass) on the caller's buffers: Q_dev [n_cols x >=
+ * (j0 + m + 1) b] with block j in columns [(j - 1) b, j b), T_dev [>= (j0 + m) b square] (block column j AND its mirror
+ * image are written), S_out_dev [b x b] = W_perp^T W_perp of the LAST step run (the coupling behind the residual
+ * estimates of the Ritz pairs), flags_dev[2] += Cholesky verdicts / max= distance of a last pass's Gram matrix from I.
+ * last_closes: the last step of the call does not compute a next block (the space is full).  No host synchronisation.
+ * pk_gramian_apply_f64: Z = A^T (A X), X / Z [n_cols x nc] with leading dimensions ldx / ldz (the verification product). */
+int pk_mat_wrap_device(pk_ctx *ctx, void *stream, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t *indptr_dev,
+                       const int32_t *indices_dev, const void *values_dev, int32_t val_kind, int32_t block_cols,
+                       pk_mat **mat_out);
+int pk_lanczos_steps(pk_ctx *ctx, void *stream, pk_mat *A, int32_t b, int32_t j0, int32_t m, int32_t last_closes,
+                     double *Q_dev, int64_t ldq, double *T_dev, int64_t ldt, double *S_out_dev, double *flags_dev);
+int pk_gramian_apply_f64(pk_ctx *ctx, void *stream, pk_mat *A, int32_t nc, const double *X_dev, int64_t ldx, double *Z_dev,
+                         int64_t ldz);
 /* the context's HIP stream (hipStream_t as void*): what a pk_comm callback is handed, for hosts that create the
  * communicator's work on it */
 void *pk_ctx_stream(pk_ctx *ctx);

@@ -133,6 +133,11 @@ PROTOTYPES = {
                                       _vp, _i64, _vp, _vp, _vp]),
     'pk_svd_build_sharded': (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f64, _i32, C.c_uint64, _vp, _vp, _vp, _vp]),
     'pk_ctx_stream': (_vp, [_vp]),
+    'pk_ctx_set_option': (C.c_int, [_vp, C.c_char_p, _i32]),
+    'pk_ctx_spmm_timings': (_i64, [_vp, _vp, _vp, _i64]),
+    'pk_mat_wrap_device': (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i32, _i32, C.POINTER(_vp)]),
+    'pk_lanczos_steps': (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp]),
+    'pk_gramian_apply_f64': (C.c_int, [_vp, _vp, _vp, _i32, _vp, _i64, _vp, _i64]),
     'pk_score_topk': (C.c_int, [_vp, _i64, _i32, _vp, _vp, _i32, _i32, _vp, _vp]),
     'pk_serving_create': (C.c_int, [_vp, _i64, _i32, _vp, _vp, C.POINTER(_vp)]),
     'pk_serving_score': (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp]),
@@ -174,9 +179,12 @@ def load():
     return lib
 
 
-def check(rc, what=''):
+def check(rc, what='', lib=None, ctx=None):
+    """raises on a non-zero return code; `ctx`: the call belonged to a coarse-ABI context, whose own message says why"""
     if rc != 0:
-        msg = load().pk_last_error()
+        lib = lib or load()
+        msg = lib.pk_ctx_error(ctx) if ctx is not None else None
+        msg = msg or lib.pk_last_error()
         raise PolaraHipError('%s failed (rc=%d): %s' % (what, rc, msg.decode() if msg else ''))
 
 

@@ -52,12 +52,28 @@ struct DevPool {
     }
 };
 
+// What a host may choose about the builds of a context (pk_ctx_set_option): explicit calls, not environment variables.
+struct CtxOptions {
+    int svd_method = 0;      // 0 = the cost model (svd_build_impl), 1 = block Lanczos, 2 = filtered subspace iteration
+    int krylov_block = 0;    // 0 = the cost model (choose_krylov_block), else the width of a Krylov block
+    int dist_overlap = 1;    // two-panel exchange of a sharded product: 0 = never, 1 = by the cost model, 2 = whenever possible
+    int hooi_ttm = 0;        // 1 = the per-entry mode products (pk_ttm_f64) instead of the factored form
+    int time_spmm = 0;       // 1 = HIP events around every SpMM launch of this context's builds (pk_ctx_spmm_timings: bench.py's roofline of the build)
+};
+
+struct SpmmTiming {
+    hipEvent_t e0, e1;
+    int64_t meta[6];         // rows written, rows gathered from, entries, columns, bytes per stored value, bytes per element of the dense block
+};
+
 struct pk_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::mutex mu;
     std::string err;
     DevPool pool;
+    CtxOptions opt;
+    std::vector<SpmmTiming> spmm_timings;
 };
 
 static thread_local DevPool *g_pool = nullptr;   // the pool of the context whose call runs on this thread
@@ -98,17 +114,22 @@ struct Dev {   // one device allocation (from the calling context's pool)
     size_t bytes = 0;
     size_t cap = 0;
     DevPool *pool = nullptr;
+    bool borrowed = false;      // memory of the caller (pk_mat_wrap_device, the views of pk_lanczos_steps): never freed here
     Dev() {}
     explicit Dev(size_t b) { alloc(b); }
     Dev(const Dev &) = delete;
     Dev &operator=(const Dev &) = delete;
-    Dev(Dev &&o) noexcept : p(o.p), bytes(o.bytes), cap(o.cap), pool(o.pool) { o.p = nullptr; o.bytes = o.cap = 0; }
+    Dev(Dev &&o) noexcept : p(o.p), bytes(o.bytes), cap(o.cap), pool(o.pool), borrowed(o.borrowed) { o.p = nullptr; o.bytes = o.cap = 0; o.borrowed = false; }
     Dev &operator=(Dev &&o) noexcept {
         if (this != &o) {
             release();
-            p = o.p; bytes = o.bytes; cap = o.cap; pool = o.pool; o.p = nullptr; o.bytes = o.cap = 0;
+            p = o.p; bytes = o.bytes; cap = o.cap; pool = o.pool; borrowed = o.borrowed; o.p = nullptr; o.bytes = o.cap = 0; o.borrowed = false;
         }
         return *this;
+    }
+    void borrow(const void *ptr, size_t b) {
+        release();
+        p = const_cast<void *>(ptr); bytes = b; cap = 0; pool = nullptr; borrowed = true;
     }
     ~Dev() { release(); }
     bool alloc(size_t b) {
@@ -123,10 +144,11 @@ struct Dev {   // one device allocation (from the calling context's pool)
         return true;
     }
     void release() {
-        if (p) {
+        if (p && !borrowed) {
             if (pool) pool->put(p, cap); else (void)hipFree(p);
-            p = nullptr;
         }
+        p = nullptr;
+        borrowed = false;
         bytes = cap = 0;
     }
     template <typename T> T *as() const { return static_cast<T *>(p); }
@@ -138,6 +160,12 @@ struct DMat {   // dense row-major fp64 [n x l], contiguous
     int l = 0;
     DMat() {}
     DMat(int64_t n_, int l_) : buf((size_t)std::max<int64_t>(n_, 1) * std::max(l_, 1) * 8), n(n_), l(l_) {}
+    static DMat view(const double *ptr, int64_t n_, int l_) {      // a contiguous [n x l] block of the caller's memory
+        DMat m;
+        m.buf.borrow(ptr, (size_t)n_ * l_ * 8);
+        m.n = n_; m.l = l_;
+        return m;
+    }
     double *p() const { return buf.as<double>(); }
     bool ok() const { return buf.p != nullptr; }
 };
@@ -228,6 +256,7 @@ struct pk_mat {
     std::unique_ptr<Csr> Tb;          // user-blocked transpose image
     int64_t rows_per_block = 0, n_blocks = 0;
     std::vector<Range> block_ranges;
+    std::vector<int64_t> block_nnz;
     bool nonneg = true;
 };
 
@@ -271,18 +300,32 @@ int task_range(pk_ctx *ctx, Csr &M, int64_t lo, int64_t hi, Range *out) {
 
 // out[.. x nc] (+)= M X over the plan slice `rg`
 int spmm(pk_ctx *ctx, Csr &M, const void *X, int x_kind, int64_t ldx, int nc, double *out, int64_t ldo, const Range &rg,
-         int64_t row_base = 0, int accumulate = 0) {
+         int64_t row_base = 0, int accumulate = 0, const int64_t *shape3 = nullptr) {
     Plan &P = M.plan;
     const size_t xe = x_kind == PK_VAL_F64 ? 8 : 4;
     for (int c0 = 0; c0 < nc; c0 += 256) {
         const int w = std::min(256, nc - c0);
         const size_t need = (size_t)P.n_slots * w * 8;
         if (need > P.partial.bytes && !P.partial.alloc(need)) return fail(ctx, PK_E_LAUNCH, "out of device memory (spmm partials)");
+        SpmmTiming tm;
+        if (ctx->opt.time_spmm) {
+            HIPCK(hipEventCreate(&tm.e0));
+            HIPCK(hipEventCreate(&tm.e1));
+            const int64_t whole[3] = {M.n_rows, M.n_cols, M.nnz};
+            const int64_t *sh = shape3 ? shape3 : whole;
+            tm.meta[0] = sh[0]; tm.meta[1] = sh[1]; tm.meta[2] = sh[2]; tm.meta[3] = w;
+            tm.meta[4] = M.val_kind == PK_VAL_F32 ? 4 : 8; tm.meta[5] = (int64_t)xe;
+            HIPCK(hipEventRecord(tm.e0, ctx->stream));
+        }
         CK(pk_spmm_csr_ex(ctx->stream, rg.nt, P.task_row.as<int32_t>() + rg.t0, P.task_begin.as<int64_t>() + rg.t0,
                           P.task_end.as<int64_t>() + rg.t0, P.task_slot.as<int32_t>() + rg.t0, rg.nl,
                           P.long_row.as<int32_t>() + rg.l0, P.long_sb.as<int32_t>() + rg.l0, P.long_se.as<int32_t>() + rg.l0,
                           M.indices.as<int32_t>(), M.values.p, M.val_kind, static_cast<const char *>(X) + (size_t)c0 * xe, x_kind, ldx,
                           w, out + c0, ldo, P.partial.as<double>(), row_base, accumulate, 0));
+        if (ctx->opt.time_spmm) {
+            HIPCK(hipEventRecord(tm.e1, ctx->stream));
+            ctx->spmm_timings.push_back(tm);
+        }
     }
     return PK_OK;
 }
@@ -291,10 +334,14 @@ int spmm_full(pk_ctx *ctx, Csr &M, const DMat &X, DMat &out) {
     return spmm(ctx, M, X.p(), PK_VAL_F64, X.l, X.l, out.p(), out.l, Range{0, M.plan.n_tasks, 0, M.plan.n_long});
 }
 
-int ensure_blocked_transpose(pk_ctx *ctx, pk_mat *m) {
+// nc: the width of the blocks the image will multiply — a user block's rows of Y (nc fp64 columns) are meant to stay in the L2s
+// (8 MB at 16 384 rows of 64 columns), so a narrow Krylov block takes proportionally more users per launch (round 6: eight
+// launches of A^T Y per step at b = 16 were four fifths launch overhead)
+int ensure_blocked_transpose(pk_ctx *ctx, pk_mat *m, int nc = 64) {
     if (m->Tb) return PK_OK;
     Csr &A = m->A;
-    int64_t rpb = std::max<int64_t>(16384, (int64_t)(64.0 * (double)A.n_cols * (double)A.n_rows / (double)std::max<int64_t>(A.nnz, 1)));
+    const int64_t l2_rows = 16384 * (int64_t)std::max(1, 64 / std::max(16, std::min(nc, 64)));
+    int64_t rpb = std::max<int64_t>(l2_rows, (int64_t)(64.0 * (double)A.n_cols * (double)A.n_rows / (double)std::max<int64_t>(A.nnz, 1)));
     rpb = ((rpb + 4095) / 4096) * 4096;
     rpb = std::min<int64_t>(rpb, std::max<int64_t>(A.n_rows, 1));
     if (A.n_rows < 2 * 16384) rpb = std::max<int64_t>(A.n_rows, 1);          // small matrices: one block = the plain transpose
@@ -313,6 +360,14 @@ int ensure_blocked_transpose(pk_ctx *ctx, pk_mat *m) {
     CK(build_plan(ctx, *T));
     m->block_ranges.resize((size_t)nb);
     for (int64_t b = 0; b < nb; ++b) CK(task_range(ctx, *T, b * A.n_cols, (b + 1) * A.n_cols, &m->block_ranges[(size_t)b]));
+    {   // entries per block (the timing records of bench.py's build roofline)
+        std::vector<int64_t> edges((size_t)nb + 1);
+        for (int64_t b = 0; b <= nb; ++b)
+            HIPCK(hipMemcpyAsync(&edges[(size_t)b], T->indptr.as<int64_t>() + b * A.n_cols, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCK(hipStreamSynchronize(ctx->stream));
+        m->block_nnz.resize((size_t)nb);
+        for (int64_t b = 0; b < nb; ++b) m->block_nnz[(size_t)b] = edges[(size_t)b + 1] - edges[(size_t)b];
+    }
     m->rows_per_block = rpb; m->n_blocks = nb;
     m->Tb = std::move(T);
     return PK_OK;
@@ -320,8 +375,10 @@ int ensure_blocked_transpose(pk_ctx *ctx, pk_mat *m) {
 
 // Z = A^T Y, user block by user block (block b > 0 adds)
 int spmm_t(pk_ctx *ctx, pk_mat *m, const DMat &Y, DMat &Z) {
-    for (int64_t b = 0; b < m->n_blocks; ++b)
-        CK(spmm(ctx, *m->Tb, Y.p(), PK_VAL_F64, Y.l, Y.l, Z.p(), Z.l, m->block_ranges[(size_t)b], b * m->A.n_cols, b > 0));
+    for (int64_t b = 0; b < m->n_blocks; ++b) {
+        const int64_t shape3[3] = {b == 0 ? m->A.n_cols : 0, m->rows_per_block, m->block_nnz[(size_t)b]};
+        CK(spmm(ctx, *m->Tb, Y.p(), PK_VAL_F64, Y.l, Y.l, Z.p(), Z.l, m->block_ranges[(size_t)b], b * m->A.n_cols, b > 0, shape3));
+    }
     return PK_OK;
 }
 
@@ -598,6 +655,45 @@ extern "C" void pk_ctx_destroy(pk_ctx *ctx) {
 
 extern "C" const char *pk_ctx_error(pk_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
+extern "C" int pk_ctx_set_option(pk_ctx *ctx, const char *name, int32_t value) {
+    if (!ctx || !name) return PK_E_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    struct { const char *name; int *slot; int lo, hi; } table[] = {
+        {"svd_method", &ctx->opt.svd_method, 0, 2},   {"krylov_block", &ctx->opt.krylov_block, 0, 1024},
+        {"dist_overlap", &ctx->opt.dist_overlap, 0, 2}, {"hooi_ttm", &ctx->opt.hooi_ttm, 0, 1}, {"time_spmm", &ctx->opt.time_spmm, 0, 1}};
+    for (auto &e : table)
+        if (!strcmp(name, e.name)) {
+            if (value < e.lo || value > e.hi) return fail(ctx, PK_E_INVALID, "pk_ctx_set_option: %s takes %d..%d", name, e.lo, e.hi);
+            *e.slot = value;
+            return PK_OK;
+        }
+    return fail(ctx, PK_E_INVALID, "pk_ctx_set_option: unknown option '%s'", name);
+}
+
+// the SpMM launches recorded since the last call (option "time_spmm"): waits for them, writes min(count, cap) records —
+// ms_out[i] = duration, meta_out[6 i ..] = {rows written, rows gathered from, entries, columns, bytes per stored value, bytes per
+// element of the dense block} — forgets them all, returns the count
+extern "C" int64_t pk_ctx_spmm_timings(pk_ctx *ctx, double *ms_out, int64_t *meta_out, int64_t cap) {
+    if (!ctx) return -1;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    const int64_t count = (int64_t)ctx->spmm_timings.size();
+    for (int64_t i = 0; i < count; ++i) {
+        SpmmTiming &t = ctx->spmm_timings[(size_t)i];
+        float ms = 0.f;
+        (void)hipEventSynchronize(t.e1);
+        (void)hipEventElapsedTime(&ms, t.e0, t.e1);
+        if (i < cap && ms_out && meta_out) {
+            ms_out[i] = (double)ms;
+            for (int q = 0; q < 6; ++q) meta_out[6 * i + q] = t.meta[q];
+        }
+        (void)hipEventDestroy(t.e0);
+        (void)hipEventDestroy(t.e1);
+    }
+    ctx->spmm_timings.clear();
+    return count;
+}
+
 extern "C" int pk_mat_from_csr(pk_ctx *ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t *indptr,
                                const int32_t *indices, const void *values, int32_t val_kind, pk_mat **out) {
     if (!ctx || !out) return PK_E_INVALID;
@@ -857,12 +953,11 @@ struct GramianOp {
     // Is the exchange of an [n_cols x l] block long enough to be worth hiding behind half of its own products?  The rule of
     // solver.py::ItemRows.product (one statement of the solver, two languages): the modelled all-reduce reaches 0.4 ms —
     // the split costs two launches of A^T Y per user block instead of one, and a half-width panel costs ~0.7 of the full
-    // launch, not half.  PK_DIST_OVERLAP: 0 = never, force = whenever there is something to exchange (tests).
+    // launch, not half.  Context option "dist_overlap": 0 = never, 2 = whenever there is something to exchange (tests).
     bool split_product(int l) const {
         if (!comm || comm->world < 2 || l < 32 || l % 16 != 0) return false;
-        const char *mode = getenv("PK_DIST_OVERLAP");
-        if (mode && strcmp(mode, "0") == 0) return false;
-        if (mode && strcmp(mode, "force") == 0) return true;
+        if (ctx->opt.dist_overlap == 0) return false;
+        if (ctx->opt.dist_overlap == 2) return true;
         constexpr double kXgmiBusBps = 100e9 /* assumed: machine_model.py xgmi_bus_Bps */;
         return 2.0 * (comm->world - 1) / comm->world * (double)A->A.n_cols * l * 8.0 / kXgmiBusBps >= 4e-4;
     }
@@ -966,7 +1061,7 @@ struct RitzLook {
     bool conv = false;
 };
 
-static int ritz_look(pk_ctx *ctx, Solver &S, const DMat &T, const DMat &Sc, const DMat *warm, int k, int b, double est_tol,
+static int ritz_look(pk_ctx *ctx, Solver &S, const DMat &T, const DMat &Sc, const DMat *warm, int k, int b, int width, double est_tol,
                      double prior, uint64_t seed, LanczosOut &lo, RitzLook &out) {
     const int N = (int)T.n;
     DMat X0;
@@ -981,7 +1076,7 @@ static int ritz_look(pk_ctx *ctx, Solver &S, const DMat &T, const DMat &Sc, cons
         }
         return PK_OK;
     };
-    CK(pad(warm, warm ? warm->l : b));
+    CK(pad(warm, warm ? warm->l : std::min(N, std::max(b, width))));      // cold: the first unit vectors, k + guard of them
     double t_in = std::max(0.3 * est_tol, prior < 0 ? 1e-4 : 0.03 * prior);
     for (;;) {
         DenseOp dop{ctx, S, T};
@@ -1062,7 +1157,76 @@ __global__ void lanczos_flags_kernel(int l, const double *__restrict__ G, const 
     }
 }
 
-static int block_lanczos(pk_ctx *ctx, Solver &S, GramianOp &gop, int64_t n, int k, int b, double tol, uint64_t seed, int max_steps,
+struct LanczosBuffers {
+    double *Q; int64_t ldq;      // the Krylov basis [n x >= (j + 1) b], block j in columns [(j - 1) b, j b)
+    double *T; int64_t ldt;      // the projected matrix [>= j b square]
+    double *flags;               // [sum of Cholesky verdicts, max distance of a last pass's Gram matrix from I]
+    int32_t *info;               // 3 Cholesky verdicts (scratch)
+    void *chol_work;
+};
+
+// ONE step of the recurrence (solver.py::_block_lanczos loop body + _next_lanczos_block): W = B Q_j, block column j of T,
+// the next block by shifted CholeskyQR3 re-projected against the whole basis in every pass.  Sc = W_perp^T W_perp, the
+// coupling behind the residual estimates.  The ONE statement of the step: the coarse build (block_lanczos below) and the
+// Python layer's build (pk_lanczos_steps; solver.py keeps the looks, their monitors and the decisions) both run it.
+static int lanczos_step(pk_ctx *ctx, Solver &S, GramianOp &gop, int64_t n, int b, int j, bool last, const LanczosBuffers &B, DMat &Sc) {
+    const int N = j * b;
+    const int64_t ldq = B.ldq, ldt = B.ldt;
+    const double u = 1.1102230246251565e-16;
+    DMat Qj(n, b), W;
+    if (!Qj.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (block Lanczos)");
+    HIPCK(hipMemcpy2DAsync(Qj.p(), (size_t)b * 8, B.Q + (N - b), (size_t)ldq * 8, (size_t)b * 8, (size_t)n, hipMemcpyDeviceToDevice, S.st));
+    CK(gop.apply(Qj, W));
+    // block column j of T = Q^T W, rows of all blocks so far (and its mirror image)
+    DMat C(N, b);
+    const size_t need = (size_t)pk_gram_work_bytes(n, N, b);
+    if (!C.ok() || (need > S.gram_work.bytes && !S.gram_work.alloc(need))) return fail(ctx, PK_E_LAUNCH, "out of device memory (gram)");
+    CK(pk_gram_f64(S.st, n, N, b, B.Q, ldq, W.p(), b, C.p(), b, S.gram_work.p));
+    HIPCK(hipMemcpy2DAsync(B.T + (N - b), (size_t)ldt * 8, C.p(), (size_t)b * 8, (size_t)b * 8, (size_t)N, hipMemcpyDeviceToDevice, S.st));
+    if (N > b)
+        hipLaunchKernelGGL(mirror_block_kernel, dim3((unsigned)(((int64_t)(N - b) * b + 255) / 256)), dim3(256), 0, S.st, N - b, b, ldt, C.p(),
+                           B.T);
+    if (!last) {
+        // solver.py::_next_lanczos_block: shifted CholeskyQR3, re-projected against the whole basis in every pass
+        HIPCK(hipMemsetAsync(B.info, 0, 12, S.st));
+        // The block lives where it will stay — columns [N, N + b) of the basis — so that a re-projection pass needs ONE Gram
+        // product: [Q | Y]^T Y = (the coefficients Q^T Y of the re-projection; the Gram matrix of Y before it).
+        DMat G, M(N + b, b);
+        if (!M.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (block Lanczos)");
+        const double *Gp = nullptr;
+        int64_t ldgp = b;
+        for (int p = 0; p < 3; ++p) {
+            DMat Yp(n, b), Rinv(b, b);
+            if (!Yp.ok() || !Rinv.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (block Lanczos)");
+            if (p == 0) {
+                CK(pk_tsmm_sub_f64(S.st, n, N, b, B.Q, ldq, C.p(), b, W.p(), b, Yp.p(), b));
+                CK(S.gram(Yp, Yp, G));
+                CK(S.col_slice(G, 0, b, Sc));
+                Gp = G.p();
+            } else {
+                const size_t need = (size_t)pk_gram_work_bytes(n, N + b, b);
+                if (need > S.gram_work.bytes && !S.gram_work.alloc(need)) return fail(ctx, PK_E_LAUNCH, "out of device memory (gram)");
+                CK(pk_gram_f64(S.st, n, N + b, b, B.Q, ldq, B.Q + N, ldq, M.p(), b, S.gram_work.p));
+                CK(pk_tsmm_sub_f64(S.st, n, N, b, B.Q, ldq, M.p(), b, B.Q + N, ldq, Yp.p(), b));
+                Gp = M.p() + (size_t)N * b;
+            }
+            CK(pk_chol_rinv_f64(S.st, b, Gp, ldgp, p == 0 ? 11.0 * ((double)n * b + (double)b * (b + 1)) * u : 0.0, Rinv.p(), b, B.chol_work,
+                                B.info + p));
+            CK(pk_tsmm_f64(S.st, n, b, b, Yp.p(), b, Rinv.p(), b, B.Q + N, ldq));
+        }
+        hipLaunchKernelGGL(lanczos_flags_kernel, dim3(1), dim3(256), 0, S.st, b, Gp, B.info, B.flags);
+    } else {
+        DMat Wp(n, b);
+        if (!Wp.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (block Lanczos)");
+        CK(pk_tsmm_sub_f64(S.st, n, N, b, B.Q, ldq, C.p(), b, W.p(), b, Wp.p(), b));
+        CK(S.gram(Wp, Wp, Sc));
+    }
+    return PK_OK;
+}
+
+// b: width of a Krylov block; l: width of the nested solves (k + guard vectors).  Round 6: b < l — a narrower block needs
+// (l / b)^0.36 times the steps and gathers b / l of the columns per step (solver.py::choose_krylov_block).
+static int block_lanczos(pk_ctx *ctx, Solver &S, GramianOp &gop, int64_t n, int k, int l, int b, double tol, uint64_t seed, int max_steps,
                          LanczosOut &out) {
     // pk_gram_f64 takes operands of at most 4096 columns: a Krylov space that would outgrow them ends the recurrence like
     // any other breakdown (out.ok stays false -> filtered subspace iteration), as solver.py::_block_lanczos does
@@ -1081,12 +1245,11 @@ static int block_lanczos(pk_ctx *ctx, Solver &S, GramianOp &gop, int64_t n, int 
         CK(S.orthonormalize(R, nullptr, 12345, Q1));
         HIPCK(hipMemcpy2DAsync(Q.p(), (size_t)Q.l * 8, Q1.p(), (size_t)b * 8, (size_t)b * 8, (size_t)n, hipMemcpyDeviceToDevice, S.st));
     }
-    const double u = 1.1102230246251565e-16;
     std::vector<std::pair<int, double>> hist;
     RitzLook look;
     bool have_warm = false;
     double est_tol = tol;
-    int next_look = std::min(std::max(4, (2 * k + b - 1) / b + 2), qcap);
+    int next_look = std::min(std::max(std::max(4, (2 * k + b - 1) / b + 2), (l + b - 1) / b), qcap);
     int j = 0;
     while (j < qcap) {
         ++j;
@@ -1102,57 +1265,9 @@ static int block_lanczos(pk_ctx *ctx, Solver &S, GramianOp &gop, int64_t n, int 
             T = std::move(T2);
             cap = cap2;
         }
-        const int ldq = Q.l, ldt = T.l;
-        DMat Qj(n, b), W;
-        if (!Qj.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (block Lanczos)");
-        HIPCK(hipMemcpy2DAsync(Qj.p(), (size_t)b * 8, Q.p() + (N - b), (size_t)ldq * 8, (size_t)b * 8, (size_t)n, hipMemcpyDeviceToDevice, S.st));
-        CK(gop.apply(Qj, W));
-        // block column j of T = Q^T W, rows of all blocks so far (and its mirror image)
-        DMat C(N, b);
-        const size_t need = (size_t)pk_gram_work_bytes(n, N, b);
-        if (!C.ok() || (need > S.gram_work.bytes && !S.gram_work.alloc(need))) return fail(ctx, PK_E_LAUNCH, "out of device memory (gram)");
-        CK(pk_gram_f64(S.st, n, N, b, Q.p(), ldq, W.p(), b, C.p(), b, S.gram_work.p));
-        HIPCK(hipMemcpy2DAsync(T.p() + (N - b), (size_t)ldt * 8, C.p(), (size_t)b * 8, (size_t)b * 8, (size_t)N, hipMemcpyDeviceToDevice, S.st));
-        if (N > b)
-            hipLaunchKernelGGL(mirror_block_kernel, dim3((unsigned)(((int64_t)(N - b) * b + 255) / 256)), dim3(256), 0, S.st, N - b, b, ldt, C.p(),
-                               T.p());
         const bool last = j == qcap;
         DMat Sc;
-        if (!last) {
-            // solver.py::_next_lanczos_block: shifted CholeskyQR3, re-projected against the whole basis in every pass
-            HIPCK(hipMemsetAsync(info.p, 0, 12, S.st));
-            // The block lives where it will stay — columns [N, N + b) of the basis — so that a re-projection pass needs ONE Gram
-            // product: [Q | Y]^T Y = (the coefficients Q^T Y of the re-projection; the Gram matrix of Y before it).
-            DMat G, M(N + b, b);
-            if (!M.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (block Lanczos)");
-            const double *Gp = nullptr;
-            int64_t ldgp = b;
-            for (int p = 0; p < 3; ++p) {
-                DMat Yp(n, b), Rinv(b, b);
-                if (!Yp.ok() || !Rinv.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (block Lanczos)");
-                if (p == 0) {
-                    CK(pk_tsmm_sub_f64(S.st, n, N, b, Q.p(), ldq, C.p(), b, W.p(), b, Yp.p(), b));
-                    CK(S.gram(Yp, Yp, G));
-                    CK(S.col_slice(G, 0, b, Sc));
-                    Gp = G.p();
-                } else {
-                    const size_t need = (size_t)pk_gram_work_bytes(n, N + b, b);
-                    if (need > S.gram_work.bytes && !S.gram_work.alloc(need)) return fail(ctx, PK_E_LAUNCH, "out of device memory (gram)");
-                    CK(pk_gram_f64(S.st, n, N + b, b, Q.p(), ldq, Q.p() + N, ldq, M.p(), b, S.gram_work.p));
-                    CK(pk_tsmm_sub_f64(S.st, n, N, b, Q.p(), ldq, M.p(), b, Q.p() + N, ldq, Yp.p(), b));
-                    Gp = M.p() + (size_t)N * b;
-                }
-                CK(pk_chol_rinv_f64(S.st, b, Gp, ldgp, p == 0 ? 11.0 * ((double)n * b + (double)b * (b + 1)) * u : 0.0, Rinv.p(), b, chol_work.p,
-                                    info.as<int32_t>() + p));
-                CK(pk_tsmm_f64(S.st, n, b, b, Yp.p(), b, Rinv.p(), b, Q.p() + N, ldq));
-            }
-            hipLaunchKernelGGL(lanczos_flags_kernel, dim3(1), dim3(256), 0, S.st, b, Gp, info.as<int32_t>(), flags.as<double>());
-        } else {
-            DMat Wp(n, b);
-            if (!Wp.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (block Lanczos)");
-            CK(pk_tsmm_sub_f64(S.st, n, N, b, Q.p(), ldq, C.p(), b, W.p(), b, Wp.p(), b));
-            CK(S.gram(Wp, Wp, Sc));
-        }
+        CK(lanczos_step(ctx, S, gop, n, b, j, last, LanczosBuffers{Q.p(), Q.l, T.p(), T.l, flags.as<double>(), info.as<int32_t>(), chol_work.p}, Sc));
         out.steps = j;
         if (j < next_look && !last) continue;
         // ---- a look: breakdown flags, the pairs of T_j, verification ---------------------------------------------------
@@ -1161,9 +1276,9 @@ static int block_lanczos(pk_ctx *ctx, Solver &S, GramianOp &gop, int64_t n, int 
         if (fl[0] != 0.0 || !(fl[1] < 1e-4)) return PK_OK;        // the residual block lost rank: out.ok stays false
         DMat Tj(N, N);
         if (!Tj.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (block Lanczos)");
-        hipLaunchKernelGGL(sym_block_kernel, dim3((unsigned)(((int64_t)N * N + 255) / 256)), dim3(256), 0, S.st, N, ldt, T.p(), Tj.p());
+        hipLaunchKernelGGL(sym_block_kernel, dim3((unsigned)(((int64_t)N * N + 255) / 256)), dim3(256), 0, S.st, N, T.l, T.p(), Tj.p());
         RitzLook nl;
-        CK(ritz_look(ctx, S, Tj, Sc, have_warm ? &look.basis : nullptr, k, b, est_tol, hist.empty() ? -1.0 : hist.back().second,
+        CK(ritz_look(ctx, S, Tj, Sc, have_warm ? &look.basis : nullptr, k, b, l, est_tol, hist.empty() ? -1.0 : hist.back().second,
                      seed + 1000ull * (uint64_t)j, out, nl));
         look = std::move(nl);
         have_warm = true;
@@ -1172,7 +1287,7 @@ static int block_lanczos(pk_ctx *ctx, Solver &S, GramianOp &gop, int64_t n, int 
             // one true product on the k Ritz vectors: V = Q Y
             DMat Vk(n, k), Z;
             if (!Vk.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (block Lanczos)");
-            CK(pk_tsmm_f64(S.st, n, N, k, Q.p(), ldq, look.Yk.p(), k, Vk.p(), k));
+            CK(pk_tsmm_f64(S.st, n, N, k, Q.p(), Q.l, look.Yk.p(), k, Vk.p(), k));
             CK(gop.apply(Vk, Z));
             std::vector<double> res;
             CK(S.resid(Z, Vk, look.lam_k_dev, res));
@@ -1218,7 +1333,6 @@ static int svd_build_impl(pk_ctx *ctx, pk_mat *A, const pk_comm *comm, int32_t k
     }
     l = (int)std::max<int64_t>(k, std::min<int64_t>(l, n_items));
     if (l > 1024) return fail(ctx, PK_E_UNSUPPORTED, "pk_svd_build: block width %d beyond the 1024 of the dense kernels", l);
-    CK(ensure_blocked_transpose(ctx, A));
     Solver S{ctx, ctx->stream, Dev()};
     pk_build_stats stats;
     memset(&stats, 0, sizeof(stats));
@@ -1233,10 +1347,10 @@ static int svd_build_impl(pk_ctx *ctx, pk_mat *A, const pk_comm *comm, int32_t k
     GramianOp gop{ctx, S, A, comm};
     // the method, as solver.py::svd_topk chooses it: block Lanczos where a Gramian step is heavy (stored entries x block
     // width, summed over the ranks), the filtered subspace iteration on small matrices and whenever the Krylov recurrence
-    // breaks down (PK_SVD_METHOD = lanczos | subspace overrides)
+    // breaks down (context option "svd_method" overrides)
     bool use_lanczos;
+    int kb = l;
     {
-        const char *me = getenv("PK_SVD_METHOD");
         double work = (double)A->A.nnz;
         if (comm) {
             Dev wd(8);
@@ -1246,27 +1360,46 @@ static int svd_build_impl(pk_ctx *ctx, pk_mat *A, const pk_comm *comm, int32_t k
                 return fail(ctx, PK_E_LAUNCH, "pk_svd_build_sharded: the communicator's all-reduce failed");
             CK(S.to_host(wd.p, &work, 8));
         }
-        // solver.py::choose_method: a step's products against the re-orthogonalisation over the Krylov basis and the
-        // projected eigenproblems
-        // (the constants: polara_amd/machine_model.py — measured rates with their records under profiles/, and the two
-        // multi-GPU figures that are assumptions because no N > 1 run exists)
-        constexpr double kSpmmGatherBps = 15e12, kDenseF64Flops = 20e12, kNestedSolveS = 8e-3 / 16.0;
-        constexpr double kXgmiBusBps = 100e9 /* assumed */, kCollectiveStepS = 5e-6 /* assumed */;
+        // solver.py::choose_method / choose_krylov_block / _lanczos_model, restated with the same constants
+        // (polara_amd/machine_model.py — measured rates with their records under profiles/, and the two multi-GPU figures
+        // that are assumptions because no N > 1 run exists)
         const int world = comm ? comm->world : 1;
-        double t_step = work * l * 16.0 / kSpmmGatherBps / world;
-        if (world > 1) t_step += 2.0 * (world - 1) / world * (double)n_items * l * 8.0 / kXgmiBusBps + 2 * (world - 1) * kCollectiveStepS;
-        const double t_reorth = 96.0 * (double)n_items * l * l / kDenseF64Flops,
-                     t_nested = kNestedSolveS * std::max(1.0, (l / 64.0) * (l / 64.0));
-        const bool model = !(work * l < 2e8 || t_reorth + t_nested >= 2.0 * t_step);
-        use_lanczos = me && !strcmp(me, "lanczos") ? true : me && !strcmp(me, "subspace") ? false : model;
+        auto model = [&](int b, double &steps, double &t_step) {
+            constexpr double kDenseF64Flops = 20e12, kStepFixedS = 0.75e-3;
+            constexpr double kXgmiBusBps = 100e9 /* assumed */, kCollectiveStepS = 5e-6 /* assumed */;
+            steps = 14.0 * std::pow((double)l / b, 0.36);
+            double t_spmm = work * (8.0 + std::max(b, 16)) * 1e-12 / world;
+            if (world > 1) t_spmm += 2.0 * (world - 1) / world * (double)n_items * b * 8.0 / kXgmiBusBps + 6 * (world - 1) * kCollectiveStepS;
+            const double n_avg = 0.5 * steps * b;
+            t_step = t_spmm + kStepFixedS + 14.0 * (double)n_items * n_avg * b / kDenseF64Flops / world;
+        };
+        static const int widths[] = {16, 32, 64, 128, 256};
+        double best_t = -1.0;
+        for (int w : widths) {
+            if (w > l && best_t >= 0) break;
+            const int b = std::min(w, l);
+            double steps, t_step;
+            model(b, steps, t_step);
+            if (best_t < 0 || steps * t_step < best_t) { best_t = steps * t_step; kb = b; }
+        }
+        constexpr double kNestedSolveS = 1.5e-3, kStepFixedS = 0.75e-3;
+        const double wide2 = std::max(1.0, (l / 64.0) * (l / 64.0));
+        double steps_l, t_wide;
+        model(l, steps_l, t_wide);
+        const double t_lanczos = best_t + 4.0 * kNestedSolveS * wide2;
+        const double t_subspace = 2.6 * 14.0 * (t_wide - kStepFixedS) + 8 * 0.5e-3 * wide2;
+        use_lanczos = ctx->opt.svd_method == 1 ? true : ctx->opt.svd_method == 2 ? false : t_lanczos < t_subspace;
+        if (ctx->opt.krylov_block > 0) kb = std::max(1, std::min(ctx->opt.krylov_block, l));
     }
+    CK(ensure_blocked_transpose(ctx, A, use_lanczos ? kb : l));
     DMat Vk;
     std::vector<double> lam_k, res_host;
     int n_lock = 0;
     bool have = false;
     if (use_lanczos) {
         LanczosOut lo;
-        CK(block_lanczos(ctx, S, gop, n_items, k, l, tol, seed, std::min(64, 4 * max_outer), lo));
+        const int max_steps = std::min(4096 / kb, (int)(64.0 * std::sqrt((double)l / kb)));
+        CK(block_lanczos(ctx, S, gop, n_items, k, l, kb, tol, seed, std::min(max_steps, 4 * max_outer), lo));
         stats.outer = lo.looks;
         if (lo.ok) {
             Vk = std::move(lo.Vk);
@@ -1329,6 +1462,88 @@ static int svd_build_impl(pk_ctx *ctx, pk_mat *A, const pk_comm *comm, int32_t k
                                "the best available factors were written", stats.outer, stats.final_rel_residual, tol);
         return PK_E_NOCONV;
     }
+    return PK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// The recurrence of the block Lanczos build for a host layer that keeps the looks (polara_amd/solver.py::_block_lanczos:
+// monitors on a side stream, the schedule of looks, the verification): a NON-OWNING matrix over CSR arrays that already live
+// in HBM, steps of the recurrence on buffers of the caller, and the Gramian product for the verification — all on the stream
+// the caller names, temporaries from the context's pool.
+// ------------------------------------------------------------------------------------------------------------
+struct StreamScope {        // the context's stream is the caller's for the duration of one call (the context mutex is held)
+    pk_ctx *ctx;
+    hipStream_t prev;
+    StreamScope(pk_ctx *c, void *stream) : ctx(c), prev(c->stream) { c->stream = pk_stream(stream); }      // (0 = the null stream, where torch's default stream lives)
+    ~StreamScope() { ctx->stream = prev; }
+};
+
+extern "C" int pk_mat_wrap_device(pk_ctx *ctx, void *stream, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t *indptr_dev,
+                                  const int32_t *indices_dev, const void *values_dev, int32_t val_kind, int32_t block_cols,
+                                  pk_mat **out) {
+    if (!ctx || !out) return PK_E_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    PoolScope pool_scope(ctx);
+    StreamScope stream_scope(ctx, stream);
+    (void)hipSetDevice(ctx->device);
+    if (n_rows < 1 || n_cols < 1 || nnz < 0 || !indptr_dev || (nnz && (!indices_dev || !values_dev)) ||
+        (val_kind != PK_VAL_F32 && val_kind != PK_VAL_F64))
+        return fail(ctx, PK_E_INVALID, "pk_mat_wrap_device: bad arguments");
+    auto m = std::make_unique<pk_mat>();
+    Csr &A = m->A;
+    A.n_rows = n_rows; A.n_cols = n_cols; A.nnz = nnz; A.val_kind = val_kind;
+    A.indptr.borrow(indptr_dev, (size_t)(n_rows + 1) * 8);
+    A.indices.borrow(indices_dev, (size_t)nnz * 4);
+    A.values.borrow(values_dev, (size_t)nnz * (val_kind == PK_VAL_F32 ? 4 : 8));
+    m->nonneg = false;          // not examined: the wrapped matrix serves products only
+    int rc = build_plan(ctx, A);
+    if (rc != PK_OK) return rc;
+    rc = ensure_blocked_transpose(ctx, m.get(), block_cols > 0 ? block_cols : 64);
+    if (rc != PK_OK) return rc;
+    *out = m.release();
+    return PK_OK;
+}
+
+extern "C" int pk_lanczos_steps(pk_ctx *ctx, void *stream, pk_mat *A, int32_t b, int32_t j0, int32_t m, int32_t last_closes,
+                                double *Q_dev, int64_t ldq, double *T_dev, int64_t ldt, double *S_out_dev, double *flags_dev) {
+    if (!ctx || !A) return PK_E_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    PoolScope pool_scope(ctx);
+    StreamScope stream_scope(ctx, stream);
+    (void)hipSetDevice(ctx->device);
+    const int64_t n = A->A.n_cols;
+    if (b < 1 || b > 1024 || j0 < 0 || m < 1 || !Q_dev || !T_dev || !S_out_dev || !flags_dev || !A->Tb ||
+        ldq < (int64_t)(j0 + m + (last_closes ? 0 : 1)) * b || ldt < (int64_t)(j0 + m) * b || (int64_t)(j0 + m) * b > 4096)
+        return fail(ctx, PK_E_INVALID, "pk_lanczos_steps: bad arguments (b=%d, j0=%d, m=%d)", b, j0, m);
+    Solver S{ctx, ctx->stream, Dev()};
+    GramianOp gop{ctx, S, A, nullptr};
+    Dev info(12), chol_work((size_t)std::max<int64_t>(pk_chol_work_bytes(b), 8));
+    if (!info.p || !chol_work.p) return fail(ctx, PK_E_LAUNCH, "out of device memory (pk_lanczos_steps)");
+    for (int j = j0 + 1; j <= j0 + m; ++j) {
+        DMat Sc;
+        CK(lanczos_step(ctx, S, gop, n, b, j, last_closes && j == j0 + m, LanczosBuffers{Q_dev, ldq, T_dev, ldt, flags_dev, info.as<int32_t>(), chol_work.p}, Sc));
+        if (j == j0 + m) HIPCK(hipMemcpyAsync(S_out_dev, Sc.p(), (size_t)b * b * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    return PK_OK;
+}
+
+extern "C" int pk_gramian_apply_f64(pk_ctx *ctx, void *stream, pk_mat *A, int32_t nc, const double *X_dev, int64_t ldx, double *Z_dev,
+                                    int64_t ldz) {
+    if (!ctx || !A) return PK_E_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    PoolScope pool_scope(ctx);
+    StreamScope stream_scope(ctx, stream);
+    (void)hipSetDevice(ctx->device);
+    if (nc < 1 || nc > 1024 || !X_dev || !Z_dev || ldx < nc || ldz < nc || !A->Tb)
+        return fail(ctx, PK_E_INVALID, "pk_gramian_apply_f64: bad arguments (nc=%d)", nc);
+    const int64_t n = A->A.n_cols;
+    Solver S{ctx, ctx->stream, Dev()};
+    GramianOp gop{ctx, S, A, nullptr};
+    DMat X(n, nc), Z;
+    if (!X.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (pk_gramian_apply_f64)");
+    HIPCK(hipMemcpy2DAsync(X.p(), (size_t)nc * 8, X_dev, (size_t)ldx * 8, (size_t)nc * 8, (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+    CK(gop.apply(X, Z));
+    HIPCK(hipMemcpy2DAsync(Z_dev, (size_t)ldz * 8, Z.p(), (size_t)nc * 8, (size_t)nc * 8, (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
     return PK_OK;
 }
 
@@ -1867,9 +2082,8 @@ extern "C" int pk_hooi(pk_ctx *ctx, int64_t nnz, const int64_t *idx_host, const 
     // The three mode products of lib/tensor.py:70,74,78 in FACTORED form (polara_amd/tucker.py::factored_products): the
     // tensor as two CSR unfoldings, M0 [(n0 L) x n1] with row i0 L + l and M1 [(n1 L) x n0] with row i1 L + l (L = n2, the
     // feedback mode); SpMM gathers W0 = M0 u1, W1 = M1 u0, then dense contractions on the fp64 matrix cores (tsmm against
-    // kron(u2, I), one gram for the feedback mode).  PK_HOOI_TTM=1 keeps the per-entry kernel (pk_ttm_f64, dttm_seq restated).
-    const char *ttm_env = getenv("PK_HOOI_TTM");
-    const bool factored = !(ttm_env && atoi(ttm_env) != 0);
+    // kron(u2, I), one gram for the feedback mode).  Context option "hooi_ttm" = 1 keeps the per-entry kernel (pk_ttm_f64, dttm_seq restated).
+    const bool factored = ctx->opt.hooi_ttm == 0;
     const int64_t L = n2;
     ModePlan mp0, mp1, mp2;
     std::unique_ptr<pk_mat> M0, M1;

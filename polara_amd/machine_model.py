@@ -9,7 +9,10 @@ MI355X = {
     # fp64 matrix-core rate the tall-skinny kernels (gram / tsmm) reach on 26 744-row operands
     'dense_f64_flops': (20e12, 'profiles/r04_solver_timeline_lanczos.txt (tsmm 53 us for 26 744 x 448 x 64)'),
     # one nested eigen-solve of a 896 x 896 projected problem, block 64
-    'nested_solve_s': (8e-3 / 16.0, 'profiles/r04_solver_methods_ml20m_50.txt (8 ms of nested work over 16 looks)'),
+    'nested_solve_s': (1.5e-3, 'profiles/r05_solver_timeline_lanczos.txt (a look on the main stream: 2.5-4 ms of dependent small kernels, half of it hidden)'),
+    # what a block Lanczos step costs besides its sparse products and the basis traffic: ~20 small dependent launches
+    # (Gram products, CholeskyQR3 with re-projection) and its share of the looks — (build - SpMM) / steps at b = 16 / 32
+    'lanczos_step_fixed_s': (0.75e-3, 'profiles/r06_krylov_block_ml20m.txt, r06_krylov_block_s1m.txt'),
     # bus bandwidth of a ring exchange over xGMI, per rank — ASSUMED (7 links x ~153 GB/s peak; a ring is bound by one link
     # pair): never measured, there has been no multi-GPU box
     'xgmi_bus_Bps': (100e9, 'ASSUMED: no N > 1 run over RCCL exists (SCALE_r01..r05 skipped)'),

@@ -30,11 +30,11 @@ same control decisions because they derive from all-reduced data and determinist
 `shard_items=False` keeps the round-1 layout (item side replicated, one all-reduce of Z per step).
 """
 import math
-import os
 
 import numpy as np
 import torch
 
+DEFAULT_METHOD = 'auto'    # what `svd_topk(method=None)` means; tests pin 'lanczos' / 'subspace' here (a module attribute, not the environment)
 MAX_KRYLOV_COLS = 4096     # widest operand of pk_gram_f64 (csrc/dense.hip): the Krylov basis of a block Lanczos build stays below it
 
 
@@ -62,8 +62,11 @@ class ItemRows:
     pass-through.  N ranks: rank r holds rows [r*rows, (r+1)*rows) of the (zero-padded to N*rows) item axis; the
     padding rows are zero in every block and stay zero through every kernel of the solver (linear, row-wise)."""
 
-    def __init__(self, ops, comm, n_items, shard_items=True, exchange_dtype=None):
+    def __init__(self, ops, comm, n_items, shard_items=True, exchange_dtype=None, overlap='auto'):
         self.ops, self.comm, self.n = ops, comm, int(n_items)
+        if overlap not in ('auto', 'never', 'force'):
+            raise ValueError("overlap must be 'auto', 'never' or 'force'")
+        self.overlap = overlap          # the two-panel exchange of `product`: by the cost model / never / whenever possible (tests)
         # payload of the two big exchanges of a Gramian step (all-gather of X, reduce-scatter / all-reduce of Z): None = the
         # blocks as they are (fp64); torch.float32 = rounded to fp32 on the wire (half the bytes, north_star's "fp32 Gramian
         # all-reduce").  An fp32 payload perturbs every product by ~6e-8 of its norm: good for builds to a tolerance of 1e-6
@@ -107,14 +110,14 @@ class ItemRows:
         launch, not half (the narrow instances pay off for A X, whose dense block sits on chip):
         +0.23 ms per step on ML-20M-shaped (tools/probes/overlap_one_rank.py).  So it is taken when the modelled exchange of
         the block — 2 (N-1)/N n_items nc 8 bytes at 100 GB/s — reaches 0.4 ms (S-1M on 8 ranks: 0.9 ms; ML-20M-shaped:
-        0.14-0.24 ms, not taken).  PK_DIST_OVERLAP: 0 = never, force = whenever there is something to exchange (tests)."""
+        0.14-0.24 ms, not taken).  `self.overlap`: 'never', or 'force' = whenever there is something to exchange (tests)."""
         ops, comm = self.ops, self.comm
         nc = Y.shape[1]
-        mode = os.environ.get('PK_DIST_OVERLAP', '1')
+        mode = self.overlap
         exchanging = comm.world > 1 or (mode == 'force' and getattr(comm, '_always', False))
         from .machine_model import value as mm
         worth = mode == 'force' or 2.0 * (comm.world - 1) / max(comm.world, 1) * self.n * nc * 8.0 / mm('xgmi_bus_Bps') >= 4e-4
-        split = (exchanging and worth and mode != '0' and nc >= 32 and nc % 16 == 0 and hasattr(comm, 'allreduce_start')
+        split = (exchanging and worth and mode != 'never' and nc >= 32 and nc % 16 == 0 and hasattr(comm, 'allreduce_start')
                  and not hasattr(At, 'matvec'))
         panels = ((0, nc // 2), (nc // 2, nc)) if split else ((0, nc),)
         moving = comm.world > 1 or getattr(comm, '_always', False)
@@ -250,13 +253,28 @@ def _cheb_degree(theta_top, b, spread, m_max):
     return max(2, min(m_max, m))
 
 
+class _Lazy:
+    """something built at first use"""
+
+    def __init__(self, make):
+        self.make = make
+
+
 class _Gramian:
     """B = A^T A of the (row-sharded) sparse matrix: the operator of the build.  `ritz` hands back H = X^T B X together
     with the carrier Y = A X, from which B (X C) = A^T (Y C) follows with ONE more product — Rayleigh-Ritz and the first
     filter step share a Gramian step."""
 
     def __init__(self, ops, A, At, lay, comm, stats):
-        self.ops, self.A, self.At, self.lay, self.comm, self.stats = ops, A, At, lay, comm, stats
+        self.ops, self.A, self._At, self.lay, self.comm, self.stats = ops, A, At, lay, comm, stats
+
+    @property
+    def At(self):
+        # the operator of Z = A^T Y, built when the first product needs it (a callable: `svd_topk` does not pay for the
+        # transposed image of a build whose recurrence runs inside the library, on the library's own image)
+        if isinstance(self._At, _Lazy):
+            self._At = self._At.make()
+        return self._At
 
     def _count(self, cols):
         self.stats['gramian_steps'] += 1
@@ -427,15 +445,16 @@ class _LanczosBreakdown(RuntimeError):
     `svd_topk` then runs the filtered subspace iteration, which has a rebuild path for exactly these matrices."""
 
 
-def _ritz_check(ops, Tj, S, X0, k, b, est_tol, prior, seed, inner, final=False):
+def _ritz_check(ops, Tj, S, X0, k, b, est_tol, prior, seed, inner, final=False, width=None):
     """The k leading Ritz pairs of T_j and estimates of their residuals (one per pair, relative to theta_1).
     The pairs come in stages: while the outer method is far from converged an ESTIMATE is all a check needs, so the nested
     iteration first runs to a loose tolerance and is tightened (warm) only while its own residual, not the coupling to the
     next block, is what limits the estimate.  Returns dict(est, coupling, conv, basis, lam_all, Yk, lam_k)."""
     N = Tj.shape[0]
-    if X0 is None:           # the first b unit vectors: orthonormal, and the seed of this very Krylov space
-        X0 = ops.zeros(b, b)
-        X0[:b] = torch.eye(b, dtype=X0.dtype, device=X0.device)
+    if X0 is None:           # the first unit vectors: orthonormal, and (the first b of them) the seed of this very Krylov space
+        w = min(N, max(b, width or b))
+        X0 = ops.zeros(w, w)
+        X0[:w] = torch.eye(w, dtype=X0.dtype, device=X0.device)
     t_in = max(0.3 * est_tol, 1e-4 if prior is None else 0.03 * prior)
     if final:                # the look at the step the pairs are predicted to have converged at: straight to the end
         t_in = 0.3 * est_tol
@@ -472,7 +491,7 @@ class _Monitor:
     The result is collected at a FIXED number of steps after the launch (blocking if need be), so every rank of a sharded
     build takes its decisions at the same steps from the same numbers."""
 
-    def __init__(self, ops, j, Tj, S, X0, k, b, est_tol, prior, seed, inner, flags=None):
+    def __init__(self, ops, j, Tj, S, X0, k, b, est_tol, prior, seed, inner, flags=None, width=None):
         import threading
         self.j = j
         self.out = self.err = None
@@ -496,12 +515,12 @@ class _Monitor:
                     with torch.cuda.stream(side):
                         if fsnap is not None:
                             _raise_on_breakdown(ops.to_host(fsnap), j)
-                        self.out = _ritz_check(ops, Tj, S, X0, k, b, est_tol, prior, seed, inner)
+                        self.out = _ritz_check(ops, Tj, S, X0, k, b, est_tol, prior, seed, inner, width=width)
                         side.synchronize()
                 else:
                     if fsnap is not None:
                         _raise_on_breakdown(ops.to_host(fsnap), j)
-                    self.out = _ritz_check(ops, Tj, S, X0, k, b, est_tol, prior, seed, inner)
+                    self.out = _ritz_check(ops, Tj, S, X0, k, b, est_tol, prior, seed, inner, width=width)
             except BaseException as exc:        # re-raised by join() in the thread that owns the build
                 self.err = exc
         self.thread = threading.Thread(target=work, name='pk-lanczos-monitor', daemon=True)
@@ -514,7 +533,8 @@ class _Monitor:
         return self.out
 
 
-def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_steps, m_max, spread, even_lock):
+def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_steps, m_max, spread, even_lock, kb=None,
+                   monitor_lag=None, t_step=None):
     """Block Lanczos on B = A^T A with FULL reorthogonalisation and Rayleigh-Ritz over the WHOLE Krylov space
     span[X, B X, ..., B^(q-1) X] — the Krylov-class method behind the reference's `svds` (ARPACK: single-vector implicitly
     restarted Lanczos on the same operator, models.py:844), in the block form a GPU wants.  One Gramian step per block:
@@ -531,9 +551,9 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
     On the ML-20M-shaped matrix, rank 50, block 64: 14 Gramian steps + 1 verification against 37 of the filtered
     subspace iteration (the Krylov space keeps every block: its Ritz values beyond the block width deflate the tail of
     the planted spectrum, which a fixed-width filter has to damp uniformly)."""
-    import os
+    import time
     n = lay.n
-    b = l
+    b = int(kb or l)            # width of a Krylov block; the nested solves keep the width l (k + guard vectors)
     # the Gram products against the whole basis (Q^T W, the re-projections, the nested T X) take at most
     # MAX_KRYLOV_COLS columns (pk_gram_f64's limit): a space that would outgrow them is a breakdown like any other —
     # the filtered subspace iteration takes over — not an error out of a kernel launcher (rank 100: b = 128, 32 blocks)
@@ -542,6 +562,16 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
         raise _LanczosBreakdown('Krylov space of at most %d blocks' % qcap)
     qcap = min(qcap, max_steps)
     gop = _Gramian(ops, A, At, lay, comm, stats)
+    # One process, a device matrix: the steps of the recurrence run inside the library (pk_lanczos_steps — the ONE statement of
+    # the step, csrc/driver.hip::lanczos_step, which the coarse build runs too): a step is ~40 dependent launches, and at the
+    # narrow blocks of round 6 the Python composition below spent more host time enqueueing them than the GPU spent running
+    # them.  The looks, their monitors and every decision stay here.  Sharded builds (collectives inside the step), host-side
+    # operators and the CPU double of the tests take the composition (`_next_lanczos_block`).
+    rec = None
+    if _library_recurrence(ops, A, comm, lay.sharded):
+        rec = ops.lanczos_recurrence(A, b)
+    stats['recurrence'] = 'library' if rec is not None else 'composition'
+    S_buf = ops.zeros(b, b) if rec is not None else None
     cap = min(qcap, 20)
     Qbuf = ops.empty(lay.rows, cap * b)
     T = ops.zeros(cap * b, cap * b)
@@ -552,9 +582,16 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
     inner = dict(steps=0, outer=0, checks=0)
     stats['nested'] = inner
     hist = []                              # (step, worst relative residual estimate of the k leading pairs)
-    LAG = int(os.environ.get('PK_LANCZOS_LAG', '3'))          # steps between the launch of a monitor and its collection
+    # steps between the launch of a monitor and its collection: a nested solve next to the products takes ~4.5 ms of wall
+    # time, so the lag is that many steps of the modelled step time (3 at the 1.7 ms steps of a 64-column block, up to 5 for the
+    # cheap steps of a narrow one: a longer lag only finds convergence later) — a number every rank derives from the same
+    # all-reduced entry count.  0: no monitors, every look on the calling thread (the form the C++ statement takes).
+    if monitor_lag is None:
+        monitor_lag = 3 if not t_step else int(min(5, max(3, math.ceil(4.5e-3 / t_step))))
+    LAG = int(monitor_lag)
+    stats['monitor_lag'] = LAG
     use_monitor = LAG > 0
-    first = max(4, -(-2 * k // b) + 2)
+    first = max(4, -(-2 * k // b) + 2, -(-l // b))
     next_look = min(first, qcap)           # the step of the next monitor, or of the final check once the rate is known
     look_is_final = not use_monitor
     est_tol = tol
@@ -592,20 +629,28 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
                 Qn_[:, :cap * b] = Qbuf
                 Tn_[:cap * b, :cap * b] = T
                 Qbuf, T, cap = Qn_, Tn_, cap2
-            Qj = Qbuf[:, N - b:N].contiguous()     # (a compact copy: the SpMM gathers rows of it — 512-byte rows 10 KB apart would spread the gathers over twenty times the pages)
-            W = gop.apply(Qj)
             Qall = Qbuf[:, :N]
-            C = lay.gram(Qall, W)                                      # block column j of T, rows of all blocks so far
-            T[:N, N - b:N] = C
-            T[N - b:N, :N - b] = C[:N - b].t()
             last = j == qcap
-            if not last:
-                S = _next_lanczos_block(lay, W, Qbuf, N, C, flags)
-            else:                              # the last block the space can hold: the coupling of W_perp directly
-                S = lay.gram(ops.tsmm_sub(W, Qall, C))
+            if rec is not None:
+                rec.steps(Qbuf, T, S_buf, flags, j - 1, 1, last)
+                stats['gramian_steps'] += 1
+                stats['spmm_cols'] += b
+                S = S_buf
+            else:
+                Qj = Qbuf[:, N - b:N].contiguous()     # (a compact copy: the SpMM gathers rows of it — 512-byte rows 10 KB apart would spread the gathers over twenty times the pages)
+                W = gop.apply(Qj)
+                C = lay.gram(Qall, W)                                      # block column j of T, rows of all blocks so far
+                T[:N, N - b:N] = C
+                T[N - b:N, :N - b] = C[:N - b].t()
+                if not last:
+                    S = _next_lanczos_block(lay, W, Qbuf, N, C, flags)
+                else:                              # the last block the space can hold: the coupling of W_perp directly
+                    S = lay.gram(ops.tsmm_sub(W, Qall, C))
             # ---- a monitor that is due: collect it and plan the next look --------------------------------------
             if monitor is not None and (j >= monitor.j + LAG or last or j + 1 >= next_look):
+                t_w = time.perf_counter()
                 out = monitor.join()
+                stats.setdefault('monitor_wait_ms', []).append(round(1e3 * (time.perf_counter() - t_w), 3))
                 jm, monitor = monitor.j, None
                 warm = out['basis']
                 hist.append((jm, out['worst']))
@@ -624,14 +669,16 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
             inner['checks'] += 1
             if not (look_is_final or last):
                 # ---- launch a monitor on the side stream and keep stepping (it reads the breakdown flags too) ---
-                monitor = _Monitor(ops, j, snapshot(N), S, warm, k, b, est_tol, hist[-1][1] if hist else None,
-                                   seed + 1000 * j, inner, flags=flags)
+                monitor = _Monitor(ops, j, snapshot(N), S.clone() if rec is not None else S, warm, k, b, est_tol, hist[-1][1] if hist else None,
+                                   seed + 1000 * j, inner, flags=flags, width=l)
                 next_look = qcap + 1           # decided when the monitor comes back
                 continue
             # ---- the pairs of T_j on the main stream, and their verification ------------------------------------
+            t_w = time.perf_counter()
             breakdown_check(j)
             out = _ritz_check(ops, snapshot(N), S, warm, k, b, est_tol, hist[-1][1] if hist else None, seed + 1000 * j, inner,
-                              final=len(hist) >= 2)
+                              final=len(hist) >= 2, width=l)
+            stats.setdefault('look_ms', []).append(round(1e3 * (time.perf_counter() - t_w), 3))    # includes draining the steps queued before it
             warm = out['basis']
             hist.append((j, out['worst']))
             if verbose and comm.rank == 0:
@@ -639,7 +686,12 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
                       % (j, N, k, out['worst'], inner['outer'], inner['steps'], out['conv']))
             if out['worst'] <= est_tol and out['conv']:
                 Vk = ops.tsmm(Qall, out['Yk'])
-                Z = gop.apply(Vk)                  # one true product on the k Ritz vectors
+                if rec is not None:                # one true product on the k Ritz vectors
+                    Z = rec.gramian(Vk)
+                    stats['gramian_steps'] += 1
+                    stats['spmm_cols'] += k
+                else:
+                    Z = gop.apply(Vk)
                 lam1 = max(float(out['lam_all'][0]), 1e-300)
                 res2 = lay.total(ops.resid_colnorm2(Z, Vk, out['lam_k']))
                 res_true = np.sqrt(np.maximum(ops.to_host(res2), 0.0)) / lam1
@@ -658,6 +710,8 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
                 monitor.join()
             except BaseException:
                 pass
+        if rec is not None:
+            rec.collect_timings()
     stats['lanczos_steps'] = j
     stats['outer'] = len(hist)
     stats['krylov_dim'] = j * b
@@ -667,78 +721,168 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
     return result
 
 
+KRYLOV_WIDTHS = (16, 32, 64, 128, 256)      # the widths the SpMM has instances for (csrc/spmm.hip: 4 / 8 / 16 / 32 / 64 lanes per gathered row)
+
+
+def _lanczos_model(nnz, n_items, l, b, world=1):
+    """(steps, seconds per step) of a block Lanczos build with Krylov blocks of b columns, nested width l — the cost model
+    behind `choose_krylov_block` / `choose_method` (same constants in csrc/driver.hip::lanczos_model).  Measured on one
+    MI355X (profiles/r06_krylov_block_*.txt):
+      steps: 14 at b = l, growing like (l / b)^0.36 as the block narrows (ML-20M-shaped rank 50: 14 / 15 / 17 / 19 / 23 at
+             64 / 48 / 32 / 24 / 16; rank 100: 15 / 19 / 25 / 36 at 128 / 64 / 32 / 16; S-1M: 15 / 19 / 24 at 64 / 32 / 16);
+      both products of a step: nnz (8 + b) ps  (ML-20M-shaped: 1.22 / 0.78 / 0.50 ms at 64 / 32 / 16; S-1M: 9.0 / 4.6 / 2.5 ms) —
+             the row pieces of a narrow block stay on chip, and every gather instruction carries 16 columns whatever b is;
+      everything else of a step (the projections against the Krylov basis, CholeskyQR3, the share of the looks): 0.75 ms
+             plus the basis traffic of the re-orthogonalisation (14 passes over n_items x N x b flop at the fp64 rate)."""
+    from .machine_model import value as mm
+    steps = 14.0 * (float(l) / b) ** 0.36
+    t_spmm = nnz * (8.0 + max(b, 16)) * 1e-12 / world
+    if world > 1:
+        t_spmm += 2.0 * (world - 1) / world * n_items * b * 8.0 / mm('xgmi_bus_Bps') + 6 * (world - 1) * mm('collective_step_s')
+    n_avg = 0.5 * steps * b
+    t_reorth = 14.0 * n_items * n_avg * b / mm('dense_f64_flops') / world
+    return steps, t_spmm + mm('lanczos_step_fixed_s') + t_reorth
+
+
+def choose_krylov_block(nnz, n_items, l, world=1):
+    """Width of a Krylov block: the widest block is NOT the cheapest build.  A block of b < l columns needs (l / b)^0.36 times
+    the steps, but a step's sparse products shrink almost in proportion to b — the Krylov space reaches a given dimension
+    with fewer gathered columns in total — so the width is chosen where steps x (products + the fixed cost of a step) is
+    least (round 6; rounds 4-5 tied the block to the nested width l: ML-20M-shaped rank 50 33.3 -> 27.8 ms at b = 32, S-1M
+    169 -> 80 ms at b = 16, rank 100 89.7 -> 60 ms)."""
+    best, best_t = None, None
+    for b in KRYLOV_WIDTHS:
+        if b > l and best is not None:
+            break
+        b = min(b, l)
+        steps, t_step = _lanczos_model(nnz, n_items, l, b, world)
+        if best_t is None or steps * t_step < best_t:
+            best, best_t = b, steps * t_step
+    return int(best)
+
+
 def choose_method(nnz, n_items, l, world=1):
-    """'lanczos' or 'subspace' from a cost model of one Gramian step (the same rule in csrc/driver.hip::svd_build_impl).
-    Block Lanczos needs ~2.5x fewer Gramian steps and pays for them per step with the re-orthogonalisation against the
-    whole Krylov basis (three Gram products and three projections over ~8 blocks on average: ~96 n_items l^2 flop on the
-    fp64 matrix cores at ~20 TFLOP/s) and with its projected eigenproblems (a few ms per build, growing with l^2):
-      ML-20M-shaped rank 50 (l = 64): step 1.4 ms, re-orthogonalisation 0.5 ms      47.7 -> 32.3 ms
-      ML-20M-shaped rank 100 (l = 128): 2.7 / 2.1 ms                                112 -> 85 ms
-      S-1M rank 50: 6.8 / 2.0 ms                                                   289 -> 172 ms
-      ML-1M-shaped rank 10 (l = 24): a step is 0.05 ms, the eigenproblems are not: 4.6 -> 9.1 ms          => subspace
-      S-50M shard, rank 200 (l = 256, 500 K items): 14.5 ms against 157 ms of re-orthogonalisation: 1.4 -> 2.2 s => subspace
+    """'lanczos' or 'subspace' from the cost model of a build (the same rule in csrc/driver.hip::svd_build_impl).
+    Block Lanczos (with its best block width, `choose_krylov_block`) against the filtered subspace iteration, which needs
+    ~2.6x the Gramian steps of the widest Krylov block, every one of them l columns wide, plus ~8 outer iterations of
+    Rayleigh-Ritz and CholeskyQR on the block (0.5 ms each):
+      ML-20M-shaped rank 50 (l = 64):      subspace 47.7 ms, lanczos 27.8 ms (b = 32)
+      ML-20M-shaped rank 100 (l = 128):    112 / 60 ms
+      S-1M rank 50:                        289 / 80 ms (b = 16)
+      ML-1M-shaped rank 10 (l = 24): a step is 0.05 ms, the looks and the fixed cost of 11 steps are not: 4.6 / 8.2 ms => subspace
     Sharded over `world` ranks the products shrink by the number of ranks and the exchange of the block joins every step of
-    either method; the re-orthogonalisation launches and the (replicated) eigenproblems do not shrink: ML-20M-shaped on 8
-    ranks is back on the subspace iteration (both ~33 ms in the scaling proxy: 17 K users per rank is a latency problem)."""
-    from .machine_model import value as mm          # one table, with the provenance of every number (measured / assumed)
-    t_step = nnz * l * 16.0 / mm('spmm_gather_Bps') / world    # both products of a step: gathers of l fp64 columns per entry
-    if world > 1:    # every step of either method also pays its exchange (all-gather + reduce-scatter of an [n_items x l] block)
-        t_step += 2.0 * (world - 1) / world * n_items * l * 8.0 / mm('xgmi_bus_Bps') + 2 * (world - 1) * mm('collective_step_s')
-    t_reorth = 96.0 * n_items * float(l) * l / mm('dense_f64_flops')
-    t_nested = mm('nested_solve_s') * max(1.0, (l / 64.0) ** 2)
-    if nnz * l < 2e8 or t_reorth + t_nested >= 2.0 * t_step:
-        return 'subspace'
-    return 'lanczos'
+    either method."""
+    from .machine_model import value as mm
+    if not math.isfinite(nnz):
+        return 'lanczos'
+    b = choose_krylov_block(nnz, n_items, l, world)
+    steps, t_step = _lanczos_model(nnz, n_items, l, b, world)
+    t_lanczos = steps * t_step + 4.0 * mm('nested_solve_s') * max(1.0, (l / 64.0) ** 2)
+    _, t_wide = _lanczos_model(nnz, n_items, l, l, world)
+    t_wide -= mm('lanczos_step_fixed_s')
+    t_subspace = 2.6 * 14.0 * t_wide + 8 * 0.5e-3 * max(1.0, (l / 64.0) ** 2)
+    return 'subspace' if t_subspace <= t_lanczos else 'lanczos'
 
 
-def svd_topk(ops, A, k, block=None, tol=1e-12, max_outer=200, m_max=24, spread=1e7, seed=0,
-             comm=None, want_u=False, verbose=False, even_lock=True, shard_items=True, method=None, max_steps=64,
-             exchange='auto'):
-    """Returns (U_local | None, sigma[k] desc, V [n_items x k], stats) as device tensors of `ops`.
-
-    A: ops-level CSR of the LOCAL row shard (n_local x n_items).  Convergence: every one of the k
-    leading Ritz pairs has ||B x - theta x|| <= tol * theta_1  (B = A^T A, theta = sigma^2), measured on a true product.
-    method: 'lanczos' (default; PK_SVD_METHOD overrides) = block Lanczos with full reorthogonalisation and Rayleigh-Ritz
-    over the whole Krylov space (`_block_lanczos`), falling back to 'subspace' = Chebyshev-filtered subspace iteration
-    with locking (`_subspace_iteration`) when the recurrence breaks down (rank-deficient matrices, tiny item counts).
-    """
-    import os
+def plan_build(ops, A, k, block=None, method=None, krylov_block=None, max_steps=None, comm=None):
+    """The decisions of a build before its first product: nested width, method, width of a Krylov block, the modelled step
+    time (for the monitors' lag), the step limit.  Every rank decides alike: the entry count is summed over the ranks;
+    operators that do not say how many entries they hold (host-side LinearOperators: their products are the expensive
+    kind) count as large and keep the full block width."""
     comm = comm or NoComm()
     n_items = A.shape[1]
     if not (0 < k <= n_items):
         raise ValueError('k must satisfy 0 < k <= n_items')
     l = int(block or default_block(k, n_items))
     l = max(k, min(l, n_items))
-    method = method or os.environ.get('PK_SVD_METHOD', 'auto')
+    method = method or DEFAULT_METHOD
     if method not in ('lanczos', 'subspace', 'auto'):
         raise ValueError("method must be 'lanczos', 'subspace' or 'auto'")
-    if method == 'auto':
-        # every rank decides alike: the entry count is summed over the ranks; operators that do not say how many entries
-        # they hold (host-side LinearOperators: their products are the expensive kind) count as large
-        nnz = getattr(A, 'nnz', None)
-        total = float('inf')
-        if nnz is not None:
+    nnz = getattr(A, 'nnz', None)
+    total = float('inf')
+    if nnz is not None:
+        if comm.world > 1:
             t = ops.to_device(np.array([float(nnz)]))
             total = float(ops.to_host(comm.allreduce(t))[0])
+        else:
+            total = float(nnz)
+    if method == 'auto':
         method = choose_method(total, n_items, l, comm.world)
+    kb, t_step = l, None
+    if method == 'lanczos':
+        if krylov_block is not None:
+            kb = max(1, min(int(krylov_block), l))
+        elif math.isfinite(total):
+            kb = choose_krylov_block(total, n_items, l, comm.world)
+        if math.isfinite(total):
+            t_step = _lanczos_model(total, n_items, l, kb, comm.world)[1]
+        if max_steps is None:
+            max_steps = min(MAX_KRYLOV_COLS // kb, int(64 * math.sqrt(l / float(kb))))
+    elif max_steps is None:
+        max_steps = 64
+    return dict(block=l, method=method, krylov_block=kb, t_step=t_step, max_steps=max_steps, nnz_total=total)
+
+
+def _library_recurrence(ops, A, comm, sharded):
+    """True when the steps of a Lanczos build of A run inside the library (ops.lanczos_recurrence): one process, a device
+    matrix.  Sharded builds (collectives inside the step), host-side operators and the CPU double take the composition."""
+    return (not sharded and comm.world == 1 and not getattr(comm, '_always', False) and hasattr(ops, 'lanczos_recurrence')
+            and hasattr(A, 'indptr') and not hasattr(A, 'matvec'))
+
+
+def prepare_operator(ops, A, k, comm=None, **kw):
+    """Builds, ahead of `svd_topk`, the image of A its products will run on — the library's handle with its user-blocked
+    transpose (one process) or the layer's own transposed operator — so that a caller can account for it separately
+    (bench.py's `transpose_and_plans_s`); `svd_topk` finds it cached on the matrix.  Returns the plan of the build."""
+    comm = comm or NoComm()
+    plan = plan_build(ops, A, k, comm=comm, **kw)
+    if plan['method'] == 'lanczos' and _library_recurrence(ops, A, comm, comm.world > 1):
+        ops.lanczos_recurrence(A, plan['krylov_block'])
+    elif hasattr(A, 'transpose_operator'):
+        A.transpose_operator()
+    return plan
+
+
+def svd_topk(ops, A, k, block=None, tol=1e-12, max_outer=200, m_max=24, spread=1e7, seed=0,
+             comm=None, want_u=False, verbose=False, even_lock=True, shard_items=True, method=None, max_steps=None,
+             exchange='auto', krylov_block=None, monitor_lag=None, exchange_overlap='auto'):
+    """Returns (U_local | None, sigma[k] desc, V [n_items x k], stats) as device tensors of `ops`.
+
+    A: ops-level CSR of the LOCAL row shard (n_local x n_items).  Convergence: every one of the k
+    leading Ritz pairs has ||B x - theta x|| <= tol * theta_1  (B = A^T A, theta = sigma^2), measured on a true product.
+    method: 'lanczos' = block Lanczos with full reorthogonalisation and Rayleigh-Ritz over the whole Krylov space
+    (`_block_lanczos`), falling back to 'subspace' = Chebyshev-filtered subspace iteration with locking
+    (`_subspace_iteration`) when the recurrence breaks down (rank-deficient matrices, tiny item counts); None / 'auto' =
+    `choose_method` (a cost model), unless `solver.DEFAULT_METHOD` names one (tests).
+    krylov_block: width of a Krylov block of the Lanczos build (None: `choose_krylov_block`; the nested solves and the
+    subspace iteration keep the width `block`).  monitor_lag: steps between the launch of a monitor and its collection
+    (None: from the modelled step time; 0: every look on the calling thread).  max_steps: blocks of the Krylov space at
+    most (None: 64 at the full width, more for narrow blocks, never beyond the 4096 columns of the Gram kernels).
+    """
+    comm = comm or NoComm()
+    n_items = A.shape[1]
+    plan = plan_build(ops, A, k, block=block, method=method, krylov_block=krylov_block, max_steps=max_steps, comm=comm)
+    l, method, kb, t_step, max_steps = plan['block'], plan['method'], plan['krylov_block'], plan['t_step'], plan['max_steps']
     stats_method = method
-    # the operator of Z = A^T Y: a device matrix offers its user-blocked transpose (ops.BlockedTranspose)
-    At = A.transpose_operator() if hasattr(A, 'transpose_operator') else A.T
+    # the operator of Z = A^T Y: a device matrix offers its user-blocked transpose (ops.BlockedTranspose) — built at the first
+    # product that needs it (`_Gramian.At`)
+    At = _Lazy((lambda: A.transpose_operator()) if hasattr(A, 'transpose_operator') else (lambda: A.T))
 
     # payload of the block exchanges on more than one rank: 'f64', 'f32', or 'auto' = fp32 where the tolerance leaves room
     # for its 6e-8 (tol >= 1e-6), fp64 otherwise (the default 1e-12 build)
     if exchange not in ('auto', 'f64', 'f32'):
         raise ValueError("exchange must be 'auto', 'f64' or 'f32'")
     xdt = torch.float32 if (exchange == 'f32' or (exchange == 'auto' and tol >= 1e-6)) else None
-    lay = ItemRows(ops, comm, n_items, shard_items, exchange_dtype=xdt)
-    stats = dict(exchange='f32' if xdt is not None else 'f64', outer=0, gramian_steps=0, spmm_cols=0, degrees=[], locked_at=[], block=l, converged=False,
+    lay = ItemRows(ops, comm, n_items, shard_items, exchange_dtype=xdt, overlap=exchange_overlap)
+    stats = dict(krylov_block=kb if method == 'lanczos' else None, exchange='f32' if xdt is not None else 'f64', outer=0, gramian_steps=0, spmm_cols=0, degrees=[], locked_at=[], block=l, converged=False,
                  item_rows_per_rank=lay.rows, items_sharded=lay.sharded, method=stats_method)
     Vk = lam_k = res_k = None
     if method == 'lanczos':
         try:
             # `max_outer` bounds the work of either method: an outer iteration of the subspace method is worth a few blocks
             Vk, lam_k, res_k = _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose,
-                                              min(max_steps, 4 * max_outer), m_max, spread, even_lock)
+                                              min(max_steps, 4 * max_outer), m_max, spread, even_lock, kb=kb,
+                                              monitor_lag=monitor_lag, t_step=t_step)
             stats['converged'] = True
         except _LanczosBreakdown as exc:
             stats['lanczos_fallback'] = str(exc)

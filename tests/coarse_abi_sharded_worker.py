@@ -35,6 +35,7 @@ class Comm(C.Structure):
 lib.pk_ctx_create.argtypes, lib.pk_ctx_create.restype = [i32, C.POINTER(vp)], C.c_int
 lib.pk_ctx_destroy.argtypes, lib.pk_ctx_destroy.restype = [vp], None
 lib.pk_ctx_error.argtypes, lib.pk_ctx_error.restype = [vp], C.c_char_p
+lib.pk_ctx_set_option.argtypes, lib.pk_ctx_set_option.restype = [vp, C.c_char_p, i32], C.c_int
 lib.pk_ctx_stream.argtypes, lib.pk_ctx_stream.restype = [vp], vp
 lib.pk_mat_from_csr.argtypes, lib.pk_mat_from_csr.restype = [vp, i64, i64, i64, vp, vp, vp, i32, C.POINTER(vp)], C.c_int
 lib.pk_mat_free.argtypes, lib.pk_mat_free.restype = [vp, vp], None
@@ -103,7 +104,7 @@ def main():
         check(ctx, lib.pk_mat_from_csr(ctx, M.shape[0], M.shape[1], M.nnz, ptr(ip), ptr(ix), ptr(vv), 1, C.byref(h)), 'pk_mat_from_csr')
         return h
     Ml = upload(Al)
-    os.environ['PK_DIST_OVERLAP'] = '0'
+    check(ctx, lib.pk_ctx_set_option(ctx, b'dist_overlap', 0), 'pk_ctx_set_option')      # 0 = never split a product
     sigma, V = np.empty(k), np.empty((n_items, k), order='F')
     U = np.empty((hi - lo, k), order='F')
     st = Stats()
@@ -112,12 +113,12 @@ def main():
     # one all-reduce of Z per Gramian step + one of the Rayleigh-Ritz matrix per outer iteration (+ ONE scalar at the start:
     # the entry count of the whole matrix, from which every rank picks the same method): nothing else leaves the rank
     assert st.converged == 1 and calls['n'] == st.gramian_steps + st.outer + 1, (calls, st.gramian_steps, st.outer)
-    # The same build with every Gramian product cut into TWO column panels (PK_DIST_OVERLAP=force; on its own the library
+    # The same build with every Gramian product cut into TWO column panels (context option dist_overlap = 2; on its own the library
     # splits when the modelled exchange reaches 0.4 ms): the first panel's sum is handed to the callback on a SIDE stream
     # while the second panel's products are enqueued — twice the all-reduce calls for the steps, the same bytes, the same
     # factors.
     n0, b0 = calls['n'], calls['bytes']
-    os.environ['PK_DIST_OVERLAP'] = 'force'
+    check(ctx, lib.pk_ctx_set_option(ctx, b'dist_overlap', 2), 'pk_ctx_set_option')      # 2 = whenever possible
     sigma2, V2 = np.empty(k), np.empty((n_items, k), order='F')
     st2 = Stats()
     streams = set()
@@ -133,7 +134,7 @@ def main():
     comm2 = Comm(rank, world, cb2, None)
     check(ctx, lib.pk_svd_build_sharded(ctx, Ml, C.byref(comm2), k, 0, 0.0, 0, 7, ptr(sigma2), ptr(V2), None, C.byref(st2)),
           'pk_svd_build_sharded (two panels)')
-    os.environ['PK_DIST_OVERLAP'] = '0'
+    check(ctx, lib.pk_ctx_set_option(ctx, b'dist_overlap', 0), 'pk_ctx_set_option')
     assert st2.converged == 1 and st2.gramian_steps == st.gramian_steps and st2.outer == st.outer
     # every product of a full-width block went in two panels (blocks narrowed by locking, and the rotations of the
     # Rayleigh-Ritz steps, go whole): one more call per split product, the first panel's on the side stream

@@ -24,6 +24,7 @@ class Stats(C.Structure):
 lib.pk_ctx_create.argtypes, lib.pk_ctx_create.restype = [i32, C.POINTER(vp)], C.c_int
 lib.pk_ctx_destroy.argtypes, lib.pk_ctx_destroy.restype = [vp], None
 lib.pk_ctx_error.argtypes, lib.pk_ctx_error.restype = [vp], C.c_char_p
+lib.pk_ctx_set_option.argtypes, lib.pk_ctx_set_option.restype = [vp, C.c_char_p, i32], C.c_int
 lib.pk_mat_from_csr.argtypes, lib.pk_mat_from_csr.restype = [vp, i64, i64, i64, vp, vp, vp, i32, C.POINTER(vp)], C.c_int
 lib.pk_mat_from_coo.argtypes, lib.pk_mat_from_coo.restype = [vp, i64, i64, i64, vp, vp, i64, vp, i32, C.POINTER(vp)], C.c_int
 lib.pk_mat_free.argtypes, lib.pk_mat_free.restype = [vp, vp], None
@@ -84,13 +85,14 @@ def main():
     assert np.abs(S @ V - U * sigma).max() < 1e-8 * sigma[0]
     # the same build by block Lanczos (what pk_svd_build picks by itself once a Gramian step is heavy; forced here): the
     # factors of the filtered subspace iteration to the solver tolerance, in fewer Gramian steps, residual VERIFIED
-    os.environ['PK_SVD_METHOD'] = 'lanczos'
+    check(ctx, lib.pk_ctx_set_option(ctx, b'svd_method', 1), 'pk_ctx_set_option')      # 1 = block Lanczos
     sigma_l = np.empty(rank); V_l = np.empty((n_items, rank), order='F'); st_l = Stats()
     check(ctx, lib.pk_svd_build(ctx, A, rank, 0, 0.0, 0, 0, ptr(sigma_l), ptr(V_l), None, C.byref(st_l)), 'pk_svd_build(lanczos)')
-    os.environ['PK_SVD_METHOD'] = 'subspace'
+    check(ctx, lib.pk_ctx_set_option(ctx, b'svd_method', 2), 'pk_ctx_set_option')      # 2 = filtered subspace iteration
     st_s = Stats()
     check(ctx, lib.pk_svd_build(ctx, A, rank, 0, 0.0, 0, 0, ptr(sigma), ptr(V), ptr(U), C.byref(st_s)), 'pk_svd_build(subspace)')
-    del os.environ['PK_SVD_METHOD']
+    check(ctx, lib.pk_ctx_set_option(ctx, b'svd_method', 0), 'pk_ctx_set_option')
+    assert lib.pk_ctx_set_option(ctx, b'svd_method', 7) != 0 and lib.pk_ctx_set_option(ctx, b'no_such_option', 0) != 0
     assert st_l.converged == 1 and st_l.final_rel_residual <= 1e-12 and st_l.gramian_steps < st_s.gramian_steps, (
         st_l.gramian_steps, st_s.gramian_steps, st_l.final_rel_residual)
     assert np.allclose(sigma_l, s_ref, rtol=1e-10) and np.abs(V_l @ V_l.T - V @ V.T).max() < 1e-8
@@ -173,11 +175,11 @@ def main():
         assert np.allclose(core, np.einsum('uif,ua,ib,fc->abc', dense, u0, u1, u2, optimize=True), atol=1e-9 * np.abs(core).max())
         # the default route factors the mode products (SpMM over two unfoldings + fp64-MFMA contractions); the per-entry
         # kernel (pk_ttm_f64 = dttm_seq restated) must give the same iteration
-        os.environ['PK_HOOI_TTM'] = '1'
+        check(ctx, lib.pk_ctx_set_option(ctx, b'hooi_ttm', 1), 'pk_ctx_set_option')
         v0 = np.empty_like(u0); v1 = np.empty_like(u1); v2 = np.empty_like(u2); core2 = np.empty_like(core); trace2 = np.zeros(n_it); it2 = i32(0)
         check(ctx, lib.pk_hooi(ctx, len(val), ptr(idx), ptr(val), ptr(shape), ptr(mlrank), n_it, float(g['growth_tol']), ptr(u1s), ptr(u2s),
                                0, ptr(v0), ptr(v1), ptr(v2), ptr(core2), ptr(trace2), C.byref(it2)), 'pk_hooi (per-entry products)')
-        del os.environ['PK_HOOI_TTM']
+        check(ctx, lib.pk_ctx_set_option(ctx, b'hooi_ttm', 0), 'pk_ctx_set_option')
         assert it2.value == iters.value and np.allclose(trace2[:it2.value], trace[:iters.value], rtol=1e-10)
         for a, b in ((u0, v0), (u1, v1), (u2, v2)):
             assert np.abs(a @ a.T - b @ b.T).max() < 1e-8

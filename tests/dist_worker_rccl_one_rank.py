@@ -52,14 +52,12 @@ def main():
     h1 = comm.reduce_scatter_rows_start(X.clone(), X.shape[0])
     h2 = comm.reduce_scatter_rows_start(X[:, :32].contiguous(), X.shape[0], count=False)
     ok['reduce_scatter_rows_start'] = bool(torch.equal(h1.wait(), X) and torch.equal(h2.wait(), X[:, :32]))
-    os.environ['PK_DIST_OVERLAP'] = 'force'
     p0 = comm.n_panel_exchanges
     for shard_items in (True, False):
-        _, s2, V2, st2 = svd_topk(ops, A, 18, seed=3, comm=comm, shard_items=shard_items)      # block 32: two panels of 16
+        _, s2, V2, st2 = svd_topk(ops, A, 18, seed=3, comm=comm, shard_items=shard_items, exchange_overlap='force')      # block 32: two panels of 16
         _, s3, V3, st3 = svd_topk(ops, A, 18, seed=3)
         ok['solver_two_panel_exchange_%s' % ('sharded' if shard_items else 'replicated')] = bool(
             torch.allclose(s2, s3, rtol=1e-12) and float((V2 @ V2.T - V3 @ V3.T).abs().max()) < 1e-10 and st2['gramian_steps'] == st3['gramian_steps'])
-    os.environ.pop('PK_DIST_OVERLAP')
     ok['panel_exchanges_started'] = comm.n_panel_exchanges - p0 > 0
     print('RCCL_ONE_RANK_RESULT', ok, 'allgathers', comm.n_allgather, 'reduce_scatters', comm.n_reduce_scatter, 'allreduces', comm.n_allreduce)
     assert all(ok.values()), ok

@@ -15,8 +15,12 @@ import scipy.sparse as sp
 from numpy_ops import NumpyOps
 from polara_amd.csr import nnz_balanced_row_partition
 from polara_amd.dist import init_from_env
+import polara_amd.solver as solver_module
 from polara_amd.solver import svd_topk
 from polara_amd.synth import planted_csr
+
+# which method `svd_topk(method=None)` runs in this worker: the test's own variable, set on the module (the product reads no environment)
+solver_module.DEFAULT_METHOD = os.environ.get('PK_TEST_SVD_METHOD', 'auto')
 
 
 def matrices():
@@ -69,12 +73,10 @@ def main():
     part = ops.csr(P.indptr.astype(np.int64), P.indices.astype(np.int32), P.data.astype(np.float64), P.shape)
     for shard_items in (True, False):
         res = {}
-        for overlap in ('force', '0'):
-            os.environ['PK_DIST_OVERLAP'] = overlap
+        for overlap, mode in (('force', 'force'), ('0', 'never')):
             p0 = comm.n_panel_exchanges
-            _, s, V, st = svd_topk(ops, part, k, comm=comm, shard_items=shard_items)
+            _, s, V, st = svd_topk(ops, part, k, comm=comm, shard_items=shard_items, exchange_overlap=mode)
             res[overlap] = (s.numpy(), V.numpy(), comm.n_panel_exchanges - p0, st['gramian_steps'])
-        os.environ.pop('PK_DIST_OVERLAP')
         out['panels_%s' % ('sharded' if shard_items else 'replicated')] = bool(
             np.allclose(res['force'][0], res['0'][0], rtol=1e-12) and np.abs(res['force'][1] @ res['force'][1].T - res['0'][1] @ res['0'][1].T).max() < 1e-10
             and 0 < res['force'][2] <= 2 * res['force'][3] and res['force'][2] % 2 == 0 and res['0'][2] == 0 and res['force'][3] == res['0'][3])

@@ -24,7 +24,7 @@ def test_row_sharded_item_side_of_the_solver(world, method):
     matrix, at item counts that are not multiples of the world size, and through the rank-deficient refill path —
     for the filtered subspace iteration and for the block Lanczos method (whose Krylov basis is row-sharded the same
     way; the rank-deficient and the 61-item cases exercise its hand-over to the subspace iteration)."""
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='2', PK_SVD_METHOD=method)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='2', PK_TEST_SVD_METHOD=method)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world),
            '--master-addr', '127.0.0.1', '--master-port', str(free_port()),
            os.path.join(ROOT, 'tests', 'dist_worker_solver.py')]

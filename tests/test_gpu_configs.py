@@ -137,7 +137,7 @@ def test_ml20m_shaped_coarse_abi_agrees_with_the_python_layer(hip_ops, ml20m):
     n_users, n_items = c['shape']
     rank, topk = 50, 10
     _, sigma, V, st = svd_topk(ops, A, rank)
-    assert st['method'] == 'lanczos' and st['gramian_steps'] <= 18
+    assert st['method'] == 'lanczos' and st['recurrence'] == 'library' and st['gramian_steps'] <= 28       # narrow Krylov blocks (round 6): more, cheaper steps
     lib = _lib.load()
     vp = C.c_void_p
 
@@ -153,7 +153,7 @@ def test_ml20m_shaped_coarse_abi_agrees_with_the_python_layer(hip_ops, ml20m):
     s_c, V_c, stc = np.empty(rank), np.empty((n_items, rank), order='F'), Stats()
     rc = lib.pk_svd_build(ctx, M, rank, 0, 0.0, 0, 0, ptr(s_c), ptr(V_c), None, C.byref(stc))
     assert rc == 0, lib.pk_ctx_error(ctx)
-    assert stc.converged == 1 and stc.final_rel_residual <= 1e-12 and stc.gramian_steps <= 18
+    assert stc.converged == 1 and stc.final_rel_residual <= 1e-12 and stc.gramian_steps <= 28
     sig = ops.to_host(sigma)
     assert np.abs(s_c / sig - 1).max() < 1e-11
     V_ext = np.ascontiguousarray(ops.to_host(V)[rank_of])           # external item j = internal row rank_of[j]

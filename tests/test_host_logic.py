@@ -381,7 +381,7 @@ def test_block_lanczos_matches_the_subspace_iteration_and_arpack(monkeypatch):
     """solver._block_lanczos (Rayleigh-Ritz over the whole Krylov space, nested solve of the projected problem, monitors
     on a worker thread) against the filtered subspace iteration and against the reference's own call (scipy svds = ARPACK,
     tol 0): singular values to 1e-10, projectors to 1e-8, fewer Gramian steps, a VERIFIED residual below the tolerance;
-    the same factors with the monitors switched off (PK_LANCZOS_LAG=0: every look on the calling thread)."""
+    the same factors with the monitors switched off (monitor_lag=0: every look on the calling thread)."""
     from scipy.sparse.linalg import svds
     from polara_amd.synth import planted_csr
     m = planted_csr(5000, 2000, 50, 16, levels=5, seed=7, min_items=6, max_items=300)
@@ -401,13 +401,49 @@ def test_block_lanczos_matches_the_subspace_iteration_and_arpack(monkeypatch):
     np.random.seed(0)
     _, s_ref, vt = svds(A.m, k=k, tol=0)
     assert np.allclose(np.sort(s_ref)[::-1], sl, rtol=1e-10) and np.abs(vt.T @ vt - Vl @ Vl.T).max() < 1e-8
-    monkeypatch.setenv('PK_LANCZOS_LAG', '0')
-    _, s0, V0, st0 = svd_topk(ops, A, k, method='lanczos')
+    _, s0, V0, st0 = svd_topk(ops, A, k, method='lanczos', monitor_lag=0)
     assert np.allclose(s0.numpy(), sl, rtol=1e-12) and np.abs(V0.numpy() @ V0.numpy().T - Vl @ Vl.T).max() < 1e-9
-    monkeypatch.delenv('PK_LANCZOS_LAG')
     # 'auto' keeps small matrices on the subspace iteration (the projected eigenproblems cost more than they save there)
     _, _, _, sta = svd_topk(ops, A, k)
     assert sta['method'] == 'subspace'
+
+
+def test_narrow_krylov_blocks_give_the_same_factors():
+    """Round 6: the width of a Krylov block is decoupled from the nested width l = k + guard vectors.  A narrower block takes
+    more steps (about (l / b)^0.36 times) and gathers fewer columns in total; the factors are those of the full-width build,
+    the verified residual stays below the tolerance, blocks narrower than k included (the Ritz vectors come from the whole
+    Krylov space)."""
+    from polara_amd.synth import planted_csr
+    m = planted_csr(5000, 2000, 50, 16, levels=5, seed=7, min_items=6, max_items=300)
+    ops = NumpyOps()
+    A = ops.csr(m['indptr'].numpy(), m['indices'].numpy(), m['values'].numpy().astype(np.float64), m['shape'])
+    k = 16
+    _, s0, V0, st0 = svd_topk(ops, A, k, method='lanczos', krylov_block=32, monitor_lag=3)
+    assert st0['krylov_block'] == st0['block'] == 32
+    cols0 = st0['lanczos_steps'] * 32
+    for kb, lag in ((8, 3), (12, 0), (16, 3)):
+        _, s, V, st = svd_topk(ops, A, k, method='lanczos', krylov_block=kb, monitor_lag=lag)
+        assert st['method'] == 'lanczos' and 'lanczos_fallback' not in st and st['krylov_block'] == kb and st['block'] == 32
+        assert st['converged'] and st['verified_rel_residual'] <= 1e-12
+        assert st['lanczos_steps'] > st0['lanczos_steps'] and st['lanczos_steps'] * kb < cols0      # more steps, fewer columns
+        assert np.allclose(s.numpy(), s0.numpy(), rtol=1e-11) and np.abs(V.numpy() @ V.numpy().T - V0.numpy() @ V0.numpy().T).max() < 1e-9
+    with pytest.raises(ValueError):
+        svd_topk(ops, A, k, method='krylov')
+
+
+def test_choice_of_the_krylov_block_width_and_of_the_method():
+    """solver.choose_krylov_block / choose_method (the same rule in csrc/driver.hip): never wider than the nested width, narrow
+    where the sparse products dominate a step, and the subspace iteration where a build is all fixed costs."""
+    from polara_amd.solver import choose_krylov_block, choose_method, KRYLOV_WIDTHS
+    for nnz, n_items, l in ((2e7, 26744, 64), (2e7, 26744, 128), (1e8, 100000, 64), (5e7, 500000, 256), (1e6, 3706, 24), (500, 40, 8)):
+        for world in (1, 2, 8):
+            b = choose_krylov_block(nnz, n_items, l, world)
+            assert b <= l and (b in KRYLOV_WIDTHS or b == l)
+    assert choose_krylov_block(1e8, 100000, 64) == 16          # S-1M: 169 -> 80 ms measured
+    assert choose_krylov_block(2e7, 26744, 64) in (16, 32)
+    assert choose_method(2e7, 26744, 64) == 'lanczos' and choose_method(1e8, 100000, 64) == 'lanczos'
+    assert choose_method(1e6, 3706, 24) == 'subspace' and choose_method(6e4, 800, 24) == 'subspace'
+    assert choose_method(float('inf'), 1000, 24) == 'lanczos'  # an operator that does not say how many entries it holds
 
 
 def test_block_lanczos_hands_rank_deficient_matrices_to_the_subspace_iteration():

@@ -11,21 +11,23 @@ if sys.argv[1] == 'run':
     from polara_amd.solver import svd_topk
     from polara_amd.csr import popularity_order
     ops = HipOps('cuda:0')
-    csr, cfg = make_workload('ml20m', device='cuda:0')
+    csr, cfg = make_workload(sys.argv[4] if len(sys.argv) > 4 else 'ml20m', device='cuda:0')
     c = csr_to_numpy(csr); del csr
     A = ops.csr(c['indptr'], c['indices'], c['values'], c['shape'])
     rank_of, inv = popularity_order(None, c['shape'][1], counts=ops.item_counts(A))
     A = ops.csr_relabel_cols(A, rank_of); A.transpose_operator(); _ = A.plan
     meth = sys.argv[2] if len(sys.argv) > 2 else 'lanczos'
+    kw = dict(krylov_block=int(sys.argv[3])) if len(sys.argv) > 3 and int(sys.argv[3]) > 0 else {}
+    wl = sys.argv[4] if len(sys.argv) > 4 else 'ml20m'
     for _ in range(2):
-        svd_topk(ops, A, 50, method=meth)
+        svd_topk(ops, A, 50, method=meth, **kw)
     torch.cuda.synchronize()
     # marker: a recognisable kernel (randn of an odd size) brackets the traced solve
     ops.randn(777, 3, 1); torch.cuda.synchronize()
-    _, s, V, st = svd_topk(ops, A, 50, method=meth)
+    _, s, V, st = svd_topk(ops, A, 50, method=meth, **kw)
     torch.cuda.synchronize()
     ops.randn(777, 3, 2); torch.cuda.synchronize()
-    print(st['gramian_steps'], st.get('nested'))
+    print(st['gramian_steps'], st.get('nested'), st.get('krylov_block'), st.get('monitor_lag'), st.get('monitor_wait_ms'), st.get('look_ms'))
 else:
     rows = []
     for path in glob.glob(os.path.join(sys.argv[2], '**', '*kernel_trace.csv'), recursive=True):
