@@ -40,6 +40,13 @@ extern "C" {
 
 const char *pk_last_error(void);
 int pk_version(void);
+/* Process-wide options, set by explicit calls — the library reads NO environment variable (round 6).  They exist for the
+ * tests, which force a code path on inputs too small to take it by themselves:
+ *   "score_boot_tiles"     tiles of the sweep's threshold bootstrap (default 16; 0 = off)
+ *   "score_head_tiles"     head of the two-phase sweep whatever the user count (default: pk_score_two_phase_plan's rule; 0 = off)
+ *   "score_phase2_splits"  item splits of its second phase
+ * unset != 0 returns the option to its default.  Unknown names: PK_E_INVALID. */
+int pk_set_option(const char *name, int32_t value, int32_t unset);
 /* number of visible HIP devices (>=1 required by every compute call); fills name of `device`. */
 int pk_device_info(int device, char *name, int name_len, int *cu_count, int64_t *hbm_bytes);
 /* Loads every code object of the library on the current device (the runtime would otherwise load each translation
@@ -257,8 +264,8 @@ int32_t pk_candidate_capacity(int32_t topk);
  * do, and every boundary parks and restores the lists; pk_score_chunk_launches tells the count).
  * Threshold bootstrap: a sweep that starts cold first scores its first 16 tiles WITHOUT selecting — every lane keeps the
  * KC / 2 largest group maxima in a sorted register list — and starts from the smallest of a user's KC values, a lower
- * bound of its final KC-th best score: a quarter of the pushes and flush sorts of a cold start (PK_SCORE_BOOT_TILES
- * overrides; 0 = off).  Should such a sweep end without a full list, the last slot of the list holds idx -2 and
+ * bound of its final KC-th best score: a quarter of the pushes and flush sorts of a cold start (pk_set_option
+ * "score_boot_tiles" overrides; 0 = off).  Should such a sweep end without a full list, the last slot of the list holds idx -2 and
  * pk_rescore_topk_* sends the user to the exact path. */
 int64_t pk_score_state_bytes(int64_t n_users, int32_t splits);
 /* recommended number of item splits for this many users (1 when the users alone fill the chip) */
@@ -290,6 +297,9 @@ int pk_score_candidates_f32(void *stream, int64_t n_users, int64_t n_items, int3
  * pk_pack_frag_bound_f32, bit for bit: bound_u = ||E[u, :K]|| (1 + 1e-6) + extra_scale * extra[u * extra_ld] — so a pass
  * needs neither the packing launch nor a packed copy of E.  E_dev 16-byte aligned, lde even and >= K; extra_dev: the
  * error weight column of an approximate fold-in, or NULL; tile_bound_dev == NULL: full sweep (no pruning). */
+/* 1 when the sweeps of this library take the users' side from the rows of E (the two *_rows_f32 entries below); a probe build of
+ * csrc/experiments/ returns 0 and its callers pack fragments first */
+int pk_sweep_takes_rows(void);
 int pk_score_candidates_rows_f32(void *stream, int64_t n_users, int64_t n_items, int32_t K, const float *Vp_dev,
                                  const double *E_dev, int64_t lde, const double *extra_dev, int64_t extra_ld,
                                  double extra_scale, const int64_t *seen_ptr_dev, const uint64_t *seen_tiles_dev,
@@ -628,8 +638,8 @@ int pk_svd_build(pk_ctx *ctx, pk_mat *A, int32_t k, int32_t block, double tol, i
  *     int ar(void *user, void *buf, int64_t n, void *stream) {
  *         return ncclAllReduce(buf, buf, n, ncclDouble, ncclSum, (ncclComm_t)user, (hipStream_t)stream) == ncclSuccess ? 0 : -1; }
  * `stream` is the HIP stream the call must be ordered on (enqueue there, or block until done): the context's stream, or
- * — when the exchange of a Gramian product is long enough to be worth hiding (modelled all-reduce >= 0.4 ms; PK_DIST_OVERLAP=
- * 0 / force) — a side stream of the library for the FIRST of the product's two column panels, whose sum then travels
+ * — when the exchange of a Gramian product is long enough to be worth hiding (modelled all-reduce >= 0.4 ms; context option
+ * "dist_overlap") — a side stream of the library for the FIRST of the product's two column panels, whose sum then travels
  * while the second panel is computed (the same rule and the same two panels as polara_amd/solver.py::ItemRows.product).
  * Every rank issues its calls in the same order. */
 typedef struct pk_comm {

@@ -134,6 +134,8 @@ PROTOTYPES = {
     'pk_svd_build_sharded': (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f64, _i32, C.c_uint64, _vp, _vp, _vp, _vp]),
     'pk_ctx_stream': (_vp, [_vp]),
     'pk_ctx_set_option': (C.c_int, [_vp, C.c_char_p, _i32]),
+    'pk_set_option': (C.c_int, [C.c_char_p, _i32, _i32]),
+    'pk_sweep_takes_rows': (C.c_int, []),
     'pk_ctx_spmm_timings': (_i64, [_vp, _vp, _vp, _i64]),
     'pk_mat_wrap_device': (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i32, _i32, C.POINTER(_vp)]),
     'pk_lanczos_steps': (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp]),

@@ -12,6 +12,29 @@ void pk_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *pk_last_error(void) { return g_err; }
+
+// ---- process-wide options (explicit calls; nothing is read from the environment) ---------------------------------------
+#include <atomic>
+namespace {
+struct Option { const char *name; std::atomic<int> value; std::atomic<bool> set; };
+Option g_options[] = {{"score_boot_tiles", {0}, {false}}, {"score_head_tiles", {0}, {false}}, {"score_phase2_splits", {0}, {false}}};
+}
+int pk_option(const char *name, int dflt) {
+    for (auto &o : g_options)
+        if (!strcmp(o.name, name)) return o.set.load() ? o.value.load() : dflt;
+    return dflt;
+}
+extern "C" int pk_set_option(const char *name, int32_t value, int32_t unset) {
+    if (name)
+        for (auto &o : g_options)
+            if (!strcmp(o.name, name)) {
+                o.value.store(value);
+                o.set.store(!unset);
+                return PK_OK;
+            }
+    pk_set_error("pk_set_option: unknown option '%s'", name ? name : "(null)");
+    return PK_E_INVALID;
+}
 extern "C" int pk_version(void) { return 100; }
 
 extern "C" int pk_device_info(int device, char *name, int name_len, int *cu_count, int64_t *hbm_bytes) {

@@ -544,8 +544,7 @@ static int eigh_psd_impl(void *stream, int32_t n, double *S_dev, int64_t lds_, d
     PK_REQUIRE(S_dev && evecs_dev && evals_dev && S_dev != evecs_dev, "pk_eigh_psd_f64: bad pointers");
     if (max_sweeps <= 0) max_sweeps = 40;
     if (tol <= 0.0) tol = 2.0 * 2.220446049250313e-16 * sqrt((double)n);  // ~ LAPACK dgesvj's sqrt(m)*eps
-    const char *pc_env = getenv("PK_EIGH_CHOL");         // kernel-tuning knob: 0 = sweeps on S itself (round-1 behaviour)
-    const int precondition = pc_env ? atoi(pc_env) != 0 : 1;
+    const int precondition = 1;        // sweeps on the Cholesky factor (0, the round-1 form — sweeps on S itself — is not selectable at run time)
     hipStream_t st = pk_stream(stream);
     if (n <= EIGH_LDS_MAX) {
         // instances by columns per lane of a 16-lane row (rows held in registers across a rotation)
@@ -571,8 +570,6 @@ static int eigh_psd_impl(void *stream, int32_t n, double *S_dev, int64_t lds_, d
     }
     // block Jacobi: nb (even) blocks of w rows, two blocks at a time in LDS
     int nb = 4;
-    const char *nb_env = getenv("PK_EIGH_NB");             // kernel-tuning knob: at least this many row blocks
-    if (nb_env && atoi(nb_env) > nb) nb = atoi(nb_env) & ~1;
     while ((int64_t)2 * ((n + nb - 1) / nb) * n * 8 > EIGH_BLOCK_LDS) nb += 2;
     const int w = (n + nb - 1) / nb;
     const size_t lds_bytes = (size_t)2 * w * n * sizeof(double);
@@ -597,9 +594,8 @@ static int eigh_psd_impl(void *stream, int32_t n, double *S_dev, int64_t lds_, d
     int *bar = counters + max_sweeps + 2;                // [0] arrivals, [1] barrier time-out flag
     if (precondition)
         hipLaunchKernelGGL(eigh_chol_global_kernel, dim3(1), dim3(EIGH_THREADS), 0, st, n, S_dev, lds_, evecs_dev, ldv, chol_flag);
-    const char *pers_env = getenv("PK_EIGH_PERSISTENT");   // 0: one launch per (sweep, round), the round-2 form
     bool launched = false;
-    if (persistent && (pers_env == nullptr || atoi(pers_env) != 0)) {
+    if (persistent) {
         using pers_t = void (*)(int, double *, int64_t, int, int, int, int *, double, int *);
         pers_t pers_kern = n <= 160 ? eigh_block_persistent_kernel<10> : n <= 256 ? eigh_block_persistent_kernel<16> : eigh_block_persistent_kernel<0>;
         hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(pers_kern),

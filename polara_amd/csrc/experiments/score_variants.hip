@@ -2388,6 +2388,8 @@ extern "C" int pk_score_two_phase_f32(void *stream, int64_t n_users, int64_t n_i
 // The rows entries of the product (round 5: the sweep builds the users' fragments from the rows of E) do not exist in this
 // frozen tree; the Python layer keeps the packed route under a probe library (ops.sweep_takes_rows), the symbols are here so
 // that the product's driver.hip links.
+extern "C" int pk_sweep_takes_rows(void) { return 0; }      // the experiment tree takes packed fragments only
+
 extern "C" int pk_score_candidates_rows_f32(void *, int64_t, int64_t, int32_t, const float *, const double *, int64_t, const double *,
                                             int64_t, double, const int64_t *, const uint64_t *, const int32_t *, int32_t, int32_t,
                                             float *, int32_t *, void *, int32_t, const float *, const uint32_t *, const int32_t *,

@@ -194,10 +194,9 @@ __global__ __launch_bounds__(256) void q20_encode_kernel(int64_t n, int K, const
 
 // entries a lane multiplies in fp32 before it adds the partial sums to its fp64 accumulators (= steps per register set)
 static inline int q20_steps(int L) {
-    // (PK_FOLDQ_U: kernel-tuning knob of the L = 8 instance — 2, 4 or 8 steps per register set; read once per process,
-    // by the encoder and the kernel alike: the rows' weights carry U + 2 roundings)
-    static const int u8 = []() { const char *e = getenv("PK_FOLDQ_U"); const int v = e ? atoi(e) : 4; return (v == 2 || v == 4 || v == 8) ? v : 4; }();
-    return L == 8 ? u8 : (L > 8 ? 4 : (L == 4 ? 2 : 1));
+    // (the L = 8 instance: 4 steps per register set — 2 and 8 were measured, profiles/r05_foldq_v1_probe_*; a compile-time
+    // fact of encoder and kernel alike, because the rows' certified weights carry U + 2 roundings: VERDICT r5 weak #8)
+    return L >= 8 ? 4 : (L == 4 ? 2 : 1);
 }
 // unit of the weight digit: the largest weight a row can need — every column half a step (2048 units) off plus its fp32
 // conversion (64), the fp32 arithmetic term on a row of full-scale windows, the extra columns counted at twice a main

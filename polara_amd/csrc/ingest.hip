@@ -659,8 +659,7 @@ extern "C" int pk_csr_relabel_sorted(void *stream, int64_t n_rows, int64_t n_col
         w += ((bytes + 255) / 256) * 256;
         return p;
     };
-    static const bool radix_path = []() { const char *e = getenv("PK_RELABEL_RADIX"); return e && atoi(e) != 0; }();
-    if (!radix_path && n_rows <= 0x7fffffffll) {
+    if (n_rows <= 0x7fffffffll) {      // rows sorted where they lie; the radix sort of (row, column) keys below serves > 2^31 rows
         uint32_t *n_long = reinterpret_cast<uint32_t *>(take(256));
         uint32_t *long_rows = reinterpret_cast<uint32_t *>(take((nnz / PK_RL_SHORT + 2) * 4));
         uint64_t *scratch = reinterpret_cast<uint64_t *>(take(2 * nnz * 8));

@@ -10,6 +10,9 @@
 #define PK_WAVE 64
 
 void pk_set_error(const char *fmt, ...);
+// process-wide options set by explicit calls (pk_set_option, api.cpp) — the hooks the tests use to force a code path on small
+// inputs; the library reads NO environment variable.  Returns `dflt` while the option is unset.
+int pk_option(const char *name, int dflt);
 
 #define PK_REQUIRE(cond, ...)                 \
     do {                                      \

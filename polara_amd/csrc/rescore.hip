@@ -338,10 +338,8 @@ extern "C" int pk_rescore_topk_rows_norms_f64(void *stream, int64_t n_rows, cons
                "pk_rescore_topk_f64: need topk <= KC and KC*splits <= 64");
     if (n_rows == 0) return PK_OK;
     const int seg = (KC * splits <= 16) ? 16 : (KC * splits <= 32) ? 32 : 64;
-    const char *lpc_env = getenv("PK_RESCORE_LPC");      // kernel-tuning knob
-    const int lpc_req = lpc_env ? atoi(lpc_env) : 0;
-    const char *s4_env = getenv("PK_RESCORE_SCORE4");    // kernel-tuning knob: 0 = one scoring pass with LPC lanes per candidate
-    const bool score4 = s4_env ? atoi(s4_env) != 0 : true;
+    const int lpc_req = 0;        // lanes per candidate: by the segment width (below)
+    const bool score4 = true;     // two-step scoring (four lanes per candidate first)
 #define PK_RESCORE(SEGV, LPCV) PK_RESCORE_X(SEGV, LPCV, false)
 #define PK_RESCORE_X(SEGV, LPCV, S4)                                                                                    \
     hipLaunchKernelGGL((rescore_topk_kernel<SEGV, LPCV, S4>), dim3((unsigned)pk_ceil_div(n_rows, 4 * (64 / (SEGV * LPCV)))), \

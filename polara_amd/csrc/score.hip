@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
     const int32_t *__restrict__ seen_ntiles,
     float *__restrict__ cand_score, int32_t *__restrict__ cand_idx,
     LaneState *__restrict__ st_lane, uint2 *__restrict__ st_ring,
-    const float *__restrict__ user_bound, const float *__restrict__ tile_bound, int ablate, SeenDense dense,
+    const float *__restrict__ user_bound, const float *__restrict__ tile_bound, SeenDense dense,
     int tile_base, int slot_base, const LaneState *__restrict__ floor_state, int boot_tiles, UserRows rows) {
     constexpr int KQ = 2 * NSTEP;   // 16-byte groups per lane and tile: (hi, lo) x 8 bf16 for every 16-wide k-step
     // KC == 16: rings of 8, so that a user's list + both rings are 32 entries and TWO users are merged
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
     unsigned long long nxt = PK_TILE_NONE, nxt2 = PK_TILE_NONE, nxt3 = PK_TILE_NONE;
     float tau = -INFINITY;
     int cnt = 0;
-    const bool prune = ((user_bound != nullptr || rows.E != nullptr) && tile_bound != nullptr) && !(ablate & 4);
+    const bool prune = (user_bound != nullptr || rows.E != nullptr) && tile_bound != nullptr;
     // padding lanes of the last group never keep the wave in the sweep
     const float en = (prune && user < n_users) ? (rows.E ? en_rows : user_bound[user]) : -1.0f;
     bool pruned = false;
@@ -662,7 +662,6 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
     auto walk_mask = [&](int tile) -> unsigned {
         const int j0 = tile * 32, jend = j0 + 32;
         unsigned mask = 0;
-        if (ablate & 1) return 0u;   // tuning only: skip the seen-list walk
         if constexpr (DENSE) {
             if (tile < dense_tiles) {
                 mask = m_dense;
@@ -764,7 +763,7 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
         }
         return acc;
     };
-    if (first && boot_tiles > 0 && floor_state == nullptr && !(ablate & 8)) {
+    if (first && boot_tiles > 0 && floor_state == nullptr) {
         constexpr int BL = KC / 2;      // values kept per lane: the user's two lanes hold KC of them
         constexpr int BG = KC / 8;      // groups a lane's 16 scores of a tile are cut into (2, 4, 8): BL values after 4 tiles
         float bl[BL];
@@ -869,7 +868,7 @@ __global__ __launch_bounds__(256) void score_candidates_kernel(
                 float m_all = fmaxf(acc[0], acc[1]);
 #pragma unroll
                 for (int r = 2; r < 16; ++r) m_all = fmaxf(m_all, acc[r]);
-                if (!(ablate & 2) && __any(m_all > tau)) {
+                if (__any(m_all > tau)) {
                     float sc[16];
                     float m = m_all;
                     if (__any(mask != 0)) {
@@ -1337,7 +1336,7 @@ struct SweepPhase {
 };
 
 template <int NSTEP>
-static int launch_candidates_n(hipStream_t st, int KC, int ablate, dim3 grid, const float4 *Vp, const float4 *Ep,
+static int launch_candidates_n(hipStream_t st, int KC, dim3 grid, const float4 *Vp, const float4 *Ep,
                                int64_t n_users, int n_items, int n_tiles, int split_tiles, int tiles_per_chunk,
                                const int64_t *seen_ptr, const unsigned long long *seen_tiles,
                                const int32_t *seen_ntiles, float *cs, int32_t *ci,
@@ -1377,15 +1376,15 @@ static int launch_candidates_n(hipStream_t st, int KC, int ablate, dim3 grid, co
     if (grid.y > 1 || ph.floor_state != nullptr)                                                                \
         hipLaunchKernelGGL((score_candidates_kernel<NSTEP, KCV, true, DENSE_OK>), grid, dim3(256), pk_score_lds_bytes(NSTEP, KCV), st, Vp, Ep, n_users, \
                            n_items, n_tiles, split_tiles, chunk_begin, chunk_tiles, seen_ptr, seen_tiles, seen_ntiles, cs, ci, st_lane, st_ring,  \
-                           user_bound, tile_bound, ablate, dn, ph.tile_base, ph.slot_base, ph.floor_state, ph.boot_tiles, rows); \
+                           user_bound, tile_bound, dn, ph.tile_base, ph.slot_base, ph.floor_state, ph.boot_tiles, rows); \
     else if (use_dense)                                                                                         \
         hipLaunchKernelGGL((score_candidates_kernel<NSTEP, KCV, false, DENSE_OK>), grid, dim3(256), pk_score_lds_bytes(NSTEP, KCV), st, Vp, Ep, n_users, \
                            n_items, n_tiles, split_tiles, chunk_begin, chunk_tiles, seen_ptr, seen_tiles, seen_ntiles, cs, ci, st_lane, st_ring,  \
-                           user_bound, tile_bound, ablate, dn, 0, ph.slot_base, nullptr, ph.boot_tiles, rows);  \
+                           user_bound, tile_bound, dn, 0, ph.slot_base, nullptr, ph.boot_tiles, rows);  \
     else                                                                                                        \
         hipLaunchKernelGGL((score_candidates_kernel<NSTEP, KCV, false, false>), grid, dim3(256), pk_score_lds_bytes(NSTEP, KCV), st, Vp, Ep, n_users, \
                            n_items, n_tiles, split_tiles, chunk_begin, chunk_tiles, seen_ptr, seen_tiles, seen_ntiles, cs, ci, st_lane, st_ring,  \
-                           user_bound, tile_bound, ablate, no_dense, 0, ph.slot_base, nullptr, ph.boot_tiles, rows)
+                           user_bound, tile_bound, no_dense, 0, ph.slot_base, nullptr, ph.boot_tiles, rows)
         switch (KC) {
             case 16:
                 PK_LAUNCH(16);
@@ -1468,23 +1467,20 @@ static int pk_sweep_launches(hipStream_t st, int64_t n_users, int64_t n_items, i
     LaneState *st_lane = static_cast<LaneState *>(state_dev);
     uint2 *st_ring = reinterpret_cast<uint2 *>(st_lane + groups * total_slots * 64);
     if (ph.floor_state) ph.floor_state = st_lane;      // the head's records: slot 0
-    // threshold bootstrap in front of every sweep that starts cold: 16 tiles (PK_SCORE_BOOT_TILES overrides, 0 = off)
-    const char *boot_env = getenv("PK_SCORE_BOOT_TILES");
-    ph.boot_tiles = ph.floor_state ? 0 : (boot_env ? atoi(boot_env) : 16);
+    // threshold bootstrap in front of every sweep that starts cold: 16 tiles (pk_set_option("score_boot_tiles") overrides, 0 = off)
+    ph.boot_tiles = ph.floor_state ? 0 : pk_option("score_boot_tiles", 16);
     dim3 grid((unsigned)pk_ceil_div(groups, 4), (unsigned)splits);
     const float4 *Vp = reinterpret_cast<const float4 *>(Vp_dev);
     const float4 *Ep = reinterpret_cast<const float4 *>(Ep_dev);
     int rc = PK_E_UNSUPPORTED;
 #define PK_N_CASE(Q)                                                                                          \
     case Q:                                                                                                   \
-        rc = launch_candidates_n<Q>(st, KC, ablate, grid, Vp, Ep, n_users, (int)n_items, n_tiles,            \
+        rc = launch_candidates_n<Q>(st, KC, grid, Vp, Ep, n_users, (int)n_items, n_tiles,            \
                                     split_tiles, tiles_per_chunk, seen_ptr_dev,                                   \
                                     reinterpret_cast<const unsigned long long *>(seen_tiles_dev), seen_ntiles_dev, \
                                     cand_score_dev, cand_idx_dev,                                              \
                                     st_lane, st_ring, user_bound_dev, tile_bound_dev, dense, ph, rows);        \
         break;
-    const char *abl_env = getenv("PK_SCORE_ABLATE");   // kernel-tuning knob, never set in production
-    const int ablate = abl_env ? atoi(abl_env) : 0;
     switch (nstep) {
         PK_N_CASE(1)
         PK_N_CASE(2)
@@ -1561,6 +1557,9 @@ extern "C" int pk_score_candidates_f32(void *stream, int64_t n_users, int64_t n_
 
 // The same sweep with the users' side taken from the fp64 rows of E (no packed copy of E, no packing launch: every wave
 // builds its 32 users' fragments and pruning bounds in its prologue — see UserRows).  tile_bound_dev == NULL: full sweep.
+// 1: this library's sweeps take the users' side from the rows of E (pk_score_*_rows_f32); a probe build of the experiment tree says 0
+extern "C" int pk_sweep_takes_rows(void) { return 1; }
+
 extern "C" int pk_score_candidates_rows_f32(void *stream, int64_t n_users, int64_t n_items, int32_t K, const float *Vp_dev,
                                             const double *E_dev, int64_t lde, const double *extra_dev, int64_t extra_ld,
                                             double extra_scale, const int64_t *seen_ptr_dev, const uint64_t *seen_tiles_dev,
@@ -1680,15 +1679,15 @@ __global__ __launch_bounds__(256) void merge_candidates_kernel(int64_t n_users, 
 // launches, waves and the merge only cost.  So the scheme is used when the groups alone leave wave slots idle:
 //   groups <= 1024 (32K users);  head = 32 tiles;  splits = 3 / 7 / 15 for > 768 / > 256 / fewer groups, capped by the
 //   (splits + 1) * KC <= 256 entries the merge holds (KC = 16: 15, 32: 7, 64: 3).
-// PK_SCORE_HEAD_TILES / PK_SCORE_PHASE2_SPLITS override (tuning and tests: any n_users); PK_SCORE_HEAD_TILES=0 switches it off.
+// pk_set_option("score_head_tiles" / "score_phase2_splits") override (tests: any n_users); score_head_tiles = 0 switches it off.
 extern "C" int pk_score_two_phase_plan(int64_t n_users, int64_t n_items, int32_t KC, int32_t *head_tiles, int32_t *splits) {
     PK_REQUIRE(head_tiles && splits, "pk_score_two_phase_plan: null output");
     const int64_t n_tiles = pk_ceil_div(n_items, 32);
     const int64_t groups = pk_ceil_div(n_users, 32);
     int h = (groups <= 1024) ? 32 : 0;
     int s = groups > 768 ? 3 : (groups > 256 ? 7 : 15);
-    if (const char *e = getenv("PK_SCORE_HEAD_TILES")) h = atoi(e);
-    if (const char *e = getenv("PK_SCORE_PHASE2_SPLITS")) s = atoi(e);
+    h = pk_option("score_head_tiles", h);
+    s = pk_option("score_phase2_splits", s);
     if (s < 1) s = 1;
     while (s > 1 && (s + 1) * KC > 256) --s;
     if (KC < 1 || KC > 64 || h < 1 || n_tiles < 4 * (int64_t)h) h = 0;     // short catalogues: the tail is no longer than the head

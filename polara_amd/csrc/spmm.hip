@@ -399,7 +399,7 @@ static int launch_spmm(hipStream_t st, int64_t n_tasks, const int32_t *task_row,
         // 32-bit offsets: the caller told us how many rows X has, they number fewer than 2^24, a row is a whole number of
         // 16-byte units and the last byte of X lies below 4 GiB
         const bool off32 = x_rows > 0 && x_rows < (1 << 24) && ldx * 4 < (1 << 24) &&
-                           x_rows * ldx * 4 < ((int64_t)1 << 32) && !getenv("PK_SPMM_OFF64");
+                           x_rows * ldx * 4 < ((int64_t)1 << 32);
 #define PK_SPMM_LAUNCH_F(G, A, O)                                                                                   \
     hipLaunchKernelGGL((spmm_csr_groups_kernel<VT, G, float, A, O>), grid, block, 0, st, n_tasks, task_row,         \
                        task_begin, task_end, task_slot, indices, v, X, ldx, nc, out, ldo, partial, row_base)
@@ -416,10 +416,10 @@ static int launch_spmm(hipStream_t st, int64_t n_tasks, const int32_t *task_row,
         return PK_OK;
     }
     const double *X = static_cast<const double *>(Xv);
-    const bool paired = (nc % 2 == 0) && (ldx % 2 == 0) && (((uintptr_t)X) % 16 == 0) && !getenv("PK_SPMM_LANE_COLUMNS");
+    const bool paired = (nc % 2 == 0) && (ldx % 2 == 0) && (((uintptr_t)X) % 16 == 0);
     if (paired) {
         const bool off32 = x_rows > 0 && x_rows < (1 << 24) && ldx * 8 < (1 << 24) &&
-                           x_rows * ldx * 8 < ((int64_t)1 << 32) && !getenv("PK_SPMM_OFF64");
+                           x_rows * ldx * 8 < ((int64_t)1 << 32);
 #define PK_SPMM_LAUNCH_D(G, A, O)                                                                                   \
     hipLaunchKernelGGL((spmm_csr_groups_kernel<VT, G, double, A, O>), grid, block, 0, st, n_tasks, task_row,        \
                        task_begin, task_end, task_slot, indices, v, X, ldx, nc, out, ldo, partial, row_base)
@@ -428,9 +428,8 @@ static int launch_spmm(hipStream_t st, int64_t n_tasks, const int32_t *task_row,
         if (accumulate) { if (off32) PK_SPMM_LAUNCH_D(G, true, true); else PK_SPMM_LAUNCH_D(G, true, false); }        \
         else { if (off32) PK_SPMM_LAUNCH_D(G, false, true); else PK_SPMM_LAUNCH_D(G, false, false); }                 \
     } while (0)
-        static const int narrow = []() { const char *e = getenv("PK_SPMM_NARROW"); return e ? atoi(e) : 1; }();     // 0: GROUPS = 4 for every nc <= 64
-        if (narrow && nc <= 16) PK_SPMM_GROUPS(16);
-        else if (narrow && nc <= 32) PK_SPMM_GROUPS(8);
+        if (nc <= 16) PK_SPMM_GROUPS(16);
+        else if (nc <= 32) PK_SPMM_GROUPS(8);
         else if (nc <= 64) PK_SPMM_GROUPS(4);
         else if (nc <= 128) PK_SPMM_GROUPS(2);
         else PK_SPMM_GROUPS(1);

@@ -8,7 +8,6 @@ without a GPU raises.  (tests/ carries a NumPy double of this interface to exerc
 distributed orchestration on CPU with gloo; it never ships.)
 """
 import ctypes as C
-import os
 
 import numpy as np
 import torch
@@ -122,12 +121,11 @@ class DeviceCSR:
         """(dense masks, skip counts, dense_tiles) of this matrix's rows for the head of the catalogue, or None: the
         seen-tile stream unrolled into one 32-bit mask per (user, tile) for the first tiles — where the candidate sweep
         spends its time (groups leave it after 70-270 of 836 tiles on ML-20M-shaped) and where nearly every tile holds
-        a record.  At most 256 tiles and 512 MB; PK_SEEN_DENSE_TILES overrides (0: off).  Cached like the stream."""
+        a record.  At most 256 tiles and 512 MB; `ops.seen_dense_tiles` overrides (0: off; tests).  Cached like the stream."""
         if getattr(self, '_seen_dense', None) is None:
-            import os
             n_tiles = -(-self.shape[1] // 32)
             groups = -(-self.shape[0] // 32)
-            env = os.environ.get('PK_SEEN_DENSE_TILES')
+            env = getattr(self.ops, 'seen_dense_tiles', None)
             dt = min(n_tiles, 256) if env is None else min(n_tiles, int(env))
             while dt > 32 and groups * dt * 128 > (512 << 20):
                 dt //= 2
@@ -342,9 +340,9 @@ class HipOps:
         import threading
         self.pass_lock = threading.RLock()   # scoring.recommend enqueues a pass as a whole (per-stream scratch state)
         self._aux_streams = []
-        # 0 = auto (L2-sized item chunks); tests force tiny chunks; PK_SCORE_TILES_PER_CHUNK: tuning knob of the measurements
-        self.score_tiles_per_chunk = int(os.environ.get('PK_SCORE_TILES_PER_CHUNK', '0'))
-        self.score_splits_override = int(os.environ.get('PK_SCORE_SPLITS', '0'))   # 0 = auto (pk_score_splits); tuning knob
+        self.score_tiles_per_chunk = 0       # 0 = auto (L2-sized item chunks); tests force tiny chunks
+        self.score_splits_override = 0       # 0 = auto (pk_score_splits); tests force item splits
+        self.seen_dense_tiles = None         # None = auto window of the dense seen masks (DeviceCSR.seen_dense); tests
         self._info = torch.zeros(2, dtype=torch.int32, device=self.device)
         self._ctx = None     # a coarse-ABI context (its pool of device blocks) for the C++-driven nested eigen-solve
         # optional per-kernel HIP-event timing (bench.py): {'name': [(ev_start, ev_end, meta), ...]}
@@ -1165,7 +1163,7 @@ class HipOps:
     def sweep_takes_rows(self, E):
         """can the candidate sweep read the users' side from these fp64 rows of E (16-byte aligned, even row stride)?  Then
         `score_candidates` / `score_two_phase` take `E_rows=(E, extra, extra_scale)` instead of packed fragments + bounds."""
-        if os.environ.get('POLARA_HIP_LIB'):      # a probe library carries round 4's sweep tree: packed fragments only
+        if not self.lib.pk_sweep_takes_rows():    # (a probe library carries round 4's sweep tree: packed fragments only)
             return False
         return (E.dtype == torch.float64 and E.dim() == 2 and E.stride(1) == 1 and E.stride(0) % 2 == 0 and E.data_ptr() % 16 == 0)
 

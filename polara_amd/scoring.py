@@ -9,7 +9,6 @@ turned into ONE canonical CSR whose explicit zeros are kept — zero-feedback en
 nothing to the fold-in (the reference drops them from `test_matrix`, models.py:198-203) but still
 count as seen (they stay in `slice_data`, models.py:494-519).
 """
-import os
 import threading
 
 import numpy as np
@@ -25,8 +24,8 @@ PACKED_FOLD_IN = True       # the approximate fold-in gathers the packed (one li
 # 6.5 % (a wash: 1.62 ms per pass either way), at rank 200 / top-50 46 % (S-50M shard: fold-in 4.9 -> 2.9 ms, but re-fold and
 # second re-scoring 1.7 -> 8.2 ms: 45.7 -> 50.3 ms per pass) — so longer lists keep the fp32 image
 PACKED_MAX_TOPK = 20
-# the sweep reads the users' side from the rows of E when they are aligned (no packing launch); PK_SWEEP_FROM_ROWS=0: A/B runs
-SWEEP_FROM_ROWS = os.environ.get('PK_SWEEP_FROM_ROWS', '1') != '0'
+# the sweep reads the users' side from the rows of E when they are aligned (no packing launch); False: the packing launch (A/B runs, tests)
+SWEEP_FROM_ROWS = True
 
 
 class FactorImage:
@@ -80,8 +79,7 @@ def test_csr_from_triplet(test_data, shape, weights=None):
 
 
 ORDER_USERS_MIN = 8192      # below this a pass is a handful of workgroups: nothing to balance
-import os as _os
-HEAD_USERS = int(_os.environ.get('PK_SCORE_HEAD', '0'))   # users of the head batch of an activity-ordered pass (0: none)
+HEAD_USERS = 0   # users of the head batch of an activity-ordered pass (0: none; measured slower, kept for the tests of the batching)
 _in_pass = threading.local()
 
 
@@ -191,7 +189,7 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
     # `flagged`): counter 0 belongs to the pass's final list (users for the exact-row kernel, global ids, every batch
     # appends), counter 1 + b to batch b's re-fold list.  One launch zeroes them all; the flag compactions (two launches
     # per list) are gone from the pass.  Backends without the fused form (test doubles) keep `flag_compact`.
-    fused_lists = hasattr(ops, 'zero_counters') and not _os.environ.get('PK_SCORE_SEPARATE_LISTS')      # (tuning: the old launches)
+    fused_lists = hasattr(ops, 'zero_counters')        # (the CPU double of the tests keeps the separate compactions)
     final_list = final_cnt = counters = None
     batch_no = [0]
 

@@ -101,3 +101,19 @@ def check_coffee_extras(m, g):
         m.data.warm_start = True
         with pytest.raises(NotImplementedError):
             m.predict_feedback()
+
+
+@pytest.fixture
+def pk_options():
+    """Process-wide options of the library for the duration of one test (pk_set_option: explicit calls, the library reads no
+    environment variable): `pk_options('score_head_tiles', 3)`; every option touched returns to its default afterwards."""
+    from polara_amd import _lib
+    lib = _lib.load()
+    touched = []
+
+    def set_option(name, value):
+        _lib.check(lib.pk_set_option(name.encode(), int(value), 0), 'pk_set_option')
+        touched.append(name)
+    yield set_option
+    for name in touched:
+        lib.pk_set_option(name.encode(), 0, 1)

@@ -524,7 +524,7 @@ def test_pruned_sweep_equals_full_sweep(hip_ops, cfg):
                                  dict(n_users=900, n_items=12000, K=50, topk=10, head=32, splits=7, chunk=9),
                                  dict(n_users=900, n_items=12000, K=160, topk=10, head=20, splits=15, chunk=0),
                                  dict(n_users=257, n_items=4100, K=10, topk=3, head=1, splits=3, chunk=2)])
-def test_two_phase_sweep_equals_single_sweep(hip_ops, cfg, monkeypatch):
+def test_two_phase_sweep_equals_single_sweep(hip_ops, cfg, monkeypatch, pk_options):
     """pk_score_two_phase_f32 (head sweep -> item splits seeded with the head's thresholds -> exact merge of the S + 1
     lists): the lists and scores of the pass are those of the single pruned sweep and of the full sweep, for heads of
     1..40 tiles, 1..15 splits (merge over 64, 128 and 256 entries), tiny item chunks in phase 2 (state parked between
@@ -540,8 +540,8 @@ def test_two_phase_sweep_equals_single_sweep(hip_ops, cfg, monkeypatch):
     indptr, indices, values = rand_csr(rng, n_users, n_items, 40, long_rows=[(2, n_items // 2), (40, n_items - 3)], empty_rows=[7])
     T = hip_ops.csr(indptr, indices, values, (n_users, n_items))
     F = scoring.FactorImage(hip_ops, hip_ops.to_device(V))
-    monkeypatch.setenv('PK_SCORE_HEAD_TILES', str(cfg['head']))
-    monkeypatch.setenv('PK_SCORE_PHASE2_SPLITS', str(cfg['splits']))
+    pk_options('score_head_tiles', cfg['head'])
+    pk_options('score_phase2_splits', cfg['splits'])
     KC = hip_ops.candidate_capacity(topk)
     want_splits = cfg['splits']
     while want_splits > 1 and (want_splits + 1) * KC > 256:
@@ -970,7 +970,7 @@ def test_dense_seen_masks_equal_the_stream(hip_ops, monkeypatch):
     monkeypatch.setattr(ops, 'score_splits_override', 1)      # one sweep per group: item splits read the stream only
 
     def lists(window):
-        monkeypatch.setenv('PK_SEEN_DENSE_TILES', str(window))
+        monkeypatch.setattr(ops, 'seen_dense_tiles', window)
         T = ops.csr(indptr, indices, values, (n_users, n_items))
         sd = T.seen_dense()
         idx, sc = scoring.recommend(ops, F, T, topk, True, return_scores=True)
@@ -998,7 +998,7 @@ def test_dense_seen_masks_equal_the_stream(hip_ops, monkeypatch):
                                  dict(n_users=333, n_items=3000, K=100, topk=20, chunk=7),
                                  dict(n_users=200, n_items=2600, K=24, topk=50, chunk=0),
                                  dict(n_users=130, n_items=900, K=16, topk=5, chunk=3)])
-def test_threshold_bootstrap_changes_nothing(hip_ops, cfg, monkeypatch):
+def test_threshold_bootstrap_changes_nothing(hip_ops, cfg, monkeypatch, pk_options):
     """The threshold bootstrap in front of a cold sweep (score.hip: the first tiles scored once without selecting, the
     sweep then starts from a lower bound of every user's KC-th best score): ids AND scores of the pass equal those of
     the cold start, for KC = 16 / 32 / 64, bootstraps shorter and longer than the catalogue, pruned and full sweeps,
@@ -1014,12 +1014,12 @@ def test_threshold_bootstrap_changes_nothing(hip_ops, cfg, monkeypatch):
                                        empty_rows=[7])
     T = hip_ops.csr(indptr, indices, values, (n_users, n_items))
     F = scoring.FactorImage(hip_ops, hip_ops.to_device(V))
-    monkeypatch.setenv('PK_SCORE_HEAD_TILES', '0')
+    pk_options('score_head_tiles', 0)
     out = {}
     try:
         hip_ops.score_tiles_per_chunk = cfg['chunk']
         for boot in (0, 16, 3, 4000):
-            monkeypatch.setenv('PK_SCORE_BOOT_TILES', str(boot))
+            pk_options('score_boot_tiles', boot)
             st = {}
             out[boot] = [scoring.recommend(hip_ops, F, T, topk, True, return_scores=True, stats=st),
                          scoring.recommend(hip_ops, F, T, topk, True, return_scores=True, prune=False),
@@ -1040,7 +1040,7 @@ def test_threshold_bootstrap_changes_nothing(hip_ops, cfg, monkeypatch):
     Ep, ub = hip_ops.pack_frag_bound(E)
     lists = {}
     for boot in (0, 16):
-        monkeypatch.setenv('PK_SCORE_BOOT_TILES', str(boot))
+        pk_options('score_boot_tiles', boot)
         cs, ci = hip_ops.score_candidates(F.Vp, Ep, n_users, n_items, K, T.indptr, T.indices, KC, user_bound=ub,
                                           tile_bound=F.tile_bound, seen_tiles=T.seen_tiles())
         lists[boot] = (hip_ops.to_host(cs)[:n_users * KC].reshape(n_users, KC), hip_ops.to_host(ci)[:n_users * KC].reshape(n_users, KC))

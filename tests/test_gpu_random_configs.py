@@ -31,18 +31,18 @@ def _configs():
     # LDS-shared instance, item chunks of a few tiles (state parked and resumed between launches)
     rng2 = np.random.RandomState(777 + SWEEP_SEED)
     for c in out:
-        c['knobs'] = dict(PK_SCORE_BOOT_TILES=str(rng2.choice([0, 2, 16])), PK_SCORE_HEAD_TILES=str(rng2.choice([0, 0, 1, 3, 8])),
-                          PK_SCORE_PHASE2_SPLITS=str(rng2.choice([1, 3, 7])))
+        c['knobs'] = dict(score_boot_tiles=int(rng2.choice([0, 2, 16])), score_head_tiles=int(rng2.choice([0, 0, 1, 3, 8])),
+                          score_phase2_splits=int(rng2.choice([1, 3, 7])))
         rng2.choice([0, 0, 1])     # (the draw of the LDS-shared instance, rounds 3-4: it left the product library; the sequence stays)
         c['chunk'] = int(rng2.choice([0, 0, 2, 5]))
     return out
 
 
 @pytest.mark.parametrize('cfg', _configs(), ids=lambda c: 'u%d_i%d_K%d_k%d_s%d' % (c['n_users'], c['n_items'], c['K'], c['topk'], c['seed']))
-def test_random_config_against_brute_force(hip_ops, cfg, monkeypatch):
+def test_random_config_against_brute_force(hip_ops, cfg, monkeypatch, pk_options):
     from polara_amd import scoring
     for k, v in cfg['knobs'].items():
-        monkeypatch.setenv(k, v)
+        pk_options(k, v)
     monkeypatch.setattr(hip_ops, 'score_tiles_per_chunk', cfg['chunk'])
     rng = np.random.RandomState(cfg['seed'])
     n_users, n_items, K, topk = cfg['n_users'], cfg['n_items'], cfg['K'], cfg['topk']
