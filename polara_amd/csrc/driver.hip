@@ -321,7 +321,7 @@ int spmm(pk_ctx *ctx, Csr &M, const void *X, int x_kind, int64_t ldx, int nc, do
                           P.task_end.as<int64_t>() + rg.t0, P.task_slot.as<int32_t>() + rg.t0, rg.nl,
                           P.long_row.as<int32_t>() + rg.l0, P.long_sb.as<int32_t>() + rg.l0, P.long_se.as<int32_t>() + rg.l0,
                           M.indices.as<int32_t>(), M.values.p, M.val_kind, static_cast<const char *>(X) + (size_t)c0 * xe, x_kind, ldx,
-                          w, out + c0, ldo, P.partial.as<double>(), row_base, accumulate, 0));
+                          w, out + c0, ldo, P.partial.as<double>(), row_base, accumulate, M.n_cols));      // (x_rows: the dense block has one row per column of M — lets the launcher take 32-bit row offsets)
         if (ctx->opt.time_spmm) {
             HIPCK(hipEventRecord(tm.e1, ctx->stream));
             ctx->spmm_timings.push_back(tm);
@@ -1226,8 +1226,12 @@ static int lanczos_step(pk_ctx *ctx, Solver &S, GramianOp &gop, int64_t n, int b
 
 // b: width of a Krylov block; l: width of the nested solves (k + guard vectors).  Round 6: b < l — a narrower block needs
 // (l / b)^0.36 times the steps and gathers b / l of the columns per step (solver.py::choose_krylov_block).
+// Looks are synchronous here (no side-stream monitors: those are a host-side scheduling matter of solver.py), and a look — a
+// nested solve of ~5 ms — costs as much as nine steps of a 16-column block: the first one is taken where the cost model puts
+// convergence (a late look wastes cheap steps, an early one costs a whole solve and a second look), later ones where the
+// estimate and the measured (or, from one point, the prior) rate put it.
 static int block_lanczos(pk_ctx *ctx, Solver &S, GramianOp &gop, int64_t n, int k, int l, int b, double tol, uint64_t seed, int max_steps,
-                         LanczosOut &out) {
+                         double steps_model, LanczosOut &out) {
     // pk_gram_f64 takes operands of at most 4096 columns: a Krylov space that would outgrow them ends the recurrence like
     // any other breakdown (out.ok stays false -> filtered subspace iteration), as solver.py::_block_lanczos does
     int qcap = (int)std::min<int64_t>(n / b, 4096 / b);
@@ -1249,7 +1253,10 @@ static int block_lanczos(pk_ctx *ctx, Solver &S, GramianOp &gop, int64_t n, int 
     RitzLook look;
     bool have_warm = false;
     double est_tol = tol;
-    int next_look = std::min(std::max(std::max(4, (2 * k + b - 1) / b + 2), (l + b - 1) / b), qcap);
+    int next_look = std::max(std::max(4, (2 * k + b - 1) / b + 2), (l + b - 1) / b);
+    if (steps_model > 0) next_look = std::max(next_look, (int)std::ceil(steps_model));
+    next_look = std::min(next_look, qcap);
+    const double prior_rate = 0.8 * 1.72 * std::pow(b / 16.0, 0.27);      // solver.py::_block_lanczos: natural log per step, late phase
     int j = 0;
     while (j < qcap) {
         ++j;
@@ -1304,14 +1311,24 @@ static int block_lanczos(pk_ctx *ctx, Solver &S, GramianOp &gop, int64_t n, int 
             est_tol *= 0.1;
         }
         if (last) break;
-        double rate = 1.6;
+        double rate = prior_rate;
         if (hist.size() >= 2 && hist[hist.size() - 2].second > hist.back().second && hist.back().second > 0)
             rate = std::max(0.4, std::log(hist[hist.size() - 2].second / hist.back().second) / (hist.back().first - hist[hist.size() - 2].first));
-        double remaining = std::log(std::max(look.worst, est_tol) / est_tol) / rate;
-        if (hist.size() < 2) remaining *= 0.5;
-        next_look = std::min(qcap, j + std::max(1, (int)remaining));
+        const double remaining = std::log(std::max(look.worst, est_tol) / est_tol) / rate;
+        next_look = std::min(qcap, j + std::max(1, (int)std::ceil(remaining)));
     }
     return PK_OK;
+}
+
+// solver.py::_lanczos_model restated (same constants: polara_amd/machine_model.py)
+static void lanczos_model(double nnz, int64_t n_items, int l, int b, int world, double &steps, double &t_step) {
+    constexpr double kDenseF64Flops = 20e12, kStepFixedS = 0.75e-3;
+    constexpr double kXgmiBusBps = 100e9 /* assumed */, kCollectiveStepS = 5e-6 /* assumed */;
+    steps = 14.0 * std::pow((double)l / b, 0.36);
+    double t_spmm = nnz * (8.0 + std::max(b, 16)) * 1e-12 / world;
+    if (world > 1) t_spmm += 2.0 * (world - 1) / world * (double)n_items * b * 8.0 / kXgmiBusBps + 6 * (world - 1) * kCollectiveStepS;
+    const double n_avg = 0.5 * steps * b;
+    t_step = t_spmm + kStepFixedS + 14.0 * (double)n_items * n_avg * b / kDenseF64Flops / world;
 }
 
 static int svd_build_impl(pk_ctx *ctx, pk_mat *A, const pk_comm *comm, int32_t k, int32_t block, double tol, int32_t max_outer,
@@ -1350,6 +1367,8 @@ static int svd_build_impl(pk_ctx *ctx, pk_mat *A, const pk_comm *comm, int32_t k
     // breaks down (context option "svd_method" overrides)
     bool use_lanczos;
     int kb = l;
+    double work_total = 0.0;
+    const int world_size = comm ? comm->world : 1;
     {
         double work = (double)A->A.nnz;
         if (comm) {
@@ -1363,16 +1382,9 @@ static int svd_build_impl(pk_ctx *ctx, pk_mat *A, const pk_comm *comm, int32_t k
         // solver.py::choose_method / choose_krylov_block / _lanczos_model, restated with the same constants
         // (polara_amd/machine_model.py — measured rates with their records under profiles/, and the two multi-GPU figures
         // that are assumptions because no N > 1 run exists)
-        const int world = comm ? comm->world : 1;
-        auto model = [&](int b, double &steps, double &t_step) {
-            constexpr double kDenseF64Flops = 20e12, kStepFixedS = 0.75e-3;
-            constexpr double kXgmiBusBps = 100e9 /* assumed */, kCollectiveStepS = 5e-6 /* assumed */;
-            steps = 14.0 * std::pow((double)l / b, 0.36);
-            double t_spmm = work * (8.0 + std::max(b, 16)) * 1e-12 / world;
-            if (world > 1) t_spmm += 2.0 * (world - 1) / world * (double)n_items * b * 8.0 / kXgmiBusBps + 6 * (world - 1) * kCollectiveStepS;
-            const double n_avg = 0.5 * steps * b;
-            t_step = t_spmm + kStepFixedS + 14.0 * (double)n_items * n_avg * b / kDenseF64Flops / world;
-        };
+        work_total = work;
+        const int world = world_size;
+        auto model = [&](int b, double &steps, double &t_step) { lanczos_model(work, n_items, l, b, world, steps, t_step); };
         static const int widths[] = {16, 32, 64, 128, 256};
         double best_t = -1.0;
         for (int w : widths) {
@@ -1399,7 +1411,9 @@ static int svd_build_impl(pk_ctx *ctx, pk_mat *A, const pk_comm *comm, int32_t k
     if (use_lanczos) {
         LanczosOut lo;
         const int max_steps = std::min(4096 / kb, (int)(64.0 * std::sqrt((double)l / kb)));
-        CK(block_lanczos(ctx, S, gop, n_items, k, l, kb, tol, seed, std::min(max_steps, 4 * max_outer), lo));
+        double steps_model, t_step_model;
+        lanczos_model(work_total, n_items, l, kb, world_size, steps_model, t_step_model);
+        CK(block_lanczos(ctx, S, gop, n_items, k, l, kb, tol, seed, std::min(max_steps, 4 * max_outer), steps_model, lo));
         stats.outer = lo.looks;
         if (lo.ok) {
             Vk = std::move(lo.Vk);

@@ -13,6 +13,8 @@ MI355X = {
     # what a block Lanczos step costs besides its sparse products and the basis traffic: ~20 small dependent launches
     # (Gram products, CholeskyQR3 with re-projection) and its share of the looks — (build - SpMM) / steps at b = 16 / 32
     'lanczos_step_fixed_s': (0.75e-3, 'profiles/r06_krylov_block_ml20m.txt, r06_krylov_block_s1m.txt'),
+    # wall time of a nested solve that runs on a side stream next to the products (the lag of the monitors)
+    'look_wall_s': (5e-3, 'profiles/r06_krylov_block_ml20m.txt (monitor waits 4-8 ms at lag 4 x 0.55 ms steps)'),
     # bus bandwidth of a ring exchange over xGMI, per rank — ASSUMED (7 links x ~153 GB/s peak; a ring is bound by one link
     # pair): never measured, there has been no multi-GPU box
     'xgmi_bus_Bps': (100e9, 'ASSUMED: no N > 1 run over RCCL exists (SCALE_r01..r05 skipped)'),

@@ -534,7 +534,7 @@ class _Monitor:
 
 
 def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_steps, m_max, spread, even_lock, kb=None,
-                   monitor_lag=None, t_step=None):
+                   monitor_lag=None, t_step=None, steps_model=None):
     """Block Lanczos on B = A^T A with FULL reorthogonalisation and Rayleigh-Ritz over the WHOLE Krylov space
     span[X, B X, ..., B^(q-1) X] — the Krylov-class method behind the reference's `svds` (ARPACK: single-vector implicitly
     restarted Lanczos on the same operator, models.py:844), in the block form a GPU wants.  One Gramian step per block:
@@ -582,16 +582,23 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
     inner = dict(steps=0, outer=0, checks=0)
     stats['nested'] = inner
     hist = []                              # (step, worst relative residual estimate of the k leading pairs)
-    # steps between the launch of a monitor and its collection: a nested solve next to the products takes ~4.5 ms of wall
-    # time, so the lag is that many steps of the modelled step time (3 at the 1.7 ms steps of a 64-column block, up to 5 for the
-    # cheap steps of a narrow one: a longer lag only finds convergence later) — a number every rank derives from the same
-    # all-reduced entry count.  0: no monitors, every look on the calling thread (the form the C++ statement takes).
+    # Looks are the expensive part of a build with narrow blocks: a nested solve is ~5 ms of dependent small kernels, a step
+    # of a 16-column block 0.55 ms (round 6; at the 1.7 ms steps of round 4's 64-column blocks it was the other way round).  So:
+    # ONE monitor half way to the modelled number of steps, collected after as many steps as its solve takes next to the
+    # products (never blocking: lag = look time / modelled step time), the final look where that estimate and a PRIOR rate put
+    # convergence (a late look wastes cheap steps, an early one costs a whole nested solve and a second look), further
+    # monitors only when convergence is far.  Every number is derived from the all-reduced entry count: all ranks decide alike.
+    # monitor_lag = 0: no monitors, every look on the calling thread (the form the C++ statement takes).
+    from .machine_model import value as mm
     if monitor_lag is None:
-        monitor_lag = 3 if not t_step else int(min(5, max(3, math.ceil(4.5e-3 / t_step))))
+        monitor_lag = 3 if not t_step else int(min(10, max(3, math.ceil(mm('look_wall_s') / t_step))))
     LAG = int(monitor_lag)
     stats['monitor_lag'] = LAG
     use_monitor = LAG > 0
     first = max(4, -(-2 * k // b) + 2, -(-l // b))
+    if steps_model:
+        first = max(first, int(math.ceil(0.5 * steps_model)))
+    prior_rate = 0.8 * 1.72 * (b / 16.0) ** 0.27      # natural log per step, late phase: x5.6 / x8.2 / x12 per step at b = 16 / 32 / 64 (measured), less a fifth
     next_look = min(first, qcap)           # the step of the next monitor, or of the final check once the rate is known
     look_is_final = not use_monitor
     est_tol = tol
@@ -606,18 +613,32 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
     def breakdown_check(j):
         _raise_on_breakdown(ops.to_host(flags), j)
 
+    relax_at = [None]                      # the step from which a relaxed build rounds its exchanged blocks
+
+    def relax_gate(worst, j_est, j_now):
+        # A relaxed build (svd_topk: exchange='relaxed') rounds the exchanged blocks to fp32 once the pairs are within
+        # 1e-7 / world of convergence: now, if the estimate just collected says so, else at the step where HALF the prior rate
+        # puts that (a conservative extrapolation; should it be wrong the fp64 verification fails and the build goes on exact).
+        if not getattr(lay, 'relaxed', False) or lay.exchange_dtype is not None:
+            return
+        gate = 1e-7 / max(comm.world, 1)
+        at = j_est + (0 if worst <= gate else int(math.ceil(np.log(worst / gate) / (0.5 * prior_rate))))
+        relax_at[0] = at if relax_at[0] is None else min(relax_at[0], at)
+
+    def relax_now(j_now):
+        if relax_at[0] is not None and j_now >= relax_at[0] and getattr(lay, 'relaxed', False) and lay.exchange_dtype is None:
+            lay.exchange_dtype = torch.float32
+            stats['exchange_relaxed_from'] = j_now + 1
+
     def plan(j_now):
         """the step of the next look from the history of estimates; (step, final?)"""
         jl, worst = hist[-1]
-        rate = 1.6                         # natural log per step until two estimates have been seen (~ x5 per step)
+        rate = prior_rate                  # until two estimates have been seen
         if len(hist) >= 2 and hist[-2][1] > hist[-1][1] > 0:
             rate = max(0.4, np.log(hist[-2][1] / hist[-1][1]) / (hist[-1][0] - hist[-2][0]))
         remaining = np.log(max(worst, est_tol) / est_tol) / rate
-        known = len(hist) >= 2
-        if not known:
-            remaining *= 0.5               # one point says nothing about the rate: look again half way
-        step = min(qcap, max(j_now + 1, jl + max(1, int(remaining))))
-        return step, (known or not use_monitor)
+        step = min(qcap, max(j_now + 1, jl + max(1, int(math.ceil(remaining)))))
+        return step, True
 
     try:
         while j < qcap:
@@ -631,6 +652,7 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
                 Qbuf, T, cap = Qn_, Tn_, cap2
             Qall = Qbuf[:, :N]
             last = j == qcap
+            relax_now(j - 1)
             if rec is not None:
                 rec.steps(Qbuf, T, S_buf, flags, j - 1, 1, last)
                 stats['gramian_steps'] += 1
@@ -641,7 +663,15 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
                 W = gop.apply(Qj)
                 C = lay.gram(Qall, W)                                      # block column j of T, rows of all blocks so far
                 T[:N, N - b:N] = C
-                T[N - b:N, :N - b] = C[:N - b].t()
+                if lay.exchange_dtype is not None and getattr(lay, 'relaxed', False) and N > 2 * b:
+                    # a ROUNDED product: C = Q^T (B Q_j + E_j) carries E_j (6e-8) in every block row.  In the rows of the early
+                    # blocks that noise is harmless where it stands (it multiplies the small late coefficients y_j), but its
+                    # MIRROR image would multiply the O(1) early coefficients: the rows of T below the band are Q_j^T W_i with
+                    # W_i exact — zero to rounding under full reorthogonalisation — and are left so
+                    T[N - b:N, N - 2 * b:N - b] = C[N - 2 * b:N - b].t()
+                    T[:N - 2 * b, N - b:N] = 0.0          # (the look symmetrises its snapshot: the noise above the band goes too)
+                else:
+                    T[N - b:N, :N - b] = C[:N - b].t()
                 if not last:
                     S = _next_lanczos_block(lay, W, Qbuf, N, C, flags)
                 else:                              # the last block the space can hold: the coupling of W_perp directly
@@ -654,13 +684,14 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
                 jm, monitor = monitor.j, None
                 warm = out['basis']
                 hist.append((jm, out['worst']))
+                relax_gate(out['worst'], jm, j)
                 if verbose and comm.rank == 0:
                     print('[svd] lanczos monitor of step %2d (seen at %2d)  worst rel.res (first %d) %.2e  nested so far: %d outer, %d products'
                           % (jm, j, k, out['worst'], inner['outer'], inner['steps']))
                 next_look, look_is_final = plan(j)
-                if not last and not (look_is_final and next_look <= j + LAG):
-                    # convergence is not imminent: the next monitor starts at once, warm from the one just collected
-                    # (a chain of short nested solves next to the Gramian steps; only the final look is on the main stream)
+                if not last and next_look > j + 2 * LAG:
+                    # convergence is far: another monitor starts at once, warm from the one just collected (it will be back
+                    # before the look is due); otherwise the next look is the one on the main stream, where convergence is expected
                     next_look, look_is_final = j, False
             if j < next_look and not last:
                 continue
@@ -677,21 +708,24 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
             t_w = time.perf_counter()
             breakdown_check(j)
             out = _ritz_check(ops, snapshot(N), S, warm, k, b, est_tol, hist[-1][1] if hist else None, seed + 1000 * j, inner,
-                              final=len(hist) >= 2, width=l)
+                              final=len(hist) >= 1, width=l)
             stats.setdefault('look_ms', []).append(round(1e3 * (time.perf_counter() - t_w), 3))    # includes draining the steps queued before it
             warm = out['basis']
             hist.append((j, out['worst']))
             if verbose and comm.rank == 0:
                 print('[svd] lanczos step %2d  dim %4d  worst rel.res (first %d) %.2e  nested so far: %d outer, %d products, inner converged %s'
                       % (j, N, k, out['worst'], inner['outer'], inner['steps'], out['conv']))
+            relax_gate(out['worst'], j, j)
             if out['worst'] <= est_tol and out['conv']:
                 Vk = ops.tsmm(Qall, out['Yk'])
+                rounded, lay.exchange_dtype = lay.exchange_dtype, (None if getattr(lay, 'relaxed', False) else lay.exchange_dtype)
                 if rec is not None:                # one true product on the k Ritz vectors
                     Z = rec.gramian(Vk)
                     stats['gramian_steps'] += 1
                     stats['spmm_cols'] += k
                 else:
-                    Z = gop.apply(Vk)
+                    Z = gop.apply(Vk)              # (a relaxed build exchanges THIS product in fp64: a pair is accepted on a true residual)
+                lay.exchange_dtype = rounded
                 lam1 = max(float(out['lam_all'][0]), 1e-300)
                 res2 = lay.total(ops.resid_colnorm2(Z, Vk, out['lam_k']))
                 res_true = np.sqrt(np.maximum(ops.to_host(res2), 0.0)) / lam1
@@ -700,10 +734,12 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
                     result = (Vk, out['lam_all'][:k].copy(), res_true * lam1)
                     break
                 est_tol *= 0.1                 # the estimate was optimistic (orthogonality): ask for more, keep going
+                if getattr(lay, 'relaxed', False) and lay.exchange_dtype is not None:
+                    lay.relaxed, lay.exchange_dtype = False, None      # ... and with exact exchanges from here on
+                    stats['exchange_relaxed_failed_at'] = j
             if last:
                 break
-            next_look, look_is_final = plan(j)
-            look_is_final = True               # from here on every look is on the main stream: convergence is near
+            next_look, look_is_final = plan(j)     # from here on every look is on the main stream: convergence is near
     finally:
         if monitor is not None:                # never leave a worker behind (exceptions, early exits)
             try:
@@ -808,19 +844,19 @@ def plan_build(ops, A, k, block=None, method=None, krylov_block=None, max_steps=
             total = float(nnz)
     if method == 'auto':
         method = choose_method(total, n_items, l, comm.world)
-    kb, t_step = l, None
+    kb, t_step, steps_model = l, None, None
     if method == 'lanczos':
         if krylov_block is not None:
             kb = max(1, min(int(krylov_block), l))
         elif math.isfinite(total):
             kb = choose_krylov_block(total, n_items, l, comm.world)
         if math.isfinite(total):
-            t_step = _lanczos_model(total, n_items, l, kb, comm.world)[1]
+            steps_model, t_step = _lanczos_model(total, n_items, l, kb, comm.world)
         if max_steps is None:
             max_steps = min(MAX_KRYLOV_COLS // kb, int(64 * math.sqrt(l / float(kb))))
     elif max_steps is None:
         max_steps = 64
-    return dict(block=l, method=method, krylov_block=kb, t_step=t_step, max_steps=max_steps, nnz_total=total)
+    return dict(block=l, method=method, krylov_block=kb, t_step=t_step, steps_model=steps_model, max_steps=max_steps, nnz_total=total)
 
 
 def _library_recurrence(ops, A, comm, sharded):
@@ -868,13 +904,27 @@ def svd_topk(ops, A, k, block=None, tol=1e-12, max_outer=200, m_max=24, spread=1
     # product that needs it (`_Gramian.At`)
     At = _Lazy((lambda: A.transpose_operator()) if hasattr(A, 'transpose_operator') else (lambda: A.T))
 
-    # payload of the block exchanges on more than one rank: 'f64', 'f32', or 'auto' = fp32 where the tolerance leaves room
-    # for its 6e-8 (tol >= 1e-6), fp64 otherwise (the default 1e-12 build)
-    if exchange not in ('auto', 'f64', 'f32'):
-        raise ValueError("exchange must be 'auto', 'f64' or 'f32'")
-    xdt = torch.float32 if (exchange == 'f32' or (exchange == 'auto' and tol >= 1e-6)) else None
+    # Payload of the block exchanges on more than one rank (never silently):
+    #   'f64'      the blocks as they are — what 'auto' means;
+    #   'relaxed'  fp32 on the wire for the LATE steps of a Lanczos build only: the true residual of a Ritz pair is the estimated
+    #              one plus  sum_j E_j y_j  (E_j: what the rounding did to the product of step j, 6e-8 of its norm; y_j: block j
+    #              of the pair's coefficients), and the coefficients of a converging pair in the blocks added late are as small
+    #              as its residual was when they were added — so a product may be rounded once a collected estimate says the
+    #              pairs are within 1e-7 / world (its error then enters at 6e-15), never earlier; the verification product is
+    #              exchanged in fp64 (a pair is accepted on a TRUE residual), and a failed verification ends the rounding for
+    #              the rest of the build.  (The relaxation theory of inexact Krylov methods: early products exact, late ones
+    #              loose — the opposite of "fp32 until the end", which stalled at 5e-12 in round 4)
+    #   'f32'      every exchange rounded (an explicit choice for builds to a tolerance >= 1e-6; warns below it).
+    if exchange not in ('auto', 'f64', 'f32', 'relaxed'):
+        raise ValueError("exchange must be 'auto', 'f64', 'relaxed' or 'f32'")
+    if exchange == 'f32' and tol < 1e-6:
+        import warnings
+        warnings.warn('svd_topk: exchange=\'f32\' rounds every exchanged product to 6e-8 of its norm; a tolerance of %.1e is out of '
+                      'its reach (use \'relaxed\' or \'f64\')' % tol, RuntimeWarning, stacklevel=2)
+    xdt = torch.float32 if exchange == 'f32' else None
     lay = ItemRows(ops, comm, n_items, shard_items, exchange_dtype=xdt, overlap=exchange_overlap)
-    stats = dict(krylov_block=kb if method == 'lanczos' else None, exchange='f32' if xdt is not None else 'f64', outer=0, gramian_steps=0, spmm_cols=0, degrees=[], locked_at=[], block=l, converged=False,
+    lay.relaxed = exchange == 'relaxed'
+    stats = dict(krylov_block=kb if method == 'lanczos' else None, exchange={'auto': 'f64'}.get(exchange, exchange), outer=0, gramian_steps=0, spmm_cols=0, degrees=[], locked_at=[], block=l, converged=False,
                  item_rows_per_rank=lay.rows, items_sharded=lay.sharded, method=stats_method)
     Vk = lam_k = res_k = None
     if method == 'lanczos':
@@ -882,7 +932,7 @@ def svd_topk(ops, A, k, block=None, tol=1e-12, max_outer=200, m_max=24, spread=1
             # `max_outer` bounds the work of either method: an outer iteration of the subspace method is worth a few blocks
             Vk, lam_k, res_k = _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose,
                                               min(max_steps, 4 * max_outer), m_max, spread, even_lock, kb=kb,
-                                              monitor_lag=monitor_lag, t_step=t_step)
+                                              monitor_lag=monitor_lag, t_step=t_step, steps_model=plan['steps_model'])
             stats['converged'] = True
         except _LanczosBreakdown as exc:
             stats['lanczos_fallback'] = str(exc)
@@ -902,6 +952,7 @@ def svd_topk(ops, A, k, block=None, tol=1e-12, max_outer=200, m_max=24, spread=1
         # residuals of the k leading pairs: locked pairs are below tol by construction
         res_k = res_act[:max(1, min(k - n_lock, len(res_act)))]
 
+    lay.exchange_dtype = None                               # the factors themselves always travel as they are
     Vk = lay.full(Vk[:, :k].contiguous()).contiguous()      # the factors are replicated: scoring needs every item row
     lam_k = np.maximum(np.asarray(lam_k, dtype=np.float64)[:k], 0.0)
     order = np.argsort(-lam_k, kind='stable')
