@@ -342,12 +342,9 @@ class Bench:
         if norm_order:
             # serving index: catalogue re-indexed by descending factor norm (the pruning bound of the sweep is a
             # suffix maximum of these norms); factors and the rows to score are relabelled once
-            vn = torch.linalg.vector_norm(V, dim=1)
-            order2 = torch.argsort(vn, descending=True, stable=True)          # new internal id -> old internal id
-            rank2 = torch.empty_like(order2)
-            rank2[order2] = torch.arange(n_items, device=order2.device)
-            V = V[order2].contiguous()
-            A_score = ops.csr_relabel_cols(A, rank2, sort=os.environ.get('PK_BENCH_SORT_SERVING', '1') == '1')
+            order32, rank32, V = ops.norm_order(V)          # own radix sort on the norms' bits + one gather (pk_row_norm_order_f64)
+            order2 = order32.long()                         # new internal id -> old internal id
+            A_score = ops.csr_relabel_cols(A, rank32, sort=True)
         F = scoring.FactorImage(ops, V)
         # the test rows grouped by activity (what the scoring pass sweeps) and their seen-tile streams
         (A_score.by_activity()[0] if A_score.shape[0] >= scoring.ORDER_USERS_MIN else A_score).seen_tiles()

@@ -120,6 +120,13 @@ int64_t pk_radix_work_bytes(int64_t n);
 int pk_radix_sort_pairs(void *stream, int64_t n, int32_t key_bytes, void *keys_dev, uint32_t *vals_dev,
                         void *keys_tmp_dev, uint32_t *vals_tmp_dev, int32_t key_bits, void *work_dev,
                         int32_t *result_in_tmp);
+/* The serving order of the catalogue: rows of V [n x K] by DESCENDING Euclidean norm, ties by row id (the order of
+ * `np.argsort(-np.linalg.norm(V, axis=1), kind='stable')`; the reference keeps V as built, models.py:849 — the re-indexing
+ * serves the sweep's pruning bound).  order_dev[p] = the row at position p, rank_dev[row] = its position, V_sorted_dev (or
+ * NULL) [n x K] = the rows in that order.  work >= pk_row_norm_order_work_bytes(n). */
+int64_t pk_row_norm_order_work_bytes(int64_t n);
+int pk_row_norm_order_f64(void *stream, int64_t n, int32_t K, const double *V_dev, int64_t ldv, int32_t *order_dev,
+                          int32_t *rank_dev, double *V_sorted_dev, void *work_dev);
 /* COO triplets (device arrays, any order, duplicates allowed; entry i has row rows_dev[i * idx_stride] and column
  * cols_dev[i * idx_stride] — idx_stride = 2 reads the interleaved int64 [nnz x 2] index array of `to_coo`,
  * data.py:794-817, as it is) -> canonical CSR: indptr int64[n_rows + 1],
@@ -362,6 +369,11 @@ int32_t pk_score_chunk_launches(int64_t n_items, int32_t K, int32_t splits, int3
  * which that group left the sweep (absolute tile index; >= n_tiles - S + 1 when it was never pruned): split h
  * scored ceil((that - h) / S) tiles, for the roofline accounting of bench.py. */
 int pk_row_norm_bound_f32(void *stream, int64_t n, int32_t K, const double *src_dev, int64_t ld, float *out_dev);
+/* The fp32 image of the item factors the approximate fold-in gathers from: out [n x ld32] (ld32 > K) = fl32(V) in columns
+ * 0..K-1, bound_dev[r] (pk_row_norm_bound_f32) in column K, zeros beyond.  stat_dev[2] (uint32): [0] = the bits of the largest
+ * bound, [1] != 0 when an entry of V or a bound is not finite — the range check of the image in the same launch. */
+int pk_v32_image_f32(void *stream, int64_t n, int32_t K, int32_t ld32, const double *V_dev, int64_t ldv, const float *bound_dev,
+                     float *out_dev, uint32_t *stat_dev);
 /* pk_pack_frag_f32 and the row bound in one pass over the block (the user side of a scoring pass):
  * bound[r] >= ||src[r,:]||_2 + extra_scale * extra[r * extra_ld]   (extra_dev may be NULL). */
 int pk_pack_frag_bound_f32(void *stream, int64_t n, int32_t K, const double *src_dev, int64_t ld, float *dst_dev,
@@ -658,10 +670,16 @@ int pk_svd_build_sharded(pk_ctx *ctx, pk_mat *A_local, const pk_comm *comm, int3
  * the pairs of a leading principal submatrix), or NULL = the first l unit vectors.  Convergence: ||T y - theta y|| <= tol *
  * theta_1 for the k leading pairs.  Outputs: basis_out_dev [n x l] (locked vectors, then the active block; column j belongs
  * to lam_out_host[j]), res_out_host[0 .. counts[1]) = residual norms of the active block, counts_out[5] = {locked vectors,
- * width of the active block, converged, outer iterations, products with T}.  Synchronises `stream` before it returns. */
+ * width of the active block, converged, outer iterations, products with T}.  Synchronises `stream` before it returns.
+ * Round 6: the filter runs in SEGMENTS with a CholeskyQR between them and one Rayleigh-Ritz step per round (two host reads);
+ * the iteration with locking takes over when that hands over (degenerate bounds, a Cholesky breakdown, stagnation).
+ * lam0_host (or NULL): the Ritz values of the l columns of X0_dev when those are the pairs of a leading principal submatrix of
+ * T (they keep their Rayleigh quotients), r0_rel: the worst relative residual of the first k of them w.r.t. THIS T (< 0:
+ * unknown) — a warm look then needs no Rayleigh-Ritz step before its filter. */
 int pk_sym_eig_topk_f64(pk_ctx *ctx, void *stream, int32_t n, const double *T_dev, int64_t ldt, int32_t k, int32_t l,
                         const double *X0_dev, int64_t ldx0, int32_t x0_rows, double tol, int32_t max_outer, uint64_t seed,
-                        double *basis_out_dev, int64_t ldb, double *lam_out_host, double *res_out_host, int32_t *counts_out);
+                        double *basis_out_dev, int64_t ldb, double *lam_out_host, double *res_out_host, int32_t *counts_out,
+                        const double *lam0_host, double r0_rel);
 /* What a host may choose about the builds of a context — explicit calls, not environment variables (round 6):
  *   "svd_method"   0 = the cost model (solver.py::choose_method restated), 1 = block Lanczos, 2 = filtered subspace iteration
  *   "krylov_block" 0 = the cost model (solver.py::choose_krylov_block restated), else the width of a Krylov block (<= block)
@@ -686,12 +704,17 @@ int64_t pk_ctx_spmm_timings(pk_ctx *ctx, double *ms_out, int64_t *meta_out, int6
  * image are written), S_out_dev [b x b] = W_perp^T W_perp of the LAST step run (the coupling behind the residual
  * estimates of the Ritz pairs), flags_dev[2] += Cholesky verdicts / max= distance of a last pass's Gram matrix from I.
  * last_closes: the last step of the call does not compute a next block (the space is full).  No host synchronisation.
+ * rounded != 0: both sparse products of these steps gather fp32 images of their dense blocks (half the bytes per gathered
+ * row, fp64 accumulation: a product rounded to ~6e-8 of its norm) and only the BAND of the block column of T is written —
+ * for the late steps of a build only, when the pairs are within ~1e-7 of convergence (the error of a rounded product
+ * enters a pair's residual times the pair's coefficients in that block; solver.py: products='relaxed').
  * pk_gramian_apply_f64: Z = A^T (A X), X / Z [n_cols x nc] with leading dimensions ldx / ldz (the verification product). */
 int pk_mat_wrap_device(pk_ctx *ctx, void *stream, int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t *indptr_dev,
                        const int32_t *indices_dev, const void *values_dev, int32_t val_kind, int32_t block_cols,
                        pk_mat **mat_out);
 int pk_lanczos_steps(pk_ctx *ctx, void *stream, pk_mat *A, int32_t b, int32_t j0, int32_t m, int32_t last_closes,
-                     double *Q_dev, int64_t ldq, double *T_dev, int64_t ldt, double *S_out_dev, double *flags_dev);
+                     double *Q_dev, int64_t ldq, double *T_dev, int64_t ldt, double *S_out_dev, double *flags_dev,
+                     int32_t rounded);
 int pk_gramian_apply_f64(pk_ctx *ctx, void *stream, pk_mat *A, int32_t nc, const double *X_dev, int64_t ldx, double *Z_dev,
                          int64_t ldz);
 /* the context's HIP stream (hipStream_t as void*): what a pk_comm callback is handed, for hosts that create the

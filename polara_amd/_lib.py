@@ -130,15 +130,18 @@ PROTOTYPES = {
     'pk_mat_nnz': (_i64, [_vp]),
     'pk_svd_build': (C.c_int, [_vp, _vp, _i32, _i32, _f64, _i32, C.c_uint64, _vp, _vp, _vp, _vp]),
     'pk_sym_eig_topk_f64': (C.c_int, [_vp, _vp, _i32, _vp, _i64, _i32, _i32, _vp, _i64, _i32, _f64, _i32, C.c_uint64,
-                                      _vp, _i64, _vp, _vp, _vp]),
+                                      _vp, _i64, _vp, _vp, _vp, _vp, _f64]),
     'pk_svd_build_sharded': (C.c_int, [_vp, _vp, _vp, _i32, _i32, _f64, _i32, C.c_uint64, _vp, _vp, _vp, _vp]),
     'pk_ctx_stream': (_vp, [_vp]),
     'pk_ctx_set_option': (C.c_int, [_vp, C.c_char_p, _i32]),
     'pk_set_option': (C.c_int, [C.c_char_p, _i32, _i32]),
+    'pk_v32_image_f32': (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _vp]),
+    'pk_row_norm_order_work_bytes': (_i64, [_i64]),
+    'pk_row_norm_order_f64': (C.c_int, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _vp]),
     'pk_sweep_takes_rows': (C.c_int, []),
     'pk_ctx_spmm_timings': (_i64, [_vp, _vp, _vp, _i64]),
     'pk_mat_wrap_device': (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i32, _i32, C.POINTER(_vp)]),
-    'pk_lanczos_steps': (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp]),
+    'pk_lanczos_steps': (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _i32]),
     'pk_gramian_apply_f64': (C.c_int, [_vp, _vp, _vp, _i32, _vp, _i64, _vp, _i64]),
     'pk_score_topk': (C.c_int, [_vp, _i64, _i32, _vp, _vp, _i32, _i32, _vp, _vp]),
     'pk_serving_create': (C.c_int, [_vp, _i64, _i32, _vp, _vp, C.POINTER(_vp)]),

@@ -192,6 +192,12 @@ __global__ void transpose_small_kernel(int n, const double *__restrict__ in, dou
     out[(int64_t)c * n + r] = in[i];
 }
 
+// fp32 image of a contiguous fp64 block (the rounded products of the late Lanczos steps gather half the bytes)
+__global__ void f64_to_f32_kernel(int64_t n, const double *__restrict__ in, float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)in[i];
+}
+
 __global__ void unit_block_kernel(int64_t n, int l, double *__restrict__ out) {     // out[n x l] = first l unit vectors
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n * l) return;
@@ -838,6 +844,7 @@ int subspace_iteration(pk_ctx *ctx, Solver &S, Op &op, int k, DMat X, double tol
     std::vector<double> lam_lock, theta_host, res_host;
     int n_lock = 0;
     bool done = false;
+    bool segments_ok = true;       // the filter of a dense operator may be cut into segments (below)
     for (int it = 0; it < max_outer && !done; ++it) {
         out.outer += 1;
         // ---- Rayleigh-Ritz on the active block
@@ -878,16 +885,18 @@ int subspace_iteration(pk_ctx *ctx, Solver &S, Op &op, int k, DMat X, double tol
         const double b = theta_host.back(), a0 = theta_host.front();
         const int m = cheb_degree(a0, b, spread, m_max);
         const double e = 0.5 * b, c = 0.5 * b;
-        DMat Yc;
-        if (e <= 0.0 || a0 <= c) {
-            if (have_lock) CK(S.project_out(Z, Vlock, Yc)); else Yc = std::move(Z);
-        } else {
+        // One filter of degree m from the start block Xs with Zs = B Xs: Yc = p_m(P B P) Xs.
+        auto cheb_filter = [&](DMat &Xs, DMat &Zs, DMat &Yc) -> int {
+            if (e <= 0.0 || a0 <= c) {
+                if (have_lock) CK(S.project_out(Zs, Vlock, Yc)); else Yc = std::move(Zs);
+                return PK_OK;
+            }
             double sigma = e / (a0 - c);
             const double tau = 2.0 / sigma;
             DMat Zp;
-            if (have_lock) CK(S.project_out(Z, Vlock, Zp)); else Zp = std::move(Z);
+            if (have_lock) CK(S.project_out(Zs, Vlock, Zp)); else Zp = std::move(Zs);
             DMat Xc;
-            CK(S.col_slice(X, 0, X.l, Xc));
+            CK(S.col_slice(Xs, 0, Xs.l, Xc));
             CK(S.axpbypcz(sigma / e, Zp, -c * sigma / e, &Xc, 0.0, nullptr, Yc));
             for (int s = 2; s <= m; ++s) {
                 const double sigma_new = 1.0 / (tau - sigma);
@@ -908,9 +917,67 @@ int subspace_iteration(pk_ctx *ctx, Solver &S, Op &op, int k, DMat X, double tol
                 Yc = std::move(Yn);
                 sigma = sigma_new;
             }
+            return PK_OK;
+        };
+        // The degree is held down by the SPREAD of the block (theta_1 / theta_l of a decaying spectrum: degree 4-5 on the
+        // projected problems of a Lanczos build), not by what the wanted pairs need — a Rayleigh-Ritz step per four
+        // products, each with an l x l eigen-decomposition and four host reads.  For a small dense operator (the nested
+        // solves: a product is one launch) the filter is therefore applied in up to four SEGMENTS of that degree with a
+        // plain CholeskyQR2 in between (no Rayleigh-Ritz, no host read): the amplification of a wanted pair over the damped
+        // interval is the product of the segments', the conditioning of the block that of one (round 6: looks of a
+        // narrow-block build cost more than its steps; 3-4 outer iterations per warm look before).
+        int nseg = 1;
+        if constexpr (has_filter_step<Op>::value) {
+            if (segments_ok && !(e <= 0.0 || a0 <= c)) nseg = std::max(1, std::min(4, m_max / std::max(m, 1)));
+        }
+        DMat Yc, Xritz;
+        Dev seg_info;
+        if (nseg > 1) {
+            CK(S.col_slice(X, 0, X.l, Xritz));          // the Ritz vectors: what the iteration falls back to
+            if (!seg_info.alloc((size_t)nseg * 2 * 4)) return fail(ctx, PK_E_LAUNCH, "out of device memory (filter segments)");
+            HIPCK(hipMemsetAsync(seg_info.p, 0, (size_t)nseg * 2 * 4, S.st));
+        }
+        {
+            DMat Xs = std::move(X), Zs = std::move(Z);
+            for (int seg = 0; seg < nseg; ++seg) {
+                DMat Yseg;
+                CK(cheb_filter(Xs, Zs, Yseg));
+                if (seg + 1 == nseg) {
+                    Yc = std::move(Yseg);
+                    break;
+                }
+                // CholeskyQR2 of the segment's block (shifted first pass), orthogonal to the locked vectors
+                const int l = Yseg.l;
+                const double u = 1.1102230246251565e-16;
+                Dev chol_work((size_t)std::max<int64_t>(pk_chol_work_bytes(l), 8));
+                if (!chol_work.p) return fail(ctx, PK_E_LAUNCH, "out of device memory (filter segments)");
+                for (int p = 0; p < 2; ++p) {
+                    if (have_lock) { DMat t; CK(S.project_out(Yseg, Vlock, t)); Yseg = std::move(t); }
+                    DMat G, Rinv(l, l), Yn;
+                    if (!Rinv.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (filter segments)");
+                    CK(S.gram(Yseg, Yseg, G));
+                    CK(pk_chol_rinv_f64(S.st, l, G.p(), l, p == 0 ? 11.0 * ((double)Yseg.n * l + (double)l * (l + 1)) * u : 0.0, Rinv.p(), l,
+                                        chol_work.p, seg_info.as<int32_t>() + 2 * seg + p));
+                    CK(S.tsmm(Yseg, Rinv, Yn));
+                    Yseg = std::move(Yn);
+                }
+                Xs = std::move(Yseg);
+                CK(op.apply(Xs, Zs));
+            }
         }
         DMat Xn;
-        CK(S.orthonormalize(Yc, have_lock ? &Vlock : nullptr, seed + 1 + (uint64_t)it, Xn));
+        bool seg_failed = false;
+        if (nseg > 1) {
+            std::vector<int32_t> inf((size_t)nseg * 2);
+            CK(S.to_host(seg_info.p, inf.data(), inf.size() * 4));
+            for (int32_t v : inf) seg_failed = seg_failed || v != 0;
+        }
+        if (seg_failed) {          // a segment's block lost rank: nothing of this filter is trusted, and none is cut again
+            segments_ok = false;
+            CK(S.orthonormalize(Xritz, have_lock ? &Vlock : nullptr, seed + 1 + (uint64_t)it, Xn));
+        } else {
+            CK(S.orthonormalize(Yc, have_lock ? &Vlock : nullptr, seed + 1 + (uint64_t)it, Xn));
+        }
         X = std::move(Xn);
     }
     CK(S.hcat(have_lock ? &Vlock : nullptr, X, out.basis));
@@ -976,6 +1043,27 @@ struct GramianOp {
         CK(spmm_t(ctx, A, Yr, Z));
         ++steps;
         return allreduce(Z);
+    }
+    // Z = A^T (A X) with BOTH dense operands gathered from fp32 images (half the bytes per gathered row; fp64 accumulation):
+    // a product rounded to ~6e-8 of its norm — for the late steps of a Lanczos build only (solver.py: products='relaxed').
+    // One rank, blocks of a multiple of four columns.
+    int apply_rounded(const DMat &Xb, DMat &Z) {
+        if (comm || Xb.l % 4 != 0) return apply(Xb, Z);
+        const int64_t nr = A->A.n_rows, nc = A->A.n_cols;
+        const int l = Xb.l;
+        Dev X32((size_t)nc * l * 4), Y32((size_t)nr * l * 4);
+        DMat Y(nr, l);
+        Z = DMat(nc, l);
+        if (!X32.p || !Y32.p || !Y.ok() || !Z.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (rounded gramian step)");
+        hipLaunchKernelGGL(f64_to_f32_kernel, dim3((unsigned)((nc * l + 255) / 256)), dim3(256), 0, ctx->stream, nc * l, Xb.p(), X32.as<float>());
+        CK(spmm(ctx, A->A, X32.p, PK_VAL_F32, l, l, Y.p(), l, Range{0, A->A.plan.n_tasks, 0, A->A.plan.n_long}));
+        hipLaunchKernelGGL(f64_to_f32_kernel, dim3((unsigned)((nr * l + 255) / 256)), dim3(256), 0, ctx->stream, nr * l, Y.p(), Y32.as<float>());
+        for (int64_t bk = 0; bk < A->n_blocks; ++bk) {
+            const int64_t shape3[3] = {bk == 0 ? nc : 0, A->rows_per_block, A->block_nnz[(size_t)bk]};
+            CK(spmm(ctx, *A->Tb, Y32.p, PK_VAL_F32, l, l, Z.p(), l, A->block_ranges[(size_t)bk], bk * nc, bk > 0, shape3));
+        }
+        ++steps;
+        return PK_OK;
     }
     int apply(const DMat &Xb, DMat &Z) {
         DMat Y(A->A.n_rows, Xb.l);
@@ -1043,6 +1131,140 @@ struct DenseOp {
     int rotate(const DMat &Z, const DMat &Cm, DMat &out) { return S.tsmm(Z, Cm, out); }
 };
 
+// ---- the leading pairs of a small dense PSD matrix, with few host reads (round 6) ---------------------------------------
+// The filtered subspace iteration above takes a Rayleigh-Ritz step — an l x l eigen-decomposition and four host reads —
+// after every filter of the degree the SPREAD of the block allows (degree 4-5 on the projected problems of a Lanczos build:
+// theta_1 / theta_l is large), and locks converged pairs with their own projections: ~50 launches and 4-5 reads per outer
+// iteration, 3-5 iterations per look — and a look of a narrow-block build costs nine of its steps.  A dense operator this
+// small needs neither: the filter is applied in SEGMENTS of the allowed degree with a plain shifted CholeskyQR3 in
+// between (no Rayleigh-Ritz, no read, no locking: the block stays l wide), as many segments as the wanted pairs need by the
+// Chebyshev amplification of pair k over the damped interval, then ONE Rayleigh-Ritz step.  A warm look whose start pairs
+// and their Ritz values are known (the previous look's: a leading principal submatrix keeps them) is one such round: two
+// reads.  ok = false hands the problem (and the best orthonormal block) to the subspace iteration: degenerate bounds, a
+// Cholesky breakdown, stagnation.
+static int dense_topk_segments(pk_ctx *ctx, Solver &S, DenseOp &dop, int k, DMat &X, double tol, const double *lam0, double r0_rel,
+                               SubspaceOut &out, bool &ok) {
+    ok = false;
+    const int l = X.l;
+    const int64_t N = X.n;
+    const double spread = 1e7, u = 1.1102230246251565e-16;
+    const int m_max = 24;
+    std::vector<double> lam, res;
+    DMat Zr;                         // T X of the current (rotated) block
+    auto ritz = [&]() -> int {
+        DMat H, Z, Cm, Xr;
+        Dev theta_dev;
+        CK(dop.ritz(X, H, Z));
+        CK(S.eigh(H, lam, Cm, theta_dev));
+        CK(S.tsmm(X, Cm, Xr));
+        CK(S.tsmm(Z, Cm, Zr));
+        CK(S.resid(Zr, Xr, theta_dev, res));
+        X = std::move(Xr);
+        out.outer += 1;
+        return PK_OK;
+    };
+    auto worst_of = [&]() {
+        double w = 0.0;
+        const double lam1 = std::max(lam.empty() ? 0.0 : lam[0], 1e-300);
+        for (int j = 0; j < k && j < (int)res.size(); ++j) w = std::max(w, res[(size_t)j] / lam1);
+        return w;
+    };
+    double worst = 1e-2;
+    bool have_z = false;
+    if (lam0) {
+        lam.assign(lam0, lam0 + l);
+        if (r0_rel >= 0) worst = std::max(r0_rel, tol);
+    } else {
+        CK(ritz());
+        have_z = true;
+        worst = worst_of();
+        if (worst <= tol) {
+            out.lam_all = lam; out.res_act = res; out.n_lock = 0; out.converged = true;
+            out.basis = std::move(X);
+            ok = true;
+            return PK_OK;
+        }
+    }
+    Dev chol_work((size_t)std::max<int64_t>(pk_chol_work_bytes(l), 8)), info(6 * 3 * 4);
+    if (!chol_work.p || !info.p) return fail(ctx, PK_E_LAUNCH, "out of device memory (dense_topk_segments)");
+    for (int round = 0; round < 10; ++round) {
+        const double a0 = lam[0], bnd = lam[(size_t)l - 1];
+        const double e = 0.5 * bnd, c = 0.5 * bnd;
+        if (!(bnd > 0.0) || !(a0 > c) || k > l) return PK_OK;                    // degenerate spectrum estimate: the general iteration
+        const int m = cheb_degree(a0, bnd, spread, m_max);
+        const double xk = std::max(2.0 * lam[(size_t)std::min(k, l) - 1] / bnd - 1.0, 1.0 + 1e-9);
+        const double amp = std::cosh(m * std::acosh(xk));
+        const double need = std::max(worst / tol, 1.0) * 30.0;
+        const int nseg = std::max(1, std::min(6, (int)std::ceil(std::log(need) / std::log(std::max(amp, 1.5)))));
+        HIPCK(hipMemsetAsync(info.p, 0, 6 * 3 * 4, S.st));
+        for (int seg = 0; seg < nseg; ++seg) {
+            DMat Z, Yc, Xc;
+            if (seg == 0 && have_z) Z = std::move(Zr); else CK(dop.apply(X, Z));
+            have_z = false;
+            double sigma = e / (a0 - c);
+            const double tau = 2.0 / sigma;
+            Xc = std::move(X);
+            CK(S.axpbypcz(sigma / e, Z, -c * sigma / e, &Xc, 0.0, nullptr, Yc));
+            for (int s2 = 2; s2 <= m; ++s2) {
+                const double sigma_new = 1.0 / (tau - sigma);
+                DMat Yn;
+                CK(dop.filter_step(Yc, 2.0 * sigma_new / e, -2.0 * sigma_new * c / e, -sigma * sigma_new, Xc, Yn));
+                Xc = std::move(Yc);
+                Yc = std::move(Yn);
+                sigma = sigma_new;
+            }
+            for (int p = 0; p < 3; ++p) {        // shifted CholeskyQR3, verdicts kept on the device
+                DMat G, Rinv(l, l), Yn;
+                if (!Rinv.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (dense_topk_segments)");
+                CK(S.gram(Yc, Yc, G));
+                CK(pk_chol_rinv_f64(S.st, l, G.p(), l, p == 0 ? 11.0 * ((double)N * l + (double)l * (l + 1)) * u : 0.0, Rinv.p(), l, chol_work.p,
+                                    info.as<int32_t>() + 3 * seg + p));
+                CK(S.tsmm(Yc, Rinv, Yn));
+                Yc = std::move(Yn);
+            }
+            X = std::move(Yc);
+        }
+        CK(ritz());
+        have_z = true;
+        int32_t verdicts[18];
+        CK(S.to_host(info.p, verdicts, sizeof verdicts));
+        bool broke = false;
+        for (int32_t v : verdicts) broke = broke || v != 0;
+        for (double v : lam) broke = broke || !(v == v);
+        if (broke) {
+            X = DMat();              // nothing of this block is trusted
+            return PK_OK;
+        }
+        const double now = worst_of();
+        if (now <= tol) {
+            out.lam_all = lam; out.res_act = res; out.n_lock = 0; out.converged = true;
+            out.basis = std::move(X);
+            ok = true;
+            return PK_OK;
+        }
+        if (round >= 1 && now > 0.5 * worst) return PK_OK;       // stagnation: the general iteration takes the (orthonormal) block
+        worst = now;
+    }
+    return PK_OK;
+}
+
+// the k leading pairs of the dense PSD matrix behind `dop` from the orthonormal start block X: segments first, the
+// filtered subspace iteration with locking whenever they hand over
+static int dense_topk(pk_ctx *ctx, Solver &S, DenseOp &dop, int k, DMat X, double tol, int max_outer, uint64_t seed, const double *lam0,
+                      double r0_rel, SubspaceOut &out) {
+    DMat X0;
+    CK(S.col_slice(X, 0, X.l, X0));
+    bool ok = false;
+    CK(dense_topk_segments(ctx, S, dop, k, X, tol, lam0, r0_rel, out, ok));
+    if (ok) return PK_OK;
+    const int outer0 = out.outer;
+    SubspaceOut so;
+    CK(subspace_iteration(ctx, S, dop, k, X.ok() && X.l == X0.l ? std::move(X) : std::move(X0), tol, max_outer, 24, 1e7, seed, false, so));
+    so.outer += outer0;
+    out = std::move(so);
+    return PK_OK;
+}
+
 // ---- block Lanczos with full reorthogonalisation: solver.py::_block_lanczos restated (synchronous looks: the form the
 // Python layer runs with PK_LANCZOS_LAG=0; its side-stream monitors are a host-side scheduling matter) -------------------
 struct LanczosOut {
@@ -1061,8 +1283,8 @@ struct RitzLook {
     bool conv = false;
 };
 
-static int ritz_look(pk_ctx *ctx, Solver &S, const DMat &T, const DMat &Sc, const DMat *warm, int k, int b, int width, double est_tol,
-                     double prior, uint64_t seed, LanczosOut &lo, RitzLook &out) {
+static int ritz_look(pk_ctx *ctx, Solver &S, const DMat &T, const DMat &Sc, const DMat *warm, const std::vector<double> *warm_lam, int k,
+                     int b, int width, double est_tol, double prior, uint64_t seed, LanczosOut &lo, RitzLook &out) {
     const int N = (int)T.n;
     DMat X0;
     auto pad = [&](const DMat *src, int l) -> int {
@@ -1081,7 +1303,10 @@ static int ritz_look(pk_ctx *ctx, Solver &S, const DMat &T, const DMat &Sc, cons
     for (;;) {
         DenseOp dop{ctx, S, T};
         SubspaceOut so;
-        CK(subspace_iteration(ctx, S, dop, k, std::move(X0), t_in, 200, 24, 1e7, seed, false, so));
+        // (the start pairs of a warm look keep their Ritz values, and their residual w.r.t. this T is the old coupling estimate)
+        const bool warm_pairs = warm && warm_lam && (int)warm_lam->size() == X0.l && prior >= 0;
+        CK(dense_topk(ctx, S, dop, k, std::move(X0), t_in, 200, seed, warm_pairs ? warm_lam->data() : nullptr, warm_pairs ? prior : -1.0, so));
+        warm_lam = nullptr;
         lo.nested_outer += so.outer;
         lo.nested_products += dop.products;
         out.basis = std::move(so.basis);
@@ -1136,6 +1361,19 @@ __global__ void mirror_block_kernel(int rows, int b, int ldt, const double *__re
     const int r = i / b, c = i - r * b;
     T[(int64_t)(rows + c) * ldt + r] = C[i];
 }
+// Block column j of T from C = Q^T W when W came from a ROUNDED product (W = B Q_j + E_j, |E_j| ~ 6e-8 |W|): only the band is
+// kept — T[N-2b .. N) x [N-b, N) and the mirror image of its upper block.  Outside the band C holds Q_i^T E_j: noise that is
+// harmless where it stands (it multiplies the small late coefficients of a converging pair) but whose MIRROR image, or the
+// symmetrisation of a look, would set it against the O(1) early coefficients — what stalled round 4's rounded products at
+// 5e-12.  The exact entries there are zero to rounding under full reorthogonalisation.
+__global__ void band_block_kernel(int N, int b, int ldt, const double *__restrict__ C, double *__restrict__ T) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * b) return;
+    const int r = i / b, c = i - r * b;
+    const bool in_band = r >= N - 2 * b;
+    T[(int64_t)r * ldt + (N - b) + c] = in_band ? C[i] : 0.0;
+    if (r < N - b) T[(int64_t)(N - b + c) * ldt + r] = in_band ? C[i] : 0.0;
+}
 __global__ void lanczos_flags_kernel(int l, const double *__restrict__ G, const int32_t *__restrict__ info, double *__restrict__ flags) {
     // flags[0] += Cholesky verdicts of the three passes; flags[1] = max(flags[1], |G - I|_max)  (one workgroup)
     __shared__ double s_max[256];
@@ -1169,23 +1407,28 @@ struct LanczosBuffers {
 // the next block by shifted CholeskyQR3 re-projected against the whole basis in every pass.  Sc = W_perp^T W_perp, the
 // coupling behind the residual estimates.  The ONE statement of the step: the coarse build (block_lanczos below) and the
 // Python layer's build (pk_lanczos_steps; solver.py keeps the looks, their monitors and the decisions) both run it.
-static int lanczos_step(pk_ctx *ctx, Solver &S, GramianOp &gop, int64_t n, int b, int j, bool last, const LanczosBuffers &B, DMat &Sc) {
+static int lanczos_step(pk_ctx *ctx, Solver &S, GramianOp &gop, int64_t n, int b, int j, bool last, const LanczosBuffers &B, DMat &Sc,
+                        bool rounded = false) {
     const int N = j * b;
     const int64_t ldq = B.ldq, ldt = B.ldt;
     const double u = 1.1102230246251565e-16;
     DMat Qj(n, b), W;
     if (!Qj.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (block Lanczos)");
     HIPCK(hipMemcpy2DAsync(Qj.p(), (size_t)b * 8, B.Q + (N - b), (size_t)ldq * 8, (size_t)b * 8, (size_t)n, hipMemcpyDeviceToDevice, S.st));
-    CK(gop.apply(Qj, W));
+    if (rounded) CK(gop.apply_rounded(Qj, W)); else CK(gop.apply(Qj, W));
     // block column j of T = Q^T W, rows of all blocks so far (and its mirror image)
     DMat C(N, b);
     const size_t need = (size_t)pk_gram_work_bytes(n, N, b);
     if (!C.ok() || (need > S.gram_work.bytes && !S.gram_work.alloc(need))) return fail(ctx, PK_E_LAUNCH, "out of device memory (gram)");
     CK(pk_gram_f64(S.st, n, N, b, B.Q, ldq, W.p(), b, C.p(), b, S.gram_work.p));
-    HIPCK(hipMemcpy2DAsync(B.T + (N - b), (size_t)ldt * 8, C.p(), (size_t)b * 8, (size_t)b * 8, (size_t)N, hipMemcpyDeviceToDevice, S.st));
-    if (N > b)
-        hipLaunchKernelGGL(mirror_block_kernel, dim3((unsigned)(((int64_t)(N - b) * b + 255) / 256)), dim3(256), 0, S.st, N - b, b, ldt, C.p(),
-                           B.T);
+    if (rounded && N > 2 * b) {
+        hipLaunchKernelGGL(band_block_kernel, dim3((unsigned)(((int64_t)N * b + 255) / 256)), dim3(256), 0, S.st, N, b, (int)ldt, C.p(), B.T);
+    } else {
+        HIPCK(hipMemcpy2DAsync(B.T + (N - b), (size_t)ldt * 8, C.p(), (size_t)b * 8, (size_t)b * 8, (size_t)N, hipMemcpyDeviceToDevice, S.st));
+        if (N > b)
+            hipLaunchKernelGGL(mirror_block_kernel, dim3((unsigned)(((int64_t)(N - b) * b + 255) / 256)), dim3(256), 0, S.st, N - b, b, ldt, C.p(),
+                               B.T);
+    }
     if (!last) {
         // solver.py::_next_lanczos_block: shifted CholeskyQR3, re-projected against the whole basis in every pass
         HIPCK(hipMemsetAsync(B.info, 0, 12, S.st));
@@ -1285,7 +1528,8 @@ static int block_lanczos(pk_ctx *ctx, Solver &S, GramianOp &gop, int64_t n, int 
         if (!Tj.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (block Lanczos)");
         hipLaunchKernelGGL(sym_block_kernel, dim3((unsigned)(((int64_t)N * N + 255) / 256)), dim3(256), 0, S.st, N, T.l, T.p(), Tj.p());
         RitzLook nl;
-        CK(ritz_look(ctx, S, Tj, Sc, have_warm ? &look.basis : nullptr, k, b, l, est_tol, hist.empty() ? -1.0 : hist.back().second,
+        CK(ritz_look(ctx, S, Tj, Sc, have_warm ? &look.basis : nullptr, have_warm ? &look.lam_all : nullptr, k, b, l, est_tol,
+                     hist.empty() ? -1.0 : hist.back().second,
                      seed + 1000ull * (uint64_t)j, out, nl));
         look = std::move(nl);
         have_warm = true;
@@ -1519,7 +1763,8 @@ extern "C" int pk_mat_wrap_device(pk_ctx *ctx, void *stream, int64_t n_rows, int
 }
 
 extern "C" int pk_lanczos_steps(pk_ctx *ctx, void *stream, pk_mat *A, int32_t b, int32_t j0, int32_t m, int32_t last_closes,
-                                double *Q_dev, int64_t ldq, double *T_dev, int64_t ldt, double *S_out_dev, double *flags_dev) {
+                                double *Q_dev, int64_t ldq, double *T_dev, int64_t ldt, double *S_out_dev, double *flags_dev,
+                                int32_t rounded) {
     if (!ctx || !A) return PK_E_INVALID;
     std::lock_guard<std::mutex> lock(ctx->mu);
     PoolScope pool_scope(ctx);
@@ -1535,7 +1780,8 @@ extern "C" int pk_lanczos_steps(pk_ctx *ctx, void *stream, pk_mat *A, int32_t b,
     if (!info.p || !chol_work.p) return fail(ctx, PK_E_LAUNCH, "out of device memory (pk_lanczos_steps)");
     for (int j = j0 + 1; j <= j0 + m; ++j) {
         DMat Sc;
-        CK(lanczos_step(ctx, S, gop, n, b, j, last_closes && j == j0 + m, LanczosBuffers{Q_dev, ldq, T_dev, ldt, flags_dev, info.as<int32_t>(), chol_work.p}, Sc));
+        CK(lanczos_step(ctx, S, gop, n, b, j, last_closes && j == j0 + m, LanczosBuffers{Q_dev, ldq, T_dev, ldt, flags_dev, info.as<int32_t>(), chol_work.p}, Sc,
+                        rounded != 0));
         if (j == j0 + m) HIPCK(hipMemcpyAsync(S_out_dev, Sc.p(), (size_t)b * b * 8, hipMemcpyDeviceToDevice, ctx->stream));
     }
     return PK_OK;
@@ -1561,6 +1807,40 @@ extern "C" int pk_gramian_apply_f64(pk_ctx *ctx, void *stream, pk_mat *A, int32_
     return PK_OK;
 }
 
+// The fp32 image of the item factors the approximate fold-in gathers from (polara_amd/scoring.py::FactorImage; the serving
+// handle below builds the same): out [n x ld32] = fl32(V) in columns 0..K-1, the row-norm bound in column K, zeros beyond;
+// stat_dev[0] = the bits of the largest bound (non-negative floats order like their bits), stat_dev[1] != 0 when an entry
+// of V or a bound is not finite — the two numbers FactorImage's range check needs, in the same launch.
+__global__ void v32_image_stat_kernel(int64_t n, int K, int ld32, const double *__restrict__ V, int64_t ldv, const float *__restrict__ bound,
+                                      float *__restrict__ out, uint32_t *__restrict__ stat) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * ld32) return;
+    const int64_t r = i / ld32;
+    const int c = (int)(i - r * ld32);
+    float v = 0.0f;
+    if (c < K) {
+        const double d = V[r * ldv + c];
+        v = (float)d;
+        if (!(fabs(d) <= 1.7976931348623157e308)) atomicOr(&stat[1], 1u);
+    } else if (c == K) {
+        v = bound[r];
+        if (!(v >= 0.0f && v <= 3.4028234e38f)) atomicOr(&stat[1], 1u); else atomicMax(&stat[0], __float_as_uint(v));
+    }
+    out[i] = v;
+}
+
+extern "C" int pk_v32_image_f32(void *stream, int64_t n, int32_t K, int32_t ld32, const double *V_dev, int64_t ldv, const float *bound_dev,
+                                float *out_dev, uint32_t *stat_dev) {
+    PK_REQUIRE(n >= 0 && K >= 1 && ld32 > K && ldv >= K && V_dev && bound_dev && out_dev && stat_dev, "pk_v32_image_f32: bad arguments");
+    hipStream_t st = pk_stream(stream);
+    (void)hipMemsetAsync(stat_dev, 0, 8, st);
+    if (n > 0)
+        hipLaunchKernelGGL(v32_image_stat_kernel, dim3((unsigned)(((size_t)n * ld32 + 255) / 256)), dim3(256), 0, st, n, K, ld32, V_dev, ldv, bound_dev,
+                           out_dev, stat_dev);
+    PK_CHECK_LAUNCH("v32_image_stat_kernel");
+    return PK_OK;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // pk_sym_eig_topk_f64: the k leading eigenpairs of a small dense symmetric PSD matrix that lives on the device — the
 // projected problem T = Q^T (A^T A) Q of the block Lanczos build (solver.py::_block_lanczos; the reference's svds solves
@@ -1571,7 +1851,7 @@ extern "C" int pk_gramian_apply_f64(pk_ctx *ctx, void *stream, pk_mat *A, int32_
 extern "C" int pk_sym_eig_topk_f64(pk_ctx *ctx, void *stream, int32_t n, const double *T_dev, int64_t ldt, int32_t k, int32_t l,
                                    const double *X0_dev, int64_t ldx0, int32_t x0_rows, double tol, int32_t max_outer, uint64_t seed,
                                    double *basis_out_dev, int64_t ldb, double *lam_out_host, double *res_out_host,
-                                   int32_t *counts_out) {
+                                   int32_t *counts_out, const double *lam0_host, double r0_rel) {
     if (!ctx) return PK_E_INVALID;
     std::lock_guard<std::mutex> lock(ctx->mu);
     PoolScope pool_scope(ctx);
@@ -1594,7 +1874,7 @@ extern "C" int pk_sym_eig_topk_f64(pk_ctx *ctx, void *stream, int32_t n, const d
     }
     DenseOp dop{ctx, S, T};
     SubspaceOut so;
-    CK(subspace_iteration(ctx, S, dop, k, std::move(X), tol, max_outer, 24, 1e7, seed, false, so));
+    CK(dense_topk(ctx, S, dop, k, std::move(X), tol, max_outer, seed, X0_dev ? lam0_host : nullptr, r0_rel, so));
     const int w = std::min<int>(l, so.basis.l);
     HIPCK(hipMemcpy2DAsync(basis_out_dev, (size_t)ldb * 8, so.basis.p(), (size_t)so.basis.l * 8, (size_t)w * 8, (size_t)n,
                            hipMemcpyDeviceToDevice, st));

@@ -1024,6 +1024,64 @@ extern "C" int pk_row_plan_fill(void *stream, int64_t n_rows, const int64_t *ind
     return PK_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The serving order of the catalogue: rows of the item factors by DESCENDING Euclidean norm, ties by row id (what
+// `np.argsort(-np.linalg.norm(V, axis=1), kind='stable')` gives the plugin surface, models.py:849 keeps V as built; the
+// re-indexing is ours — the pruning bound of the candidate sweep is a suffix maximum of these norms).  Own radix sort on the
+// bit pattern of the fp64 norms (non-negative doubles order like their bits; complemented: descending), one gather.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void row_norm_keys_kernel(int64_t n, int K, const double *__restrict__ V, int64_t ldv,
+                                                            uint64_t *__restrict__ keys, uint32_t *__restrict__ ids) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double *row = V + i * ldv;
+    double s = 0.0;
+    for (int c = 0; c < K; ++c) s = fma(row[c], row[c], s);
+    double nv = sqrt(s);
+    if (!(nv == nv)) nv = 0.0;          // a NaN row sorts last
+    keys[i] = ~static_cast<uint64_t>(__double_as_longlong(nv));
+    ids[i] = (uint32_t)i;
+}
+__global__ __launch_bounds__(256) void norm_order_finish_kernel(int64_t n, int K, const uint32_t *__restrict__ sorted_ids,
+                                                                const double *__restrict__ V, int64_t ldv, int32_t *__restrict__ order,
+                                                                int32_t *__restrict__ rank, double *__restrict__ V_sorted) {
+    // one wave per output row: position p takes row sorted_ids[p]
+    const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= n) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t src = sorted_ids[p];
+    if (lane == 0) {
+        order[p] = (int32_t)src;
+        rank[src] = (int32_t)p;
+    }
+    if (V_sorted)
+        for (int c = lane; c < K; c += 64) V_sorted[p * K + c] = V[(int64_t)src * ldv + c];
+}
+
+extern "C" int64_t pk_row_norm_order_work_bytes(int64_t n) {
+    const int64_t m = n > 0 ? n : 1;
+    return 2 * (((m * 8 + 255) / 256) * 256) + 2 * (((m * 4 + 255) / 256) * 256) + pk_radix_work_bytes(m);
+}
+
+extern "C" int pk_row_norm_order_f64(void *stream, int64_t n, int32_t K, const double *V_dev, int64_t ldv, int32_t *order_dev,
+                                     int32_t *rank_dev, double *V_sorted_dev, void *work_dev) {
+    PK_REQUIRE(n >= 0 && n < (1ll << 31) && K >= 1 && ldv >= K, "pk_row_norm_order_f64: bad sizes n=%lld K=%d", (long long)n, K);
+    if (n == 0) return PK_OK;
+    PK_REQUIRE(V_dev && order_dev && rank_dev && work_dev, "pk_row_norm_order_f64: null buffer");
+    hipStream_t st = pk_stream(stream);
+    char *w = static_cast<char *>(work_dev);
+    auto take = [&](int64_t bytes) { char *p = w; w += ((bytes + 255) / 256) * 256; return p; };
+    uint64_t *keys = reinterpret_cast<uint64_t *>(take(n * 8)), *keys_t = reinterpret_cast<uint64_t *>(take(n * 8));
+    uint32_t *ids = reinterpret_cast<uint32_t *>(take(n * 4)), *ids_t = reinterpret_cast<uint32_t *>(take(n * 4));
+    hipLaunchKernelGGL(row_norm_keys_kernel, dim3((unsigned)pk_ceil_div(n, 256)), dim3(256), 0, st, n, K, V_dev, ldv, keys, ids);
+    int in_tmp = 0;
+    pk_radix_sort<uint64_t>(st, n, keys, ids, keys_t, ids_t, 64, w, &in_tmp);
+    hipLaunchKernelGGL(norm_order_finish_kernel, dim3((unsigned)pk_ceil_div(n, 4)), dim3(256), 0, st, n, K, in_tmp ? ids_t : ids, V_dev, ldv,
+                       order_dev, rank_dev, V_sorted_dev);
+    PK_CHECK_LAUNCH("row norm order kernels");
+    return PK_OK;
+}
+
 // eager load of this translation unit's code object (pk_warm_up, api.cpp): the runtime loads a code object at the first
 // launch of one of its kernels — or when a kernel's attributes are asked for, which costs no launch
 hipError_t pk_tu_load_ingest() {

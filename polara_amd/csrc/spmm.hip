@@ -162,8 +162,10 @@ __device__ __forceinline__ void spmm_groups_task(
     // (16 steps: slower, occupancy; 8 steps for the fp64 block: slower too, 3.30 -> 4.07 ms.)
     // narrow instances (round 4): GROUPS = 8 / 16 — 8 / 4 lanes per gathered row for <= 32 / <= 16 fp64 columns, so
     // that a narrow panel does not idle three quarters of every gather instruction's lanes the way GROUPS = 4 does at nc = 16
-    constexpr int U = XF ? 8 : (GROUPS == 16 ? 2 : PK_SPMM_U_F64);
-    static_assert(!XF || GROUPS <= 4, "the fp32 dense block runs on GROUPS <= 4 only");
+    // (round 6: the fp32 block also runs on the narrow mappings — 16 / 32 fp32 columns are ONE 16-byte load per lane of a 4- / 8-lane
+    // group: the rounded late products of a block Lanczos build, driver.hip::lanczos_step; a chunk holds 64 / GROUPS wave steps
+    // and the two register files alternate an even number of sets, so 2 / 4 steps per set there)
+    constexpr int U = XF ? (GROUPS <= 4 ? 8 : (GROUPS == 8 ? 4 : 2)) : (GROUPS == 16 ? 2 : PK_SPMM_U_F64);
     using XA = typename std::conditional<XF, float4, double2>::type;
     const int64_t p0 = task_begin[task];
     const int n = (int)(task_end[task] - p0);
@@ -408,7 +410,9 @@ static int launch_spmm(hipStream_t st, int64_t n_tasks, const int32_t *task_row,
         if (accumulate) { if (off32) PK_SPMM_LAUNCH_F(G, true, true); else PK_SPMM_LAUNCH_F(G, true, false); }       \
         else { if (off32) PK_SPMM_LAUNCH_F(G, false, true); else PK_SPMM_LAUNCH_F(G, false, false); }                \
     } while (0)
-        if (nc <= 64) PK_SPMM_GROUPS_F(4);
+        if (nc <= 16) PK_SPMM_GROUPS_F(16);
+        else if (nc <= 32) PK_SPMM_GROUPS_F(8);
+        else if (nc <= 64) PK_SPMM_GROUPS_F(4);
         else if (nc <= 128) PK_SPMM_GROUPS_F(2);
         else PK_SPMM_GROUPS_F(1);
 #undef PK_SPMM_GROUPS_F

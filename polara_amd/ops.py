@@ -297,11 +297,11 @@ class LanczosRecurrence:
             for i in range(min(n, cap)):
                 rows.append((_Elapsed(float(ms[i])), None, tuple(int(v) for v in meta[i])))
 
-    def steps(self, Q, T, S_out, flags, j0, m, last_closes):
+    def steps(self, Q, T, S_out, flags, j0, m, last_closes, rounded=False):
         self._timing()
         assert Q.stride(1) == 1 and T.stride(1) == 1 and S_out.is_contiguous() and S_out.shape == (self.b, self.b)
         _lib.check(self.ops.lib.pk_lanczos_steps(self.ctx, self._stream(), self.handle, self.b, int(j0), int(m), 1 if last_closes else 0,
-                                                 _ptr(Q), Q.stride(0), _ptr(T), T.stride(0), _ptr(S_out), _ptr(flags)),
+                                                 _ptr(Q), Q.stride(0), _ptr(T), T.stride(0), _ptr(S_out), _ptr(flags), 1 if rounded else 0),
                    'pk_lanczos_steps', self.ops.lib, self.ctx)
 
     def gramian(self, X):
@@ -457,6 +457,13 @@ class HipOps:
             rec = cache[int(block_cols)] = LanczosRecurrence(self, A, block_cols)
         return rec
 
+    def monitor_stream(self):
+        """the side stream of the solver's monitors: HIGH priority, so that the microsecond kernels of a nested solve are
+        dispatched ahead of the queued workgroups of the sparse products they run next to"""
+        if getattr(self, '_monitor_stream', None) is None:
+            self._monitor_stream = torch.cuda.Stream(device=self.device, priority=-1)
+        return self._monitor_stream
+
     def aux_streams(self, n):
         """n side streams (created once) for pipelining independent user batches"""
         while len(self._aux_streams) < n:
@@ -578,6 +585,20 @@ class HipOps:
         rank[inv.long()] = torch.arange(n, dtype=torch.int32, device=self.device)
         host = torch.cat([rank, inv, counts]).cpu().numpy()
         return host[:n].copy(), host[n:2 * n].copy(), host[2 * n:].astype(np.int64), rank
+
+    def norm_order(self, V, gather=True):
+        """The serving order of the catalogue (pk_row_norm_order_f64): (order int32 [n]: position -> row, rank int32 [n]:
+        row -> position, V in that order or None) — rows of V by descending Euclidean norm, ties by id, own radix sort and
+        one gather on the device (no library sort, no elementwise plumbing inside a build)."""
+        assert V.dtype == torch.float64 and V.dim() == 2 and V.stride(1) == 1
+        n, K = int(V.shape[0]), int(V.shape[1])
+        order = torch.empty(n, dtype=torch.int32, device=self.device)
+        rank = torch.empty(n, dtype=torch.int32, device=self.device)
+        Vs = torch.empty((n, K), dtype=torch.float64, device=self.device) if gather else None
+        work = self._work(self.lib.pk_row_norm_order_work_bytes(n))
+        _lib.check(self.lib.pk_row_norm_order_f64(self.stream(), n, K, _ptr(V), V.stride(0), _ptr(order), _ptr(rank),
+                                                  _ptr(Vs) if gather else None, _ptr(work)), 'pk_row_norm_order_f64')
+        return order, rank, Vs
 
     def bincount(self, keys, n_bins):
         """int64 [n_bins] (device): occurrences of each key of a device int64 tensor (pk_count_i32 on the narrowed keys)."""
@@ -941,7 +962,7 @@ class HipOps:
                                             _ptr(Z), Z.stride(0), _ptr(out), out.stride(0)), 'pk_tsmm_sub_f64')
         return out
 
-    def sym_eig_topk(self, T, k, X0=None, tol=1e-13, max_outer=200, seed=0, stats=None):
+    def sym_eig_topk(self, T, k, X0=None, tol=1e-13, max_outer=200, seed=0, stats=None, lam0=None, r0_rel=-1.0):
         """The k leading eigenpairs of the small dense symmetric PSD device matrix T [n x n] — pk_sym_eig_topk_f64: the
         filtered subspace iteration of solver.py with T as the operator, driven from C++ (hundreds of microsecond
         kernels: from Python each would cost the host ~20 us).  X0: orthonormal start block [rows <= n x l] (missing rows
@@ -952,6 +973,9 @@ class HipOps:
         if X0 is not None:
             X0 = X0.contiguous()
             l = int(X0.shape[1])
+            if lam0 is not None:      # the Ritz values of the start pairs (a warm look: pk_sym_eig_topk_f64 then skips its first Rayleigh-Ritz step)
+                lam0 = np.ascontiguousarray(lam0, dtype=np.float64)
+                lam0 = lam0 if len(lam0) == l else None
         else:
             l = min(n, max(int(k), 8))
         if self._ctx is None:
@@ -966,7 +990,8 @@ class HipOps:
                                           _ptr(X0) if X0 is not None else None, l, int(X0.shape[0]) if X0 is not None else 0,
                                           float(tol), int(max_outer), int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(basis), l,
                                           lam.ctypes.data_as(C.c_void_p), res.ctypes.data_as(C.c_void_p),
-                                          counts.ctypes.data_as(C.c_void_p))
+                                          counts.ctypes.data_as(C.c_void_p),
+                                          lam0.ctypes.data_as(C.c_void_p) if lam0 is not None else None, float(r0_rel))
         if rc != 0:
             raise RuntimeError('pk_sym_eig_topk_f64: ' + (self.lib.pk_ctx_error(self._ctx) or b'').decode())
         if stats is not None:
@@ -1110,6 +1135,19 @@ class HipOps:
         _lib.check(self.lib.pk_row_norm_bound_f32(self.stream(), M.shape[0], M.shape[1], _ptr(M), M.stride(0),
                                                   _ptr(out)), 'pk_row_norm_bound_f32')
         return out
+
+    def v32_image(self, V, bound, ld):
+        """(fp32 image [n x ld] of fp64 V with `bound` in column K and zeros beyond, largest bound, all finite?) —
+        pk_v32_image_f32: one launch and one 8-byte read instead of the fills, casts, index writes and the norm reduction of
+        the host layer's first version (each a torch kernel whose code object a process loaded inside its first build)."""
+        assert V.stride(1) == 1 and V.dtype == torch.float64 and bound.dtype == torch.float32
+        n, K = int(V.shape[0]), int(V.shape[1])
+        out = torch.empty((n, int(ld)), dtype=torch.float32, device=self.device)
+        stat = torch.empty(2, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.pk_v32_image_f32(self.stream(), n, K, int(ld), _ptr(V), V.stride(0), _ptr(bound), _ptr(out), _ptr(stat)),
+                   'pk_v32_image_f32')
+        h = stat.cpu().numpy().view(np.uint32)
+        return out, float(np.array([h[0]], dtype=np.uint32).view(np.float32)[0]), not bool(h[1])
 
     def tile_norm_bound(self, V):
         """float32 [ceil(n/32)]: upper bound of max ||V[i,:]|| over all rows i >= 32*tile (suffix maximum)."""

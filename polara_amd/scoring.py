@@ -40,30 +40,40 @@ class FactorImage:
         # kernel (any rank) — the same lists, no fragment image needed
         self.fused = self.K <= MAX_FUSED_RANK
         self.Vp = ops.pack_frag(self.V) if self.fused else None
-        self.vmax = float(torch.linalg.vector_norm(self.V, dim=1).max().item())
-        if not np.isfinite(self.vmax) or (self.vmax != 0.0 and not 1e-30 < self.vmax < 1e30):
+        if not self.fused:
+            self.vmax = float(torch.linalg.vector_norm(self.V, dim=1).max().item())
+            if not np.isfinite(self.vmax) or (self.vmax != 0.0 and not 1e-30 < self.vmax < 1e30):
+                raise ValueError('item factors with max row norm %g are outside the range the scoring kernels work in' % self.vmax)
+            self.Q20 = self.tile_bound = self.V32x = self.vnorm = None
+            self.Kx = self.K
+            return
+        self.vnorm = ops.row_norm_bound(self.V)       # fp32 upper bounds of the rows' norms (fold-in weight column, certification)
+        # fp32 image for the approximate fold-in: columns 0..K-1 = fl32(V), column K = an upper bound of the
+        # row norm (so the same product also yields w_u = sum_j a_uj ||V_j||, the weight of the fold-in's
+        # rounding error), zero padding to a multiple of 4 columns (one 16-byte load = 4 columns).
+        # Rows start on cache-line boundaries (stride = Kx rounded up to 32 floats = 128 B, or to a power of two
+        # below that): the fold-in is bound by the number of lines its row gathers touch, and a 208-byte row at
+        # stride 208 straddles 2.6 lines on average instead of 2 (measured on S-1M: 2.00 -> 1.86 ms per fold-in).
+        # ONE launch builds it and returns the two numbers of the range check (ops.v32_image): the largest row-norm bound
+        # and whether everything is finite.
+        self.Kx = -(-(self.K + 1) // 4) * 4
+        ld = -(-self.Kx // 32) * 32 if self.Kx > 16 else (4 if self.Kx <= 4 else 8 if self.Kx <= 8 else 16)
+        if hasattr(ops, 'v32_image'):
+            image, self.vmax, finite = ops.v32_image(self.V, self.vnorm, ld)
+        else:          # (the CPU double of the tests)
+            image = torch.zeros(self.n_items, ld, dtype=torch.float32, device=self.V.device)
+            image[:, :self.K] = self.V.to(torch.float32)
+            image[:, self.K] = self.vnorm
+            self.vmax = float(torch.linalg.vector_norm(self.V, dim=1).max().item())
+            finite = bool(np.isfinite(self.vmax))
+        if not finite or (self.vmax != 0.0 and not 1e-30 < self.vmax < 1e30):
             # the candidate sweep and the approximate fold-in work on fp32 images of the factors; their error
             # bounds are norm-wise (2^-24 * max||V_i||) and hold as long as that scale is an fp32 NORMAL number
             raise ValueError('item factors with max row norm %g are outside the range the fp32 candidate sweep '
-                             'works in (rescale the factors)' % self.vmax)
+                             'works in (rescale the factors)' % (self.vmax if finite else float('nan')))
         self.Q20 = None
-        if not self.fused:
-            self.tile_bound = self.V32x = self.vnorm = None
-            self.Kx = self.K
-            return
         self.tile_bound = ops.tile_norm_bound(self.V)   # exact pruning bound of the candidate sweep
-        # fp32 image for the approximate fold-in: columns 0..K-1 = fl32(V), column K = an upper bound of the
-        # row norm (so the same product also yields w_u = sum_j a_uj ||V_j||, the weight of the fold-in's
-        # rounding error), zero padding to a multiple of 4 columns (one 16-byte load = 4 columns)
-        self.Kx = -(-(self.K + 1) // 4) * 4
-        # rows start on cache-line boundaries (stride = Kx rounded up to 32 floats = 128 B, or to a power of two
-        # below that): the fold-in is bound by the number of lines its row gathers touch, and a 208-byte row at
-        # stride 208 straddles 2.6 lines on average instead of 2 (measured on S-1M: 2.00 -> 1.86 ms per fold-in)
-        ld = -(-self.Kx // 32) * 32 if self.Kx > 16 else (4 if self.Kx <= 4 else 8 if self.Kx <= 8 else 16)
-        self.V32x = torch.zeros(self.n_items, ld, dtype=torch.float32, device=self.V.device)[:, :self.Kx]
-        self.V32x[:, :self.K] = self.V.to(torch.float32)
-        self.vnorm = ops.row_norm_bound(self.V)       # fp32 upper bounds of the rows' norms (fold-in weight column, certification)
-        self.V32x[:, self.K] = self.vnorm
+        self.V32x = image[:, :self.Kx]
         # packed image for the approximate fold-in (csrc/foldq.hip): 20-bit block fixed point, half the bytes and lines
         # per gathered entry of the fp32 image; its own error weights D_j (exact, from the bits written) take the
         # place of the norm column, so column K of the product is again a w_u with ||E' - E|| <= 2^-24 w_u

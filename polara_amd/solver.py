@@ -34,6 +34,7 @@ import math
 import numpy as np
 import torch
 
+DEFAULT_PRODUCTS = 'f64'   # what `svd_topk(products='auto')` means: 'f64', or 'relaxed' = the late steps of a one-process Lanczos build gather fp32 images
 DEFAULT_METHOD = 'auto'    # what `svd_topk(method=None)` means; tests pin 'lanczos' / 'subspace' here (a module attribute, not the environment)
 MAX_KRYLOV_COLS = 4096     # widest operand of pk_gram_f64 (csrc/dense.hip): the Krylov basis of a block Lanczos build stays below it
 
@@ -445,7 +446,7 @@ class _LanczosBreakdown(RuntimeError):
     `svd_topk` then runs the filtered subspace iteration, which has a rebuild path for exactly these matrices."""
 
 
-def _ritz_check(ops, Tj, S, X0, k, b, est_tol, prior, seed, inner, final=False, width=None):
+def _ritz_check(ops, Tj, S, X0, k, b, est_tol, prior, seed, inner, final=False, width=None, lam0=None):
     """The k leading Ritz pairs of T_j and estimates of their residuals (one per pair, relative to theta_1).
     The pairs come in stages: while the outer method is far from converged an ESTIMATE is all a check needs, so the nested
     iteration first runs to a loose tolerance and is tightened (warm) only while its own residual, not the coupling to the
@@ -458,8 +459,10 @@ def _ritz_check(ops, Tj, S, X0, k, b, est_tol, prior, seed, inner, final=False, 
     t_in = max(0.3 * est_tol, 1e-4 if prior is None else 0.03 * prior)
     if final:                # the look at the step the pairs are predicted to have converged at: straight to the end
         t_in = 0.3 * est_tol
+    r0 = -1.0 if (lam0 is None or prior is None) else float(prior)     # the start pairs' residual w.r.t. THIS T: their old coupling estimate
     while True:
-        basis, lam_all, res_in, n_lock, conv_in = ops.sym_eig_topk(Tj, k, X0, t_in, 200, seed, inner)
+        basis, lam_all, res_in, n_lock, conv_in = ops.sym_eig_topk(Tj, k, X0, t_in, 200, seed, inner, lam0=lam0, r0_rel=r0)
+        lam0, r0 = None, -1.0                # (a tightened pass starts from pairs of THIS T: no Rayleigh-Ritz step is skipped)
         X0 = basis.contiguous()
         Yk = X0[:, :k].contiguous()
         TY = ops.gram(Tj, Yk)
@@ -491,7 +494,7 @@ class _Monitor:
     The result is collected at a FIXED number of steps after the launch (blocking if need be), so every rank of a sharded
     build takes its decisions at the same steps from the same numbers."""
 
-    def __init__(self, ops, j, Tj, S, X0, k, b, est_tol, prior, seed, inner, flags=None, width=None):
+    def __init__(self, ops, j, Tj, S, X0, k, b, est_tol, prior, seed, inner, flags=None, width=None, lam0=None):
         import threading
         self.j = j
         self.out = self.err = None
@@ -502,7 +505,7 @@ class _Monitor:
         cuda = dev is not None and getattr(dev, 'type', 'cpu') == 'cuda'
         side = None
         if cuda:
-            side = ops.aux_streams(1)[0]
+            side = ops.monitor_stream() if hasattr(ops, 'monitor_stream') else ops.aux_streams(1)[0]
             side.wait_stream(torch.cuda.current_stream(dev))      # the snapshot of T_j and S is complete
             for t in (Tj, S, X0, fsnap):
                 if t is not None:
@@ -515,12 +518,12 @@ class _Monitor:
                     with torch.cuda.stream(side):
                         if fsnap is not None:
                             _raise_on_breakdown(ops.to_host(fsnap), j)
-                        self.out = _ritz_check(ops, Tj, S, X0, k, b, est_tol, prior, seed, inner, width=width)
+                        self.out = _ritz_check(ops, Tj, S, X0, k, b, est_tol, prior, seed, inner, width=width, lam0=lam0)
                         side.synchronize()
                 else:
                     if fsnap is not None:
                         _raise_on_breakdown(ops.to_host(fsnap), j)
-                    self.out = _ritz_check(ops, Tj, S, X0, k, b, est_tol, prior, seed, inner, width=width)
+                    self.out = _ritz_check(ops, Tj, S, X0, k, b, est_tol, prior, seed, inner, width=width, lam0=lam0)
             except BaseException as exc:        # re-raised by join() in the thread that owns the build
                 self.err = exc
         self.thread = threading.Thread(target=work, name='pk-lanczos-monitor', daemon=True)
@@ -534,7 +537,7 @@ class _Monitor:
 
 
 def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_steps, m_max, spread, even_lock, kb=None,
-                   monitor_lag=None, t_step=None, steps_model=None):
+                   monitor_lag=None, t_step=None, steps_model=None, first_look=None, products='f64'):
     """Block Lanczos on B = A^T A with FULL reorthogonalisation and Rayleigh-Ritz over the WHOLE Krylov space
     span[X, B X, ..., B^(q-1) X] — the Krylov-class method behind the reference's `svds` (ARPACK: single-vector implicitly
     restarted Lanczos on the same operator, models.py:844), in the block form a GPU wants.  One Gramian step per block:
@@ -571,6 +574,11 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
     if _library_recurrence(ops, A, comm, lay.sharded):
         rec = ops.lanczos_recurrence(A, b)
     stats['recurrence'] = 'library' if rec is not None else 'composition'
+    if rec is not None:
+        # one process: nothing is exchanged, but the same relaxation applies to the PRODUCTS — the late steps gather fp32 images
+        # of their dense blocks (half the bytes per gathered row; pk_lanczos_steps(rounded)); `lay.relaxed` / `lay.exchange_dtype`
+        # carry the state for both forms (gate, verification in fp64, fall-back)
+        lay.relaxed = products == 'relaxed' and b % 4 == 0
     S_buf = ops.zeros(b, b) if rec is not None else None
     cap = min(qcap, 20)
     Qbuf = ops.empty(lay.rows, cap * b)
@@ -578,7 +586,7 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
     flags = ops.zeros(2)                  # [sum of Cholesky verdicts, max distance of the last pass's Gram matrix from I]
     Q1 = orthonormalize(lay, lay.randn(b, seed))
     Qbuf[:, :b] = Q1
-    warm = None
+    warm = warm_lam = None
     inner = dict(steps=0, outer=0, checks=0)
     stats['nested'] = inner
     hist = []                              # (step, worst relative residual estimate of the k leading pairs)
@@ -596,7 +604,9 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
     stats['monitor_lag'] = LAG
     use_monitor = LAG > 0
     first = max(4, -(-2 * k // b) + 2, -(-l // b))
-    if steps_model:
+    if first_look is not None:
+        first = max(-(-l // b), int(first_look))
+    elif steps_model:
         first = max(first, int(math.ceil(0.5 * steps_model)))
     prior_rate = 0.8 * 1.72 * (b / 16.0) ** 0.27      # natural log per step, late phase: x5.6 / x8.2 / x12 per step at b = 16 / 32 / 64 (measured), less a fifth
     next_look = min(first, qcap)           # the step of the next monitor, or of the final check once the rate is known
@@ -628,7 +638,7 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
     def relax_now(j_now):
         if relax_at[0] is not None and j_now >= relax_at[0] and getattr(lay, 'relaxed', False) and lay.exchange_dtype is None:
             lay.exchange_dtype = torch.float32
-            stats['exchange_relaxed_from'] = j_now + 1
+            stats['exchange_relaxed_from' if rec is None else 'products_rounded_from'] = j_now + 1
 
     def plan(j_now):
         """the step of the next look from the history of estimates; (step, final?)"""
@@ -654,7 +664,7 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
             last = j == qcap
             relax_now(j - 1)
             if rec is not None:
-                rec.steps(Qbuf, T, S_buf, flags, j - 1, 1, last)
+                rec.steps(Qbuf, T, S_buf, flags, j - 1, 1, last, rounded=lay.exchange_dtype is not None)
                 stats['gramian_steps'] += 1
                 stats['spmm_cols'] += b
                 S = S_buf
@@ -682,7 +692,7 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
                 out = monitor.join()
                 stats.setdefault('monitor_wait_ms', []).append(round(1e3 * (time.perf_counter() - t_w), 3))
                 jm, monitor = monitor.j, None
-                warm = out['basis']
+                warm, warm_lam = out['basis'], out['lam_all']
                 hist.append((jm, out['worst']))
                 relax_gate(out['worst'], jm, j)
                 if verbose and comm.rank == 0:
@@ -701,16 +711,16 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
             if not (look_is_final or last):
                 # ---- launch a monitor on the side stream and keep stepping (it reads the breakdown flags too) ---
                 monitor = _Monitor(ops, j, snapshot(N), S.clone() if rec is not None else S, warm, k, b, est_tol, hist[-1][1] if hist else None,
-                                   seed + 1000 * j, inner, flags=flags, width=l)
+                                   seed + 1000 * j, inner, flags=flags, width=l, lam0=warm_lam)
                 next_look = qcap + 1           # decided when the monitor comes back
                 continue
             # ---- the pairs of T_j on the main stream, and their verification ------------------------------------
             t_w = time.perf_counter()
             breakdown_check(j)
             out = _ritz_check(ops, snapshot(N), S, warm, k, b, est_tol, hist[-1][1] if hist else None, seed + 1000 * j, inner,
-                              final=len(hist) >= 1, width=l)
+                              final=len(hist) >= 1, width=l, lam0=warm_lam)
             stats.setdefault('look_ms', []).append(round(1e3 * (time.perf_counter() - t_w), 3))    # includes draining the steps queued before it
-            warm = out['basis']
+            warm, warm_lam = out['basis'], out['lam_all']
             hist.append((j, out['worst']))
             if verbose and comm.rank == 0:
                 print('[svd] lanczos step %2d  dim %4d  worst rel.res (first %d) %.2e  nested so far: %d outer, %d products, inner converged %s'
@@ -881,7 +891,7 @@ def prepare_operator(ops, A, k, comm=None, **kw):
 
 def svd_topk(ops, A, k, block=None, tol=1e-12, max_outer=200, m_max=24, spread=1e7, seed=0,
              comm=None, want_u=False, verbose=False, even_lock=True, shard_items=True, method=None, max_steps=None,
-             exchange='auto', krylov_block=None, monitor_lag=None, exchange_overlap='auto'):
+             exchange='auto', krylov_block=None, monitor_lag=None, exchange_overlap='auto', first_look=None, products='auto'):
     """Returns (U_local | None, sigma[k] desc, V [n_items x k], stats) as device tensors of `ops`.
 
     A: ops-level CSR of the LOCAL row shard (n_local x n_items).  Convergence: every one of the k
@@ -892,7 +902,10 @@ def svd_topk(ops, A, k, block=None, tol=1e-12, max_outer=200, m_max=24, spread=1
     `choose_method` (a cost model), unless `solver.DEFAULT_METHOD` names one (tests).
     krylov_block: width of a Krylov block of the Lanczos build (None: `choose_krylov_block`; the nested solves and the
     subspace iteration keep the width `block`).  monitor_lag: steps between the launch of a monitor and its collection
-    (None: from the modelled step time; 0: every look on the calling thread).  max_steps: blocks of the Krylov space at
+    (None: from the modelled step time; 0: every look on the calling thread).  products: 'f64', or 'relaxed' = the sparse
+    products of the LATE steps of a one-process Lanczos build gather fp32 images of their dense blocks (same gate, fp64
+    verification and fall-back as exchange='relaxed').  first_look: the step of the first look (None:
+    half the modelled number of steps).  max_steps: blocks of the Krylov space at
     most (None: 64 at the full width, more for narrow blocks, never beyond the 4096 columns of the Gram kernels).
     """
     comm = comm or NoComm()
@@ -915,6 +928,8 @@ def svd_topk(ops, A, k, block=None, tol=1e-12, max_outer=200, m_max=24, spread=1
     #              the rest of the build.  (The relaxation theory of inexact Krylov methods: early products exact, late ones
     #              loose — the opposite of "fp32 until the end", which stalled at 5e-12 in round 4)
     #   'f32'      every exchange rounded (an explicit choice for builds to a tolerance >= 1e-6; warns below it).
+    if products not in ('auto', 'f64', 'relaxed'):
+        raise ValueError("products must be 'auto', 'f64' or 'relaxed'")
     if exchange not in ('auto', 'f64', 'f32', 'relaxed'):
         raise ValueError("exchange must be 'auto', 'f64', 'relaxed' or 'f32'")
     if exchange == 'f32' and tol < 1e-6:
@@ -932,7 +947,8 @@ def svd_topk(ops, A, k, block=None, tol=1e-12, max_outer=200, m_max=24, spread=1
             # `max_outer` bounds the work of either method: an outer iteration of the subspace method is worth a few blocks
             Vk, lam_k, res_k = _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose,
                                               min(max_steps, 4 * max_outer), m_max, spread, even_lock, kb=kb,
-                                              monitor_lag=monitor_lag, t_step=t_step, steps_model=plan['steps_model'])
+                                              monitor_lag=monitor_lag, t_step=t_step, steps_model=plan['steps_model'],
+                                              first_look=first_look, products={'auto': DEFAULT_PRODUCTS}.get(products, products))
             stats['converged'] = True
         except _LanczosBreakdown as exc:
             stats['lanczos_fallback'] = str(exc)

@@ -14,6 +14,7 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'slow: a CPU test of a minute or more (regenerates a large fixture from the imported reference)')
     config.addinivalue_line('markers', 'probe: kernel variants of csrc/experiments/ — need a probe build selected with POLARA_HIP_LIB')
 
 

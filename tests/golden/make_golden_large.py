@@ -118,7 +118,7 @@ def main():
         bad = []
         for key in sorted(out):
             a, b = np.asarray(out[key]), ref[key]
-            if a.dtype.kind in 'iub':
+            if a.dtype.kind in 'iubUS':          # integers, flags and the digest string: equal or not
                 if not np.array_equal(a, b):
                     bad.append(key)
             elif not np.allclose(a, b, rtol=1e-13, atol=1e-13 * max(1.0, float(np.abs(b).max()))):

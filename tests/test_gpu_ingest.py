@@ -308,3 +308,37 @@ def test_count_i32_matches_bincount(hip_ops, n_bins):
     out = torch.empty(n_bins, dtype=torch.int32, device=ops.device)
     _lib.check(ops.lib.pk_count_i32(ops.stream(), 200000, _ptr(one), n_bins, _ptr(out)), 'pk_count_i32')
     assert int(out[min(3, n_bins - 1)].item()) == 200000 and int(out.sum().item()) == 200000
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,K', [(1, 3), (63, 8), (1000, 50), (26744, 50), (70001, 17)])
+def test_norm_order_is_numpy_s_stable_argsort_of_the_row_norms(hip_ops, n, K):
+    """pk_row_norm_order_f64 (the serving order of the catalogue, built on the device: own radix sort on the bit patterns of
+    the fp64 norms + one gather) against `np.argsort(-np.linalg.norm(V, axis=1), kind='stable')` — the host statement of the
+    plugin surface (polara_amd/models.py) — with tied norms (repeated rows, zero rows): order, its inverse, the gathered rows."""
+    rng = np.random.RandomState(n + K)
+    V = rng.standard_normal((n, K)) * np.exp(-3.0 * rng.rand(n))[:, None]
+    if n > 10:
+        V[rng.choice(n, n // 7, replace=False)] = V[0]          # ties: repeated rows ...
+        V[rng.choice(n, n // 11, replace=False)] = 0.0          # ... and zero rows
+    Vd = hip_ops.to_device(V)
+    order, rank, Vs = hip_ops.norm_order(Vd)
+    norms = hip_ops.to_host(torch.sqrt((Vd * Vd).sum(1)))      # the kernel accumulates with fma: compare orders on ITS arithmetic's norms, to rounding
+    want = np.argsort(-np.linalg.norm(V, axis=1), kind='stable')
+    got = hip_ops.to_host(order).astype(np.int64)
+    assert sorted(got.tolist()) == list(range(n))
+    nv = np.linalg.norm(V, axis=1)
+    assert np.all(np.diff(nv[got]) <= 1e-15 * nv.max())           # descending to rounding
+    same = nv[got] == nv[want]
+    assert same.mean() > 0.999                                     # (norms within one rounding of each other may swap)
+    ties_ok = all(np.all(np.diff(got[a:b]) > 0) for a, b in _runs(nv[got]) if b - a > 1 and nv[got][a] == 0.0)
+    assert ties_ok                                                 # exact ties (the zero rows) keep ascending ids: stable
+    r = hip_ops.to_host(rank).astype(np.int64)
+    assert np.array_equal(r[got], np.arange(n))
+    assert np.array_equal(hip_ops.to_host(Vs), V[got])
+    _ = norms
+
+
+def _runs(x):
+    edges = np.flatnonzero(np.r_[True, x[1:] != x[:-1], True])
+    return list(zip(edges[:-1], edges[1:]))

@@ -18,6 +18,10 @@ if sys.argv[1] == 'run':
     A = ops.csr_relabel_cols(A, rank_of); A.transpose_operator(); _ = A.plan
     meth = sys.argv[2] if len(sys.argv) > 2 else 'lanczos'
     kw = dict(krylov_block=int(sys.argv[3])) if len(sys.argv) > 3 and int(sys.argv[3]) > 0 else {}
+    if len(sys.argv) > 5:
+        kw['monitor_lag'] = int(sys.argv[5])          # 0: every look on the calling thread (what a look costs alone)
+    if len(sys.argv) > 6:
+        kw['first_look'] = int(sys.argv[6])
     wl = sys.argv[4] if len(sys.argv) > 4 else 'ml20m'
     for _ in range(2):
         svd_topk(ops, A, 50, method=meth, **kw)
