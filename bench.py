@@ -107,6 +107,8 @@ def parse():
     ap.add_argument('--pass-streams', type=int, default=2,
                     help='HIP streams consecutive scoring passes alternate between (python launches; 1 = strictly serial passes)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--warm', default='code', choices=['code', 'pipeline', 'none'],
+                    help="what HipOps() does once per process: load the library's code objects (default), also run the miniature pipeline, or nothing")
     ap.add_argument('--cpu-users', type=int, default=0, help='users in the CPU scoring sample (0 = auto)')
     return ap.parse_args()
 
@@ -171,7 +173,7 @@ def pmc_traffic(tag):
                     parts = line.split()
                     found.append((line, int(parts[-3]), float(parts[-2]) * 1024.0, float(parts[-1]) * 1024.0))   # launches, sum, per launch (KB -> B)
             return commit, found
-        rnd = next((r for r in ('r05', 'r04', 'r03', 'r02') if os.path.exists(os.path.join(ROOT, 'profiles', '%s_%s_pmc_fetch_size.txt' % (r, tag)))), 'r02')
+        rnd = next((r for r in ('r06', 'r05', 'r04', 'r03', 'r02') if os.path.exists(os.path.join(ROOT, 'profiles', '%s_%s_pmc_fetch_size.txt' % (r, tag)))), 'r02')
         out['round'] = rnd
         cf, fetch = rows('%s_%s_pmc_fetch_size.txt' % (rnd, tag))
         _, write = rows('%s_%s_pmc_write_size.txt' % (rnd, tag))
@@ -228,7 +230,7 @@ class Bench:
         self.dev = 'cuda:%d' % torch.cuda.current_device()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        self.ops = HipOps(self.dev)        # loads the library's code objects (pk_warm_up); no miniature pipeline: the first build pays its own first calls
+        self.ops = HipOps(self.dev, warm=False if getattr(args, 'warm', 'code') == 'none' else getattr(args, 'warm', 'code'))     # default: the library's code objects only (pk_warm_up); the first build pays its own first calls
         torch.cuda.synchronize()
         self.ops_create_s = time.perf_counter() - t0
         self.dist_info = {'world': self.world, 'backend': 'none (one process)', 'device': torch.cuda.get_device_name(self.dev)}
@@ -639,6 +641,9 @@ class Bench:
                                                    'graph_replay': extra.get('graph_replay_ms_per_step')},
                 'build_s': tb['total_s'], 'build': dict(tb, gramian_steps=bstats['gramian_steps'],
                                                          outer_iterations=bstats['outer'], block=bstats['block'],
+                                                         krylov_block=bstats.get('krylov_block'), method=bstats.get('method'),
+                                                         recurrence=bstats.get('recurrence'), looks=[list(c) for c in bstats.get('checks', [])],
+                                                         nested=bstats.get('nested'), monitor_lag=bstats.get('monitor_lag'),
                                                          converged=bstats['converged'],
                                                          final_rel_residual=bstats.get('final_rel_residual'),
                                                          spmm_launches=len(spmm_ms), spmm_ms=float(sum(spmm_ms)),
@@ -667,18 +672,25 @@ class Bench:
                 # the sweep computes every fp32-accurate product as THREE bf16 MFMAs (hi.hi + hi.lo + lo.hi) over the rank
                 # padded to a multiple of 16: executed bf16 flops = 3 * (16 * k_steps / rank) * the algorithmic flops swept
                 k_steps = int(ops.lib.pk_pack_kq(rank)) // 2
-                bf16_flops = flops * swept * 3.0 * (16.0 * k_steps / rank)
-                ach = bf16_flops / (cand_ms * 1e-3) / 1e12
+                # USEFUL work: the algorithmic flops of the tiles actually scored (2 n_users n_items k,
+                # times the swept fraction), times 3 for the split product — no credit for the zero columns of the rank padded
+                # to a multiple of 16.  `issued_*` is what the matrix cores were actually given (padding included).
+                useful_flops = flops * swept * 3.0
+                bf16_flops = useful_flops * (16.0 * k_steps / rank)
+                ach = useful_flops / (cand_ms * 1e-3) / 1e12
+                issued = bf16_flops / (cand_ms * 1e-3) / 1e12
                 f32_eq = flops * swept / (cand_ms * 1e-3) / 1e12
                 out['roofline'] = {
                     'kernel': 'score_candidates_kernel', 'bound': 'mfma', 'dtype': 'bf16 (split product: 3 bf16 MFMAs per fp32-class product)',
                     'achieved': ach, 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_MFMA_TFLOPS, 'traffic': None,
+                    'issued': issued, 'issued_frac': issued / PEAK_BF16_MFMA_TFLOPS,
                     'avg_ms': cand_ms / max(n_chunk, 1), 'sweep_ms_per_pass': cand_ms, 'launches_per_pass': n_chunk,
-                    'flop_per_launch': bf16_flops / max(n_chunk, 1),
+                    'flop_per_launch': useful_flops / max(n_chunk, 1), 'issued_flop_per_launch': bf16_flops / max(n_chunk, 1),
                     'swept_fraction': swept,
-                    'note': 'achieved/frac count the bf16 MFMA flops actually issued for the tiles actually scored (the sweep is pruned '
-                            'exactly: Cauchy-Schwarz bound, identical results; --no-prune scores every tile). At rank 50 the kernel is '
-                            'no longer bound by the matrix cores but by its selection epilogue (VALU): see DESIGN.md K3',
+                    'note': 'achieved/frac: ALGORITHMIC flops of the tiles actually scored x 3 (split product), no padding; issued/issued_frac: '
+                            'the bf16 MFMA flops actually issued (rank padded to a multiple of 16). The sweep is pruned '
+                            'exactly (Cauchy-Schwarz bound, identical results; --no-prune scores every tile). At rank 50 the kernel is '
+                            'not bound by the matrix cores but by its selection epilogue (VALU): see DESIGN.md K3',
                     'f32_equivalent': {'flop_per_launch': flops * swept, 'TFLOP/s': f32_eq, 'of_f32_mfma_peak': f32_eq / PEAK_FP32_MFMA_TFLOPS,
                                        'note': 'the same products on v_mfma_f32_32x32x2_f32 (round 1) are capped at 157.3 TFLOP/s'},
                     'dense_equivalent': {'flop_per_launch': flops, 'TFLOP/s': flops / (cand_ms * 1e-3) / 1e12,
@@ -948,7 +960,7 @@ def compact_line(head, n_gpus, steps, warmup, adversarial=None, scale=1.0):
            'latency_ms_per_pass': _r(head.get('latency_ms_per_pass')), 'ms_per_step_serial': _r(head.get('ms_per_step_serial')),
            'ms_per_step_long_region': _r(head.get('ms_per_step_long_region'))}
     b = head.get('build', {})
-    out['build'] = {k: _r(b.get(k)) for k in ('solver_s', 'gramian_steps', 'converged', 'spmm_ms') if k in b}
+    out['build'] = {k: _r(b.get(k)) for k in ('solver_s', 'gramian_steps', 'krylov_block', 'converged', 'spmm_ms') if k in b}
     di = head.get('dist')
     if di:
         bc = di.get('build_collectives', {})
@@ -958,7 +970,7 @@ def compact_line(head, n_gpus, steps, warmup, adversarial=None, scale=1.0):
     rf = head.get('roofline')
     if rf:
         out['roofline'] = {k: (_r(rf.get(k)) if not isinstance(rf.get(k), str) else rf.get(k)) for k in
-                           ('kernel', 'bound', 'dtype', 'achieved', 'peak', 'unit', 'frac', 'avg_ms', 'launches_per_pass',
+                           ('kernel', 'bound', 'dtype', 'achieved', 'peak', 'unit', 'frac', 'issued_frac', 'avg_ms', 'launches_per_pass',
                             'swept_fraction', 'traffic', 'traffic_commit', 'stale') if k in rf or k == 'traffic'}
     rfo = head.get('roofline_foldin')
     if rfo:

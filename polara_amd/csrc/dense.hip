@@ -522,7 +522,7 @@ __global__ __launch_bounds__(PK_CHOL_THREADS) void chol_rinv_kernel(int n, const
     double *A = IN_LDS ? chol_lds : work;
     const int ld = IN_LDS ? n + 1 : n;
     const int tid = threadIdx.x;
-    const int TX = 1 << tx_log2, TY = PK_CHOL_THREADS >> tx_log2;
+    const int TX = 1 << tx_log2, TY = (int)blockDim.x >> tx_log2;      // (the launcher sizes the workgroup for n: a barrier of 4 waves costs a third of one of 16)
     const int tx = tid & (TX - 1), ty = tid >> tx_log2;
     if (tid < 64) {
         double tr = 0.0;                             // shift = shift_rel * trace(G) >= shift_rel * ||X||_2^2
@@ -546,6 +546,8 @@ __global__ __launch_bounds__(PK_CHOL_THREADS) void chol_rinv_kernel(int n, const
         const double invd = 1.0 / d;
         for (int c = tx; c < n; c += TX) {
             const double pj = (c == j) ? 1.0 : A[j * ld + c];
+            // (issuing the loads of four rows before the first store — row j is not written in step j — was measured and is
+            // SLOWER: 33.7 us against 25 us on the build's mix of 16 x 16 and 64 x 64 factorisations; so was a 256-thread workgroup)
             for (int i = j + 1 + ty; i < n; i += TY)
                 if (c <= j || c >= i) {
                     const double f = A[j * ld + i] * invd;
@@ -586,8 +588,13 @@ extern "C" int pk_chol_rinv_f64(void *stream, int32_t n, const double *G_dev, in
     }
     int tx_log2 = 4;                                 // columns of the thread grid: the power of two >= n, 16 ... 256
     while ((1 << tx_log2) < n && tx_log2 < 8) ++tx_log2;
+    // one barrier per column is what the factorisation costs: small matrices take a small workgroup (round 6: the nested solves
+    // of a narrow-block Lanczos build run 150 of these per build; 64 x 64 on 1024 threads: 42 us)
+    // (a smaller workgroup for small n was measured and is SLOWER — 64 x 64 on 256 threads: 75 us against 37: the rows a thread
+    // updates per column, not the barrier, are what a step costs)
+    const int threads = PK_CHOL_THREADS;
     if (n <= PK_CHOL_LDS_MAX)
-        hipLaunchKernelGGL(chol_rinv_kernel<true>, dim3(1), dim3(PK_CHOL_THREADS), (size_t)n * (n + 1) * sizeof(double),
+        hipLaunchKernelGGL(chol_rinv_kernel<true>, dim3(1), dim3(threads), (size_t)n * (n + 1) * sizeof(double),
                            pk_stream(stream), n, G_dev, ldg, shift_rel, Rinv_dev, ldr, static_cast<double *>(work_dev),
                            info_dev, tx_log2);
     else

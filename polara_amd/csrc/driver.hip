@@ -25,6 +25,17 @@
 #include <type_traits>
 #include <vector>
 
+// The machine constants of the cost models, ONE table (the split decision of a sharded product and the choice of
+// method / block width must not drift between copies — every rank derives its sequence of collectives from them).  The Python
+// layer reads the same numbers from polara_amd/machine_model.py; tests/test_host_logic.py compares the two tables.
+namespace model {
+constexpr double kDenseF64Flops = 20e12;          // dense_f64_flops
+constexpr double kLanczosStepFixedS = 0.75e-3;    // lanczos_step_fixed_s
+constexpr double kNestedSolveS = 1.5e-3;          // nested_solve_s
+constexpr double kXgmiBusBps = 100e9;             // xgmi_bus_Bps (ASSUMED: no N > 1 run exists)
+constexpr double kCollectiveStepS = 5e-6;         // collective_step_s (ASSUMED likewise)
+}  // namespace model
+
 // Device memory of a context: freed blocks are kept and handed out again (best fit within 25 %): every buffer of the
 // solver lives for a few launches on the context's ONE stream, so reuse is stream-ordered and a build does not pay a
 // hipMalloc / hipFree (each a device synchronisation) per temporary.
@@ -844,7 +855,6 @@ int subspace_iteration(pk_ctx *ctx, Solver &S, Op &op, int k, DMat X, double tol
     std::vector<double> lam_lock, theta_host, res_host;
     int n_lock = 0;
     bool done = false;
-    bool segments_ok = true;       // the filter of a dense operator may be cut into segments (below)
     for (int it = 0; it < max_outer && !done; ++it) {
         out.outer += 1;
         // ---- Rayleigh-Ritz on the active block
@@ -919,65 +929,12 @@ int subspace_iteration(pk_ctx *ctx, Solver &S, Op &op, int k, DMat X, double tol
             }
             return PK_OK;
         };
-        // The degree is held down by the SPREAD of the block (theta_1 / theta_l of a decaying spectrum: degree 4-5 on the
-        // projected problems of a Lanczos build), not by what the wanted pairs need — a Rayleigh-Ritz step per four
-        // products, each with an l x l eigen-decomposition and four host reads.  For a small dense operator (the nested
-        // solves: a product is one launch) the filter is therefore applied in up to four SEGMENTS of that degree with a
-        // plain CholeskyQR2 in between (no Rayleigh-Ritz, no host read): the amplification of a wanted pair over the damped
-        // interval is the product of the segments', the conditioning of the block that of one (round 6: looks of a
-        // narrow-block build cost more than its steps; 3-4 outer iterations per warm look before).
-        int nseg = 1;
-        if constexpr (has_filter_step<Op>::value) {
-            if (segments_ok && !(e <= 0.0 || a0 <= c)) nseg = std::max(1, std::min(4, m_max / std::max(m, 1)));
-        }
-        DMat Yc, Xritz;
-        Dev seg_info;
-        if (nseg > 1) {
-            CK(S.col_slice(X, 0, X.l, Xritz));          // the Ritz vectors: what the iteration falls back to
-            if (!seg_info.alloc((size_t)nseg * 2 * 4)) return fail(ctx, PK_E_LAUNCH, "out of device memory (filter segments)");
-            HIPCK(hipMemsetAsync(seg_info.p, 0, (size_t)nseg * 2 * 4, S.st));
-        }
+        DMat Yc, Xn;
         {
             DMat Xs = std::move(X), Zs = std::move(Z);
-            for (int seg = 0; seg < nseg; ++seg) {
-                DMat Yseg;
-                CK(cheb_filter(Xs, Zs, Yseg));
-                if (seg + 1 == nseg) {
-                    Yc = std::move(Yseg);
-                    break;
-                }
-                // CholeskyQR2 of the segment's block (shifted first pass), orthogonal to the locked vectors
-                const int l = Yseg.l;
-                const double u = 1.1102230246251565e-16;
-                Dev chol_work((size_t)std::max<int64_t>(pk_chol_work_bytes(l), 8));
-                if (!chol_work.p) return fail(ctx, PK_E_LAUNCH, "out of device memory (filter segments)");
-                for (int p = 0; p < 2; ++p) {
-                    if (have_lock) { DMat t; CK(S.project_out(Yseg, Vlock, t)); Yseg = std::move(t); }
-                    DMat G, Rinv(l, l), Yn;
-                    if (!Rinv.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (filter segments)");
-                    CK(S.gram(Yseg, Yseg, G));
-                    CK(pk_chol_rinv_f64(S.st, l, G.p(), l, p == 0 ? 11.0 * ((double)Yseg.n * l + (double)l * (l + 1)) * u : 0.0, Rinv.p(), l,
-                                        chol_work.p, seg_info.as<int32_t>() + 2 * seg + p));
-                    CK(S.tsmm(Yseg, Rinv, Yn));
-                    Yseg = std::move(Yn);
-                }
-                Xs = std::move(Yseg);
-                CK(op.apply(Xs, Zs));
-            }
+            CK(cheb_filter(Xs, Zs, Yc));
         }
-        DMat Xn;
-        bool seg_failed = false;
-        if (nseg > 1) {
-            std::vector<int32_t> inf((size_t)nseg * 2);
-            CK(S.to_host(seg_info.p, inf.data(), inf.size() * 4));
-            for (int32_t v : inf) seg_failed = seg_failed || v != 0;
-        }
-        if (seg_failed) {          // a segment's block lost rank: nothing of this filter is trusted, and none is cut again
-            segments_ok = false;
-            CK(S.orthonormalize(Xritz, have_lock ? &Vlock : nullptr, seed + 1 + (uint64_t)it, Xn));
-        } else {
-            CK(S.orthonormalize(Yc, have_lock ? &Vlock : nullptr, seed + 1 + (uint64_t)it, Xn));
-        }
+        CK(S.orthonormalize(Yc, have_lock ? &Vlock : nullptr, seed + 1 + (uint64_t)it, Xn));
         X = std::move(Xn);
     }
     CK(S.hcat(have_lock ? &Vlock : nullptr, X, out.basis));
@@ -1025,8 +982,7 @@ struct GramianOp {
         if (!comm || comm->world < 2 || l < 32 || l % 16 != 0) return false;
         if (ctx->opt.dist_overlap == 0) return false;
         if (ctx->opt.dist_overlap == 2) return true;
-        constexpr double kXgmiBusBps = 100e9 /* assumed: machine_model.py xgmi_bus_Bps */;
-        return 2.0 * (comm->world - 1) / comm->world * (double)A->A.n_cols * l * 8.0 / kXgmiBusBps >= 4e-4;
+        return 2.0 * (comm->world - 1) / comm->world * (double)A->A.n_cols * l * 8.0 / model::kXgmiBusBps >= 4e-4;
     }
     int ritz(const DMat &X, DMat &H, DMat &Y) {
         Y = DMat(A->A.n_rows, X.l);
@@ -1089,15 +1045,26 @@ struct GramianOp {
         const int w0 = Xb.l / 2, w1 = Xb.l - w0;
         DMat Z0(A->A.n_cols, w0), Z1(A->A.n_cols, w1);
         if (!Z0.ok() || !Z1.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (gramian step panels)");
-        CK(spmm_t_cols(ctx, A, Y, 0, w0, Z0));
-        HIPCK(hipEventRecord(ev_panel, ctx->stream));
-        HIPCK(hipStreamWaitEvent(side, ev_panel, 0));
-        CK(allreduce(Z0, side));
-        CK(spmm_t_cols(ctx, A, Y, w0, w1, Z1));
-        CK(allreduce(Z1));
-        HIPCK(hipEventRecord(ev_summed, side));
-        HIPCK(hipStreamWaitEvent(ctx->stream, ev_summed, 0));
-        CK(S.hcat(&Z0, Z1, Z));
+        // (once the first panel's sum is on the side stream, an error return must not hand Z0 / Z1 back to the pool —
+        // which re-issues blocks in the order of the context's stream only — while that collective may still touch Z0)
+        auto rest = [&]() -> int {
+            CK(spmm_t_cols(ctx, A, Y, 0, w0, Z0));
+            HIPCK(hipEventRecord(ev_panel, ctx->stream));
+            HIPCK(hipStreamWaitEvent(side, ev_panel, 0));
+            CK(allreduce(Z0, side));
+            CK(spmm_t_cols(ctx, A, Y, w0, w1, Z1));
+            CK(allreduce(Z1));
+            HIPCK(hipEventRecord(ev_summed, side));
+            HIPCK(hipStreamWaitEvent(ctx->stream, ev_summed, 0));
+            CK(S.hcat(&Z0, Z1, Z));
+            return PK_OK;
+        };
+        const int rc = rest();
+        if (rc != PK_OK) {
+            (void)hipStreamSynchronize(side);
+            (void)hipStreamSynchronize(ctx->stream);
+            return rc;
+        }
         ++overlapped_panels;
         return PK_OK;
     }
@@ -1255,7 +1222,9 @@ static int dense_topk(pk_ctx *ctx, Solver &S, DenseOp &dop, int k, DMat X, doubl
     DMat X0;
     CK(S.col_slice(X, 0, X.l, X0));
     bool ok = false;
-    CK(dense_topk_segments(ctx, S, dop, k, X, tol, lam0, r0_rel, out, ok));
+    // (blocks of at most 64 columns: the Cholesky kernels of wider ones cost more than the Rayleigh-Ritz steps the segments save —
+    // rank 100, l = 128: 55.9 -> 65.6 ms per build, profiles/r06_krylov_block_ml20m_r100.txt)
+    if (X.l <= 64) CK(dense_topk_segments(ctx, S, dop, k, X, tol, lam0, r0_rel, out, ok));
     if (ok) return PK_OK;
     const int outer0 = out.outer;
     SubspaceOut so;
@@ -1566,8 +1535,8 @@ static int block_lanczos(pk_ctx *ctx, Solver &S, GramianOp &gop, int64_t n, int 
 
 // solver.py::_lanczos_model restated (same constants: polara_amd/machine_model.py)
 static void lanczos_model(double nnz, int64_t n_items, int l, int b, int world, double &steps, double &t_step) {
-    constexpr double kDenseF64Flops = 20e12, kStepFixedS = 0.75e-3;
-    constexpr double kXgmiBusBps = 100e9 /* assumed */, kCollectiveStepS = 5e-6 /* assumed */;
+    using namespace model;
+    constexpr double kStepFixedS = kLanczosStepFixedS;
     steps = 14.0 * std::pow((double)l / b, 0.36);
     double t_spmm = nnz * (8.0 + std::max(b, 16)) * 1e-12 / world;
     if (world > 1) t_spmm += 2.0 * (world - 1) / world * (double)n_items * b * 8.0 / kXgmiBusBps + 6 * (world - 1) * kCollectiveStepS;
@@ -1638,7 +1607,7 @@ static int svd_build_impl(pk_ctx *ctx, pk_mat *A, const pk_comm *comm, int32_t k
             model(b, steps, t_step);
             if (best_t < 0 || steps * t_step < best_t) { best_t = steps * t_step; kb = b; }
         }
-        constexpr double kNestedSolveS = 1.5e-3, kStepFixedS = 0.75e-3;
+        constexpr double kNestedSolveS = model::kNestedSolveS, kStepFixedS = model::kLanczosStepFixedS;
         const double wide2 = std::max(1.0, (l / 64.0) * (l / 64.0));
         double steps_l, t_wide;
         model(l, steps_l, t_wide);

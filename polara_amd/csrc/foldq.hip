@@ -89,7 +89,10 @@ __global__ void q20_scale_kernel(const unsigned long long *__restrict__ bmax_bit
     const double m = __longlong_as_double((long long)bmax_bits[b]);
     // a window spans +-2^31 and a target stays 8192 units inside it; non-finite or subnormal-scale factors: no image
     double s = m * (1.0 + 9.5367431640625e-07) / (2147483648.0 - 8192.0);
-    if (!(m < 1e300) || (m > 0.0 && s < 1e-290)) {
+    // (the certified bound |E' - E| <= 2^-24 w_u rests on RELATIVE fp32 roundings of the per-entry factor
+    // (float)(a * s): a bracket whose scale lies below ~2^-100 would make that factor an fp32 denormal — absolute error, not
+    // covered by the weights D_j — so such factors get no packed image either: the caller keeps the fp32 image)
+    if (!(m < 1e300) || (m > 0.0 && s < 7.888609052210118e-31)) {
         atomicOr(info, 1);
         s = 0.0;
     }

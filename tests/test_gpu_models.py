@@ -458,3 +458,77 @@ def test_scaled_svd_device_scaling_equals_the_host_formula(hip_ops):
     from test_gpu_configs import _oracle_lists
     ref, clear = _oracle_lists(c, V, np.arange(3000), 10)
     assert clear.mean() > 0.9 and np.array_equal(recs_dev[clear], ref[clear])
+
+
+def _planted_device_matrix(ops, n_users=30000, n_items=4000, seed=11):
+    m = planted_csr(n_users, n_items, 60, 40, levels=5, seed=seed, min_items=8, max_items=400)
+    c = csr_to_numpy(m)
+    return ops.csr(c['indptr'], c['indices'], c['values'], c['shape']), c
+
+
+def test_library_recurrence_equals_the_composition_and_arpack(hip_ops, monkeypatch):
+    """Round 6: on one GPU the steps of the block Lanczos recurrence run inside the library (pk_lanczos_steps on a NON-owning
+    pk_mat over the layer's CSR arrays: csrc/driver.hip::lanczos_step, the function the coarse build runs) — against the
+    Python composition of the same step from single kernels (what sharded builds, host operators and the CPU double take)
+    and against the reference's own call (scipy svds = ARPACK, tol 0, models.py:844): singular values to 1e-11 / 1e-9,
+    projectors to 1e-9 / 1e-8, the same number of steps; narrow Krylov blocks (16 columns under a nested width of 40)."""
+    from scipy.sparse.linalg import svds
+    from polara_amd.ops import HipOps
+    from polara_amd.solver import svd_topk
+    A, c = _planted_device_matrix(hip_ops)
+    k = 24
+    _, s_lib, V_lib, st_lib = svd_topk(hip_ops, A, k, method='lanczos', krylov_block=16, monitor_lag=0, first_look=6)
+    assert st_lib['recurrence'] == 'library' and st_lib['krylov_block'] == 16 and st_lib['block'] > 16
+    assert st_lib['converged'] and st_lib['verified_rel_residual'] <= 1e-12
+    monkeypatch.delattr(HipOps, 'lanczos_recurrence')
+    _, s_cmp, V_cmp, st_cmp = svd_topk(hip_ops, A, k, method='lanczos', krylov_block=16, monitor_lag=0, first_look=6)
+    assert st_cmp['recurrence'] == 'composition' and st_cmp['lanczos_steps'] == st_lib['lanczos_steps']
+    s_lib, s_cmp = hip_ops.to_host(s_lib), hip_ops.to_host(s_cmp)
+    V_lib, V_cmp = hip_ops.to_host(V_lib), hip_ops.to_host(V_cmp)
+    assert np.allclose(s_lib, s_cmp, rtol=1e-11) and np.abs(V_lib @ V_lib[:300].T - V_cmp @ V_cmp[:300].T).max() < 1e-9
+    M = sps.csr_matrix((c['values'].astype(np.float64), c['indices'], c['indptr']), shape=c['shape'])
+    np.random.seed(0)
+    _, s_ref, vt = svds(M, k=k, tol=0)
+    assert np.allclose(np.sort(s_ref)[::-1], s_lib, rtol=1e-9) and np.abs(vt.T @ vt[:, :300] - V_lib @ V_lib[:300].T).max() < 1e-8
+
+
+def test_rounded_late_products_give_the_factors_of_the_exact_build(hip_ops):
+    """svd_topk(products='relaxed'): once a look says the pairs are within 1e-7 of convergence, both sparse products of a
+    step gather fp32 images of their dense blocks and only the BAND of the block column of T is kept (the mirror image of the
+    rounding noise would meet the O(1) early coefficients: what stalled round 4's rounded products at 5e-12) — the pairs are
+    accepted on a TRUE fp64 residual below 1e-12 like those of the exact build, and the factors agree to 1e-11 / 1e-9."""
+    from polara_amd.solver import svd_topk
+    A, _ = _planted_device_matrix(hip_ops, seed=12)
+    k = 24
+    kw = dict(method='lanczos', krylov_block=16, monitor_lag=1, first_look=4)      # a look per step: the gate opens while steps remain
+    _, s0, V0, st0 = svd_topk(hip_ops, A, k, **kw)
+    _, s1, V1, st1 = svd_topk(hip_ops, A, k, products='relaxed', **kw)
+    assert st0.get('products_rounded_from') is None and st1.get('products_rounded_from') is not None
+    assert st1['products_rounded_from'] < st1['lanczos_steps'], st1          # rounded steps did run
+    assert st1['converged'] and st1['verified_rel_residual'] <= 1e-12 and 'exchange_relaxed_failed_at' not in st1
+    s0, s1, V0, V1 = (hip_ops.to_host(t) for t in (s0, s1, V0, V1))
+    assert np.allclose(s0, s1, rtol=1e-11) and np.abs(V0 @ V0[:300].T - V1 @ V1[:300].T).max() < 1e-9
+
+
+def test_factor_image_without_torch_kernels_is_the_image_of_round_5(hip_ops):
+    """ops.v32_image (pk_v32_image_f32: the fp32 image of the item factors, the row-norm bounds in column K, the range check's
+    two numbers in one launch) against the fills / casts / index writes it replaced, and the serving order on the device
+    (pk_row_norm_order_f64) inside a FactorImage round trip; non-finite factors are refused as before."""
+    import torch
+    from polara_amd import scoring
+    rng = np.random.RandomState(5)
+    V = rng.standard_normal((3001, 50)) * np.exp(-2.0 * rng.rand(3001))[:, None]
+    Vd = hip_ops.to_device(V)
+    F = scoring.FactorImage(hip_ops, Vd)
+    want = torch.zeros(3001, F.V32x.stride(0), dtype=torch.float32, device=Vd.device)
+    want[:, :50] = Vd.to(torch.float32)
+    want[:, 50] = F.vnorm
+    assert torch.equal(F.V32x, want[:, :F.Kx])
+    true_max = float(np.linalg.norm(V, axis=1).max())
+    assert true_max <= F.vmax <= true_max * (1 + 1e-6)
+    bad = V.copy(); bad[17, 3] = np.inf
+    with pytest.raises(ValueError):
+        scoring.FactorImage(hip_ops, hip_ops.to_device(bad))
+    bad[17, 3] = np.nan
+    with pytest.raises(ValueError):
+        scoring.FactorImage(hip_ops, hip_ops.to_device(bad))

@@ -759,3 +759,19 @@ def test_explicit_test_set_shortcut_builds_the_protocol_test_matrix(gaps):
         scoring.renumbered_test_rows(NumpyOps(), np.array([0, 2, 1]))
     assert scoring.renumbered_test_rows(NumpyOps(), np.array([5])).tolist() == [0]
     assert scoring.renumbered_test_rows(NumpyOps(), np.array([3, 3, 8, 8, 9])).tolist() == [0, 0, 1, 1, 2]
+
+
+def test_the_cost_models_constants_are_one_table_in_each_language():
+    """the C++ statement of the solver (csrc/driver.hip, namespace model) and the Python one
+    (polara_amd/machine_model.py) must price a step alike — every rank of a sharded build derives its sequence of collectives
+    (two-panel exchange or not, method, block width) from these numbers.  The C++ table is read from the source."""
+    import re
+    from polara_amd.machine_model import value
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, 'polara_amd', 'csrc', 'driver.hip')).read()
+    block = src.split('namespace model {')[1].split('}  // namespace model')[0]
+    table = {name: float(val) for val, name in re.findall(r'constexpr double k\w+ = ([0-9.e+-]+);\s*//\s*(\w+)', block)}
+    assert set(table) == {'dense_f64_flops', 'lanczos_step_fixed_s', 'nested_solve_s', 'xgmi_bus_Bps', 'collective_step_s'}
+    for name, val in table.items():
+        assert val == value(name), (name, val, value(name))
+    assert src.count('100e9') == 1 and src.count('20e12') == 1          # no second copy of a constant outside the table

@@ -1,4 +1,7 @@
 export TMPDIR=/tmp
-python tools/probes/krylov_block_probe.py ml20m 100 16:10:0 16:14:0 0 > gpurun_out/kb11_ml20m_r100.txt 2>&1
-python tools/probes/krylov_block_probe.py s1m 50 16:8:0 0 > gpurun_out/kb11_s1m.txt 2>&1
-python tools/probes/krylov_block_probe.py ml20m 50 16:6:0 16:8:0 16:10:0 > gpurun_out/kb11_ml20m.txt 2>&1
+R=$GRAFT_REPO_ROOT
+python tools/probes/krylov_block_probe.py ml20m 50 0 16:8:0 > gpurun_out/kb13_ml20m.txt 2>&1
+(cd /tmp && rocprofv3 --kernel-trace --output-format csv -d /tmp/stA -- python $R/tools/probes/solver_timeline.py run lanczos 16 ml20m 0 8 > $R/gpurun_out/timeline_run_lag0c.txt 2>&1)
+python tools/probes/solver_timeline.py report /tmp/stA > gpurun_out/solver_timeline_lag0c.txt 2>&1
+timeout 1200 python -m pytest tests -m gpu -q -x > gpurun_out/gputests13.txt 2>&1
+tail -5 gpurun_out/gputests13.txt

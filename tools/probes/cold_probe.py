@@ -1,6 +1,6 @@
 """What a process pays before its first build and pass run like its second: one child process per setting
-   (PK_WARM_UP=0: the library as it was — code objects loaded at first launch; PK_WARM_UP=1: HipOps() loads them and runs the
-   miniature pipeline), each timing  HipOps()  ->  first build (itemised)  ->  first pass  ->  second build  ->  a warm pass,
+   (--warm none: code objects loaded at first launch; code: HipOps() loads them — the default since round 6; pipeline: it also
+   runs the miniature build + passes of round 5), each timing  HipOps()  ->  first build (itemised)  ->  first pass  ->  second build  ->  a warm pass,
    with the allocator's device allocations counted per stage.
    usage: python tools/probes/cold_probe.py [ml20m|s1m] [rank]"""
 import json
@@ -16,7 +16,7 @@ if len(sys.argv) > 1 and sys.argv[1] == 'child':
     import torch
     t_torch = time.perf_counter() - t_start
     wl, rank = sys.argv[2], int(sys.argv[3])
-    argv, sys.argv = sys.argv, ['bench.py', '--workload', wl]
+    argv, sys.argv = sys.argv, ['bench.py', '--workload', wl, '--warm', sys.argv[4]]
     import bench
     args = bench.parse()
     sys.argv = argv
@@ -34,10 +34,11 @@ if len(sys.argv) > 1 and sys.argv[1] == 'child':
 
     def mallocs():
         return torch.cuda.memory_stats().get('num_device_alloc', 0)
-    rec = dict(warm_up=os.environ.get('PK_WARM_UP', '1'), import_torch_s=t_torch, ops_create_s=t_ops, warm_up_s=B.ops.warm_up_s)
+    rec = dict(warm=argv[4], import_torch_s=t_torch, ops_create_s=t_ops, warm_up_s=B.ops.warm_up_s)
     m0 = mallocs()
     st, tb = B.build(c, rank)
     rec['build_first'] = dict(tb, device_allocs=mallocs() - m0)
+    rec['time_to_first_model_s'] = t_ops + tb['total_s']
     m0 = mallocs()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -66,9 +67,8 @@ else:
     wl = sys.argv[1] if len(sys.argv) > 1 else 'ml20m'
     rank = sys.argv[2] if len(sys.argv) > 2 else '50'
     out = []
-    for warm in ('0', '1'):
-        r = subprocess.run([sys.executable, __file__, 'child', wl, rank], capture_output=True, text=True,
-                           env=dict(os.environ, PK_WARM_UP=warm))
+    for warm in ('none', 'code', 'pipeline'):
+        r = subprocess.run([sys.executable, __file__, 'child', wl, rank, warm], capture_output=True, text=True)
         line = [l for l in r.stdout.splitlines() if l.startswith('RESULT ')]
         if not line:
             print('child failed:', r.stderr[-1500:])

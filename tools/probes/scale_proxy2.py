@@ -15,7 +15,7 @@ sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '.'))
 import torch, numpy as np
 from polara_amd.ops import HipOps
 from polara_amd.synth import make_workload, csr_to_numpy
-from polara_amd.solver import svd_topk
+from polara_amd.solver import svd_topk, NoComm, choose_krylov_block, default_block
 from polara_amd.csr import popularity_order, nnz_balanced_row_partition
 from polara_amd import scoring
 ops = HipOps('cuda:0')
@@ -69,23 +69,31 @@ def replay(log, rows):
     return e0.elapsed_time(e1), len(calls)
 
 
+class ShardComm(NoComm):
+    """rank 0 of an N-rank job with the exchange stubbed: the build takes the Python COMPOSITION of the Lanczos step (what a
+    sharded build runs: its collectives sit inside the step), not the library recurrence of a one-process build"""
+    _always = True
+
+
 METHOD = None
+NNZ_TOTAL = int(c['indptr'][-1])
 for N in (1, 2, 4, 8):
     bounds = nnz_balanced_row_partition(c['indptr'], N)
     A = A0 if N == 1 else ops.csr_rows(A0, 0, int(bounds[1]))
-    A.transpose_operator(); _ = A.plan
-    _, _, _, st0 = svd_topk(ops, A, rank, method=METHOD)                     # warm-up (allocations)
+    KW = {} if N == 1 else dict(comm=ShardComm(), krylov_block=choose_krylov_block(NNZ_TOTAL, n_items, default_block(rank, n_items), N))
+    _ = A.plan
+    _, _, _, st0 = svd_topk(ops, A, rank, method=METHOD, **KW)                     # warm-up (allocations)
     if N == 1:
         METHOD = st0['method'].split()[0]      # the JOB's choice (the all-reduced entry count decides, not the shard's)
     torch.cuda.synchronize()
     ops.timers = {}
     t0 = time.perf_counter()
-    _, s, Vn, st = svd_topk(ops, A, rank, method=METHOD)
+    _, s, Vn, st = svd_topk(ops, A, rank, method=METHOD, **KW)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     rec = Recorder(ops)
     timers, ops.timers = ops.timers, None
-    svd_topk(rec, A, rank, method=METHOD)
+    svd_topk(rec, A, rank, method=METHOD, **KW)
     torch.cuda.synchronize()
     ops.timers = timers
     full_ms, n_calls = replay(rec.log, n_items)
@@ -105,7 +113,7 @@ for N in (1, 2, 4, 8):
     out['build']['N=%d' % N] = dict(rows_on_rank0=A.shape[0], solver_wall_s=wall, spmm_ms=spmm_ms, non_spmm_ms=1e3 * wall - spmm_ms,
                                     item_side_calls=n_calls, item_side_ms_replicated=full_ms, item_side_ms_sharded=shard_ms,
                                     non_spmm_sharded_ms=1e3 * sharded_wall - spmm_ms,
-                                    gramian_steps=st['gramian_steps'], method=st.get('method'), small_allreduces=small,
+                                    gramian_steps=st['gramian_steps'], method=st.get('method'), krylov_block=st.get('krylov_block'), recurrence=st.get('recurrence'), small_allreduces=small,
                                     modelled_exchange_ms=1e3 * ring,
                                     modelled_exchange_ms_busbw_300=1e3 * bus,
                                     modelled_total_s_replicated=wall + ring,
@@ -117,10 +125,8 @@ for k, v in out['build'].items():
     v['speedup_vs_N1'] = b1 / v['modelled_total_s']
     v['speedup_vs_N1_replicated'] = b1 / v['modelled_total_s_replicated']
     v['speedup_vs_N1_busbw_300'] = b1 / v['modelled_total_s_busbw_300']
-order2 = torch.argsort(torch.linalg.vector_norm(V, dim=1), descending=True, stable=True)
-rank2 = torch.empty_like(order2); rank2[order2] = torch.arange(n_items, device=order2.device)
-V = V[order2].contiguous()
-As = ops.csr_relabel_cols(A0, rank2)
+order32, rank32, V = ops.norm_order(V)
+As = ops.csr_relabel_cols(A0, rank32)
 F = scoring.FactorImage(ops, V)
 copy_stream = torch.cuda.Stream()
 for N in (1, 2, 4, 8):
