@@ -280,13 +280,15 @@ class LanczosRecurrence:
     def _timing(self):
         # bench.py's per-launch SpMM records (ops.timers): the library takes them itself for the launches it makes
         want = 1 if self.ops.timers is not None else 0
-        if want != getattr(self, '_timing_on', 0):
+        if want != getattr(self.ops, '_rec_timing_on', 0):      # (the state of the CONTEXT, which outlives this handle)
             _lib.check(self.ops.lib.pk_ctx_set_option(self.ctx, b'time_spmm', want), 'pk_ctx_set_option', self.ops.lib, self.ctx)
-            self._timing_on = want
+            if not want:      # records nobody will read
+                self.ops.lib.pk_ctx_spmm_timings(self.ctx, None, None, 0)
+            self.ops._rec_timing_on = want
 
     def collect_timings(self):
         """moves the library's SpMM records into ops.timers['spmm'] (as (duration, None, meta) with the meta of HipOps.spmm)"""
-        if not getattr(self, '_timing_on', 0):
+        if not getattr(self.ops, '_rec_timing_on', 0):
             return
         cap = 1 << 14
         ms = np.zeros(cap)

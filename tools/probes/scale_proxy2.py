@@ -100,7 +100,7 @@ for N in (1, 2, 4, 8):
     shard_ms, _ = replay(rec.log, -(-n_items // N))
     spmm_ms = sum(a.elapsed_time(b) for a, b, _ in ops.timers.get('spmm', []))
     ops.timers = None
-    l = st['block']
+    l = st.get('krylov_block') or st['block']          # the exchanged block is a Krylov block (round 6: narrower than the nested width)
     z_bytes = n_items * l * 8
     # small all-reduces per step: block Lanczos reduces the block column of T and the l x l Gram matrices of its three
     # orthogonalisation passes (5 per step, <= 0.5 MB each); the subspace iteration about as many per filter step
