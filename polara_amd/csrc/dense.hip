@@ -590,8 +590,10 @@ extern "C" int pk_chol_rinv_f64(void *stream, int32_t n, const double *G_dev, in
     while ((1 << tx_log2) < n && tx_log2 < 8) ++tx_log2;
     // one barrier per column is what the factorisation costs: small matrices take a small workgroup (round 6: the nested solves
     // of a narrow-block Lanczos build run 150 of these per build; 64 x 64 on 1024 threads: 42 us)
-    // (a smaller workgroup for small n was measured and is SLOWER — 64 x 64 on 256 threads: 75 us against 37: the rows a thread
-    // updates per column, not the barrier, are what a step costs)
+    // (round 6 measured three cheaper-looking forms of this kernel for n <= 64 and kept none: 256 threads instead of 1024 — 75 us
+    // against 37 at 64 x 64; the loads of four rows issued before the first store — 33.7 us against 25 us on a build's mix of
+    // sizes; a dedicated kernel, lane = column, one wave for n <= 16 and four above, loads batched — 19 us against 12 at 16 x 16,
+    // 66 us against 37 at 64 x 64 (tools/probes/chol_probe.py))
     const int threads = PK_CHOL_THREADS;
     if (n <= PK_CHOL_LDS_MAX)
         hipLaunchKernelGGL(chol_rinv_kernel<true>, dim3(1), dim3(threads), (size_t)n * (n + 1) * sizeof(double),

@@ -30,7 +30,7 @@
 // layer reads the same numbers from polara_amd/machine_model.py; tests/test_host_logic.py compares the two tables.
 namespace model {
 constexpr double kDenseF64Flops = 20e12;          // dense_f64_flops
-constexpr double kLanczosStepFixedS = 0.75e-3;    // lanczos_step_fixed_s
+constexpr double kLanczosStepFixedS = 0.3e-3;     // lanczos_step_fixed_s
 constexpr double kNestedSolveS = 1.5e-3;          // nested_solve_s
 constexpr double kXgmiBusBps = 100e9;             // xgmi_bus_Bps (ASSUMED: no N > 1 run exists)
 constexpr double kCollectiveStepS = 5e-6;         // collective_step_s (ASSUMED likewise)

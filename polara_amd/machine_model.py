@@ -10,9 +10,9 @@ MI355X = {
     'dense_f64_flops': (20e12, 'profiles/r04_solver_timeline_lanczos.txt (tsmm 53 us for 26 744 x 448 x 64)'),
     # one nested eigen-solve of a 896 x 896 projected problem, block 64
     'nested_solve_s': (1.5e-3, 'profiles/r05_solver_timeline_lanczos.txt (a look on the main stream: 2.5-4 ms of dependent small kernels, half of it hidden)'),
-    # what a block Lanczos step costs besides its sparse products and the basis traffic: ~20 small dependent launches
-    # (Gram products, CholeskyQR3 with re-projection) and its share of the looks — (build - SpMM) / steps at b = 16 / 32
-    'lanczos_step_fixed_s': (0.75e-3, 'profiles/r06_krylov_block_ml20m.txt, r06_krylov_block_s1m.txt'),
+    # what a block Lanczos step costs besides its sparse products and the basis traffic: ~20 small dependent launches (Gram
+    # products, CholeskyQR3 with re-projection) from the library's recurrence — 24 steps: 15.0 ms of which SpMM 8.6
+    'lanczos_step_fixed_s': (0.3e-3, 'profiles/r06_solver_timeline_lanczos_sync_looks.txt'),
     # wall time of a nested solve that runs on a side stream next to the products (the lag of the monitors)
     'look_wall_s': (5e-3, 'profiles/r06_krylov_block_ml20m.txt (monitor waits 4-8 ms at lag 4 x 0.55 ms steps)'),
     # bus bandwidth of a ring exchange over xGMI, per rank — ASSUMED (7 links x ~153 GB/s peak; a ring is bound by one link

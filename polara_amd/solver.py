@@ -592,7 +592,7 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
     hist = []                              # (step, worst relative residual estimate of the k leading pairs)
     # Looks are the expensive part of a build with narrow blocks: a nested solve is ~5 ms of dependent small kernels, a step
     # of a 16-column block 0.55 ms (round 6; at the 1.7 ms steps of round 4's 64-column blocks it was the other way round).  So:
-    # ONE monitor half way to the modelled number of steps, collected after as many steps as its solve takes next to the
+    # ONE monitor at 0.7 of the modelled number of steps where steps are cheap (0.5 where they are not: below), collected after as many steps as its solve takes next to the
     # products (never blocking: lag = look time / modelled step time), the final look where that estimate and a PRIOR rate put
     # convergence (a late look wastes cheap steps, an early one costs a whole nested solve and a second look), further
     # monitors only when convergence is far.  Every number is derived from the all-reduced entry count: all ranks decide alike.
@@ -607,7 +607,9 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
     if first_look is not None:
         first = max(-(-l // b), int(first_look))
     elif steps_model:
-        first = max(first, int(math.ceil(0.5 * steps_model)))
+        # cheap steps (a look is worth five or more of them): one late monitor; expensive steps (S-1M: 2.9 ms): an early chain of
+        # warm monitors — ML-20M-shaped rank 50 30.4 -> 26.9 ms and rank 100 58.5 -> 49.7 ms with 0.7, S-1M 88 -> 93 ms (so: 0.5)
+        first = max(first, int(math.ceil((0.7 if int(monitor_lag) >= 5 else 0.5) * steps_model)))
     prior_rate = 0.8 * 1.72 * (b / 16.0) ** 0.27      # natural log per step, late phase: x5.6 / x8.2 / x12 per step at b = 16 / 32 / 64 (measured), less a fifth
     next_look = min(first, qcap)           # the step of the next monitor, or of the final check once the rate is known
     look_is_final = not use_monitor
@@ -778,7 +780,7 @@ def _lanczos_model(nnz, n_items, l, b, world=1):
              64 / 48 / 32 / 24 / 16; rank 100: 15 / 19 / 25 / 36 at 128 / 64 / 32 / 16; S-1M: 15 / 19 / 24 at 64 / 32 / 16);
       both products of a step: nnz (8 + b) ps  (ML-20M-shaped: 1.22 / 0.78 / 0.50 ms at 64 / 32 / 16; S-1M: 9.0 / 4.6 / 2.5 ms) —
              the row pieces of a narrow block stay on chip, and every gather instruction carries 16 columns whatever b is;
-      everything else of a step (the projections against the Krylov basis, CholeskyQR3, the share of the looks): 0.75 ms
+      everything else of a step (the projections against the Krylov basis, CholeskyQR3 — inside the library): 0.3 ms
              plus the basis traffic of the re-orthogonalisation (14 passes over n_items x N x b flop at the fp64 rate)."""
     from .machine_model import value as mm
     steps = 14.0 * (float(l) / b) ** 0.36
