@@ -1437,7 +1437,7 @@ static int lanczos_step(pk_ctx *ctx, Solver &S, GramianOp &gop, int64_t n, int b
 }
 
 // b: width of a Krylov block; l: width of the nested solves (k + guard vectors).  Round 6: b < l — a narrower block needs
-// (l / b)^0.36 times the steps and gathers b / l of the columns per step (solver.py::choose_krylov_block).
+// (l / b)^(0.33 + 0.035 log2(l / b)) times the steps and gathers b / l of the columns per step (solver.py::choose_krylov_block).
 // Looks are synchronous here (no side-stream monitors: those are a host-side scheduling matter of solver.py), and a look — a
 // nested solve of ~5 ms — costs as much as nine steps of a 16-column block: the first one is taken where the cost model puts
 // convergence (a late look wastes cheap steps, an early one costs a whole solve and a second look), later ones where the
@@ -1537,7 +1537,8 @@ static int block_lanczos(pk_ctx *ctx, Solver &S, GramianOp &gop, int64_t n, int 
 static void lanczos_model(double nnz, int64_t n_items, int l, int b, int world, double &steps, double &t_step) {
     using namespace model;
     constexpr double kStepFixedS = kLanczosStepFixedS;
-    steps = 14.0 * std::pow((double)l / b, 0.36);
+    const double ratio = std::max((double)l / b, 1.0);
+    steps = (14.0 + std::max(0.0, std::log2(l / 64.0))) * std::pow(ratio, 0.33 + 0.035 * std::log2(ratio));
     double t_spmm = nnz * (8.0 + std::max(b, 16)) * 1e-12 / world;
     if (world > 1) t_spmm += 2.0 * (world - 1) / world * (double)n_items * b * 8.0 / kXgmiBusBps + 6 * (world - 1) * kCollectiveStepS;
     const double n_avg = 0.5 * steps * b;

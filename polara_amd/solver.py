@@ -599,7 +599,8 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
     # monitor_lag = 0: no monitors, every look on the calling thread (the form the C++ statement takes).
     from .machine_model import value as mm
     if monitor_lag is None:
-        monitor_lag = 3 if not t_step else int(min(10, max(3, math.ceil(mm('look_wall_s') / t_step))))
+        # (a look at nested width l costs ~(l / 64)^1.5 of the 64-wide one: rank 100 waits 24 / 13 ms where rank 50 waits 17 / 5.4)
+        monitor_lag = 3 if not t_step else int(min(10, max(3, math.ceil(mm('look_wall_s') * max(1.0, l / 64.0) ** 1.5 / t_step))))
     LAG = int(monitor_lag)
     stats['monitor_lag'] = LAG
     use_monitor = LAG > 0
@@ -776,14 +777,16 @@ def _lanczos_model(nnz, n_items, l, b, world=1):
     """(steps, seconds per step) of a block Lanczos build with Krylov blocks of b columns, nested width l — the cost model
     behind `choose_krylov_block` / `choose_method` (same constants in csrc/driver.hip::lanczos_model).  Measured on one
     MI355X (profiles/r06_krylov_block_*.txt):
-      steps: 14 at b = l, growing like (l / b)^0.36 as the block narrows (ML-20M-shaped rank 50: 14 / 15 / 17 / 19 / 23 at
-             64 / 48 / 32 / 24 / 16; rank 100: 15 / 19 / 25 / 36 at 128 / 64 / 32 / 16; S-1M: 15 / 19 / 24 at 64 / 32 / 16);
+      steps: 14 at b = l = 64 (one more per doubling of l), growing like (l / b)^(0.33 + 0.035 log2(l / b)) as the block narrows
+             (ML-20M-shaped rank 50: 14 / 15 / 17 / 19 / 23-24 at 64 / 48 / 32 / 24 / 16; rank 100: 15 / 19 / 25-27 / 36-38 at
+             128 / 64 / 32 / 16; S-1M: 15 / 19 / 24-25 at 64 / 32 / 16) — the model gives 14 / 18.0 / 24.4 and 15 / 19.3 / 26.1 / 37.0;
       both products of a step: nnz (8 + b) ps  (ML-20M-shaped: 1.22 / 0.78 / 0.50 ms at 64 / 32 / 16; S-1M: 9.0 / 4.6 / 2.5 ms) —
              the row pieces of a narrow block stay on chip, and every gather instruction carries 16 columns whatever b is;
       everything else of a step (the projections against the Krylov basis, CholeskyQR3 — inside the library): 0.3 ms
              plus the basis traffic of the re-orthogonalisation (14 passes over n_items x N x b flop at the fp64 rate)."""
     from .machine_model import value as mm
-    steps = 14.0 * (float(l) / b) ** 0.36
+    ratio = max(float(l) / b, 1.0)
+    steps = (14.0 + max(0.0, math.log2(l / 64.0))) * ratio ** (0.33 + 0.035 * math.log2(ratio))
     t_spmm = nnz * (8.0 + max(b, 16)) * 1e-12 / world
     if world > 1:
         t_spmm += 2.0 * (world - 1) / world * n_items * b * 8.0 / mm('xgmi_bus_Bps') + 6 * (world - 1) * mm('collective_step_s')
@@ -793,7 +796,7 @@ def _lanczos_model(nnz, n_items, l, b, world=1):
 
 
 def choose_krylov_block(nnz, n_items, l, world=1):
-    """Width of a Krylov block: the widest block is NOT the cheapest build.  A block of b < l columns needs (l / b)^0.36 times
+    """Width of a Krylov block: the widest block is NOT the cheapest build.  A block of b < l columns needs (l / b)^(0.33 + 0.035 log2(l / b)) times
     the steps, but a step's sparse products shrink almost in proportion to b — the Krylov space reaches a given dimension
     with fewer gathered columns in total — so the width is chosen where steps x (products + the fixed cost of a step) is
     least (round 6; rounds 4-5 tied the block to the nested width l: ML-20M-shaped rank 50 33.3 -> 27.8 ms at b = 32, S-1M

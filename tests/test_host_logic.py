@@ -410,7 +410,7 @@ def test_block_lanczos_matches_the_subspace_iteration_and_arpack(monkeypatch):
 
 def test_narrow_krylov_blocks_give_the_same_factors():
     """Round 6: the width of a Krylov block is decoupled from the nested width l = k + guard vectors.  A narrower block takes
-    more steps (about (l / b)^0.36 times) and gathers fewer columns in total; the factors are those of the full-width build,
+    more steps (about (l / b)^(0.33 + 0.035 log2(l / b)) times) and gathers fewer columns in total; the factors are those of the full-width build,
     the verified residual stays below the tolerance, blocks narrower than k included (the Ritz vectors come from the whole
     Krylov space)."""
     from polara_amd.synth import planted_csr
