@@ -944,8 +944,8 @@ def compact_line(head, n_gpus, steps, warmup, adversarial=None, scale=1.0):
            'rank': head['rank'], 'topk': head['topk'], 'prune': head['prune'],
            'swept_fraction': _r(sc.get('swept_fraction')), 'launch': head.get('launch_short', 'python'),
            'launches_per_pass': head.get('launches_per_pass'),
-           'parallelism': 'users sharded over %d GPU(s); all-gather X + reduce-scatter Z per Gramian step in the build, '
-                          'no collective in scoring' % n_gpus}
+           'parallelism': 'users sharded over %d GPU(s); one all-reduce of the 16-column Krylov block (n_items x 16 fp64) per Gramian step '
+                          'in the build (item side replicated, steps inside the library), no collective in scoring' % n_gpus}
     if scale != 1.0:
         cfg['scale'] = scale
     if adversarial:

@@ -717,6 +717,15 @@ int pk_lanczos_steps(pk_ctx *ctx, void *stream, pk_mat *A, int32_t b, int32_t j0
                      int32_t rounded);
 int pk_gramian_apply_f64(pk_ctx *ctx, void *stream, pk_mat *A, int32_t nc, const double *X_dev, int64_t ldx, double *Z_dev,
                          int64_t ldz);
+/* The two halves of step j (j >= 1) for a host layer that shards the USERS itself — one process per GPU, item side replicated:
+ * pk_lanczos_products writes W = A_p^T (A_p Q_j) of THIS rank's rows into W_out_dev [n_cols x b] (contiguous); the host sums W
+ * over the ranks (ONE all-reduce of n_cols x b per step, e.g. ncclAllReduce on `stream`); pk_lanczos_orth then does on every
+ * rank what pk_lanczos_steps does after its products: block column j of T and its mirror image, the next block by shifted
+ * CholeskyQR3 re-projected in every pass, S_out_dev and flags_dev as there (`rounded`: band-only block column, see there). */
+int pk_lanczos_products(pk_ctx *ctx, void *stream, pk_mat *A, int32_t b, int32_t j, const double *Q_dev, int64_t ldq,
+                        double *W_out_dev, int32_t rounded);
+int pk_lanczos_orth(pk_ctx *ctx, void *stream, int64_t n_items, int32_t b, int32_t j, int32_t last_closes, double *Q_dev, int64_t ldq,
+                    double *T_dev, int64_t ldt, const double *W_dev, double *S_out_dev, double *flags_dev, int32_t rounded);
 /* the context's HIP stream (hipStream_t as void*): what a pk_comm callback is handed, for hosts that create the
  * communicator's work on it */
 void *pk_ctx_stream(pk_ctx *ctx);

@@ -143,6 +143,8 @@ PROTOTYPES = {
     'pk_mat_wrap_device': (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i32, _i32, C.POINTER(_vp)]),
     'pk_lanczos_steps': (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _i32]),
     'pk_gramian_apply_f64': (C.c_int, [_vp, _vp, _vp, _i32, _vp, _i64, _vp, _i64]),
+    'pk_lanczos_products': (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _i32]),
+    'pk_lanczos_orth': (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i32]),
     'pk_score_topk': (C.c_int, [_vp, _i64, _i32, _vp, _vp, _i32, _i32, _vp, _vp]),
     'pk_serving_create': (C.c_int, [_vp, _i64, _i32, _vp, _vp, C.POINTER(_vp)]),
     'pk_serving_score': (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp]),

@@ -1376,15 +1376,31 @@ struct LanczosBuffers {
 // the next block by shifted CholeskyQR3 re-projected against the whole basis in every pass.  Sc = W_perp^T W_perp, the
 // coupling behind the residual estimates.  The ONE statement of the step: the coarse build (block_lanczos below) and the
 // Python layer's build (pk_lanczos_steps; solver.py keeps the looks, their monitors and the decisions) both run it.
+// The step in its two halves: the PRODUCTS  W = A^T (A Q_j)  of the matrix behind `gop` (summed over the ranks inside `gop.apply`
+// when the build owns a communicator; a host layer that shards the users itself sums W between the two halves:
+// pk_lanczos_products / pk_lanczos_orth), and everything that follows from W on the replicated item side.
+static int lanczos_products(pk_ctx *ctx, Solver &S, GramianOp &gop, int64_t n, int b, int j, const LanczosBuffers &B, DMat &W, bool rounded) {
+    const int N = j * b;
+    DMat Qj(n, b);
+    if (!Qj.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (block Lanczos)");
+    HIPCK(hipMemcpy2DAsync(Qj.p(), (size_t)b * 8, B.Q + (N - b), (size_t)B.ldq * 8, (size_t)b * 8, (size_t)n, hipMemcpyDeviceToDevice, S.st));
+    if (rounded) CK(gop.apply_rounded(Qj, W)); else CK(gop.apply(Qj, W));
+    return PK_OK;
+}
+
+static int lanczos_orth(pk_ctx *ctx, Solver &S, int64_t n, int b, int j, bool last, const LanczosBuffers &B, const DMat &W, DMat &Sc, bool rounded);
+
 static int lanczos_step(pk_ctx *ctx, Solver &S, GramianOp &gop, int64_t n, int b, int j, bool last, const LanczosBuffers &B, DMat &Sc,
                         bool rounded = false) {
+    DMat W;
+    CK(lanczos_products(ctx, S, gop, n, b, j, B, W, rounded));
+    return lanczos_orth(ctx, S, n, b, j, last, B, W, Sc, rounded);
+}
+
+static int lanczos_orth(pk_ctx *ctx, Solver &S, int64_t n, int b, int j, bool last, const LanczosBuffers &B, const DMat &W, DMat &Sc, bool rounded) {
     const int N = j * b;
     const int64_t ldq = B.ldq, ldt = B.ldt;
     const double u = 1.1102230246251565e-16;
-    DMat Qj(n, b), W;
-    if (!Qj.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (block Lanczos)");
-    HIPCK(hipMemcpy2DAsync(Qj.p(), (size_t)b * 8, B.Q + (N - b), (size_t)ldq * 8, (size_t)b * 8, (size_t)n, hipMemcpyDeviceToDevice, S.st));
-    if (rounded) CK(gop.apply_rounded(Qj, W)); else CK(gop.apply(Qj, W));
     // block column j of T = Q^T W, rows of all blocks so far (and its mirror image)
     DMat C(N, b);
     const size_t need = (size_t)pk_gram_work_bytes(n, N, b);
@@ -1754,6 +1770,48 @@ extern "C" int pk_lanczos_steps(pk_ctx *ctx, void *stream, pk_mat *A, int32_t b,
                         rounded != 0));
         if (j == j0 + m) HIPCK(hipMemcpyAsync(S_out_dev, Sc.p(), (size_t)b * b * 8, hipMemcpyDeviceToDevice, ctx->stream));
     }
+    return PK_OK;
+}
+
+// The two halves of a step for a host layer that shards the USERS itself (one process per GPU, item side replicated): every
+// rank computes the products of ITS rows, the host sums W over the ranks (one all-reduce of n_items x b per step — RCCL), every
+// rank runs the same orthogonalisation on the same sum.  polara_amd/solver.py::_block_lanczos on more than one rank.
+extern "C" int pk_lanczos_products(pk_ctx *ctx, void *stream, pk_mat *A, int32_t b, int32_t j, const double *Q_dev, int64_t ldq,
+                                   double *W_out_dev, int32_t rounded) {
+    if (!ctx || !A) return PK_E_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    PoolScope pool_scope(ctx);
+    StreamScope stream_scope(ctx, stream);
+    (void)hipSetDevice(ctx->device);
+    const int64_t n = A->A.n_cols;
+    if (b < 1 || b > 1024 || j < 1 || !Q_dev || !W_out_dev || !A->Tb || ldq < (int64_t)j * b)
+        return fail(ctx, PK_E_INVALID, "pk_lanczos_products: bad arguments (b=%d, j=%d)", b, j);
+    Solver S{ctx, ctx->stream, Dev()};
+    GramianOp gop{ctx, S, A, nullptr};
+    DMat W;
+    CK(lanczos_products(ctx, S, gop, n, b, j, LanczosBuffers{const_cast<double *>(Q_dev), ldq, nullptr, 0, nullptr, nullptr, nullptr}, W, rounded != 0));
+    HIPCK(hipMemcpyAsync(W_out_dev, W.p(), (size_t)n * b * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    return PK_OK;
+}
+
+extern "C" int pk_lanczos_orth(pk_ctx *ctx, void *stream, int64_t n_items, int32_t b, int32_t j, int32_t last_closes, double *Q_dev,
+                               int64_t ldq, double *T_dev, int64_t ldt, const double *W_dev, double *S_out_dev, double *flags_dev,
+                               int32_t rounded) {
+    if (!ctx) return PK_E_INVALID;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    PoolScope pool_scope(ctx);
+    StreamScope stream_scope(ctx, stream);
+    (void)hipSetDevice(ctx->device);
+    if (n_items < 1 || b < 1 || b > 1024 || j < 1 || !Q_dev || !T_dev || !W_dev || !S_out_dev || !flags_dev ||
+        ldq < (int64_t)(j + (last_closes ? 0 : 1)) * b || ldt < (int64_t)j * b || (int64_t)j * b > 4096)
+        return fail(ctx, PK_E_INVALID, "pk_lanczos_orth: bad arguments (b=%d, j=%d)", b, j);
+    Solver S{ctx, ctx->stream, Dev()};
+    Dev info(12), chol_work((size_t)std::max<int64_t>(pk_chol_work_bytes(b), 8));
+    if (!info.p || !chol_work.p) return fail(ctx, PK_E_LAUNCH, "out of device memory (pk_lanczos_orth)");
+    DMat W = DMat::view(W_dev, n_items, b), Sc;
+    CK(lanczos_orth(ctx, S, n_items, b, j, last_closes != 0, LanczosBuffers{Q_dev, ldq, T_dev, ldt, flags_dev, info.as<int32_t>(), chol_work.p}, W, Sc,
+                    rounded != 0));
+    HIPCK(hipMemcpyAsync(S_out_dev, Sc.p(), (size_t)b * b * 8, hipMemcpyDeviceToDevice, ctx->stream));
     return PK_OK;
 }
 

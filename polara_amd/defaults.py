@@ -18,7 +18,7 @@ _TABLE = dict(
     # has no dense score chunks, hence no use for the host-memory cap
     test_chunk_size=1000, max_test_workers=None, memory_hard_limit=1,
     # device solver knobs (new)
-    svd_tol=1e-12, svd_oversample=None, svd_seed=0, svd_max_outer=200, svd_shard_items=True,
+    svd_tol=1e-12, svd_oversample=None, svd_seed=0, svd_max_outer=200, svd_shard_items=None,
 )
 
 globals().update(_TABLE)

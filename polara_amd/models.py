@@ -615,7 +615,7 @@ class SVDModel(RecommenderModel):
         self.svd_seed = defaults.svd_seed
         self.svd_block = defaults.svd_oversample
         self.svd_max_outer = defaults.svd_max_outer
-        self.svd_shard_items = defaults.svd_shard_items   # multi-GPU: row-shard the item-side blocks of the solver (solver.ItemRows)
+        self.svd_shard_items = defaults.svd_shard_items   # multi-GPU: row-shard the item-side blocks of the solver (solver.ItemRows); None = the solver's choice (replicated where the library runs the step)
         self.svd_on_no_convergence = 'raise'   # or 'warn': keep the best available factors (stats['converged'] False)
         self.build_stats = {}
 

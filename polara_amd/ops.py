@@ -306,6 +306,23 @@ class LanczosRecurrence:
                                                  _ptr(Q), Q.stride(0), _ptr(T), T.stride(0), _ptr(S_out), _ptr(flags), 1 if rounded else 0),
                    'pk_lanczos_steps', self.ops.lib, self.ctx)
 
+    def products(self, Q, j, rounded=False):
+        """W [n_items x b] = A^T (A Q_j) of THIS process's rows (block j of the basis Q): the first half of a step of a
+        user-sharded build — the caller sums W over the ranks and hands it to `orth`"""
+        self._timing()
+        assert Q.stride(1) == 1
+        W = self.ops.empty(Q.shape[0], self.b)
+        _lib.check(self.ops.lib.pk_lanczos_products(self.ctx, self._stream(), self.handle, self.b, int(j), _ptr(Q), Q.stride(0), _ptr(W),
+                                                    1 if rounded else 0), 'pk_lanczos_products', self.ops.lib, self.ctx)
+        return W
+
+    def orth(self, Q, T, S_out, flags, W, j, last_closes, rounded=False):
+        """the second half of step j from the summed W: block column j of T, the next block of Q, the coupling S"""
+        assert Q.stride(1) == 1 and T.stride(1) == 1 and W.is_contiguous() and W.shape == (Q.shape[0], self.b)
+        _lib.check(self.ops.lib.pk_lanczos_orth(self.ctx, self._stream(), Q.shape[0], self.b, int(j), 1 if last_closes else 0, _ptr(Q),
+                                                Q.stride(0), _ptr(T), T.stride(0), _ptr(W), _ptr(S_out), _ptr(flags), 1 if rounded else 0),
+                   'pk_lanczos_orth', self.ops.lib, self.ctx)
+
     def gramian(self, X):
         self._timing()
         X = X.contiguous()

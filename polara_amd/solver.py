@@ -578,7 +578,7 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
         # one process: nothing is exchanged, but the same relaxation applies to the PRODUCTS — the late steps gather fp32 images
         # of their dense blocks (half the bytes per gathered row; pk_lanczos_steps(rounded)); `lay.relaxed` / `lay.exchange_dtype`
         # carry the state for both forms (gate, verification in fp64, fall-back)
-        lay.relaxed = products == 'relaxed' and b % 4 == 0
+        lay.relaxed = (products == 'relaxed' and b % 4 == 0) if comm.world == 1 else bool(getattr(lay, 'relaxed', False))
     S_buf = ops.zeros(b, b) if rec is not None else None
     cap = min(qcap, 20)
     Qbuf = ops.empty(lay.rows, cap * b)
@@ -641,7 +641,7 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
     def relax_now(j_now):
         if relax_at[0] is not None and j_now >= relax_at[0] and getattr(lay, 'relaxed', False) and lay.exchange_dtype is None:
             lay.exchange_dtype = torch.float32
-            stats['exchange_relaxed_from' if rec is None else 'products_rounded_from'] = j_now + 1
+            stats['exchange_relaxed_from' if (rec is None or comm.world > 1) else 'products_rounded_from'] = j_now + 1
 
     def plan(j_now):
         """the step of the next look from the history of estimates; (step, final?)"""
@@ -667,7 +667,15 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
             last = j == qcap
             relax_now(j - 1)
             if rec is not None:
-                rec.steps(Qbuf, T, S_buf, flags, j - 1, 1, last, rounded=lay.exchange_dtype is not None)
+                rounded = lay.exchange_dtype is not None
+                if comm.world == 1:
+                    rec.steps(Qbuf, T, S_buf, flags, j - 1, 1, last, rounded=rounded)
+                else:
+                    # users sharded, item side replicated: this rank's products, ONE sum over the ranks (the blocks travel in
+                    # fp32 once a relaxed build has opened its gate), the same orthogonalisation on every rank
+                    W = rec.products(Qbuf, j, rounded=False)
+                    W = comm.allreduce(W.to(lay.exchange_dtype)).to(torch.float64) if rounded else comm.allreduce(W)
+                    rec.orth(Qbuf, T, S_buf, flags, W.contiguous(), j, last, rounded=rounded)
                 stats['gramian_steps'] += 1
                 stats['spmm_cols'] += b
                 S = S_buf
@@ -734,6 +742,8 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
                 rounded, lay.exchange_dtype = lay.exchange_dtype, (None if getattr(lay, 'relaxed', False) else lay.exchange_dtype)
                 if rec is not None:                # one true product on the k Ritz vectors
                     Z = rec.gramian(Vk)
+                    if comm.world > 1:
+                        Z = comm.allreduce(Z)
                     stats['gramian_steps'] += 1
                     stats['spmm_cols'] += k
                 else:
@@ -875,9 +885,11 @@ def plan_build(ops, A, k, block=None, method=None, krylov_block=None, max_steps=
 
 
 def _library_recurrence(ops, A, comm, sharded):
-    """True when the steps of a Lanczos build of A run inside the library (ops.lanczos_recurrence): one process, a device
-    matrix.  Sharded builds (collectives inside the step), host-side operators and the CPU double take the composition."""
-    return (not sharded and comm.world == 1 and not getattr(comm, '_always', False) and hasattr(ops, 'lanczos_recurrence')
+    """True when the steps of a Lanczos build of A run inside the library (ops.lanczos_recurrence): a device matrix and a
+    REPLICATED item side — one process, or users sharded over the ranks with ONE all-reduce of W = A^T A Q_j per step between the
+    two halves of the library's step (pk_lanczos_products / pk_lanczos_orth).  The row-sharded item layout (`ItemRows.sharded`:
+    collectives inside the orthogonalisation), host-side operators and the CPU double take the composition."""
+    return (not sharded and not getattr(comm, '_always', False) and hasattr(ops, 'lanczos_recurrence')
             and hasattr(A, 'indptr') and not hasattr(A, 'matvec'))
 
 
@@ -895,7 +907,7 @@ def prepare_operator(ops, A, k, comm=None, **kw):
 
 
 def svd_topk(ops, A, k, block=None, tol=1e-12, max_outer=200, m_max=24, spread=1e7, seed=0,
-             comm=None, want_u=False, verbose=False, even_lock=True, shard_items=True, method=None, max_steps=None,
+             comm=None, want_u=False, verbose=False, even_lock=True, shard_items=None, method=None, max_steps=None,
              exchange='auto', krylov_block=None, monitor_lag=None, exchange_overlap='auto', first_look=None, products='auto'):
     """Returns (U_local | None, sigma[k] desc, V [n_items x k], stats) as device tensors of `ops`.
 
@@ -942,6 +954,11 @@ def svd_topk(ops, A, k, block=None, tol=1e-12, max_outer=200, m_max=24, spread=1
         warnings.warn('svd_topk: exchange=\'f32\' rounds every exchanged product to 6e-8 of its norm; a tolerance of %.1e is out of '
                       'its reach (use \'relaxed\' or \'f64\')' % tol, RuntimeWarning, stacklevel=2)
     xdt = torch.float32 if exchange == 'f32' else None
+    if shard_items is None:
+        # the item side of a sharded build: REPLICATED where the library runs the step (one all-reduce of a 16-column block per
+        # step, the orthogonalisation — 0.3 ms — repeated on every rank), row-sharded (`ItemRows`) for the composition, whose
+        # per-rank dense work it divides by the number of ranks
+        shard_items = not (method == 'lanczos' and _library_recurrence(ops, A, comm, False))
     lay = ItemRows(ops, comm, n_items, shard_items, exchange_dtype=xdt, overlap=exchange_overlap)
     lay.relaxed = exchange == 'relaxed'
     stats = dict(krylov_block=kb if method == 'lanczos' else None, exchange={'auto': 'f64'}.get(exchange, exchange), outer=0, gramian_steps=0, spmm_cols=0, degrees=[], locked_at=[], block=l, converged=False,

@@ -68,6 +68,38 @@ def main():
     ok['ml1m_sigma'] = bool(np.allclose(sharded.factors['singular_values'], single.factors['singular_values'], rtol=1e-11))
     ok['ml1m_recs_equal_frac'] = float((r_sh == r_si).all(axis=1).mean())
     ok['allreduces'] = comm.n_allreduce
+    # Round 6: the block Lanczos build of a user-sharded matrix with the steps INSIDE the library — every rank computes the
+    # products of its rows (pk_lanczos_products), W is summed over the ranks (ONE all-reduce of n_items x 16 per step), every
+    # rank runs the same orthogonalisation (pk_lanczos_orth) and the same looks on the replicated projected matrix: the
+    # factors of the one-process build of the whole matrix; also with the late exchanges rounded to fp32 (exchange='relaxed')
+    from polara_amd.csr import nnz_balanced_row_partition
+    from polara_amd.solver import svd_topk
+    from polara_amd.synth import planted_csr
+    m = planted_csr(30000, 4000, 60, 40, levels=5, seed=11, min_items=8, max_items=400)
+    c = csr_to_numpy(m)
+    whole = ops.csr(c['indptr'], c['indices'], c['values'], c['shape'])
+    k = 24
+    _, s1, V1, st1 = svd_topk(ops, whole, k, method='lanczos', krylov_block=16)
+    bounds = nnz_balanced_row_partition(c['indptr'], comm.world)
+    lo, hi = int(bounds[comm.rank]), int(bounds[comm.rank + 1])
+    sub = slice(int(c['indptr'][lo]), int(c['indptr'][hi]))
+    part = ops.csr(c['indptr'][lo:hi + 1] - c['indptr'][lo], c['indices'][sub], c['values'][sub], (hi - lo, c['shape'][1]))
+    n0 = comm.n_allreduce
+    U2, s2, V2, st2 = svd_topk(ops, part, k, comm=comm, method='lanczos', krylov_block=16, want_u=True)
+    n1 = comm.n_allreduce
+    s1h, s2h, V1h, V2h = (ops.to_host(t) for t in (s1, s2, V1, V2))
+    ok['library_recurrence_sharded'] = bool(
+        st1['recurrence'] == 'library' and st2['recurrence'] == 'library' and not st2['items_sharded'] and st2['converged']
+        and st2['verified_rel_residual'] <= 1e-12 and np.allclose(s1h, s2h, rtol=1e-10)
+        and np.abs(V1h @ V1h[:300].T - V2h @ V2h[:300].T).max() < 1e-8
+        and n1 - n0 == st2['gramian_steps'] and U2.shape == (hi - lo, k))          # one all-reduce per product (steps + verification), nothing else
+    ok['library_recurrence_sharded_steps'] = (st1['lanczos_steps'], st2['lanczos_steps'], n1 - n0)
+    _, s3, V3, st3 = svd_topk(ops, part, k, comm=comm, method='lanczos', krylov_block=16, monitor_lag=1, first_look=4, exchange='relaxed')
+    s3h, V3h = ops.to_host(s3), ops.to_host(V3)
+    ok['library_recurrence_relaxed_exchange'] = bool(
+        st3['recurrence'] == 'library' and st3['converged'] and st3['verified_rel_residual'] <= 1e-12
+        and st3.get('exchange_relaxed_from') is not None and np.allclose(s1h, s3h, rtol=1e-10)
+        and np.abs(V1h @ V1h[:300].T - V3h @ V3h[:300].T).max() < 1e-8)
     comm.barrier()
     if comm.rank == 0:
         print('DIST_GPU_RESULT', ok)
