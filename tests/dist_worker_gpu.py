@@ -92,7 +92,7 @@ def main():
         st1['recurrence'] == 'library' and st2['recurrence'] == 'library' and not st2['items_sharded'] and st2['converged']
         and st2['verified_rel_residual'] <= 1e-12 and np.allclose(s1h, s2h, rtol=1e-10)
         and np.abs(V1h @ V1h[:300].T - V2h @ V2h[:300].T).max() < 1e-8
-        and n1 - n0 == st2['gramian_steps'] and U2.shape == (hi - lo, k))          # one all-reduce per product (steps + verification), nothing else
+        and n1 - n0 == st2['gramian_steps'] + 1 and U2.shape == (hi - lo, k))      # one all-reduce per product (steps + verification) + the entry count of the plan: nothing else
     ok['library_recurrence_sharded_steps'] = (st1['lanczos_steps'], st2['lanczos_steps'], n1 - n0)
     _, s3, V3, st3 = svd_topk(ops, part, k, comm=comm, method='lanczos', krylov_block=16, monitor_lag=1, first_look=4, exchange='relaxed')
     s3h, V3h = ops.to_host(s3), ops.to_host(V3)
