@@ -85,6 +85,7 @@ struct pk_ctx {
     DevPool pool;
     CtxOptions opt;
     std::vector<SpmmTiming> spmm_timings;
+    std::vector<hipEvent_t> event_pool;      // events of collected timings, handed out again (hipEventCreate costs tens of microseconds)
 };
 
 static thread_local DevPool *g_pool = nullptr;   // the pool of the context whose call runs on this thread
@@ -326,8 +327,12 @@ int spmm(pk_ctx *ctx, Csr &M, const void *X, int x_kind, int64_t ldx, int nc, do
         if (need > P.partial.bytes && !P.partial.alloc(need)) return fail(ctx, PK_E_LAUNCH, "out of device memory (spmm partials)");
         SpmmTiming tm;
         if (ctx->opt.time_spmm) {
-            HIPCK(hipEventCreate(&tm.e0));
-            HIPCK(hipEventCreate(&tm.e1));
+            auto take = [&](hipEvent_t *e) -> hipError_t {
+                if (!ctx->event_pool.empty()) { *e = ctx->event_pool.back(); ctx->event_pool.pop_back(); return hipSuccess; }
+                return hipEventCreate(e);
+            };
+            HIPCK(take(&tm.e0));
+            HIPCK(take(&tm.e1));
             const int64_t whole[3] = {M.n_rows, M.n_cols, M.nnz};
             const int64_t *sh = shape3 ? shape3 : whole;
             tm.meta[0] = sh[0]; tm.meta[1] = sh[1]; tm.meta[2] = sh[2]; tm.meta[3] = w;
@@ -663,6 +668,10 @@ extern "C" int pk_ctx_create(int32_t device, pk_ctx **out) {
 
 extern "C" void pk_ctx_destroy(pk_ctx *ctx) {
     if (!ctx) return;
+    for (auto &t : ctx->spmm_timings) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
+    for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+    ctx->spmm_timings.clear();
+    ctx->event_pool.clear();
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     ctx->pool.trim();
@@ -704,8 +713,8 @@ extern "C" int64_t pk_ctx_spmm_timings(pk_ctx *ctx, double *ms_out, int64_t *met
             ms_out[i] = (double)ms;
             for (int q = 0; q < 6; ++q) meta_out[6 * i + q] = t.meta[q];
         }
-        (void)hipEventDestroy(t.e0);
-        (void)hipEventDestroy(t.e1);
+        ctx->event_pool.push_back(t.e0);
+        ctx->event_pool.push_back(t.e1);
     }
     ctx->spmm_timings.clear();
     return count;

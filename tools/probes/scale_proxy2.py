@@ -70,9 +70,12 @@ def replay(log, rows):
 
 
 class ShardComm(NoComm):
-    """rank 0 of an N-rank job with the exchange stubbed: the build takes the Python COMPOSITION of the Lanczos step (what a
-    sharded build runs: its collectives sit inside the step), not the library recurrence of a one-process build"""
-    _always = True
+    """rank 0 of an N-rank job with the exchange stubbed (the sum over the ranks is the identity): since round 6 a sharded
+    build runs the library's recurrence too — this rank's products, ONE all-reduce of the Krylov block per step (modelled
+    below), the orthogonalisation replicated on every rank"""
+
+    def __init__(self, world):
+        self.world = world
 
 
 METHOD = None
@@ -80,7 +83,15 @@ NNZ_TOTAL = int(c['indptr'][-1])
 for N in (1, 2, 4, 8):
     bounds = nnz_balanced_row_partition(c['indptr'], N)
     A = A0 if N == 1 else ops.csr_rows(A0, 0, int(bounds[1]))
-    KW = {} if N == 1 else dict(comm=ShardComm(), krylov_block=choose_krylov_block(NNZ_TOTAL, n_items, default_block(rank, n_items), N))
+    KW = {}
+    if N > 1:      # the JOB's decisions (the stub cannot sum the entry count): block width, look schedule
+        from polara_amd.solver import _lanczos_model
+        import math
+        lw = default_block(rank, n_items)
+        kb = choose_krylov_block(NNZ_TOTAL, n_items, lw, N)
+        steps_m, t_m = _lanczos_model(NNZ_TOTAL, n_items, lw, kb, N)
+        lag = int(min(10, max(3, math.ceil(5e-3 * max(1.0, lw / 64.0) ** 1.5 / t_m))))
+        KW = dict(comm=ShardComm(N), krylov_block=kb, monitor_lag=lag, first_look=int(math.ceil((0.7 if lag >= 5 else 0.5) * steps_m)))
     _ = A.plan
     _, _, _, st0 = svd_topk(ops, A, rank, method=METHOD, **KW)                     # warm-up (allocations)
     if N == 1:
@@ -105,6 +116,8 @@ for N in (1, 2, 4, 8):
     # small all-reduces per step: block Lanczos reduces the block column of T and the l x l Gram matrices of its three
     # orthogonalisation passes (5 per step, <= 0.5 MB each); the subspace iteration about as many per filter step
     small = (5 if st.get('method') == 'lanczos' else 3) * st['gramian_steps'] + 4 * st['outer']
+    if st.get('recurrence') == 'library':
+        small = 0          # the replicated item side exchanges nothing but the block itself
     ring = 0.0 if N == 1 else st['gramian_steps'] * (2.0 * (N - 1) / N * z_bytes / LINK + 2 * (N - 1) * 5e-6) \
         + small * (2 * (N - 1) * 5e-6)
     bus = 0.0 if N == 1 else st['gramian_steps'] * (2.0 * (N - 1) / N * z_bytes / 300e9 + 2 * (N - 1) * 5e-6) \
