@@ -332,10 +332,12 @@ class LanczosRecurrence:
         return Z
 
     def __del__(self):
+        # The handle is NOT freed here: a finaliser runs whenever the collector pleases — inside a hipGraph capture, say, where
+        # the synchronisation a free implies would invalidate the capture (scoring.CapturedPass; found by the scaling proxy).
+        # It is queued on the operator set, which frees queued handles at its next safe point (`lanczos_recurrence`).
         try:
             if getattr(self, 'handle', None):
-                torch.cuda.synchronize(self.ops.device)
-                self.ops.lib.pk_mat_free(self.ctx, self.handle)
+                self.ops._pending_mat_free.append((self.ctx, self.handle, self._keep))
                 self.handle = None
         except Exception:
             pass
@@ -359,6 +361,7 @@ class HipOps:
         import threading
         self.pass_lock = threading.RLock()   # scoring.recommend enqueues a pass as a whole (per-stream scratch state)
         self._aux_streams = []
+        self._pending_mat_free = []          # (context, handle, borrowed arrays) of collected LanczosRecurrence objects
         self.score_tiles_per_chunk = 0       # 0 = auto (L2-sized item chunks); tests force tiny chunks
         self.score_splits_override = 0       # 0 = auto (pk_score_splits); tests force item splits
         self.seen_dense_tiles = None         # None = auto window of the dense seen masks (DeviceCSR.seen_dense); tests
@@ -466,9 +469,19 @@ class HipOps:
             self._ctx_rec = ctx
         return self._ctx_rec
 
+    def free_pending_handles(self):
+        """releases the library handles of recurrence objects that have been collected (never inside a stream capture)"""
+        if not self._pending_mat_free or torch.cuda.is_current_stream_capturing():
+            return
+        pending, self._pending_mat_free = self._pending_mat_free, []
+        torch.cuda.synchronize(self.device)
+        for ctx, handle, _keep in pending:
+            self.lib.pk_mat_free(ctx, handle)
+
     def lanczos_recurrence(self, A, block_cols):
         """The recurrence object of the device matrix A for blocks of `block_cols` columns (cached on the matrix: the
         handle carries the library's transposed image of A)"""
+        self.free_pending_handles()
         cache = A.__dict__.setdefault('_recurrences', {})
         rec = cache.get(int(block_cols))
         if rec is None:
