@@ -227,6 +227,12 @@ int pk_eigh_top_f64(void *stream, int32_t n, const double *S_dev, int64_t lds_, 
 int64_t pk_chol_work_bytes(int32_t n);
 int pk_chol_rinv_f64(void *stream, int32_t n, const double *G_dev, int64_t ldg, double shift_rel, double *Rinv_dev,
                      int64_t ldr, void *work_dev, int32_t *info_dev);
+/* The same on the column-scaled matrix D G D, D = diag(G)^-1/2 (unit diagonal): Rinv = D R'^-1, so X Rinv is orthonormal all the
+ * same, but the factorisation sees the conditioning of the scaled block (columns of very different norm that are otherwise
+ * nearly orthogonal — filtered Ritz vectors — need one pass where the unscaled form needs two).  shift_rel is relative to
+ * trace(D G D) = n.  A non-positive diagonal entry of G is reported like a non-positive pivot. */
+int pk_chol_rinv_scaled_f64(void *stream, int32_t n, const double *G_dev, int64_t ldg, double shift_rel, double *Rinv_dev,
+                     int64_t ldr, void *work_dev, int32_t *info_dev);
 /* out = alpha*Z + beta*Y + gamma*X over n_elems (Chebyshev three-term recurrence); Y/X may be NULL */
 int pk_axpbypcz_f64(void *stream, int64_t n_elems, double alpha, const double *Z_dev, double beta,
                     const double *Y_dev, double gamma, const double *X_dev, double *out_dev);

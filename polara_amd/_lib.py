@@ -56,6 +56,7 @@ PROTOTYPES = {
     'pk_eigh_top_f64': (C.c_int, [_vp, _i32, _vp, _i64, _i32, _vp, _i64, _vp, _vp, _vp]),
     'pk_chol_work_bytes': (_i64, [_i32]),
     'pk_chol_rinv_f64': (C.c_int, [_vp, _i32, _vp, _i64, _f64, _vp, _i64, _vp, _vp]),
+    'pk_chol_rinv_scaled_f64': (C.c_int, [_vp, _i32, _vp, _i64, _f64, _vp, _i64, _vp, _vp]),
     'pk_axpbypcz_f64': (C.c_int, [_vp, _i64, _f64, _vp, _f64, _vp, _f64, _vp, _vp]),
     'pk_resid_blocks': (_i32, [_i64]),
     'pk_resid_colnorm2_f64': (C.c_int, [_vp, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _vp]),

@@ -512,7 +512,12 @@ extern "C" int pk_dgemm_small_f64(void *stream, int transA, int transB, int32_t 
 // back to the eigen-whitening, which clamps).
 #define PK_CHOL_LDS_MAX 136
 #define PK_CHOL_THREADS 1024
-template <bool IN_LDS>
+// SCALED: the factorisation runs on the column-scaled matrix D G D, D = diag(G)^-1/2 (unit diagonal; a zero or negative diagonal
+// entry is a failure like a non-positive pivot), and Rinv comes back as D R'^-1: X Rinv is orthonormal all the same, but the
+// Cholesky sees the conditioning of the SCALED block — for a block of filtered Ritz vectors, whose columns differ by the
+// filter's amplification (up to 1e7) and are otherwise nearly orthogonal, ~1e1 instead of ~1e14 (round 6: one pass where two
+// were needed between the segments of a nested solve).
+template <bool IN_LDS, bool SCALED = false>
 __global__ __launch_bounds__(PK_CHOL_THREADS) void chol_rinv_kernel(int n, const double *__restrict__ G, int64_t ldg,
                                                                     double shift_rel, double *__restrict__ Rinv,
                                                                     int64_t ldr, double *__restrict__ work,
@@ -526,15 +531,22 @@ __global__ __launch_bounds__(PK_CHOL_THREADS) void chol_rinv_kernel(int n, const
     const int tx = tid & (TX - 1), ty = tid >> tx_log2;
     if (tid < 64) {
         double tr = 0.0;                             // shift = shift_rel * trace(G) >= shift_rel * ||X||_2^2
-        for (int i = tid; i < n; i += 64) tr += G[(int64_t)i * ldg + i];
+        for (int i = tid; i < n; i += 64) tr += SCALED ? 1.0 : G[(int64_t)i * ldg + i];      // (the scaled matrix has a unit diagonal)
         for (int o = 32; o > 0; o >>= 1) tr += __shfl_xor(tr, o);      // fixed order: the same sum on every rank
         if (tid == 0) s_shift = shift_rel * tr;
     }
     __syncthreads();
     const double shift = s_shift;
     for (int i = ty; i < n; i += TY)
-        for (int c = tx; c < n; c += TX)
-            A[i * ld + c] = (c > i) ? G[(int64_t)i * ldg + c] : (c == i ? G[(int64_t)i * ldg + c] + shift : 0.0);
+        for (int c = tx; c < n; c += TX) {
+            double g = (c >= i) ? G[(int64_t)i * ldg + c] : 0.0;
+            if constexpr (SCALED) {
+                const double gi = G[(int64_t)i * ldg + i], gc = G[(int64_t)c * ldg + c];
+                // a non-positive diagonal entry makes the first pivot of its column fail below (NaN or <= 0 compares false to > 0)
+                g = (c > i) ? g / (sqrt(gi) * sqrt(gc)) : (c == i ? (gi > 0.0 ? 1.0 : -1.0) : 0.0);
+            }
+            A[i * ld + c] = (c > i) ? g : (c == i ? g + shift : 0.0);
+        }
     int fail = 0;
     for (int j = 0; j < n; ++j) {
         __syncthreads();
@@ -564,6 +576,7 @@ __global__ __launch_bounds__(PK_CHOL_THREADS) void chol_rinv_kernel(int n, const
             if (c >= k) {
                 const double rs = 1.0 / sqrt(A[c * ld + c]);
                 v = (c == k) ? rs : A[c * ld + k] * rs;
+                if constexpr (SCALED) v /= sqrt(G[(int64_t)k * ldg + k]);       // Rinv = D R'^-1: row k carries d_k
             }
             Rinv[(int64_t)k * ldr + c] = v;
         }
@@ -571,15 +584,31 @@ __global__ __launch_bounds__(PK_CHOL_THREADS) void chol_rinv_kernel(int n, const
 
 extern "C" int64_t pk_chol_work_bytes(int32_t n) { return (n > PK_CHOL_LDS_MAX) ? (int64_t)n * n * 8 : 0; }
 
+static int chol_rinv_launch(void *stream, int32_t n, const double *G_dev, int64_t ldg, double shift_rel, double *Rinv_dev, int64_t ldr,
+                            void *work_dev, int32_t *info_dev, bool scaled);
+
 extern "C" int pk_chol_rinv_f64(void *stream, int32_t n, const double *G_dev, int64_t ldg, double shift_rel,
                                 double *Rinv_dev, int64_t ldr, void *work_dev, int32_t *info_dev) {
+    return chol_rinv_launch(stream, n, G_dev, ldg, shift_rel, Rinv_dev, ldr, work_dev, info_dev, false);
+}
+
+extern "C" int pk_chol_rinv_scaled_f64(void *stream, int32_t n, const double *G_dev, int64_t ldg, double shift_rel,
+                                       double *Rinv_dev, int64_t ldr, void *work_dev, int32_t *info_dev) {
+    return chol_rinv_launch(stream, n, G_dev, ldg, shift_rel, Rinv_dev, ldr, work_dev, info_dev, true);
+}
+
+static int chol_rinv_launch(void *stream, int32_t n, const double *G_dev, int64_t ldg, double shift_rel, double *Rinv_dev, int64_t ldr,
+                            void *work_dev, int32_t *info_dev, bool scaled) {
     PK_REQUIRE(n >= 1 && n <= 1024 && ldg >= n && ldr >= n, "pk_chol_rinv_f64: bad sizes");
     PK_REQUIRE(G_dev && Rinv_dev && info_dev && (n <= PK_CHOL_LDS_MAX || work_dev), "pk_chol_rinv_f64: bad pointers");
     static PkDeviceOnce attr_set;   
     if (attr_set.pending()) {
-        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&chol_rinv_kernel<true>),
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&chol_rinv_kernel<true, false>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize,
                                             PK_CHOL_LDS_MAX * (PK_CHOL_LDS_MAX + 1) * 8);
+        if (e1 == hipSuccess)
+            e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&chol_rinv_kernel<true, true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, PK_CHOL_LDS_MAX * (PK_CHOL_LDS_MAX + 1) * 8);
         if (e1 != hipSuccess) {
             pk_set_error("pk_chol_rinv_f64: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e1));
             return PK_E_LAUNCH;
@@ -595,13 +624,18 @@ extern "C" int pk_chol_rinv_f64(void *stream, int32_t n, const double *G_dev, in
     // sizes; a dedicated kernel, lane = column, one wave for n <= 16 and four above, loads batched — 19 us against 12 at 16 x 16,
     // 66 us against 37 at 64 x 64 (tools/probes/chol_probe.py))
     const int threads = PK_CHOL_THREADS;
-    if (n <= PK_CHOL_LDS_MAX)
-        hipLaunchKernelGGL(chol_rinv_kernel<true>, dim3(1), dim3(threads), (size_t)n * (n + 1) * sizeof(double),
-                           pk_stream(stream), n, G_dev, ldg, shift_rel, Rinv_dev, ldr, static_cast<double *>(work_dev),
-                           info_dev, tx_log2);
-    else
-        hipLaunchKernelGGL(chol_rinv_kernel<false>, dim3(1), dim3(PK_CHOL_THREADS), 0, pk_stream(stream), n, G_dev,
-                           ldg, shift_rel, Rinv_dev, ldr, static_cast<double *>(work_dev), info_dev, tx_log2);
+#define PK_CHOL_LAUNCH(SC)                                                                                                   \
+    do {                                                                                                                     \
+        if (n <= PK_CHOL_LDS_MAX)                                                                                            \
+            hipLaunchKernelGGL((chol_rinv_kernel<true, SC>), dim3(1), dim3(threads), (size_t)n * (n + 1) * sizeof(double),   \
+                               pk_stream(stream), n, G_dev, ldg, shift_rel, Rinv_dev, ldr, static_cast<double *>(work_dev),  \
+                               info_dev, tx_log2);                                                                           \
+        else                                                                                                                 \
+            hipLaunchKernelGGL((chol_rinv_kernel<false, SC>), dim3(1), dim3(PK_CHOL_THREADS), 0, pk_stream(stream), n, G_dev, \
+                               ldg, shift_rel, Rinv_dev, ldr, static_cast<double *>(work_dev), info_dev, tx_log2);           \
+    } while (0)
+    if (scaled) PK_CHOL_LAUNCH(true); else PK_CHOL_LAUNCH(false);
+#undef PK_CHOL_LAUNCH
     PK_CHECK_LAUNCH("chol_rinv_kernel");
     return PK_OK;
 }

@@ -1189,12 +1189,23 @@ static int dense_topk_segments(pk_ctx *ctx, Solver &S, DenseOp &dop, int k, DMat
                 Yc = std::move(Yn);
                 sigma = sigma_new;
             }
-            for (int p = 0; p < 3; ++p) {        // shifted CholeskyQR3, verdicts kept on the device
+            // CholeskyQR, verdicts kept on the device.  The first pass factorises the COLUMN-SCALED Gram matrix (pk_chol_rinv_scaled_f64):
+            // the columns of a filtered block of Ritz vectors differ by the filter's amplification (up to the spread, 1e7) and are
+            // otherwise nearly orthogonal, so the scaled block is well conditioned and ONE shifted pass leaves a block fit for the
+            // next filter (between segments); in front of the Rayleigh-Ritz step one plain pass follows (orthonormal to
+            // rounding: the scaled pass leaves I + O(shift) = I + 1e-11).  A pass is a 37 us Cholesky plus two small products: the
+            // largest item of a look (three unscaled passes per segment: 26.1-26.5 ms per build; two between segments: 24.5;
+            // one scaled between segments and two in front of the Rayleigh-Ritz step: 23.2-23.8)
+            const int passes = (seg + 1 == nseg) ? 2 : 1;
+            for (int p = 0; p < passes; ++p) {
                 DMat G, Rinv(l, l), Yn;
                 if (!Rinv.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (dense_topk_segments)");
                 CK(S.gram(Yc, Yc, G));
-                CK(pk_chol_rinv_f64(S.st, l, G.p(), l, p == 0 ? 11.0 * ((double)N * l + (double)l * (l + 1)) * u : 0.0, Rinv.p(), l, chol_work.p,
-                                    info.as<int32_t>() + 3 * seg + p));
+                if (p == 0)
+                    CK(pk_chol_rinv_scaled_f64(S.st, l, G.p(), l, 11.0 * ((double)N * l + (double)l * (l + 1)) * u, Rinv.p(), l, chol_work.p,
+                                               info.as<int32_t>() + 3 * seg + p));
+                else
+                    CK(pk_chol_rinv_f64(S.st, l, G.p(), l, 0.0, Rinv.p(), l, chol_work.p, info.as<int32_t>() + 3 * seg + p));
                 CK(S.tsmm(Yc, Rinv, Yn));
                 Yc = std::move(Yn);
             }
@@ -1227,12 +1238,35 @@ static int dense_topk_segments(pk_ctx *ctx, Solver &S, DenseOp &dop, int k, DMat
 // the k leading pairs of the dense PSD matrix behind `dop` from the orthonormal start block X: segments first, the
 // filtered subspace iteration with locking whenever they hand over
 static int dense_topk(pk_ctx *ctx, Solver &S, DenseOp &dop, int k, DMat X, double tol, int max_outer, uint64_t seed, const double *lam0,
-                      double r0_rel, SubspaceOut &out) {
+                      double r0_rel, SubspaceOut &out, bool cold = false) {
+    std::vector<double> lam_cold;
+    const int l = X.l;
+    const int64_t N = X.n;
+    if (cold && l <= 64 && N >= 2 * (int64_t)l) {
+        // A COLD solve (no pairs of an earlier look): the l unit vectors span the first blocks of the Krylov space only, and the
+        // wanted vectors have weight well beyond them — the segments then spend rounds finding it.  The leading 2l x 2l block of T
+        // is a projected matrix in its own right (that of the Krylov space 2l columns in): ONE eigen-decomposition of it
+        // (128 x 128: 2.7 ms) gives l start vectors with their Ritz values, from the span of twice as many blocks (fewer
+        // products — 57 -> 51 per build — for the same wall time: kept for the Ritz values it hands the first filter).
+        const int w = 2 * l;
+        DMat Tl(w, w), C2;
+        Dev lam_dev;
+        if (!Tl.ok()) return fail(ctx, PK_E_LAUNCH, "out of device memory (dense_topk)");
+        HIPCK(hipMemcpy2DAsync(Tl.p(), (size_t)w * 8, dop.T.p(), (size_t)dop.T.l * 8, (size_t)w * 8, (size_t)w, hipMemcpyDeviceToDevice, S.st));
+        std::vector<double> lam2;
+        CK(S.eigh(Tl, lam2, C2, lam_dev));
+        HIPCK(hipMemsetAsync(X.p(), 0, (size_t)N * l * 8, S.st));
+        HIPCK(hipMemcpy2DAsync(X.p(), (size_t)l * 8, C2.p(), (size_t)w * 8, (size_t)l * 8, (size_t)w, hipMemcpyDeviceToDevice, S.st));
+        lam_cold.assign(lam2.begin(), lam2.begin() + l);
+        lam0 = lam_cold.data();
+        r0_rel = -1.0;
+        out.outer += 1;
+    }
     DMat X0;
     CK(S.col_slice(X, 0, X.l, X0));
     bool ok = false;
     // (blocks of at most 64 columns: the Cholesky kernels of wider ones cost more than the Rayleigh-Ritz steps the segments save —
-    // rank 100, l = 128: 55.9 -> 65.6 ms per build, profiles/r06_krylov_block_ml20m_r100.txt)
+    // rank 100, l = 128: 55.9 -> 65.6 ms per build with three unscaled passes per segment, 44.8 -> 47.5 ms with one scaled pass)
     if (X.l <= 64) CK(dense_topk_segments(ctx, S, dop, k, X, tol, lam0, r0_rel, out, ok));
     if (ok) return PK_OK;
     const int outer0 = out.outer;
@@ -1278,13 +1312,16 @@ static int ritz_look(pk_ctx *ctx, Solver &S, const DMat &T, const DMat &Sc, cons
     };
     CK(pad(warm, warm ? warm->l : std::min(N, std::max(b, width))));      // cold: the first unit vectors, k + guard of them
     double t_in = std::max(0.3 * est_tol, prior < 0 ? 1e-4 : 0.03 * prior);
+    bool first_pass = true;
     for (;;) {
         DenseOp dop{ctx, S, T};
         SubspaceOut so;
         // (the start pairs of a warm look keep their Ritz values, and their residual w.r.t. this T is the old coupling estimate)
         const bool warm_pairs = warm && warm_lam && (int)warm_lam->size() == X0.l && prior >= 0;
-        CK(dense_topk(ctx, S, dop, k, std::move(X0), t_in, 200, seed, warm_pairs ? warm_lam->data() : nullptr, warm_pairs ? prior : -1.0, so));
+        CK(dense_topk(ctx, S, dop, k, std::move(X0), t_in, 200, seed, warm_pairs ? warm_lam->data() : nullptr, warm_pairs ? prior : -1.0, so,
+                      /*cold=*/!warm && first_pass));
         warm_lam = nullptr;
+        first_pass = false;
         lo.nested_outer += so.outer;
         lo.nested_products += dop.products;
         out.basis = std::move(so.basis);
@@ -1911,7 +1948,7 @@ extern "C" int pk_sym_eig_topk_f64(pk_ctx *ctx, void *stream, int32_t n, const d
     }
     DenseOp dop{ctx, S, T};
     SubspaceOut so;
-    CK(dense_topk(ctx, S, dop, k, std::move(X), tol, max_outer, seed, X0_dev ? lam0_host : nullptr, r0_rel, so));
+    CK(dense_topk(ctx, S, dop, k, std::move(X), tol, max_outer, seed, X0_dev ? lam0_host : nullptr, r0_rel, so, /*cold=*/X0_dev == nullptr));
     const int w = std::min<int>(l, so.basis.l);
     HIPCK(hipMemcpy2DAsync(basis_out_dev, (size_t)ldb * 8, so.basis.p(), (size_t)so.basis.l * 8, (size_t)w * 8, (size_t)n,
                            hipMemcpyDeviceToDevice, st));

@@ -994,7 +994,7 @@ class HipOps:
                                             _ptr(Z), Z.stride(0), _ptr(out), out.stride(0)), 'pk_tsmm_sub_f64')
         return out
 
-    def sym_eig_topk(self, T, k, X0=None, tol=1e-13, max_outer=200, seed=0, stats=None, lam0=None, r0_rel=-1.0):
+    def sym_eig_topk(self, T, k, X0=None, tol=1e-13, max_outer=200, seed=0, stats=None, lam0=None, r0_rel=-1.0, width=None):
         """The k leading eigenpairs of the small dense symmetric PSD device matrix T [n x n] — pk_sym_eig_topk_f64: the
         filtered subspace iteration of solver.py with T as the operator, driven from C++ (hundreds of microsecond
         kernels: from Python each would cost the host ~20 us).  X0: orthonormal start block [rows <= n x l] (missing rows
@@ -1009,7 +1009,7 @@ class HipOps:
                 lam0 = np.ascontiguousarray(lam0, dtype=np.float64)
                 lam0 = lam0 if len(lam0) == l else None
         else:
-            l = min(n, max(int(k), 8))
+            l = min(n, max(int(k), 8, int(width or 0)))       # a cold solve of block width `width`: the library picks its own start
         if self._ctx is None:
             ctx = C.c_void_p()
             _lib.check(self.lib.pk_ctx_create(self.device.index or 0, C.byref(ctx)), 'pk_ctx_create')

@@ -452,16 +452,16 @@ def _ritz_check(ops, Tj, S, X0, k, b, est_tol, prior, seed, inner, final=False, 
     iteration first runs to a loose tolerance and is tightened (warm) only while its own residual, not the coupling to the
     next block, is what limits the estimate.  Returns dict(est, coupling, conv, basis, lam_all, Yk, lam_k)."""
     N = Tj.shape[0]
-    if X0 is None:           # the first unit vectors: orthonormal, and (the first b of them) the seed of this very Krylov space
-        w = min(N, max(b, width or b))
-        X0 = ops.zeros(w, w)
-        X0[:w] = torch.eye(w, dtype=X0.dtype, device=X0.device)
+    cold_width = None
+    if X0 is None:           # a COLD look — the first unit vectors (the first b of them are the seed of this very Krylov space); the
+        cold_width = min(N, max(b, width or b))      # library starts it from the eigenvectors of T's leading block (pk_sym_eig_topk_f64)
     t_in = max(0.3 * est_tol, 1e-4 if prior is None else 0.03 * prior)
     if final:                # the look at the step the pairs are predicted to have converged at: straight to the end
         t_in = 0.3 * est_tol
     r0 = -1.0 if (lam0 is None or prior is None) else float(prior)     # the start pairs' residual w.r.t. THIS T: their old coupling estimate
     while True:
-        basis, lam_all, res_in, n_lock, conv_in = ops.sym_eig_topk(Tj, k, X0, t_in, 200, seed, inner, lam0=lam0, r0_rel=r0)
+        basis, lam_all, res_in, n_lock, conv_in = ops.sym_eig_topk(Tj, k, X0, t_in, 200, seed, inner, lam0=lam0, r0_rel=r0, width=cold_width)
+        cold_width = None
         lam0, r0 = None, -1.0                # (a tightened pass starts from pairs of THIS T: no Rayleigh-Ritz step is skipped)
         X0 = basis.contiguous()
         Yk = X0[:, :k].contiguous()

@@ -132,13 +132,13 @@ class NumpyOps:
             return out
         return r
 
-    def sym_eig_topk(self, T, k, X0=None, tol=1e-13, max_outer=200, seed=0, stats=None, lam0=None, r0_rel=-1.0):
+    def sym_eig_topk(self, T, k, X0=None, tol=1e-13, max_outer=200, seed=0, stats=None, lam0=None, r0_rel=-1.0, width=None):
         # (lam0 / r0_rel: what the product's segmented solve starts a warm look from; the double runs the general iteration)
         # the product path runs this loop in C++ (pk_sym_eig_topk_f64); the double runs the Python statement of it
         from polara_amd.solver import _subspace_iteration, _Dense, ItemRows, NoComm
         n = T.shape[0]
         if X0 is None:
-            l = min(n, max(int(k), 8))
+            l = min(n, max(int(k), 8, int(width or 0)))
             X = torch.zeros(n, l, dtype=torch.float64)
             X[:l] = torch.eye(l, dtype=torch.float64)
         else:

@@ -262,6 +262,38 @@ def test_chol_rinv(hip_ops, n):
         assert int(hip_ops.to_host(info)[0]) != 0
 
 
+@pytest.mark.parametrize('n', [5, 16, 64, 128, 200])
+def test_chol_rinv_of_the_column_scaled_gram_matrix(hip_ops, n):
+    """pk_chol_rinv_scaled_f64: Rinv = D R'^-1 from the Cholesky factor of D G D (D = diag(G)^-1/2): X Rinv is orthonormal
+    like the unscaled form's — and stays so on a block whose columns differ by twelve orders of magnitude and are otherwise
+    well conditioned (filtered Ritz vectors), where the unscaled, unshifted factorisation breaks down or loses everything."""
+    import ctypes as C
+    import torch
+    from polara_amd import _lib
+    from polara_amd.ops import _ptr
+    rng = np.random.RandomState(n)
+    Q, _ = np.linalg.qr(rng.randn(4 * n + 3, n))
+    X = (Q + 0.05 * rng.randn(4 * n + 3, n)) * np.exp(rng.uniform(-14, 14, n))       # cond(X) ~ 1e12, cond of the scaled block ~ 2
+    G = hip_ops.to_device(X.T @ X)
+    Rinv = hip_ops.empty(n, n)
+    info = torch.zeros(1, dtype=torch.int32, device=G.device)
+    need = hip_ops.lib.pk_chol_work_bytes(n)
+    work = hip_ops.empty((need + 7) // 8) if need else None
+    _lib.check(hip_ops.lib.pk_chol_rinv_scaled_f64(hip_ops.stream(), n, _ptr(G), n, 0.0, _ptr(Rinv), n, _ptr(work), _ptr(info)),
+               'pk_chol_rinv_scaled_f64')
+    assert int(hip_ops.to_host(info)[0]) == 0
+    R = hip_ops.to_host(Rinv)
+    assert np.allclose(R, np.triu(R))
+    Y = X @ R
+    assert np.abs(Y.T @ Y - np.eye(n)).max() < 1e-9
+    # a zero column is reported
+    Xz = X.copy(); Xz[:, n // 2] = 0.0
+    Gz = hip_ops.to_device(Xz.T @ Xz)
+    _lib.check(hip_ops.lib.pk_chol_rinv_scaled_f64(hip_ops.stream(), n, _ptr(Gz), n, 0.0, _ptr(Rinv), n, _ptr(work), _ptr(info)),
+               'pk_chol_rinv_scaled_f64')
+    assert int(hip_ops.to_host(info)[0]) != 0
+
+
 def test_elementwise_and_small_kernels(hip_ops):
     rng = np.random.RandomState(0)
     for n in (1, 7, 1000, 100001):
