@@ -532,3 +532,32 @@ def test_factor_image_without_torch_kernels_is_the_image_of_round_5(hip_ops):
     bad[17, 3] = np.nan
     with pytest.raises(ValueError):
         scoring.FactorImage(hip_ops, hip_ops.to_device(bad))
+
+
+def test_library_recurrence_hands_hard_matrices_to_the_subspace_iteration(hip_ops):
+    """The breakdown paths of the block Lanczos build with the steps inside the library: an exactly rank-deficient matrix (the
+    residual block loses rank: Cholesky verdicts / orthonormality flags on the device, read at the first look), a matrix with
+    fewer items than four Krylov blocks, and clustered singular values (tripled columns) — every one ends with the factors of
+    the dense SVD, through the fall-back where the recurrence cannot finish (`stats['lanczos_fallback']`), never with an error
+    out of a launcher."""
+    from polara_amd.solver import svd_topk
+    rng = np.random.RandomState(3)
+    cases = []
+    B = rng.standard_normal((400, 5)) @ rng.standard_normal((5, 90))                      # rank 5 exactly, 9 vectors asked for
+    cases.append(('rank5_ask9', sps.csr_matrix(B), 9, True))
+    cases.append(('tiny_40_items', sps.random(300, 40, density=0.3, random_state=1, format='csr'), 6, False))     # five blocks of 8 fill the whole space: the recurrence may finish
+    M = sps.random(3000, 120, density=0.08, random_state=2, format='csr')
+    cases.append(('tripled_columns', sps.hstack([M, M, M]).tocsr(), 20, False))
+    for name, M, k, must_fall_back in cases:
+        M = M.astype(np.float64)
+        A = hip_ops.csr(M.indptr.astype(np.int64), M.indices.astype(np.int32), M.data, M.shape)
+        _, s, V, st = svd_topk(hip_ops, A, k, method='lanczos', krylov_block=8)
+        s_ref = np.linalg.svd(M.toarray(), compute_uv=False)[:k]
+        s = hip_ops.to_host(s)
+        nz = s_ref > 1e-8 * s_ref[0]
+        assert st['converged'], (name, st)
+        assert np.allclose(s[nz], s_ref[nz], rtol=1e-9), (name, np.abs(s[nz] / s_ref[nz] - 1).max())
+        Vh = hip_ops.to_host(V)
+        assert np.abs(Vh.T @ Vh - np.eye(k)).max() < 1e-8, name
+        if must_fall_back:
+            assert 'lanczos_fallback' in st and st['method'].startswith('subspace'), (name, st.get('method'))
