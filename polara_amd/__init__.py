@@ -63,6 +63,23 @@ def runtime_info():
 
 configure_runtime()
 
+
+def freeze_imports():
+    """For a process that is about to build or serve: import the package's host modules, then move everything allocated so
+    far into the cycle collector's permanent generation (`gc.freeze()`).  CPython triggers a FULL collection whenever the
+    young survivors exceed a quarter of what the last full collection saw; right after `import torch` that count is small and
+    the heap holds ~half a million objects, so the first second of the process runs three full collections of 34 ms each —
+    one of them used to land inside the first build or the first scoring pass of `bench.py` (tools/probes/gc_trace.py: the
+    35-38 ms `cold.first_pass_ms` of rounds 5-6 were this; the pass itself takes 1.4-1.6 ms cold).  Frozen objects are still
+    freed by reference counting; only cycles among them are never looked at again.  Process-global, therefore explicit: the
+    library never calls it by itself.  Returns the number of frozen objects."""
+    import gc
+    import importlib
+    for mod in ('ops', 'solver', 'scoring', 'models', 'data', 'operator', 'dist'):
+        importlib.import_module('.' + mod, __name__)
+    gc.freeze()
+    return gc.get_freeze_count()
+
 _EXPORTS = {
     'RecommenderModel': 'models', 'SVDModel': 'models', 'ScaledSVD': 'models', 'CoffeeModel': 'models',
     'ArrayData': 'data', 'ShardedArrayData': 'data',

@@ -22,16 +22,21 @@ import torch.distributed as dist
 class TorchComm:
     """Communicator interface used by solver.svd_topk and models (rank, world, allreduce, gather_rows)."""
 
-    def __init__(self, group=None, exercise_collectives=False):
+    def __init__(self, group=None, exercise_collectives=False, split_step=False):
         """exercise_collectives: issue every collective even in a group of ONE rank (the shortcuts below return the local
         buffer instead).  A test switch: on a one-GPU box it is the only way to run the RCCL calls of this class — shapes,
-        dtypes, contiguity, in-place rules — against the real library (tests/test_gpu_dist.py)."""
+        dtypes, contiguity, in-place rules — against the real library (tests/test_gpu_dist.py).  By itself it selects the
+        row-sharded item layout of the solver (collectives inside the orthogonalisation); with `split_step` the build takes the
+        DEFAULT form of a user-sharded build instead — the library's step in its two halves with ONE all-reduce of the block
+        between them (solver._block_lanczos) — so that this sequence too (our kernels on the current stream, RCCL's on its
+        own, the library's buffers as operands) meets the real library on a one-GPU box."""
         if not dist.is_initialized():
             raise RuntimeError('torch.distributed is not initialised; call init_from_env() first')
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
-        self._always = bool(exercise_collectives)
+        self.split_step = bool(split_step)
+        self._always = bool(exercise_collectives) or self.split_step
         self.bytes_reduced = 0
         self.n_allreduce = 0
         self.bytes_gathered = self.bytes_scattered = 0

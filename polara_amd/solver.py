@@ -573,12 +573,13 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
     rec = None
     if _library_recurrence(ops, A, comm, lay.sharded):
         rec = ops.lanczos_recurrence(A, b)
+    halves = comm.world > 1 or getattr(comm, 'split_step', False)      # the library's step with the sum over the ranks in the middle
     stats['recurrence'] = 'library' if rec is not None else 'composition'
     if rec is not None:
         # one process: nothing is exchanged, but the same relaxation applies to the PRODUCTS — the late steps gather fp32 images
         # of their dense blocks (half the bytes per gathered row; pk_lanczos_steps(rounded)); `lay.relaxed` / `lay.exchange_dtype`
         # carry the state for both forms (gate, verification in fp64, fall-back)
-        lay.relaxed = (products == 'relaxed' and b % 4 == 0) if comm.world == 1 else bool(getattr(lay, 'relaxed', False))
+        lay.relaxed = (products == 'relaxed' and b % 4 == 0) if not halves else bool(getattr(lay, 'relaxed', False))
     S_buf = ops.zeros(b, b) if rec is not None else None
     cap = min(qcap, 20)
     Qbuf = ops.empty(lay.rows, cap * b)
@@ -641,7 +642,7 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
     def relax_now(j_now):
         if relax_at[0] is not None and j_now >= relax_at[0] and getattr(lay, 'relaxed', False) and lay.exchange_dtype is None:
             lay.exchange_dtype = torch.float32
-            stats['exchange_relaxed_from' if (rec is None or comm.world > 1) else 'products_rounded_from'] = j_now + 1
+            stats['exchange_relaxed_from' if (rec is None or halves) else 'products_rounded_from'] = j_now + 1
 
     def plan(j_now):
         """the step of the next look from the history of estimates; (step, final?)"""
@@ -668,7 +669,7 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
             relax_now(j - 1)
             if rec is not None:
                 rounded = lay.exchange_dtype is not None
-                if comm.world == 1:
+                if not halves:
                     rec.steps(Qbuf, T, S_buf, flags, j - 1, 1, last, rounded=rounded)
                 else:
                     # users sharded, item side replicated: this rank's products, ONE sum over the ranks (the blocks travel in
@@ -742,7 +743,7 @@ def _block_lanczos(ops, A, At, lay, comm, k, l, tol, seed, stats, verbose, max_s
                 rounded, lay.exchange_dtype = lay.exchange_dtype, (None if getattr(lay, 'relaxed', False) else lay.exchange_dtype)
                 if rec is not None:                # one true product on the k Ritz vectors
                     Z = rec.gramian(Vk)
-                    if comm.world > 1:
+                    if halves:
                         Z = comm.allreduce(Z)
                     stats['gramian_steps'] += 1
                     stats['spmm_cols'] += k
@@ -889,7 +890,7 @@ def _library_recurrence(ops, A, comm, sharded):
     REPLICATED item side — one process, or users sharded over the ranks with ONE all-reduce of W = A^T A Q_j per step between the
     two halves of the library's step (pk_lanczos_products / pk_lanczos_orth).  The row-sharded item layout (`ItemRows.sharded`:
     collectives inside the orthogonalisation), host-side operators and the CPU double take the composition."""
-    return (not sharded and not getattr(comm, '_always', False) and hasattr(ops, 'lanczos_recurrence')
+    return (not sharded and (not getattr(comm, '_always', False) or getattr(comm, 'split_step', False)) and hasattr(ops, 'lanczos_recurrence')
             and hasattr(A, 'indptr') and not hasattr(A, 'matvec'))
 
 
@@ -899,7 +900,7 @@ def prepare_operator(ops, A, k, comm=None, **kw):
     (bench.py's `transpose_and_plans_s`); `svd_topk` finds it cached on the matrix.  Returns the plan of the build."""
     comm = comm or NoComm()
     plan = plan_build(ops, A, k, comm=comm, **kw)
-    if plan['method'] == 'lanczos' and _library_recurrence(ops, A, comm, comm.world > 1):
+    if plan['method'] == 'lanczos' and _library_recurrence(ops, A, comm, False):      # svd_topk's own default (item side replicated)
         ops.lanczos_recurrence(A, plan['krylov_block'])
     elif hasattr(A, 'transpose_operator'):
         A.transpose_operator()
@@ -954,6 +955,8 @@ def svd_topk(ops, A, k, block=None, tol=1e-12, max_outer=200, m_max=24, spread=1
         warnings.warn('svd_topk: exchange=\'f32\' rounds every exchanged product to 6e-8 of its norm; a tolerance of %.1e is out of '
                       'its reach (use \'relaxed\' or \'f64\')' % tol, RuntimeWarning, stacklevel=2)
     xdt = torch.float32 if exchange == 'f32' else None
+    if getattr(comm, 'split_step', False) and shard_items is None:
+        shard_items = False                 # (TorchComm's test switch: the two halves of the library's step in a group of one)
     if shard_items is None:
         # the item side of a sharded build: REPLICATED where the library runs the step (one all-reduce of a 16-column block per
         # step, the orthogonalisation — 0.3 ms — repeated on every rank), row-sharded (`ItemRows`) for the composition, whose

@@ -59,7 +59,20 @@ def main():
         ok['solver_two_panel_exchange_%s' % ('sharded' if shard_items else 'replicated')] = bool(
             torch.allclose(s2, s3, rtol=1e-12) and float((V2 @ V2.T - V3 @ V3.T).abs().max()) < 1e-10 and st2['gramian_steps'] == st3['gramian_steps'])
     ok['panel_exchanges_started'] = comm.n_panel_exchanges - p0 > 0
-    print('RCCL_ONE_RANK_RESULT', ok, 'allgathers', comm.n_allgather, 'reduce_scatters', comm.n_reduce_scatter, 'allreduces', comm.n_allreduce)
+    # the DEFAULT form of a user-sharded build: the library's step in its two halves (pk_lanczos_products / pk_lanczos_orth) with
+    # RCCL's all-reduce of the block between them, the verification product summed the same way — in a group of one the sums are
+    # the identity and the halves are the functions the single call runs: the same bits as the communicator-free build
+    split = TorchComm(split_step=True)
+    _, sl, Vl, stl = svd_topk(ops, A, 10, seed=3, method='lanczos')
+    _, s4, V4, st4 = svd_topk(ops, A, 10, seed=3, comm=split, method='lanczos')
+    ok['split_step_library_recurrence'] = st4.get('recurrence') == 'library' and not st4['items_sharded'] and stl.get('recurrence') == 'library'
+    ok['split_step_allreduces'] = split.n_allreduce >= st4['gramian_steps']      # one per product (+ the plan's entry count)
+    ok['split_step_same_bits'] = bool(torch.equal(sl, s4) and torch.equal(Vl, V4)) and stl['gramian_steps'] == st4['gramian_steps']
+    split2 = TorchComm(split_step=True)
+    _, s5, V5, st5 = svd_topk(ops, A, 10, seed=3, comm=split2, method='lanczos', exchange='relaxed')
+    ok['split_step_relaxed_exchange'] = bool(torch.allclose(sl, s5, rtol=1e-12) and float((Vl @ Vl.T - V5 @ V5.T).abs().max()) < 1e-10
+                                             and st5['verified_rel_residual'] <= 1e-12)
+    print('RCCL_ONE_RANK_RESULT', ok, 'split-step', split.n_allreduce, st4['gramian_steps'], 'relaxed from', st5.get('exchange_relaxed_from'), 'allgathers', comm.n_allgather, 'reduce_scatters', comm.n_reduce_scatter, 'allreduces', comm.n_allreduce)
     assert all(ok.values()), ok
 
 

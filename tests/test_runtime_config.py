@@ -35,6 +35,18 @@ def test_a_value_the_user_exported_wins_and_a_small_one_is_reported_as_not_ok():
     assert json.loads(r.stdout.strip().splitlines()[-1])['hw_queues'] == 12
 
 
+def test_freeze_imports_is_explicit_and_moves_the_heap_out_of_the_collectors_sight():
+    """The package never freezes the collector's generations by itself (a process-global setting); `freeze_imports()` does,
+    after importing the host modules, and says how much it froze (bench.py reports it in `cold.gc_frozen_objects`)."""
+    r = run('import gc, json, polara_amd\n'
+            'before = gc.get_freeze_count()\n'
+            'n = polara_amd.freeze_imports()\n'
+            'import sys\n'
+            'print(json.dumps([before, n, gc.get_freeze_count(), "polara_amd.solver" in sys.modules, "polara_amd.scoring" in sys.modules]))')
+    before, n, after, solver_in, scoring_in = json.loads(r.stdout.strip().splitlines()[-1])
+    assert before == 0 and n == after and n > 50000 and solver_in and scoring_in
+
+
 @pytest.mark.gpu
 def test_device_used_before_the_import_is_detected_and_hipops_warns():
     code = ('import torch, json, warnings\n'
