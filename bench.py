@@ -104,6 +104,8 @@ def parse():
                          'split-bf16 sweep an ML-20M-shaped pass is ~0.9 ms of kernels: ~14 Python launches cost 0.9-1.3 ms '
                          'of host time depending on the box, a replay ~10 us per graph node: 1.03-1.17 ms')
     ap.set_defaults(graph=True)
+    ap.add_argument('--replay-streams', type=int, default=4,
+                    help='streams the replayed form of a short pass alternates between (scoring.RecordedPass; default 4)')
     ap.add_argument('--pass-streams', type=int, default=2,
                     help='HIP streams consecutive scoring passes alternate between (python launches; 1 = strictly serial passes)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -111,6 +113,9 @@ def parse():
                     help="what HipOps() does once per process: load the library's code objects (default), also run the miniature pipeline, or nothing")
     ap.add_argument('--cpu-users', type=int, default=0, help='users in the CPU scoring sample (0 = auto)')
     return ap.parse_args()
+
+
+MAX_PASS_STREAMS = 6      # pass streams + copy stream + the solver's monitor stream stay within the 8 hardware queues asked for
 
 
 def ensure_world(args):
@@ -249,7 +254,11 @@ class Bench:
         # the pipelined loop its whole gain: 0.83 instead of 0.69 ms per pass in the same process).  Taken back to back the
         # copy stream and the pass streams sit on different queues.
         self.copy_stream = torch.cuda.Stream(device=self.dev)
-        self.pass_streams_all = [torch.cuda.Stream(device=self.dev) for _ in range(max(0, min(int(getattr(args, 'pass_streams', 2)), 3)))]
+        self.pass_streams_all = [torch.cuda.Stream(device=self.dev) for _ in range(max(0, min(int(getattr(args, 'pass_streams', 2)), MAX_PASS_STREAMS)))]
+        # the replayed form of a SHORT pass (scoring.RecordedPass) is bound by the host's launches, not by the chip: four streams
+        # keep it fed (tools/probes/shard_pass_modes.py: 2 / 4 / 6 streams at a rank's shard of N = 8: 0.180 / 0.147 / 0.275 ms)
+        n_rec = max(len(self.pass_streams_all), min(int(getattr(args, 'replay_streams', 4)), MAX_PASS_STREAMS)) if self.pass_streams_all else 0
+        self.rec_streams_all = self.pass_streams_all + [torch.cuda.Stream(device=self.dev) for _ in range(n_rec - len(self.pass_streams_all))]
 
     def barrier(self):
         torch.cuda.synchronize()
@@ -399,10 +408,24 @@ class Bench:
         n_ps = max(1, min(int(getattr(self.args, 'pass_streams', 2)), len(self.pass_streams_all)))
         self.pass_streams = self.pass_streams_all[:n_ps] if n_ps > 1 else []
 
+        recorded = []                # scoring.RecordedPass per pass stream (mode 'recorded')
+
         def one(i, use_cap=True):
             b = i % DEPTH
             src = main
-            if cap is not None and use_cap:
+            if use_cap == 'recorded':
+                # the pass as its recorded library calls, on the stream it was recorded on; its output buffer is rewritten by
+                # the next replay of the same recording, which therefore waits for the copy of this one
+                # (its result goes to the host on the SAME stream: the copy of a short pass's lists is microseconds, the passes
+                # of the other streams run next to it, and the host saves two event operations and a stream switch per pass)
+                r = i % len(recorded)
+                src = rec_streams[r]
+                recs = recorded[r].replay()
+                with torch.cuda.stream(src):
+                    host[b].copy_(recs, non_blocking=True)
+                done[b].record(src)
+                return recs
+            elif cap is not None and use_cap:
                 recs = stage[b]
                 recs.copy_(cap.replay())       # device copy (microseconds): the D2H of pass i overlaps replay i + 1
             elif self.pass_streams:
@@ -421,7 +444,7 @@ class Bench:
             return recs
         def loop(n, use_cap):
             r = None
-            for ps in self.pass_streams:
+            for ps in (rec_streams if use_cap == 'recorded' else self.pass_streams):
                 ps.wait_stream(main)            # whatever the main stream set up is visible to the pass streams
             for i in range(n):
                 if i >= DEPTH:
@@ -439,7 +462,29 @@ class Bench:
 
         def set_mode(mode):
             self.pass_streams = all_streams if mode == 'pipelined' else []
-            return mode == 'graph'
+            return 'recorded' if mode == 'recorded' else mode == 'graph'
+
+        def record():
+            # The pass as a list of recorded library calls per pass stream (scoring.RecordedPass): for SHORT passes, where
+            # two passes in flight are bound by the 170 us of host time `recommend` takes to enqueue one (a rank's shard at
+            # N >= 4).  Checked against the launched pass like the graph.
+            nonlocal recorded, rec_streams
+            try:
+                rec_streams = list(self.rec_streams_all) or [main]
+                check = scoring.recommend(ops, F, A, topk, True, prune=prune)
+                for s_ in rec_streams:
+                    s_.wait_stream(main)
+                    with torch.cuda.stream(s_):
+                        rp = scoring.RecordedPass(ops, F, A, topk, True, prune=prune)
+                        for _ in range(2):
+                            if not bool((rp.replay() == check).all()):
+                                raise RuntimeError('the replayed calls and the launched pass disagree')
+                    recorded.append(rp)
+                torch.cuda.synchronize()
+            except Exception as exc:      # a recording problem must not cost the run its number
+                log('recording the pass failed (%s: %s): launching through recommend()' % (type(exc).__name__, exc))
+                recorded = []
+                torch.cuda.synchronize()
 
         cal = {}
         n_cal = max(10, warmup)
@@ -459,6 +504,20 @@ class Bench:
         modes = ['serial'] + (['pipelined'] if all_streams else [])
         for mode in modes:
             calibrate(mode)
+        rec_streams = []
+        try_record = self.args.graph and not batches and min(cal.values()) < 0.4     # host-bound territory: ~0.2 ms per pass
+        if self.world > 1:
+            flag = torch.tensor([1.0 if try_record else 0.0], dtype=torch.float64, device='cpu' if self.debug_backend == 'gloo' else self.dev)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+            try_record = bool(flag.item() > 0.5)
+        if try_record:
+            record()
+            ok = torch.tensor([1.0 if recorded else 0.0], dtype=torch.float64, device='cpu' if self.debug_backend == 'gloo' else self.dev)
+            if self.world > 1:
+                torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
+            if ok.item() > 0.5:
+                modes.append('recorded')
+                calibrate('recorded')
         try_graph = self.args.graph and not batches and cal['serial'] < 0.5
         if self.world > 1:
             flag = torch.tensor([1.0 if try_graph else 0.0], dtype=torch.float64, device='cpu' if self.debug_backend == 'gloo' else self.dev)
@@ -485,6 +544,7 @@ class Bench:
             best = min([m for m in modes if m != 'pipelined'], key=lambda m: cal[m])
         use_cap = set_mode(best)
         self.launch_mode = {'graph': 'hipGraph replay of the captured pass',
+                            'recorded': 'recorded library calls of the pass (scoring.RecordedPass), replayed on %d HIP streams' % max(len(rec_streams), 1),
                             'serial': 'python, kernel by kernel, passes one after the other',
                             'pipelined': 'python, kernel by kernel; consecutive passes alternate between %d HIP streams' % len(all_streams)}[best]
         serial_ms = cal.get('serial')
@@ -529,6 +589,7 @@ class Bench:
         extras['python_launch_ms_per_step'] = cal.get('serial')
         extras['graph_replay_ms_per_step'] = cal.get('graph')
         extras['pipelined_ms_per_step'] = cal.get('pipelined')
+        extras['recorded_ms_per_step'] = cal.get('recorded')
         self.pass_streams = all_streams
         return elapsed, recs, extras
 
@@ -634,11 +695,13 @@ class Bench:
                 'score_order': 'factor norm' if norm_order else 'popularity',
                 'launch': extra.get('launch', 'python, kernel by kernel'),
                 'launch_short': 'hipGraph' if extra.get('launch', '').startswith('hipGraph') else (
-                    'python, passes on %d streams' % len(self.pass_streams) if 'alternate' in extra.get('launch', '') else 'python'),
+                    'recorded calls, %d streams' % len(self.rec_streams_all or [0]) if extra.get('launch', '').startswith('recorded') else (
+                        'python, passes on %d streams' % len(self.pass_streams) if 'alternate' in extra.get('launch', '') else 'python')),
                 'launches_per_pass': int(sum(n_launch.values()) // 5) if n_launch else None,
                 'warmup_calibration_ms_per_step': {'python_launch': extra.get('python_launch_ms_per_step'),
                                                    'python_pipelined': extra.get('pipelined_ms_per_step'),
-                                                   'graph_replay': extra.get('graph_replay_ms_per_step')},
+                                                   'graph_replay': extra.get('graph_replay_ms_per_step'),
+                                                   'recorded_replay': extra.get('recorded_ms_per_step')},
                 'build_s': tb['total_s'], 'build': dict(tb, gramian_steps=bstats['gramian_steps'],
                                                          outer_iterations=bstats['outer'], block=bstats['block'],
                                                          krylov_block=bstats.get('krylov_block'), method=bstats.get('method'),

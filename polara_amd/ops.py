@@ -16,9 +16,42 @@ from . import _lib
 from .csr import SPLIT_NNZ
 
 
+_PTR_KEEP = None      # scoring.RecordedPass: the tensors whose addresses went into the recorded calls (kept alive with them)
+
+
 def _ptr(t, offset=0):
     """device pointer of tensor `t`, advanced by `offset` ELEMENTS"""
-    return C.c_void_p(t.data_ptr() + offset * t.element_size()) if t is not None else None
+    if t is None:
+        return None
+    if _PTR_KEEP is not None:
+        _PTR_KEEP.append(t)
+    return C.c_void_p(t.data_ptr() + offset * t.element_size())
+
+
+def _raw_stream(index):
+    """handle of torch's current stream on device `index` (the call the Python wrappers of torch.cuda.current_stream end in:
+    0.3 us instead of 4 — a scoring pass asks a dozen times)"""
+    return torch._C._cuda_getCurrentRawStream(index)
+
+
+class _KernelTimer:
+    """Context manager recording HIP events on the launch stream around one kernel call (HipOps._timed)."""
+    __slots__ = ('ops', 'name', 'meta', 'e0', 'e1')
+
+    def __init__(self, ops, name, meta):
+        self.ops, self.name, self.meta = ops, name, meta
+
+    def __enter__(self):
+        if self.ops.timers is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record(torch.cuda.current_stream(self.ops.device))
+
+    def __exit__(self, *exc):
+        if self.ops.timers is not None:
+            self.e1.record(torch.cuda.current_stream(self.ops.device))
+            self.ops.timers.setdefault(self.name, []).append((self.e0, self.e1, self.meta))
+        return False
 
 
 class DeviceCSR:
@@ -103,7 +136,7 @@ class DeviceCSR:
             return None
         if not isinstance(self._partial, dict):
             self._partial = {}
-        skey = torch.cuda.current_stream(self.ops.device).cuda_stream
+        skey = self.ops.stream_key()
         buf = self._partial.get(skey)
         if buf is None or buf.numel() < need:
             buf = self._partial[skey] = torch.empty(need, dtype=torch.float64, device=self.ops.device)
@@ -355,6 +388,7 @@ class HipOps:
         if not torch.cuda.is_available():
             raise _lib.PolaraHipError('no HIP device visible: polara_amd has no CPU fallback')
         self.device = torch.device(device if device is not None else 'cuda:%d' % torch.cuda.current_device())
+        self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self._gram_work = None
         self._score_state = None
         self._score_states = None
@@ -440,25 +474,15 @@ class HipOps:
 
     def _timed(self, name, meta):
         """Context manager recording HIP events on the launch stream around one kernel call."""
-        ops = self
-
-        class _T:
-            def __enter__(self_t):
-                if ops.timers is not None:
-                    self_t.e0 = torch.cuda.Event(enable_timing=True)
-                    self_t.e1 = torch.cuda.Event(enable_timing=True)
-                    self_t.e0.record(torch.cuda.current_stream(ops.device))
-
-            def __exit__(self_t, *exc):
-                if ops.timers is not None:
-                    self_t.e1.record(torch.cuda.current_stream(ops.device))
-                    ops.timers.setdefault(name, []).append((self_t.e0, self_t.e1, meta))
-                return False
-        return _T()
+        return _KernelTimer(self, name, meta)
 
     # ---- plumbing ---------------------------------------------------------------------------
     def stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return C.c_void_p(_raw_stream(self._dev_index))
+
+    def stream_key(self):
+        """the current stream's handle as an int: key of the per-stream scratch buffers"""
+        return _raw_stream(self._dev_index)
 
     def recurrence_ctx(self):
         """the coarse-ABI context (its own pool of device blocks) the library-side Lanczos recurrence runs in — not the one of
@@ -939,7 +963,7 @@ class HipOps:
         need = self.lib.pk_gram_work_bytes(n, la, lb)
         # the partial sums of the row splits: one scratch buffer PER STREAM (a monitor of the block Lanczos build runs its
         # small Gram products on a side stream while the main stream's are in flight)
-        key = torch.cuda.current_stream(self.device).cuda_stream
+        key = self.stream_key()
         if self._gram_work is None:
             self._gram_work = {}
         work = self._gram_work.get(key)
@@ -1253,7 +1277,7 @@ class HipOps:
         need = self.lib.pk_score_state_bytes(n_users, splits)
         if self._score_states is None:
             self._score_states = {}
-        skey = torch.cuda.current_stream(self.device).cuda_stream   # one state buffer per launch stream
+        skey = self.stream_key()   # one state buffer per launch stream
         if skey not in self._score_states or self._score_states[skey].numel() < need:
             self._score_states[skey] = torch.empty(need, dtype=torch.uint8, device=self.device)
         self._score_state = self._score_states[skey]
@@ -1301,7 +1325,7 @@ class HipOps:
         need = self.lib.pk_score_state_bytes(n_users, total)
         if self._score_states is None:
             self._score_states = {}
-        skey = torch.cuda.current_stream(self.device).cuda_stream   # one state buffer per launch stream
+        skey = self.stream_key()   # one state buffer per launch stream
         if skey not in self._score_states or self._score_states[skey].numel() < need:
             self._score_states[skey] = torch.empty(need, dtype=torch.uint8, device=self.device)
         self._score_state = self._score_states[skey]
@@ -1418,7 +1442,7 @@ class HipOps:
         """score_exact_rows for the device-side list (lst[:cnt]) straight into rows of out_idx / out_s: no host sync."""
         K = E.shape[1]
         # one work buffer per launch stream (two passes on different streams must not share it), regrown on demand
-        skey = torch.cuda.current_stream(self.device).cuda_stream
+        skey = self.stream_key()
         need = self.lib.pk_exact_work_bytes(n_wg, n_items)
         if getattr(self, '_exact_work', None) is None:
             self._exact_work = {}

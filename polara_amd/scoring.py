@@ -14,6 +14,7 @@ import threading
 import numpy as np
 import torch
 
+from . import _lib
 from .csr import coo_to_csr
 
 EXACT_ROWS_BYTES = 2 << 30  # work-buffer budget per launch of the exact path
@@ -392,6 +393,75 @@ class CapturedPass:
 
     def replay(self):
         self.graph.replay()
+        return self.out
+
+
+class _CallRecorder:
+    """stands in for `ops.lib` while a pass is recorded: every library call goes through unchanged and is written down"""
+
+    def __init__(self, lib):
+        self.lib = lib
+        self.calls = []
+
+    def __getattr__(self, name):
+        fn = getattr(self.lib, name)
+        calls = self.calls
+
+        def call(*args):
+            calls.append((name, fn, args))
+            return fn(*args)
+        return call
+
+
+class RecordedPass:
+    """One scoring pass over a FIXED (factors, test matrix, topk) as the LIST OF LIBRARY CALLS it consists of, recorded once —
+    entry point and converted arguments, the stream handle among them — and issued again by `replay()`: the dozen launches of
+    a pass without the Python around them (argument conversion, per-stream scratch look-ups, the temporaries' allocation:
+    168 us of host time per pass through `recommend`, against ~9 launches of ~5 us).  What it is for is what `CapturedPass`
+    is for — user sets whose pass is shorter on the GPU than on the host: a rank's shard of ML-20M at 8 GPUs is 17 K users,
+    0.25 ms per pass on the device, and two such passes in flight are bound by the host — without the hipGraph, whose
+    replay costs this runtime ~70 us per kernel node.  The pass has no host round trip inside, so its calls and their
+    arguments do not depend on the data; only entries that take the stream as their first argument are replayed (the
+    planning queries of a pass — splits, capacities, work sizes — are pure host functions and were answered at the
+    recording).  Bound to the stream it was recorded on.  `replay()` returns the SAME device tensor every time (the pass's
+    output buffer, like every temporary of the recorded pass, is kept with the recording): consume it, or order the next
+    replay behind its consumer, before replaying again."""
+
+    def __init__(self, ops, factors, T, topk, filter_seen=True, prune=True):
+        from . import ops as ops_module
+        self.ops = ops
+        T.nonneg()
+        if filter_seen:
+            T.seen_tiles()
+        _ = T.plan
+        for _ in range(2):                     # lazily created buffers (per-stream scratch, cached images) exist afterwards
+            recommend(ops, factors, T, topk, filter_seen, prune=prune, batches=1)
+        self.stream = ops.stream_key()
+        recorder = _CallRecorder(ops.lib)
+        keep = []
+        with ops.pass_lock:
+            ops_module._PTR_KEEP, ops.lib = keep, recorder
+            try:
+                self.out = recommend(ops, factors, T, topk, filter_seen, prune=prune, batches=1)
+            finally:
+                ops_module._PTR_KEEP, ops.lib = None, recorder.lib
+        import ctypes
+        self.calls = []
+        for name, fn, args in recorder.calls:
+            first = args[0] if args else None
+            handle = (first.value or 0) if isinstance(first, ctypes.c_void_p) else None
+            if handle is not None and handle == (self.stream or 0) and fn.restype is ctypes.c_int and name != 'pk_ctx_create':
+                self.calls.append((name, fn, args))
+        if not self.calls:
+            raise RuntimeError('RecordedPass: the pass made no library call on its stream')
+        # everything the recorded arguments point at outlives the recording: operands, temporaries, per-stream scratch
+        self._keep = (factors, T, keep, dict(ops._score_states or {}), dict(getattr(ops, '_exact_work', None) or {}))
+
+    def replay(self):
+        for name, fn, args in self.calls:
+            rc = fn(*args)
+            if rc:
+                _lib.check(rc, name)
         return self.out
 
 

@@ -561,3 +561,39 @@ def test_library_recurrence_hands_hard_matrices_to_the_subspace_iteration(hip_op
         assert np.abs(Vh.T @ Vh - np.eye(k)).max() < 1e-8, name
         if must_fall_back:
             assert 'lanczos_fallback' in st and st['method'].startswith('subspace'), (name, st.get('method'))
+
+
+@pytest.mark.gpu
+def test_recorded_pass_replays_the_pass_call_by_call():
+    """scoring.RecordedPass: the library calls of one pass recorded once and issued again give, replay after replay and on
+    two streams in turn, the lists of the launched pass — pruned and unpruned, a user set small enough for item splits, and
+    a second recording on another stream does not disturb the first."""
+    import torch
+    from polara_amd import scoring
+    from polara_amd.ops import HipOps
+    from polara_amd.solver import svd_topk
+    ops = HipOps('cuda:0')
+    for (n_users, n_items, per, topk, prune) in ((6000, 3000, 40, 10, True), (900, 5000, 25, 20, True), (3000, 2000, 30, 10, False)):
+        csr = planted_csr(n_users, n_items, per, rank=16, seed=n_users)
+        A = ops.csr(np.asarray(csr['indptr']), np.asarray(csr['indices']), np.asarray(csr['values']), csr['shape'])
+        _, sigma, V, _ = svd_topk(ops, A, 12, seed=1)
+        order, rank, Vs = ops.norm_order(V)
+        T = ops.csr_relabel_cols(A, rank, sort=True)
+        F = scoring.FactorImage(ops, Vs)
+        want = scoring.recommend(ops, F, T, topk, True, prune=prune).clone()
+        main = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        rp0 = scoring.RecordedPass(ops, F, T, topk, True, prune=prune)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            rp1 = scoring.RecordedPass(ops, F, T, topk, True, prune=prune)
+        assert rp0.stream != rp1.stream and len(rp0.calls) == len(rp1.calls) >= 4
+        assert all(name.startswith('pk_') for name, _, _ in rp0.calls)
+        for i in range(6):
+            rp = (rp0, rp1)[i & 1]
+            out = rp.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out, want), (n_users, i)
+        # a launched pass in between uses the same per-stream scratch and leaves the recording intact
+        assert torch.equal(scoring.recommend(ops, F, T, topk, True, prune=prune), want)
+        assert torch.equal(rp0.replay(), want)

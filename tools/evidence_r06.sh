@@ -26,3 +26,6 @@ timeout 300 python tools/probes/reindex_stages.py s1m > $O/reindex_stages_s1m.tx
 timeout 400 python tools/probes/scale_proxy2.py ml20m > $O/scaling_proxy_ml20m.json 2> $O/proxy_err_ml20m.txt
 timeout 600 python tools/probes/scale_proxy2.py s1m > $O/scaling_proxy_s1m.json 2> $O/proxy_err_s1m.txt
 cat $O/bench_line_default_flags.json
+timeout 600 python tools/probes/shard_pass_modes.py ml20m 2 > $O/shard_pass_modes_ml20m.txt 2>&1
+timeout 900 python tools/probes/shard_pass_modes.py s1m 2 > $O/shard_pass_modes_s1m.txt 2>&1
+timeout 300 python tools/probes/pass_host_cost.py ml20m 8 > $O/pass_host_cost_ml20m.txt 2>&1
