@@ -416,14 +416,12 @@ class Bench:
             if use_cap == 'recorded':
                 # the pass as its recorded library calls, on the stream it was recorded on; its output buffer is rewritten by
                 # the next replay of the same recording, which therefore waits for the copy of this one
-                # (its result goes to the host on the SAME stream: the copy of a short pass's lists is microseconds, the passes
-                # of the other streams run next to it, and the host saves two event operations and a stream switch per pass)
+                # (its lists go to the host from the pass's LAST KERNEL, which writes the recording's own pinned buffer — mapped
+                # memory, ops.scatter_rows — : no copy call, no cross-stream event, no stream switch per pass; DEPTH >= the
+                # number of recordings, so the throttle below keeps a buffer from being rewritten before its pass was waited for)
                 r = i % len(recorded)
-                src = rec_streams[r]
                 recs = recorded[r].replay()
-                with torch.cuda.stream(src):
-                    host[b].copy_(recs, non_blocking=True)
-                done[b].record(src)
+                done[b].record(rec_streams[r])
                 return recs
             elif cap is not None and use_cap:
                 recs = stage[b]
@@ -470,15 +468,19 @@ class Bench:
             # N >= 4).  Checked against the launched pass like the graph.
             nonlocal recorded, rec_streams
             try:
-                rec_streams = list(self.rec_streams_all) or [main]
-                check = scoring.recommend(ops, F, A, topk, True, prune=prune)
+                rec_streams = list(self.rec_streams_all)[:DEPTH] or [main]      # (one result buffer per recording, DEPTH of them)
+                check_host = scoring.recommend(ops, F, A, topk, True, prune=prune).cpu()
                 for s_ in rec_streams:
                     s_.wait_stream(main)
                     with torch.cuda.stream(s_):
-                        rp = scoring.RecordedPass(ops, F, A, topk, True, prune=prune)
+                        rp = scoring.RecordedPass(ops, F, A, topk, True, prune=prune,
+                                                  host_out=torch.empty((n_local, topk), dtype=torch.int64).pin_memory())
                         for _ in range(2):
-                            if not bool((rp.replay() == check).all()):
-                                raise RuntimeError('the replayed calls and the launched pass disagree')
+                            rp.host_out.fill_(-7)
+                            got = rp.replay()             # the pinned buffer: the pass's last kernel writes it
+                            s_.synchronize()
+                            if got is not rp.host_out or not bool((got == check_host).all()):
+                                raise RuntimeError('the lists handed to the host by the replayed pass differ from the launched pass')
                     recorded.append(rp)
                 torch.cuda.synchronize()
             except Exception as exc:      # a recording problem must not cost the run its number
@@ -582,6 +584,8 @@ class Bench:
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
             elapsed = float(tt.item())
         last = host[(steps - 1) % DEPTH if steps else 0]
+        if use_cap == 'recorded' and steps:
+            last = recorded[(steps - 1) % len(recorded)].host_out
         extras = dict(latency_ms_per_pass=1e3 * float(np.median(lat)), d2h_bytes_per_pass=int(n_local * topk * 8),
                       host_result=last, launch=self.launch_mode)
         extras['serial_ms_per_step'] = serial_ms

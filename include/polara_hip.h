@@ -47,6 +47,9 @@ int pk_version(void);
  *   "score_phase2_splits"  item splits of its second phase
  * unset != 0 returns the option to its default.  Unknown names: PK_E_INVALID. */
 int pk_set_option(const char *name, int32_t value, int32_t unset);
+/* hipMemcpyAsync device -> host on `stream` (pinned destination: asynchronous): the hand-over of a pass's lists as one more
+ * call of the pass (the reference returns host arrays: models.py:400-405). */
+int pk_copy_to_host_async(void *stream, void *dst_host, const void *src_dev, int64_t bytes);
 /* number of visible HIP devices (>=1 required by every compute call); fills name of `device`. */
 int pk_device_info(int device, char *name, int name_len, int *cu_count, int64_t *hbm_bytes);
 /* Loads every code object of the library on the current device (the runtime would otherwise load each translation

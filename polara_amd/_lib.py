@@ -136,6 +136,7 @@ PROTOTYPES = {
     'pk_ctx_stream': (_vp, [_vp]),
     'pk_ctx_set_option': (C.c_int, [_vp, C.c_char_p, _i32]),
     'pk_set_option': (C.c_int, [C.c_char_p, _i32, _i32]),
+    'pk_copy_to_host_async': (C.c_int, [_vp, _vp, _vp, _i64]),
     'pk_v32_image_f32': (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _vp]),
     'pk_row_norm_order_work_bytes': (_i64, [_i64]),
     'pk_row_norm_order_f64': (C.c_int, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _vp]),

@@ -37,6 +37,23 @@ extern "C" int pk_set_option(const char *name, int32_t value, int32_t unset) {
 }
 extern "C" int pk_version(void) { return 100; }
 
+// Results on their way out, in stream order behind the kernels that produced them: `dst_host` should be pinned memory (the copy
+// is then asynchronous; from pageable memory the runtime stages it).  An entry of its own so that a host layer that replays a
+// recorded pass (scoring.RecordedPass) issues the hand-over like any other call of the pass.
+extern "C" int pk_copy_to_host_async(void *stream, void *dst_host, const void *src_dev, int64_t bytes) {
+    if (bytes < 0 || (bytes > 0 && (!dst_host || !src_dev))) {
+        pk_set_error("pk_copy_to_host_async: bad arguments");
+        return PK_E_INVALID;
+    }
+    if (bytes == 0) return PK_OK;
+    const hipError_t e = hipMemcpyAsync(dst_host, src_dev, (size_t)bytes, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) {
+        pk_set_error("pk_copy_to_host_async: %s", hipGetErrorString(e));
+        return PK_E_LAUNCH;
+    }
+    return PK_OK;
+}
+
 extern "C" int pk_device_info(int device, char *name, int name_len, int *cu_count, int64_t *hbm_bytes) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);

@@ -113,10 +113,13 @@ def renumbered_test_rows(ops, users):
 
 
 def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stats=None, prune=True, batches=None,
-              approx_fold_in=None, order_users=True, head_users=None, two_phase_ok=True):
+              approx_fold_in=None, order_users=True, head_users=None, two_phase_ok=True, out=None):
     """factors: FactorImage; T: ops-level CSR of the test users [n_users x n_items].
     Returns int64 device tensor [n_users x topk] (+ fp64 scores), rows in test-user order,
     columns by descending score — the contract of models.py:400-405.
+    out (ids only): where the lists are to end up — a device tensor or a PINNED HOST tensor [n_users x topk] int64; the last
+    kernel of the pass writes it (ops.scatter_rows: the host-side array of the reference's contract without a copy-engine
+    transfer behind the pass) and it is what the call returns.
 
     approx_fold_in (default: on when only the ids are asked for and the feedback is non-negative): the fold-in
     E = T V gathers the fp32 image of V (half the bytes of the product that is bound by them), and so does the
@@ -133,10 +136,13 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
             _in_pass.held = True
             try:
                 return recommend(ops, factors, T, topk, filter_seen, return_scores, stats, prune, batches, approx_fold_in,
-                                 order_users, head_users, two_phase_ok)
+                                 order_users, head_users, two_phase_ok, out)
             finally:
                 _in_pass.held = False
     n_users, n_items = T.shape
+    if out is not None and (return_scores or tuple(out.shape) != (n_users, topk) or out.dtype != torch.int64 or not out.is_contiguous()
+                            or not (out.is_cuda or out.is_pinned())):
+        raise ValueError('recommend: `out` takes the ids only: a contiguous int64 [n_users x topk] device or pinned host tensor')
     if n_items != factors.n_items:
         raise ValueError('test matrix and item factors disagree on the number of items')
     if topk > n_items:
@@ -156,6 +162,8 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
             out_idx[perm] = idx_p
             out_s[perm] = sc_p
             return out_idx, out_s
+        if out is not None:
+            return ops.scatter_rows(res, perm, out=out)
         return ops.scatter_rows(res, perm) if hasattr(ops, 'scatter_rows') else torch.empty_like(res).index_copy_(0, perm, res)
     KC = ops.candidate_capacity(topk) if factors.fused else 0
     K = factors.K
@@ -356,6 +364,8 @@ def recommend(ops, factors, T, topk, filter_seen=True, return_scores=False, stat
         stats['exit_tile_quantiles'] = dict(zip(('p50', 'p90', 'p99', 'p999', 'max'), [float(v) for v in q.tolist()]))
     if return_scores:
         return out_idx, out_s
+    if out is not None:
+        return ops.scatter_rows(out_idx, None, out=out)
     return out_idx
 
 
@@ -427,7 +437,15 @@ class RecordedPass:
     output buffer, like every temporary of the recorded pass, is kept with the recording): consume it, or order the next
     replay behind its consumer, before replaying again."""
 
-    def __init__(self, ops, factors, T, topk, filter_seen=True, prune=True):
+    def __init__(self, ops, factors, T, topk, filter_seen=True, prune=True, host_out=None, hand_over='copy'):
+        """host_out: a pinned host tensor [n_users x topk] int64 the lists are handed to by the recording itself; `replay()` then
+        returns that tensor, valid once the stream has passed the pass.  hand_over='copy' (default): one more recorded call,
+        pk_copy_to_host_async, in stream order behind the kernels; 'mapped': the pass's last kernel writes the pinned buffer
+        itself (`recommend(out=...)`: no copy call at all) — measured slower for a pass in a loop (the kernel stays on the stream
+        until its PCIe writes are through: 0.1225 against 0.099-0.101 ms per pass on a 17 K-user shard, and against 0.099-0.117
+        for torch's `copy_` under the pass's stream; tools/probes/recorded_handover.py), the form for a single hand-over."""
+        if hand_over not in ('copy', 'mapped'):
+            raise ValueError("hand_over must be 'copy' or 'mapped'")
         from . import ops as ops_module
         self.ops = ops
         T.nonneg()
@@ -442,7 +460,7 @@ class RecordedPass:
         with ops.pass_lock:
             ops_module._PTR_KEEP, ops.lib = keep, recorder
             try:
-                self.out = recommend(ops, factors, T, topk, filter_seen, prune=prune, batches=1)
+                self.out = recommend(ops, factors, T, topk, filter_seen, prune=prune, batches=1, out=host_out if hand_over == 'mapped' else None)
             finally:
                 ops_module._PTR_KEEP, ops.lib = None, recorder.lib
         import ctypes
@@ -454,6 +472,16 @@ class RecordedPass:
                 self.calls.append((name, fn, args))
         if not self.calls:
             raise RuntimeError('RecordedPass: the pass made no library call on its stream')
+        self.host_out = host_out
+        if host_out is not None and hand_over != 'mapped':
+            out = self.out
+            if (host_out.is_cuda or not host_out.is_pinned() or host_out.shape != out.shape or host_out.dtype != out.dtype
+                    or not host_out.is_contiguous() or not out.is_contiguous()):
+                raise ValueError('RecordedPass: host_out must be a contiguous pinned host tensor of the output\'s shape and dtype')
+            self.calls.append(('pk_copy_to_host_async', ops.lib.pk_copy_to_host_async,
+                               (ctypes.c_void_p(self.stream), ctypes.c_void_p(host_out.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                out.numel() * out.element_size())))
+            self.out = host_out
         # everything the recorded arguments point at outlives the recording: operands, temporaries, per-stream scratch
         self._keep = (factors, T, keep, dict(ops._score_states or {}), dict(getattr(ops, '_exact_work', None) or {}))
 

@@ -585,15 +585,29 @@ def test_recorded_pass_replays_the_pass_call_by_call():
         side = torch.cuda.Stream()
         rp0 = scoring.RecordedPass(ops, F, T, topk, True, prune=prune)
         side.wait_stream(main)
+        pinned = torch.empty(tuple(want.shape), dtype=torch.int64).pin_memory()
         with torch.cuda.stream(side):
-            rp1 = scoring.RecordedPass(ops, F, T, topk, True, prune=prune)
-        assert rp0.stream != rp1.stream and len(rp0.calls) == len(rp1.calls) >= 4
+            rp1 = scoring.RecordedPass(ops, F, T, topk, True, prune=prune, host_out=pinned)     # ... handing its lists to the host itself
+        assert rp0.stream != rp1.stream and len(rp1.calls) == len(rp0.calls) + 1 >= 5 and rp1.calls[-1][0] == 'pk_copy_to_host_async'
         assert all(name.startswith('pk_') for name, _, _ in rp0.calls)
         for i in range(6):
             rp = (rp0, rp1)[i & 1]
             out = rp.replay()
             torch.cuda.synchronize()
-            assert torch.equal(out, want), (n_users, i)
+            if rp is rp1:
+                assert out is pinned and torch.equal(pinned, want.cpu()), (n_users, i)      # handed over by the recording's last call
+                pinned.zero_()
+            else:
+                assert torch.equal(out, want), (n_users, i)
         # a launched pass in between uses the same per-stream scratch and leaves the recording intact
         assert torch.equal(scoring.recommend(ops, F, T, topk, True, prune=prune), want)
         assert torch.equal(rp0.replay(), want)
+        with pytest.raises(ValueError):
+            scoring.recommend(ops, F, T, topk, True, prune=prune, out=torch.empty(tuple(want.shape), dtype=torch.int64))   # a host destination must be pinned
+        pinned.zero_()
+        rp2 = scoring.RecordedPass(ops, F, T, topk, True, prune=prune, host_out=pinned, hand_over='mapped')    # the last KERNEL writes the host array
+        assert len(rp2.calls) <= len(rp0.calls) + 1 and rp2.calls[-1][0] == 'pk_scatter_rows_i64' and rp2.replay() is pinned
+        torch.cuda.synchronize()
+        assert torch.equal(pinned, want.cpu())
+        dev_out = torch.empty_like(want)
+        assert scoring.recommend(ops, F, T, topk, True, prune=prune, out=dev_out) is dev_out and torch.equal(dev_out, want)

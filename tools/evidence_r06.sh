@@ -29,3 +29,4 @@ cat $O/bench_line_default_flags.json
 timeout 600 python tools/probes/shard_pass_modes.py ml20m 2 > $O/shard_pass_modes_ml20m.txt 2>&1
 timeout 900 python tools/probes/shard_pass_modes.py s1m 2 > $O/shard_pass_modes_s1m.txt 2>&1
 timeout 300 python tools/probes/pass_host_cost.py ml20m 8 > $O/pass_host_cost_ml20m.txt 2>&1
+timeout 300 python tools/probes/recorded_handover.py ml20m 8 > $O/recorded_handover_ml20m.txt 2>&1
