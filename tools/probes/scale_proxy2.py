@@ -1,6 +1,5 @@
 """Strong-scaling proxies on ONE GPU (round 2): the work rank 0 would own at N = 1, 2, 4, 8 GPUs.
-  scoring: the scoring pass (ids-only, result copied to the host, passes queued back to back like bench.py) on rank
-           0's nnz-balanced user shard — the pass has no collective, so N x (users of the shard) / time is the job's rate;
+  scoring: see tools/probes/shard_pass_modes.py (bench.py's own loop on rank 0's nnz-balanced user shard);
   build:   the eigensolver on rank 0's row shard with the exchange stubbed (NoComm), per-kernel-class times from HIP
            events, plus the MODELLED exchange: per Gramian step one all-gather of X and one reduce-scatter of Z
            [n_items x l] fp64 (= the volume of a sum all-reduce) over a ring of N GPUs at 100 GB/s per direction
@@ -139,57 +138,8 @@ for k, v in out['build'].items():
     v['speedup_vs_N1'] = b1 / v['modelled_total_s']
     v['speedup_vs_N1_replicated'] = b1 / v['modelled_total_s_replicated']
     v['speedup_vs_N1_busbw_300'] = b1 / v['modelled_total_s_busbw_300']
-order32, rank32, V = ops.norm_order(V)
-As = ops.csr_relabel_cols(A0, rank32)
-F = scoring.FactorImage(ops, V)
-# (end of round 6: the loop bench.py runs — python launches on two streams, or the pass's recorded library calls on four when a
-# pass is short enough to be bound by the host: scoring.RecordedPass; the hipGraph replay of rounds 2-5 costs this runtime
-# ~70 us per kernel node.  tools/probes/shard_pass_modes.py puts bench.py's own calibration on the same shards.)
-copy_stream = torch.cuda.Stream()
-pass_streams = [torch.cuda.Stream() for _ in range(4)]
-for N in (1, 2, 4, 8):
-    bounds = nnz_balanced_row_partition(c['indptr'], N)
-    T = As if N == 1 else ops.csr_rows(As, 0, int(bounds[1]))
-    T.seen_tiles()
-    main = torch.cuda.current_stream()
-    results = {}
-    for form in ('python, 2 streams', 'recorded calls, 4 streams'):
-        use = pass_streams[:2] if form.startswith('python') else pass_streams
-        host = [torch.empty((T.shape[0], topk), dtype=torch.int64).pin_memory() for _ in range(4)]
-        done = [torch.cuda.Event() for _ in range(4)]
-        recs = []
-        if form.startswith('recorded'):
-            for k, s_ in enumerate(use):
-                s_.wait_stream(main)
-                with torch.cuda.stream(s_):
-                    recs.append(scoring.RecordedPass(ops, F, T, topk, True, host_out=host[k]))
-        def one(i):
-            b = i & 3
-            if recs:
-                recs[b].replay(); done[b].record(use[b]); return
-            src = use[i % len(use)]
-            with torch.cuda.stream(src):
-                r = scoring.recommend(ops, F, T, topk, True)
-            ev = torch.cuda.Event(); ev.record(src)
-            with torch.cuda.stream(copy_stream):
-                copy_stream.wait_event(ev)
-                host[b].copy_(r, non_blocking=True); r.record_stream(copy_stream); done[b].record(copy_stream)
-        for s_ in use: s_.wait_stream(main)
-        for i in range(12): one(i)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        steps = 100
-        for i in range(steps):
-            if i >= 4: done[i & 3].synchronize()
-            one(i)
-        torch.cuda.synchronize(); results[form] = (time.perf_counter() - t0) / steps * 1e3
-        del recs
-    form = min(results, key=results.get)
-    ms = results[form]
-    st = {}
-    scoring.recommend(ops, F, T, topk, True, stats=st)
-    out['scoring']['N=%d' % N] = dict(users_on_rank0=T.shape[0], ms_per_pass=ms, launch=form, ms_per_pass_by_form=results, job_users_per_s=n_users / (ms * 1e-3),
-                                      item_splits=st['item_splits'], swept_fraction=st['tiles_scored'] / max(st['tiles_total'], 1))
-s1 = out['scoring']['N=1']['ms_per_pass']
-for k, v in out['scoring'].items():
-    v['speedup_vs_N1'] = s1 / v['ms_per_pass']
+# The scoring leg of rounds 2-5 (a hipGraph replay, one pass at a time) left this file at the end of round 6: a shard's pass is
+# bound by how the HOST launches it, so the loop that matters is bench.py's own — tools/probes/shard_pass_modes.py runs that loop,
+# with its calibration of the launch forms, on the same shards (profiles/r06_shard_pass_modes_*.txt).
+out['scoring'] = 'tools/probes/shard_pass_modes.py'
 print(json.dumps(out))
