@@ -747,13 +747,18 @@ class Bench:
                 ach = useful_flops / (cand_ms * 1e-3) / 1e12
                 issued = bf16_flops / (cand_ms * 1e-3) / 1e12
                 f32_eq = flops * swept / (cand_ms * 1e-3) / 1e12
+                # what the sweep asks of the L2: every wave (32 users) reads the fragments of every tile it scores — 2 k_steps KB
+                # per tile and wave — through 16-byte-per-lane loads.  The UNPRUNED sweep runs at the 17-19 TB/s this chip's L2
+                # delivers to such loads (the same ceiling the SpMM gathers meet, DESIGN K1): there the matrix cores wait for
+                # fragments, not the other way round
+                frag_bytes = swept * ((int(st['A'].shape[0]) + 31) // 32) * ((n_items + 31) // 32) * 2 * k_steps * 1024.0     # (this rank's users)
                 out['roofline'] = {
                     'kernel': 'score_candidates_kernel', 'bound': 'mfma', 'dtype': 'bf16 (split product: 3 bf16 MFMAs per fp32-class product)',
                     'achieved': ach, 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_MFMA_TFLOPS, 'traffic': None,
                     'issued': issued, 'issued_frac': issued / PEAK_BF16_MFMA_TFLOPS,
                     'avg_ms': cand_ms / max(n_chunk, 1), 'sweep_ms_per_pass': cand_ms, 'launches_per_pass': n_chunk,
                     'flop_per_launch': useful_flops / max(n_chunk, 1), 'issued_flop_per_launch': bf16_flops / max(n_chunk, 1),
-                    'swept_fraction': swept,
+                    'swept_fraction': swept, 'l2_delivery_TBps': frag_bytes / (cand_ms * 1e-3) / 1e12,
                     'note': 'achieved/frac: ALGORITHMIC flops of the tiles actually scored x 3 (split product), no padding; issued/issued_frac: '
                             'the bf16 MFMA flops actually issued (rank padded to a multiple of 16). The sweep is pruned '
                             'exactly (Cauchy-Schwarz bound, identical results; --no-prune scores every tile). At rank 50 the kernel is '
@@ -1037,7 +1042,7 @@ def compact_line(head, n_gpus, steps, warmup, adversarial=None, scale=1.0):
     rf = head.get('roofline')
     if rf:
         out['roofline'] = {k: (_r(rf.get(k)) if not isinstance(rf.get(k), str) else rf.get(k)) for k in
-                           ('kernel', 'bound', 'dtype', 'achieved', 'peak', 'unit', 'frac', 'issued_frac', 'avg_ms', 'launches_per_pass',
+                           ('kernel', 'bound', 'dtype', 'achieved', 'peak', 'unit', 'frac', 'issued_frac', 'l2_delivery_TBps', 'avg_ms', 'launches_per_pass',
                             'swept_fraction', 'traffic', 'traffic_commit', 'stale') if k in rf or k == 'traffic'}
     rfo = head.get('roofline_foldin')
     if rfo:
