@@ -748,9 +748,8 @@ class Bench:
                 issued = bf16_flops / (cand_ms * 1e-3) / 1e12
                 f32_eq = flops * swept / (cand_ms * 1e-3) / 1e12
                 # what the sweep asks of the L2: every wave (32 users) reads the fragments of every tile it scores — 2 k_steps KB
-                # per tile and wave — through 16-byte-per-lane loads.  The UNPRUNED sweep runs at the 17-19 TB/s this chip's L2
-                # delivers to such loads (the same ceiling the SpMM gathers meet, DESIGN K1): there the matrix cores wait for
-                # fragments, not the other way round
+                # per tile and wave — through 16-byte-per-lane loads.  (The UNPRUNED sweep asks 17-21 TB/s, about what the SpMM
+                # gathers reach; round 4's diagnostic build prices those loads at 15 % of the loop at most: DESIGN K3)
                 frag_bytes = swept * ((int(st['A'].shape[0]) + 31) // 32) * ((n_items + 31) // 32) * 2 * k_steps * 1024.0     # (this rank's users)
                 out['roofline'] = {
                     'kernel': 'score_candidates_kernel', 'bound': 'mfma', 'dtype': 'bf16 (split product: 3 bf16 MFMAs per fp32-class product)',
