@@ -1015,8 +1015,8 @@ def compact_line(head, n_gpus, steps, warmup, adversarial=None, scale=1.0):
            'rank': head['rank'], 'topk': head['topk'], 'prune': head['prune'],
            'swept_fraction': _r(sc.get('swept_fraction')), 'launch': head.get('launch_short', 'python'),
            'launches_per_pass': head.get('launches_per_pass'),
-           'parallelism': 'users sharded over %d GPU(s); one all-reduce of the 16-column Krylov block (n_items x 16 fp64) per Gramian step '
-                          'in the build (item side replicated, steps inside the library), no collective in scoring' % n_gpus}
+           'parallelism': 'users sharded over %d GPU(s); build: one all-reduce of the Krylov block (n_items x 16 fp64) per Gramian '
+                          'step; scoring: no collective' % n_gpus}
     if scale != 1.0:
         cfg['scale'] = scale
     if adversarial:
@@ -1040,6 +1040,7 @@ def compact_line(head, n_gpus, steps, warmup, adversarial=None, scale=1.0):
                        'build_collectives': {k: _r(v) for k, v in bc.items()}, 'scoring_collectives': di.get('scoring_collectives')}
     rf = head.get('roofline')
     if rf:
+        rf = dict(rf, dtype='bf16x3 (split product)') if str(rf.get('dtype', '')).startswith('bf16 (split') else rf     # (the long form stays in the detail record)
         out['roofline'] = {k: (_r(rf.get(k)) if not isinstance(rf.get(k), str) else rf.get(k)) for k in
                            ('kernel', 'bound', 'dtype', 'achieved', 'peak', 'unit', 'frac', 'issued_frac', 'l2_delivery_TBps', 'avg_ms', 'launches_per_pass',
                             'swept_fraction', 'traffic', 'traffic_commit', 'stale') if k in rf or k == 'traffic'}
