@@ -31,3 +31,9 @@ def test_default_bench_prints_one_compact_parseable_line(tmp_path):
     assert {'value', 'unit', 'cores', 'kind', 'sample'} <= set(d['cpu_baseline']) and d['cpu_baseline']['kind'] in ('port', 'reference')
     assert d['cpu_baseline']['identical_rows'] == 1.0                      # the GPU lists against the CPU path's on the sample
     assert 'adversarial_users_per_s' not in d['config']     # those three catalogues only ride along at full size (scale 1.0)
+    # a pass over 7 K users is shorter on the device than on the host: the loop must have calibrated the replayed form
+    # (scoring.RecordedPass) next to the launched ones, and whichever ran, the lists above came out of it
+    detail = json.load(open(os.path.join(ROOT, 'bench_detail.json')))
+    cal = detail['warmup_calibration_ms_per_step']
+    assert cal['python_launch'] > 0 and cal.get('recorded_replay') is not None and cal['recorded_replay'] > 0, cal
+    assert d['config']['launch'] in ('python', 'hipGraph', 'python, passes on 2 streams') or d['config']['launch'].startswith('recorded calls'), d['config']['launch']
