@@ -78,6 +78,17 @@ def test_random_config_against_brute_force(hip_ops, cfg, monkeypatch, pk_options
     ids = hip_ops.to_host(scoring.recommend(hip_ops, F, T, topk, fs))
     ids2, sc = scoring.recommend(hip_ops, F, T, topk, fs, return_scores=True)
     ids2, sc = hip_ops.to_host(ids2), hip_ops.to_host(sc)
+    if cfg['seed'] % 3 == 0:
+        # the same pass as its recorded library calls (scoring.RecordedPass), handing its lists to the host itself: bit for bit
+        # the launched pass, on every shape of the sweep (chunked, split, two-phase, empty rows, one user)
+        import torch
+        pinned = torch.empty((n_users, topk), dtype=torch.int64).pin_memory()
+        rp = scoring.RecordedPass(hip_ops, F, T, topk, fs, host_out=pinned)
+        for _ in range(2):
+            pinned.fill_(-9)
+            assert rp.replay() is pinned
+            torch.cuda.synchronize()
+            assert np.array_equal(pinned.numpy(), ids), cfg
     for u in range(n_users):
         ref_s = s[u, want[u]]
         # positions whose reference score is separated from its neighbours (ties at 1e-13 relative and all-zero
